@@ -1,0 +1,21 @@
+"""adelie_amd — an MI355X-native group-elastic-net path solver behind adelie's Python API.
+
+Mirrors the user-facing surface of JamesYang007/adelie for the ``grpnet`` hot path only
+(``solver.grpnet``, ``cv.cv_grpnet``, ``matrix.dense`` / ``matrix.snp_unphased``,
+``glm.gaussian`` / ``glm.binomial``, the naive State objects).  All numerics run in hand-written HIP
+kernels for gfx950 behind the C ABI declared in ``include/adelie_hip.h``.
+"""
+from . import configs
+from . import glm
+from . import matrix
+from . import state
+from . import solver
+from . import diagnostic
+from . import cv
+from . import data
+from . import io
+from .configs import set_configs
+from .cv import cv_grpnet
+from .solver import grpnet
+
+__version__ = "0.1.0"

@@ -1,0 +1,227 @@
+"""ctypes binding of ``include/adelie_hip.h`` (the C ABI of ``libadelie_hip.so``).
+
+This is the only place where Python touches the native library.  It replaces what
+``adelie.adelie_core`` (the pybind11 module, reference ``adelie/src/py_adelie_core.cpp:6-44``)
+is for the reference: the boundary between the Python API layer and the native solver.
+
+The binding is written against a *symbol prefix* so that the test-suite can bind the CPU
+oracle (``oracle/liboracle.so``, prefix ``oracle_``) through the very same structures; the
+product itself only ever binds ``adelie_hip_`` and raises if the HIP library is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+F32, F64 = 0, 1
+COL_MAJOR, ROW_MAJOR = 0, 1
+SCREEN_STRONG, SCREEN_PIVOT = 0, 1
+GLM_GAUSSIAN, GLM_BINOMIAL_LOGIT, GLM_GAUSSIAN_IRLS = 0, 1, 2
+
+POLL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int64)
+
+
+class GrpnetArgs(C.Structure):
+    """``adelie_hip_grpnet_args`` — field order must match include/adelie_hip.h exactly."""
+
+    _fields_ = [
+        ("G", C.c_int64),
+        ("groups", C.c_void_p),
+        ("group_sizes", C.c_void_p),
+        ("alpha", C.c_double),
+        ("penalty", C.c_void_p),
+        ("weights", C.c_void_p),
+        ("X_means", C.c_void_p),
+        ("y_mean", C.c_double),
+        ("y_var", C.c_double),
+        ("resid_sum", C.c_double),
+        ("rsq", C.c_double),
+        ("glm_kind", C.c_int32),
+        ("_pad0", C.c_int32),
+        ("glm_y", C.c_void_p),
+        ("glm_weights", C.c_void_p),
+        ("offsets", C.c_void_p),
+        ("eta", C.c_void_p),
+        ("beta0", C.c_double),
+        ("loss_null", C.c_double),
+        ("loss_full", C.c_double),
+        ("irls_max_iters", C.c_int64),
+        ("irls_tol", C.c_double),
+        ("setup_loss_null", C.c_int32),
+        ("_pad1", C.c_int32),
+        ("resid", C.c_void_p),
+        ("grad", C.c_void_p),
+        ("lmda_path", C.c_void_p),
+        ("n_lmda_path", C.c_int64),
+        ("lmda_max", C.c_double),
+        ("min_ratio", C.c_double),
+        ("lmda_path_size", C.c_int64),
+        ("max_screen_size", C.c_int64),
+        ("max_active_size", C.c_int64),
+        ("pivot_subset_ratio", C.c_double),
+        ("pivot_subset_min", C.c_int64),
+        ("pivot_slack_ratio", C.c_double),
+        ("screen_rule", C.c_int32),
+        ("early_exit", C.c_int32),
+        ("max_iters", C.c_int64),
+        ("tol", C.c_double),
+        ("adev_tol", C.c_double),
+        ("ddev_tol", C.c_double),
+        ("newton_tol", C.c_double),
+        ("newton_max_iters", C.c_int64),
+        ("setup_lmda_max", C.c_int32),
+        ("setup_lmda_path", C.c_int32),
+        ("intercept", C.c_int32),
+        ("n_threads", C.c_int32),
+        ("screen_set_size", C.c_int64),
+        ("screen_set", C.c_void_p),
+        ("screen_beta_size", C.c_int64),
+        ("screen_beta", C.c_void_p),
+        ("screen_is_active", C.c_void_p),
+        ("active_set_size", C.c_int64),
+        ("active_set", C.c_void_p),
+        ("lmda", C.c_double),
+        ("poll", POLL_FN),
+        ("poll_user", C.c_void_p),
+    ]
+
+
+# enum adelie_hip_vec / adelie_hip_scalar
+V = dict(
+    intercepts=0, devs=1, lmdas=2, lmda_path=3, screen_beta=4, grad=5, abs_grad=6, resid=7, eta=8,
+    screen_X_means=9, screen_vars=10, screen_transforms=11,
+    benchmark_screen=12, benchmark_fit_screen=13, benchmark_fit_active=14, benchmark_kkt=15,
+    benchmark_invariance=16,
+    betas_values=200,
+)
+I = dict(
+    screen_set=100, screen_begins=101, screen_is_active=102, active_set=103, n_valid_solutions=104,
+    active_sizes=105, screen_sizes=106, betas_indptr=107, betas_indices=108,
+)
+S = dict(
+    lmda_max=0, lmda=1, rsq=2, resid_sum=3, active_set_size=4, beta0=5, loss_null=6, loss_full=7,
+    total_time=8,
+    n_basil_iters=50, n_sweeps=51, n_cd_visits_screen=52, n_cd_visits_active=53, n_updates=54,
+    n_irls_iters=55, n_new_screen_cols=56, n_cd_passes_screen=57, n_cd_passes_active=58,
+    n_gram_col_reads=59, n_resid_col_reads=60,
+)
+
+# every symbol include/adelie_hip.h declares (checked by tests/test_abi.py)
+HIP_SYMBOLS = [
+    "abi_version", "last_error", "device_count", "set_config",
+    "design_create_dense", "design_adopt_dense_dev", "design_create_snp_unphased",
+    "design_create_snp_calldata", "design_destroy", "design_rows", "design_cols", "design_dtype",
+    "design_device", "design_stream",
+    "design_cmul", "design_ctmul", "design_bmul", "design_btmul", "design_mul", "design_cov",
+    "design_sq_mul", "design_sp_tmul",
+    "grpnet_solve", "result_destroy", "result_size", "result_copy", "result_scalar", "result_error",
+    "bench_sweep",
+]
+
+
+def np_dtype(code):
+    return np.float64 if code == F64 else np.float32
+
+
+def dtype_code(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return F64
+    if dtype == np.float32:
+        return F32
+    raise RuntimeError("dtype must be either np.float32 or np.float64.")
+
+
+class Backend:
+    """A loaded native library exposing the adelie_hip ABI under ``prefix``."""
+
+    def __init__(self, path, prefix):
+        self.path = path
+        self.prefix = prefix
+        self.lib = C.CDLL(path)
+        self._setup()
+
+    def fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def has(self, name):
+        return hasattr(self.lib, self.prefix + name)
+
+    def _setup(self):
+        p, i64, dbl, vp, ci = C.POINTER, C.c_int64, C.c_double, C.c_void_p, C.c_int
+
+        def sig(name, restype, argtypes):
+            if self.has(name):
+                f = self.fn(name)
+                f.restype = restype
+                f.argtypes = argtypes
+
+        sig("abi_version", ci, [])
+        sig("last_error", C.c_char_p, [])
+        sig("device_count", ci, [])
+        sig("set_config", ci, [C.c_char_p, dbl])
+        sig("design_create_dense", ci, [vp, i64, i64, ci, ci, ci, p(vp)])
+        sig("design_adopt_dense_dev", ci, [vp, i64, i64, ci, ci, ci, p(vp)])
+        sig("design_create_snp_unphased", ci, [vp, i64, ci, ci, p(vp)])
+        sig("design_create_snp_calldata", ci, [vp, i64, i64, vp, ci, ci, p(vp)])
+        sig("design_destroy", ci, [vp])
+        sig("design_rows", i64, [vp])
+        sig("design_cols", i64, [vp])
+        sig("design_dtype", ci, [vp])
+        sig("design_device", ci, [vp])
+        sig("design_stream", vp, [vp])
+        sig("design_cmul", ci, [vp, i64, vp, vp, p(dbl)])
+        sig("design_ctmul", ci, [vp, i64, dbl, vp])
+        sig("design_bmul", ci, [vp, i64, i64, vp, vp, vp])
+        sig("design_btmul", ci, [vp, i64, i64, vp, vp])
+        sig("design_mul", ci, [vp, vp, vp, vp])
+        sig("design_cov", ci, [vp, i64, i64, vp, vp])
+        sig("design_sq_mul", ci, [vp, vp, vp])
+        sig("design_sp_tmul", ci, [vp, i64, vp, vp, vp, vp])
+        sig("grpnet_solve", ci, [vp, p(GrpnetArgs), p(vp)])
+        sig("result_destroy", ci, [vp])
+        sig("result_size", i64, [vp, ci])
+        sig("result_copy", ci, [vp, ci, vp, i64])
+        sig("result_scalar", dbl, [vp, ci])
+        sig("result_error", C.c_char_p, [vp])
+        sig("bench_sweep", ci, [vp, i64, p(dbl)])
+
+    def check(self, rc):
+        if rc != 0:
+            msg = self.fn("last_error")()
+            raise RuntimeError(msg.decode() if msg else "native call failed")
+
+    # -- result helpers ---------------------------------------------------------------------
+    def result_vec(self, r, which, index=False):
+        n = self.fn("result_size")(r, which)
+        if n < 0:
+            raise RuntimeError(f"unknown result vector {which}")
+        out = np.empty(n, dtype=np.int64 if index else np.float64)
+        if n:
+            self.check(self.fn("result_copy")(r, which, out.ctypes.data, n))
+        return out
+
+
+_HIP = None
+
+
+def hip_library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadelie_hip.so")
+
+
+def hip_backend():
+    """Load ``libadelie_hip.so``.  There is no CPU fallback: a missing library is an error."""
+    global _HIP
+    if _HIP is None:
+        path = hip_library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  adelie_amd has no CPU fallback."
+            )
+        _HIP = Backend(path, "adelie_hip_")
+    return _HIP
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data

@@ -1,0 +1,144 @@
+"""``cv_grpnet`` — mirrors ``adelie.cv.cv_grpnet`` (reference ``adelie/cv.py:130-325``), with the fold loop
+sharded over the GPUs of one node.
+
+Folds differ only by their weight vector (validation rows get weight 0, reference ``cv.py:248-252``), so every
+rank keeps a full replica of X in its own HBM and solves the folds ``k`` with ``k % world_size == rank``.
+Nothing inside the path solver communicates; the only collective is one ``all_gather`` of the ``(L,)`` loss
+rows at the end (RCCL over xGMI when the process group backend is ``nccl``, ``gloo`` in CPU tests).
+"""
+from dataclasses import dataclass
+import logging
+
+import numpy as np
+import scipy.sparse
+
+from . import matrix
+from .diagnostic import coefficient, predict
+from .solver import grpnet
+
+logger = logging.getLogger("adelie_amd")
+
+
+@dataclass
+class CVGrpnetResult:
+    """Result of K-fold CV group elastic net (reference ``cv.py:25-45``)."""
+
+    lmdas: np.ndarray
+    losses: np.ndarray
+    avg_losses: np.ndarray
+    best_idx: int
+
+    def fit(self, X, glm, *, lmda_path_size: int = 100, **grpnet_params):
+        """Fits the full data down to the best CV lambda (reference ``cv.py:95-127``)."""
+        logger_level = logger.level
+        logger.setLevel(logging.ERROR)
+        state = grpnet(X=X, glm=glm, lmda_path_size=0, progress_bar=False)
+        logger.setLevel(logger_level)
+        lmda_star = self.lmdas[self.best_idx]
+        full_lmdas = state.lmda_max * np.logspace(
+            0, np.log10(lmda_star / state.lmda_max), lmda_path_size
+        )
+        return grpnet(X=X, glm=glm, lmda_path=full_lmdas, early_exit=False, **grpnet_params)
+
+
+def fold_ranges(n: int, n_folds: int):
+    """Contiguous fold blocks with the remainder spread over the first folds (reference ``cv.py:222-245``)."""
+    fold_size = n // n_folds
+    remaining = n % n_folds
+    out = []
+    for fold in range(n_folds):
+        begin = (fold_size + 1) * min(fold, remaining) + max(fold - remaining, 0) * fold_size
+        out.append((begin, begin + fold_size + (fold < remaining)))
+    return out
+
+
+def _fold_loss(X, glm, fold_idx, full_lmdas, *, n_threads, early_exit, min_ratio, lmda_path_size, grpnet_params):
+    """Body of the reference's fold loop (``cv.py:247-314``)."""
+    weights = glm.weights.copy()
+    weights[fold_idx] = 0
+    weights_sum = np.sum(weights)
+    weights /= weights_sum
+    glm_c = glm.reweight(weights)
+
+    state = grpnet(X=X, glm=glm_c, n_threads=n_threads, lmda_path_size=0, progress_bar=False)
+    curr_lmdas = state.lmda_max * np.logspace(0, np.log10(min_ratio), lmda_path_size)
+    curr_lmdas = curr_lmdas[curr_lmdas > full_lmdas[0]]
+    aug_lmdas = np.sort(np.concatenate([full_lmdas, curr_lmdas]))[::-1]
+
+    state = grpnet(X=X, glm=glm_c, ddev_tol=0, n_threads=n_threads, early_exit=early_exit, lmda_path=aug_lmdas,
+                   **grpnet_params)
+
+    weights_sum_val = np.sum(glm.weights[fold_idx])
+    betas, intercepts, lmdas = state.betas, state.intercepts, state.lmdas
+    beta_ints = [coefficient(lmda=lmda, betas=betas, intercepts=intercepts, lmdas=lmdas) for lmda in full_lmdas]
+    full_betas = scipy.sparse.vstack([x[0] for x in beta_ints]).tocsr()
+    full_intercepts = np.array([x[1] for x in beta_ints])
+    etas = predict(X=X, betas=full_betas, intercepts=full_intercepts, offsets=state._offsets, n_threads=n_threads)
+    full_data_losses = np.array([glm.loss(eta) for eta in etas])
+    train_losses = weights_sum * np.array([glm_c.loss(eta) for eta in etas])
+    return (full_data_losses - train_losses) / weights_sum_val if weights_sum_val > 0 else np.zeros(len(full_lmdas))
+
+
+def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio: float = 1e-1,
+              lmda_path_size: int = 100, n_folds: int = 5, seed: int = None, process_group=None, **grpnet_params):
+    """Cross-validated group elastic net (reference ``adelie.cv.cv_grpnet``; same arguments and defaults).
+
+    ``process_group``: optional ``torch.distributed`` group (or ``True`` for the default group).  When given,
+    fold ``k`` is solved by rank ``k % world_size`` and the per-fold loss rows are all-gathered; every rank
+    returns the same ``CVGrpnetResult``.  Every rank must pass the same data and seed.
+    """
+    if isinstance(X, np.ndarray):
+        X = matrix.dense(X, method="naive", n_threads=n_threads)
+    assert isinstance(X, (matrix.MatrixNaiveBase64, matrix.MatrixNaiveBase32))
+    n = X.rows()
+
+    if seed is not None:
+        np.random.seed(seed)
+    order = np.random.choice(n, n, replace=False)
+
+    rank, world = 0, 1
+    dist = None
+    if process_group is not None:
+        import torch.distributed as dist  # noqa: F811
+        group = None if process_group is True else process_group
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+    logger_level = logger.level
+    logger.setLevel(logging.ERROR)
+    try:
+        state = grpnet(X=X, glm=glm, n_threads=n_threads, lmda_path_size=0, progress_bar=False)
+        full_lmdas = state.lmda_max * np.logspace(0, np.log10(min_ratio), lmda_path_size)
+
+        cv_losses = np.zeros((n_folds, full_lmdas.shape[0]))
+        for fold, (b, e) in enumerate(fold_ranges(n, n_folds)):
+            if fold % world != rank:
+                continue
+            cv_losses[fold] = _fold_loss(
+                X, glm, order[b:e], full_lmdas, n_threads=n_threads, early_exit=early_exit, min_ratio=min_ratio,
+                lmda_path_size=lmda_path_size, grpnet_params=grpnet_params)
+    finally:
+        logger.setLevel(logger_level)
+
+    if world > 1:
+        cv_losses = _gather_fold_rows(dist, None if process_group is True else process_group, cv_losses, n_folds,
+                                      rank, world)
+
+    avg_losses = np.mean(cv_losses, axis=0)
+    best_idx = int(np.argmin(avg_losses))
+    return CVGrpnetResult(lmdas=full_lmdas, losses=cv_losses, avg_losses=avg_losses, best_idx=best_idx)
+
+
+def _gather_fold_rows(dist, group, local, n_folds, rank, world):
+    """One all_gather of the (n_folds, L) loss table; rows a rank does not own are zero, so the gathered
+    tables are merged by ownership (fold k lives on rank k % world)."""
+    import torch
+
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    t = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t, group=group)
+    merged = np.empty_like(local)
+    for k in range(n_folds):
+        merged[k] = outs[k % world][k].cpu().numpy()
+    return merged

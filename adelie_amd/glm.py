@@ -1,0 +1,161 @@
+"""GLM plugin surface — mirrors ``adelie.glm`` for the families on the grpnet hot path.
+
+Reference: ``adelie/glm.py:40-55`` (weight normalisation), ``:83-196`` (``binomial``), ``:374-453``
+(``gaussian`` with its ``opt`` flag), and the C++ classes ``glm/glm_base.ipp:23-37``,
+``glm/glm_gaussian.ipp:15-63``, ``glm/glm_binomial.ipp:14-99``.
+
+The objects below are host-side descriptors: they carry ``y``/``weights`` and the closed-form
+member functions (written in numpy, used by the Python preamble of ``grpnet`` and by ``cv_grpnet``).
+Inside the path solver the same functions run as fused HIP elementwise kernels, selected by
+``core_kind`` (``adelie_hip_glm_kind`` in ``include/adelie_hip.h``).
+"""
+import numpy as np
+
+from . import _abi
+from . import configs as _configs
+
+
+def _coerce_dtype(y, dtype):
+    """Reference ``glm.py:12-33`` (with ``np.asarray`` instead of numpy-1 ``copy=False``)."""
+    valid = (np.dtype("float32"), np.dtype("float64"))
+    y = np.asarray(y, order="C")
+    if dtype is None:
+        if y.dtype not in valid:
+            raise RuntimeError(
+                "y must have an underlying type of np.float32 or np.float64, "
+                "or dtype must be explicitly specified."
+            )
+        dtype = y.dtype.type
+    else:
+        if np.dtype(dtype) not in valid:
+            raise RuntimeError("dtype must be either np.float32 or np.float64.")
+        dtype = np.dtype(dtype).type
+    return y.astype(dtype, copy=False), dtype
+
+
+class GlmBase:
+    is_multi = False
+
+
+class GlmBase64(GlmBase):
+    pass
+
+
+class GlmBase32(GlmBase):
+    pass
+
+
+class glm_base:
+    """Reference ``glm.py:36-55``."""
+
+    def __init__(self, y, weights, dtype):
+        self.y = np.array(y, copy=True, dtype=dtype)
+        self.dtype = dtype
+        if len(y.shape) != 1:
+            raise RuntimeError("y must be 1-dimensional.")
+        n = y.shape[0]
+        if weights is not None:
+            weights = np.asarray(weights)
+            if weights.shape != (n,):
+                raise RuntimeError("y and weights must have same length.")
+            weights_sum = np.sum(weights)
+            if not np.allclose(weights_sum, 1):
+                weights = weights / weights_sum
+        else:
+            weights = np.full(n, 1 / n, dtype=dtype)
+        self.weights = np.array(weights, copy=True, dtype=dtype)
+
+    # glm_base.ipp:23-37
+    def inv_hessian_gradient(self, eta, grad, hess, inv_hess_grad):
+        hmin = self.dtype(_configs.Configs.hessian_min)
+        inv_hess_grad[...] = grad / (np.maximum(hess, 0) + hmin * (hess <= 0))
+
+
+def _mixin(dtype):
+    return GlmBase64 if np.dtype(dtype) == np.float64 else GlmBase32
+
+
+def gaussian(y, *, weights=None, dtype=None, opt: bool = True):
+    """Gaussian family (reference ``adelie.glm.gaussian``, ``glm.py:374-453``)."""
+    y, dtype = _coerce_dtype(y, dtype)
+
+    class _gaussian(glm_base, _mixin(dtype)):
+        name = "gaussian"
+
+        def __init__(self):
+            self.opt = opt
+            glm_base.__init__(self, y, weights, dtype)
+            self.core_kind = _abi.GLM_GAUSSIAN if opt else _abi.GLM_GAUSSIAN_IRLS
+
+        # glm_gaussian.ipp:15-63
+        def gradient(self, eta, grad):
+            grad[...] = self.weights * (self.y - eta)
+
+        def hessian(self, eta, grad, hess):
+            hess[...] = self.weights
+
+        def loss(self, eta):
+            return np.sum(self.weights * (0.5 * np.square(eta) - self.y * eta))
+
+        def loss_full(self):
+            return -0.5 * np.sum(np.square(self.y) * self.weights)
+
+        def inv_link(self, eta, out):
+            out[...] = eta
+
+        def reweight(self, weights=None):
+            w = self.weights if weights is None else weights
+            return gaussian(y=y, weights=w, dtype=dtype, opt=opt)
+
+    return _gaussian()
+
+
+def binomial(y, *, weights=None, link: str = "logit", dtype=None):
+    """Binomial family, logit link (reference ``adelie.glm.binomial``, ``glm.py:83-196``)."""
+    if link != "logit":
+        raise NotImplementedError("adelie_amd.glm.binomial: only link='logit' is on the grpnet hot path.")
+    y, dtype = _coerce_dtype(y, dtype)
+
+    class _binomial(glm_base, _mixin(dtype)):
+        name = "binomial_logit"
+
+        def __init__(self):
+            glm_base.__init__(self, y, weights, dtype)
+            self.core_kind = _abi.GLM_BINOMIAL_LOGIT
+
+        # glm_binomial.ipp:37-99
+        def gradient(self, eta, grad):
+            grad[...] = self.weights * (self.y - 1 / (1 + np.exp(-eta)))
+
+        def hessian(self, eta, grad, hess):
+            w = self.weights
+            h = w * self.y - grad
+            hess[...] = (h * (w - h)) / (w + (w <= 0))
+
+        def loss(self, eta):
+            mx = np.finfo(self.dtype).max
+            return np.sum(self.weights * (
+                ((eta > 0).astype(self.dtype) - self.y) * np.clip(eta, -mx, mx)
+                + np.log1p(np.exp(-np.abs(eta)))
+            ))
+
+        def loss_full(self):
+            # glm_binomial.ipp:14-33: non-finite logs are skipped
+            with np.errstate(divide="ignore", invalid="ignore"):
+                ly = np.log(self.y)
+                l1y = np.log(1 - self.y)
+                t1 = self.weights * self.y * ly
+                t2 = self.weights * (1 - self.y) * l1y
+            loss = 0.0
+            loss -= np.sum(t1[np.isfinite(ly)])
+            loss -= np.sum(t2[np.isfinite(l1y)])
+            return self.dtype(loss)
+
+        def inv_link(self, eta, out):
+            out[...] = 1 / (1 + np.exp(-eta))
+
+        def reweight(self, weights=None):
+            w = self.weights if weights is None else weights
+            return binomial(y=y, weights=w, dtype=dtype)
+
+    return _binomial()

@@ -1,0 +1,333 @@
+"""Design-matrix plugin surface — mirrors ``adelie.matrix`` for the grpnet hot path.
+
+Reference: ``adelie/matrix.py:52-191`` (Python sugar ``@``, ``.T``), ``:549-680`` (``dense``),
+``:1245-1298`` (``snp_unphased``) and the C++ virtual interface
+``adelie_core/matrix/matrix_naive_base.hpp:18-144``.
+
+A matrix object here is a handle to a design that is *resident in MI355X HBM*; every method is
+one call through the C ABI of ``libadelie_hip.so`` (``include/adelie_hip.h``) with host numpy
+vectors in/out, exactly the argument convention of the reference's pybind methods
+(pre-allocated outputs written in place).
+"""
+import warnings
+
+import numpy as np
+from scipy.sparse import csc_matrix, csr_matrix
+
+from . import _abi
+
+
+class MatrixNaiveBase:
+    """Common base of every design handle (role of ``MatrixNaiveBase{32,64}``)."""
+
+    dtype = None
+
+
+class MatrixNaiveBase64(MatrixNaiveBase):
+    dtype = np.float64
+
+
+class MatrixNaiveBase32(MatrixNaiveBase):
+    dtype = np.float32
+
+
+def _as(v, dtype):
+    return np.ascontiguousarray(v, dtype=dtype)
+
+
+class PyMatrixNaiveTranspose:
+    """``X.T @ v`` (reference ``matrix.py:52-76``)."""
+
+    def __init__(self, mat):
+        self._mat = mat
+        self.T = mat
+
+    def __matmul__(self, v):
+        dtype = self._mat.dtype
+        v = np.asarray(v, dtype=dtype)
+        if (len(v.shape) <= 0) or (len(v.shape) > 2):
+            raise ValueError("Right argument must be either 1 or 2-dimensional.")
+        n, p = self._mat.shape
+        ones = np.ones(n, dtype=dtype)
+        if len(v.shape) == 1:
+            out = np.empty(p, dtype=dtype)
+            self._mat.mul(v, ones, out)
+            return out
+        v = np.asfortranarray(v)
+        out = np.empty((v.shape[1], p), dtype=dtype)
+        for i in range(out.shape[0]):
+            self._mat.mul(v[:, i], ones, out[i])
+        return out.T
+
+
+class _NativeMatrix:
+    """Methods shared by every native design handle; ``_backend`` is an ``_abi.Backend``."""
+
+    def _init_native(self, backend, handle, n_threads):
+        self._backend = backend
+        self._handle = handle
+        self._n_threads = n_threads
+        self._rows = int(backend.fn("design_rows")(handle))
+        self._cols = int(backend.fn("design_cols")(handle))
+        self.T = PyMatrixNaiveTranspose(self)
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None:
+            try:
+                self._backend.fn("design_destroy")(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    # -- MatrixNaiveBase virtuals (matrix_naive_base.hpp:18-144) -----------------------------
+    def rows(self):
+        return self._rows
+
+    def cols(self):
+        return self._cols
+
+    @property
+    def ndim(self):
+        return 2
+
+    @property
+    def shape(self):
+        return (self._rows, self._cols)
+
+    def _chk(self, cond, msg):
+        if not cond:
+            raise RuntimeError(msg)
+
+    def cmul(self, j, v, weights):
+        self._chk(0 <= j < self._cols and len(v) == self._rows and len(weights) == self._rows,
+                  "cmul() is given inconsistent inputs!")
+        v = _as(v, self.dtype)
+        w = _as(weights, self.dtype)
+        out = _abi.C.c_double()
+        self._backend.check(self._backend.fn("design_cmul")(self._handle, j, v.ctypes.data, w.ctypes.data, out))
+        return self.dtype(out.value)
+
+    cmul_safe = cmul
+
+    def ctmul(self, j, v, out):
+        self._chk(0 <= j < self._cols and len(out) == self._rows, "ctmul() is given inconsistent inputs!")
+        o = self._out(out)
+        self._backend.check(self._backend.fn("design_ctmul")(self._handle, j, float(v), o.ctypes.data))
+        self._writeback(o, out)
+
+    def bmul(self, j, q, v, weights, out):
+        self._chk(0 <= j <= self._cols - q and len(v) == self._rows and len(weights) == self._rows and len(out) == q,
+                  "bmul() is given inconsistent inputs!")
+        v = _as(v, self.dtype)
+        w = _as(weights, self.dtype)
+        o = self._out(out)
+        self._backend.check(self._backend.fn("design_bmul")(self._handle, j, q, v.ctypes.data, w.ctypes.data, o.ctypes.data))
+        self._writeback(o, out)
+
+    bmul_safe = bmul
+
+    def btmul(self, j, q, v, out):
+        self._chk(0 <= j <= self._cols - q and len(v) == q and len(out) == self._rows,
+                  "btmul() is given inconsistent inputs!")
+        v = _as(v, self.dtype)
+        o = self._out(out)
+        self._backend.check(self._backend.fn("design_btmul")(self._handle, j, q, v.ctypes.data, o.ctypes.data))
+        self._writeback(o, out)
+
+    def mul(self, v, weights, out):
+        self._chk(len(v) == self._rows and len(weights) == self._rows and len(out) == self._cols,
+                  "mul() is given inconsistent inputs!")
+        v = _as(v, self.dtype)
+        w = _as(weights, self.dtype)
+        o = self._out(out)
+        self._backend.check(self._backend.fn("design_mul")(self._handle, v.ctypes.data, w.ctypes.data, o.ctypes.data))
+        self._writeback(o, out)
+
+    def cov(self, j, q, sqrt_weights, out):
+        self._chk(0 <= j <= self._cols - q and len(sqrt_weights) == self._rows and out.shape == (q, q),
+                  "cov() is given inconsistent inputs!")
+        sw = _as(sqrt_weights, self.dtype)
+        o = np.empty(q * q, dtype=self.dtype)
+        self._backend.check(self._backend.fn("design_cov")(self._handle, j, q, sw.ctypes.data, o.ctypes.data))
+        out[...] = o.reshape(q, q, order="F")
+
+    def sq_mul(self, weights, out):
+        self._chk(len(weights) == self._rows and len(out) == self._cols, "sq_mul() is given inconsistent inputs!")
+        w = _as(weights, self.dtype)
+        o = self._out(out)
+        self._backend.check(self._backend.fn("design_sq_mul")(self._handle, w.ctypes.data, o.ctypes.data))
+        self._writeback(o, out)
+
+    def sp_tmul(self, v, out):
+        v = csr_matrix(v)
+        L = v.shape[0]
+        self._chk(v.shape[1] == self._cols and out.shape == (L, self._rows), "sp_tmul() is given inconsistent inputs!")
+        indptr = np.ascontiguousarray(v.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(v.indices, dtype=np.int64)
+        values = _as(v.data, self.dtype)
+        o = np.empty((L, self._rows), dtype=self.dtype)
+        self._backend.check(self._backend.fn("design_sp_tmul")(
+            self._handle, L, indptr.ctypes.data, indices.ctypes.data, values.ctypes.data, o.ctypes.data))
+        out[...] = o
+
+    def mean(self, weights, out):
+        """Default ``MatrixNaiveBase::mean`` (matrix_naive_base.hpp:113-122): ``out = w^T X``."""
+        ones = np.ones(self._rows, dtype=self.dtype)
+        self.mul(ones, weights, out)
+
+    def var(self, centers, weights, out):
+        """Default ``MatrixNaiveBase::var`` (matrix_naive_base.hpp:124-133)."""
+        sum_w = np.sum(weights)
+        m = np.empty(self._cols, dtype=self.dtype)
+        self.mean(weights, m)
+        self.sq_mul(weights, out)
+        centers = np.asarray(centers, dtype=self.dtype)
+        out += centers * (centers * sum_w - 2 * m)
+
+    # -- python sugar (matrix.py:79-191) ---------------------------------------------------
+    def __matmul__(self, v):
+        dtype = self.dtype
+        n, p = self.shape
+        if isinstance(v, (csr_matrix, csc_matrix)):
+            v = v.tocsr().transpose()
+            out = np.empty((v.shape[0], n), dtype=dtype)
+            self.sp_tmul(v, out)
+            return out.T
+        v = np.asarray(v, dtype=dtype)
+        if (len(v.shape) <= 0) or (len(v.shape) > 2):
+            raise ValueError("Right argument must be either 1 or 2-dimensional.")
+        if len(v.shape) == 1:
+            out = np.zeros(n, dtype=dtype)
+            self.btmul(0, p, v, out)
+            return out
+        v = np.asfortranarray(v)
+        out = np.zeros((v.shape[1], n), dtype=dtype)
+        for i in range(out.shape[0]):
+            self.btmul(0, p, v[:, i], out[i])
+        return out.T
+
+    # -- helpers ---------------------------------------------------------------------------
+    def _out(self, out):
+        if isinstance(out, np.ndarray) and out.dtype == self.dtype and out.flags.c_contiguous:
+            return out
+        return np.ascontiguousarray(out, dtype=self.dtype)
+
+    @staticmethod
+    def _writeback(o, out):
+        if o is not out:
+            out[...] = o
+
+
+def _make_class(dtype):
+    base = MatrixNaiveBase64 if np.dtype(dtype) == np.float64 else MatrixNaiveBase32
+
+    class _matrix(_NativeMatrix, base):
+        pass
+
+    _matrix.dtype = base.dtype
+    return _matrix
+
+
+def _wrap(backend, handle, dtype, n_threads, keep=None):
+    obj = _make_class(dtype)()
+    obj._init_native(backend, handle, n_threads)
+    obj._keep = keep
+    return obj
+
+
+def dense(mat, *, method: str = "naive", copy: bool = False, n_threads: int = 1, device: int = 0):
+    """Creates a dense design resident on an MI355X (reference ``adelie.matrix.dense``, ``matrix.py:549-680``).
+
+    Parameters
+    ----------
+    mat : (n, p) ndarray or torch.Tensor
+        float32/float64 matrix.  A numpy array is copied to HBM once.  A CUDA(ROCm) torch tensor is
+        adopted in place (no copy); it must be F- or C-contiguous and is kept alive by the handle.
+    method : str
+        Only ``"naive"`` is on the hot path.
+    n_threads : int
+        Accepted for API parity (the reference's OpenMP thread count); must be >= 1.
+    device : int
+        HIP device ordinal for host inputs.
+    """
+    if method != "naive":
+        raise NotImplementedError("adelie_amd.matrix.dense: only method='naive' is on the grpnet hot path.")
+    if n_threads < 1:
+        raise RuntimeError("adelie_core: n_threads must be >= 1.")
+    backend = _abi.hip_backend()
+    handle = _abi.C.c_void_p()
+
+    if not isinstance(mat, np.ndarray) and type(mat).__module__.startswith("torch"):
+        t = mat
+        if t.dim() != 2 or not t.is_cuda:
+            raise RuntimeError("torch input must be a 2-D tensor in device memory.")
+        dtype = {"torch.float64": np.float64, "torch.float32": np.float32}[str(t.dtype)]
+        n, p = t.shape
+        if t.stride() == (1, n) or (p == 1 and t.stride(0) == 1):
+            order = _abi.COL_MAJOR
+        elif t.is_contiguous():
+            order = _abi.ROW_MAJOR
+            warnings.warn("Detected matrix to be C-contiguous. Performance may improve with F-contiguous matrix.")
+        else:
+            raise RuntimeError("torch input must be F- or C-contiguous.")
+        backend.check(backend.fn("design_adopt_dense_dev")(
+            t.data_ptr(), n, p, _abi.dtype_code(dtype), order, t.device.index or 0, handle))
+        return _wrap(backend, handle, dtype, n_threads, keep=t)
+
+    mat = np.asarray(mat)
+    if mat.ndim != 2:
+        raise RuntimeError("mat must be 2-dimensional.")
+    dtype = mat.dtype
+    code = _abi.dtype_code(dtype)
+    if mat.flags.f_contiguous:
+        order = _abi.COL_MAJOR
+    else:
+        order = _abi.ROW_MAJOR
+        mat = np.ascontiguousarray(mat)
+        warnings.warn("Detected matrix to be C-contiguous. Performance may improve with F-contiguous matrix.")
+    backend.check(backend.fn("design_create_dense")(
+        mat.ctypes.data, mat.shape[0], mat.shape[1], code, order, device, handle))
+    return _wrap(backend, handle, dtype.type, n_threads)
+
+
+def snp_unphased(io, *, dtype=np.float64, n_threads: int = 1, device: int = 0):
+    """Creates an SNP-unphased design resident on an MI355X as dense 2-bit calls
+    (reference ``adelie.matrix.snp_unphased``, ``matrix.py:1245-1298``).
+
+    ``io`` is an ``adelie_amd.io.snp_unphased`` handler that has been ``read()``.
+    """
+    if n_threads < 1:
+        raise RuntimeError("adelie_core: n_threads must be >= 1.")
+    if not io.is_read:
+        io.read()
+    backend = _abi.hip_backend()
+    handle = _abi.C.c_void_p()
+    buf = io._buffer
+    backend.check(backend.fn("design_create_snp_unphased")(
+        buf.ctypes.data, buf.size, _abi.dtype_code(dtype), device, handle))
+    return _wrap(backend, handle, np.dtype(dtype).type, n_threads, keep=io)
+
+
+def snp_calldata(calldata, impute=None, *, dtype=np.float64, n_threads: int = 1, device: int = 0):
+    """SNP design straight from an int8 ``(n, p)`` calldata matrix (negative = missing), skipping the
+    ``.snpdat`` file.  ``impute`` defaults to the column mean of the non-missing calls
+    (reference ``io/utils.hpp:10-31``)."""
+    calldata = np.asfortranarray(calldata, dtype=np.int8)
+    n, p = calldata.shape
+    if impute is None:
+        impute = compute_impute(calldata)
+    impute = np.ascontiguousarray(impute, dtype=np.float64)
+    backend = _abi.hip_backend()
+    handle = _abi.C.c_void_p()
+    backend.check(backend.fn("design_create_snp_calldata")(
+        calldata.ctypes.data, n, p, impute.ctypes.data, _abi.dtype_code(dtype), device, handle))
+    return _wrap(backend, handle, np.dtype(dtype).type, n_threads)
+
+
+def compute_impute(calldata):
+    """Mean imputation (reference ``io/utils.hpp:10-31``): mean of the non-missing entries per column."""
+    calldata = np.asarray(calldata)
+    valid = calldata >= 0
+    cnt = np.maximum(valid.sum(axis=0), 1)
+    return (np.where(valid, calldata, 0).sum(axis=0) / cnt).astype(np.float64)

@@ -1,0 +1,225 @@
+"""``grpnet`` — mirrors ``adelie.solver.grpnet`` (reference ``adelie/solver.py:354-958``).
+
+Same keyword arguments, same defaults, same preamble: the initial invariants are computed with two
+``X.mul`` sweeps through the matrix plugin surface (reference ``solver.py:891-904``), the state object
+is built by ``adelie_amd.state`` and ``state.solve()`` runs the whole lambda path on the MI355X.
+
+Multi-response GLMs (``glm.is_multi``) are outside the hot path and raise.
+"""
+from typing import Callable
+
+import numpy as np
+
+from . import matrix
+from .state import gaussian_naive as state_gaussian_naive
+from .state import glm_naive as state_glm_naive
+
+
+def grpnet(
+    X,
+    glm,
+    *,
+    constraints: list = None,
+    groups: np.ndarray = None,
+    alpha: float = 1,
+    penalty: np.ndarray = None,
+    offsets: np.ndarray = None,
+    lmda_path: np.ndarray = None,
+    irls_max_iters: int = int(1e4),
+    irls_tol: float = 1e-7,
+    max_iters: int = int(1e5),
+    tol: float = 1e-7,
+    adev_tol: float = 0.9,
+    ddev_tol: float = 0,
+    newton_tol: float = 1e-12,
+    newton_max_iters: int = 1000,
+    n_threads: int = 1,
+    early_exit: bool = True,
+    intercept: bool = True,
+    screen_rule: str = "pivot",
+    min_ratio: float = 1e-2,
+    lmda_path_size: int = 100,
+    max_screen_size: int = None,
+    max_active_size: int = None,
+    pivot_subset_ratio: float = 0.1,
+    pivot_subset_min: int = 1,
+    pivot_slack_ratio: float = 1.25,
+    check_state: bool = False,
+    progress_bar: bool = False,
+    warm_start=None,
+    exit_cond: Callable = None,
+):
+    """Solves group elastic net via the naive method on an MI355X.
+
+    Minimises ``l(eta) + lmda * sum_g penalty_g (alpha ||beta_g|| + (1-alpha)/2 ||beta_g||^2)`` with
+    ``eta = X beta + beta0 + offsets`` along a decreasing path of ``lmda`` (see the reference docstring,
+    ``adelie/solver.py:388-620``, for the meaning of every argument; they are identical).
+
+    Returns
+    -------
+    state
+        The solved state (``betas`` CSR ``(L, p)``, ``intercepts``, ``devs``, ``lmdas`` and the invariants).
+    """
+    X_raw = X
+    if isinstance(X, np.ndarray):
+        X = matrix.dense(X, method="naive", n_threads=n_threads)
+    assert isinstance(X, (matrix.MatrixNaiveBase64, matrix.MatrixNaiveBase32))
+    dtype = np.float64 if isinstance(X, matrix.MatrixNaiveBase64) else np.float32
+    n, p = X.rows(), X.cols()
+
+    if getattr(glm, "is_multi", False):
+        raise NotImplementedError("adelie_amd.grpnet: multi-response GLMs are outside the hot path.")
+    if isinstance(constraints, list) and any(c is not None for c in constraints):
+        raise NotImplementedError("adelie_amd.grpnet: constraints are outside the hot path (pass None).")
+
+    if offsets is not None:
+        offsets = np.asarray(offsets)
+        if offsets.shape != glm.y.shape:
+            raise RuntimeError("offsets must be same shape as y if not None.")
+        offsets = np.asarray(offsets, order="C", dtype=dtype)
+    else:
+        offsets = np.zeros(glm.y.shape, dtype=dtype)
+
+    if lmda_path is not None:
+        lmda_path = np.array(np.flip(np.sort(lmda_path)), dtype=dtype)
+
+    solver_args = {
+        "X": X,
+        "constraints": constraints,
+        "alpha": alpha,
+        "offsets": offsets,
+        "lmda_path": lmda_path,
+        "max_iters": max_iters,
+        "tol": tol,
+        "adev_tol": adev_tol,
+        "ddev_tol": ddev_tol,
+        "newton_tol": newton_tol,
+        "newton_max_iters": newton_max_iters,
+        "n_threads": n_threads,
+        "early_exit": early_exit,
+        "intercept": intercept,
+        "screen_rule": screen_rule,
+        "min_ratio": min_ratio,
+        "lmda_path_size": lmda_path_size,
+        "max_screen_size": max_screen_size,
+        "max_active_size": max_active_size,
+        "pivot_subset_ratio": pivot_subset_ratio,
+        "pivot_subset_min": pivot_subset_min,
+        "pivot_slack_ratio": pivot_slack_ratio,
+    }
+    del X_raw
+
+    is_gaussian_opt = (glm.name in ["gaussian", "multigaussian"]) and glm.opt  # solver.py:683-686
+    if not is_gaussian_opt:
+        solver_args["glm"] = glm
+        solver_args["irls_max_iters"] = irls_max_iters
+        solver_args["irls_tol"] = irls_tol
+    else:
+        solver_args["y"] = glm.y
+        solver_args["weights"] = glm.weights
+
+    if groups is None:
+        groups = np.arange(p, dtype=int)
+    groups = np.asarray(groups, dtype=int)
+
+    # single-response GLMs: solver.py:846-950
+    group_sizes = np.concatenate([groups, [p]], dtype=int)
+    group_sizes = group_sizes[1:] - group_sizes[:-1]
+    G = len(groups)
+    if penalty is None:
+        penalty = np.sqrt(group_sizes).astype(dtype)
+    penalty = np.asarray(penalty, dtype=dtype)
+
+    if warm_start is None:
+        lmda = np.inf
+        lmda_max = None
+        screen_set = np.arange(G)[(penalty <= 0) | (alpha <= 0)]
+        screen_beta = np.zeros(np.sum(group_sizes[screen_set]), dtype=dtype)
+        screen_is_active = np.ones(screen_set.shape[0], dtype=bool)
+        active_set_size = screen_set.shape[0]
+        active_set = np.empty(groups.shape[0], dtype=int)
+        active_set[:active_set_size] = np.arange(active_set_size)
+    else:
+        lmda = warm_start.lmda
+        lmda_max = warm_start.lmda_max
+        screen_set = warm_start.screen_set
+        screen_beta = warm_start.screen_beta
+        screen_is_active = warm_start.screen_is_active
+        active_set_size = warm_start.active_set_size
+        active_set = warm_start.active_set
+
+    solver_args["groups"] = groups
+    solver_args["group_sizes"] = group_sizes
+    solver_args["penalty"] = penalty
+    solver_args["lmda"] = lmda
+    solver_args["lmda_max"] = lmda_max
+    solver_args["screen_set"] = screen_set
+    solver_args["screen_beta"] = screen_beta
+    solver_args["screen_is_active"] = screen_is_active
+    solver_args["active_set_size"] = active_set_size
+    solver_args["active_set"] = active_set
+
+    if is_gaussian_opt:
+        y = glm.y
+        weights = glm.weights
+        if warm_start is None:
+            ones = np.ones(n, dtype=dtype)
+            X_means = np.empty(p, dtype=dtype)
+            X.mul(ones, weights, X_means)
+            y_off = y - offsets
+            y_mean = np.sum(y_off * weights)
+            yc = y_off
+            if intercept:
+                yc = yc - y_mean
+            y_var = np.sum(weights * yc ** 2)
+            rsq = 0
+            resid = yc
+            resid_sum = np.sum(weights * resid)
+            grad = np.empty(p, dtype=dtype)
+            X.mul(resid, weights, grad)
+        else:
+            X_means = warm_start.X_means
+            y_mean = warm_start.y_mean
+            y_var = warm_start.y_var
+            rsq = warm_start.rsq
+            resid = warm_start.resid
+            resid_sum = warm_start.resid_sum
+            grad = warm_start.grad
+        solver_args["X_means"] = X_means
+        solver_args["y_mean"] = y_mean
+        solver_args["y_var"] = y_var
+        solver_args["rsq"] = rsq
+        solver_args["resid"] = resid
+        solver_args["resid_sum"] = resid_sum
+        solver_args["grad"] = grad
+        state = state_gaussian_naive(**solver_args)
+    else:
+        if warm_start is None:
+            ones = np.ones(n, dtype=dtype)
+            beta0 = 0
+            eta = offsets
+            resid = np.empty(n, dtype=dtype)
+            glm.gradient(eta, resid)
+            grad = np.empty(p, dtype=dtype)
+            X.mul(resid, ones, grad)
+            loss_null = None
+            loss_full = glm.loss_full()
+        else:
+            beta0 = warm_start.beta0
+            eta = warm_start.eta
+            resid = warm_start.resid
+            grad = warm_start.grad
+            loss_null = warm_start.loss_null
+            loss_full = warm_start.loss_full
+        solver_args["beta0"] = beta0
+        solver_args["grad"] = grad
+        solver_args["eta"] = eta
+        solver_args["resid"] = resid
+        solver_args["loss_null"] = loss_null
+        solver_args["loss_full"] = loss_full
+        state = state_glm_naive(**solver_args)
+
+    if check_state:
+        state.check(method="assert")
+
+    return state.solve(progress_bar=progress_bar, exit_cond=exit_cond)

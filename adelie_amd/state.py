@@ -1,0 +1,492 @@
+"""State objects — mirrors ``adelie.state`` for ``gaussian_naive`` and ``glm_naive``.
+
+Reference: ``adelie/state.py:118-176`` (``base.create_from_core`` / ``base.solve``), ``:1007-1045``
+(sentinel rendering), ``:1421-1675`` (``gaussian_naive_base.check``), ``:1677-2024`` (``gaussian_naive``),
+``:2407-2753`` (``glm_naive``); core constructors ``py_state.cpp:1068-1154`` / ``:1556-1720``.
+
+In the reference a state is a Python object that *inherits* from a pybind C++ state; ``solve()`` passes
+the C++ state by value into the solver and re-wraps the solved copy.  Here a state is a plain Python
+object that owns the constructor arguments; ``solve()`` marshals them into ``adelie_hip_grpnet_args``
+(include/adelie_hip.h), runs the path on the GPU, and returns a *new* state whose attributes are read
+back through the result accessors — the caller's state is left untouched, as in the reference.
+"""
+import logging
+
+import numpy as np
+from scipy.sparse import csr_matrix
+
+from . import _abi
+from . import glm as _glm
+from . import matrix as _matrix
+
+logger = logging.getLogger("adelie_amd")
+
+
+def _render_inputs(*, groups, lmda_max, lmda_path, lmda_path_size, max_screen_size, max_active_size, dtype):
+    """Reference ``state.py:1007-1045`` (``_render_gaussian_inputs``)."""
+    if max_screen_size is None:
+        max_screen_size = len(groups)
+    if max_active_size is None:
+        max_active_size = len(groups)
+    max_screen_size = int(np.minimum(max_screen_size, len(groups)))
+    max_active_size = int(np.minimum(max_active_size, len(groups)))
+    lmda_path_size = lmda_path_size if lmda_path is None else len(lmda_path)
+    setup_lmda_max = lmda_max is None
+    setup_lmda_path = lmda_path is None
+    if setup_lmda_max:
+        lmda_max = -1
+    if setup_lmda_path:
+        lmda_path = np.empty(0, dtype=dtype)
+    return max_screen_size, max_active_size, int(lmda_path_size), setup_lmda_max, setup_lmda_path, lmda_max, lmda_path
+
+
+_SCREEN_RULES = {"strong": _abi.SCREEN_STRONG, "pivot": _abi.SCREEN_PIVOT}
+
+_RESULT_VALUE_VECS = ["intercepts", "devs", "lmdas", "lmda_path", "screen_beta", "grad", "abs_grad", "resid",
+                      "screen_X_means", "screen_vars",
+                      "benchmark_screen", "benchmark_fit_screen", "benchmark_fit_active", "benchmark_kkt",
+                      "benchmark_invariance"]
+_RESULT_INDEX_VECS = ["screen_set", "screen_begins", "screen_is_active", "active_set", "n_valid_solutions",
+                      "active_sizes", "screen_sizes"]
+_COUNTERS = ["n_basil_iters", "n_sweeps", "n_cd_visits_screen", "n_cd_visits_active", "n_updates", "n_irls_iters",
+             "n_new_screen_cols", "n_cd_passes_screen", "n_cd_passes_active", "n_gram_col_reads",
+             "n_resid_col_reads"]
+
+
+class base:
+    """Common machinery of the two naive states."""
+
+    # names of the constructor arguments that are carried over unchanged into a solved state
+    _static = ()
+
+    def _marshal(self):  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def solve(self, progress_bar: bool = False, exit_cond=None):
+        """Runs the path solver; returns a new solved state (reference ``state.py:157-176``).
+
+        ``exit_cond`` takes the number of solutions found so far wrapped in a light view object exposing
+        ``lmdas``-length via ``n_solutions`` (the reference passes the live C++ state; on device the live
+        state is not host-visible mid-path, so only the solution count is offered).
+        """
+        backend = self._X._backend
+        args, keep = self._marshal()
+
+        class _View:
+            n_solutions = 0
+
+        view = _View()
+        pending = {}
+
+        def _poll(user, final, n_solutions):
+            try:
+                if final and exit_cond is not None:
+                    view.n_solutions = int(n_solutions)
+                    return 1 if exit_cond(view) else 0
+            except KeyboardInterrupt as e:  # pragma: no cover
+                pending["exc"] = e
+                return 1
+            return 0
+
+        cb = _abi.POLL_FN(_poll)
+        args.poll = cb
+        args.poll_user = None
+        handle = _abi.C.c_void_p()
+        backend.check(backend.fn("grpnet_solve")(self._X._handle, _abi.C.byref(args), handle))
+        del keep
+        if "exc" in pending:
+            backend.fn("result_destroy")(handle)
+            raise pending["exc"]
+        try:
+            out = self._from_result(backend, handle)
+        finally:
+            backend.fn("result_destroy")(handle)
+        if out.error != "":
+            if out.error.startswith("adelie_core solver: "):
+                logger.error(RuntimeError(out.error))
+            else:
+                logger.warning(RuntimeError(out.error))
+        return out
+
+    def _from_result(self, backend, r):
+        new = object.__new__(type(self))
+        new.__dict__.update({k: v for k, v in self.__dict__.items()})
+        dtype = self.dtype
+        for name in _RESULT_VALUE_VECS:
+            v = backend.result_vec(r, _abi.V[name])
+            setattr(new, name, v.astype(dtype) if not name.startswith("benchmark") else v)
+        for name in _RESULT_INDEX_VECS:
+            v = backend.result_vec(r, _abi.I[name], index=True)
+            setattr(new, name, v)
+        new.screen_is_active = new.screen_is_active.astype(bool)
+        new.n_valid_solutions = new.n_valid_solutions.astype(np.int32)
+        new.active_sizes = new.active_sizes.astype(np.int32)
+        new.screen_sizes = new.screen_sizes.astype(np.int32)
+        indptr = backend.result_vec(r, _abi.I["betas_indptr"], index=True)
+        indices = backend.result_vec(r, _abi.I["betas_indices"], index=True)
+        values = backend.result_vec(r, _abi.V["betas_values"]).astype(dtype)
+        p = self._X.cols()
+        new.betas = csr_matrix((values, indices, indptr), shape=(len(indptr) - 1, p))
+        new.duals = csr_matrix((len(indptr) - 1, 0), dtype=dtype)
+        sc = lambda nm: backend.fn("result_scalar")(r, _abi.S[nm])
+        new.lmda_max = dtype(sc("lmda_max"))
+        new.lmda = dtype(sc("lmda"))
+        new.active_set_size = int(sc("active_set_size"))
+        new.total_time = sc("total_time")
+        new.counters = {nm: int(v) if v == v else 0 for nm, v in ((nm, sc(nm)) for nm in _COUNTERS)}
+        err = backend.fn("result_error")(r)
+        new.error = err.decode() if err else ""
+        # screen_transforms: list of (q,q) F-ordered blocks in screen order
+        flat = backend.result_vec(r, _abi.V["screen_transforms"]).astype(dtype)
+        tr, off = [], 0
+        if len(flat) == int(np.sum(np.square(self.group_sizes[new.screen_set]))):
+            for g in new.screen_set:
+                q = int(self.group_sizes[g])
+                tr.append(flat[off:off + q * q].reshape(q, q, order="F"))
+                off += q * q
+        new.screen_transforms = tr
+        self._from_result_extra(new, backend, r, sc)
+        return new
+
+    def _from_result_extra(self, new, backend, r, sc):
+        pass
+
+    def _common_args(self, a, keep):
+        dtype = self.dtype
+
+        def val(x):
+            arr = np.ascontiguousarray(x, dtype=dtype)
+            keep.append(arr)
+            return arr.ctypes.data
+
+        def idx(x):
+            arr = np.ascontiguousarray(x, dtype=np.int64)
+            keep.append(arr)
+            return arr.ctypes.data
+
+        a.G = len(self.groups)
+        a.groups = idx(self.groups)
+        a.group_sizes = idx(self.group_sizes)
+        a.alpha = float(self.alpha)
+        a.penalty = val(self.penalty)
+        a.resid = val(self.resid)
+        a.grad = val(self.grad)
+        lp = np.ascontiguousarray(self.lmda_path, dtype=dtype)
+        keep.append(lp)
+        a.lmda_path = lp.ctypes.data if lp.size else None
+        a.n_lmda_path = lp.size
+        a.lmda_max = float(self.lmda_max)
+        a.min_ratio = float(self.min_ratio)
+        a.lmda_path_size = int(self.lmda_path_size)
+        a.max_screen_size = int(self.max_screen_size)
+        a.max_active_size = int(self.max_active_size)
+        a.pivot_subset_ratio = float(self.pivot_subset_ratio)
+        a.pivot_subset_min = int(self.pivot_subset_min)
+        a.pivot_slack_ratio = float(self.pivot_slack_ratio)
+        if self.screen_rule not in _SCREEN_RULES:
+            raise RuntimeError("adelie_core: Invalid screen rule type: " + str(self.screen_rule))
+        a.screen_rule = _SCREEN_RULES[self.screen_rule]
+        a.early_exit = int(bool(self.early_exit))
+        a.max_iters = int(self.max_iters)
+        a.tol = float(self.tol)
+        a.adev_tol = float(self.adev_tol)
+        a.ddev_tol = float(self.ddev_tol)
+        a.newton_tol = float(self.newton_tol)
+        a.newton_max_iters = int(self.newton_max_iters)
+        a.setup_lmda_max = int(self.setup_lmda_max)
+        a.setup_lmda_path = int(self.setup_lmda_path)
+        a.intercept = int(bool(self.intercept))
+        a.n_threads = int(self.n_threads)
+        ss = np.ascontiguousarray(self.screen_set, dtype=np.int64)
+        keep.append(ss)
+        a.screen_set_size = ss.size
+        a.screen_set = ss.ctypes.data
+        sb = np.ascontiguousarray(self.screen_beta, dtype=dtype)
+        keep.append(sb)
+        a.screen_beta_size = sb.size
+        a.screen_beta = sb.ctypes.data
+        sa = np.ascontiguousarray(self.screen_is_active, dtype=np.int8)
+        keep.append(sa)
+        if sa.size != ss.size:
+            raise RuntimeError("adelie_core: screen_is_active must be (s,) where screen_set is (s,).")
+        a.screen_is_active = sa.ctypes.data
+        a.active_set_size = int(self.active_set_size)
+        act = np.ascontiguousarray(self.active_set, dtype=np.int64)
+        if act.size != a.G:
+            raise RuntimeError("adelie_core: active_set must be (G,) where groups is (G,).")
+        keep.append(act)
+        a.active_set = act.ctypes.data
+        a.lmda = float(self.lmda)
+
+    def _check_shapes(self):
+        G = len(self.groups)
+        if len(self.group_sizes) != G:
+            raise RuntimeError("adelie_core: group_sizes must be (G,) where groups is (G,).")
+        if len(self.penalty) != G:
+            raise RuntimeError("adelie_core: penalty must be (G,) where groups is (G,).")
+        if self.constraints is not None and any(c is not None for c in self.constraints):
+            raise NotImplementedError("adelie_amd: per-group constraints are outside the grpnet hot path (pass None).")
+        n, p = self._X.rows(), self._X.cols()
+        if len(self.resid) != n:
+            raise RuntimeError("adelie_core: resid must be (n,) where X is (n, p).")
+        if len(self.grad) != p:
+            raise RuntimeError("adelie_core: grad must be (p,) where X is (n, p).")
+
+
+class gaussian_naive_base(base):
+    """Gaussian naive state (reference ``state.py:1421-1675``)."""
+
+    def _marshal(self):
+        keep = []
+        a = _abi.GrpnetArgs()
+        self._common_args(a, keep)
+        dtype = self.dtype
+        w = np.ascontiguousarray(self.weights, dtype=dtype)
+        xm = np.ascontiguousarray(self.X_means, dtype=dtype)
+        keep += [w, xm]
+        a.glm_kind = _abi.GLM_GAUSSIAN
+        a.weights = w.ctypes.data
+        a.X_means = xm.ctypes.data
+        a.y_mean = float(self.y_mean)
+        a.y_var = float(self.y_var)
+        a.resid_sum = float(self.resid_sum)
+        a.rsq = float(self.rsq)
+        return a, keep
+
+    def _from_result_extra(self, new, backend, r, sc):
+        dtype = self.dtype
+        new.rsq = dtype(sc("rsq"))
+        new.resid_sum = dtype(sc("resid_sum"))
+        new.loss_null = dtype(sc("loss_null"))
+        new.loss_full = dtype(sc("loss_full"))
+
+    def check(self, method: str = None, logger=logger):
+        """Invariance checks of reference ``state.py:1563-1674`` on the host copy of the state
+        (X accessed through the matrix handle).  ``method="assert"`` asserts each check."""
+        X = self._X
+        dtype = self.dtype
+        n, p = X.rows(), X.cols()
+        w = np.asarray(self.weights, dtype=dtype)
+        ok = True
+
+        def _c(cond, msg):
+            nonlocal ok
+            ok = ok and bool(cond)
+            logger.log(logging.INFO if cond else logging.ERROR, f"check {msg}: {'pass' if cond else 'FAIL'}")
+            if method == "assert":
+                assert cond, msg
+
+        _c(np.allclose(np.sum(w), 1), "weights sum to 1")
+        beta = np.zeros(p, dtype=dtype)
+        for ss, g in enumerate(self.screen_set):
+            b = self.screen_begins[ss] if hasattr(self, "screen_begins") else int(np.sum(self.group_sizes[self.screen_set[:ss]]))
+            q = self.group_sizes[g]
+            beta[self.groups[g]:self.groups[g] + q] = self.screen_beta[b:b + q]
+        Xb = X @ beta
+        yc = self._yc
+        resid = yc - Xb
+        _c(np.allclose(self.resid, resid, atol=1e-6), "resid = y_c - X beta")
+        _c(np.allclose(self.resid_sum, np.sum(w * resid), atol=1e-6), "resid_sum")
+        grad = X.T @ (w * resid)
+        if self.intercept:
+            grad = grad - np.sum(w * resid) * np.asarray(self.X_means)
+        _c(np.allclose(self.grad, grad, atol=1e-6), "grad = X_c^T W resid")
+        return ok
+
+
+class glm_naive_base(base):
+    """GLM naive state (reference ``state.py:2407-2753``)."""
+
+    def _marshal(self):
+        keep = []
+        a = _abi.GrpnetArgs()
+        self._common_args(a, keep)
+        dtype = self.dtype
+        g = self._glm
+        y = np.ascontiguousarray(g.y, dtype=dtype)
+        w = np.ascontiguousarray(g.weights, dtype=dtype)
+        off = np.ascontiguousarray(self._offsets, dtype=dtype)
+        eta = np.ascontiguousarray(self.eta, dtype=dtype)
+        keep += [y, w, off, eta]
+        a.glm_kind = int(g.core_kind) if g.core_kind != _abi.GLM_GAUSSIAN else _abi.GLM_GAUSSIAN_IRLS
+        a.glm_y = y.ctypes.data
+        a.glm_weights = w.ctypes.data
+        a.offsets = off.ctypes.data
+        a.eta = eta.ctypes.data
+        a.beta0 = float(self.beta0)
+        a.loss_null = float(self.loss_null)
+        a.loss_full = float(self.loss_full)
+        a.irls_max_iters = int(self.irls_max_iters)
+        a.irls_tol = float(self.irls_tol)
+        a.setup_loss_null = int(self.setup_loss_null)
+        return a, keep
+
+    def _from_result_extra(self, new, backend, r, sc):
+        dtype = self.dtype
+        new.beta0 = dtype(sc("beta0"))
+        new.loss_null = dtype(sc("loss_null"))
+        new.loss_full = dtype(sc("loss_full"))
+        new.eta = backend.result_vec(r, _abi.V["eta"]).astype(dtype)
+
+
+def _matrix_of(X, n_threads):
+    if isinstance(X, np.ndarray):
+        X = _matrix.dense(X, method="naive", n_threads=n_threads)
+    if not hasattr(X, "_backend"):
+        raise RuntimeError(
+            "adelie_amd: X must be an adelie_amd.matrix design (dense / snp_unphased) or an ndarray; "
+            "Python-subclassed matrices cannot run on the device path."
+        )
+    return X
+
+
+def gaussian_naive(
+    *, X, y, X_means, y_mean, y_var, resid, resid_sum, constraints, groups, group_sizes, alpha, penalty, weights,
+    offsets, screen_set, screen_beta, screen_is_active, active_set_size, active_set, rsq, lmda, grad,
+    lmda_path=None, lmda_max=None, max_iters=int(1e5), tol=1e-7, adev_tol=0.9, ddev_tol=0, newton_tol=1e-12,
+    newton_max_iters=1000, n_threads=1, early_exit=True, intercept=True, screen_rule="pivot", min_ratio=1e-2,
+    lmda_path_size=100, max_screen_size=None, max_active_size=None, pivot_subset_ratio=0.1, pivot_subset_min=1,
+    pivot_slack_ratio=1.25,
+):
+    """Creates a Gaussian, naive method state object (reference ``adelie.state.gaussian_naive``,
+    ``state.py:1677-2024``; argument meaning identical)."""
+    X = _matrix_of(X, n_threads)
+    dtype = X.dtype
+    (max_screen_size, max_active_size, lmda_path_size, setup_lmda_max, setup_lmda_path, lmda_max, lmda_path) = \
+        _render_inputs(groups=groups, lmda_max=lmda_max, lmda_path=lmda_path, lmda_path_size=lmda_path_size,
+                       max_screen_size=max_screen_size, max_active_size=max_active_size, dtype=dtype)
+    s = gaussian_naive_base()
+    s.dtype = dtype
+    s._X = X
+    s.X = X
+    s._glm = _glm.gaussian(y=np.asarray(y), weights=np.asarray(weights), dtype=dtype)
+    s.weights = s._glm.weights
+    s._offsets = np.array(offsets, copy=True, dtype=dtype)
+    s.X_means = np.array(X_means, copy=True, dtype=dtype)
+    s.y_mean = y_mean
+    s.y_var = y_var
+    s._yc = (np.asarray(y, dtype=dtype) - s._offsets) - (y_mean if intercept else 0)
+    s.resid = np.array(resid, copy=True, dtype=dtype)
+    s.resid_sum = resid_sum
+    s.constraints = constraints
+    s.groups = np.array(groups, copy=True, dtype=int)
+    s.group_sizes = np.array(group_sizes, copy=True, dtype=int)
+    s.alpha = alpha
+    s.penalty = np.array(penalty, copy=True, dtype=dtype)
+    s.lmda_path = np.asarray(lmda_path, dtype=dtype)
+    s.lmda_max = lmda_max
+    s.min_ratio = min_ratio
+    s.lmda_path_size = lmda_path_size
+    s.max_screen_size = max_screen_size
+    s.max_active_size = max_active_size
+    s.pivot_subset_ratio = pivot_subset_ratio
+    s.pivot_subset_min = pivot_subset_min
+    s.pivot_slack_ratio = pivot_slack_ratio
+    s.screen_rule = screen_rule
+    s.max_iters = max_iters
+    s.tol = tol
+    s.adev_tol = adev_tol
+    s.ddev_tol = ddev_tol
+    s.newton_tol = newton_tol
+    s.newton_max_iters = newton_max_iters
+    s.early_exit = early_exit
+    s.setup_lmda_max = setup_lmda_max
+    s.setup_lmda_path = setup_lmda_path
+    s.intercept = intercept
+    s.n_threads = n_threads
+    s.screen_set = np.asarray(screen_set, dtype=int)
+    s.screen_beta = np.asarray(screen_beta, dtype=dtype)
+    s.screen_is_active = np.asarray(screen_is_active, dtype=bool)
+    s.active_set_size = active_set_size
+    s.active_set = np.asarray(active_set, dtype=int)
+    s.rsq = rsq
+    s.lmda = lmda
+    s.grad = np.asarray(grad, dtype=dtype)
+    s.error = ""
+    s._check_shapes()
+    if len(s.weights) != X.rows():
+        raise RuntimeError("adelie_core: weights must be (n,) where X is (n, p).")
+    if len(s.X_means) != X.cols():
+        raise RuntimeError("adelie_core: X_means must be (p,) where X is (n, p).")
+    return s
+
+
+def glm_naive(
+    *, X, glm, constraints, groups, group_sizes, alpha, penalty, offsets, screen_set, screen_beta, screen_is_active,
+    active_set_size, active_set, beta0, lmda, grad, eta, resid, loss_full, loss_null=None, lmda_path=None,
+    lmda_max=None, irls_max_iters=int(1e4), irls_tol=1e-7, max_iters=int(1e5), tol=1e-7, adev_tol=0.9, ddev_tol=0,
+    newton_tol=1e-12, newton_max_iters=1000, n_threads=1, early_exit=True, intercept=True, screen_rule="pivot",
+    min_ratio=1e-2, lmda_path_size=100, max_screen_size=None, max_active_size=None, pivot_subset_ratio=0.1,
+    pivot_subset_min=1, pivot_slack_ratio=1.25,
+):
+    """Creates a GLM, naive method state object (reference ``adelie.state.glm_naive``, ``state.py:2407-2753``)."""
+    X = _matrix_of(X, n_threads)
+    dtype = X.dtype
+    if not hasattr(glm, "core_kind"):
+        raise RuntimeError(
+            "adelie_amd: glm must be adelie_amd.glm.gaussian / binomial; Python-subclassed GLMs cannot run on device."
+        )
+    (max_screen_size, max_active_size, lmda_path_size, setup_lmda_max, setup_lmda_path, lmda_max, lmda_path) = \
+        _render_inputs(groups=groups, lmda_max=lmda_max, lmda_path=lmda_path, lmda_path_size=lmda_path_size,
+                       max_screen_size=max_screen_size, max_active_size=max_active_size, dtype=dtype)
+    setup_loss_null = loss_null is None  # state.py:2401-2403
+    if setup_loss_null:
+        loss_null = np.inf
+    s = glm_naive_base()
+    s.dtype = dtype
+    s._X = X
+    s.X = X
+    s._glm = glm
+    s._offsets = np.array(offsets, copy=True, dtype=dtype)
+    s.offsets = s._offsets
+    s.constraints = constraints
+    s.groups = np.array(groups, copy=True, dtype=int)
+    s.group_sizes = np.array(group_sizes, copy=True, dtype=int)
+    s.alpha = alpha
+    s.penalty = np.array(penalty, copy=True, dtype=dtype)
+    s.lmda_path = np.asarray(lmda_path, dtype=dtype)
+    s.lmda_max = lmda_max
+    s.min_ratio = min_ratio
+    s.lmda_path_size = lmda_path_size
+    s.max_screen_size = max_screen_size
+    s.max_active_size = max_active_size
+    s.pivot_subset_ratio = pivot_subset_ratio
+    s.pivot_subset_min = pivot_subset_min
+    s.pivot_slack_ratio = pivot_slack_ratio
+    s.screen_rule = screen_rule
+    s.irls_max_iters = irls_max_iters
+    s.irls_tol = irls_tol
+    s.max_iters = max_iters
+    s.tol = tol
+    s.adev_tol = adev_tol
+    s.ddev_tol = ddev_tol
+    s.newton_tol = newton_tol
+    s.newton_max_iters = newton_max_iters
+    s.early_exit = early_exit
+    s.setup_lmda_max = setup_lmda_max
+    s.setup_lmda_path = setup_lmda_path
+    s.setup_loss_null = setup_loss_null
+    s.intercept = intercept
+    s.n_threads = n_threads
+    s.screen_set = np.asarray(screen_set, dtype=int)
+    s.screen_beta = np.asarray(screen_beta, dtype=dtype)
+    s.screen_is_active = np.asarray(screen_is_active, dtype=bool)
+    s.active_set_size = active_set_size
+    s.active_set = np.asarray(active_set, dtype=int)
+    s.beta0 = beta0
+    s.lmda = lmda
+    s.grad = np.asarray(grad, dtype=dtype)
+    s.eta = np.asarray(eta, dtype=dtype)
+    s.resid = np.asarray(resid, dtype=dtype)
+    s.loss_null = loss_null
+    s.loss_full = loss_full
+    s.error = ""
+    s._check_shapes()
+    n = X.rows()
+    if len(s._offsets) != n:
+        raise RuntimeError("adelie_core: offsets must be (n,) where X is (n, p).")
+    if len(s.eta) != n:
+        raise RuntimeError("adelie_core: eta must be (n,) where X is (n, p).")
+    if irls_tol <= 0:
+        raise RuntimeError("adelie_core: irls_tol must be > 0.")
+    return s

@@ -1,0 +1,239 @@
+/*
+ * adelie_hip.h — C ABI of libadelie_hip.so: the MI355X-native replacement for the
+ * grpnet hot path of JamesYang007/adelie.
+ *
+ * The reference has no C ABI: its boundary is the pybind11 module `adelie.adelie_core`
+ * (reference adelie/src/py_adelie_core.cpp:6-44).  Every entry point below names the
+ * pybind class / method it stands in for (file:line relative to /root/reference).
+ * Plain pointers and sizes only; no torch / Eigen / numpy types cross this boundary.
+ *
+ * Conventions
+ *   - dtype: ADELIE_HIP_F32 / ADELIE_HIP_F64 is a property of the design matrix; every
+ *     `const void*` / `void*` value array is in that dtype (value_t of the reference).
+ *     Scalars cross as double.  Indices are int64 (Eigen::Index, state_base.hpp:33).
+ *   - All array arguments are HOST pointers unless the name ends in `_dev`.
+ *   - Return value 0 = ok; nonzero = construction / argument error, message via
+ *     adelie_hip_last_error() (the reference throws adelie_core_error -> RuntimeError,
+ *     state_base.ipp:15-92).  Errors raised INSIDE a solve do not fail the call: they are
+ *     recorded in the result's error string and the partial path is returned, exactly as
+ *     py_state.cpp:62-91 (`_solve`) does.
+ */
+#ifndef ADELIE_HIP_H
+#define ADELIE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADELIE_HIP_ABI_VERSION 1
+
+enum adelie_hip_dtype { ADELIE_HIP_F32 = 0, ADELIE_HIP_F64 = 1 };
+enum adelie_hip_order { ADELIE_HIP_COL_MAJOR = 0, ADELIE_HIP_ROW_MAJOR = 1 };
+enum adelie_hip_screen_rule { ADELIE_HIP_SCREEN_STRONG = 0, ADELIE_HIP_SCREEN_PIVOT = 1 };
+/* glm_kind: which GlmBase implementation runs on device (glm_gaussian.ipp, glm_binomial.ipp) */
+enum adelie_hip_glm_kind {
+    ADELIE_HIP_GLM_GAUSSIAN = 0,        /* glm.gaussian(opt=True): StateGaussianNaive, no IRLS (solver.py:683-686) */
+    ADELIE_HIP_GLM_BINOMIAL_LOGIT = 1,  /* glm.binomial(link="logit"): StateGlmNaive + IRLS */
+    ADELIE_HIP_GLM_GAUSSIAN_IRLS = 2    /* glm.gaussian(opt=False): Gaussian loss forced through StateGlmNaive */
+};
+
+/* Opaque handles. */
+typedef struct adelie_hip_design adelie_hip_design; /* device-resident MatrixNaiveBase object */
+typedef struct adelie_hip_result adelie_hip_result; /* solved state snapshot (the `state` copy _solve returns) */
+
+/* ------------------------------------------------------------------------------------------
+ * Library
+ * ------------------------------------------------------------------------------------------ */
+int         adelie_hip_abi_version(void);
+/* Thread-local message of the last failing call on this thread. */
+const char* adelie_hip_last_error(void);
+/* Number of visible HIP devices (0 if none / runtime unavailable). */
+int         adelie_hip_device_count(void);
+/* Mirrors adelie.configs.set_configs (py_configs.cpp:6-49): names "hessian_min", "dbeta_tol". */
+int         adelie_hip_set_config(const char* name, double value);
+
+/* ------------------------------------------------------------------------------------------
+ * Design matrix  == adelie.matrix.dense / MatrixNaiveDense{32,64}{C,F}
+ *                   (matrix.py:549-680, matrix_naive_dense.ipp:9-21)
+ * The reference holds a non-owning Eigen::Map of the caller's ndarray; here the matrix is
+ * copied once into HBM (or adopted in place when it already lives there) and stays resident.
+ * ------------------------------------------------------------------------------------------ */
+/* Copy an (n,p) host matrix to device `device`. */
+int adelie_hip_design_create_dense(const void* host, int64_t n, int64_t p, int dtype, int order,
+                                   int device, adelie_hip_design** out);
+/* Adopt an (n,p) matrix that is ALREADY in device memory (e.g. a torch tensor's data_ptr);
+ * not owned, must outlive the design. */
+int adelie_hip_design_adopt_dense_dev(const void* dev_ptr, int64_t n, int64_t p, int dtype, int order,
+                                      int device, adelie_hip_design** out);
+/* == adelie.matrix.snp_unphased over an adelie.io.snp_unphased file image
+ * (matrix.py:1245-1298, io_snp_unphased.ipp:10-41): `snpdat` is the whole .snpdat byte image;
+ * it is decoded once into a dense 2-bit-per-call column-major device layout. */
+int adelie_hip_design_create_snp_unphased(const void* snpdat, int64_t n_bytes, int dtype,
+                                          int device, adelie_hip_design** out);
+/* Same, from an int8 calldata matrix (n,p) column-major (values 0/1/2, negative = missing)
+ * and per-column impute values (io_snp_unphased.ipp:70-303 semantics, without the file). */
+int adelie_hip_design_create_snp_calldata(const int8_t* calldata, int64_t n, int64_t p,
+                                          const double* impute, int dtype, int device,
+                                          adelie_hip_design** out);
+int adelie_hip_design_destroy(adelie_hip_design* d);
+
+int64_t adelie_hip_design_rows(const adelie_hip_design* d);   /* MatrixNaiveBase::rows */
+int64_t adelie_hip_design_cols(const adelie_hip_design* d);   /* MatrixNaiveBase::cols */
+int     adelie_hip_design_dtype(const adelie_hip_design* d);
+int     adelie_hip_design_device(const adelie_hip_design* d);
+/* Raw device pointer / HIP stream of the design (for callers that keep vectors on device). */
+void*   adelie_hip_design_stream(const adelie_hip_design* d);
+
+/* The MatrixNaiveBase virtuals (matrix_naive_base.hpp:18-144), host vectors in/out.
+ * Semantics follow matrix_naive_dense.ipp line by line:                                   */
+/* cmul  (:23-34):  *out = X[:,j] . (v * weights) */
+int adelie_hip_design_cmul(adelie_hip_design* d, int64_t j, const void* v, const void* weights, double* out);
+/* ctmul (:49-59):  out += v * X[:,j] */
+int adelie_hip_design_ctmul(adelie_hip_design* d, int64_t j, double v, void* out);
+/* bmul  (:61-80):  out = (v * weights)^T X[:, j:j+q] */
+int adelie_hip_design_bmul(adelie_hip_design* d, int64_t j, int64_t q, const void* v, const void* weights, void* out);
+/* btmul (:106-123): out += v^T X[:, j:j+q]^T */
+int adelie_hip_design_btmul(adelie_hip_design* d, int64_t j, int64_t q, const void* v, void* out);
+/* mul   (:125-146): out = (v * weights)^T X */
+int adelie_hip_design_mul(adelie_hip_design* d, const void* v, const void* weights, void* out);
+/* cov   (:162-197): out = X[:, j:j+q]^T diag(sqrt_weights^2) X[:, j:j+q], (q,q) column-major */
+int adelie_hip_design_cov(adelie_hip_design* d, int64_t j, int64_t q, const void* sqrt_weights, void* out);
+/* sq_mul (:199-217): out = weights^T X^2 */
+int adelie_hip_design_sq_mul(adelie_hip_design* d, const void* weights, void* out);
+/* sp_tmul (:219-256): out = V X^T with V an (L,p) CSR matrix, out (L,n) row-major */
+int adelie_hip_design_sp_tmul(adelie_hip_design* d, int64_t L, const int64_t* indptr, const int64_t* indices,
+                              const void* values, void* out);
+
+/* ------------------------------------------------------------------------------------------
+ * grpnet path solver
+ *   == StateGaussianNaive{32,64}(...).solve(pb, exit_cond)   py_state.cpp:1068-1226
+ *   == StateGlmNaive{32,64}(...).solve(glm, pb, exit_cond)   py_state.cpp:1556-1720
+ * The struct carries exactly the constructor keyword arguments (py_state.cpp:1068-1154,
+ * state_glm_naive.hpp:90-135); the Python sentinels are resolved by the caller the same way
+ * adelie/state.py:1007-1045 resolves them (setup_lmda_max / setup_lmda_path / setup_loss_null).
+ * ------------------------------------------------------------------------------------------ */
+/* Polled once per saved lambda (the reference's exit_cond granularity, solver_base.hpp:581,679)
+ * with `final`=1, and once per coordinate-descent fit with `final`=0 (the reference polls
+ * PyErr_CheckSignals per CD sweep, py_state.cpp:70-74).  Return nonzero to stop:
+ *   final=1 -> behaves as exit_cond() == True;  final=0 -> raises "interrupted" into error. */
+typedef int (*adelie_hip_poll_fn)(void* user, int final, int64_t n_solutions);
+
+typedef struct adelie_hip_grpnet_args {
+    /* ---- problem (static) ---- */
+    int64_t        G;                 /* number of groups */
+    const int64_t* groups;            /* (G,) start column of each group */
+    const int64_t* group_sizes;       /* (G,) */
+    double         alpha;
+    const void*    penalty;           /* (G,) value_t */
+    /* Gaussian (glm_kind == GAUSSIAN, the `opt` path of solver.py:683-686) */
+    const void*    weights;           /* (n,) value_t, sums to 1 */
+    const void*    X_means;           /* (p,) value_t */
+    double         y_mean;
+    double         y_var;
+    double         resid_sum;
+    double         rsq;
+    /* GLM (glm_kind != GAUSSIAN): the GlmBase object is rebuilt on device from (y, weights) */
+    int32_t        glm_kind;
+    int32_t        _pad0;
+    const void*    glm_y;             /* (n,) value_t */
+    const void*    glm_weights;       /* (n,) value_t */
+    const void*    offsets;           /* (n,) value_t */
+    const void*    eta;               /* (n,) value_t */
+    double         beta0;
+    double         loss_null;         /* ignored if setup_loss_null */
+    double         loss_full;
+    int64_t        irls_max_iters;
+    double         irls_tol;
+    int32_t        setup_loss_null;
+    int32_t        _pad1;
+    /* shared dynamic inputs */
+    const void*    resid;             /* (n,) value_t */
+    const void*    grad;              /* (p,) value_t */
+    /* ---- lambda path ---- */
+    const void*    lmda_path;         /* (n_lmda_path,) value_t, may be NULL when setup_lmda_path */
+    int64_t        n_lmda_path;
+    double         lmda_max;          /* ignored if setup_lmda_max */
+    double         min_ratio;
+    int64_t        lmda_path_size;
+    /* ---- configuration ---- */
+    int64_t        max_screen_size;
+    int64_t        max_active_size;
+    double         pivot_subset_ratio;
+    int64_t        pivot_subset_min;
+    double         pivot_slack_ratio;
+    int32_t        screen_rule;       /* adelie_hip_screen_rule */
+    int32_t        early_exit;
+    int64_t        max_iters;
+    double         tol;
+    double         adev_tol;
+    double         ddev_tol;
+    double         newton_tol;
+    int64_t        newton_max_iters;
+    int32_t        setup_lmda_max;
+    int32_t        setup_lmda_path;
+    int32_t        intercept;
+    int32_t        n_threads;         /* accepted for API parity; host-side only */
+    /* ---- warm-start invariants ---- */
+    int64_t        screen_set_size;
+    const int64_t* screen_set;        /* (s,) */
+    int64_t        screen_beta_size;
+    const void*    screen_beta;       /* (bs,) value_t */
+    const int8_t*  screen_is_active;  /* (s,) */
+    int64_t        active_set_size;
+    const int64_t* active_set;        /* (G,) first active_set_size entries valid */
+    double         lmda;              /* +inf for a cold start (solver.py:857) */
+    /* ---- callbacks ---- */
+    adelie_hip_poll_fn poll;          /* may be NULL */
+    void*          poll_user;
+} adelie_hip_grpnet_args;
+
+/* Runs the whole path.  `*out` is always set on return code 0 (even when the solve recorded
+ * an error string): the caller owns it and frees it with adelie_hip_result_destroy. */
+int adelie_hip_grpnet_solve(adelie_hip_design* X, const adelie_hip_grpnet_args* args, adelie_hip_result** out);
+int adelie_hip_result_destroy(adelie_hip_result* r);
+
+/* ---- result accessors: the read-only properties of py_state.cpp:763-1040,1156-1217 ---- */
+enum adelie_hip_vec {
+    /* value vectors (copied out as double) */
+    ADELIE_HIP_V_INTERCEPTS = 0, ADELIE_HIP_V_DEVS, ADELIE_HIP_V_LMDAS, ADELIE_HIP_V_LMDA_PATH,
+    ADELIE_HIP_V_SCREEN_BETA, ADELIE_HIP_V_GRAD, ADELIE_HIP_V_ABS_GRAD, ADELIE_HIP_V_RESID,
+    ADELIE_HIP_V_ETA, ADELIE_HIP_V_SCREEN_X_MEANS, ADELIE_HIP_V_SCREEN_VARS,
+    ADELIE_HIP_V_SCREEN_TRANSFORMS, /* concatenated column-major (q,q) blocks in screen order */
+    ADELIE_HIP_V_BENCHMARK_SCREEN, ADELIE_HIP_V_BENCHMARK_FIT_SCREEN, ADELIE_HIP_V_BENCHMARK_FIT_ACTIVE,
+    ADELIE_HIP_V_BENCHMARK_KKT, ADELIE_HIP_V_BENCHMARK_INVARIANCE,
+    /* index vectors (copied out as int64) */
+    ADELIE_HIP_I_SCREEN_SET = 100, ADELIE_HIP_I_SCREEN_BEGINS, ADELIE_HIP_I_SCREEN_IS_ACTIVE,
+    ADELIE_HIP_I_ACTIVE_SET, ADELIE_HIP_I_N_VALID_SOLUTIONS, ADELIE_HIP_I_ACTIVE_SIZES,
+    ADELIE_HIP_I_SCREEN_SIZES, ADELIE_HIP_I_BETAS_INDPTR, ADELIE_HIP_I_BETAS_INDICES,
+    /* betas values (double), CSR (L, p) like convert_sparse_to_dense's input, py_state.cpp:9-60 */
+    ADELIE_HIP_V_BETAS_VALUES = 200
+};
+enum adelie_hip_scalar {
+    ADELIE_HIP_S_LMDA_MAX = 0, ADELIE_HIP_S_LMDA, ADELIE_HIP_S_RSQ, ADELIE_HIP_S_RESID_SUM,
+    ADELIE_HIP_S_ACTIVE_SET_SIZE, ADELIE_HIP_S_BETA0, ADELIE_HIP_S_LOSS_NULL, ADELIE_HIP_S_LOSS_FULL,
+    ADELIE_HIP_S_TOTAL_TIME,
+    /* instrumentation used by bench.py for the algorithmic-byte count */
+    ADELIE_HIP_S_N_BASIL_ITERS = 50, ADELIE_HIP_S_N_SWEEPS, ADELIE_HIP_S_N_CD_VISITS_SCREEN,
+    ADELIE_HIP_S_N_CD_VISITS_ACTIVE, ADELIE_HIP_S_N_UPDATES, ADELIE_HIP_S_N_IRLS_ITERS,
+    ADELIE_HIP_S_N_NEW_SCREEN_COLS, ADELIE_HIP_S_N_CD_PASSES_SCREEN, ADELIE_HIP_S_N_CD_PASSES_ACTIVE,
+    ADELIE_HIP_S_N_GRAM_COL_READS, ADELIE_HIP_S_N_RESID_COL_READS
+};
+int64_t     adelie_hip_result_size(const adelie_hip_result* r, int which);
+/* Copies min(size, cap) elements: value vectors as double, index vectors as int64. */
+int         adelie_hip_result_copy(const adelie_hip_result* r, int which, void* out, int64_t cap);
+double      adelie_hip_result_scalar(const adelie_hip_result* r, int which);
+const char* adelie_hip_result_error(const adelie_hip_result* r);
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel-level timing hook used by bench.py (HIP events on the design's own stream):
+ * runs `reps` launches of the dominant kernel (the full gradient sweep grad = X^T(w*r) - rs*X_means
+ * with fused per-group abs_grad) on resident buffers and returns the mean milliseconds per launch.
+ * ------------------------------------------------------------------------------------------ */
+int adelie_hip_bench_sweep(adelie_hip_design* d, int64_t reps, double* ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADELIE_HIP_H */

@@ -1,0 +1,416 @@
+// design.hip — C ABI: library info, design-matrix handles and the MatrixNaiveBase operations.
+// (include/adelie_hip.h documents which reference method each entry point replaces.)
+#include "common.hpp"
+
+#include <mutex>
+
+using namespace ahip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+inline int fail(const std::exception& e) {
+    g_last_error = e.what();
+    return 1;
+}
+
+template <class T>
+T* scratch(DevBuf<char>& b, size_t n) {
+    return reinterpret_cast<T*>(b.reserve((n ? n : 1) * sizeof(T)));
+}
+
+void set_device(const adelie_hip_design* d) { AHIP_CHECK(hipSetDevice(d->device)); }
+
+void check_device(int device) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
+        throw make_core_error("no HIP device is visible: adelie_hip has no CPU fallback.");
+    if (device < 0 || device >= cnt) throw make_core_error("device ordinal out of range.");
+    AHIP_CHECK(hipSetDevice(device));
+}
+
+template <class T>
+void create_dense_t(adelie_hip_design* d, const void* src, bool src_on_device, int order) {
+    constexpr int64_t kAlign = 32; // elements: columns start 128/256-byte aligned
+    const int64_t n = d->n, p = d->p;
+    if (src_on_device && order == ADELIE_HIP_COL_MAJOR) {
+        d->X = const_cast<void*>(src);
+        d->ld = n;
+        d->owned = false;
+        return;
+    }
+    const int64_t ld = ((n + kAlign - 1) / kAlign) * kAlign;
+    T* X = nullptr;
+    AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&X), size_t(ld) * size_t(p > 0 ? p : 1) * sizeof(T)));
+    d->X = X;
+    d->ld = ld;
+    d->owned = true;
+    if (order == ADELIE_HIP_COL_MAJOR) {
+        AHIP_CHECK(hipMemcpy2DAsync(X, size_t(ld) * sizeof(T), src, size_t(n) * sizeof(T), size_t(n) * sizeof(T), size_t(p),
+                                    hipMemcpyHostToDevice, d->stream));
+        // zero the padding rows so that vector loads past n never see NaN payloads
+        if (ld > n)
+            AHIP_CHECK(hipMemset2DAsync(X + n, size_t(ld) * sizeof(T), 0, size_t(ld - n) * sizeof(T), size_t(p), d->stream));
+    } else {
+        // row-major source: stage (if on host) and transpose on device
+        const T* rsrc = static_cast<const T*>(src);
+        T* tmp = nullptr;
+        if (!src_on_device) {
+            AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&tmp), size_t(n) * size_t(p) * sizeof(T)));
+            AHIP_CHECK(hipMemcpyAsync(tmp, src, size_t(n) * size_t(p) * sizeof(T), hipMemcpyHostToDevice, d->stream));
+            rsrc = tmp;
+        }
+        AHIP_CHECK(hipMemsetAsync(X, 0, size_t(ld) * size_t(p) * sizeof(T), d->stream));
+        launch_transpose<T>(rsrc, n, p, X, ld, d->stream);
+        AHIP_CHECK(hipStreamSynchronize(d->stream));
+        if (tmp) (void)hipFree(tmp);
+    }
+    AHIP_CHECK(hipStreamSynchronize(d->stream));
+}
+
+adelie_hip_design* new_design(int64_t n, int64_t p, int dtype, int device) {
+    if (n <= 0 || p <= 0) throw make_core_error("matrix must have positive dimensions.");
+    if (dtype != ADELIE_HIP_F32 && dtype != ADELIE_HIP_F64) throw make_core_error("dtype must be F32 or F64.");
+    if (p >= (int64_t(1) << 31)) throw make_core_error("number of columns must fit in int32.");
+    check_device(device);
+    auto* d = new adelie_hip_design();
+    d->dtype = dtype;
+    d->device = device;
+    d->n = n;
+    d->p = p;
+    AHIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    return d;
+}
+
+void create_snp_from_calldata(adelie_hip_design* d, const int8_t* calldata, const double* impute) {
+    const int64_t n = d->n, p = d->p;
+    d->kind = 1;
+    d->ldb = (((n + 3) / 4 + 63) / 64) * 64;
+    AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->bits), size_t(d->ldb) * size_t(p)));
+    int8_t* tmp = nullptr;
+    // stage the calldata in panels of columns to bound the temporary
+    const int64_t panel = std::max<int64_t>(1, (int64_t(1) << 28) / n);
+    AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&tmp), size_t(n) * size_t(std::min(panel, p))));
+    for (int64_t j0 = 0; j0 < p; j0 += panel) {
+        const int64_t pc = std::min(panel, p - j0);
+        AHIP_CHECK(hipMemcpyAsync(tmp, calldata + j0 * n, size_t(n) * size_t(pc), hipMemcpyHostToDevice, d->stream));
+        launch_pack_snp(tmp, n, pc, d->bits + j0 * d->ldb, d->ldb, d->stream);
+        AHIP_CHECK(hipStreamSynchronize(d->stream));
+    }
+    (void)hipFree(tmp);
+    if (d->dtype == ADELIE_HIP_F64) {
+        AHIP_CHECK(hipMalloc(&d->impute, size_t(p) * sizeof(double)));
+        AHIP_CHECK(hipMemcpy(d->impute, impute, size_t(p) * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> f(impute, impute + p);
+        AHIP_CHECK(hipMalloc(&d->impute, size_t(p) * sizeof(float)));
+        AHIP_CHECK(hipMemcpy(d->impute, f.data(), size_t(p) * sizeof(float), hipMemcpyHostToDevice));
+    }
+}
+
+// ---- host-vector matrix operations ----------------------------------------------------------------------
+template <class T>
+void op_sweep(adelie_hip_design* d, int64_t c0, int64_t ncols, const T* v, const T* w, T* out, bool square) {
+    set_device(d);
+    hipStream_t s = d->stream;
+    const int64_t n = d->n;
+    T* dv = scratch<T>(d->s_n1, n);
+    T* dw = scratch<T>(d->s_n2, n);
+    T* dout = scratch<T>(d->s_p1, ncols);
+    T* work = scratch<T>(d->s_work, sweep_work_elems(n, ncols));
+    AHIP_CHECK(hipMemcpyAsync(dv, v, n * sizeof(T), hipMemcpyHostToDevice, s));
+    if (w) {
+        AHIP_CHECK(hipMemcpyAsync(dw, w, n * sizeof(T), hipMemcpyHostToDevice, s));
+        launch_vmul<T>(dv, dw, dv, n, s);
+    }
+    if (d->kind == 0)
+        launch_sweep<T>(d->dense<T>(), dv, dout, c0, ncols, nullptr, nullptr, nullptr, square, work, s);
+    else
+        launch_sweep_snp<T>(d->snp(), static_cast<const T*>(d->impute), dv, dout, c0, ncols, nullptr, nullptr, nullptr,
+                            square, work, s);
+    AHIP_CHECK(hipMemcpyAsync(out, dout, ncols * sizeof(T), hipMemcpyDeviceToHost, s));
+    AHIP_CHECK(hipStreamSynchronize(s));
+}
+
+template <class T>
+void op_axpy(adelie_hip_design* d, int64_t j, int64_t q, const T* coef, T* out) {
+    set_device(d);
+    hipStream_t s = d->stream;
+    const int64_t n = d->n;
+    T* dout = scratch<T>(d->s_n1, n);
+    T* dcoef = scratch<T>(d->s_p1, q);
+    int32_t* dcols = scratch<int32_t>(d->s_idx1, q);
+    std::vector<int32_t> cols(q);
+    for (int64_t k = 0; k < q; ++k) cols[k] = int32_t(j + k);
+    AHIP_CHECK(hipMemcpyAsync(dout, out, n * sizeof(T), hipMemcpyHostToDevice, s));
+    AHIP_CHECK(hipMemcpyAsync(dcoef, coef, q * sizeof(T), hipMemcpyHostToDevice, s));
+    AHIP_CHECK(hipMemcpyAsync(dcols, cols.data(), q * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (d->kind == 0)
+        launch_axpy_cols<T>(d->dense<T>(), dcols, dcoef, nullptr, int32_t(q), T(1), dout, s);
+    else
+        launch_axpy_cols_snp<T>(d->snp(), static_cast<const T*>(d->impute), dcols, dcoef, nullptr, int32_t(q), T(1), dout, s);
+    AHIP_CHECK(hipMemcpyAsync(out, dout, n * sizeof(T), hipMemcpyDeviceToHost, s));
+    AHIP_CHECK(hipStreamSynchronize(s));
+}
+
+template <class T>
+void op_cov(adelie_hip_design* d, int64_t j, int64_t q, const T* sw, T* out) {
+    set_device(d);
+    hipStream_t s = d->stream;
+    const int64_t n = d->n;
+    T* dw = scratch<T>(d->s_n1, n);
+    T* dC = scratch<T>(d->s_p1, q * q);
+    T* work = scratch<T>(d->s_work, gram_work_elems(n, q, q));
+    int32_t* dcols = scratch<int32_t>(d->s_idx1, q);
+    std::vector<int32_t> cols(q);
+    for (int64_t k = 0; k < q; ++k) cols[k] = int32_t(j + k);
+    AHIP_CHECK(hipMemcpyAsync(dw, sw, n * sizeof(T), hipMemcpyHostToDevice, s));
+    launch_vmul<T>(dw, dw, dw, n, s); // weights = sqrt_weights^2
+    AHIP_CHECK(hipMemcpyAsync(dcols, cols.data(), q * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (d->kind == 0)
+        launch_gram<T>(d->dense<T>(), dw, dcols, int32_t(q), 0, dcols, int32_t(q), 0, nullptr, false, dC, q, work, s);
+    else
+        launch_gram_snp<T>(d->snp(), static_cast<const T*>(d->impute), dw, dcols, int32_t(q), 0, dcols, int32_t(q), 0,
+                           nullptr, false, dC, q, work, s);
+    AHIP_CHECK(hipMemcpyAsync(out, dC, q * q * sizeof(T), hipMemcpyDeviceToHost, s));
+    AHIP_CHECK(hipStreamSynchronize(s));
+}
+
+template <class T>
+void op_sp_tmul(adelie_hip_design* d, int64_t L, const int64_t* indptr, const int64_t* indices, const T* values, T* out) {
+    set_device(d);
+    hipStream_t s = d->stream;
+    const int64_t n = d->n;
+    const int64_t nnz = indptr[L];
+    int64_t* dptr = scratch<int64_t>(d->s_idx1, L + 1);
+    int64_t* dind = scratch<int64_t>(d->s_idx2, nnz);
+    T* dval = scratch<T>(d->s_p1, nnz);
+    AHIP_CHECK(hipMemcpyAsync(dptr, indptr, (L + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    if (nnz) {
+        AHIP_CHECK(hipMemcpyAsync(dind, indices, nnz * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        AHIP_CHECK(hipMemcpyAsync(dval, values, nnz * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    // bound the device output panel to ~1 GiB
+    const int64_t Lp = std::max<int64_t>(1, (int64_t(1) << 30) / int64_t(n * sizeof(T)));
+    T* dout = scratch<T>(d->s_misc, size_t(std::min(Lp, L)) * n);
+    for (int64_t l0 = 0; l0 < L; l0 += Lp) {
+        const int64_t lc = std::min(Lp, L - l0);
+        if (d->kind == 0) launch_sp_tmul<T>(d->dense<T>(), lc, dptr + l0, dind, dval, dout, s);
+        else launch_sp_tmul_snp<T>(d->snp(), static_cast<const T*>(d->impute), lc, dptr + l0, dind, dval, dout, s);
+        AHIP_CHECK(hipMemcpyAsync(out + l0 * n, dout, size_t(lc) * n * sizeof(T), hipMemcpyDeviceToHost, s));
+        AHIP_CHECK(hipStreamSynchronize(s));
+    }
+}
+
+void check_col(const adelie_hip_design* d, int64_t j, int64_t q, const char* what) {
+    if (j < 0 || q < 0 || j + q > d->p) throw make_core_error(std::string(what) + "() is given inconsistent inputs!");
+}
+
+// .snpdat decoder (io_snp_unphased.ipp:10-68; layout in adelie_amd/io.py)
+template <class U>
+U read_as(const uint8_t* p) {
+    U v;
+    std::memcpy(&v, p, sizeof(U));
+    return v;
+}
+
+} // namespace
+
+#define ABI_TRY try {
+#define ABI_CATCH                      \
+    }                                  \
+    catch (const std::exception& e) {  \
+        return fail(e);                \
+    }                                  \
+    return 0;
+
+#define DTYPE_DISPATCH(d, call64, call32)               \
+    if ((d)->dtype == ADELIE_HIP_F64) { using T = double; (void)sizeof(T); call64; } \
+    else { using T = float; (void)sizeof(T); call32; }
+
+extern "C" {
+
+int adelie_hip_abi_version(void) { return ADELIE_HIP_ABI_VERSION; }
+const char* adelie_hip_last_error(void) { return g_last_error.c_str(); }
+int adelie_hip_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+int adelie_hip_design_create_dense(const void* host, int64_t n, int64_t p, int dtype, int order, int device,
+                                   adelie_hip_design** out) {
+    ABI_TRY
+    if (!host || !out) throw make_core_error("null argument.");
+    adelie_hip_design* d = new_design(n, p, dtype, device);
+    try {
+        if (dtype == ADELIE_HIP_F64) create_dense_t<double>(d, host, false, order);
+        else create_dense_t<float>(d, host, false, order);
+    } catch (...) {
+        adelie_hip_design_destroy(d);
+        throw;
+    }
+    *out = d;
+    ABI_CATCH
+}
+
+int adelie_hip_design_adopt_dense_dev(const void* dev_ptr, int64_t n, int64_t p, int dtype, int order, int device,
+                                      adelie_hip_design** out) {
+    ABI_TRY
+    if (!dev_ptr || !out) throw make_core_error("null argument.");
+    adelie_hip_design* d = new_design(n, p, dtype, device);
+    try {
+        if (dtype == ADELIE_HIP_F64) create_dense_t<double>(d, dev_ptr, true, order);
+        else create_dense_t<float>(d, dev_ptr, true, order);
+    } catch (...) {
+        adelie_hip_design_destroy(d);
+        throw;
+    }
+    *out = d;
+    ABI_CATCH
+}
+
+int adelie_hip_design_create_snp_calldata(const int8_t* calldata, int64_t n, int64_t p, const double* impute, int dtype,
+                                          int device, adelie_hip_design** out) {
+    ABI_TRY
+    if (!calldata || !impute || !out) throw make_core_error("null argument.");
+    adelie_hip_design* d = new_design(n, p, dtype, device);
+    try {
+        create_snp_from_calldata(d, calldata, impute);
+    } catch (...) {
+        adelie_hip_design_destroy(d);
+        throw;
+    }
+    *out = d;
+    ABI_CATCH
+}
+
+int adelie_hip_design_create_snp_unphased(const void* snpdat, int64_t n_bytes, int dtype, int device,
+                                          adelie_hip_design** out) {
+    ABI_TRY
+    if (!snpdat || !out) throw make_core_error("null argument.");
+    const uint8_t* buf = static_cast<const uint8_t*>(snpdat);
+    if (n_bytes < 17) throw make_core_error("buffer is too small to be a .snpdat image.");
+    const uint64_t n = read_as<uint64_t>(buf + 1), p = read_as<uint64_t>(buf + 9);
+    const size_t hdr = 17 + 8 * p * 3 + 8 * (p + 1);
+    if (size_t(n_bytes) < hdr) throw make_core_error("truncated .snpdat header.");
+    const uint8_t* impute_p = buf + 17 + 16 * p;
+    const uint8_t* outer_p = buf + 17 + 24 * p;
+    std::vector<double> impute(p);
+    std::memcpy(impute.data(), impute_p, 8 * p);
+    // decode to int8 calldata (missing = -9), then pack on device
+    std::vector<int8_t> calldata(size_t(n) * size_t(p), 0);
+    for (uint64_t j = 0; j < p; ++j) {
+        const uint64_t base = read_as<uint64_t>(outer_p + 8 * j), endc = read_as<uint64_t>(outer_p + 8 * (j + 1));
+        if (endc > uint64_t(n_bytes) || base + 24 > endc) throw make_core_error("corrupt .snpdat column index.");
+        int8_t* col = calldata.data() + size_t(j) * size_t(n);
+        for (int c = 0; c < 3; ++c) {
+            uint64_t pos = base + read_as<uint64_t>(buf + base + 8 * c);
+            const uint32_t n_chunks = read_as<uint32_t>(buf + pos);
+            pos += 4;
+            const int8_t val = c == 0 ? int8_t(-9) : int8_t(c);
+            for (uint32_t k = 0; k < n_chunks; ++k) {
+                const uint32_t cidx = read_as<uint32_t>(buf + pos);
+                const uint32_t cnt = uint32_t(buf[pos + 4]) + 1;
+                pos += 5;
+                for (uint32_t t = 0; t < cnt; ++t) {
+                    const uint64_t row = uint64_t(cidx) * 256 + buf[pos + t];
+                    if (row >= n) throw make_core_error("corrupt .snpdat chunk (row out of range).");
+                    col[row] = val;
+                }
+                pos += cnt;
+                if (pos > endc) throw make_core_error("corrupt .snpdat chunk (overrun).");
+            }
+        }
+    }
+    adelie_hip_design* d = new_design(int64_t(n), int64_t(p), dtype, device);
+    try {
+        create_snp_from_calldata(d, calldata.data(), impute.data());
+    } catch (...) {
+        adelie_hip_design_destroy(d);
+        throw;
+    }
+    *out = d;
+    ABI_CATCH
+}
+
+int adelie_hip_design_destroy(adelie_hip_design* d) {
+    if (!d) return 0;
+    (void)hipSetDevice(d->device);
+    if (d->stream) {
+        (void)hipStreamSynchronize(d->stream);
+        (void)hipStreamDestroy(d->stream);
+    }
+    if (d->owned && d->X) (void)hipFree(d->X);
+    if (d->bits) (void)hipFree(d->bits);
+    if (d->impute) (void)hipFree(d->impute);
+    delete d;
+    return 0;
+}
+
+int64_t adelie_hip_design_rows(const adelie_hip_design* d) { return d->n; }
+int64_t adelie_hip_design_cols(const adelie_hip_design* d) { return d->p; }
+int adelie_hip_design_dtype(const adelie_hip_design* d) { return d->dtype; }
+int adelie_hip_design_device(const adelie_hip_design* d) { return d->device; }
+void* adelie_hip_design_stream(const adelie_hip_design* d) { return d->stream; }
+
+int adelie_hip_design_cmul(adelie_hip_design* d, int64_t j, const void* v, const void* weights, double* out) {
+    ABI_TRY
+    check_col(d, j, 1, "cmul");
+    DTYPE_DISPATCH(d, { T o; op_sweep<T>(d, j, 1, (const T*)v, (const T*)weights, &o, false); *out = o; },
+                   { T o; op_sweep<T>(d, j, 1, (const T*)v, (const T*)weights, &o, false); *out = o; })
+    ABI_CATCH
+}
+int adelie_hip_design_ctmul(adelie_hip_design* d, int64_t j, double v, void* out) {
+    ABI_TRY
+    check_col(d, j, 1, "ctmul");
+    DTYPE_DISPATCH(d, { T c = T(v); op_axpy<T>(d, j, 1, &c, (T*)out); }, { T c = T(v); op_axpy<T>(d, j, 1, &c, (T*)out); })
+    ABI_CATCH
+}
+int adelie_hip_design_bmul(adelie_hip_design* d, int64_t j, int64_t q, const void* v, const void* weights, void* out) {
+    ABI_TRY
+    check_col(d, j, q, "bmul");
+    DTYPE_DISPATCH(d, op_sweep<T>(d, j, q, (const T*)v, (const T*)weights, (T*)out, false),
+                   op_sweep<T>(d, j, q, (const T*)v, (const T*)weights, (T*)out, false))
+    ABI_CATCH
+}
+int adelie_hip_design_btmul(adelie_hip_design* d, int64_t j, int64_t q, const void* v, void* out) {
+    ABI_TRY
+    check_col(d, j, q, "btmul");
+    DTYPE_DISPATCH(d, op_axpy<T>(d, j, q, (const T*)v, (T*)out), op_axpy<T>(d, j, q, (const T*)v, (T*)out))
+    ABI_CATCH
+}
+int adelie_hip_design_mul(adelie_hip_design* d, const void* v, const void* weights, void* out) {
+    ABI_TRY
+    DTYPE_DISPATCH(d, op_sweep<T>(d, 0, d->p, (const T*)v, (const T*)weights, (T*)out, false),
+                   op_sweep<T>(d, 0, d->p, (const T*)v, (const T*)weights, (T*)out, false))
+    ABI_CATCH
+}
+int adelie_hip_design_cov(adelie_hip_design* d, int64_t j, int64_t q, const void* sqrt_weights, void* out) {
+    ABI_TRY
+    check_col(d, j, q, "cov");
+    DTYPE_DISPATCH(d, op_cov<T>(d, j, q, (const T*)sqrt_weights, (T*)out), op_cov<T>(d, j, q, (const T*)sqrt_weights, (T*)out))
+    ABI_CATCH
+}
+int adelie_hip_design_sq_mul(adelie_hip_design* d, const void* weights, void* out) {
+    ABI_TRY
+    DTYPE_DISPATCH(d, op_sweep<T>(d, 0, d->p, (const T*)weights, (const T*)nullptr, (T*)out, true),
+                   op_sweep<T>(d, 0, d->p, (const T*)weights, (const T*)nullptr, (T*)out, true))
+    ABI_CATCH
+}
+int adelie_hip_design_sp_tmul(adelie_hip_design* d, int64_t L, const int64_t* indptr, const int64_t* indices,
+                              const void* values, void* out) {
+    ABI_TRY
+    if (L < 0) throw make_core_error("sp_tmul() is given inconsistent inputs!");
+    if (L == 0) return 0;
+    DTYPE_DISPATCH(d, op_sp_tmul<T>(d, L, indptr, indices, (const T*)values, (T*)out),
+                   op_sp_tmul<T>(d, L, indptr, indices, (const T*)values, (T*)out))
+    ABI_CATCH
+}
+
+} // extern "C"
+
+namespace ahip {
+void set_last_error(const std::string& s) { g_last_error = s; }
+} // namespace ahip

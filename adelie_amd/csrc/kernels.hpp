@@ -1,0 +1,136 @@
+// kernels.hpp — launch interface of the gfx950 kernels (implemented in kernels_*.hip).
+// Everything here works on DEVICE pointers and enqueues on the given HIP stream; no host sync.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace ahip {
+
+// Dense column-major design in HBM: element (i,j) at X[i + j*ld].
+template <class T>
+struct DenseView {
+    const T* X;
+    int64_t n, p, ld;
+};
+// SNP design: 2-bit calls, column-major, 4 calls per byte (row i of column j in byte (i>>2) of
+// the column, bits 2*(i&3)); code 0 -> 0, 1 -> 1, 2 -> 2, 3 -> missing (impute[j]).
+struct SnpView {
+    const uint8_t* bits;
+    int64_t n, p, ldb; // ldb = bytes per column (padded)
+};
+
+// ---- vector helpers -------------------------------------------------------------------------
+// out[i] = a[i] * b[i]
+template <class T> void launch_vmul(const T* a, const T* b, T* out, int64_t n, hipStream_t s);
+template <class T> void launch_fill(T* out, T value, int64_t n, hipStream_t s);
+
+// ---- sweep: out[c] = sum_i X[i, col(c)] * v[i]  (col(c) = cols ? cols[c] : c0 + c) --------------
+// epilogue: out[c] -= sub_scale[0] * sub_vec[col(c)] when sub_vec != nullptr (sub_scale is a DEVICE scalar)
+// square: use X^2 instead of X (sq_mul).  `work` must hold sweep_work_elems(n, ncols) elements.
+template <class T>
+void launch_sweep(const DenseView<T>& X, const T* v, T* out, int64_t c0, int64_t ncols, const int32_t* cols,
+                  const T* sub_scale, const T* sub_vec, bool square, T* work, hipStream_t s);
+template <class T>
+void launch_sweep_snp(const SnpView& X, const T* impute, const T* v, T* out, int64_t c0, int64_t ncols,
+                      const int32_t* cols, const T* sub_scale, const T* sub_vec, bool square, T* work, hipStream_t s);
+int64_t sweep_work_elems(int64_t n, int64_t ncols);
+
+// ---- panel axpy: out[i] += sign * sum_k coef[k] * X[i, cols[k]],  k < *count_dev (or count if count_dev null)
+template <class T>
+void launch_axpy_cols(const DenseView<T>& X, const int32_t* cols, const T* coef, const int32_t* count_dev,
+                      int32_t count, T sign, T* out, hipStream_t s);
+template <class T>
+void launch_axpy_cols_snp(const SnpView& X, const T* impute, const int32_t* cols, const T* coef,
+                          const int32_t* count_dev, int32_t count, T sign, T* out, hipStream_t s);
+// batched variant for sp_tmul: out (L,n) row-major, CSR (indptr,indices,values) on device
+template <class T>
+void launch_sp_tmul(const DenseView<T>& X, int64_t L, const int64_t* indptr, const int64_t* indices, const T* values,
+                    T* out, hipStream_t s);
+template <class T>
+void launch_sp_tmul_snp(const SnpView& X, const T* impute, int64_t L, const int64_t* indptr, const int64_t* indices,
+                        const T* values, T* out, hipStream_t s);
+
+// ---- Gram (MFMA): for a in [0,M), b in [0,N):
+//   C[rowpos[a] + colpos[b]*ldc] = C[colpos[b] + rowpos[a]*ldc]
+//        = sum_i w[i] X[i,mcols[a]] X[i,ncols[b]]  - (center ? xm[mcols[a]]*xm[ncols[b]] : 0)
+// where rowpos[a] = m_pos0 + a, colpos[b] = n_pos0 + b.  `work` holds gram_work_elems(...) elements.
+template <class T>
+void launch_gram(const DenseView<T>& X, const T* w, const int32_t* mcols, int32_t M, int32_t m_pos0,
+                 const int32_t* ncols, int32_t N, int32_t n_pos0, const T* xm_by_col, bool center, T* C, int64_t ldc,
+                 T* work, hipStream_t s);
+template <class T>
+void launch_gram_snp(const SnpView& X, const T* impute, const T* w, const int32_t* mcols, int32_t M, int32_t m_pos0,
+                     const int32_t* ncols, int32_t N, int32_t n_pos0, const T* xm_by_col, bool center, T* C,
+                     int64_t ldc, T* work, hipStream_t s);
+int64_t gram_work_elems(int64_t n, int64_t M, int64_t N);
+
+// ---- abs_grad (solver_base.hpp:20-110) --------------------------------------------------------
+// abs_grad[g] = || grad[groups[g] : +gs] - regul_g * beta_slot ||,  regul_g = (1-alpha)*lmda*penalty[g] for screen
+// groups (slot[g] >= 0 gives the value offset into screen_beta), plain norm otherwise.
+template <class T>
+void launch_abs_grad(const T* grad, const int64_t* groups, const int64_t* group_sizes, int64_t G, const int32_t* slot,
+                     const T* screen_beta, const T* penalty, T one_minus_alpha_lmda, T* abs_grad, hipStream_t s);
+
+// ---- coordinate descent (pin solver) ----------------------------------------------------------
+enum CdStatus : int32_t { CD_OK = 0, CD_MAX_CDS = 1, CD_MAX_ACTIVE = 2, CD_NEWTON = 3 };
+
+template <class T>
+struct CdScalars { // one instance in device memory, read back by the host after the kernel
+    T rsq;
+    T resid_sum;
+    int64_t iters;
+    int64_t n_visits_screen, n_visits_active, n_updates, n_passes_screen, n_passes_active;
+    int32_t active_size;
+    int32_t status;
+    int32_t n_delta; // number of (col, delta) entries produced for the residual update
+    int32_t _pad;
+};
+
+template <class T>
+struct CdParams {
+    int32_t nv, ns;          // screen values / screen groups
+    const int32_t* sbegin;   // [ns]
+    const int32_t* ssize;    // [ns]
+    const T* spen;           // [ns] penalty per screen group
+    const T* C;              // centred Gram, screen-value order
+    int64_t ldc;
+    const T* vars;           // [nv]
+    const T* xmean;          // [nv]
+    const T* V;              // concatenated (q,q) col-major eigenvector blocks
+    const int64_t* voff;     // [ns]
+    T* beta;                 // [nv] in/out
+    T* g;                    // [nv] in/out: gradient x_a^T W r - xmean_a * resid_sum at the current beta
+    int8_t* is_active;       // [ns]
+    int32_t* active_set;     // [>= ns]
+    T lmda, alpha, tol, newton_tol, dbeta_tol;
+    int32_t newton_max_iters, max_active_size, intercept, all_scalar;
+    int64_t max_iters;
+    CdScalars<T>* sc;        // in: rsq, resid_sum, active_size; out: everything
+    // residual-update list produced at exit: delta = beta - beta0 per changed value
+    const T* beta0;          // [nv] snapshot of beta at fit entry
+    const int32_t* vcol;     // [nv] design column of each screen value
+    int32_t* dcols;          // [nv] out
+    T* dvals;                // [nv] out
+    int32_t max_group_size;
+};
+template <class T> void launch_cd(const CdParams<T>& p, hipStream_t s);
+
+// ---- GLM elementwise (solver_glm_naive.hpp:336-348, 439-449; glm_*.ipp) --------------------------
+template <class T>
+struct IrlsScalars {
+    T hess_sum, y_mean, y_var, resid_sum, conv, loss;
+};
+// step 1: hess/irls_resid from (eta, resid); partial sums
+// (implemented in kernels_glm.hip; declared there to keep this header small)
+
+// ---- misc -------------------------------------------------------------------------------------
+// copy a (rows x cols) block between column-major matrices with different leading dimensions
+template <class T> void launch_copy2d(const T* src, int64_t lds, T* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s);
+// vars[pos0 + a] = max(C[(pos0+a)*(ldc+1)], 0) for a < cnt   (gs == 1 groups)
+template <class T> void launch_diag_vars(const T* C, int64_t ldc, int32_t pos0, int32_t cnt, T* vars, hipStream_t s);
+// transpose row-major (n,p) into column-major with leading dimension ld
+template <class T> void launch_transpose(const T* src, int64_t n, int64_t p, T* dst, int64_t ld, hipStream_t s);
+// pack int8 calldata (n,p col-major) into 2-bit codes
+void launch_pack_snp(const int8_t* calldata, int64_t n, int64_t p, uint8_t* bits, int64_t ldb, hipStream_t s);
+
+} // namespace ahip

@@ -1,0 +1,245 @@
+// kernels_gram.hip — weighted Gram panels  C[a,b] = sum_i w_i X[i,ma] X[i,nb]  on the matrix cores (gfx950).
+//
+// Replaces, for the screen set as a whole, what the reference does one group at a time with
+// MatrixNaiveDense::cov (matrix_naive_dense.ipp:162-197) inside update_screen_derived
+// (solver_gaussian_naive.hpp:41-125): the centred weighted Gram  X_S^T W X_S - xbar xbar^T.  Its diagonal
+// blocks are exactly the reference's per-group `XiTXi`; the off-diagonal blocks are what lets the
+// coordinate-descent kernel (kernels_cd.hip) replace every per-visit X.cmul / X.ctmul by O(|S|) work.
+//
+// This is the one true GEMM on the path (K = n = 1e5..5e5, M,N = screen values), so it runs on MFMA:
+//   f64: v_mfma_f64_16x16x4_f64   (A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D col=l&15,row=(l>>4)+4*reg)
+//   f32: v_mfma_f32_16x16x4_f32   (same A/B maps,                         D col=l&15,row=(l>>4)*4+reg)
+// Tiling: a 256-thread block (4 waves, 2x2) owns a 64x64 output tile and one K-split; each wave owns 32x32 =
+// 2x2 MFMA tiles.  Column panels are K-contiguous in HBM (column-major X), so a stage is 64 columns x 32 rows:
+// every thread brings 8 consecutive rows of one column (64 B, coalesced in 256-B runs), the B panel is scaled by
+// w on the way into LDS, and fragments are read back with ds_read_b64 from rows padded to 34 elements (conflict
+// free for the 16x4 fragment shape).  Global loads for stage t+1 are issued before the MFMAs of stage t.
+// K-splits write partial tiles; a second kernel sums them (deterministic), centres, and writes C symmetrically.
+#include "kernels.hpp"
+#include "accessors.hpp"
+
+namespace ahip {
+
+namespace {
+
+constexpr int BM = 64, BN = 64, KT = 32, LDK = KT + 2, GT = 256;
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef float f4v_t __attribute__((ext_vector_type(4)));
+
+template <class T> struct Mfma;
+template <> struct Mfma<double> {
+    using acc_t = d4_t;
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct Mfma<float> {
+    using acc_t = f4v_t;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) * 4 + reg; }
+};
+
+// Loads 8 consecutive rows [k, k+8) of column j (zero beyond kend), optionally scaled by w.
+template <class T, class Acc, bool VECOK>
+__device__ __forceinline__ void load8(const Acc& X, int64_t j, bool valid, int64_t k, int64_t kend, T (&r)[8]) {
+    if (!valid || k >= kend) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = T(0);
+        return;
+    }
+    auto cp = X.colptr(j);
+    constexpr int V = VecOf<T>::N;
+    if (VECOK && k + 8 <= kend) {
+#pragma unroll
+        for (int u = 0; u < 8 / V; ++u) {
+            const Pack<T, V> x = X.template load<V>(cp, k + u * V, j);
+#pragma unroll
+            for (int e = 0; e < V; ++e) r[u * V + e] = x.v[e];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (k + e < kend) ? X.template load<1>(cp, k + e, j).v[0] : T(0);
+    }
+}
+
+template <class T, class Acc, bool VECOK>
+__global__ __launch_bounds__(GT) void gram_kernel(Acc X, const T* __restrict__ w, const int32_t* __restrict__ mcols,
+                                                  int32_t M, const int32_t* __restrict__ ncols, int32_t N, int64_t n,
+                                                  int64_t kchunk, int32_t m_pos0, int32_t n_pos0, int symmetric,
+                                                  T* __restrict__ part, int64_t Mpad, int64_t Npad) {
+    const int bm = blockIdx.x, bn = blockIdx.y, sp = blockIdx.z;
+    // symmetric call (same column list on both sides): only the lower block triangle is needed
+    // (tile rows lie inside the new x new square and entirely above its diagonal; the reduce kernel mirrors)
+    if (symmetric && (m_pos0 + bm * BM >= n_pos0) && (m_pos0 + (bm + 1) * BM <= n_pos0 + bn * BN)) return;
+
+    __shared__ T As[BM * LDK];
+    __shared__ T Bs[BN * LDK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int64_t k0 = int64_t(sp) * kchunk;
+    const int64_t kend = min(n, k0 + kchunk);
+
+    // staging role: column (tid>>2) of the tile, rows (tid&3)*8 .. +8 of the stage
+    const int sc = tid >> 2, sr = (tid & 3) * 8;
+    const int am = bm * BM + sc, bnn = bn * BN + sc;
+    const bool a_ok = am < M, b_ok = bnn < N;
+    const int64_t ja = a_ok ? int64_t(mcols[am]) : 0;
+    const int64_t jb = b_ok ? int64_t(ncols[bnn]) : 0;
+
+    typename Mfma<T>::acc_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = T(0);
+
+    T ra[8], rb[8], rw[8];
+    auto fetch = [&](int64_t k) {
+        load8<T, Acc, VECOK>(X, ja, a_ok, k + sr, kend, ra);
+        load8<T, Acc, VECOK>(X, jb, b_ok, k + sr, kend, rb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rw[e] = (k + sr + e < kend) ? w[k + sr + e] : T(0);
+    };
+
+    if (k0 < kend) fetch(k0);
+    for (int64_t k = k0; k < kend; k += KT) {
+        __syncthreads(); // previous stage fully consumed
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            As[sc * LDK + sr + e] = ra[e];
+            Bs[sc * LDK + sr + e] = rb[e] * rw[e];
+        }
+        __syncthreads();
+        if (k + KT < kend) fetch(k + KT); // in flight while the MFMAs run
+        const int fr = (lane & 15), fk = (lane >> 4);
+#pragma unroll
+        for (int kk = 0; kk < KT / 4; ++kk) {
+            T a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[(wm * 32 + i * 16 + fr) * LDK + kk * 4 + fk];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[(wn * 32 + j * 16 + fr) * LDK + kk * 4 + fk];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
+        }
+    }
+
+    // partial tile -> part[sp][col][row]  (col = N index, row = M index)
+    T* P = part + int64_t(sp) * Mpad * Npad;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = bm * BM + wm * 32 + i * 16 + Mfma<T>::row(lane, e);
+                const int col = bn * BN + wn * 32 + j * 16 + (lane & 15);
+                P[int64_t(col) * Mpad + row] = acc[i][j][e];
+            }
+}
+
+template <class T>
+__global__ void gram_reduce_kernel(const T* __restrict__ part, int nsplit, int64_t Mpad, int64_t Npad, int32_t M,
+                                   int32_t N, const int32_t* __restrict__ mcols, const int32_t* __restrict__ ncols,
+                                   int32_t m_pos0, int32_t n_pos0, const T* __restrict__ xm, int center,
+                                   int symmetric, T* __restrict__ C, int64_t ldc) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x; // M index (fast: coalesced partial reads)
+    const int b = blockIdx.y;
+    if (a >= M || b >= N) return;
+    const int64_t rp = int64_t(m_pos0) + a, cp = int64_t(n_pos0) + b;
+    // inside the (new x new) square every unordered pair is taken from its lower-triangle entry only,
+    // so that C is exactly symmetric
+    if (symmetric && rp >= n_pos0 && rp < cp) return;
+    T s = T(0);
+    for (int sp = 0; sp < nsplit; ++sp) s += part[int64_t(sp) * Mpad * Npad + int64_t(b) * Mpad + a];
+    if (center) s -= xm[mcols[a]] * xm[ncols[b]];
+    C[rp + cp * ldc] = s;
+    if (symmetric) C[cp + rp * ldc] = s;
+}
+
+inline void gram_shape(int64_t n, int64_t M, int64_t N, int64_t& Mt, int64_t& Nt, int& nsplit, int64_t& kchunk) {
+    Mt = (M + BM - 1) / BM;
+    Nt = (N + BN - 1) / BN;
+    const int64_t tiles = Mt * Nt;
+    int64_t want = (1024 + tiles - 1) / tiles;
+    const int64_t max_split = (n + KT * 8 - 1) / (KT * 8);
+    if (want > max_split) want = max_split;
+    // bound the partial buffer (<= 2^28 elements)
+    const int64_t cap = (int64_t(1) << 28) / (Mt * BM * Nt * BN);
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    kchunk = (n + want - 1) / want;
+    kchunk = ((kchunk + KT - 1) / KT) * KT;
+    int64_t ns = (n + kchunk - 1) / kchunk;
+    if (ns < 1) ns = 1;
+    nsplit = int(ns);
+}
+
+template <class T, class Acc>
+void gram_launch(Acc acc, bool vecok, const T* w, const int32_t* mcols, int32_t M, int32_t m_pos0, const int32_t* ncols,
+                 int32_t N, int32_t n_pos0, int64_t n, const T* xm, bool center, T* C, int64_t ldc, T* work,
+                 hipStream_t s) {
+    if (M <= 0 || N <= 0) return;
+    int64_t Mt, Nt, kchunk;
+    int nsplit;
+    gram_shape(n, M, N, Mt, Nt, nsplit, kchunk);
+    const int64_t Mpad = Mt * BM, Npad = Nt * BN;
+    // "symmetric": the N list is the tail (or all) of the M list at the same positions -> skip tiles that lie
+    // entirely above the diagonal of the (new x new) square; the reduce kernel mirrors them.
+    const int symmetric = (mcols + (n_pos0 - m_pos0) == ncols && m_pos0 + M == n_pos0 + N && n_pos0 >= m_pos0) ? 1 : 0;
+    dim3 grid((unsigned)Mt, (unsigned)Nt, (unsigned)nsplit);
+    if (vecok)
+        hipLaunchKernelGGL((gram_kernel<T, Acc, true>), grid, dim3(GT), 0, s, acc, w, mcols, M, ncols, N, n, kchunk,
+                           m_pos0, n_pos0, symmetric, work, Mpad, Npad);
+    else
+        hipLaunchKernelGGL((gram_kernel<T, Acc, false>), grid, dim3(GT), 0, s, acc, w, mcols, M, ncols, N, n, kchunk,
+                           m_pos0, n_pos0, symmetric, work, Mpad, Npad);
+    hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3((unsigned)((M + 255) / 256), (unsigned)N), dim3(256), 0, s, work,
+                       nsplit, Mpad, Npad, M, N, mcols, ncols, m_pos0, n_pos0, xm, center ? 1 : 0, symmetric, C, ldc);
+}
+
+} // namespace
+
+int64_t gram_work_elems(int64_t n, int64_t M, int64_t N) {
+    if (M <= 0 || N <= 0) return 0;
+    int64_t Mt, Nt, kchunk;
+    int nsplit;
+    gram_shape(n, M, N, Mt, Nt, nsplit, kchunk);
+    return int64_t(nsplit) * Mt * BM * Nt * BN;
+}
+
+template <class T>
+void launch_gram(const DenseView<T>& X, const T* w, const int32_t* mcols, int32_t M, int32_t m_pos0,
+                 const int32_t* ncols, int32_t N, int32_t n_pos0, const T* xm_by_col, bool center, T* C, int64_t ldc,
+                 T* work, hipStream_t s) {
+    DenseAcc<T> acc{X.X, X.ld};
+    constexpr int V = VecOf<T>::N;
+    const bool vecok = (X.ld % V == 0) && ((reinterpret_cast<uintptr_t>(X.X) % 16) == 0);
+    gram_launch<T, DenseAcc<T>>(acc, vecok, w, mcols, M, m_pos0, ncols, N, n_pos0, X.n, xm_by_col, center, C, ldc, work, s);
+}
+template <class T>
+void launch_gram_snp(const SnpView& X, const T* impute, const T* w, const int32_t* mcols, int32_t M, int32_t m_pos0,
+                     const int32_t* ncols, int32_t N, int32_t n_pos0, const T* xm_by_col, bool center, T* C,
+                     int64_t ldc, T* work, hipStream_t s) {
+    SnpAcc<T> acc{X.bits, X.ldb, impute};
+    gram_launch<T, SnpAcc<T>>(acc, true, w, mcols, M, m_pos0, ncols, N, n_pos0, X.n, xm_by_col, center, C, ldc, work, s);
+}
+
+#define INST(T)                                                                                                        \
+    template void launch_gram<T>(const DenseView<T>&, const T*, const int32_t*, int32_t, int32_t, const int32_t*,      \
+                                 int32_t, int32_t, const T*, bool, T*, int64_t, T*, hipStream_t);                      \
+    template void launch_gram_snp<T>(const SnpView&, const T*, const T*, const int32_t*, int32_t, int32_t,             \
+                                     const int32_t*, int32_t, int32_t, const T*, bool, T*, int64_t, T*, hipStream_t);
+INST(double)
+INST(float)
+#undef INST
+
+} // namespace ahip

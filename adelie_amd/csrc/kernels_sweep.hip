@@ -1,0 +1,552 @@
+// kernels_sweep.hip — HBM-bound streaming kernels over the resident design (gfx950 / CDNA4).
+//
+//   sweep      out[c] = X[:,col(c)] . v            replaces MatrixNaiveDense::mul / bmul / cmul / sq_mul
+//                                                  (reference matrix_naive_dense.ipp:23-34,61-80,125-146,199-217,
+//                                                   kernels matrix/utils.hpp:131-161,194-269) and the invariance
+//                                                  sweep of solver_gaussian_naive.hpp:377-393 (incl. the
+//                                                  `grad -= resid_sum * X_means` epilogue, fused).
+//   axpy_cols  out += sign * sum_k coef_k X[:,col_k]  replaces ctmul / btmul (matrix_naive_dense.ipp:49-59,106-123)
+//                                                  and applies the residual update of a whole CD fit at once.
+//   sp_tmul    out[l,:] = sum_e V[l,e] X[:,idx_e]  replaces MatrixNaiveDense::sp_tmul (:219-256).
+//
+// Design notes (MI355X): one column is n*sizeof(T) contiguous bytes (800 KB at n=100k f64).  A sweep block owns a
+// panel of CB columns and walks the rows with 16-byte loads per lane (1 KiB per wave-instruction); the vector
+// v = w*r (<= 4 MB) is read through L2 once per panel instead of once per column, the CB column streams are
+// independent loads in flight (no LDS staging needed: there is no reuse of X), lanes reduce with wave shuffles
+// (64-wide), waves through a few LDS words.  Grid = panels x row-splits >> 256 CUs; partial sums of the row
+// splits are combined by a second tiny kernel so results are deterministic (no float atomics).
+#include "kernels.hpp"
+#include "accessors.hpp"
+
+namespace ahip {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+template <class T>
+__device__ __forceinline__ T wave_sum(T x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    return x;
+}
+
+template <class T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> load_vec(const T* p) {
+    Pack<T, VEC> r;
+    if constexpr (VEC == 1) r.v[0] = p[0];
+    else {
+        using V = typename VecOf<T>::type;
+        V x = *reinterpret_cast<const V*>(p);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) r.v[e] = x[e];
+    }
+    return r;
+}
+
+// ---- sweep ----------------------------------------------------------------------------------------
+template <class T, class Acc, int CB, int VEC, bool SQ>
+__global__ __launch_bounds__(kThreads) void sweep_kernel(Acc X, const T* __restrict__ v, T* __restrict__ out,
+                                                         int64_t n, int64_t c0, int64_t ncols,
+                                                         const int32_t* __restrict__ cols, int64_t rows_per_split,
+                                                         int nsplit, const T* __restrict__ sub_scale,
+                                                         const T* __restrict__ sub_vec) {
+    const int tid = threadIdx.x;
+    const int64_t cb = blockIdx.x;
+    const int split = blockIdx.y;
+    const int64_t r0 = int64_t(split) * rows_per_split;
+    const int64_t r1 = min(n, r0 + rows_per_split);
+
+    int64_t cj[CB];
+    decltype(X.colptr(0)) cp[CB];
+#pragma unroll
+    for (int k = 0; k < CB; ++k) {
+        int64_t c = cb * CB + k;
+        if (c >= ncols) c = ncols - 1; // duplicate work on the tail panel, discarded below
+        cj[k] = cols ? int64_t(cols[c]) : c0 + c;
+        cp[k] = X.colptr(cj[k]);
+    }
+    T acc[CB];
+#pragma unroll
+    for (int k = 0; k < CB; ++k) acc[k] = T(0);
+
+    const int64_t body_end = r0 + ((r1 - r0) / VEC) * VEC;
+#pragma unroll 2
+    for (int64_t i = r0 + int64_t(tid) * VEC; i < body_end; i += int64_t(kThreads) * VEC) {
+        const Pack<T, VEC> vv = load_vec<T, VEC>(v + i);
+        Pack<T, VEC> xx[CB];
+#pragma unroll
+        for (int k = 0; k < CB; ++k) xx[k] = X.template load<VEC>(cp[k], i, cj[k]);
+#pragma unroll
+        for (int k = 0; k < CB; ++k)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const T x = SQ ? xx[k].v[e] * xx[k].v[e] : xx[k].v[e];
+                acc[k] = fma(x, vv.v[e], acc[k]);
+            }
+    }
+    // row tail (< VEC rows)
+    for (int64_t i = body_end + tid; i < r1; i += kThreads) {
+        const T vi = v[i];
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            const T x0 = X.template load<1>(cp[k], i, cj[k]).v[0];
+            const T x = SQ ? x0 * x0 : x0;
+            acc[k] = fma(x, vi, acc[k]);
+        }
+    }
+
+    __shared__ T red[kThreads / 64][CB];
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < CB; ++k) {
+        const T s = wave_sum(acc[k]);
+        if (lane == 0) red[wv][k] = s;
+    }
+    __syncthreads();
+    if (tid < CB) {
+        const int64_t c = cb * CB + tid;
+        if (c < ncols) {
+            T s = T(0);
+#pragma unroll
+            for (int w = 0; w < kThreads / 64; ++w) s += red[w][tid];
+            if (nsplit == 1) {
+                if (sub_vec) s -= sub_scale[0] * sub_vec[cols ? int64_t(cols[c]) : c0 + c];
+                out[c] = s;
+            } else {
+                out[int64_t(split) * ncols + c] = s; // partial
+            }
+        }
+    }
+}
+
+template <class T>
+__global__ void sweep_reduce_kernel(const T* __restrict__ part, T* __restrict__ out, int64_t ncols, int nsplit,
+                                    int64_t c0, const int32_t* __restrict__ cols, const T* __restrict__ sub_scale,
+                                    const T* __restrict__ sub_vec) {
+    const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    T s = T(0);
+    for (int r = 0; r < nsplit; ++r) s += part[int64_t(r) * ncols + c];
+    if (sub_vec) {
+        const int64_t j = cols ? int64_t(cols[c]) : c0 + c;
+        s -= sub_scale[0] * sub_vec[j];
+    }
+    out[c] = s;
+}
+
+constexpr int kSweepCB = 4;
+
+inline void sweep_shape(int64_t n, int64_t ncols, int vec, int64_t& blocks_c, int& nsplit, int64_t& rows_per_split) {
+    blocks_c = (ncols + kSweepCB - 1) / kSweepCB;
+    const int64_t unit = int64_t(kThreads) * vec;      // rows per block iteration
+    const int64_t max_split = (n + unit * 4 - 1) / (unit * 4); // >= 4 iterations per split
+    int64_t want = (1024 + blocks_c - 1) / blocks_c;
+    int64_t ns = want < 1 ? 1 : want;
+    if (ns > max_split) ns = max_split;
+    if (ns < 1) ns = 1;
+    if (ns > 65535) ns = 65535;
+    rows_per_split = (n + ns - 1) / ns;
+    rows_per_split = ((rows_per_split + unit - 1) / unit) * unit;
+    ns = (n + rows_per_split - 1) / rows_per_split;
+    if (ns < 1) ns = 1;
+    nsplit = int(ns);
+}
+
+template <class T, class Acc, int VEC>
+void sweep_dispatch(Acc acc, const T* v, T* out, int64_t n, int64_t c0, int64_t ncols, const int32_t* cols,
+                    const T* sub_scale, const T* sub_vec, bool square, T* work, hipStream_t s) {
+    if (ncols <= 0) return;
+    int64_t blocks_c, rows_per_split;
+    int nsplit;
+    sweep_shape(n, ncols, VEC, blocks_c, nsplit, rows_per_split);
+    dim3 grid((unsigned)blocks_c, (unsigned)nsplit);
+    T* dst = nsplit == 1 ? out : work;
+    if (square)
+        hipLaunchKernelGGL((sweep_kernel<T, Acc, kSweepCB, VEC, true>), grid, dim3(kThreads), 0, s, acc, v, dst, n, c0,
+                           ncols, cols, rows_per_split, nsplit, sub_scale, sub_vec);
+    else
+        hipLaunchKernelGGL((sweep_kernel<T, Acc, kSweepCB, VEC, false>), grid, dim3(kThreads), 0, s, acc, v, dst, n, c0,
+                           ncols, cols, rows_per_split, nsplit, sub_scale, sub_vec);
+    if (nsplit > 1) {
+        const int bt = 256;
+        hipLaunchKernelGGL((sweep_reduce_kernel<T>), dim3((unsigned)((ncols + bt - 1) / bt)), dim3(bt), 0, s, work, out,
+                           ncols, nsplit, c0, cols, sub_scale, sub_vec);
+    }
+}
+
+// ---- axpy_cols --------------------------------------------------------------------------------------
+template <class T, class Acc, int VEC>
+__global__ __launch_bounds__(kThreads) void axpy_cols_kernel(Acc X, int64_t n, const int32_t* __restrict__ cols,
+                                                             const T* __restrict__ coef,
+                                                             const int32_t* __restrict__ count_dev, int32_t count,
+                                                             T sign, T* __restrict__ out) {
+    const int K = count_dev ? count_dev[0] : count;
+    if (K <= 0) return;
+    const int64_t i = (int64_t(blockIdx.x) * kThreads + threadIdx.x) * VEC;
+    if (i >= n) return;
+    if (i + VEC <= n) {
+        T acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = T(0);
+        int k = 0;
+        for (; k + 4 <= K; k += 4) {
+            Pack<T, VEC> xx[4];
+            T cf[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = cols[k + u];
+                cf[u] = coef[k + u];
+                xx[u] = X.template load<VEC>(X.colptr(j), i, j);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = fma(cf[u], xx[u].v[e], acc[e]);
+        }
+        for (; k < K; ++k) {
+            const int64_t j = cols[k];
+            const T cf = coef[k];
+            const Pack<T, VEC> xx = X.template load<VEC>(X.colptr(j), i, j);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = fma(cf, xx.v[e], acc[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) out[i + e] += sign * acc[e];
+    } else {
+        for (int64_t r = i; r < n; ++r) {
+            T acc = T(0);
+            for (int k = 0; k < K; ++k) {
+                const int64_t j = cols[k];
+                acc = fma(coef[k], X.template load<1>(X.colptr(j), r, j).v[0], acc);
+            }
+            out[r] += sign * acc;
+        }
+    }
+}
+
+template <class T, class Acc, int VEC>
+__global__ __launch_bounds__(kThreads) void sp_tmul_kernel(Acc X, int64_t n, const int64_t* __restrict__ indptr,
+                                                           const int64_t* __restrict__ indices,
+                                                           const T* __restrict__ values, T* __restrict__ out) {
+    const int64_t l = blockIdx.y;
+    const int64_t e0 = indptr[l], e1 = indptr[l + 1];
+    const int64_t i = (int64_t(blockIdx.x) * kThreads + threadIdx.x) * VEC;
+    if (i >= n) return;
+    T* o = out + l * n;
+    if (i + VEC <= n) {
+        T acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = T(0);
+        int64_t k = e0;
+        for (; k + 4 <= e1; k += 4) {
+            Pack<T, VEC> xx[4];
+            T cf[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = indices[k + u];
+                cf[u] = values[k + u];
+                xx[u] = X.template load<VEC>(X.colptr(j), i, j);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = fma(cf[u], xx[u].v[e], acc[e]);
+        }
+        for (; k < e1; ++k) {
+            const int64_t j = indices[k];
+            const T cf = values[k];
+            const Pack<T, VEC> xx = X.template load<VEC>(X.colptr(j), i, j);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = fma(cf, xx.v[e], acc[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[i + e] = acc[e];
+    } else {
+        for (int64_t r = i; r < n; ++r) {
+            T acc = T(0);
+            for (int64_t k = e0; k < e1; ++k) {
+                const int64_t j = indices[k];
+                acc = fma(values[k], X.template load<1>(X.colptr(j), r, j).v[0], acc);
+            }
+            o[r] = acc;
+        }
+    }
+}
+
+template <class T>
+__global__ void vmul_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int64_t n) {
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+        out[i] = a[i] * b[i];
+}
+template <class T>
+__global__ void fill_kernel(T* __restrict__ out, T value, int64_t n) {
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+        out[i] = value;
+}
+
+template <class T>
+__global__ void abs_grad_kernel(const T* __restrict__ grad, const int64_t* __restrict__ groups,
+                                const int64_t* __restrict__ group_sizes, int64_t G, const int32_t* __restrict__ slot,
+                                const T* __restrict__ screen_beta, const T* __restrict__ penalty, T oma_lmda,
+                                T* __restrict__ abs_grad) {
+    const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const int64_t k = groups[g], sz = group_sizes[g];
+    const int32_t sl = slot[g];
+    T acc = T(0);
+    if (sl >= 0) {
+        const T regul = oma_lmda * penalty[g];
+        for (int64_t t = 0; t < sz; ++t) {
+            const T e = grad[k + t] - regul * screen_beta[sl + t];
+            acc += e * e;
+        }
+    } else {
+        for (int64_t t = 0; t < sz; ++t) acc += grad[k + t] * grad[k + t];
+    }
+    abs_grad[g] = sqrt(acc);
+}
+
+template <class T>
+__global__ void copy2d_kernel(const T* __restrict__ src, int64_t lds_, T* __restrict__ dst, int64_t ldd, int64_t rows,
+                              int64_t cols) {
+    const int64_t j = blockIdx.y;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < rows; i += int64_t(gridDim.x) * blockDim.x)
+        dst[i + j * ldd] = src[i + j * lds_];
+    (void)cols;
+}
+
+template <class T>
+__global__ void diag_vars_kernel(const T* __restrict__ C, int64_t ldc, int32_t pos0, int32_t cnt, T* __restrict__ vars) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= cnt) return;
+    const T d = C[int64_t(pos0 + a) * (ldc + 1)];
+    vars[pos0 + a] = d > T(0) ? d : T(0);
+}
+
+// row-major (n,p) -> column-major with leading dimension ld, through a 32x33 LDS tile
+template <class T>
+__global__ void transpose_kernel(const T* __restrict__ src, int64_t n, int64_t p, T* __restrict__ dst, int64_t ld) {
+    __shared__ T tile[32][33];
+    const int64_t i0 = int64_t(blockIdx.y) * 32, j0 = int64_t(blockIdx.x) * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int64_t i = i0 + r, j = j0 + threadIdx.x;
+        if (i < n && j < p) tile[r][threadIdx.x] = src[i * p + j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.y; c < 32; c += blockDim.y) {
+        const int64_t j = j0 + c, i = i0 + threadIdx.x;
+        if (i < n && j < p) dst[i + j * ld] = tile[threadIdx.x][c];
+    }
+}
+
+__global__ void pack_snp_kernel(const int8_t* __restrict__ calldata, int64_t n, int64_t p, uint8_t* __restrict__ bits,
+                                int64_t ldb) {
+    const int64_t j = blockIdx.y;
+    const int64_t nb = (n + 3) / 4;
+    for (int64_t b = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; b < ldb; b += int64_t(gridDim.x) * blockDim.x) {
+        unsigned byte = 0;
+        if (b < nb) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t i = b * 4 + k;
+                unsigned code = 0;
+                if (i < n) {
+                    const int8_t c = calldata[i + j * n];
+                    code = c < 0 ? 3u : unsigned(c);
+                }
+                byte |= code << (2 * k);
+            }
+        }
+        bits[j * ldb + b] = uint8_t(byte);
+    }
+    (void)p;
+}
+
+inline unsigned grid1d(int64_t n, int bt, int64_t cap = 4096) {
+    int64_t g = (n + bt - 1) / bt;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return unsigned(g);
+}
+
+} // namespace
+
+int64_t sweep_work_elems(int64_t n, int64_t ncols) {
+    if (ncols <= 0) return 0;
+    int64_t blocks_c, rps;
+    int ns;
+    sweep_shape(n, ncols, 1, blocks_c, ns, rps); // VEC=1 gives the largest split count
+    int64_t a = int64_t(ns) * ncols;
+    sweep_shape(n, ncols, 4, blocks_c, ns, rps);
+    int64_t b = int64_t(ns) * ncols;
+    return (a > b ? a : b) + 16;
+}
+
+template <class T>
+void launch_vmul(const T* a, const T* b, T* out, int64_t n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL((vmul_kernel<T>), dim3(grid1d(n, 256)), dim3(256), 0, s, a, b, out, n);
+}
+template <class T>
+void launch_fill(T* out, T value, int64_t n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL((fill_kernel<T>), dim3(grid1d(n, 256)), dim3(256), 0, s, out, value, n);
+}
+
+template <class T>
+static inline bool dense_vec_ok(const DenseView<T>& X) {
+    constexpr int V = VecOf<T>::N;
+    return (X.ld % V == 0) && ((reinterpret_cast<uintptr_t>(X.X) % 16) == 0);
+}
+
+template <class T>
+void launch_sweep(const DenseView<T>& X, const T* v, T* out, int64_t c0, int64_t ncols, const int32_t* cols,
+                  const T* sub_scale, const T* sub_vec, bool square, T* work, hipStream_t s) {
+    DenseAcc<T> acc{X.X, X.ld};
+    if (dense_vec_ok(X) && (reinterpret_cast<uintptr_t>(v) % 16) == 0)
+        sweep_dispatch<T, DenseAcc<T>, VecOf<T>::N>(acc, v, out, X.n, c0, ncols, cols, sub_scale, sub_vec, square, work, s);
+    else
+        sweep_dispatch<T, DenseAcc<T>, 1>(acc, v, out, X.n, c0, ncols, cols, sub_scale, sub_vec, square, work, s);
+}
+template <class T>
+void launch_sweep_snp(const SnpView& X, const T* impute, const T* v, T* out, int64_t c0, int64_t ncols,
+                      const int32_t* cols, const T* sub_scale, const T* sub_vec, bool square, T* work, hipStream_t s) {
+    SnpAcc<T> acc{X.bits, X.ldb, impute};
+    sweep_dispatch<T, SnpAcc<T>, VecOf<T>::N>(acc, v, out, X.n, c0, ncols, cols, sub_scale, sub_vec, square, work, s);
+}
+
+template <class T>
+void launch_axpy_cols(const DenseView<T>& X, const int32_t* cols, const T* coef, const int32_t* count_dev,
+                      int32_t count, T sign, T* out, hipStream_t s) {
+    if (X.n <= 0 || (!count_dev && count <= 0)) return;
+    DenseAcc<T> acc{X.X, X.ld};
+    constexpr int V = VecOf<T>::N;
+    if (dense_vec_ok(X)) {
+        const unsigned g = unsigned((X.n + int64_t(kThreads) * V - 1) / (int64_t(kThreads) * V));
+        hipLaunchKernelGGL((axpy_cols_kernel<T, DenseAcc<T>, V>), dim3(g), dim3(kThreads), 0, s, acc, X.n, cols, coef,
+                           count_dev, count, sign, out);
+    } else {
+        const unsigned g = unsigned((X.n + kThreads - 1) / kThreads);
+        hipLaunchKernelGGL((axpy_cols_kernel<T, DenseAcc<T>, 1>), dim3(g), dim3(kThreads), 0, s, acc, X.n, cols, coef,
+                           count_dev, count, sign, out);
+    }
+}
+template <class T>
+void launch_axpy_cols_snp(const SnpView& X, const T* impute, const int32_t* cols, const T* coef,
+                          const int32_t* count_dev, int32_t count, T sign, T* out, hipStream_t s) {
+    if (X.n <= 0 || (!count_dev && count <= 0)) return;
+    SnpAcc<T> acc{X.bits, X.ldb, impute};
+    constexpr int V = VecOf<T>::N;
+    const unsigned g = unsigned((X.n + int64_t(kThreads) * V - 1) / (int64_t(kThreads) * V));
+    hipLaunchKernelGGL((axpy_cols_kernel<T, SnpAcc<T>, V>), dim3(g), dim3(kThreads), 0, s, acc, X.n, cols, coef,
+                       count_dev, count, sign, out);
+}
+
+template <class T>
+void launch_sp_tmul(const DenseView<T>& X, int64_t L, const int64_t* indptr, const int64_t* indices, const T* values,
+                    T* out, hipStream_t s) {
+    if (L <= 0 || X.n <= 0) return;
+    DenseAcc<T> acc{X.X, X.ld};
+    constexpr int V = VecOf<T>::N;
+    const bool vec = dense_vec_ok(X) && (X.n % V == 0);
+    for (int64_t l0 = 0; l0 < L; l0 += 65535) {
+        const unsigned ly = unsigned(L - l0 < 65535 ? L - l0 : 65535);
+        if (vec) {
+            const unsigned g = unsigned((X.n + int64_t(kThreads) * V - 1) / (int64_t(kThreads) * V));
+            hipLaunchKernelGGL((sp_tmul_kernel<T, DenseAcc<T>, V>), dim3(g, ly), dim3(kThreads), 0, s, acc, X.n,
+                               indptr + l0, indices, values, out + l0 * X.n);
+        } else {
+            const unsigned g = unsigned((X.n + kThreads - 1) / kThreads);
+            hipLaunchKernelGGL((sp_tmul_kernel<T, DenseAcc<T>, 1>), dim3(g, ly), dim3(kThreads), 0, s, acc, X.n,
+                               indptr + l0, indices, values, out + l0 * X.n);
+        }
+    }
+}
+template <class T>
+void launch_sp_tmul_snp(const SnpView& X, const T* impute, int64_t L, const int64_t* indptr, const int64_t* indices,
+                        const T* values, T* out, hipStream_t s) {
+    if (L <= 0 || X.n <= 0) return;
+    SnpAcc<T> acc{X.bits, X.ldb, impute};
+    constexpr int V = VecOf<T>::N;
+    const bool vec = (X.n % V == 0);
+    for (int64_t l0 = 0; l0 < L; l0 += 65535) {
+        const unsigned ly = unsigned(L - l0 < 65535 ? L - l0 : 65535);
+        if (vec) {
+            const unsigned g = unsigned((X.n + int64_t(kThreads) * V - 1) / (int64_t(kThreads) * V));
+            hipLaunchKernelGGL((sp_tmul_kernel<T, SnpAcc<T>, V>), dim3(g, ly), dim3(kThreads), 0, s, acc, X.n,
+                               indptr + l0, indices, values, out + l0 * X.n);
+        } else {
+            const unsigned g = unsigned((X.n + kThreads - 1) / kThreads);
+            hipLaunchKernelGGL((sp_tmul_kernel<T, SnpAcc<T>, 1>), dim3(g, ly), dim3(kThreads), 0, s, acc, X.n,
+                               indptr + l0, indices, values, out + l0 * X.n);
+        }
+    }
+}
+
+template <class T>
+void launch_abs_grad(const T* grad, const int64_t* groups, const int64_t* group_sizes, int64_t G, const int32_t* slot,
+                     const T* screen_beta, const T* penalty, T oma_lmda, T* abs_grad, hipStream_t s) {
+    if (G <= 0) return;
+    hipLaunchKernelGGL((abs_grad_kernel<T>), dim3(unsigned((G + 255) / 256)), dim3(256), 0, s, grad, groups,
+                       group_sizes, G, slot, screen_beta, penalty, oma_lmda, abs_grad);
+}
+
+template <class T>
+void launch_copy2d(const T* src, int64_t lds_, T* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return;
+    for (int64_t j0 = 0; j0 < cols; j0 += 65535) {
+        const unsigned cy = unsigned(cols - j0 < 65535 ? cols - j0 : 65535);
+        hipLaunchKernelGGL((copy2d_kernel<T>), dim3(grid1d(rows, 256, 64), cy), dim3(256), 0, s, src + j0 * lds_, lds_,
+                           dst + j0 * ldd, ldd, rows, cols);
+    }
+}
+template <class T>
+void launch_diag_vars(const T* C, int64_t ldc, int32_t pos0, int32_t cnt, T* vars, hipStream_t s) {
+    if (cnt <= 0) return;
+    hipLaunchKernelGGL((diag_vars_kernel<T>), dim3((cnt + 255) / 256), dim3(256), 0, s, C, ldc, pos0, cnt, vars);
+}
+template <class T>
+void launch_transpose(const T* src, int64_t n, int64_t p, T* dst, int64_t ld, hipStream_t s) {
+    if (n <= 0 || p <= 0) return;
+    const int64_t gy_total = (n + 31) / 32;
+    for (int64_t y0 = 0; y0 < gy_total; y0 += 65535) {
+        const unsigned gy = unsigned(gy_total - y0 < 65535 ? gy_total - y0 : 65535);
+        hipLaunchKernelGGL((transpose_kernel<T>), dim3(unsigned((p + 31) / 32), gy), dim3(32, 8), 0, s,
+                           src + y0 * 32 * p, n - y0 * 32, p, dst + y0 * 32, ld);
+    }
+}
+void launch_pack_snp(const int8_t* calldata, int64_t n, int64_t p, uint8_t* bits, int64_t ldb, hipStream_t s) {
+    if (n <= 0 || p <= 0) return;
+    for (int64_t j0 = 0; j0 < p; j0 += 65535) {
+        const unsigned cy = unsigned(p - j0 < 65535 ? p - j0 : 65535);
+        hipLaunchKernelGGL(pack_snp_kernel, dim3(grid1d(ldb, 256, 256), cy), dim3(256), 0, s, calldata + j0 * n, n, p,
+                           bits + j0 * ldb, ldb);
+    }
+}
+
+#define INST(T)                                                                                                        \
+    template void launch_vmul<T>(const T*, const T*, T*, int64_t, hipStream_t);                                        \
+    template void launch_fill<T>(T*, T, int64_t, hipStream_t);                                                         \
+    template void launch_sweep<T>(const DenseView<T>&, const T*, T*, int64_t, int64_t, const int32_t*, const T*,       \
+                                  const T*, bool, T*, hipStream_t);                                                    \
+    template void launch_sweep_snp<T>(const SnpView&, const T*, const T*, T*, int64_t, int64_t, const int32_t*,        \
+                                      const T*, const T*, bool, T*, hipStream_t);                                      \
+    template void launch_axpy_cols<T>(const DenseView<T>&, const int32_t*, const T*, const int32_t*, int32_t, T, T*,   \
+                                      hipStream_t);                                                                    \
+    template void launch_axpy_cols_snp<T>(const SnpView&, const T*, const int32_t*, const T*, const int32_t*, int32_t, \
+                                          T, T*, hipStream_t);                                                         \
+    template void launch_sp_tmul<T>(const DenseView<T>&, int64_t, const int64_t*, const int64_t*, const T*, T*,        \
+                                    hipStream_t);                                                                      \
+    template void launch_sp_tmul_snp<T>(const SnpView&, const T*, int64_t, const int64_t*, const int64_t*, const T*,   \
+                                        T*, hipStream_t);                                                              \
+    template void launch_abs_grad<T>(const T*, const int64_t*, const int64_t*, int64_t, const int32_t*, const T*,      \
+                                     const T*, T, T*, hipStream_t);                                                    \
+    template void launch_copy2d<T>(const T*, int64_t, T*, int64_t, int64_t, int64_t, hipStream_t);                     \
+    template void launch_diag_vars<T>(const T*, int64_t, int32_t, int32_t, T*, hipStream_t);                           \
+    template void launch_transpose<T>(const T*, int64_t, int64_t, T*, int64_t, hipStream_t);
+INST(double)
+INST(float)
+#undef INST
+
+} // namespace ahip

@@ -1,0 +1,1299 @@
+// solver.hip — C ABI: the grpnet path driver (host side) over the device-resident state.
+//
+// Host logic restated from the reference (paths relative to adelie/src/include/adelie_core):
+//   solve_core            solver/solver_base.hpp:435-687   (lambda_max bootstrap, path generation, BASIL loop)
+//   screen / search_pivot solver/solver_base.hpp:273-403, optimization/search_pivot.hpp:7-62
+//   kkt, early_exit       solver/solver_base.hpp:408-433, :241-263
+//   update_screen_derived solver/solver_base.hpp:120-153, solver/solver_gaussian_naive.hpp:41-176
+//   gaussian fit          solver/solver_gaussian_naive.hpp:209-349
+//   glm (IRLS) fit        solver/solver_glm_naive.hpp:160-459
+// These are O(G log G) scalar decisions per lambda and stay on the host; everything that touches an n- or
+// p-vector or the design runs in the kernels of kernels_*.hip on the design's stream.  Per BASIL iteration the
+// host receives: the CD kernel's scalar block, the screen coefficients (<= |S| values) and abs_grad (G values).
+#include "common.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <limits>
+#include <numeric>
+#include <unordered_set>
+
+namespace ahip {
+void set_last_error(const std::string& s);
+double g_hessian_min = 1e-24; // configs.hpp:6-21
+double g_dbeta_tol = 1e-12;
+
+// elementwise GLM kernels (kernels_glm.hip)
+template <class T>
+void launch_irls_prepare(int kind, const T* y, const T* w, const T* eta, const T* resid, const T* offsets, T hessian_min,
+                         int64_t n, T* hess, T* irls_resid, T* irls_y, T* sums4, hipStream_t s);
+template <class T>
+void launch_irls_weights(const T* hess, T hess_sum, const T* irls_y, T shift, int64_t n, T* wts, T* irls_resid,
+                         T* sums3, hipStream_t s);
+template <class T>
+void launch_irls_finish(int kind, const T* y, const T* w, const T* irls_y, const T* offsets, const T* irls_resid, T shift,
+                        int64_t n, T* eta, T* resid, T* sums2, hipStream_t s);
+template <class T>
+void launch_glm_gradient(int kind, const T* y, const T* w, const T* eta, int64_t n, T* resid, hipStream_t s);
+template <class T>
+void launch_glm_loss(int kind, const T* y, const T* w, const T* eta, int64_t n, T* out1, hipStream_t s);
+template <class T>
+void launch_null_step(int kind, const T* y, const T* w, const T* eta, const T* resid, const T* offsets, T hessian_min,
+                      int64_t n, T* sums2, hipStream_t s);
+template <class T>
+void launch_set_eta(const T* offsets, T beta0, int64_t n, T* eta, hipStream_t s);
+template <class T>
+void launch_dot_diff(const T* a, const T* a0, const T* b, const T* b0, int64_t n, T* out1, hipStream_t s);
+template <class T>
+void launch_gather(const T* src, const int32_t* idx, int64_t cnt, T* dst, hipStream_t s);
+} // namespace ahip
+
+using namespace ahip;
+using idx = int64_t;
+
+namespace {
+
+struct Stopwatch {
+    std::chrono::steady_clock::time_point t0;
+    void start() { t0 = std::chrono::steady_clock::now(); }
+    double elapsed() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+core_error max_cds_error(int l) {
+    return make_solver_error("max coordinate descents reached at lambda index: " + std::to_string(l) + ".");
+}
+core_error max_screen_set_error() { return make_solver_error("maximum screen set size reached."); }
+
+// cyclic Jacobi eigen-decomposition of a symmetric (q,q) matrix; stands in for Eigen::SelfAdjointEigenSolver
+// (solver_gaussian_naive.hpp:113).  Eigenvalues ascending, V column-major with eigenvectors in columns.
+void jacobi_eigh(int q, std::vector<double>& A, std::vector<double>& V, std::vector<double>& D) {
+    V.assign(size_t(q) * q, 0.0);
+    for (int i = 0; i < q; ++i) V[i + size_t(i) * q] = 1.0;
+    auto a = [&](int i, int j) -> double& { return A[i + size_t(j) * q]; };
+    auto v = [&](int i, int j) -> double& { return V[i + size_t(j) * q]; };
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0, dg = 0;
+        for (int i = 0; i < q; ++i) {
+            dg += a(i, i) * a(i, i);
+            for (int j = i + 1; j < q; ++j) off += a(i, j) * a(i, j);
+        }
+        if (off == 0 || off <= 1e-32 * (dg + off)) break;
+        for (int r = 0; r < q - 1; ++r)
+            for (int c = r + 1; c < q; ++c) {
+                const double arc = a(r, c);
+                if (arc == 0.0) continue;
+                const double theta = (a(c, c) - a(r, r)) / (2.0 * arc);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < q; ++k) {
+                    const double x = a(k, r), y = a(k, c);
+                    a(k, r) = cs * x - sn * y;
+                    a(k, c) = sn * x + cs * y;
+                }
+                for (int k = 0; k < q; ++k) {
+                    const double x = a(r, k), y = a(c, k);
+                    a(r, k) = cs * x - sn * y;
+                    a(c, k) = sn * x + cs * y;
+                }
+                for (int k = 0; k < q; ++k) {
+                    const double x = v(k, r), y = v(k, c);
+                    v(k, r) = cs * x - sn * y;
+                    v(k, c) = sn * x + cs * y;
+                }
+            }
+    }
+    std::vector<int> ord(q);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::sort(ord.begin(), ord.end(), [&](int i, int j) { return a(i, i) < a(j, j); });
+    std::vector<double> V2(size_t(q) * q);
+    D.resize(q);
+    for (int k = 0; k < q; ++k) {
+        D[k] = a(ord[k], ord[k]);
+        for (int i = 0; i < q; ++i) V2[i + size_t(k) * q] = v(i, ord[k]);
+    }
+    V.swap(V2);
+}
+
+struct Counters {
+    int64_t n_basil_iters = 0, n_sweeps = 0, n_cd_visits_screen = 0, n_cd_visits_active = 0, n_updates = 0,
+            n_irls_iters = 0, n_new_screen_cols = 0, n_cd_passes_screen = 0, n_cd_passes_active = 0,
+            n_gram_col_reads = 0, n_resid_col_reads = 0;
+};
+
+template <class T>
+struct FitOut {
+    std::vector<idx> beta_idx;
+    std::vector<T> beta_val;
+    T intercept = 0, rsq = 0;
+    double t_screen = 0, t_active = 0;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// Solver: host mirror of StateGaussianNaive / StateGlmNaive + the device-resident working set
+// ------------------------------------------------------------------------------------------------------------
+template <class T>
+struct Solver {
+    adelie_hip_design* D;
+    hipStream_t st;
+    idx n, p, G;
+    // ---- static inputs (host copies) ----
+    std::vector<idx> groups, group_sizes;
+    std::vector<T> penalty;
+    T alpha, min_ratio;
+    size_t lmda_path_size, max_screen_size, max_active_size;
+    T pivot_subset_ratio;
+    size_t pivot_subset_min;
+    T pivot_slack_ratio;
+    int screen_rule;
+    size_t max_iters;
+    T tol, adev_tol, ddev_tol, newton_tol;
+    size_t newton_max_iters;
+    bool early_exit_, setup_lmda_max, setup_lmda_path, intercept;
+    int glm_kind;
+    adelie_hip_poll_fn poll;
+    void* poll_user;
+    idx max_gs = 1;
+    bool all_scalar = true;
+    // ---- dynamic host state ----
+    T lmda_max;
+    std::vector<T> lmda_path;
+    std::unordered_set<idx> screen_hashset;
+    std::vector<idx> screen_set, screen_begins;
+    std::vector<T> screen_beta;
+    std::vector<int8_t> screen_is_active;
+    size_t active_set_size;
+    std::vector<idx> active_set;
+    T lmda;
+    std::vector<T> grad, abs_grad, X_means, resid, eta;
+    std::vector<T> screen_X_means, screen_vars;
+    std::vector<std::vector<T>> screen_transforms;
+    T y_mean = 0, y_var = 0, loss_null = 0, loss_full = 0, rsq = 0, resid_sum = 0, beta0 = 0;
+    size_t irls_max_iters = 0;
+    T irls_tol = 0;
+    bool setup_loss_null = false;
+    // outputs
+    std::vector<std::vector<idx>> betas_idx;
+    std::vector<std::vector<T>> betas_val;
+    std::vector<T> intercepts, devs, lmdas;
+    std::vector<double> benchmark_screen, benchmark_fit_screen, benchmark_fit_active, benchmark_kkt, benchmark_invariance;
+    std::vector<int> n_valid_solutions, active_sizes, screen_sizes;
+    Counters cnt;
+    std::string error;
+    double total_time = 0;
+
+    // ---- device working set ----
+    DevBuf<T> d_w, d_r, d_v, d_xm, d_grad, d_absgrad, d_penalty;
+    DevBuf<idx> d_groups, d_gsizes;
+    DevBuf<int32_t> d_slot;
+    // per screen value / group (sized p / G up front: a few hundred KB)
+    DevBuf<int32_t> d_vcol, d_sbegin, d_ssize, d_actset, d_dcols;
+    DevBuf<T> d_spen, d_beta, d_beta0, d_g, d_vars, d_sxm, d_dvals;
+    DevBuf<int8_t> d_isact;
+    DevBuf<idx> d_voff;
+    DevBuf<T> d_V;
+    size_t v_used = 0;
+    DevBuf<T> d_C;
+    idx ldc = 0;
+    idx gram_nv = 0; // number of screen values whose Gram rows/cols are valid (for the current weights)
+    DevBuf<CdScalars<T>> d_sc;
+    DevBuf<T> d_work_sweep, d_work_gram;
+    bool grad_valid = false; // d_grad == X^T W r - rsum*xbar for the current r
+    // glm device vectors
+    DevBuf<T> d_y, d_gw, d_off, d_eta, d_hess, d_irls_y, d_irls_resid, d_eta_prev, d_resid_prev, d_sums, d_ones;
+    // host mirrors of per-screen arrays used to append
+    idx nv = 0; // screen values
+    idx ns_dev = 0; // screen groups already mirrored on device
+
+    bool is_screen(idx i) const { return screen_hashset.find(i) != screen_hashset.end(); }
+    bool dense() const { return D->kind == 0; }
+
+    // ---------------------------------------------------------------------------------------------------------
+    void sweep(const T* v, T* out, const int32_t* cols, idx ncols, const T* sub_scale, const T* sub_vec) {
+        T* work = d_work_sweep.reserve(size_t(sweep_work_elems(n, ncols)));
+        if (dense()) launch_sweep<T>(D->dense<T>(), v, out, 0, ncols, cols, sub_scale, sub_vec, false, work, st);
+        else launch_sweep_snp<T>(D->snp(), static_cast<const T*>(D->impute), v, out, 0, ncols, cols, sub_scale, sub_vec, false, work, st);
+    }
+    void axpy_cols(const int32_t* cols, const T* coef, const int32_t* cnt_dev, int32_t count, T sign, T* out) {
+        if (dense()) launch_axpy_cols<T>(D->dense<T>(), cols, coef, cnt_dev, count, sign, out, st);
+        else launch_axpy_cols_snp<T>(D->snp(), static_cast<const T*>(D->impute), cols, coef, cnt_dev, count, sign, out, st);
+    }
+    void gram(const T* w, idx M, idx pos0, idx N, const T* xm, bool center) {
+        T* work = d_work_gram.reserve(size_t(gram_work_elems(n, M, N)));
+        if (dense())
+            launch_gram<T>(D->dense<T>(), w, d_vcol.p, int32_t(M), 0, d_vcol.p + pos0, int32_t(N), int32_t(pos0), xm, center,
+                           d_C.p, ldc, work, st);
+        else
+            launch_gram_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, d_vcol.p, int32_t(M), 0, d_vcol.p + pos0,
+                               int32_t(N), int32_t(pos0), xm, center, d_C.p, ldc, work, st);
+        cnt.n_gram_col_reads += M + N;
+    }
+    void sync() { AHIP_CHECK(hipStreamSynchronize(st)); }
+
+    // ---------------------------------------------------------------------------------------------------------
+    // solver_base.hpp:20-110 on the host (used at construction only; later abs_grad comes from the device)
+    void update_abs_grad_host(T lm) {
+        for (size_t ss = 0; ss < screen_set.size(); ++ss) {
+            const idx i = screen_set[ss], b = screen_begins[ss], k = groups[i], sz = group_sizes[i];
+            const T regul = ((1 - alpha) * lm) * penalty[i];
+            T acc = 0;
+            for (idx t = 0; t < sz; ++t) {
+                const T e = grad[k + t] - regul * screen_beta[b + t];
+                acc += e * e;
+            }
+            abs_grad[i] = std::sqrt(acc);
+        }
+        for (idx i = 0; i < G; ++i) {
+            if (is_screen(i)) continue;
+            const idx k = groups[i];
+            T acc = 0;
+            for (idx t = 0; t < group_sizes[i]; ++t) acc += grad[k + t] * grad[k + t];
+            abs_grad[i] = std::sqrt(acc);
+        }
+    }
+
+    // solver_base.hpp:120-153
+    void update_screen_derived_base() {
+        const auto old = screen_begins.size();
+        for (size_t i = old; i < screen_set.size(); ++i) screen_hashset.insert(screen_set[i]);
+        size_t vs = (old == 0) ? 0 : (screen_begins.back() + group_sizes[screen_set[old - 1]]);
+        for (size_t i = old; i < screen_set.size(); ++i) {
+            screen_begins.push_back(vs);
+            vs += group_sizes[screen_set[i]];
+        }
+        screen_beta.resize(vs, 0);
+        screen_is_active.resize(screen_set.size(), 0);
+    }
+
+    // Mirror newly appended screen groups on the device (value->column map, begins, sizes, penalties, slots,
+    // coefficients) and make room in the Gram matrix.  `beta_known`: upload host screen_beta for the new values
+    // (warm start) instead of zeros.
+    void device_append_screen() {
+        const idx ns = idx(screen_set.size());
+        if (ns_dev == ns) return;
+        std::vector<int32_t> vcol, sbegin, ssize, slot_idx;
+        std::vector<T> spen, beta_new;
+        std::vector<int8_t> isact;
+        const idx nv_old = nv;
+        idx nv_new = nv_old;
+        for (idx ss = ns_dev; ss < ns; ++ss) {
+            const idx g = screen_set[ss];
+            sbegin.push_back(int32_t(screen_begins[ss]));
+            ssize.push_back(int32_t(group_sizes[g]));
+            spen.push_back(penalty[g]);
+            isact.push_back(screen_is_active[ss]);
+            for (idx t = 0; t < group_sizes[g]; ++t) {
+                vcol.push_back(int32_t(groups[g] + t));
+                beta_new.push_back(screen_beta[screen_begins[ss] + t]);
+            }
+            nv_new += group_sizes[g];
+        }
+        d_vcol.upload(vcol.data(), vcol.size(), st, nv_old);
+        d_beta.upload(beta_new.data(), beta_new.size(), st, nv_old);
+        d_sbegin.upload(sbegin.data(), sbegin.size(), st, ns_dev);
+        d_ssize.upload(ssize.data(), ssize.size(), st, ns_dev);
+        d_spen.upload(spen.data(), spen.size(), st, ns_dev);
+        d_isact.upload(isact.data(), isact.size(), st, ns_dev);
+        // slots: group -> value offset
+        for (idx ss = ns_dev; ss < ns; ++ss) {
+            const int32_t b = int32_t(screen_begins[ss]);
+            AHIP_CHECK(hipMemcpyAsync(d_slot.p + screen_set[ss], &sbegin[ss - ns_dev], sizeof(int32_t), hipMemcpyHostToDevice, st));
+            (void)b;
+        }
+        sync(); // the staging vectors above go out of scope
+        ns_dev = ns;
+        nv = nv_new;
+        // Gram capacity
+        if (nv > ldc) {
+            idx want = std::max<idx>(ldc * 2, 256);
+            while (want < nv) want *= 2;
+            want = std::min<idx>(want, ((p + 63) / 64) * 64);
+            if (want < nv) want = nv;
+            DevBuf<T> nc;
+            nc.reserve(size_t(want) * size_t(want));
+            if (gram_nv > 0) launch_copy2d<T>(d_C.p, ldc, nc.p, want, gram_nv, gram_nv, st);
+            sync();
+            std::swap(d_C.p, nc.p);
+            std::swap(d_C.cap, nc.cap);
+            ldc = want;
+        }
+    }
+
+    // Bring the Gram matrix, variances and eigen-bases up to date for screen values [gram_nv, nv) under weights w
+    // (centred with xm_by_col when intercept).  Fills host screen_X_means / screen_vars / screen_transforms for the
+    // new groups [g_begin, ns)  (solver_gaussian_naive.hpp:41-125).
+    void update_gram_and_vars(const T* w_dev, const T* xm_dev, const std::vector<T>& xm_host, size_t g_begin) {
+        const idx ns = idx(screen_set.size());
+        const idx pos0 = (g_begin < size_t(ns)) ? screen_begins[g_begin] : nv;
+        const idx N = nv - pos0;
+        screen_X_means.resize(nv);
+        screen_vars.resize(nv, 0);
+        screen_transforms.resize(ns);
+        if (N <= 0) return;
+        gram(w_dev, nv, pos0, N, xm_dev, intercept);
+        gram_nv = nv;
+        cnt.n_new_screen_cols += N;
+        launch_diag_vars<T>(d_C.p, ldc, int32_t(pos0), int32_t(N), d_vars.p, st);
+        // host-side pieces: X_means of the new values, eigen-bases of the new groups with q > 1
+        std::vector<T> sxm(N);
+        for (idx ss = idx(g_begin); ss < ns; ++ss) {
+            const idx g = screen_set[ss], b = screen_begins[ss];
+            for (idx t = 0; t < group_sizes[g]; ++t) {
+                screen_X_means[b + t] = xm_host[groups[g] + t];
+                sxm[b + t - pos0] = screen_X_means[b + t];
+            }
+        }
+        d_sxm.upload(sxm.data(), sxm.size(), st, pos0);
+        std::vector<idx> voff(ns - g_begin, 0);
+        bool any_group = false;
+        for (idx ss = idx(g_begin); ss < ns; ++ss) {
+            const idx q = group_sizes[screen_set[ss]];
+            if (q > 1) any_group = true;
+        }
+        std::vector<T> vars_host(N);
+        d_vars.download(vars_host.data(), N, st, pos0);
+        sync();
+        if (any_group) {
+            for (idx ss = idx(g_begin); ss < ns; ++ss) {
+                const idx q = group_sizes[screen_set[ss]], b = screen_begins[ss];
+                if (q == 1) {
+                    screen_transforms[ss] = std::vector<T>{T(1)};
+                    continue;
+                }
+                std::vector<T> blk(size_t(q) * q);
+                AHIP_CHECK(hipMemcpy2DAsync(blk.data(), q * sizeof(T), d_C.p + b + b * ldc, ldc * sizeof(T), q * sizeof(T), q,
+                                            hipMemcpyDeviceToHost, st));
+                sync();
+                std::vector<double> A(blk.begin(), blk.end()), V, Dv;
+                jacobi_eigh(int(q), A, V, Dv);
+                std::vector<T> Vt(V.begin(), V.end());
+                for (idx t = 0; t < q; ++t) vars_host[b + t - pos0] = T(Dv[t] >= 0 ? Dv[t] : 0.0);
+                // append to the device transform pool
+                d_V.grow(v_used + size_t(q) * q, v_used, st);
+                d_V.upload(Vt.data(), Vt.size(), st, v_used);
+                voff[ss - g_begin] = idx(v_used);
+                v_used += size_t(q) * q;
+                screen_transforms[ss] = std::move(Vt);
+                sync();
+            }
+            d_vars.upload(vars_host.data(), N, st, pos0);
+            d_voff.upload(voff.data(), voff.size(), st, g_begin);
+            sync();
+        } else {
+            for (idx ss = idx(g_begin); ss < ns; ++ss) screen_transforms[ss] = std::vector<T>{T(1)};
+        }
+        for (idx t = 0; t < N; ++t) screen_vars[pos0 + t] = vars_host[t];
+    }
+
+    // solver_gaussian_naive.hpp:134-176
+    void gaussian_update_screen_derived() {
+        const size_t old_groups = screen_transforms.size();
+        update_screen_derived_base();
+        device_append_screen();
+        update_gram_and_vars(d_w.p, d_xm.p, X_means, old_groups);
+    }
+
+    // optimization/search_pivot.hpp:7-62
+    static int search_pivot(const std::vector<T>& x, const std::vector<T>& y, std::vector<T>& mses) {
+        const idx m = idx(x.size());
+        if (m <= 0) return -1;
+        mses[0] = std::numeric_limits<T>::infinity();
+        if (m == 1) return 0;
+        T y_mean = 0;
+        for (idx i = 0; i < m; ++i) y_mean += y[i];
+        y_mean /= T(m);
+        T x_sum = x[0], xsq_sum = x[0] * x[0], y_sum = y[0], yx_sum = y[0] * x[0], min_mse = mses[0];
+        int argmin = 0;
+        for (idx i = 1; i < m; ++i) {
+            x_sum += x[i];
+            xsq_sum += x[i] * x[i];
+            y_sum += y[i];
+            yx_sum += y[i] * x[i];
+            const T t_bar = ((i + 1) * x[i] - x_sum) / m;
+            const T var_t = ((i + 1) * x[i] * x[i] - 2 * x[i] * x_sum + xsq_sum - m * t_bar * t_bar);
+            const T cov_ty = (x[i] * (y_sum - (i + 1) * y_mean) - (yx_sum - y_mean * x_sum));
+            const T b1 = cov_ty / var_t;
+            mses[i] = -b1 * b1 * var_t;
+            if (mses[i] < min_mse) { argmin = int(i); min_mse = mses[i]; }
+        }
+        return argmin;
+    }
+
+    // solver_base.hpp:273-403
+    void screen(T lmda_next, bool all_kkt_passed, int n_new_active) {
+        const int old_size = int(screen_set.size());
+        if (screen_rule == ADELIE_HIP_SCREEN_STRONG) {
+            const T strong = (2 * lmda_next - lmda) * alpha;
+            for (idx i = 0; i < G; ++i) {
+                if (is_screen(i)) continue;
+                if (abs_grad[i] > strong * penalty[i]) screen_set.push_back(i);
+            }
+        } else if (screen_rule == ADELIE_HIP_SCREEN_PIVOT) {
+            if (n_new_active) {
+                const int Gi = int(G);
+                std::vector<idx> order(Gi);
+                std::iota(order.begin(), order.end(), 0);
+                std::vector<T> wts(Gi);
+                for (int i = 0; i < Gi; ++i)
+                    wts[i] = (penalty[i] <= 0) ? alpha * lmda : std::min(abs_grad[i] / penalty[i], alpha * lmda);
+                std::sort(order.begin(), order.end(), [&](idx i, idx j) { return wts[i] < wts[j]; });
+                const int subset_size =
+                    std::min<int>(std::max<int>(int(old_size * (1 + pivot_subset_ratio)), int(pivot_subset_min)), Gi);
+                std::vector<T> sub(subset_size), mses(subset_size), ind(subset_size);
+                for (int i = 0; i < subset_size; ++i) {
+                    sub[i] = wts[order[Gi - subset_size + i]];
+                    ind[i] = T(i);
+                }
+                const int pivot_idx = search_pivot(ind, sub, mses);
+                const int full_pivot_idx = Gi - subset_size + pivot_idx;
+                for (int ii = Gi - 1; ii >= full_pivot_idx; --ii) {
+                    const idx i = order[ii];
+                    if (is_screen(i)) continue;
+                    screen_set.push_back(i);
+                }
+                int count = 0;
+                for (int ii = full_pivot_idx - 1; ii >= 0; --ii) {
+                    if (count >= pivot_slack_ratio * n_new_active) break;
+                    const idx i = order[ii];
+                    if (is_screen(i)) continue;
+                    screen_set.push_back(i);
+                    ++count;
+                }
+            }
+            if ((int(screen_set.size()) == old_size) && !all_kkt_passed) {
+                for (idx i = 0; i < G; ++i) {
+                    if (is_screen(i)) continue;
+                    if (abs_grad[i] > lmda_next * penalty[i] * alpha) screen_set.push_back(i);
+                }
+            }
+        } else {
+            throw make_solver_error("Unknown screen rule!");
+        }
+        if (screen_set.size() > max_screen_size) {
+            screen_set.resize(old_size);
+            throw max_screen_set_error();
+        }
+    }
+
+    // solver_base.hpp:408-433
+    bool kkt(T lm) const {
+        for (idx k = 0; k < G; ++k) {
+            if (is_screen(k)) continue;
+            if (abs_grad[k] > lm * alpha * penalty[k]) return false;
+        }
+        return true;
+    }
+    // solver_base.hpp:241-263
+    bool early_exit() const {
+        if (!early_exit_ || devs.empty()) return false;
+        const T dev_u = devs.back();
+        if (dev_u >= adev_tol) return true;
+        if (devs.size() == 1) return false;
+        const T dev_m = devs[devs.size() - 2];
+        if (std::abs(dev_u - dev_m) < ddev_tol) return true;
+        return false;
+    }
+
+    void poll_mid() {
+        if (poll && poll(poll_user, 0, int64_t(lmdas.size()))) throw core_error("interrupted");
+    }
+
+    // ---------------------------------------------------------------------------------------------------------
+    // One pin solve on the device (solver_gaussian_pin_naive.hpp:217-401 for a single lambda).
+    // Preconditions: Gram/vars/sxm valid for [0,nv) under the weights in use; d_g holds the current gradient of the
+    // screen values; d_beta the current coefficients.  On success the residual `r_dev` is updated.
+    FitOut<T> pin_solve(T lm, T pin_tol, T rsq_in, T& rsum_io, T y_mean_pin, T* r_dev) {
+        poll_mid();
+        const idx ns = idx(screen_set.size());
+        FitOut<T> o;
+        AHIP_CHECK(hipMemcpyAsync(d_beta0.p, d_beta.p, size_t(nv) * sizeof(T), hipMemcpyDeviceToDevice, st));
+        CdScalars<T> sc{};
+        sc.rsq = rsq_in;
+        sc.resid_sum = rsum_io;
+        sc.active_size = int32_t(active_set_size);
+        d_sc.upload(&sc, 1, st);
+        CdParams<T> cp{};
+        cp.nv = int32_t(nv);
+        cp.ns = int32_t(ns);
+        cp.sbegin = d_sbegin.p;
+        cp.ssize = d_ssize.p;
+        cp.spen = d_spen.p;
+        cp.C = d_C.p;
+        cp.ldc = ldc;
+        cp.vars = d_vars.p;
+        cp.xmean = d_sxm.p;
+        cp.V = d_V.p;
+        cp.voff = d_voff.p;
+        cp.beta = d_beta.p;
+        cp.g = d_g.p;
+        cp.is_active = d_isact.p;
+        cp.active_set = d_actset.p;
+        cp.lmda = lm;
+        cp.alpha = alpha;
+        cp.tol = pin_tol;
+        cp.newton_tol = newton_tol;
+        cp.dbeta_tol = T(g_dbeta_tol);
+        cp.newton_max_iters = int32_t(std::min<size_t>(newton_max_iters, size_t(1) << 30));
+        cp.max_active_size = int32_t(std::min<size_t>(max_active_size, size_t(1) << 30));
+        cp.intercept = intercept;
+        cp.all_scalar = all_scalar ? 1 : 0;
+        cp.max_iters = int64_t(max_iters);
+        cp.sc = d_sc.p;
+        cp.beta0 = d_beta0.p;
+        cp.vcol = d_vcol.p;
+        cp.dcols = d_dcols.p;
+        cp.dvals = d_dvals.p;
+        cp.max_group_size = int32_t(max_gs);
+        Stopwatch sw;
+        sw.start();
+        if (nv > 0) launch_cd<T>(cp, st);
+        d_sc.download(&sc, 1, st);
+        sync();
+        const double t_cd = sw.elapsed();
+        if (nv == 0) {
+            sc.status = CD_OK;
+            sc.iters = 2; // one (empty) active pass + one (empty) screen pass
+        }
+        cnt.n_cd_visits_screen += sc.n_visits_screen;
+        cnt.n_cd_visits_active += sc.n_visits_active;
+        cnt.n_updates += sc.n_updates;
+        cnt.n_cd_passes_screen += sc.n_passes_screen;
+        cnt.n_cd_passes_active += sc.n_passes_active;
+        if (sc.status != CD_OK) {
+            // restore the pre-fit invariants (solver_gaussian_naive.hpp:286-290,326-329)
+            AHIP_CHECK(hipMemcpyAsync(d_beta.p, d_beta0.p, size_t(nv) * sizeof(T), hipMemcpyDeviceToDevice, st));
+            d_isact.upload(screen_is_active.data(), screen_is_active.size(), st);
+            sync();
+            if (sc.status == CD_MAX_CDS) throw max_cds_error(0);
+            if (sc.status == CD_MAX_ACTIVE) throw make_solver_error("Maximum number of active groups reached.");
+            throw make_solver_error("Newton-ABS max iterations reached! Try increasing newton_max_iters.");
+        }
+        // residual update r -= X_S (beta - beta0), once per fit
+        if (sc.n_delta > 0) {
+            axpy_cols(d_dcols.p, d_dvals.p, &d_sc.p->n_delta, 0, T(-1), r_dev);
+            cnt.n_resid_col_reads += sc.n_delta;
+        }
+        grad_valid = false;
+        // host mirrors
+        const size_t old_active = active_set_size;
+        active_set_size = size_t(sc.active_size);
+        rsum_io = sc.resid_sum;
+        o.rsq = sc.rsq;
+        d_beta.download(screen_beta.data(), size_t(nv), st);
+        if (active_set_size > old_active) {
+            std::vector<int32_t> act(active_set_size - old_active);
+            d_actset.download(act.data(), act.size(), st, old_active);
+            sync();
+            for (size_t i = 0; i < act.size(); ++i) {
+                active_set[old_active + i] = act[i];
+                screen_is_active[act[i]] = 1;
+            }
+        } else {
+            sync();
+        }
+        // pin_naive:359-394: active groups sorted by design column
+        std::vector<idx> order(active_set_size);
+        std::iota(order.begin(), order.end(), 0);
+        std::sort(order.begin(), order.end(),
+                  [&](idx i, idx j) { return groups[screen_set[active_set[i]]] < groups[screen_set[active_set[j]]]; });
+        for (size_t i = 0; i < order.size(); ++i) {
+            const idx ss = active_set[order[i]], g = screen_set[ss];
+            for (idx t = 0; t < group_sizes[g]; ++t) {
+                o.beta_idx.push_back(groups[g] + t);
+                o.beta_val.push_back(screen_beta[screen_begins[ss] + t]);
+            }
+        }
+        o.intercept = T(intercept) * (y_mean_pin + rsum_io);
+        // the single kernel interleaves active and screen passes; split the wall time by visit counts
+        const double va = double(sc.n_visits_active), vs = double(sc.n_visits_screen);
+        o.t_active = (va + vs) > 0 ? t_cd * va / (va + vs) : 0;
+        o.t_screen = t_cd - o.t_active;
+        return o;
+    }
+
+    // gradient of the screen values into d_g
+    void load_screen_gradient(const T* w_dev, const T* r_dev, const T* rsum_dev) {
+        if (nv == 0) return;
+        if (grad_valid) {
+            launch_gather<T>(d_grad.p, d_vcol.p, nv, d_g.p, st);
+        } else {
+            launch_vmul<T>(w_dev, r_dev, d_v.p, n, st);
+            sweep(d_v.p, d_g.p, d_vcol.p, nv, rsum_dev, intercept ? d_sxm_by_value() : nullptr);
+        }
+    }
+    // the sweep epilogue indexes sub_vec by design column -> use the by-column means
+    const T* d_sxm_by_value() const { return d_xm.p; }
+
+    // gaussian::naive::fit, solver_gaussian_naive.hpp:209-349
+    FitOut<T> gaussian_fit(T lm) {
+        // device scalar for the sweep epilogue
+        CdScalars<T> sc{};
+        sc.resid_sum = resid_sum;
+        d_sc.upload(&sc, 1, st);
+        load_screen_gradient(d_w.p, d_r.p, &d_sc.p->resid_sum);
+        T rsum = resid_sum;
+        FitOut<T> o = pin_solve(lm, tol * y_var, rsq, rsum, y_mean, d_r.p);
+        resid_sum = rsum;
+        rsq = o.rsq;
+        return o;
+    }
+
+    // ---------------------------------------------------------------------------------------------------------
+    // GLM: glm::naive::fit (IRLS), solver_glm_naive.hpp:234-459
+    std::vector<T> irls_xm_host; // X_means under the IRLS weights (screen columns only), by design column
+    DevBuf<T> d_irls_xm, d_irls_w;
+
+    T device_scalar(const T* dptr) {
+        T h;
+        AHIP_CHECK(hipMemcpyAsync(&h, dptr, sizeof(T), hipMemcpyDeviceToHost, st));
+        sync();
+        return h;
+    }
+
+    FitOut<T> glm_fit(T lm) {
+        FitOut<T> o;
+        size_t irls_it = 0;
+        const T hmin = T(g_hessian_min);
+        irls_xm_host.assign(p, 0);
+        while (1) {
+            if (irls_it >= irls_max_iters) throw make_solver_error("Maximum IRLS iterations reached.");
+            ++cnt.n_irls_iters;
+            // :336-348
+            T sums[4];
+            launch_irls_prepare<T>(glm_kind, d_y.p, d_gw.p, d_eta.p, d_r.p, d_off.p, hmin, n, d_hess.p, d_irls_resid.p,
+                                   d_irls_y.p, d_sums.p, st);
+            d_sums.download(sums, 1, st);
+            sync();
+            const T hess_sum = sums[0];
+            launch_irls_weights<T>(d_hess.p, hess_sum, d_irls_y.p, T(0), n, d_irls_w.p, d_irls_resid.p, d_sums.p, st);
+            d_sums.download(sums, 3, st);
+            sync();
+            const T ym = sums[0];
+            const T yv = sums[1] - T(intercept) * ym * ym;
+            T rsum;
+            if (intercept) {
+                const T shift = beta0 - ym;
+                launch_irls_weights<T>(d_hess.p, hess_sum, d_irls_y.p, shift, n, d_irls_w.p, d_irls_resid.p, d_sums.p, st);
+                d_sums.download(sums, 3, st);
+                sync();
+            }
+            rsum = sums[2];
+            T lmda_adj = lm / hess_sum;
+            if (std::isinf(lmda_adj)) {
+                if (lm == std::numeric_limits<T>::max()) lmda_adj = lm;
+                else
+                    throw make_solver_error(
+                        "IRLS lambda is unexpectedly inf. This likely indicates a bug in the code. Please report this!");
+            }
+            // :361-385  X_means on the screen columns and all screen-derived quantities under the IRLS weights
+            if (nv > 0) {
+                sweep(d_irls_w.p, d_g.p, d_vcol.p, nv, nullptr, nullptr); // means by value
+                std::vector<T> m(nv);
+                d_g.download(m.data(), size_t(nv), st);
+                sync();
+                for (idx ss = 0; ss < idx(screen_set.size()); ++ss) {
+                    const idx g = screen_set[ss];
+                    for (idx t = 0; t < group_sizes[g]; ++t) irls_xm_host[groups[g] + t] = m[screen_begins[ss] + t];
+                }
+                d_irls_xm.upload(irls_xm_host.data(), size_t(p), st);
+                gram_nv = 0;
+                v_used = 0;
+                screen_transforms.clear();
+                update_gram_and_vars(d_irls_w.p, d_irls_xm.p, irls_xm_host, 0);
+            }
+            // gradient of the screen values for the working response
+            CdScalars<T> sc{};
+            sc.resid_sum = rsum;
+            d_sc.upload(&sc, 1, st);
+            grad_valid = false;
+            if (nv > 0) {
+                launch_vmul<T>(d_irls_w.p, d_irls_resid.p, d_v.p, n, st);
+                sweep(d_v.p, d_g.p, d_vcol.p, nv, &d_sc.p->resid_sum, intercept ? d_irls_xm.p : nullptr);
+            }
+            const T pin_tol = tol * (loss_null - loss_full) / hess_sum; // :407
+            FitOut<T> po = pin_solve(lmda_adj, pin_tol, T(0), rsum, ym, d_irls_resid.p);
+            o.t_screen += po.t_screen;
+            o.t_active += po.t_active;
+            beta0 = po.intercept;
+            // :439-449
+            std::swap(d_eta.p, d_eta_prev.p);
+            std::swap(d_r.p, d_resid_prev.p);
+            launch_irls_finish<T>(glm_kind, d_y.p, d_gw.p, d_irls_y.p, d_off.p, d_irls_resid.p,
+                                  intercept ? (beta0 - ym) : T(0), n, d_eta.p, d_r.p, d_sums.p, st);
+            launch_dot_diff<T>(d_r.p, d_resid_prev.p, d_eta.p, d_eta_prev.p, n, d_sums.p, st);
+            const T conv = device_scalar(d_sums.p);
+            if (std::abs(conv) <= irls_tol) {
+                o.beta_idx.swap(po.beta_idx);
+                o.beta_val.swap(po.beta_val);
+                o.intercept = po.intercept;
+                o.rsq = po.rsq;
+                return o;
+            }
+            ++irls_it;
+        }
+    }
+
+    // update_loss_null, solver_glm_naive.hpp:160-232
+    void update_loss_null() {
+        if (!intercept) {
+            launch_glm_loss<T>(glm_kind, d_y.p, d_gw.p, d_off.p, n, d_sums.p, st);
+            loss_null = device_scalar(d_sums.p);
+            return;
+        }
+        T b0 = beta0;
+        DevBuf<T> e, r, e_prev, r_prev;
+        e.reserve(n); r.reserve(n); e_prev.reserve(n); r_prev.reserve(n);
+        AHIP_CHECK(hipMemcpyAsync(e.p, d_eta.p, n * sizeof(T), hipMemcpyDeviceToDevice, st));
+        AHIP_CHECK(hipMemcpyAsync(r.p, d_r.p, n * sizeof(T), hipMemcpyDeviceToDevice, st));
+        size_t it = 0;
+        const T hmin = T(g_hessian_min);
+        while (1) {
+            if (it >= irls_max_iters) throw make_solver_error("Maximum IRLS iterations reached.");
+            T sums[2];
+            launch_null_step<T>(glm_kind, d_y.p, d_gw.p, e.p, r.p, d_off.p, hmin, n, d_sums.p, st);
+            d_sums.download(sums, 2, st);
+            sync();
+            b0 = sums[1] / sums[0];
+            std::swap(e.p, e_prev.p);
+            launch_set_eta<T>(d_off.p, b0, n, e.p, st);
+            std::swap(r.p, r_prev.p);
+            launch_glm_gradient<T>(glm_kind, d_y.p, d_gw.p, e.p, n, r.p, st);
+            launch_dot_diff<T>(r.p, r_prev.p, e.p, e_prev.p, n, d_sums.p, st);
+            const T conv = device_scalar(d_sums.p);
+            if (std::abs(conv) <= irls_tol) {
+                launch_glm_loss<T>(glm_kind, d_y.p, d_gw.p, e.p, n, d_sums.p, st);
+                loss_null = device_scalar(d_sums.p);
+                return;
+            }
+            ++it;
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------------------------
+    static T compute_lmda_max(const Solver& s) { // solver/utils.hpp:7-23
+        const T factor = (s.alpha <= 0) ? T(1e-3) : s.alpha;
+        T mx = -std::numeric_limits<T>::infinity();
+        for (idx i = 0; i < s.G; ++i) mx = std::max<T>(mx, (s.penalty[i] <= 0.0) ? T(0) : s.abs_grad[i] / s.penalty[i]);
+        return mx / factor;
+    }
+    static void compute_lmda_path(std::vector<T>& path, T mr, T lmax) { // solver/utils.hpp:25-42
+        const idx L = idx(path.size());
+        if (L > 1) {
+            const T log_factor = std::log(mr) / (L - 1);
+            for (idx i = 0; i < L; ++i) path[i] = lmax * std::exp(log_factor * T(i));
+        }
+        path[0] = lmax;
+    }
+
+    bool is_glm() const { return glm_kind != ADELIE_HIP_GLM_GAUSSIAN; }
+
+    // update_invariance_f: solver_gaussian_naive.hpp:377-393 / solver_glm_naive.hpp:495-503, + update_abs_grad
+    void update_invariance(T lm) {
+        lmda = lm;
+        ++cnt.n_sweeps;
+        CdScalars<T> sc{};
+        sc.resid_sum = resid_sum;
+        d_sc.upload(&sc, 1, st);
+        if (is_glm()) {
+            sweep(d_r.p, d_grad.p, nullptr, p, nullptr, nullptr); // resid already carries the weights
+        } else {
+            launch_vmul<T>(d_w.p, d_r.p, d_v.p, n, st);
+            sweep(d_v.p, d_grad.p, nullptr, p, &d_sc.p->resid_sum, intercept ? d_xm.p : nullptr);
+            grad_valid = true;
+        }
+        launch_abs_grad<T>(d_grad.p, d_groups.p, d_gsizes.p, G, d_slot.p, d_beta.p, d_penalty.p, (1 - alpha) * lm,
+                           d_absgrad.p, st);
+        d_absgrad.download(abs_grad.data(), size_t(G), st);
+        sync();
+    }
+
+    void update_solutions(FitOut<T>& fo, T lm) {
+        betas_idx.emplace_back(std::move(fo.beta_idx));
+        betas_val.emplace_back(std::move(fo.beta_val));
+        intercepts.push_back(fo.intercept);
+        lmdas.push_back(lm);
+        if (is_glm()) { // solver_glm_naive.hpp:153-157
+            launch_glm_loss<T>(glm_kind, d_y.p, d_gw.p, d_eta.p, n, d_sums.p, st);
+            const T loss = device_scalar(d_sums.p);
+            devs.push_back((loss_null - loss) / (loss_null - loss_full));
+        } else {
+            devs.push_back(fo.rsq / y_var);
+        }
+    }
+
+    bool early_exit_f() {
+        const bool ee = early_exit();
+        const bool ec = poll && poll(poll_user, 1, int64_t(lmdas.size()));
+        return ee || ec;
+    }
+
+    void screen_f(T lm, bool kkt_passed, int n_new_active) {
+        screen(lm, kkt_passed, n_new_active);
+        if (is_glm()) {
+            update_screen_derived_base();
+            device_append_screen();
+        } else {
+            gaussian_update_screen_derived();
+        }
+    }
+
+    FitOut<T> fit_f(T lm) { return is_glm() ? glm_fit(lm) : gaussian_fit(lm); }
+
+    // solve_core, solver_base.hpp:435-687
+    void solve() {
+        if (screen_set.size() > max_screen_size) throw max_screen_set_error();
+        if (is_glm() && setup_loss_null) update_loss_null();
+
+        if (setup_lmda_max) { // :500-515
+            T pmax = -std::numeric_limits<T>::infinity();
+            for (idx i = 0; i < G; ++i) pmax = std::max(pmax, penalty[i]);
+            const T large_lmda = T(1e-3) * std::numeric_limits<T>::max() / std::max<T>(1, pmax);
+            fit_f(large_lmda);
+            update_invariance(large_lmda);
+            lmda_max = compute_lmda_max(*this);
+        }
+        if (setup_lmda_path) { // :520-526
+            if (lmda_path_size <= 0) return;
+            lmda_path.resize(lmda_path_size);
+            compute_lmda_path(lmda_path, min_ratio, lmda_max);
+        }
+        const size_t L = lmda_path.size();
+        size_t pb_it = 0, large_sz = 0;
+        while (large_sz < L && !(lmda_path[large_sz] <= lmda_max)) ++large_sz;
+        if (large_sz || setup_lmda_max) { // :553-591
+            std::vector<T> large(large_sz + 1);
+            for (size_t i = 0; i < large_sz; ++i) large[i] = lmda_path[i];
+            large[large_sz] = lmda_max;
+            for (size_t i = 0; i < large.size(); ++i) {
+                auto fo = fit_f(large[i]);
+                if (i < large.size() - 1) {
+                    update_solutions(fo, large[i]);
+                    ++pb_it;
+                    if (early_exit_f()) return;
+                } else {
+                    update_invariance(large[i]);
+                }
+            }
+        }
+        size_t lmda_path_idx = large_sz;
+        int current_active_size = int(active_set_size);
+        bool kkt_passed = true;
+        int n_new_active = 0;
+        Stopwatch sw;
+        for (; pb_it < L; ++pb_it) { // :605-686
+            const T lmda_curr = lmda_path[lmda_path_idx];
+            while (1) {
+                ++cnt.n_basil_iters;
+                sw.start();
+                screen_f(lmda_curr, kkt_passed, n_new_active);
+                benchmark_screen.push_back(sw.elapsed());
+                auto fo = fit_f(lmda_curr);
+                benchmark_fit_screen.push_back(fo.t_screen);
+                benchmark_fit_active.push_back(fo.t_active);
+                sw.start();
+                update_invariance(lmda_curr);
+                benchmark_invariance.push_back(sw.elapsed());
+                sw.start();
+                kkt_passed = kkt(lmda_curr);
+                n_valid_solutions.push_back(kkt_passed);
+                lmda_path_idx += kkt_passed;
+                if (kkt_passed) update_solutions(fo, lmda_curr);
+                benchmark_kkt.push_back(sw.elapsed());
+                if (kkt_passed) {
+                    active_sizes.push_back(int(active_set_size));
+                    screen_sizes.push_back(int(screen_set.size()));
+                }
+                n_new_active = kkt_passed ? (active_sizes.back() - current_active_size) : n_new_active;
+                current_active_size = kkt_passed ? active_sizes.back() : current_active_size;
+                if (kkt_passed) break;
+            }
+            if (early_exit_f()) break;
+        }
+    }
+
+    // pull the device-resident invariants back into the host mirrors that the result accessors expose
+    void finalize() {
+        d_grad.download(grad.data(), size_t(p), st);
+        d_r.download(resid.data(), size_t(n), st);
+        if (is_glm()) d_eta.download(eta.data(), size_t(n), st);
+        if (nv > 0) {
+            d_beta.download(screen_beta.data(), size_t(nv), st);
+            screen_X_means.resize(nv);
+            screen_vars.resize(nv);
+            d_sxm.download(screen_X_means.data(), size_t(nv), st);
+            d_vars.download(screen_vars.data(), size_t(nv), st);
+        }
+        sync();
+    }
+
+    // ---------------------------------------------------------------------------------------------------------
+    void build(adelie_hip_design* X, const adelie_hip_grpnet_args* a) {
+        D = X;
+        st = X->stream;
+        n = X->n; p = X->p; G = a->G;
+        if (G <= 0) throw make_core_error("groups must be non-empty.");
+        groups.assign(a->groups, a->groups + G);
+        group_sizes.assign(a->group_sizes, a->group_sizes + G);
+        penalty.assign((const T*)a->penalty, (const T*)a->penalty + G);
+        alpha = T(a->alpha); min_ratio = T(a->min_ratio);
+        lmda_path_size = size_t(a->lmda_path_size);
+        max_screen_size = size_t(a->max_screen_size); max_active_size = size_t(a->max_active_size);
+        pivot_subset_ratio = T(a->pivot_subset_ratio); pivot_subset_min = size_t(a->pivot_subset_min);
+        pivot_slack_ratio = T(a->pivot_slack_ratio); screen_rule = a->screen_rule;
+        max_iters = size_t(a->max_iters); tol = T(a->tol); adev_tol = T(a->adev_tol); ddev_tol = T(a->ddev_tol);
+        newton_tol = T(a->newton_tol); newton_max_iters = size_t(a->newton_max_iters);
+        early_exit_ = a->early_exit; setup_lmda_max = a->setup_lmda_max; setup_lmda_path = a->setup_lmda_path;
+        intercept = a->intercept; glm_kind = a->glm_kind;
+        poll = a->poll; poll_user = a->poll_user;
+        lmda_max = T(a->lmda_max);
+        if (a->lmda_path && a->n_lmda_path > 0) lmda_path.assign((const T*)a->lmda_path, (const T*)a->lmda_path + a->n_lmda_path);
+        screen_set.assign(a->screen_set, a->screen_set + a->screen_set_size);
+        screen_beta.assign((const T*)a->screen_beta, (const T*)a->screen_beta + a->screen_beta_size);
+        screen_is_active.assign(a->screen_is_active, a->screen_is_active + a->screen_set_size);
+        active_set_size = size_t(a->active_set_size);
+        active_set.assign(a->active_set, a->active_set + G);
+        lmda = T(a->lmda);
+        grad.assign((const T*)a->grad, (const T*)a->grad + p);
+        abs_grad.assign(G, 0);
+        for (idx g = 0; g < G; ++g) {
+            max_gs = std::max(max_gs, group_sizes[g]);
+            if (group_sizes[g] != 1) all_scalar = false;
+        }
+
+        // state_base.ipp:9-116
+        if (alpha < 0 || alpha > 1) throw make_core_error("alpha must be in [0,1].");
+        if (tol < 0) throw make_core_error("tol must be >= 0.");
+        if (adev_tol < 0 || adev_tol > 1) throw make_core_error("adev_tol must be in [0,1].");
+        if (ddev_tol < 0 || ddev_tol > 1) throw make_core_error("ddev_tol must be in [0,1].");
+        if (newton_tol < 0) throw make_core_error("newton_tol must be >= 0.");
+        if (a->n_threads < 1) throw make_core_error("n_threads must be >= 1.");
+        if (min_ratio < 0 || min_ratio > 1) throw make_core_error("min_ratio must be in [0,1].");
+        if (pivot_subset_ratio <= 0 || pivot_subset_ratio > 1) throw make_core_error("pivot_subset_ratio must be in (0,1].");
+        if (pivot_subset_min < 1) throw make_core_error("pivot_subset_min must be >= 1.");
+        if (pivot_slack_ratio < 0) throw make_core_error("pivot_slack_ratio must be >= 0.");
+        if (screen_beta.size() < screen_set.size())
+            throw make_core_error(
+                "screen_beta must be (bs,) where bs >= s and screen_set is (s,). "
+                "It is likely screen_beta has been initialized incorrectly. ");
+        if (active_set_size > size_t(G)) throw make_core_error("active_set_size must be <= G where groups is (G,).");
+        if (p != groups[G - 1] + group_sizes[G - 1])
+            throw make_core_error(
+                "grad.size() != groups[G-1] + group_sizes[G-1]. "
+                "It is likely either grad has the wrong shape, "
+                "or groups/group_sizes have been initialized incorrectly.");
+        for (idx i : screen_set)
+            if (i < 0 || i >= G) throw make_core_error("screen_set contains an out-of-range group index.");
+
+        AHIP_CHECK(hipSetDevice(X->device));
+        // device allocations
+        d_r.reserve(n); d_v.reserve(n); d_grad.reserve(p); d_absgrad.reserve(G); d_penalty.reserve(G);
+        d_groups.reserve(G); d_gsizes.reserve(G); d_slot.reserve(G);
+        d_vcol.reserve(p); d_sbegin.reserve(G); d_ssize.reserve(G); d_actset.reserve(G); d_dcols.reserve(p);
+        d_spen.reserve(G); d_beta.reserve(p); d_beta0.reserve(p); d_g.reserve(p); d_vars.reserve(p); d_sxm.reserve(p);
+        d_dvals.reserve(p); d_isact.reserve(G); d_voff.reserve(G); d_V.reserve(16); d_sc.reserve(1); d_sums.reserve(16 + 4 * 256);
+        d_penalty.upload(penalty.data(), G, st);
+        d_groups.upload(groups.data(), G, st);
+        d_gsizes.upload(group_sizes.data(), G, st);
+        AHIP_CHECK(hipMemsetAsync(d_slot.p, 0xFF, size_t(G) * sizeof(int32_t), st)); // -1
+        AHIP_CHECK(hipMemsetAsync(d_voff.p, 0, size_t(G) * sizeof(idx), st));
+        d_grad.upload(grad.data(), p, st);
+        std::vector<int32_t> act32(G, 0);
+        for (size_t i = 0; i < active_set_size; ++i) act32[i] = int32_t(active_set[i]);
+        d_actset.upload(act32.data(), G, st);
+        sync();
+
+        update_screen_derived_base();
+        update_abs_grad_host(lmda);
+
+        if (!is_glm()) {
+            // state_gaussian_naive.hpp:40-160
+            const T* w = (const T*)a->weights;
+            if (!w || !a->X_means || !a->resid) throw make_core_error("weights, X_means and resid are required.");
+            d_w.reserve(n); d_xm.reserve(p);
+            d_w.upload(w, n, st);
+            X_means.assign((const T*)a->X_means, (const T*)a->X_means + p);
+            d_xm.upload(X_means.data(), p, st);
+            y_mean = T(a->y_mean); y_var = T(a->y_var);
+            loss_null = -T(0.5) * y_mean * y_mean;
+            loss_full = -T(0.5) * y_var + loss_null;
+            rsq = T(a->rsq); resid_sum = T(a->resid_sum);
+            resid.assign((const T*)a->resid, (const T*)a->resid + n);
+            d_r.upload(resid.data(), n, st);
+            sync();
+            grad_valid = true; // the caller's grad is X^T W r (and resid_sum*X_means is already folded in or zero)
+            // (solver.py:891-904 passes the un-corrected gradient with resid_sum == 0 when intercept; a warm start
+            //  passes the corrected invariant; in both cases grad equals the invariant the CD kernel needs.)
+            gaussian_update_screen_derived();
+        } else {
+            // state_glm_naive.hpp:60-164
+            if (a->irls_tol <= 0) throw make_core_error("irls_tol must be > 0.");
+            if (!a->glm_y || !a->glm_weights || !a->offsets || !a->eta || !a->resid)
+                throw make_core_error("glm_y, glm_weights, offsets, eta and resid are required.");
+            d_y.reserve(n); d_gw.reserve(n); d_off.reserve(n); d_eta.reserve(n); d_hess.reserve(n); d_irls_y.reserve(n);
+            d_irls_resid.reserve(n); d_eta_prev.reserve(n); d_resid_prev.reserve(n); d_irls_w.reserve(n); d_irls_xm.reserve(p);
+            d_xm.reserve(p);
+            d_y.upload((const T*)a->glm_y, n, st);
+            d_gw.upload((const T*)a->glm_weights, n, st);
+            d_off.upload((const T*)a->offsets, n, st);
+            eta.assign((const T*)a->eta, (const T*)a->eta + n);
+            resid.assign((const T*)a->resid, (const T*)a->resid + n);
+            d_eta.upload(eta.data(), n, st);
+            d_r.upload(resid.data(), n, st);
+            beta0 = T(a->beta0); loss_null = T(a->loss_null); loss_full = T(a->loss_full);
+            irls_max_iters = size_t(a->irls_max_iters); irls_tol = T(a->irls_tol);
+            setup_loss_null = a->setup_loss_null;
+            sync();
+            device_append_screen();
+        }
+    }
+};
+
+struct ResultBase {
+    virtual ~ResultBase() {}
+    virtual int64_t size(int which) const = 0;
+    virtual int copy(int which, void* out, int64_t cap) const = 0;
+    virtual double scalar(int which) const = 0;
+    virtual const char* err() const = 0;
+};
+
+template <class V>
+void cp_d(const V& v, double* out, int64_t cap) {
+    const int64_t m = std::min<int64_t>(cap, int64_t(v.size()));
+    for (int64_t i = 0; i < m; ++i) out[i] = double(v[i]);
+}
+template <class V>
+void cp_i(const V& v, int64_t* out, int64_t cap) {
+    const int64_t m = std::min<int64_t>(cap, int64_t(v.size()));
+    for (int64_t i = 0; i < m; ++i) out[i] = int64_t(v[i]);
+}
+
+template <class T>
+struct Result : ResultBase {
+    Solver<T> s;
+    int64_t size(int which) const override {
+        switch (which) {
+            case ADELIE_HIP_V_INTERCEPTS: return s.intercepts.size();
+            case ADELIE_HIP_V_DEVS: return s.devs.size();
+            case ADELIE_HIP_V_LMDAS: return s.lmdas.size();
+            case ADELIE_HIP_V_LMDA_PATH: return s.lmda_path.size();
+            case ADELIE_HIP_V_SCREEN_BETA: return s.screen_beta.size();
+            case ADELIE_HIP_V_GRAD: return s.grad.size();
+            case ADELIE_HIP_V_ABS_GRAD: return s.abs_grad.size();
+            case ADELIE_HIP_V_RESID: return s.resid.size();
+            case ADELIE_HIP_V_ETA: return s.eta.size();
+            case ADELIE_HIP_V_SCREEN_X_MEANS: return s.screen_X_means.size();
+            case ADELIE_HIP_V_SCREEN_VARS: return s.screen_vars.size();
+            case ADELIE_HIP_V_SCREEN_TRANSFORMS: { int64_t t = 0; for (auto& v : s.screen_transforms) t += v.size(); return t; }
+            case ADELIE_HIP_V_BENCHMARK_SCREEN: return s.benchmark_screen.size();
+            case ADELIE_HIP_V_BENCHMARK_FIT_SCREEN: return s.benchmark_fit_screen.size();
+            case ADELIE_HIP_V_BENCHMARK_FIT_ACTIVE: return s.benchmark_fit_active.size();
+            case ADELIE_HIP_V_BENCHMARK_KKT: return s.benchmark_kkt.size();
+            case ADELIE_HIP_V_BENCHMARK_INVARIANCE: return s.benchmark_invariance.size();
+            case ADELIE_HIP_I_SCREEN_SET: return s.screen_set.size();
+            case ADELIE_HIP_I_SCREEN_BEGINS: return s.screen_begins.size();
+            case ADELIE_HIP_I_SCREEN_IS_ACTIVE: return s.screen_is_active.size();
+            case ADELIE_HIP_I_ACTIVE_SET: return s.active_set.size();
+            case ADELIE_HIP_I_N_VALID_SOLUTIONS: return s.n_valid_solutions.size();
+            case ADELIE_HIP_I_ACTIVE_SIZES: return s.active_sizes.size();
+            case ADELIE_HIP_I_SCREEN_SIZES: return s.screen_sizes.size();
+            case ADELIE_HIP_I_BETAS_INDPTR: return s.betas_idx.size() + 1;
+            case ADELIE_HIP_I_BETAS_INDICES:
+            case ADELIE_HIP_V_BETAS_VALUES: { int64_t t = 0; for (auto& v : s.betas_idx) t += v.size(); return t; }
+        }
+        return -1;
+    }
+    int copy(int which, void* out, int64_t cap) const override {
+        double* d = (double*)out;
+        int64_t* ii = (int64_t*)out;
+        switch (which) {
+            case ADELIE_HIP_V_INTERCEPTS: cp_d(s.intercepts, d, cap); return 0;
+            case ADELIE_HIP_V_DEVS: cp_d(s.devs, d, cap); return 0;
+            case ADELIE_HIP_V_LMDAS: cp_d(s.lmdas, d, cap); return 0;
+            case ADELIE_HIP_V_LMDA_PATH: cp_d(s.lmda_path, d, cap); return 0;
+            case ADELIE_HIP_V_SCREEN_BETA: cp_d(s.screen_beta, d, cap); return 0;
+            case ADELIE_HIP_V_GRAD: cp_d(s.grad, d, cap); return 0;
+            case ADELIE_HIP_V_ABS_GRAD: cp_d(s.abs_grad, d, cap); return 0;
+            case ADELIE_HIP_V_RESID: cp_d(s.resid, d, cap); return 0;
+            case ADELIE_HIP_V_ETA: cp_d(s.eta, d, cap); return 0;
+            case ADELIE_HIP_V_SCREEN_X_MEANS: cp_d(s.screen_X_means, d, cap); return 0;
+            case ADELIE_HIP_V_SCREEN_VARS: cp_d(s.screen_vars, d, cap); return 0;
+            case ADELIE_HIP_V_SCREEN_TRANSFORMS: {
+                int64_t k = 0;
+                for (auto& v : s.screen_transforms)
+                    for (auto x : v) { if (k < cap) d[k] = double(x); ++k; }
+                return 0;
+            }
+            case ADELIE_HIP_V_BENCHMARK_SCREEN: cp_d(s.benchmark_screen, d, cap); return 0;
+            case ADELIE_HIP_V_BENCHMARK_FIT_SCREEN: cp_d(s.benchmark_fit_screen, d, cap); return 0;
+            case ADELIE_HIP_V_BENCHMARK_FIT_ACTIVE: cp_d(s.benchmark_fit_active, d, cap); return 0;
+            case ADELIE_HIP_V_BENCHMARK_KKT: cp_d(s.benchmark_kkt, d, cap); return 0;
+            case ADELIE_HIP_V_BENCHMARK_INVARIANCE: cp_d(s.benchmark_invariance, d, cap); return 0;
+            case ADELIE_HIP_I_SCREEN_SET: cp_i(s.screen_set, ii, cap); return 0;
+            case ADELIE_HIP_I_SCREEN_BEGINS: cp_i(s.screen_begins, ii, cap); return 0;
+            case ADELIE_HIP_I_SCREEN_IS_ACTIVE: cp_i(s.screen_is_active, ii, cap); return 0;
+            case ADELIE_HIP_I_ACTIVE_SET: cp_i(s.active_set, ii, cap); return 0;
+            case ADELIE_HIP_I_N_VALID_SOLUTIONS: cp_i(s.n_valid_solutions, ii, cap); return 0;
+            case ADELIE_HIP_I_ACTIVE_SIZES: cp_i(s.active_sizes, ii, cap); return 0;
+            case ADELIE_HIP_I_SCREEN_SIZES: cp_i(s.screen_sizes, ii, cap); return 0;
+            case ADELIE_HIP_I_BETAS_INDPTR: {
+                int64_t acc = 0, k = 0;
+                if (k < cap) ii[k] = 0;
+                ++k;
+                for (auto& v : s.betas_idx) { acc += v.size(); if (k < cap) ii[k] = acc; ++k; }
+                return 0;
+            }
+            case ADELIE_HIP_I_BETAS_INDICES: {
+                int64_t k = 0;
+                for (auto& v : s.betas_idx) for (auto x : v) { if (k < cap) ii[k] = x; ++k; }
+                return 0;
+            }
+            case ADELIE_HIP_V_BETAS_VALUES: {
+                int64_t k = 0;
+                for (auto& v : s.betas_val) for (auto x : v) { if (k < cap) d[k] = double(x); ++k; }
+                return 0;
+            }
+        }
+        return 1;
+    }
+    double scalar(int which) const override {
+        switch (which) {
+            case ADELIE_HIP_S_LMDA_MAX: return s.lmda_max;
+            case ADELIE_HIP_S_LMDA: return s.lmda;
+            case ADELIE_HIP_S_RSQ: return s.rsq;
+            case ADELIE_HIP_S_RESID_SUM: return s.resid_sum;
+            case ADELIE_HIP_S_ACTIVE_SET_SIZE: return double(s.active_set_size);
+            case ADELIE_HIP_S_BETA0: return s.beta0;
+            case ADELIE_HIP_S_LOSS_NULL: return s.loss_null;
+            case ADELIE_HIP_S_LOSS_FULL: return s.loss_full;
+            case ADELIE_HIP_S_TOTAL_TIME: return s.total_time;
+            case ADELIE_HIP_S_N_BASIL_ITERS: return double(s.cnt.n_basil_iters);
+            case ADELIE_HIP_S_N_SWEEPS: return double(s.cnt.n_sweeps);
+            case ADELIE_HIP_S_N_CD_VISITS_SCREEN: return double(s.cnt.n_cd_visits_screen);
+            case ADELIE_HIP_S_N_CD_VISITS_ACTIVE: return double(s.cnt.n_cd_visits_active);
+            case ADELIE_HIP_S_N_UPDATES: return double(s.cnt.n_updates);
+            case ADELIE_HIP_S_N_IRLS_ITERS: return double(s.cnt.n_irls_iters);
+            case ADELIE_HIP_S_N_NEW_SCREEN_COLS: return double(s.cnt.n_new_screen_cols);
+            case ADELIE_HIP_S_N_CD_PASSES_SCREEN: return double(s.cnt.n_cd_passes_screen);
+            case ADELIE_HIP_S_N_CD_PASSES_ACTIVE: return double(s.cnt.n_cd_passes_active);
+            case ADELIE_HIP_S_N_GRAM_COL_READS: return double(s.cnt.n_gram_col_reads);
+            case ADELIE_HIP_S_N_RESID_COL_READS: return double(s.cnt.n_resid_col_reads);
+        }
+        return std::numeric_limits<double>::quiet_NaN();
+    }
+    const char* err() const override { return s.error.c_str(); }
+};
+
+template <class T>
+ResultBase* run(adelie_hip_design* X, const adelie_hip_grpnet_args* a) {
+    auto* r = new Result<T>();
+    try {
+        r->s.build(X, a);
+    } catch (...) {
+        delete r;
+        throw;
+    }
+    Stopwatch sw;
+    sw.start();
+    try {
+        r->s.solve();
+    } catch (const std::exception& e) {
+        r->s.error = e.what();
+    }
+    try {
+        r->s.finalize();
+    } catch (const std::exception& e) {
+        if (r->s.error.empty()) r->s.error = e.what();
+    }
+    r->s.total_time = sw.elapsed();
+    return r;
+}
+
+} // namespace
+
+struct adelie_hip_result {
+    ResultBase* r = nullptr;
+    ~adelie_hip_result() { delete r; }
+};
+
+extern "C" {
+
+int adelie_hip_set_config(const char* name, double value) {
+    const std::string nm(name ? name : "");
+    if (nm == "hessian_min") g_hessian_min = value;
+    else if (nm == "dbeta_tol") g_dbeta_tol = value;
+    else {
+        set_last_error("adelie_core: unknown config name.");
+        return 1;
+    }
+    return 0;
+}
+
+int adelie_hip_grpnet_solve(adelie_hip_design* X, const adelie_hip_grpnet_args* args, adelie_hip_result** out) {
+    try {
+        if (!X || !args || !out) throw make_core_error("null argument.");
+        auto* res = new adelie_hip_result();
+        try {
+            res->r = (X->dtype == ADELIE_HIP_F64) ? run<double>(X, args) : run<float>(X, args);
+        } catch (...) {
+            delete res;
+            throw;
+        }
+        *out = res;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return 1;
+    }
+    return 0;
+}
+int adelie_hip_result_destroy(adelie_hip_result* r) {
+    delete r;
+    return 0;
+}
+int64_t adelie_hip_result_size(const adelie_hip_result* r, int which) { return r->r->size(which); }
+int adelie_hip_result_copy(const adelie_hip_result* r, int which, void* out, int64_t cap) { return r->r->copy(which, out, cap); }
+double adelie_hip_result_scalar(const adelie_hip_result* r, int which) { return r->r->scalar(which); }
+const char* adelie_hip_result_error(const adelie_hip_result* r) { return r->r->err(); }
+
+// Times `reps` launches of the dominant kernel with HIP events on the design's own stream.
+int adelie_hip_bench_sweep(adelie_hip_design* d, int64_t reps, double* ms_per_launch) {
+    try {
+        if (!d || !ms_per_launch || reps <= 0) throw make_core_error("bad arguments.");
+        AHIP_CHECK(hipSetDevice(d->device));
+        hipStream_t s = d->stream;
+        auto body = [&](auto tag) {
+            using T = decltype(tag);
+            DevBuf<T> v, out, xm, work, sc;
+            v.reserve(d->n); out.reserve(d->p); xm.reserve(d->p); sc.reserve(1);
+            work.reserve(size_t(sweep_work_elems(d->n, d->p)));
+            launch_fill<T>(v.p, T(1) / T(d->n), d->n, s);
+            launch_fill<T>(xm.p, T(0.5), d->p, s);
+            launch_fill<T>(sc.p, T(0.25), 1, s);
+            auto once = [&]() {
+                if (d->kind == 0) launch_sweep<T>(d->dense<T>(), v.p, out.p, 0, d->p, nullptr, sc.p, xm.p, false, work.p, s);
+                else launch_sweep_snp<T>(d->snp(), static_cast<const T*>(d->impute), v.p, out.p, 0, d->p, nullptr, sc.p, xm.p, false, work.p, s);
+            };
+            once();
+            AHIP_CHECK(hipStreamSynchronize(s));
+            hipEvent_t e0, e1;
+            AHIP_CHECK(hipEventCreate(&e0));
+            AHIP_CHECK(hipEventCreate(&e1));
+            AHIP_CHECK(hipEventRecord(e0, s));
+            for (int64_t i = 0; i < reps; ++i) once();
+            AHIP_CHECK(hipEventRecord(e1, s));
+            AHIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            AHIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            *ms_per_launch = double(ms) / double(reps);
+        };
+        if (d->dtype == ADELIE_HIP_F64) body(double{});
+        else body(float{});
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return 1;
+    }
+    return 0;
+}
+
+} // extern "C"

@@ -3,7 +3,7 @@
 
 File layout (little endian, reference ``io_snp_unphased.ipp:117-135,225-274``)::
 
-    [u8 endian][u64 n][u64 p][u64 nnz[p]][u64 nnm[p]][f64 impute[p]][u64 outer[p+1]]
+    [u8 is_big_endian][u64 n][u64 p][u64 nnz[p]][u64 nnm[p]][f64 impute[p]][u64 outer[p+1]]
     per column j at outer[j]:  [u64 off_cat0, off_cat1, off_cat2]   (offsets relative to the column start)
       per category c in (0 = missing, 1, 2) at off_catc:  [u32 n_chunks]
         per non-empty 256-row chunk:  [u32 chunk_idx][u8 nnz-1][u8 row_in_chunk * nnz]
@@ -46,7 +46,7 @@ def _encode(calldata, impute):
     outer[0] = header_size
     for j in range(p):
         outer[j + 1] = outer[j] + np.uint64(len(cols[j]))
-    head = (np.uint8(1).tobytes() + np.uint64(n).tobytes() + np.uint64(p).tobytes() + nnz.tobytes() + nnm.tobytes()
+    head = (np.uint8(0 if np.little_endian else 1).tobytes() + np.uint64(n).tobytes() + np.uint64(p).tobytes() + nnz.tobytes() + nnm.tobytes()
             + np.asarray(impute, dtype=np.float64).tobytes() + outer.tobytes())
     return head + b"".join(cols)
 
@@ -120,7 +120,7 @@ class snp_unphased:
             buf = np.fromfile(self._filename, dtype=np.uint8)
         if buf.size < 17:
             raise RuntimeError("adelie_core: file is too small to be a .snpdat file.")
-        if bool(buf[0]) != (np.little_endian):
+        if bool(buf[0]) != (not np.little_endian):  # byte 0 = is_big_endian() of the writer
             raise RuntimeError("adelie_core: Endianness is inconsistent! Regenerate the file on this machine.")
         self._buffer = np.ascontiguousarray(buf)
         return int(buf.size)

@@ -200,7 +200,14 @@ __global__ __launch_bounds__(NT) void cd_kernel(CdParams<T> p) {
                     }
                     if (add) ++asz;
                     const T* __restrict__ Cc = p.C + int64_t(b) * p.ldc;
-                    for (int a = tid; a < nv; a += NT) gl[a] = fma(-del, Cc[a], gl[a]);
+                    for (int a0 = tid; a0 < nv; a0 += 8 * NT) { // 8 independent loads in flight per lane
+                        T c8[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) c8[u] = (a0 + u * NT < nv) ? Cc[a0 + u * NT] : T(0);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (a0 + u * NT < nv) gl[a0 + u * NT] = fma(-del, c8[u], gl[a0 + u * NT]);
+                    }
                     __syncthreads();
                     ++n_upd;
                 }
@@ -297,8 +304,11 @@ __global__ __launch_bounds__(NT) void cd_kernel(CdParams<T> p) {
 
 } // namespace
 
+template <class T> bool launch_cd_lasso(const CdParams<T>& p, hipStream_t s); // kernels_cd_lasso.hip
+
 template <class T>
 void launch_cd(const CdParams<T>& p, hipStream_t s) {
+    if (launch_cd_lasso<T>(p, s)) return;
     constexpr int NT = 256;
     const size_t base = size_t(8 * p.max_group_size + 8) * sizeof(T);
     const size_t with_g = base + size_t(p.nv) * sizeof(T);

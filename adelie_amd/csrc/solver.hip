@@ -115,10 +115,39 @@ void jacobi_eigh(int q, std::vector<double>& A, std::vector<double>& V, std::vec
     V.swap(V2);
 }
 
+// HIP-event timing of the device phases on the design's own stream (read by bench.py for the roofline object)
+struct KTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    double ms = 0;
+    int64_t launches = 0;
+    void begin(hipStream_t st) {
+        hipEvent_t a, b;
+        AHIP_CHECK(hipEventCreate(&a));
+        AHIP_CHECK(hipEventCreate(&b));
+        AHIP_CHECK(hipEventRecord(a, st));
+        ev.emplace_back(a, b);
+    }
+    void end(hipStream_t st) { AHIP_CHECK(hipEventRecord(ev.back().second, st)); }
+    void collect() {
+        for (auto& e : ev) {
+            float t = 0;
+            if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&t, e.first, e.second) == hipSuccess) {
+                ms += t;
+                ++launches;
+            }
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        ev.clear();
+    }
+    ~KTimer() { collect(); }
+};
+
 struct Counters {
     int64_t n_basil_iters = 0, n_sweeps = 0, n_cd_visits_screen = 0, n_cd_visits_active = 0, n_updates = 0,
             n_irls_iters = 0, n_new_screen_cols = 0, n_cd_passes_screen = 0, n_cd_passes_active = 0,
             n_gram_col_reads = 0, n_resid_col_reads = 0;
+    double gram_flops = 0;
 };
 
 template <class T>
@@ -179,6 +208,8 @@ struct Solver {
     std::vector<double> benchmark_screen, benchmark_fit_screen, benchmark_fit_active, benchmark_kkt, benchmark_invariance;
     std::vector<int> n_valid_solutions, active_sizes, screen_sizes;
     Counters cnt;
+    KTimer t_sweep, t_gram, t_cd, t_axpy;
+    double t_host_screen = 0;
     std::string error;
     double total_time = 0;
 
@@ -194,7 +225,7 @@ struct Solver {
     DevBuf<T> d_V;
     size_t v_used = 0;
     DevBuf<T> d_C;
-    idx ldc = 0;
+    idx ldc = 0, gcap = 0;
     idx gram_nv = 0; // number of screen values whose Gram rows/cols are valid (for the current weights)
     DevBuf<CdScalars<T>> d_sc;
     DevBuf<T> d_work_sweep, d_work_gram;
@@ -220,13 +251,16 @@ struct Solver {
     }
     void gram(const T* w, idx M, idx pos0, idx N, const T* xm, bool center) {
         T* work = d_work_gram.reserve(size_t(gram_work_elems(n, M, N)));
+        t_gram.begin(st);
         if (dense())
             launch_gram<T>(D->dense<T>(), w, d_vcol.p, int32_t(M), 0, d_vcol.p + pos0, int32_t(N), int32_t(pos0), xm, center,
                            d_C.p, ldc, work, st);
         else
             launch_gram_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, d_vcol.p, int32_t(M), 0, d_vcol.p + pos0,
                                int32_t(N), int32_t(pos0), xm, center, d_C.p, ldc, work, st);
+        t_gram.end(st);
         cnt.n_gram_col_reads += M + N;
+        cnt.gram_flops += 2.0 * double(n) * double(M) * double(N);
     }
     void sync() { AHIP_CHECK(hipStreamSynchronize(st)); }
 
@@ -303,19 +337,23 @@ struct Solver {
         sync(); // the staging vectors above go out of scope
         ns_dev = ns;
         nv = nv_new;
-        // Gram capacity
-        if (nv > ldc) {
-            idx want = std::max<idx>(ldc * 2, 256);
+        // Gram capacity: `gcap` columns, leading dimension ldc = gcap rounded up to 2048 rows (the CD kernel reads
+        // whole 512-lane x 16-byte chunks of a column; zero-filled so the padding never carries NaN payloads)
+        if (nv > gcap) {
+            idx want = std::max<idx>(gcap * 2, 256);
             while (want < nv) want *= 2;
             want = std::min<idx>(want, ((p + 63) / 64) * 64);
             if (want < nv) want = nv;
+            const idx new_ld = ((want + 2047) / 2048) * 2048;
             DevBuf<T> nc;
-            nc.reserve(size_t(want) * size_t(want));
-            if (gram_nv > 0) launch_copy2d<T>(d_C.p, ldc, nc.p, want, gram_nv, gram_nv, st);
+            nc.reserve(size_t(new_ld) * size_t(want));
+            AHIP_CHECK(hipMemsetAsync(nc.p, 0, size_t(new_ld) * size_t(want) * sizeof(T), st));
+            if (gram_nv > 0) launch_copy2d<T>(d_C.p, ldc, nc.p, new_ld, gram_nv, gram_nv, st);
             sync();
             std::swap(d_C.p, nc.p);
             std::swap(d_C.cap, nc.cap);
-            ldc = want;
+            ldc = new_ld;
+            gcap = want;
         }
     }
 
@@ -546,7 +584,11 @@ struct Solver {
         cp.max_group_size = int32_t(max_gs);
         Stopwatch sw;
         sw.start();
-        if (nv > 0) launch_cd<T>(cp, st);
+        if (nv > 0) {
+            t_cd.begin(st);
+            launch_cd<T>(cp, st);
+            t_cd.end(st);
+        }
         d_sc.download(&sc, 1, st);
         sync();
         const double t_cd = sw.elapsed();
@@ -570,7 +612,9 @@ struct Solver {
         }
         // residual update r -= X_S (beta - beta0), once per fit
         if (sc.n_delta > 0) {
+            t_axpy.begin(st);
             axpy_cols(d_dcols.p, d_dvals.p, &d_sc.p->n_delta, 0, T(-1), r_dev);
+            t_axpy.end(st);
             cnt.n_resid_col_reads += sc.n_delta;
         }
         grad_valid = false;
@@ -795,10 +839,14 @@ struct Solver {
         sc.resid_sum = resid_sum;
         d_sc.upload(&sc, 1, st);
         if (is_glm()) {
+            t_sweep.begin(st);
             sweep(d_r.p, d_grad.p, nullptr, p, nullptr, nullptr); // resid already carries the weights
+            t_sweep.end(st);
         } else {
             launch_vmul<T>(d_w.p, d_r.p, d_v.p, n, st);
+            t_sweep.begin(st);
             sweep(d_v.p, d_grad.p, nullptr, p, &d_sc.p->resid_sum, intercept ? d_xm.p : nullptr);
+            t_sweep.end(st);
             grad_valid = true;
         }
         launch_abs_grad<T>(d_grad.p, d_groups.p, d_gsizes.p, G, d_slot.p, d_beta.p, d_penalty.p, (1 - alpha) * lm,
@@ -887,6 +935,7 @@ struct Solver {
                 sw.start();
                 screen_f(lmda_curr, kkt_passed, n_new_active);
                 benchmark_screen.push_back(sw.elapsed());
+                t_host_screen += benchmark_screen.back();
                 auto fo = fit_f(lmda_curr);
                 benchmark_fit_screen.push_back(fo.t_screen);
                 benchmark_fit_active.push_back(fo.t_active);
@@ -913,6 +962,7 @@ struct Solver {
 
     // pull the device-resident invariants back into the host mirrors that the result accessors expose
     void finalize() {
+        t_sweep.collect(); t_gram.collect(); t_cd.collect(); t_axpy.collect();
         d_grad.download(grad.data(), size_t(p), st);
         d_r.download(resid.data(), size_t(n), st);
         if (is_glm()) d_eta.download(eta.data(), size_t(n), st);
@@ -1177,6 +1227,14 @@ struct Result : ResultBase {
             case ADELIE_HIP_S_N_CD_PASSES_ACTIVE: return double(s.cnt.n_cd_passes_active);
             case ADELIE_HIP_S_N_GRAM_COL_READS: return double(s.cnt.n_gram_col_reads);
             case ADELIE_HIP_S_N_RESID_COL_READS: return double(s.cnt.n_resid_col_reads);
+            case ADELIE_HIP_S_GRAM_FLOPS: return s.cnt.gram_flops;
+            case ADELIE_HIP_S_T_SWEEP_MS: return s.t_sweep.ms;
+            case ADELIE_HIP_S_T_GRAM_MS: return s.t_gram.ms;
+            case ADELIE_HIP_S_T_CD_MS: return s.t_cd.ms;
+            case ADELIE_HIP_S_T_AXPY_MS: return s.t_axpy.ms;
+            case ADELIE_HIP_S_N_SWEEP_LAUNCHES: return double(s.t_sweep.launches);
+            case ADELIE_HIP_S_N_GRAM_LAUNCHES: return double(s.t_gram.launches);
+            case ADELIE_HIP_S_T_HOST_SCREEN_MS: return 1e3 * s.t_host_screen;
         }
         return std::numeric_limits<double>::quiet_NaN();
     }

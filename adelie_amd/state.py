@@ -51,6 +51,8 @@ _RESULT_INDEX_VECS = ["screen_set", "screen_begins", "screen_is_active", "active
 _COUNTERS = ["n_basil_iters", "n_sweeps", "n_cd_visits_screen", "n_cd_visits_active", "n_updates", "n_irls_iters",
              "n_new_screen_cols", "n_cd_passes_screen", "n_cd_passes_active", "n_gram_col_reads",
              "n_resid_col_reads"]
+_TIMERS = ["gram_flops", "t_sweep_ms", "t_gram_ms", "t_cd_ms", "t_axpy_ms", "n_sweep_launches", "n_gram_launches",
+           "t_host_screen_ms"]
 
 
 class base:
@@ -134,6 +136,7 @@ class base:
         new.active_set_size = int(sc("active_set_size"))
         new.total_time = sc("total_time")
         new.counters = {nm: int(v) if v == v else 0 for nm, v in ((nm, sc(nm)) for nm in _COUNTERS)}
+        new.timers = {nm: (v if v == v else 0.0) for nm, v in ((nm, sc(nm)) for nm in _TIMERS)}
         err = backend.fn("result_error")(r)
         new.error = err.decode() if err else ""
         # screen_transforms: list of (q,q) F-ordered blocks in screen order

@@ -25,6 +25,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <limits>
@@ -109,17 +110,32 @@ struct DenseDesign : Design<T> {
     using Design<T>::nt;
     const T* X;
     idx rs, cs; /* element (i,j) at X[i*rs + j*cs] */
+    int ntc;    /* threads for single-column kernels (ddot / dvaddi): the reference uses the same n_threads for
+                   everything and documents that too many threads hurt these (parallelism.ipynb cells 11-18); the
+                   port caps them (ORACLE_COL_THREADS, default min(n_threads, 8)) so the CPU baseline is not
+                   handicapped on many-core hosts */
     DenseDesign(const T* X_, idx n_, idx p_, bool colmajor, int nt_) : X(X_) {
         n = n_; p = p_; nt = nt_;
         rs = colmajor ? 1 : p_;
         cs = colmajor ? n_ : 1;
+        const char* e = std::getenv("ORACLE_COL_THREADS");
+        ntc = e ? std::max(1, atoi(e)) : std::min(nt_, 8);
+        ntc = std::min(ntc, nt_);
+    }
+    bool parc(size_t bytes) const {
+#ifdef _OPENMP
+        return ntc > 1 && bytes > g_min_bytes && !omp_in_parallel();
+#else
+        (void)bytes;
+        return false;
+#endif
     }
     /* ddot (utils.hpp:131-161) on col j with v*w */
     T cmul(idx j, const T* v, const T* w) const override {
         const T* x = X + j * cs;
         T s = 0;
-        if (this->par(sizeof(T) * n)) {
-#pragma omp parallel for schedule(static) num_threads(nt) reduction(+ : s)
+        if (this->parc(sizeof(T) * n)) {
+#pragma omp parallel for schedule(static) num_threads(ntc) reduction(+ : s)
             for (idx i = 0; i < n; ++i) s += x[i * rs] * (v[i] * w[i]);
         } else if (rs == 1) {
             for (idx i = 0; i < n; ++i) s += x[i] * (v[i] * w[i]);
@@ -131,8 +147,8 @@ struct DenseDesign : Design<T> {
     /* dvaddi (utils.hpp:11-39) */
     void ctmul(idx j, T a, T* out) const override {
         const T* x = X + j * cs;
-        if (this->par(sizeof(T) * n)) {
-#pragma omp parallel for schedule(static) num_threads(nt)
+        if (this->parc(sizeof(T) * n)) {
+#pragma omp parallel for schedule(static) num_threads(ntc)
             for (idx i = 0; i < n; ++i) out[i] += a * x[i * rs];
         } else if (rs == 1) {
             for (idx i = 0; i < n; ++i) out[i] += a * x[i];
@@ -179,8 +195,8 @@ struct DenseDesign : Design<T> {
                 const T* xa = X + (j + a) * cs;
                 const T* xb = X + (j + b) * cs;
                 T s = 0;
-                if (this->par(sizeof(T) * n)) {
-#pragma omp parallel for schedule(static) num_threads(nt) reduction(+ : s)
+                if (this->parc(sizeof(T) * n)) {
+#pragma omp parallel for schedule(static) num_threads(ntc) reduction(+ : s)
                     for (idx i = 0; i < n; ++i) s += (xa[i * rs] * sw[i]) * (xb[i * rs] * sw[i]);
                 } else {
                     for (idx i = 0; i < n; ++i) s += (xa[i * rs] * sw[i]) * (xb[i * rs] * sw[i]);

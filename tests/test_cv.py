@@ -1,0 +1,85 @@
+"""cv_grpnet: fold partition rule, the induced-validation-loss identity, and the fold sharding over ranks
+(world_size 2, gloo, CPU) — reference adelie/cv.py:130-325 (untested upstream; pinned here as SURVEY.md 8a/C1 says)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import adelie_amd as ad
+from adelie_amd.cv import fold_ranges
+from util import make_gaussian
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_fold_ranges_match_reference_rule():
+    for n, k in [(10, 3), (100, 8), (7, 7), (23, 5)]:
+        fr = fold_ranges(n, k)
+        sizes = [e - b for b, e in fr]
+        assert sum(sizes) == n and fr[0][0] == 0 and fr[-1][1] == n
+        assert all(fr[i][1] == fr[i + 1][0] for i in range(k - 1))
+        assert sizes == [n // k + (i < n % k) for i in range(k)]  # cv.py:241-245
+
+
+def test_cv_loss_identity(oracle):
+    """cv_losses[k, i] == sum_{i in fold k} w_i l_i(eta_i) / sum_{i in fold k} w_i with beta from the training fit."""
+    d = make_gaussian(120, 20, seed=3)
+    X, y = d["X"], d["y"]
+    Xo = oracle.dense(X)
+    glm = ad.glm.gaussian(y)
+    res = ad.cv_grpnet(Xo, glm, n_folds=4, seed=7, lmda_path_size=12, tol=1e-12)
+    assert res.losses.shape == (4, 12) and res.lmdas.shape == (12,)
+    assert res.best_idx == int(np.argmin(res.avg_losses)) and np.allclose(res.avg_losses, res.losses.mean(0))
+    np.random.seed(7)
+    order = np.random.choice(120, 120, replace=False)
+    k = 2
+    b, e = fold_ranges(120, 4)[k]
+    w = glm.weights.copy()
+    w[order[b:e]] = 0
+    w /= w.sum()
+    st = ad.grpnet(Xo, glm.reweight(w), lmda_path=res.lmdas, early_exit=False, tol=1e-12)
+    val = order[b:e]
+    for i in [0, 5, 11]:
+        eta = X @ st.betas[i].toarray().ravel() + st.intercepts[i]
+        li = 0.5 * eta[val] ** 2 - y[val] * eta[val]
+        assert np.isclose(res.losses[k, i], li.mean(), rtol=1e-5, atol=1e-8)
+
+
+def test_cv_fold_sharding_world_size_2_gloo(oracle, tmp_path):
+    """Two CPU ranks over gloo: folds k%2==rank solved per rank, one all_gather, identical result on both ranks and
+    equal to the single-process result."""
+    script = tmp_path / "run.py"
+    script.write_text(f"""
+import os, sys, numpy as np
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+import torch.distributed as dist
+import adelie_amd as ad
+from oracle import oracle
+from util import make_gaussian
+dist.init_process_group(backend="gloo")
+d = make_gaussian(90, 15, seed=1)
+res = ad.cv_grpnet(oracle.dense(d["X"]), ad.glm.gaussian(d["y"]), n_folds=5, seed=3, lmda_path_size=8, tol=1e-12,
+                   process_group=True)
+np.save({str(tmp_path)!r} + f"/loss{{dist.get_rank()}}.npy", res.losses)
+dist.destroy_process_group()
+""")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)], env=env, timeout=600)
+    l0, l1 = np.load(tmp_path / "loss0.npy"), np.load(tmp_path / "loss1.npy")
+    assert np.array_equal(l0, l1)
+    d = make_gaussian(90, 15, seed=1)
+    single = ad.cv_grpnet(oracle.dense(d["X"]), ad.glm.gaussian(d["y"]), n_folds=5, seed=3, lmda_path_size=8, tol=1e-12)
+    assert np.allclose(l0, single.losses, rtol=1e-12, atol=0)
+
+
+@pytest.mark.gpu
+def test_cv_on_device_matches_oracle(hip, oracle):
+    d = make_gaussian(400, 60, seed=2)
+    a = ad.cv_grpnet(ad.matrix.dense(d["X"]), ad.glm.gaussian(d["y"]), n_folds=4, seed=1, lmda_path_size=15, tol=1e-10)
+    b = ad.cv_grpnet(oracle.dense(d["X"]), ad.glm.gaussian(d["y"]), n_folds=4, seed=1, lmda_path_size=15, tol=1e-10)
+    assert np.allclose(a.lmdas, b.lmdas, rtol=1e-10)
+    assert np.abs(a.losses - b.losses).max() < 1e-7
+    assert a.best_idx == b.best_idx

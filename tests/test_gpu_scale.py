@@ -1,0 +1,50 @@
+"""Size-independent properties at (a tenth of) BASELINE.json's headline size: too big for the oracle to be the checker
+in a unit test, so the path is certified from first principles on the device design itself — KKT of sampled
+solutions, the state invariants (resid / grad / rsq), monotone deviance, sorted lambdas."""
+import numpy as np
+import pytest
+
+import adelie_amd as ad
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,p,gs,alpha", [(20000, 4000, 1, 1.0), (20000, 2000, 10, 0.5)])
+def test_full_size_properties(hip, n, p, gs, alpha):
+    import torch
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0)
+    Xt = torch.randn((p, n), generator=g, device="cuda", dtype=torch.float64)
+    X = Xt.t()
+    rng = np.random.RandomState(0)
+    beta = rng.normal(size=p) * (rng.uniform(size=p) < 0.05)
+    y = (X @ torch.from_numpy(beta).cuda()).cpu().numpy() + np.sqrt(beta @ beta) * rng.normal(size=n)
+    Xd = ad.matrix.dense(X)
+    groups = np.arange(0, p, gs)
+    st = ad.grpnet(Xd, ad.glm.gaussian(y), groups=groups, alpha=alpha, early_exit=False)
+    assert st.error == "" and len(st.lmdas) == 100
+    assert np.all(np.diff(st.lmdas) < 0) and np.all(np.diff(st.devs) >= -1e-9)
+    w = np.full(n, 1 / n)
+    pen = np.sqrt(np.full(len(groups), gs, dtype=float))
+    yc = y - y.mean()
+    for l in [5, 50, 99]:
+        b = st.betas[l].toarray().ravel()
+        r = yc - (Xd @ b) - (st.intercepts[l] - y.mean())
+        assert abs(np.sum(w * r)) < 1e-10
+        grad = Xd.T @ (w * r)
+        lm = st.lmdas[l]
+        gn = np.linalg.norm(grad.reshape(-1, gs), axis=1)
+        bn = np.linalg.norm(b.reshape(-1, gs), axis=1)
+        zero = bn == 0
+        assert np.all(gn[zero] <= lm * alpha * pen[zero] * (1 + 1e-6) + 1e-9)
+        G_, B_ = grad.reshape(-1, gs)[~zero], b.reshape(-1, gs)[~zero]
+        target = lm * pen[~zero, None] * (alpha * B_ / bn[~zero, None] + (1 - alpha) * B_)
+        # stationarity holds to the CD tolerance: |dbeta| ~ sqrt(tol * y_var / A)
+        assert np.abs(G_ - target).max() < 5e-3 * lm + 1e-6
+    # state invariants at the end of the path (adelie/state.py:1563-1674)
+    b = st.betas[-1].toarray().ravel()
+    r = yc - (Xd @ b)
+    assert np.abs(st.resid - r).max() < 1e-8
+    assert np.abs(st.grad - (Xd.T @ (w * r) - np.sum(w * r) * st.X_means)).max() < 1e-9
+    assert abs(st.rsq - (np.sum(w * yc ** 2) - np.sum(w * (r - np.sum(w * r)) ** 2))) < 1e-7

@@ -1,0 +1,192 @@
+"""Parity of the HIP path with the CPU oracle through the C ABI (`adelie_hip_grpnet_solve`), written like the reference's
+own solver tests (tests/test_solver.py:596-649,899-975): same shapes, weighted, random penalties with zeros, warm restart.
+
+Tolerance.  Both implementations run the same iterate sequence in exact arithmetic (same visiting order, same
+predicates); they differ by floating-point summation order (wave-shuffle / MFMA reductions vs sequential sums).
+f64: max-abs 1e-6 on beta and intercept (the reference's own threshold, tests/test_solver.py:444-445) — observed
+differences are ~1e-13; support / screen sets must be identical.  f32: 1e-3 (tests/test_solver.py:745-746)."""
+import numpy as np
+import pytest
+
+import adelie_amd as ad
+from util import assert_same_path, kkt_gaussian, make_gaussian
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(oracle, d, glm_f, dtype=np.float64, **kw):
+    X = np.asarray(d["X"], dtype=dtype, order="F")
+    a = ad.grpnet(ad.matrix.dense(X), glm_f(), **kw)
+    b = ad.grpnet(oracle.dense(X), glm_f(), **kw)
+    return a, b
+
+
+@pytest.mark.parametrize("alpha", [1.0, 0.5])
+@pytest.mark.parametrize("intercept", [True, False])
+@pytest.mark.parametrize("n,p,G", [(10, 4, 2), (10, 100, 10), (10, 100, 20), (100, 23, 4), (100, 100, 50), (300, 120, 120)])
+def test_gaussian_groups_weighted(hip, oracle, n, p, G, intercept, alpha):
+    d = make_gaussian(n, p, G=G, seed=0, sparsity=0.95, weights=True, zero_pen=0.05)
+    kw = dict(groups=d["groups"], penalty=d["penalty"], alpha=alpha, intercept=intercept, tol=1e-10, min_ratio=1e-1,
+              lmda_path_size=30, early_exit=False)
+    a, b = _both(oracle, d, lambda: ad.glm.gaussian(d["y"], weights=d["weights"]), **kw)
+    assert_same_path(a, b, 1e-6)
+    assert np.abs(a.grad - b.grad).max() < 1e-8 and np.abs(a.resid - b.resid).max() < 1e-8
+    assert abs(a.rsq - b.rsq) < 1e-8 and abs(a.resid_sum - b.resid_sum) < 1e-10
+    assert np.allclose(a.screen_vars, b.screen_vars, atol=1e-9)
+    v = kkt_gaussian(d["X"], d["y"], a.weights, d["groups"], d["group_sizes"], d["penalty"], alpha, intercept,
+                     a.betas, a.intercepts, a.lmdas, 1e-5)
+    assert v < 3e-5 * max(1.0, float(np.max(np.abs(a.grad))))
+
+
+def test_config1_lasso_default_settings(hip, oracle):
+    """BASELINE.json configs[0]: dense 1000x200, ungrouped lasso, 100 lambdas, default tolerances."""
+    d = make_gaussian(1000, 200, seed=0, sparsity=0.95)
+    for ee in (True, False):
+        a, b = _both(oracle, d, lambda: ad.glm.gaussian(d["y"]), early_exit=ee)
+        assert_same_path(a, b, 1e-6)
+        assert a.counters["n_updates"] == b.counters["n_updates"]
+        assert a.counters["n_cd_visits_screen"] == b.counters["n_cd_visits_screen"]
+        assert a.counters["n_basil_iters"] == b.counters["n_basil_iters"]
+
+
+def test_config3_shape_group10_enet(hip, oracle):
+    d = make_gaussian(2000, 400, seed=1, sparsity=0.95)
+    kw = dict(groups=np.arange(0, 400, 10), alpha=0.5, early_exit=False)
+    a, b = _both(oracle, d, lambda: ad.glm.gaussian(d["y"]), **kw)
+    assert_same_path(a, b, 1e-6)
+    assert len(a.screen_transforms) == len(a.screen_set)
+
+
+def test_ragged_group_sizes_incl_large(hip, oracle):
+    rng = np.random.RandomState(5)
+    n, p = 400, 151
+    d = make_gaussian(n, p, seed=5)
+    groups = np.array([0, 1, 2, 70, 71, 100, 150])  # sizes 1,1,68,1,29,50,1 (one group wider than a wavefront)
+    a, b = _both(oracle, d, lambda: ad.glm.gaussian(d["y"]), groups=groups, alpha=0.7, early_exit=False,
+                 lmda_path_size=20, min_ratio=1e-1, tol=1e-10)
+    assert_same_path(a, b, 1e-6)
+
+
+def test_f32(hip, oracle):
+    d = make_gaussian(500, 100, seed=2)
+    a, b = _both(oracle, d, lambda: ad.glm.gaussian(d["y"].astype(np.float32)), dtype=np.float32, early_exit=False,
+                 lmda_path_size=30, min_ratio=5e-2)
+    assert a.betas.dtype == np.float32
+    assert len(a.lmdas) == len(b.lmdas) == 30
+    assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-3
+    assert np.abs(a.intercepts - b.intercepts).max() < 1e-3
+
+
+def test_strong_rule_and_user_path_above_lmda_max(hip, oracle):
+    d = make_gaussian(200, 80, seed=3)
+    ref = ad.grpnet(oracle.dense(d["X"]), ad.glm.gaussian(d["y"]), lmda_path_size=0)
+    path = ref.lmda_max * np.array([2.0, 1.5, 1.0, 0.7, 0.4, 0.2, 0.1])
+    for rule in ("strong", "pivot"):
+        a, b = _both(oracle, d, lambda: ad.glm.gaussian(d["y"]), lmda_path=path, screen_rule=rule, early_exit=False,
+                     tol=1e-10)
+        assert len(a.lmdas) == 7
+        assert_same_path(a, b, 1e-6)
+        assert a.betas[:2].nnz == 0  # lambdas above lmda_max: null model, solutions saved (solver_base.hpp:553-591)
+
+
+def test_lmda_path_size_zero_returns_lmda_max_only(hip, oracle):
+    d = make_gaussian(120, 50, seed=4, weights=True)
+    a, b = _both(oracle, d, lambda: ad.glm.gaussian(d["y"], weights=d["weights"]), lmda_path_size=0)
+    assert len(a.lmdas) == 0 and a.error == ""
+    assert np.isclose(a.lmda_max, b.lmda_max, rtol=1e-12)
+
+
+def test_warm_start_continuation(hip, oracle):
+    """tests/test_solver.py:633-649: continue from a solved state down a longer path."""
+    d = make_gaussian(150, 90, G=30, seed=6, weights=True)
+    glm = lambda: ad.glm.gaussian(d["y"], weights=d["weights"])
+    Xg, Xo = ad.matrix.dense(d["X"]), oracle.dense(d["X"])
+    kw = dict(groups=d["groups"], tol=1e-10, early_exit=False)
+    s1g = ad.grpnet(Xg, glm(), lmda_path_size=12, min_ratio=0.3, **kw)
+    s1o = ad.grpnet(Xo, glm(), lmda_path_size=12, min_ratio=0.3, **kw)
+    nxt = [s1o.lmdas[-1] * 0.8, s1o.lmdas[-1] * 0.6]
+    s2g = ad.grpnet(Xg, glm(), lmda_path=nxt, warm_start=s1g, **kw)
+    s2o = ad.grpnet(Xo, glm(), lmda_path=nxt, warm_start=s1o, **kw)
+    assert_same_path(s2g, s2o, 1e-6)
+
+
+def test_errors_and_partial_paths(hip, oracle):
+    d = make_gaussian(60, 40, seed=1)
+    a, b = _both(oracle, d, lambda: ad.glm.gaussian(d["y"]), max_iters=1, early_exit=False)
+    assert a.error == b.error and a.error.startswith("adelie_core solver: max coordinate descents")
+    assert len(a.lmdas) == len(b.lmdas)
+    a, b = _both(oracle, d, lambda: ad.glm.gaussian(d["y"]), max_screen_size=3, early_exit=False)
+    assert a.error == b.error == "adelie_core solver: maximum screen set size reached."
+    assert len(a.lmdas) == len(b.lmdas) > 0
+    assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-6
+    a, b = _both(oracle, d, lambda: ad.glm.gaussian(d["y"]), max_active_size=2, early_exit=False)
+    assert a.error == b.error == "adelie_core solver: Maximum number of active groups reached."
+    with pytest.raises(RuntimeError, match="alpha must be in"):
+        ad.grpnet(ad.matrix.dense(d["X"]), ad.glm.gaussian(d["y"]), alpha=-0.1)
+
+
+def test_exit_cond_callback(hip):
+    d = make_gaussian(100, 40, seed=8)
+    st = ad.grpnet(ad.matrix.dense(d["X"]), ad.glm.gaussian(d["y"]), early_exit=False,
+                   exit_cond=lambda s: s.n_solutions >= 7)
+    assert len(st.lmdas) == 7
+
+
+@pytest.mark.parametrize("n,p,G", [(200, 30, 30), (150, 60, 12)])
+def test_binomial_irls(hip, oracle, n, p, G):
+    rng = np.random.RandomState(4)
+    d = make_gaussian(n, p, G=G, seed=9)
+    eta = d["X"][:, :3] @ np.array([1.0, -2.0, 0.5])
+    y = rng.binomial(1, 1 / (1 + np.exp(-eta))).astype(float)
+    kw = dict(groups=d["groups"], tol=1e-10, irls_tol=1e-10, early_exit=False, lmda_path_size=15, min_ratio=5e-2)
+    a, b = _both(oracle, d, lambda: ad.glm.binomial(y), **kw)
+    assert_same_path(a, b, 1e-6)
+    assert np.abs(a.eta - b.eta).max() < 1e-6 and abs(a.beta0 - b.beta0) < 1e-6
+    assert a.counters["n_irls_iters"] == b.counters["n_irls_iters"]
+    assert np.isclose(a.loss_null, b.loss_null, rtol=1e-10)
+
+
+def test_gaussian_forced_through_irls(hip, oracle):
+    d = make_gaussian(80, 40, G=10, seed=2)
+    kw = dict(groups=d["groups"], tol=1e-12, irls_tol=1e-12, early_exit=False, lmda_path_size=15, min_ratio=1e-1)
+    a, b = _both(oracle, d, lambda: ad.glm.gaussian(d["y"], opt=False), **kw)
+    assert_same_path(a, b, 1e-6)
+    c = ad.grpnet(ad.matrix.dense(d["X"]), ad.glm.gaussian(d["y"]), **kw)
+    assert np.abs(a.betas.toarray() - c.betas.toarray()).max() < 1e-5
+
+
+def test_snp_design_equals_densified(hip, oracle):
+    """tests/test_solver.py:749-818: the SNP matrix and its densified copy give the same path (atol 1e-3 there)."""
+    rng = np.random.RandomState(3)
+    n, p = 600, 80
+    calldata = rng.choice([0, 1, 2, -9], size=(n, p), p=[0.6, 0.25, 0.05, 0.1]).astype(np.int8)
+    imp = ad.matrix.compute_impute(calldata)
+    Xd = np.asfortranarray(np.where(calldata < 0, imp[None], calldata).astype(np.float64))
+    beta = rng.normal(size=p) * (rng.uniform(size=p) < 0.1)
+    y = Xd @ beta + rng.normal(size=n)
+    kw = dict(early_exit=False, tol=1e-10, lmda_path_size=30)
+    s_snp = ad.grpnet(ad.matrix.snp_calldata(calldata), ad.glm.gaussian(y), **kw)
+    s_den = ad.grpnet(ad.matrix.dense(Xd), ad.glm.gaussian(y), **kw)
+    s_orc = ad.grpnet(oracle.snp_calldata(calldata), ad.glm.gaussian(y), **kw)
+    assert_same_path(s_snp, s_den, 1e-6)
+    assert_same_path(s_snp, s_orc, 1e-6)
+    yb = rng.binomial(1, 1 / (1 + np.exp(-(Xd @ beta)))).astype(float)
+    kb = dict(early_exit=False, tol=1e-10, irls_tol=1e-10, lmda_path_size=12, min_ratio=1e-1)
+    b_snp = ad.grpnet(ad.matrix.snp_calldata(calldata), ad.glm.binomial(yb), **kb)
+    b_orc = ad.grpnet(oracle.snp_calldata(calldata), ad.glm.binomial(yb), **kb)
+    assert_same_path(b_snp, b_orc, 1e-6)
+
+
+def test_caller_state_untouched_and_result_surface(hip):
+    """state.solve() returns a NEW state (py_state.cpp:1218-1226); the attribute surface of SURVEY.md 8b exists."""
+    d = make_gaussian(100, 30, seed=1)
+    st = ad.grpnet(ad.matrix.dense(d["X"]), ad.glm.gaussian(d["y"]), early_exit=False, lmda_path_size=10)
+    for name in ["betas", "intercepts", "devs", "lmdas", "duals", "lmda_max", "lmda_path", "lmda", "screen_set",
+                 "screen_begins", "screen_beta", "screen_is_active", "active_set_size", "active_set", "grad", "abs_grad",
+                 "resid", "resid_sum", "rsq", "X_means", "y_mean", "y_var", "loss_null", "loss_full", "screen_X_means",
+                 "screen_transforms", "screen_vars", "weights", "X", "benchmark_screen", "benchmark_fit_screen",
+                 "benchmark_fit_active", "benchmark_kkt", "benchmark_invariance", "n_valid_solutions", "active_sizes",
+                 "screen_sizes", "error", "total_time", "_offsets", "_glm", "_X"]:
+        assert hasattr(st, name), name
+    assert st.betas.shape == (10, 30) and st.betas.indices.dtype in (np.int32, np.int64)
+    assert st.screen_is_active.dtype == bool and st.active_set.shape == (30,)

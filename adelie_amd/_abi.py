@@ -221,6 +221,13 @@ def hip_backend():
                 f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  adelie_amd has no CPU fallback."
             )
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.  If torch is going to be
+        # used next to this library (device tensors adopted by matrix.dense, torch.distributed in cv_grpnet),
+        # it must initialise first so that libadelie_hip.so binds to the runtime that is already loaded.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is optional plumbing
+            pass
         _HIP = Backend(path, "adelie_hip_")
     return _HIP
 

@@ -474,7 +474,12 @@ struct Solver {
                 std::vector<T> wts(Gi);
                 for (int i = 0; i < Gi; ++i)
                     wts[i] = (penalty[i] <= 0) ? alpha * lmda : std::min(abs_grad[i] / penalty[i], alpha * lmda);
-                std::sort(order.begin(), order.end(), [&](idx i, idx j) { return wts[i] < wts[j]; });
+                // The reference sorts with `weights[i] < weights[j]` only (solver_base.hpp:320-326): every group whose score is
+                // capped at alpha*lmda ties exactly, and std::sort leaves the order of ties unspecified.  Ties are broken by
+                // group index here so that the screen insertion order (= the CD visiting order) is reproducible.
+                std::sort(order.begin(), order.end(), [&](idx i, idx j) {
+                    return wts[i] < wts[j] || (wts[i] == wts[j] && i < j);
+                });
                 const int subset_size =
                     std::min<int>(std::max<int>(int(old_size * (1 + pivot_subset_ratio)), int(pivot_subset_min)), Gi);
                 std::vector<T> sub(subset_size), mses(subset_size), ind(subset_size);

@@ -864,7 +864,12 @@ static void screen(State<T>& s, T lmda_next, bool all_kkt_passed, int n_new_acti
             std::vector<T> weights(G);
             for (int i = 0; i < G; ++i)
                 weights[i] = (s.penalty[i] <= 0) ? s.alpha * lmda : std::min(s.abs_grad[i] / s.penalty[i], s.alpha * lmda);
-            std::sort(order.begin(), order.end(), [&](idx i, idx j) { return weights[i] < weights[j]; });
+            // The reference sorts with `weights[i] < weights[j]` only (solver_base.hpp:320-326): every group whose score is
+                // capped at alpha*lmda ties exactly, and std::sort leaves the order of ties unspecified.  Ties are broken by
+                // group index here so that the screen insertion order (= the CD visiting order) is reproducible.
+                std::sort(order.begin(), order.end(), [&](idx i, idx j) {
+                    return weights[i] < weights[j] || (weights[i] == weights[j] && i < j);
+                });
             const int subset_size =
                 std::min<int>(std::max<int>(int(old_size * (1 + s.pivot_subset_ratio)), int(s.pivot_subset_min)), G);
             std::vector<T> sub(subset_size), mses(subset_size), ind(subset_size);

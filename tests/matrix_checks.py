@@ -53,7 +53,7 @@ def run_naive(cX, X, dtype):
     # sq_mul
     out = np.empty(p, dtype=dtype)
     cX.sq_mul(w, out)
-    assert np.abs(out - w @ (X64 ** 2)).max() <= tol * max(1.0, np.abs(X).max())
+    assert np.abs(out - w @ (X64 ** 2)).max() <= tol * max(1.0, np.abs(X).max()) * (4 if dtype == np.float32 else 1)
     # sp_tmul
     L = 5
     dense = rng.normal(size=(L, p)) * (rng.uniform(size=(L, p)) < 0.3)
@@ -70,7 +70,7 @@ def run_naive(cX, X, dtype):
     var = np.empty(p, dtype=dtype)
     cX.var(centers, w, var)
     ref = w @ (X64 - centers[None]) ** 2
-    assert np.abs(var - ref).max() <= tol * max(1.0, np.abs(X).max()) * 4
+    assert np.abs(var - ref).max() <= tol * max(1.0, np.abs(X).max()) * (32 if dtype == np.float32 else 4)  # f32: cancellation
     b = rng.normal(size=p).astype(dtype)
     assert np.abs(cX @ b - X64 @ b).max() <= tol
     assert np.abs(cX.T @ v - X64.T @ v).max() <= tol

@@ -40,8 +40,11 @@ def test_full_size_properties(hip, n, p, gs, alpha):
         assert np.all(gn[zero] <= lm * alpha * pen[zero] * (1 + 1e-6) + 1e-9)
         G_, B_ = grad.reshape(-1, gs)[~zero], b.reshape(-1, gs)[~zero]
         target = lm * pen[~zero, None] * (alpha * B_ / bn[~zero, None] + (1 - alpha) * B_)
-        # stationarity holds to the CD tolerance: |dbeta| ~ sqrt(tol * y_var / A)
-        assert np.abs(G_ - target).max() < 5e-3 * lm + 1e-6
+        # stationarity holds to the CD stopping rule max_k A_kk dbeta_k^2 < tol*y_var (pin_base:100-122,
+        # gaussian_naive.hpp:312): each coordinate's gradient is within ~sqrt(tol*y_var*A_kk) of its target,
+        # plus the drift from the other coordinates' last moves; allow 20x that
+        slack = 20 * np.sqrt(1e-7 * st.y_var * gs)
+        assert np.abs(G_ - target).max() < slack
     # state invariants at the end of the path (adelie/state.py:1563-1674)
     b = st.betas[-1].toarray().ravel()
     r = yc - (Xd @ b)

@@ -84,6 +84,7 @@ struct CdScalars { // one instance in device memory, read back by the host after
     int32_t status;
     int32_t n_delta; // number of (col, delta) entries produced for the residual update
     int32_t _pad;
+    int64_t dbg[8];  // cycle counters of the kernel's phases (only filled when built with -DAHIP_CD_PROFILE)
 };
 
 template <class T>
@@ -114,6 +115,42 @@ struct CdParams {
     int32_t max_group_size;
 };
 template <class T> void launch_cd(const CdParams<T>& p, hipStream_t s);
+
+// ---- block Gauss-Seidel form of a lasso CD pass (kernels_cd_block.hip) ---------------------------
+template <class T>
+struct CdBlkState { // device-resident scalars carried from block to block and read by the host once per pass
+    T rsq, resid_sum, cm;
+    int64_t n_updates;
+    int32_t active_size, status, nz, _pad;
+};
+template <class T>
+struct CdBlkParams {
+    int32_t nv;
+    const T* C;
+    int64_t ldc;
+    const T* vars;
+    const T* xmean;
+    const T* spen;
+    T* beta;
+    T* g;
+    int8_t* is_active;
+    int32_t* active_set;
+    T l1, l2;
+    int32_t max_active_size;
+    T* Dbuf;          // 2 * BLK * BLK
+    T* dlt;           // BLK
+    int32_t* didx;    // BLK
+    CdBlkState<T>* st;
+    const int32_t* list; // visiting list of the pass (nullptr: screen order 0..count-1)
+    int32_t count;
+    int32_t mark;
+};
+int cd_block_size();
+// enqueues one whole pass (gather, then solve/update per block); the host reads st afterwards
+template <class T> void launch_cd_block_pass(const CdBlkParams<T>& p, hipStream_t s);
+template <class T>
+void launch_cd_compact(const T* beta, const T* beta0, const int32_t* vcol, int nv, int32_t* dcols, T* dvals,
+                       int32_t* n_delta, hipStream_t s);
 
 // ---- GLM elementwise (solver_glm_naive.hpp:336-348, 439-449; glm_*.ipp) --------------------------
 template <class T>

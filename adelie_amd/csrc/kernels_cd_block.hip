@@ -1,0 +1,257 @@
+// kernels_cd_block.hip — block Gauss–Seidel form of the lasso coordinate-descent pass, spread over the whole chip.
+//
+// Same iteration as cd_lasso_kernel / cd_kernel (reference solver_gaussian_pin_naive.hpp:16-168, visiting order
+// preserved), reorganised so that a single CU's 62 GB/s HBM stream is no longer what a pass waits for.  The visiting
+// list of a pass (activation order, or screen order) is cut into blocks of B = 128 consecutive visits.  For block j
+//
+//   blk_solve_kernel   (ONE workgroup)  loads the B x B diagonal Gram block D_j (pre-gathered, contiguous) and the
+//                      block's g / beta / A / penalty into LDS, and one wavefront runs the B coordinate updates
+//                      strictly in order, keeping g_B current with  g_B -= D_j[:,i] * del_i  (LDS only, no barrier);
+//                      it emits the block's non-zero changes (index, del).
+//   blk_update_kernel  (nv/64 workgroups) applies those changes to every screen value,
+//                      g_r -= sum_m C[r, idx_m] * del_m,  streaming the touched Gram columns at full-chip bandwidth
+//                      (deterministic: fixed column order per row, 4-wave LDS reduction), and gathers D_{j+1}.
+//
+// Kernel boundaries on the stream are the only synchronisation (cheaper than any grid barrier on this chip, see
+// guides/MI355X_MICROARCH.md "boundary" vs "barrier-xcd").  The result is the same Gauss–Seidel sequence: inside a block
+// every coordinate sees all earlier changes of the block through D_j, across blocks through the update kernel.
+#include "kernels.hpp"
+
+namespace ahip {
+
+namespace {
+
+constexpr int BLK = 128; // visits per block
+
+typedef double cb_d2 __attribute__((ext_vector_type(2)));
+typedef float cb_f4 __attribute__((ext_vector_type(4)));
+template <class T> struct CbVec;
+template <> struct CbVec<double> { using type = cb_d2; static constexpr int N = 2; };
+template <> struct CbVec<float> { using type = cb_f4; static constexpr int N = 4; };
+
+template <class T>
+__device__ __forceinline__ int blk_index(const CdBlkParams<T>& p, int pos) {
+    return p.list ? p.list[pos] : pos;
+}
+
+// D_j[i + m*BLK] = C[idx_i + idx_m*ldc] for the block starting at list position j*BLK
+template <class T>
+__device__ __forceinline__ void gather_block(const CdBlkParams<T>& p, int j, int gtid, int gthreads) {
+    const int base = j * BLK;
+    const int nb = min(BLK, p.count - base);
+    if (nb <= 0) return;
+    T* D = p.Dbuf + size_t(j & 1) * BLK * BLK;
+    for (int e = gtid; e < nb * nb; e += gthreads) {
+        const int i = e % nb, m = e / nb;
+        const int64_t ri = blk_index(p, base + i), cm = blk_index(p, base + m);
+        D[i + m * BLK] = p.C[ri + cm * p.ldc];
+    }
+}
+
+template <class T>
+__global__ void blk_gather_kernel(CdBlkParams<T> p, int j) {
+    gather_block(p, j, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* D = reinterpret_cast<T*>(smem_raw);   // BLK*BLK
+    T* gB = D + BLK * BLK;
+    T* bB = gB + BLK;
+    T* AB = bB + BLK;
+    T* l1B = AB + BLK;
+    T* denB = l1B + BLK;
+    T* rdenB = denB + BLK;
+    T* xmB = rdenB + BLK;
+    T* dB = xmB + BLK;                        // net change of each coordinate of the block
+    int32_t* idxB = reinterpret_cast<int32_t*>(dB + BLK);
+    int32_t* actB = idxB + BLK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int base = j * BLK;
+    const int nb = min(BLK, p.count - base);
+
+    if (tid < BLK) {
+        const int i = tid;
+        if (i < nb) {
+            const int idx = blk_index(p, base + i);
+            const T A = p.vars[idx], pk = p.spen[idx];
+            const T den = A + p.l2 * pk;
+            idxB[i] = idx;
+            gB[i] = p.g[idx];
+            bB[i] = p.beta[idx];
+            AB[i] = A;
+            l1B[i] = p.l1 * pk;
+            denB[i] = den;
+            rdenB[i] = T(1) / den;
+            xmB[i] = p.xmean[idx];
+            actB[i] = p.is_active[idx];
+        } else {
+            idxB[i] = 0; gB[i] = 0; bB[i] = 0; AB[i] = 0; l1B[i] = 0; denB[i] = 1; rdenB[i] = 1; xmB[i] = 0; actB[i] = 1;
+        }
+        dB[i] = 0;
+    }
+    {
+        using V = typename CbVec<T>::type;
+        constexpr int VEC = CbVec<T>::N;
+        const V* src = reinterpret_cast<const V*>(p.Dbuf + size_t(j & 1) * BLK * BLK);
+        V* dst = reinterpret_cast<V*>(D);
+        for (int e = tid; e < BLK * BLK / VEC; e += 256) dst[e] = src[e];
+    }
+    __syncthreads();
+    if (wv != 0) return;
+
+    // ---- one wavefront: the block's visits, strictly in order ------------------------------------------------------
+    CdBlkState<T>* st = p.st;
+    T rsq = st->rsq, rsum = st->resid_sum, cm = (j == 0) ? T(0) : st->cm;
+    int asz = st->active_size, status = st->status;
+    int64_t n_upd = st->n_updates;
+    constexpr int EPL = BLK / 64; // g elements per lane
+    for (int i = 0; i < nb && status == CD_OK; ++i) {
+        const T gcur = gB[i];
+        const T bi = bB[i], A = AB[i];
+        const T gk = fma(bi, A, gcur);                    // pin_naive:85-89
+        const T v = fabs(gk) - l1B[i];                    // pin_base:181-195
+        T ak = T(0);
+        if (v > T(0)) {
+            const T x = copysign(v, gk);
+            const T den = denB[i], rden = rdenB[i];
+            const T q0 = x * rden;
+            const T r = fma(-q0, den, x);
+            ak = fma(r, rden, q0);
+        }
+        if (ak != bi) {                                   // pin_naive:97
+            const T del = ak - bi;
+            const T c1 = A * del * del;
+            cm = c1 > cm ? c1 : cm;                       // pin_base:112-122
+            rsq += del * (T(2) * gcur - del * A);         // pin_base:136-146
+            rsum -= xmB[i] * del;                         // pin_naive:107
+            if (p.mark && actB[i] == 0) {                 // add_active_set, pin_naive:294-304
+                if (asz >= p.max_active_size) { status = CD_MAX_ACTIVE; break; }
+                if (lane == 0) { actB[i] = 1; p.is_active[idxB[i]] = 1; p.active_set[asz] = idxB[i]; }
+                ++asz;
+            }
+            if (lane == 0) { bB[i] = ak; dB[i] += del; }
+            const T* Dc = D + i * BLK;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int l = lane * EPL + e;
+                gB[l] = fma(-del, Dc[l], gB[l]);
+            }
+            ++n_upd;
+        }
+    }
+    // ---- write back the block: beta, and the compacted non-zero changes for the update kernel ---------------------------
+    int nz = 0;
+    for (int i0 = 0; i0 < BLK; i0 += 64) {
+        const int i = i0 + lane;
+        const T d = (i < nb) ? dB[i] : T(0);
+        const bool ch = d != T(0);
+        if (ch) p.beta[idxB[i]] = bB[i];
+        const unsigned long long m = __ballot(ch);
+        const int pos = nz + __popcll(m & ((1ull << lane) - 1ull));
+        if (ch) { p.didx[pos] = idxB[i]; p.dlt[pos] = d; }
+        nz += __popcll(m);
+    }
+    if (lane == 0) {
+        st->rsq = rsq;
+        st->resid_sum = rsum;
+        st->cm = cm;
+        st->active_size = asz;
+        st->status = status;
+        st->n_updates = n_upd;
+        st->nz = nz;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void blk_update_kernel(CdBlkParams<T> p, int j) {
+    __shared__ T red[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nz = p.st->nz;
+    const int r = blockIdx.x * 64 + lane;
+    if (nz > 0) {
+        T acc = T(0);
+        if (r < p.nv) {
+            for (int m = wv; m < nz; m += 4) acc = fma(p.C[r + int64_t(p.didx[m]) * p.ldc], p.dlt[m], acc);
+        }
+        red[wv][lane] = acc;
+        __syncthreads();
+        if (wv == 0 && r < p.nv) p.g[r] -= ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+    }
+    // prefetch-gather of the next block's diagonal block while the chip is otherwise idle
+    gather_block(p, j + 1, blockIdx.x * 256 + tid, gridDim.x * 256);
+}
+
+// ordered compaction of beta - beta0 into the (design column, delta) list of the residual update
+template <class T>
+__global__ __launch_bounds__(1024) void cd_compact_kernel(const T* __restrict__ beta, const T* __restrict__ beta0,
+                                                          const int32_t* __restrict__ vcol, int nv,
+                                                          int32_t* __restrict__ dcols, T* __restrict__ dvals,
+                                                          int32_t* __restrict__ n_delta) {
+    constexpr int NT = 1024;
+    __shared__ int cnt[NT + 1];
+    const int tid = threadIdx.x;
+    const int chunk = (nv + NT - 1) / NT;
+    const int a0 = tid * chunk, a1 = min(nv, a0 + chunk);
+    int c = 0;
+    for (int a = a0; a < a1; ++a) c += (beta[a] != beta0[a]) ? 1 : 0;
+    cnt[tid + 1] = c;
+    if (tid == 0) cnt[0] = 0;
+    __syncthreads();
+    if (tid == 0)
+        for (int t = 1; t <= NT; ++t) cnt[t] += cnt[t - 1];
+    __syncthreads();
+    int o = cnt[tid];
+    for (int a = a0; a < a1; ++a) {
+        const T b1 = beta[a], b0 = beta0[a];
+        if (b1 != b0) { dcols[o] = vcol[a]; dvals[o] = b1 - b0; ++o; }
+    }
+    if (tid == 0) n_delta[0] = cnt[NT];
+}
+
+template <class T>
+size_t blk_solve_lds() {
+    return size_t(BLK) * BLK * sizeof(T) + size_t(BLK) * 8 * sizeof(T) + size_t(BLK) * 2 * sizeof(int32_t) + 16;
+}
+
+} // namespace
+
+int cd_block_size() { return BLK; }
+
+template <class T>
+void launch_cd_block_pass(const CdBlkParams<T>& p, hipStream_t s) {
+    if (p.count <= 0) return;
+    const int nblk = (p.count + BLK - 1) / BLK;
+    const unsigned ug = unsigned((p.nv + 63) / 64);
+    hipLaunchKernelGGL((blk_gather_kernel<T>), dim3(64), dim3(256), 0, s, p, 0);
+    static bool attr_done = false;
+    const size_t lds = blk_solve_lds<T>();
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk_solve_kernel<double>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(blk_solve_lds<double>()));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk_solve_kernel<float>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(blk_solve_lds<float>()));
+        attr_done = true;
+    }
+    for (int j = 0; j < nblk; ++j) {
+        hipLaunchKernelGGL((blk_solve_kernel<T>), dim3(1), dim3(256), lds, s, p, j);
+        hipLaunchKernelGGL((blk_update_kernel<T>), dim3(ug), dim3(256), 0, s, p, j);
+    }
+}
+
+template <class T>
+void launch_cd_compact(const T* beta, const T* beta0, const int32_t* vcol, int nv, int32_t* dcols, T* dvals,
+                       int32_t* n_delta, hipStream_t s) {
+    hipLaunchKernelGGL((cd_compact_kernel<T>), dim3(1), dim3(1024), 0, s, beta, beta0, vcol, nv, dcols, dvals, n_delta);
+}
+
+#define INST(T)                                                                                       \
+    template void launch_cd_block_pass<T>(const CdBlkParams<T>&, hipStream_t);                        \
+    template void launch_cd_compact<T>(const T*, const T*, const int32_t*, int, int32_t*, T*, int32_t*, hipStream_t);
+INST(double)
+INST(float)
+#undef INST
+
+} // namespace ahip

@@ -28,6 +28,16 @@ template <> struct CdVec<float> { using type = cd_f4; static constexpr int N = 4
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+#ifdef AHIP_CD_PROFILE
+#define CDP_DECL int64_t cdp[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int64_t cdp_t = __builtin_readcyclecounter();
+#define CDP_MARK(i) { const int64_t t_ = __builtin_readcyclecounter(); cdp[i] += t_ - cdp_t; cdp_t = t_; }
+#define CDP_STORE if (tid == 0) { for (int i_ = 0; i_ < 8; ++i_) p.sc->dbg[i_] = cdp[i_]; }
+#else
+#define CDP_DECL
+#define CDP_MARK(i)
+#define CDP_STORE
+#endif
+
 template <class T, int NT, int K, bool TAIL>
 __global__ __launch_bounds__(NT) void cd_lasso_kernel(CdParams<T> p) {
     using V = typename CdVec<T>::type;
@@ -51,6 +61,7 @@ __global__ __launch_bounds__(NT) void cd_lasso_kernel(CdParams<T> p) {
     const T l1 = p.lmda * p.alpha;
     const T l2 = p.lmda * (T(1) - p.alpha);
     const int64_t ldc = p.ldc;
+    CDP_DECL
 
     struct Slot {
         int ss;       // coordinate (-1: past the end of the list)
@@ -62,21 +73,16 @@ __global__ __launch_bounds__(NT) void cd_lasso_kernel(CdParams<T> p) {
     auto load_col = [&](int b, V (&col)[K]) {
         const T* __restrict__ Cc = p.C + int64_t(b) * ldc;
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int kk = k < kmax ? k : 0; // unused chunks re-read chunk 0 (cache hit), never applied
-            col[k] = *reinterpret_cast<const V*>(Cc + (kk * NT + tid) * VEC);
-        }
+        for (int k = 0; k < K; ++k) col[k] = *reinterpret_cast<const V*>(Cc + (k * NT + tid) * VEC);
     };
     auto apply_col = [&](int b, T del, const V (&col)[K]) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (k < kmax) { // uniform
-                const int a = (k * NT + tid) * VEC;
-                V g = *reinterpret_cast<V*>(gl + a);
+            const int a = (k * NT + tid) * VEC;
+            V g = *reinterpret_cast<V*>(gl + a);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) g[e] = fma(-del, col[k][e], g[e]);
-                *reinterpret_cast<V*>(gl + a) = g;
-            }
+            for (int e = 0; e < VEC; ++e) g[e] = fma(-del, col[k][e], g[e]);
+            *reinterpret_cast<V*>(gl + a) = g;
         }
         if (TAIL) { // chunks beyond the register-resident ones (nv > K*NT*VEC): on demand, 4 loads in flight
             const T* __restrict__ Cc = p.C + int64_t(b) * ldc;
@@ -120,6 +126,7 @@ __global__ __launch_bounds__(NT) void cd_lasso_kernel(CdParams<T> p) {
         // A visit is straight-line code apart from the (uniform) "changed" branch, which contains no global loads
         // except on the rare misprediction path: the compiler's vmcnt bookkeeping for the prefetched slots stays exact.
         auto visit = [&](Slot& s) {
+            CDP_MARK(0) // fetch issue + loop overhead
             const bool valid = s.ss >= 0;
             const int b = valid ? s.ss : 0;
             const T gcur = gl[b];
@@ -135,6 +142,7 @@ __global__ __launch_bounds__(NT) void cd_lasso_kernel(CdParams<T> p) {
                 ak = fma(r, rden, q0);
             }
             if (!valid) ak = s.beta;                         // padding visit past the end of the list: no-op
+            CDP_MARK(1) // g read + coefficient update (waits for the slot's scalar loads)
             if (ak != s.beta) {                              // pin_naive:97
                 const T del = ak - s.beta;
                 const T c1 = s.A * del * del;
@@ -145,6 +153,7 @@ __global__ __launch_bounds__(NT) void cd_lasso_kernel(CdParams<T> p) {
                 const bool full = add && asz >= p.max_active_size;
                 if (full) status = CD_MAX_ACTIVE;            // the host restores the pre-fit state on any error
                 lds_barrier(); // every wave has read gl[b] and act[b]
+                CDP_MARK(2) // barrier 1
                 if (tid == 0) {
                     p.beta[b] = ak;
                     if (add && !full) { act[b] = 1; p.is_active[b] = 1; p.active_set[asz] = b; }
@@ -157,7 +166,9 @@ __global__ __launch_bounds__(NT) void cd_lasso_kernel(CdParams<T> p) {
                     load_col(b, tmp);
                     apply_col(b, del, tmp);
                 }
+                CDP_MARK(3) // wait for the column + LDS update
                 lds_barrier();
+                CDP_MARK(4) // barrier 2
                 ++n_upd;
             }
         };
@@ -236,22 +247,41 @@ __global__ __launch_bounds__(NT) void cd_lasso_kernel(CdParams<T> p) {
         p.sc->status = status;
         p.sc->n_delta = cnt[NT];
     }
+    CDP_STORE
 }
 
 } // namespace
 
 // Returns false when the problem does not fit this specialisation (the caller then uses the generic kernel).
+// The kernel is instantiated per number of 512-lane x 16-byte chunks of g (K = 1..8, exactly the chunks in use: every
+// load instruction moves 8 KB through the CU's vector cache whether it hits or not, so none is issued in vain);
+// longer screen sets use K = 8 plus an on-demand tail.
+template <class T, int NT, int K>
+static void launch_k(const CdParams<T>& p, size_t bytes, bool tail, hipStream_t s) {
+    auto k = tail ? cd_lasso_kernel<T, NT, K, true> : cd_lasso_kernel<T, NT, K, false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
+    hipLaunchKernelGGL(k, dim3(1), dim3(NT), bytes, s, p);
+}
+
 template <class T>
 bool launch_cd_lasso(const CdParams<T>& p, hipStream_t s) {
     if (!(p.all_scalar && p.nv == p.ns)) return false;
-    constexpr int NT = 512, K = 8, VEC = 16 / sizeof(T);
+    constexpr int NT = 512, KMAX = 8, VEC = 16 / sizeof(T);
     const size_t lds_cap = 150 * 1024; // of the 160 KiB per CU (static arrays take a few KiB)
     const size_t nvp = size_t((p.nv + NT * VEC - 1) / (NT * VEC)) * (NT * VEC);
     const size_t bytes = nvp * sizeof(T) + size_t(p.ns) + 16;
     if (bytes > lds_cap || int64_t(nvp) > p.ldc) return false;
-    auto k = (nvp <= size_t(K) * NT * VEC) ? cd_lasso_kernel<T, NT, K, false> : cd_lasso_kernel<T, NT, K, true>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
-    hipLaunchKernelGGL(k, dim3(1), dim3(NT), bytes, s, p);
+    const int kmax = int(nvp / (NT * VEC));
+    switch (kmax < KMAX ? kmax : KMAX) {
+        case 1: launch_k<T, NT, 1>(p, bytes, false, s); break;
+        case 2: launch_k<T, NT, 2>(p, bytes, false, s); break;
+        case 3: launch_k<T, NT, 3>(p, bytes, false, s); break;
+        case 4: launch_k<T, NT, 4>(p, bytes, false, s); break;
+        case 5: launch_k<T, NT, 5>(p, bytes, false, s); break;
+        case 6: launch_k<T, NT, 6>(p, bytes, false, s); break;
+        case 7: launch_k<T, NT, 7>(p, bytes, false, s); break;
+        default: launch_k<T, NT, 8>(p, bytes, kmax > KMAX, s); break;
+    }
     return true;
 }
 

@@ -9,11 +9,13 @@
 // This is the one true GEMM on the path (K = n = 1e5..5e5, M,N = screen values), so it runs on MFMA:
 //   f64: v_mfma_f64_16x16x4_f64   (A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D col=l&15,row=(l>>4)+4*reg)
 //   f32: v_mfma_f32_16x16x4_f32   (same A/B maps,                         D col=l&15,row=(l>>4)*4+reg)
-// Tiling: a 256-thread block (4 waves, 2x2) owns a 64x64 output tile and one K-split; each wave owns 32x32 =
-// 2x2 MFMA tiles.  Column panels are K-contiguous in HBM (column-major X), so a stage is 64 columns x 32 rows:
-// every thread brings 8 consecutive rows of one column (64 B, coalesced in 256-B runs), the B panel is scaled by
-// w on the way into LDS, and fragments are read back with ds_read_b64 from rows padded to 34 elements (conflict
-// free for the 16x4 fragment shape).  Global loads for stage t+1 are issued before the MFMAs of stage t.
+// Tiling: a 256-thread block (4 waves) owns a 128 x {64,128} output tile and one K-split; each wave owns 64x64 (or
+// 32x64) = 4x4 (2x4) MFMA tiles, so one pair of LDS fragment reads feeds 16 (8) MFMAs.  The N tile is as wide as the
+// batch of new screen columns allows (<= 128) so that the M-side panel - the whole screen set, the bulk of the bytes
+// - is read once per launch.  Column panels are K-contiguous in HBM (column-major X), so a stage is (128+BN) columns x
+// 32 rows: every thread brings 16 (8) consecutive rows of one column (128 B runs), fragments are read back with
+// ds_read_b64 from rows padded to 34 elements (conflict free for the 16x4 fragment shape), the weights of the stage
+// sit in LDS and scale the B fragment.  Global loads for stage t+1 are issued before the MFMAs of stage t.
 // K-splits write partial tiles; a second kernel sums them (deterministic), centres, and writes C symmetrically.
 #include "kernels.hpp"
 #include "accessors.hpp"
@@ -22,7 +24,7 @@ namespace ahip {
 
 namespace {
 
-constexpr int BM = 64, BN = 64, KT = 32, LDK = KT + 2, GT = 256;
+constexpr int BM = 128, KT = 32, LDK = KT + 2, GT = 256;
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef float f4v_t __attribute__((ext_vector_type(4)));
@@ -43,105 +45,114 @@ template <> struct Mfma<float> {
     static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) * 4 + reg; }
 };
 
-// Loads 8 consecutive rows [k, k+8) of column j (zero beyond kend), optionally scaled by w.
-template <class T, class Acc, bool VECOK>
-__device__ __forceinline__ void load8(const Acc& X, int64_t j, bool valid, int64_t k, int64_t kend, T (&r)[8]) {
+// Loads R consecutive rows [k, k+R) of column j (zero beyond kend / for an invalid column).
+template <class T, class Acc, bool VECOK, int R>
+__device__ __forceinline__ void load_rows(const Acc& X, int64_t j, bool valid, int64_t k, int64_t kend, T (&r)[R]) {
     if (!valid || k >= kend) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = T(0);
+        for (int e = 0; e < R; ++e) r[e] = T(0);
         return;
     }
     auto cp = X.colptr(j);
     constexpr int V = VecOf<T>::N;
-    if (VECOK && k + 8 <= kend) {
+    if (VECOK && k + R <= kend) {
 #pragma unroll
-        for (int u = 0; u < 8 / V; ++u) {
+        for (int u = 0; u < R / V; ++u) {
             const Pack<T, V> x = X.template load<V>(cp, k + u * V, j);
 #pragma unroll
             for (int e = 0; e < V; ++e) r[u * V + e] = x.v[e];
         }
     } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = (k + e < kend) ? X.template load<1>(cp, k + e, j).v[0] : T(0);
+        for (int e = 0; e < R; ++e) r[e] = (k + e < kend) ? X.template load<1>(cp, k + e, j).v[0] : T(0);
     }
 }
 
-template <class T, class Acc, bool VECOK>
-__global__ __launch_bounds__(GT) void gram_kernel(Acc X, const T* __restrict__ w, const int32_t* __restrict__ mcols,
+// Block tile BM x BN = 128 x {64,128}; 4 waves: 2x2 of 64x64 (BN=128) or 4x1 of 32x64 (BN=64).
+template <class T, class Acc, bool VECOK, int BN>
+__global__ __launch_bounds__(GT, 2) void gram_kernel(Acc X, const T* __restrict__ w, const int32_t* __restrict__ mcols,
                                                   int32_t M, const int32_t* __restrict__ ncols, int32_t N, int64_t n,
                                                   int64_t kchunk, int32_t m_pos0, int32_t n_pos0, int symmetric,
                                                   T* __restrict__ part, int64_t Mpad, int64_t Npad) {
+    constexpr int WN = BN / 64;            // waves along N
+    constexpr int WM = 4 / WN;             // waves along M
+    constexpr int TM = BM / WM / 16;       // MFMA tiles per wave along M (4 or 2)
+    constexpr int TN = 4;                  // 64 columns per wave along N
+    constexpr int RA = KT * BM / GT;       // rows of one A column staged per thread (16)
+    constexpr int RB = KT * BN / GT;       // rows of one B column staged per thread (16 or 8)
     const int bm = blockIdx.x, bn = blockIdx.y, sp = blockIdx.z;
-    // symmetric call (same column list on both sides): only the lower block triangle is needed
-    // (tile rows lie inside the new x new square and entirely above its diagonal; the reduce kernel mirrors)
+    // symmetric call (same column list on both sides): tiles that lie inside the new x new square and entirely above
+    // its diagonal are skipped; the reduce kernel mirrors them from the lower triangle
     if (symmetric && (m_pos0 + bm * BM >= n_pos0) && (m_pos0 + (bm + 1) * BM <= n_pos0 + bn * BN)) return;
 
     __shared__ T As[BM * LDK];
     __shared__ T Bs[BN * LDK];
+    __shared__ T Ws[KT];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
+    const int wm = wv / WN, wn = wv % WN;
     const int64_t k0 = int64_t(sp) * kchunk;
     const int64_t kend = min(n, k0 + kchunk);
 
-    // staging role: column (tid>>2) of the tile, rows (tid&3)*8 .. +8 of the stage
-    const int sc = tid >> 2, sr = (tid & 3) * 8;
-    const int am = bm * BM + sc, bnn = bn * BN + sc;
+    // staging roles
+    const int sca = tid / (KT / RA), sra = (tid % (KT / RA)) * RA;
+    const int scb = tid / (KT / RB), srb = (tid % (KT / RB)) * RB;
+    const int am = bm * BM + sca, bnn = bn * BN + scb;
     const bool a_ok = am < M, b_ok = bnn < N;
     const int64_t ja = a_ok ? int64_t(mcols[am]) : 0;
     const int64_t jb = b_ok ? int64_t(ncols[bnn]) : 0;
 
-    typename Mfma<T>::acc_t acc[2][2];
+    typename Mfma<T>::acc_t acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][e] = T(0);
 
-    T ra[8], rb[8], rw[8];
+    T ra[RA], rb[RB], rw = T(0);
     auto fetch = [&](int64_t k) {
-        load8<T, Acc, VECOK>(X, ja, a_ok, k + sr, kend, ra);
-        load8<T, Acc, VECOK>(X, jb, b_ok, k + sr, kend, rb);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) rw[e] = (k + sr + e < kend) ? w[k + sr + e] : T(0);
+        load_rows<T, Acc, VECOK, RA>(X, ja, a_ok, k + sra, kend, ra);
+        load_rows<T, Acc, VECOK, RB>(X, jb, b_ok, k + srb, kend, rb);
+        if (tid < KT) rw = (k + tid < kend) ? w[k + tid] : T(0);
     };
 
     if (k0 < kend) fetch(k0);
+    const int fr = (lane & 15), fk = (lane >> 4);
     for (int64_t k = k0; k < kend; k += KT) {
         __syncthreads(); // previous stage fully consumed
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            As[sc * LDK + sr + e] = ra[e];
-            Bs[sc * LDK + sr + e] = rb[e] * rw[e];
-        }
+        for (int e = 0; e < RA; ++e) As[sca * LDK + sra + e] = ra[e];
+#pragma unroll
+        for (int e = 0; e < RB; ++e) Bs[scb * LDK + srb + e] = rb[e];
+        if (tid < KT) Ws[tid] = rw;
         __syncthreads();
         if (k + KT < kend) fetch(k + KT); // in flight while the MFMAs run
-        const int fr = (lane & 15), fk = (lane >> 4);
 #pragma unroll
         for (int kk = 0; kk < KT / 4; ++kk) {
-            T a[2], b[2];
+            T a[TM], b[TN];
+            const T wk = Ws[kk * 4 + fk];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[(wm * 32 + i * 16 + fr) * LDK + kk * 4 + fk];
+            for (int i = 0; i < TM; ++i) a[i] = As[(wm * (BM / WM) + i * 16 + fr) * LDK + kk * 4 + fk];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[(wn * 32 + j * 16 + fr) * LDK + kk * 4 + fk];
+            for (int j = 0; j < TN; ++j) b[j] = Bs[(wn * 64 + j * 16 + fr) * LDK + kk * 4 + fk] * wk;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
         }
     }
 
     // partial tile -> part[sp][col][row]  (col = N index, row = M index)
     T* P = part + int64_t(sp) * Mpad * Npad;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int row = bm * BM + wm * 32 + i * 16 + Mfma<T>::row(lane, e);
-                const int col = bn * BN + wn * 32 + j * 16 + (lane & 15);
+                const int row = bm * BM + wm * (BM / WM) + i * 16 + Mfma<T>::row(lane, e);
+                const int col = bn * BN + wn * 64 + j * 16 + (lane & 15);
                 P[int64_t(col) * Mpad + row] = acc[i][j][e];
             }
 }
@@ -165,15 +176,18 @@ __global__ void gram_reduce_kernel(const T* __restrict__ part, int nsplit, int64
     if (symmetric) C[cp + rp * ldc] = s;
 }
 
+inline int gram_bn(int64_t N) { return N <= 64 ? 64 : 128; }
+
 inline void gram_shape(int64_t n, int64_t M, int64_t N, int64_t& Mt, int64_t& Nt, int& nsplit, int64_t& kchunk) {
+    const int bn = gram_bn(N);
     Mt = (M + BM - 1) / BM;
-    Nt = (N + BN - 1) / BN;
+    Nt = (N + bn - 1) / bn;
     const int64_t tiles = Mt * Nt;
-    int64_t want = (1024 + tiles - 1) / tiles;
+    int64_t want = (768 + tiles - 1) / tiles;
     const int64_t max_split = (n + KT * 8 - 1) / (KT * 8);
     if (want > max_split) want = max_split;
     // bound the partial buffer (<= 2^28 elements)
-    const int64_t cap = (int64_t(1) << 28) / (Mt * BM * Nt * BN);
+    const int64_t cap = (int64_t(1) << 28) / (Mt * BM * Nt * bn);
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     kchunk = (n + want - 1) / want;
@@ -191,17 +205,21 @@ void gram_launch(Acc acc, bool vecok, const T* w, const int32_t* mcols, int32_t 
     int64_t Mt, Nt, kchunk;
     int nsplit;
     gram_shape(n, M, N, Mt, Nt, nsplit, kchunk);
-    const int64_t Mpad = Mt * BM, Npad = Nt * BN;
+    const int bn = gram_bn(N);
+    const int64_t Mpad = Mt * BM, Npad = Nt * bn;
     // "symmetric": the N list is the tail (or all) of the M list at the same positions -> skip tiles that lie
     // entirely above the diagonal of the (new x new) square; the reduce kernel mirrors them.
     const int symmetric = (mcols + (n_pos0 - m_pos0) == ncols && m_pos0 + M == n_pos0 + N && n_pos0 >= m_pos0) ? 1 : 0;
     dim3 grid((unsigned)Mt, (unsigned)Nt, (unsigned)nsplit);
-    if (vecok)
-        hipLaunchKernelGGL((gram_kernel<T, Acc, true>), grid, dim3(GT), 0, s, acc, w, mcols, M, ncols, N, n, kchunk,
-                           m_pos0, n_pos0, symmetric, work, Mpad, Npad);
-    else
-        hipLaunchKernelGGL((gram_kernel<T, Acc, false>), grid, dim3(GT), 0, s, acc, w, mcols, M, ncols, N, n, kchunk,
-                           m_pos0, n_pos0, symmetric, work, Mpad, Npad);
+#define AHIP_GRAM_LAUNCH(VOK, BNV)                                                                                     \
+    hipLaunchKernelGGL((gram_kernel<T, Acc, VOK, BNV>), grid, dim3(GT), 0, s, acc, w, mcols, M, ncols, N, n, kchunk,    \
+                       m_pos0, n_pos0, symmetric, work, Mpad, Npad)
+    if (vecok) {
+        if (bn == 64) AHIP_GRAM_LAUNCH(true, 64); else AHIP_GRAM_LAUNCH(true, 128);
+    } else {
+        if (bn == 64) AHIP_GRAM_LAUNCH(false, 64); else AHIP_GRAM_LAUNCH(false, 128);
+    }
+#undef AHIP_GRAM_LAUNCH
     hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3((unsigned)((M + 255) / 256), (unsigned)N), dim3(256), 0, s, work,
                        nsplit, Mpad, Npad, M, N, mcols, ncols, m_pos0, n_pos0, xm, center ? 1 : 0, symmetric, C, ldc);
 }
@@ -213,7 +231,7 @@ int64_t gram_work_elems(int64_t n, int64_t M, int64_t N) {
     int64_t Mt, Nt, kchunk;
     int nsplit;
     gram_shape(n, M, N, Mt, Nt, nsplit, kchunk);
-    return int64_t(nsplit) * Mt * BM * Nt * BN;
+    return int64_t(nsplit) * Mt * BM * Nt * gram_bn(N);
 }
 
 template <class T>

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <numeric>
 #include <unordered_set>
@@ -209,6 +210,7 @@ struct Solver {
     std::vector<int> n_valid_solutions, active_sizes, screen_sizes;
     Counters cnt;
     KTimer t_sweep, t_gram, t_cd, t_axpy;
+    int64_t cd_dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double t_host_screen = 0;
     std::string error;
     double total_time = 0;
@@ -228,6 +230,10 @@ struct Solver {
     idx ldc = 0, gcap = 0;
     idx gram_nv = 0; // number of screen values whose Gram rows/cols are valid (for the current weights)
     DevBuf<CdScalars<T>> d_sc;
+    DevBuf<CdBlkState<T>> d_blk;
+    DevBuf<T> d_Dbuf, d_dlt;
+    DevBuf<int32_t> d_didx;
+    int64_t cd_block_min_nv = 1024; // screen sets at least this large use the multi-CU block passes
     DevBuf<T> d_work_sweep, d_work_gram;
     bool grad_valid = false; // d_grad == X^T W r - rsum*xbar for the current r
     // glm device vectors
@@ -542,6 +548,76 @@ struct Solver {
     }
 
     // ---------------------------------------------------------------------------------------------------------
+    // Lasso pin solve as a sequence of block passes spread over the chip (kernels_cd_block.hip).  The pass structure
+    // (solve_active until convergence, one screen pass, repeat; pin_naive:317-357) is driven from the host, which reads
+    // one small scalar block per pass.  Fills `sc` like the single-workgroup kernel does.
+    void run_block_passes(const CdParams<T>& cp, CdScalars<T>& sc) {
+        const int B = cd_block_size();
+        d_blk.reserve(1);
+        d_Dbuf.reserve(size_t(2) * B * B);
+        d_dlt.reserve(B);
+        d_didx.reserve(B);
+        CdBlkState<T> bs{};
+        bs.rsq = sc.rsq;
+        bs.resid_sum = sc.resid_sum;
+        bs.cm = 0;
+        bs.n_updates = 0;
+        bs.active_size = sc.active_size;
+        bs.status = CD_OK;
+        d_blk.upload(&bs, 1, st);
+        CdBlkParams<T> bp{};
+        bp.nv = cp.nv; bp.C = cp.C; bp.ldc = cp.ldc; bp.vars = cp.vars; bp.xmean = cp.xmean; bp.spen = cp.spen;
+        bp.beta = cp.beta; bp.g = cp.g; bp.is_active = cp.is_active; bp.active_set = cp.active_set;
+        bp.l1 = cp.lmda * cp.alpha; bp.l2 = cp.lmda * (T(1) - cp.alpha);
+        bp.max_active_size = cp.max_active_size;
+        bp.Dbuf = d_Dbuf.p; bp.dlt = d_dlt.p; bp.didx = d_didx.p; bp.st = d_blk.p;
+        int64_t iters = 0;
+        int status = CD_OK;
+        int asz = sc.active_size;
+        auto pass = [&](const int32_t* list, int count, bool mark) -> T {
+            if (count <= 0) return T(0);
+            bp.list = list; bp.count = count; bp.mark = mark ? 1 : 0;
+            t_cd.begin(st);
+            launch_cd_block_pass<T>(bp, st);
+            t_cd.end(st);
+            d_blk.download(&bs, 1, st);
+            sync();
+            status = bs.status;
+            asz = bs.active_size;
+            return bs.cm;
+        };
+        while (status == CD_OK) {
+            while (status == CD_OK) { // solve_active, pin_naive:173-215
+                ++iters;
+                ++sc.n_passes_active;
+                sc.n_visits_active += asz;
+                const T cm = pass(cp.active_set, asz, false);
+                if (status != CD_OK) break;
+                if (cm < cp.tol) break;
+                if (iters >= cp.max_iters) { status = CD_MAX_CDS; break; }
+            }
+            if (status != CD_OK) break;
+            ++iters;
+            ++sc.n_passes_screen;
+            sc.n_visits_screen += cp.nv;
+            const T cm = pass(nullptr, cp.nv, true);
+            if (status != CD_OK) break;
+            if (cm < cp.tol) break;
+            if (iters >= cp.max_iters) { status = CD_MAX_CDS; break; }
+        }
+        sc.rsq = bs.rsq;
+        sc.resid_sum = bs.resid_sum;
+        sc.iters = iters;
+        sc.n_updates = bs.n_updates;
+        sc.active_size = asz;
+        sc.status = status;
+        // (column, delta) list of the residual update + the device copy of resid_sum for the sweep epilogue
+        launch_cd_compact<T>(cp.beta, cp.beta0, cp.vcol, cp.nv, cp.dcols, cp.dvals, &cp.sc->n_delta, st);
+        AHIP_CHECK(hipMemcpyAsync(&sc.n_delta, &cp.sc->n_delta, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        sync();
+    }
+
+    // ---------------------------------------------------------------------------------------------------------
     // One pin solve on the device (solver_gaussian_pin_naive.hpp:217-401 for a single lambda).
     // Preconditions: Gram/vars/sxm valid for [0,nv) under the weights in use; d_g holds the current gradient of the
     // screen values; d_beta the current coefficients.  On success the residual `r_dev` is updated.
@@ -589,13 +665,17 @@ struct Solver {
         cp.max_group_size = int32_t(max_gs);
         Stopwatch sw;
         sw.start();
-        if (nv > 0) {
-            t_cd.begin(st);
-            launch_cd<T>(cp, st);
-            t_cd.end(st);
+        if (nv > 0 && all_scalar && nv >= cd_block_min_nv) {
+            run_block_passes(cp, sc);
+        } else {
+            if (nv > 0) {
+                t_cd.begin(st);
+                launch_cd<T>(cp, st);
+                t_cd.end(st);
+            }
+            d_sc.download(&sc, 1, st);
+            sync();
         }
-        d_sc.download(&sc, 1, st);
-        sync();
         const double t_cd = sw.elapsed();
         if (nv == 0) {
             sc.status = CD_OK;
@@ -606,6 +686,7 @@ struct Solver {
         cnt.n_updates += sc.n_updates;
         cnt.n_cd_passes_screen += sc.n_passes_screen;
         cnt.n_cd_passes_active += sc.n_passes_active;
+        for (int i = 0; i < 8; ++i) cd_dbg[i] += sc.dbg[i];
         if (sc.status != CD_OK) {
             // restore the pre-fit invariants (solver_gaussian_naive.hpp:286-290,326-329)
             AHIP_CHECK(hipMemcpyAsync(d_beta.p, d_beta0.p, size_t(nv) * sizeof(T), hipMemcpyDeviceToDevice, st));
@@ -1040,6 +1121,7 @@ struct Solver {
             if (i < 0 || i >= G) throw make_core_error("screen_set contains an out-of-range group index.");
 
         AHIP_CHECK(hipSetDevice(X->device));
+        if (const char* e = std::getenv("ADELIE_HIP_CD_BLOCK_MIN_NV")) cd_block_min_nv = std::atoll(e); // test hook
         // device allocations
         d_r.reserve(n); d_v.reserve(n); d_grad.reserve(p); d_absgrad.reserve(G); d_penalty.reserve(G);
         d_groups.reserve(G); d_gsizes.reserve(G); d_slot.reserve(G);
@@ -1240,6 +1322,7 @@ struct Result : ResultBase {
             case ADELIE_HIP_S_N_SWEEP_LAUNCHES: return double(s.t_sweep.launches);
             case ADELIE_HIP_S_N_GRAM_LAUNCHES: return double(s.t_gram.launches);
             case ADELIE_HIP_S_T_HOST_SCREEN_MS: return 1e3 * s.t_host_screen;
+            default: if (which >= 900 && which < 908) return double(s.cd_dbg[which - 900]);
         }
         return std::numeric_limits<double>::quiet_NaN();
     }

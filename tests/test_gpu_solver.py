@@ -194,3 +194,23 @@ def test_caller_state_untouched_and_result_surface(hip):
         assert hasattr(st, name), name
     assert st.betas.shape == (10, 30) and st.betas.indices.dtype in (np.int32, np.int64)
     assert st.screen_is_active.dtype == bool and st.active_set.shape == (30,)
+
+
+@pytest.mark.parametrize("n,p,alpha", [(400, 300, 1.0), (1500, 700, 0.6)])
+def test_block_cd_passes_match_oracle(hip, oracle, monkeypatch, n, p, alpha):
+    """Forces the multi-CU block Gauss-Seidel passes (kernels_cd_block.hip) at sizes the oracle checks in seconds:
+    several 128-visit blocks per pass, ragged last block, active-set growth inside screen passes."""
+    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    d = make_gaussian(n, p, seed=11, sparsity=0.5, weights=True)
+    kw = dict(alpha=alpha, tol=1e-10, early_exit=False, lmda_path_size=25, min_ratio=1e-2)
+    a, b = _both(oracle, d, lambda: ad.glm.gaussian(d["y"], weights=d["weights"]), **kw)
+    assert_same_path(a, b, 1e-6)
+    assert a.active_set_size > 128
+    assert abs(a.counters["n_updates"] - b.counters["n_updates"]) <= 0.01 * b.counters["n_updates"]
+    # (the oracle also counts the empty active pass of fits with an empty screen set; the device skips those fits)
+    assert abs(a.counters["n_cd_passes_active"] - b.counters["n_cd_passes_active"]) <= 8
+    # errors keep working through the block path
+    e1 = ad.grpnet(ad.matrix.dense(d["X"]), ad.glm.gaussian(d["y"]), max_active_size=5, early_exit=False)
+    assert e1.error == "adelie_core solver: Maximum number of active groups reached."
+    e2 = ad.grpnet(ad.matrix.dense(d["X"]), ad.glm.gaussian(d["y"]), max_iters=3, early_exit=False)
+    assert e2.error.startswith("adelie_core solver: max coordinate descents")

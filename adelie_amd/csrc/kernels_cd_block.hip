@@ -107,41 +107,62 @@ __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j)
     T rsq = st->rsq, rsum = st->resid_sum, cm = (j == 0) ? T(0) : st->cm;
     int asz = st->active_size, status = st->status;
     int64_t n_upd = st->n_updates;
-    constexpr int EPL = BLK / 64; // g elements per lane
-    for (int i = 0; i < nb && status == CD_OK; ++i) {
-        const T gcur = gB[i];
-        const T bi = bB[i], A = AB[i];
-        const T gk = fma(bi, A, gcur);                    // pin_naive:85-89
-        const T v = fabs(gk) - l1B[i];                    // pin_base:181-195
-        T ak = T(0);
-        if (v > T(0)) {
-            const T x = copysign(v, gk);
-            const T den = denB[i], rden = rdenB[i];
-            const T q0 = x * rden;
-            const T r = fma(-q0, den, x);
-            ak = fma(r, rden, q0);
-        }
-        if (ak != bi) {                                   // pin_naive:97
-            const T del = ak - bi;
-            const T c1 = A * del * del;
-            cm = c1 > cm ? c1 : cm;                       // pin_base:112-122
-            rsq += del * (T(2) * gcur - del * A);         // pin_base:136-146
-            rsum -= xmB[i] * del;                         // pin_naive:107
-            if (p.mark && actB[i] == 0) {                 // add_active_set, pin_naive:294-304
-                if (asz >= p.max_active_size) { status = CD_MAX_ACTIVE; break; }
-                if (lane == 0) { actB[i] = 1; p.is_active[idxB[i]] = 1; p.active_set[asz] = idxB[i]; }
-                ++asz;
-            }
-            if (lane == 0) { bB[i] = ak; dB[i] += del; }
-            const T* Dc = D + i * BLK;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const int l = lane * EPL + e;
-                gB[l] = fma(-del, Dc[l], gB[l]);
-            }
-            ++n_upd;
-        }
+    // Lane l keeps coordinates l and l+64 of the block in registers (g and the per-coordinate constants); a visit reads
+    // its operands with v_readlane (uniform lane index), so the dependent chain of a visit is register-only:
+    // readlane g_i -> soft-threshold -> fma into the two g registers.  The D column comes from LDS (2 x ds_read_b64,
+    // address independent of the chain).
+    static_assert(BLK == 128, "two coordinates per lane");
+    T g0 = gB[lane], g1 = gB[lane + 64];
+    const T b0 = bB[lane], b1 = bB[lane + 64];
+    const T A0 = AB[lane], A1 = AB[lane + 64];
+    const T L0 = l1B[lane], L1 = l1B[lane + 64];
+    const T N0 = denB[lane], N1 = denB[lane + 64];
+    const T R0 = rdenB[lane], R1 = rdenB[lane + 64];
+    const T X0 = xmB[lane], X1 = xmB[lane + 64];
+    const int a0 = actB[lane], a1 = actB[lane + 64];
+    T nb0 = b0, nb1 = b1; // new coefficients of this lane's two coordinates
+#define AHIP_BLK_VISIT(GREG, BREG, AREG, LREG, NREG, RREG, XREG, ACTREG, NBREG, IL)                                   \
+    {                                                                                                                  \
+        const T gcur = __shfl(GREG, IL, 64);                                                                           \
+        const T bi = __shfl(BREG, IL, 64), A = __shfl(AREG, IL, 64);                                                   \
+        const T gk = fma(bi, A, gcur);                    /* pin_naive:85-89 */                                       \
+        const T v = fabs(gk) - __shfl(LREG, IL, 64);      /* pin_base:181-195 */                                      \
+        T ak = T(0);                                                                                                   \
+        if (v > T(0)) {                                                                                                \
+            const T x = copysign(v, gk);                                                                               \
+            const T den = __shfl(NREG, IL, 64), rden = __shfl(RREG, IL, 64);                                           \
+            const T q0 = x * rden;                                                                                     \
+            const T r = fma(-q0, den, x);                                                                              \
+            ak = fma(r, rden, q0);                                                                                     \
+        }                                                                                                              \
+        if (ak != bi) {                                   /* pin_naive:97 */                                          \
+            const T del = ak - bi;                                                                                     \
+            const T c1 = A * del * del;                                                                                \
+            cm = c1 > cm ? c1 : cm;                       /* pin_base:112-122 */                                      \
+            rsq += del * (T(2) * gcur - del * A);         /* pin_base:136-146 */                                      \
+            rsum -= __shfl(XREG, IL, 64) * del;           /* pin_naive:107 */                                         \
+            if (p.mark && __shfl(ACTREG, IL, 64) == 0) {  /* add_active_set, pin_naive:294-304 */                     \
+                if (asz >= p.max_active_size) { status = CD_MAX_ACTIVE; break; }                                       \
+                if (lane == 0) { p.is_active[idxB[i]] = 1; p.active_set[asz] = idxB[i]; }                              \
+                ++asz;                                                                                                 \
+            }                                                                                                          \
+            if (lane == (IL)) NBREG = ak;                                                                              \
+            const T* Dc = D + i * BLK;                                                                                 \
+            g0 = fma(-del, Dc[lane], g0);                                                                              \
+            g1 = fma(-del, Dc[lane + 64], g1);                                                                         \
+            ++n_upd;                                                                                                   \
+        }                                                                                                              \
     }
+    {
+        const int n0 = nb < 64 ? nb : 64;
+        for (int i = 0; i < n0; ++i) AHIP_BLK_VISIT(g0, b0, A0, L0, N0, R0, X0, a0, nb0, i)
+        if (status == CD_OK)
+            for (int i = 64; i < nb; ++i) AHIP_BLK_VISIT(g1, b1, A1, L1, N1, R1, X1, a1, nb1, i - 64)
+    }
+#undef AHIP_BLK_VISIT
+    // net changes of the block (a coordinate is visited once per pass, so delta = new - old)
+    bB[lane] = nb0; bB[lane + 64] = nb1;
+    dB[lane] = nb0 - b0; dB[lane + 64] = nb1 - b1;
     // ---- write back the block: beta, and the compacted non-zero changes for the update kernel ---------------------------
     int nz = 0;
     for (int i0 = 0; i0 < BLK; i0 += 64) {

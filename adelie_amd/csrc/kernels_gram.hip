@@ -73,17 +73,32 @@ template <class T, class Acc, bool VECOK, int BN>
 __global__ __launch_bounds__(GT, 2) void gram_kernel(Acc X, const T* __restrict__ w, const int32_t* __restrict__ mcols,
                                                   int32_t M, const int32_t* __restrict__ ncols, int32_t N, int64_t n,
                                                   int64_t kchunk, int32_t m_pos0, int32_t n_pos0, int symmetric,
-                                                  T* __restrict__ part, int64_t Mpad, int64_t Npad) {
+                                                  T* __restrict__ part, int64_t Mpad, int64_t Npad, int32_t ncol0,
+                                                  int32_t Mt, int32_t Nt, int32_t nsplit) {
     constexpr int WN = BN / 64;            // waves along N
     constexpr int WM = 4 / WN;             // waves along M
     constexpr int TM = BM / WM / 16;       // MFMA tiles per wave along M (4 or 2)
     constexpr int TN = 4;                  // 64 columns per wave along N
     constexpr int RA = KT * BM / GT;       // rows of one A column staged per thread (16)
     constexpr int RB = KT * BN / GT;       // rows of one B column staged per thread (16 or 8)
-    const int bm = blockIdx.x, bn = blockIdx.y, sp = blockIdx.z;
+    // XCD-aware block -> tile map: workgroup L runs on XCD L % 8 (guides/MI355X_MICROARCH.md).  The Nt tiles that share
+    // one (M tile, K split) - i.e. the same A panel, the bulk of the bytes - get ids L, L+8, ..., so they run on the same
+    // XCD at about the same time and the panel is fetched from HBM once and re-read from that XCD's L2.
+    int bm, bn, sp;
+    {
+        const int64_t L = blockIdx.x;
+        const int64_t npair = int64_t(Mt) * nsplit;          // (bm, sp) pairs
+        const int64_t grp = L / (8 * int64_t(Nt));            // group of 8 pairs
+        const int64_t rem = L % (8 * int64_t(Nt));
+        const int64_t pair = grp * 8 + (rem % 8);
+        bn = int(rem / 8);
+        if (pair >= npair) return;
+        bm = int(pair % Mt);
+        sp = int(pair / Mt);
+    }
     // symmetric call (same column list on both sides): tiles that lie inside the new x new square and entirely above
     // its diagonal are skipped; the reduce kernel mirrors them from the lower triangle
-    if (symmetric && (m_pos0 + bm * BM >= n_pos0) && (m_pos0 + (bm + 1) * BM <= n_pos0 + bn * BN)) return;
+    if (symmetric && (m_pos0 + bm * BM >= n_pos0) && (m_pos0 + (bm + 1) * BM <= n_pos0 + ncol0 + bn * BN)) return;
 
     __shared__ T As[BM * LDK];
     __shared__ T Bs[BN * LDK];
@@ -97,7 +112,7 @@ __global__ __launch_bounds__(GT, 2) void gram_kernel(Acc X, const T* __restrict_
     // staging roles
     const int sca = tid / (KT / RA), sra = (tid % (KT / RA)) * RA;
     const int scb = tid / (KT / RB), srb = (tid % (KT / RB)) * RB;
-    const int am = bm * BM + sca, bnn = bn * BN + scb;
+    const int am = bm * BM + sca, bnn = ncol0 + bn * BN + scb;
     const bool a_ok = am < M, b_ok = bnn < N;
     const int64_t ja = a_ok ? int64_t(mcols[am]) : 0;
     const int64_t jb = b_ok ? int64_t(ncols[bnn]) : 0;
@@ -152,7 +167,7 @@ __global__ __launch_bounds__(GT, 2) void gram_kernel(Acc X, const T* __restrict_
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = bm * BM + wm * (BM / WM) + i * 16 + Mfma<T>::row(lane, e);
-                const int col = bn * BN + wn * 64 + j * 16 + (lane & 15);
+                const int col = ncol0 + bn * BN + wn * 64 + j * 16 + (lane & 15);
                 P[int64_t(col) * Mpad + row] = acc[i][j][e];
             }
 }
@@ -176,25 +191,33 @@ __global__ void gram_reduce_kernel(const T* __restrict__ part, int nsplit, int64
     if (symmetric) C[cp + rp * ldc] = s;
 }
 
-inline int gram_bn(int64_t N) { return N <= 64 ? 64 : 128; }
-
-inline void gram_shape(int64_t n, int64_t M, int64_t N, int64_t& Mt, int64_t& Nt, int& nsplit, int64_t& kchunk) {
-    const int bn = gram_bn(N);
-    Mt = (M + BM - 1) / BM;
-    Nt = (N + bn - 1) / bn;
-    const int64_t tiles = Mt * Nt;
-    int64_t want = (768 + tiles - 1) / tiles;
+// N tiling: full 128-wide tiles, then the remainder as one 64-wide tile when it fits (less padding than a 128 tile)
+struct GramShape {
+    int64_t Mt, n128, n64, Npad, kchunk;
+    int nsplit;
+};
+inline GramShape gram_shape(int64_t n, int64_t M, int64_t N) {
+    GramShape g;
+    g.Mt = (M + BM - 1) / BM;
+    g.n128 = N / 128;
+    const int64_t rem = N - g.n128 * 128;
+    g.n64 = 0;
+    if (rem > 64) ++g.n128;
+    else if (rem > 0) g.n64 = 1;
+    g.Npad = g.n128 * 128 + g.n64 * 64;
+    // enough blocks that the last partial round over the 256 CUs x 2 resident blocks costs little
+    const int64_t tiles = g.Mt * (g.n128 + g.n64);
+    int64_t want = (3072 + tiles - 1) / tiles;
     const int64_t max_split = (n + KT * 8 - 1) / (KT * 8);
     if (want > max_split) want = max_split;
-    // bound the partial buffer (<= 2^28 elements)
-    const int64_t cap = (int64_t(1) << 28) / (Mt * BM * Nt * bn);
+    const int64_t cap = (int64_t(1) << 28) / (g.Mt * BM * g.Npad); // partial buffer <= 2^28 elements
     if (want > cap) want = cap;
     if (want < 1) want = 1;
-    kchunk = (n + want - 1) / want;
-    kchunk = ((kchunk + KT - 1) / KT) * KT;
-    int64_t ns = (n + kchunk - 1) / kchunk;
-    if (ns < 1) ns = 1;
-    nsplit = int(ns);
+    g.kchunk = (n + want - 1) / want;
+    g.kchunk = ((g.kchunk + KT - 1) / KT) * KT;
+    int64_t ns = (n + g.kchunk - 1) / g.kchunk;
+    g.nsplit = int(ns < 1 ? 1 : ns);
+    return g;
 }
 
 template <class T, class Acc>
@@ -202,36 +225,36 @@ void gram_launch(Acc acc, bool vecok, const T* w, const int32_t* mcols, int32_t 
                  int32_t N, int32_t n_pos0, int64_t n, const T* xm, bool center, T* C, int64_t ldc, T* work,
                  hipStream_t s) {
     if (M <= 0 || N <= 0) return;
-    int64_t Mt, Nt, kchunk;
-    int nsplit;
-    gram_shape(n, M, N, Mt, Nt, nsplit, kchunk);
-    const int bn = gram_bn(N);
-    const int64_t Mpad = Mt * BM, Npad = Nt * bn;
+    const GramShape g = gram_shape(n, M, N);
+    const int64_t Mpad = g.Mt * BM, Npad = g.Npad;
     // "symmetric": the N list is the tail (or all) of the M list at the same positions -> skip tiles that lie
     // entirely above the diagonal of the (new x new) square; the reduce kernel mirrors them.
     const int symmetric = (mcols + (n_pos0 - m_pos0) == ncols && m_pos0 + M == n_pos0 + N && n_pos0 >= m_pos0) ? 1 : 0;
-    dim3 grid((unsigned)Mt, (unsigned)Nt, (unsigned)nsplit);
-#define AHIP_GRAM_LAUNCH(VOK, BNV)                                                                                     \
-    hipLaunchKernelGGL((gram_kernel<T, Acc, VOK, BNV>), grid, dim3(GT), 0, s, acc, w, mcols, M, ncols, N, n, kchunk,    \
-                       m_pos0, n_pos0, symmetric, work, Mpad, Npad)
-    if (vecok) {
-        if (bn == 64) AHIP_GRAM_LAUNCH(true, 64); else AHIP_GRAM_LAUNCH(true, 128);
-    } else {
-        if (bn == 64) AHIP_GRAM_LAUNCH(false, 64); else AHIP_GRAM_LAUNCH(false, 128);
+    auto blocks = [&](int64_t nt) {
+        const int64_t npair = g.Mt * g.nsplit;
+        return unsigned(((npair + 7) / 8) * 8 * nt);
+    };
+#define AHIP_GRAM_LAUNCH(VOK, BNV, NT_, COL0)                                                                           \
+    hipLaunchKernelGGL((gram_kernel<T, Acc, VOK, BNV>), dim3(blocks(NT_)), dim3(GT), 0, s, acc, w, mcols, M, ncols, N, n, \
+                       g.kchunk, m_pos0, n_pos0, symmetric, work, Mpad, Npad, int32_t(COL0), int32_t(g.Mt), int32_t(NT_), \
+                       int32_t(g.nsplit))
+    if (g.n128 > 0) {
+        if (vecok) AHIP_GRAM_LAUNCH(true, 128, g.n128, 0); else AHIP_GRAM_LAUNCH(false, 128, g.n128, 0);
+    }
+    if (g.n64 > 0) {
+        if (vecok) AHIP_GRAM_LAUNCH(true, 64, 1, g.n128 * 128); else AHIP_GRAM_LAUNCH(false, 64, 1, g.n128 * 128);
     }
 #undef AHIP_GRAM_LAUNCH
     hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3((unsigned)((M + 255) / 256), (unsigned)N), dim3(256), 0, s, work,
-                       nsplit, Mpad, Npad, M, N, mcols, ncols, m_pos0, n_pos0, xm, center ? 1 : 0, symmetric, C, ldc);
+                       g.nsplit, Mpad, Npad, M, N, mcols, ncols, m_pos0, n_pos0, xm, center ? 1 : 0, symmetric, C, ldc);
 }
 
 } // namespace
 
 int64_t gram_work_elems(int64_t n, int64_t M, int64_t N) {
     if (M <= 0 || N <= 0) return 0;
-    int64_t Mt, Nt, kchunk;
-    int nsplit;
-    gram_shape(n, M, N, Mt, Nt, nsplit, kchunk);
-    return int64_t(nsplit) * Mt * BM * Nt * gram_bn(N);
+    const GramShape g = gram_shape(n, M, N);
+    return int64_t(g.nsplit) * g.Mt * BM * g.Npad;
 }
 
 template <class T>

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <limits>
 #include <numeric>
@@ -129,12 +130,14 @@ struct KTimer {
         ev.emplace_back(a, b);
     }
     void end(hipStream_t st) { AHIP_CHECK(hipEventRecord(ev.back().second, st)); }
+    std::vector<float> each; // per-launch milliseconds (debug / tuning)
     void collect() {
         for (auto& e : ev) {
             float t = 0;
             if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&t, e.first, e.second) == hipSuccess) {
                 ms += t;
                 ++launches;
+                each.push_back(t);
             }
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
@@ -188,7 +191,8 @@ struct Solver {
     // ---- dynamic host state ----
     T lmda_max;
     std::vector<T> lmda_path;
-    std::unordered_set<idx> screen_hashset;
+    std::vector<uint8_t> in_screen; // role of screen_hashset (state_base.hpp): membership bitmap over the G groups
+    std::vector<int32_t> slot_host; // group -> screen value offset (-1: not screened), mirrored in d_slot
     std::vector<idx> screen_set, screen_begins;
     std::vector<T> screen_beta;
     std::vector<int8_t> screen_is_active;
@@ -211,6 +215,8 @@ struct Solver {
     Counters cnt;
     KTimer t_sweep, t_gram, t_cd, t_axpy;
     int64_t cd_dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<std::pair<idx, idx>> gram_shapes;
+    double t_host[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // wall-clock split of solve(): screen logic, append, gram+vars, fit, invariance, kkt+solutions
     double t_host_screen = 0;
     std::string error;
     double total_time = 0;
@@ -233,7 +239,7 @@ struct Solver {
     DevBuf<CdBlkState<T>> d_blk;
     DevBuf<T> d_Dbuf, d_dlt;
     DevBuf<int32_t> d_didx;
-    int64_t cd_block_min_nv = 1024; // screen sets at least this large use the multi-CU block passes
+    int64_t cd_block_min_nv = 256; // screen sets at least this large use the multi-CU block passes
     DevBuf<T> d_work_sweep, d_work_gram;
     bool grad_valid = false; // d_grad == X^T W r - rsum*xbar for the current r
     // glm device vectors
@@ -242,7 +248,7 @@ struct Solver {
     idx nv = 0; // screen values
     idx ns_dev = 0; // screen groups already mirrored on device
 
-    bool is_screen(idx i) const { return screen_hashset.find(i) != screen_hashset.end(); }
+    bool is_screen(idx i) const { return in_screen[i] != 0; }
     bool dense() const { return D->kind == 0; }
 
     // ---------------------------------------------------------------------------------------------------------
@@ -267,6 +273,7 @@ struct Solver {
         t_gram.end(st);
         cnt.n_gram_col_reads += M + N;
         cnt.gram_flops += 2.0 * double(n) * double(M) * double(N);
+        gram_shapes.emplace_back(M, N);
     }
     void sync() { AHIP_CHECK(hipStreamSynchronize(st)); }
 
@@ -295,7 +302,8 @@ struct Solver {
     // solver_base.hpp:120-153
     void update_screen_derived_base() {
         const auto old = screen_begins.size();
-        for (size_t i = old; i < screen_set.size(); ++i) screen_hashset.insert(screen_set[i]);
+        if (in_screen.size() != size_t(G)) in_screen.assign(G, 0);
+        for (size_t i = old; i < screen_set.size(); ++i) in_screen[screen_set[i]] = 1;
         size_t vs = (old == 0) ? 0 : (screen_begins.back() + group_sizes[screen_set[old - 1]]);
         for (size_t i = old; i < screen_set.size(); ++i) {
             screen_begins.push_back(vs);
@@ -334,12 +342,10 @@ struct Solver {
         d_ssize.upload(ssize.data(), ssize.size(), st, ns_dev);
         d_spen.upload(spen.data(), spen.size(), st, ns_dev);
         d_isact.upload(isact.data(), isact.size(), st, ns_dev);
-        // slots: group -> value offset
-        for (idx ss = ns_dev; ss < ns; ++ss) {
-            const int32_t b = int32_t(screen_begins[ss]);
-            AHIP_CHECK(hipMemcpyAsync(d_slot.p + screen_set[ss], &sbegin[ss - ns_dev], sizeof(int32_t), hipMemcpyHostToDevice, st));
-            (void)b;
-        }
+        // slots: group -> value offset (whole table re-uploaded: G * 4 bytes)
+        if (slot_host.size() != size_t(G)) slot_host.assign(G, -1);
+        for (idx ss = ns_dev; ss < ns; ++ss) slot_host[screen_set[ss]] = int32_t(screen_begins[ss]);
+        d_slot.upload(slot_host.data(), size_t(G), st);
         sync(); // the staging vectors above go out of scope
         ns_dev = ns;
         nv = nv_new;
@@ -475,17 +481,22 @@ struct Solver {
         } else if (screen_rule == ADELIE_HIP_SCREEN_PIVOT) {
             if (n_new_active) {
                 const int Gi = int(G);
-                std::vector<idx> order(Gi);
-                std::iota(order.begin(), order.end(), 0);
-                std::vector<T> wts(Gi);
-                for (int i = 0; i < Gi; ++i)
-                    wts[i] = (penalty[i] <= 0) ? alpha * lmda : std::min(abs_grad[i] / penalty[i], alpha * lmda);
+                // sort (score, group) pairs in place: contiguous keys instead of an indirect comparator
+                std::vector<std::pair<T, idx>> keyed(Gi);
+                for (int i = 0; i < Gi; ++i) {
+                    const T wt = (penalty[i] <= 0) ? alpha * lmda : std::min(abs_grad[i] / penalty[i], alpha * lmda);
+                    keyed[i] = std::make_pair(wt, idx(i));
+                }
                 // The reference sorts with `weights[i] < weights[j]` only (solver_base.hpp:320-326): every group whose score is
                 // capped at alpha*lmda ties exactly, and std::sort leaves the order of ties unspecified.  Ties are broken by
-                // group index here so that the screen insertion order (= the CD visiting order) is reproducible.
-                std::sort(order.begin(), order.end(), [&](idx i, idx j) {
-                    return wts[i] < wts[j] || (wts[i] == wts[j] && i < j);
-                });
+                // group index here (pair comparison) so that the screen insertion order (= CD visiting order) is reproducible.
+                std::sort(keyed.begin(), keyed.end());
+                std::vector<idx> order(Gi);
+                std::vector<T> wts(Gi);
+                for (int i = 0; i < Gi; ++i) {
+                    order[i] = keyed[i].second;
+                    wts[keyed[i].second] = keyed[i].first;
+                }
                 const int subset_size =
                     std::min<int>(std::max<int>(int(old_size * (1 + pivot_subset_ratio)), int(pivot_subset_min)), Gi);
                 std::vector<T> sub(subset_size), mses(subset_size), ind(subset_size);
@@ -962,16 +973,33 @@ struct Solver {
     }
 
     void screen_f(T lm, bool kkt_passed, int n_new_active) {
+        Stopwatch sw;
+        sw.start();
         screen(lm, kkt_passed, n_new_active);
+        t_host[0] += sw.elapsed();
+        sw.start();
         if (is_glm()) {
             update_screen_derived_base();
             device_append_screen();
+            t_host[1] += sw.elapsed();
         } else {
-            gaussian_update_screen_derived();
+            const size_t old_groups = screen_transforms.size();
+            update_screen_derived_base();
+            device_append_screen();
+            t_host[1] += sw.elapsed();
+            sw.start();
+            update_gram_and_vars(d_w.p, d_xm.p, X_means, old_groups);
+            t_host[2] += sw.elapsed();
         }
     }
 
-    FitOut<T> fit_f(T lm) { return is_glm() ? glm_fit(lm) : gaussian_fit(lm); }
+    FitOut<T> fit_f(T lm) {
+        Stopwatch sw;
+        sw.start();
+        FitOut<T> o = is_glm() ? glm_fit(lm) : gaussian_fit(lm);
+        t_host[3] += sw.elapsed();
+        return o;
+    }
 
     // solve_core, solver_base.hpp:435-687
     void solve() {
@@ -1028,12 +1056,14 @@ struct Solver {
                 sw.start();
                 update_invariance(lmda_curr);
                 benchmark_invariance.push_back(sw.elapsed());
+                t_host[4] += benchmark_invariance.back();
                 sw.start();
                 kkt_passed = kkt(lmda_curr);
                 n_valid_solutions.push_back(kkt_passed);
                 lmda_path_idx += kkt_passed;
                 if (kkt_passed) update_solutions(fo, lmda_curr);
                 benchmark_kkt.push_back(sw.elapsed());
+                t_host[5] += benchmark_kkt.back();
                 if (kkt_passed) {
                     active_sizes.push_back(int(active_set_size));
                     screen_sizes.push_back(int(screen_set.size()));
@@ -1049,6 +1079,13 @@ struct Solver {
     // pull the device-resident invariants back into the host mirrors that the result accessors expose
     void finalize() {
         t_sweep.collect(); t_gram.collect(); t_cd.collect(); t_axpy.collect();
+        if (std::getenv("ADELIE_HIP_DEBUG_GRAM")) {
+            for (size_t i = 0; i < gram_shapes.size() && i < t_gram.each.size(); ++i) {
+                const double fl = 2.0 * double(n) * double(gram_shapes[i].first) * double(gram_shapes[i].second);
+                std::fprintf(stderr, "gram M=%lld N=%lld ms=%.3f TF=%.1f\n", (long long)gram_shapes[i].first,
+                             (long long)gram_shapes[i].second, t_gram.each[i], fl / (t_gram.each[i] * 1e-3) / 1e12);
+            }
+        }
         d_grad.download(grad.data(), size_t(p), st);
         d_r.download(resid.data(), size_t(n), st);
         if (is_glm()) d_eta.download(eta.data(), size_t(n), st);
@@ -1322,7 +1359,9 @@ struct Result : ResultBase {
             case ADELIE_HIP_S_N_SWEEP_LAUNCHES: return double(s.t_sweep.launches);
             case ADELIE_HIP_S_N_GRAM_LAUNCHES: return double(s.t_gram.launches);
             case ADELIE_HIP_S_T_HOST_SCREEN_MS: return 1e3 * s.t_host_screen;
-            default: if (which >= 900 && which < 908) return double(s.cd_dbg[which - 900]);
+            default:
+                if (which >= 900 && which < 908) return double(s.cd_dbg[which - 900]);
+                if (which >= 910 && which < 918) return 1e3 * s.t_host[which - 910];
         }
         return std::numeric_limits<double>::quiet_NaN();
     }

@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--alpha", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=90.0)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
 
     import torch
@@ -170,7 +171,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(n, p, args.dtype),
                 "launches": int(sweep_launches),
                 "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": sweep_bytes,
@@ -193,17 +194,32 @@ def main():
         dist.destroy_process_group()
 
 
+def measured_traffic(n, p, dtype):
+    """HBM bytes per sweep launch from the PMC passes kept under profiles/ (FETCH_SIZE doubled as the gfx950 note in
+    guides/MI355X_MICROARCH.md prescribes, plus WRITE_SIZE); None when this shape was not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(f"sweep_kernel:{n}x{p}:{dtype}")
+    except Exception:
+        return None
+
+
 def cpu_baseline(X, y, glm, kw, args, npdtype, gpu_state):
     """Times the CPU oracle (a port of the reference algorithm, same OpenMP flags) on the same data."""
     from oracle import oracle
 
     import adelie_amd as ad
 
-    cores = os.cpu_count() or 1
+    avail = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    # Thread count: the reference documents that more threads are not faster for this solver (parallelism.ipynb cells
+    # 10-18: its OpenMP regions are per column visit).  Probed on the 256-core GPU-box host (scripts/cpu_threads_probe.py,
+    # first 25 lambdas): 8 thr 2.27 s, 16 thr 1.31 s, 32 thr 1.65 s, 64 thr 3.2 s, 128 thr 6.3 s -> use 16.
+    cores = min(avail, args.cpu_threads)
+    os.environ["ORACLE_COL_THREADS"] = str(cores)
     os.environ.setdefault("OMP_PROC_BIND", "TRUE")  # reference adelie/__init__.py:8-19
     Xh = X.t().contiguous().cpu().numpy().T  # (n, p) F-ordered host copy of the same matrix
     Xo = oracle.dense(Xh, n_threads=cores)

@@ -145,6 +145,34 @@ struct CdBlkParams {
     int32_t count;
     int32_t mark;
 };
+// group (q > 1) variant: a block = consecutive groups of the visiting list with <= 128 values in total
+template <class T>
+struct CdGrpBlkParams {
+    int32_t nv;
+    const T* C;
+    int64_t ldc;
+    const T* vars;
+    const T* xmean;
+    T* beta;
+    T* g;
+    int8_t* is_active;
+    int32_t* active_set;
+    T l1, l2, newton_tol, dbeta_tol;
+    int32_t newton_max_iters, max_active_size, mark;
+    const T* V;
+    const int64_t* voff;
+    const T* spen;
+    const int32_t* sbegin;
+    const int32_t* ssize;
+    const int32_t* blk_g0; // [nblk+1] first list position of each block
+    const int32_t* list;   // visiting list of screen-group indices (nullptr: 0..)
+    int32_t nblk;
+    T* Dbuf;
+    T* dlt;
+    int32_t* didx;
+    CdBlkState<T>* st;
+};
+template <class T> void launch_cd_group_block_pass(const CdGrpBlkParams<T>& p, hipStream_t s);
 int cd_block_size();
 // enqueues one whole pass (gather, then solve/update per block); the host reads st afterwards
 template <class T> void launch_cd_block_pass(const CdBlkParams<T>& p, hipStream_t s);

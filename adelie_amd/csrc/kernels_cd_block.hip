@@ -195,7 +195,19 @@ __global__ __launch_bounds__(256) void blk_update_kernel(CdBlkParams<T> p, int j
     if (nz > 0) {
         T acc = T(0);
         if (r < p.nv) {
-            for (int m = wv; m < nz; m += 4) acc = fma(p.C[r + int64_t(p.didx[m]) * p.ldc], p.dlt[m], acc);
+            // 8 independent column reads in flight per lane (the fixed summation order keeps the result deterministic)
+            int m = wv;
+            for (; m + 28 < nz; m += 32) {
+                T c[8], d[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    c[u] = p.C[r + int64_t(p.didx[m + 4 * u]) * p.ldc];
+                    d[u] = p.dlt[m + 4 * u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = fma(c[u], d[u], acc);
+            }
+            for (; m < nz; m += 4) acc = fma(p.C[r + int64_t(p.didx[m]) * p.ldc], p.dlt[m], acc);
         }
         red[wv][lane] = acc;
         __syncthreads();

@@ -1,0 +1,368 @@
+// kernels_cd_block_group.hip — block Gauss–Seidel passes for problems with groups (q > 1), spread over the chip.
+//
+// Same structure as kernels_cd_block.hip (one solver workgroup per block, the rest of the chip applies the block's
+// changes to every screen value and gathers the next diagonal block), with a block = consecutive GROUPS of the visiting
+// list whose sizes add up to <= 128 values.  The group coordinate update is the reference's
+// (solver_gaussian_pin_naive.hpp:109-164, bcd/unconstrained/newton.hpp:35-142, optimization/newton.hpp:28-65):
+// rotate into the eigenbasis of the centred weighted Gram block, Newton root find for the norm, rotate back; one
+// wavefront does it lane-parallel over the q coefficients with wave reductions.  Groups wider than 128 values fall back
+// to the single-workgroup kernel (kernels_cd.hip).
+#include "kernels.hpp"
+
+namespace ahip {
+
+namespace {
+
+constexpr int GBLK = 128;
+
+template <class T>
+__device__ __forceinline__ T gwsum(T x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+// Sum over the first 16 lanes with DPP (no LDS crossbar): xor-1, xor-2 by quad_perm, then row_half_mirror and
+// row_mirror; the result is made wave-uniform with readfirstlane.  Lanes >= 16 must not contribute.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double first_lane(double x) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+__device__ __forceinline__ float first_lane(float x) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
+}
+template <class T>
+__device__ __forceinline__ T row16_sum(T x) {
+    x += dpp_move<0xB1>(x);  // quad_perm [1,0,3,2]
+    x += dpp_move<0x4E>(x);  // quad_perm [2,3,0,1]
+    x += dpp_move<0x141>(x); // row_half_mirror
+    x += dpp_move<0x140>(x); // row_mirror
+    return first_lane(x);
+}
+// sum of per-lane partials of a q-long group (lanes >= q hold 0)
+template <class T>
+__device__ __forceinline__ T group_sum(T x, int q) {
+    return q <= 16 ? row16_sum(x) : gwsum(x);
+}
+
+// Fills vmap[0..nval) with the global screen-value index of every value of block j, plus the group tables.
+// Executed by one thread; returns nval through *nval_out (all in LDS).
+template <class T>
+__device__ __forceinline__ void block_layout(const CdGrpBlkParams<T>& p, int j, int32_t* vmap, int32_t* goff,
+                                             int32_t* gq, int32_t* gss, int32_t* meta /* [0]=ngrp [1]=nval */) {
+    const int g0 = p.blk_g0[j], g1 = p.blk_g0[j + 1];
+    int o = 0;
+    for (int pos = g0; pos < g1; ++pos) {
+        const int ss = p.list ? p.list[pos] : pos;
+        const int b = p.sbegin[ss], q = p.ssize[ss];
+        const int k = pos - g0;
+        goff[k] = o;
+        gq[k] = q;
+        gss[k] = ss;
+        for (int t = 0; t < q; ++t) vmap[o + t] = b + t;
+        o += q;
+    }
+    goff[g1 - g0] = o;
+    meta[0] = g1 - g0;
+    meta[1] = o;
+}
+
+template <class T>
+__device__ __forceinline__ void gather_group_block(const CdGrpBlkParams<T>& p, int j, const int32_t* vmap, int nval,
+                                                   int gtid, int gthreads) {
+    T* D = p.Dbuf + size_t(j & 1) * GBLK * GBLK;
+    for (int e = gtid; e < nval * nval; e += gthreads) {
+        const int i = e % nval, m = e / nval;
+        D[i + m * GBLK] = p.C[int64_t(vmap[i]) + int64_t(vmap[m]) * p.ldc];
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void grp_gather_kernel(CdGrpBlkParams<T> p, int j) {
+    __shared__ int32_t vmap[GBLK], goff[GBLK + 1], gq[GBLK], gss[GBLK], meta[2];
+    if (j >= p.nblk) return;
+    if (threadIdx.x == 0) block_layout(p, j, vmap, goff, gq, gss, meta);
+    __syncthreads();
+    gather_group_block(p, j, vmap, meta[1], blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int j) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* D = reinterpret_cast<T*>(smem_raw); // GBLK*GBLK
+    T* gB = D + GBLK * GBLK;
+    T* bB = gB + GBLK;     // current beta of the block's values
+    T* b0B = bB + GBLK;    // beta at block entry
+    T* AB = b0B + GBLK;
+    T* xmB = AB + GBLK;
+    T* scr = xmB + GBLK;   // 8 * GBLK group scratch
+    int32_t* vmap = reinterpret_cast<int32_t*>(scr + 8 * GBLK);
+    int32_t* goff = vmap + GBLK;
+    int32_t* gq = goff + GBLK + 1;
+    int32_t* gss = gq + GBLK;
+    int32_t* meta = gss + GBLK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) block_layout(p, j, vmap, goff, gq, gss, meta);
+    __syncthreads();
+    const int ngrp = meta[0], nval = meta[1];
+    if (tid < GBLK) {
+        const int i = tid;
+        if (i < nval) {
+            const int a = vmap[i];
+            gB[i] = p.g[a];
+            bB[i] = p.beta[a];
+            b0B[i] = bB[i];
+            AB[i] = p.vars[a];
+            xmB[i] = p.xmean[a];
+        } else {
+            gB[i] = 0; bB[i] = 0; b0B[i] = 0; AB[i] = 0; xmB[i] = 0;
+        }
+    }
+    {
+        const T* src = p.Dbuf + size_t(j & 1) * GBLK * GBLK;
+        for (int e = tid; e < GBLK * GBLK; e += 256) D[e] = src[e];
+    }
+    __syncthreads();
+    if (wv != 0) return;
+
+    CdBlkState<T>* st = p.st;
+    T rsq = st->rsq, rsum = st->resid_sum, cm = (j == 0) ? T(0) : st->cm;
+    int asz = st->active_size, status = st->status;
+    int64_t n_upd = st->n_updates;
+    T* gk_t = scr;
+    T* ak_old_t = scr + GBLK;
+    T* ak_t = scr + 2 * GBLK;
+    T* buf1 = scr + 3 * GBLK;
+    T* buf2 = scr + 4 * GBLK;
+    T* del = scr + 5 * GBLK;
+
+    for (int k = 0; k < ngrp && status == CD_OK; ++k) {
+        const int o = goff[k], q = gq[k], ss = gss[k];
+        const T pk = p.spen[ss];
+        const T l1p = p.l1 * pk, l2p = p.l2 * pk;
+        bool changed = false;
+        if (q == 1) {
+            const T gcur = gB[o], bi = bB[o], A = AB[o];
+            const T gk = fma(bi, A, gcur);                       // pin_naive:85-89
+            const T v = fabs(gk) - l1p;                          // pin_base:181-195
+            const T ak = (v > T(0)) ? copysign(v, gk) / (A + l2p) : T(0);
+            if (ak != bi) {                                      // pin_naive:97
+                changed = true;
+                const T d = ak - bi;
+                const T c1 = A * d * d;
+                cm = c1 > cm ? c1 : cm;
+                rsq += d * (T(2) * gcur - d * A);
+                rsum -= xmB[o] * d;
+                if (lane == 0) { bB[o] = ak; del[0] = d; }
+            }
+        } else {
+            // stage the (q,q) eigenbasis in LDS (one coalesced read) when it fits the scratch; else read it in place
+            const T* Vg = p.V + p.voff[ss];
+            const T* V = Vg;
+            if (q * q <= 2 * GBLK) {
+                T* Vl = scr + 6 * GBLK;
+                for (int e = lane; e < q * q; e += 64) Vl[e] = Vg[e];
+                V = Vl;
+                __builtin_amdgcn_wave_barrier();
+            }
+            const T* A = AB + o;
+            // gk_t = gk V ; ak_old_t = ak_old V ; gk_t += A * ak_old_t   (pin_naive:123-140)
+            for (int jj = lane; jj < q; jj += 64) {
+                T s1 = 0, s2 = 0;
+                const T* Vj = V + int64_t(jj) * q;
+#pragma unroll 4
+                for (int i = 0; i < q; ++i) {
+                    s1 = fma(gB[o + i], Vj[i], s1);
+                    s2 = fma(bB[o + i], Vj[i], s2);
+                }
+                ak_old_t[jj] = s2;
+                gk_t[jj] = s1 + A[jj] * s2;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // newton_solver (bcd/unconstrained/newton.hpp:35-142): v = gk_t, L = A
+            T nrm2 = 0;
+            for (int i = lane; i < q; i += 64) nrm2 = fma(gk_t[i], gk_t[i], nrm2);
+            nrm2 = group_sum(nrm2, q);
+            if (sqrt(nrm2) <= l1p) {
+                for (int i = lane; i < q; i += 64) ak_t[i] = 0;
+            } else if (l1p <= T(0)) {
+                for (int i = lane; i < q; i += 64) ak_t[i] = gk_t[i] / (A[i] + l2p);
+            } else {
+                for (int i = lane; i < q; i += 64) buf1[i] = A[i] + l2p;
+                T h = 0, fh, dfh;
+                auto step = [&](T hh) {
+                    T t = 0, s = 0;
+                    for (int i = lane; i < q; i += 64) {
+                        const T b2 = T(1) / (buf1[i] * hh + l1p);
+                        const T z = gk_t[i] * b2;
+                        const T x = z * z;
+                        buf2[i] = b2;
+                        t += x;
+                        s += x * buf1[i] * b2;
+                    }
+                    t = group_sum(t, q);
+                    s = group_sum(s, q);
+                    fh = t - T(1);
+                    dfh = -s * (T(1) + sqrt(t)) / t;
+                };
+                step(h);
+                int iters = 0;
+                while ((fabs(fh) > p.newton_tol) && (iters < p.newton_max_iters)) {
+                    h -= fh / dfh;
+                    h = h > T(0) ? h : T(0);
+                    step(h);
+                    ++iters;
+                }
+                for (int i = lane; i < q; i += 64) ak_t[i] = h * gk_t[i] * buf2[i];
+                if (iters >= p.newton_max_iters) { status = CD_NEWTON; break; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // changed? ; convergence / rsq in rotated coordinates (pin_naive:144-154)
+            T dn = 0, c1 = 0, rs = 0;
+            for (int i = lane; i < q; i += 64) {
+                const T gg = gk_t[i] - A[i] * ak_old_t[i];
+                const T d = ak_t[i] - ak_old_t[i];
+                dn = fma(d, d, dn);
+                c1 = fma(A[i] * d, d, c1);
+                rs += d * (T(2) * gg - d * A[i]);
+            }
+            dn = group_sum(dn, q);
+            c1 = group_sum(c1, q);
+            rs = group_sum(rs, q);
+            if (!(sqrt(dn) <= p.dbeta_tol * sqrt(T(q)))) {
+                changed = true;
+                c1 /= T(q);
+                cm = c1 > cm ? c1 : cm;
+                rsq += rs;
+                // ak = ak_t V^T ; del = ak - ak_old ; resid_sum -= xbar . del   (pin_naive:156-163)
+                T rsd = 0;
+                for (int i = lane; i < q; i += 64) {
+                    T s = 0;
+#pragma unroll 4
+                    for (int jj = 0; jj < q; ++jj) s = fma(ak_t[jj], V[i + int64_t(jj) * q], s);
+                    const T d = s - bB[o + i];
+                    del[i] = d;
+                    bB[o + i] = s;
+                    rsd = fma(xmB[o + i], d, rsd);
+                }
+                rsum -= group_sum(rsd, q);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (changed) {
+            if (p.mark && p.is_active[ss] == 0) {                  // add_active_set, pin_naive:294-304
+                if (asz >= p.max_active_size) { status = CD_MAX_ACTIVE; break; }
+                if (lane == 0) { p.is_active[ss] = 1; p.active_set[asz] = ss; }
+                ++asz;
+            }
+            // keep the block's gradient current: gB -= D[:, o:o+q] del
+            for (int l = lane; l < GBLK; l += 64) {
+                T acc = gB[l];
+#pragma unroll 4
+                for (int t = 0; t < q; ++t) acc = fma(-D[l + (o + t) * GBLK], del[t], acc);
+                gB[l] = acc;
+            }
+            __builtin_amdgcn_wave_barrier();
+            ++n_upd;
+        }
+    }
+    // write back beta and the compacted non-zero value changes for the update kernel
+    int nz = 0;
+    for (int i0 = 0; i0 < GBLK; i0 += 64) {
+        const int i = i0 + lane;
+        const T d = (i < nval) ? (bB[i] - b0B[i]) : T(0);
+        const bool ch = (i < nval) && (bB[i] != b0B[i]);
+        if (ch) p.beta[vmap[i]] = bB[i];
+        const unsigned long long m = __ballot(ch);
+        const int pos = nz + __popcll(m & ((1ull << lane) - 1ull));
+        if (ch) { p.didx[pos] = vmap[i]; p.dlt[pos] = d; }
+        nz += __popcll(m);
+    }
+    if (lane == 0) {
+        st->rsq = rsq;
+        st->resid_sum = rsum;
+        st->cm = cm;
+        st->active_size = asz;
+        st->status = status;
+        st->n_updates = n_upd;
+        st->nz = nz;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void grp_update_kernel(CdGrpBlkParams<T> p, int j) {
+    __shared__ T red[4][64];
+    __shared__ int32_t vmap[GBLK], goff[GBLK + 1], gq[GBLK], gss[GBLK], meta[2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nz = p.st->nz;
+    const int r = blockIdx.x * 64 + lane;
+    if (nz > 0) {
+        T acc = T(0);
+        if (r < p.nv) {
+            // 8 independent column reads in flight per lane (the fixed summation order keeps the result deterministic)
+            int m = wv;
+            for (; m + 28 < nz; m += 32) {
+                T c[8], d[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    c[u] = p.C[r + int64_t(p.didx[m + 4 * u]) * p.ldc];
+                    d[u] = p.dlt[m + 4 * u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = fma(c[u], d[u], acc);
+            }
+            for (; m < nz; m += 4) acc = fma(p.C[r + int64_t(p.didx[m]) * p.ldc], p.dlt[m], acc);
+        }
+        red[wv][lane] = acc;
+        __syncthreads();
+        if (wv == 0 && r < p.nv) p.g[r] -= ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+    }
+    if (j + 1 < p.nblk) { // gather the next block's diagonal block
+        if (tid == 0) block_layout(p, j + 1, vmap, goff, gq, gss, meta);
+        __syncthreads();
+        gather_group_block(p, j + 1, vmap, meta[1], blockIdx.x * 256 + tid, gridDim.x * 256);
+    }
+}
+
+template <class T>
+size_t grp_solve_lds() {
+    return size_t(GBLK) * GBLK * sizeof(T) + size_t(GBLK) * (5 + 8) * sizeof(T) + (size_t(GBLK) * 4 + 8) * sizeof(int32_t) + 16;
+}
+
+} // namespace
+
+template <class T>
+void launch_cd_group_block_pass(const CdGrpBlkParams<T>& p, hipStream_t s) {
+    if (p.nblk <= 0) return;
+    const unsigned ug = unsigned((p.nv + 63) / 64);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grp_solve_kernel<double>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_solve_lds<double>()));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grp_solve_kernel<float>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_solve_lds<float>()));
+        attr_done = true;
+    }
+    const size_t lds = grp_solve_lds<T>();
+    hipLaunchKernelGGL((grp_gather_kernel<T>), dim3(64), dim3(256), 0, s, p, 0);
+    for (int j = 0; j < p.nblk; ++j) {
+        hipLaunchKernelGGL((grp_solve_kernel<T>), dim3(1), dim3(256), lds, s, p, j);
+        hipLaunchKernelGGL((grp_update_kernel<T>), dim3(ug), dim3(256), 0, s, p, j);
+    }
+}
+
+template void launch_cd_group_block_pass<double>(const CdGrpBlkParams<double>&, hipStream_t);
+template void launch_cd_group_block_pass<float>(const CdGrpBlkParams<float>&, hipStream_t);
+
+} // namespace ahip

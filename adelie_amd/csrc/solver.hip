@@ -628,6 +628,105 @@ struct Solver {
         sync();
     }
 
+    // Same for problems with groups: blocks of consecutive groups (<= 128 values), partition built on the host.
+    DevBuf<int32_t> d_blk_g0;
+    std::vector<int32_t> part_host;
+    int build_partition(const idx* list, idx count) { // returns nblk; fills part_host with nblk+1 list positions
+        const int B = cd_block_size();
+        part_host.clear();
+        part_host.push_back(0);
+        idx acc = 0;
+        for (idx pos = 0; pos < count; ++pos) {
+            const idx ss = list ? list[pos] : pos;
+            const idx q = group_sizes[screen_set[ss]];
+            if (acc + q > B) {
+                part_host.push_back(int32_t(pos));
+                acc = 0;
+            }
+            acc += q;
+        }
+        if (count > 0) part_host.push_back(int32_t(count));
+        return int(part_host.size()) - 1;
+    }
+    void run_group_block_passes(const CdParams<T>& cp, CdScalars<T>& sc) {
+        const int B = cd_block_size();
+        d_blk.reserve(1);
+        d_Dbuf.reserve(size_t(2) * B * B);
+        d_dlt.reserve(B);
+        d_didx.reserve(B);
+        CdBlkState<T> bs{};
+        bs.rsq = sc.rsq;
+        bs.resid_sum = sc.resid_sum;
+        bs.active_size = sc.active_size;
+        bs.status = CD_OK;
+        d_blk.upload(&bs, 1, st);
+        CdGrpBlkParams<T> bp{};
+        bp.nv = cp.nv; bp.C = cp.C; bp.ldc = cp.ldc; bp.vars = cp.vars; bp.xmean = cp.xmean; bp.beta = cp.beta; bp.g = cp.g;
+        bp.is_active = cp.is_active; bp.active_set = cp.active_set;
+        bp.l1 = cp.lmda * cp.alpha; bp.l2 = cp.lmda * (T(1) - cp.alpha);
+        bp.newton_tol = cp.newton_tol; bp.dbeta_tol = cp.dbeta_tol; bp.newton_max_iters = cp.newton_max_iters;
+        bp.max_active_size = cp.max_active_size;
+        bp.V = cp.V; bp.voff = cp.voff; bp.spen = cp.spen; bp.sbegin = cp.sbegin; bp.ssize = cp.ssize;
+        bp.Dbuf = d_Dbuf.p; bp.dlt = d_dlt.p; bp.didx = d_didx.p; bp.st = d_blk.p;
+        int64_t iters = 0;
+        int status = CD_OK;
+        int asz = sc.active_size;
+        std::vector<idx> act_host(active_set.begin(), active_set.begin() + asz); // host mirror of the active list
+        auto pass = [&](bool screen_pass) -> T {
+            const idx count = screen_pass ? idx(cp.ns) : idx(asz);
+            if (count <= 0) return T(0);
+            const int nblk = build_partition(screen_pass ? nullptr : act_host.data(), count);
+            d_blk_g0.reserve(part_host.size());
+            d_blk_g0.upload(part_host.data(), part_host.size(), st);
+            bp.blk_g0 = d_blk_g0.p;
+            bp.list = screen_pass ? nullptr : cp.active_set;
+            bp.nblk = nblk;
+            bp.mark = screen_pass ? 1 : 0;
+            t_cd.begin(st);
+            launch_cd_group_block_pass<T>(bp, st);
+            t_cd.end(st);
+            d_blk.download(&bs, 1, st);
+            sync();
+            status = bs.status;
+            if (bs.active_size > asz) { // pick up the groups activated by this screen pass
+                std::vector<int32_t> fresh(bs.active_size - asz);
+                d_actset.download(fresh.data(), fresh.size(), st, asz);
+                sync();
+                for (int32_t v : fresh) act_host.push_back(v);
+            }
+            asz = bs.active_size;
+            return bs.cm;
+        };
+        while (status == CD_OK) {
+            while (status == CD_OK) { // solve_active, pin_naive:173-215
+                ++iters;
+                ++sc.n_passes_active;
+                sc.n_visits_active += asz;
+                const T cm = pass(false);
+                if (status != CD_OK) break;
+                if (cm < cp.tol) break;
+                if (iters >= cp.max_iters) { status = CD_MAX_CDS; break; }
+            }
+            if (status != CD_OK) break;
+            ++iters;
+            ++sc.n_passes_screen;
+            sc.n_visits_screen += cp.ns;
+            const T cm = pass(true);
+            if (status != CD_OK) break;
+            if (cm < cp.tol) break;
+            if (iters >= cp.max_iters) { status = CD_MAX_CDS; break; }
+        }
+        sc.rsq = bs.rsq;
+        sc.resid_sum = bs.resid_sum;
+        sc.iters = iters;
+        sc.n_updates = bs.n_updates;
+        sc.active_size = asz;
+        sc.status = status;
+        launch_cd_compact<T>(cp.beta, cp.beta0, cp.vcol, cp.nv, cp.dcols, cp.dvals, &cp.sc->n_delta, st);
+        AHIP_CHECK(hipMemcpyAsync(&sc.n_delta, &cp.sc->n_delta, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        sync();
+    }
+
     // ---------------------------------------------------------------------------------------------------------
     // One pin solve on the device (solver_gaussian_pin_naive.hpp:217-401 for a single lambda).
     // Preconditions: Gram/vars/sxm valid for [0,nv) under the weights in use; d_g holds the current gradient of the
@@ -678,6 +777,8 @@ struct Solver {
         sw.start();
         if (nv > 0 && all_scalar && nv >= cd_block_min_nv) {
             run_block_passes(cp, sc);
+        } else if (nv > 0 && !all_scalar && max_gs <= cd_block_size() && nv >= cd_block_min_nv) {
+            run_group_block_passes(cp, sc);
         } else {
             if (nv > 0) {
                 t_cd.begin(st);

@@ -216,3 +216,26 @@ def test_block_cd_passes_match_oracle(hip, oracle, monkeypatch, n, p, alpha):
     assert e1.error == "adelie_core solver: Maximum number of active groups reached."
     e2 = ad.grpnet(ad.matrix.dense(d["X"]), ad.glm.gaussian(d["y"]), max_iters=3, early_exit=False)
     assert e2.error.startswith("adelie_core solver: max coordinate descents")
+
+
+@pytest.mark.parametrize("alpha", [1.0, 0.5])
+def test_group_block_cd_passes_match_oracle(hip, oracle, monkeypatch, alpha):
+    """Forces the multi-CU block passes for grouped problems (kernels_cd_block_group.hip): mixed group sizes
+    (1..40), several blocks per pass, groups activated inside screen passes."""
+    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    rng = np.random.RandomState(7)
+    n, p = 1200, 640
+    d = make_gaussian(n, p, seed=13, sparsity=0.6, weights=True)
+    sizes = []
+    while sum(sizes) < p:
+        sizes.append(int(rng.choice([1, 1, 2, 5, 10, 40])))
+    sizes[-1] -= sum(sizes) - p
+    if sizes[-1] <= 0:
+        sizes.pop()
+        sizes[-1] += p - sum(sizes)
+    groups = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    kw = dict(groups=groups, alpha=alpha, tol=1e-14, early_exit=False, lmda_path_size=20, min_ratio=2e-2)
+    a, b = _both(oracle, d, lambda: ad.glm.gaussian(d["y"], weights=d["weights"]), **kw)
+    assert_same_path(a, b, 1e-6)
+    assert a.active_set_size > 30
+    assert abs(a.counters["n_updates"] - b.counters["n_updates"]) <= 0.02 * b.counters["n_updates"] + 5

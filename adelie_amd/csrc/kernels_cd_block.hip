@@ -29,6 +29,15 @@ template <class T> struct CbVec;
 template <> struct CbVec<double> { using type = cb_d2; static constexpr int N = 2; };
 template <> struct CbVec<float> { using type = cb_f4; static constexpr int N = 4; };
 
+// v_readlane with a wave-uniform lane index (SGPR): a register-to-scalar move, no LDS crossbar as __shfl would use
+__device__ __forceinline__ double rdlane(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ float rdlane(float x, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
+}
+__device__ __forceinline__ int rdlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+
 template <class T>
 __device__ __forceinline__ int blk_index(const CdBlkParams<T>& p, int pos) {
     return p.list ? p.list[pos] : pos;
@@ -97,7 +106,16 @@ __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j)
         constexpr int VEC = CbVec<T>::N;
         const V* src = reinterpret_cast<const V*>(p.Dbuf + size_t(j & 1) * BLK * BLK);
         V* dst = reinterpret_cast<V*>(D);
-        for (int e = tid; e < BLK * BLK / VEC; e += 256) dst[e] = src[e];
+        // 8 loads in flight per lane: the 128 KB block arrives in ~4 round trips instead of 32
+        constexpr int NE = BLK * BLK / VEC;
+        for (int e0 = tid; e0 < NE; e0 += 256 * 8) {
+            V v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[min(e0 + u * 256, NE - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u * 256 < NE) dst[e0 + u * 256] = v[u];
+        }
     }
     __syncthreads();
     if (wv != 0) return;
@@ -123,14 +141,14 @@ __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j)
     T nb0 = b0, nb1 = b1; // new coefficients of this lane's two coordinates
 #define AHIP_BLK_VISIT(GREG, BREG, AREG, LREG, NREG, RREG, XREG, ACTREG, NBREG, IL)                                   \
     {                                                                                                                  \
-        const T gcur = __shfl(GREG, IL, 64);                                                                           \
-        const T bi = __shfl(BREG, IL, 64), A = __shfl(AREG, IL, 64);                                                   \
+        const T gcur = rdlane(GREG, IL);                                                                           \
+        const T bi = rdlane(BREG, IL), A = rdlane(AREG, IL);                                                   \
         const T gk = fma(bi, A, gcur);                    /* pin_naive:85-89 */                                       \
-        const T v = fabs(gk) - __shfl(LREG, IL, 64);      /* pin_base:181-195 */                                      \
+        const T v = fabs(gk) - rdlane(LREG, IL);      /* pin_base:181-195 */                                      \
         T ak = T(0);                                                                                                   \
         if (v > T(0)) {                                                                                                \
             const T x = copysign(v, gk);                                                                               \
-            const T den = __shfl(NREG, IL, 64), rden = __shfl(RREG, IL, 64);                                           \
+            const T den = rdlane(NREG, IL), rden = rdlane(RREG, IL);                                           \
             const T q0 = x * rden;                                                                                     \
             const T r = fma(-q0, den, x);                                                                              \
             ak = fma(r, rden, q0);                                                                                     \
@@ -140,8 +158,8 @@ __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j)
             const T c1 = A * del * del;                                                                                \
             cm = c1 > cm ? c1 : cm;                       /* pin_base:112-122 */                                      \
             rsq += del * (T(2) * gcur - del * A);         /* pin_base:136-146 */                                      \
-            rsum -= __shfl(XREG, IL, 64) * del;           /* pin_naive:107 */                                         \
-            if (p.mark && __shfl(ACTREG, IL, 64) == 0) {  /* add_active_set, pin_naive:294-304 */                     \
+            rsum -= rdlane(XREG, IL) * del;           /* pin_naive:107 */                                         \
+            if (p.mark && rdlane(ACTREG, IL) == 0) {  /* add_active_set, pin_naive:294-304 */                     \
                 if (asz >= p.max_active_size) { status = CD_MAX_ACTIVE; break; }                                       \
                 if (lane == 0) { p.is_active[idxB[i]] = 1; p.active_set[asz] = idxB[i]; }                              \
                 ++asz;                                                                                                 \

@@ -131,7 +131,16 @@ __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int
     }
     {
         const T* src = p.Dbuf + size_t(j & 1) * GBLK * GBLK;
-        for (int e = tid; e < GBLK * GBLK; e += 256) D[e] = src[e];
+        // 16 loads in flight per lane
+        constexpr int NE = GBLK * GBLK;
+        for (int e0 = tid; e0 < NE; e0 += 256 * 16) {
+            T v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = src[min(e0 + u * 256, NE - 1)];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (e0 + u * 256 < NE) D[e0 + u * 256] = v[u];
+        }
     }
     __syncthreads();
     if (wv != 0) return;

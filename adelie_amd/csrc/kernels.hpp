@@ -144,6 +144,12 @@ struct CdBlkParams {
     const int32_t* list; // visiting list of the pass (nullptr: screen order 0..count-1)
     int32_t count;
     int32_t mark;
+    // panel (residual-based) variant, kernels_cd_panel.hip: gradient of the block from the panel step, diagonal block
+    // from the cache, changed design columns out for the residual update
+    const T* gblk;       // [BLK] gradient of the block's coordinates (list order)
+    const T* Dptr;       // BLK x BLK block (ld = BLK)
+    const int32_t* vcol; // screen value -> design column
+    int32_t* dcol;       // [BLK] out: design columns of the changed coordinates (same order as dlt)
 };
 // group (q > 1) variant: a block = consecutive groups of the visiting list with <= 128 values in total
 template <class T>
@@ -176,6 +182,24 @@ template <class T> void launch_cd_group_block_pass(const CdGrpBlkParams<T>& p, h
 int cd_block_size();
 // enqueues one whole pass (gather, then solve/update per block); the host reads st afterwards
 template <class T> void launch_cd_block_pass(const CdBlkParams<T>& p, hipStream_t s);
+// ---- panel form (kernels_cd_panel.hip): residual-based block passes ------------------------------------------------
+// step: r -= sum_{m < *nz_dev} dlt[m] X[:, dcol[m]]; then part[c][slice] = X[slice, cols[c]] . (w*r)[slice] for c < nb.
+// Returns the number of row slices.  `part` holds panel_part_elems(n) elements.
+template <class T>
+int launch_panel_step(const DenseView<T>& X, const T* w, T* r, const int32_t* dcol, const T* dlt, const int32_t* nz_dev,
+                      const int32_t* cols, int nb, T* part, hipStream_t s);
+template <class T>
+int launch_panel_step_snp(const SnpView& X, const T* impute, const T* w, T* r, const int32_t* dcol, const T* dlt,
+                          const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s);
+int64_t panel_part_elems(int64_t n);
+// gblk[c] = sum_slices part[c][.] - (xm_by_col ? rsum_dev[0] * xm_by_col[cols[c]] : 0)
+template <class T>
+void launch_panel_reduce(const T* part, int nslices, int nb, const int32_t* cols, const T* rsum_dev, const T* xm_by_col,
+                         T* gblk, hipStream_t s);
+// the visits of block j of the pass (one workgroup); p.gblk / p.Dptr / p.vcol / p.dcol must be set
+template <class T> void launch_cd_panel_solve(const CdBlkParams<T>& p, int j, hipStream_t s);
+template <class T> void launch_center_vars(T* vars, const T* xm, int cnt, bool center, hipStream_t s);
+void launch_gather_i32(const int32_t* src, const int32_t* idx, int cnt, int32_t* out, hipStream_t s);
 template <class T>
 void launch_cd_compact(const T* beta, const T* beta0, const int32_t* vcol, int nv, int32_t* dcols, T* dvals,
                        int32_t* n_delta, hipStream_t s);

@@ -62,7 +62,7 @@ __global__ void blk_gather_kernel(CdBlkParams<T> p, int j) {
     gather_block(p, j, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
-template <class T>
+template <class T, bool NAIVE>
 __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* D = reinterpret_cast<T*>(smem_raw);   // BLK*BLK
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j)
             const T A = p.vars[idx], pk = p.spen[idx];
             const T den = A + p.l2 * pk;
             idxB[i] = idx;
-            gB[i] = p.g[idx];
+            gB[i] = NAIVE ? p.gblk[i] : p.g[idx];
             bB[i] = p.beta[idx];
             AB[i] = A;
             l1B[i] = p.l1 * pk;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j)
     {
         using V = typename CbVec<T>::type;
         constexpr int VEC = CbVec<T>::N;
-        const V* src = reinterpret_cast<const V*>(p.Dbuf + size_t(j & 1) * BLK * BLK);
+        const V* src = reinterpret_cast<const V*>(NAIVE ? p.Dptr : p.Dbuf + size_t(j & 1) * BLK * BLK);
         V* dst = reinterpret_cast<V*>(D);
         // 8 loads in flight per lane: the 128 KB block arrives in ~4 round trips instead of 32
         constexpr int NE = BLK * BLK / VEC;
@@ -190,7 +190,11 @@ __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j)
         if (ch) p.beta[idxB[i]] = bB[i];
         const unsigned long long m = __ballot(ch);
         const int pos = nz + __popcll(m & ((1ull << lane) - 1ull));
-        if (ch) { p.didx[pos] = idxB[i]; p.dlt[pos] = d; }
+        if (ch) {
+            if (NAIVE) p.dcol[pos] = p.vcol[idxB[i]];
+            else p.didx[pos] = idxB[i];
+            p.dlt[pos] = d;
+        }
         nz += __popcll(m);
     }
     if (lane == 0) {
@@ -280,16 +284,29 @@ void launch_cd_block_pass(const CdBlkParams<T>& p, hipStream_t s) {
     static bool attr_done = false;
     const size_t lds = blk_solve_lds<T>();
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk_solve_kernel<double>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk_solve_kernel<double, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(blk_solve_lds<double>()));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk_solve_kernel<float>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk_solve_kernel<float, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(blk_solve_lds<float>()));
         attr_done = true;
     }
     for (int j = 0; j < nblk; ++j) {
-        hipLaunchKernelGGL((blk_solve_kernel<T>), dim3(1), dim3(256), lds, s, p, j);
+        hipLaunchKernelGGL((blk_solve_kernel<T, false>), dim3(1), dim3(256), lds, s, p, j);
         hipLaunchKernelGGL((blk_update_kernel<T>), dim3(ug), dim3(256), 0, s, p, j);
     }
+}
+
+template <class T>
+void launch_cd_panel_solve(const CdBlkParams<T>& p, int j, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk_solve_kernel<double, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(blk_solve_lds<double>()));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk_solve_kernel<float, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(blk_solve_lds<float>()));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((blk_solve_kernel<T, true>), dim3(1), dim3(256), blk_solve_lds<T>(), s, p, j);
 }
 
 template <class T>
@@ -300,6 +317,7 @@ void launch_cd_compact(const T* beta, const T* beta0, const int32_t* vcol, int n
 
 #define INST(T)                                                                                       \
     template void launch_cd_block_pass<T>(const CdBlkParams<T>&, hipStream_t);                        \
+    template void launch_cd_panel_solve<T>(const CdBlkParams<T>&, int, hipStream_t);                  \
     template void launch_cd_compact<T>(const T*, const T*, const int32_t*, int, int32_t*, T*, int32_t*, hipStream_t);
 INST(double)
 INST(float)

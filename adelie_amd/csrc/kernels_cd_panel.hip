@@ -1,0 +1,322 @@
+// kernels_cd_panel.hip — the "panel" form of a lasso coordinate-descent pass: residual based, exactly the naive
+// method's data flow (reference solver_gaussian_pin_naive.hpp:16-168: gradient of a coordinate from the residual,
+// residual updated with the coordinate's column), but organised per block of B = 128 consecutive visits so the whole
+// chip streams the block's columns while one wavefront does the (inherently sequential) updates:
+//
+//   panel_step_kernel    (n / rows-per-slice workgroups, row sliced)
+//                        (A) applies the previous block's changes to its slice of the residual,
+//                            r -= sum_m del_m X[:, col_m]            (ctmul of pin_naive:104-108, 128 columns at once)
+//                        (B) partial gradients of the next block on the same slice,
+//                            part[c][slice] = X[slice, col_c] . (w*r)[slice]   (cmul of pin_naive:84-86)
+//                        r is read and written once per block; the block's columns are read once for (B) and, if they
+//                        changed, once more for (A) of the following step (second read served by the 256 MB MALL).
+//   panel_reduce_kernel  sums the slice partials in a fixed order and applies the intercept term  - resid_sum * xbar_c.
+//   blk_solve_kernel     (kernels_cd_block.hip, NAIVE variant, ONE workgroup) runs the block's visits in order against
+//                        the B x B block  D = X_B^T W X_B - xbar xbar^T  (computed once per block and weight vector by
+//                        the MFMA Gram kernel and cached), which carries the within-block coupling exactly.
+//
+// Compared with keeping the full |S| x |S| Gram matrix current, the MFMA work drops from n|S|^2/2 to 128 n |S| MACs and
+// nothing has to be recomputed per IRLS iteration except the blocks that are actually visited.  The iterates are the
+// Gauss-Seidel sequence of the reference in exact arithmetic.
+#include "kernels.hpp"
+#include "accessors.hpp"
+
+namespace ahip {
+
+namespace {
+
+constexpr int PB = 128;
+constexpr int PT = 256;
+
+template <int CTRL>
+__device__ __forceinline__ double pdpp(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float pdpp(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double prdl(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ float prdl(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+
+// sum over the 64 lanes, fixed order: DPP inside each row of 16, then the four row sums via v_readlane
+template <class T>
+__device__ __forceinline__ T wave_sum64(T x) {
+    x += pdpp<0xB1>(x);  // quad_perm [1,0,3,2]
+    x += pdpp<0x4E>(x);  // quad_perm [2,3,0,1]
+    x += pdpp<0x141>(x); // row_half_mirror
+    x += pdpp<0x140>(x); // row_mirror
+    return (prdl(x, 0) + prdl(x, 16)) + (prdl(x, 32) + prdl(x, 48));
+}
+
+// Raw (undecoded) row-slice loads: VEC consecutive rows of one column per lane.  Dense: the values themselves, with
+// temporal (cache-allocating) loads because the block's columns are read again by the next step.  SNP: the byte
+// holding the four 2-bit calls, decoded at use (keeps 16 loads in flight within the register budget).
+template <class T, int VEC>
+struct RawDense { Pack<T, VEC> v; };
+struct RawSnp { unsigned byte; };
+
+template <class T, int VEC>
+__device__ __forceinline__ RawDense<T, VEC> praw(const DenseAcc<T>& X, int64_t j, int64_t i, int64_t n, bool full) {
+    RawDense<T, VEC> r;
+    const T* col = X.colptr(j);
+    if constexpr (VEC == 1) {
+        r.v.v[0] = (i < n) ? col[i] : T(0);
+    } else {
+        using V = typename VecOf<T>::type;
+        static_assert(VEC == VecOf<T>::N, "dense vector width");
+        if (full) {
+            const V x = *reinterpret_cast<const V*>(col + i);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r.v.v[e] = x[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r.v.v[e] = (i + e < n) ? col[i + e] : T(0);
+        }
+    }
+    return r;
+}
+template <class T, int VEC>
+__device__ __forceinline__ RawSnp praw(const SnpAcc<T>& X, int64_t j, int64_t i, int64_t n, bool /*full*/) {
+    static_assert(VEC == 4, "one byte of calls per lane");
+    RawSnp r;
+    r.byte = (i < n) ? unsigned(X.colptr(j)[i >> 2]) : 0u;
+    return r;
+}
+template <class T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> pdecode(const DenseAcc<T>&, const RawDense<T, VEC>& r, int64_t, int64_t, int64_t) {
+    return r.v;
+}
+template <class T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> pdecode(const SnpAcc<T>& X, const RawSnp& r, int64_t j, int64_t i, int64_t n) {
+    Pack<T, VEC> o;
+    const T imp = X.impute[j];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const unsigned c = (r.byte >> (2 * e)) & 3u;
+        o.v[e] = (i + e < n) ? (c == 3u ? imp : T(c)) : T(0);
+    }
+    return o;
+}
+template <class T, class Acc, int VEC> struct RawOf;
+template <class T, int VEC> struct RawOf<T, DenseAcc<T>, VEC> { using type = RawDense<T, VEC>; };
+template <class T, int VEC> struct RawOf<T, SnpAcc<T>, VEC> { using type = RawSnp; };
+
+// Latency structure (the kernel is bound by dependent HBM round trips otherwise): column indices and coefficients are
+// wave-uniform scalar loads; each wave keeps U = 16 column-slice loads in flight; the first batch of phase (B) is
+// issued before phase (A) so that its round trip overlaps (A)'s.
+template <class T, class Acc, int VEC, bool FULL>
+__device__ __forceinline__ void panel_step_body(const Acc& X, int64_t n, const T* __restrict__ w, T* __restrict__ r,
+                                                const int32_t* __restrict__ dcol, const T* __restrict__ dlt, int nz,
+                                                const int32_t* __restrict__ cols, int nb, T* __restrict__ part,
+                                                int64_t part_ld, T (*red)[64 * VEC], T* wrs) {
+    constexpr int U = 16;
+    using Raw = typename RawOf<T, Acc, VEC>::type;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t i = int64_t(blockIdx.x) * (64 * VEC) + int64_t(lane) * VEC;
+    const bool full = FULL ? true : (i + VEC <= n);
+
+    // first batch of (B): columns wv, wv+4, ... of the next block
+    Raw xb[U];
+    int jb[U];
+    if (nb > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) jb[u] = cols[min(wv + 4 * u, nb - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xb[u] = praw<T, VEC>(X, jb[u], i, n, full);
+    }
+
+    // ---- (A) residual slice -= X[slice, changed columns] * del ---------------------------------------------------------
+    if (nz > 0) {
+        T acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = T(0);
+        for (int m0 = wv; m0 < nz; m0 += 4 * U) {
+            Raw xa[U];
+            int ja[U];
+            T cf[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int m = m0 + 4 * u;
+                ja[u] = dcol[min(m, nz - 1)];
+                cf[u] = m < nz ? dlt[min(m, nz - 1)] : T(0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) xa[u] = praw<T, VEC>(X, ja[u], i, n, full);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const Pack<T, VEC> xx = pdecode<T, VEC>(X, xa[u], ja[u], i, n);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = fma(cf[u], xx.v[e], acc[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) red[wv][lane * VEC + e] = acc[e];
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int q = lane * VEC + e;
+                T wr = T(0);
+                if (FULL || i + e < n) {
+                    const T rr = r[i + e] - ((red[0][q] + red[1][q]) + (red[2][q] + red[3][q]));
+                    r[i + e] = rr;
+                    wr = w[i + e] * rr;
+                }
+                wrs[q] = wr;
+            }
+        }
+    } else if (wv == 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) wrs[lane * VEC + e] = (FULL || i + e < n) ? w[i + e] * r[i + e] : T(0);
+    }
+    if (nb <= 0) return;
+    __syncthreads();
+
+    // ---- (B) partial gradients of the next block on this slice ----------------------------------------------------------
+    T wr[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) wr[e] = wrs[lane * VEC + e];
+    for (int c0 = wv; c0 < nb; c0 += 4 * U) {
+        if (c0 != wv) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) jb[u] = cols[min(c0 + 4 * u, nb - 1)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) xb[u] = praw<T, VEC>(X, jb[u], i, n, full);
+        }
+        T pu[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const Pack<T, VEC> xx = pdecode<T, VEC>(X, xb[u], jb[u], i, n);
+            T sacc = T(0);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sacc = fma(xx.v[e], wr[e], sacc);
+            pu[u] = sacc;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) pu[u] = wave_sum64(pu[u]);
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (c0 + 4 * u < nb) part[int64_t(c0 + 4 * u) * part_ld + blockIdx.x] = pu[u];
+        }
+    }
+}
+
+template <class T, class Acc, int VEC>
+__global__ __launch_bounds__(PT) void panel_step_kernel(Acc X, int64_t n, const T* __restrict__ w, T* __restrict__ r,
+                                                        const int32_t* __restrict__ dcol, const T* __restrict__ dlt,
+                                                        const int32_t* __restrict__ nz_dev,
+                                                        const int32_t* __restrict__ cols, int nb, T* __restrict__ part,
+                                                        int64_t part_ld) {
+    constexpr int RS = 64 * VEC;
+    __shared__ T red[4][RS];
+    __shared__ T wrs[RS];
+    const int nz = nz_dev[0];
+    // only the last slice can be ragged; every other workgroup runs the branch-free body
+    if ((int64_t(blockIdx.x) + 1) * RS <= n)
+        panel_step_body<T, Acc, VEC, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs);
+    else
+        panel_step_body<T, Acc, VEC, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs);
+}
+
+template <class T>
+__global__ __launch_bounds__(PT) void panel_reduce_kernel(const T* __restrict__ part, int64_t part_ld, int nslices,
+                                                          const int32_t* __restrict__ cols,
+                                                          const T* __restrict__ rsum, const T* __restrict__ xm_by_col,
+                                                          T* __restrict__ gblk) {
+    __shared__ T red[4];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const T* pc = part + int64_t(c) * part_ld;
+    T s = T(0);
+    for (int k = tid; k < nslices; k += PT) s += pc[k];
+    s = wave_sum64(s);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    if (tid == 0) {
+        T g = (red[0] + red[1]) + (red[2] + red[3]);
+        if (xm_by_col) g -= rsum[0] * xm_by_col[cols[c]];
+        gblk[c] = g;
+    }
+}
+
+// vars[a] = max(vars[a] - xm[a]^2, 0)   (solver_gaussian_naive.hpp:99-111 for groups of size one)
+template <class T>
+__global__ void center_vars_kernel(T* __restrict__ vars, const T* __restrict__ xm, int cnt, int center) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= cnt) return;
+    T v = vars[a];
+    if (center) v -= xm[a] * xm[a];
+    vars[a] = v > T(0) ? v : T(0);
+}
+
+__global__ void gather_i32_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ idx, int cnt,
+                                  int32_t* __restrict__ out) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < cnt) out[a] = src[idx[a]];
+}
+
+template <class T, class Acc, int VEC>
+int step_launch(const Acc& acc, int64_t n, const T* w, T* r, const int32_t* dcol, const T* dlt, const int32_t* nz_dev,
+                const int32_t* cols, int nb, T* part, hipStream_t s) {
+    constexpr int RS = 64 * VEC;
+    const int64_t ns = (n + RS - 1) / RS;
+    hipLaunchKernelGGL((panel_step_kernel<T, Acc, VEC>), dim3((unsigned)ns), dim3(PT), 0, s, acc, n, w, r, dcol, dlt,
+                       nz_dev, cols, nb, part, ns);
+    return int(ns);
+}
+
+} // namespace
+
+int64_t panel_part_elems(int64_t n) { return int64_t(PB) * ((n + 63) / 64) + 16; }
+
+template <class T>
+int launch_panel_step(const DenseView<T>& X, const T* w, T* r, const int32_t* dcol, const T* dlt, const int32_t* nz_dev,
+                      const int32_t* cols, int nb, T* part, hipStream_t s) {
+    DenseAcc<T> acc{X.X, X.ld};
+    constexpr int V = VecOf<T>::N;
+    const bool vecok = (X.ld % V == 0) && ((reinterpret_cast<uintptr_t>(X.X) % 16) == 0);
+    if (vecok) return step_launch<T, DenseAcc<T>, V>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
+    return step_launch<T, DenseAcc<T>, 1>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
+}
+template <class T>
+int launch_panel_step_snp(const SnpView& X, const T* impute, const T* w, T* r, const int32_t* dcol, const T* dlt,
+                          const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s) {
+    SnpAcc<T> acc{X.bits, X.ldb, impute};
+    return step_launch<T, SnpAcc<T>, 4>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
+}
+template <class T>
+void launch_panel_reduce(const T* part, int nslices, int nb, const int32_t* cols, const T* rsum_dev, const T* xm_by_col,
+                         T* gblk, hipStream_t s) {
+    if (nb <= 0) return;
+    hipLaunchKernelGGL((panel_reduce_kernel<T>), dim3((unsigned)nb), dim3(PT), 0, s, part, int64_t(nslices), nslices, cols,
+                       rsum_dev, xm_by_col, gblk);
+}
+template <class T>
+void launch_center_vars(T* vars, const T* xm, int cnt, bool center, hipStream_t s) {
+    if (cnt <= 0) return;
+    hipLaunchKernelGGL((center_vars_kernel<T>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, vars, xm, cnt,
+                       center ? 1 : 0);
+}
+void launch_gather_i32(const int32_t* src, const int32_t* idx, int cnt, int32_t* out, hipStream_t s) {
+    if (cnt <= 0) return;
+    hipLaunchKernelGGL(gather_i32_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, src, idx, cnt, out);
+}
+
+#define INST(T)                                                                                                        \
+    template int launch_panel_step<T>(const DenseView<T>&, const T*, T*, const int32_t*, const T*, const int32_t*,     \
+                                      const int32_t*, int, T*, hipStream_t);                                           \
+    template int launch_panel_step_snp<T>(const SnpView&, const T*, const T*, T*, const int32_t*, const T*,            \
+                                          const int32_t*, const int32_t*, int, T*, hipStream_t);                       \
+    template void launch_panel_reduce<T>(const T*, int, int, const int32_t*, const T*, const T*, T*, hipStream_t);     \
+    template void launch_center_vars<T>(T*, const T*, int, bool, hipStream_t);
+INST(double)
+INST(float)
+#undef INST
+
+} // namespace ahip

@@ -150,7 +150,7 @@ struct KTimer {
 struct Counters {
     int64_t n_basil_iters = 0, n_sweeps = 0, n_cd_visits_screen = 0, n_cd_visits_active = 0, n_updates = 0,
             n_irls_iters = 0, n_new_screen_cols = 0, n_cd_passes_screen = 0, n_cd_passes_active = 0,
-            n_gram_col_reads = 0, n_resid_col_reads = 0;
+            n_gram_col_reads = 0, n_resid_col_reads = 0, n_panel_blocks = 0, n_panel_grams = 0;
     double gram_flops = 0;
 };
 
@@ -240,6 +240,16 @@ struct Solver {
     DevBuf<T> d_Dbuf, d_dlt;
     DevBuf<int32_t> d_didx;
     int64_t cd_block_min_nv = 256; // screen sets at least this large use the multi-CU block passes
+    // panel engine (kernels_cd_panel.hip): residual-based block passes with cached B x B diagonal blocks
+    bool engine_panel = true;
+    const T* cur_w = nullptr;   // weights / by-column means the pin solve runs under (Gaussian: w, X_means; IRLS: per iteration)
+    const T* cur_xm = nullptr;
+    uint64_t w_version = 1;     // bumped whenever the weights behind cur_w change
+    DevBuf<T> d_Dpool, d_part, d_gblk;
+    DevBuf<int32_t> d_actcols, d_dcolblk;
+    std::vector<int32_t> dscr_nb, dact_nb;      // cached block: number of members it was built for
+    std::vector<uint64_t> dscr_ver, dact_ver;   // ... and the weight version
+    bool panel_mode() const { return engine_panel && all_scalar && nv >= cd_block_min_nv; }
     DevBuf<T> d_work_sweep, d_work_gram;
     bool grad_valid = false; // d_grad == X^T W r - rsum*xbar for the current r
     // glm device vectors
@@ -252,10 +262,30 @@ struct Solver {
     bool dense() const { return D->kind == 0; }
 
     // ---------------------------------------------------------------------------------------------------------
-    void sweep(const T* v, T* out, const int32_t* cols, idx ncols, const T* sub_scale, const T* sub_vec) {
+    void sweep(const T* v, T* out, const int32_t* cols, idx ncols, const T* sub_scale, const T* sub_vec,
+               bool square = false) {
         T* work = d_work_sweep.reserve(size_t(sweep_work_elems(n, ncols)));
-        if (dense()) launch_sweep<T>(D->dense<T>(), v, out, 0, ncols, cols, sub_scale, sub_vec, false, work, st);
-        else launch_sweep_snp<T>(D->snp(), static_cast<const T*>(D->impute), v, out, 0, ncols, cols, sub_scale, sub_vec, false, work, st);
+        if (dense()) launch_sweep<T>(D->dense<T>(), v, out, 0, ncols, cols, sub_scale, sub_vec, square, work, st);
+        else launch_sweep_snp<T>(D->snp(), static_cast<const T*>(D->impute), v, out, 0, ncols, cols, sub_scale, sub_vec, square, work, st);
+    }
+    int panel_step(const T* w, T* r, const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb) {
+        if (dense()) return launch_panel_step<T>(D->dense<T>(), w, r, dcol, dlt, nz_dev, cols, nb, d_part.p, st);
+        return launch_panel_step_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, r, dcol, dlt, nz_dev, cols, nb,
+                                        d_part.p, st);
+    }
+    // B x B block  X_cols^T W X_cols - xm xm^T  into Dptr (ld = B)
+    void gram_block(const T* w, const int32_t* cols, int nb, const T* xm, T* Dptr) {
+        T* work = d_work_gram.reserve(size_t(gram_work_elems(n, nb, nb)));
+        const int B = cd_block_size();
+        t_gram.begin(st);
+        if (dense())
+            launch_gram<T>(D->dense<T>(), w, cols, nb, 0, cols, nb, 0, xm, intercept, Dptr, B, work, st);
+        else
+            launch_gram_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols, nb, 0, cols, nb, 0, xm, intercept, Dptr,
+                               B, work, st);
+        t_gram.end(st);
+        cnt.n_gram_col_reads += 2 * nb;
+        cnt.gram_flops += 2.0 * double(n) * double(nb) * double(nb);
     }
     void axpy_cols(const int32_t* cols, const T* coef, const int32_t* cnt_dev, int32_t count, T sign, T* out) {
         if (dense()) launch_axpy_cols<T>(D->dense<T>(), cols, coef, cnt_dev, count, sign, out, st);
@@ -351,7 +381,7 @@ struct Solver {
         nv = nv_new;
         // Gram capacity: `gcap` columns, leading dimension ldc = gcap rounded up to 2048 rows (the CD kernel reads
         // whole 512-lane x 16-byte chunks of a column; zero-filled so the padding never carries NaN payloads)
-        if (nv > gcap) {
+        if (nv > gcap && !panel_mode()) {
             idx want = std::max<idx>(gcap * 2, 256);
             while (want < nv) want *= 2;
             want = std::min<idx>(want, ((p + 63) / 64) * 64);
@@ -435,12 +465,43 @@ struct Solver {
         for (idx t = 0; t < N; ++t) screen_vars[pos0 + t] = vars_host[t];
     }
 
+    // Panel engine (groups of size one only): the screen-derived quantities are the by-value means and the variances
+    // A_k = x_k^T W x_k - xbar_k^2 (solver_gaussian_naive.hpp:99-111); no |S| x |S| Gram matrix is kept.
+    void update_vars_panel(const T* w_dev, const T* xm_dev, const std::vector<T>& xm_host, size_t g_begin) {
+        const idx ns = idx(screen_set.size());
+        const idx pos0 = (g_begin < size_t(ns)) ? screen_begins[g_begin] : nv;
+        const idx N = nv - pos0;
+        screen_X_means.resize(nv);
+        screen_vars.resize(nv, 0);
+        screen_transforms.resize(ns);
+        if (N <= 0) return;
+        cnt.n_new_screen_cols += N;
+        const bool trace = std::getenv("ADELIE_HIP_TRACE") != nullptr;
+        if (trace) { sync(); std::fprintf(stderr, "[panel] vars pos0=%d N=%d w=%p vars=%p vcol=%p\n", int(pos0), int(N), (const void*)w_dev, (void*)d_vars.p, (void*)d_vcol.p); }
+        sweep(w_dev, d_vars.p + pos0, d_vcol.p + pos0, N, nullptr, nullptr, true);
+        if (trace) { sync(); std::fprintf(stderr, "[panel] vars sweep ok\n"); }
+        std::vector<T> sxm(N);
+        for (idx ss = idx(g_begin); ss < ns; ++ss) {
+            const idx g = screen_set[ss], b = screen_begins[ss];
+            screen_X_means[b] = xm_host[groups[g]];
+            sxm[b - pos0] = screen_X_means[b];
+            screen_transforms[ss] = std::vector<T>{T(1)};
+        }
+        d_sxm.upload(sxm.data(), sxm.size(), st, pos0);
+        launch_center_vars<T>(d_vars.p + pos0, d_sxm.p + pos0, int(N), intercept, st);
+        d_vars.download(screen_vars.data() + pos0, size_t(N), st, pos0);
+        sync();
+        if (trace) std::fprintf(stderr, "[panel] vars done\n");
+        (void)xm_dev;
+    }
+
     // solver_gaussian_naive.hpp:134-176
     void gaussian_update_screen_derived() {
         const size_t old_groups = screen_transforms.size();
         update_screen_derived_base();
         device_append_screen();
-        update_gram_and_vars(d_w.p, d_xm.p, X_means, old_groups);
+        if (panel_mode()) update_vars_panel(d_w.p, d_xm.p, X_means, old_groups);
+        else update_gram_and_vars(d_w.p, d_xm.p, X_means, old_groups);
     }
 
     // optimization/search_pivot.hpp:7-62
@@ -628,6 +689,130 @@ struct Solver {
         sync();
     }
 
+    // Residual-based block passes (kernels_cd_panel.hip).  Per block: panel step (apply the previous block's changes to the
+    // residual, partial gradients of this block) -> reduce -> one-workgroup solve against the cached diagonal block.
+    // The residual is current when this returns (no end-of-fit update), also on failure (changes are undone).
+    void run_panel_passes(const CdParams<T>& cp, CdScalars<T>& sc, T* r_dev) {
+        const int B = cd_block_size();
+        const size_t maxblk = size_t((p + B - 1) / B + 1);
+        d_blk.reserve(1);
+        d_dlt.reserve(B);
+        d_dcolblk.reserve(B);
+        d_gblk.reserve(B);
+        d_actcols.reserve(size_t(p) + B);
+        d_part.reserve(size_t(panel_part_elems(n)));
+        if (dscr_nb.size() != maxblk) {
+            d_Dpool.reserve(size_t(2) * maxblk * B * B);
+            AHIP_CHECK(hipMemsetAsync(d_Dpool.p, 0, size_t(2) * maxblk * B * B * sizeof(T), st));
+            dscr_nb.assign(maxblk, 0); dact_nb.assign(maxblk, 0);
+            dscr_ver.assign(maxblk, 0); dact_ver.assign(maxblk, 0);
+        }
+        CdBlkState<T> bs{};
+        bs.rsq = sc.rsq;
+        bs.resid_sum = sc.resid_sum;
+        bs.active_size = sc.active_size;
+        bs.status = CD_OK;
+        bs.nz = 0;
+        d_blk.upload(&bs, 1, st);
+        CdBlkParams<T> bp{};
+        bp.nv = cp.nv; bp.vars = cp.vars; bp.xmean = cp.xmean; bp.spen = cp.spen;
+        bp.beta = cp.beta; bp.is_active = cp.is_active; bp.active_set = cp.active_set;
+        bp.l1 = cp.lmda * cp.alpha; bp.l2 = cp.lmda * (T(1) - cp.alpha);
+        bp.max_active_size = cp.max_active_size;
+        bp.dlt = d_dlt.p; bp.st = d_blk.p;
+        bp.gblk = d_gblk.p; bp.vcol = cp.vcol; bp.dcol = d_dcolblk.p;
+        const T* xm_c = intercept ? cur_xm : nullptr;
+        if (std::getenv("ADELIE_HIP_TRACE")) { sync(); std::fprintf(stderr, "[panel] enter nv=%d asz=%d\n", cp.nv, sc.active_size); }
+        static const bool trace = std::getenv("ADELIE_HIP_TRACE") != nullptr;
+        int64_t iters = 0;
+        int status = CD_OK;
+        int asz = sc.active_size;
+        auto pass = [&](bool screen_pass) -> T {
+            const int count = screen_pass ? cp.nv : asz;
+            if (count <= 0) return T(0);
+            const int32_t* cols_all = d_vcol.p;
+            if (!screen_pass) {
+                launch_gather_i32(d_vcol.p, cp.active_set, count, d_actcols.p, st);
+                cols_all = d_actcols.p;
+            }
+            auto& tab_nb = screen_pass ? dscr_nb : dact_nb;
+            auto& tab_ver = screen_pass ? dscr_ver : dact_ver;
+            T* pool = d_Dpool.p + (screen_pass ? size_t(0) : maxblk * B * B);
+            bp.list = screen_pass ? nullptr : cp.active_set;
+            bp.count = count;
+            bp.mark = screen_pass ? 1 : 0;
+            const int nblk = (count + B - 1) / B;
+            t_cd.begin(st);
+            for (int j = 0; j < nblk; ++j) {
+                const int nb = std::min(B, count - j * B);
+                const int32_t* cols = cols_all + size_t(j) * B;
+                T* Dptr = pool + size_t(j) * B * B;
+                if (tab_nb[j] != nb || tab_ver[j] != w_version) {
+                    t_cd.end(st);
+                    gram_block(cur_w, cols, nb, cur_xm, Dptr);
+                    if (trace) { sync(); std::fprintf(stderr, "[panel] gram j=%d nb=%d ok\n", j, nb); }
+                    t_cd.begin(st);
+                    tab_nb[j] = nb;
+                    tab_ver[j] = w_version;
+                    ++cnt.n_panel_grams;
+                }
+                const int nsl = panel_step(cur_w, r_dev, d_dcolblk.p, d_dlt.p, &d_blk.p->nz, cols, nb);
+                if (trace) { sync(); std::fprintf(stderr, "[panel] step j=%d nsl=%d ok\n", j, nsl); }
+                launch_panel_reduce<T>(d_part.p, nsl, nb, cols, &d_blk.p->resid_sum, xm_c, d_gblk.p, st);
+                if (trace) { sync(); std::fprintf(stderr, "[panel] reduce ok\n"); }
+                bp.Dptr = Dptr;
+                launch_cd_panel_solve<T>(bp, j, st);
+                if (trace) { sync(); std::fprintf(stderr, "[panel] solve ok\n"); }
+            }
+            t_cd.end(st);
+            cnt.n_panel_blocks += nblk;
+            d_blk.download(&bs, 1, st);
+            sync();
+            status = bs.status;
+            asz = bs.active_size;
+            if (trace) std::fprintf(stderr, "[panel] %s count=%d nblk=%d cm=%g tol=%g status=%d asz=%d nz=%d rsq=%g rsum=%g nupd=%lld\n",
+                                    screen_pass ? "screen" : "active", count, nblk, double(bs.cm), double(cp.tol), status, asz,
+                                    bs.nz, double(bs.rsq), double(bs.resid_sum), (long long)bs.n_updates);
+            return bs.cm;
+        };
+        while (status == CD_OK) {
+            while (status == CD_OK) { // solve_active, pin_naive:173-215
+                ++iters;
+                ++sc.n_passes_active;
+                sc.n_visits_active += asz;
+                const T cm = pass(false);
+                if (status != CD_OK) break;
+                if (cm < cp.tol) break;
+                if (iters >= cp.max_iters) { status = CD_MAX_CDS; break; }
+            }
+            if (status != CD_OK) break;
+            ++iters;
+            ++sc.n_passes_screen;
+            sc.n_visits_screen += cp.nv;
+            const T cm = pass(true);
+            if (status != CD_OK) break;
+            if (cm < cp.tol) break;
+            if (iters >= cp.max_iters) { status = CD_MAX_CDS; break; }
+        }
+        // flush the last block's changes into the residual
+        t_cd.begin(st);
+        panel_step(cur_w, r_dev, d_dcolblk.p, d_dlt.p, &d_blk.p->nz, d_vcol.p, 0);
+        t_cd.end(st);
+        sc.rsq = bs.rsq;
+        sc.resid_sum = bs.resid_sum;
+        sc.iters = iters;
+        sc.n_updates = bs.n_updates;
+        sc.active_size = asz;
+        sc.status = status;
+        sc.n_delta = 0;
+        if (status != CD_OK) {
+            // undo: r += X_S (beta - beta0)   (solver_gaussian_naive.hpp:286-290,326-329 restore the saved residual)
+            launch_cd_compact<T>(cp.beta, cp.beta0, cp.vcol, cp.nv, cp.dcols, cp.dvals, &cp.sc->n_delta, st);
+            axpy_cols(cp.dcols, cp.dvals, &cp.sc->n_delta, 0, T(1), r_dev);
+            sync();
+        }
+    }
+
     // Same for problems with groups: blocks of consecutive groups (<= 128 values), partition built on the host.
     DevBuf<int32_t> d_blk_g0;
     std::vector<int32_t> part_host;
@@ -775,7 +960,9 @@ struct Solver {
         cp.max_group_size = int32_t(max_gs);
         Stopwatch sw;
         sw.start();
-        if (nv > 0 && all_scalar && nv >= cd_block_min_nv) {
+        if (nv > 0 && panel_mode()) {
+            run_panel_passes(cp, sc, r_dev);
+        } else if (nv > 0 && all_scalar && nv >= cd_block_min_nv) {
             run_block_passes(cp, sc);
         } else if (nv > 0 && !all_scalar && max_gs <= cd_block_size() && nv >= cd_block_min_nv) {
             run_group_block_passes(cp, sc);
@@ -872,7 +1059,9 @@ struct Solver {
         CdScalars<T> sc{};
         sc.resid_sum = resid_sum;
         d_sc.upload(&sc, 1, st);
-        load_screen_gradient(d_w.p, d_r.p, &d_sc.p->resid_sum);
+        cur_w = d_w.p;
+        cur_xm = d_xm.p;
+        if (!panel_mode()) load_screen_gradient(d_w.p, d_r.p, &d_sc.p->resid_sum);
         T rsum = resid_sum;
         FitOut<T> o = pin_solve(lm, tol * y_var, rsq, rsum, y_mean, d_r.p);
         resid_sum = rsum;
@@ -911,7 +1100,6 @@ struct Solver {
             d_sums.download(sums, 3, st);
             sync();
             const T ym = sums[0];
-            const T yv = sums[1] - T(intercept) * ym * ym;
             T rsum;
             if (intercept) {
                 const T shift = beta0 - ym;
@@ -941,14 +1129,18 @@ struct Solver {
                 gram_nv = 0;
                 v_used = 0;
                 screen_transforms.clear();
-                update_gram_and_vars(d_irls_w.p, d_irls_xm.p, irls_xm_host, 0);
+                if (panel_mode()) update_vars_panel(d_irls_w.p, d_irls_xm.p, irls_xm_host, 0);
+                else update_gram_and_vars(d_irls_w.p, d_irls_xm.p, irls_xm_host, 0);
             }
+            ++w_version;
+            cur_w = d_irls_w.p;
+            cur_xm = d_irls_xm.p;
             // gradient of the screen values for the working response
             CdScalars<T> sc{};
             sc.resid_sum = rsum;
             d_sc.upload(&sc, 1, st);
             grad_valid = false;
-            if (nv > 0) {
+            if (nv > 0 && !panel_mode()) {
                 launch_vmul<T>(d_irls_w.p, d_irls_resid.p, d_v.p, n, st);
                 sweep(d_v.p, d_g.p, d_vcol.p, nv, &d_sc.p->resid_sum, intercept ? d_irls_xm.p : nullptr);
             }
@@ -1089,7 +1281,8 @@ struct Solver {
             device_append_screen();
             t_host[1] += sw.elapsed();
             sw.start();
-            update_gram_and_vars(d_w.p, d_xm.p, X_means, old_groups);
+            if (panel_mode()) update_vars_panel(d_w.p, d_xm.p, X_means, old_groups);
+            else update_gram_and_vars(d_w.p, d_xm.p, X_means, old_groups);
             t_host[2] += sw.elapsed();
         }
     }
@@ -1260,6 +1453,7 @@ struct Solver {
 
         AHIP_CHECK(hipSetDevice(X->device));
         if (const char* e = std::getenv("ADELIE_HIP_CD_BLOCK_MIN_NV")) cd_block_min_nv = std::atoll(e); // test hook
+        if (const char* e = std::getenv("ADELIE_HIP_CD_ENGINE")) engine_panel = std::string(e) != "gram"; // A/B hook
         // device allocations
         d_r.reserve(n); d_v.reserve(n); d_grad.reserve(p); d_absgrad.reserve(G); d_penalty.reserve(G);
         d_groups.reserve(G); d_gsizes.reserve(G); d_slot.reserve(G);
@@ -1453,6 +1647,8 @@ struct Result : ResultBase {
             case ADELIE_HIP_S_N_GRAM_COL_READS: return double(s.cnt.n_gram_col_reads);
             case ADELIE_HIP_S_N_RESID_COL_READS: return double(s.cnt.n_resid_col_reads);
             case ADELIE_HIP_S_GRAM_FLOPS: return s.cnt.gram_flops;
+            case ADELIE_HIP_S_N_PANEL_BLOCKS: return double(s.cnt.n_panel_blocks);
+            case ADELIE_HIP_S_N_PANEL_GRAMS: return double(s.cnt.n_panel_grams);
             case ADELIE_HIP_S_T_SWEEP_MS: return s.t_sweep.ms;
             case ADELIE_HIP_S_T_GRAM_MS: return s.t_gram.ms;
             case ADELIE_HIP_S_T_CD_MS: return s.t_cd.ms;

@@ -219,6 +219,7 @@ enum adelie_hip_scalar {
     ADELIE_HIP_S_N_CD_VISITS_ACTIVE, ADELIE_HIP_S_N_UPDATES, ADELIE_HIP_S_N_IRLS_ITERS,
     ADELIE_HIP_S_N_NEW_SCREEN_COLS, ADELIE_HIP_S_N_CD_PASSES_SCREEN, ADELIE_HIP_S_N_CD_PASSES_ACTIVE,
     ADELIE_HIP_S_N_GRAM_COL_READS, ADELIE_HIP_S_N_RESID_COL_READS, ADELIE_HIP_S_GRAM_FLOPS,
+    ADELIE_HIP_S_N_PANEL_BLOCKS, ADELIE_HIP_S_N_PANEL_GRAMS, /* block visits / diagonal blocks built by the panel engine */
     /* HIP-event time (ms) of the device phases on the design's stream, summed over the solve, and launch counts */
     ADELIE_HIP_S_T_SWEEP_MS = 80, ADELIE_HIP_S_T_GRAM_MS, ADELIE_HIP_S_T_CD_MS, ADELIE_HIP_S_T_AXPY_MS,
     ADELIE_HIP_S_N_SWEEP_LAUNCHES, ADELIE_HIP_S_N_GRAM_LAUNCHES, ADELIE_HIP_S_T_HOST_SCREEN_MS

@@ -196,11 +196,15 @@ def test_caller_state_untouched_and_result_surface(hip):
     assert st.screen_is_active.dtype == bool and st.active_set.shape == (30,)
 
 
-@pytest.mark.parametrize("n,p,alpha", [(400, 300, 1.0), (1500, 700, 0.6)])
-def test_block_cd_passes_match_oracle(hip, oracle, monkeypatch, n, p, alpha):
-    """Forces the multi-CU block Gauss-Seidel passes (kernels_cd_block.hip) at sizes the oracle checks in seconds:
-    several 128-visit blocks per pass, ragged last block, active-set growth inside screen passes."""
+@pytest.mark.parametrize("engine", ["panel", "gram"])
+@pytest.mark.parametrize("n,p,alpha", [(400, 300, 1.0), (1500, 700, 0.6), (1027, 520, 1.0)])
+def test_block_cd_passes_match_oracle(hip, oracle, monkeypatch, n, p, alpha, engine):
+    """Forces the multi-CU block Gauss-Seidel passes at sizes the oracle checks in seconds: several 128-visit blocks per
+    pass, ragged last block, active-set growth inside screen passes, n not a multiple of the row slice.
+    engine "panel": residual-based blocks with cached diagonal Gram blocks (kernels_cd_panel.hip, the default);
+    engine "gram": full screen-set Gram kept current (kernels_cd_block.hip)."""
     monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    monkeypatch.setenv("ADELIE_HIP_CD_ENGINE", engine)
     d = make_gaussian(n, p, seed=11, sparsity=0.5, weights=True)
     # beta is resolved to ~sqrt(tol) by the stopping rule; 1e-14 makes two trajectories that differ in the order of
     # the first activation (the lambda_0 == lmda_max tie) agree to 1e-6
@@ -239,3 +243,45 @@ def test_group_block_cd_passes_match_oracle(hip, oracle, monkeypatch, alpha):
     assert_same_path(a, b, 1e-6)
     assert a.active_set_size > 30
     assert abs(a.counters["n_updates"] - b.counters["n_updates"]) <= 0.02 * b.counters["n_updates"] + 5
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_panel_engine_binomial_snp(hip, oracle, monkeypatch, dtype):
+    """IRLS on a 2-bit SNP design through the panel engine: the diagonal blocks are rebuilt per IRLS iteration (weights
+    change), the residual of the working response is updated block by block (solver_glm_naive.hpp:234-459)."""
+    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    rng = np.random.default_rng(5)
+    n, p = 1501, 400
+    u = rng.random((n, p))
+    cd = np.zeros((n, p), dtype=np.int8, order="F")
+    cd[u < 0.25] = 1
+    cd[(u >= 0.25) & (u < 0.30)] = 2
+    cd[u >= 0.92] = -9
+    imp = ad.matrix.compute_impute(cd)
+    Xd = np.where(cd < 0, imp[None, :], cd).astype(np.float64)
+    beta = rng.standard_normal(p) * (rng.random(p) < 0.1)
+    eta = Xd @ beta
+    eta = (eta - eta.mean()) / eta.std()
+    y = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(np.float64)
+    kw = dict(early_exit=False, lmda_path_size=12, min_ratio=0.05, tol=1e-12 if dtype == np.float64 else 1e-7,
+              irls_tol=1e-10 if dtype == np.float64 else 1e-6)
+    a = ad.grpnet(ad.matrix.snp_calldata(cd, imp, dtype=dtype), ad.glm.binomial(y, dtype=dtype), **kw)
+    b = ad.grpnet(oracle.snp_calldata(cd, imp, dtype=dtype), ad.glm.binomial(y, dtype=dtype), **kw)
+    assert a.error == "" and b.error == ""
+    assert a.counters["n_panel_blocks"] > 0 and a.counters["n_panel_grams"] > 0
+    assert_same_path(a, b, 1e-6 if dtype == np.float64 else 5e-3)
+
+
+def test_panel_engine_matches_gram_engine(hip, monkeypatch):
+    """Both engines run the same Gauss-Seidel sequence: same path to rounding, same number of coordinate updates."""
+    d = make_gaussian(3000, 1500, seed=21, sparsity=0.7)
+    kw = dict(early_exit=False, lmda_path_size=30, min_ratio=1e-2, tol=1e-14)
+    out = {}
+    for eng in ["panel", "gram"]:
+        monkeypatch.setenv("ADELIE_HIP_CD_ENGINE", eng)
+        out[eng] = ad.grpnet(ad.matrix.dense(d["X"]), ad.glm.gaussian(d["y"]), **kw)
+    a, b = out["panel"], out["gram"]
+    assert a.counters["n_panel_blocks"] > 0 and b.counters["n_panel_blocks"] == 0
+    assert_same_path(a, b, 1e-7)
+    assert abs(a.counters["n_updates"] - b.counters["n_updates"]) <= 0.01 * b.counters["n_updates"]
+    np.testing.assert_allclose(a.resid, b.resid, atol=1e-9)

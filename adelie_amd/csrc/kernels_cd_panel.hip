@@ -70,7 +70,11 @@ __device__ __forceinline__ RawDense<T, VEC> praw(const DenseAcc<T>& X, int64_t j
         using V = typename VecOf<T>::type;
         static_assert(VEC == VecOf<T>::N, "dense vector width");
         if (full) {
+#ifdef AHIP_PANEL_TEMPORAL
             const V x = *reinterpret_cast<const V*>(col + i);
+#else
+            const V x = __builtin_nontemporal_load(reinterpret_cast<const V*>(col + i));
+#endif
 #pragma unroll
             for (int e = 0; e < VEC; ++e) r.v.v[e] = x[e];
         } else {
@@ -107,8 +111,10 @@ template <class T, int VEC> struct RawOf<T, DenseAcc<T>, VEC> { using type = Raw
 template <class T, int VEC> struct RawOf<T, SnpAcc<T>, VEC> { using type = RawSnp; };
 
 // Latency structure (the kernel is bound by dependent HBM round trips otherwise): column indices and coefficients are
-// wave-uniform scalar loads; each wave keeps U = 16 column-slice loads in flight; the first batch of phase (B) is
-// issued before phase (A) so that its round trip overlaps (A)'s.
+// wave-uniform scalar loads; each wave keeps 16 (A) + 8 (B) column-slice loads in flight: the first batch of phase (B)
+// is issued before phase (A) so that its round trip overlaps (A)'s.  The register budget is held at 128 VGPRs so that
+// 4 workgroups fit per CU: 1024 resident slots cover the 782 row slices of n = 100k in ONE round (at 3 per CU a
+// handful of stragglers cost a whole second round).
 template <class T, class Acc, int VEC, bool FULL>
 __device__ __forceinline__ void panel_step_body(const Acc& X, int64_t n, const T* __restrict__ w, T* __restrict__ r,
                                                 const int32_t* __restrict__ dcol, const T* __restrict__ dlt, int nz,
@@ -122,13 +128,14 @@ __device__ __forceinline__ void panel_step_body(const Acc& X, int64_t n, const T
     const bool full = FULL ? true : (i + VEC <= n);
 
     // first batch of (B): columns wv, wv+4, ... of the next block
-    Raw xb[U];
-    int jb[U];
+    constexpr int UB = 8;
+    Raw xb[UB];
+    int jb[UB];
     if (nb > 0) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) jb[u] = cols[min(wv + 4 * u, nb - 1)];
+        for (int u = 0; u < UB; ++u) jb[u] = cols[min(wv + 4 * u, nb - 1)];
 #pragma unroll
-        for (int u = 0; u < U; ++u) xb[u] = praw<T, VEC>(X, jb[u], i, n, full);
+        for (int u = 0; u < UB; ++u) xb[u] = praw<T, VEC>(X, jb[u], i, n, full);
     }
 
     // ---- (A) residual slice -= X[slice, changed columns] * del ---------------------------------------------------------
@@ -182,16 +189,16 @@ __device__ __forceinline__ void panel_step_body(const Acc& X, int64_t n, const T
     T wr[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) wr[e] = wrs[lane * VEC + e];
-    for (int c0 = wv; c0 < nb; c0 += 4 * U) {
+    for (int c0 = wv; c0 < nb; c0 += 4 * UB) {
         if (c0 != wv) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) jb[u] = cols[min(c0 + 4 * u, nb - 1)];
+            for (int u = 0; u < UB; ++u) jb[u] = cols[min(c0 + 4 * u, nb - 1)];
 #pragma unroll
-            for (int u = 0; u < U; ++u) xb[u] = praw<T, VEC>(X, jb[u], i, n, full);
+            for (int u = 0; u < UB; ++u) xb[u] = praw<T, VEC>(X, jb[u], i, n, full);
         }
-        T pu[U];
+        T pu[UB];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < UB; ++u) {
             const Pack<T, VEC> xx = pdecode<T, VEC>(X, xb[u], jb[u], i, n);
             T sacc = T(0);
 #pragma unroll
@@ -199,17 +206,17 @@ __device__ __forceinline__ void panel_step_body(const Acc& X, int64_t n, const T
             pu[u] = sacc;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) pu[u] = wave_sum64(pu[u]);
+        for (int u = 0; u < UB; ++u) pu[u] = wave_sum64(pu[u]);
         if (lane == 0) {
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int u = 0; u < UB; ++u)
                 if (c0 + 4 * u < nb) part[int64_t(c0 + 4 * u) * part_ld + blockIdx.x] = pu[u];
         }
     }
 }
 
 template <class T, class Acc, int VEC>
-__global__ __launch_bounds__(PT) void panel_step_kernel(Acc X, int64_t n, const T* __restrict__ w, T* __restrict__ r,
+__global__ __launch_bounds__(PT, 4) void panel_step_kernel(Acc X, int64_t n, const T* __restrict__ w, T* __restrict__ r,
                                                         const int32_t* __restrict__ dcol, const T* __restrict__ dlt,
                                                         const int32_t* __restrict__ nz_dev,
                                                         const int32_t* __restrict__ cols, int nb, T* __restrict__ part,

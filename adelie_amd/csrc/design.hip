@@ -94,7 +94,8 @@ void create_snp_from_calldata(adelie_hip_design* d, const int8_t* calldata, cons
     AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&tmp), size_t(n) * size_t(std::min(panel, p))));
     for (int64_t j0 = 0; j0 < p; j0 += panel) {
         const int64_t pc = std::min(panel, p - j0);
-        AHIP_CHECK(hipMemcpyAsync(tmp, calldata + j0 * n, size_t(n) * size_t(pc), hipMemcpyHostToDevice, d->stream));
+        // hipMemcpyDefault: the calldata may live on the host or (generated in place) on this device
+        AHIP_CHECK(hipMemcpyAsync(tmp, calldata + j0 * n, size_t(n) * size_t(pc), hipMemcpyDefault, d->stream));
         launch_pack_snp(tmp, n, pc, d->bits + j0 * d->ldb, d->ldb, d->stream);
         AHIP_CHECK(hipStreamSynchronize(d->stream));
     }

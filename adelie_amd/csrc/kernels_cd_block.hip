@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j)
     T nb0 = b0, nb1 = b1; // new coefficients of this lane's two coordinates
 #define AHIP_BLK_VISIT(GREG, BREG, AREG, LREG, NREG, RREG, XREG, ACTREG, NBREG, IL)                                   \
     {                                                                                                                  \
+        const T dc0 = D[i * BLK + lane], dc1 = D[i * BLK + lane + 64]; /* off the dependent chain: issued first */  \
         const T gcur = rdlane(GREG, IL);                                                                           \
         const T bi = rdlane(BREG, IL), A = rdlane(AREG, IL);                                                   \
         const T gk = fma(bi, A, gcur);                    /* pin_naive:85-89 */                                       \
@@ -165,9 +166,8 @@ __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j)
                 ++asz;                                                                                                 \
             }                                                                                                          \
             if (lane == (IL)) NBREG = ak;                                                                              \
-            const T* Dc = D + i * BLK;                                                                                 \
-            g0 = fma(-del, Dc[lane], g0);                                                                              \
-            g1 = fma(-del, Dc[lane + 64], g1);                                                                         \
+            g0 = fma(-del, dc0, g0);                                                                                   \
+            g1 = fma(-del, dc1, g1);                                                                                   \
             ++n_upd;                                                                                                   \
         }                                                                                                              \
     }

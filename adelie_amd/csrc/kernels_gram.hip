@@ -177,15 +177,33 @@ __global__ void gram_reduce_kernel(const T* __restrict__ part, int nsplit, int64
                                    int32_t N, const int32_t* __restrict__ mcols, const int32_t* __restrict__ ncols,
                                    int32_t m_pos0, int32_t n_pos0, const T* __restrict__ xm, int center,
                                    int symmetric, T* __restrict__ C, int64_t ldc) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x; // M index (fast: coalesced partial reads)
+    // 64 consecutive M indices per block (coalesced partial reads) x 4 interleaved groups of K-splits; the four group
+    // sums are combined in a fixed order, so the result does not depend on scheduling
+    __shared__ T red[4][64];
+    const int ta = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    const int a = blockIdx.x * 64 + ta;
     const int b = blockIdx.y;
-    if (a >= M || b >= N) return;
+    const bool live = a < M && b < N;
     const int64_t rp = int64_t(m_pos0) + a, cp = int64_t(n_pos0) + b;
     // inside the (new x new) square every unordered pair is taken from its lower-triangle entry only,
     // so that C is exactly symmetric
-    if (symmetric && rp >= n_pos0 && rp < cp) return;
+    const bool skip = !live || (symmetric && rp >= n_pos0 && rp < cp);
     T s = T(0);
-    for (int sp = 0; sp < nsplit; ++sp) s += part[int64_t(sp) * Mpad * Npad + int64_t(b) * Mpad + a];
+    if (!skip) {
+        const int64_t stride = Mpad * Npad;
+        const T* base = part + int64_t(b) * Mpad + a;
+        int sp = tg;
+        for (; sp + 12 < nsplit; sp += 16) {
+            const T v0 = base[int64_t(sp) * stride], v1 = base[int64_t(sp + 4) * stride];
+            const T v2 = base[int64_t(sp + 8) * stride], v3 = base[int64_t(sp + 12) * stride];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; sp < nsplit; sp += 4) s += base[int64_t(sp) * stride];
+    }
+    red[tg][ta] = s;
+    __syncthreads();
+    if (tg != 0 || skip) return;
+    s = (red[0][ta] + red[1][ta]) + (red[2][ta] + red[3][ta]);
     if (center) s -= xm[mcols[a]] * xm[ncols[b]];
     C[rp + cp * ldc] = s;
     if (symmetric) C[cp + rp * ldc] = s;
@@ -245,7 +263,7 @@ void gram_launch(Acc acc, bool vecok, const T* w, const int32_t* mcols, int32_t 
         if (vecok) AHIP_GRAM_LAUNCH(true, 64, 1, g.n128 * 128); else AHIP_GRAM_LAUNCH(false, 64, 1, g.n128 * 128);
     }
 #undef AHIP_GRAM_LAUNCH
-    hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3((unsigned)((M + 255) / 256), (unsigned)N), dim3(256), 0, s, work,
+    hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3((unsigned)((M + 63) / 64), (unsigned)N), dim3(256), 0, s, work,
                        g.nsplit, Mpad, Npad, M, N, mcols, ncols, m_pos0, n_pos0, xm, center ? 1 : 0, symmetric, C, ldc);
 }
 

@@ -313,15 +313,30 @@ def snp_calldata(calldata, impute=None, *, dtype=np.float64, n_threads: int = 1,
     """SNP design straight from an int8 ``(n, p)`` calldata matrix (negative = missing), skipping the
     ``.snpdat`` file.  ``impute`` defaults to the column mean of the non-missing calls
     (reference ``io/utils.hpp:10-31``)."""
-    calldata = np.asfortranarray(calldata, dtype=np.int8)
-    n, p = calldata.shape
-    if impute is None:
-        impute = compute_impute(calldata)
+    if hasattr(calldata, "data_ptr"):
+        # a torch int8 tensor already on the device, column-major (n, p): packed in place, no host round trip
+        import torch
+
+        if calldata.dtype != torch.int8 or calldata.dim() != 2 or calldata.stride() != (1, calldata.shape[0]):
+            raise RuntimeError("adelie_core: device calldata must be an int8 (n, p) tensor with strides (1, n).")
+        n, p = calldata.shape
+        if impute is None:
+            valid = calldata >= 0
+            cnt = valid.sum(dim=0).clamp(min=1)
+            impute = ((calldata * valid).sum(dim=0, dtype=torch.float64) / cnt).cpu().numpy()
+        ptr = calldata.data_ptr()
+        device = calldata.device.index if calldata.is_cuda else device
+    else:
+        calldata = np.asfortranarray(calldata, dtype=np.int8)
+        n, p = calldata.shape
+        if impute is None:
+            impute = compute_impute(calldata)
+        ptr = calldata.ctypes.data
     impute = np.ascontiguousarray(impute, dtype=np.float64)
     backend = _abi.hip_backend()
     handle = _abi.C.c_void_p()
     backend.check(backend.fn("design_create_snp_calldata")(
-        calldata.ctypes.data, n, p, impute.ctypes.data, _abi.dtype_code(dtype), device, handle))
+        ptr, n, p, impute.ctypes.data, _abi.dtype_code(dtype), device, handle))
     return _wrap(backend, handle, np.dtype(dtype).type, n_threads)
 
 

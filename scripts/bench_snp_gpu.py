@@ -1,0 +1,47 @@
+"""Config 4 (binomial lasso, 2-bit SNP design) at scale: calldata generated on the device.  argv: n p [L] [early_exit]"""
+import sys, os, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import adelie_amd as ad
+n, p = int(sys.argv[1]), int(sys.argv[2])
+L = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+ee = bool(int(sys.argv[4])) if len(sys.argv) > 4 else True
+budget = float(sys.argv[5]) if len(sys.argv) > 5 else 600.0
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev); g.manual_seed(0)
+t0 = time.perf_counter()
+cdt = torch.empty((p, n), dtype=torch.int8, device=dev)   # (p, n) row-major == (n, p) column-major
+for j0 in range(0, p, 2048):
+    j1 = min(p, j0 + 2048)
+    u = torch.rand((j1 - j0, n), generator=g, device=dev)
+    blk = torch.zeros_like(u, dtype=torch.int8)
+    blk[u < 0.25] = 1
+    blk[(u >= 0.25) & (u < 0.30)] = 2
+    blk[u >= 0.90] = -9
+    cdt[j0:j1] = blk
+cd = cdt.t()
+valid = cd >= 0
+imp = ((cd * valid).sum(dim=0, dtype=torch.float64) / valid.sum(dim=0).clamp(min=1))
+rng = np.random.default_rng(0)
+beta = rng.standard_normal(p) * (rng.random(p) < min(0.05, 500 / p))
+eta = torch.zeros(n, dtype=torch.float64, device=dev)
+for j in np.flatnonzero(beta):
+    c = cd[:, j].to(torch.float64)
+    c = torch.where(c < 0, imp[j], c)
+    eta += c * beta[j]
+eta = ((eta - eta.mean()) / eta.std()).cpu().numpy()
+y = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(np.float64)
+torch.cuda.synchronize()
+print("gen %.1fs  nnz(beta)=%d" % (time.perf_counter() - t0, int((beta != 0).sum())), flush=True)
+t0 = time.perf_counter()
+X = ad.matrix.snp_calldata(cd, imp.cpu().numpy())
+del cdt, cd, valid
+torch.cuda.empty_cache()
+print("pack %.2fs" % (time.perf_counter() - t0), flush=True)
+for rep in range(2):
+    t0 = time.perf_counter()
+    def ec(view, t0=t0):
+        return (time.perf_counter() - t0) > budget
+    st = ad.grpnet(X, ad.glm.binomial(y), early_exit=ee, lmda_path_size=L, exit_cond=ec)
+    el = time.perf_counter() - t0
+    print("path %.2fs  nsol %d err %r dev %.4f active %d screen %d" % (el, len(st.lmdas), st.error, st.devs[-1] if len(st.devs) else -1, st.active_set_size, len(st.screen_set)), flush=True)
+    print("  ", {k: round(v, 1) for k, v in st.timers.items()}, {k: st.counters[k] for k in ["n_irls_iters", "n_updates", "n_cd_passes_screen", "n_cd_passes_active", "n_panel_blocks", "n_panel_grams", "n_sweeps"]}, flush=True)

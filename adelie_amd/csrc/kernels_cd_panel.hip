@@ -20,6 +20,7 @@
 // Gauss-Seidel sequence of the reference in exact arithmetic.
 #include "kernels.hpp"
 #include "accessors.hpp"
+#include <cstdlib>
 
 namespace ahip {
 
@@ -53,6 +54,31 @@ __device__ __forceinline__ T wave_sum64(T x) {
     return (prdl(x, 0) + prdl(x, 16)) + (prdl(x, 32) + prdl(x, 48));
 }
 
+// Sums eight per-lane values over the 64 lanes at once (butterfly with halving): after the xor-1 / xor-2 / xor-4 steps a
+// lane carries one value (index lane & 7) summed over its group of 8, three more xor steps finish it.  ~10 exchange-adds
+// instead of 8 x 7 for eight separate wave sums; the order is fixed, so the result is deterministic.
+template <class T>
+__device__ __forceinline__ T reduce8(const T (&v)[8], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    T a[4], c[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const T keep = b0 ? v[2 * m + 1] : v[2 * m], send = b0 ? v[2 * m] : v[2 * m + 1];
+        a[m] = keep + pdpp<0xB1>(send); // xor 1
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const T keep = b1 ? a[2 * m + 1] : a[2 * m], send = b1 ? a[2 * m] : a[2 * m + 1];
+        c[m] = keep + pdpp<0x4E>(send); // xor 2
+    }
+    const T keep = b2 ? c[1] : c[0], send = b2 ? c[0] : c[1];
+    T t = keep + __shfl_xor(send, 4, 64);
+    t += pdpp<0x128>(t); // row_ror:8 == xor 8 inside a row of 16
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    return t; // lane l: total of value (l & 7)
+}
+
 // Raw (undecoded) row-slice loads: VEC consecutive rows of one column per lane.  Dense: the values themselves, with
 // temporal (cache-allocating) loads because the block's columns are read again by the next step.  SNP: the byte
 // holding the four 2-bit calls, decoded at use (keeps 16 loads in flight within the register budget).
@@ -60,35 +86,37 @@ template <class T, int VEC>
 struct RawDense { Pack<T, VEC> v; };
 struct RawSnp { unsigned byte; };
 
+// `full` == false (only in the ragged last slice): lanes whose rows lie beyond n read from row 0 instead (a valid
+// address) and every out-of-range element is zeroed by a select — no branches, so the loads of a batch stay in flight
+// together (a branchy tail path made the one ragged workgroup the slowest of the launch by ~10 us).
 template <class T, int VEC>
 __device__ __forceinline__ RawDense<T, VEC> praw(const DenseAcc<T>& X, int64_t j, int64_t i, int64_t n, bool full) {
     RawDense<T, VEC> r;
     const T* col = X.colptr(j);
     if constexpr (VEC == 1) {
-        r.v.v[0] = (i < n) ? col[i] : T(0);
+        const T x = col[(full || i < n) ? i : 0];
+        r.v.v[0] = (full || i < n) ? x : T(0);
     } else {
         using V = typename VecOf<T>::type;
         static_assert(VEC == VecOf<T>::N, "dense vector width");
-        if (full) {
+        // vector path requires ld % VEC == 0, so a lane starting below n may read up to VEC-1 pad elements: in bounds
+        const int64_t ii = (full || i < n) ? i : 0;
 #ifdef AHIP_PANEL_TEMPORAL
-            const V x = *reinterpret_cast<const V*>(col + i);
+        const V x = *reinterpret_cast<const V*>(col + ii);
 #else
-            const V x = __builtin_nontemporal_load(reinterpret_cast<const V*>(col + i));
+        const V x = __builtin_nontemporal_load(reinterpret_cast<const V*>(col + ii));
 #endif
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) r.v.v[e] = x[e];
-        } else {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) r.v.v[e] = (i + e < n) ? col[i + e] : T(0);
-        }
+        for (int e = 0; e < VEC; ++e) r.v.v[e] = (full || i + e < n) ? x[e] : T(0);
     }
     return r;
 }
 template <class T, int VEC>
-__device__ __forceinline__ RawSnp praw(const SnpAcc<T>& X, int64_t j, int64_t i, int64_t n, bool /*full*/) {
+__device__ __forceinline__ RawSnp praw(const SnpAcc<T>& X, int64_t j, int64_t i, int64_t n, bool full) {
     static_assert(VEC == 4, "one byte of calls per lane");
     RawSnp r;
-    r.byte = (i < n) ? unsigned(X.colptr(j)[i >> 2]) : 0u;
+    const unsigned b = unsigned(X.colptr(j)[((full || i < n) ? i : 0) >> 2]);
+    r.byte = (full || i < n) ? b : 0u;
     return r;
 }
 template <class T, int VEC>
@@ -205,13 +233,9 @@ __device__ __forceinline__ void panel_step_body(const Acc& X, int64_t n, const T
             for (int e = 0; e < VEC; ++e) sacc = fma(xx.v[e], wr[e], sacc);
             pu[u] = sacc;
         }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) pu[u] = wave_sum64(pu[u]);
-        if (lane == 0) {
-#pragma unroll
-            for (int u = 0; u < UB; ++u)
-                if (c0 + 4 * u < nb) part[int64_t(c0 + 4 * u) * part_ld + blockIdx.x] = pu[u];
-        }
+        static_assert(UB == 8, "reduce8");
+        const T tot = reduce8(pu, lane);
+        if (lane < UB && c0 + 4 * lane < nb) part[int64_t(c0 + 4 * lane) * part_ld + blockIdx.x] = tot;
     }
 }
 
@@ -230,6 +254,100 @@ __global__ __launch_bounds__(PT, 4) void panel_step_kernel(Acc X, int64_t n, con
         panel_step_body<T, Acc, VEC, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs);
     else
         panel_step_body<T, Acc, VEC, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs);
+}
+
+// Row-owner variant: a wave owns 64*VEC rows and walks ALL the columns of both phases itself (no cross-wave reduction,
+// no barrier); the WPB waves of a workgroup own consecutive row runs, so at any time the workgroup reads WPB KiB of
+// contiguous bytes from a handful of columns (DRAM-page and TLB friendly) instead of one KiB from 64 different columns.
+template <class T, class Acc, int VEC, int WPB, bool FULL>
+__device__ __forceinline__ void panel_step2_body(const Acc& X, int64_t n, const T* __restrict__ w,
+                                                                T* __restrict__ r, const int32_t* __restrict__ dcol,
+                                                                const T* __restrict__ dlt,
+                                                                int nz,
+                                                                const int32_t* __restrict__ cols, int nb,
+                                                                T* __restrict__ part, int64_t part_ld) {
+    constexpr int U = 16;
+    using Raw = typename RawOf<T, Acc, VEC>::type;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t slice = int64_t(blockIdx.x) * WPB + wv;
+    const int64_t i = slice * (64 * VEC) + int64_t(lane) * VEC;
+    if (slice * (64 * VEC) >= n) return;
+    const bool full = FULL ? true : (i + VEC <= n);
+    T rr[VEC], ww[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        rr[e] = (FULL || i + e < n) ? r[i + e] : T(0);
+        ww[e] = (FULL || i + e < n) ? w[i + e] : T(0);
+    }
+    if (nz > 0) {
+        T acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = T(0);
+        for (int m0 = 0; m0 < nz; m0 += U) {
+            Raw xa[U];
+            int ja[U];
+            T cf[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int m = m0 + u;
+                ja[u] = dcol[min(m, nz - 1)];
+                cf[u] = m < nz ? dlt[min(m, nz - 1)] : T(0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) xa[u] = praw<T, VEC>(X, ja[u], i, n, full);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const Pack<T, VEC> xx = pdecode<T, VEC>(X, xa[u], ja[u], i, n);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = fma(cf[u], xx.v[e], acc[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            rr[e] -= acc[e];
+            if (FULL || i + e < n) r[i + e] = rr[e];
+        }
+    }
+    T wr[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) wr[e] = ww[e] * rr[e];
+    for (int c0 = 0; c0 < nb; c0 += U) {
+        Raw xb[U];
+        int jb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) jb[u] = cols[min(c0 + u, nb - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xb[u] = praw<T, VEC>(X, jb[u], i, n, full);
+        T pu[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const Pack<T, VEC> xx = pdecode<T, VEC>(X, xb[u], jb[u], i, n);
+            T sacc = T(0);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sacc = fma(xx.v[e], wr[e], sacc);
+            pu[u] = wave_sum64(sacc);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (c0 + u < nb) part[int64_t(c0 + u) * part_ld + slice] = pu[u];
+        }
+    }
+}
+
+template <class T, class Acc, int VEC, int WPB>
+__global__ __launch_bounds__(64 * WPB) void panel_step2_kernel(Acc X, int64_t n, const T* __restrict__ w,
+                                                                T* __restrict__ r, const int32_t* __restrict__ dcol,
+                                                                const T* __restrict__ dlt,
+                                                                const int32_t* __restrict__ nz_dev,
+                                                                const int32_t* __restrict__ cols, int nb,
+                                                                T* __restrict__ part, int64_t part_ld) {
+    const int nz = nz_dev[0];
+    if ((int64_t(blockIdx.x) + 1) * WPB * 64 * VEC <= n)
+        panel_step2_body<T, Acc, VEC, WPB, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld);
+    else
+        panel_step2_body<T, Acc, VEC, WPB, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld);
 }
 
 template <class T>
@@ -273,8 +391,19 @@ int step_launch(const Acc& acc, int64_t n, const T* w, T* r, const int32_t* dcol
                 const int32_t* cols, int nb, T* part, hipStream_t s) {
     constexpr int RS = 64 * VEC;
     const int64_t ns = (n + RS - 1) / RS;
-    hipLaunchKernelGGL((panel_step_kernel<T, Acc, VEC>), dim3((unsigned)ns), dim3(PT), 0, s, acc, n, w, r, dcol, dlt,
-                       nz_dev, cols, nb, part, ns);
+    static const int variant = std::getenv("AHIP_PANEL_VARIANT") ? std::atoi(std::getenv("AHIP_PANEL_VARIANT")) : 0;
+    if (variant == 4)
+        hipLaunchKernelGGL((panel_step2_kernel<T, Acc, VEC, 4>), dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, s, acc, n, w,
+                           r, dcol, dlt, nz_dev, cols, nb, part, ns);
+    else if (variant == 2)
+        hipLaunchKernelGGL((panel_step2_kernel<T, Acc, VEC, 2>), dim3((unsigned)((ns + 1) / 2)), dim3(128), 0, s, acc, n, w,
+                           r, dcol, dlt, nz_dev, cols, nb, part, ns);
+    else if (variant == 1)
+        hipLaunchKernelGGL((panel_step2_kernel<T, Acc, VEC, 1>), dim3((unsigned)ns), dim3(64), 0, s, acc, n, w,
+                           r, dcol, dlt, nz_dev, cols, nb, part, ns);
+    else
+        hipLaunchKernelGGL((panel_step_kernel<T, Acc, VEC>), dim3((unsigned)ns), dim3(PT), 0, s, acc, n, w, r, dcol, dlt,
+                           nz_dev, cols, nb, part, ns);
     return int(ns);
 }
 

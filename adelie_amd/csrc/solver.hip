@@ -152,7 +152,7 @@ struct KTimer {
 struct Counters {
     int64_t n_basil_iters = 0, n_sweeps = 0, n_cd_visits_screen = 0, n_cd_visits_active = 0, n_updates = 0,
             n_irls_iters = 0, n_new_screen_cols = 0, n_cd_passes_screen = 0, n_cd_passes_active = 0,
-            n_gram_col_reads = 0, n_resid_col_reads = 0, n_panel_blocks = 0, n_panel_grams = 0;
+            n_gram_col_reads = 0, n_resid_col_reads = 0, n_panel_blocks = 0, n_panel_grams = 0, n_panel_cols = 0;
     double gram_flops = 0;
 };
 
@@ -215,7 +215,8 @@ struct Solver {
     std::vector<double> benchmark_screen, benchmark_fit_screen, benchmark_fit_active, benchmark_kkt, benchmark_invariance;
     std::vector<int> n_valid_solutions, active_sizes, screen_sizes;
     Counters cnt;
-    KTimer t_sweep, t_gram, t_cd, t_axpy;
+    KTimer t_sweep, t_gram, t_cd, t_axpy, t_step;
+    bool time_panel = false;
     int64_t cd_dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<std::pair<idx, idx>> gram_shapes;
     double t_host[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // wall-clock split of solve(): screen logic, append, gram+vars, fit, invariance, kkt+solutions
@@ -798,7 +799,10 @@ struct Solver {
                     tab_ver[j] = w_version;
                     ++cnt.n_panel_grams;
                 }
+                if (time_panel) t_step.begin(st);
                 const int nsl = panel_step(cur_w, r_dev, d_dcolblk.p, d_dlt.p, &d_blk.p->nz, cols, nb);
+                if (time_panel) t_step.end(st);
+                cnt.n_panel_cols += nb;
                 if (trace) { sync(); std::fprintf(stderr, "[panel] step j=%d nsl=%d ok\n", j, nsl); }
                 launch_panel_reduce<T>(d_part.p, nsl, nb, cols, &d_blk.p->resid_sum, xm_c, d_gblk.p, st);
                 if (trace) { sync(); std::fprintf(stderr, "[panel] reduce ok\n"); }
@@ -1414,7 +1418,7 @@ struct Solver {
 
     // pull the device-resident invariants back into the host mirrors that the result accessors expose
     void finalize() {
-        t_sweep.collect(); t_gram.collect(); t_cd.collect(); t_axpy.collect();
+        t_sweep.collect(); t_gram.collect(); t_cd.collect(); t_axpy.collect(); t_step.collect();
         if (std::getenv("ADELIE_HIP_DEBUG_GRAM")) {
             for (size_t i = 0; i < gram_shapes.size() && i < t_gram.each.size(); ++i) {
                 const double fl = 2.0 * double(n) * double(gram_shapes[i].first) * double(gram_shapes[i].second);
@@ -1496,6 +1500,7 @@ struct Solver {
         AHIP_CHECK(hipSetDevice(X->device));
         if (const char* e = std::getenv("ADELIE_HIP_CD_BLOCK_MIN_NV")) cd_block_min_nv = std::atoll(e); // test hook
         if (const char* e = std::getenv("ADELIE_HIP_CD_ENGINE")) engine_panel = std::string(e) != "gram"; // A/B hook
+        time_panel = std::getenv("ADELIE_HIP_TIME_PANEL") != nullptr;
         // device allocations
         d_r.reserve(n); d_v.reserve(n); d_grad.reserve(p); d_absgrad.reserve(G); d_penalty.reserve(G);
         d_groups.reserve(G); d_gsizes.reserve(G); d_slot.reserve(G);
@@ -1691,6 +1696,9 @@ struct Result : ResultBase {
             case ADELIE_HIP_S_GRAM_FLOPS: return s.cnt.gram_flops;
             case ADELIE_HIP_S_N_PANEL_BLOCKS: return double(s.cnt.n_panel_blocks);
             case ADELIE_HIP_S_N_PANEL_GRAMS: return double(s.cnt.n_panel_grams);
+            case ADELIE_HIP_S_N_PANEL_COLS: return double(s.cnt.n_panel_cols);
+            case ADELIE_HIP_S_T_PANEL_STEP_MS: return s.t_step.ms;
+            case ADELIE_HIP_S_N_PANEL_STEP_LAUNCHES: return double(s.t_step.launches);
             case ADELIE_HIP_S_T_SWEEP_MS: return s.t_sweep.ms;
             case ADELIE_HIP_S_T_GRAM_MS: return s.t_gram.ms;
             case ADELIE_HIP_S_T_CD_MS: return s.t_cd.ms;

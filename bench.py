@@ -137,6 +137,25 @@ def main():
     assert state.error == "", state.error
     assert len(state.lmdas) == args.lmda_path_size
 
+    # one extra, untimed step with per-launch events on the panel step kernel (second HBM-bound kernel of the path)
+    panel = None
+    if rank == 0:
+        os.environ["ADELIE_HIP_TIME_PANEL"] = "1"
+        stp = step()
+        del os.environ["ADELIE_HIP_TIME_PANEL"]
+        if stp.timers["n_panel_step_launches"] > 0:
+            s_ = np.dtype(npdtype).itemsize
+            cols = stp.counters["n_panel_cols"] + stp.counters["n_updates"]  # gradient columns + residual-update columns
+            bytes_ = float(cols) * n * s_
+            ms = stp.timers["t_panel_step_ms"]
+            panel = {
+                "kernel": "panel_step_kernel (r -= X_B dbeta_B of the previous block; partial gradients of the next block)",
+                "bound": "hbm", "achieved": bytes_ / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(n, p, args.dtype, "panel_step_kernel"),
+                "launches": int(stp.timers["n_panel_step_launches"]), "avg_launch_ms": ms / stp.timers["n_panel_step_launches"],
+                "algorithmic_bytes_per_launch": bytes_ / stp.timers["n_panel_step_launches"],
+            }
+
     if rank == 0:
         s = np.dtype(npdtype).itemsize
         sweep_bytes = float(n) * p * s  # algorithmic bytes of one launch: X read once (vectors are cache resident)
@@ -176,6 +195,7 @@ def main():
                 "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": sweep_bytes,
             },
+            "roofline_panel_step": panel,
             "breakdown_ms_last_step": {
                 "sweep": tm["t_sweep_ms"], "gram_mfma": tm["t_gram_ms"], "cd": tm["t_cd_ms"], "resid_axpy": tm["t_axpy_ms"],
                 "host_screen": tm["t_host_screen_ms"], "total": 1e3 * state.total_time,
@@ -194,12 +214,12 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(n, p, dtype):
+def measured_traffic(n, p, dtype, kernel="sweep_kernel"):
     """HBM bytes per sweep launch from the PMC passes kept under profiles/ (FETCH_SIZE doubled as the gfx950 note in
     guides/MI355X_MICROARCH.md prescribes, plus WRITE_SIZE); None when this shape was not profiled."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f).get(f"sweep_kernel:{n}x{p}:{dtype}")
+            return json.load(f).get(f"{kernel}:{n}x{p}:{dtype}")
     except Exception:
         return None
 

@@ -220,9 +220,12 @@ enum adelie_hip_scalar {
     ADELIE_HIP_S_N_NEW_SCREEN_COLS, ADELIE_HIP_S_N_CD_PASSES_SCREEN, ADELIE_HIP_S_N_CD_PASSES_ACTIVE,
     ADELIE_HIP_S_N_GRAM_COL_READS, ADELIE_HIP_S_N_RESID_COL_READS, ADELIE_HIP_S_GRAM_FLOPS,
     ADELIE_HIP_S_N_PANEL_BLOCKS, ADELIE_HIP_S_N_PANEL_GRAMS, /* block visits / diagonal blocks built by the panel engine */
+    ADELIE_HIP_S_N_PANEL_COLS, /* design columns streamed by the panel steps (gradient + residual update) */
     /* HIP-event time (ms) of the device phases on the design's stream, summed over the solve, and launch counts */
     ADELIE_HIP_S_T_SWEEP_MS = 80, ADELIE_HIP_S_T_GRAM_MS, ADELIE_HIP_S_T_CD_MS, ADELIE_HIP_S_T_AXPY_MS,
-    ADELIE_HIP_S_N_SWEEP_LAUNCHES, ADELIE_HIP_S_N_GRAM_LAUNCHES, ADELIE_HIP_S_T_HOST_SCREEN_MS
+    ADELIE_HIP_S_N_SWEEP_LAUNCHES, ADELIE_HIP_S_N_GRAM_LAUNCHES, ADELIE_HIP_S_T_HOST_SCREEN_MS,
+    /* per-launch timing of the panel step kernel; only collected when ADELIE_HIP_TIME_PANEL=1 (adds two events per launch) */
+    ADELIE_HIP_S_T_PANEL_STEP_MS, ADELIE_HIP_S_N_PANEL_STEP_LAUNCHES
 };
 int64_t     adelie_hip_result_size(const adelie_hip_result* r, int which);
 /* Copies min(size, cap) elements: value vectors as double, index vectors as int64. */

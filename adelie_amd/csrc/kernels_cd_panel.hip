@@ -20,7 +20,6 @@
 // Gauss-Seidel sequence of the reference in exact arithmetic.
 #include "kernels.hpp"
 #include "accessors.hpp"
-#include <cstdlib>
 
 namespace ahip {
 
@@ -256,100 +255,6 @@ __global__ __launch_bounds__(PT, 4) void panel_step_kernel(Acc X, int64_t n, con
         panel_step_body<T, Acc, VEC, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs);
 }
 
-// Row-owner variant: a wave owns 64*VEC rows and walks ALL the columns of both phases itself (no cross-wave reduction,
-// no barrier); the WPB waves of a workgroup own consecutive row runs, so at any time the workgroup reads WPB KiB of
-// contiguous bytes from a handful of columns (DRAM-page and TLB friendly) instead of one KiB from 64 different columns.
-template <class T, class Acc, int VEC, int WPB, bool FULL>
-__device__ __forceinline__ void panel_step2_body(const Acc& X, int64_t n, const T* __restrict__ w,
-                                                                T* __restrict__ r, const int32_t* __restrict__ dcol,
-                                                                const T* __restrict__ dlt,
-                                                                int nz,
-                                                                const int32_t* __restrict__ cols, int nb,
-                                                                T* __restrict__ part, int64_t part_ld) {
-    constexpr int U = 16;
-    using Raw = typename RawOf<T, Acc, VEC>::type;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t slice = int64_t(blockIdx.x) * WPB + wv;
-    const int64_t i = slice * (64 * VEC) + int64_t(lane) * VEC;
-    if (slice * (64 * VEC) >= n) return;
-    const bool full = FULL ? true : (i + VEC <= n);
-    T rr[VEC], ww[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        rr[e] = (FULL || i + e < n) ? r[i + e] : T(0);
-        ww[e] = (FULL || i + e < n) ? w[i + e] : T(0);
-    }
-    if (nz > 0) {
-        T acc[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[e] = T(0);
-        for (int m0 = 0; m0 < nz; m0 += U) {
-            Raw xa[U];
-            int ja[U];
-            T cf[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int m = m0 + u;
-                ja[u] = dcol[min(m, nz - 1)];
-                cf[u] = m < nz ? dlt[min(m, nz - 1)] : T(0);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) xa[u] = praw<T, VEC>(X, ja[u], i, n, full);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const Pack<T, VEC> xx = pdecode<T, VEC>(X, xa[u], ja[u], i, n);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[e] = fma(cf[u], xx.v[e], acc[e]);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            rr[e] -= acc[e];
-            if (FULL || i + e < n) r[i + e] = rr[e];
-        }
-    }
-    T wr[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) wr[e] = ww[e] * rr[e];
-    for (int c0 = 0; c0 < nb; c0 += U) {
-        Raw xb[U];
-        int jb[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) jb[u] = cols[min(c0 + u, nb - 1)];
-#pragma unroll
-        for (int u = 0; u < U; ++u) xb[u] = praw<T, VEC>(X, jb[u], i, n, full);
-        T pu[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const Pack<T, VEC> xx = pdecode<T, VEC>(X, xb[u], jb[u], i, n);
-            T sacc = T(0);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) sacc = fma(xx.v[e], wr[e], sacc);
-            pu[u] = wave_sum64(sacc);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (c0 + u < nb) part[int64_t(c0 + u) * part_ld + slice] = pu[u];
-        }
-    }
-}
-
-template <class T, class Acc, int VEC, int WPB>
-__global__ __launch_bounds__(64 * WPB) void panel_step2_kernel(Acc X, int64_t n, const T* __restrict__ w,
-                                                                T* __restrict__ r, const int32_t* __restrict__ dcol,
-                                                                const T* __restrict__ dlt,
-                                                                const int32_t* __restrict__ nz_dev,
-                                                                const int32_t* __restrict__ cols, int nb,
-                                                                T* __restrict__ part, int64_t part_ld) {
-    const int nz = nz_dev[0];
-    if ((int64_t(blockIdx.x) + 1) * WPB * 64 * VEC <= n)
-        panel_step2_body<T, Acc, VEC, WPB, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld);
-    else
-        panel_step2_body<T, Acc, VEC, WPB, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld);
-}
-
 template <class T>
 __global__ __launch_bounds__(PT) void panel_reduce_kernel(const T* __restrict__ part, int64_t part_ld, int nslices,
                                                           const int32_t* __restrict__ cols,
@@ -391,19 +296,8 @@ int step_launch(const Acc& acc, int64_t n, const T* w, T* r, const int32_t* dcol
                 const int32_t* cols, int nb, T* part, hipStream_t s) {
     constexpr int RS = 64 * VEC;
     const int64_t ns = (n + RS - 1) / RS;
-    static const int variant = std::getenv("AHIP_PANEL_VARIANT") ? std::atoi(std::getenv("AHIP_PANEL_VARIANT")) : 0;
-    if (variant == 4)
-        hipLaunchKernelGGL((panel_step2_kernel<T, Acc, VEC, 4>), dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, s, acc, n, w,
-                           r, dcol, dlt, nz_dev, cols, nb, part, ns);
-    else if (variant == 2)
-        hipLaunchKernelGGL((panel_step2_kernel<T, Acc, VEC, 2>), dim3((unsigned)((ns + 1) / 2)), dim3(128), 0, s, acc, n, w,
-                           r, dcol, dlt, nz_dev, cols, nb, part, ns);
-    else if (variant == 1)
-        hipLaunchKernelGGL((panel_step2_kernel<T, Acc, VEC, 1>), dim3((unsigned)ns), dim3(64), 0, s, acc, n, w,
-                           r, dcol, dlt, nz_dev, cols, nb, part, ns);
-    else
-        hipLaunchKernelGGL((panel_step_kernel<T, Acc, VEC>), dim3((unsigned)ns), dim3(PT), 0, s, acc, n, w, r, dcol, dlt,
-                           nz_dev, cols, nb, part, ns);
+    hipLaunchKernelGGL((panel_step_kernel<T, Acc, VEC>), dim3((unsigned)ns), dim3(PT), 0, s, acc, n, w, r, dcol, dlt,
+                       nz_dev, cols, nb, part, ns);
     return int(ns);
 }
 

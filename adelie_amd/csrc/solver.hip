@@ -479,10 +479,7 @@ struct Solver {
         screen_transforms.resize(ns);
         if (N <= 0) return;
         cnt.n_new_screen_cols += N;
-        const bool trace = std::getenv("ADELIE_HIP_TRACE") != nullptr;
-        if (trace) { sync(); std::fprintf(stderr, "[panel] vars pos0=%d N=%d w=%p vars=%p vcol=%p\n", int(pos0), int(N), (const void*)w_dev, (void*)d_vars.p, (void*)d_vcol.p); }
         sweep(w_dev, d_vars.p + pos0, d_vcol.p + pos0, N, nullptr, nullptr, true);
-        if (trace) { sync(); std::fprintf(stderr, "[panel] vars sweep ok\n"); }
         std::vector<T> sxm(N);
         for (idx ss = idx(g_begin); ss < ns; ++ss) {
             const idx g = screen_set[ss], b = screen_begins[ss];
@@ -494,7 +491,6 @@ struct Solver {
         launch_center_vars<T>(d_vars.p + pos0, d_sxm.p + pos0, int(N), intercept, st);
         d_vars.download(screen_vars.data() + pos0, size_t(N), st, pos0);
         sync();
-        if (trace) std::fprintf(stderr, "[panel] vars done\n");
         (void)xm_dev;
     }
 
@@ -765,7 +761,6 @@ struct Solver {
         bp.dlt = d_dlt.p; bp.st = d_blk.p;
         bp.gblk = d_gblk.p; bp.vcol = cp.vcol; bp.dcol = d_dcolblk.p;
         const T* xm_c = intercept ? cur_xm : nullptr;
-        if (std::getenv("ADELIE_HIP_TRACE")) { sync(); std::fprintf(stderr, "[panel] enter nv=%d asz=%d\n", cp.nv, sc.active_size); }
         static const bool trace = std::getenv("ADELIE_HIP_TRACE") != nullptr;
         int64_t iters = 0;
         int status = CD_OK;
@@ -793,7 +788,6 @@ struct Solver {
                 if (tab_nb[j] != nb || tab_ver[j] != w_version) {
                     t_cd.end(st);
                     gram_block(cur_w, cols, nb, cur_xm, Dptr);
-                    if (trace) { sync(); std::fprintf(stderr, "[panel] gram j=%d nb=%d ok\n", j, nb); }
                     t_cd.begin(st);
                     tab_nb[j] = nb;
                     tab_ver[j] = w_version;
@@ -803,12 +797,9 @@ struct Solver {
                 const int nsl = panel_step(cur_w, r_dev, d_dcolblk.p, d_dlt.p, &d_blk.p->nz, cols, nb);
                 if (time_panel) t_step.end(st);
                 cnt.n_panel_cols += nb;
-                if (trace) { sync(); std::fprintf(stderr, "[panel] step j=%d nsl=%d ok\n", j, nsl); }
                 launch_panel_reduce<T>(d_part.p, nsl, nb, cols, &d_blk.p->resid_sum, xm_c, d_gblk.p, st);
-                if (trace) { sync(); std::fprintf(stderr, "[panel] reduce ok\n"); }
                 bp.Dptr = Dptr;
                 launch_cd_panel_solve<T>(bp, j, st);
-                if (trace) { sync(); std::fprintf(stderr, "[panel] solve ok\n"); }
             }
             t_cd.end(st);
             cnt.n_panel_blocks += nblk;

@@ -128,7 +128,10 @@ __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j)
     // Lane l keeps coordinates l and l+64 of the block in registers (g and the per-coordinate constants); a visit reads
     // its operands with v_readlane (uniform lane index), so the dependent chain of a visit is register-only:
     // readlane g_i -> soft-threshold -> fma into the two g registers.  The D column comes from LDS (2 x ds_read_b64,
-    // address independent of the chain).
+    // address independent of the chain).  The single wave is bound by its instruction count, so everything that is not on
+    // the chain (rsq, convergence measure, resid_sum, active-set marking, counters) is left out of the loop: a visit
+    // only records the new coefficient and the gradient it saw in the owning lane, and the bookkeeping of the whole block
+    // is done lane-parallel afterwards (same quantities; the sums are wave reductions instead of running sums).
     static_assert(BLK == 128, "two coordinates per lane");
     T g0 = gB[lane], g1 = gB[lane + 64];
     const T b0 = bB[lane], b1 = bB[lane + 64];
@@ -139,7 +142,8 @@ __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j)
     const T X0 = xmB[lane], X1 = xmB[lane + 64];
     const int a0 = actB[lane], a1 = actB[lane + 64];
     T nb0 = b0, nb1 = b1; // new coefficients of this lane's two coordinates
-#define AHIP_BLK_VISIT(GREG, BREG, AREG, LREG, NREG, RREG, XREG, ACTREG, NBREG, IL)                                   \
+    T gc0 = T(0), gc1 = T(0); // gradient seen by the visit of this lane's coordinates (only meaningful if they changed)
+#define AHIP_BLK_VISIT(GREG, BREG, AREG, LREG, NREG, RREG, NBREG, GCREG, IL)                                          \
     {                                                                                                                  \
         const T dc0 = D[i * BLK + lane], dc1 = D[i * BLK + lane + 64]; /* off the dependent chain: issued first */  \
         const T gcur = rdlane(GREG, IL);                                                                           \
@@ -156,28 +160,57 @@ __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j)
         }                                                                                                              \
         if (ak != bi) {                                   /* pin_naive:97 */                                          \
             const T del = ak - bi;                                                                                     \
-            const T c1 = A * del * del;                                                                                \
-            cm = c1 > cm ? c1 : cm;                       /* pin_base:112-122 */                                      \
-            rsq += del * (T(2) * gcur - del * A);         /* pin_base:136-146 */                                      \
-            rsum -= rdlane(XREG, IL) * del;           /* pin_naive:107 */                                         \
-            if (p.mark && rdlane(ACTREG, IL) == 0) {  /* add_active_set, pin_naive:294-304 */                     \
-                if (asz >= p.max_active_size) { status = CD_MAX_ACTIVE; break; }                                       \
-                if (lane == 0) { p.is_active[idxB[i]] = 1; p.active_set[asz] = idxB[i]; }                              \
-                ++asz;                                                                                                 \
-            }                                                                                                          \
-            if (lane == (IL)) NBREG = ak;                                                                              \
             g0 = fma(-del, dc0, g0);                                                                                   \
             g1 = fma(-del, dc1, g1);                                                                                   \
-            ++n_upd;                                                                                                   \
+            if (lane == (IL)) { NBREG = ak; GCREG = gcur; }                                                            \
         }                                                                                                              \
     }
     {
         const int n0 = nb < 64 ? nb : 64;
-        for (int i = 0; i < n0; ++i) AHIP_BLK_VISIT(g0, b0, A0, L0, N0, R0, X0, a0, nb0, i)
-        if (status == CD_OK)
-            for (int i = 64; i < nb; ++i) AHIP_BLK_VISIT(g1, b1, A1, L1, N1, R1, X1, a1, nb1, i - 64)
+        for (int i = 0; i < n0; ++i) AHIP_BLK_VISIT(g0, b0, A0, L0, N0, R0, nb0, gc0, i)
+        for (int i = 64; i < nb; ++i) AHIP_BLK_VISIT(g1, b1, A1, L1, N1, R1, nb1, gc1, i - 64)
     }
 #undef AHIP_BLK_VISIT
+    // ---- bookkeeping of the block, lane-parallel --------------------------------------------------------------------
+    {
+        const T d0 = nb0 - b0, d1 = nb1 - b1; // lanes beyond nb hold b = nb = 0
+        const bool ch0 = d0 != T(0), ch1 = d1 != T(0);
+        // pin_base:136-146 (rsq), pin_naive:107 (resid_sum), pin_base:112-122 (convergence measure)
+        const T rs = (ch0 ? d0 * (T(2) * gc0 - d0 * A0) : T(0)) + (ch1 ? d1 * (T(2) * gc1 - d1 * A1) : T(0));
+        const T xs = X0 * d0 + X1 * d1;
+        const T c0 = A0 * d0 * d0, c1 = A1 * d1 * d1;
+        T cmx = c0 > c1 ? c0 : c1;
+        T rs_t = rs, xs_t = xs;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            rs_t += __shfl_xor(rs_t, off, 64);
+            xs_t += __shfl_xor(xs_t, off, 64);
+            const T o = __shfl_xor(cmx, off, 64);
+            cmx = o > cmx ? o : cmx;
+        }
+        rsq += rs_t;
+        rsum -= xs_t;
+        cm = cmx > cm ? cmx : cm;
+        const unsigned long long m0 = __ballot(ch0), m1 = __ballot(ch1);
+        n_upd += __popcll(m0) + __popcll(m1);
+        if (p.mark) { // add_active_set in visiting order, pin_naive:294-304
+            const bool new0 = ch0 && a0 == 0, new1 = ch1 && a1 == 0;
+            const unsigned long long q0 = __ballot(new0), q1 = __ballot(new1);
+            const int cnt = __popcll(q0) + __popcll(q1);
+            if (asz + cnt > p.max_active_size) {
+                status = CD_MAX_ACTIVE;
+            } else {
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                if (new0) { const int pos = asz + __popcll(q0 & lt); p.is_active[idxB[lane]] = 1; p.active_set[pos] = idxB[lane]; }
+                if (new1) {
+                    const int pos = asz + __popcll(q0) + __popcll(q1 & lt);
+                    p.is_active[idxB[lane + 64]] = 1;
+                    p.active_set[pos] = idxB[lane + 64];
+                }
+                asz += cnt;
+            }
+        }
+    }
     // net changes of the block (a coordinate is visited once per pass, so delta = new - old)
     bB[lane] = nb0; bB[lane + 64] = nb1;
     dB[lane] = nb0 - b0; dB[lane + 64] = nb1 - b1;

@@ -18,6 +18,7 @@
 // sit in LDS and scale the B fragment.  Global loads for stage t+1 are issued before the MFMAs of stage t.
 // K-splits write partial tiles; a second kernel sums them (deterministic), centres, and writes C symmetrically.
 #include "kernels.hpp"
+#include <cstdlib>
 #include "accessors.hpp"
 
 namespace ahip {
@@ -225,7 +226,8 @@ inline GramShape gram_shape(int64_t n, int64_t M, int64_t N) {
     g.Npad = g.n128 * 128 + g.n64 * 64;
     // enough blocks that the last partial round over the 256 CUs x 2 resident blocks costs little
     const int64_t tiles = g.Mt * (g.n128 + g.n64);
-    int64_t want = (3072 + tiles - 1) / tiles;
+    static const int64_t target = std::getenv("AHIP_GRAM_TARGET") ? std::atoll(std::getenv("AHIP_GRAM_TARGET")) : 3072;
+    int64_t want = (target + tiles - 1) / tiles;
     const int64_t max_split = (n + KT * 8 - 1) / (KT * 8);
     if (want > max_split) want = max_split;
     const int64_t cap = (int64_t(1) << 28) / (g.Mt * BM * g.Npad); // partial buffer <= 2^28 elements

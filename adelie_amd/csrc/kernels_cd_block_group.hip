@@ -14,6 +14,7 @@ namespace ahip {
 namespace {
 
 constexpr int GBLK = 128;
+constexpr int VPOOL = 1280; // LDS pool (elements) for the eigenbases of a block's groups (12 groups of 10: 1200)
 
 template <class T>
 __device__ __forceinline__ T gwsum(T x) {
@@ -55,26 +56,42 @@ __device__ __forceinline__ T group_sum(T x, int q) {
     return q <= 16 ? row16_sum(x) : gwsum(x);
 }
 
-// Fills vmap[0..nval) with the global screen-value index of every value of block j, plus the group tables.
-// Executed by one thread; returns nval through *nval_out (all in LDS).
+// Fills vmap[0..nval) with the global screen-value index of every value of block j, plus the group tables (all in LDS).
+// Cooperative: every thread of the (256-thread) workgroup must call it.  The per-group lookups (list -> begin / size)
+// are two dependent global loads; doing them one group per thread costs two round trips for the whole block instead of
+// two per group in a serial loop (which was most of a 12-group block's latency).
 template <class T>
 __device__ __forceinline__ void block_layout(const CdGrpBlkParams<T>& p, int j, int32_t* vmap, int32_t* goff,
                                              int32_t* gq, int32_t* gss, int32_t* meta /* [0]=ngrp [1]=nval */) {
+    __shared__ int32_t gb_[GBLK];
+    const int tid = threadIdx.x;
     const int g0 = p.blk_g0[j], g1 = p.blk_g0[j + 1];
-    int o = 0;
-    for (int pos = g0; pos < g1; ++pos) {
-        const int ss = p.list ? p.list[pos] : pos;
-        const int b = p.sbegin[ss], q = p.ssize[ss];
-        const int k = pos - g0;
-        goff[k] = o;
-        gq[k] = q;
-        gss[k] = ss;
-        for (int t = 0; t < q; ++t) vmap[o + t] = b + t;
-        o += q;
+    const int ng = g1 - g0;
+    if (tid < GBLK) {
+        int ss = 0, b = 0, q = 0;
+        if (tid < ng) {
+            ss = p.list ? p.list[g0 + tid] : g0 + tid;
+            b = p.sbegin[ss];
+            q = p.ssize[ss];
+        }
+        gss[tid] = ss;
+        gb_[tid] = b;
+        gq[tid] = q;
     }
-    goff[g1 - g0] = o;
-    meta[0] = g1 - g0;
-    meta[1] = o;
+    __syncthreads();
+    if (tid == 0) {
+        int o = 0;
+        for (int k = 0; k < ng; ++k) { goff[k] = o; o += gq[k]; }
+        goff[ng] = o;
+        meta[0] = ng;
+        meta[1] = o;
+    }
+    __syncthreads();
+    for (int k = tid >> 1; k < ng; k += 128) { // two threads per group
+        const int o = goff[k], q = gq[k], b = gb_[k];
+        for (int t = tid & 1; t < q; t += 2) vmap[o + t] = b + t;
+    }
+    __syncthreads();
 }
 
 template <class T>
@@ -91,8 +108,7 @@ template <class T>
 __global__ __launch_bounds__(256) void grp_gather_kernel(CdGrpBlkParams<T> p, int j) {
     __shared__ int32_t vmap[GBLK], goff[GBLK + 1], gq[GBLK], gss[GBLK], meta[2];
     if (j >= p.nblk) return;
-    if (threadIdx.x == 0) block_layout(p, j, vmap, goff, gq, gss, meta);
-    __syncthreads();
+    block_layout(p, j, vmap, goff, gq, gss, meta);
     gather_group_block(p, j, vmap, meta[1], blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
@@ -113,9 +129,35 @@ __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int
     int32_t* meta = gss + GBLK;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) block_layout(p, j, vmap, goff, gq, gss, meta);
-    __syncthreads();
+    block_layout(p, j, vmap, goff, gq, gss, meta);
     const int ngrp = meta[0], nval = meta[1];
+    // per-group constants and (when they fit) all eigenbases of the block, fetched by the whole workgroup up front so that
+    // the sequential wave never waits on a global load
+    T* gpenB = reinterpret_cast<T*>(meta + 5); // int index 518 of the region: 8-byte aligned
+    int32_t* gactB = reinterpret_cast<int32_t*>(gpenB + GBLK);
+    int32_t* gvoB = gactB + GBLK;          // offset of the group's eigenbasis in Vpool, or -1
+    T* Vpool = reinterpret_cast<T*>(gvoB + GBLK);
+    if (tid < GBLK && tid < ngrp) {
+        const int ss = gss[tid];
+        gpenB[tid] = p.spen[ss];
+        gactB[tid] = p.is_active[ss];
+    }
+    if (tid == 0) {
+        int used = 0;
+        for (int k = 0; k < ngrp; ++k) {
+            const int q = gq[k];
+            if (q > 1 && used + q * q <= VPOOL) { gvoB[k] = used; used += q * q; }
+            else gvoB[k] = -1;
+        }
+    }
+    __syncthreads();
+    for (int k = wv; k < ngrp; k += 4) { // one wave per group
+        const int vo = gvoB[k];
+        if (vo < 0) continue;
+        const int q = gq[k];
+        const T* Vg = p.V + p.voff[gss[k]];
+        for (int e = lane; e < q * q; e += 64) Vpool[vo + e] = Vg[e];
+    }
     if (tid < GBLK) {
         const int i = tid;
         if (i < nval) {
@@ -158,7 +200,7 @@ __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int
 
     for (int k = 0; k < ngrp && status == CD_OK; ++k) {
         const int o = goff[k], q = gq[k], ss = gss[k];
-        const T pk = p.spen[ss];
+        const T pk = gpenB[k];
         const T l1p = p.l1 * pk, l2p = p.l2 * pk;
         bool changed = false;
         if (q == 1) {
@@ -177,13 +219,18 @@ __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int
             }
         } else {
             // stage the (q,q) eigenbasis in LDS (one coalesced read) when it fits the scratch; else read it in place
-            const T* Vg = p.V + p.voff[ss];
-            const T* V = Vg;
-            if (q * q <= 2 * GBLK) {
-                T* Vl = scr + 6 * GBLK;
-                for (int e = lane; e < q * q; e += 64) Vl[e] = Vg[e];
-                V = Vl;
-                __builtin_amdgcn_wave_barrier();
+            const T* V;
+            if (gvoB[k] >= 0) {
+                V = Vpool + gvoB[k];
+            } else {
+                const T* Vg = p.V + p.voff[ss];
+                V = Vg;
+                if (q * q <= 2 * GBLK) {
+                    T* Vl = scr + 6 * GBLK;
+                    for (int e = lane; e < q * q; e += 64) Vl[e] = Vg[e];
+                    V = Vl;
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
             const T* A = AB + o;
             // gk_t = gk V ; ak_old_t = ak_old V ; gk_t += A * ak_old_t   (pin_naive:123-140)
@@ -270,7 +317,7 @@ __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int
         }
         __builtin_amdgcn_wave_barrier();
         if (changed) {
-            if (p.mark && p.is_active[ss] == 0) {                  // add_active_set, pin_naive:294-304
+            if (p.mark && gactB[k] == 0) {                         // add_active_set, pin_naive:294-304
                 if (asz >= p.max_active_size) { status = CD_MAX_ACTIVE; break; }
                 if (lane == 0) { p.is_active[ss] = 1; p.active_set[asz] = ss; }
                 ++asz;
@@ -338,15 +385,15 @@ __global__ __launch_bounds__(256) void grp_update_kernel(CdGrpBlkParams<T> p, in
         if (wv == 0 && r < p.nv) p.g[r] -= ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
     }
     if (j + 1 < p.nblk) { // gather the next block's diagonal block
-        if (tid == 0) block_layout(p, j + 1, vmap, goff, gq, gss, meta);
-        __syncthreads();
+        block_layout(p, j + 1, vmap, goff, gq, gss, meta);
         gather_group_block(p, j + 1, vmap, meta[1], blockIdx.x * 256 + tid, gridDim.x * 256);
     }
 }
 
 template <class T>
 size_t grp_solve_lds() {
-    return size_t(GBLK) * GBLK * sizeof(T) + size_t(GBLK) * (5 + 8) * sizeof(T) + (size_t(GBLK) * 4 + 8) * sizeof(int32_t) + 16;
+    return size_t(GBLK) * GBLK * sizeof(T) + size_t(GBLK) * (5 + 8) * sizeof(T) + (size_t(GBLK) * 4 + 8) * sizeof(int32_t) + 16 +
+           size_t(GBLK) * sizeof(T) + size_t(GBLK) * 2 * sizeof(int32_t) + size_t(VPOOL) * sizeof(T);
 }
 
 } // namespace

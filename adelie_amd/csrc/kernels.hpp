@@ -63,6 +63,15 @@ void launch_gram_snp(const SnpView& X, const T* impute, const T* w, const int32_
                      const int32_t* ncols, int32_t N, int32_t n_pos0, const T* xm_by_col, bool center, T* C,
                      int64_t ldc, T* work, hipStream_t s);
 int64_t gram_work_elems(int64_t n, int64_t M, int64_t N);
+// symmetric diagonal block of M <= 64 columns: C[a + b*ldc] = C[b + a*ldc] = sum_i w_i X[i,cols[a]] X[i,cols[b]] (- xm xm^T);
+// only the lower-triangle MFMA tiles are computed.  `work` holds syrk64_work_elems(n) elements.
+template <class T>
+void launch_syrk64(const DenseView<T>& X, const T* w, const int32_t* cols, int32_t M, const T* xm_by_col, bool center, T* C,
+                   int64_t ldc, T* work, hipStream_t s);
+template <class T>
+void launch_syrk64_snp(const SnpView& X, const T* impute, const T* w, const int32_t* cols, int32_t M, const T* xm_by_col,
+                       bool center, T* C, int64_t ldc, T* work, hipStream_t s);
+int64_t syrk64_work_elems(int64_t n);
 
 // ---- abs_grad (solver_base.hpp:20-110) --------------------------------------------------------
 // abs_grad[g] = || grad[groups[g] : +gs] - regul_g * beta_slot ||,  regul_g = (1-alpha)*lmda*penalty[g] for screen
@@ -144,6 +153,7 @@ struct CdBlkParams {
     const int32_t* list; // visiting list of the pass (nullptr: screen order 0..count-1)
     int32_t count;
     int32_t mark;
+    int32_t bsz;         // visits per block, <= cd_block_size() (the D slot keeps leading dimension cd_block_size())
     // panel (residual-based) variant, kernels_cd_panel.hip: gradient of the block from the panel step, diagonal block
     // from the cache, changed design columns out for the residual update
     const T* gblk;       // [BLK] gradient of the block's coordinates (list order)

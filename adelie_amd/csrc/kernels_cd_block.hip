@@ -46,8 +46,8 @@ __device__ __forceinline__ int blk_index(const CdBlkParams<T>& p, int pos) {
 // D_j[i + m*BLK] = C[idx_i + idx_m*ldc] for the block starting at list position j*BLK
 template <class T>
 __device__ __forceinline__ void gather_block(const CdBlkParams<T>& p, int j, int gtid, int gthreads) {
-    const int base = j * BLK;
-    const int nb = min(BLK, p.count - base);
+    const int base = j * p.bsz;
+    const int nb = min(p.bsz, p.count - base);
     if (nb <= 0) return;
     T* D = p.Dbuf + size_t(j & 1) * BLK * BLK;
     for (int e = gtid; e < nb * nb; e += gthreads) {
@@ -78,8 +78,8 @@ __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j)
     int32_t* actB = idxB + BLK;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int base = j * BLK;
-    const int nb = min(BLK, p.count - base);
+    const int base = j * p.bsz;
+    const int nb = min(p.bsz, p.count - base);
 
     if (tid < BLK) {
         const int i = tid;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j)
         const V* src = reinterpret_cast<const V*>(NAIVE ? p.Dptr : p.Dbuf + size_t(j & 1) * BLK * BLK);
         V* dst = reinterpret_cast<V*>(D);
         // 8 loads in flight per lane: the 128 KB block arrives in ~4 round trips instead of 32
-        constexpr int NE = BLK * BLK / VEC;
+        const int NE = nb * BLK / VEC; // columns [0, nb) of the slot
         for (int e0 = tid; e0 < NE; e0 += 256 * 8) {
             V v[8];
 #pragma unroll
@@ -311,7 +311,7 @@ int cd_block_size() { return BLK; }
 template <class T>
 void launch_cd_block_pass(const CdBlkParams<T>& p, hipStream_t s) {
     if (p.count <= 0) return;
-    const int nblk = (p.count + BLK - 1) / BLK;
+    const int nblk = (p.count + p.bsz - 1) / p.bsz;
     const unsigned ug = unsigned((p.nv + 63) / 64);
     hipLaunchKernelGGL((blk_gather_kernel<T>), dim3(64), dim3(256), 0, s, p, 0);
     static bool attr_done = false;

@@ -245,6 +245,7 @@ struct Solver {
     int64_t cd_block_min_nv = 256; // screen sets at least this large use the multi-CU block passes
     // panel engine (kernels_cd_panel.hip): residual-based block passes with cached B x B diagonal blocks
     bool engine_panel = true;
+    int panel_bsz = 0;          // 0: automatic (128 Gaussian, 64 IRLS); test/tuning hook ADELIE_HIP_PANEL_BSZ
     const T* cur_w = nullptr;   // weights / by-column means the pin solve runs under (Gaussian: w, X_means; IRLS: per iteration)
     const T* cur_xm = nullptr;
     uint64_t w_version = 1;     // bumped whenever the weights behind cur_w change
@@ -278,17 +279,24 @@ struct Solver {
     }
     // B x B block  X_cols^T W X_cols - xm xm^T  into Dptr (ld = B)
     void gram_block(const T* w, const int32_t* cols, int nb, const T* xm, T* Dptr) {
-        T* work = d_work_gram.reserve(size_t(gram_work_elems(n, nb, nb)));
         const int B = cd_block_size();
         t_gram.begin(st);
-        if (dense())
-            launch_gram<T>(D->dense<T>(), w, cols, nb, 0, cols, nb, 0, xm, intercept, Dptr, B, work, st);
-        else
-            launch_gram_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols, nb, 0, cols, nb, 0, xm, intercept, Dptr,
-                               B, work, st);
+        if (nb <= 64) { // lower-triangle tiles only
+            T* work = d_work_gram.reserve(size_t(syrk64_work_elems(n)));
+            if (dense()) launch_syrk64<T>(D->dense<T>(), w, cols, nb, xm, intercept, Dptr, B, work, st);
+            else launch_syrk64_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols, nb, xm, intercept, Dptr, B, work, st);
+            cnt.gram_flops += 2.0 * double(n) * 2560.0; // 10 tiles of 16 x 16
+        } else {
+            T* work = d_work_gram.reserve(size_t(gram_work_elems(n, nb, nb)));
+            if (dense())
+                launch_gram<T>(D->dense<T>(), w, cols, nb, 0, cols, nb, 0, xm, intercept, Dptr, B, work, st);
+            else
+                launch_gram_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols, nb, 0, cols, nb, 0, xm, intercept,
+                                   Dptr, B, work, st);
+            cnt.gram_flops += 2.0 * double(n) * double(nb) * double(nb);
+        }
         t_gram.end(st);
         cnt.n_gram_col_reads += 2 * nb;
-        cnt.gram_flops += 2.0 * double(n) * double(nb) * double(nb);
     }
     void axpy_cols(const int32_t* cols, const T* coef, const int32_t* cnt_dev, int32_t count, T sign, T* out) {
         if (dense()) launch_axpy_cols<T>(D->dense<T>(), cols, coef, cnt_dev, count, sign, out, st);
@@ -682,6 +690,7 @@ struct Solver {
         bp.l1 = cp.lmda * cp.alpha; bp.l2 = cp.lmda * (T(1) - cp.alpha);
         bp.max_active_size = cp.max_active_size;
         bp.Dbuf = d_Dbuf.p; bp.dlt = d_dlt.p; bp.didx = d_didx.p; bp.st = d_blk.p;
+        bp.bsz = B;
         int64_t iters = 0;
         int status = CD_OK;
         int asz = sc.active_size;
@@ -732,7 +741,11 @@ struct Solver {
     // residual, partial gradients of this block) -> reduce -> one-workgroup solve against the cached diagonal block.
     // The residual is current when this returns (no end-of-fit update), also on failure (changes are undone).
     void run_panel_passes(const CdParams<T>& cp, CdScalars<T>& sc, T* r_dev) {
-        const int B = cd_block_size();
+        // Block size: 128 visits under fixed weights (Gaussian: a diagonal block is built once and re-used for the rest of
+        // the path); 64 under IRLS, where every block is rebuilt per IRLS iteration and used about once, so the MFMA cost
+        // per coordinate (block size x n MACs, lower triangle only below 64) matters more than the per-block latencies.
+        const int B = panel_bsz > 0 ? panel_bsz : (is_glm() ? 64 : cd_block_size());
+        const int SL = cd_block_size(); // D slot: SL x SL, leading dimension SL
         const size_t maxblk = size_t((p + B - 1) / B + 1);
         d_blk.reserve(1);
         d_dlt.reserve(B);
@@ -741,8 +754,8 @@ struct Solver {
         d_actcols.reserve(size_t(p) + B);
         d_part.reserve(size_t(panel_part_elems(n)));
         if (dscr_nb.size() != maxblk) {
-            d_Dpool.reserve(size_t(2) * maxblk * B * B);
-            AHIP_CHECK(hipMemsetAsync(d_Dpool.p, 0, size_t(2) * maxblk * B * B * sizeof(T), st));
+            d_Dpool.reserve(size_t(2) * maxblk * SL * SL);
+            AHIP_CHECK(hipMemsetAsync(d_Dpool.p, 0, size_t(2) * maxblk * SL * SL * sizeof(T), st));
             dscr_nb.assign(maxblk, 0); dact_nb.assign(maxblk, 0);
             dscr_ver.assign(maxblk, 0); dact_ver.assign(maxblk, 0);
         }
@@ -760,6 +773,7 @@ struct Solver {
         bp.max_active_size = cp.max_active_size;
         bp.dlt = d_dlt.p; bp.st = d_blk.p;
         bp.gblk = d_gblk.p; bp.vcol = cp.vcol; bp.dcol = d_dcolblk.p;
+        bp.bsz = B;
         const T* xm_c = intercept ? cur_xm : nullptr;
         static const bool trace = std::getenv("ADELIE_HIP_TRACE") != nullptr;
         int64_t iters = 0;
@@ -775,7 +789,7 @@ struct Solver {
             }
             auto& tab_nb = screen_pass ? dscr_nb : dact_nb;
             auto& tab_ver = screen_pass ? dscr_ver : dact_ver;
-            T* pool = d_Dpool.p + (screen_pass ? size_t(0) : maxblk * B * B);
+            T* pool = d_Dpool.p + (screen_pass ? size_t(0) : maxblk * SL * SL);
             bp.list = screen_pass ? nullptr : cp.active_set;
             bp.count = count;
             bp.mark = screen_pass ? 1 : 0;
@@ -784,7 +798,7 @@ struct Solver {
             for (int j = 0; j < nblk; ++j) {
                 const int nb = std::min(B, count - j * B);
                 const int32_t* cols = cols_all + size_t(j) * B;
-                T* Dptr = pool + size_t(j) * B * B;
+                T* Dptr = pool + size_t(j) * SL * SL;
                 if (tab_nb[j] != nb || tab_ver[j] != w_version) {
                     t_cd.end(st);
                     gram_block(cur_w, cols, nb, cur_xm, Dptr);
@@ -1492,6 +1506,10 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_CD_BLOCK_MIN_NV")) cd_block_min_nv = std::atoll(e); // test hook
         if (const char* e = std::getenv("ADELIE_HIP_CD_ENGINE")) engine_panel = std::string(e) != "gram"; // A/B hook
         time_panel = std::getenv("ADELIE_HIP_TIME_PANEL") != nullptr;
+        if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {
+            panel_bsz = std::atoi(e);
+            if (panel_bsz != 32 && panel_bsz != 64 && panel_bsz != 128) panel_bsz = 0;
+        }
         // device allocations
         d_r.reserve(n); d_v.reserve(n); d_grad.reserve(p); d_absgrad.reserve(G); d_penalty.reserve(G);
         d_groups.reserve(G); d_gsizes.reserve(G); d_slot.reserve(G);

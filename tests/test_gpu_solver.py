@@ -285,3 +285,18 @@ def test_panel_engine_matches_gram_engine(hip, monkeypatch):
     assert_same_path(a, b, 1e-7)
     assert abs(a.counters["n_updates"] - b.counters["n_updates"]) <= 0.01 * b.counters["n_updates"]
     np.testing.assert_allclose(a.resid, b.resid, atol=1e-9)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("bsz", [32, 64])
+def test_panel_engine_small_blocks(hip, oracle, monkeypatch, bsz, dtype):
+    """Panel blocks of 32 / 64 visits (the IRLS default is 64): diagonal blocks come from the lower-triangle MFMA kernel
+    (syrk64), ragged last block, n not a multiple of the K tile."""
+    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    monkeypatch.setenv("ADELIE_HIP_PANEL_BSZ", str(bsz))
+    d = make_gaussian(1203, 450, seed=17, sparsity=0.6, weights=True)
+    f32 = dtype == np.float32
+    kw = dict(alpha=0.8, tol=1e-7 if f32 else 1e-14, early_exit=False, lmda_path_size=20, min_ratio=2e-2)
+    a, b = _both(oracle, d, lambda: ad.glm.gaussian(d["y"], weights=d["weights"], dtype=dtype), dtype=dtype, **kw)
+    assert a.counters["n_panel_blocks"] > 0
+    assert_same_path(a, b, 5e-3 if f32 else 1e-6)

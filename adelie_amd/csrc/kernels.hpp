@@ -63,15 +63,15 @@ void launch_gram_snp(const SnpView& X, const T* impute, const T* w, const int32_
                      const int32_t* ncols, int32_t N, int32_t n_pos0, const T* xm_by_col, bool center, T* C,
                      int64_t ldc, T* work, hipStream_t s);
 int64_t gram_work_elems(int64_t n, int64_t M, int64_t N);
-// symmetric diagonal block of M <= 64 columns: C[a + b*ldc] = C[b + a*ldc] = sum_i w_i X[i,cols[a]] X[i,cols[b]] (- xm xm^T);
-// only the lower-triangle MFMA tiles are computed.  `work` holds syrk64_work_elems(n) elements.
+// symmetric diagonal block of M <= 128 columns: C[a + b*ldc] = C[b + a*ldc] = sum_i w_i X[i,cols[a]] X[i,cols[b]] (- xm xm^T);
+// only the lower-triangle MFMA tiles are computed.  `work` holds syrk_work_elems(n, M) elements.
 template <class T>
-void launch_syrk64(const DenseView<T>& X, const T* w, const int32_t* cols, int32_t M, const T* xm_by_col, bool center, T* C,
+void launch_syrk(const DenseView<T>& X, const T* w, const int32_t* cols, int32_t M, const T* xm_by_col, bool center, T* C,
                    int64_t ldc, T* work, hipStream_t s);
 template <class T>
-void launch_syrk64_snp(const SnpView& X, const T* impute, const T* w, const int32_t* cols, int32_t M, const T* xm_by_col,
+void launch_syrk_snp(const SnpView& X, const T* impute, const T* w, const int32_t* cols, int32_t M, const T* xm_by_col,
                        bool center, T* C, int64_t ldc, T* work, hipStream_t s);
-int64_t syrk64_work_elems(int64_t n);
+int64_t syrk_work_elems(int64_t n, int64_t M);
 
 // ---- abs_grad (solver_base.hpp:20-110) --------------------------------------------------------
 // abs_grad[g] = || grad[groups[g] : +gs] - regul_g * beta_slot ||,  regul_g = (1-alpha)*lmda*penalty[g] for screen

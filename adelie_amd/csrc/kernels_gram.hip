@@ -209,37 +209,68 @@ __global__ void gram_reduce_kernel(const T* __restrict__ part, int nsplit, int64
     if (symmetric) C[cp + rp * ldc] = s;
 }
 
-// ---- symmetric diagonal block, <= 64 columns (the panel engine's blocks under IRLS) ------------------------------------------
-// D = X_B^T W X_B for ONE column list on both sides: a single 64 x KT panel is staged per stage (it feeds the A and the B
-// fragments), and only the 10 lower-triangle 16x16 tiles of the 4x4 tile grid are computed (the reduce kernel mirrors
-// them), spread 3/3/2/2 over the four waves so that each wave re-uses its fragments.  Grid = K-splits only.
-template <class T, int NT, int R0, int C0, int R1, int C1, int R2, int C2>
+// ---- symmetric diagonal block of <= 64 or <= 128 columns (the panel engine's blocks) --------------------------------------------
+// D = X_B^T W X_B for ONE column list on both sides: a single SB x KT panel is staged per stage (it feeds the A and the B
+// fragments), and only the lower-triangle 16x16 tiles of the tile grid are computed (10 of 16 for SB = 64, 36 of 64 for
+// SB = 128; the reduce kernel mirrors them), spread evenly over the four waves in runs that share fragments.
+// Grid = K-splits only.
+template <int W, int SB> struct SyrkPlan;
+// SB = 64: 3 / 3 / 2 / 2 tiles
+template <> struct SyrkPlan<0, 64> { static constexpr int N = 3; static constexpr int R[3] = {0, 1, 1}; static constexpr int C[3] = {0, 0, 1}; };
+template <> struct SyrkPlan<1, 64> { static constexpr int N = 3; static constexpr int R[3] = {2, 2, 2}; static constexpr int C[3] = {0, 1, 2}; };
+template <> struct SyrkPlan<2, 64> { static constexpr int N = 2; static constexpr int R[2] = {3, 3}; static constexpr int C[2] = {0, 1}; };
+template <> struct SyrkPlan<3, 64> { static constexpr int N = 2; static constexpr int R[2] = {3, 3}; static constexpr int C[2] = {2, 3}; };
+// SB = 128: 9 tiles per wave (rows 0-2 + row 3 cols 0-2 | (3,3), row 4, row 5 cols 0-2 | row 5 cols 3-5, row 6 cols 0-5 | (6,6), row 7)
+template <> struct SyrkPlan<0, 128> {
+    static constexpr int N = 9;
+    static constexpr int R[9] = {0, 1, 1, 2, 2, 2, 3, 3, 3};
+    static constexpr int C[9] = {0, 0, 1, 0, 1, 2, 0, 1, 2};
+};
+template <> struct SyrkPlan<1, 128> {
+    static constexpr int N = 9;
+    static constexpr int R[9] = {3, 4, 4, 4, 4, 4, 5, 5, 5};
+    static constexpr int C[9] = {3, 0, 1, 2, 3, 4, 0, 1, 2};
+};
+template <> struct SyrkPlan<2, 128> {
+    static constexpr int N = 9;
+    static constexpr int R[9] = {5, 5, 5, 6, 6, 6, 6, 6, 6};
+    static constexpr int C[9] = {3, 4, 5, 0, 1, 2, 3, 4, 5};
+};
+template <> struct SyrkPlan<3, 128> {
+    static constexpr int N = 9;
+    static constexpr int R[9] = {6, 7, 7, 7, 7, 7, 7, 7, 7};
+    static constexpr int C[9] = {6, 0, 1, 2, 3, 4, 5, 6, 7};
+};
+
+template <class T, class Plan, int NA>
 __device__ __forceinline__ void syrk_stage(const T* __restrict__ As, const T* __restrict__ Ws, int fr, int fk,
-                                           typename Mfma<T>::acc_t (&acc)[3]) {
+                                           typename Mfma<T>::acc_t (&acc)[NA]) {
 #pragma unroll
     for (int kk = 0; kk < KT / 4; ++kk) {
         const T wk = Ws[kk * 4 + fk];
         const int ko = kk * 4 + fk;
-        {
-            const T a = As[(R0 * 16 + fr) * LDK + ko], b = As[(C0 * 16 + fr) * LDK + ko] * wk;
-            acc[0] = Mfma<T>::run(a, b, acc[0]);
-        }
-        if (NT > 1) {
-            const T a = As[(R1 * 16 + fr) * LDK + ko], b = As[(C1 * 16 + fr) * LDK + ko] * wk;
-            acc[1] = Mfma<T>::run(a, b, acc[1]);
-        }
-        if (NT > 2) {
-            const T a = As[(R2 * 16 + fr) * LDK + ko], b = As[(C2 * 16 + fr) * LDK + ko] * wk;
-            acc[2] = Mfma<T>::run(a, b, acc[2]);
+#pragma unroll
+        for (int t = 0; t < Plan::N; ++t) {
+            const T a = As[(Plan::R[t] * 16 + fr) * LDK + ko];
+            const T b = As[(Plan::C[t] * 16 + fr) * LDK + ko] * wk;
+            acc[t] = Mfma<T>::run(a, b, acc[t]);
         }
     }
 }
+template <class T, class Plan, int NA, int SB>
+__device__ __forceinline__ void syrk_store(T* __restrict__ P, int lane, const typename Mfma<T>::acc_t (&acc)[NA]) {
+#pragma unroll
+    for (int t = 0; t < Plan::N; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            P[(Plan::C[t] * 16 + (lane & 15)) * SB + Plan::R[t] * 16 + Mfma<T>::row(lane, e)] = acc[t][e];
+}
 
-template <class T, class Acc, bool VECOK>
-__global__ __launch_bounds__(GT) void syrk64_kernel(Acc X, const T* __restrict__ w, const int32_t* __restrict__ cols,
-                                                    int32_t M, int64_t n, int64_t kchunk, T* __restrict__ part) {
-    constexpr int SB = 64;
-    constexpr int RA = KT * SB / GT; // rows of one column staged per thread (8)
+template <class T, class Acc, bool VECOK, int SB>
+__global__ __launch_bounds__(GT, 2) void syrk_kernel(Acc X, const T* __restrict__ w, const int32_t* __restrict__ cols,
+                                                     int32_t M, int64_t n, int64_t kchunk, T* __restrict__ part) {
+    constexpr int RA = KT * SB / GT; // rows of one column staged per thread (8 or 16)
+    constexpr int NA = SB == 64 ? 3 : 9;
     __shared__ T As[SB * LDK];
     __shared__ T Ws[KT];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -251,9 +282,9 @@ __global__ __launch_bounds__(GT) void syrk64_kernel(Acc X, const T* __restrict__
     const bool c_ok = sc < M;
     const int64_t jc = c_ok ? int64_t(cols[sc]) : 0;
 
-    typename Mfma<T>::acc_t acc[3];
+    typename Mfma<T>::acc_t acc[NA];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NA; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[t][e] = T(0);
 
@@ -271,25 +302,21 @@ __global__ __launch_bounds__(GT) void syrk64_kernel(Acc X, const T* __restrict__
         if (tid < KT) Ws[tid] = rw;
         __syncthreads();
         if (k + KT < kend) fetch(k + KT);
-        if (wv == 0) syrk_stage<T, 3, 0, 0, 1, 0, 1, 1>(As, Ws, fr, fk, acc);
-        else if (wv == 1) syrk_stage<T, 3, 2, 0, 2, 1, 2, 2>(As, Ws, fr, fk, acc);
-        else if (wv == 2) syrk_stage<T, 2, 3, 0, 3, 1, 3, 1>(As, Ws, fr, fk, acc);
-        else syrk_stage<T, 2, 3, 2, 3, 3, 3, 3>(As, Ws, fr, fk, acc);
+        if (wv == 0) syrk_stage<T, SyrkPlan<0, SB>, NA>(As, Ws, fr, fk, acc);
+        else if (wv == 1) syrk_stage<T, SyrkPlan<1, SB>, NA>(As, Ws, fr, fk, acc);
+        else if (wv == 2) syrk_stage<T, SyrkPlan<2, SB>, NA>(As, Ws, fr, fk, acc);
+        else syrk_stage<T, SyrkPlan<3, SB>, NA>(As, Ws, fr, fk, acc);
     }
-    // partial tiles -> part[sp][col][row] (64 x 64, only the lower-triangle tiles are written / ever read)
+    // partial tiles -> part[sp][col][row] (SB x SB, only the lower-triangle tiles are written / ever read)
     T* P = part + int64_t(sp) * SB * SB;
-    auto put = [&](int t, int R, int C) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) P[(C * 16 + (lane & 15)) * SB + R * 16 + Mfma<T>::row(lane, e)] = acc[t][e];
-    };
-    if (wv == 0) { put(0, 0, 0); put(1, 1, 0); put(2, 1, 1); }
-    else if (wv == 1) { put(0, 2, 0); put(1, 2, 1); put(2, 2, 2); }
-    else if (wv == 2) { put(0, 3, 0); put(1, 3, 1); }
-    else { put(0, 3, 2); put(1, 3, 3); }
+    if (wv == 0) syrk_store<T, SyrkPlan<0, SB>, NA, SB>(P, lane, acc);
+    else if (wv == 1) syrk_store<T, SyrkPlan<1, SB>, NA, SB>(P, lane, acc);
+    else if (wv == 2) syrk_store<T, SyrkPlan<2, SB>, NA, SB>(P, lane, acc);
+    else syrk_store<T, SyrkPlan<3, SB>, NA, SB>(P, lane, acc);
 }
 
-inline void syrk64_shape(int64_t n, int& nsplit, int64_t& kchunk) {
-    int64_t want = 512;
+inline void syrk_shape(int64_t n, int& nsplit, int64_t& kchunk) {
+    int64_t want = 512; // one full round of 2 resident blocks per CU
     const int64_t max_split = (n + KT * 8 - 1) / (KT * 8);
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
@@ -300,18 +327,20 @@ inline void syrk64_shape(int64_t n, int& nsplit, int64_t& kchunk) {
 }
 
 template <class T, class Acc>
-void syrk64_launch(Acc acc, bool vecok, const T* w, const int32_t* cols, int32_t M, int64_t n, const T* xm, bool center,
-                   T* C, int64_t ldc, T* work, hipStream_t s) {
+void syrk_launch(Acc acc, bool vecok, const T* w, const int32_t* cols, int32_t M, int64_t n, const T* xm, bool center,
+                 T* C, int64_t ldc, T* work, hipStream_t s) {
     if (M <= 0) return;
     int nsplit;
     int64_t kchunk;
-    syrk64_shape(n, nsplit, kchunk);
-    if (vecok)
-        hipLaunchKernelGGL((syrk64_kernel<T, Acc, true>), dim3((unsigned)nsplit), dim3(GT), 0, s, acc, w, cols, M, n, kchunk, work);
-    else
-        hipLaunchKernelGGL((syrk64_kernel<T, Acc, false>), dim3((unsigned)nsplit), dim3(GT), 0, s, acc, w, cols, M, n, kchunk, work);
-    hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3(1, (unsigned)M), dim3(256), 0, s, work, nsplit, int64_t(64), int64_t(64), M, M,
-                       cols, cols, 0, 0, xm, center ? 1 : 0, 1, C, ldc);
+    syrk_shape(n, nsplit, kchunk);
+    const int64_t SB = M <= 64 ? 64 : 128;
+#define AHIP_SYRK(VOK, SBV) \
+    hipLaunchKernelGGL((syrk_kernel<T, Acc, VOK, SBV>), dim3((unsigned)nsplit), dim3(GT), 0, s, acc, w, cols, M, n, kchunk, work)
+    if (M <= 64) { if (vecok) AHIP_SYRK(true, 64); else AHIP_SYRK(false, 64); }
+    else { if (vecok) AHIP_SYRK(true, 128); else AHIP_SYRK(false, 128); }
+#undef AHIP_SYRK
+    hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3((unsigned)((M + 63) / 64), (unsigned)M), dim3(256), 0, s, work, nsplit, SB,
+                       SB, M, M, cols, cols, 0, 0, xm, center ? 1 : 0, 1, C, ldc);
 }
 
 // N tiling: full 128-wide tiles, then the remainder as one 64-wide tile when it fits (less padding than a 128 tile)
@@ -377,25 +406,26 @@ void gram_launch(Acc acc, bool vecok, const T* w, const int32_t* mcols, int32_t 
 
 } // namespace
 
-int64_t syrk64_work_elems(int64_t n) {
+int64_t syrk_work_elems(int64_t n, int64_t M) {
     int nsplit;
     int64_t kchunk;
-    syrk64_shape(n, nsplit, kchunk);
-    return int64_t(nsplit) * 64 * 64;
+    syrk_shape(n, nsplit, kchunk);
+    const int64_t SB = M <= 64 ? 64 : 128;
+    return int64_t(nsplit) * SB * SB;
 }
 template <class T>
-void launch_syrk64(const DenseView<T>& X, const T* w, const int32_t* cols, int32_t M, const T* xm_by_col, bool center, T* C,
+void launch_syrk(const DenseView<T>& X, const T* w, const int32_t* cols, int32_t M, const T* xm_by_col, bool center, T* C,
                    int64_t ldc, T* work, hipStream_t s) {
     DenseAcc<T> acc{X.X, X.ld};
     constexpr int V = VecOf<T>::N;
     const bool vecok = (X.ld % V == 0) && ((reinterpret_cast<uintptr_t>(X.X) % 16) == 0);
-    syrk64_launch<T, DenseAcc<T>>(acc, vecok, w, cols, M, X.n, xm_by_col, center, C, ldc, work, s);
+    syrk_launch<T, DenseAcc<T>>(acc, vecok, w, cols, M, X.n, xm_by_col, center, C, ldc, work, s);
 }
 template <class T>
-void launch_syrk64_snp(const SnpView& X, const T* impute, const T* w, const int32_t* cols, int32_t M, const T* xm_by_col,
+void launch_syrk_snp(const SnpView& X, const T* impute, const T* w, const int32_t* cols, int32_t M, const T* xm_by_col,
                        bool center, T* C, int64_t ldc, T* work, hipStream_t s) {
     SnpAcc<T> acc{X.bits, X.ldb, impute};
-    syrk64_launch<T, SnpAcc<T>>(acc, true, w, cols, M, X.n, xm_by_col, center, C, ldc, work, s);
+    syrk_launch<T, SnpAcc<T>>(acc, true, w, cols, M, X.n, xm_by_col, center, C, ldc, work, s);
 }
 
 int64_t gram_work_elems(int64_t n, int64_t M, int64_t N) {
@@ -430,9 +460,9 @@ INST(double)
 INST(float)
 #undef INST
 #define INST2(T)                                                                                                       \
-    template void launch_syrk64<T>(const DenseView<T>&, const T*, const int32_t*, int32_t, const T*, bool, T*, int64_t, \
+    template void launch_syrk<T>(const DenseView<T>&, const T*, const int32_t*, int32_t, const T*, bool, T*, int64_t, \
                                    T*, hipStream_t);                                                                   \
-    template void launch_syrk64_snp<T>(const SnpView&, const T*, const T*, const int32_t*, int32_t, const T*, bool, T*, \
+    template void launch_syrk_snp<T>(const SnpView&, const T*, const T*, const int32_t*, int32_t, const T*, bool, T*, \
                                        int64_t, T*, hipStream_t);
 INST2(double)
 INST2(float)

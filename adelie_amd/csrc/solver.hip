@@ -281,19 +281,11 @@ struct Solver {
     void gram_block(const T* w, const int32_t* cols, int nb, const T* xm, T* Dptr) {
         const int B = cd_block_size();
         t_gram.begin(st);
-        if (nb <= 64) { // lower-triangle tiles only
-            T* work = d_work_gram.reserve(size_t(syrk64_work_elems(n)));
-            if (dense()) launch_syrk64<T>(D->dense<T>(), w, cols, nb, xm, intercept, Dptr, B, work, st);
-            else launch_syrk64_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols, nb, xm, intercept, Dptr, B, work, st);
-            cnt.gram_flops += 2.0 * double(n) * 2560.0; // 10 tiles of 16 x 16
-        } else {
-            T* work = d_work_gram.reserve(size_t(gram_work_elems(n, nb, nb)));
-            if (dense())
-                launch_gram<T>(D->dense<T>(), w, cols, nb, 0, cols, nb, 0, xm, intercept, Dptr, B, work, st);
-            else
-                launch_gram_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols, nb, 0, cols, nb, 0, xm, intercept,
-                                   Dptr, B, work, st);
-            cnt.gram_flops += 2.0 * double(n) * double(nb) * double(nb);
+        {   // lower-triangle MFMA tiles only: 10 of 16 (nb <= 64) or 36 of 64
+            T* work = d_work_gram.reserve(size_t(syrk_work_elems(n, nb)));
+            if (dense()) launch_syrk<T>(D->dense<T>(), w, cols, nb, xm, intercept, Dptr, B, work, st);
+            else launch_syrk_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols, nb, xm, intercept, Dptr, B, work, st);
+            cnt.gram_flops += 2.0 * double(n) * 256.0 * (nb <= 64 ? 10.0 : 36.0);
         }
         t_gram.end(st);
         cnt.n_gram_col_reads += 2 * nb;

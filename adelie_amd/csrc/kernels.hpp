@@ -154,6 +154,11 @@ struct CdBlkParams {
     int32_t count;
     int32_t mark;
     int32_t bsz;         // visits per block, <= cd_block_size() (the D slot keeps leading dimension cd_block_size())
+    // end-of-pass report straight into host-mapped memory (no stream synchronisation on the host side): the solve of block
+    // `report_j` copies the state to host_st and then publishes `report_seq` in host_seq (system-scope release)
+    CdBlkState<T>* host_st;
+    int32_t* host_seq;
+    int32_t report_j, report_seq;
     // panel (residual-based) variant, kernels_cd_panel.hip: gradient of the block from the panel step, diagonal block
     // from the cache, changed design columns out for the residual update
     const T* gblk;       // [BLK] gradient of the block's coordinates (list order)

@@ -238,6 +238,14 @@ __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j)
         st->status = status;
         st->n_updates = n_upd;
         st->nz = nz;
+        if (NAIVE && p.host_st && j == p.report_j) {
+            CdBlkState<T> out;
+            out.rsq = rsq; out.resid_sum = rsum; out.cm = cm; out.n_updates = n_upd;
+            out.active_size = asz; out.status = status; out.nz = nz; out._pad = 0;
+            *p.host_st = out;
+            __threadfence_system();
+            __hip_atomic_store(p.host_seq, p.report_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

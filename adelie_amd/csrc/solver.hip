@@ -251,6 +251,14 @@ struct Solver {
     uint64_t w_version = 1;     // bumped whenever the weights behind cur_w change
     DevBuf<T> d_Dpool, d_part, d_gblk;
     DevBuf<int32_t> d_actcols, d_dcolblk;
+    // host-mapped end-of-pass report (state + sequence number), see CdBlkParams::host_st
+    struct PassReport { CdBlkState<T> st; int32_t seq; int32_t pad[15]; };
+    PassReport* h_report = nullptr;
+    int32_t report_seq = 0;
+    bool use_report = true;
+    ~Solver() {
+        if (h_report) (void)hipHostFree(h_report);
+    }
     std::vector<int32_t> dscr_nb, dact_nb;      // cached block: number of members it was built for
     std::vector<uint64_t> dscr_ver, dact_ver;   // ... and the weight version
     bool panel_mode() const { return engine_panel && all_scalar && nv >= cd_block_min_nv; }
@@ -766,6 +774,29 @@ struct Solver {
         bp.dlt = d_dlt.p; bp.st = d_blk.p;
         bp.gblk = d_gblk.p; bp.vcol = cp.vcol; bp.dcol = d_dcolblk.p;
         bp.bsz = B;
+        if (use_report && !h_report) {
+            void* hp = nullptr;
+            if (hipHostMalloc(&hp, sizeof(PassReport), hipHostMallocMapped) == hipSuccess) {
+                h_report = static_cast<PassReport*>(hp);
+                std::memset(h_report, 0, sizeof(PassReport));
+            } else {
+                (void)hipGetLastError();
+                use_report = false;
+            }
+        }
+        bp.host_st = nullptr; bp.host_seq = nullptr; bp.report_j = -1; bp.report_seq = 0;
+        if (h_report) {
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, h_report, 0) == hipSuccess) {
+                bp.host_st = &static_cast<PassReport*>(dp)->st;
+                bp.host_seq = &static_cast<PassReport*>(dp)->seq;
+            } else {
+                (void)hipGetLastError();
+                (void)hipHostFree(h_report);
+                h_report = nullptr;
+                use_report = false;
+            }
+        }
         const T* xm_c = intercept ? cur_xm : nullptr;
         static const bool trace = std::getenv("ADELIE_HIP_TRACE") != nullptr;
         int64_t iters = 0;
@@ -805,12 +836,31 @@ struct Solver {
                 cnt.n_panel_cols += nb;
                 launch_panel_reduce<T>(d_part.p, nsl, nb, cols, &d_blk.p->resid_sum, xm_c, d_gblk.p, st);
                 bp.Dptr = Dptr;
+                if (h_report && j == nblk - 1) {
+                    bp.report_j = j;
+                    bp.report_seq = ++report_seq;
+                } else {
+                    bp.report_j = -1;
+                }
                 launch_cd_panel_solve<T>(bp, j, st);
             }
             t_cd.end(st);
             cnt.n_panel_blocks += nblk;
-            d_blk.download(&bs, 1, st);
-            sync();
+            bool got = false;
+            if (h_report) { // spin on the sequence number the last solve of the pass publishes
+                const auto t_spin = std::chrono::steady_clock::now();
+                int spins = 0;
+                while (__atomic_load_n(&h_report->seq, __ATOMIC_ACQUIRE) != report_seq) {
+                    if ((++spins & 0xFFFF) == 0 &&
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_spin).count() > 20.0)
+                        break; // something is wrong on the device side: fall back to a real synchronisation
+                }
+                if (__atomic_load_n(&h_report->seq, __ATOMIC_ACQUIRE) == report_seq) { bs = h_report->st; got = true; }
+            }
+            if (!got) {
+                d_blk.download(&bs, 1, st);
+                sync();
+            }
             status = bs.status;
             asz = bs.active_size;
             if (trace) std::fprintf(stderr, "[panel] %s count=%d nblk=%d cm=%g tol=%g status=%d asz=%d nz=%d rsq=%g rsum=%g nupd=%lld\n",
@@ -1498,6 +1548,7 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_CD_BLOCK_MIN_NV")) cd_block_min_nv = std::atoll(e); // test hook
         if (const char* e = std::getenv("ADELIE_HIP_CD_ENGINE")) engine_panel = std::string(e) != "gram"; // A/B hook
         time_panel = std::getenv("ADELIE_HIP_TIME_PANEL") != nullptr;
+        if (const char* e = std::getenv("ADELIE_HIP_PASS_REPORT")) use_report = std::atoi(e) != 0; // A/B hook
         if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {
             panel_bsz = std::atoi(e);
             if (panel_bsz != 32 && panel_bsz != 64 && panel_bsz != 128) panel_bsz = 0;

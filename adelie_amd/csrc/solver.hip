@@ -488,18 +488,15 @@ struct Solver {
         if (N <= 0) return;
         cnt.n_new_screen_cols += N;
         sweep(w_dev, d_vars.p + pos0, d_vcol.p + pos0, N, nullptr, nullptr, true);
-        std::vector<T> sxm(N);
         for (idx ss = idx(g_begin); ss < ns; ++ss) {
             const idx g = screen_set[ss], b = screen_begins[ss];
             screen_X_means[b] = xm_host[groups[g]];
-            sxm[b - pos0] = screen_X_means[b];
             screen_transforms[ss] = std::vector<T>{T(1)};
         }
-        d_sxm.upload(sxm.data(), sxm.size(), st, pos0);
+        // by-value means on the device straight from the by-column vector; the host copy of the variances is only an output
+        // (finalize() downloads it), so no synchronisation here
+        launch_gather<T>(xm_dev, d_vcol.p + pos0, N, d_sxm.p + pos0, st);
         launch_center_vars<T>(d_vars.p + pos0, d_sxm.p + pos0, int(N), intercept, st);
-        d_vars.download(screen_vars.data() + pos0, size_t(N), st, pos0);
-        sync();
-        (void)xm_dev;
     }
 
     // solver_gaussian_naive.hpp:134-176

@@ -142,11 +142,14 @@ class base:
         # screen_transforms: list of (q,q) F-ordered blocks in screen order
         flat = backend.result_vec(r, _abi.V["screen_transforms"]).astype(dtype)
         tr, off = [], 0
-        if len(flat) == int(np.sum(np.square(self.group_sizes[new.screen_set]))):
-            for g in new.screen_set:
-                q = int(self.group_sizes[g])
-                tr.append(flat[off:off + q * q].reshape(q, q, order="F"))
-                off += q * q
+        qs = np.asarray(self.group_sizes)[new.screen_set]
+        if len(flat) == int(np.sum(np.square(qs))):
+            if len(qs) and np.all(qs == 1):
+                tr = list(flat.reshape(-1, 1, 1))  # lasso: one (1,1) block per screened coordinate, no Python loop
+            else:
+                for q in qs.tolist():
+                    tr.append(flat[off:off + q * q].reshape(q, q, order="F"))
+                    off += q * q
         new.screen_transforms = tr
         self._from_result_extra(new, backend, r, sc)
         return new

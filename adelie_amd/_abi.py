@@ -112,7 +112,7 @@ S = dict(
 HIP_SYMBOLS = [
     "abi_version", "last_error", "device_count", "set_config",
     "design_create_dense", "design_adopt_dense_dev", "design_create_snp_unphased",
-    "design_create_snp_calldata", "design_destroy", "design_rows", "design_cols", "design_dtype",
+    "design_create_snp_calldata", "design_create_snp_bed", "design_impute", "design_destroy", "design_rows", "design_cols", "design_dtype",
     "design_device", "design_stream",
     "design_cmul", "design_ctmul", "design_bmul", "design_btmul", "design_mul", "design_cov",
     "design_sq_mul", "design_sp_tmul",
@@ -166,6 +166,8 @@ class Backend:
         sig("design_adopt_dense_dev", ci, [vp, i64, i64, ci, ci, ci, p(vp)])
         sig("design_create_snp_unphased", ci, [vp, i64, ci, ci, p(vp)])
         sig("design_create_snp_calldata", ci, [vp, i64, i64, vp, ci, ci, p(vp)])
+        sig("design_create_snp_bed", ci, [vp, i64, i64, i64, ci, ci, p(vp)])
+        sig("design_impute", ci, [vp, vp])
         sig("design_destroy", ci, [vp])
         sig("design_rows", i64, [vp])
         sig("design_cols", i64, [vp])

@@ -336,6 +336,63 @@ int adelie_hip_design_create_snp_unphased(const void* snpdat, int64_t n_bytes, i
     ABI_CATCH
 }
 
+int adelie_hip_design_create_snp_bed(const void* bed, int64_t n_bytes, int64_t n, int64_t p, int dtype, int device,
+                                     adelie_hip_design** out) {
+    ABI_TRY
+    if (!bed || !out) throw make_core_error("null argument.");
+    if (n <= 0 || p <= 0) throw make_core_error("n and p must be positive.");
+    const uint8_t* buf = static_cast<const uint8_t*>(bed);
+    const int64_t stride = (n + 3) / 4;
+    if (n_bytes < 3 || buf[0] != 0x6c || buf[1] != 0x1b) throw make_core_error("not a PLINK .bed image (bad magic).");
+    if (buf[2] != 0x01) throw make_core_error("only SNP-major .bed files (third byte 0x01) are supported.");
+    if (n_bytes < 3 + stride * p) throw make_core_error("truncated .bed image: expected 3 + ceil(n/4)*p bytes.");
+    adelie_hip_design* d = new_design(n, p, dtype, device);
+    try {
+        d->kind = 1;
+        d->ldb = (((n + 3) / 4 + 63) / 64) * 64;
+        AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->bits), size_t(d->ldb) * size_t(p)));
+        // stage the records in panels of SNPs to bound the temporary
+        const int64_t panel = std::max<int64_t>(1, (int64_t(1) << 28) / stride);
+        uint8_t* tmp = nullptr;
+        AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&tmp), size_t(stride) * size_t(std::min(panel, p))));
+        for (int64_t j0 = 0; j0 < p; j0 += panel) {
+            const int64_t pc = std::min(panel, p - j0);
+            AHIP_CHECK(hipMemcpyAsync(tmp, buf + 3 + j0 * stride, size_t(stride) * size_t(pc), hipMemcpyDefault, d->stream));
+            launch_bed_transcode(tmp, n, pc, stride, d->bits + j0 * d->ldb, d->ldb, d->stream);
+            AHIP_CHECK(hipStreamSynchronize(d->stream));
+        }
+        (void)hipFree(tmp);
+        if (d->dtype == ADELIE_HIP_F64) {
+            AHIP_CHECK(hipMalloc(&d->impute, size_t(p) * sizeof(double)));
+            launch_snp_impute<double>(d->bits, n, p, d->ldb, static_cast<double*>(d->impute), d->stream);
+        } else {
+            AHIP_CHECK(hipMalloc(&d->impute, size_t(p) * sizeof(float)));
+            launch_snp_impute<float>(d->bits, n, p, d->ldb, static_cast<float*>(d->impute), d->stream);
+        }
+        AHIP_CHECK(hipStreamSynchronize(d->stream));
+    } catch (...) {
+        adelie_hip_design_destroy(d);
+        throw;
+    }
+    *out = d;
+    ABI_CATCH
+}
+
+int adelie_hip_design_impute(adelie_hip_design* d, double* out) {
+    ABI_TRY
+    if (!d || !out) throw make_core_error("null argument.");
+    if (d->kind != 1) throw make_core_error("impute is only defined for SNP designs.");
+    set_device(d);
+    if (d->dtype == ADELIE_HIP_F64) {
+        AHIP_CHECK(hipMemcpy(out, d->impute, size_t(d->p) * sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+        std::vector<float> f(size_t(d->p));
+        AHIP_CHECK(hipMemcpy(f.data(), d->impute, size_t(d->p) * sizeof(float), hipMemcpyDeviceToHost));
+        for (int64_t j = 0; j < d->p; ++j) out[j] = f[size_t(j)];
+    }
+    ABI_CATCH
+}
+
 int adelie_hip_design_destroy(adelie_hip_design* d) {
     if (!d) return 0;
     (void)hipSetDevice(d->device);

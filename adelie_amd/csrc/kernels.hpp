@@ -236,5 +236,9 @@ template <class T> void launch_diag_vars(const T* C, int64_t ldc, int32_t pos0, 
 template <class T> void launch_transpose(const T* src, int64_t n, int64_t p, T* dst, int64_t ld, hipStream_t s);
 // pack int8 calldata (n,p col-major) into 2-bit codes
 void launch_pack_snp(const int8_t* calldata, int64_t n, int64_t p, uint8_t* bits, int64_t ldb, hipStream_t s);
+// PLINK .bed records (p records of stride_in bytes, device memory) -> 2-bit codes; column means of the non-missing calls
+void launch_bed_transcode(const uint8_t* bed, int64_t n, int64_t p, int64_t stride_in, uint8_t* bits, int64_t ldb,
+                          hipStream_t s);
+template <class T> void launch_snp_impute(const uint8_t* bits, int64_t n, int64_t p, int64_t ldb, T* impute, hipStream_t s);
 
 } // namespace ahip

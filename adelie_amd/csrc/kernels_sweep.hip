@@ -363,6 +363,61 @@ __global__ void pack_snp_kernel(const int8_t* __restrict__ calldata, int64_t n, 
     (void)p;
 }
 
+// PLINK 1 .bed record (SNP-major) -> device 2-bit codes.  .bed: 2 bits per sample, low bits first,
+// 00 = two copies of A1, 10 = one, 11 = none, 01 = missing; device code = count of A1 (0/1/2), 3 = missing.
+// Each byte is four samples in both layouts, so a byte maps to a byte; the tail samples of the last byte are zeroed.
+__global__ void bed_transcode_kernel(const uint8_t* __restrict__ bed, int64_t n, int64_t stride_in,
+                                     uint8_t* __restrict__ bits, int64_t ldb) {
+    const int64_t j = blockIdx.y;
+    const int64_t nb = (n + 3) / 4;
+    for (int64_t b = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; b < ldb; b += int64_t(gridDim.x) * blockDim.x) {
+        unsigned out = 0;
+        if (b < nb) {
+            const unsigned in = bed[j * stride_in + b];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned f = (in >> (2 * k)) & 3u;
+                // 00 -> 2, 01 -> 3 (missing), 10 -> 1, 11 -> 0
+                const unsigned code = (b * 4 + k < n) ? ((0x1Eu >> (2 * f)) & 3u) : 0u;
+                out |= code << (2 * k);
+            }
+        }
+        bits[j * ldb + b] = uint8_t(out);
+    }
+}
+
+// impute[j] = mean of the non-missing calls of column j (reference io/utils.hpp:10-31); one workgroup per column
+template <class T>
+__global__ __launch_bounds__(256) void snp_impute_kernel(const uint8_t* __restrict__ bits, int64_t n, int64_t ldb,
+                                                         T* __restrict__ impute) {
+    __shared__ unsigned long long red[3][4];
+    const int64_t j = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t nb = (n + 3) / 4;
+    unsigned long long c1 = 0, c2 = 0, c3 = 0;
+    for (int64_t b = tid; b < nb; b += 256) {
+        const unsigned byte = bits[j * ldb + b];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned c = (byte >> (2 * k)) & 3u;
+            c1 += c == 1u; c2 += c == 2u; c3 += c == 3u;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        c1 += __shfl_xor(c1, off, 64); c2 += __shfl_xor(c2, off, 64); c3 += __shfl_xor(c3, off, 64);
+    }
+    if (lane == 0) { red[0][wv] = c1; red[1][wv] = c2; red[2][wv] = c3; }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        const unsigned long long s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const unsigned long long s3 = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        const unsigned long long valid = (unsigned long long)n - s3;
+        impute[j] = T(double(s1 + 2 * s2) / double(valid > 0 ? valid : 1));
+    }
+}
+
 inline unsigned grid1d(int64_t n, int bt, int64_t cap = 4096) {
     int64_t g = (n + bt - 1) / bt;
     if (g > cap) g = cap;
@@ -524,6 +579,23 @@ void launch_pack_snp(const int8_t* calldata, int64_t n, int64_t p, uint8_t* bits
                            bits + j0 * ldb, ldb);
     }
 }
+
+void launch_bed_transcode(const uint8_t* bed, int64_t n, int64_t p, int64_t stride_in, uint8_t* bits, int64_t ldb,
+                          hipStream_t s) {
+    if (n <= 0 || p <= 0) return;
+    for (int64_t j0 = 0; j0 < p; j0 += 65535) {
+        const unsigned cy = unsigned(p - j0 < 65535 ? p - j0 : 65535);
+        hipLaunchKernelGGL(bed_transcode_kernel, dim3(grid1d(ldb, 256, 256), cy), dim3(256), 0, s, bed + j0 * stride_in, n,
+                           stride_in, bits + j0 * ldb, ldb);
+    }
+}
+template <class T>
+void launch_snp_impute(const uint8_t* bits, int64_t n, int64_t p, int64_t ldb, T* impute, hipStream_t s) {
+    if (p <= 0) return;
+    hipLaunchKernelGGL((snp_impute_kernel<T>), dim3((unsigned)p), dim3(256), 0, s, bits, n, ldb, impute);
+}
+template void launch_snp_impute<double>(const uint8_t*, int64_t, int64_t, int64_t, double*, hipStream_t);
+template void launch_snp_impute<float>(const uint8_t*, int64_t, int64_t, int64_t, float*, hipStream_t);
 
 #define INST(T)                                                                                                        \
     template void launch_vmul<T>(const T*, const T*, T*, int64_t, hipStream_t);                                        \

@@ -168,3 +168,43 @@ class snp_unphased:
                     out[rows, j] = vals[c]
                     pos += 5 + k
         return out
+
+
+# ---- PLINK 1 .bed (SNP-major) -------------------------------------------------------------------------------------------
+_BED_MAGIC = bytes([0x6C, 0x1B, 0x01])
+# count of allele A1 -> 2-bit field (low bits first in the byte): 2 -> 00, missing -> 01, 1 -> 10, 0 -> 11
+_BED_FIELD = {2: 0b00, -9: 0b01, 1: 0b10, 0: 0b11}
+
+
+def write_bed(path, calldata):
+    """Writes an int8 ``(n, p)`` calldata matrix (A1 counts 0/1/2, negative = missing) as a PLINK 1 ``.bed`` image
+    (SNP-major).  Returns the number of bytes written.  Host-side reference codec for ``matrix.snp_bed``."""
+    cd = np.asarray(calldata)
+    n, p = cd.shape
+    field = np.full(cd.shape, _BED_FIELD[-9], dtype=np.uint8)
+    for v, f in _BED_FIELD.items():
+        if v >= 0:
+            field[cd == v] = f
+    stride = (n + 3) // 4
+    pad = np.zeros((stride * 4, p), dtype=np.uint8)
+    pad[:n] = field
+    q = pad.reshape(stride, 4, p)
+    rec = (q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)).astype(np.uint8)  # (stride, p)
+    image = _BED_MAGIC + np.ascontiguousarray(rec.T).tobytes()
+    with open(path, "wb") as f:
+        f.write(image)
+    return len(image)
+
+
+def read_bed(path, n, p=None):
+    """Decodes a PLINK 1 ``.bed`` image into int8 ``(n, p)`` calldata (A1 counts, -9 = missing) on the host."""
+    buf = np.fromfile(path, dtype=np.uint8) if isinstance(path, str) else np.frombuffer(path, dtype=np.uint8)
+    if buf.size < 3 or bytes(buf[:3]) != _BED_MAGIC:
+        raise RuntimeError("adelie_core: not a SNP-major PLINK .bed image.")
+    stride = (n + 3) // 4
+    if p is None:
+        p = (buf.size - 3) // stride
+    rec = buf[3:3 + stride * p].reshape(p, stride).T  # (stride, p)
+    fields = np.stack([(rec >> (2 * k)) & 3 for k in range(4)], axis=1).reshape(stride * 4, p)[:n]
+    lut = np.array([2, -9, 1, 0], dtype=np.int8)
+    return np.asfortranarray(lut[fields])

@@ -87,6 +87,12 @@ class _NativeMatrix:
     def cols(self):
         return self._cols
 
+    def impute(self):
+        """The ``(p,)`` impute values of an SNP design (what a missing call contributes)."""
+        out = np.empty(self._cols, dtype=np.float64)
+        self._backend.check(self._backend.fn("design_impute")(self._handle, out.ctypes.data))
+        return out
+
     @property
     def ndim(self):
         return 2
@@ -337,6 +343,26 @@ def snp_calldata(calldata, impute=None, *, dtype=np.float64, n_threads: int = 1,
     handle = _abi.C.c_void_p()
     backend.check(backend.fn("design_create_snp_calldata")(
         ptr, n, p, impute.ctypes.data, _abi.dtype_code(dtype), device, handle))
+    return _wrap(backend, handle, np.dtype(dtype).type, n_threads)
+
+
+def snp_bed(bed, n: int, p: int = None, *, dtype=np.float64, n_threads: int = 1, device: int = 0):
+    """SNP design from a PLINK 1 ``.bed`` file (SNP-major): ``bed`` is a path, a ``bytes``-like image or a ``uint8`` array.
+    ``n`` (samples) comes from the ``.fam`` file; ``p`` defaults to what the image holds.  Calls are counts of allele A1,
+    missing calls are mean-imputed; the 2-bit records are transcoded on the device (no host decode)."""
+    if isinstance(bed, str):
+        buf = np.fromfile(bed, dtype=np.uint8)
+    elif isinstance(bed, np.ndarray):
+        buf = np.ascontiguousarray(bed, dtype=np.uint8)
+    else:
+        buf = np.frombuffer(bed, dtype=np.uint8)
+    stride = (int(n) + 3) // 4
+    if p is None:
+        p = (buf.size - 3) // stride
+    backend = _abi.hip_backend()
+    handle = _abi.C.c_void_p()
+    backend.check(backend.fn("design_create_snp_bed")(
+        buf.ctypes.data, buf.size, int(n), int(p), _abi.dtype_code(dtype), device, handle))
     return _wrap(backend, handle, np.dtype(dtype).type, n_threads)
 
 

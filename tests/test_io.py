@@ -33,3 +33,22 @@ def test_snp_unphased_rejects_bad_values(tmp_path):
         h.write(np.array([[3]], dtype=np.int8))
     with pytest.raises(RuntimeError, match="not read"):
         h.rows
+
+
+@pytest.mark.parametrize("n,p", [(1, 1), (7, 3), (64, 5), (1001, 17)])
+def test_bed_codec_roundtrip(tmp_path, n, p):
+    """PLINK 1 .bed host codec (the checker of matrix.snp_bed): magic, record stride ceil(n/4), field code points
+    (00 = 2 copies of A1, 01 = missing, 10 = 1, 11 = 0, low bits first), zero padding of the last byte."""
+    rng = np.random.RandomState(n + p)
+    cd = rng.choice(np.array([0, 1, 2, -9], dtype=np.int8), size=(n, p), p=[0.6, 0.2, 0.1, 0.1])
+    path = str(tmp_path / "x.bed")
+    nbytes = ad.io.write_bed(path, cd)
+    assert nbytes == 3 + ((n + 3) // 4) * p
+    raw = np.fromfile(path, dtype=np.uint8)
+    assert bytes(raw[:3]) == bytes([0x6C, 0x1B, 0x01])
+    # first sample of the first SNP sits in the two low bits of the first record byte
+    want = {2: 0b00, -9: 0b01, 1: 0b10, 0: 0b11}[int(cd[0, 0])]
+    assert (raw[3] & 3) == want
+    back = ad.io.read_bed(path, n)
+    assert back.dtype == np.int8 and back.shape == (n, p)
+    np.testing.assert_array_equal(back, cd)

@@ -204,6 +204,59 @@ void op_sp_tmul(adelie_hip_design* d, int64_t L, const int64_t* indptr, const in
     }
 }
 
+} // namespace
+namespace ahip {
+template <class T>
+void launch_glm_loss2(int kind, const T* y, const T* wa, const T* wb, const T* base, T b0, const T* off, int64_t n, T* sums,
+                      hipStream_t s);
+}
+namespace {
+
+// Per-row losses of eta_l = X beta_l + intercepts[l] + offsets under two weight vectors, without moving eta to the host.
+template <class T>
+void op_path_losses(adelie_hip_design* d, int kind, int64_t L, const int64_t* indptr, const int64_t* indices,
+                    const T* values, const T* intercepts, const T* offsets, const T* y, const T* wa, const T* wb,
+                    double* out) {
+    set_device(d);
+    hipStream_t s = d->stream;
+    const int64_t n = d->n;
+    const int64_t nnz = indptr[L];
+    int64_t* dptr = scratch<int64_t>(d->s_idx1, L + 1);
+    int64_t* dind = scratch<int64_t>(d->s_idx2, nnz);
+    T* dval = scratch<T>(d->s_p1, nnz);
+    AHIP_CHECK(hipMemcpyAsync(dptr, indptr, (L + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    if (nnz) {
+        AHIP_CHECK(hipMemcpyAsync(dind, indices, nnz * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        AHIP_CHECK(hipMemcpyAsync(dval, values, nnz * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    // n-vectors y, wa, wb, offsets and the reduction scratch share one buffer
+    const size_t SUMS = 16 + 4 * 256;
+    T* vec = scratch<T>(d->s_n1, size_t(4) * n + SUMS + size_t(2) * L);
+    T *dy = vec, *dwa = vec + n, *dwb = vec + 2 * n, *doff = vec + 3 * n, *sums = vec + 4 * n, *dres = sums + SUMS;
+    AHIP_CHECK(hipMemcpyAsync(dy, y, n * sizeof(T), hipMemcpyHostToDevice, s));
+    AHIP_CHECK(hipMemcpyAsync(dwa, wa, n * sizeof(T), hipMemcpyHostToDevice, s));
+    AHIP_CHECK(hipMemcpyAsync(dwb, wb, n * sizeof(T), hipMemcpyHostToDevice, s));
+    AHIP_CHECK(hipMemcpyAsync(doff, offsets, n * sizeof(T), hipMemcpyHostToDevice, s));
+    const int64_t Lp = std::max<int64_t>(1, (int64_t(1) << 30) / int64_t(n * sizeof(T)));
+    T* dout = scratch<T>(d->s_misc, size_t(std::min(Lp, L)) * n);
+    for (int64_t l0 = 0; l0 < L; l0 += Lp) {
+        const int64_t lc = std::min(Lp, L - l0);
+        if (d->kind == 0) launch_sp_tmul<T>(d->dense<T>(), lc, dptr + l0, dind, dval, dout, s);
+        else launch_sp_tmul_snp<T>(d->snp(), static_cast<const T*>(d->impute), lc, dptr + l0, dind, dval, dout, s);
+        for (int64_t l = 0; l < lc; ++l) {
+            launch_glm_loss2<T>(kind, dy, dwa, dwb, dout + l * n, intercepts[l0 + l], doff, n, sums, s);
+            AHIP_CHECK(hipMemcpyAsync(dres + 2 * (l0 + l), sums, 2 * sizeof(T), hipMemcpyDeviceToDevice, s));
+        }
+    }
+    std::vector<T> res(size_t(2) * L);
+    AHIP_CHECK(hipMemcpyAsync(res.data(), dres, res.size() * sizeof(T), hipMemcpyDeviceToHost, s));
+    AHIP_CHECK(hipStreamSynchronize(s));
+    for (int64_t l = 0; l < L; ++l) {
+        out[l] = double(res[2 * l]);
+        out[L + l] = double(res[2 * l + 1]);
+    }
+}
+
 void check_col(const adelie_hip_design* d, int64_t j, int64_t q, const char* what) {
     if (j < 0 || q < 0 || j + q > d->p) throw make_core_error(std::string(what) + "() is given inconsistent inputs!");
 }
@@ -464,6 +517,23 @@ int adelie_hip_design_sp_tmul(adelie_hip_design* d, int64_t L, const int64_t* in
     if (L == 0) return 0;
     DTYPE_DISPATCH(d, op_sp_tmul<T>(d, L, indptr, indices, (const T*)values, (T*)out),
                    op_sp_tmul<T>(d, L, indptr, indices, (const T*)values, (T*)out))
+    ABI_CATCH
+}
+
+int adelie_hip_design_glm_path_losses(adelie_hip_design* d, int glm_kind, int64_t L, const int64_t* indptr,
+                                      const int64_t* indices, const void* values, const void* intercepts,
+                                      const void* offsets, const void* y, const void* weights_a, const void* weights_b,
+                                      double* out) {
+    ABI_TRY
+    if (!d || !indptr || !intercepts || !offsets || !y || !weights_a || !weights_b || !out)
+        throw make_core_error("null argument.");
+    if (L < 0) throw make_core_error("L must be >= 0.");
+    if (L > 0) {
+        DTYPE_DISPATCH(d, op_path_losses<T>(d, glm_kind, L, indptr, indices, (const T*)values, (const T*)intercepts,
+                                            (const T*)offsets, (const T*)y, (const T*)weights_a, (const T*)weights_b, out),
+                       op_path_losses<T>(d, glm_kind, L, indptr, indices, (const T*)values, (const T*)intercepts,
+                                         (const T*)offsets, (const T*)y, (const T*)weights_a, (const T*)weights_b, out))
+    }
     ABI_CATCH
 }
 

@@ -142,6 +142,23 @@ __global__ __launch_bounds__(RT) void glm_loss_kernel(int kind, const T* __restr
     block_partials<T, 1>(acc, sums);
 }
 
+// loss of eta = base + b0 + off under two weight vectors at once (cv_grpnet: full-data and training-fold weights)
+template <class T>
+__global__ __launch_bounds__(RT) void glm_loss2_kernel(int kind, const T* __restrict__ y, const T* __restrict__ wa,
+                                                       const T* __restrict__ wb, const T* __restrict__ base, T b0,
+                                                       const T* __restrict__ off, int64_t n, T* sums) {
+    T acc[2] = {T(0), T(0)};
+    GRID_STRIDE(i, n) {
+        const T e = base[i] + b0 + off[i];
+        T l;
+        if (kind == ADELIE_HIP_GLM_BINOMIAL_LOGIT) l = (T(e > T(0)) - y[i]) * e + log(T(1) + exp(-fabs(e)));
+        else l = T(0.5) * e * e - y[i] * e;
+        acc[0] += wa[i] * l;
+        acc[1] += wb[i] * l;
+    }
+    block_partials<T, 2>(acc, sums);
+}
+
 template <class T>
 __global__ __launch_bounds__(RT) void null_step_kernel(int kind, const T* __restrict__ y, const T* __restrict__ w,
                                                        const T* __restrict__ eta, const T* __restrict__ resid,
@@ -215,6 +232,12 @@ void launch_glm_loss(int kind, const T* y, const T* w, const T* eta, int64_t n, 
     finish(sums, 1, s);
 }
 template <class T>
+void launch_glm_loss2(int kind, const T* y, const T* wa, const T* wb, const T* base, T b0, const T* off, int64_t n, T* sums,
+                      hipStream_t s) {
+    hipLaunchKernelGGL((glm_loss2_kernel<T>), dim3(RB), dim3(RT), 0, s, kind, y, wa, wb, base, b0, off, n, sums);
+    finish(sums, 2, s);
+}
+template <class T>
 void launch_null_step(int kind, const T* y, const T* w, const T* eta, const T* resid, const T* offsets, T hessian_min,
                       int64_t n, T* sums, hipStream_t s) {
     hipLaunchKernelGGL((null_step_kernel<T>), dim3(RB), dim3(RT), 0, s, kind, y, w, eta, resid, offsets, hessian_min, n,
@@ -244,6 +267,8 @@ void launch_gather(const T* src, const int32_t* idx, int64_t cnt, T* dst, hipStr
                                         hipStream_t);                                                                  \
     template void launch_glm_gradient<T>(int, const T*, const T*, const T*, int64_t, T*, hipStream_t);                 \
     template void launch_glm_loss<T>(int, const T*, const T*, const T*, int64_t, T*, hipStream_t);                     \
+    template void launch_glm_loss2<T>(int, const T*, const T*, const T*, const T*, T, const T*, int64_t, T*,           \
+                                      hipStream_t);                                                                    \
     template void launch_null_step<T>(int, const T*, const T*, const T*, const T*, const T*, T, int64_t, T*,           \
                                       hipStream_t);                                                                    \
     template void launch_set_eta<T>(const T*, T, int64_t, T*, hipStream_t);                                            \

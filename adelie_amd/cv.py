@@ -73,9 +73,15 @@ def _fold_loss(X, glm, fold_idx, full_lmdas, *, n_threads, early_exit, min_ratio
     beta_ints = [coefficient(lmda=lmda, betas=betas, intercepts=intercepts, lmdas=lmdas) for lmda in full_lmdas]
     full_betas = scipy.sparse.vstack([x[0] for x in beta_ints]).tocsr()
     full_intercepts = np.array([x[1] for x in beta_ints])
-    etas = predict(X=X, betas=full_betas, intercepts=full_intercepts, offsets=state._offsets, n_threads=n_threads)
-    full_data_losses = np.array([glm.loss(eta) for eta in etas])
-    train_losses = weights_sum * np.array([glm_c.loss(eta) for eta in etas])
+    if hasattr(X, "glm_path_losses") and X._backend.has("design_glm_path_losses") and hasattr(glm, "core_kind"):
+        # predictions and both losses per lambda on the device; only 2 L scalars come back
+        full_data_losses, train = X.glm_path_losses(glm.core_kind, full_betas, full_intercepts, state._offsets, glm.y,
+                                                    glm.weights, glm_c.weights)
+        train_losses = weights_sum * train
+    else:
+        etas = predict(X=X, betas=full_betas, intercepts=full_intercepts, offsets=state._offsets, n_threads=n_threads)
+        full_data_losses = np.array([glm.loss(eta) for eta in etas])
+        train_losses = weights_sum * np.array([glm_c.loss(eta) for eta in etas])
     return (full_data_losses - train_losses) / weights_sum_val if weights_sum_val > 0 else np.zeros(len(full_lmdas))
 
 

@@ -87,6 +87,22 @@ class _NativeMatrix:
     def cols(self):
         return self._cols
 
+    def glm_path_losses(self, glm_kind, betas, intercepts, offsets, y, weights_a, weights_b):
+        """Losses of ``eta_l = X beta_l + intercepts[l] + offsets`` under two weight vectors, all on the device
+        (``adelie_hip_design_glm_path_losses``).  ``betas`` is a CSR ``(L, p)`` matrix.  Returns two ``(L,)`` arrays."""
+        dt = self.dtype
+        betas = betas.tocsr()
+        L = betas.shape[0]
+        indptr = np.ascontiguousarray(betas.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(betas.indices, dtype=np.int64)
+        values = np.ascontiguousarray(betas.data, dtype=dt)
+        vecs = [np.ascontiguousarray(v, dtype=dt) for v in (intercepts, offsets, y, weights_a, weights_b)]
+        out = np.empty(2 * L, dtype=np.float64)
+        self._backend.check(self._backend.fn("design_glm_path_losses")(
+            self._handle, int(glm_kind), L, indptr.ctypes.data, indices.ctypes.data, values.ctypes.data,
+            *[v.ctypes.data for v in vecs], out.ctypes.data))
+        return out[:L], out[L:]
+
     def impute(self):
         """The ``(p,)`` impute values of an SNP design (what a missing call contributes)."""
         out = np.empty(self._cols, dtype=np.float64)

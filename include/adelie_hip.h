@@ -88,6 +88,16 @@ int adelie_hip_design_create_snp_bed(const void* bed, int64_t n_bytes, int64_t n
 int adelie_hip_design_impute(adelie_hip_design* d, double* out);
 int adelie_hip_design_destroy(adelie_hip_design* d);
 
+/* cv_grpnet post-processing on the device (adelie/cv.py:296-312, diagnostic.py:30-121): for the L
+ * sparse coefficient rows (CSR, int64 indices) computes eta_l = X beta_l + intercepts[l] + offsets and returns
+ *   out[l]     = sum_i weights_a[i] * (A(eta_l,i) - y_i eta_l,i)        (the GLM's loss, glm_gaussian.ipp / glm_binomial.ipp)
+ *   out[L + l] = the same under weights_b
+ * without moving the (L, n) linear predictors to the host.  values / intercepts / offsets / y / weights in the design's dtype. */
+int adelie_hip_design_glm_path_losses(adelie_hip_design* d, int glm_kind, int64_t L, const int64_t* indptr,
+                                      const int64_t* indices, const void* values, const void* intercepts,
+                                      const void* offsets, const void* y, const void* weights_a, const void* weights_b,
+                                      double* out);
+
 int64_t adelie_hip_design_rows(const adelie_hip_design* d);   /* MatrixNaiveBase::rows */
 int64_t adelie_hip_design_cols(const adelie_hip_design* d);   /* MatrixNaiveBase::cols */
 int     adelie_hip_design_dtype(const adelie_hip_design* d);

@@ -97,3 +97,37 @@ def test_snp_bed_matches_calldata(hip, tmp_path, n, p, dtype):
         ad.matrix.snp_bed(np.zeros(3 + ((n + 3) // 4) * p, dtype=np.uint8), n)
     with pytest.raises(RuntimeError, match="truncated"):
         ad.matrix.snp_bed(np.fromfile(path, dtype=np.uint8)[:-1], n, p)
+
+
+@pytest.mark.parametrize("family", ["gaussian", "binomial"])
+@pytest.mark.parametrize("kind", ["dense", "snp"])
+def test_glm_path_losses_match_host(hip, family, kind):
+    """cv_grpnet's per-lambda losses computed on the device (adelie_hip_design_glm_path_losses) equal predict() +
+    glm.loss() on the host (reference cv.py:296-312): two weight vectors, intercepts, offsets, empty rows."""
+    import scipy.sparse as sp
+
+    rng = np.random.RandomState(4)
+    n, p, L = 1237, 61, 9
+    if kind == "dense":
+        Xh = np.asfortranarray(rng.normal(size=(n, p)))
+        X = ad.matrix.dense(Xh)
+    else:
+        cd = rng.choice(np.array([0, 1, 2, -9], dtype=np.int8), size=(n, p), p=[0.6, 0.2, 0.1, 0.1])
+        imp = ad.matrix.compute_impute(cd)
+        Xh = np.where(cd < 0, imp[None, :], cd).astype(np.float64)
+        X = ad.matrix.snp_calldata(cd, imp)
+    B = sp.random(L, p, density=0.2, random_state=rng, format="csr", dtype=np.float64)
+    B = sp.vstack([B[:3], sp.csr_matrix((1, p)), B[3:]]).tocsr()   # an all-zero row
+    L = B.shape[0]
+    b0 = rng.normal(size=L)
+    off = 0.1 * rng.normal(size=n)
+    y = rng.normal(size=n) if family == "gaussian" else (rng.uniform(size=n) < 0.4).astype(np.float64)
+    wa = rng.uniform(0.5, 1.5, size=n); wa /= wa.sum()
+    wb = wa.copy(); wb[rng.choice(n, n // 5, replace=False)] = 0; wb /= wb.sum()
+    ga = ad.glm.gaussian(y, weights=wa) if family == "gaussian" else ad.glm.binomial(y, weights=wa)
+    gb = ga.reweight(wb)
+    la, lb = X.glm_path_losses(ga.core_kind, B, b0, off, y, ga.weights, gb.weights)
+    etas = ad.diagnostic.predict(X=X, betas=B, intercepts=b0, offsets=off)
+    np.testing.assert_allclose(etas, (B @ Xh.T) + b0[:, None] + off, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(la, [ga.loss(e) for e in etas], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(lb, [gb.loss(e) for e in etas], rtol=1e-12, atol=1e-14)

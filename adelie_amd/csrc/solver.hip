@@ -1067,8 +1067,11 @@ struct Solver {
         }
         const double t_cd = sw.elapsed();
         if (nv == 0) {
+            // one (empty) active pass + one (empty) screen pass; their convergence measure is 0, so with a zero
+            // tolerance (y_var == 0) the reference never leaves the loop and reports max_iters (pin_naive:317-357)
+            if (!(T(0) < pin_tol)) throw max_cds_error(0);
             sc.status = CD_OK;
-            sc.iters = 2; // one (empty) active pass + one (empty) screen pass
+            sc.iters = 2;
         }
         cnt.n_cd_visits_screen += sc.n_visits_screen;
         cnt.n_cd_visits_active += sc.n_visits_active;

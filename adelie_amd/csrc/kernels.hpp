@@ -192,8 +192,18 @@ struct CdGrpBlkParams {
     T* dlt;
     int32_t* didx;
     CdBlkState<T>* st;
+    // panel (residual-based) variant: see CdBlkParams
+    const T* gblk;       // [128] gradient of the block's values (block-local order)
+    const T* Dptr;       // 128 x 128 slot, block-local order
+    const int32_t* vcol; // screen value -> design column
+    int32_t* dcol;       // [128] out: design columns of the changed values
+    CdBlkState<T>* host_st;
+    int32_t* host_seq;
+    int32_t report_j, report_seq;
 };
 template <class T> void launch_cd_group_block_pass(const CdGrpBlkParams<T>& p, hipStream_t s);
+// the visits of block j against p.gblk / p.Dptr (one workgroup)
+template <class T> void launch_cd_group_panel_solve(const CdGrpBlkParams<T>& p, int j, hipStream_t s);
 int cd_block_size();
 // enqueues one whole pass (gather, then solve/update per block); the host reads st afterwards
 template <class T> void launch_cd_block_pass(const CdBlkParams<T>& p, hipStream_t s);

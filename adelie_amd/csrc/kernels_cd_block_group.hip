@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void grp_gather_kernel(CdGrpBlkParams<T> p, in
     gather_group_block(p, j, vmap, meta[1], blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
-template <class T>
+template <class T, bool NAIVE>
 __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int j) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* D = reinterpret_cast<T*>(smem_raw); // GBLK*GBLK
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int
         const int i = tid;
         if (i < nval) {
             const int a = vmap[i];
-            gB[i] = p.g[a];
+            gB[i] = NAIVE ? p.gblk[i] : p.g[a];
             bB[i] = p.beta[a];
             b0B[i] = bB[i];
             AB[i] = p.vars[a];
@@ -172,9 +172,9 @@ __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int
         }
     }
     {
-        const T* src = p.Dbuf + size_t(j & 1) * GBLK * GBLK;
-        // 16 loads in flight per lane
-        constexpr int NE = GBLK * GBLK;
+        const T* src = NAIVE ? p.Dptr : p.Dbuf + size_t(j & 1) * GBLK * GBLK;
+        // 16 loads in flight per lane; columns [0, nval) of the slot
+        const int NE = nval * GBLK;
         for (int e0 = tid; e0 < NE; e0 += 256 * 16) {
             T v[16];
 #pragma unroll
@@ -342,7 +342,11 @@ __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int
         if (ch) p.beta[vmap[i]] = bB[i];
         const unsigned long long m = __ballot(ch);
         const int pos = nz + __popcll(m & ((1ull << lane) - 1ull));
-        if (ch) { p.didx[pos] = vmap[i]; p.dlt[pos] = d; }
+        if (ch) {
+            if (NAIVE) p.dcol[pos] = p.vcol[vmap[i]];
+            else p.didx[pos] = vmap[i];
+            p.dlt[pos] = d;
+        }
         nz += __popcll(m);
     }
     if (lane == 0) {
@@ -353,6 +357,14 @@ __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int
         st->status = status;
         st->n_updates = n_upd;
         st->nz = nz;
+        if (NAIVE && p.host_st && j == p.report_j) {
+            CdBlkState<T> out;
+            out.rsq = rsq; out.resid_sum = rsum; out.cm = cm; out.n_updates = n_upd;
+            out.active_size = asz; out.status = status; out.nz = nz; out._pad = 0;
+            *p.host_st = out;
+            __threadfence_system();
+            __hip_atomic_store(p.host_seq, p.report_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -404,19 +416,34 @@ void launch_cd_group_block_pass(const CdGrpBlkParams<T>& p, hipStream_t s) {
     const unsigned ug = unsigned((p.nv + 63) / 64);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grp_solve_kernel<double>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grp_solve_kernel<double, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_solve_lds<double>()));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grp_solve_kernel<float>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grp_solve_kernel<float, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_solve_lds<float>()));
         attr_done = true;
     }
     const size_t lds = grp_solve_lds<T>();
     hipLaunchKernelGGL((grp_gather_kernel<T>), dim3(64), dim3(256), 0, s, p, 0);
     for (int j = 0; j < p.nblk; ++j) {
-        hipLaunchKernelGGL((grp_solve_kernel<T>), dim3(1), dim3(256), lds, s, p, j);
+        hipLaunchKernelGGL((grp_solve_kernel<T, false>), dim3(1), dim3(256), lds, s, p, j);
         hipLaunchKernelGGL((grp_update_kernel<T>), dim3(ug), dim3(256), 0, s, p, j);
     }
 }
+
+template <class T>
+void launch_cd_group_panel_solve(const CdGrpBlkParams<T>& p, int j, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grp_solve_kernel<double, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_solve_lds<double>()));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grp_solve_kernel<float, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_solve_lds<float>()));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((grp_solve_kernel<T, true>), dim3(1), dim3(256), grp_solve_lds<T>(), s, p, j);
+}
+template void launch_cd_group_panel_solve<double>(const CdGrpBlkParams<double>&, int, hipStream_t);
+template void launch_cd_group_panel_solve<float>(const CdGrpBlkParams<float>&, int, hipStream_t);
 
 template void launch_cd_group_block_pass<double>(const CdGrpBlkParams<double>&, hipStream_t);
 template void launch_cd_group_block_pass<float>(const CdGrpBlkParams<float>&, hipStream_t);

@@ -261,7 +261,10 @@ struct Solver {
     }
     std::vector<int32_t> dscr_nb, dact_nb;      // cached block: number of members it was built for
     std::vector<uint64_t> dscr_ver, dact_ver;   // ... and the weight version
-    bool panel_mode() const { return engine_panel && all_scalar && nv >= cd_block_min_nv; }
+    bool group_panel = true;    // groups (q > 1) on the panel engine too (A/B hook ADELIE_HIP_GROUP_PANEL=0: full-Gram block engine)
+    bool panel_mode() const {
+        return engine_panel && nv >= cd_block_min_nv && (all_scalar || (group_panel && max_gs <= idx(cd_block_size())));
+    }
     DevBuf<T> d_work_sweep, d_work_gram;
     bool grad_valid = false; // d_grad == X^T W r - rsum*xbar for the current r
     // glm device vectors
@@ -487,6 +490,10 @@ struct Solver {
         screen_transforms.resize(ns);
         if (N <= 0) return;
         cnt.n_new_screen_cols += N;
+        if (!all_scalar) {
+            update_vars_panel_groups(w_dev, xm_dev, xm_host, g_begin, pos0, N);
+            return;
+        }
         sweep(w_dev, d_vars.p + pos0, d_vcol.p + pos0, N, nullptr, nullptr, true);
         for (idx ss = idx(g_begin); ss < ns; ++ss) {
             const idx g = screen_set[ss], b = screen_begins[ss];
@@ -497,6 +504,85 @@ struct Solver {
         // (finalize() downloads it), so no synchronisation here
         launch_gather<T>(xm_dev, d_vcol.p + pos0, N, d_sxm.p + pos0, st);
         launch_center_vars<T>(d_vars.p + pos0, d_sxm.p + pos0, int(N), intercept, st);
+    }
+
+    // Same with groups: X_g^T W X_g - xbar xbar^T of every new group is a diagonal sub-block of one of the screen-order
+    // diagonal blocks of the panel engine (groups are never split across blocks), so those blocks are built here (they are
+    // needed by the next screen pass anyway), copied to the host once, and the eigen-decompositions
+    // (solver_gaussian_naive.hpp:105-125) are done on the host copies.
+    std::vector<int32_t> gp_vbeg; // per block of the current partition: offset of its first value in the pass's column list
+    size_t group_maxblk() const { return size_t(2 * p / cd_block_size() + 2); }
+    int build_partition_values(const idx* list, idx count) {
+        const int nblk = build_partition(list, count);
+        gp_vbeg.assign(size_t(nblk) + 1, 0);
+        int32_t acc = 0;
+        for (int j = 0; j < nblk; ++j) {
+            for (int32_t pos = part_host[j]; pos < part_host[j + 1]; ++pos)
+                acc += int32_t(group_sizes[screen_set[list ? list[pos] : pos]]);
+            gp_vbeg[size_t(j) + 1] = acc;
+        }
+        return nblk;
+    }
+    void update_vars_panel_groups(const T* w_dev, const T* xm_dev, const std::vector<T>& xm_host, size_t g_begin, idx pos0,
+                                  idx N) {
+        const idx ns = idx(screen_set.size());
+        const int SL = cd_block_size();
+        panel_setup(group_maxblk());
+        const int nblk = build_partition_values(nullptr, ns);
+        for (idx ss = idx(g_begin); ss < ns; ++ss) {
+            const idx g = screen_set[ss], b = screen_begins[ss];
+            for (idx t = 0; t < group_sizes[g]; ++t) screen_X_means[b + t] = xm_host[groups[g] + t];
+        }
+        launch_gather<T>(xm_dev, d_vcol.p + pos0, N, d_sxm.p + pos0, st);
+        int j0 = 0;
+        while (j0 + 1 < nblk && size_t(part_host[j0 + 1]) <= g_begin) ++j0;
+        std::vector<T> hD(size_t(nblk - j0) * SL * SL);
+        for (int j = j0; j < nblk; ++j) {
+            const int nval = gp_vbeg[size_t(j) + 1] - gp_vbeg[j];
+            T* Dptr = d_Dpool.p + size_t(j) * SL * SL;
+            if (dscr_nb[j] != nval || dscr_ver[j] != w_version) {
+                gram_block(w_dev, d_vcol.p + gp_vbeg[j], nval, xm_dev, Dptr);
+                dscr_nb[j] = nval;
+                dscr_ver[j] = w_version;
+                ++cnt.n_panel_grams;
+            }
+            AHIP_CHECK(hipMemcpyAsync(hD.data() + size_t(j - j0) * SL * SL, Dptr, size_t(SL) * SL * sizeof(T),
+                                      hipMemcpyDeviceToHost, st));
+        }
+        sync();
+        std::vector<T> vars_host(N), vnew;
+        std::vector<idx> voff(size_t(ns) - g_begin, 0);
+        int j = j0;
+        for (idx ss = idx(g_begin); ss < ns; ++ss) {
+            while (j + 1 < nblk && part_host[j + 1] <= int32_t(ss)) ++j;
+            const idx q = group_sizes[screen_set[ss]], b = screen_begins[ss];
+            const idx o = b - gp_vbeg[j];
+            const T* Dj = hD.data() + size_t(j - j0) * SL * SL;
+            if (q == 1) {
+                const T d = Dj[o + o * SL];
+                vars_host[b - pos0] = d > T(0) ? d : T(0);
+                screen_transforms[ss] = std::vector<T>{T(1)};
+                continue;
+            }
+            std::vector<double> A(size_t(q) * q), V, Dv;
+            for (idx c = 0; c < q; ++c)
+                for (idx r = 0; r < q; ++r) A[r + c * q] = double(Dj[(o + r) + (o + c) * SL]);
+            jacobi_eigh(int(q), A, V, Dv);
+            for (idx t = 0; t < q; ++t) vars_host[b + t - pos0] = T(Dv[t] >= 0 ? Dv[t] : 0.0);
+            voff[ss - g_begin] = idx(v_used + vnew.size());
+            std::vector<T> Vt(V.begin(), V.end());
+            vnew.insert(vnew.end(), Vt.begin(), Vt.end());
+            screen_transforms[ss] = std::move(Vt);
+        }
+        if (!vnew.empty()) {
+            d_V.grow(v_used + vnew.size(), v_used, st);
+            d_V.upload(vnew.data(), vnew.size(), st, v_used);
+            v_used += vnew.size();
+        }
+        d_vars.upload(vars_host.data(), N, st, pos0);
+        d_voff.upload(voff.data(), voff.size(), st, g_begin);
+        sync(); // the staging vectors go out of scope
+        for (idx t = 0; t < N; ++t) screen_vars[pos0 + t] = vars_host[t];
     }
 
     // solver_gaussian_naive.hpp:134-176
@@ -734,6 +820,61 @@ struct Solver {
         sync();
     }
 
+    // Buffers of the panel engine: per-block vectors, slice partials, the two tables of cached diagonal blocks (screen order /
+    // activation order, `maxblk` slots of 128 x 128 each) and the host-mapped end-of-pass report.
+    CdBlkState<T>* rep_st_dev = nullptr;
+    int32_t* rep_seq_dev = nullptr;
+    size_t panel_maxblk = 0;
+    void panel_setup(size_t maxblk) {
+        const int SL = cd_block_size();
+        d_blk.reserve(1);
+        d_dlt.reserve(SL);
+        d_dcolblk.reserve(SL);
+        d_gblk.reserve(SL);
+        d_actcols.reserve(size_t(p) + SL);
+        d_part.reserve(size_t(panel_part_elems(n)));
+        if (panel_maxblk != maxblk) {
+            d_Dpool.reserve(size_t(2) * maxblk * SL * SL);
+            AHIP_CHECK(hipMemsetAsync(d_Dpool.p, 0, size_t(2) * maxblk * SL * SL * sizeof(T), st));
+            dscr_nb.assign(maxblk, 0); dact_nb.assign(maxblk, 0);
+            dscr_ver.assign(maxblk, 0); dact_ver.assign(maxblk, 0);
+            panel_maxblk = maxblk;
+        }
+        if (use_report && !h_report) {
+            void* hp = nullptr;
+            void* dp = nullptr;
+            if (hipHostMalloc(&hp, sizeof(PassReport), hipHostMallocMapped) == hipSuccess &&
+                hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+                h_report = static_cast<PassReport*>(hp);
+                std::memset(h_report, 0, sizeof(PassReport));
+                rep_st_dev = &static_cast<PassReport*>(dp)->st;
+                rep_seq_dev = &static_cast<PassReport*>(dp)->seq;
+            } else {
+                (void)hipGetLastError();
+                if (hp) (void)hipHostFree(hp);
+                use_report = false;
+            }
+        }
+    }
+    // state of the pass that was just enqueued: spin on the sequence number its last solve publishes in host-mapped memory
+    void wait_pass_state(CdBlkState<T>& bs) {
+        if (h_report) {
+            const auto t_spin = std::chrono::steady_clock::now();
+            int spins = 0;
+            while (__atomic_load_n(&h_report->seq, __ATOMIC_ACQUIRE) != report_seq) {
+                if ((++spins & 0xFFFF) == 0 &&
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_spin).count() > 20.0)
+                    break; // something is wrong on the device side: fall back to a real synchronisation
+            }
+            if (__atomic_load_n(&h_report->seq, __ATOMIC_ACQUIRE) == report_seq) {
+                bs = h_report->st;
+                return;
+            }
+        }
+        d_blk.download(&bs, 1, st);
+        sync();
+    }
+
     // Residual-based block passes (kernels_cd_panel.hip).  Per block: panel step (apply the previous block's changes to the
     // residual, partial gradients of this block) -> reduce -> one-workgroup solve against the cached diagonal block.
     // The residual is current when this returns (no end-of-fit update), also on failure (changes are undone).
@@ -744,18 +885,7 @@ struct Solver {
         const int B = panel_bsz > 0 ? panel_bsz : (is_glm() ? 64 : cd_block_size());
         const int SL = cd_block_size(); // D slot: SL x SL, leading dimension SL
         const size_t maxblk = size_t((p + B - 1) / B + 1);
-        d_blk.reserve(1);
-        d_dlt.reserve(B);
-        d_dcolblk.reserve(B);
-        d_gblk.reserve(B);
-        d_actcols.reserve(size_t(p) + B);
-        d_part.reserve(size_t(panel_part_elems(n)));
-        if (dscr_nb.size() != maxblk) {
-            d_Dpool.reserve(size_t(2) * maxblk * SL * SL);
-            AHIP_CHECK(hipMemsetAsync(d_Dpool.p, 0, size_t(2) * maxblk * SL * SL * sizeof(T), st));
-            dscr_nb.assign(maxblk, 0); dact_nb.assign(maxblk, 0);
-            dscr_ver.assign(maxblk, 0); dact_ver.assign(maxblk, 0);
-        }
+        panel_setup(maxblk);
         CdBlkState<T> bs{};
         bs.rsq = sc.rsq;
         bs.resid_sum = sc.resid_sum;
@@ -771,29 +901,7 @@ struct Solver {
         bp.dlt = d_dlt.p; bp.st = d_blk.p;
         bp.gblk = d_gblk.p; bp.vcol = cp.vcol; bp.dcol = d_dcolblk.p;
         bp.bsz = B;
-        if (use_report && !h_report) {
-            void* hp = nullptr;
-            if (hipHostMalloc(&hp, sizeof(PassReport), hipHostMallocMapped) == hipSuccess) {
-                h_report = static_cast<PassReport*>(hp);
-                std::memset(h_report, 0, sizeof(PassReport));
-            } else {
-                (void)hipGetLastError();
-                use_report = false;
-            }
-        }
-        bp.host_st = nullptr; bp.host_seq = nullptr; bp.report_j = -1; bp.report_seq = 0;
-        if (h_report) {
-            void* dp = nullptr;
-            if (hipHostGetDevicePointer(&dp, h_report, 0) == hipSuccess) {
-                bp.host_st = &static_cast<PassReport*>(dp)->st;
-                bp.host_seq = &static_cast<PassReport*>(dp)->seq;
-            } else {
-                (void)hipGetLastError();
-                (void)hipHostFree(h_report);
-                h_report = nullptr;
-                use_report = false;
-            }
-        }
+        bp.host_st = rep_st_dev; bp.host_seq = rep_seq_dev; bp.report_j = -1; bp.report_seq = 0;
         const T* xm_c = intercept ? cur_xm : nullptr;
         static const bool trace = std::getenv("ADELIE_HIP_TRACE") != nullptr;
         int64_t iters = 0;
@@ -843,21 +951,7 @@ struct Solver {
             }
             t_cd.end(st);
             cnt.n_panel_blocks += nblk;
-            bool got = false;
-            if (h_report) { // spin on the sequence number the last solve of the pass publishes
-                const auto t_spin = std::chrono::steady_clock::now();
-                int spins = 0;
-                while (__atomic_load_n(&h_report->seq, __ATOMIC_ACQUIRE) != report_seq) {
-                    if ((++spins & 0xFFFF) == 0 &&
-                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_spin).count() > 20.0)
-                        break; // something is wrong on the device side: fall back to a real synchronisation
-                }
-                if (__atomic_load_n(&h_report->seq, __ATOMIC_ACQUIRE) == report_seq) { bs = h_report->st; got = true; }
-            }
-            if (!got) {
-                d_blk.download(&bs, 1, st);
-                sync();
-            }
+            wait_pass_state(bs);
             status = bs.status;
             asz = bs.active_size;
             if (trace) std::fprintf(stderr, "[panel] %s count=%d nblk=%d cm=%g tol=%g status=%d asz=%d nz=%d rsq=%g rsum=%g nupd=%lld\n",
@@ -1002,6 +1096,135 @@ struct Solver {
         sync();
     }
 
+    // Panel engine with groups: blocks = consecutive groups of the visiting list with <= 128 values (partition built on the
+    // host, prefix-stable because both lists are append-only); otherwise the same data flow as run_panel_passes.
+    void run_group_panel_passes(const CdParams<T>& cp, CdScalars<T>& sc, T* r_dev) {
+        const int SL = cd_block_size();
+        panel_setup(group_maxblk());
+        const size_t maxblk = panel_maxblk;
+        CdBlkState<T> bs{};
+        bs.rsq = sc.rsq;
+        bs.resid_sum = sc.resid_sum;
+        bs.active_size = sc.active_size;
+        bs.status = CD_OK;
+        bs.nz = 0;
+        d_blk.upload(&bs, 1, st);
+        CdGrpBlkParams<T> bp{};
+        bp.nv = cp.nv; bp.vars = cp.vars; bp.xmean = cp.xmean; bp.beta = cp.beta;
+        bp.is_active = cp.is_active; bp.active_set = cp.active_set;
+        bp.l1 = cp.lmda * cp.alpha; bp.l2 = cp.lmda * (T(1) - cp.alpha);
+        bp.newton_tol = cp.newton_tol; bp.dbeta_tol = cp.dbeta_tol; bp.newton_max_iters = cp.newton_max_iters;
+        bp.max_active_size = cp.max_active_size;
+        bp.V = cp.V; bp.voff = cp.voff; bp.spen = cp.spen; bp.sbegin = cp.sbegin; bp.ssize = cp.ssize;
+        bp.dlt = d_dlt.p; bp.st = d_blk.p;
+        bp.gblk = d_gblk.p; bp.vcol = cp.vcol; bp.dcol = d_dcolblk.p;
+        bp.host_st = rep_st_dev; bp.host_seq = rep_seq_dev; bp.report_j = -1; bp.report_seq = 0;
+        const T* xm_c = intercept ? cur_xm : nullptr;
+        int64_t iters = 0;
+        int status = CD_OK;
+        int asz = sc.active_size;
+        std::vector<idx> act_host(active_set.begin(), active_set.begin() + asz); // host mirror of the active list
+        std::vector<int32_t> acols;
+        auto pass = [&](bool screen_pass) -> T {
+            const idx count = screen_pass ? idx(cp.ns) : idx(asz);
+            if (count <= 0) return T(0);
+            const int nblk = build_partition_values(screen_pass ? nullptr : act_host.data(), count);
+            d_blk_g0.reserve(part_host.size());
+            d_blk_g0.upload(part_host.data(), part_host.size(), st);
+            const int32_t* cols_all = d_vcol.p;
+            if (!screen_pass) { // design columns of the active values in visiting order
+                acols.clear();
+                for (idx pos = 0; pos < count; ++pos) {
+                    const idx g = screen_set[act_host[pos]];
+                    for (idx t = 0; t < group_sizes[g]; ++t) acols.push_back(int32_t(groups[g] + t));
+                }
+                d_actcols.upload(acols.data(), acols.size(), st);
+                cols_all = d_actcols.p;
+            }
+            auto& tab_nb = screen_pass ? dscr_nb : dact_nb;
+            auto& tab_ver = screen_pass ? dscr_ver : dact_ver;
+            T* pool = d_Dpool.p + (screen_pass ? size_t(0) : maxblk * SL * SL);
+            bp.blk_g0 = d_blk_g0.p;
+            bp.list = screen_pass ? nullptr : cp.active_set;
+            bp.nblk = nblk;
+            bp.mark = screen_pass ? 1 : 0;
+            t_cd.begin(st);
+            for (int j = 0; j < nblk; ++j) {
+                const int nval = gp_vbeg[size_t(j) + 1] - gp_vbeg[j];
+                const int32_t* cols = cols_all + gp_vbeg[j];
+                T* Dptr = pool + size_t(j) * SL * SL;
+                if (tab_nb[j] != nval || tab_ver[j] != w_version) {
+                    t_cd.end(st);
+                    gram_block(cur_w, cols, nval, cur_xm, Dptr);
+                    t_cd.begin(st);
+                    tab_nb[j] = nval;
+                    tab_ver[j] = w_version;
+                    ++cnt.n_panel_grams;
+                }
+                if (time_panel) t_step.begin(st);
+                const int nsl = panel_step(cur_w, r_dev, d_dcolblk.p, d_dlt.p, &d_blk.p->nz, cols, nval);
+                if (time_panel) t_step.end(st);
+                cnt.n_panel_cols += nval;
+                launch_panel_reduce<T>(d_part.p, nsl, nval, cols, &d_blk.p->resid_sum, xm_c, d_gblk.p, st);
+                bp.Dptr = Dptr;
+                if (h_report && j == nblk - 1) {
+                    bp.report_j = j;
+                    bp.report_seq = ++report_seq;
+                } else {
+                    bp.report_j = -1;
+                }
+                launch_cd_group_panel_solve<T>(bp, j, st);
+            }
+            t_cd.end(st);
+            cnt.n_panel_blocks += nblk;
+            wait_pass_state(bs);
+            status = bs.status;
+            if (bs.active_size > asz) { // pick up the groups activated by this screen pass
+                std::vector<int32_t> fresh(size_t(bs.active_size - asz));
+                d_actset.download(fresh.data(), fresh.size(), st, asz);
+                sync();
+                for (int32_t v : fresh) act_host.push_back(v);
+            }
+            asz = bs.active_size;
+            return bs.cm;
+        };
+        while (status == CD_OK) {
+            while (status == CD_OK) { // solve_active, pin_naive:173-215
+                ++iters;
+                ++sc.n_passes_active;
+                sc.n_visits_active += asz;
+                const T cm = pass(false);
+                if (status != CD_OK) break;
+                if (cm < cp.tol) break;
+                if (iters >= cp.max_iters) { status = CD_MAX_CDS; break; }
+            }
+            if (status != CD_OK) break;
+            ++iters;
+            ++sc.n_passes_screen;
+            sc.n_visits_screen += cp.ns;
+            const T cm = pass(true);
+            if (status != CD_OK) break;
+            if (cm < cp.tol) break;
+            if (iters >= cp.max_iters) { status = CD_MAX_CDS; break; }
+        }
+        // flush the last block's changes into the residual
+        t_cd.begin(st);
+        panel_step(cur_w, r_dev, d_dcolblk.p, d_dlt.p, &d_blk.p->nz, d_vcol.p, 0);
+        t_cd.end(st);
+        sc.rsq = bs.rsq;
+        sc.resid_sum = bs.resid_sum;
+        sc.iters = iters;
+        sc.n_updates = bs.n_updates;
+        sc.active_size = asz;
+        sc.status = status;
+        sc.n_delta = 0;
+        if (status != CD_OK) { // undo: r += X_S (beta - beta0)
+            launch_cd_compact<T>(cp.beta, cp.beta0, cp.vcol, cp.nv, cp.dcols, cp.dvals, &cp.sc->n_delta, st);
+            axpy_cols(cp.dcols, cp.dvals, &cp.sc->n_delta, 0, T(1), r_dev);
+            sync();
+        }
+    }
+
     // ---------------------------------------------------------------------------------------------------------
     // One pin solve on the device (solver_gaussian_pin_naive.hpp:217-401 for a single lambda).
     // Preconditions: Gram/vars/sxm valid for [0,nv) under the weights in use; d_g holds the current gradient of the
@@ -1051,7 +1274,8 @@ struct Solver {
         Stopwatch sw;
         sw.start();
         if (nv > 0 && panel_mode()) {
-            run_panel_passes(cp, sc, r_dev);
+            if (all_scalar) run_panel_passes(cp, sc, r_dev);
+            else run_group_panel_passes(cp, sc, r_dev);
         } else if (nv > 0 && all_scalar && nv >= cd_block_min_nv) {
             run_block_passes(cp, sc);
         } else if (nv > 0 && !all_scalar && max_gs <= cd_block_size() && nv >= cd_block_min_nv) {
@@ -1222,10 +1446,10 @@ struct Solver {
                 gram_nv = 0;
                 v_used = 0;
                 screen_transforms.clear();
+                ++w_version; // diagonal blocks built from here on belong to this iteration's weights
                 if (panel_mode()) update_vars_panel(d_irls_w.p, d_irls_xm.p, irls_xm_host, 0);
                 else update_gram_and_vars(d_irls_w.p, d_irls_xm.p, irls_xm_host, 0);
             }
-            ++w_version;
             cur_w = d_irls_w.p;
             cur_xm = d_irls_xm.p;
             // gradient of the screen values for the working response
@@ -1549,6 +1773,7 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_CD_ENGINE")) engine_panel = std::string(e) != "gram"; // A/B hook
         time_panel = std::getenv("ADELIE_HIP_TIME_PANEL") != nullptr;
         if (const char* e = std::getenv("ADELIE_HIP_PASS_REPORT")) use_report = std::atoi(e) != 0; // A/B hook
+        if (const char* e = std::getenv("ADELIE_HIP_GROUP_PANEL")) group_panel = std::atoi(e) != 0; // A/B hook
         if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {
             panel_bsz = std::atoi(e);
             if (panel_bsz != 32 && panel_bsz != 64 && panel_bsz != 128) panel_bsz = 0;

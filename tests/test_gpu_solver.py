@@ -222,11 +222,14 @@ def test_block_cd_passes_match_oracle(hip, oracle, monkeypatch, n, p, alpha, eng
     assert e2.error.startswith("adelie_core solver: max coordinate descents")
 
 
+@pytest.mark.parametrize("engine", ["panel", "gram"])
 @pytest.mark.parametrize("alpha", [1.0, 0.5])
-def test_group_block_cd_passes_match_oracle(hip, oracle, monkeypatch, alpha):
+def test_group_block_cd_passes_match_oracle(hip, oracle, monkeypatch, alpha, engine):
     """Forces the multi-CU block passes for grouped problems (kernels_cd_block_group.hip): mixed group sizes
-    (1..40), several blocks per pass, groups activated inside screen passes."""
+    (1..40), several blocks per pass, groups activated inside screen passes.  engine "panel": residual-based blocks with
+    cached diagonal Gram blocks, eigenbases from those blocks (the default); "gram": full screen-set Gram kept current."""
     monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    monkeypatch.setenv("ADELIE_HIP_GROUP_PANEL", "1" if engine == "panel" else "0")
     rng = np.random.RandomState(7)
     n, p = 1200, 640
     d = make_gaussian(n, p, seed=13, sparsity=0.6, weights=True)
@@ -243,6 +246,7 @@ def test_group_block_cd_passes_match_oracle(hip, oracle, monkeypatch, alpha):
     assert_same_path(a, b, 1e-6)
     assert a.active_set_size > 30
     assert abs(a.counters["n_updates"] - b.counters["n_updates"]) <= 0.02 * b.counters["n_updates"] + 5
+    assert (a.counters["n_panel_blocks"] > 0) == (engine == "panel")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -300,3 +304,21 @@ def test_panel_engine_small_blocks(hip, oracle, monkeypatch, bsz, dtype):
     a, b = _both(oracle, d, lambda: ad.glm.gaussian(d["y"], weights=d["weights"], dtype=dtype), dtype=dtype, **kw)
     assert a.counters["n_panel_blocks"] > 0
     assert_same_path(a, b, 5e-3 if f32 else 1e-6)
+
+
+def test_group_panel_binomial(hip, oracle, monkeypatch):
+    """Grouped binomial path (IRLS) through the group panel engine: diagonal blocks and eigenbases are rebuilt per IRLS
+    iteration from the IRLS weights (solver_glm_naive.hpp:361-385)."""
+    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    rng = np.random.RandomState(5)
+    n, p, gs = 900, 240, 6
+    X = np.asfortranarray(rng.normal(size=(n, p)))
+    beta = rng.normal(size=p) * np.repeat(rng.uniform(size=p // gs) < 0.3, gs)
+    eta = X @ beta
+    y = (rng.uniform(size=n) < 1 / (1 + np.exp(-eta / eta.std()))).astype(np.float64)
+    kw = dict(groups=np.arange(0, p, gs), alpha=0.7, early_exit=False, lmda_path_size=12, min_ratio=0.1, tol=1e-12,
+              irls_tol=1e-10)
+    a = ad.grpnet(ad.matrix.dense(X), ad.glm.binomial(y), **kw)
+    b = ad.grpnet(oracle.dense(X), ad.glm.binomial(y), **kw)
+    assert a.counters["n_panel_blocks"] > 0
+    assert_same_path(a, b, 1e-6)

@@ -717,6 +717,16 @@ struct Solver {
                     if (abs_grad[i] > lmda_next * penalty[i] * alpha) screen_set.push_back(i);
                 }
             }
+            // Progress guard (deliberate deviation): the KKT check multiplies in the order
+            // lmda * alpha * penalty (solver_base.hpp:428) and the fallback above in the order lmda * penalty * alpha
+            // (:369), which can round differently; a gradient that falls between the two fails KKT forever without ever
+            // being screened (seen in f32 at lambda_0 == lmda_max with alpha < 1).  Screen it with KKT's own expression.
+            if ((int(screen_set.size()) == old_size) && !all_kkt_passed) {
+                for (idx i = 0; i < G; ++i) {
+                    if (is_screen(i)) continue;
+                    if (abs_grad[i] > lmda_next * alpha * penalty[i]) screen_set.push_back(i);
+                }
+            }
         } else {
             throw make_solver_error("Unknown screen rule!");
         }

@@ -896,6 +896,16 @@ static void screen(State<T>& s, T lmda_next, bool all_kkt_passed, int n_new_acti
                 if (s.abs_grad[i] > lmda_next * s.penalty[i] * s.alpha) s.screen_set.push_back(i);
             }
         }
+        /* Progress guard, NOT in the reference: kkt() compares against lmda * alpha * penalty (solver_base.hpp:428), the
+         * fallback above against lmda * penalty * alpha (:369); a gradient between the two roundings fails KKT forever
+         * and the reference's BASIL loop never terminates (reproduced in f32, alpha = 0.3, lambda_0 == lmda_max).  The
+         * product carries the same guard (csrc/solver.hip::screen), so the two stay comparable. */
+        if ((int(s.screen_set.size()) == old_size) && !all_kkt_passed) {
+            for (idx i = 0; i < s.G; ++i) {
+                if (s.is_screen(i)) continue;
+                if (s.abs_grad[i] > lmda_next * s.alpha * s.penalty[i]) s.screen_set.push_back(i);
+            }
+        }
     } else {
         throw make_solver_error("Unknown screen rule!");
     }

@@ -213,3 +213,34 @@ def test_error_taxonomy(oracle):
     assert 0 < len(st.lmdas) < 100
     with pytest.raises(RuntimeError, match="alpha must be in"):
         ad.grpnet(Xo, ad.glm.gaussian(d["y"]), alpha=1.5)
+
+
+@pytest.mark.timeout(120)
+def test_basil_loop_terminates_when_kkt_and_fallback_round_differently(oracle):
+    """f32, alpha < 1, lambda_0 == lmda_max: the KKT check (lmda * alpha * penalty, solver_base.hpp:428) can flag a group
+    that the screening fallback (lmda * penalty * alpha, :369) does not pick up; the reference's BASIL loop then never
+    terminates.  The restatement (and the product, csrc/solver.hip::screen) screen such a group with KKT's own expression.
+    Found by scripts/fuzz_parity.py (seed 4, case 70); the solve must come back (here with the f32 Newton error)."""
+    rng = np.random.RandomState(4 * 1000 + 70)
+    n = int(rng.choice([37, 150, 513, 1200, 2049])); p = int(rng.choice([40, 130, 300, 777]))
+    rng.choice(["gaussian", "gaussian", "binomial"]); rng.choice(["dense", "dense", "snp"])
+    rng.uniform(); rng.uniform()
+    sizes = []
+    while sum(sizes) < p:
+        sizes.append(int(rng.choice([1, 1, 2, 3, 7, 16, 33])))
+    sizes[-1] -= sum(sizes) - p
+    if sizes[-1] <= 0:
+        sizes.pop(); sizes[-1] += p - sum(sizes)
+    groups = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    alpha = float(rng.choice([1.0, 0.7, 0.3])); rng.uniform(); rng.uniform()
+    rng.choice([1, 1, 64, 256]); rng.choice(["", "32", "64", "128"])
+    assert (n, p, alpha) == (37, 300, 0.3)
+    cd = rng.choice(np.array([0, 1, 2, -9], dtype=np.int8), size=(n, p), p=[0.6, 0.22, 0.1, 0.08])
+    imp = ad.matrix.compute_impute(cd)
+    Xd = np.where(cd < 0, imp[None, :], cd).astype(np.float64)
+    beta = rng.normal(size=p) * (rng.uniform(size=p) < 0.15)
+    eta = Xd @ beta; eta = eta / max(eta.std(), 1e-9)
+    y = eta + rng.normal(size=n)
+    st = ad.grpnet(oracle.snp_calldata(cd, imp, dtype=np.float32), ad.glm.gaussian(y, dtype=np.float32), groups=groups,
+                   alpha=alpha, early_exit=False, lmda_path_size=15, min_ratio=0.3, tol=1e-7, max_iters=4000)
+    assert st.error == "" or st.error.startswith("adelie_core solver: Newton-ABS max iterations reached")

@@ -200,6 +200,7 @@ struct CdGrpBlkParams {
     CdBlkState<T>* host_st;
     int32_t* host_seq;
     int32_t report_j, report_seq;
+    int64_t* dbg;        // 8 cycle counters, only written by builds with -DAHIP_GRP_PROFILE
 };
 template <class T> void launch_cd_group_block_pass(const CdGrpBlkParams<T>& p, hipStream_t s);
 // the visits of block j against p.gblk / p.Dptr (one workgroup)

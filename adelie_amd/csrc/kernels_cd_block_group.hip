@@ -187,6 +187,14 @@ __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int
     __syncthreads();
     if (wv != 0) return;
 
+#ifdef AHIP_GRP_PROFILE
+    long long tmark = __builtin_readcyclecounter();
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define GP_MARK(k) { const long long tn = __builtin_readcyclecounter(); tacc[k] += tn - tmark; tmark = tn; }
+    GP_MARK(0) /* prologue (since wave start is not visible: from here) */
+#else
+#define GP_MARK(k)
+#endif
     CdBlkState<T>* st = p.st;
     T rsq = st->rsq, rsum = st->resid_sum, cm = (j == 0) ? T(0) : st->cm;
     int asz = st->active_size, status = st->status;
@@ -246,6 +254,7 @@ __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int
                 gk_t[jj] = s1 + A[jj] * s2;
             }
             __builtin_amdgcn_wave_barrier();
+            GP_MARK(1) /* rotation */
             // newton_solver (bcd/unconstrained/newton.hpp:35-142): v = gk_t, L = A
             T nrm2 = 0;
             for (int i = lane; i < q; i += 64) nrm2 = fma(gk_t[i], gk_t[i], nrm2);
@@ -284,6 +293,7 @@ __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int
                 if (iters >= p.newton_max_iters) { status = CD_NEWTON; break; }
             }
             __builtin_amdgcn_wave_barrier();
+            GP_MARK(2) /* norm + newton */
             // changed? ; convergence / rsq in rotated coordinates (pin_naive:144-154)
             T dn = 0, c1 = 0, rs = 0;
             for (int i = lane; i < q; i += 64) {
@@ -316,6 +326,7 @@ __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int
             }
         }
         __builtin_amdgcn_wave_barrier();
+        GP_MARK(3) /* changed test + back rotation */
         if (changed) {
             if (p.mark && gactB[k] == 0) {                         // add_active_set, pin_naive:294-304
                 if (asz >= p.max_active_size) { status = CD_MAX_ACTIVE; break; }
@@ -332,6 +343,7 @@ __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int
             __builtin_amdgcn_wave_barrier();
             ++n_upd;
         }
+        GP_MARK(4) /* active marking + block gradient update */
     }
     // write back beta and the compacted non-zero value changes for the update kernel
     int nz = 0;
@@ -357,6 +369,11 @@ __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int
         st->status = status;
         st->n_updates = n_upd;
         st->nz = nz;
+#ifdef AHIP_GRP_PROFILE
+        GP_MARK(5) /* epilogue */
+        if (p.dbg) for (int k = 0; k < 8; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(p.dbg) + k, (unsigned long long)tacc[k]);
+        if (p.dbg) atomicAdd(reinterpret_cast<unsigned long long*>(p.dbg) + 7, 1ull);
+#endif
         if (NAIVE && p.host_st && j == p.report_j) {
             CdBlkState<T> out;
             out.rsq = rsq; out.resid_sum = rsum; out.cm = cm; out.n_updates = n_upd;

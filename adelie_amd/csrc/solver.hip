@@ -251,6 +251,7 @@ struct Solver {
     uint64_t w_version = 1;     // bumped whenever the weights behind cur_w change
     DevBuf<T> d_Dpool, d_part, d_gblk;
     DevBuf<int32_t> d_actcols, d_dcolblk;
+    DevBuf<int64_t> d_grp_dbg;
     // host-mapped end-of-pass report (state + sequence number), see CdBlkParams::host_st
     struct PassReport { CdBlkState<T> st; int32_t seq; int32_t pad[15]; };
     PassReport* h_report = nullptr;
@@ -1129,6 +1130,10 @@ struct Solver {
         bp.dlt = d_dlt.p; bp.st = d_blk.p;
         bp.gblk = d_gblk.p; bp.vcol = cp.vcol; bp.dcol = d_dcolblk.p;
         bp.host_st = rep_st_dev; bp.host_seq = rep_seq_dev; bp.report_j = -1; bp.report_seq = 0;
+        if (std::getenv("ADELIE_HIP_GRP_PROFILE")) {
+            if (!d_grp_dbg.p) { d_grp_dbg.reserve(8); AHIP_CHECK(hipMemsetAsync(d_grp_dbg.p, 0, 8 * sizeof(int64_t), st)); }
+            bp.dbg = d_grp_dbg.p;
+        }
         const T* xm_c = intercept ? cur_xm : nullptr;
         int64_t iters = 0;
         int status = CD_OK;
@@ -1416,6 +1421,8 @@ struct Solver {
         while (1) {
             if (irls_it >= irls_max_iters) throw make_solver_error("Maximum IRLS iterations reached.");
             ++cnt.n_irls_iters;
+            Stopwatch sw_irls;
+            sw_irls.start();
             // :336-348
             T sums[4];
             launch_irls_prepare<T>(glm_kind, d_y.p, d_gw.p, d_eta.p, d_r.p, d_off.p, hmin, n, d_hess.p, d_irls_resid.p,
@@ -1472,7 +1479,11 @@ struct Solver {
                 sweep(d_v.p, d_g.p, d_vcol.p, nv, &d_sc.p->resid_sum, intercept ? d_irls_xm.p : nullptr);
             }
             const T pin_tol = tol * (loss_null - loss_full) / hess_sum; // :407
+            sync();
+            t_host[6] += sw_irls.elapsed(); // IRLS set-up of the iteration (weights, means, screen-derived quantities)
+            sw_irls.start();
             FitOut<T> po = pin_solve(lmda_adj, pin_tol, T(0), rsum, ym, d_irls_resid.p);
+            t_host[7] += sw_irls.elapsed(); // the weighted least-squares pin solve
             o.t_screen += po.t_screen;
             o.t_active += po.t_active;
             beta0 = po.intercept;
@@ -1700,6 +1711,11 @@ struct Solver {
     // pull the device-resident invariants back into the host mirrors that the result accessors expose
     void finalize() {
         t_sweep.collect(); t_gram.collect(); t_cd.collect(); t_axpy.collect(); t_step.collect();
+        if (d_grp_dbg.p) {
+            sync();
+            d_grp_dbg.download(cd_dbg, 8, st);
+            sync();
+        }
         if (std::getenv("ADELIE_HIP_DEBUG_GRAM")) {
             for (size_t i = 0; i < gram_shapes.size() && i < t_gram.each.size(); ++i) {
                 const double fl = 2.0 * double(n) * double(gram_shapes[i].first) * double(gram_shapes[i].second);

@@ -2,6 +2,10 @@
 import sys, os, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import adelie_amd as ad
+from adelie_amd import _abi
+import adelie_amd.state as S_
+_abi.S.update({f"t_host_phase{i}": 910 + i for i in range(8)})
+S_._TIMERS = list(S_._TIMERS) + [f"t_host_phase{i}" for i in range(8)]
 n, p = int(sys.argv[1]), int(sys.argv[2])
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 ee = bool(int(sys.argv[4])) if len(sys.argv) > 4 else True

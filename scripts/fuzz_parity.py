@@ -3,6 +3,7 @@ usage: python scripts/fuzz_parity.py [n_cases] [seed]"""
 import os, sys, time, numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+BIG = bool(os.environ.get("FUZZ_BIG"))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 import adelie_amd as ad
@@ -14,6 +15,8 @@ for case in range(N):
     rng = np.random.RandomState(seed0 * 1000 + case)
     n = int(rng.choice([37, 150, 513, 1200, 2049]))
     p = int(rng.choice([40, 130, 300, 777]))
+    if BIG:  # default engine thresholds, screen sets beyond 256 values
+        n = int(rng.choice([900, 2500, 4100])); p = int(rng.choice([1200, 2000]))
     fam = rng.choice(["gaussian", "gaussian", "binomial"])
     kind = rng.choice(["dense", "dense", "snp"])
     dtype = np.float64 if rng.uniform() < 0.75 else np.float32
@@ -33,6 +36,8 @@ for case in range(N):
     use_w = rng.uniform() < 0.5
     min_nv = int(rng.choice([1, 1, 64, 256]))
     bsz = rng.choice(["", "32", "64", "128"])
+    if BIG:
+        min_nv, bsz = 256, ""
     os.environ["ADELIE_HIP_CD_BLOCK_MIN_NV"] = str(min_nv)
     if bsz: os.environ["ADELIE_HIP_PANEL_BSZ"] = bsz
     else: os.environ.pop("ADELIE_HIP_PANEL_BSZ", None)
@@ -57,7 +62,7 @@ for case in range(N):
         glm = lambda: ad.glm.binomial(y, weights=w, dtype=dtype)
     f32 = dtype == np.float32
     kw = dict(groups=groups, alpha=alpha, intercept=intercept, early_exit=False, lmda_path_size=int(rng.choice([8, 15])),
-              min_ratio=float(rng.choice([0.3, 0.05])), tol=1e-7 if f32 else 1e-13)
+              min_ratio=float(rng.choice([0.3, 0.05])) if not BIG else 0.02, tol=1e-7 if f32 else 1e-13)
     kw["max_iters"] = 4000  # p >> n cases can take 1e5 passes at tol 1e-13; both sides must then report the same error
     if fam == "binomial":
         kw["irls_tol"] = 1e-6 if f32 else 1e-10

@@ -90,6 +90,7 @@ struct adelie_hip_design {
     uint8_t* bits = nullptr;
     int64_t ldb = 0;
     void* impute = nullptr; // (p,) value_t on device
+    bool alias = false;     // shares X / bits / impute with another design (adelie_hip_design_alias): never frees them
     hipStream_t stream = nullptr;
     // scratch for the host-vector matrix ops (value_t typed, grow-only)
     ahip::DevBuf<char> s_n1, s_n2, s_p1, s_work, s_misc, s_idx1, s_idx2;

@@ -431,6 +431,22 @@ int adelie_hip_design_create_snp_bed(const void* bed, int64_t n_bytes, int64_t n
     ABI_CATCH
 }
 
+int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out) {
+    ABI_TRY
+    if (!src || !out) throw make_core_error("null argument.");
+    adelie_hip_design* d = new_design(src->n, src->p, src->dtype, src->device); // own stream, own scratch
+    d->kind = src->kind;
+    d->X = src->X;
+    d->ld = src->ld;
+    d->owned = false;
+    d->bits = src->bits;
+    d->ldb = src->ldb;
+    d->impute = src->impute;
+    d->alias = true;
+    *out = d;
+    ABI_CATCH
+}
+
 int adelie_hip_design_impute(adelie_hip_design* d, double* out) {
     ABI_TRY
     if (!d || !out) throw make_core_error("null argument.");
@@ -453,9 +469,9 @@ int adelie_hip_design_destroy(adelie_hip_design* d) {
         (void)hipStreamSynchronize(d->stream);
         (void)hipStreamDestroy(d->stream);
     }
-    if (d->owned && d->X) (void)hipFree(d->X);
-    if (d->bits) (void)hipFree(d->bits);
-    if (d->impute) (void)hipFree(d->impute);
+    if (d->owned && d->X && !d->alias) (void)hipFree(d->X);
+    if (d->bits && !d->alias) (void)hipFree(d->bits);
+    if (d->impute && !d->alias) (void)hipFree(d->impute);
     delete d;
     return 0;
 }

@@ -86,12 +86,17 @@ def _fold_loss(X, glm, fold_idx, full_lmdas, *, n_threads, early_exit, min_ratio
 
 
 def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio: float = 1e-1,
-              lmda_path_size: int = 100, n_folds: int = 5, seed: int = None, process_group=None, **grpnet_params):
+              lmda_path_size: int = 100, n_folds: int = 5, seed: int = None, process_group=None, n_concurrent: int = None,
+              **grpnet_params):
     """Cross-validated group elastic net (reference ``adelie.cv.cv_grpnet``; same arguments and defaults).
 
     ``process_group``: optional ``torch.distributed`` group (or ``True`` for the default group).  When given,
     fold ``k`` is solved by rank ``k % world_size`` and the per-fold loss rows are all-gathered; every rank
     returns the same ``CVGrpnetResult``.  Every rank must pass the same data and seed.
+
+    ``n_concurrent``: folds solved at the same time on this rank's GPU, each from its own host thread on its own HIP stream
+    (an alias handle of the resident design).  One path keeps most of the chip idle while its sequential block solves run,
+    so two or three folds interleave well; default 3 for device designs, 1 otherwise.  The result does not depend on it.
     """
     if isinstance(X, np.ndarray):
         X = matrix.dense(X, method="naive", n_threads=n_threads)
@@ -116,12 +121,38 @@ def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio
         full_lmdas = state.lmda_max * np.logspace(0, np.log10(min_ratio), lmda_path_size)
 
         cv_losses = np.zeros((n_folds, full_lmdas.shape[0]))
-        for fold, (b, e) in enumerate(fold_ranges(n, n_folds)):
-            if fold % world != rank:
-                continue
-            cv_losses[fold] = _fold_loss(
-                X, glm, order[b:e], full_lmdas, n_threads=n_threads, early_exit=early_exit, min_ratio=min_ratio,
-                lmda_path_size=lmda_path_size, grpnet_params=grpnet_params)
+        ranges = fold_ranges(n, n_folds)
+        my_folds = [fold for fold in range(n_folds) if fold % world == rank]
+        can_alias = hasattr(X, "alias") and hasattr(X, "_backend") and X._backend.has("design_alias")
+        nc = n_concurrent if n_concurrent is not None else (3 if can_alias else 1)
+        nc = max(1, min(int(nc), len(my_folds))) if can_alias else 1
+
+        def one(Xa, fold):
+            b, e = ranges[fold]
+            return _fold_loss(Xa, glm, order[b:e], full_lmdas, n_threads=n_threads, early_exit=early_exit,
+                              min_ratio=min_ratio, lmda_path_size=lmda_path_size, grpnet_params=grpnet_params)
+
+        if nc <= 1:
+            for fold in my_folds:
+                cv_losses[fold] = one(X, fold)
+        else:
+            import queue
+            from concurrent.futures import ThreadPoolExecutor
+
+            handles = queue.Queue()
+            for h in [X] + [X.alias() for _ in range(nc - 1)]:
+                handles.put(h)
+
+            def run(fold):
+                Xa = handles.get()
+                try:
+                    return fold, one(Xa, fold)
+                finally:
+                    handles.put(Xa)
+
+            with ThreadPoolExecutor(max_workers=nc) as pool:
+                for fold, row in pool.map(run, my_folds):
+                    cv_losses[fold] = row
     finally:
         logger.setLevel(logger_level)
 

@@ -103,6 +103,15 @@ class _NativeMatrix:
             *[v.ctypes.data for v in vecs], out.ctypes.data))
         return out[:L], out[L:]
 
+    def alias(self):
+        """A second handle on the same resident matrix with its own stream (``adelie_hip_design_alias``): lets independent
+        solves run concurrently from different threads.  Keeps this design alive."""
+        handle = _abi.C.c_void_p()
+        self._backend.check(self._backend.fn("design_alias")(self._handle, handle))
+        out = _wrap(self._backend, handle, self.dtype, self._n_threads)
+        out._alias_of = self
+        return out
+
     def impute(self):
         """The ``(p,)`` impute values of an SNP design (what a missing call contributes)."""
         out = np.empty(self._cols, dtype=np.float64)

@@ -72,15 +72,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # test hooks (one-GPU boxes): BENCH_BACKEND=gloo + BENCH_DEVICE=0 run several ranks on one device to exercise the
+    # multi-rank logic; the driver's multi-GPU runs use the defaults (RCCL, one device per rank)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    dev_index = int(os.environ.get("BENCH_DEVICE", local_rank))
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
     else:
-        torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    comm_device = device if backend == "nccl" else torch.device("cpu")
     tdtype = torch.float64 if args.dtype == "f64" else torch.float32
     npdtype = np.float64 if args.dtype == "f64" else np.float32
     n, p = args.n, args.p
@@ -127,11 +135,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=comm_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the fold gather of cv_grpnet: one small all_gather of the per-lambda rows
-        row = torch.from_numpy(np.asarray(state.devs, dtype=np.float64)).to(device)
+        row = torch.from_numpy(np.asarray(state.devs, dtype=np.float64)).to(comm_device)
         rows = [torch.empty_like(row) for _ in range(world)]
         dist.all_gather(rows, row)
     assert state.error == "", state.error

@@ -84,6 +84,10 @@ int adelie_hip_design_create_snp_calldata(const int8_t* calldata, int64_t n, int
  * adelie.io.snp_unphased in a genotype pipeline; both are 2 bits per call, so the record is transcoded on the device. */
 int adelie_hip_design_create_snp_bed(const void* bed, int64_t n_bytes, int64_t n, int64_t p, int dtype, int device,
                                      adelie_hip_design** out);
+/* A second handle on the same resident matrix with its own HIP stream and scratch space, so that independent solves
+ * (the folds of cv_grpnet) can run concurrently from different host threads: one path leaves most of the chip idle
+ * while its sequential block solves run, two or three paths interleave.  The alias must be destroyed before `src`. */
+int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out);
 /* Copies the (p,) impute vector of an SNP design (as double). */
 int adelie_hip_design_impute(adelie_hip_design* d, double* out);
 int adelie_hip_design_destroy(adelie_hip_design* d);

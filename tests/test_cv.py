@@ -83,3 +83,30 @@ def test_cv_on_device_matches_oracle(hip, oracle):
     assert np.allclose(a.lmdas, b.lmdas, rtol=1e-10)
     assert np.abs(a.losses - b.losses).max() < 1e-7
     assert a.best_idx == b.best_idx
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["dense", "snp"])
+def test_cv_concurrent_folds_on_alias_handles(hip, kind):
+    """Folds solved concurrently from host threads on alias handles of the resident design (own HIP stream each) give
+    bit-identical loss tables; an alias is the same matrix."""
+    rng = np.random.RandomState(2)
+    n, p = 900, 120
+    if kind == "dense":
+        X = ad.matrix.dense(np.asfortranarray(rng.normal(size=(n, p))))
+    else:
+        cd = rng.choice(np.array([0, 1, 2, -9], dtype=np.int8), size=(n, p), p=[0.6, 0.2, 0.1, 0.1])
+        X = ad.matrix.snp_calldata(cd)
+    Xa = X.alias()
+    v = rng.normal(size=n)
+    np.testing.assert_array_equal(X.T @ v, Xa.T @ v)
+    y = (X @ (rng.normal(size=p) * (rng.uniform(size=p) < 0.1))) + rng.normal(size=n)
+    glm = ad.glm.gaussian(y)
+    kw = dict(n_folds=6, seed=5, lmda_path_size=20, tol=1e-10)
+    a = ad.cv_grpnet(X, glm, n_concurrent=1, **kw)
+    b = ad.cv_grpnet(X, glm, n_concurrent=3, **kw)
+    c = ad.cv_grpnet(X, glm, **kw)  # default concurrency
+    np.testing.assert_array_equal(a.losses, b.losses)
+    np.testing.assert_array_equal(a.losses, c.losses)
+    assert a.best_idx == b.best_idx
+    del Xa

@@ -18,6 +18,9 @@
  * The algorithm is the reference's *naive* method verbatim: per-visit gradients from the residual
  * (X.cmul / X.bmul), residual updates (X.ctmul / X.btmul), same visiting order, same tolerances,
  * same screening rule, same IRLS wrapper.  No Eigen: small dense linear algebra is written out.
+ * Two deliberate deviations, both mirrored by the product: exact ties in the pivot-rule sort are
+ * broken by group index, and screen() carries a progress guard for a rounding mismatch between the KKT check and the
+ * screening fallback on which the reference's BASIL loop does not terminate.
  */
 #include "../include/adelie_hip.h"
 

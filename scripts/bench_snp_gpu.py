@@ -38,6 +38,9 @@ torch.cuda.synchronize()
 print("gen %.1fs  nnz(beta)=%d" % (time.perf_counter() - t0, int((beta != 0).sum())), flush=True)
 t0 = time.perf_counter()
 X = ad.matrix.snp_calldata(cd, imp.cpu().numpy())
+cpu_budget = float(os.environ.get("SNP_CPU_BUDGET", "0"))
+cd_host = np.asfortranarray(cd.cpu().numpy()) if cpu_budget > 0 else None
+imp_host = imp.cpu().numpy()
 del cdt, cd, valid
 torch.cuda.empty_cache()
 print("pack %.2fs" % (time.perf_counter() - t0), flush=True)
@@ -49,3 +52,18 @@ for rep in range(2):
     el = time.perf_counter() - t0
     print("path %.2fs  nsol %d err %r dev %.4f active %d screen %d" % (el, len(st.lmdas), st.error, st.devs[-1] if len(st.devs) else -1, st.active_set_size, len(st.screen_set)), flush=True)
     print("  ", {k: round(v, 1) for k, v in st.timers.items()}, {k: st.counters[k] for k in ["n_irls_iters", "n_updates", "n_cd_passes_screen", "n_cd_passes_active", "n_panel_blocks", "n_panel_grams", "n_sweeps"]}, flush=True)
+
+if cpu_budget > 0:
+    # the CPU oracle (16 threads) on the same calldata, bounded by a time budget: rate on the solved prefix
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import oracle
+    os.environ["ORACLE_COL_THREADS"] = "16"
+    Xo = oracle.snp_calldata(cd_host, imp_host, n_threads=16)
+    t0 = time.perf_counter()
+    so = ad.grpnet(Xo, ad.glm.binomial(y), early_exit=ee, lmda_path_size=L, n_threads=16,
+                   exit_cond=lambda view: (time.perf_counter() - t0) > cpu_budget)
+    elc = time.perf_counter() - t0
+    k = len(so.lmdas)
+    db = float(np.abs(so.betas.toarray() - st.betas[:k].toarray()).max()) if k else float("nan")
+    print("cpu oracle: %d lambdas in %.1f s (16 threads); GPU needed %.3f s for the same prefix?; max|dbeta| vs GPU on the prefix %.2e" % (k, elc, float("nan"), db))
+    print("cpu irls iters", so.counters["n_irls_iters"], "updates", so.counters["n_updates"])

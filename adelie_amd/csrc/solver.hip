@@ -962,6 +962,7 @@ struct Solver {
                 launch_cd_panel_solve<T>(bp, j, st);
             }
             t_cd.end(st);
+            AHIP_CHECK(hipGetLastError()); // a failed launch would otherwise only show up as a stalled pass report
             cnt.n_panel_blocks += nblk;
             wait_pass_state(bs);
             status = bs.status;
@@ -1192,6 +1193,7 @@ struct Solver {
                 launch_cd_group_panel_solve<T>(bp, j, st);
             }
             t_cd.end(st);
+            AHIP_CHECK(hipGetLastError()); // a failed launch would otherwise only show up as a stalled pass report
             cnt.n_panel_blocks += nblk;
             wait_pass_state(bs);
             status = bs.status;

@@ -80,7 +80,7 @@ int adelie_hip_design_create_snp_calldata(const int8_t* calldata, int64_t n, int
 /* Same device layout straight from a PLINK 1 `.bed` image (SNP-major: magic 6c 1b 01, then p records of ceil(n/4)
  * bytes, 2 bits per sample, low bits first: 00 = two copies of allele A1, 10 = one, 11 = none, 01 = missing).  Calls become
  * A1 counts; missing calls are imputed with the column mean of the non-missing ones (the reference's default,
- * io/utils.hpp:10-31).  `bed` may be host or device memory.  SURVEY.md 8(f) rank 2: the on-disk format upstream of
+ * io/utils.hpp:10-31).  `bed` is host memory (the header is validated on the host).  SURVEY.md 8(f) rank 2: the on-disk format upstream of
  * adelie.io.snp_unphased in a genotype pipeline; both are 2 bits per call, so the record is transcoded on the device. */
 int adelie_hip_design_create_snp_bed(const void* bed, int64_t n_bytes, int64_t n, int64_t p, int dtype, int device,
                                      adelie_hip_design** out);

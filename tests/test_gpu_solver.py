@@ -322,3 +322,30 @@ def test_group_panel_binomial(hip, oracle, monkeypatch):
     b = ad.grpnet(oracle.dense(X), ad.glm.binomial(y), **kw)
     assert a.counters["n_panel_blocks"] > 0
     assert_same_path(a, b, 1e-6)
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+@pytest.mark.parametrize("family", ["gaussian", "binomial"])
+def test_warm_start_on_panel_engine(hip, oracle, monkeypatch, grouped, family):
+    """Warm restart (tests/test_solver.py:633-649) with the panel engine active from the first fit: the solver starts from
+    a non-empty screen / active set, so every screen-derived quantity and diagonal block is built for pre-existing groups."""
+    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    d = make_gaussian(700, 360, seed=31, sparsity=0.8, weights=True)
+    groups = np.arange(0, 360, 4) if grouped else np.arange(360)
+    if family == "gaussian":
+        glm = lambda: ad.glm.gaussian(d["y"], weights=d["weights"])
+    else:
+        yb = (d["y"] > np.median(d["y"])).astype(np.float64)
+        glm = lambda: ad.glm.binomial(yb, weights=d["weights"])
+    Xg, Xo = ad.matrix.dense(d["X"]), oracle.dense(d["X"])
+    kw = dict(groups=groups, tol=1e-13, early_exit=False)
+    if family == "binomial":
+        kw["irls_tol"] = 1e-10
+    s1g = ad.grpnet(Xg, glm(), lmda_path_size=10, min_ratio=0.4, **kw)
+    s1o = ad.grpnet(Xo, glm(), lmda_path_size=10, min_ratio=0.4, **kw)
+    assert s1g.active_set_size > 0
+    nxt = [s1o.lmdas[-1] * 0.8, s1o.lmdas[-1] * 0.6, s1o.lmdas[-1] * 0.45]
+    s2g = ad.grpnet(Xg, glm(), lmda_path=nxt, warm_start=s1g, **kw)
+    s2o = ad.grpnet(Xo, glm(), lmda_path=nxt, warm_start=s1o, **kw)
+    assert s2g.counters["n_panel_blocks"] > 0
+    assert_same_path(s2g, s2o, 1e-6)

@@ -241,71 +241,142 @@ __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int
                 }
             }
             const T* A = AB + o;
-            // gk_t = gk V ; ak_old_t = ak_old V ; gk_t += A * ak_old_t   (pin_naive:123-140)
-            for (int jj = lane; jj < q; jj += 64) {
-                T s1 = 0, s2 = 0;
-                const T* Vj = V + int64_t(jj) * q;
-#pragma unroll 4
-                for (int i = 0; i < q; ++i) {
-                    s1 = fma(gB[o + i], Vj[i], s1);
-                    s2 = fma(bB[o + i], Vj[i], s2);
-                }
-                ak_old_t[jj] = s2;
-                gk_t[jj] = s1 + A[jj] * s2;
-            }
-            __builtin_amdgcn_wave_barrier();
-            GP_MARK(1) /* rotation */
-            // newton_solver (bcd/unconstrained/newton.hpp:35-142): v = gk_t, L = A
-            T nrm2 = 0;
-            for (int i = lane; i < q; i += 64) nrm2 = fma(gk_t[i], gk_t[i], nrm2);
-            nrm2 = group_sum(nrm2, q);
-            if (sqrt(nrm2) <= l1p) {
-                for (int i = lane; i < q; i += 64) ak_t[i] = 0;
-            } else if (l1p <= T(0)) {
-                for (int i = lane; i < q; i += 64) ak_t[i] = gk_t[i] / (A[i] + l2p);
-            } else {
-                for (int i = lane; i < q; i += 64) buf1[i] = A[i] + l2p;
-                T h = 0, fh, dfh;
-                auto step = [&](T hh) {
-                    T t = 0, s = 0;
-                    for (int i = lane; i < q; i += 64) {
-                        const T b2 = T(1) / (buf1[i] * hh + l1p);
-                        const T z = gk_t[i] * b2;
-                        const T x = z * z;
-                        buf2[i] = b2;
-                        t += x;
-                        s += x * buf1[i] * b2;
-                    }
-                    t = group_sum(t, q);
-                    s = group_sum(s, q);
-                    fh = t - T(1);
-                    dfh = -s * (T(1) + sqrt(t)) / t;
-                };
-                step(h);
-                int iters = 0;
-                while ((fabs(fh) > p.newton_tol) && (iters < p.newton_max_iters)) {
-                    h -= fh / dfh;
-                    h = h > T(0) ? h : T(0);
-                    step(h);
-                    ++iters;
-                }
-                for (int i = lane; i < q; i += 64) ak_t[i] = h * gk_t[i] * buf2[i];
-                if (iters >= p.newton_max_iters) { status = CD_NEWTON; break; }
-            }
-            __builtin_amdgcn_wave_barrier();
-            GP_MARK(2) /* norm + newton */
-            // changed? ; convergence / rsq in rotated coordinates (pin_naive:144-154)
             T dn = 0, c1 = 0, rs = 0;
-            for (int i = lane; i < q; i += 64) {
-                const T gg = gk_t[i] - A[i] * ak_old_t[i];
-                const T d = ak_t[i] - ak_old_t[i];
-                dn = fma(d, d, dn);
-                c1 = fma(A[i] * d, d, c1);
-                rs += d * (T(2) * gg - d * A[i]);
+            if (q <= 64) {
+                // One element per lane: the group's rotated vectors stay in registers from the rotation to the change test
+                // (same operations in the same order as the general path below, so the results are bit-identical; only the
+                // LDS round trips between the phases are gone).
+                const bool on = lane < q;
+                const T A_r = on ? A[lane] : T(0);
+                T gk_r = T(0), ako_r = T(0);
+                if (on) { // gk_t = gk V ; ak_old_t = ak_old V ; gk_t += A * ak_old_t   (pin_naive:123-140)
+                    T s1 = 0, s2 = 0;
+                    const T* Vj = V + int64_t(lane) * q;
+#pragma unroll 4
+                    for (int i = 0; i < q; ++i) {
+                        s1 = fma(gB[o + i], Vj[i], s1);
+                        s2 = fma(bB[o + i], Vj[i], s2);
+                    }
+                    ako_r = s2;
+                    gk_r = s1 + A_r * s2;
+                }
+                GP_MARK(1) /* rotation */
+                // newton_solver (bcd/unconstrained/newton.hpp:35-142): v = gk_t, L = A
+                const T nrm2 = group_sum(on ? gk_r * gk_r : T(0), q);
+                T akt_r = T(0);
+                if (sqrt(nrm2) <= l1p) {
+                    akt_r = T(0);
+                } else if (l1p <= T(0)) {
+                    akt_r = on ? gk_r / (A_r + l2p) : T(0);
+                } else {
+                    const T b1 = A_r + l2p;
+                    T h = 0, fh, dfh, b2 = T(0);
+                    auto step = [&](T hh) {
+                        T t = 0, sx = 0;
+                        if (on) {
+                            b2 = T(1) / (b1 * hh + l1p);
+                            const T z = gk_r * b2;
+                            const T x = z * z;
+                            t = x;
+                            sx = x * b1 * b2;
+                        }
+                        t = group_sum(t, q);
+                        sx = group_sum(sx, q);
+                        fh = t - T(1);
+                        dfh = -sx * (T(1) + sqrt(t)) / t;
+                    };
+                    step(h);
+                    int iters = 0;
+                    while ((fabs(fh) > p.newton_tol) && (iters < p.newton_max_iters)) {
+                        h -= fh / dfh;
+                        h = h > T(0) ? h : T(0);
+                        step(h);
+                        ++iters;
+                    }
+                    akt_r = on ? h * gk_r * b2 : T(0);
+                    if (iters >= p.newton_max_iters) { status = CD_NEWTON; break; }
+                }
+                if (on) ak_t[lane] = akt_r; // read by every lane in the back rotation
+                __builtin_amdgcn_wave_barrier();
+                GP_MARK(2) /* norm + newton */
+                // changed? ; convergence / rsq in rotated coordinates (pin_naive:144-154)
+                if (on) {
+                    const T gg = gk_r - A_r * ako_r;
+                    const T d = akt_r - ako_r;
+                    dn = d * d;
+                    c1 = (A_r * d) * d;
+                    rs = d * (T(2) * gg - d * A_r);
+                }
+                dn = group_sum(dn, q);
+                c1 = group_sum(c1, q);
+                rs = group_sum(rs, q);
+            } else {
+                const T* A = AB + o;
+                // gk_t = gk V ; ak_old_t = ak_old V ; gk_t += A * ak_old_t   (pin_naive:123-140)
+                for (int jj = lane; jj < q; jj += 64) {
+                    T s1 = 0, s2 = 0;
+                    const T* Vj = V + int64_t(jj) * q;
+#pragma unroll 4
+                    for (int i = 0; i < q; ++i) {
+                        s1 = fma(gB[o + i], Vj[i], s1);
+                        s2 = fma(bB[o + i], Vj[i], s2);
+                    }
+                    ak_old_t[jj] = s2;
+                    gk_t[jj] = s1 + A[jj] * s2;
+                }
+                __builtin_amdgcn_wave_barrier();
+                GP_MARK(1) /* rotation */
+                // newton_solver (bcd/unconstrained/newton.hpp:35-142): v = gk_t, L = A
+                T nrm2 = 0;
+                for (int i = lane; i < q; i += 64) nrm2 = fma(gk_t[i], gk_t[i], nrm2);
+                nrm2 = group_sum(nrm2, q);
+                if (sqrt(nrm2) <= l1p) {
+                    for (int i = lane; i < q; i += 64) ak_t[i] = 0;
+                } else if (l1p <= T(0)) {
+                    for (int i = lane; i < q; i += 64) ak_t[i] = gk_t[i] / (A[i] + l2p);
+                } else {
+                    for (int i = lane; i < q; i += 64) buf1[i] = A[i] + l2p;
+                    T h = 0, fh, dfh;
+                    auto step = [&](T hh) {
+                        T t = 0, s = 0;
+                        for (int i = lane; i < q; i += 64) {
+                            const T b2 = T(1) / (buf1[i] * hh + l1p);
+                            const T z = gk_t[i] * b2;
+                            const T x = z * z;
+                            buf2[i] = b2;
+                            t += x;
+                            s += x * buf1[i] * b2;
+                        }
+                        t = group_sum(t, q);
+                        s = group_sum(s, q);
+                        fh = t - T(1);
+                        dfh = -s * (T(1) + sqrt(t)) / t;
+                    };
+                    step(h);
+                    int iters = 0;
+                    while ((fabs(fh) > p.newton_tol) && (iters < p.newton_max_iters)) {
+                        h -= fh / dfh;
+                        h = h > T(0) ? h : T(0);
+                        step(h);
+                        ++iters;
+                    }
+                    for (int i = lane; i < q; i += 64) ak_t[i] = h * gk_t[i] * buf2[i];
+                    if (iters >= p.newton_max_iters) { status = CD_NEWTON; break; }
+                }
+                __builtin_amdgcn_wave_barrier();
+                GP_MARK(2) /* norm + newton */
+                // changed? ; convergence / rsq in rotated coordinates (pin_naive:144-154)
+                for (int i = lane; i < q; i += 64) {
+                    const T gg = gk_t[i] - A[i] * ak_old_t[i];
+                    const T d = ak_t[i] - ak_old_t[i];
+                    dn = fma(d, d, dn);
+                    c1 = fma(A[i] * d, d, c1);
+                    rs += d * (T(2) * gg - d * A[i]);
+                }
+                dn = group_sum(dn, q);
+                c1 = group_sum(c1, q);
+                rs = group_sum(rs, q);
             }
-            dn = group_sum(dn, q);
-            c1 = group_sum(c1, q);
-            rs = group_sum(rs, q);
             if (!(sqrt(dn) <= p.dbeta_tol * sqrt(T(q)))) {
                 changed = true;
                 c1 /= T(q);

@@ -253,6 +253,53 @@ struct Solver {
     DevBuf<T> d_Dpool, d_part, d_gblk;
     DevBuf<int32_t> d_actcols, d_dcolblk;
     DevBuf<int64_t> d_grp_dbg;
+    // Side stream for the diagonal-block builds of a pass: they only depend on the weights, so all stale blocks of a pass are
+    // enqueued there up front and the MFMA work overlaps the HBM-bound steps / single-wave solves of the main chain, which
+    // waits on a per-block event right before the block's solve.
+    hipStream_t st2 = nullptr;
+    bool side_grams = true;
+    DevBuf<T> d_work_gram2;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    hipEvent_t next_event() {
+        if (ev_used == ev_pool.size()) {
+            hipEvent_t e;
+            AHIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ev_pool.push_back(e);
+        }
+        return ev_pool[ev_used++];
+    }
+    std::vector<hipEvent_t> blk_ev; // per block of the current pass: event of its build on the side stream (or nullptr)
+    // Builds the stale blocks among `nblk` blocks of a pass; block j has nb_of(j) members and columns cols_of(j).
+    template <class NbOf, class ColsOf>
+    void build_stale_blocks(int nblk, std::vector<int32_t>& tab_nb, std::vector<uint64_t>& tab_ver, T* pool, NbOf nb_of,
+                            ColsOf cols_of) {
+        const int SL = cd_block_size();
+        blk_ev.assign(size_t(nblk), nullptr);
+        ev_used = 0;
+        bool first = true;
+        for (int j = 0; j < nblk; ++j) {
+            const int nb = nb_of(j);
+            if (tab_nb[j] == nb && tab_ver[j] == w_version) continue;
+            T* Dptr = pool + size_t(j) * SL * SL;
+            const bool side = side_grams && st2 != nullptr;
+            if (side && first) { // the weights (and everything else the builds read) are final at this point of the main stream
+                hipEvent_t e0 = next_event();
+                AHIP_CHECK(hipEventRecord(e0, st));
+                AHIP_CHECK(hipStreamWaitEvent(st2, e0, 0));
+                first = false;
+            }
+            gram_block(cur_w, cols_of(j), nb, cur_xm, Dptr, side);
+            if (side) {
+                hipEvent_t e = next_event();
+                AHIP_CHECK(hipEventRecord(e, st2));
+                blk_ev[size_t(j)] = e;
+            }
+            tab_nb[j] = nb;
+            tab_ver[j] = w_version;
+            ++cnt.n_panel_grams;
+        }
+    }
     // host-mapped end-of-pass report (state + sequence number), see CdBlkParams::host_st
     struct PassReport { CdBlkState<T> st; int32_t seq; int32_t pad[15]; };
     PassReport* h_report = nullptr;
@@ -260,6 +307,11 @@ struct Solver {
     bool use_report = true;
     ~Solver() {
         if (h_report) (void)hipHostFree(h_report);
+        if (st2) {
+            (void)hipStreamSynchronize(st2);
+            (void)hipStreamDestroy(st2);
+        }
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     }
     std::vector<int32_t> dscr_nb, dact_nb;      // cached block: number of members it was built for
     std::vector<uint64_t> dscr_ver, dact_ver;   // ... and the weight version
@@ -291,16 +343,17 @@ struct Solver {
                                         d_part.p, st);
     }
     // B x B block  X_cols^T W X_cols - xm xm^T  into Dptr (ld = B)
-    void gram_block(const T* w, const int32_t* cols, int nb, const T* xm, T* Dptr) {
+    void gram_block(const T* w, const int32_t* cols, int nb, const T* xm, T* Dptr, bool side = false) {
         const int B = cd_block_size();
-        t_gram.begin(st);
+        hipStream_t gs = side ? st2 : st;
+        t_gram.begin(gs);
         {   // lower-triangle MFMA tiles only: 10 of 16 (nb <= 64) or 36 of 64
-            T* work = d_work_gram.reserve(size_t(syrk_work_elems(n, nb)));
-            if (dense()) launch_syrk<T>(D->dense<T>(), w, cols, nb, xm, intercept, Dptr, B, work, st);
-            else launch_syrk_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols, nb, xm, intercept, Dptr, B, work, st);
+            T* work = (side ? d_work_gram2 : d_work_gram).reserve(size_t(syrk_work_elems(n, 128)));
+            if (dense()) launch_syrk<T>(D->dense<T>(), w, cols, nb, xm, intercept, Dptr, B, work, gs);
+            else launch_syrk_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols, nb, xm, intercept, Dptr, B, work, gs);
             cnt.gram_flops += 2.0 * double(n) * 256.0 * (nb <= 64 ? 10.0 : 36.0);
         }
-        t_gram.end(st);
+        t_gram.end(gs);
         cnt.n_gram_col_reads += 2 * nb;
     }
     void axpy_cols(const int32_t* cols, const T* coef, const int32_t* cnt_dev, int32_t count, T sign, T* out) {
@@ -852,6 +905,7 @@ struct Solver {
             dscr_ver.assign(maxblk, 0); dact_ver.assign(maxblk, 0);
             panel_maxblk = maxblk;
         }
+        if (side_grams && !st2) AHIP_CHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
         if (use_report && !h_report) {
             void* hp = nullptr;
             void* dp = nullptr;
@@ -934,19 +988,13 @@ struct Solver {
             bp.count = count;
             bp.mark = screen_pass ? 1 : 0;
             const int nblk = (count + B - 1) / B;
+            build_stale_blocks(nblk, tab_nb, tab_ver, pool, [&](int j) { return std::min(B, count - j * B); },
+                               [&](int j) { return cols_all + size_t(j) * B; });
             t_cd.begin(st);
             for (int j = 0; j < nblk; ++j) {
                 const int nb = std::min(B, count - j * B);
                 const int32_t* cols = cols_all + size_t(j) * B;
                 T* Dptr = pool + size_t(j) * SL * SL;
-                if (tab_nb[j] != nb || tab_ver[j] != w_version) {
-                    t_cd.end(st);
-                    gram_block(cur_w, cols, nb, cur_xm, Dptr);
-                    t_cd.begin(st);
-                    tab_nb[j] = nb;
-                    tab_ver[j] = w_version;
-                    ++cnt.n_panel_grams;
-                }
                 if (time_panel) t_step.begin(st);
                 const int nsl = panel_step(cur_w, r_dev, d_dcolblk.p, d_dlt.p, &d_blk.p->nz, cols, nb);
                 if (time_panel) t_step.end(st);
@@ -959,6 +1007,7 @@ struct Solver {
                 } else {
                     bp.report_j = -1;
                 }
+                if (blk_ev[size_t(j)]) AHIP_CHECK(hipStreamWaitEvent(st, blk_ev[size_t(j)], 0));
                 launch_cd_panel_solve<T>(bp, j, st);
             }
             t_cd.end(st);
@@ -1165,19 +1214,13 @@ struct Solver {
             bp.list = screen_pass ? nullptr : cp.active_set;
             bp.nblk = nblk;
             bp.mark = screen_pass ? 1 : 0;
+            build_stale_blocks(nblk, tab_nb, tab_ver, pool, [&](int j) { return int(gp_vbeg[size_t(j) + 1] - gp_vbeg[j]); },
+                               [&](int j) { return cols_all + gp_vbeg[j]; });
             t_cd.begin(st);
             for (int j = 0; j < nblk; ++j) {
                 const int nval = gp_vbeg[size_t(j) + 1] - gp_vbeg[j];
                 const int32_t* cols = cols_all + gp_vbeg[j];
                 T* Dptr = pool + size_t(j) * SL * SL;
-                if (tab_nb[j] != nval || tab_ver[j] != w_version) {
-                    t_cd.end(st);
-                    gram_block(cur_w, cols, nval, cur_xm, Dptr);
-                    t_cd.begin(st);
-                    tab_nb[j] = nval;
-                    tab_ver[j] = w_version;
-                    ++cnt.n_panel_grams;
-                }
                 if (time_panel) t_step.begin(st);
                 const int nsl = panel_step(cur_w, r_dev, d_dcolblk.p, d_dlt.p, &d_blk.p->nz, cols, nval);
                 if (time_panel) t_step.end(st);
@@ -1190,6 +1233,7 @@ struct Solver {
                 } else {
                     bp.report_j = -1;
                 }
+                if (blk_ev[size_t(j)]) AHIP_CHECK(hipStreamWaitEvent(st, blk_ev[size_t(j)], 0));
                 launch_cd_group_panel_solve<T>(bp, j, st);
             }
             t_cd.end(st);
@@ -1838,6 +1882,7 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_CD_ENGINE")) engine_panel = std::string(e) != "gram"; // A/B hook
         time_panel = std::getenv("ADELIE_HIP_TIME_PANEL") != nullptr;
         if (const char* e = std::getenv("ADELIE_HIP_PASS_REPORT")) use_report = std::atoi(e) != 0; // A/B hook
+        if (const char* e = std::getenv("ADELIE_HIP_SIDE_GRAMS")) side_grams = std::atoi(e) != 0; // A/B hook
         if (const char* e = std::getenv("ADELIE_HIP_PRELAUNCH_SWEEP")) prelaunch_sweep = std::atoi(e) != 0; // A/B hook
         if (const char* e = std::getenv("ADELIE_HIP_GROUP_PANEL")) group_panel = std::atoi(e) != 0; // A/B hook
         if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {

@@ -349,3 +349,35 @@ def test_warm_start_on_panel_engine(hip, oracle, monkeypatch, grouped, family):
     s2o = ad.grpnet(Xo, glm(), lmda_path=nxt, warm_start=s1o, **kw)
     assert s2g.counters["n_panel_blocks"] > 0
     assert_same_path(s2g, s2o, 1e-6)
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+def test_panel_engine_error_paths_match_oracle(hip, oracle, monkeypatch, grouped):
+    """max_active_size / max_iters / max_screen_size through the panel engine (scalar and group blocks): same error strings,
+    same partial paths, and the pre-fit state is restored (residual undone) exactly like the reference does
+    (solver_gaussian_naive.hpp:286-290,326-329)."""
+    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    d = make_gaussian(600, 280, seed=41, sparsity=0.6, weights=True)
+    groups = np.arange(0, 280, 5) if grouped else np.arange(280)
+    glm = lambda: ad.glm.gaussian(d["y"], weights=d["weights"])
+    Xg, Xo = ad.matrix.dense(d["X"]), oracle.dense(d["X"])
+    base = dict(groups=groups, early_exit=False, lmda_path_size=20, min_ratio=0.05, tol=1e-12)
+    for extra in [dict(max_active_size=7), dict(max_iters=6), dict(max_screen_size=9)]:
+        a = ad.grpnet(Xg, glm(), **base, **extra)
+        b = ad.grpnet(Xo, glm(), **base, **extra)
+        assert a.error == b.error and a.error != "", (extra, a.error, b.error)
+        assert len(a.lmdas) == len(b.lmdas), extra
+        if len(a.lmdas):
+            assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-6
+        # invariants of the returned (rolled back) state
+        np.testing.assert_allclose(a.resid, b.resid, atol=1e-8)
+        np.testing.assert_allclose(a.screen_beta[:len(b.screen_beta)], b.screen_beta, atol=1e-8)
+        assert abs(a.rsq - b.rsq) < 1e-8 and a.active_set_size == b.active_set_size
+
+
+def test_exit_cond_on_panel_engine(hip, monkeypatch):
+    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    d = make_gaussian(500, 200, seed=43, sparsity=0.7)
+    st = ad.grpnet(ad.matrix.dense(d["X"]), ad.glm.gaussian(d["y"]), early_exit=False, lmda_path_size=30,
+                   exit_cond=lambda s: s.n_solutions >= 9)
+    assert st.error == "" and len(st.lmdas) == 9 and st.counters["n_panel_blocks"] > 0

@@ -9,8 +9,8 @@ int main(int argc, char** argv) {
     const int64_t n = argc > 1 ? atoll(argv[1]) : 100000, p = argc > 2 ? atoll(argv[2]) : 4096, ld = argc > 3 ? atoll(argv[3]) : n;
     double* X; CK(hipMalloc(&X, ld * p * 8)); CK(hipMemset(X, 0, ld * p * 8));
     double *w, *r, *dlt, *part, *g, *work; int32_t *cols, *dcol, *nz;
-    CK(hipMalloc(&w, n * 8)); CK(hipMalloc(&r, n * 8)); CK(hipMalloc(&dlt, 128 * 8)); CK(hipMalloc(&g, 128 * 8));
-    CK(hipMalloc(&part, panel_part_elems(n) * 8)); CK(hipMalloc(&work, (sweep_work_elems(n, 1024) + 16) * 8));
+    CK(hipMalloc(&w, n * 8)); CK(hipMalloc(&r, n * 8)); CK(hipMalloc(&dlt, 128 * 8)); CK(hipMalloc(&g, (p + 128) * 8));
+    CK(hipMalloc(&part, panel_part_elems(n) * 8)); CK(hipMalloc(&work, (sweep_work_elems(n, p) + sweep_work_elems(n, 1024) + 16) * 8));
     CK(hipMalloc(&cols, 128 * 4)); CK(hipMalloc(&dcol, 128 * 4)); CK(hipMalloc(&nz, 4));
     CK(hipMemset(w, 0, n * 8)); CK(hipMemset(r, 0, n * 8)); CK(hipMemset(dlt, 0, 128 * 8));
     std::mt19937 rng(1);
@@ -63,6 +63,14 @@ int main(int argc, char** argv) {
             float ms; CK(hipEventElapsedTime(&ms, a, b)); if (it >= 3) tot += ms;
         }
         printf("sweep 1024 cols (0..1023): %.1f us  %.2f TB/s\n", 1e3 * tot / reps, 1024.0 * n * 8 / (tot / reps * 1e-3) / 1e12);
+        tot = 0;
+        for (int it = 0; it < 8; ++it) {
+            CK(hipEventRecord(a, s));
+            launch_sweep<double>(V, w, g, 0, p, nullptr, nullptr, nullptr, false, work, s);
+            CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b)); if (it >= 3) tot += ms;
+        }
+        printf("sweep ALL %lld cols: %.1f us  %.3f TB/s\n", (long long)p, 1e3 * tot / 5, double(p) * n * 8 / (tot / 5 * 1e-3) / 1e12);
     }
     {   // reuse: the (A) columns of a step are the (B) columns of the step before (as in a real pass)
         int nzv = 128; CK(hipMemcpy(nz, &nzv, 4, hipMemcpyHostToDevice));

@@ -215,6 +215,11 @@ __global__ void gram_reduce_kernel(const T* __restrict__ part, int nsplit, int64
 // SB = 128; the reduce kernel mirrors them), spread evenly over the four waves in runs that share fragments.
 // Grid = K-splits only.
 template <int W, int SB> struct SyrkPlan;
+// SB = 32: the three lower tiles of the 2x2 grid, one per wave (the fourth wave only helps staging)
+template <> struct SyrkPlan<0, 32> { static constexpr int N = 1; static constexpr int R[1] = {0}; static constexpr int C[1] = {0}; };
+template <> struct SyrkPlan<1, 32> { static constexpr int N = 1; static constexpr int R[1] = {1}; static constexpr int C[1] = {0}; };
+template <> struct SyrkPlan<2, 32> { static constexpr int N = 1; static constexpr int R[1] = {1}; static constexpr int C[1] = {1}; };
+template <> struct SyrkPlan<3, 32> { static constexpr int N = 0; static constexpr int R[1] = {0}; static constexpr int C[1] = {0}; };
 // SB = 64: 3 / 3 / 2 / 2 tiles
 template <> struct SyrkPlan<0, 64> { static constexpr int N = 3; static constexpr int R[3] = {0, 1, 1}; static constexpr int C[3] = {0, 0, 1}; };
 template <> struct SyrkPlan<1, 64> { static constexpr int N = 3; static constexpr int R[3] = {2, 2, 2}; static constexpr int C[3] = {0, 1, 2}; };
@@ -270,7 +275,7 @@ template <class T, class Acc, bool VECOK, int SB>
 __global__ __launch_bounds__(GT, 2) void syrk_kernel(Acc X, const T* __restrict__ w, const int32_t* __restrict__ cols,
                                                      int32_t M, int64_t n, int64_t kchunk, T* __restrict__ part) {
     constexpr int RA = KT * SB / GT; // rows of one column staged per thread (8 or 16)
-    constexpr int NA = SB == 64 ? 3 : 9;
+    constexpr int NA = SB == 32 ? 1 : (SB == 64 ? 3 : 9);
     __shared__ T As[SB * LDK];
     __shared__ T Ws[KT];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -333,10 +338,11 @@ void syrk_launch(Acc acc, bool vecok, const T* w, const int32_t* cols, int32_t M
     int nsplit;
     int64_t kchunk;
     syrk_shape(n, nsplit, kchunk);
-    const int64_t SB = M <= 64 ? 64 : 128;
+    const int64_t SB = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
 #define AHIP_SYRK(VOK, SBV) \
     hipLaunchKernelGGL((syrk_kernel<T, Acc, VOK, SBV>), dim3((unsigned)nsplit), dim3(GT), 0, s, acc, w, cols, M, n, kchunk, work)
-    if (M <= 64) { if (vecok) AHIP_SYRK(true, 64); else AHIP_SYRK(false, 64); }
+    if (M <= 32) { if (vecok) AHIP_SYRK(true, 32); else AHIP_SYRK(false, 32); }
+    else if (M <= 64) { if (vecok) AHIP_SYRK(true, 64); else AHIP_SYRK(false, 64); }
     else { if (vecok) AHIP_SYRK(true, 128); else AHIP_SYRK(false, 128); }
 #undef AHIP_SYRK
     hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3((unsigned)((M + 63) / 64), (unsigned)M), dim3(256), 0, s, work, nsplit, SB,
@@ -410,7 +416,7 @@ int64_t syrk_work_elems(int64_t n, int64_t M) {
     int nsplit;
     int64_t kchunk;
     syrk_shape(n, nsplit, kchunk);
-    const int64_t SB = M <= 64 ? 64 : 128;
+    const int64_t SB = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
     return int64_t(nsplit) * SB * SB;
 }
 template <class T>

@@ -351,7 +351,7 @@ struct Solver {
             T* work = (side ? d_work_gram2 : d_work_gram).reserve(size_t(syrk_work_elems(n, 128)));
             if (dense()) launch_syrk<T>(D->dense<T>(), w, cols, nb, xm, intercept, Dptr, B, work, gs);
             else launch_syrk_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols, nb, xm, intercept, Dptr, B, work, gs);
-            cnt.gram_flops += 2.0 * double(n) * 256.0 * (nb <= 64 ? 10.0 : 36.0);
+            cnt.gram_flops += 2.0 * double(n) * 256.0 * (nb <= 32 ? 3.0 : (nb <= 64 ? 10.0 : 36.0));
         }
         t_gram.end(gs);
         cnt.n_gram_col_reads += 2 * nb;
@@ -948,6 +948,8 @@ struct Solver {
         // Block size: 128 visits under fixed weights (Gaussian: a diagonal block is built once and re-used for the rest of
         // the path); 64 under IRLS, where every block is rebuilt per IRLS iteration and used about once, so the MFMA cost
         // per coordinate (block size x n MACs, lower triangle only below 64) matters more than the per-block latencies.
+        // (32-visit blocks with a 3-tile kernel were measured too: the fixed cost per block build and per chain step wins back
+        // nothing - 0.52 vs 0.44 s on a 500k x 8000 SNP path, 2.05 vs 1.58 s on the dense 100k x 10k binomial path.)
         const int B = panel_bsz > 0 ? panel_bsz : (is_glm() ? 64 : cd_block_size());
         const int SL = cd_block_size(); // D slot: SL x SL, leading dimension SL
         const size_t maxblk = size_t((p + B - 1) / B + 1);

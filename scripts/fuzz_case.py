@@ -7,6 +7,9 @@ from oracle import oracle
 case, seed0 = int(sys.argv[1]), int(sys.argv[2]); which = sys.argv[3] if len(sys.argv) > 3 else "both"
 rng = np.random.RandomState(seed0 * 1000 + case)
 n = int(rng.choice([37, 150, 513, 1200, 2049])); p = int(rng.choice([40, 130, 300, 777]))
+BIG = bool(os.environ.get("FUZZ_BIG"))
+if BIG:
+    n = int(rng.choice([900, 2500, 4100])); p = int(rng.choice([1200, 2000]))
 fam = rng.choice(["gaussian", "gaussian", "binomial"]); kind = rng.choice(["dense", "dense", "snp"])
 dtype = np.float64 if rng.uniform() < 0.75 else np.float32
 grouped = rng.uniform() < 0.5
@@ -22,6 +25,8 @@ else:
     groups = np.arange(p)
 alpha = float(rng.choice([1.0, 0.7, 0.3])); intercept = bool(rng.uniform() < 0.8); use_w = rng.uniform() < 0.5
 min_nv = int(rng.choice([1, 1, 64, 256])); bsz = rng.choice(["", "32", "64", "128"])
+if BIG:
+    min_nv, bsz = 256, ""
 os.environ["ADELIE_HIP_CD_BLOCK_MIN_NV"] = str(min_nv)
 if bsz: os.environ["ADELIE_HIP_PANEL_BSZ"] = bsz
 if kind == "dense":
@@ -37,7 +42,7 @@ else:
     y = (rng.uniform(size=n) < 1 / (1 + np.exp(-eta))).astype(np.float64); glm = lambda: ad.glm.binomial(y, weights=w, dtype=dtype)
 f32 = dtype == np.float32
 kw = dict(groups=groups, alpha=alpha, intercept=intercept, early_exit=False, lmda_path_size=int(rng.choice([8, 15])),
-          min_ratio=float(rng.choice([0.3, 0.05])), tol=1e-7 if f32 else 1e-13)
+          min_ratio=float(rng.choice([0.3, 0.05])) if not BIG else 0.02, tol=1e-7 if f32 else 1e-13)
 kw["max_iters"] = 4000
 if fam == "binomial": kw["irls_tol"] = 1e-6 if f32 else 1e-10
 kw.update(eval(os.environ.get("FUZZ_KW", "{}")))

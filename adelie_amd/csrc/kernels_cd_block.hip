@@ -119,6 +119,9 @@ __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j)
     }
     __syncthreads();
     if (wv != 0) return;
+    // the chain below is the critical path of the whole pass: let this wave win the issue arbitration against whatever
+    // else is resident on the CU (diagonal-block builds of the side stream)
+    __builtin_amdgcn_s_setprio(3);
 
     // ---- one wavefront: the block's visits, strictly in order ------------------------------------------------------
     CdBlkState<T>* st = p.st;

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int
     }
     __syncthreads();
     if (wv != 0) return;
+    __builtin_amdgcn_s_setprio(3); // critical path of the pass: win the issue arbitration on this CU
 
 #ifdef AHIP_GRP_PROFILE
     long long tmark = __builtin_readcyclecounter();

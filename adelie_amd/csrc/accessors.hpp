@@ -34,6 +34,30 @@ struct DenseAcc {
     }
 };
 
+// Dense design preceded by `shift` (0 or 1) columns of ones: the "extended features" of the multi-response view
+// [1 (x) I_K, X (x) I_K] (kernels_multi.hip).  Same interface as DenseAcc, so the MFMA syrk kernel takes it unchanged.
+template <class T>
+struct DenseOnesAcc {
+    const T* X;
+    int64_t ld;
+    const T* ones;
+    int64_t shift;
+    __device__ __forceinline__ const T* colptr(int64_t u) const { return u < shift ? ones : X + (u - shift) * ld; }
+    template <int VEC>
+    __device__ __forceinline__ Pack<T, VEC> load(const T* col, int64_t i, int64_t /*j*/) const {
+        Pack<T, VEC> r;
+        if constexpr (VEC == 1) {
+            r.v[0] = col[i];
+        } else {
+            using V = typename VecOf<T>::type;
+            V x = __builtin_nontemporal_load(reinterpret_cast<const V*>(col + i));
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r.v[e] = x[e];
+        }
+        return r;
+    }
+};
+
 // 2-bit SNP calls: value = code<3 ? code : impute[j]   (matrix_naive_snp_unphased.ipp:8-22 semantics)
 template <class T>
 struct SnpAcc {

@@ -80,7 +80,7 @@ struct DevBuf {
 struct adelie_hip_design {
     int dtype = ADELIE_HIP_F64;
     int device = 0;
-    int kind = 0; // 0 dense, 1 snp (2-bit)
+    int kind = 0; // 0 dense, 1 snp (2-bit), 2 multi-response view of a dense design (adelie_hip_design_create_multi)
     int64_t n = 0, p = 0;
     // dense
     void* X = nullptr;
@@ -91,10 +91,17 @@ struct adelie_hip_design {
     int64_t ldb = 0;
     void* impute = nullptr; // (p,) value_t on device
     bool alias = false;     // shares X / bits / impute with another design (adelie_hip_design_alias): never frees them
+    // multi-response view: [1 (x) I_K, X (x) I_K] over the base's X (nb x pb); n = nb*K, p = (pb + micpt)*K
+    int64_t mK = 0, nb = 0, pb = 0;
+    int micpt = 0;
+    void* ones = nullptr; // nb ones (owned)
     hipStream_t stream = nullptr;
     // scratch for the host-vector matrix ops (value_t typed, grow-only)
     ahip::DevBuf<char> s_n1, s_n2, s_p1, s_work, s_misc, s_idx1, s_idx2;
 
     template <class T> ahip::DenseView<T> dense() const { return ahip::DenseView<T>{static_cast<const T*>(X), n, p, ld}; }
     ahip::SnpView snp() const { return ahip::SnpView{bits, n, p, ldb}; }
+    template <class T> ahip::MultiView<T> multi() const {
+        return ahip::MultiView<T>{static_cast<const T*>(X), nb, pb, ld, static_cast<const T*>(ones), int32_t(mK), int32_t(micpt)};
+    }
 };

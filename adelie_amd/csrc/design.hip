@@ -257,6 +257,12 @@ void op_path_losses(adelie_hip_design* d, int kind, int64_t L, const int64_t* in
     }
 }
 
+// the multi-response view (kind 2) only serves grpnet_solve; its matrix ops go through the base design
+void no_view(const adelie_hip_design* d) {
+    if (d && d->kind == 2)
+        throw make_core_error("this entry point is not offered on a multi-response view; use the base design.");
+}
+
 void check_col(const adelie_hip_design* d, int64_t j, int64_t q, const char* what) {
     if (j < 0 || q < 0 || j + q > d->p) throw make_core_error(std::string(what) + "() is given inconsistent inputs!");
 }
@@ -433,6 +439,7 @@ int adelie_hip_design_create_snp_bed(const void* bed, int64_t n_bytes, int64_t n
 
 int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out) {
     ABI_TRY
+    no_view(src);
     if (!src || !out) throw make_core_error("null argument.");
     adelie_hip_design* d = new_design(src->n, src->p, src->dtype, src->device); // own stream, own scratch
     d->kind = src->kind;
@@ -447,8 +454,39 @@ int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out) {
     ABI_CATCH
 }
 
+int adelie_hip_design_create_multi(adelie_hip_design* base, int64_t K, int intercept, adelie_hip_design** out) {
+    ABI_TRY
+    if (!base || !out) throw make_core_error("null argument.");
+    if (base->kind != 0) throw make_core_error("the multi-response view needs a dense base design.");
+    if (K < 1) throw make_core_error("K must be >= 1.");
+    const int64_t icpt = intercept ? 1 : 0;
+    if ((base->p + icpt) * K > int64_t(0x7fffffff) || base->n * K > (int64_t(1) << 40))
+        throw make_core_error("the multi-response view is too large.");
+    adelie_hip_design* d = new_design(base->n * K, (base->p + icpt) * K, base->dtype, base->device); // own stream + scratch
+    d->kind = 2;
+    d->X = base->X;
+    d->ld = base->ld;
+    d->owned = false;
+    d->alias = true;
+    d->mK = K;
+    d->micpt = int(icpt);
+    d->nb = base->n;
+    d->pb = base->p;
+    {   // the column of ones (padded like a design column so that vector loads past nb stay in bounds)
+        const size_t esz = base->dtype == ADELIE_HIP_F64 ? sizeof(double) : sizeof(float);
+        const int64_t len = ((base->n + 31) / 32) * 32;
+        AHIP_CHECK(hipMalloc(&d->ones, size_t(len) * esz));
+        AHIP_CHECK(hipMemsetAsync(d->ones, 0, size_t(len) * esz, d->stream));
+        DTYPE_DISPATCH(d, launch_fill<T>((T*)d->ones, T(1), base->n, d->stream), launch_fill<T>((T*)d->ones, T(1), base->n, d->stream))
+        AHIP_CHECK(hipStreamSynchronize(d->stream));
+    }
+    *out = d;
+    ABI_CATCH
+}
+
 int adelie_hip_design_impute(adelie_hip_design* d, double* out) {
     ABI_TRY
+    no_view(d);
     if (!d || !out) throw make_core_error("null argument.");
     if (d->kind != 1) throw make_core_error("impute is only defined for SNP designs.");
     set_device(d);
@@ -472,6 +510,7 @@ int adelie_hip_design_destroy(adelie_hip_design* d) {
     if (d->owned && d->X && !d->alias) (void)hipFree(d->X);
     if (d->bits && !d->alias) (void)hipFree(d->bits);
     if (d->impute && !d->alias) (void)hipFree(d->impute);
+    if (d->ones) (void)hipFree(d->ones);
     delete d;
     return 0;
 }
@@ -484,6 +523,7 @@ void* adelie_hip_design_stream(const adelie_hip_design* d) { return d->stream; }
 
 int adelie_hip_design_cmul(adelie_hip_design* d, int64_t j, const void* v, const void* weights, double* out) {
     ABI_TRY
+    no_view(d);
     check_col(d, j, 1, "cmul");
     DTYPE_DISPATCH(d, { T o; op_sweep<T>(d, j, 1, (const T*)v, (const T*)weights, &o, false); *out = o; },
                    { T o; op_sweep<T>(d, j, 1, (const T*)v, (const T*)weights, &o, false); *out = o; })
@@ -491,12 +531,14 @@ int adelie_hip_design_cmul(adelie_hip_design* d, int64_t j, const void* v, const
 }
 int adelie_hip_design_ctmul(adelie_hip_design* d, int64_t j, double v, void* out) {
     ABI_TRY
+    no_view(d);
     check_col(d, j, 1, "ctmul");
     DTYPE_DISPATCH(d, { T c = T(v); op_axpy<T>(d, j, 1, &c, (T*)out); }, { T c = T(v); op_axpy<T>(d, j, 1, &c, (T*)out); })
     ABI_CATCH
 }
 int adelie_hip_design_bmul(adelie_hip_design* d, int64_t j, int64_t q, const void* v, const void* weights, void* out) {
     ABI_TRY
+    no_view(d);
     check_col(d, j, q, "bmul");
     DTYPE_DISPATCH(d, op_sweep<T>(d, j, q, (const T*)v, (const T*)weights, (T*)out, false),
                    op_sweep<T>(d, j, q, (const T*)v, (const T*)weights, (T*)out, false))
@@ -504,24 +546,28 @@ int adelie_hip_design_bmul(adelie_hip_design* d, int64_t j, int64_t q, const voi
 }
 int adelie_hip_design_btmul(adelie_hip_design* d, int64_t j, int64_t q, const void* v, void* out) {
     ABI_TRY
+    no_view(d);
     check_col(d, j, q, "btmul");
     DTYPE_DISPATCH(d, op_axpy<T>(d, j, q, (const T*)v, (T*)out), op_axpy<T>(d, j, q, (const T*)v, (T*)out))
     ABI_CATCH
 }
 int adelie_hip_design_mul(adelie_hip_design* d, const void* v, const void* weights, void* out) {
     ABI_TRY
+    no_view(d);
     DTYPE_DISPATCH(d, op_sweep<T>(d, 0, d->p, (const T*)v, (const T*)weights, (T*)out, false),
                    op_sweep<T>(d, 0, d->p, (const T*)v, (const T*)weights, (T*)out, false))
     ABI_CATCH
 }
 int adelie_hip_design_cov(adelie_hip_design* d, int64_t j, int64_t q, const void* sqrt_weights, void* out) {
     ABI_TRY
+    no_view(d);
     check_col(d, j, q, "cov");
     DTYPE_DISPATCH(d, op_cov<T>(d, j, q, (const T*)sqrt_weights, (T*)out), op_cov<T>(d, j, q, (const T*)sqrt_weights, (T*)out))
     ABI_CATCH
 }
 int adelie_hip_design_sq_mul(adelie_hip_design* d, const void* weights, void* out) {
     ABI_TRY
+    no_view(d);
     DTYPE_DISPATCH(d, op_sweep<T>(d, 0, d->p, (const T*)weights, (const T*)nullptr, (T*)out, true),
                    op_sweep<T>(d, 0, d->p, (const T*)weights, (const T*)nullptr, (T*)out, true))
     ABI_CATCH
@@ -529,6 +575,7 @@ int adelie_hip_design_sq_mul(adelie_hip_design* d, const void* weights, void* ou
 int adelie_hip_design_sp_tmul(adelie_hip_design* d, int64_t L, const int64_t* indptr, const int64_t* indices,
                               const void* values, void* out) {
     ABI_TRY
+    no_view(d);
     if (L < 0) throw make_core_error("sp_tmul() is given inconsistent inputs!");
     if (L == 0) return 0;
     DTYPE_DISPATCH(d, op_sp_tmul<T>(d, L, indptr, indices, (const T*)values, (T*)out),
@@ -541,6 +588,7 @@ int adelie_hip_design_glm_path_losses(adelie_hip_design* d, int glm_kind, int64_
                                       const void* offsets, const void* y, const void* weights_a, const void* weights_b,
                                       double* out) {
     ABI_TRY
+    no_view(d);
     if (!d || !indptr || !intercepts || !offsets || !y || !weights_a || !weights_b || !out)
         throw make_core_error("null argument.");
     if (L < 0) throw make_core_error("L must be >= 0.");

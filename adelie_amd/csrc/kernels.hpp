@@ -230,6 +230,51 @@ template <class T>
 void launch_cd_compact(const T* beta, const T* beta0, const int32_t* vcol, int nv, int32_t* dcols, T* dvals,
                        int32_t* n_delta, hipStream_t s);
 
+// ---- multi-response view (kernels_multi.hip) -------------------------------------------------------------------------
+// The design [1 (x) I_K, X (x) I_K] (first block iff icpt) over a dense base X (nb x pb), never materialised.  Column
+// j = u*K + l is (extended feature u, response l); u < icpt is the column of ones, u - icpt the base column otherwise.
+// Row vectors (residual, weights) live on the device RESPONSE-MAJOR: element (i, l) at [l*nb + i] (K contiguous vectors of
+// length nb), so that every kernel reads a slice of a column of X once and applies it to all K responses with unit-stride
+// vector accesses; the C ABI's (n, K) row-major vectors are transposed once on the way in and out.
+template <class T>
+struct MultiView {
+    const T* X;
+    int64_t nb, pb, ld;
+    const T* ones; // nb ones
+    int32_t K, icpt;
+};
+// out[u*K + l] = sum_i xcol(u)[i] * v[l*nb + i]  for every u in [0, pb + icpt): X is read ONCE for all K responses.
+template <class T> void launch_multi_sweep(const MultiView<T>& X, const T* v, T* out, T* work, hipStream_t s);
+template <class T> int64_t multi_sweep_work_elems(const MultiView<T>& X);
+// panel step on view columns (same contract as launch_panel_step; `part` holds multi_panel_part_elems(nb) elements):
+//   r -= sum_{m < *nz_dev} dlt[m] X'[:, dcol[m]];   part[c][slice] = X'[slice, cols[c]] . (w*r)[slice]  for c < nb_cols
+// entries that share an extended feature (the K responses of a group) are served by one load of the column slice.
+template <class T>
+int launch_multi_panel_step(const MultiView<T>& X, const T* w, T* r, const int32_t* dcol, const T* dlt,
+                            const int32_t* nz_dev, const int32_t* cols, int nb_cols, T* part, hipStream_t s);
+int64_t multi_panel_part_elems(int64_t nb);
+// out[:, response] += sign * coef[m] * xcol(feature)  for m < *cnt_dev   (rollback path)
+template <class T>
+void launch_multi_axpy_cols(const MultiView<T>& X, const int32_t* cols, const T* coef, const int32_t* cnt_dev, T sign,
+                            T* out, hipStream_t s);
+// symmetric M x M block over extended features ucols (MFMA syrk of kernels_gram.hip with the ones-aware accessor)
+template <class T>
+void launch_syrk_multi(const MultiView<T>& X, const T* w, const int32_t* ucols, int32_t M, T* C, int64_t ldc, T* work,
+                       hipStream_t s);
+// D[a + b*ldd] = (resp[a] == resp[b] && (lsel < 0 || resp[a] == lsel)) ? C[slot[a] + slot[b]*ldc] : (lsel <= 0 ? 0 : keep)
+// for a, b < nv: expands a Gram block over extended features into the block over view columns (X (x) I_K has no entries
+// between different responses).  lsel < 0: one weight vector for all responses; otherwise the call for response lsel.
+template <class T>
+void launch_multi_expand(const T* C, int64_t ldc, const int32_t* slot, const int32_t* resp, int nv, int lsel, T* D,
+                         int64_t ldd, hipStream_t s);
+// distinct extended features of a block's view columns (order of first appearance) -> ulist; per column its slot in
+// ulist and its response.  nv <= 128.
+void launch_multi_block_lists(const int32_t* cols, int nv, int K, int32_t* ulist, int32_t* slot, int32_t* resp,
+                              hipStream_t s);
+// (n, K) row-major <-> response-major
+template <class T> void launch_multi_to_major(const T* src, int64_t nb, int K, T* dst, hipStream_t s);
+template <class T> void launch_multi_from_major(const T* src, int64_t nb, int K, T* dst, hipStream_t s);
+
 // ---- GLM elementwise (solver_glm_naive.hpp:336-348, 439-449; glm_*.ipp) --------------------------
 template <class T>
 struct IrlsScalars {

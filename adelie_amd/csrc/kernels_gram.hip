@@ -434,6 +434,16 @@ void launch_syrk_snp(const SnpView& X, const T* impute, const T* w, const int32_
     syrk_launch<T, SnpAcc<T>>(acc, true, w, cols, M, X.n, xm_by_col, center, C, ldc, work, s);
 }
 
+template <class T>
+void launch_syrk_multi(const MultiView<T>& X, const T* w, const int32_t* ucols, int32_t M, T* C, int64_t ldc, T* work,
+                       hipStream_t s) {
+    DenseOnesAcc<T> acc{X.X, X.ld, X.ones, int64_t(X.icpt)};
+    constexpr int V = VecOf<T>::N;
+    const bool vecok = (X.ld % V == 0) && ((reinterpret_cast<uintptr_t>(X.X) % 16) == 0) &&
+                       ((reinterpret_cast<uintptr_t>(X.ones) % 16) == 0);
+    syrk_launch<T, DenseOnesAcc<T>>(acc, vecok, w, ucols, M, X.nb, nullptr, false, C, ldc, work, s);
+}
+
 int64_t gram_work_elems(int64_t n, int64_t M, int64_t N) {
     if (M <= 0 || N <= 0) return 0;
     const GramShape g = gram_shape(n, M, N);
@@ -472,6 +482,10 @@ INST(float)
                                        int64_t, T*, hipStream_t);
 INST2(double)
 INST2(float)
+template void launch_syrk_multi<double>(const MultiView<double>&, const double*, const int32_t*, int32_t, double*, int64_t,
+                                        double*, hipStream_t);
+template void launch_syrk_multi<float>(const MultiView<float>&, const float*, const int32_t*, int32_t, float*, int64_t,
+                                       float*, hipStream_t);
 #undef INST2
 
 } // namespace ahip

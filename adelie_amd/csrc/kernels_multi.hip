@@ -1,0 +1,458 @@
+// kernels_multi.hip — the multi-response view [1 (x) I_K, X (x) I_K] of a resident dense design (gfx950 / CDNA4).
+//
+// Replaces, for StateMultiGaussianNaive (reference adelie/state.py:2027-2391, solver_multigaussian_naive.hpp:9-52), the
+// composition MatrixNaiveConcatenate([MatrixNaiveKroneckerEye(ones), MatrixNaiveKroneckerEye(X)])
+// (matrix_naive_kronecker_eye.ipp:27-245, matrix_naive_concatenate.ipp): there every cmul / ctmul of a view column copies
+// the strided response column of v and w into a buffer and calls the base matrix, so a group of K view columns streams
+// the same base column K times.  Here the residual and the weights live response-major in HBM (element (i, l) at
+// [l*nb + i]) and every kernel reads a slice of a base column ONCE and applies it to all K responses from registers:
+//
+//   multi_sweep        out[u*K + l] = x_u . v_l for every extended feature u   (invariance / KKT sweep: X read once, not K times)
+//   multi_panel_step   the panel step of kernels_cd_panel.hip on view columns: r_l -= sum Delta[u, l] x_u, then the partial
+//                      gradients of the next block; entries of one feature are merged into one column-slice load
+//   multi_expand       Gram block over extended features (MFMA syrk, kernels_gram.hip) -> block over view columns
+//                      (entries between different responses are zero)
+//   multi_axpy_cols    rollback of a failed fit
+//   multi_{to,from}_major   (n, K) row-major <-> response-major, once per solve on the way in / out
+//
+// All of these are HBM-bound streaming kernels; the bytes per view column visited drop by K against the single-response
+// kernels because the K columns of a feature share one read.
+#include "kernels.hpp"
+#include "accessors.hpp"
+#include "wavered.hpp"
+
+#include <algorithm>
+
+namespace ahip {
+
+namespace {
+
+constexpr int MT = 256;  // threads of the sweep kernel
+constexpr int MCB = 4;   // features per sweep block
+constexpr int MAXB = 128; // entries of a panel block (== cd_block_size())
+
+template <class T>
+__device__ __forceinline__ T wsum(T x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    return x;
+}
+
+// ---- sweep ------------------------------------------------------------------------------------------------------------
+// grid (feature panels, row splits, response chunks of KT).  A block owns MCB features and walks its rows once; the KT
+// response vectors v_l are re-read per panel but from L2 (blocks of one row split are scheduled together and share them).
+template <class T, int VEC, int KT>
+__global__ __launch_bounds__(MT) void multi_sweep_kernel(DenseOnesAcc<T> X, const T* __restrict__ v, T* __restrict__ part,
+                                                        int64_t nb, int64_t nfeat, int K, int64_t rows_per_split) {
+    const int tid = threadIdx.x;
+    const int64_t cb = blockIdx.x;
+    const int split = blockIdx.y;
+    const int l0 = blockIdx.z * KT;
+    const int64_t r0 = int64_t(split) * rows_per_split;
+    const int64_t r1 = min(nb, r0 + rows_per_split);
+    const T* cp[MCB];
+#pragma unroll
+    for (int k = 0; k < MCB; ++k) cp[k] = X.colptr(min(cb * MCB + k, nfeat - 1));
+    const T* vp[KT];
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) vp[kk] = v + int64_t(min(l0 + kk, K - 1)) * nb; // clamped: duplicates are discarded below
+    T acc[MCB][KT];
+#pragma unroll
+    for (int k = 0; k < MCB; ++k)
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) acc[k][kk] = T(0);
+
+    const int64_t body_end = r0 + ((r1 - r0) / VEC) * VEC;
+    for (int64_t i = r0 + int64_t(tid) * VEC; i < body_end; i += int64_t(MT) * VEC) {
+        Pack<T, VEC> xx[MCB];
+#pragma unroll
+        for (int k = 0; k < MCB; ++k) xx[k] = X.template load<VEC>(cp[k], i, 0);
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const T vv = vp[kk][i + e];
+#pragma unroll
+                for (int k = 0; k < MCB; ++k) acc[k][kk] = fma(xx[k].v[e], vv, acc[k][kk]);
+            }
+        }
+    }
+    for (int64_t i = body_end + tid; i < r1; i += MT) {
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            const T vv = vp[kk][i];
+#pragma unroll
+            for (int k = 0; k < MCB; ++k) acc[k][kk] = fma(cp[k][i], vv, acc[k][kk]);
+        }
+    }
+
+    __shared__ T red[MT / 64][MCB * KT];
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < MCB; ++k)
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            const T s = wsum(acc[k][kk]);
+            if (lane == 0) red[wv][k * KT + kk] = s;
+        }
+    __syncthreads();
+    if (tid < MCB * KT) {
+        const int k = tid / KT, kk = tid % KT;
+        const int64_t u = cb * MCB + k;
+        const int l = l0 + kk;
+        if (u < nfeat && l < K) {
+            T s = T(0);
+#pragma unroll
+            for (int w = 0; w < MT / 64; ++w) s += red[w][tid];
+            part[(int64_t(split) * nfeat + u) * K + l] = s;
+        }
+    }
+}
+
+template <class T>
+__global__ void multi_sweep_reduce_kernel(const T* __restrict__ part, T* __restrict__ out, int64_t ncols, int nsplit) {
+    const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    T s = T(0);
+    for (int r = 0; r < nsplit; ++r) s += part[int64_t(r) * ncols + c];
+    out[c] = s;
+}
+
+inline void msweep_shape(int64_t nb, int64_t nfeat, int vec, int64_t& blocks_c, int& nsplit, int64_t& rows_per_split) {
+    blocks_c = (nfeat + MCB - 1) / MCB;
+    const int64_t unit = int64_t(MT) * vec;
+    const int64_t max_split = std::max<int64_t>(1, (nb + unit * 4 - 1) / (unit * 4));
+    int64_t ns = std::max<int64_t>(1, (1024 + blocks_c - 1) / blocks_c);
+    ns = std::min<int64_t>(std::min<int64_t>(ns, max_split), 65535);
+    rows_per_split = (nb + ns - 1) / ns;
+    rows_per_split = ((rows_per_split + unit - 1) / unit) * unit;
+    ns = std::max<int64_t>(1, (nb + rows_per_split - 1) / rows_per_split);
+    nsplit = int(ns);
+}
+
+template <class T>
+bool multi_vecok(const MultiView<T>& X) {
+    constexpr int V = VecOf<T>::N;
+    return (X.ld % V == 0) && ((reinterpret_cast<uintptr_t>(X.X) % 16) == 0) &&
+           ((reinterpret_cast<uintptr_t>(X.ones) % 16) == 0);
+}
+
+// ---- panel step -------------------------------------------------------------------------------------------------------
+// One wave per workgroup owns 64*VEC base rows and a chunk of KT responses.  Prologue (LDS): the entry lists (view
+// columns) are merged into per-feature slots -- consecutive entries of one extended feature share a slot -- with the
+// coefficients spread over the KT responses; then phase (A)/(B) of kernels_cd_panel.hip run per slot, with the residual
+// slices of the KT responses in registers.
+template <class T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> mload(const T* col, int64_t i, int64_t nb, bool full) {
+    Pack<T, VEC> r;
+    if constexpr (VEC == 1) {
+        const T x = col[(full || i < nb) ? i : 0];
+        r.v[0] = (full || i < nb) ? x : T(0);
+    } else {
+        using V = typename VecOf<T>::type;
+        const int64_t ii = (full || i < nb) ? i : 0; // ld % VEC == 0: a lane starting below nb reads at most pad elements
+        const V x = *reinterpret_cast<const V*>(col + ii);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) r.v[e] = (full || i + e < nb) ? x[e] : T(0);
+    }
+    return r;
+}
+
+// slots of a list of view columns: returns the number of slots; feat[slot] = extended feature; for every entry m the
+// callback gets (m, slot, response)
+template <class F>
+__device__ __forceinline__ int build_slots(const int32_t* __restrict__ list, int cnt, int K, int* feat, int lane, F f) {
+    int nslot = 0;
+    for (int base = 0; base < cnt; base += 64) {
+        const int m = base + lane;
+        const bool valid = m < cnt;
+        const int col = valid ? list[m] : 0;
+        const int u = col / K, l = col - u * K;
+        const int pu = (valid && m > 0) ? list[m - 1] / K : -1;
+        const bool head = valid && (m == 0 || u != pu);
+        const unsigned long long mask = __ballot(head);
+        const int slot = nslot + __popcll(mask & ((2ull << lane) - 1ull)) - 1;
+        if (head) feat[slot] = u;
+        if (valid) f(m, slot, l);
+        nslot += __popcll(mask);
+    }
+    return nslot;
+}
+
+template <class T, int VEC, int KT>
+__global__ __launch_bounds__(64) void multi_panel_step_kernel(DenseOnesAcc<T> X, int64_t nb, int K,
+                                                              const T* __restrict__ w, T* __restrict__ r,
+                                                              const int32_t* __restrict__ dcol,
+                                                              const T* __restrict__ dlt,
+                                                              const int32_t* __restrict__ nz_dev,
+                                                              const int32_t* __restrict__ cols, int nbc,
+                                                              T* __restrict__ part, int64_t part_ld) {
+    __shared__ int featA[MAXB], featB[MAXB];
+    __shared__ T dA[MAXB * KT];
+    __shared__ int valB[MAXB * KT];
+    const int lane = threadIdx.x;
+    const int l0 = blockIdx.y * KT;
+    const int64_t i = int64_t(blockIdx.x) * (64 * VEC) + int64_t(lane) * VEC;
+    const bool full = (int64_t(blockIdx.x) + 1) * (64 * VEC) <= nb;
+    const int nz = min(nz_dev[0], MAXB);
+
+    for (int q = lane; q < MAXB * KT; q += 64) {
+        dA[q] = T(0);
+        valB[q] = -1;
+    }
+    __syncthreads();
+    const int nsA = build_slots(dcol, nz, K, featA, lane, [&](int m, int slot, int l) {
+        if (l >= l0 && l < l0 + KT) dA[slot * KT + (l - l0)] = dlt[m];
+    });
+    const int nsB = build_slots(cols, nbc, K, featB, lane, [&](int m, int slot, int l) {
+        if (l >= l0 && l < l0 + KT) valB[slot * KT + (l - l0)] = m;
+    });
+    __syncthreads();
+
+    constexpr int U = 8;
+    // ---- (A) ---------------------------------------------------------------------------------------------------------
+    T acc[KT][VEC];
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[kk][e] = T(0);
+    for (int s0 = 0; s0 < nsA; s0 += U) {
+        Pack<T, VEC> xa[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xa[u] = mload<T, VEC>(X.colptr(featA[min(s0 + u, nsA - 1)]), i, nb, full);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (s0 + u < nsA) {
+#pragma unroll
+                for (int kk = 0; kk < KT; ++kk) {
+                    const T d = dA[(s0 + u) * KT + kk];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[kk][e] = fma(d, xa[u].v[e], acc[kk][e]);
+                }
+            }
+        }
+    }
+    // residual slices of the chunk's responses; acc becomes w * r
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+        const int l = l0 + kk;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            T wr = T(0);
+            if (l < K && i + e < nb) {
+                const int64_t q = int64_t(l) * nb + i + e;
+                T rr = r[q];
+                if (nsA > 0) {
+                    rr -= acc[kk][e];
+                    r[q] = rr;
+                }
+                wr = w[q] * rr;
+            }
+            acc[kk][e] = wr;
+        }
+    }
+    // ---- (B) ---------------------------------------------------------------------------------------------------------
+    for (int s0 = 0; s0 < nsB; s0 += U) {
+        Pack<T, VEC> xb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xb[u] = mload<T, VEC>(X.colptr(featB[min(s0 + u, nsB - 1)]), i, nb, full);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (s0 + u < nsB) {
+                T d8[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    T d = T(0);
+                    if (kk < KT) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) d = fma(xb[u].v[e], acc[kk][e], d);
+                    }
+                    d8[kk] = d;
+                }
+                const T tot = reduce8(d8, lane); // lane kk < 8: the total of response l0 + kk
+                if (lane < KT) {
+                    const int c = valB[(s0 + u) * KT + lane];
+                    if (c >= 0) part[int64_t(c) * part_ld + blockIdx.x] = tot;
+                }
+            }
+        }
+    }
+}
+
+template <class T>
+__global__ void multi_expand_kernel(const T* __restrict__ C, int64_t ldc, const int32_t* __restrict__ slot,
+                                    const int32_t* __restrict__ resp, int nv, int lsel, T* __restrict__ D, int64_t ldd) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (a >= nv || b >= nv) return;
+    const int la = resp[a], lb = resp[b];
+    if (la == lb && (lsel < 0 || la == lsel)) D[a + int64_t(b) * ldd] = C[slot[a] + int64_t(slot[b]) * ldc];
+    else if (lsel <= 0) D[a + int64_t(b) * ldd] = T(0);
+}
+
+// ulist / slot / resp of a block's view columns: distinct extended features in order of first appearance (one workgroup
+// of MAXB threads; the host counts the same way to size the syrk launch)
+__global__ __launch_bounds__(MAXB) void multi_block_lists_kernel(const int32_t* __restrict__ cols, int nv, int K,
+                                                                 int32_t* __restrict__ ulist, int32_t* __restrict__ slot,
+                                                                 int32_t* __restrict__ resp) {
+    __shared__ int us[MAXB], first[MAXB], rank[MAXB];
+    const int a = threadIdx.x;
+    const int u = a < nv ? cols[a] / K : -1;
+    us[a] = u;
+    __syncthreads();
+    int f = a;
+    for (int b = 0; b < a; ++b)
+        if (us[b] == u) { f = b; break; }
+    first[a] = f;
+    __syncthreads();
+    int rk = 0;
+    for (int b = 0; b < a; ++b) rk += (b < nv && first[b] == b) ? 1 : 0;
+    rank[a] = rk;
+    __syncthreads();
+    if (a < nv) {
+        if (first[a] == a) ulist[rank[a]] = u;
+        slot[a] = rank[first[a]];
+        resp[a] = cols[a] - u * K;
+    }
+}
+
+template <class T>
+__global__ void multi_axpy_kernel(DenseOnesAcc<T> X, int64_t nb, int K, const int32_t* __restrict__ cols,
+                                  const T* __restrict__ coef, const int32_t* __restrict__ cnt_dev, T sign,
+                                  T* __restrict__ out) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    const int cnt = cnt_dev[0];
+    for (int m = 0; m < cnt; ++m) {
+        const int col = cols[m];
+        const int u = col / K, l = col - u * K;
+        out[int64_t(l) * nb + i] += sign * coef[m] * X.colptr(u)[i];
+    }
+}
+
+template <class T>
+__global__ void multi_to_major_kernel(const T* __restrict__ src, int64_t nb, int K, T* __restrict__ dst) {
+    const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (q >= nb * K) return;
+    const int64_t l = q / nb, i = q - l * nb;
+    dst[q] = src[i * K + l];
+}
+template <class T>
+__global__ void multi_from_major_kernel(const T* __restrict__ src, int64_t nb, int K, T* __restrict__ dst) {
+    const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (q >= nb * K) return;
+    const int64_t i = q / K, l = q - i * K;
+    dst[q] = src[l * nb + i];
+}
+
+inline int kt_of(int K) { return K > 4 ? 8 : (K > 2 ? 4 : 2); }
+
+} // namespace
+
+template <class T>
+int64_t multi_sweep_work_elems(const MultiView<T>& X) {
+    int64_t bc, rps;
+    int ns;
+    msweep_shape(X.nb, X.pb + X.icpt, VecOf<T>::N, bc, ns, rps);
+    return int64_t(ns) * (X.pb + X.icpt) * X.K + 16;
+}
+
+template <class T>
+void launch_multi_sweep(const MultiView<T>& X, const T* v, T* out, T* work, hipStream_t s) {
+    const int64_t nfeat = X.pb + X.icpt;
+    if (nfeat <= 0 || X.K <= 0) return;
+    DenseOnesAcc<T> acc{X.X, X.ld, X.ones, int64_t(X.icpt)};
+    constexpr int V = VecOf<T>::N;
+    int64_t bc, rps;
+    int ns;
+    msweep_shape(X.nb, nfeat, V, bc, ns, rps); // shape for the vector width (also valid for scalar loads)
+    const int KT = kt_of(X.K);
+    const dim3 grid((unsigned)bc, (unsigned)ns, (unsigned)((X.K + KT - 1) / KT));
+    const bool vok = multi_vecok(X);
+#define AHIP_MS(VV, KK)                                                                                                 \
+    hipLaunchKernelGGL((multi_sweep_kernel<T, VV, KK>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps)
+    if (vok) {
+        if (KT == 8) AHIP_MS(V, 8); else if (KT == 4) AHIP_MS(V, 4); else AHIP_MS(V, 2);
+    } else {
+        if (KT == 8) AHIP_MS(1, 8); else if (KT == 4) AHIP_MS(1, 4); else AHIP_MS(1, 2);
+    }
+#undef AHIP_MS
+    const int64_t ncols = nfeat * X.K;
+    hipLaunchKernelGGL((multi_sweep_reduce_kernel<T>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, work, out,
+                       ncols, ns);
+}
+
+int64_t multi_panel_part_elems(int64_t nb) { return int64_t(MAXB) * ((nb + 63) / 64) + 16; }
+
+template <class T>
+int launch_multi_panel_step(const MultiView<T>& X, const T* w, T* r, const int32_t* dcol, const T* dlt,
+                            const int32_t* nz_dev, const int32_t* cols, int nb_cols, T* part, hipStream_t s) {
+    DenseOnesAcc<T> acc{X.X, X.ld, X.ones, int64_t(X.icpt)};
+    constexpr int V = VecOf<T>::N;
+    const bool vok = multi_vecok(X);
+    const int RS = 64 * (vok ? V : 1);
+    const int64_t nsl = (X.nb + RS - 1) / RS;
+    const int KT = kt_of(X.K);
+    const dim3 grid((unsigned)nsl, (unsigned)((X.K + KT - 1) / KT));
+#define AHIP_MP(VV, KK)                                                                                                 \
+    hipLaunchKernelGGL((multi_panel_step_kernel<T, VV, KK>), grid, dim3(64), 0, s, acc, X.nb, int(X.K), w, r, dcol, dlt, \
+                       nz_dev, cols, nb_cols, part, nsl)
+    if (vok) {
+        if (KT == 8) AHIP_MP(V, 8); else if (KT == 4) AHIP_MP(V, 4); else AHIP_MP(V, 2);
+    } else {
+        if (KT == 8) AHIP_MP(1, 8); else if (KT == 4) AHIP_MP(1, 4); else AHIP_MP(1, 2);
+    }
+#undef AHIP_MP
+    return int(nsl);
+}
+
+template <class T>
+void launch_multi_axpy_cols(const MultiView<T>& X, const int32_t* cols, const T* coef, const int32_t* cnt_dev, T sign,
+                            T* out, hipStream_t s) {
+    DenseOnesAcc<T> acc{X.X, X.ld, X.ones, int64_t(X.icpt)};
+    hipLaunchKernelGGL((multi_axpy_kernel<T>), dim3((unsigned)((X.nb + 255) / 256)), dim3(256), 0, s, acc, X.nb, int(X.K),
+                       cols, coef, cnt_dev, sign, out);
+}
+
+template <class T>
+void launch_multi_expand(const T* C, int64_t ldc, const int32_t* slot, const int32_t* resp, int nv, int lsel, T* D,
+                         int64_t ldd, hipStream_t s) {
+    if (nv <= 0) return;
+    hipLaunchKernelGGL((multi_expand_kernel<T>), dim3((unsigned)((nv + 63) / 64), (unsigned)nv), dim3(64), 0, s, C, ldc,
+                       slot, resp, nv, lsel, D, ldd);
+}
+
+void launch_multi_block_lists(const int32_t* cols, int nv, int K, int32_t* ulist, int32_t* slot, int32_t* resp,
+                              hipStream_t s) {
+    if (nv <= 0) return;
+    hipLaunchKernelGGL(multi_block_lists_kernel, dim3(1), dim3(MAXB), 0, s, cols, nv, K, ulist, slot, resp);
+}
+
+template <class T>
+void launch_multi_to_major(const T* src, int64_t nb, int K, T* dst, hipStream_t s) {
+    const int64_t tot = nb * K;
+    if (tot <= 0) return;
+    hipLaunchKernelGGL((multi_to_major_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, nb, K, dst);
+}
+template <class T>
+void launch_multi_from_major(const T* src, int64_t nb, int K, T* dst, hipStream_t s) {
+    const int64_t tot = nb * K;
+    if (tot <= 0) return;
+    hipLaunchKernelGGL((multi_from_major_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, nb, K, dst);
+}
+
+#define INST(T)                                                                                                        \
+    template int64_t multi_sweep_work_elems<T>(const MultiView<T>&);                                                   \
+    template void launch_multi_sweep<T>(const MultiView<T>&, const T*, T*, T*, hipStream_t);                           \
+    template int launch_multi_panel_step<T>(const MultiView<T>&, const T*, T*, const int32_t*, const T*, const int32_t*, \
+                                            const int32_t*, int, T*, hipStream_t);                                     \
+    template void launch_multi_axpy_cols<T>(const MultiView<T>&, const int32_t*, const T*, const int32_t*, T, T*,      \
+                                            hipStream_t);                                                              \
+    template void launch_multi_expand<T>(const T*, int64_t, const int32_t*, const int32_t*, int, int, T*, int64_t,     \
+                                         hipStream_t);                                                                 \
+    template void launch_multi_to_major<T>(const T*, int64_t, int, T*, hipStream_t);                                   \
+    template void launch_multi_from_major<T>(const T*, int64_t, int, T*, hipStream_t);
+INST(double)
+INST(float)
+#undef INST
+
+} // namespace ahip

@@ -329,15 +329,44 @@ struct Solver {
 
     bool is_screen(idx i) const { return in_screen[i] != 0; }
     bool dense() const { return D->kind == 0; }
+    // multi-response view (adelie_hip_design_create_multi): residual / weights live response-major on the device
+    bool multi() const { return D->kind == 2; }
+    bool multi_w_uniform = true;
+    std::vector<int32_t> h_vcol, h_actcols, multi_seen; // host mirrors of d_vcol / d_actcols (block column lists)
+    DevBuf<int32_t> d_mlist, d_mlist2;
+    DevBuf<T> d_mC, d_mC2;
+    const int32_t* host_cols(const int32_t* dev) const {
+        if (dev >= d_vcol.p && dev < d_vcol.p + h_vcol.size()) return h_vcol.data() + (dev - d_vcol.p);
+        if (dev >= d_actcols.p && dev < d_actcols.p + h_actcols.size()) return h_actcols.data() + (dev - d_actcols.p);
+        throw make_core_error("internal: block column list without a host mirror.");
+    }
+    // (n, K) row-major (the ABI's layout, matrix_naive_kronecker_eye.ipp:36-37) <-> response-major
+    void to_major(const T* src, T* dst) const {
+        const int64_t nb = D->nb, K = D->mK;
+        for (int64_t i = 0; i < nb; ++i)
+            for (int64_t l = 0; l < K; ++l) dst[l * nb + i] = src[i * K + l];
+    }
+    void from_major(const T* src, T* dst) const {
+        const int64_t nb = D->nb, K = D->mK;
+        for (int64_t i = 0; i < nb; ++i)
+            for (int64_t l = 0; l < K; ++l) dst[i * K + l] = src[l * nb + i];
+    }
 
     // ---------------------------------------------------------------------------------------------------------
     void sweep(const T* v, T* out, const int32_t* cols, idx ncols, const T* sub_scale, const T* sub_vec,
                bool square = false) {
+        if (multi()) { // only the full sweep of the Gaussian path is needed on the view (intercept off: no centring epilogue)
+            if (cols || ncols != p || sub_vec || square) throw make_core_error("unsupported sweep on a multi-response view.");
+            const MultiView<T> mv = D->multi<T>();
+            launch_multi_sweep<T>(mv, v, out, d_work_sweep.reserve(size_t(multi_sweep_work_elems<T>(mv))), st);
+            return;
+        }
         T* work = d_work_sweep.reserve(size_t(sweep_work_elems(n, ncols)));
         if (dense()) launch_sweep<T>(D->dense<T>(), v, out, 0, ncols, cols, sub_scale, sub_vec, square, work, st);
         else launch_sweep_snp<T>(D->snp(), static_cast<const T*>(D->impute), v, out, 0, ncols, cols, sub_scale, sub_vec, square, work, st);
     }
     int panel_step(const T* w, T* r, const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb) {
+        if (multi()) return launch_multi_panel_step<T>(D->multi<T>(), w, r, dcol, dlt, nz_dev, cols, nb, d_part.p, st);
         if (dense()) return launch_panel_step<T>(D->dense<T>(), w, r, dcol, dlt, nz_dev, cols, nb, d_part.p, st);
         return launch_panel_step_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, r, dcol, dlt, nz_dev, cols, nb,
                                         d_part.p, st);
@@ -347,6 +376,34 @@ struct Solver {
         const int B = cd_block_size();
         hipStream_t gs = side ? st2 : st;
         t_gram.begin(gs);
+        if (multi()) {
+            // Gram over the block's distinct extended features (MFMA syrk), expanded to the view columns: entries between
+            // different responses are zero.  One syrk when all responses carry the same weights (always so for
+            // multigaussian: w_i / K), otherwise one per response.
+            const MultiView<T> mv = D->multi<T>();
+            const int32_t* hc = host_cols(cols);
+            multi_seen.clear();
+            for (int a = 0; a < nb; ++a) {
+                const int32_t u = hc[a] / mv.K;
+                if (std::find(multi_seen.begin(), multi_seen.end(), u) == multi_seen.end()) multi_seen.push_back(u);
+            }
+            const int nu = int(multi_seen.size());
+            DevBuf<int32_t>& ml = side ? d_mlist2 : d_mlist;
+            DevBuf<T>& mc = side ? d_mC2 : d_mC;
+            ml.reserve(size_t(3 * B));
+            mc.reserve(size_t(B) * B);
+            launch_multi_block_lists(cols, nb, mv.K, ml.p, ml.p + B, ml.p + 2 * B, gs);
+            T* work = (side ? d_work_gram2 : d_work_gram).reserve(size_t(syrk_work_elems(mv.nb, 128)));
+            const int reps = multi_w_uniform ? 1 : mv.K;
+            for (int l = 0; l < reps; ++l) {
+                launch_syrk_multi<T>(mv, w + size_t(l) * size_t(mv.nb), ml.p, nu, mc.p, B, work, gs);
+                launch_multi_expand<T>(mc.p, B, ml.p + B, ml.p + 2 * B, nb, multi_w_uniform ? -1 : l, Dptr, B, gs);
+                cnt.gram_flops += 2.0 * double(mv.nb) * 256.0 * (nu <= 32 ? 3.0 : (nu <= 64 ? 10.0 : 36.0));
+            }
+            cnt.n_gram_col_reads += 2 * nu * reps;
+            t_gram.end(gs);
+            return;
+        }
         {   // lower-triangle MFMA tiles only: 10 of 16 (nb <= 64) or 36 of 64
             T* work = (side ? d_work_gram2 : d_work_gram).reserve(size_t(syrk_work_elems(n, 128)));
             if (dense()) launch_syrk<T>(D->dense<T>(), w, cols, nb, xm, intercept, Dptr, B, work, gs);
@@ -357,6 +414,11 @@ struct Solver {
         cnt.n_gram_col_reads += 2 * nb;
     }
     void axpy_cols(const int32_t* cols, const T* coef, const int32_t* cnt_dev, int32_t count, T sign, T* out) {
+        if (multi()) {
+            if (!cnt_dev) throw make_core_error("unsupported axpy on a multi-response view.");
+            launch_multi_axpy_cols<T>(D->multi<T>(), cols, coef, cnt_dev, sign, out, st);
+            return;
+        }
         if (dense()) launch_axpy_cols<T>(D->dense<T>(), cols, coef, cnt_dev, count, sign, out, st);
         else launch_axpy_cols_snp<T>(D->snp(), static_cast<const T*>(D->impute), cols, coef, cnt_dev, count, sign, out, st);
     }
@@ -436,6 +498,8 @@ struct Solver {
             nv_new += group_sizes[g];
         }
         d_vcol.upload(vcol.data(), vcol.size(), st, nv_old);
+        h_vcol.resize(size_t(nv_old));
+        h_vcol.insert(h_vcol.end(), vcol.begin(), vcol.end());
         d_beta.upload(beta_new.data(), beta_new.size(), st, nv_old);
         d_sbegin.upload(sbegin.data(), sbegin.size(), st, ns_dev);
         d_ssize.upload(ssize.data(), ssize.size(), st, ns_dev);
@@ -1192,7 +1256,7 @@ struct Solver {
         int status = CD_OK;
         int asz = sc.active_size;
         std::vector<idx> act_host(active_set.begin(), active_set.begin() + asz); // host mirror of the active list
-        std::vector<int32_t> acols;
+        std::vector<int32_t>& acols = h_actcols;
         auto pass = [&](bool screen_pass) -> T {
             const idx count = screen_pass ? idx(cp.ns) : idx(asz);
             if (count <= 0) return T(0);
@@ -1819,6 +1883,10 @@ struct Solver {
             d_vars.download(screen_vars.data(), size_t(nv), st);
         }
         sync();
+        if (multi()) { // back to the ABI's (n, K) row-major layout
+            std::vector<T> tmp(resid);
+            from_major(tmp.data(), resid.data());
+        }
     }
 
     // ---------------------------------------------------------------------------------------------------------
@@ -1891,6 +1959,18 @@ struct Solver {
             panel_bsz = std::atoi(e);
             if (panel_bsz != 32 && panel_bsz != 64 && panel_bsz != 128) panel_bsz = 0;
         }
+        if (multi()) {
+            // StateMultiGaussianNaive (state.py:2300-2380): the Gaussian naive solver, global intercept off, on the view.
+            // Everything runs on the group panel engine (its blocks are what lets a column slice serve K responses).
+            if (is_glm()) throw make_core_error("a multi-response view only supports the Gaussian (multigaussian) solver.");
+            if (intercept) throw make_core_error("a multi-response view is solved with intercept = false (the intercepts are its first K columns).");
+            if (max_gs > idx(cd_block_size()))
+                throw make_core_error("multi-response groups (group size x K) must not exceed " + std::to_string(cd_block_size()) + " columns.");
+            all_scalar = false;
+            engine_panel = true;
+            group_panel = true;
+            cd_block_min_nv = 0;
+        }
         // device allocations
         d_r.reserve(n); d_v.reserve(n); d_grad.reserve(p); d_absgrad.reserve(G); d_penalty.reserve(G);
         d_groups.reserve(G); d_gsizes.reserve(G); d_slot.reserve(G);
@@ -1916,6 +1996,16 @@ struct Solver {
             const T* w = (const T*)a->weights;
             if (!w || !a->X_means || !a->resid) throw make_core_error("weights, X_means and resid are required.");
             d_w.reserve(n); d_xm.reserve(p);
+            std::vector<T> w_major;
+            if (multi()) {
+                w_major.resize(size_t(n));
+                to_major(w, w_major.data());
+                const int64_t nb_ = D->nb;
+                multi_w_uniform = true;
+                for (int64_t l = 1; l < D->mK && multi_w_uniform; ++l)
+                    multi_w_uniform = std::equal(w_major.begin(), w_major.begin() + nb_, w_major.begin() + l * nb_);
+                w = w_major.data();
+            }
             d_w.upload(w, n, st);
             X_means.assign((const T*)a->X_means, (const T*)a->X_means + p);
             d_xm.upload(X_means.data(), p, st);
@@ -1924,7 +2014,14 @@ struct Solver {
             loss_full = -T(0.5) * y_var + loss_null;
             rsq = T(a->rsq); resid_sum = T(a->resid_sum);
             resid.assign((const T*)a->resid, (const T*)a->resid + n);
-            d_r.upload(resid.data(), n, st);
+            std::vector<T> r_major;
+            if (multi()) {
+                r_major.resize(size_t(n));
+                to_major(resid.data(), r_major.data());
+                d_r.upload(r_major.data(), n, st);
+            } else {
+                d_r.upload(resid.data(), n, st);
+            }
             sync();
             grad_valid = true; // the caller's grad is X^T W r (and resid_sum*X_means is already folded in or zero)
             // (solver.py:891-904 passes the un-corrected gradient with resid_sum == 0 when intercept; a warm start

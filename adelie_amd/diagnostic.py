@@ -17,10 +17,22 @@ def predict(X, betas, intercepts, offsets=None, n_threads: int = 1):
     (reference ``diagnostic.py:30-121``, single-response branch).  ``betas`` CSR goes through
     ``X.sp_tmul`` — one device kernel over the resident design."""
     intercepts = np.atleast_1d(intercepts)
-    if len(intercepts.shape) == 2:
-        raise NotImplementedError("adelie_amd.predict: multi-response is outside the hot path.")
+    is_multi = len(intercepts.shape) == 2
     if isinstance(X, np.ndarray):
         X = matrix.dense(X, method="naive", n_threads=n_threads)
+    if is_multi:  # (L, n, K) predictions through X (x) I_K  (diagnostic.py:84-88)
+        K = intercepts.shape[1]
+        n = X.rows()
+        X = matrix.kronecker_eye(X, K, n_threads=n_threads)
+        dtype = X.dtype
+        if offsets is None:
+            offsets = np.zeros((n, K), dtype=dtype)
+        if isinstance(betas, np.ndarray):
+            betas = csr_matrix(np.atleast_2d(betas))
+        L = betas.shape[0]
+        etas = np.zeros((L, n * K), order="C", dtype=dtype)
+        X.sp_tmul(betas, etas)
+        return etas.reshape(L, n, K) + intercepts[:, None] + offsets
     n = X.rows()
     dtype = X.dtype
     if offsets is None:

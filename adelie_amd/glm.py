@@ -110,6 +110,67 @@ def gaussian(y, *, weights=None, dtype=None, opt: bool = True):
     return _gaussian()
 
 
+class multiglm_base:
+    """Reference ``glm.py:57-80``: ``y`` is ``(n, K)``, one weight per observation."""
+
+    def __init__(self, y, weights, dtype):
+        self.y = np.array(y, copy=True, dtype=dtype)
+        self.dtype = dtype
+        if len(y.shape) != 2:
+            raise RuntimeError("y must be 2-dimensional.")
+        n = y.shape[0]
+        if weights is not None:
+            weights = np.asarray(weights)
+            if weights.shape != (n,):
+                raise RuntimeError("y rows and weights must have same length.")
+            weights_sum = np.sum(weights)
+            if not np.allclose(weights_sum, 1):
+                weights = weights / weights_sum
+        else:
+            weights = np.full(n, 1 / n, dtype=dtype)
+        self.weights = np.array(weights, copy=True, dtype=dtype)
+
+
+def multigaussian(y, *, weights=None, dtype=None, opt: bool = True):
+    """MultiGaussian family (reference ``adelie.glm.multigaussian``, ``glm.py:456-535``; arithmetic
+    ``glm_multigaussian.ipp:15-63``): ``loss = (1/K) sum_i w_i (||eta_i||^2 / 2 - y_i . eta_i)``.
+
+    Only the optimised route (``opt=True``: the Gaussian naive solver on ``[1 (x) I_K, X (x) I_K]``) is on the device
+    path; the IRLS route for multi-response GLMs is not."""
+    y, dtype = _coerce_dtype(y, dtype)
+    if not opt:
+        raise NotImplementedError("adelie_amd.glm.multigaussian: only opt=True is on the device path.")
+
+    class _multigaussian(multiglm_base, _mixin(dtype)):
+        name = "multigaussian"
+        is_multi = True
+
+        def __init__(self):
+            self.opt = opt
+            multiglm_base.__init__(self, y, weights, dtype)
+
+        def gradient(self, eta, grad):
+            grad[...] = (self.weights[:, None] * (self.y - eta)) / self.y.shape[1]
+
+        def hessian(self, eta, grad, hess):
+            hess[...] = self.weights[:, None] / self.y.shape[1]
+
+        def loss(self, eta):
+            return np.sum(self.weights * np.sum(0.5 * np.square(eta) - self.y * eta, axis=1)) / self.y.shape[1]
+
+        def loss_full(self):
+            return -0.5 * np.sum(np.square(self.y) * self.weights[:, None]) / self.y.shape[1]
+
+        def inv_link(self, eta, out):
+            out[...] = eta
+
+        def reweight(self, weights=None):
+            w = self.weights if weights is None else weights
+            return multigaussian(y=y, weights=w, dtype=dtype, opt=opt)
+
+    return _multigaussian()
+
+
 def binomial(y, *, weights=None, link: str = "logit", dtype=None):
     """Binomial family, logit link (reference ``adelie.glm.binomial``, ``glm.py:83-196``)."""
     if link != "logit":

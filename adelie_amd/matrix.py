@@ -267,6 +267,195 @@ def _wrap(backend, handle, dtype, n_threads, keep=None):
     return obj
 
 
+class _MultiView(_NativeMatrix):
+    """``[1 (x) I_K, X (x) I_K]`` (or ``X (x) I_K``) over a resident base design — what the reference assembles from
+    ``matrix.kronecker_eye`` and ``matrix.concatenate`` for multi-response fits (``state.py:1100-1125``).
+
+    The native handle (``adelie_hip_design_create_multi``) is what ``grpnet_solve`` runs on; the matrix plugin methods are
+    served here through the *base* design's device kernels, one response at a time
+    (``matrix_naive_kronecker_eye.ipp``: column ``j`` = (feature ``j // K``, response ``j % K``), vectors ``(n, K)`` C-order).
+    """
+
+    def _init_view(self, base, K, icpt):
+        self._base, self._K, self._icpt = base, int(K), 1 if icpt else 0
+
+    def _split(self, j):
+        u, l = divmod(int(j), self._K)
+        return u - self._icpt, l  # base column (-1: the column of ones), response
+
+    def _mat(self, v):
+        return np.asarray(v, dtype=self.dtype).reshape(-1, self._K)
+
+    def cmul(self, j, v, weights):
+        self._chk(0 <= j < self._cols and len(v) == self._rows and len(weights) == self._rows,
+                  "cmul() is given inconsistent inputs!")
+        f, l = self._split(j)
+        vl, wl = self._mat(v)[:, l], self._mat(weights)[:, l]
+        if f < 0:
+            return self.dtype(np.sum(vl * wl))
+        return self._base.cmul(f, vl, wl)
+
+    cmul_safe = cmul
+
+    def ctmul(self, j, v, out):
+        self._chk(0 <= j < self._cols and len(out) == self._rows, "ctmul() is given inconsistent inputs!")
+        f, l = self._split(j)
+        O = out.reshape(-1, self._K)
+        if f < 0:
+            O[:, l] += v
+            return
+        t = np.zeros(O.shape[0], dtype=self.dtype)
+        self._base.ctmul(f, v, t)
+        O[:, l] += t
+
+    def bmul(self, j, q, v, weights, out):
+        self._chk(0 <= j <= self._cols - q and len(v) == self._rows and len(weights) == self._rows and len(out) == q,
+                  "bmul() is given inconsistent inputs!")
+        for t in range(q):
+            out[t] = self.cmul(j + t, v, weights)
+
+    bmul_safe = bmul
+
+    def btmul(self, j, q, v, out):
+        self._chk(0 <= j <= self._cols - q and len(v) == q and len(out) == self._rows,
+                  "btmul() is given inconsistent inputs!")
+        K, I = self._K, self._icpt
+        full = np.zeros(self._cols, dtype=self.dtype)
+        full[j:j + q] = v
+        B = full.reshape(-1, K)  # (p + I, K)
+        O = out.reshape(-1, K)
+        pb = self._base.cols()
+        for l in range(K):
+            if I:
+                O[:, l] += B[0, l]
+            if np.any(B[I:, l]):
+                t = np.zeros(O.shape[0], dtype=self.dtype)
+                self._base.btmul(0, pb, np.ascontiguousarray(B[I:, l]), t)
+                O[:, l] += t
+
+    def mul(self, v, weights, out):
+        self._chk(len(v) == self._rows and len(weights) == self._rows and len(out) == self._cols,
+                  "mul() is given inconsistent inputs!")
+        K, I = self._K, self._icpt
+        V, W = self._mat(v), self._mat(weights)
+        O = np.empty((self._base.cols() + I, K), dtype=self.dtype)
+        t = np.empty(self._base.cols(), dtype=self.dtype)
+        for l in range(K):
+            vl, wl = np.ascontiguousarray(V[:, l]), np.ascontiguousarray(W[:, l])
+            if I:
+                O[0, l] = np.sum(vl * wl)
+            self._base.mul(vl, wl, t)
+            O[I:, l] = t
+        out[...] = O.ravel()
+
+    def cov(self, j, q, sqrt_weights, out):
+        self._chk(0 <= j <= self._cols - q and len(sqrt_weights) == self._rows and out.shape == (q, q),
+                  "cov() is given inconsistent inputs!")
+        SW = self._mat(sqrt_weights)
+        out[...] = 0
+        fs = [self._split(j + t) for t in range(q)]
+        for l in range(self._K):
+            idx = [t for t in range(q) if fs[t][1] == l]
+            if not idx:
+                continue
+            swl = np.ascontiguousarray(SW[:, l])
+            cols = [fs[t][0] for t in idx]
+            if min(cols) < 0:
+                self._chk(max(cols) < 0, "cov() across the intercept block and the feature block.")
+                for t in idx:
+                    out[t, t] = np.sum(swl ** 2)
+                continue
+            f0, nf = min(cols), max(cols) - min(cols) + 1
+            c = np.empty((nf, nf), dtype=self.dtype, order="F")
+            self._base.cov(f0, nf, swl, c)
+            for a, ta in enumerate(idx):
+                for b, tb in enumerate(idx):
+                    out[ta, tb] = c[cols[a] - f0, cols[b] - f0]
+
+    def sq_mul(self, weights, out):
+        self._chk(len(weights) == self._rows and len(out) == self._cols, "sq_mul() is given inconsistent inputs!")
+        K, I = self._K, self._icpt
+        W = self._mat(weights)
+        O = np.empty((self._base.cols() + I, K), dtype=self.dtype)
+        t = np.empty(self._base.cols(), dtype=self.dtype)
+        for l in range(K):
+            wl = np.ascontiguousarray(W[:, l])
+            if I:
+                O[0, l] = np.sum(wl)
+            self._base.sq_mul(wl, t)
+            O[I:, l] = t
+        out[...] = O.ravel()
+
+    def sp_tmul(self, v, out):
+        v = csr_matrix(v)
+        L = v.shape[0]
+        self._chk(v.shape[1] == self._cols and out.shape == (L, self._rows), "sp_tmul() is given inconsistent inputs!")
+        K, I = self._K, self._icpt
+        nb = self._base.rows()
+        O = np.zeros((L, nb, K), dtype=self.dtype)
+        vc = v.tocsc()
+        t = np.empty((L, nb), dtype=self.dtype)
+        for l in range(K):
+            if I:
+                O[:, :, l] += np.asarray(vc[:, l].todense()).reshape(L, 1)
+            self._base.sp_tmul(vc[:, I * K + l::K].tocsr(), t)
+            O[:, :, l] += t
+        out[...] = O.reshape(L, -1)
+
+    def alias(self):
+        raise NotImplementedError("adelie_amd: alias() of a multi-response view; alias the base design instead.")
+
+
+def _multi_view(base, K, intercept):
+    if not isinstance(base, _NativeMatrix) or isinstance(base, _MultiView):
+        raise RuntimeError("adelie_amd: the multi-response view needs a resident (dense) design as its base.")
+    if int(K) < 1:
+        raise RuntimeError("adelie_core: K must be >= 1.")
+    backend = base._backend
+    handle = _abi.C.c_void_p()
+    backend.check(backend.fn("design_create_multi")(base._handle, int(K), 1 if intercept else 0, handle))
+    mixin = MatrixNaiveBase64 if np.dtype(base.dtype) == np.float64 else MatrixNaiveBase32
+
+    class _view(_MultiView, mixin):
+        pass
+
+    _view.dtype = mixin.dtype
+    obj = _view()
+    obj._init_native(backend, handle, base._n_threads)
+    obj._init_view(base, K, intercept)
+    obj._keep = base
+    return obj
+
+
+def kronecker_eye(mat, K: int, *, n_threads: int = 1):
+    """``mat (x) I_K`` as a view of a resident design (reference ``adelie.matrix.kronecker_eye``,
+    ``matrix_naive_kronecker_eye.ipp``).  An ``(n, 1)`` array of ones is recognised as the intercept block that
+    :func:`concatenate` puts in front of ``kronecker_eye(X, K)``."""
+    if isinstance(mat, np.ndarray):
+        if mat.ndim == 2 and mat.shape[1] == 1 and np.all(mat == 1):
+            return _OnesKron(mat.shape[0], int(K), mat.dtype.type)
+        mat = dense(mat, method="naive", n_threads=n_threads)
+    return _multi_view(mat, K, False)
+
+
+class _OnesKron:
+    """``1_n (x) I_K`` — only meaningful as the first block of :func:`concatenate`."""
+
+    def __init__(self, n, K, dtype):
+        self.n, self.K, self.dtype = n, K, dtype
+
+
+def concatenate(mats, *, axis: int = 0, n_threads: int = 1):
+    """Reference ``adelie.matrix.concatenate``.  The device path offers exactly the combination the multi-response
+    solver uses (``state.py:1110-1120``): ``[kronecker_eye(ones((n, 1)), K), kronecker_eye(X, K)]`` along ``axis=1``."""
+    if (axis == 1 and len(mats) == 2 and isinstance(mats[0], _OnesKron) and isinstance(mats[1], _MultiView)
+            and mats[1]._icpt == 0 and mats[0].K == mats[1]._K and mats[0].n == mats[1]._base.rows()):
+        return _multi_view(mats[1]._base, mats[1]._K, True)
+    raise NotImplementedError(
+        "adelie_amd.matrix.concatenate: only [kronecker_eye(ones((n,1)), K), kronecker_eye(X, K)], axis=1 is on the "
+        "device path.")
+
+
 def dense(mat, *, method: str = "naive", copy: bool = False, n_threads: int = 1, device: int = 0):
     """Creates a dense design resident on an MI355X (reference ``adelie.matrix.dense``, ``matrix.py:549-680``).
 

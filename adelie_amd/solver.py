@@ -4,7 +4,8 @@ Same keyword arguments, same defaults, same preamble: the initial invariants are
 ``X.mul`` sweeps through the matrix plugin surface (reference ``solver.py:891-904``), the state object
 is built by ``adelie_amd.state`` and ``state.solve()`` runs the whole lambda path on the MI355X.
 
-Multi-response GLMs (``glm.is_multi``) are outside the hot path and raise.
+``glm.multigaussian`` runs the same solver on the expanded design ``[1 (x) I_K, X (x) I_K]``
+(reference ``solver.py:700-816``); the IRLS route for other multi-response families (multinomial) raises.
 """
 from typing import Callable
 
@@ -13,6 +14,7 @@ import numpy as np
 from . import matrix
 from .state import gaussian_naive as state_gaussian_naive
 from .state import glm_naive as state_glm_naive
+from .state import multigaussian_naive as state_multigaussian_naive
 
 
 def grpnet(
@@ -67,8 +69,9 @@ def grpnet(
     dtype = np.float64 if isinstance(X, matrix.MatrixNaiveBase64) else np.float32
     n, p = X.rows(), X.cols()
 
-    if getattr(glm, "is_multi", False):
-        raise NotImplementedError("adelie_amd.grpnet: multi-response GLMs are outside the hot path.")
+    is_multi = bool(getattr(glm, "is_multi", False))
+    if is_multi and not (glm.name == "multigaussian" and glm.opt):
+        raise NotImplementedError("adelie_amd.grpnet: of the multi-response GLMs only glm.multigaussian is on the device path.")
     if isinstance(constraints, list) and any(c is not None for c in constraints):
         raise NotImplementedError("adelie_amd.grpnet: constraints are outside the hot path (pass None).")
 
@@ -107,7 +110,6 @@ def grpnet(
         "pivot_subset_min": pivot_subset_min,
         "pivot_slack_ratio": pivot_slack_ratio,
     }
-    del X_raw
 
     is_gaussian_opt = (glm.name in ["gaussian", "multigaussian"]) and glm.opt  # solver.py:683-686
     if not is_gaussian_opt:
@@ -121,6 +123,10 @@ def grpnet(
     if groups is None:
         groups = np.arange(p, dtype=int)
     groups = np.asarray(groups, dtype=int)
+
+    if is_multi:
+        return _grpnet_multigaussian(X, glm, groups, penalty, offsets, intercept, alpha, warm_start, solver_args,
+                                     check_state, progress_bar, exit_cond, n, p, dtype, n_threads)
 
     # single-response GLMs: solver.py:846-950
     group_sizes = np.concatenate([groups, [p]], dtype=int)
@@ -222,4 +228,93 @@ def grpnet(
     if check_state:
         state.check(method="assert")
 
+    return state.solve(progress_bar=progress_bar, exit_cond=exit_cond)
+
+
+def _grpnet_multigaussian(X, glm, groups, penalty, offsets, intercept, alpha, warm_start, solver_args, check_state,
+                          progress_bar, exit_cond, n, p, dtype, n_threads):
+    """The multi-response branch of the reference's ``grpnet`` (``solver.py:700-816``) for ``glm.multigaussian``."""
+    K = glm.y.shape[-1]
+    groups = groups * K  # flatten the grouping index across the classes
+    if intercept:
+        groups = np.concatenate([np.arange(K), K + groups], dtype=int)
+    group_sizes = np.concatenate([groups, [(p + intercept) * K]], dtype=int)
+    group_sizes = group_sizes[1:] - group_sizes[:-1]
+    if penalty is None:
+        penalty = np.sqrt(group_sizes).astype(dtype)
+        if intercept:
+            penalty[:K] = 0
+    else:
+        penalty = np.asarray(penalty, dtype=dtype)
+        if intercept:
+            penalty = np.concatenate([np.zeros(K), penalty], dtype=dtype)
+
+    if warm_start is None:
+        lmda = np.inf
+        lmda_max = None
+        screen_set = np.arange(groups.shape[0])[(penalty <= 0) | (alpha <= 0)]
+        screen_beta = np.zeros(np.sum(group_sizes[screen_set]), dtype=dtype)
+        screen_is_active = np.ones(screen_set.shape[0], dtype=bool)
+        active_set_size = screen_set.shape[0]
+        active_set = np.empty(groups.shape[0], dtype=int)
+        active_set[:active_set_size] = np.arange(active_set_size)
+    else:
+        lmda = warm_start.lmda
+        lmda_max = warm_start.lmda_max
+        screen_set = warm_start.screen_set
+        screen_beta = warm_start.screen_beta
+        screen_is_active = warm_start.screen_is_active
+        active_set_size = warm_start.active_set_size
+        active_set = warm_start.active_set
+
+    solver_args.update(groups=groups, group_sizes=group_sizes, penalty=penalty, lmda=lmda, lmda_max=lmda_max,
+                       screen_set=screen_set, screen_beta=screen_beta, screen_is_active=screen_is_active,
+                       active_set_size=active_set_size, active_set=active_set)
+
+    y = glm.y
+    weights = glm.weights
+    weights_mscaled = weights / K
+    if warm_start is None:
+        ones = np.ones(n, dtype=dtype)
+        X_means = np.empty(p, dtype=dtype)
+        X.mul(ones, weights_mscaled, X_means)
+        X_means = np.repeat(X_means, K)
+        if intercept:
+            X_means = np.concatenate([np.full(K, 1 / K), X_means], dtype=dtype)
+        y_off = y - offsets
+        y_var = np.sum(weights_mscaled[:, None] * y_off ** 2)
+        # R^2 starts at (MSE of the intercept-only model) - y_var <= 0 and is brought to 0 by the fit of the unpenalised
+        # intercept columns; normalising by the centred variance then makes it relative to the intercept model
+        # (solver.py:760-772)
+        if intercept:
+            y_off_c = y_off - (y_off.T @ weights)[None]  # weights, not weights_mscaled (sic, solver.py:769)
+            yc_var = np.sum(weights_mscaled[:, None] * y_off_c ** 2)
+            rsq = yc_var - y_var
+            y_var = yc_var
+        else:
+            rsq = 0
+        resid = np.ascontiguousarray(y_off, dtype=dtype).ravel()
+        resid_sum = np.sum(weights_mscaled[:, None] * y_off)
+        # grad = X_aug^T (w' * resid): one sweep of the base design per response
+        G = np.empty((p + (1 if intercept else 0), K), dtype=dtype)
+        t = np.empty(p, dtype=dtype)
+        for l in range(K):
+            rl = np.ascontiguousarray(y_off[:, l], dtype=dtype)
+            X.mul(rl, weights_mscaled, t)
+            if intercept:
+                G[0, l] = np.sum(rl * weights_mscaled)
+                G[1:, l] = t
+            else:
+                G[:, l] = t
+        grad = G.ravel()
+    else:
+        X_means = warm_start.X_means
+        y_var = warm_start.y_var
+        rsq = warm_start.rsq
+        resid = warm_start.resid
+        resid_sum = warm_start.resid_sum
+        grad = warm_start.grad
+
+    solver_args.update(X_means=X_means, y_var=y_var, rsq=rsq, resid=resid, resid_sum=resid_sum, grad=grad)
+    state = state_multigaussian_naive(**solver_args)
     return state.solve(progress_bar=progress_bar, exit_cond=exit_cond)

@@ -417,6 +417,109 @@ def gaussian_naive(
     return s
 
 
+class multigaussian_naive_base(gaussian_naive_base):
+    """MultiGaussian naive state (reference ``state.py:2027-2391``): the Gaussian naive solver with the global intercept
+    off on the expanded design ``[1 (x) I_K, X (x) I_K]``; the per-response intercepts are its first ``K`` (unpenalised)
+    coefficients and are split off every solution (``solver_multigaussian_naive.hpp:31-44``, ``py_state.cpp:1352-1366``)."""
+
+    def _from_result_extra(self, new, backend, r, sc):
+        gaussian_naive_base._from_result_extra(self, new, backend, r, sc)
+        K = self.n_classes
+        L = new.betas.shape[0]
+        if self.multi_intercept:
+            B = new.betas.tocsc()
+            new.intercepts = np.asarray(B[:, :K].todense(), dtype=self.dtype).reshape(L, K)
+            new.betas = csr_matrix(B[:, K:].tocsr())
+        else:
+            new.intercepts = np.zeros((L, K), dtype=self.dtype)
+
+    def check(self, method: str = None, logger=logger):
+        raise NotImplementedError("adelie_amd: check() of the multi-response state.")
+
+
+def multigaussian_naive(
+    *, X, y, X_means, y_var, resid, resid_sum, constraints, groups, group_sizes, alpha, penalty, weights,
+    offsets, screen_set, screen_beta, screen_is_active, active_set_size, active_set, rsq, lmda, grad,
+    lmda_path=None, lmda_max=None, max_iters=int(1e5), tol=1e-7, adev_tol=0.9, ddev_tol=0, newton_tol=1e-12,
+    newton_max_iters=1000, n_threads=1, early_exit=True, intercept=True, screen_rule="pivot", min_ratio=1e-2,
+    lmda_path_size=100, max_screen_size=None, max_active_size=None, pivot_subset_ratio=0.1, pivot_subset_min=1,
+    pivot_slack_ratio=1.25,
+):
+    """Creates a MultiGaussian, naive method state object (reference ``adelie.state.multigaussian_naive``,
+    ``state.py:2027-2391``; argument meaning identical: ``X`` is the raw ``(n, p)`` design, ``y`` and ``offsets`` are
+    ``(n, K)``, ``groups`` / ``grad`` / ``X_means`` are in the expanded coordinates)."""
+    X_raw = _matrix_of(X, n_threads)
+    dtype = X_raw.dtype
+    y = np.asarray(y, dtype=dtype)
+    offsets = np.array(offsets, order="C", copy=True, dtype=dtype)
+    n, n_classes = offsets.shape
+    # state.py:1100-1125 (_render_multi_inputs)
+    X_exp = _matrix.kronecker_eye(X_raw, n_classes, n_threads=n_threads)
+    if intercept:
+        X_exp = _matrix.concatenate(
+            [_matrix.kronecker_eye(np.ones((n, 1), dtype=dtype), n_classes, n_threads=n_threads), X_exp],
+            axis=1, n_threads=n_threads)
+    (max_screen_size, max_active_size, lmda_path_size, setup_lmda_max, setup_lmda_path, lmda_max, lmda_path) = \
+        _render_inputs(groups=groups, lmda_max=lmda_max, lmda_path=lmda_path, lmda_path_size=lmda_path_size,
+                       max_screen_size=max_screen_size, max_active_size=max_active_size, dtype=dtype)
+    if len(X_means) != X_exp.cols():
+        raise RuntimeError("X_means must have the same length as the number of columns of X after reshaping.")
+    s = multigaussian_naive_base()
+    s.dtype = dtype
+    s._glm = _glm.multigaussian(y=y, weights=np.asarray(weights), dtype=dtype)
+    s.X = X_raw
+    s._X_raw = X_raw
+    s._X = X_exp            # what solve() runs on (the reference's `_X_expanded`)
+    s._X_expanded = X_exp
+    s.n_classes = int(n_classes)
+    s.multi_intercept = bool(intercept)
+    s.weights = np.repeat(s._glm.weights, n_classes) / n_classes  # state.py:2316
+    s._offsets = offsets
+    s.X_means = np.array(X_means, copy=True, dtype=dtype)
+    # state.py:2333-2337: not the mean of y; only enters loss_null / loss_full
+    s.y_mean = np.linalg.norm(np.sum(s._glm.weights[:, None] * (y - offsets), axis=-1) / n_classes)
+    s.y_var = y_var
+    s.resid = np.array(resid, copy=True, dtype=dtype).ravel()
+    s.resid_sum = resid_sum
+    s.constraints = constraints
+    s.groups = np.array(groups, copy=True, dtype=int)
+    s.group_sizes = np.array(group_sizes, copy=True, dtype=int)
+    s.alpha = alpha
+    s.penalty = np.array(penalty, copy=True, dtype=dtype)
+    s.lmda_path = np.asarray(lmda_path, dtype=dtype)
+    s.lmda_max = lmda_max
+    s.min_ratio = min_ratio
+    s.lmda_path_size = lmda_path_size
+    s.max_screen_size = max_screen_size
+    s.max_active_size = max_active_size
+    s.pivot_subset_ratio = pivot_subset_ratio
+    s.pivot_subset_min = pivot_subset_min
+    s.pivot_slack_ratio = pivot_slack_ratio
+    s.screen_rule = screen_rule
+    s.max_iters = max_iters
+    s.tol = tol
+    s.adev_tol = adev_tol
+    s.ddev_tol = ddev_tol
+    s.newton_tol = newton_tol
+    s.newton_max_iters = newton_max_iters
+    s.early_exit = early_exit
+    s.setup_lmda_max = setup_lmda_max
+    s.setup_lmda_path = setup_lmda_path
+    s.intercept = False     # the core state runs with the global intercept off (state.py:2364)
+    s.n_threads = n_threads
+    s.screen_set = np.asarray(screen_set, dtype=int)
+    s.screen_beta = np.asarray(screen_beta, dtype=dtype)
+    s.screen_is_active = np.asarray(screen_is_active, dtype=bool)
+    s.active_set_size = active_set_size
+    s.active_set = np.asarray(active_set, dtype=int)
+    s.rsq = rsq
+    s.lmda = lmda
+    s.grad = np.asarray(grad, dtype=dtype)
+    s.error = ""
+    s._check_shapes()
+    return s
+
+
 def glm_naive(
     *, X, glm, constraints, groups, group_sizes, alpha, penalty, offsets, screen_set, screen_beta, screen_is_active,
     active_set_size, active_set, beta0, lmda, grad, eta, resid, loss_full, loss_null=None, lmda_path=None,

@@ -88,6 +88,16 @@ int adelie_hip_design_create_snp_bed(const void* bed, int64_t n_bytes, int64_t n
  * (the folds of cv_grpnet) can run concurrently from different host threads: one path leaves most of the chip idle
  * while its sequential block solves run, two or three paths interleave.  The alias must be destroyed before `src`. */
 int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out);
+/* Multi-response view of a resident dense design: the (n*K) x ((p + intercept)*K) matrix
+ *     [ 1_n (x) I_K ,  X (x) I_K ]      (the first block only when `intercept` != 0)
+ * that adelie/state.py:1100-1125 (_render_multi_inputs) builds from matrix.kronecker_eye / matrix.concatenate
+ * (matrix_naive_kronecker_eye.ipp:27-47, matrix_naive_concatenate.ipp) and hands to StateMultiGaussianNaive.  Column j is
+ * (extended feature j / K, response j % K); vectors over the rows are (n, K) row-major, as in the reference.  Nothing is
+ * materialised: the view shares `base`'s matrix (which must outlive it) and owns a stream, scratch space and one column of
+ * ones.  adelie_hip_grpnet_solve on the view runs the Gaussian naive solver with every kernel reading a column of X once
+ * for all K responses.  The matrix-op entry points (cmul ... sp_tmul) are not offered on the view: the Python layer
+ * reaches them through `base`. */
+int adelie_hip_design_create_multi(adelie_hip_design* base, int64_t K, int intercept, adelie_hip_design** out);
 /* Copies the (p,) impute vector of an SNP design (as double). */
 int adelie_hip_design_impute(adelie_hip_design* d, double* out);
 int adelie_hip_design_destroy(adelie_hip_design* d);

@@ -1,0 +1,283 @@
+"""Multi-response (multigaussian) path — SURVEY.md 8(f) rank 3.
+
+CPU part: the oracle's restatement of ``concatenate([kronecker_eye(ones), kronecker_eye(X)])`` + the Gaussian naive solver
+(reference ``solver.py:700-816``, ``state.py:1100-1125,2027-2391``, ``matrix_naive_kronecker_eye.ipp``,
+``solver_multigaussian_naive.hpp:31-44``) is pinned against
+
+* the reference's own printed output: quickstart.ipynb cell 41-42 (n=100, p=1000, K=4, seed 0) shows
+  ``61/100 ... [dev:90.2%]``;
+* scikit-learn's ``MultiTaskLasso`` (an independent solver of the same objective up to the scaling
+  ``alpha_sklearn = lmda * sqrt(K) * K``);
+* first-principles KKT conditions;
+* the same solver run on the explicitly materialised Kronecker matrix.
+
+GPU part (``-m gpu``): the HIP path through the C ABI against the oracle on the same inputs.
+"""
+import numpy as np
+import pytest
+from scipy.sparse import csr_matrix
+
+import adelie_amd as ad
+from adelie_amd import matrix
+
+
+def make_multi(n, p, K, seed=0, nnz=4, dtype=np.float64, weights=False):
+    rng = np.random.RandomState(seed)
+    X = np.asfortranarray(rng.normal(size=(n, p)), dtype=dtype)
+    B = np.zeros((p, K))
+    B[rng.choice(p, nnz, replace=False)] = rng.normal(size=(nnz, K))
+    Y = (X @ B + 0.5 * rng.normal(size=(n, K)) + rng.normal(size=K)).astype(dtype)
+    w = None
+    if weights:
+        w = rng.uniform(1, 2, n)
+        w /= w.sum()
+    return X, Y, w
+
+
+def explicit(X, K, icpt):
+    n = X.shape[0]
+    Xa = np.kron(X, np.eye(K))
+    if icpt:
+        Xa = np.hstack([np.kron(np.ones((n, 1)), np.eye(K)), Xa])
+    return np.asfortranarray(Xa)
+
+
+def kkt_multi(X, Y, w, K, groups, group_sizes, penalty, alpha, intercept, betas, intercepts, lmdas):
+    """Worst violation of the stationarity conditions of
+    (1/K) sum_i w_i (||eta_i||^2/2 - y_i.eta_i) + lmda sum_g pen_g (alpha ||B_g|| + (1-alpha)/2 ||B_g||^2)."""
+    n, p = X.shape
+    if w is None:
+        w = np.full(n, 1 / n)
+    worst = 0.0
+    Bs = betas.toarray()
+    for l, lm in enumerate(lmdas):
+        B = Bs[l].reshape(p, K)
+        R = Y - X @ B - intercepts[l]
+        if intercept:
+            worst = max(worst, np.abs(w @ R).max() / K)
+        Gr = X.T @ (w[:, None] * R) / K
+        for g, gs, pen in zip(groups, group_sizes, penalty):
+            gg, bb = Gr[g:g + gs].ravel(), B[g:g + gs].ravel()
+            nb = np.linalg.norm(bb)
+            if nb == 0:
+                worst = max(worst, np.linalg.norm(gg) - lm * alpha * pen)
+            else:
+                worst = max(worst, np.linalg.norm(gg - lm * pen * (alpha * bb / nb + (1 - alpha) * bb)))
+    return worst
+
+
+@pytest.mark.parametrize("icpt", [False, True])
+def test_view_matches_explicit_kronecker(oracle, icpt):
+    rng = np.random.RandomState(0)
+    n, p, K = 7, 5, 3
+    X = np.asfortranarray(rng.normal(size=(n, p)))
+    V = matrix._multi_view(oracle.dense(X), K, icpt)
+    Xa = explicit(X, K, icpt)
+    assert V.shape == Xa.shape
+    v, w = rng.normal(size=n * K), rng.uniform(size=n * K)
+    out = np.empty(Xa.shape[1])
+    V.mul(v, w, out)
+    np.testing.assert_allclose(out, Xa.T @ (v * w), atol=1e-12)
+    for j in range(Xa.shape[1]):
+        np.testing.assert_allclose(V.cmul(j, v, w), Xa[:, j] @ (v * w), atol=1e-12)
+        o = np.zeros(n * K)
+        V.ctmul(j, 1.5, o)
+        np.testing.assert_allclose(o, 1.5 * Xa[:, j], atol=1e-12)
+    j, q = K, 2 * K
+    o, b = np.zeros(n * K), rng.normal(size=q)
+    V.btmul(j, q, b, o)
+    np.testing.assert_allclose(o, Xa[:, j:j + q] @ b, atol=1e-12)
+    c = np.empty((q, q))
+    V.cov(j, q, np.sqrt(w), c)
+    np.testing.assert_allclose(c, Xa[:, j:j + q].T @ (w[:, None] * Xa[:, j:j + q]), atol=1e-12)
+    o = np.empty(Xa.shape[1])
+    V.sq_mul(w, o)
+    np.testing.assert_allclose(o, (Xa ** 2).T @ w, atol=1e-12)
+    Bm = csr_matrix(rng.normal(size=(4, Xa.shape[1])) * (rng.uniform(size=(4, Xa.shape[1])) < 0.3))
+    o = np.empty((4, n * K))
+    V.sp_tmul(Bm, o)
+    np.testing.assert_allclose(o, (Xa @ Bm.T.toarray()).T, atol=1e-12)
+    if icpt:  # the reference's way of assembling it
+        V2 = matrix.concatenate([matrix.kronecker_eye(np.ones((n, 1)), K), matrix.kronecker_eye(oracle.dense(X), K)], axis=1)
+        assert V2.shape == V.shape
+    with pytest.raises(NotImplementedError):
+        matrix.concatenate([matrix.kronecker_eye(oracle.dense(X), K)] * 2, axis=0)
+
+
+def test_reference_quickstart_known_answer(oracle):
+    """quickstart.ipynb cells 41-42: ``61/100 ... [dev:90.2%]``."""
+    n, p, K = 100, 1000, 4
+    np.random.seed(0)
+    X = np.random.normal(0, 1, (n, p))
+    y = X[:, -1:] @ np.random.normal(0, 1, (1, K)) + np.random.normal(0, 1, (n, K))
+    s = ad.grpnet(X=oracle.dense(np.asfortranarray(X)), glm=ad.glm.multigaussian(y=y))
+    assert s.error == ""
+    assert len(s.lmdas) == 61
+    assert f"{100 * s.devs[-1]:.1f}" == "90.2" and s.devs[-2] < 0.9
+    assert s.betas.shape == (61, p * K) and s.intercepts.shape == (61, K)
+
+
+def test_oracle_vs_sklearn_multitask_lasso(oracle):
+    sk = pytest.importorskip("sklearn.linear_model")
+    X, Y, _ = make_multi(60, 30, 3, seed=1)
+    n, p, K = 60, 30, 3
+    s = ad.grpnet(X=oracle.dense(X), glm=ad.glm.multigaussian(Y), tol=1e-13, early_exit=False, lmda_path_size=20)
+    for l in (5, 12, 19):
+        m = sk.MultiTaskLasso(alpha=s.lmdas[l] * np.sqrt(K) * K, fit_intercept=True, tol=1e-14, max_iter=200000).fit(X, Y)
+        B = s.betas[l].toarray().reshape(p, K)
+        assert np.abs(B - m.coef_.T).max() < 1e-5  # resolution of sklearn's own stopping rule; KKT below is the certificate
+        assert np.abs(s.intercepts[l] - m.intercept_).max() < 1e-5
+
+
+@pytest.mark.parametrize("icpt", [False, True])
+@pytest.mark.parametrize("alpha", [1.0, 0.5])
+def test_oracle_kkt_and_explicit_matrix(oracle, icpt, alpha):
+    n, p, K = 50, 24, 3
+    X, Y, w = make_multi(n, p, K, seed=2, weights=True)
+    groups = np.array([0, 1, 2, 5, 6, 10, 11, 12, 20])
+    gs = np.diff(np.concatenate([groups, [p]]))
+    glm = ad.glm.multigaussian(Y, weights=w)
+    kw = dict(groups=groups, alpha=alpha, intercept=icpt, tol=1e-13, early_exit=False, lmda_path_size=15, min_ratio=5e-2)
+    s = ad.grpnet(X=oracle.dense(X), glm=glm, **kw)
+    assert s.error == "" and len(s.lmdas) == 15
+    pen = np.sqrt(gs * K)
+    v = kkt_multi(X, Y, glm.weights, K, groups, gs, pen, alpha, icpt, s.betas, s.intercepts, s.lmdas)
+    assert v < 1e-6, v
+    eta = ad.diagnostic.predict(oracle.dense(X), s.betas, s.intercepts)
+    assert eta.shape == (15, n, K)
+    np.testing.assert_allclose(eta[-1], X @ s.betas[-1].toarray().reshape(p, K) + s.intercepts[-1], atol=1e-12)
+    # the same state on the explicitly materialised matrix: identical algorithm, so the path agrees to rounding
+    st = ad.state.multigaussian_naive
+    Xa = oracle.dense(explicit(X, K, icpt))
+    s2 = _solve_on(Xa, X, glm, kw, oracle)
+    assert np.abs(s2.betas.toarray() - s.betas.toarray()).max() < 1e-9
+    np.testing.assert_allclose(s2.lmdas, s.lmdas, rtol=1e-12)
+
+
+def _solve_on(Xa, X, glm, kw, oracle):
+    """Builds the multigaussian state through grpnet's preamble, then swaps in `Xa` (a plain dense design holding the
+    materialised Kronecker matrix) as the matrix the solver runs on."""
+    captured = {}
+    real = ad.solver.state_multigaussian_naive
+
+    def spy(**a):
+        s = real(**a)
+        s._X = Xa
+        captured["s"] = s
+        return s
+
+    ad.solver.state_multigaussian_naive = spy
+    try:
+        return ad.grpnet(X=oracle.dense(X), glm=glm, **kw)
+    finally:
+        ad.solver.state_multigaussian_naive = real
+
+
+def test_multi_errors(oracle):
+    X, Y, _ = make_multi(20, 6, 2)
+    with pytest.raises(RuntimeError):
+        ad.glm.multigaussian(Y[:, 0])
+    with pytest.raises(NotImplementedError):
+        ad.glm.multigaussian(Y, opt=False)
+    with pytest.raises(RuntimeError):
+        matrix._multi_view(oracle.dense(X), 0, True)
+
+
+# ---- HIP path ----------------------------------------------------------------------------------------------------------
+def _both(oracle, X, glm, **kw):
+    a = ad.grpnet(X=ad.matrix.dense(X), glm=glm, **kw)
+    b = ad.grpnet(X=oracle.dense(X), glm=glm, **kw)
+    return a, b
+
+
+def _assert_same(a, b, atol):
+    assert a.error == "" and b.error == "", (a.error, b.error)
+    assert len(a.lmdas) == len(b.lmdas)
+    f32 = np.asarray(a.lmdas).dtype == np.float32
+    np.testing.assert_allclose(a.lmdas, b.lmdas, rtol=1e-4 if f32 else 1e-9)
+    assert np.abs(a.betas.toarray() - b.betas.toarray()).max() <= atol
+    assert np.abs(a.intercepts - b.intercepts).max() <= atol
+    assert np.abs(np.asarray(a.devs) - np.asarray(b.devs)).max() <= 10 * atol
+    assert sorted(a.screen_set.tolist()) == sorted(b.screen_set.tolist())
+    np.testing.assert_allclose(a.resid, b.resid, atol=10 * atol)
+    np.testing.assert_allclose(a.grad, b.grad, atol=10 * atol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 8, 11])
+@pytest.mark.parametrize("icpt", [False, True])
+def test_hip_multigaussian_matches_oracle(hip, oracle, K, icpt):
+    X, Y, w = make_multi(203, 40, K, seed=K, weights=True)
+    glm = ad.glm.multigaussian(Y, weights=w)
+    a, b = _both(oracle, X, glm, intercept=icpt, tol=1e-12, early_exit=False, lmda_path_size=25)
+    _assert_same(a, b, 1e-8)
+    assert a.betas.shape == (25, 40 * K) and a.intercepts.shape == (25, K)
+    assert a.counters["n_panel_blocks"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alpha", [1.0, 0.3])
+def test_hip_multigaussian_feature_groups(hip, oracle, alpha):
+    n, p, K = 300, 60, 3
+    X, Y, w = make_multi(n, p, K, seed=5, nnz=8)
+    rng = np.random.RandomState(3)
+    groups = np.sort(np.concatenate([[0], rng.choice(np.arange(1, p), 19, replace=False)]))
+    gs = np.diff(np.concatenate([groups, [p]]))
+    glm = ad.glm.multigaussian(Y)
+    kw = dict(groups=groups, alpha=alpha, tol=1e-12, early_exit=False, lmda_path_size=30)
+    a, b = _both(oracle, X, glm, **kw)
+    _assert_same(a, b, 1e-8)
+    v = kkt_multi(X, Y, glm.weights, K, groups, gs, np.sqrt(gs * K), alpha, True, a.betas, a.intercepts, a.lmdas)
+    assert v < 1e-5, v
+
+
+@pytest.mark.gpu
+def test_hip_multigaussian_many_blocks_and_f32(hip, oracle):
+    # enough screened columns for several 128-value blocks per pass, odd n (scalar loads), C-ordered input
+    n, p, K = 1001, 400, 4
+    X, Y, _ = make_multi(n, p, K, seed=9, nnz=40)
+    glm = ad.glm.multigaussian(Y)
+    a, b = _both(oracle, X, glm, tol=1e-11, early_exit=False, lmda_path_size=30, min_ratio=1e-2)
+    _assert_same(a, b, 1e-7)
+    assert a.screen_set.size * K > 256
+    X32, Y32 = np.ascontiguousarray(X, dtype=np.float32), Y.astype(np.float32)
+    # (the default newton_tol = 1e-12 is below float32 resolution: both the oracle and the HIP path then report the
+    #  reference's "Newton-ABS max iterations reached" error)
+    a32, b32 = _both(oracle, X32, ad.glm.multigaussian(Y32), tol=1e-6, newton_tol=1e-6, lmda_path_size=20, early_exit=False)
+    assert a32.error == "" and len(a32.lmdas) == len(b32.lmdas)
+    assert np.abs(a32.betas.toarray() - b32.betas.toarray()).max() < 2e-3
+    assert np.abs(a32.intercepts - b32.intercepts).max() < 2e-3
+
+
+@pytest.mark.gpu
+def test_hip_multigaussian_reference_quickstart(hip):
+    n, p, K = 100, 1000, 4
+    np.random.seed(0)
+    X = np.random.normal(0, 1, (n, p))
+    y = X[:, -1:] @ np.random.normal(0, 1, (1, K)) + np.random.normal(0, 1, (n, K))
+    s = ad.grpnet(X=ad.matrix.dense(np.asfortranarray(X)), glm=ad.glm.multigaussian(y=y))
+    assert s.error == "" and len(s.lmdas) == 61 and f"{100 * s.devs[-1]:.1f}" == "90.2"
+
+
+@pytest.mark.gpu
+def test_hip_multigaussian_warm_start_and_predict(hip, oracle):
+    X, Y, _ = make_multi(150, 30, 3, seed=4)
+    glm = ad.glm.multigaussian(Y)
+    Xd = ad.matrix.dense(X)
+    full = ad.grpnet(X=Xd, glm=glm, tol=1e-12, early_exit=False, lmda_path_size=20)
+    head = ad.grpnet(X=Xd, glm=glm, tol=1e-12, early_exit=False, lmda_path=full.lmdas[:10])
+    # warm_start takes the raw (pre-tidy) invariants of the solved state
+    tail = ad.grpnet(X=Xd, glm=glm, tol=1e-12, early_exit=False, lmda_path=full.lmdas[10:], warm_start=head)
+    assert tail.error == ""
+    assert np.abs(tail.betas.toarray() - full.betas[10:].toarray()).max() < 1e-7
+    eta = ad.diagnostic.predict(Xd, full.betas, full.intercepts)
+    np.testing.assert_allclose(eta[-1], X @ full.betas[-1].toarray().reshape(30, 3) + full.intercepts[-1], atol=1e-10)
+    with pytest.raises(RuntimeError):  # the view only serves the solver
+        out = np.empty(full._X.cols())
+        _abi_mul(full._X, out)
+
+
+def _abi_mul(V, out):
+    from adelie_amd import _abi
+    v = np.zeros(V.rows())
+    V._backend.check(V._backend.fn("design_mul")(V._handle, v.ctypes.data, v.ctypes.data, out.ctypes.data))

@@ -62,8 +62,13 @@ __device__ __forceinline__ T glm_grad(int kind, T y, T w, T eta) {
     if (kind == ADELIE_HIP_GLM_BINOMIAL_LOGIT) return w * (y - T(1) / (T(1) + exp(-eta)));
     return w * (y - eta);
 }
+// multinomial (glm_multinomial.ipp:47-66): w is the observation weight repeated for every class, K the class count
 template <class T>
-__device__ __forceinline__ T glm_hess(int kind, T y, T w, T grad) {
+__device__ __forceinline__ T glm_hess(int kind, T y, T w, T grad, int K = 1) {
+    if (kind == ADELIE_HIP_GLM_MULTINOMIAL) {
+        const T h = y * w / T(K) - grad;
+        return h * (T(2) * (T(1) - T(K) * (h / (w + T(w <= T(0))))));
+    }
     if (kind == ADELIE_HIP_GLM_BINOMIAL_LOGIT) {
         const T h = w * y - grad;
         return (h * (w - h)) / (w + T(w <= T(0)));
@@ -78,10 +83,10 @@ __global__ __launch_bounds__(RT) void irls_prepare_kernel(int kind, const T* __r
                                                           const T* __restrict__ eta, const T* __restrict__ resid,
                                                           const T* __restrict__ off, T hmin, int64_t n,
                                                           T* __restrict__ hess, T* __restrict__ irls_resid,
-                                                          T* __restrict__ irls_y, T* sums) {
+                                                          T* __restrict__ irls_y, T* sums, int K) {
     T acc[1] = {T(0)};
     GRID_STRIDE(i, n) {
-        const T h0 = glm_hess(kind, y[i], w[i], resid[i]);
+        const T h0 = glm_hess(kind, y[i], w[i], resid[i], K);
         const T h = (h0 > T(0) ? h0 : T(0)) + hmin * T(h0 <= T(0));
         const T z = resid[i] / h; // inv_hessian_gradient uses the same raised hessian (glm_base.ipp:32-36)
         hess[i] = h;
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(RT) void irls_finish_kernel(int kind, const T* __re
     GRID_STRIDE(i, n) {
         const T e = irls_y[i] + off[i] - irls_resid[i] + shift;
         eta[i] = e;
-        resid[i] = glm_grad(kind, y[i], w[i], e);
+        if (kind != ADELIE_HIP_GLM_MULTINOMIAL) resid[i] = glm_grad(kind, y[i], w[i], e); // multinomial: row-coupled, below
     }
 }
 
@@ -162,16 +167,52 @@ __global__ __launch_bounds__(RT) void glm_loss2_kernel(int kind, const T* __rest
 template <class T>
 __global__ __launch_bounds__(RT) void null_step_kernel(int kind, const T* __restrict__ y, const T* __restrict__ w,
                                                        const T* __restrict__ eta, const T* __restrict__ resid,
-                                                       const T* __restrict__ off, T hmin, int64_t n, T* sums) {
+                                                       const T* __restrict__ off, T hmin, int64_t n, T* sums, int K) {
     T acc[2] = {T(0), T(0)};
     GRID_STRIDE(i, n) {
-        const T h0 = glm_hess(kind, y[i], w[i], resid[i]);
+        const T h0 = glm_hess(kind, y[i], w[i], resid[i], K);
         const T h = (h0 > T(0) ? h0 : T(0)) + hmin * T(h0 <= T(0));
         const T z = resid[i] / h;
         acc[0] += h;
         acc[1] += h * (z + eta[i] - off[i]);
     }
     block_partials<T, 2>(acc, sums);
+}
+
+// multinomial gradient / loss (glm_multinomial.ipp:21-45, 68-87) on response-major (nb, K) arrays: element (i, k) at
+// [k*nb + i]; one thread per observation walks its K classes (coalesced across threads for every k)
+template <class T>
+__global__ __launch_bounds__(RT) void multinomial_gradient_kernel(const T* __restrict__ y, const T* __restrict__ w,
+                                                                  const T* __restrict__ eta, int64_t nb, int K,
+                                                                  T* __restrict__ resid) {
+    GRID_STRIDE(i, nb) {
+        T mx = eta[i];
+        for (int k = 1; k < K; ++k) mx = max(mx, eta[int64_t(k) * nb + i]);
+        T sum = T(0);
+        for (int k = 0; k < K; ++k) sum += exp(eta[int64_t(k) * nb + i] - mx);
+        const T wk = w[i] / T(K);
+        for (int k = 0; k < K; ++k) {
+            const int64_t q = int64_t(k) * nb + i;
+            resid[q] = (y[q] - exp(eta[q] - mx) / sum) * wk;
+        }
+    }
+}
+template <class T>
+__global__ __launch_bounds__(RT) void multinomial_loss_kernel(const T* __restrict__ y, const T* __restrict__ w,
+                                                              const T* __restrict__ eta, int64_t nb, int K, T* sums) {
+    T acc[1] = {T(0)};
+    GRID_STRIDE(i, nb) {
+        T mx = eta[i];
+        for (int k = 1; k < K; ++k) mx = max(mx, eta[int64_t(k) * nb + i]);
+        T ye = T(0), se = T(0);
+        for (int k = 0; k < K; ++k) {
+            const int64_t q = int64_t(k) * nb + i;
+            ye += y[q] * (eta[q] - mx);
+            se += exp(eta[q] - mx);
+        }
+        acc[0] += w[i] * (-ye + log(se)) / T(K);
+    }
+    block_partials<T, 1>(acc, sums);
 }
 
 template <class T>
@@ -204,9 +245,9 @@ void finish(T* sums, int K, hipStream_t s) {
 
 template <class T>
 void launch_irls_prepare(int kind, const T* y, const T* w, const T* eta, const T* resid, const T* offsets, T hessian_min,
-                         int64_t n, T* hess, T* irls_resid, T* irls_y, T* sums, hipStream_t s) {
+                         int64_t n, T* hess, T* irls_resid, T* irls_y, T* sums, hipStream_t s, int K) {
     hipLaunchKernelGGL((irls_prepare_kernel<T>), dim3(RB), dim3(RT), 0, s, kind, y, w, eta, resid, offsets, hessian_min,
-                       n, hess, irls_resid, irls_y, sums);
+                       n, hess, irls_resid, irls_y, sums, K);
     finish(sums, 1, s);
 }
 template <class T>
@@ -218,17 +259,26 @@ void launch_irls_weights(const T* hess, T hess_sum, const T* irls_y, T shift, in
 }
 template <class T>
 void launch_irls_finish(int kind, const T* y, const T* w, const T* irls_y, const T* offsets, const T* irls_resid, T shift,
-                        int64_t n, T* eta, T* resid, T* /*sums*/, hipStream_t s) {
+                        int64_t n, T* eta, T* resid, T* /*sums*/, hipStream_t s, int K) {
     hipLaunchKernelGGL((irls_finish_kernel<T>), dim3(RB), dim3(RT), 0, s, kind, y, w, irls_y, offsets, irls_resid, shift,
                        n, eta, resid);
+    if (kind == ADELIE_HIP_GLM_MULTINOMIAL)
+        hipLaunchKernelGGL((multinomial_gradient_kernel<T>), dim3(RB), dim3(RT), 0, s, y, w, eta, n / K, K, resid);
 }
 template <class T>
-void launch_glm_gradient(int kind, const T* y, const T* w, const T* eta, int64_t n, T* resid, hipStream_t s) {
+void launch_glm_gradient(int kind, const T* y, const T* w, const T* eta, int64_t n, T* resid, hipStream_t s, int K) {
+    if (kind == ADELIE_HIP_GLM_MULTINOMIAL) {
+        hipLaunchKernelGGL((multinomial_gradient_kernel<T>), dim3(RB), dim3(RT), 0, s, y, w, eta, n / K, K, resid);
+        return;
+    }
     hipLaunchKernelGGL((glm_gradient_kernel<T>), dim3(RB), dim3(RT), 0, s, kind, y, w, eta, n, resid);
 }
 template <class T>
-void launch_glm_loss(int kind, const T* y, const T* w, const T* eta, int64_t n, T* sums, hipStream_t s) {
-    hipLaunchKernelGGL((glm_loss_kernel<T>), dim3(RB), dim3(RT), 0, s, kind, y, w, eta, n, sums);
+void launch_glm_loss(int kind, const T* y, const T* w, const T* eta, int64_t n, T* sums, hipStream_t s, int K) {
+    if (kind == ADELIE_HIP_GLM_MULTINOMIAL)
+        hipLaunchKernelGGL((multinomial_loss_kernel<T>), dim3(RB), dim3(RT), 0, s, y, w, eta, n / K, K, sums);
+    else
+        hipLaunchKernelGGL((glm_loss_kernel<T>), dim3(RB), dim3(RT), 0, s, kind, y, w, eta, n, sums);
     finish(sums, 1, s);
 }
 template <class T>
@@ -239,9 +289,9 @@ void launch_glm_loss2(int kind, const T* y, const T* wa, const T* wb, const T* b
 }
 template <class T>
 void launch_null_step(int kind, const T* y, const T* w, const T* eta, const T* resid, const T* offsets, T hessian_min,
-                      int64_t n, T* sums, hipStream_t s) {
+                      int64_t n, T* sums, hipStream_t s, int K) {
     hipLaunchKernelGGL((null_step_kernel<T>), dim3(RB), dim3(RT), 0, s, kind, y, w, eta, resid, offsets, hessian_min, n,
-                       sums);
+                       sums, K);
     finish(sums, 2, s);
 }
 template <class T>
@@ -261,16 +311,16 @@ void launch_gather(const T* src, const int32_t* idx, int64_t cnt, T* dst, hipStr
 
 #define INST(T)                                                                                                        \
     template void launch_irls_prepare<T>(int, const T*, const T*, const T*, const T*, const T*, T, int64_t, T*, T*,    \
-                                         T*, T*, hipStream_t);                                                         \
+                                         T*, T*, hipStream_t, int);                                                       \
     template void launch_irls_weights<T>(const T*, T, const T*, T, int64_t, T*, T*, T*, hipStream_t);                  \
     template void launch_irls_finish<T>(int, const T*, const T*, const T*, const T*, const T*, T, int64_t, T*, T*, T*, \
-                                        hipStream_t);                                                                  \
-    template void launch_glm_gradient<T>(int, const T*, const T*, const T*, int64_t, T*, hipStream_t);                 \
-    template void launch_glm_loss<T>(int, const T*, const T*, const T*, int64_t, T*, hipStream_t);                     \
+                                        hipStream_t, int);                                                                \
+    template void launch_glm_gradient<T>(int, const T*, const T*, const T*, int64_t, T*, hipStream_t, int);              \
+    template void launch_glm_loss<T>(int, const T*, const T*, const T*, int64_t, T*, hipStream_t, int);                  \
     template void launch_glm_loss2<T>(int, const T*, const T*, const T*, const T*, T, const T*, int64_t, T*,           \
                                       hipStream_t);                                                                    \
     template void launch_null_step<T>(int, const T*, const T*, const T*, const T*, const T*, T, int64_t, T*,           \
-                                      hipStream_t);                                                                    \
+                                      hipStream_t, int);                                                                  \
     template void launch_set_eta<T>(const T*, T, int64_t, T*, hipStream_t);                                            \
     template void launch_dot_diff<T>(const T*, const T*, const T*, const T*, int64_t, T*, hipStream_t);                \
     template void launch_gather<T>(const T*, const int32_t*, int64_t, T*, hipStream_t);

@@ -31,20 +31,20 @@ double g_dbeta_tol = 1e-12;
 // elementwise GLM kernels (kernels_glm.hip)
 template <class T>
 void launch_irls_prepare(int kind, const T* y, const T* w, const T* eta, const T* resid, const T* offsets, T hessian_min,
-                         int64_t n, T* hess, T* irls_resid, T* irls_y, T* sums4, hipStream_t s);
+                         int64_t n, T* hess, T* irls_resid, T* irls_y, T* sums4, hipStream_t s, int K = 1);
 template <class T>
 void launch_irls_weights(const T* hess, T hess_sum, const T* irls_y, T shift, int64_t n, T* wts, T* irls_resid,
                          T* sums3, hipStream_t s);
 template <class T>
 void launch_irls_finish(int kind, const T* y, const T* w, const T* irls_y, const T* offsets, const T* irls_resid, T shift,
-                        int64_t n, T* eta, T* resid, T* sums2, hipStream_t s);
+                        int64_t n, T* eta, T* resid, T* sums2, hipStream_t s, int K = 1);
 template <class T>
-void launch_glm_gradient(int kind, const T* y, const T* w, const T* eta, int64_t n, T* resid, hipStream_t s);
+void launch_glm_gradient(int kind, const T* y, const T* w, const T* eta, int64_t n, T* resid, hipStream_t s, int K = 1);
 template <class T>
-void launch_glm_loss(int kind, const T* y, const T* w, const T* eta, int64_t n, T* out1, hipStream_t s);
+void launch_glm_loss(int kind, const T* y, const T* w, const T* eta, int64_t n, T* out1, hipStream_t s, int K = 1);
 template <class T>
 void launch_null_step(int kind, const T* y, const T* w, const T* eta, const T* resid, const T* offsets, T hessian_min,
-                      int64_t n, T* sums2, hipStream_t s);
+                      int64_t n, T* sums2, hipStream_t s, int K = 1);
 template <class T>
 void launch_set_eta(const T* offsets, T beta0, int64_t n, T* eta, hipStream_t s);
 template <class T>
@@ -331,10 +331,11 @@ struct Solver {
     bool dense() const { return D->kind == 0; }
     // multi-response view (adelie_hip_design_create_multi): residual / weights live response-major on the device
     bool multi() const { return D->kind == 2; }
+    int mk() const { return D->kind == 2 ? int(D->mK) : 1; } // class count handed to the GLM kernels
     bool multi_w_uniform = true;
     std::vector<int32_t> h_vcol, h_actcols, multi_seen; // host mirrors of d_vcol / d_actcols (block column lists)
     DevBuf<int32_t> d_mlist, d_mlist2;
-    DevBuf<T> d_mC, d_mC2;
+    DevBuf<T> d_mC, d_mC2, d_mxm;
     const int32_t* host_cols(const int32_t* dev) const {
         if (dev >= d_vcol.p && dev < d_vcol.p + h_vcol.size()) return h_vcol.data() + (dev - d_vcol.p);
         if (dev >= d_actcols.p && dev < d_actcols.p + h_actcols.size()) return h_actcols.data() + (dev - d_actcols.p);
@@ -1565,7 +1566,7 @@ struct Solver {
             // :336-348
             T sums[4];
             launch_irls_prepare<T>(glm_kind, d_y.p, d_gw.p, d_eta.p, d_r.p, d_off.p, hmin, n, d_hess.p, d_irls_resid.p,
-                                   d_irls_y.p, d_sums.p, st);
+                                   d_irls_y.p, d_sums.p, st, mk());
             d_sums.download(sums, 1, st);
             sync();
             const T hess_sum = sums[0];
@@ -1590,7 +1591,13 @@ struct Solver {
             }
             // :361-385  X_means on the screen columns and all screen-derived quantities under the IRLS weights
             if (nv > 0) {
-                sweep(d_irls_w.p, d_g.p, d_vcol.p, nv, nullptr, nullptr); // means by value
+                if (multi()) { // the view's sweep covers all columns in one pass over X; pick the screen values out of it
+                    d_mxm.reserve(size_t(p));
+                    sweep(d_irls_w.p, d_mxm.p, nullptr, p, nullptr, nullptr);
+                    launch_gather<T>(d_mxm.p, d_vcol.p, nv, d_g.p, st);
+                } else {
+                    sweep(d_irls_w.p, d_g.p, d_vcol.p, nv, nullptr, nullptr); // means by value
+                }
                 std::vector<T> m(nv);
                 d_g.download(m.data(), size_t(nv), st);
                 sync();
@@ -1630,7 +1637,7 @@ struct Solver {
             std::swap(d_eta.p, d_eta_prev.p);
             std::swap(d_r.p, d_resid_prev.p);
             launch_irls_finish<T>(glm_kind, d_y.p, d_gw.p, d_irls_y.p, d_off.p, d_irls_resid.p,
-                                  intercept ? (beta0 - ym) : T(0), n, d_eta.p, d_r.p, d_sums.p, st);
+                                  intercept ? (beta0 - ym) : T(0), n, d_eta.p, d_r.p, d_sums.p, st, mk());
             launch_dot_diff<T>(d_r.p, d_resid_prev.p, d_eta.p, d_eta_prev.p, n, d_sums.p, st);
             const T conv = device_scalar(d_sums.p);
             if (std::abs(conv) <= irls_tol) {
@@ -1646,8 +1653,46 @@ struct Solver {
 
     // update_loss_null, solver_glm_naive.hpp:160-232
     void update_loss_null() {
+        if (multi() && D->micpt) { // solver_multiglm_naive.hpp:99-184: intercept-only model with one intercept per class
+            const int64_t nb_ = D->nb;
+            const int K_ = int(D->mK);
+            DevBuf<T> e, r, e_prev, r_prev;
+            e.reserve(n); r.reserve(n); e_prev.reserve(n); r_prev.reserve(n);
+            AHIP_CHECK(hipMemcpyAsync(e.p, d_eta.p, n * sizeof(T), hipMemcpyDeviceToDevice, st));
+            AHIP_CHECK(hipMemcpyAsync(r.p, d_r.p, n * sizeof(T), hipMemcpyDeviceToDevice, st));
+            size_t it = 0;
+            const T hmin = T(g_hessian_min);
+            std::vector<T> b0(size_t(K_), T(0));
+            while (1) {
+                if (it >= irls_max_iters) throw make_solver_error("Maximum IRLS iterations reached.");
+                // per class: sum of raised hessians and of hess * working response; the common 1 / hess_sum cancels
+                for (int l = 0; l < K_; ++l) {
+                    const int64_t o = int64_t(l) * nb_;
+                    T sums[2];
+                    launch_null_step<T>(glm_kind, d_y.p + o, d_gw.p + o, e.p + o, r.p + o, d_off.p + o, hmin, nb_, d_sums.p, st, K_);
+                    d_sums.download(sums, 2, st);
+                    sync();
+                    b0[size_t(l)] = sums[1] / sums[0];
+                }
+                std::swap(e.p, e_prev.p);
+                for (int l = 0; l < K_; ++l) {
+                    const int64_t o = int64_t(l) * nb_;
+                    launch_set_eta<T>(d_off.p + o, b0[size_t(l)], nb_, e.p + o, st);
+                }
+                std::swap(r.p, r_prev.p);
+                launch_glm_gradient<T>(glm_kind, d_y.p, d_gw.p, e.p, n, r.p, st, K_);
+                launch_dot_diff<T>(r.p, r_prev.p, e.p, e_prev.p, n, d_sums.p, st);
+                const T conv = device_scalar(d_sums.p);
+                if (std::abs(conv) <= irls_tol) {
+                    launch_glm_loss<T>(glm_kind, d_y.p, d_gw.p, e.p, n, d_sums.p, st, K_);
+                    loss_null = device_scalar(d_sums.p);
+                    return;
+                }
+                ++it;
+            }
+        }
         if (!intercept) {
-            launch_glm_loss<T>(glm_kind, d_y.p, d_gw.p, d_off.p, n, d_sums.p, st);
+            launch_glm_loss<T>(glm_kind, d_y.p, d_gw.p, d_off.p, n, d_sums.p, st, mk());
             loss_null = device_scalar(d_sums.p);
             return;
         }
@@ -1661,18 +1706,18 @@ struct Solver {
         while (1) {
             if (it >= irls_max_iters) throw make_solver_error("Maximum IRLS iterations reached.");
             T sums[2];
-            launch_null_step<T>(glm_kind, d_y.p, d_gw.p, e.p, r.p, d_off.p, hmin, n, d_sums.p, st);
+            launch_null_step<T>(glm_kind, d_y.p, d_gw.p, e.p, r.p, d_off.p, hmin, n, d_sums.p, st, mk());
             d_sums.download(sums, 2, st);
             sync();
             b0 = sums[1] / sums[0];
             std::swap(e.p, e_prev.p);
             launch_set_eta<T>(d_off.p, b0, n, e.p, st);
             std::swap(r.p, r_prev.p);
-            launch_glm_gradient<T>(glm_kind, d_y.p, d_gw.p, e.p, n, r.p, st);
+            launch_glm_gradient<T>(glm_kind, d_y.p, d_gw.p, e.p, n, r.p, st, mk());
             launch_dot_diff<T>(r.p, r_prev.p, e.p, e_prev.p, n, d_sums.p, st);
             const T conv = device_scalar(d_sums.p);
             if (std::abs(conv) <= irls_tol) {
-                launch_glm_loss<T>(glm_kind, d_y.p, d_gw.p, e.p, n, d_sums.p, st);
+                launch_glm_loss<T>(glm_kind, d_y.p, d_gw.p, e.p, n, d_sums.p, st, mk());
                 loss_null = device_scalar(d_sums.p);
                 return;
             }
@@ -1738,7 +1783,7 @@ struct Solver {
         intercepts.push_back(fo.intercept);
         lmdas.push_back(lm);
         if (is_glm()) { // solver_glm_naive.hpp:153-157
-            launch_glm_loss<T>(glm_kind, d_y.p, d_gw.p, d_eta.p, n, d_sums.p, st);
+            launch_glm_loss<T>(glm_kind, d_y.p, d_gw.p, d_eta.p, n, d_sums.p, st, mk());
             const T loss = device_scalar(d_sums.p);
             devs.push_back((loss_null - loss) / (loss_null - loss_full));
         } else {
@@ -1886,6 +1931,10 @@ struct Solver {
         if (multi()) { // back to the ABI's (n, K) row-major layout
             std::vector<T> tmp(resid);
             from_major(tmp.data(), resid.data());
+            if (is_glm()) {
+                tmp = eta;
+                from_major(tmp.data(), eta.data());
+            }
         }
     }
 
@@ -1962,7 +2011,10 @@ struct Solver {
         if (multi()) {
             // StateMultiGaussianNaive (state.py:2300-2380): the Gaussian naive solver, global intercept off, on the view.
             // Everything runs on the group panel engine (its blocks are what lets a column slice serve K responses).
-            if (is_glm()) throw make_core_error("a multi-response view only supports the Gaussian (multigaussian) solver.");
+            if (is_glm() && glm_kind != ADELIE_HIP_GLM_MULTINOMIAL)
+                throw make_core_error("a multi-response view supports the multigaussian and multinomial families only.");
+            if (glm_kind == ADELIE_HIP_GLM_MULTINOMIAL && D->mK < 2)
+                throw make_core_error("y must have at least 2 columns (classes).");
             if (intercept) throw make_core_error("a multi-response view is solved with intercept = false (the intercepts are its first K columns).");
             if (max_gs > idx(cd_block_size()))
                 throw make_core_error("multi-response groups (group size x K) must not exceed " + std::to_string(cd_block_size()) + " columns.");
@@ -1970,6 +2022,8 @@ struct Solver {
             engine_panel = true;
             group_panel = true;
             cd_block_min_nv = 0;
+        } else if (glm_kind == ADELIE_HIP_GLM_MULTINOMIAL) {
+            throw make_core_error("the multinomial family needs a multi-response view as its design.");
         }
         // device allocations
         d_r.reserve(n); d_v.reserve(n); d_grad.reserve(p); d_absgrad.reserve(G); d_penalty.reserve(G);
@@ -2035,13 +2089,32 @@ struct Solver {
             d_y.reserve(n); d_gw.reserve(n); d_off.reserve(n); d_eta.reserve(n); d_hess.reserve(n); d_irls_y.reserve(n);
             d_irls_resid.reserve(n); d_eta_prev.reserve(n); d_resid_prev.reserve(n); d_irls_w.reserve(n); d_irls_xm.reserve(p);
             d_xm.reserve(p);
-            d_y.upload((const T*)a->glm_y, n, st);
-            d_gw.upload((const T*)a->glm_weights, n, st);
-            d_off.upload((const T*)a->offsets, n, st);
             eta.assign((const T*)a->eta, (const T*)a->eta + n);
             resid.assign((const T*)a->resid, (const T*)a->resid + n);
-            d_eta.upload(eta.data(), n, st);
-            d_r.upload(resid.data(), n, st);
+            std::vector<T> stage;
+            if (multi()) {
+                // response-major device layout; glm_weights is (n,): repeated per class so that the elementwise kernels index it
+                // like every other vector (the multinomial kernels read its first segment)
+                const size_t nb_ = size_t(D->nb), K_ = size_t(D->mK);
+                stage.resize(5 * size_t(n));
+                to_major((const T*)a->glm_y, stage.data());
+                for (size_t l = 0; l < K_; ++l) std::copy((const T*)a->glm_weights, (const T*)a->glm_weights + nb_, stage.data() + size_t(n) + l * nb_);
+                to_major((const T*)a->offsets, stage.data() + 2 * size_t(n));
+                to_major(eta.data(), stage.data() + 3 * size_t(n));
+                to_major(resid.data(), stage.data() + 4 * size_t(n));
+                d_y.upload(stage.data(), n, st);
+                d_gw.upload(stage.data() + size_t(n), n, st);
+                d_off.upload(stage.data() + 2 * size_t(n), n, st);
+                d_eta.upload(stage.data() + 3 * size_t(n), n, st);
+                d_r.upload(stage.data() + 4 * size_t(n), n, st);
+                multi_w_uniform = false; // IRLS weights differ between classes
+            } else {
+                d_y.upload((const T*)a->glm_y, n, st);
+                d_gw.upload((const T*)a->glm_weights, n, st);
+                d_off.upload((const T*)a->offsets, n, st);
+                d_eta.upload(eta.data(), n, st);
+                d_r.upload(resid.data(), n, st);
+            }
             beta0 = T(a->beta0); loss_null = T(a->loss_null); loss_full = T(a->loss_full);
             irls_max_iters = size_t(a->irls_max_iters); irls_tol = T(a->irls_tol);
             setup_loss_null = a->setup_loss_null;

@@ -171,6 +171,59 @@ def multigaussian(y, *, weights=None, dtype=None, opt: bool = True):
     return _multigaussian()
 
 
+def multinomial(y, *, weights=None, dtype=None):
+    """Multinomial family (reference ``adelie.glm.multinomial``, ``glm.py:538-618``; arithmetic ``glm_multinomial.ipp:21-115``):
+    ``loss = (1/K) sum_i w_i (-y_i . eta_i + log sum_k exp eta_ik)``, diagonal majorant ``2 K^-1 W P (1 - P)`` as Hessian."""
+    y, dtype = _coerce_dtype(y, dtype)
+    if y.ndim == 2 and y.shape[1] <= 1:
+        raise RuntimeError("adelie_core: y must have at least 2 columns (classes).")
+
+    class _multinomial(multiglm_base, _mixin(dtype)):
+        name = "multinomial"
+        is_multi = True
+        opt = False
+
+        def __init__(self):
+            multiglm_base.__init__(self, y, weights, dtype)
+            self.core_kind = _abi.GLM_MULTINOMIAL
+
+        def _prob(self, eta):
+            e = np.exp(eta - np.max(eta, axis=1)[:, None])
+            return e / np.sum(e, axis=1)[:, None]
+
+        def gradient(self, eta, grad):
+            grad[...] = (self.y - self._prob(eta)) * self.weights[:, None] / self.y.shape[1]
+
+        def hessian(self, eta, grad, hess):
+            K = self.y.shape[1]
+            w = self.weights[:, None]
+            h = self.y * w / K - grad
+            hess[...] = h * (2 * (1 - K * (h / (w + (w <= 0)))))
+
+        def inv_hessian_gradient(self, eta, grad, hess, inv_hess_grad):
+            hmin = self.dtype(_configs.Configs.hessian_min)
+            inv_hess_grad[...] = grad / (np.maximum(hess, 0) + hmin * (hess <= 0))
+
+        def loss(self, eta):
+            es = eta - np.max(eta, axis=1)[:, None]
+            return np.sum(self.weights * (-np.sum(self.y * es, axis=1) + np.log(np.sum(np.exp(es), axis=1)))) / self.y.shape[1]
+
+        def loss_full(self):
+            with np.errstate(divide="ignore", invalid="ignore"):
+                ly = np.log(self.y)
+                t = np.where(np.isfinite(ly), self.y * ly, 0.0)
+            return self.dtype(-np.sum(np.sum(t, axis=1) * self.weights) / self.y.shape[1])
+
+        def inv_link(self, eta, out):
+            out[...] = self._prob(eta)
+
+        def reweight(self, weights=None):
+            w = self.weights if weights is None else weights
+            return multinomial(y=y, weights=w, dtype=dtype)
+
+    return _multinomial()
+
+
 def binomial(y, *, weights=None, link: str = "logit", dtype=None):
     """Binomial family, logit link (reference ``adelie.glm.binomial``, ``glm.py:83-196``)."""
     if link != "logit":

@@ -15,6 +15,7 @@ from . import matrix
 from .state import gaussian_naive as state_gaussian_naive
 from .state import glm_naive as state_glm_naive
 from .state import multigaussian_naive as state_multigaussian_naive
+from .state import multiglm_naive as state_multiglm_naive
 
 
 def grpnet(
@@ -70,8 +71,8 @@ def grpnet(
     n, p = X.rows(), X.cols()
 
     is_multi = bool(getattr(glm, "is_multi", False))
-    if is_multi and not (glm.name == "multigaussian" and glm.opt):
-        raise NotImplementedError("adelie_amd.grpnet: of the multi-response GLMs only glm.multigaussian is on the device path.")
+    if is_multi and not ((glm.name == "multigaussian" and glm.opt) or glm.name == "multinomial"):
+        raise NotImplementedError("adelie_amd.grpnet: of the multi-response GLMs, glm.multigaussian and glm.multinomial are on the device path.")
     if isinstance(constraints, list) and any(c is not None for c in constraints):
         raise NotImplementedError("adelie_amd.grpnet: constraints are outside the hot path (pass None).")
 
@@ -125,7 +126,7 @@ def grpnet(
     groups = np.asarray(groups, dtype=int)
 
     if is_multi:
-        return _grpnet_multigaussian(X, glm, groups, penalty, offsets, intercept, alpha, warm_start, solver_args,
+        return _grpnet_multi(X, glm, groups, penalty, offsets, intercept, alpha, warm_start, solver_args,
                                      check_state, progress_bar, exit_cond, n, p, dtype, n_threads)
 
     # single-response GLMs: solver.py:846-950
@@ -231,9 +232,10 @@ def grpnet(
     return state.solve(progress_bar=progress_bar, exit_cond=exit_cond)
 
 
-def _grpnet_multigaussian(X, glm, groups, penalty, offsets, intercept, alpha, warm_start, solver_args, check_state,
+def _grpnet_multi(X, glm, groups, penalty, offsets, intercept, alpha, warm_start, solver_args, check_state,
                           progress_bar, exit_cond, n, p, dtype, n_threads):
-    """The multi-response branch of the reference's ``grpnet`` (``solver.py:700-816``) for ``glm.multigaussian``."""
+    """The multi-response branch of the reference's ``grpnet`` (``solver.py:700-844``): ``glm.multigaussian`` (Gaussian naive
+    solver on the expanded design) and ``glm.multinomial`` (IRLS on the expanded design)."""
     K = glm.y.shape[-1]
     groups = groups * K  # flatten the grouping index across the classes
     if intercept:
@@ -270,6 +272,37 @@ def _grpnet_multigaussian(X, glm, groups, penalty, offsets, intercept, alpha, wa
     solver_args.update(groups=groups, group_sizes=group_sizes, penalty=penalty, lmda=lmda, lmda_max=lmda_max,
                        screen_set=screen_set, screen_beta=screen_beta, screen_is_active=screen_is_active,
                        active_set_size=active_set_size, active_set=active_set)
+
+    if not (glm.name == "multigaussian" and glm.opt):  # IRLS route, solver.py:818-844
+        if warm_start is None:
+            eta = offsets
+            resid = np.empty(eta.shape, dtype=dtype)
+            glm.gradient(eta, resid)
+            G = np.empty((p + (1 if intercept else 0), K), dtype=dtype)
+            t = np.empty(p, dtype=dtype)
+            ones = np.ones(n, dtype=dtype)
+            for l in range(K):  # grad = X_aug^T resid, one sweep of the base design per class
+                rl = np.ascontiguousarray(resid[:, l], dtype=dtype)
+                X.mul(rl, ones, t)
+                if intercept:
+                    G[0, l] = np.sum(rl)
+                    G[1:, l] = t
+                else:
+                    G[:, l] = t
+            grad = G.ravel()
+            resid = resid.ravel()
+            loss_null = None
+            loss_full = glm.loss_full()
+            eta = eta.ravel()
+        else:
+            eta = warm_start.eta
+            resid = warm_start.resid
+            grad = warm_start.grad
+            loss_null = warm_start.loss_null
+            loss_full = warm_start.loss_full
+        solver_args.update(grad=grad, eta=eta, resid=resid, loss_null=loss_null, loss_full=loss_full)
+        state = state_multiglm_naive(**solver_args)
+        return state.solve(progress_bar=progress_bar, exit_cond=exit_cond)
 
     y = glm.y
     weights = glm.weights

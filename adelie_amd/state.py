@@ -520,6 +520,74 @@ def multigaussian_naive(
     return s
 
 
+class multiglm_naive_base(glm_naive_base):
+    """Multi-response GLM naive state (reference ``state.py:2756-3121``): ``StateGlmNaive`` with the global intercept off on
+    ``[1 (x) I_K, X (x) I_K]``; null model and tidy step of ``solver_multiglm_naive.hpp:99-246``."""
+
+    def _marshal(self):
+        a, keep = glm_naive_base._marshal(self)
+        y = np.ascontiguousarray(self._glm.y, dtype=self.dtype)  # (n, K) row-major
+        w = np.ascontiguousarray(self._glm.weights, dtype=self.dtype)  # (n,)
+        keep += [y, w]
+        a.glm_y = y.ctypes.data
+        a.glm_weights = w.ctypes.data
+        return a, keep
+
+    def _from_result_extra(self, new, backend, r, sc):
+        glm_naive_base._from_result_extra(self, new, backend, r, sc)
+        K = self.n_classes
+        L = new.betas.shape[0]
+        if self.multi_intercept:
+            B = new.betas.tocsc()
+            new.intercepts = np.asarray(B[:, :K].todense(), dtype=self.dtype).reshape(L, K)
+            new.betas = csr_matrix(B[:, K:].tocsr())
+        else:
+            new.intercepts = np.zeros((L, K), dtype=self.dtype)
+
+
+def multiglm_naive(
+    *, X, glm, constraints, groups, group_sizes, alpha, penalty, offsets, screen_set, screen_beta, screen_is_active,
+    active_set_size, active_set, lmda, grad, eta, resid, loss_full, loss_null=None, lmda_path=None,
+    lmda_max=None, irls_max_iters=int(1e4), irls_tol=1e-7, max_iters=int(1e5), tol=1e-7, adev_tol=0.9, ddev_tol=0,
+    newton_tol=1e-12, newton_max_iters=1000, n_threads=1, early_exit=True, intercept=True, screen_rule="pivot",
+    min_ratio=1e-2, lmda_path_size=100, max_screen_size=None, max_active_size=None, pivot_subset_ratio=0.1,
+    pivot_subset_min=1, pivot_slack_ratio=1.25,
+):
+    """Creates a multi-response GLM, naive method state object (reference ``adelie.state.multiglm_naive``,
+    ``state.py:2756-3121``).  ``X`` is the raw ``(n, p)`` design; ``offsets`` is ``(n, K)``; ``eta`` / ``resid`` are the
+    flattened ``(n, K)`` arrays; ``groups`` / ``grad`` are in the expanded coordinates."""
+    X_raw = _matrix_of(X, n_threads)
+    dtype = X_raw.dtype
+    if getattr(glm, "core_kind", None) != _abi.GLM_MULTINOMIAL:
+        raise RuntimeError("adelie_amd: of the multi-response IRLS families only adelie_amd.glm.multinomial runs on device.")
+    offsets = np.array(offsets, order="C", copy=True, dtype=dtype)
+    n, n_classes = offsets.shape
+    X_exp = _matrix.kronecker_eye(X_raw, n_classes, n_threads=n_threads)
+    if intercept:
+        X_exp = _matrix.concatenate(
+            [_matrix.kronecker_eye(np.ones((n, 1), dtype=dtype), n_classes, n_threads=n_threads), X_exp],
+            axis=1, n_threads=n_threads)
+    s = glm_naive(
+        X=X_exp, glm=glm, constraints=constraints, groups=groups, group_sizes=group_sizes, alpha=alpha, penalty=penalty,
+        offsets=offsets.ravel(), screen_set=screen_set, screen_beta=screen_beta, screen_is_active=screen_is_active,
+        active_set_size=active_set_size, active_set=active_set, beta0=0, lmda=lmda, grad=grad,
+        eta=np.asarray(eta, dtype=dtype).ravel(), resid=np.asarray(resid, dtype=dtype).ravel(), loss_full=loss_full,
+        loss_null=loss_null, lmda_path=lmda_path, lmda_max=lmda_max, irls_max_iters=irls_max_iters, irls_tol=irls_tol,
+        max_iters=max_iters, tol=tol, adev_tol=adev_tol, ddev_tol=ddev_tol, newton_tol=newton_tol,
+        newton_max_iters=newton_max_iters, n_threads=n_threads, early_exit=early_exit, intercept=False,
+        screen_rule=screen_rule, min_ratio=min_ratio, lmda_path_size=lmda_path_size, max_screen_size=max_screen_size,
+        max_active_size=max_active_size, pivot_subset_ratio=pivot_subset_ratio, pivot_subset_min=pivot_subset_min,
+        pivot_slack_ratio=pivot_slack_ratio,
+    )
+    s.__class__ = multiglm_naive_base
+    s.X = X_raw
+    s._X_raw = X_raw
+    s._X_expanded = X_exp
+    s.n_classes = int(n_classes)
+    s.multi_intercept = bool(intercept)
+    return s
+
+
 def glm_naive(
     *, X, glm, constraints, groups, group_sizes, alpha, penalty, offsets, screen_set, screen_beta, screen_is_active,
     active_set_size, active_set, beta0, lmda, grad, eta, resid, loss_full, loss_null=None, lmda_path=None,

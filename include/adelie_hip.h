@@ -36,7 +36,10 @@ enum adelie_hip_screen_rule { ADELIE_HIP_SCREEN_STRONG = 0, ADELIE_HIP_SCREEN_PI
 enum adelie_hip_glm_kind {
     ADELIE_HIP_GLM_GAUSSIAN = 0,        /* glm.gaussian(opt=True): StateGaussianNaive, no IRLS (solver.py:683-686) */
     ADELIE_HIP_GLM_BINOMIAL_LOGIT = 1,  /* glm.binomial(link="logit"): StateGlmNaive + IRLS */
-    ADELIE_HIP_GLM_GAUSSIAN_IRLS = 2    /* glm.gaussian(opt=False): Gaussian loss forced through StateGlmNaive */
+    ADELIE_HIP_GLM_GAUSSIAN_IRLS = 2,   /* glm.gaussian(opt=False): Gaussian loss forced through StateGlmNaive */
+    ADELIE_HIP_GLM_MULTINOMIAL = 3      /* glm.multinomial: StateMultiGlmNaive (solver_multiglm_naive.hpp) + IRLS; the design must
+                                           be a multi-response view (adelie_hip_design_create_multi).  glm_y is (n, K) row-major,
+                                           glm_weights is (n,), offsets / eta / resid are (n, K) row-major (glm_multinomial.ipp) */
 };
 
 /* Opaque handles. */

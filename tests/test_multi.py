@@ -183,6 +183,133 @@ def test_multi_errors(oracle):
         matrix._multi_view(oracle.dense(X), 0, True)
 
 
+# ---- multinomial (IRLS on the view) ---------------------------------------------------------------------------------------
+def make_multinomial(n, p, K, seed=0, nnz=3, weights=False):
+    rng = np.random.RandomState(seed)
+    X = np.asfortranarray(rng.normal(size=(n, p)))
+    B = np.zeros((p, K))
+    B[rng.choice(p, nnz, replace=False)] = 1.5 * rng.normal(size=(nnz, K))
+    eta = X @ B + 0.3 * rng.normal(size=K)
+    mu = np.exp(eta) / np.sum(np.exp(eta), axis=1)[:, None]
+    y = np.array([rng.multinomial(1, m) for m in mu]).astype(np.float64)
+    w = None
+    if weights:
+        w = rng.uniform(1, 2, n)
+        w /= w.sum()
+    return X, y, w
+
+
+def test_multinomial_glm_members():
+    """gradient = -d loss / d eta; hessian = 2 K^-1 W P (1 - P) (glm_multinomial.ipp:21-66)."""
+    rng = np.random.RandomState(0)
+    n, K = 9, 4
+    y = np.eye(K)[rng.randint(0, K, n)]
+    w = rng.uniform(1, 2, n)
+    glm = ad.glm.multinomial(y, weights=w)
+    eta = rng.normal(size=(n, K))
+    g = np.empty((n, K))
+    glm.gradient(eta, g)
+    num = np.empty((n, K))
+    for i in range(n):
+        for k in range(K):
+            e = eta.copy(); e[i, k] += 1e-6
+            e2 = eta.copy(); e2[i, k] -= 1e-6
+            num[i, k] = -(glm.loss(e) - glm.loss(e2)) / 2e-6
+    np.testing.assert_allclose(g, num, atol=1e-8)
+    P = np.exp(eta) / np.exp(eta).sum(1)[:, None]
+    h = np.empty((n, K))
+    glm.hessian(eta, g, h)
+    np.testing.assert_allclose(h, 2 * glm.weights[:, None] * P * (1 - P) / K, atol=1e-12)
+    assert glm.loss_full() == 0  # one-hot responses
+    with pytest.raises(RuntimeError):
+        ad.glm.multinomial(y[:, :1])
+
+
+def test_reference_quickstart_multinomial_known_answer(oracle):
+    """quickstart.ipynb cells 46-47: ``52/100 ... [dev:90.2%]``."""
+    n, p, K = 100, 1000, 4
+    np.random.seed(0)
+    X = np.random.normal(0, 1, (n, p))
+    eta = X[:, -1:] @ np.random.normal(0, 1, (1, K)) + np.random.normal(0, 1, (n, K))
+    mu = np.exp(eta) / np.sum(np.exp(eta), axis=-1)[:, None]
+    y = np.array([np.random.multinomial(1, m) for m in mu])
+    s = ad.grpnet(X=oracle.dense(np.asfortranarray(X)), glm=ad.glm.multinomial(y=y, dtype=np.float64))
+    assert s.error == ""
+    assert len(s.lmdas) == 52
+    assert f"{100 * s.devs[-1]:.1f}" == "90.2" and s.devs[-2] < 0.9
+    assert s.betas.shape == (52, p * K) and s.intercepts.shape == (52, K)
+
+
+def kkt_multinomial(X, glm, K, groups, group_sizes, penalty, alpha, intercept, betas, intercepts, lmdas):
+    n, p = X.shape
+    worst = 0.0
+    Bs = betas.toarray()
+    for l, lm in enumerate(lmdas):
+        B = Bs[l].reshape(p, K)
+        R = np.empty((n, K))
+        glm.gradient(X @ B + intercepts[l], R)  # -(d loss / d eta)
+        if intercept:
+            worst = max(worst, np.abs(R.sum(0)).max())
+        Gr = X.T @ R
+        for g, gs, pen in zip(groups, group_sizes, penalty):
+            gg, bb = Gr[g:g + gs].ravel(), B[g:g + gs].ravel()
+            nb = np.linalg.norm(bb)
+            if nb == 0:
+                worst = max(worst, np.linalg.norm(gg) - lm * alpha * pen)
+            else:
+                worst = max(worst, np.linalg.norm(gg - lm * pen * (alpha * bb / nb + (1 - alpha) * bb)))
+    return worst
+
+
+@pytest.mark.parametrize("icpt", [False, True])
+def test_oracle_multinomial_kkt(oracle, icpt):
+    n, p, K = 80, 12, 3
+    X, y, w = make_multinomial(n, p, K, seed=3, weights=True)
+    glm = ad.glm.multinomial(y, weights=w)
+    groups = np.array([0, 1, 3, 4, 8])
+    gs = np.diff(np.concatenate([groups, [p]]))
+    s = ad.grpnet(X=oracle.dense(X), glm=glm, groups=groups, intercept=icpt, alpha=0.7, tol=1e-14, irls_tol=1e-16,
+                  early_exit=False, lmda_path_size=12, min_ratio=0.1)
+    assert s.error == "" and len(s.lmdas) == 12
+    v = kkt_multinomial(X, glm, K, groups, gs, np.sqrt(gs * K), 0.7, icpt, s.betas, s.intercepts, s.lmdas)
+    assert v < 1e-6, v
+    assert np.all(np.diff(s.devs) > -1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [2, 3, 5])
+@pytest.mark.parametrize("icpt", [False, True])
+def test_hip_multinomial_matches_oracle(hip, oracle, K, icpt):
+    X, y, w = make_multinomial(300, 30, K, seed=10 + K, weights=True)
+    glm = ad.glm.multinomial(y, weights=w)
+    kw = dict(intercept=icpt, tol=1e-13, irls_tol=1e-16, early_exit=False, lmda_path_size=20, min_ratio=5e-2)
+    a, b = _both(oracle, X, glm, **kw)
+    assert a.error == "" and b.error == "", (a.error, b.error)
+    assert len(a.lmdas) == len(b.lmdas) == 20
+    np.testing.assert_allclose(a.lmdas, b.lmdas, rtol=1e-9)
+    assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-7
+    assert np.abs(a.intercepts - b.intercepts).max() < 1e-7
+    np.testing.assert_allclose(a.devs, b.devs, atol=1e-8)
+    np.testing.assert_allclose(a.eta, b.eta, atol=1e-6)
+    np.testing.assert_allclose(a.resid, b.resid, atol=1e-8)
+    np.testing.assert_allclose(a.loss_null, b.loss_null, rtol=1e-10)
+    gs = np.ones(30, dtype=int)
+    v = kkt_multinomial(X, glm, K, np.arange(30), gs, np.sqrt(gs * K), 1.0, icpt, a.betas, a.intercepts, a.lmdas)
+    assert v < 1e-5, v
+
+
+@pytest.mark.gpu
+def test_hip_multinomial_reference_quickstart(hip):
+    n, p, K = 100, 1000, 4
+    np.random.seed(0)
+    X = np.random.normal(0, 1, (n, p))
+    eta = X[:, -1:] @ np.random.normal(0, 1, (1, K)) + np.random.normal(0, 1, (n, K))
+    mu = np.exp(eta) / np.sum(np.exp(eta), axis=-1)[:, None]
+    y = np.array([np.random.multinomial(1, m) for m in mu])
+    s = ad.grpnet(X=ad.matrix.dense(np.asfortranarray(X)), glm=ad.glm.multinomial(y=y, dtype=np.float64))
+    assert s.error == "" and len(s.lmdas) == 52 and f"{100 * s.devs[-1]:.1f}" == "90.2"
+
+
 # ---- HIP path ----------------------------------------------------------------------------------------------------------
 def _both(oracle, X, glm, **kw):
     a = ad.grpnet(X=ad.matrix.dense(X), glm=glm, **kw)

@@ -1,8 +1,8 @@
 """adelie_amd — an MI355X-native group-elastic-net path solver behind adelie's Python API.
 
 Mirrors the user-facing surface of JamesYang007/adelie for the ``grpnet`` hot path only
-(``solver.grpnet``, ``cv.cv_grpnet``, ``matrix.dense`` / ``matrix.snp_unphased``,
-``glm.gaussian`` / ``glm.binomial``, the naive State objects).  All numerics run in hand-written HIP
+(``solver.grpnet``, ``cv.cv_grpnet``, ``matrix.dense`` / ``matrix.snp_unphased`` / ``matrix.kronecker_eye``,
+``glm.gaussian`` / ``glm.binomial`` / ``glm.multigaussian`` / ``glm.multinomial``, the naive State objects).  All numerics run in hand-written HIP
 kernels for gfx950 behind the C ABI declared in ``include/adelie_hip.h``.
 """
 from . import configs

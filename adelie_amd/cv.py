@@ -73,7 +73,8 @@ def _fold_loss(X, glm, fold_idx, full_lmdas, *, n_threads, early_exit, min_ratio
     beta_ints = [coefficient(lmda=lmda, betas=betas, intercepts=intercepts, lmdas=lmdas) for lmda in full_lmdas]
     full_betas = scipy.sparse.vstack([x[0] for x in beta_ints]).tocsr()
     full_intercepts = np.array([x[1] for x in beta_ints])
-    if hasattr(X, "glm_path_losses") and X._backend.has("design_glm_path_losses") and hasattr(glm, "core_kind"):
+    if (hasattr(X, "glm_path_losses") and X._backend.has("design_glm_path_losses") and hasattr(glm, "core_kind")
+            and not getattr(glm, "is_multi", False)):
         # predictions and both losses per lambda on the device; only 2 L scalars come back
         full_data_losses, train = X.glm_path_losses(glm.core_kind, full_betas, full_intercepts, state._offsets, glm.y,
                                                     glm.weights, glm_c.weights)

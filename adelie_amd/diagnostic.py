@@ -32,7 +32,7 @@ def predict(X, betas, intercepts, offsets=None, n_threads: int = 1):
         L = betas.shape[0]
         etas = np.zeros((L, n * K), order="C", dtype=dtype)
         X.sp_tmul(betas, etas)
-        return etas.reshape(L, n, K) + intercepts[:, None] + offsets
+        return etas.reshape(L, n, K) + intercepts[:, None] + np.asarray(offsets, dtype=dtype).reshape(n, K)
     n = X.rows()
     dtype = X.dtype
     if offsets is None:

@@ -580,6 +580,8 @@ def multiglm_naive(
         pivot_slack_ratio=pivot_slack_ratio,
     )
     s.__class__ = multiglm_naive_base
+    s._offsets = offsets  # (n, K), as the reference keeps it (state.py:3046); the core gets the same memory flattened
+    s.offsets = offsets
     s.X = X_raw
     s._X_raw = X_raw
     s._X_expanded = X_exp

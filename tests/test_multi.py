@@ -173,6 +173,34 @@ def _solve_on(Xa, X, glm, kw, oracle):
         ad.solver.state_multigaussian_naive = real
 
 
+def test_cv_grpnet_multi_response(oracle):
+    """cv_grpnet on a multi-response family (reference cv.py:130-325 is family-agnostic): fold losses are
+    validation-weighted losses of the interpolated solutions, recomputed here from first principles for one fold."""
+    n, p, K = 60, 10, 3
+    X, Y, _ = make_multi(n, p, K, seed=7, nnz=3)
+    glm = ad.glm.multigaussian(Y)
+    Xd = oracle.dense(X)
+    cv = ad.cv_grpnet(Xd, glm, n_folds=3, seed=5, lmda_path_size=12, min_ratio=0.2, tol=1e-12)
+    assert cv.losses.shape == (3, 12) and 0 <= cv.best_idx < 12
+    np.random.seed(5)
+    order = np.random.choice(n, n, replace=False)
+    b, e = ad.cv.fold_ranges(n, 3)[1]
+    val = order[b:e]
+    w = np.full(n, 1 / n)
+    w[val] = 0
+    w /= w.sum()
+    st = ad.grpnet(X=Xd, glm=ad.glm.multigaussian(Y, weights=w), lmda_path=cv.lmdas, early_exit=False, tol=1e-12)
+    eta = ad.diagnostic.predict(Xd, st.betas, st.intercepts)
+    per_obs = np.sum(0.5 * eta ** 2 - Y[None] * eta, axis=2) / K          # (L, n)
+    expect = per_obs[:, val].mean(axis=1)                                   # weights 1/n on the validation rows, renormalised
+    np.testing.assert_allclose(cv.losses[1], expect, atol=1e-7)
+    fit = cv.fit(Xd, glm, lmda_path_size=5)
+    assert fit.betas.shape == (5, p * K) and fit.intercepts.shape == (5, K)
+    Xm, ym, _ = make_multinomial(60, 8, 3, seed=2)
+    cvm = ad.cv_grpnet(oracle.dense(Xm), ad.glm.multinomial(ym), n_folds=3, seed=1, lmda_path_size=8, min_ratio=0.3)
+    assert cvm.losses.shape == (3, 8) and np.all(np.isfinite(cvm.losses))
+
+
 def test_multi_errors(oracle):
     X, Y, _ = make_multi(20, 6, 2)
     with pytest.raises(RuntimeError):

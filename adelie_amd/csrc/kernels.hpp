@@ -165,6 +165,17 @@ struct CdBlkParams {
     const T* Dptr;       // BLK x BLK block (ld = BLK)
     const int32_t* vcol; // screen value -> design column
     int32_t* dcol;       // [BLK] out: design columns of the changed coordinates (same order as dlt)
+    // look-ahead form of the panel passes (solver.hip::run_panel_passes): gblk was computed from a residual that does not
+    // contain the previous block's changes yet; the solve first subtracts Cprev[:, ppos[m]] * pdlt[m], m < *pnz, where
+    // Cprev = X_b^T W X_prev - xbar_b xbar_prev^T (BLK x BLK, ld BLK, rows = this block).  Outputs for the next block /
+    // the next panel step: block-local positions of the changed coordinates, their count, resid_sum after this block.
+    const T* Cprev;
+    const T* pdlt;
+    const int32_t* ppos;
+    const int32_t* pnz;
+    int32_t* dpos;
+    int32_t* nz_out;
+    T* rsum_out;
 };
 // group (q > 1) variant: a block = consecutive groups of the visiting list with <= 128 values in total
 template <class T>
@@ -222,6 +233,18 @@ int64_t panel_part_elems(int64_t n);
 template <class T>
 void launch_panel_reduce(const T* part, int nslices, int nb, const int32_t* cols, const T* rsum_dev, const T* xm_by_col,
                          T* gblk, hipStream_t s);
+template <class T>
+void launch_panel_reduce_ld(const T* part, int64_t part_ld, int nslices, int nb, const int32_t* cols, const T* rsum_dev,
+                            const T* xm_by_col, T* gblk, hipStream_t s);
+// fused look-ahead step: the solve of block j (sp, as launch_cd_panel_solve) and a panel step in ONE launch; returns the
+// leading dimension of `part` (>= number of row slices; use launch_panel_reduce_ld).  `part` holds 2*panel_part_elems(n).
+template <class T>
+int launch_panel_fused(const CdBlkParams<T>& sp, int j, const DenseView<T>& X, const T* w, T* r, const int32_t* dcol,
+                       const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s);
+template <class T>
+int launch_panel_fused_snp(const CdBlkParams<T>& sp, int j, const SnpView& X, const T* impute, const T* w, T* r,
+                           const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part,
+                           hipStream_t s);
 // the visits of block j of the pass (one workgroup); p.gblk / p.Dptr / p.vcol / p.dcol must be set
 template <class T> void launch_cd_panel_solve(const CdBlkParams<T>& p, int j, hipStream_t s);
 template <class T> void launch_center_vars(T* vars, const T* xm, int cnt, bool center, hipStream_t s);

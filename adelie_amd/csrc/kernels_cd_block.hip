@@ -16,32 +16,11 @@
 // guides/MI355X_MICROARCH.md "boundary" vs "barrier-xcd").  The result is the same Gauss–Seidel sequence: inside a block
 // every coordinate sees all earlier changes of the block through D_j, across blocks through the update kernel.
 #include "kernels.hpp"
+#include "blk_solve_body.hpp"
 
 namespace ahip {
 
 namespace {
-
-constexpr int BLK = 128; // visits per block
-
-typedef double cb_d2 __attribute__((ext_vector_type(2)));
-typedef float cb_f4 __attribute__((ext_vector_type(4)));
-template <class T> struct CbVec;
-template <> struct CbVec<double> { using type = cb_d2; static constexpr int N = 2; };
-template <> struct CbVec<float> { using type = cb_f4; static constexpr int N = 4; };
-
-// v_readlane with a wave-uniform lane index (SGPR): a register-to-scalar move, no LDS crossbar as __shfl would use
-__device__ __forceinline__ double rdlane(double x, int l) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
-}
-__device__ __forceinline__ float rdlane(float x, int l) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
-}
-__device__ __forceinline__ int rdlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
-
-template <class T>
-__device__ __forceinline__ int blk_index(const CdBlkParams<T>& p, int pos) {
-    return p.list ? p.list[pos] : pos;
-}
 
 // D_j[i + m*BLK] = C[idx_i + idx_m*ldc] for the block starting at list position j*BLK
 template <class T>
@@ -65,191 +44,7 @@ __global__ void blk_gather_kernel(CdBlkParams<T> p, int j) {
 template <class T, bool NAIVE>
 __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* D = reinterpret_cast<T*>(smem_raw);   // BLK*BLK
-    T* gB = D + BLK * BLK;
-    T* bB = gB + BLK;
-    T* AB = bB + BLK;
-    T* l1B = AB + BLK;
-    T* denB = l1B + BLK;
-    T* rdenB = denB + BLK;
-    T* xmB = rdenB + BLK;
-    T* dB = xmB + BLK;                        // net change of each coordinate of the block
-    int32_t* idxB = reinterpret_cast<int32_t*>(dB + BLK);
-    int32_t* actB = idxB + BLK;
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int base = j * p.bsz;
-    const int nb = min(p.bsz, p.count - base);
-
-    if (tid < BLK) {
-        const int i = tid;
-        if (i < nb) {
-            const int idx = blk_index(p, base + i);
-            const T A = p.vars[idx], pk = p.spen[idx];
-            const T den = A + p.l2 * pk;
-            idxB[i] = idx;
-            gB[i] = NAIVE ? p.gblk[i] : p.g[idx];
-            bB[i] = p.beta[idx];
-            AB[i] = A;
-            l1B[i] = p.l1 * pk;
-            denB[i] = den;
-            rdenB[i] = T(1) / den;
-            xmB[i] = p.xmean[idx];
-            actB[i] = p.is_active[idx];
-        } else {
-            idxB[i] = 0; gB[i] = 0; bB[i] = 0; AB[i] = 0; l1B[i] = 0; denB[i] = 1; rdenB[i] = 1; xmB[i] = 0; actB[i] = 1;
-        }
-        dB[i] = 0;
-    }
-    {
-        using V = typename CbVec<T>::type;
-        constexpr int VEC = CbVec<T>::N;
-        const V* src = reinterpret_cast<const V*>(NAIVE ? p.Dptr : p.Dbuf + size_t(j & 1) * BLK * BLK);
-        V* dst = reinterpret_cast<V*>(D);
-        // 8 loads in flight per lane: the 128 KB block arrives in ~4 round trips instead of 32
-        const int NE = nb * BLK / VEC; // columns [0, nb) of the slot
-        for (int e0 = tid; e0 < NE; e0 += 256 * 8) {
-            V v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[min(e0 + u * 256, NE - 1)];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (e0 + u * 256 < NE) dst[e0 + u * 256] = v[u];
-        }
-    }
-    __syncthreads();
-    if (wv != 0) return;
-    // the chain below is the critical path of the whole pass: let this wave win the issue arbitration against whatever
-    // else is resident on the CU (diagonal-block builds of the side stream)
-    __builtin_amdgcn_s_setprio(3);
-
-    // ---- one wavefront: the block's visits, strictly in order ------------------------------------------------------
-    CdBlkState<T>* st = p.st;
-    T rsq = st->rsq, rsum = st->resid_sum, cm = (j == 0) ? T(0) : st->cm;
-    int asz = st->active_size, status = st->status;
-    int64_t n_upd = st->n_updates;
-    // Lane l keeps coordinates l and l+64 of the block in registers (g and the per-coordinate constants); a visit reads
-    // its operands with v_readlane (uniform lane index), so the dependent chain of a visit is register-only:
-    // readlane g_i -> soft-threshold -> fma into the two g registers.  The D column comes from LDS (2 x ds_read_b64,
-    // address independent of the chain).  The single wave is bound by its instruction count, so everything that is not on
-    // the chain (rsq, convergence measure, resid_sum, active-set marking, counters) is left out of the loop: a visit
-    // only records the new coefficient and the gradient it saw in the owning lane, and the bookkeeping of the whole block
-    // is done lane-parallel afterwards (same quantities; the sums are wave reductions instead of running sums).
-    static_assert(BLK == 128, "two coordinates per lane");
-    T g0 = gB[lane], g1 = gB[lane + 64];
-    const T b0 = bB[lane], b1 = bB[lane + 64];
-    const T A0 = AB[lane], A1 = AB[lane + 64];
-    const T L0 = l1B[lane], L1 = l1B[lane + 64];
-    const T N0 = denB[lane], N1 = denB[lane + 64];
-    const T R0 = rdenB[lane], R1 = rdenB[lane + 64];
-    const T X0 = xmB[lane], X1 = xmB[lane + 64];
-    const int a0 = actB[lane], a1 = actB[lane + 64];
-    T nb0 = b0, nb1 = b1; // new coefficients of this lane's two coordinates
-    T gc0 = T(0), gc1 = T(0); // gradient seen by the visit of this lane's coordinates (only meaningful if they changed)
-#define AHIP_BLK_VISIT(GREG, BREG, AREG, LREG, NREG, RREG, NBREG, GCREG, IL)                                          \
-    {                                                                                                                  \
-        const T dc0 = D[i * BLK + lane], dc1 = D[i * BLK + lane + 64]; /* off the dependent chain: issued first */  \
-        const T gcur = rdlane(GREG, IL);                                                                           \
-        const T bi = rdlane(BREG, IL), A = rdlane(AREG, IL);                                                   \
-        const T gk = fma(bi, A, gcur);                    /* pin_naive:85-89 */                                       \
-        const T v = fabs(gk) - rdlane(LREG, IL);      /* pin_base:181-195 */                                      \
-        T ak = T(0);                                                                                                   \
-        if (v > T(0)) {                                                                                                \
-            const T x = copysign(v, gk);                                                                               \
-            const T den = rdlane(NREG, IL), rden = rdlane(RREG, IL);                                           \
-            const T q0 = x * rden;                                                                                     \
-            const T r = fma(-q0, den, x);                                                                              \
-            ak = fma(r, rden, q0);                                                                                     \
-        }                                                                                                              \
-        if (ak != bi) {                                   /* pin_naive:97 */                                          \
-            const T del = ak - bi;                                                                                     \
-            g0 = fma(-del, dc0, g0);                                                                                   \
-            g1 = fma(-del, dc1, g1);                                                                                   \
-            if (lane == (IL)) { NBREG = ak; GCREG = gcur; }                                                            \
-        }                                                                                                              \
-    }
-    {
-        const int n0 = nb < 64 ? nb : 64;
-        for (int i = 0; i < n0; ++i) AHIP_BLK_VISIT(g0, b0, A0, L0, N0, R0, nb0, gc0, i)
-        for (int i = 64; i < nb; ++i) AHIP_BLK_VISIT(g1, b1, A1, L1, N1, R1, nb1, gc1, i - 64)
-    }
-#undef AHIP_BLK_VISIT
-    // ---- bookkeeping of the block, lane-parallel --------------------------------------------------------------------
-    {
-        const T d0 = nb0 - b0, d1 = nb1 - b1; // lanes beyond nb hold b = nb = 0
-        const bool ch0 = d0 != T(0), ch1 = d1 != T(0);
-        // pin_base:136-146 (rsq), pin_naive:107 (resid_sum), pin_base:112-122 (convergence measure)
-        const T rs = (ch0 ? d0 * (T(2) * gc0 - d0 * A0) : T(0)) + (ch1 ? d1 * (T(2) * gc1 - d1 * A1) : T(0));
-        const T xs = X0 * d0 + X1 * d1;
-        const T c0 = A0 * d0 * d0, c1 = A1 * d1 * d1;
-        T cmx = c0 > c1 ? c0 : c1;
-        T rs_t = rs, xs_t = xs;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            rs_t += __shfl_xor(rs_t, off, 64);
-            xs_t += __shfl_xor(xs_t, off, 64);
-            const T o = __shfl_xor(cmx, off, 64);
-            cmx = o > cmx ? o : cmx;
-        }
-        rsq += rs_t;
-        rsum -= xs_t;
-        cm = cmx > cm ? cmx : cm;
-        const unsigned long long m0 = __ballot(ch0), m1 = __ballot(ch1);
-        n_upd += __popcll(m0) + __popcll(m1);
-        if (p.mark) { // add_active_set in visiting order, pin_naive:294-304
-            const bool new0 = ch0 && a0 == 0, new1 = ch1 && a1 == 0;
-            const unsigned long long q0 = __ballot(new0), q1 = __ballot(new1);
-            const int cnt = __popcll(q0) + __popcll(q1);
-            if (asz + cnt > p.max_active_size) {
-                status = CD_MAX_ACTIVE;
-            } else {
-                const unsigned long long lt = (1ull << lane) - 1ull;
-                if (new0) { const int pos = asz + __popcll(q0 & lt); p.is_active[idxB[lane]] = 1; p.active_set[pos] = idxB[lane]; }
-                if (new1) {
-                    const int pos = asz + __popcll(q0) + __popcll(q1 & lt);
-                    p.is_active[idxB[lane + 64]] = 1;
-                    p.active_set[pos] = idxB[lane + 64];
-                }
-                asz += cnt;
-            }
-        }
-    }
-    // net changes of the block (a coordinate is visited once per pass, so delta = new - old)
-    bB[lane] = nb0; bB[lane + 64] = nb1;
-    dB[lane] = nb0 - b0; dB[lane + 64] = nb1 - b1;
-    // ---- write back the block: beta, and the compacted non-zero changes for the update kernel ---------------------------
-    int nz = 0;
-    for (int i0 = 0; i0 < BLK; i0 += 64) {
-        const int i = i0 + lane;
-        const T d = (i < nb) ? dB[i] : T(0);
-        const bool ch = d != T(0);
-        if (ch) p.beta[idxB[i]] = bB[i];
-        const unsigned long long m = __ballot(ch);
-        const int pos = nz + __popcll(m & ((1ull << lane) - 1ull));
-        if (ch) {
-            if (NAIVE) p.dcol[pos] = p.vcol[idxB[i]];
-            else p.didx[pos] = idxB[i];
-            p.dlt[pos] = d;
-        }
-        nz += __popcll(m);
-    }
-    if (lane == 0) {
-        st->rsq = rsq;
-        st->resid_sum = rsum;
-        st->cm = cm;
-        st->active_size = asz;
-        st->status = status;
-        st->n_updates = n_upd;
-        st->nz = nz;
-        if (NAIVE && p.host_st && j == p.report_j) {
-            CdBlkState<T> out;
-            out.rsq = rsq; out.resid_sum = rsum; out.cm = cm; out.n_updates = n_upd;
-            out.active_size = asz; out.status = status; out.nz = nz; out._pad = 0;
-            *p.host_st = out;
-            __threadfence_system();
-            __hip_atomic_store(p.host_seq, p.report_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    blk_solve_body<T, NAIVE>(p, j, smem_raw, threadIdx.x);
 }
 
 template <class T>
@@ -310,10 +105,6 @@ __global__ __launch_bounds__(1024) void cd_compact_kernel(const T* __restrict__ 
     if (tid == 0) n_delta[0] = cnt[NT];
 }
 
-template <class T>
-size_t blk_solve_lds() {
-    return size_t(BLK) * BLK * sizeof(T) + size_t(BLK) * 8 * sizeof(T) + size_t(BLK) * 2 * sizeof(int32_t) + 16;
-}
 
 } // namespace
 

@@ -21,6 +21,7 @@
 #include "kernels.hpp"
 #include "accessors.hpp"
 #include "wavered.hpp"
+#include "blk_solve_body.hpp"
 
 namespace ahip {
 
@@ -97,12 +98,12 @@ template <class T, class Acc, int VEC, bool FULL>
 __device__ __forceinline__ void panel_step_body(const Acc& X, int64_t n, const T* __restrict__ w, T* __restrict__ r,
                                                 const int32_t* __restrict__ dcol, const T* __restrict__ dlt, int nz,
                                                 const int32_t* __restrict__ cols, int nb, T* __restrict__ part,
-                                                int64_t part_ld, T (*red)[64 * VEC], T* wrs) {
+                                                int64_t part_ld, T (*red)[64 * VEC], T* wrs, int tid, int64_t slice) {
     constexpr int U = 16;
     using Raw = typename RawOf<T, Acc, VEC>::type;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t i = int64_t(blockIdx.x) * (64 * VEC) + int64_t(lane) * VEC;
+    const int64_t i = slice * (64 * VEC) + int64_t(lane) * VEC;
     const bool full = FULL ? true : (i + VEC <= n);
 
     // first batch of (B): columns wv, wv+4, ... of the next block
@@ -185,7 +186,7 @@ __device__ __forceinline__ void panel_step_body(const Acc& X, int64_t n, const T
         }
         static_assert(UB == 8, "reduce8");
         const T tot = reduce8(pu, lane);
-        if (lane < UB && c0 + 4 * lane < nb) part[int64_t(c0 + 4 * lane) * part_ld + blockIdx.x] = tot;
+        if (lane < UB && c0 + 4 * lane < nb) part[int64_t(c0 + 4 * lane) * part_ld + slice] = tot;
     }
 }
 
@@ -201,9 +202,47 @@ __global__ __launch_bounds__(PT, 4) void panel_step_kernel(Acc X, int64_t n, con
     const int nz = nz_dev[0];
     // only the last slice can be ragged; every other workgroup runs the branch-free body
     if ((int64_t(blockIdx.x) + 1) * RS <= n)
-        panel_step_body<T, Acc, VEC, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs);
+        panel_step_body<T, Acc, VEC, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, threadIdx.x, blockIdx.x);
     else
-        panel_step_body<T, Acc, VEC, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs);
+        panel_step_body<T, Acc, VEC, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, threadIdx.x, blockIdx.x);
+}
+
+// Fused look-ahead step (solver.hip::run_panel_passes): workgroup 0 runs the solve of block j (blk_solve_body, one wavefront
+// against the diagonal block in LDS) while workgroups 1.. run the panel step that prepares block j+1 -- phase (A) with the
+// changes of block j-1, phase (B) on a residual that does not contain block j's changes yet (the next solve corrects with
+// the cached cross block).  One launch, one stream: no cross-queue dependency (measured at ~35 us per hop on this
+// platform, which is why solves on a second stream lose).  Workgroups are 1024 threads = four 256-thread step slices, so
+// that the 160 KB LDS request of the solve (one workgroup per CU for everybody) costs the step nothing: 196 step
+// workgroups of 16 waves occupy the CUs exactly like 782 workgroups of 4 waves did.
+constexpr int FS = 4; // step slices per fused workgroup
+template <class T, class Acc, int VEC>
+__global__ __launch_bounds__(256 * FS) void panel_fused_kernel(CdBlkParams<T> sp, int j, Acc X, int64_t n,
+                                                              const T* __restrict__ w, T* __restrict__ r,
+                                                              const int32_t* __restrict__ dcol, const T* __restrict__ dlt,
+                                                              const int32_t* __restrict__ nz_dev,
+                                                              const int32_t* __restrict__ cols, int nb,
+                                                              T* __restrict__ part, int64_t part_ld) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int RS = 64 * VEC;
+    if (blockIdx.x == 0) {
+        static_assert(256 + BLK * NCORR == 256 * FS, "every thread of workgroup 0 has a role");
+        T* corr = reinterpret_cast<T*>(smem_raw + (blk_solve_lds_fused<T>() - size_t(NCORR) * BLK * sizeof(T)));
+        if (threadIdx.x >= 256) blk_corr_helper<T>(sp, corr, threadIdx.x - 256);
+        else blk_solve_body<T, true>(sp, j, smem_raw, threadIdx.x, corr, NCORR);
+        return;
+    }
+    const int sub = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const int64_t slice = (int64_t(blockIdx.x) - 1) * FS + sub;
+    T* base = reinterpret_cast<T*>(smem_raw) + size_t(sub) * 5 * RS;
+    T (*red)[RS] = reinterpret_cast<T (*)[RS]>(base);
+    T* wrs = base + 4 * RS;
+    const int nz = nz_dev[0];
+    // all four slices of a workgroup take the same path (same number of barriers); slices past the end of the rows do
+    // nothing through the ragged path's predication
+    if ((int64_t(blockIdx.x) * FS) * RS <= n)
+        panel_step_body<T, Acc, VEC, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
+    else
+        panel_step_body<T, Acc, VEC, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
 }
 
 template <class T>
@@ -252,7 +291,42 @@ int step_launch(const Acc& acc, int64_t n, const T* w, T* r, const int32_t* dcol
     return int(ns);
 }
 
+template <class T, class Acc, int VEC>
+int fused_launch(const CdBlkParams<T>& sp, int j, const Acc& acc, int64_t n, const T* w, T* r, const int32_t* dcol,
+                 const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s) {
+    constexpr int RS = 64 * VEC;
+    const int64_t ns = (n + RS - 1) / RS;
+    const int64_t nwg = (ns + FS - 1) / FS;
+    const int64_t part_ld = nwg * FS; // slices past the end write zeros; the reduce only sums the first ns
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fused_kernel<T, Acc, VEC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(blk_solve_lds_fused<T>()));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((panel_fused_kernel<T, Acc, VEC>), dim3((unsigned)(nwg + 1)), dim3(256 * FS), blk_solve_lds_fused<T>(), s, sp,
+                       j, acc, n, w, r, dcol, dlt, nz_dev, cols, nb, part, part_ld);
+    return int(part_ld);
+}
+
 } // namespace
+
+template <class T>
+int launch_panel_fused(const CdBlkParams<T>& sp, int j, const DenseView<T>& X, const T* w, T* r, const int32_t* dcol,
+                       const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s) {
+    DenseAcc<T> acc{X.X, X.ld};
+    constexpr int V = VecOf<T>::N;
+    const bool vecok = (X.ld % V == 0) && ((reinterpret_cast<uintptr_t>(X.X) % 16) == 0);
+    if (vecok) return fused_launch<T, DenseAcc<T>, V>(sp, j, acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
+    return fused_launch<T, DenseAcc<T>, 1>(sp, j, acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
+}
+template <class T>
+int launch_panel_fused_snp(const CdBlkParams<T>& sp, int j, const SnpView& X, const T* impute, const T* w, T* r,
+                           const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part,
+                           hipStream_t s) {
+    SnpAcc<T> acc{X.bits, X.ldb, impute};
+    return fused_launch<T, SnpAcc<T>, 4>(sp, j, acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
+}
 
 int64_t panel_part_elems(int64_t n) { return int64_t(PB) * ((n + 63) / 64) + 16; }
 
@@ -278,6 +352,14 @@ void launch_panel_reduce(const T* part, int nslices, int nb, const int32_t* cols
     hipLaunchKernelGGL((panel_reduce_kernel<T>), dim3((unsigned)nb), dim3(PT), 0, s, part, int64_t(nslices), nslices, cols,
                        rsum_dev, xm_by_col, gblk);
 }
+// same with the partials' leading dimension given separately (fused step: padded to whole workgroups)
+template <class T>
+void launch_panel_reduce_ld(const T* part, int64_t part_ld, int nslices, int nb, const int32_t* cols, const T* rsum_dev,
+                            const T* xm_by_col, T* gblk, hipStream_t s) {
+    if (nb <= 0) return;
+    hipLaunchKernelGGL((panel_reduce_kernel<T>), dim3((unsigned)nb), dim3(PT), 0, s, part, part_ld, nslices, cols, rsum_dev,
+                       xm_by_col, gblk);
+}
 template <class T>
 void launch_center_vars(T* vars, const T* xm, int cnt, bool center, hipStream_t s) {
     if (cnt <= 0) return;
@@ -295,6 +377,13 @@ void launch_gather_i32(const int32_t* src, const int32_t* idx, int cnt, int32_t*
     template int launch_panel_step_snp<T>(const SnpView&, const T*, const T*, T*, const int32_t*, const T*,            \
                                           const int32_t*, const int32_t*, int, T*, hipStream_t);                       \
     template void launch_panel_reduce<T>(const T*, int, int, const int32_t*, const T*, const T*, T*, hipStream_t);     \
+    template void launch_panel_reduce_ld<T>(const T*, int64_t, int, int, const int32_t*, const T*, const T*, T*,       \
+                                            hipStream_t);                                                              \
+    template int launch_panel_fused<T>(const CdBlkParams<T>&, int, const DenseView<T>&, const T*, T*, const int32_t*,  \
+                                       const T*, const int32_t*, const int32_t*, int, T*, hipStream_t);                \
+    template int launch_panel_fused_snp<T>(const CdBlkParams<T>&, int, const SnpView&, const T*, const T*, T*,         \
+                                           const int32_t*, const T*, const int32_t*, const int32_t*, int, T*,          \
+                                           hipStream_t);                                                               \
     template void launch_center_vars<T>(T*, const T*, int, bool, hipStream_t);
 INST(double)
 INST(float)

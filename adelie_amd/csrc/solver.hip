@@ -311,7 +311,63 @@ struct Solver {
             (void)hipStreamSynchronize(st2);
             (void)hipStreamDestroy(st2);
         }
+
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+    }
+    // ---- look-ahead form of the Gaussian panel passes (run_panel_passes) ----
+    // The solve of block j (one wavefront, strictly sequential) and the panel step that prepares block j+1 only meet through
+    // the residual; with the centred cross block C_{j+1,j} = X_{j+1}^T W X_j - xbar xbar^T cached next to the diagonal
+    // blocks, the step can run BEFORE block j's changes are known (gradient of block j+1 from a residual without them) and
+    // the solve of block j+1 subtracts C_{j+1,j} delta_j itself.  Solve j and the step for block j+1 then go out as ONE
+    // launch (panel_fused_kernel: workgroup 0 solves, the others step): the chain costs max(step, solve) + reduce per block
+    // instead of their sum.  (Solves on a second stream with event dependencies were measured first: ~35 us per
+    // cross-queue hop, slower than no look-ahead at all.)
+    bool lookahead = true;      // A/B hook ADELIE_HIP_LOOKAHEAD
+    DevBuf<T> d_Xpool, d_la_dlt, d_la_g, d_la_rsum;
+    DevBuf<int32_t> d_la_dcol, d_la_dpos, d_la_nz;
+    struct XKey { int32_t nb_prev = 0, nb = 0; uint64_t ver = 0; };
+    std::vector<XKey> xscr_key, xact_key;
+    std::vector<hipEvent_t> x_ev;
+    double t_enq = 0, t_wait = 0; // host seconds spent enqueueing panel passes / waiting for their state (ADELIE_HIP_TRACE_ENQ)
+    int pending_slot = -1;      // slot holding the changes of the last solved block that the residual does not contain yet
+    int64_t n_cross_blocks = 0;
+    template <class NbOf, class ColsOf>
+    void build_stale_cross(int nblk, std::vector<XKey>& tab, T* xpool, NbOf nb_of, ColsOf cols_of) {
+        const int SL = cd_block_size();
+        x_ev.assign(size_t(nblk), nullptr);
+        bool first = true;
+        for (int j = 1; j < nblk; ++j) {
+            const int nbp = nb_of(j - 1), nb = nb_of(j);
+            XKey& k = tab[size_t(j)];
+            if (k.nb_prev == nbp && k.nb == nb && k.ver == w_version) continue;
+            const bool side = side_grams && st2 != nullptr;
+            hipStream_t gs = side ? st2 : st;
+            if (side && first) {
+                hipEvent_t e0 = next_event();
+                AHIP_CHECK(hipEventRecord(e0, st));
+                AHIP_CHECK(hipStreamWaitEvent(st2, e0, 0));
+                first = false;
+            }
+            T* work = (side ? d_work_gram2 : d_work_gram)
+                          .reserve(size_t(std::max<int64_t>(gram_work_elems(n, SL, SL), syrk_work_elems(n, 128))));
+            T* Cx = xpool + size_t(j) * SL * SL;
+            t_gram.begin(gs);
+            if (dense())
+                launch_gram<T>(D->dense<T>(), cur_w, cols_of(j), nb, 0, cols_of(j - 1), nbp, 0, cur_xm, intercept, Cx, SL, work, gs);
+            else
+                launch_gram_snp<T>(D->snp(), static_cast<const T*>(D->impute), cur_w, cols_of(j), nb, 0, cols_of(j - 1), nbp, 0,
+                                   cur_xm, intercept, Cx, SL, work, gs);
+            t_gram.end(gs);
+            cnt.gram_flops += 2.0 * double(n) * double(nb) * double(nbp);
+            cnt.n_gram_col_reads += nb + nbp;
+            if (side) {
+                hipEvent_t e = next_event();
+                AHIP_CHECK(hipEventRecord(e, st2));
+                x_ev[size_t(j)] = e;
+            }
+            k.nb_prev = nbp; k.nb = nb; k.ver = w_version;
+            ++n_cross_blocks;
+        }
     }
     std::vector<int32_t> dscr_nb, dact_nb;      // cached block: number of members it was built for
     std::vector<uint64_t> dscr_ver, dact_ver;   // ... and the weight version
@@ -970,7 +1026,15 @@ struct Solver {
             dscr_ver.assign(maxblk, 0); dact_ver.assign(maxblk, 0);
             panel_maxblk = maxblk;
         }
-        if (side_grams && !st2) AHIP_CHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+        if (side_grams && !st2) {
+            // lowest priority: the builds are needed a whole pass (or lambda) later, the chain on the main stream is latency
+            // critical -- and the fused look-ahead step needs whole CUs, which a build kernel ahead of it in the dispatch
+            // order would hold for ~100 us
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (std::getenv("ADELIE_HIP_SIDE_PRIO") && std::atoi(std::getenv("ADELIE_HIP_SIDE_PRIO")) == 0) lo = 0;
+            AHIP_CHECK(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, lo));
+        }
         if (use_report && !h_report) {
             void* hp = nullptr;
             void* dp = nullptr;
@@ -1040,7 +1104,110 @@ struct Solver {
         int64_t iters = 0;
         int status = CD_OK;
         int asz = sc.active_size;
-        auto pass = [&](bool screen_pass) -> T {
+        // look-ahead only under fixed weights: the cross blocks are built once per block pair and re-used for the rest of the
+        // path; under IRLS they would double the MFMA work of every iteration
+        const bool la = lookahead && !is_glm() && !time_panel && B == SL;
+        if (la) {
+            if (xscr_key.size() != maxblk) {
+                d_Xpool.reserve(size_t(2) * maxblk * SL * SL);
+                xscr_key.assign(maxblk, XKey{});
+                xact_key.assign(maxblk, XKey{});
+            }
+            d_la_dlt.reserve(size_t(2) * SL); d_la_g.reserve(size_t(2) * SL); d_la_rsum.reserve(2);
+            d_la_dcol.reserve(size_t(2) * SL); d_la_dpos.reserve(size_t(2) * SL); d_la_nz.reserve(2);
+            d_part.reserve(size_t(2 * panel_part_elems(n) + 2048));
+            pending_slot = -1;
+        }
+        auto pass_la = [&](bool screen_pass) -> T {
+            const int count = screen_pass ? cp.nv : asz;
+            if (count <= 0) return T(0);
+            const int32_t* cols_all = d_vcol.p;
+            if (!screen_pass) {
+                launch_gather_i32(d_vcol.p, cp.active_set, count, d_actcols.p, st);
+                cols_all = d_actcols.p;
+            }
+            auto& tab_nb = screen_pass ? dscr_nb : dact_nb;
+            auto& tab_ver = screen_pass ? dscr_ver : dact_ver;
+            T* pool = d_Dpool.p + (screen_pass ? size_t(0) : maxblk * SL * SL);
+            T* xpool = d_Xpool.p + (screen_pass ? size_t(0) : maxblk * SL * SL);
+            bp.list = screen_pass ? nullptr : cp.active_set;
+            bp.count = count;
+            bp.mark = screen_pass ? 1 : 0;
+            const int nblk = (count + B - 1) / B;
+            auto nb_of = [&](int j) { return std::min(B, count - j * B); };
+            auto cols_of = [&](int j) { return cols_all + size_t(j) * B; };
+            Stopwatch sw_enq;
+            sw_enq.start();
+            build_stale_blocks(nblk, tab_nb, tab_ver, pool, nb_of, cols_of);
+            build_stale_cross(nblk, screen_pass ? xscr_key : xact_key, xpool, nb_of, cols_of);
+            t_cd.begin(st);
+            // first step of the pass: applies the pending changes of the previous pass's last block and prepares blocks 0 AND 1
+            // (block 1 from a residual without block 0's changes)
+            const int nb01 = nb_of(0) + (nblk > 1 ? nb_of(1) : 0);
+            {
+                const int ps = pending_slot;
+                const int nsl = panel_step(cur_w, r_dev, ps < 0 ? d_dcolblk.p : d_la_dcol.p + size_t(ps) * SL,
+                                           ps < 0 ? d_dlt.p : d_la_dlt.p + size_t(ps) * SL,
+                                           ps < 0 ? &d_blk.p->nz : d_la_nz.p + ps, cols_all, nb01);
+                launch_panel_reduce<T>(d_part.p, nsl, nb01, cols_all, &d_blk.p->resid_sum, xm_c, d_la_g.p, st);
+                cnt.n_panel_cols += nb01;
+            }
+            for (int j = 0; j < nblk; ++j) {
+                const int slot = j & 1, pslot = slot ^ 1;
+                bp.gblk = d_la_g.p + size_t(slot) * B;
+                bp.Dptr = pool + size_t(j) * SL * SL;
+                bp.Cprev = j > 0 ? xpool + size_t(j) * SL * SL : nullptr;
+                bp.pdlt = d_la_dlt.p + size_t(pslot) * SL;
+                bp.ppos = d_la_dpos.p + size_t(pslot) * SL;
+                bp.pnz = d_la_nz.p + pslot;
+                bp.dlt = d_la_dlt.p + size_t(slot) * SL;
+                bp.dcol = d_la_dcol.p + size_t(slot) * SL;
+                bp.dpos = d_la_dpos.p + size_t(slot) * SL;
+                bp.nz_out = d_la_nz.p + slot;
+                bp.rsum_out = d_la_rsum.p + slot;
+                if (h_report && j == nblk - 1) {
+                    bp.report_j = j;
+                    bp.report_seq = ++report_seq;
+                } else {
+                    bp.report_j = -1;
+                }
+                if (blk_ev[size_t(j)]) AHIP_CHECK(hipStreamWaitEvent(st, blk_ev[size_t(j)], 0));
+                if (x_ev[size_t(j)]) AHIP_CHECK(hipStreamWaitEvent(st, x_ev[size_t(j)], 0));
+                if (j == 0) { // nothing to overlap with: the step above already prepared block 1
+                    launch_cd_panel_solve<T>(bp, 0, st);
+                    continue;
+                }
+                // solve of block j  ||  step: apply block j-1's changes, partial gradients of block j+1
+                const int nbn = (j + 1 < nblk) ? nb_of(j + 1) : 0;
+                const int32_t* cols_n = cols_all + size_t(j + 1) * B;
+                int ld;
+                if (dense())
+                    ld = launch_panel_fused<T>(bp, j, D->dense<T>(), cur_w, r_dev, d_la_dcol.p + size_t(pslot) * SL,
+                                               d_la_dlt.p + size_t(pslot) * SL, d_la_nz.p + pslot, cols_n, nbn, d_part.p, st);
+                else
+                    ld = launch_panel_fused_snp<T>(bp, j, D->snp(), static_cast<const T*>(D->impute), cur_w, r_dev,
+                                                   d_la_dcol.p + size_t(pslot) * SL, d_la_dlt.p + size_t(pslot) * SL,
+                                                   d_la_nz.p + pslot, cols_n, nbn, d_part.p, st);
+                if (nbn > 0) {
+                    // resid_sum as it was before block j's solve (the residual the partials were taken from)
+                    launch_panel_reduce_ld<T>(d_part.p, ld, ld, nbn, cols_n, d_la_rsum.p + pslot, xm_c,
+                                              d_la_g.p + size_t(pslot) * B, st);
+                    cnt.n_panel_cols += nbn;
+                }
+            }
+            pending_slot = (nblk - 1) & 1;
+            t_cd.end(st);
+            AHIP_CHECK(hipGetLastError());
+            cnt.n_panel_blocks += nblk;
+            t_enq += sw_enq.elapsed();
+            sw_enq.start();
+            wait_pass_state(bs);
+            t_wait += sw_enq.elapsed();
+            status = bs.status;
+            asz = bs.active_size;
+            return bs.cm;
+        };
+        auto pass_plain = [&](bool screen_pass) -> T {
             const int count = screen_pass ? cp.nv : asz;
             if (count <= 0) return T(0);
             const int32_t* cols_all = d_vcol.p;
@@ -1055,6 +1222,8 @@ struct Solver {
             bp.count = count;
             bp.mark = screen_pass ? 1 : 0;
             const int nblk = (count + B - 1) / B;
+            Stopwatch sw_enq;
+            sw_enq.start();
             build_stale_blocks(nblk, tab_nb, tab_ver, pool, [&](int j) { return std::min(B, count - j * B); },
                                [&](int j) { return cols_all + size_t(j) * B; });
             t_cd.begin(st);
@@ -1080,7 +1249,10 @@ struct Solver {
             t_cd.end(st);
             AHIP_CHECK(hipGetLastError()); // a failed launch would otherwise only show up as a stalled pass report
             cnt.n_panel_blocks += nblk;
+            t_enq += sw_enq.elapsed();
+            sw_enq.start();
             wait_pass_state(bs);
+            t_wait += sw_enq.elapsed();
             status = bs.status;
             asz = bs.active_size;
             if (trace) std::fprintf(stderr, "[panel] %s count=%d nblk=%d cm=%g tol=%g status=%d asz=%d nz=%d rsq=%g rsum=%g nupd=%lld\n",
@@ -1088,6 +1260,7 @@ struct Solver {
                                     bs.nz, double(bs.rsq), double(bs.resid_sum), (long long)bs.n_updates);
             return bs.cm;
         };
+        auto pass = [&](bool screen_pass) -> T { return la ? pass_la(screen_pass) : pass_plain(screen_pass); };
         while (status == CD_OK) {
             while (status == CD_OK) { // solve_active, pin_naive:173-215
                 ++iters;
@@ -1109,7 +1282,13 @@ struct Solver {
         }
         // flush the last block's changes into the residual
         t_cd.begin(st);
-        panel_step(cur_w, r_dev, d_dcolblk.p, d_dlt.p, &d_blk.p->nz, d_vcol.p, 0);
+        if (la && pending_slot >= 0) {
+            panel_step(cur_w, r_dev, d_la_dcol.p + size_t(pending_slot) * SL, d_la_dlt.p + size_t(pending_slot) * SL,
+                       d_la_nz.p + pending_slot, d_vcol.p, 0);
+            pending_slot = -1;
+        } else {
+            panel_step(cur_w, r_dev, d_dcolblk.p, d_dlt.p, &d_blk.p->nz, d_vcol.p, 0);
+        }
         t_cd.end(st);
         sc.rsq = bs.rsq;
         sc.resid_sum = bs.resid_sum;
@@ -1904,6 +2083,9 @@ struct Solver {
 
     // pull the device-resident invariants back into the host mirrors that the result accessors expose
     void finalize() {
+        if (std::getenv("ADELIE_HIP_TRACE_ENQ"))
+            std::fprintf(stderr, "[enq] panel passes: host enqueue %.1f ms, host wait %.1f ms, blocks %lld\n", t_enq * 1e3,
+                         t_wait * 1e3, (long long)cnt.n_panel_blocks);
         t_sweep.collect(); t_gram.collect(); t_cd.collect(); t_axpy.collect(); t_step.collect();
         if (d_grp_dbg.p) {
             sync();
@@ -2004,6 +2186,7 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_SIDE_GRAMS")) side_grams = std::atoi(e) != 0; // A/B hook
         if (const char* e = std::getenv("ADELIE_HIP_PRELAUNCH_SWEEP")) prelaunch_sweep = std::atoi(e) != 0; // A/B hook
         if (const char* e = std::getenv("ADELIE_HIP_GROUP_PANEL")) group_panel = std::atoi(e) != 0; // A/B hook
+        if (const char* e = std::getenv("ADELIE_HIP_LOOKAHEAD")) lookahead = std::atoi(e) != 0; // A/B hook
         if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {
             panel_bsz = std::atoi(e);
             if (panel_bsz != 32 && panel_bsz != 64 && panel_bsz != 128) panel_bsz = 0;

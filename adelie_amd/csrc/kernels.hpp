@@ -212,6 +212,14 @@ struct CdGrpBlkParams {
     int32_t* host_seq;
     int32_t report_j, report_seq;
     int64_t* dbg;        // 8 cycle counters, only written by builds with -DAHIP_GRP_PROFILE
+    // look-ahead form, see CdBlkParams (positions are block-local value indices)
+    const T* Cprev;
+    const T* pdlt;
+    const int32_t* ppos;
+    const int32_t* pnz;
+    int32_t* dpos;
+    int32_t* nz_out;
+    T* rsum_out;
 };
 template <class T> void launch_cd_group_block_pass(const CdGrpBlkParams<T>& p, hipStream_t s);
 // the visits of block j against p.gblk / p.Dptr (one workgroup)
@@ -245,6 +253,13 @@ template <class T>
 int launch_panel_fused_snp(const CdBlkParams<T>& sp, int j, const SnpView& X, const T* impute, const T* w, T* r,
                            const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part,
                            hipStream_t s);
+template <class T>
+int launch_panel_fused_grp(const CdGrpBlkParams<T>& sp, int j, const DenseView<T>& X, const T* w, T* r, const int32_t* dcol,
+                           const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s);
+template <class T>
+int launch_panel_fused_grp_snp(const CdGrpBlkParams<T>& sp, int j, const SnpView& X, const T* impute, const T* w, T* r,
+                               const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb,
+                               T* part, hipStream_t s);
 // the visits of block j of the pass (one workgroup); p.gblk / p.Dptr / p.vcol / p.dcol must be set
 template <class T> void launch_cd_panel_solve(const CdBlkParams<T>& p, int j, hipStream_t s);
 template <class T> void launch_center_vars(T* vars, const T* xm, int cnt, bool center, hipStream_t s);

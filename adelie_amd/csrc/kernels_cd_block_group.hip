@@ -8,101 +8,11 @@
 // wavefront does it lane-parallel over the q coefficients with wave reductions.  Groups wider than 128 values fall back
 // to the single-workgroup kernel (kernels_cd.hip).
 #include "kernels.hpp"
+#include "grp_solve_body.hpp"
 
 namespace ahip {
 
 namespace {
-
-constexpr int GBLK = 128;
-constexpr int VPOOL = 1280; // LDS pool (elements) for the eigenbases of a block's groups (12 groups of 10: 1200)
-
-template <class T>
-__device__ __forceinline__ T gwsum(T x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-    return x;
-}
-
-// Sum over the first 16 lanes with DPP (no LDS crossbar): xor-1, xor-2 by quad_perm, then row_half_mirror and
-// row_mirror; the result is made wave-uniform with readfirstlane.  Lanes >= 16 must not contribute.
-template <int CTRL>
-__device__ __forceinline__ double dpp_move(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_move(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
-}
-__device__ __forceinline__ double first_lane(double x) {
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)),
-                            __builtin_amdgcn_readfirstlane(__double2loint(x)));
-}
-__device__ __forceinline__ float first_lane(float x) {
-    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
-}
-template <class T>
-__device__ __forceinline__ T row16_sum(T x) {
-    x += dpp_move<0xB1>(x);  // quad_perm [1,0,3,2]
-    x += dpp_move<0x4E>(x);  // quad_perm [2,3,0,1]
-    x += dpp_move<0x141>(x); // row_half_mirror
-    x += dpp_move<0x140>(x); // row_mirror
-    return first_lane(x);
-}
-// sum of per-lane partials of a q-long group (lanes >= q hold 0)
-template <class T>
-__device__ __forceinline__ T group_sum(T x, int q) {
-    return q <= 16 ? row16_sum(x) : gwsum(x);
-}
-
-// Fills vmap[0..nval) with the global screen-value index of every value of block j, plus the group tables (all in LDS).
-// Cooperative: every thread of the (256-thread) workgroup must call it.  The per-group lookups (list -> begin / size)
-// are two dependent global loads; doing them one group per thread costs two round trips for the whole block instead of
-// two per group in a serial loop (which was most of a 12-group block's latency).
-template <class T>
-__device__ __forceinline__ void block_layout(const CdGrpBlkParams<T>& p, int j, int32_t* vmap, int32_t* goff,
-                                             int32_t* gq, int32_t* gss, int32_t* meta /* [0]=ngrp [1]=nval */) {
-    __shared__ int32_t gb_[GBLK];
-    const int tid = threadIdx.x;
-    const int g0 = p.blk_g0[j], g1 = p.blk_g0[j + 1];
-    const int ng = g1 - g0;
-    if (tid < GBLK) {
-        int ss = 0, b = 0, q = 0;
-        if (tid < ng) {
-            ss = p.list ? p.list[g0 + tid] : g0 + tid;
-            b = p.sbegin[ss];
-            q = p.ssize[ss];
-        }
-        gss[tid] = ss;
-        gb_[tid] = b;
-        gq[tid] = q;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int o = 0;
-        for (int k = 0; k < ng; ++k) { goff[k] = o; o += gq[k]; }
-        goff[ng] = o;
-        meta[0] = ng;
-        meta[1] = o;
-    }
-    __syncthreads();
-    for (int k = tid >> 1; k < ng; k += 128) { // two threads per group
-        const int o = goff[k], q = gq[k], b = gb_[k];
-        for (int t = tid & 1; t < q; t += 2) vmap[o + t] = b + t;
-    }
-    __syncthreads();
-}
-
-template <class T>
-__device__ __forceinline__ void gather_group_block(const CdGrpBlkParams<T>& p, int j, const int32_t* vmap, int nval,
-                                                   int gtid, int gthreads) {
-    T* D = p.Dbuf + size_t(j & 1) * GBLK * GBLK;
-    for (int e = gtid; e < nval * nval; e += gthreads) {
-        const int i = e % nval, m = e / nval;
-        D[i + m * GBLK] = p.C[int64_t(vmap[i]) + int64_t(vmap[m]) * p.ldc];
-    }
-}
 
 template <class T>
 __global__ __launch_bounds__(256) void grp_gather_kernel(CdGrpBlkParams<T> p, int j) {
@@ -115,346 +25,7 @@ __global__ __launch_bounds__(256) void grp_gather_kernel(CdGrpBlkParams<T> p, in
 template <class T, bool NAIVE>
 __global__ __launch_bounds__(256) void grp_solve_kernel(CdGrpBlkParams<T> p, int j) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* D = reinterpret_cast<T*>(smem_raw); // GBLK*GBLK
-    T* gB = D + GBLK * GBLK;
-    T* bB = gB + GBLK;     // current beta of the block's values
-    T* b0B = bB + GBLK;    // beta at block entry
-    T* AB = b0B + GBLK;
-    T* xmB = AB + GBLK;
-    T* scr = xmB + GBLK;   // 8 * GBLK group scratch
-    int32_t* vmap = reinterpret_cast<int32_t*>(scr + 8 * GBLK);
-    int32_t* goff = vmap + GBLK;
-    int32_t* gq = goff + GBLK + 1;
-    int32_t* gss = gq + GBLK;
-    int32_t* meta = gss + GBLK;
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    block_layout(p, j, vmap, goff, gq, gss, meta);
-    const int ngrp = meta[0], nval = meta[1];
-    // per-group constants and (when they fit) all eigenbases of the block, fetched by the whole workgroup up front so that
-    // the sequential wave never waits on a global load
-    T* gpenB = reinterpret_cast<T*>(meta + 5); // int index 518 of the region: 8-byte aligned
-    int32_t* gactB = reinterpret_cast<int32_t*>(gpenB + GBLK);
-    int32_t* gvoB = gactB + GBLK;          // offset of the group's eigenbasis in Vpool, or -1
-    T* Vpool = reinterpret_cast<T*>(gvoB + GBLK);
-    if (tid < GBLK && tid < ngrp) {
-        const int ss = gss[tid];
-        gpenB[tid] = p.spen[ss];
-        gactB[tid] = p.is_active[ss];
-    }
-    if (tid == 0) {
-        int used = 0;
-        for (int k = 0; k < ngrp; ++k) {
-            const int q = gq[k];
-            if (q > 1 && used + q * q <= VPOOL) { gvoB[k] = used; used += q * q; }
-            else gvoB[k] = -1;
-        }
-    }
-    __syncthreads();
-    for (int k = wv; k < ngrp; k += 4) { // one wave per group
-        const int vo = gvoB[k];
-        if (vo < 0) continue;
-        const int q = gq[k];
-        const T* Vg = p.V + p.voff[gss[k]];
-        for (int e = lane; e < q * q; e += 64) Vpool[vo + e] = Vg[e];
-    }
-    if (tid < GBLK) {
-        const int i = tid;
-        if (i < nval) {
-            const int a = vmap[i];
-            gB[i] = NAIVE ? p.gblk[i] : p.g[a];
-            bB[i] = p.beta[a];
-            b0B[i] = bB[i];
-            AB[i] = p.vars[a];
-            xmB[i] = p.xmean[a];
-        } else {
-            gB[i] = 0; bB[i] = 0; b0B[i] = 0; AB[i] = 0; xmB[i] = 0;
-        }
-    }
-    {
-        const T* src = NAIVE ? p.Dptr : p.Dbuf + size_t(j & 1) * GBLK * GBLK;
-        // 16 loads in flight per lane; columns [0, nval) of the slot
-        const int NE = nval * GBLK;
-        for (int e0 = tid; e0 < NE; e0 += 256 * 16) {
-            T v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = src[min(e0 + u * 256, NE - 1)];
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (e0 + u * 256 < NE) D[e0 + u * 256] = v[u];
-        }
-    }
-    __syncthreads();
-    if (wv != 0) return;
-    __builtin_amdgcn_s_setprio(3); // critical path of the pass: win the issue arbitration on this CU
-
-#ifdef AHIP_GRP_PROFILE
-    long long tmark = __builtin_readcyclecounter();
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define GP_MARK(k) { const long long tn = __builtin_readcyclecounter(); tacc[k] += tn - tmark; tmark = tn; }
-    GP_MARK(0) /* prologue (since wave start is not visible: from here) */
-#else
-#define GP_MARK(k)
-#endif
-    CdBlkState<T>* st = p.st;
-    T rsq = st->rsq, rsum = st->resid_sum, cm = (j == 0) ? T(0) : st->cm;
-    int asz = st->active_size, status = st->status;
-    int64_t n_upd = st->n_updates;
-    T* gk_t = scr;
-    T* ak_old_t = scr + GBLK;
-    T* ak_t = scr + 2 * GBLK;
-    T* buf1 = scr + 3 * GBLK;
-    T* buf2 = scr + 4 * GBLK;
-    T* del = scr + 5 * GBLK;
-
-    for (int k = 0; k < ngrp && status == CD_OK; ++k) {
-        const int o = goff[k], q = gq[k], ss = gss[k];
-        const T pk = gpenB[k];
-        const T l1p = p.l1 * pk, l2p = p.l2 * pk;
-        bool changed = false;
-        if (q == 1) {
-            const T gcur = gB[o], bi = bB[o], A = AB[o];
-            const T gk = fma(bi, A, gcur);                       // pin_naive:85-89
-            const T v = fabs(gk) - l1p;                          // pin_base:181-195
-            const T ak = (v > T(0)) ? copysign(v, gk) / (A + l2p) : T(0);
-            if (ak != bi) {                                      // pin_naive:97
-                changed = true;
-                const T d = ak - bi;
-                const T c1 = A * d * d;
-                cm = c1 > cm ? c1 : cm;
-                rsq += d * (T(2) * gcur - d * A);
-                rsum -= xmB[o] * d;
-                if (lane == 0) { bB[o] = ak; del[0] = d; }
-            }
-        } else {
-            // stage the (q,q) eigenbasis in LDS (one coalesced read) when it fits the scratch; else read it in place
-            const T* V;
-            if (gvoB[k] >= 0) {
-                V = Vpool + gvoB[k];
-            } else {
-                const T* Vg = p.V + p.voff[ss];
-                V = Vg;
-                if (q * q <= 2 * GBLK) {
-                    T* Vl = scr + 6 * GBLK;
-                    for (int e = lane; e < q * q; e += 64) Vl[e] = Vg[e];
-                    V = Vl;
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            const T* A = AB + o;
-            T dn = 0, c1 = 0, rs = 0;
-            if (q <= 64) {
-                // One element per lane: the group's rotated vectors stay in registers from the rotation to the change test
-                // (same operations in the same order as the general path below, so the results are bit-identical; only the
-                // LDS round trips between the phases are gone).
-                const bool on = lane < q;
-                const T A_r = on ? A[lane] : T(0);
-                T gk_r = T(0), ako_r = T(0);
-                if (on) { // gk_t = gk V ; ak_old_t = ak_old V ; gk_t += A * ak_old_t   (pin_naive:123-140)
-                    T s1 = 0, s2 = 0;
-                    const T* Vj = V + int64_t(lane) * q;
-#pragma unroll 4
-                    for (int i = 0; i < q; ++i) {
-                        s1 = fma(gB[o + i], Vj[i], s1);
-                        s2 = fma(bB[o + i], Vj[i], s2);
-                    }
-                    ako_r = s2;
-                    gk_r = s1 + A_r * s2;
-                }
-                GP_MARK(1) /* rotation */
-                // newton_solver (bcd/unconstrained/newton.hpp:35-142): v = gk_t, L = A
-                const T nrm2 = group_sum(on ? gk_r * gk_r : T(0), q);
-                T akt_r = T(0);
-                if (sqrt(nrm2) <= l1p) {
-                    akt_r = T(0);
-                } else if (l1p <= T(0)) {
-                    akt_r = on ? gk_r / (A_r + l2p) : T(0);
-                } else {
-                    const T b1 = A_r + l2p;
-                    T h = 0, fh, dfh, b2 = T(0);
-                    auto step = [&](T hh) {
-                        T t = 0, sx = 0;
-                        if (on) {
-                            b2 = T(1) / (b1 * hh + l1p);
-                            const T z = gk_r * b2;
-                            const T x = z * z;
-                            t = x;
-                            sx = x * b1 * b2;
-                        }
-                        t = group_sum(t, q);
-                        sx = group_sum(sx, q);
-                        fh = t - T(1);
-                        dfh = -sx * (T(1) + sqrt(t)) / t;
-                    };
-                    step(h);
-                    int iters = 0;
-                    while ((fabs(fh) > p.newton_tol) && (iters < p.newton_max_iters)) {
-                        h -= fh / dfh;
-                        h = h > T(0) ? h : T(0);
-                        step(h);
-                        ++iters;
-                    }
-                    akt_r = on ? h * gk_r * b2 : T(0);
-                    if (iters >= p.newton_max_iters) { status = CD_NEWTON; break; }
-                }
-                if (on) ak_t[lane] = akt_r; // read by every lane in the back rotation
-                __builtin_amdgcn_wave_barrier();
-                GP_MARK(2) /* norm + newton */
-                // changed? ; convergence / rsq in rotated coordinates (pin_naive:144-154)
-                if (on) {
-                    const T gg = gk_r - A_r * ako_r;
-                    const T d = akt_r - ako_r;
-                    dn = d * d;
-                    c1 = (A_r * d) * d;
-                    rs = d * (T(2) * gg - d * A_r);
-                }
-                dn = group_sum(dn, q);
-                c1 = group_sum(c1, q);
-                rs = group_sum(rs, q);
-            } else {
-                const T* A = AB + o;
-                // gk_t = gk V ; ak_old_t = ak_old V ; gk_t += A * ak_old_t   (pin_naive:123-140)
-                for (int jj = lane; jj < q; jj += 64) {
-                    T s1 = 0, s2 = 0;
-                    const T* Vj = V + int64_t(jj) * q;
-#pragma unroll 4
-                    for (int i = 0; i < q; ++i) {
-                        s1 = fma(gB[o + i], Vj[i], s1);
-                        s2 = fma(bB[o + i], Vj[i], s2);
-                    }
-                    ak_old_t[jj] = s2;
-                    gk_t[jj] = s1 + A[jj] * s2;
-                }
-                __builtin_amdgcn_wave_barrier();
-                GP_MARK(1) /* rotation */
-                // newton_solver (bcd/unconstrained/newton.hpp:35-142): v = gk_t, L = A
-                T nrm2 = 0;
-                for (int i = lane; i < q; i += 64) nrm2 = fma(gk_t[i], gk_t[i], nrm2);
-                nrm2 = group_sum(nrm2, q);
-                if (sqrt(nrm2) <= l1p) {
-                    for (int i = lane; i < q; i += 64) ak_t[i] = 0;
-                } else if (l1p <= T(0)) {
-                    for (int i = lane; i < q; i += 64) ak_t[i] = gk_t[i] / (A[i] + l2p);
-                } else {
-                    for (int i = lane; i < q; i += 64) buf1[i] = A[i] + l2p;
-                    T h = 0, fh, dfh;
-                    auto step = [&](T hh) {
-                        T t = 0, s = 0;
-                        for (int i = lane; i < q; i += 64) {
-                            const T b2 = T(1) / (buf1[i] * hh + l1p);
-                            const T z = gk_t[i] * b2;
-                            const T x = z * z;
-                            buf2[i] = b2;
-                            t += x;
-                            s += x * buf1[i] * b2;
-                        }
-                        t = group_sum(t, q);
-                        s = group_sum(s, q);
-                        fh = t - T(1);
-                        dfh = -s * (T(1) + sqrt(t)) / t;
-                    };
-                    step(h);
-                    int iters = 0;
-                    while ((fabs(fh) > p.newton_tol) && (iters < p.newton_max_iters)) {
-                        h -= fh / dfh;
-                        h = h > T(0) ? h : T(0);
-                        step(h);
-                        ++iters;
-                    }
-                    for (int i = lane; i < q; i += 64) ak_t[i] = h * gk_t[i] * buf2[i];
-                    if (iters >= p.newton_max_iters) { status = CD_NEWTON; break; }
-                }
-                __builtin_amdgcn_wave_barrier();
-                GP_MARK(2) /* norm + newton */
-                // changed? ; convergence / rsq in rotated coordinates (pin_naive:144-154)
-                for (int i = lane; i < q; i += 64) {
-                    const T gg = gk_t[i] - A[i] * ak_old_t[i];
-                    const T d = ak_t[i] - ak_old_t[i];
-                    dn = fma(d, d, dn);
-                    c1 = fma(A[i] * d, d, c1);
-                    rs += d * (T(2) * gg - d * A[i]);
-                }
-                dn = group_sum(dn, q);
-                c1 = group_sum(c1, q);
-                rs = group_sum(rs, q);
-            }
-            if (!(sqrt(dn) <= p.dbeta_tol * sqrt(T(q)))) {
-                changed = true;
-                c1 /= T(q);
-                cm = c1 > cm ? c1 : cm;
-                rsq += rs;
-                // ak = ak_t V^T ; del = ak - ak_old ; resid_sum -= xbar . del   (pin_naive:156-163)
-                T rsd = 0;
-                for (int i = lane; i < q; i += 64) {
-                    T s = 0;
-#pragma unroll 4
-                    for (int jj = 0; jj < q; ++jj) s = fma(ak_t[jj], V[i + int64_t(jj) * q], s);
-                    const T d = s - bB[o + i];
-                    del[i] = d;
-                    bB[o + i] = s;
-                    rsd = fma(xmB[o + i], d, rsd);
-                }
-                rsum -= group_sum(rsd, q);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        GP_MARK(3) /* changed test + back rotation */
-        if (changed) {
-            if (p.mark && gactB[k] == 0) {                         // add_active_set, pin_naive:294-304
-                if (asz >= p.max_active_size) { status = CD_MAX_ACTIVE; break; }
-                if (lane == 0) { p.is_active[ss] = 1; p.active_set[asz] = ss; }
-                ++asz;
-            }
-            // keep the block's gradient current: gB -= D[:, o:o+q] del
-            for (int l = lane; l < GBLK; l += 64) {
-                T acc = gB[l];
-#pragma unroll 4
-                for (int t = 0; t < q; ++t) acc = fma(-D[l + (o + t) * GBLK], del[t], acc);
-                gB[l] = acc;
-            }
-            __builtin_amdgcn_wave_barrier();
-            ++n_upd;
-        }
-        GP_MARK(4) /* active marking + block gradient update */
-    }
-    // write back beta and the compacted non-zero value changes for the update kernel
-    int nz = 0;
-    for (int i0 = 0; i0 < GBLK; i0 += 64) {
-        const int i = i0 + lane;
-        const T d = (i < nval) ? (bB[i] - b0B[i]) : T(0);
-        const bool ch = (i < nval) && (bB[i] != b0B[i]);
-        if (ch) p.beta[vmap[i]] = bB[i];
-        const unsigned long long m = __ballot(ch);
-        const int pos = nz + __popcll(m & ((1ull << lane) - 1ull));
-        if (ch) {
-            if (NAIVE) p.dcol[pos] = p.vcol[vmap[i]];
-            else p.didx[pos] = vmap[i];
-            p.dlt[pos] = d;
-        }
-        nz += __popcll(m);
-    }
-    if (lane == 0) {
-        st->rsq = rsq;
-        st->resid_sum = rsum;
-        st->cm = cm;
-        st->active_size = asz;
-        st->status = status;
-        st->n_updates = n_upd;
-        st->nz = nz;
-#ifdef AHIP_GRP_PROFILE
-        GP_MARK(5) /* epilogue */
-        if (p.dbg) for (int k = 0; k < 8; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(p.dbg) + k, (unsigned long long)tacc[k]);
-        if (p.dbg) atomicAdd(reinterpret_cast<unsigned long long*>(p.dbg) + 7, 1ull);
-#endif
-        if (NAIVE && p.host_st && j == p.report_j) {
-            CdBlkState<T> out;
-            out.rsq = rsq; out.resid_sum = rsum; out.cm = cm; out.n_updates = n_upd;
-            out.active_size = asz; out.status = status; out.nz = nz; out._pad = 0;
-            *p.host_st = out;
-            __threadfence_system();
-            __hip_atomic_store(p.host_seq, p.report_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    grp_solve_body<T, NAIVE>(p, j, smem_raw);
 }
 
 template <class T>
@@ -491,11 +62,6 @@ __global__ __launch_bounds__(256) void grp_update_kernel(CdGrpBlkParams<T> p, in
     }
 }
 
-template <class T>
-size_t grp_solve_lds() {
-    return size_t(GBLK) * GBLK * sizeof(T) + size_t(GBLK) * (5 + 8) * sizeof(T) + (size_t(GBLK) * 4 + 8) * sizeof(int32_t) + 16 +
-           size_t(GBLK) * sizeof(T) + size_t(GBLK) * 2 * sizeof(int32_t) + size_t(VPOOL) * sizeof(T);
-}
 
 } // namespace
 
@@ -506,12 +72,12 @@ void launch_cd_group_block_pass(const CdGrpBlkParams<T>& p, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grp_solve_kernel<double, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_solve_lds<double>()));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_solve_lds_total<double>()));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grp_solve_kernel<float, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_solve_lds<float>()));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_solve_lds_total<float>()));
         attr_done = true;
     }
-    const size_t lds = grp_solve_lds<T>();
+    const size_t lds = grp_solve_lds_total<T>();
     hipLaunchKernelGGL((grp_gather_kernel<T>), dim3(64), dim3(256), 0, s, p, 0);
     for (int j = 0; j < p.nblk; ++j) {
         hipLaunchKernelGGL((grp_solve_kernel<T, false>), dim3(1), dim3(256), lds, s, p, j);
@@ -524,12 +90,12 @@ void launch_cd_group_panel_solve(const CdGrpBlkParams<T>& p, int j, hipStream_t 
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grp_solve_kernel<double, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_solve_lds<double>()));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_solve_lds_total<double>()));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grp_solve_kernel<float, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_solve_lds<float>()));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_solve_lds_total<float>()));
         attr_done = true;
     }
-    hipLaunchKernelGGL((grp_solve_kernel<T, true>), dim3(1), dim3(256), grp_solve_lds<T>(), s, p, j);
+    hipLaunchKernelGGL((grp_solve_kernel<T, true>), dim3(1), dim3(256), grp_solve_lds_total<T>(), s, p, j);
 }
 template void launch_cd_group_panel_solve<double>(const CdGrpBlkParams<double>&, int, hipStream_t);
 template void launch_cd_group_panel_solve<float>(const CdGrpBlkParams<float>&, int, hipStream_t);

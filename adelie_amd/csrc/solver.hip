@@ -1437,7 +1437,117 @@ struct Solver {
         int asz = sc.active_size;
         std::vector<idx> act_host(active_set.begin(), active_set.begin() + asz); // host mirror of the active list
         std::vector<int32_t>& acols = h_actcols;
-        auto pass = [&](bool screen_pass) -> T {
+        // look-ahead form (see run_panel_passes); not on the multi-response view, whose step is a different kernel
+        const bool la = lookahead && !is_glm() && !time_panel && !multi();
+        if (la) {
+            if (xscr_key.size() != maxblk) {
+                d_Xpool.reserve(size_t(2) * maxblk * SL * SL);
+                xscr_key.assign(maxblk, XKey{});
+                xact_key.assign(maxblk, XKey{});
+            }
+            d_la_dlt.reserve(size_t(2) * SL); d_la_g.reserve(size_t(2) * SL); d_la_rsum.reserve(2);
+            d_la_dcol.reserve(size_t(2) * SL); d_la_dpos.reserve(size_t(2) * SL); d_la_nz.reserve(2);
+            d_part.reserve(size_t(2 * panel_part_elems(n) + 2048));
+            pending_slot = -1;
+        }
+        auto pass_la = [&](bool screen_pass) -> T {
+            const idx count = screen_pass ? idx(cp.ns) : idx(asz);
+            if (count <= 0) return T(0);
+            const int nblk = build_partition_values(screen_pass ? nullptr : act_host.data(), count);
+            d_blk_g0.reserve(part_host.size());
+            d_blk_g0.upload(part_host.data(), part_host.size(), st);
+            const int32_t* cols_all = d_vcol.p;
+            if (!screen_pass) {
+                acols.clear();
+                for (idx pos = 0; pos < count; ++pos) {
+                    const idx g = screen_set[act_host[pos]];
+                    for (idx t = 0; t < group_sizes[g]; ++t) acols.push_back(int32_t(groups[g] + t));
+                }
+                d_actcols.upload(acols.data(), acols.size(), st);
+                cols_all = d_actcols.p;
+            }
+            auto& tab_nb = screen_pass ? dscr_nb : dact_nb;
+            auto& tab_ver = screen_pass ? dscr_ver : dact_ver;
+            T* pool = d_Dpool.p + (screen_pass ? size_t(0) : maxblk * SL * SL);
+            T* xpool = d_Xpool.p + (screen_pass ? size_t(0) : maxblk * SL * SL);
+            bp.blk_g0 = d_blk_g0.p;
+            bp.list = screen_pass ? nullptr : cp.active_set;
+            bp.nblk = nblk;
+            bp.mark = screen_pass ? 1 : 0;
+            auto nb_of = [&](int j) { return int(gp_vbeg[size_t(j) + 1] - gp_vbeg[j]); };
+            auto cols_of = [&](int j) { return cols_all + gp_vbeg[j]; };
+            build_stale_blocks(nblk, tab_nb, tab_ver, pool, nb_of, cols_of);
+            build_stale_cross(nblk, screen_pass ? xscr_key : xact_key, xpool, nb_of, cols_of);
+            t_cd.begin(st);
+            {   // first step of the pass: pending changes of the previous pass's last block; blocks 0 and 1 prepared
+                const int nv0 = nb_of(0), nv1 = nblk > 1 ? nb_of(1) : 0;
+                const int ps = pending_slot;
+                const int nsl = panel_step(cur_w, r_dev, ps < 0 ? d_dcolblk.p : d_la_dcol.p + size_t(ps) * SL,
+                                           ps < 0 ? d_dlt.p : d_la_dlt.p + size_t(ps) * SL,
+                                           ps < 0 ? &d_blk.p->nz : d_la_nz.p + ps, cols_all, nv0 + nv1);
+                launch_panel_reduce<T>(d_part.p, nsl, nv0, cols_all, &d_blk.p->resid_sum, xm_c, d_la_g.p, st);
+                if (nv1 > 0)
+                    launch_panel_reduce<T>(d_part.p + size_t(nv0) * size_t(nsl), nsl, nv1, cols_all + nv0, &d_blk.p->resid_sum,
+                                           xm_c, d_la_g.p + SL, st);
+                cnt.n_panel_cols += nv0 + nv1;
+            }
+            for (int j = 0; j < nblk; ++j) {
+                const int slot = j & 1, pslot = slot ^ 1;
+                bp.gblk = d_la_g.p + size_t(slot) * SL;
+                bp.Dptr = pool + size_t(j) * SL * SL;
+                bp.Cprev = j > 0 ? xpool + size_t(j) * SL * SL : nullptr;
+                bp.pdlt = d_la_dlt.p + size_t(pslot) * SL;
+                bp.ppos = d_la_dpos.p + size_t(pslot) * SL;
+                bp.pnz = d_la_nz.p + pslot;
+                bp.dlt = d_la_dlt.p + size_t(slot) * SL;
+                bp.dcol = d_la_dcol.p + size_t(slot) * SL;
+                bp.dpos = d_la_dpos.p + size_t(slot) * SL;
+                bp.nz_out = d_la_nz.p + slot;
+                bp.rsum_out = d_la_rsum.p + slot;
+                if (h_report && j == nblk - 1) {
+                    bp.report_j = j;
+                    bp.report_seq = ++report_seq;
+                } else {
+                    bp.report_j = -1;
+                }
+                if (blk_ev[size_t(j)]) AHIP_CHECK(hipStreamWaitEvent(st, blk_ev[size_t(j)], 0));
+                if (x_ev[size_t(j)]) AHIP_CHECK(hipStreamWaitEvent(st, x_ev[size_t(j)], 0));
+                if (j == 0) {
+                    launch_cd_group_panel_solve<T>(bp, 0, st);
+                    continue;
+                }
+                const int nbn = (j + 1 < nblk) ? nb_of(j + 1) : 0;
+                const int32_t* cols_n = cols_all + gp_vbeg[size_t(j) + 1];
+                int ld;
+                if (dense())
+                    ld = launch_panel_fused_grp<T>(bp, j, D->dense<T>(), cur_w, r_dev, d_la_dcol.p + size_t(pslot) * SL,
+                                                   d_la_dlt.p + size_t(pslot) * SL, d_la_nz.p + pslot, cols_n, nbn, d_part.p, st);
+                else
+                    ld = launch_panel_fused_grp_snp<T>(bp, j, D->snp(), static_cast<const T*>(D->impute), cur_w, r_dev,
+                                                       d_la_dcol.p + size_t(pslot) * SL, d_la_dlt.p + size_t(pslot) * SL,
+                                                       d_la_nz.p + pslot, cols_n, nbn, d_part.p, st);
+                if (nbn > 0) {
+                    launch_panel_reduce_ld<T>(d_part.p, ld, ld, nbn, cols_n, d_la_rsum.p + pslot, xm_c,
+                                              d_la_g.p + size_t(pslot) * SL, st);
+                    cnt.n_panel_cols += nbn;
+                }
+            }
+            pending_slot = (nblk - 1) & 1;
+            t_cd.end(st);
+            AHIP_CHECK(hipGetLastError());
+            cnt.n_panel_blocks += nblk;
+            wait_pass_state(bs);
+            status = bs.status;
+            if (bs.active_size > asz) {
+                std::vector<int32_t> fresh(size_t(bs.active_size - asz));
+                d_actset.download(fresh.data(), fresh.size(), st, asz);
+                sync();
+                for (int32_t v : fresh) act_host.push_back(v);
+            }
+            asz = bs.active_size;
+            return bs.cm;
+        };
+        auto pass_plain = [&](bool screen_pass) -> T {
             const idx count = screen_pass ? idx(cp.ns) : idx(asz);
             if (count <= 0) return T(0);
             const int nblk = build_partition_values(screen_pass ? nullptr : act_host.data(), count);
@@ -1496,6 +1606,7 @@ struct Solver {
             asz = bs.active_size;
             return bs.cm;
         };
+        auto pass = [&](bool screen_pass) -> T { return la ? pass_la(screen_pass) : pass_plain(screen_pass); };
         while (status == CD_OK) {
             while (status == CD_OK) { // solve_active, pin_naive:173-215
                 ++iters;
@@ -1517,7 +1628,13 @@ struct Solver {
         }
         // flush the last block's changes into the residual
         t_cd.begin(st);
-        panel_step(cur_w, r_dev, d_dcolblk.p, d_dlt.p, &d_blk.p->nz, d_vcol.p, 0);
+        if (la && pending_slot >= 0) {
+            panel_step(cur_w, r_dev, d_la_dcol.p + size_t(pending_slot) * SL, d_la_dlt.p + size_t(pending_slot) * SL,
+                       d_la_nz.p + pending_slot, d_vcol.p, 0);
+            pending_slot = -1;
+        } else {
+            panel_step(cur_w, r_dev, d_dcolblk.p, d_dlt.p, &d_blk.p->nz, d_vcol.p, 0);
+        }
         t_cd.end(st);
         sc.rsq = bs.rsq;
         sc.resid_sum = bs.resid_sum;

@@ -1106,7 +1106,7 @@ struct Solver {
         int asz = sc.active_size;
         // look-ahead only under fixed weights: the cross blocks are built once per block pair and re-used for the rest of the
         // path; under IRLS they would double the MFMA work of every iteration
-        const bool la = lookahead && !is_glm() && !time_panel && B == SL;
+        const bool la = lookahead && !is_glm() && B == SL;
         if (la) {
             if (xscr_key.size() != maxblk) {
                 d_Xpool.reserve(size_t(2) * maxblk * SL * SL);
@@ -1146,9 +1146,11 @@ struct Solver {
             const int nb01 = nb_of(0) + (nblk > 1 ? nb_of(1) : 0);
             {
                 const int ps = pending_slot;
+                if (time_panel) t_step.begin(st);
                 const int nsl = panel_step(cur_w, r_dev, ps < 0 ? d_dcolblk.p : d_la_dcol.p + size_t(ps) * SL,
                                            ps < 0 ? d_dlt.p : d_la_dlt.p + size_t(ps) * SL,
                                            ps < 0 ? &d_blk.p->nz : d_la_nz.p + ps, cols_all, nb01);
+                if (time_panel) t_step.end(st);
                 launch_panel_reduce<T>(d_part.p, nsl, nb01, cols_all, &d_blk.p->resid_sum, xm_c, d_la_g.p, st);
                 cnt.n_panel_cols += nb01;
             }
@@ -1181,6 +1183,7 @@ struct Solver {
                 const int nbn = (j + 1 < nblk) ? nb_of(j + 1) : 0;
                 const int32_t* cols_n = cols_all + size_t(j + 1) * B;
                 int ld;
+                if (time_panel) t_step.begin(st);
                 if (dense())
                     ld = launch_panel_fused<T>(bp, j, D->dense<T>(), cur_w, r_dev, d_la_dcol.p + size_t(pslot) * SL,
                                                d_la_dlt.p + size_t(pslot) * SL, d_la_nz.p + pslot, cols_n, nbn, d_part.p, st);
@@ -1188,6 +1191,7 @@ struct Solver {
                     ld = launch_panel_fused_snp<T>(bp, j, D->snp(), static_cast<const T*>(D->impute), cur_w, r_dev,
                                                    d_la_dcol.p + size_t(pslot) * SL, d_la_dlt.p + size_t(pslot) * SL,
                                                    d_la_nz.p + pslot, cols_n, nbn, d_part.p, st);
+                if (time_panel) t_step.end(st);
                 if (nbn > 0) {
                     // resid_sum as it was before block j's solve (the residual the partials were taken from)
                     launch_panel_reduce_ld<T>(d_part.p, ld, ld, nbn, cols_n, d_la_rsum.p + pslot, xm_c,
@@ -1438,7 +1442,7 @@ struct Solver {
         std::vector<idx> act_host(active_set.begin(), active_set.begin() + asz); // host mirror of the active list
         std::vector<int32_t>& acols = h_actcols;
         // look-ahead form (see run_panel_passes); not on the multi-response view, whose step is a different kernel
-        const bool la = lookahead && !is_glm() && !time_panel && !multi();
+        const bool la = lookahead && !is_glm() && !multi();
         if (la) {
             if (xscr_key.size() != maxblk) {
                 d_Xpool.reserve(size_t(2) * maxblk * SL * SL);
@@ -1482,9 +1486,11 @@ struct Solver {
             {   // first step of the pass: pending changes of the previous pass's last block; blocks 0 and 1 prepared
                 const int nv0 = nb_of(0), nv1 = nblk > 1 ? nb_of(1) : 0;
                 const int ps = pending_slot;
+                if (time_panel) t_step.begin(st);
                 const int nsl = panel_step(cur_w, r_dev, ps < 0 ? d_dcolblk.p : d_la_dcol.p + size_t(ps) * SL,
                                            ps < 0 ? d_dlt.p : d_la_dlt.p + size_t(ps) * SL,
                                            ps < 0 ? &d_blk.p->nz : d_la_nz.p + ps, cols_all, nv0 + nv1);
+                if (time_panel) t_step.end(st);
                 launch_panel_reduce<T>(d_part.p, nsl, nv0, cols_all, &d_blk.p->resid_sum, xm_c, d_la_g.p, st);
                 if (nv1 > 0)
                     launch_panel_reduce<T>(d_part.p + size_t(nv0) * size_t(nsl), nsl, nv1, cols_all + nv0, &d_blk.p->resid_sum,
@@ -1519,6 +1525,7 @@ struct Solver {
                 const int nbn = (j + 1 < nblk) ? nb_of(j + 1) : 0;
                 const int32_t* cols_n = cols_all + gp_vbeg[size_t(j) + 1];
                 int ld;
+                if (time_panel) t_step.begin(st);
                 if (dense())
                     ld = launch_panel_fused_grp<T>(bp, j, D->dense<T>(), cur_w, r_dev, d_la_dcol.p + size_t(pslot) * SL,
                                                    d_la_dlt.p + size_t(pslot) * SL, d_la_nz.p + pslot, cols_n, nbn, d_part.p, st);
@@ -1526,6 +1533,7 @@ struct Solver {
                     ld = launch_panel_fused_grp_snp<T>(bp, j, D->snp(), static_cast<const T*>(D->impute), cur_w, r_dev,
                                                        d_la_dcol.p + size_t(pslot) * SL, d_la_dlt.p + size_t(pslot) * SL,
                                                        d_la_nz.p + pslot, cols_n, nbn, d_part.p, st);
+                if (time_panel) t_step.end(st);
                 if (nbn > 0) {
                     launch_panel_reduce_ld<T>(d_part.p, ld, ld, nbn, cols_n, d_la_rsum.p + pslot, xm_c,
                                               d_la_g.p + size_t(pslot) * SL, st);

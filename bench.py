@@ -157,7 +157,8 @@ def main():
             bytes_ = float(cols) * n * s_
             ms = stp.timers["t_panel_step_ms"]
             panel = {
-                "kernel": "panel_step_kernel (r -= X_B dbeta_B of the previous block; partial gradients of the next block)",
+                "kernel": "panel_fused_kernel / panel_step_kernel (r -= X_B dbeta_B of the previous block; partial gradients of the "
+                          "next block; the fused launch also carries the one-workgroup solve of the current block)",
                 "bound": "hbm", "achieved": bytes_ / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(n, p, args.dtype, "panel_step_kernel"),
                 "launches": int(stp.timers["n_panel_step_launches"]), "avg_launch_ms": ms / stp.timers["n_panel_step_launches"],

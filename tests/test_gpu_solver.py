@@ -196,15 +196,18 @@ def test_caller_state_untouched_and_result_surface(hip):
     assert st.screen_is_active.dtype == bool and st.active_set.shape == (30,)
 
 
-@pytest.mark.parametrize("engine", ["panel", "gram"])
+@pytest.mark.parametrize("engine", ["panel", "panel-seq", "gram"])
 @pytest.mark.parametrize("n,p,alpha", [(400, 300, 1.0), (1500, 700, 0.6), (1027, 520, 1.0)])
 def test_block_cd_passes_match_oracle(hip, oracle, monkeypatch, n, p, alpha, engine):
     """Forces the multi-CU block Gauss-Seidel passes at sizes the oracle checks in seconds: several 128-visit blocks per
     pass, ragged last block, active-set growth inside screen passes, n not a multiple of the row slice.
-    engine "panel": residual-based blocks with cached diagonal Gram blocks (kernels_cd_panel.hip, the default);
+    engine "panel": residual-based blocks with cached diagonal Gram blocks and the look-ahead launches (solve of block j
+    fused with the step for block j+1, cross-block correction; kernels_cd_panel.hip, the default);
+    engine "panel-seq": the same without look-ahead (step -> reduce -> solve strictly in sequence);
     engine "gram": full screen-set Gram kept current (kernels_cd_block.hip)."""
     monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
-    monkeypatch.setenv("ADELIE_HIP_CD_ENGINE", engine)
+    monkeypatch.setenv("ADELIE_HIP_CD_ENGINE", "gram" if engine == "gram" else "panel")
+    monkeypatch.setenv("ADELIE_HIP_LOOKAHEAD", "0" if engine == "panel-seq" else "1")
     d = make_gaussian(n, p, seed=11, sparsity=0.5, weights=True)
     # beta is resolved to ~sqrt(tol) by the stopping rule; 1e-14 makes two trajectories that differ in the order of
     # the first activation (the lambda_0 == lmda_max tie) agree to 1e-6
@@ -222,14 +225,15 @@ def test_block_cd_passes_match_oracle(hip, oracle, monkeypatch, n, p, alpha, eng
     assert e2.error.startswith("adelie_core solver: max coordinate descents")
 
 
-@pytest.mark.parametrize("engine", ["panel", "gram"])
+@pytest.mark.parametrize("engine", ["panel", "panel-seq", "gram"])
 @pytest.mark.parametrize("alpha", [1.0, 0.5])
 def test_group_block_cd_passes_match_oracle(hip, oracle, monkeypatch, alpha, engine):
     """Forces the multi-CU block passes for grouped problems (kernels_cd_block_group.hip): mixed group sizes
     (1..40), several blocks per pass, groups activated inside screen passes.  engine "panel": residual-based blocks with
     cached diagonal Gram blocks, eigenbases from those blocks (the default); "gram": full screen-set Gram kept current."""
     monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
-    monkeypatch.setenv("ADELIE_HIP_GROUP_PANEL", "1" if engine == "panel" else "0")
+    monkeypatch.setenv("ADELIE_HIP_GROUP_PANEL", "0" if engine == "gram" else "1")
+    monkeypatch.setenv("ADELIE_HIP_LOOKAHEAD", "0" if engine == "panel-seq" else "1")
     rng = np.random.RandomState(7)
     n, p = 1200, 640
     d = make_gaussian(n, p, seed=13, sparsity=0.6, weights=True)
@@ -246,7 +250,7 @@ def test_group_block_cd_passes_match_oracle(hip, oracle, monkeypatch, alpha, eng
     assert_same_path(a, b, 1e-6)
     assert a.active_set_size > 30
     assert abs(a.counters["n_updates"] - b.counters["n_updates"]) <= 0.02 * b.counters["n_updates"] + 5
-    assert (a.counters["n_panel_blocks"] > 0) == (engine == "panel")
+    assert (a.counters["n_panel_blocks"] > 0) == (engine != "gram")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

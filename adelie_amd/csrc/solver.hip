@@ -323,11 +323,7 @@ struct Solver {
     // instead of their sum.  (Solves on a second stream with event dependencies were measured first: ~35 us per
     // cross-queue hop, slower than no look-ahead at all.)
     bool lookahead = true;      // A/B hook ADELIE_HIP_LOOKAHEAD
-    DevBuf<T> d_Xpool, d_la_dlt, d_la_g, d_la_rsum;
-    DevBuf<int32_t> d_la_dcol, d_la_dpos, d_la_nz;
-    struct XKey { int32_t nb_prev = 0, nb = 0; uint64_t ver = 0; };
-    std::vector<XKey> xscr_key, xact_key;
-    std::vector<hipEvent_t> x_ev;
+    int la_min_blocks = 3;      // passes with fewer blocks run in the plain form (hook ADELIE_HIP_LOOKAHEAD_MIN_BLOCKS)
     double t_enq = 0, t_wait = 0; // host seconds spent enqueueing panel passes / waiting for their state (ADELIE_HIP_TRACE_ENQ)
     int pending_slot = -1;      // slot holding the changes of the last solved block that the residual does not contain yet
     int64_t n_cross_blocks = 0;
@@ -1231,13 +1227,20 @@ struct Solver {
             build_stale_blocks(nblk, tab_nb, tab_ver, pool, [&](int j) { return std::min(B, count - j * B); },
                                [&](int j) { return cols_all + size_t(j) * B; });
             t_cd.begin(st);
+            // (a look-ahead pass may have run before: plain buffers for the solves, its pending changes for the first step)
+            bp.gblk = d_gblk.p; bp.dlt = d_dlt.p; bp.dcol = d_dcolblk.p;
+            bp.Cprev = nullptr; bp.dpos = nullptr; bp.nz_out = nullptr; bp.rsum_out = nullptr;
             for (int j = 0; j < nblk; ++j) {
                 const int nb = std::min(B, count - j * B);
                 const int32_t* cols = cols_all + size_t(j) * B;
                 T* Dptr = pool + size_t(j) * SL * SL;
+                const int ps = (j == 0) ? pending_slot : -1;
                 if (time_panel) t_step.begin(st);
-                const int nsl = panel_step(cur_w, r_dev, d_dcolblk.p, d_dlt.p, &d_blk.p->nz, cols, nb);
+                const int nsl = panel_step(cur_w, r_dev, ps < 0 ? d_dcolblk.p : d_la_dcol.p + size_t(ps) * SL,
+                                           ps < 0 ? d_dlt.p : d_la_dlt.p + size_t(ps) * SL,
+                                           ps < 0 ? &d_blk.p->nz : d_la_nz.p + ps, cols, nb);
                 if (time_panel) t_step.end(st);
+                pending_slot = -1;
                 cnt.n_panel_cols += nb;
                 launch_panel_reduce<T>(d_part.p, nsl, nb, cols, &d_blk.p->resid_sum, xm_c, d_gblk.p, st);
                 bp.Dptr = Dptr;
@@ -1264,7 +1267,12 @@ struct Solver {
                                     bs.nz, double(bs.rsq), double(bs.resid_sum), (long long)bs.n_updates);
             return bs.cm;
         };
-        auto pass = [&](bool screen_pass) -> T { return la ? pass_la(screen_pass) : pass_plain(screen_pass); };
+        // short passes gain nothing from the look-ahead (its first two blocks run as in the plain form) and would still pay
+        // for the cross blocks
+        auto pass = [&](bool screen_pass) -> T {
+            const int count = screen_pass ? cp.nv : asz;
+            return (la && (count + B - 1) / B >= la_min_blocks) ? pass_la(screen_pass) : pass_plain(screen_pass);
+        };
         while (status == CD_OK) {
             while (status == CD_OK) { // solve_active, pin_naive:173-215
                 ++iters;
@@ -1581,13 +1589,19 @@ struct Solver {
             build_stale_blocks(nblk, tab_nb, tab_ver, pool, [&](int j) { return int(gp_vbeg[size_t(j) + 1] - gp_vbeg[j]); },
                                [&](int j) { return cols_all + gp_vbeg[j]; });
             t_cd.begin(st);
+            bp.gblk = d_gblk.p; bp.dlt = d_dlt.p; bp.dcol = d_dcolblk.p;
+            bp.Cprev = nullptr; bp.dpos = nullptr; bp.nz_out = nullptr; bp.rsum_out = nullptr;
             for (int j = 0; j < nblk; ++j) {
                 const int nval = gp_vbeg[size_t(j) + 1] - gp_vbeg[j];
                 const int32_t* cols = cols_all + gp_vbeg[j];
                 T* Dptr = pool + size_t(j) * SL * SL;
+                const int ps = (j == 0) ? pending_slot : -1;
                 if (time_panel) t_step.begin(st);
-                const int nsl = panel_step(cur_w, r_dev, d_dcolblk.p, d_dlt.p, &d_blk.p->nz, cols, nval);
+                const int nsl = panel_step(cur_w, r_dev, ps < 0 ? d_dcolblk.p : d_la_dcol.p + size_t(ps) * SL,
+                                           ps < 0 ? d_dlt.p : d_la_dlt.p + size_t(ps) * SL,
+                                           ps < 0 ? &d_blk.p->nz : d_la_nz.p + ps, cols, nval);
                 if (time_panel) t_step.end(st);
+                pending_slot = -1;
                 cnt.n_panel_cols += nval;
                 launch_panel_reduce<T>(d_part.p, nsl, nval, cols, &d_blk.p->resid_sum, xm_c, d_gblk.p, st);
                 bp.Dptr = Dptr;
@@ -1614,7 +1628,12 @@ struct Solver {
             asz = bs.active_size;
             return bs.cm;
         };
-        auto pass = [&](bool screen_pass) -> T { return la ? pass_la(screen_pass) : pass_plain(screen_pass); };
+        auto pass = [&](bool screen_pass) -> T {
+            if (!la) return pass_plain(screen_pass);
+            const idx count = screen_pass ? idx(cp.ns) : idx(asz);
+            const int nblk = count > 0 ? build_partition(screen_pass ? nullptr : act_host.data(), count) : 0;
+            return nblk >= la_min_blocks ? pass_la(screen_pass) : pass_plain(screen_pass);
+        };
         while (status == CD_OK) {
             while (status == CD_OK) { // solve_active, pin_naive:173-215
                 ++iters;
@@ -2312,6 +2331,7 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_PRELAUNCH_SWEEP")) prelaunch_sweep = std::atoi(e) != 0; // A/B hook
         if (const char* e = std::getenv("ADELIE_HIP_GROUP_PANEL")) group_panel = std::atoi(e) != 0; // A/B hook
         if (const char* e = std::getenv("ADELIE_HIP_LOOKAHEAD")) lookahead = std::atoi(e) != 0; // A/B hook
+        if (const char* e = std::getenv("ADELIE_HIP_LOOKAHEAD_MIN_BLOCKS")) la_min_blocks = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {
             panel_bsz = std::atoi(e);
             if (panel_bsz != 32 && panel_bsz != 64 && panel_bsz != 128) panel_bsz = 0;

@@ -324,6 +324,11 @@ struct Solver {
     // cross-queue hop, slower than no look-ahead at all.)
     bool lookahead = true;      // A/B hook ADELIE_HIP_LOOKAHEAD
     int la_min_blocks = 3;      // passes with fewer blocks run in the plain form (hook ADELIE_HIP_LOOKAHEAD_MIN_BLOCKS)
+    DevBuf<T> d_Xpool, d_la_dlt, d_la_g, d_la_rsum;
+    DevBuf<int32_t> d_la_dcol, d_la_dpos, d_la_nz;
+    struct XKey { int32_t nb_prev = 0, nb = 0; uint64_t ver = 0; };
+    std::vector<XKey> xscr_key, xact_key;
+    std::vector<hipEvent_t> x_ev;
     double t_enq = 0, t_wait = 0; // host seconds spent enqueueing panel passes / waiting for their state (ADELIE_HIP_TRACE_ENQ)
     int pending_slot = -1;      // slot holding the changes of the last solved block that the residual does not contain yet
     int64_t n_cross_blocks = 0;

@@ -309,6 +309,18 @@ void launch_multi_expand(const T* C, int64_t ldc, const int32_t* slot, const int
 // ulist and its response.  nv <= 128.
 void launch_multi_block_lists(const int32_t* cols, int nv, int K, int32_t* ulist, int32_t* slot, int32_t* resp,
                               hipStream_t s);
+// fused look-ahead launch on the view: group solve of block j + multi-response step; returns the leading dimension of part
+template <class T>
+int launch_multi_panel_fused(const CdGrpBlkParams<T>& sp, int j, const MultiView<T>& X, const T* w, T* r,
+                             const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb_cols,
+                             T* part, hipStream_t s);
+template <class T>
+void launch_gram_multi(const MultiView<T>& X, const T* w, const int32_t* mcols, int32_t M, const int32_t* ncols, int32_t N,
+                       T* C, int64_t ldc, T* work, hipStream_t s);
+// C[a + b*ldc] = (resp_r[a] == resp_c[b]) ? G[slot_r[a] + slot_c[b]*ldg] : 0   for a < nr, b < nc
+template <class T>
+void launch_multi_expand_cross(const T* G, int64_t ldg, const int32_t* slot_r, const int32_t* resp_r, int nr,
+                               const int32_t* slot_c, const int32_t* resp_c, int nc, T* C, int64_t ldc, hipStream_t s);
 // (n, K) row-major <-> response-major
 template <class T> void launch_multi_to_major(const T* src, int64_t nb, int K, T* dst, hipStream_t s);
 template <class T> void launch_multi_from_major(const T* src, int64_t nb, int K, T* dst, hipStream_t s);

@@ -444,6 +444,17 @@ void launch_syrk_multi(const MultiView<T>& X, const T* w, const int32_t* ucols, 
     syrk_launch<T, DenseOnesAcc<T>>(acc, vecok, w, ucols, M, X.nb, nullptr, false, C, ldc, work, s);
 }
 
+// general M x N Gram over extended features of the multi-response view: C[a + b*ldc] = sum_i w_i x_{mcols[a]} x_{ncols[b]}
+template <class T>
+void launch_gram_multi(const MultiView<T>& X, const T* w, const int32_t* mcols, int32_t M, const int32_t* ncols, int32_t N,
+                       T* C, int64_t ldc, T* work, hipStream_t s) {
+    DenseOnesAcc<T> acc{X.X, X.ld, X.ones, int64_t(X.icpt)};
+    constexpr int V = VecOf<T>::N;
+    const bool vecok = (X.ld % V == 0) && ((reinterpret_cast<uintptr_t>(X.X) % 16) == 0) &&
+                       ((reinterpret_cast<uintptr_t>(X.ones) % 16) == 0);
+    gram_launch<T, DenseOnesAcc<T>>(acc, vecok, w, mcols, M, 0, ncols, N, 0, X.nb, nullptr, false, C, ldc, work, s);
+}
+
 int64_t gram_work_elems(int64_t n, int64_t M, int64_t N) {
     if (M <= 0 || N <= 0) return 0;
     const GramShape g = gram_shape(n, M, N);
@@ -482,6 +493,10 @@ INST(float)
                                        int64_t, T*, hipStream_t);
 INST2(double)
 INST2(float)
+template void launch_gram_multi<double>(const MultiView<double>&, const double*, const int32_t*, int32_t, const int32_t*,
+                                        int32_t, double*, int64_t, double*, hipStream_t);
+template void launch_gram_multi<float>(const MultiView<float>&, const float*, const int32_t*, int32_t, const int32_t*, int32_t,
+                                       float*, int64_t, float*, hipStream_t);
 template void launch_syrk_multi<double>(const MultiView<double>&, const double*, const int32_t*, int32_t, double*, int64_t,
                                         double*, hipStream_t);
 template void launch_syrk_multi<float>(const MultiView<float>&, const float*, const int32_t*, int32_t, float*, int64_t,

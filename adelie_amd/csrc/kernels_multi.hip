@@ -20,6 +20,7 @@
 #include "kernels.hpp"
 #include "accessors.hpp"
 #include "wavered.hpp"
+#include "grp_solve_body.hpp"
 
 #include <algorithm>
 
@@ -179,36 +180,12 @@ __device__ __forceinline__ int build_slots(const int32_t* __restrict__ list, int
     return nslot;
 }
 
+// phases (A) and (B) of the multi-response panel step for one wave (64 * VEC rows starting at row i, responses l0..l0+KT)
 template <class T, int VEC, int KT>
-__global__ __launch_bounds__(64) void multi_panel_step_kernel(DenseOnesAcc<T> X, int64_t nb, int K,
-                                                              const T* __restrict__ w, T* __restrict__ r,
-                                                              const int32_t* __restrict__ dcol,
-                                                              const T* __restrict__ dlt,
-                                                              const int32_t* __restrict__ nz_dev,
-                                                              const int32_t* __restrict__ cols, int nbc,
-                                                              T* __restrict__ part, int64_t part_ld) {
-    __shared__ int featA[MAXB], featB[MAXB];
-    __shared__ T dA[MAXB * KT];
-    __shared__ int valB[MAXB * KT];
-    const int lane = threadIdx.x;
-    const int l0 = blockIdx.y * KT;
-    const int64_t i = int64_t(blockIdx.x) * (64 * VEC) + int64_t(lane) * VEC;
-    const bool full = (int64_t(blockIdx.x) + 1) * (64 * VEC) <= nb;
-    const int nz = min(nz_dev[0], MAXB);
-
-    for (int q = lane; q < MAXB * KT; q += 64) {
-        dA[q] = T(0);
-        valB[q] = -1;
-    }
-    __syncthreads();
-    const int nsA = build_slots(dcol, nz, K, featA, lane, [&](int m, int slot, int l) {
-        if (l >= l0 && l < l0 + KT) dA[slot * KT + (l - l0)] = dlt[m];
-    });
-    const int nsB = build_slots(cols, nbc, K, featB, lane, [&](int m, int slot, int l) {
-        if (l >= l0 && l < l0 + KT) valB[slot * KT + (l - l0)] = m;
-    });
-    __syncthreads();
-
+__device__ __forceinline__ void multi_step_phases(const DenseOnesAcc<T>& X, int64_t nb, int K, const T* __restrict__ w,
+                                                  T* __restrict__ r, const int* featA, const int* featB, const T* dA,
+                                                  const int* valB, int nsA, int nsB, int l0, int lane, int64_t i,
+                                                  bool full, int64_t slice, T* __restrict__ part, int64_t part_ld) {
     constexpr int U = 8;
     // ---- (A) ---------------------------------------------------------------------------------------------------------
     T acc[KT][VEC];
@@ -272,11 +249,105 @@ __global__ __launch_bounds__(64) void multi_panel_step_kernel(DenseOnesAcc<T> X,
                 const T tot = reduce8(d8, lane); // lane kk < 8: the total of response l0 + kk
                 if (lane < KT) {
                     const int c = valB[(s0 + u) * KT + lane];
-                    if (c >= 0) part[int64_t(c) * part_ld + blockIdx.x] = tot;
+                    if (c >= 0) part[int64_t(c) * part_ld + slice] = tot;
                 }
             }
         }
     }
+}
+
+template <class T, int VEC, int KT>
+__global__ __launch_bounds__(64) void multi_panel_step_kernel(DenseOnesAcc<T> X, int64_t nb, int K,
+                                                              const T* __restrict__ w, T* __restrict__ r,
+                                                              const int32_t* __restrict__ dcol,
+                                                              const T* __restrict__ dlt,
+                                                              const int32_t* __restrict__ nz_dev,
+                                                              const int32_t* __restrict__ cols, int nbc,
+                                                              T* __restrict__ part, int64_t part_ld) {
+    // the gradient list may span two blocks (first step of a look-ahead pass): up to 2 * MAXB entries
+    __shared__ int featA[MAXB], featB[2 * MAXB];
+    __shared__ T dA[MAXB * KT];
+    __shared__ int valB[2 * MAXB * KT];
+    const int lane = threadIdx.x;
+    const int l0 = blockIdx.y * KT;
+    const int64_t i = int64_t(blockIdx.x) * (64 * VEC) + int64_t(lane) * VEC;
+    const bool full = (int64_t(blockIdx.x) + 1) * (64 * VEC) <= nb;
+    const int nz = min(nz_dev[0], MAXB);
+    nbc = min(nbc, 2 * MAXB);
+
+    for (int q = lane; q < 2 * MAXB * KT; q += 64) {
+        if (q < MAXB * KT) dA[q] = T(0);
+        valB[q] = -1;
+    }
+    __syncthreads();
+    const int nsA = build_slots(dcol, nz, K, featA, lane, [&](int m, int slot, int l) {
+        if (l >= l0 && l < l0 + KT) dA[slot * KT + (l - l0)] = dlt[m];
+    });
+    const int nsB = build_slots(cols, nbc, K, featB, lane, [&](int m, int slot, int l) {
+        if (l >= l0 && l < l0 + KT) valB[slot * KT + (l - l0)] = m;
+    });
+    __syncthreads();
+
+    multi_step_phases<T, VEC, KT>(X, nb, K, w, r, featA, featB, dA, valB, nsA, nsB, l0, lane, i, full, blockIdx.x, part,
+                                  part_ld);
+}
+
+// Fused look-ahead launch on the view (solver.hip::run_group_panel_passes): workgroup (0, 0) runs the group solve of block j,
+// every other workgroup of row 0.. is 16 waves = 16 row slices of the multi-response step that prepares block j+1; the slot
+// lists are built once per workgroup.  1024-thread workgroups for the same reason as panel_fused_kernel (the solve's LDS
+// request makes it one workgroup per CU for everybody).
+constexpr int MFS = 16; // waves (row slices) per fused step workgroup
+template <class T, int VEC, int KT>
+__global__ __launch_bounds__(64 * MFS) void multi_fused_kernel(CdGrpBlkParams<T> sp, int j, DenseOnesAcc<T> X, int64_t nb,
+                                                              int K, const T* __restrict__ w, T* __restrict__ r,
+                                                              const int32_t* __restrict__ dcol,
+                                                              const T* __restrict__ dlt,
+                                                              const int32_t* __restrict__ nz_dev,
+                                                              const int32_t* __restrict__ cols, int nbc,
+                                                              T* __restrict__ part, int64_t part_ld) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if (blockIdx.x == 0) {
+        if (blockIdx.y == 0 && threadIdx.x < 256) grp_solve_body<T, true>(sp, j, smem_raw);
+        return;
+    }
+    T* dA = reinterpret_cast<T*>(smem_raw);                 // MAXB * KT
+    int* valB = reinterpret_cast<int*>(dA + MAXB * KT);     // MAXB * KT
+    int* featA = valB + MAXB * KT;                          // MAXB
+    int* featB = featA + MAXB;                              // MAXB
+    int* cnts = featB + MAXB;                               // nsA, nsB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l0 = blockIdx.y * KT;
+    const int nz = min(nz_dev[0], MAXB);
+    for (int q = threadIdx.x; q < MAXB * KT; q += 64 * MFS) {
+        dA[q] = T(0);
+        valB[q] = -1;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int a = build_slots(dcol, nz, K, featA, lane, [&](int m, int slot, int l) {
+            if (l >= l0 && l < l0 + KT) dA[slot * KT + (l - l0)] = dlt[m];
+        });
+        const int b = build_slots(cols, nbc, K, featB, lane, [&](int m, int slot, int l) {
+            if (l >= l0 && l < l0 + KT) valB[slot * KT + (l - l0)] = m;
+        });
+        if (lane == 0) { cnts[0] = a; cnts[1] = b; }
+    }
+    __syncthreads();
+    const int nsA = cnts[0], nsB = cnts[1];
+    const int64_t slice = (int64_t(blockIdx.x) - 1) * MFS + wave;
+    const int64_t i = slice * (64 * VEC) + int64_t(lane) * VEC;
+    const bool full = (slice + 1) * (64 * VEC) <= nb;
+    multi_step_phases<T, VEC, KT>(X, nb, K, w, r, featA, featB, dA, valB, nsA, nsB, l0, lane, i, full, slice, part, part_ld);
+}
+
+// cross block over view columns from the Gram of the two blocks' distinct features: rows = block b, columns = block b-1
+template <class T>
+__global__ void multi_expand_cross_kernel(const T* __restrict__ G, int64_t ldg, const int32_t* __restrict__ slot_r,
+                                          const int32_t* __restrict__ resp_r, int nr, const int32_t* __restrict__ slot_c,
+                                          const int32_t* __restrict__ resp_c, int nc, T* __restrict__ C, int64_t ldc) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (a >= nr || b >= nc) return;
+    C[a + int64_t(b) * ldc] = (resp_r[a] == resp_c[b]) ? G[slot_r[a] + int64_t(slot_c[b]) * ldg] : T(0);
 }
 
 template <class T>
@@ -406,6 +477,48 @@ int launch_multi_panel_step(const MultiView<T>& X, const T* w, T* r, const int32
 }
 
 template <class T>
+int launch_multi_panel_fused(const CdGrpBlkParams<T>& sp, int j, const MultiView<T>& X, const T* w, T* r,
+                             const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb_cols,
+                             T* part, hipStream_t s) {
+    DenseOnesAcc<T> acc{X.X, X.ld, X.ones, int64_t(X.icpt)};
+    constexpr int V = VecOf<T>::N;
+    const bool vok = multi_vecok(X);
+    const int RS = 64 * (vok ? V : 1);
+    const int64_t nsl = (X.nb + RS - 1) / RS;
+    const int64_t nwg = (nsl + MFS - 1) / MFS;
+    const int64_t part_ld = nwg * MFS;
+    const int KT = kt_of(X.K);
+    const dim3 grid((unsigned)(nwg + 1), (unsigned)((X.K + KT - 1) / KT));
+    const size_t lds = grp_solve_lds_total<T>();
+#define AHIP_MF(VV, KK)                                                                                                 \
+    {                                                                                                                  \
+        static bool done = false;                                                                                      \
+        if (!done) {                                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(multi_fused_kernel<T, VV, KK>),                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));                           \
+            done = true;                                                                                               \
+        }                                                                                                              \
+        hipLaunchKernelGGL((multi_fused_kernel<T, VV, KK>), grid, dim3(64 * MFS), lds, s, sp, j, acc, X.nb, int(X.K), w, r,    \
+                           dcol, dlt, nz_dev, cols, nb_cols, part, part_ld);                                           \
+    }
+    if (vok) {
+        if (KT == 8) AHIP_MF(V, 8) else if (KT == 4) AHIP_MF(V, 4) else AHIP_MF(V, 2)
+    } else {
+        if (KT == 8) AHIP_MF(1, 8) else if (KT == 4) AHIP_MF(1, 4) else AHIP_MF(1, 2)
+    }
+#undef AHIP_MF
+    return int(part_ld);
+}
+
+template <class T>
+void launch_multi_expand_cross(const T* G, int64_t ldg, const int32_t* slot_r, const int32_t* resp_r, int nr,
+                               const int32_t* slot_c, const int32_t* resp_c, int nc, T* C, int64_t ldc, hipStream_t s) {
+    if (nr <= 0 || nc <= 0) return;
+    hipLaunchKernelGGL((multi_expand_cross_kernel<T>), dim3((unsigned)((nr + 63) / 64), (unsigned)nc), dim3(64), 0, s, G, ldg,
+                       slot_r, resp_r, nr, slot_c, resp_c, nc, C, ldc);
+}
+
+template <class T>
 void launch_multi_axpy_cols(const MultiView<T>& X, const int32_t* cols, const T* coef, const int32_t* cnt_dev, T sign,
                             T* out, hipStream_t s) {
     DenseOnesAcc<T> acc{X.X, X.ld, X.ones, int64_t(X.icpt)};
@@ -445,6 +558,11 @@ void launch_multi_from_major(const T* src, int64_t nb, int K, T* dst, hipStream_
     template void launch_multi_sweep<T>(const MultiView<T>&, const T*, T*, T*, hipStream_t);                           \
     template int launch_multi_panel_step<T>(const MultiView<T>&, const T*, T*, const int32_t*, const T*, const int32_t*, \
                                             const int32_t*, int, T*, hipStream_t);                                     \
+    template int launch_multi_panel_fused<T>(const CdGrpBlkParams<T>&, int, const MultiView<T>&, const T*, T*,         \
+                                             const int32_t*, const T*, const int32_t*, const int32_t*, int, T*,        \
+                                             hipStream_t);                                                             \
+    template void launch_multi_expand_cross<T>(const T*, int64_t, const int32_t*, const int32_t*, int, const int32_t*, \
+                                               const int32_t*, int, T*, int64_t, hipStream_t);                         \
     template void launch_multi_axpy_cols<T>(const MultiView<T>&, const int32_t*, const T*, const int32_t*, T, T*,      \
                                             hipStream_t);                                                              \
     template void launch_multi_expand<T>(const T*, int64_t, const int32_t*, const int32_t*, int, int, T*, int64_t,     \

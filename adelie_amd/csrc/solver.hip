@@ -353,7 +353,31 @@ struct Solver {
                           .reserve(size_t(std::max<int64_t>(gram_work_elems(n, SL, SL), syrk_work_elems(n, 128))));
             T* Cx = xpool + size_t(j) * SL * SL;
             t_gram.begin(gs);
-            if (dense())
+            if (multi()) {
+                // Gram of the two blocks' distinct features, expanded to view columns (zero between different responses);
+                // look-ahead only runs under uniform weights (Gaussian), so one Gram serves all responses
+                const MultiView<T> mv = D->multi<T>();
+                auto distinct = [&](const int32_t* hc, int cntv) {
+                    multi_seen.clear();
+                    for (int a = 0; a < cntv; ++a) {
+                        const int32_t u = hc[a] / mv.K;
+                        if (std::find(multi_seen.begin(), multi_seen.end(), u) == multi_seen.end()) multi_seen.push_back(u);
+                    }
+                    return int(multi_seen.size());
+                };
+                const int nu = distinct(host_cols(cols_of(j)), nb), nup = distinct(host_cols(cols_of(j - 1)), nbp);
+                DevBuf<int32_t>& ml = side ? d_mlist2 : d_mlist;
+                DevBuf<T>& mc = side ? d_mC2 : d_mC;
+                ml.reserve(size_t(6 * SL));
+                mc.reserve(size_t(SL) * SL);
+                launch_multi_block_lists(cols_of(j), nb, mv.K, ml.p, ml.p + SL, ml.p + 2 * SL, gs);
+                launch_multi_block_lists(cols_of(j - 1), nbp, mv.K, ml.p + 3 * SL, ml.p + 4 * SL, ml.p + 5 * SL, gs);
+                T* mwork = (side ? d_work_gram2 : d_work_gram)
+                               .reserve(size_t(std::max<int64_t>(gram_work_elems(mv.nb, SL, SL), syrk_work_elems(mv.nb, 128))));
+                launch_gram_multi<T>(mv, cur_w, ml.p, nu, ml.p + 3 * SL, nup, mc.p, SL, mwork, gs);
+                launch_multi_expand_cross<T>(mc.p, SL, ml.p + SL, ml.p + 2 * SL, nb, ml.p + 4 * SL, ml.p + 5 * SL, nbp, Cx, SL, gs);
+                cnt.gram_flops += 2.0 * double(mv.nb) * double(nu) * double(nup);
+            } else if (dense())
                 launch_gram<T>(D->dense<T>(), cur_w, cols_of(j), nb, 0, cols_of(j - 1), nbp, 0, cur_xm, intercept, Cx, SL, work, gs);
             else
                 launch_gram_snp<T>(D->snp(), static_cast<const T*>(D->impute), cur_w, cols_of(j), nb, 0, cols_of(j - 1), nbp, 0,
@@ -448,7 +472,7 @@ struct Solver {
             const int nu = int(multi_seen.size());
             DevBuf<int32_t>& ml = side ? d_mlist2 : d_mlist;
             DevBuf<T>& mc = side ? d_mC2 : d_mC;
-            ml.reserve(size_t(3 * B));
+            ml.reserve(size_t(6 * B));
             mc.reserve(size_t(B) * B);
             launch_multi_block_lists(cols, nb, mv.K, ml.p, ml.p + B, ml.p + 2 * B, gs);
             T* work = (side ? d_work_gram2 : d_work_gram).reserve(size_t(syrk_work_elems(mv.nb, 128)));
@@ -1455,7 +1479,7 @@ struct Solver {
         std::vector<idx> act_host(active_set.begin(), active_set.begin() + asz); // host mirror of the active list
         std::vector<int32_t>& acols = h_actcols;
         // look-ahead form (see run_panel_passes); not on the multi-response view, whose step is a different kernel
-        const bool la = lookahead && !is_glm() && !multi();
+        const bool la = lookahead && !is_glm() && (!multi() || multi_w_uniform);
         if (la) {
             if (xscr_key.size() != maxblk) {
                 d_Xpool.reserve(size_t(2) * maxblk * SL * SL);
@@ -1539,7 +1563,10 @@ struct Solver {
                 const int32_t* cols_n = cols_all + gp_vbeg[size_t(j) + 1];
                 int ld;
                 if (time_panel) t_step.begin(st);
-                if (dense())
+                if (multi())
+                    ld = launch_multi_panel_fused<T>(bp, j, D->multi<T>(), cur_w, r_dev, d_la_dcol.p + size_t(pslot) * SL,
+                                                     d_la_dlt.p + size_t(pslot) * SL, d_la_nz.p + pslot, cols_n, nbn, d_part.p, st);
+                else if (dense())
                     ld = launch_panel_fused_grp<T>(bp, j, D->dense<T>(), cur_w, r_dev, d_la_dcol.p + size_t(pslot) * SL,
                                                    d_la_dlt.p + size_t(pslot) * SL, d_la_nz.p + pslot, cols_n, nbn, d_part.p, st);
                 else

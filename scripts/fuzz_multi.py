@@ -74,7 +74,11 @@ for case in range(N):
         else:
             d = max(np.abs(a.betas.toarray() - b.betas.toarray()).max() if a.betas.shape[1] else 0.0,
                     np.abs(a.intercepts - b.intercepts).max())
-            dl = np.abs(np.asarray(a.lmdas) / np.asarray(b.lmdas) - 1).max() if len(a.lmdas) == len(b.lmdas) else np.inf
+            if len(a.lmdas) == len(b.lmdas):  # (a path at lmda_max == 0 -- every group unpenalised -- has lmdas 0 on both sides)
+                la_, lb_ = np.asarray(a.lmdas, dtype=float), np.asarray(b.lmdas, dtype=float)
+                dl = np.abs(la_ - lb_).max() / max(np.abs(lb_).max(), 1e-300) if len(la_) else 0.0
+            else:
+                dl = np.inf
             worst = max(worst, d)
             ok = len(a.lmdas) == len(b.lmdas) and d < 1e-6 and dl < 1e-9
             msg = f"max|dbeta|={d:.2e} dlmda={dl:.1e} hip {t_hip:.2f}s"

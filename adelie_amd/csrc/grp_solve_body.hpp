@@ -297,6 +297,16 @@ __device__ __forceinline__ void grp_solve_body(const CdGrpBlkParams<T>& p, int j
                 } else {
                     const T b1 = A_r + l2p;
                     T h = 0, fh, dfh, b2 = T(0);
+                    // Isotropic block (all eigenvalues equal: every group of a multi-response view, X_g^T W X_g (x) I_K): the
+                    // root of the secular equation is known in closed form, (||v|| - l1) / (A + l2).  The iteration of the
+                    // reference (start h = 0, bcd/unconstrained/newton.hpp:60-129) is kept, but started there: it then stops
+                    // after its first evaluation whenever newton_tol is reachable, and behaves as in the reference
+                    // (iterates to newton_max_iters -> the same error) when it is not.
+                    {
+                        const T a0 = first_lane(A_r);
+                        const bool iso = q > 1 && __ballot(on && A_r != a0) == 0ull && (a0 + l2p) > T(0);
+                        if (iso) h = (sqrt(nrm2) - l1p) / (a0 + l2p);
+                    }
                     auto step = [&](T hh) {
                         T t = 0, sx = 0;
                         if (on) {

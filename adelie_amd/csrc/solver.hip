@@ -1051,15 +1051,7 @@ struct Solver {
             dscr_ver.assign(maxblk, 0); dact_ver.assign(maxblk, 0);
             panel_maxblk = maxblk;
         }
-        if (side_grams && !st2) {
-            // lowest priority: the builds are needed a whole pass (or lambda) later, the chain on the main stream is latency
-            // critical -- and the fused look-ahead step needs whole CUs, which a build kernel ahead of it in the dispatch
-            // order would hold for ~100 us
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            if (std::getenv("ADELIE_HIP_SIDE_PRIO") && std::atoi(std::getenv("ADELIE_HIP_SIDE_PRIO")) == 0) lo = 0;
-            AHIP_CHECK(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, lo));
-        }
+        if (side_grams && !st2) AHIP_CHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
         if (use_report && !h_report) {
             void* hp = nullptr;
             void* dp = nullptr;

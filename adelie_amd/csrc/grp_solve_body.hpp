@@ -106,7 +106,7 @@ __host__ __device__ constexpr size_t grp_solve_lds() {
 }
 template <class T>
 __host__ __device__ constexpr size_t grp_solve_lds_total() {
-    return ((grp_solve_lds<T>() + 15) / 16) * 16 + size_t(2) * GBLK * sizeof(T);
+    return ((grp_solve_lds<T>() + 15) / 16) * 16 + size_t(2) * GBLK * sizeof(T) + size_t(GBLK) * sizeof(int32_t);
 }
 
 template <class T, bool NAIVE>
@@ -147,12 +147,25 @@ __device__ __forceinline__ void grp_solve_body(const CdGrpBlkParams<T>& p, int j
         }
     }
     __syncthreads();
+    // gidB[k] != 0: the eigenbasis of group k is exactly the identity (isotropic blocks, e.g. every group of a multi-response
+    // view): the two rotations of its visit reduce to copies -- bit-identical, the general loops would add exact zeros
+    int32_t* gidB = reinterpret_cast<int32_t*>(smem_raw + ((grp_solve_lds<T>() + 15) / 16) * 16 + size_t(2) * GBLK * sizeof(T));
     for (int k = wv; k < ngrp; k += 4) { // one wave per group
         const int vo = gvoB[k];
-        if (vo < 0) continue;
+        if (vo < 0) {
+            if (lane == 0) gidB[k] = 0;
+            continue;
+        }
         const int q = gq[k];
         const T* Vg = p.V + p.voff[gss[k]];
-        for (int e = lane; e < q * q; e += 64) Vpool[vo + e] = Vg[e];
+        bool ident = true;
+        for (int e = lane; e < q * q; e += 64) {
+            const T v = Vg[e];
+            Vpool[vo + e] = v;
+            ident = ident && (v == ((e / q == e % q) ? T(1) : T(0)));
+        }
+        const bool all_ident = __ballot(!ident) == 0ull;
+        if (lane == 0) gidB[k] = all_ident ? 1 : 0;
     }
     if (tid < GBLK) {
         const int i = tid;
@@ -268,6 +281,7 @@ __device__ __forceinline__ void grp_solve_body(const CdGrpBlkParams<T>& p, int j
             }
             const T* A = AB + o;
             T dn = 0, c1 = 0, rs = 0;
+            const bool idV = q <= 64 && gvoB[k] >= 0 && gidB[k] != 0;
             if (q <= 64) {
                 // One element per lane: the group's rotated vectors stay in registers from the rotation to the change test
                 // (same operations in the same order as the general path below, so the results are bit-identical; only the
@@ -277,11 +291,16 @@ __device__ __forceinline__ void grp_solve_body(const CdGrpBlkParams<T>& p, int j
                 T gk_r = T(0), ako_r = T(0);
                 if (on) { // gk_t = gk V ; ak_old_t = ak_old V ; gk_t += A * ak_old_t   (pin_naive:123-140)
                     T s1 = 0, s2 = 0;
-                    const T* Vj = V + int64_t(lane) * q;
+                    if (idV) {
+                        s1 = gB[o + lane];
+                        s2 = bB[o + lane];
+                    } else {
+                        const T* Vj = V + int64_t(lane) * q;
 #pragma unroll 4
-                    for (int i = 0; i < q; ++i) {
-                        s1 = fma(gB[o + i], Vj[i], s1);
-                        s2 = fma(bB[o + i], Vj[i], s2);
+                        for (int i = 0; i < q; ++i) {
+                            s1 = fma(gB[o + i], Vj[i], s1);
+                            s2 = fma(bB[o + i], Vj[i], s2);
+                        }
                     }
                     ako_r = s2;
                     gk_r = s1 + A_r * s2;
@@ -422,8 +441,12 @@ __device__ __forceinline__ void grp_solve_body(const CdGrpBlkParams<T>& p, int j
                 T rsd = 0;
                 for (int i = lane; i < q; i += 64) {
                     T s = 0;
+                    if (idV) {
+                        s = ak_t[i];
+                    } else {
 #pragma unroll 4
-                    for (int jj = 0; jj < q; ++jj) s = fma(ak_t[jj], V[i + int64_t(jj) * q], s);
+                        for (int jj = 0; jj < q; ++jj) s = fma(ak_t[jj], V[i + int64_t(jj) * q], s);
+                    }
                     const T d = s - bB[o + i];
                     del[i] = d;
                     bB[o + i] = s;

@@ -208,3 +208,25 @@ def read_bed(path, n, p=None):
     fields = np.stack([(rec >> (2 * k)) & 3 for k in range(4)], axis=1).reshape(stride * 4, p)[:n]
     lut = np.array([2, -9, 1, 0], dtype=np.int8)
     return np.asfortranarray(lut[fields])
+
+
+def plink_dims(prefix):
+    """``(n, p)`` of a PLINK 1 fileset ``prefix.{bed,bim,fam}``: one line per sample in ``.fam``, one per variant in ``.bim``."""
+    def count(path):
+        with open(path, "rb") as f:
+            return sum(1 for line in f if line.strip())
+    return count(prefix + ".fam"), count(prefix + ".bim")
+
+
+def write_plink(prefix, calldata):
+    """Writes ``prefix.bed`` (see :func:`write_bed`) with minimal ``.fam`` / ``.bim`` companions (test / demo helper)."""
+    calldata = np.asarray(calldata)
+    n, p = calldata.shape
+    nbytes = write_bed(prefix + ".bed", calldata)
+    with open(prefix + ".fam", "w") as f:
+        for i in range(n):
+            f.write(f"F{i} I{i} 0 0 0 -9\n")
+    with open(prefix + ".bim", "w") as f:
+        for j in range(p):
+            f.write(f"1 rs{j} 0 {j + 1} A C\n")
+    return nbytes

@@ -580,6 +580,15 @@ def snp_bed(bed, n: int, p: int = None, *, dtype=np.float64, n_threads: int = 1,
     return _wrap(backend, handle, np.dtype(dtype).type, n_threads)
 
 
+def snp_plink(prefix, *, dtype=np.float64, n_threads: int = 1, device: int = 0):
+    """SNP design from a PLINK 1 fileset ``prefix.{bed,bim,fam}``: the dimensions come from the ``.fam`` / ``.bim`` line
+    counts (``adelie_amd.io.plink_dims``), the ``.bed`` image goes to :func:`snp_bed`."""
+    from . import io as _io
+
+    n, p = _io.plink_dims(prefix)
+    return snp_bed(prefix + ".bed", n, p, dtype=dtype, n_threads=n_threads, device=device)
+
+
 def compute_impute(calldata):
     """Mean imputation (reference ``io/utils.hpp:10-31``): mean of the non-missing entries per column."""
     calldata = np.asarray(calldata)

@@ -131,3 +131,23 @@ def test_glm_path_losses_match_host(hip, family, kind):
     np.testing.assert_allclose(etas, (B @ Xh.T) + b0[:, None] + off, rtol=0, atol=1e-11)
     np.testing.assert_allclose(la, [ga.loss(e) for e in etas], rtol=1e-12, atol=1e-14)
     np.testing.assert_allclose(lb, [gb.loss(e) for e in etas], rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.gpu
+def test_snp_plink_fileset(hip, tmp_path):
+    """matrix.snp_plink: dimensions from .fam / .bim, records transcoded on the device; same design as the calldata route."""
+    rng = np.random.RandomState(5)
+    n, p = 203, 17
+    cd = rng.choice(np.array([0, 1, 2, -9], dtype=np.int8), size=(n, p), p=[0.55, 0.25, 0.1, 0.1])
+    prefix = str(tmp_path / "toy")
+    ad.io.write_plink(prefix, cd)
+    A = ad.matrix.snp_plink(prefix)
+    B = ad.matrix.snp_calldata(cd)
+    assert A.shape == (n, p)
+    v = rng.normal(size=n)
+    w = rng.uniform(size=n)
+    oa, ob = np.empty(p), np.empty(p)
+    A.mul(v, w, oa)
+    B.mul(v, w, ob)
+    np.testing.assert_allclose(oa, ob, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(A.impute(), B.impute(), rtol=1e-14)

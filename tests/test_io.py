@@ -52,3 +52,13 @@ def test_bed_codec_roundtrip(tmp_path, n, p):
     back = ad.io.read_bed(path, n)
     assert back.dtype == np.int8 and back.shape == (n, p)
     np.testing.assert_array_equal(back, cd)
+
+
+def test_plink_fileset_dims(tmp_path):
+    rng = np.random.RandomState(3)
+    cd = rng.choice(np.array([0, 1, 2, -9], dtype=np.int8), size=(37, 11), p=[0.6, 0.2, 0.1, 0.1])
+    prefix = str(tmp_path / "toy")
+    ad.io.write_plink(prefix, cd)
+    assert ad.io.plink_dims(prefix) == (37, 11)
+    back = ad.io.read_bed(prefix + ".bed", 37, 11)
+    assert np.array_equal(back, cd)

@@ -289,6 +289,50 @@ U read_as(const uint8_t* p) {
     if ((d)->dtype == ADELIE_HIP_F64) { using T = double; (void)sizeof(T); call64; } \
     else { using T = float; (void)sizeof(T); call32; }
 
+namespace {
+template <class T>
+void derive_t(adelie_hip_design* src, adelie_hip_design* d, const int64_t* rows, int64_t nrows, const int64_t* cols,
+              int64_t ncols, const double* centers, const double* scales) {
+    constexpr int64_t kAlign = 32;
+    const int64_t nout = d->n, pout = d->p;
+    const int64_t ld = ((nout + kAlign - 1) / kAlign) * kAlign;
+    T* X = nullptr;
+    AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&X), size_t(ld) * size_t(pout) * sizeof(T)));
+    d->X = X;
+    d->ld = ld;
+    d->owned = true;
+    d->kind = 0;
+    hipStream_t s = d->stream;
+    AHIP_CHECK(hipMemsetAsync(X, 0, size_t(ld) * size_t(pout) * sizeof(T), s));
+    int64_t *drows = nullptr, *dcols = nullptr;
+    T *dc = nullptr, *ds = nullptr;
+    std::vector<T> hc, hs;
+    if (rows) {
+        drows = scratch<int64_t>(d->s_idx1, size_t(nrows));
+        AHIP_CHECK(hipMemcpyAsync(drows, rows, size_t(nrows) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    }
+    if (cols) {
+        dcols = scratch<int64_t>(d->s_idx2, size_t(ncols));
+        AHIP_CHECK(hipMemcpyAsync(dcols, cols, size_t(ncols) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    }
+    if (centers) {
+        hc.assign(centers, centers + pout);
+        dc = scratch<T>(d->s_p1, size_t(pout));
+        AHIP_CHECK(hipMemcpyAsync(dc, hc.data(), size_t(pout) * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    if (scales) {
+        hs.assign(scales, scales + pout);
+        ds = scratch<T>(d->s_misc, size_t(pout));
+        AHIP_CHECK(hipMemcpyAsync(ds, hs.data(), size_t(pout) * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    // the source's stream may still be writing it (e.g. its own creation): order after it
+    AHIP_CHECK(hipStreamSynchronize(src->stream));
+    if (src->kind == 0) launch_derive_dense<T>(src->dense<T>(), nout, pout, drows, dcols, dc, ds, X, ld, s);
+    else launch_derive_dense_snp<T>(src->snp(), static_cast<const T*>(src->impute), nout, pout, drows, dcols, dc, ds, X, ld, s);
+    AHIP_CHECK(hipStreamSynchronize(s));
+}
+} // namespace
+
 extern "C" {
 
 int adelie_hip_abi_version(void) { return ADELIE_HIP_ABI_VERSION; }
@@ -479,6 +523,33 @@ int adelie_hip_design_create_multi(adelie_hip_design* base, int64_t K, int inter
         AHIP_CHECK(hipMemsetAsync(d->ones, 0, size_t(len) * esz, d->stream));
         DTYPE_DISPATCH(d, launch_fill<T>((T*)d->ones, T(1), base->n, d->stream), launch_fill<T>((T*)d->ones, T(1), base->n, d->stream))
         AHIP_CHECK(hipStreamSynchronize(d->stream));
+    }
+    *out = d;
+    ABI_CATCH
+}
+
+int adelie_hip_design_create_derived(adelie_hip_design* src, const int64_t* rows, int64_t n_rows, const int64_t* cols,
+                                     int64_t n_cols, const double* centers, const double* scales, adelie_hip_design** out) {
+    ABI_TRY
+    if (!src || !out) throw make_core_error("null argument.");
+    no_view(src);
+    const int64_t nout = rows ? n_rows : src->n, pout = cols ? n_cols : src->p;
+    if (rows)
+        for (int64_t i = 0; i < n_rows; ++i)
+            if (rows[i] < 0 || rows[i] >= src->n) throw make_core_error("subset contains an out-of-range row index.");
+    if (cols)
+        for (int64_t j = 0; j < n_cols; ++j)
+            if (cols[j] < 0 || cols[j] >= src->p) throw make_core_error("subset contains an out-of-range column index.");
+    if (scales)
+        for (int64_t j = 0; j < pout; ++j)
+            if (!(scales[j] != 0.0)) throw make_core_error("scales must be non-zero.");
+    adelie_hip_design* d = new_design(nout, pout, src->dtype, src->device);
+    try {
+        DTYPE_DISPATCH(src, derive_t<T>(src, d, rows, n_rows, cols, n_cols, centers, scales),
+                       derive_t<T>(src, d, rows, n_rows, cols, n_cols, centers, scales))
+    } catch (...) {
+        adelie_hip_design_destroy(d);
+        throw;
     }
     *out = d;
     ABI_CATCH

@@ -340,6 +340,13 @@ template <class T> void launch_copy2d(const T* src, int64_t lds, T* dst, int64_t
 template <class T> void launch_diag_vars(const T* C, int64_t ldc, int32_t pos0, int32_t cnt, T* vars, hipStream_t s);
 // transpose row-major (n,p) into column-major with leading dimension ld
 template <class T> void launch_transpose(const T* src, int64_t n, int64_t p, T* dst, int64_t ld, hipStream_t s);
+// new dense matrix from a resident design: optional row / column gather, optional per-column centre and scale
+template <class T>
+void launch_derive_dense(const DenseView<T>& X, int64_t nout, int64_t pout, const int64_t* rows, const int64_t* cols,
+                         const T* centers, const T* scales, T* dst, int64_t ldd, hipStream_t s);
+template <class T>
+void launch_derive_dense_snp(const SnpView& X, const T* impute, int64_t nout, int64_t pout, const int64_t* rows,
+                             const int64_t* cols, const T* centers, const T* scales, T* dst, int64_t ldd, hipStream_t s);
 // pack int8 calldata (n,p col-major) into 2-bit codes
 void launch_pack_snp(const int8_t* calldata, int64_t n, int64_t p, uint8_t* bits, int64_t ldb, hipStream_t s);
 // PLINK .bed records (p records of stride_in bytes, device memory) -> 2-bit codes; column means of the non-missing calls

@@ -561,6 +561,46 @@ void launch_diag_vars(const T* C, int64_t ldc, int32_t pos0, int32_t cnt, T* var
     if (cnt <= 0) return;
     hipLaunchKernelGGL((diag_vars_kernel<T>), dim3((cnt + 255) / 256), dim3(256), 0, s, C, ldc, pos0, cnt, vars);
 }
+// dst[i + c*ldd] = (X[rows ? rows[i] : i, cols ? cols[c] : c] - (centers ? centers[col] : 0)) / (scales ? scales[col] : 1):
+// a new dense design from a resident one (standardize / subset, reference matrix_naive_standardize.ipp,
+// matrix_naive_subset.ipp -- views there; materialised here, HBM is not the scarce resource)
+template <class T, class Acc>
+__global__ void derive_dense_kernel(Acc X, int64_t nout, int64_t pout, const int64_t* __restrict__ rows,
+                                    const int64_t* __restrict__ cols, const T* __restrict__ centers,
+                                    const T* __restrict__ scales, T* __restrict__ dst, int64_t ldd) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t c = blockIdx.y;
+    if (i >= nout || c >= pout) return;
+    const int64_t j = cols ? cols[c] : c, r = rows ? rows[i] : i;
+    const T x = X.template load<1>(X.colptr(j), r, j).v[0];
+    const T ce = centers ? centers[c] : T(0), sc = scales ? scales[c] : T(1);
+    dst[i + c * ldd] = (x - ce) / sc;
+}
+template <class T>
+void launch_derive_dense(const DenseView<T>& X, int64_t nout, int64_t pout, const int64_t* rows, const int64_t* cols,
+                         const T* centers, const T* scales, T* dst, int64_t ldd, hipStream_t s) {
+    DenseAcc<T> acc{X.X, X.ld};
+    for (int64_t c0 = 0; c0 < pout; c0 += 65535) {
+        const int64_t pc = std::min<int64_t>(65535, pout - c0);
+        hipLaunchKernelGGL((derive_dense_kernel<T, DenseAcc<T>>), dim3((unsigned)((nout + 255) / 256), (unsigned)pc), dim3(256), 0,
+                           s, acc, nout, pc, rows, cols ? cols + c0 : nullptr, centers ? centers + c0 : nullptr,
+                           scales ? scales + c0 : nullptr, dst + c0 * ldd, ldd);
+        if (!cols) acc.X += 65535 * X.ld;
+    }
+}
+template <class T>
+void launch_derive_dense_snp(const SnpView& X, const T* impute, int64_t nout, int64_t pout, const int64_t* rows,
+                             const int64_t* cols, const T* centers, const T* scales, T* dst, int64_t ldd, hipStream_t s) {
+    SnpAcc<T> acc{X.bits, X.ldb, impute};
+    for (int64_t c0 = 0; c0 < pout; c0 += 65535) {
+        const int64_t pc = std::min<int64_t>(65535, pout - c0);
+        hipLaunchKernelGGL((derive_dense_kernel<T, SnpAcc<T>>), dim3((unsigned)((nout + 255) / 256), (unsigned)pc), dim3(256), 0,
+                           s, acc, nout, pc, rows, cols ? cols + c0 : nullptr, centers ? centers + c0 : nullptr,
+                           scales ? scales + c0 : nullptr, dst + c0 * ldd, ldd);
+        if (!cols) { acc.bits += 65535 * X.ldb; acc.impute += 65535; }
+    }
+}
+
 template <class T>
 void launch_transpose(const T* src, int64_t n, int64_t p, T* dst, int64_t ld, hipStream_t s) {
     if (n <= 0 || p <= 0) return;
@@ -616,7 +656,11 @@ template void launch_snp_impute<float>(const uint8_t*, int64_t, int64_t, int64_t
                                      const T*, T, T*, hipStream_t);                                                    \
     template void launch_copy2d<T>(const T*, int64_t, T*, int64_t, int64_t, int64_t, hipStream_t);                     \
     template void launch_diag_vars<T>(const T*, int64_t, int32_t, int32_t, T*, hipStream_t);                           \
-    template void launch_transpose<T>(const T*, int64_t, int64_t, T*, int64_t, hipStream_t);
+    template void launch_transpose<T>(const T*, int64_t, int64_t, T*, int64_t, hipStream_t);                            \
+    template void launch_derive_dense<T>(const DenseView<T>&, int64_t, int64_t, const int64_t*, const int64_t*, const T*, \
+                                         const T*, T*, int64_t, hipStream_t);                                          \
+    template void launch_derive_dense_snp<T>(const SnpView&, const T*, int64_t, int64_t, const int64_t*, const int64_t*, \
+                                             const T*, const T*, T*, int64_t, hipStream_t);
 INST(double)
 INST(float)
 #undef INST

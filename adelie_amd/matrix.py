@@ -118,6 +118,28 @@ class _NativeMatrix:
         self._backend.check(self._backend.fn("design_impute")(self._handle, out.ctypes.data))
         return out
 
+    def __getitem__(self, key):
+        """``mat[rows]`` / ``mat[:, cols]`` / ``mat[rows, cols]`` -> :func:`subset` (reference ``matrix.py:102-191``)."""
+        if isinstance(key, tuple):
+            if len(key) != 2:
+                raise IndexError("too many indices for a 2-dimensional matrix.")
+            rk, ck = key
+        else:
+            rk, ck = key, slice(None)
+
+        def idx(k, size):
+            if isinstance(k, slice):
+                return None if k == slice(None) else np.arange(size)[k]
+            return np.atleast_1d(np.asarray(k))
+
+        r, c = idx(rk, self._rows), idx(ck, self._cols)
+        out = self
+        if c is not None:
+            out = subset(out, c, axis=1, n_threads=self._n_threads)
+        if r is not None:
+            out = subset(out, r, axis=0, n_threads=self._n_threads)
+        return out
+
     @property
     def ndim(self):
         return 2
@@ -578,6 +600,78 @@ def snp_bed(bed, n: int, p: int = None, *, dtype=np.float64, n_threads: int = 1,
     backend.check(backend.fn("design_create_snp_bed")(
         buf.ctypes.data, buf.size, int(n), int(p), _abi.dtype_code(dtype), device, handle))
     return _wrap(backend, handle, np.dtype(dtype).type, n_threads)
+
+
+def _derived(mat, rows, cols, centers, scales, n_threads):
+    if not isinstance(mat, _NativeMatrix) or isinstance(mat, _MultiView):
+        raise RuntimeError("adelie_amd: subset / standardize need a resident dense or SNP design.")
+    backend = mat._backend
+    if not backend.has("design_create_derived"):
+        raise NotImplementedError("this backend does not derive designs.")
+    keep = []
+
+    def arr(x, dt):
+        if x is None:
+            return None, 0
+        a = np.ascontiguousarray(x, dtype=dt)
+        keep.append(a)
+        return a.ctypes.data, a.size
+
+    r, nr = arr(rows, np.int64)
+    c, nc = arr(cols, np.int64)
+    ce, _ = arr(centers, np.float64)
+    sc, _ = arr(scales, np.float64)
+    handle = _abi.C.c_void_p()
+    backend.check(backend.fn("design_create_derived")(mat._handle, r, nr, c, nc, ce, sc, handle))
+    return _wrap(backend, handle, mat.dtype, n_threads)
+
+
+def standardize(mat, centers=None, scales=None, ddof: int = 0, *, n_threads: int = 1):
+    """``X = (Z - 1 c^T) diag(s)^-1`` (reference ``adelie.matrix.standardize``, ``matrix.py:1414-1533``,
+    ``matrix_naive_standardize.ipp``).  ``centers`` / ``scales`` default to the column means and standard deviations of ``mat``
+    under equal weights (``ddof`` as in the reference).  A numpy input gives a numpy result, as in the reference; a resident
+    design gives a new resident dense design (materialised by one kernel rather than wrapped lazily), with ``_centers`` /
+    ``_scales`` attached."""
+    if isinstance(mat, (list, np.ndarray)):
+        mat = np.array(mat, order="F", copy=True)
+        if centers is None:
+            centers = np.mean(mat, axis=0)
+        mat -= np.asarray(centers)[None]
+        if scales is None:
+            n = mat.shape[0]
+            scales = np.sqrt(np.sum(mat ** 2, axis=0) / (n - ddof))
+        mat /= np.asarray(scales)[None]
+        return mat
+    dtype = mat.dtype
+    n, p = mat.shape
+    weights = np.full(n, 1 / n, dtype=dtype)
+    if centers is None:
+        centers = np.empty(p, dtype=dtype)
+        mat.mean(weights, centers)
+    if scales is None:
+        v = np.empty(p, dtype=dtype)
+        mat.var(centers, weights, v)
+        scales = np.sqrt((n / (n - ddof)) * v)
+    out = _derived(mat, None, None, centers, scales, n_threads)
+    out._centers = np.array(centers, copy=True, dtype=dtype)
+    out._scales = np.array(scales, copy=True, dtype=dtype)
+    return out
+
+
+def subset(mat, indices, *, axis: int = 0, n_threads: int = 1):
+    """``mat[indices]`` (``axis=0``) or ``mat[:, indices]`` (``axis=1``) as a new design (reference ``adelie.matrix.subset``,
+    ``matrix.py:1538-1640``, ``matrix_naive_subset.ipp``).  As the reference notes, to fit on a subset of the observations it
+    is cheaper to zero their weights than to subset the rows."""
+    if isinstance(mat, np.ndarray):
+        return mat[indices] if axis == 0 else mat[:, indices]
+    indices = np.asarray(indices)
+    if indices.dtype == bool:
+        indices = np.flatnonzero(indices)
+    if axis == 0:
+        return _derived(mat, indices, None, None, None, n_threads)
+    if axis == 1:
+        return _derived(mat, None, indices, None, None, n_threads)
+    raise RuntimeError("axis must be 0 or 1.")
 
 
 def snp_plink(prefix, *, dtype=np.float64, n_threads: int = 1, device: int = 0):

@@ -91,6 +91,13 @@ int adelie_hip_design_create_snp_bed(const void* bed, int64_t n_bytes, int64_t n
  * (the folds of cv_grpnet) can run concurrently from different host threads: one path leaves most of the chip idle
  * while its sequential block solves run, two or three paths interleave.  The alias must be destroyed before `src`. */
 int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out);
+/* A new dense design derived from a resident one (dense or SNP): rows `rows[0..n_rows)` (NULL: all), columns
+ * `cols[0..n_cols)` (NULL: all), every resulting column j centred by centers[j] and divided by scales[j] (NULL: no centring /
+ * scaling).  This is what adelie.matrix.subset (matrix_naive_subset.ipp) and adelie.matrix.standardize
+ * (matrix_naive_standardize.ipp: X = (Z - 1 c^T) diag(s)^-1) describe; the reference wraps the parent lazily, here the result is
+ * materialised in HBM by one kernel (matrix views).  The result does not reference `src`. */
+int adelie_hip_design_create_derived(adelie_hip_design* src, const int64_t* rows, int64_t n_rows, const int64_t* cols,
+                                     int64_t n_cols, const double* centers, const double* scales, adelie_hip_design** out);
 /* Multi-response view of a resident dense design: the (n*K) x ((p + intercept)*K) matrix
  *     [ 1_n (x) I_K ,  X (x) I_K ]      (the first block only when `intercept` != 0)
  * that adelie/state.py:1100-1125 (_render_multi_inputs) builds from matrix.kronecker_eye / matrix.concatenate

@@ -151,3 +151,41 @@ def test_snp_plink_fileset(hip, tmp_path):
     B.mul(v, w, ob)
     np.testing.assert_allclose(oa, ob, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(A.impute(), B.impute(), rtol=1e-14)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["dense", "snp"])
+def test_standardize_and_subset_derived_designs(hip, oracle, kind):
+    """matrix.standardize / matrix.subset (reference matrix_naive_standardize.ipp, matrix_naive_subset.ipp) as designs
+    materialised on the device: all twelve MatrixNaiveBase operations against numpy, and a grpnet path on the standardized
+    design against the oracle on the numpy-standardized matrix."""
+    rng = np.random.RandomState(17)
+    n, p = 211, 23
+    if kind == "dense":
+        Z = np.asfortranarray(rng.normal(size=(n, p)) * rng.uniform(0.5, 3, p) + rng.normal(size=p))
+        M = ad.matrix.dense(Z)
+    else:
+        cd = rng.choice(np.array([0, 1, 2, -9], dtype=np.int8), size=(n, p), p=[0.5, 0.3, 0.1, 0.1])
+        imp = ad.matrix.compute_impute(cd)
+        Z = np.asfortranarray(np.where(cd < 0, imp[None], cd).astype(float))
+        M = ad.matrix.snp_calldata(cd, imp)
+    S = ad.matrix.standardize(M, ddof=1)
+    c = Z.mean(0)
+    s = np.sqrt(((Z - c) ** 2).sum(0) / (n - 1))
+    np.testing.assert_allclose(S._centers, c, atol=1e-12)
+    np.testing.assert_allclose(S._scales, s, rtol=1e-12)
+    Xs = np.asfortranarray((Z - c) / s)
+    run_naive(S, Xs, np.float64)
+    np.testing.assert_allclose(ad.matrix.standardize(Z, ddof=1), Xs, atol=1e-12)
+    rows = rng.choice(n, 57, replace=False)
+    cols = np.array([5, 0, 22, 7, 7])
+    run_naive(ad.matrix.subset(M, rows, axis=0), np.asfortranarray(Z[rows]), np.float64)
+    run_naive(ad.matrix.subset(M, cols, axis=1), np.asfortranarray(Z[:, cols]), np.float64)
+    run_naive(M[rows, cols], np.asfortranarray(Z[rows][:, cols]), np.float64)
+    assert M[:, 3:9].shape == (n, 6) and M[::2].shape == ((n + 1) // 2, p)
+    with pytest.raises(RuntimeError):
+        ad.matrix.subset(M, [p], axis=1)
+    y = Xs[:, :3] @ np.array([1.0, -2.0, 0.5]) + 0.3 * rng.normal(size=n)
+    a = ad.grpnet(S, ad.glm.gaussian(y), tol=1e-12, early_exit=False, lmda_path_size=15)
+    b = ad.grpnet(oracle.dense(Xs), ad.glm.gaussian(y), tol=1e-12, early_exit=False, lmda_path_size=15)
+    assert a.error == "" and np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-9

@@ -16,7 +16,7 @@ import numpy as np
 F32, F64 = 0, 1
 COL_MAJOR, ROW_MAJOR = 0, 1
 SCREEN_STRONG, SCREEN_PIVOT = 0, 1
-GLM_GAUSSIAN, GLM_BINOMIAL_LOGIT, GLM_GAUSSIAN_IRLS, GLM_MULTINOMIAL = 0, 1, 2, 3
+GLM_GAUSSIAN, GLM_BINOMIAL_LOGIT, GLM_GAUSSIAN_IRLS, GLM_MULTINOMIAL, GLM_POISSON, GLM_BINOMIAL_PROBIT = 0, 1, 2, 3, 4, 5
 
 POLL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int64)
 

@@ -57,14 +57,42 @@ __global__ void final_reduce_kernel(T* sums, int K) {
     }
 }
 
+// binomial probit helpers (glm_binomial.ipp:100-120)
+template <class T> __device__ __forceinline__ T std_cdf(T x) { return T(0.5) * (T(1) + erf(x * T(0.70710678118654752440))); }
+template <class T> __device__ __forceinline__ T std_pdf(T x) { return T(0.39894228040143267794) * exp(T(-0.5) * x * x); }
+template <class T> __device__ __forceinline__ T fmax_of();
+template <> __device__ __forceinline__ double fmax_of<double>() { return 1.7976931348623157e308; }
+template <> __device__ __forceinline__ float fmax_of<float>() { return 3.402823466e38f; }
+
 template <class T>
 __device__ __forceinline__ T glm_grad(int kind, T y, T w, T eta) {
     if (kind == ADELIE_HIP_GLM_BINOMIAL_LOGIT) return w * (y - T(1) / (T(1) + exp(-eta)));
+    if (kind == ADELIE_HIP_GLM_POISSON) return w * (y - exp(eta));                        // glm_poisson.ipp:14-23
+    if (kind == ADELIE_HIP_GLM_BINOMIAL_PROBIT) {                                         // glm_binomial.ipp:131-143
+        const T mx = fmax_of<T>(), c = std_cdf(eta);
+        return w * std_pdf(eta) * (y * min(T(1) / c, mx) - (T(1) - y) * min(T(1) / (T(1) - c), mx));
+    }
     return w * (y - eta);
+}
+// per-observation loss without the weight (glm_*.ipp loss members)
+template <class T>
+__device__ __forceinline__ T glm_loss_term(int kind, T y, T e) {
+    if (kind == ADELIE_HIP_GLM_BINOMIAL_LOGIT) return (T(e > T(0)) - y) * e + log(T(1) + exp(-fabs(e)));
+    if (kind == ADELIE_HIP_GLM_POISSON) return min(-e, fmax_of<T>()) * y + exp(e);        // glm_poisson.ipp:36-44
+    if (kind == ADELIE_HIP_GLM_BINOMIAL_PROBIT) {                                         // glm_binomial.ipp:161-173
+        const T mx = fmax_of<T>(), c = std_cdf(e);
+        return -(y * max(log(c), -mx) + (T(1) - y) * max(log(T(1) - c), -mx));
+    }
+    return T(0.5) * e * e - y * e;
 }
 // multinomial (glm_multinomial.ipp:47-66): w is the observation weight repeated for every class, K the class count
 template <class T>
-__device__ __forceinline__ T glm_hess(int kind, T y, T w, T grad, int K = 1) {
+__device__ __forceinline__ T glm_hess(int kind, T y, T w, T grad, T eta, int K = 1) {
+    if (kind == ADELIE_HIP_GLM_POISSON) return w * y - grad;                              // glm_poisson.ipp:25-34
+    if (kind == ADELIE_HIP_GLM_BINOMIAL_PROBIT) {                                         // glm_binomial.ipp:145-159
+        const T mx = fmax_of<T>(), c = std_cdf(eta), pd = std_pdf(eta), c1 = T(1) - c;
+        return w * (y * min(T(1) / (c * c), mx) + (T(1) - y) * min(T(1) / (c1 * c1), mx)) * pd * pd + eta * grad;
+    }
     if (kind == ADELIE_HIP_GLM_MULTINOMIAL) {
         const T h = y * w / T(K) - grad;
         return h * (T(2) * (T(1) - T(K) * (h / (w + T(w <= T(0))))));
@@ -86,7 +114,7 @@ __global__ __launch_bounds__(RT) void irls_prepare_kernel(int kind, const T* __r
                                                           T* __restrict__ irls_y, T* sums, int K) {
     T acc[1] = {T(0)};
     GRID_STRIDE(i, n) {
-        const T h0 = glm_hess(kind, y[i], w[i], resid[i], K);
+        const T h0 = glm_hess(kind, y[i], w[i], resid[i], eta[i], K);
         const T h = (h0 > T(0) ? h0 : T(0)) + hmin * T(h0 <= T(0));
         const T z = resid[i] / h; // inv_hessian_gradient uses the same raised hessian (glm_base.ipp:32-36)
         hess[i] = h;
@@ -138,11 +166,7 @@ __global__ __launch_bounds__(RT) void glm_loss_kernel(int kind, const T* __restr
                                                       const T* __restrict__ eta, int64_t n, T* sums) {
     T acc[1] = {T(0)};
     GRID_STRIDE(i, n) {
-        const T e = eta[i];
-        if (kind == ADELIE_HIP_GLM_BINOMIAL_LOGIT)
-            acc[0] += w[i] * ((T(e > T(0)) - y[i]) * e + log(T(1) + exp(-fabs(e))));
-        else
-            acc[0] += w[i] * (T(0.5) * e * e - y[i] * e);
+        acc[0] += w[i] * glm_loss_term(kind, y[i], eta[i]);
     }
     block_partials<T, 1>(acc, sums);
 }
@@ -155,9 +179,7 @@ __global__ __launch_bounds__(RT) void glm_loss2_kernel(int kind, const T* __rest
     T acc[2] = {T(0), T(0)};
     GRID_STRIDE(i, n) {
         const T e = base[i] + b0 + off[i];
-        T l;
-        if (kind == ADELIE_HIP_GLM_BINOMIAL_LOGIT) l = (T(e > T(0)) - y[i]) * e + log(T(1) + exp(-fabs(e)));
-        else l = T(0.5) * e * e - y[i] * e;
+        const T l = glm_loss_term(kind, y[i], e);
         acc[0] += wa[i] * l;
         acc[1] += wb[i] * l;
     }
@@ -170,7 +192,7 @@ __global__ __launch_bounds__(RT) void null_step_kernel(int kind, const T* __rest
                                                        const T* __restrict__ off, T hmin, int64_t n, T* sums, int K) {
     T acc[2] = {T(0), T(0)};
     GRID_STRIDE(i, n) {
-        const T h0 = glm_hess(kind, y[i], w[i], resid[i], K);
+        const T h0 = glm_hess(kind, y[i], w[i], resid[i], eta[i], K);
         const T h = (h0 > T(0) ? h0 : T(0)) + hmin * T(h0 <= T(0));
         const T z = resid[i] / h;
         acc[0] += h;

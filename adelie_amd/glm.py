@@ -224,11 +224,107 @@ def multinomial(y, *, weights=None, dtype=None):
     return _multinomial()
 
 
-def binomial(y, *, weights=None, link: str = "logit", dtype=None):
-    """Binomial family, logit link (reference ``adelie.glm.binomial``, ``glm.py:83-196``)."""
-    if link != "logit":
-        raise NotImplementedError("adelie_amd.glm.binomial: only link='logit' is on the grpnet hot path.")
+def poisson(y, *, weights=None, dtype=None):
+    """Poisson family, log link (reference ``adelie.glm.poisson``, ``glm.py:621-697``; arithmetic ``glm_poisson.ipp:14-58``)."""
     y, dtype = _coerce_dtype(y, dtype)
+
+    class _poisson(glm_base, _mixin(dtype)):
+        name = "poisson"
+
+        def __init__(self):
+            glm_base.__init__(self, y, weights, dtype)
+            self.core_kind = _abi.GLM_POISSON
+
+        def gradient(self, eta, grad):
+            grad[...] = self.weights * (self.y - np.exp(eta))
+
+        def hessian(self, eta, grad, hess):
+            hess[...] = self.weights * self.y - grad
+
+        def loss(self, eta):
+            mx = np.finfo(self.dtype).max
+            return np.sum(self.weights * (np.minimum(-eta, mx) * self.y + np.exp(eta)))
+
+        def loss_full(self):
+            mx = np.finfo(self.dtype).max
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = np.minimum(-np.log(self.y), mx) * self.y
+            return self.dtype(np.sum(self.weights * (np.where(self.y > 0, t, 0.0) + self.y)))
+
+        def inv_link(self, eta, out):
+            out[...] = np.exp(eta)
+
+        def reweight(self, weights=None):
+            w = self.weights if weights is None else weights
+            return poisson(y=y, weights=w, dtype=dtype)
+
+    return _poisson()
+
+
+def _binomial_probit(y, weights, dtype):
+    """Binomial family, probit link (reference ``glm_binomial.ipp:100-190``)."""
+    from scipy.special import erf
+
+    class _probit(glm_base, _mixin(dtype)):
+        name = "binomial_probit"
+
+        def __init__(self):
+            glm_base.__init__(self, y, weights, dtype)
+            self.core_kind = _abi.GLM_BINOMIAL_PROBIT
+
+        @staticmethod
+        def _cdf(x):
+            return 0.5 * (1 + erf(x / np.sqrt(2)))
+
+        @staticmethod
+        def _pdf(x):
+            return np.exp(-0.5 * np.square(x)) / np.sqrt(2 * np.pi)
+
+        def gradient(self, eta, grad):
+            mx = np.finfo(self.dtype).max
+            c = self._cdf(eta)
+            with np.errstate(divide="ignore"):
+                grad[...] = self.weights * self._pdf(eta) * (
+                    self.y * np.minimum(1 / c, mx) - (1 - self.y) * np.minimum(1 / (1 - c), mx))
+
+        def hessian(self, eta, grad, hess):
+            mx = np.finfo(self.dtype).max
+            c = self._cdf(eta)
+            with np.errstate(divide="ignore"):
+                hess[...] = self.weights * (
+                    self.y * np.minimum(1 / np.square(c), mx) + (1 - self.y) * np.minimum(1 / np.square(1 - c), mx)
+                ) * np.square(self._pdf(eta)) + eta * grad
+
+        def loss(self, eta):
+            mx = np.finfo(self.dtype).max
+            c = self._cdf(eta)
+            with np.errstate(divide="ignore"):
+                return -np.sum(self.weights * (
+                    self.y * np.maximum(np.log(c), -mx) + (1 - self.y) * np.maximum(np.log(1 - c), -mx)))
+
+        def loss_full(self):
+            with np.errstate(divide="ignore", invalid="ignore"):
+                ly, l1y = np.log(self.y), np.log(1 - self.y)
+                t1, t2 = self.weights * self.y * ly, self.weights * (1 - self.y) * l1y
+            return self.dtype(-np.sum(t1[np.isfinite(ly)]) - np.sum(t2[np.isfinite(l1y)]))
+
+        def inv_link(self, eta, out):
+            out[...] = self._cdf(eta)
+
+        def reweight(self, weights=None):
+            w = self.weights if weights is None else weights
+            return _binomial_probit(y, w, dtype)
+
+    return _probit()
+
+
+def binomial(y, *, weights=None, link: str = "logit", dtype=None):
+    """Binomial family, logit or probit link (reference ``adelie.glm.binomial``, ``glm.py:83-196``)."""
+    y, dtype = _coerce_dtype(y, dtype)
+    if link == "probit":
+        return _binomial_probit(y, weights, dtype)
+    if link != "logit":
+        raise RuntimeError("link must be one of 'logit' or 'probit'.")
 
     class _binomial(glm_base, _mixin(dtype)):
         name = "binomial_logit"

@@ -603,7 +603,7 @@ def glm_naive(
     dtype = X.dtype
     if not hasattr(glm, "core_kind"):
         raise RuntimeError(
-            "adelie_amd: glm must be adelie_amd.glm.gaussian / binomial; Python-subclassed GLMs cannot run on device."
+            "adelie_amd: glm must be one of adelie_amd.glm.gaussian / binomial / poisson; Python-subclassed GLMs cannot run on device."
         )
     (max_screen_size, max_active_size, lmda_path_size, setup_lmda_max, setup_lmda_path, lmda_max, lmda_path) = \
         _render_inputs(groups=groups, lmda_max=lmda_max, lmda_path=lmda_path, lmda_path_size=lmda_path_size,

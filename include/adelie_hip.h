@@ -37,6 +37,8 @@ enum adelie_hip_glm_kind {
     ADELIE_HIP_GLM_GAUSSIAN = 0,        /* glm.gaussian(opt=True): StateGaussianNaive, no IRLS (solver.py:683-686) */
     ADELIE_HIP_GLM_BINOMIAL_LOGIT = 1,  /* glm.binomial(link="logit"): StateGlmNaive + IRLS */
     ADELIE_HIP_GLM_GAUSSIAN_IRLS = 2,   /* glm.gaussian(opt=False): Gaussian loss forced through StateGlmNaive */
+    ADELIE_HIP_GLM_POISSON = 4,         /* glm.poisson (glm_poisson.ipp:14-58): StateGlmNaive + IRLS */
+    ADELIE_HIP_GLM_BINOMIAL_PROBIT = 5, /* glm.binomial(link="probit") (glm_binomial.ipp:100-190) */
     ADELIE_HIP_GLM_MULTINOMIAL = 3      /* glm.multinomial: StateMultiGlmNaive (solver_multiglm_naive.hpp) + IRLS; the design must
                                            be a multi-response view (adelie_hip_design_create_multi).  glm_y is (n, K) row-major,
                                            glm_weights is (n,), offsets / eta / resid are (n, K) row-major (glm_multinomial.ipp) */

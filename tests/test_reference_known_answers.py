@@ -135,3 +135,36 @@ def test_oracle_reproduces_faq_and_parallelism_notebooks(oracle):
 @pytest.mark.gpu
 def test_hip_reproduces_faq_and_parallelism_notebooks(hip):
     _check_small(_replay_small(ad.matrix.dense))
+
+
+def _replay_glm_notebook(dense):
+    """glm.ipynb cells 5-27: the notebook draws everything from one numpy stream seeded in cell 5, then runs the same data
+    through ``glm.gaussian(y, opt=False)`` — the Gaussian family forced through the IRLS (StateGlmNaive) route — and prints
+    ``44/100 ... [dev:90.7%]`` (cell 27; cell 25 prints the same for a Python-subclassed Gaussian)."""
+    n, K, p = 100, 4, 1000
+    np.random.seed(0)
+    np.random.normal(0, 1, n)          # cell 5  y
+    np.random.uniform(0, 1, n)         # cell 7  w
+    np.random.normal(0, 1, n)          # cell 10 eta
+    np.random.normal(0, 1, (n, K))     # cell 15 multi-response y
+    np.random.normal(0, 1, (n, K))     # cell 17 multi-response eta
+    X = np.random.normal(0, 1, (n, p))                                      # cell 24
+    y = X[:, -1] * np.random.normal(0, 1) + np.random.normal(0, 1, n)
+    Xd = dense(np.asfortranarray(X))
+    out = {}
+    for opt in (False, True):
+        st = ad.grpnet(Xd, ad.glm.gaussian(y=y, opt=opt))
+        assert st.error == ""
+        out[opt] = (len(st.lmdas), f"{100 * st.devs[-1]:.1f}", st.devs[-2] < 0.9)
+    return out
+
+
+def test_oracle_reproduces_glm_notebook(oracle):
+    out = _replay_glm_notebook(oracle.dense)
+    assert out[False] == (44, "90.7", True) and out[True] == (44, "90.7", True)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_glm_notebook(hip):
+    out = _replay_glm_notebook(ad.matrix.dense)
+    assert out[False] == (44, "90.7", True) and out[True] == (44, "90.7", True)

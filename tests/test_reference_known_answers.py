@@ -168,3 +168,27 @@ def test_oracle_reproduces_glm_notebook(oracle):
 def test_hip_reproduces_glm_notebook(hip):
     out = _replay_glm_notebook(ad.matrix.dense)
     assert out[False] == (44, "90.7", True) and out[True] == (44, "90.7", True)
+
+
+def _replay_matrix_notebook(dense):
+    """matrix.ipynb cells 5-21 (one numpy stream seeded in cell 5): ``52/100 ... [dev:90.2%]`` for both the Python-subclassed
+    dense matrix (cell 19) and ``ad.matrix.dense`` (cell 21)."""
+    n, p = 100, 1000
+    np.random.seed(0)
+    X = np.random.normal(0, 1, (n, p))     # cell 5
+    np.random.uniform(0, 1, n)             # cell 7  w
+    np.random.normal(0, 1, n)              # cell 7  v
+    np.random.normal(0, 1, 3)              # cell 11 values
+    y = X[:, -1] * np.random.normal(0, 1) + np.random.normal(0, 1, n)   # cell 18
+    st = ad.grpnet(dense(np.asfortranarray(X)), ad.glm.gaussian(y=y))
+    assert st.error == ""
+    return len(st.lmdas), f"{100 * st.devs[-1]:.1f}", st.devs[-2] < 0.9
+
+
+def test_oracle_reproduces_matrix_notebook(oracle):
+    assert _replay_matrix_notebook(oracle.dense) == (52, "90.2", True)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_matrix_notebook(hip):
+    assert _replay_matrix_notebook(ad.matrix.dense) == (52, "90.2", True)

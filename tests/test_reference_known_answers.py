@@ -192,3 +192,57 @@ def test_oracle_reproduces_matrix_notebook(oracle):
 @pytest.mark.gpu
 def test_hip_reproduces_matrix_notebook(hip):
     assert _replay_matrix_notebook(ad.matrix.dense) == (52, "90.2", True)
+
+
+REF_DIGITS_CONFUSION = [                    # sklearn_api.ipynb cell 39
+    [29, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+    [0, 32, 0, 0, 0, 0, 0, 0, 2, 2],
+    [0, 0, 41, 1, 0, 0, 0, 0, 0, 1],
+    [0, 1, 0, 34, 0, 0, 0, 0, 1, 0],
+    [0, 1, 0, 0, 37, 0, 0, 1, 0, 1],
+    [0, 0, 0, 0, 0, 37, 0, 0, 0, 3],
+    [0, 1, 0, 0, 0, 0, 37, 0, 0, 0],
+    [0, 0, 0, 0, 0, 1, 0, 31, 0, 0],
+    [0, 3, 0, 1, 0, 2, 0, 2, 23, 0],
+    [0, 0, 0, 0, 0, 0, 0, 1, 0, 34],
+]
+
+
+def _replay_digits(dense):
+    """Cells 35-39 of the same notebook: ``GroupElasticNet(solver="cv_grpnet", family="multinomial")`` on scikit-learn's digits
+    (1437 x 64 training rows, 10 classes), refit at the CV-selected lambda (``100/100 ... [dev:84.7%]``), test confusion matrix.
+    The train/test split draws from the notebook's global numpy stream, so the earlier cells' draws are repeated first (the
+    splits and the two fold orders; the fits themselves draw nothing)."""
+    np.random.seed(42)
+    d = sklearn_datasets.load_diabetes()
+    train_test_split(d.data, d.target, test_size=0.2)
+    np.random.choice(353, 353, replace=False)            # fold order of the Gaussian cv_grpnet (cv.py:219-221)
+    d = sklearn_datasets.load_breast_cancer()
+    train_test_split(d.data, d.target, test_size=0.2)
+    np.random.choice(455, 455, replace=False)            # fold order of the binomial cv_grpnet
+    d = sklearn_datasets.load_digits()
+    X_train, X_test, y_train, y_test = train_test_split(d.data, d.target, test_size=0.2)
+    X_train, X_test = np.asfortranarray(X_train), np.asfortranarray(X_test)
+    assert X_train.shape == (1437, 64) and X_test.shape == (360, 64)   # cell 35 output
+    y2 = np.eye(10)[y_train]                                            # OneHotEncoder(sparse_output=False)
+    Xd = dense(X_train)
+    glm = ad.glm.multinomial(y2)
+    cv = ad.cv_grpnet(Xd, glm, n_concurrent=1)
+    fit = cv.fit(Xd, glm)
+    eta = ad.diagnostic.predict(dense(X_test), fit.betas[-1], np.array([fit.intercepts[-1]])).squeeze()
+    yhat = np.argmax(eta, axis=-1)                                      # argmax of softmax, sklearn.py:185-212
+    conf = [[int(np.sum((y_test == a) & (yhat == b))) for b in range(10)] for a in range(10)]
+    return len(fit.lmdas), f"{100 * fit.devs[-1]:.1f}", conf
+
+
+def test_oracle_reproduces_reference_multinomial_cv(oracle):
+    n_lmdas, dev, conf = _replay_digits(oracle.dense)
+    assert (n_lmdas, dev) == (100, "84.7")
+    assert conf == REF_DIGITS_CONFUSION
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_reference_multinomial_cv(hip):
+    n_lmdas, dev, conf = _replay_digits(ad.matrix.dense)
+    assert (n_lmdas, dev) == (100, "84.7")
+    assert conf == REF_DIGITS_CONFUSION

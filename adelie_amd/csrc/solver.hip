@@ -257,6 +257,13 @@ struct Solver {
     // enqueued there up front and the MFMA work overlaps the HBM-bound steps / single-wave solves of the main chain, which
     // waits on a per-block event right before the block's solve.
     hipStream_t st2 = nullptr;
+    // further build streams (ADELIE_HIP_SIDE_STREAMS = 1..4 in total): under IRLS every block is rebuilt per iteration and the
+    // chain waits for the builds; one build kernel (512 workgroups, 2 per CU) leaves the MFMA pipes half idle, two or three in
+    // flight fill them
+    static constexpr int kMaxExtra = 3;
+    hipStream_t st_x[kMaxExtra] = {nullptr, nullptr, nullptr};
+    DevBuf<T> d_work_x[kMaxExtra];
+    int n_side = 1;
     bool side_grams = true;
     DevBuf<T> d_work_gram2;
     std::vector<hipEvent_t> ev_pool;
@@ -269,6 +276,7 @@ struct Solver {
         }
         return ev_pool[ev_used++];
     }
+    int n_built_side = 0;
     std::vector<hipEvent_t> blk_ev; // per block of the current pass: event of its build on the side stream (or nullptr)
     // Builds the stale blocks among `nblk` blocks of a pass; block j has nb_of(j) members and columns cols_of(j).
     template <class NbOf, class ColsOf>
@@ -283,16 +291,19 @@ struct Solver {
             if (tab_nb[j] == nb && tab_ver[j] == w_version) continue;
             T* Dptr = pool + size_t(j) * SL * SL;
             const bool side = side_grams && st2 != nullptr;
+            const int sidx = !side ? 0 : ((n_side >= 2 && st_x[0] && !multi()) ? 1 + (n_built_side++ % n_side) : 1);
             if (side && first) { // the weights (and everything else the builds read) are final at this point of the main stream
                 hipEvent_t e0 = next_event();
                 AHIP_CHECK(hipEventRecord(e0, st));
                 AHIP_CHECK(hipStreamWaitEvent(st2, e0, 0));
+                for (int k = 0; k < kMaxExtra; ++k)
+                    if (st_x[k]) AHIP_CHECK(hipStreamWaitEvent(st_x[k], e0, 0));
                 first = false;
             }
-            gram_block(cur_w, cols_of(j), nb, cur_xm, Dptr, side);
+            gram_block(cur_w, cols_of(j), nb, cur_xm, Dptr, sidx);
             if (side) {
                 hipEvent_t e = next_event();
-                AHIP_CHECK(hipEventRecord(e, st2));
+                AHIP_CHECK(hipEventRecord(e, sidx >= 2 ? st_x[sidx - 2] : st2));
                 blk_ev[size_t(j)] = e;
             }
             tab_nb[j] = nb;
@@ -311,6 +322,11 @@ struct Solver {
             (void)hipStreamSynchronize(st2);
             (void)hipStreamDestroy(st2);
         }
+        for (int k = 0; k < kMaxExtra; ++k)
+            if (st_x[k]) {
+                (void)hipStreamSynchronize(st_x[k]);
+                (void)hipStreamDestroy(st_x[k]);
+            }
 
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     }
@@ -454,9 +470,9 @@ struct Solver {
                                         d_part.p, st);
     }
     // B x B block  X_cols^T W X_cols - xm xm^T  into Dptr (ld = B)
-    void gram_block(const T* w, const int32_t* cols, int nb, const T* xm, T* Dptr, bool side = false) {
+    void gram_block(const T* w, const int32_t* cols, int nb, const T* xm, T* Dptr, int side = 0) {
         const int B = cd_block_size();
-        hipStream_t gs = side ? st2 : st;
+        hipStream_t gs = side == 0 ? st : (side >= 2 ? st_x[side - 2] : st2);
         t_gram.begin(gs);
         if (multi()) {
             // Gram over the block's distinct extended features (MFMA syrk), expanded to the view columns: entries between
@@ -487,7 +503,7 @@ struct Solver {
             return;
         }
         {   // lower-triangle MFMA tiles only: 10 of 16 (nb <= 64) or 36 of 64
-            T* work = (side ? d_work_gram2 : d_work_gram).reserve(size_t(syrk_work_elems(n, 128)));
+            T* work = (side == 0 ? d_work_gram : (side >= 2 ? d_work_x[side - 2] : d_work_gram2)).reserve(size_t(syrk_work_elems(n, 128)));
             if (dense()) launch_syrk<T>(D->dense<T>(), w, cols, nb, xm, intercept, Dptr, B, work, gs);
             else launch_syrk_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols, nb, xm, intercept, Dptr, B, work, gs);
             cnt.gram_flops += 2.0 * double(n) * 256.0 * (nb <= 32 ? 3.0 : (nb <= 64 ? 10.0 : 36.0));
@@ -1052,6 +1068,8 @@ struct Solver {
             panel_maxblk = maxblk;
         }
         if (side_grams && !st2) AHIP_CHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+        for (int k = 0; side_grams && k < std::min(n_side - 1, kMaxExtra); ++k)
+            if (!st_x[k]) AHIP_CHECK(hipStreamCreateWithFlags(&st_x[k], hipStreamNonBlocking));
         if (use_report && !h_report) {
             void* hp = nullptr;
             void* dp = nullptr;
@@ -2352,6 +2370,10 @@ struct Solver {
         time_panel = std::getenv("ADELIE_HIP_TIME_PANEL") != nullptr;
         if (const char* e = std::getenv("ADELIE_HIP_PASS_REPORT")) use_report = std::atoi(e) != 0; // A/B hook
         if (const char* e = std::getenv("ADELIE_HIP_SIDE_GRAMS")) side_grams = std::atoi(e) != 0; // A/B hook
+        // two build streams under IRLS (config 4: 8.2 -> 7.2 s; three or four are no better), one under fixed weights (the
+        // few builds of a Gaussian path only add contention for the look-ahead launches: 3.13 vs 3.08 paths/s)
+        n_side = is_glm() ? 2 : 1;
+        if (const char* e = std::getenv("ADELIE_HIP_SIDE_STREAMS")) n_side = std::max(1, std::min(1 + kMaxExtra, std::atoi(e))); // tuning hook
         if (const char* e = std::getenv("ADELIE_HIP_PRELAUNCH_SWEEP")) prelaunch_sweep = std::atoi(e) != 0; // A/B hook
         if (const char* e = std::getenv("ADELIE_HIP_GROUP_PANEL")) group_panel = std::atoi(e) != 0; // A/B hook
         if (const char* e = std::getenv("ADELIE_HIP_LOOKAHEAD")) lookahead = std::atoi(e) != 0; // A/B hook

@@ -95,6 +95,10 @@ struct adelie_hip_design {
     int64_t mK = 0, nb = 0, pb = 0;
     int micpt = 0;
     void* ones = nullptr; // nb ones (owned)
+    // Sweep batching across solvers that run concurrently on one resident matrix (cv_grpnet folds on alias handles): the
+    // batcher object lives with the design the aliases were made from (solver.hip::SweepBatcher, created on first use).
+    adelie_hip_design* batch_owner = nullptr; // nullptr: this design itself
+    void* batcher = nullptr;
     hipStream_t stream = nullptr;
     // scratch for the host-vector matrix ops (value_t typed, grow-only)
     ahip::DevBuf<char> s_n1, s_n2, s_p1, s_work, s_misc, s_idx1, s_idx2;

@@ -333,6 +333,8 @@ void derive_t(adelie_hip_design* src, adelie_hip_design* d, const int64_t* rows,
 }
 } // namespace
 
+void adelie_hip_internal_free_batcher(void* b); // solver.hip
+
 extern "C" {
 
 int adelie_hip_abi_version(void) { return ADELIE_HIP_ABI_VERSION; }
@@ -494,6 +496,7 @@ int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out) {
     d->ldb = src->ldb;
     d->impute = src->impute;
     d->alias = true;
+    d->batch_owner = src->batch_owner ? src->batch_owner : src;
     *out = d;
     ABI_CATCH
 }
@@ -582,6 +585,7 @@ int adelie_hip_design_destroy(adelie_hip_design* d) {
     if (d->bits && !d->alias) (void)hipFree(d->bits);
     if (d->impute && !d->alias) (void)hipFree(d->impute);
     if (d->ones) (void)hipFree(d->ones);
+    if (d->batcher) adelie_hip_internal_free_batcher(d->batcher);
     delete d;
     return 0;
 }

@@ -321,6 +321,9 @@ void launch_gram_multi(const MultiView<T>& X, const T* w, const int32_t* mcols, 
 template <class T>
 void launch_multi_expand_cross(const T* G, int64_t ldg, const int32_t* slot_r, const int32_t* resp_r, int nr,
                                const int32_t* slot_c, const int32_t* resp_c, int nc, T* C, int64_t ldc, hipStream_t s);
+template <class T>
+void launch_batch_pick(const T* src, int64_t nfeat, int K, int slot, const T* sub_scale, const T* sub_vec, T* out,
+                       hipStream_t s);
 // (n, K) row-major <-> response-major
 template <class T> void launch_multi_to_major(const T* src, int64_t nb, int K, T* dst, hipStream_t s);
 template <class T> void launch_multi_from_major(const T* src, int64_t nb, int K, T* dst, hipStream_t s);

@@ -400,6 +400,16 @@ __global__ void multi_axpy_kernel(DenseOnesAcc<T> X, int64_t nb, int K, const in
     }
 }
 
+// out[u] = src[u*K + slot] - (sub_vec ? sub_scale[0] * sub_vec[u] : 0): one solver's share of a batched K-vector sweep
+template <class T>
+__global__ void batch_pick_kernel(const T* __restrict__ src, int64_t nfeat, int K, int slot, const T* __restrict__ sub_scale,
+                                  const T* __restrict__ sub_vec, T* __restrict__ out) {
+    const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (u >= nfeat) return;
+    T s = src[u * K + slot];
+    if (sub_vec) s -= sub_scale[0] * sub_vec[u];
+    out[u] = s;
+}
 template <class T>
 __global__ void multi_to_major_kernel(const T* __restrict__ src, int64_t nb, int K, T* __restrict__ dst) {
     const int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -541,6 +551,12 @@ void launch_multi_block_lists(const int32_t* cols, int nv, int K, int32_t* ulist
 }
 
 template <class T>
+void launch_batch_pick(const T* src, int64_t nfeat, int K, int slot, const T* sub_scale, const T* sub_vec, T* out,
+                       hipStream_t s) {
+    hipLaunchKernelGGL((batch_pick_kernel<T>), dim3((unsigned)((nfeat + 255) / 256)), dim3(256), 0, s, src, nfeat, K, slot,
+                       sub_scale, sub_vec, out);
+}
+template <class T>
 void launch_multi_to_major(const T* src, int64_t nb, int K, T* dst, hipStream_t s) {
     const int64_t tot = nb * K;
     if (tot <= 0) return;
@@ -567,6 +583,7 @@ void launch_multi_from_major(const T* src, int64_t nb, int K, T* dst, hipStream_
                                             hipStream_t);                                                              \
     template void launch_multi_expand<T>(const T*, int64_t, const int32_t*, const int32_t*, int, int, T*, int64_t,     \
                                          hipStream_t);                                                                 \
+    template void launch_batch_pick<T>(const T*, int64_t, int, int, const T*, const T*, T*, hipStream_t);              \
     template void launch_multi_to_major<T>(const T*, int64_t, int, T*, hipStream_t);                                   \
     template void launch_multi_from_major<T>(const T*, int64_t, int, T*, hipStream_t);
 INST(double)

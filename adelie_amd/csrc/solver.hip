@@ -16,6 +16,8 @@
 #include <cstring>
 #include <type_traits>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -163,6 +165,122 @@ struct FitOut {
     T intercept = 0, rsq = 0;
     double t_screen = 0, t_active = 0;
 };
+
+// ------------------------------------------------------------------------------------------------------------
+// Sweep batching: solvers that run concurrently on one resident dense matrix (the folds of cv_grpnet, each from its own
+// host thread on an alias handle) all spend most of their time in the same HBM-bound kernel, the full-gradient sweep X^T v.
+// The K-wide sweep of kernels_multi.hip reads X once for K vectors, so the solvers that reach their sweep within a short
+// window are answered by ONE pass over X.  A solver that arrives alone (or with batching off) takes its ordinary sweep.
+// Results do not depend on who shares a batch: every vector's dot products are accumulated independently and in a fixed
+// order; they differ from the ordinary sweep kernel's only by that order (last bits).
+// ------------------------------------------------------------------------------------------------------------
+int g_sweep_batch = 0; // adelie_hip_set_config("sweep_batch", 0/1)
+std::mutex g_batcher_create_mutex;
+
+struct SweepBatcher {
+    static constexpr int KMAX = 8, NGEN = 4;
+    std::mutex m;
+    std::condition_variable cv;
+    int registered = 0;
+    struct Gen {
+        int count = 0, K = 0, pending = 0; // pending: members of the launched batch that have not enqueued their pick yet
+        hipEvent_t done = nullptr, in_ev[KMAX], out_ev[KMAX];
+        bool out_set[KMAX], done_set = false;
+    };
+    Gen gen[NGEN];
+    uint64_t cur = 0, launched_upto = 0; // generation collecting arrivals; generations < launched_upto have been launched
+    hipStream_t stream = nullptr;
+    DevBuf<char> vbuf[NGEN], obuf[NGEN], work;
+    SweepBatcher() {
+        AHIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        for (auto& g : gen) {
+            AHIP_CHECK(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+            for (int k = 0; k < KMAX; ++k) {
+                AHIP_CHECK(hipEventCreateWithFlags(&g.in_ev[k], hipEventDisableTiming));
+                AHIP_CHECK(hipEventCreateWithFlags(&g.out_ev[k], hipEventDisableTiming));
+                g.out_set[k] = false;
+            }
+        }
+    }
+    ~SweepBatcher() {
+        if (stream) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+        }
+        for (auto& g : gen) {
+            (void)hipEventDestroy(g.done);
+            for (int k = 0; k < KMAX; ++k) {
+                (void)hipEventDestroy(g.in_ev[k]);
+                (void)hipEventDestroy(g.out_ev[k]);
+            }
+        }
+    }
+    void add() { std::lock_guard<std::mutex> lk(m); ++registered; }
+    void remove() {
+        { std::lock_guard<std::mutex> lk(m); --registered; }
+        cv.notify_all();
+    }
+    // out[u] = X[:,u] . v - (sub_vec ? sub_scale[0] * sub_vec[u] : 0) on stream `ps`; returns false if the caller should run its
+    // own sweep (it is the only solver around)
+    template <class T>
+    bool sweep(const DenseView<T>& X, const T* v, T* out, const T* sub_scale, const T* sub_vec, hipStream_t ps) {
+        const int64_t n = X.n, p = X.p;
+        std::unique_lock<std::mutex> lk(m);
+        if (registered <= 1) return false;
+        // join the generation that is collecting (a full one is launched by its leader before anybody can join again)
+        while (gen[cur % NGEN].count >= KMAX || gen[cur % NGEN].pending > 0) cv.wait(lk);
+        const uint64_t g = cur;
+        Gen& G = gen[g % NGEN];
+        const int slot = G.count++;
+        char* vb = vbuf[g % NGEN].reserve(size_t(KMAX) * size_t(n) * sizeof(T));
+        if (G.done_set) AHIP_CHECK(hipStreamWaitEvent(ps, G.done, 0)); // the previous user of this buffer has been read
+        AHIP_CHECK(hipMemcpyAsync(vb + size_t(slot) * size_t(n) * sizeof(T), v, size_t(n) * sizeof(T), hipMemcpyDeviceToDevice, ps));
+        AHIP_CHECK(hipEventRecord(G.in_ev[slot], ps));
+        if (slot == 0) {
+            // leader: give the others a short window, then launch for whoever has arrived
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(250);
+            cv.wait_until(lk, deadline, [&] { return G.count >= std::min(registered, KMAX); });
+            const int K = G.count;
+            G.K = K;
+            ++cur; // later arrivals collect in the next generation
+            T* ob = reinterpret_cast<T*>(obuf[g % NGEN].reserve(size_t(KMAX) * size_t(p) * sizeof(T)));
+            for (int k = 0; k < K; ++k) AHIP_CHECK(hipStreamWaitEvent(stream, G.in_ev[k], 0));
+            for (int k = 0; k < KMAX; ++k) // the previous readers of this output buffer are done
+                if (G.out_set[k]) { AHIP_CHECK(hipStreamWaitEvent(stream, G.out_ev[k], 0)); G.out_set[k] = false; }
+            MultiView<T> mv{X.X, n, p, X.ld, nullptr, int32_t(K), 0};
+            T* wk = reinterpret_cast<T*>(work.reserve(size_t(multi_sweep_work_elems<T>(MultiView<T>{X.X, n, p, X.ld, nullptr, KMAX, 0})) * sizeof(T)));
+            launch_multi_sweep<T>(mv, reinterpret_cast<const T*>(vb), ob, wk, stream);
+            AHIP_CHECK(hipEventRecord(G.done, stream));
+            G.done_set = true;
+            G.count = 0; // the slot bookkeeping of this generation index restarts when it comes round again
+            G.pending = K;
+            launched_upto = g + 1;
+            lk.unlock();
+            cv.notify_all();
+            lk.lock();
+        } else {
+            cv.notify_all(); // the leader may be waiting for the last arrival
+            cv.wait(lk, [&] { return launched_upto > g; });
+        }
+        const int K = G.K;
+        const T* ob = reinterpret_cast<const T*>(obuf[g % NGEN].p);
+        AHIP_CHECK(hipStreamWaitEvent(ps, G.done, 0));
+        launch_batch_pick<T>(ob, p, K, slot, sub_scale, sub_vec, out, ps);
+        AHIP_CHECK(hipEventRecord(G.out_ev[slot], ps));
+        G.out_set[slot] = true;
+        --G.pending;
+        lk.unlock();
+        cv.notify_all();
+        return true;
+    }
+};
+
+SweepBatcher* batcher_of(adelie_hip_design* d) {
+    adelie_hip_design* owner = d->batch_owner ? d->batch_owner : d;
+    std::lock_guard<std::mutex> lk(g_batcher_create_mutex);
+    if (!owner->batcher) owner->batcher = new SweepBatcher();
+    return static_cast<SweepBatcher*>(owner->batcher);
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // Solver: host mirror of StateGaussianNaive / StateGlmNaive + the device-resident working set
@@ -424,6 +542,7 @@ struct Solver {
     idx nv = 0; // screen values
     idx ns_dev = 0; // screen groups already mirrored on device
 
+    SweepBatcher* batcher = nullptr; // non-null while this solver is registered for sweep batching
     bool is_screen(idx i) const { return in_screen[i] != 0; }
     bool dense() const { return D->kind == 0; }
     // multi-response view (adelie_hip_design_create_multi): residual / weights live response-major on the device
@@ -459,6 +578,9 @@ struct Solver {
             launch_multi_sweep<T>(mv, v, out, d_work_sweep.reserve(size_t(multi_sweep_work_elems<T>(mv))), st);
             return;
         }
+        if (batcher && dense() && !cols && ncols == p && !square &&
+            batcher->template sweep<T>(D->dense<T>(), v, out, sub_scale, sub_vec, st))
+            return;
         T* work = d_work_sweep.reserve(size_t(sweep_work_elems(n, ncols)));
         if (dense()) launch_sweep<T>(D->dense<T>(), v, out, 0, ncols, cols, sub_scale, sub_vec, square, work, st);
         else launch_sweep_snp<T>(D->snp(), static_cast<const T*>(D->impute), v, out, 0, ncols, cols, sub_scale, sub_vec, square, work, st);
@@ -2660,10 +2782,24 @@ ResultBase* run(adelie_hip_design* X, const adelie_hip_grpnet_args* a) {
     }
     Stopwatch sw;
     sw.start();
+    struct BatchGuard { // registered for sweep batching exactly while the path runs
+        SweepBatcher* b = nullptr;
+        ~BatchGuard() { if (b) b->remove(); }
+    } guard;
+    if (g_sweep_batch && X->kind == 0 && a->glm_kind == ADELIE_HIP_GLM_GAUSSIAN) {
+        guard.b = batcher_of(X);
+        guard.b->add();
+        r->s.batcher = guard.b;
+    }
     try {
         r->s.solve();
     } catch (const std::exception& e) {
         r->s.error = e.what();
+    }
+    r->s.batcher = nullptr;
+    if (guard.b) {
+        guard.b->remove();
+        guard.b = nullptr;
     }
     try {
         r->s.finalize();
@@ -2681,12 +2817,15 @@ struct adelie_hip_result {
     ~adelie_hip_result() { delete r; }
 };
 
+void adelie_hip_internal_free_batcher(void* b) { delete static_cast<SweepBatcher*>(b); }
+
 extern "C" {
 
 int adelie_hip_set_config(const char* name, double value) {
     const std::string nm(name ? name : "");
     if (nm == "hessian_min") g_hessian_min = value;
     else if (nm == "dbeta_tol") g_dbeta_tol = value;
+    else if (nm == "sweep_batch") g_sweep_batch = value != 0.0 ? 1 : 0;
     else {
         set_last_error("adelie_core: unknown config name.");
         return 1;

@@ -8,6 +8,7 @@ rows at the end (RCCL over xGMI when the process group backend is ``nccl``, ``gl
 """
 from dataclasses import dataclass
 import logging
+import os
 
 import numpy as np
 import scipy.sparse
@@ -97,7 +98,9 @@ def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio
 
     ``n_concurrent``: folds solved at the same time on this rank's GPU, each from its own host thread on its own HIP stream
     (an alias handle of the resident design).  One path keeps most of the chip idle while its sequential block solves run,
-    so two or three folds interleave well; default 3 for device designs, 1 otherwise.  The result does not depend on it.
+    so two or three folds interleave well (default 3 for device designs, 1 otherwise); Gaussian folds on a dense design also
+    share their full-gradient sweeps — those that reach a sweep within a short window are answered by one pass over X — so
+    there the default is 8.  The result does not depend on it beyond the summation order of the shared sweeps (last bits).
     """
     if isinstance(X, np.ndarray):
         X = matrix.dense(X, method="naive", n_threads=n_threads)
@@ -125,7 +128,10 @@ def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio
         ranges = fold_ranges(n, n_folds)
         my_folds = [fold for fold in range(n_folds) if fold % world == rank]
         can_alias = hasattr(X, "alias") and hasattr(X, "_backend") and X._backend.has("design_alias")
-        nc = n_concurrent if n_concurrent is not None else (3 if can_alias else 1)
+        # dense Gaussian folds share their sweeps (SweepBatcher), so all of them may as well be in flight; otherwise three
+        # interleave well and more only contend
+        shares = getattr(X, "_kind", None) == "dense" and getattr(glm, "name", "") == "gaussian" and getattr(glm, "opt", False)
+        nc = n_concurrent if n_concurrent is not None else ((8 if shares else 3) if can_alias else 1)
         nc = max(1, min(int(nc), len(my_folds))) if can_alias else 1
 
         def one(Xa, fold):
@@ -151,9 +157,18 @@ def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio
                 finally:
                     handles.put(Xa)
 
-            with ThreadPoolExecutor(max_workers=nc) as pool:
-                for fold, row in pool.map(run, my_folds):
-                    cv_losses[fold] = row
+            # folds in flight share their full-gradient sweeps: the ones that reach a sweep within a short window are answered
+            # by one pass over X (solver.hip::SweepBatcher)
+            batch = X._backend.has("set_config") and os.environ.get("ADELIE_HIP_SWEEP_BATCH", "1") != "0"
+            if batch:
+                batch = X._backend.fn("set_config")(b"sweep_batch", 1.0) == 0
+            try:
+                with ThreadPoolExecutor(max_workers=nc) as pool:
+                    for fold, row in pool.map(run, my_folds):
+                        cv_losses[fold] = row
+            finally:
+                if batch:
+                    X._backend.fn("set_config")(b"sweep_batch", 0.0)
     finally:
         logger.setLevel(logger_level)
 

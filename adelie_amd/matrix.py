@@ -108,7 +108,7 @@ class _NativeMatrix:
         solves run concurrently from different threads.  Keeps this design alive."""
         handle = _abi.C.c_void_p()
         self._backend.check(self._backend.fn("design_alias")(self._handle, handle))
-        out = _wrap(self._backend, handle, self.dtype, self._n_threads)
+        out = _wrap(self._backend, handle, self.dtype, self._n_threads, kind=getattr(self, "_kind", None))
         out._alias_of = self
         return out
 
@@ -282,10 +282,11 @@ def _make_class(dtype):
     return _matrix
 
 
-def _wrap(backend, handle, dtype, n_threads, keep=None):
+def _wrap(backend, handle, dtype, n_threads, keep=None, kind=None):
     obj = _make_class(dtype)()
     obj._init_native(backend, handle, n_threads)
     obj._keep = keep
+    obj._kind = kind  # "dense" for dense designs (cv_grpnet batches their sweeps across concurrent folds)
     return obj
 
 
@@ -515,7 +516,7 @@ def dense(mat, *, method: str = "naive", copy: bool = False, n_threads: int = 1,
             raise RuntimeError("torch input must be F- or C-contiguous.")
         backend.check(backend.fn("design_adopt_dense_dev")(
             t.data_ptr(), n, p, _abi.dtype_code(dtype), order, t.device.index or 0, handle))
-        return _wrap(backend, handle, dtype, n_threads, keep=t)
+        return _wrap(backend, handle, dtype, n_threads, keep=t, kind="dense")
 
     mat = np.asarray(mat)
     if mat.ndim != 2:
@@ -530,7 +531,7 @@ def dense(mat, *, method: str = "naive", copy: bool = False, n_threads: int = 1,
         warnings.warn("Detected matrix to be C-contiguous. Performance may improve with F-contiguous matrix.")
     backend.check(backend.fn("design_create_dense")(
         mat.ctypes.data, mat.shape[0], mat.shape[1], code, order, device, handle))
-    return _wrap(backend, handle, dtype.type, n_threads)
+    return _wrap(backend, handle, dtype.type, n_threads, kind="dense")
 
 
 def snp_unphased(io, *, dtype=np.float64, n_threads: int = 1, device: int = 0):
@@ -623,7 +624,7 @@ def _derived(mat, rows, cols, centers, scales, n_threads):
     sc, _ = arr(scales, np.float64)
     handle = _abi.C.c_void_p()
     backend.check(backend.fn("design_create_derived")(mat._handle, r, nr, c, nc, ce, sc, handle))
-    return _wrap(backend, handle, mat.dtype, n_threads)
+    return _wrap(backend, handle, mat.dtype, n_threads, kind="dense")
 
 
 def standardize(mat, centers=None, scales=None, ddof: int = 0, *, n_threads: int = 1):

@@ -5,7 +5,7 @@ from bench import make_data
 X, y = make_data(100000, 10000, 0, torch.device("cuda", 0), torch.float64)
 Xd = ad.matrix.dense(X); glm = ad.glm.gaussian(y)
 ref = None
-for nc in [1, 2, 3, 4, 1]:
+for nc in [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 1]:
     t0 = time.perf_counter()
     res = ad.cv_grpnet(Xd, glm, n_folds=8, seed=0, n_concurrent=nc)
     el = time.perf_counter() - t0

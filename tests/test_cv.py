@@ -87,7 +87,7 @@ def test_cv_on_device_matches_oracle(hip, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["dense", "snp"])
-def test_cv_concurrent_folds_on_alias_handles(hip, kind):
+def test_cv_concurrent_folds_on_alias_handles(hip, kind, monkeypatch):
     """Folds solved concurrently from host threads on alias handles of the resident design (own HIP stream each) give
     bit-identical loss tables; an alias is the same matrix."""
     rng = np.random.RandomState(2)
@@ -104,9 +104,18 @@ def test_cv_concurrent_folds_on_alias_handles(hip, kind):
     glm = ad.glm.gaussian(y)
     kw = dict(n_folds=6, seed=5, lmda_path_size=20, tol=1e-10)
     a = ad.cv_grpnet(X, glm, n_concurrent=1, **kw)
+    monkeypatch.setenv("ADELIE_HIP_SWEEP_BATCH", "0")
     b = ad.cv_grpnet(X, glm, n_concurrent=3, **kw)
     c = ad.cv_grpnet(X, glm, **kw)  # default concurrency
     np.testing.assert_array_equal(a.losses, b.losses)
     np.testing.assert_array_equal(a.losses, c.losses)
     assert a.best_idx == b.best_idx
+    # with the folds' sweeps batched into shared passes over X (the default; dense designs only) the gradients are summed in
+    # another order: same table to rounding, and the same whoever happens to share a batch
+    monkeypatch.delenv("ADELIE_HIP_SWEEP_BATCH")
+    d = ad.cv_grpnet(X, glm, n_concurrent=3, **kw)
+    e = ad.cv_grpnet(X, glm, n_concurrent=4, **kw)
+    np.testing.assert_allclose(d.losses, a.losses, rtol=1e-7, atol=1e-9)
+    np.testing.assert_array_equal(d.losses, e.losses)
+    assert d.best_idx == a.best_idx
     del Xa

@@ -185,7 +185,7 @@ struct SweepBatcher {
     struct Gen {
         int count = 0, K = 0, pending = 0; // pending: members of the launched batch that have not enqueued their pick yet
         hipEvent_t done = nullptr, in_ev[KMAX], out_ev[KMAX];
-        bool out_set[KMAX], done_set = false;
+        bool out_set[KMAX], done_set = false, failed = false;
     };
     Gen gen[NGEN];
     uint64_t cur = 0, launched_upto = 0; // generation collecting arrivals; generations < launched_upto have been launched
@@ -242,16 +242,21 @@ struct SweepBatcher {
             cv.wait_until(lk, deadline, [&] { return G.count >= std::min(registered, KMAX); });
             const int K = G.count;
             G.K = K;
+            G.failed = false;
             ++cur; // later arrivals collect in the next generation
-            T* ob = reinterpret_cast<T*>(obuf[g % NGEN].reserve(size_t(KMAX) * size_t(p) * sizeof(T)));
-            for (int k = 0; k < K; ++k) AHIP_CHECK(hipStreamWaitEvent(stream, G.in_ev[k], 0));
-            for (int k = 0; k < KMAX; ++k) // the previous readers of this output buffer are done
-                if (G.out_set[k]) { AHIP_CHECK(hipStreamWaitEvent(stream, G.out_ev[k], 0)); G.out_set[k] = false; }
-            MultiView<T> mv{X.X, n, p, X.ld, nullptr, int32_t(K), 0};
-            T* wk = reinterpret_cast<T*>(work.reserve(size_t(multi_sweep_work_elems<T>(MultiView<T>{X.X, n, p, X.ld, nullptr, KMAX, 0})) * sizeof(T)));
-            launch_multi_sweep<T>(mv, reinterpret_cast<const T*>(vb), ob, wk, stream);
-            AHIP_CHECK(hipEventRecord(G.done, stream));
-            G.done_set = true;
+            try {
+                T* ob = reinterpret_cast<T*>(obuf[g % NGEN].reserve(size_t(KMAX) * size_t(p) * sizeof(T)));
+                for (int k = 0; k < K; ++k) AHIP_CHECK(hipStreamWaitEvent(stream, G.in_ev[k], 0));
+                for (int k = 0; k < KMAX; ++k) // the previous readers of this output buffer are done
+                    if (G.out_set[k]) { AHIP_CHECK(hipStreamWaitEvent(stream, G.out_ev[k], 0)); G.out_set[k] = false; }
+                MultiView<T> mv{X.X, n, p, X.ld, nullptr, int32_t(K), 0};
+                T* wk = reinterpret_cast<T*>(work.reserve(size_t(multi_sweep_work_elems<T>(MultiView<T>{X.X, n, p, X.ld, nullptr, KMAX, 0})) * sizeof(T)));
+                launch_multi_sweep<T>(mv, reinterpret_cast<const T*>(vb), ob, wk, stream);
+                AHIP_CHECK(hipEventRecord(G.done, stream));
+                G.done_set = true;
+            } catch (...) {
+                G.failed = true; // the members of this batch must not wait for a launch that did not happen
+            }
             G.count = 0; // the slot bookkeeping of this generation index restarts when it comes round again
             G.pending = K;
             launched_upto = g + 1;
@@ -263,6 +268,12 @@ struct SweepBatcher {
             cv.wait(lk, [&] { return launched_upto > g; });
         }
         const int K = G.K;
+        if (G.failed) {
+            --G.pending;
+            lk.unlock();
+            cv.notify_all();
+            throw core_error("adelie_hip: the shared sweep of a batch of concurrent solves failed to launch.");
+        }
         const T* ob = reinterpret_cast<const T*>(obuf[g % NGEN].p);
         AHIP_CHECK(hipStreamWaitEvent(ps, G.done, 0));
         launch_batch_pick<T>(ob, p, K, slot, sub_scale, sub_vec, out, ps);

@@ -2797,7 +2797,7 @@ ResultBase* run(adelie_hip_design* X, const adelie_hip_grpnet_args* a) {
         SweepBatcher* b = nullptr;
         ~BatchGuard() { if (b) b->remove(); }
     } guard;
-    if (g_sweep_batch && X->kind == 0 && a->glm_kind == ADELIE_HIP_GLM_GAUSSIAN) {
+    if (g_sweep_batch && X->kind == 0) {
         guard.b = batcher_of(X);
         guard.b->add();
         r->s.batcher = guard.b;

@@ -98,8 +98,8 @@ def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio
 
     ``n_concurrent``: folds solved at the same time on this rank's GPU, each from its own host thread on its own HIP stream
     (an alias handle of the resident design).  One path keeps most of the chip idle while its sequential block solves run,
-    so two or three folds interleave well (default 3 for device designs, 1 otherwise); Gaussian folds on a dense design also
-    share their full-gradient sweeps — those that reach a sweep within a short window are answered by one pass over X — so
+    so two or three folds interleave well (default 3 for device designs, 1 otherwise); single-response folds on a dense design
+    also share their full-gradient sweeps — those that reach a sweep within a short window are answered by one pass over X — so
     there the default is 8.  The result does not depend on it beyond the summation order of the shared sweeps (last bits).
     """
     if isinstance(X, np.ndarray):
@@ -130,7 +130,7 @@ def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio
         can_alias = hasattr(X, "alias") and hasattr(X, "_backend") and X._backend.has("design_alias")
         # dense Gaussian folds share their sweeps (SweepBatcher), so all of them may as well be in flight; otherwise three
         # interleave well and more only contend
-        shares = getattr(X, "_kind", None) == "dense" and getattr(glm, "name", "") == "gaussian" and getattr(glm, "opt", False)
+        shares = getattr(X, "_kind", None) == "dense" and not getattr(glm, "is_multi", False)
         nc = n_concurrent if n_concurrent is not None else ((8 if shares else 3) if can_alias else 1)
         nc = max(1, min(int(nc), len(my_folds))) if can_alias else 1
 

@@ -57,7 +57,7 @@ const char* adelie_hip_last_error(void);
 /* Number of visible HIP devices (0 if none / runtime unavailable). */
 int         adelie_hip_device_count(void);
 /* Mirrors adelie.configs.set_configs (py_configs.cpp:6-49): names "hessian_min", "dbeta_tol".
- * One name has no counterpart upstream: "sweep_batch" (0/1, default 0).  When 1, Gaussian solves that run concurrently (from
+ * One name has no counterpart upstream: "sweep_batch" (0/1, default 0).  When 1, solves that run concurrently (from
  * different host threads) on one dense matrix -- a design and its aliases, e.g. the folds of cv_grpnet -- share their
  * full-gradient sweeps: those that reach a sweep within a short window are answered by one pass over X.  The gradients are
  * then accumulated in another (fixed) order than the ordinary sweep's, i.e. they differ from it in the last bits. */

@@ -115,7 +115,7 @@ HIP_SYMBOLS = [
     "design_create_snp_calldata", "design_create_snp_bed", "design_alias", "design_create_multi", "design_create_derived", "design_impute", "design_destroy",
     "design_glm_path_losses", "design_rows", "design_cols", "design_dtype",
     "design_device", "design_stream",
-    "design_cmul", "design_ctmul", "design_bmul", "design_btmul", "design_mul", "design_cov",
+    "design_cmul", "design_ctmul", "design_bmul", "design_btmul", "design_mul", "design_mul_batch", "design_cov",
     "design_sq_mul", "design_sp_tmul",
     "grpnet_solve", "result_destroy", "result_size", "result_copy", "result_scalar", "result_error",
     "bench_sweep",
@@ -184,6 +184,7 @@ class Backend:
         sig("design_bmul", ci, [vp, i64, i64, vp, vp, vp])
         sig("design_btmul", ci, [vp, i64, i64, vp, vp])
         sig("design_mul", ci, [vp, vp, vp, vp])
+        sig("design_mul_batch", ci, [vp, vp, i64, vp])
         sig("design_cov", ci, [vp, i64, i64, vp, vp])
         sig("design_sq_mul", ci, [vp, vp, vp])
         sig("design_sp_tmul", ci, [vp, i64, vp, vp, vp, vp])

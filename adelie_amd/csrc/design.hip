@@ -134,6 +134,52 @@ void op_sweep(adelie_hip_design* d, int64_t c0, int64_t ncols, const T* v, const
     AHIP_CHECK(hipStreamSynchronize(s));
 }
 
+// L sweeps at once (diagnostic.gradients, reference adelie/diagnostic.py:320-387: one X.mul per residual vector): the
+// vectors go through the K-wide sweep eight at a time, so a dense design is streamed once per eight vectors.
+template <class T>
+void op_mul_batch(adelie_hip_design* d, const T* V, int64_t L, T* out) {
+    set_device(d);
+    hipStream_t s = d->stream;
+    const int64_t n = d->n, p = d->p;
+    constexpr int64_t KB = 8;
+    if (d->kind == 0) {
+        T* dv = scratch<T>(d->s_n1, size_t(KB) * size_t(n));
+        T* dout = scratch<T>(d->s_p1, size_t(KB) * size_t(p));
+        const DenseView<T> X = d->dense<T>();
+        T* work = scratch<T>(d->s_work, size_t(multi_sweep_work_elems<T>(MultiView<T>{X.X, n, p, X.ld, nullptr, int32_t(KB), 0})));
+        std::vector<T> hout(size_t(KB) * size_t(p));
+        for (int64_t l0 = 0; l0 < L; l0 += KB) {
+            const int64_t K = std::min(KB, L - l0);
+            AHIP_CHECK(hipMemcpyAsync(dv, V + l0 * n, size_t(K) * size_t(n) * sizeof(T), hipMemcpyHostToDevice, s));
+            if (K == 1) {
+                T* w1 = scratch<T>(d->s_work, std::max<size_t>(size_t(sweep_work_elems(n, p)), size_t(multi_sweep_work_elems<T>(MultiView<T>{X.X, n, p, X.ld, nullptr, int32_t(KB), 0}))));
+                launch_sweep<T>(X, dv, dout, 0, p, nullptr, nullptr, nullptr, false, w1, s);
+                AHIP_CHECK(hipMemcpyAsync(out + l0 * p, dout, size_t(p) * sizeof(T), hipMemcpyDeviceToHost, s));
+                AHIP_CHECK(hipStreamSynchronize(s));
+                continue;
+            }
+            launch_multi_sweep<T>(MultiView<T>{X.X, n, p, X.ld, nullptr, int32_t(K), 0}, dv, dout, work, s);
+            AHIP_CHECK(hipMemcpyAsync(hout.data(), dout, size_t(K) * size_t(p) * sizeof(T), hipMemcpyDeviceToHost, s));
+            AHIP_CHECK(hipStreamSynchronize(s));
+            for (int64_t l = 0; l < K; ++l) {
+                T* o = out + (l0 + l) * p;
+                for (int64_t u = 0; u < p; ++u) o[u] = hout[size_t(u) * size_t(K) + size_t(l)];
+            }
+        }
+    } else {
+        T* dv = scratch<T>(d->s_n1, n);
+        T* dout = scratch<T>(d->s_p1, p);
+        T* work = scratch<T>(d->s_work, sweep_work_elems(n, p));
+        for (int64_t l = 0; l < L; ++l) {
+            AHIP_CHECK(hipMemcpyAsync(dv, V + l * n, size_t(n) * sizeof(T), hipMemcpyHostToDevice, s));
+            launch_sweep_snp<T>(d->snp(), static_cast<const T*>(d->impute), dv, dout, 0, p, nullptr, nullptr, nullptr, false,
+                                work, s);
+            AHIP_CHECK(hipMemcpyAsync(out + l * p, dout, size_t(p) * sizeof(T), hipMemcpyDeviceToHost, s));
+            AHIP_CHECK(hipStreamSynchronize(s));
+        }
+    }
+}
+
 template <class T>
 void op_axpy(adelie_hip_design* d, int64_t j, int64_t q, const T* coef, T* out) {
     set_device(d);
@@ -631,6 +677,14 @@ int adelie_hip_design_mul(adelie_hip_design* d, const void* v, const void* weigh
     no_view(d);
     DTYPE_DISPATCH(d, op_sweep<T>(d, 0, d->p, (const T*)v, (const T*)weights, (T*)out, false),
                    op_sweep<T>(d, 0, d->p, (const T*)v, (const T*)weights, (T*)out, false))
+    ABI_CATCH
+}
+int adelie_hip_design_mul_batch(adelie_hip_design* d, const void* V, int64_t L, void* out) {
+    ABI_TRY
+    no_view(d);
+    if (L < 0 || (L > 0 && (!V || !out))) throw make_core_error("mul_batch() is given inconsistent inputs!");
+    if (L == 0) return 0;
+    DTYPE_DISPATCH(d, op_mul_batch<T>(d, (const T*)V, L, (T*)out), op_mul_batch<T>(d, (const T*)V, L, (T*)out))
     ABI_CATCH
 }
 int adelie_hip_design_cov(adelie_hip_design* d, int64_t j, int64_t q, const void* sqrt_weights, void* out) {

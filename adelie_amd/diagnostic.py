@@ -1,7 +1,9 @@
-"""Post-fit helpers used by ``cv_grpnet`` — mirrors the parts of ``adelie.diagnostic`` on the hot path:
-``predict`` (reference ``adelie/diagnostic.py:30-121``), ``coefficient`` (``:577-646``) and ``objective``
-(``:124-278``, the parity fall-back metric of the reference's own tests, ``tests/test_solver.py:447-466``).
-Plotting and the other diagnostics are out of scope."""
+"""Post-fit helpers — mirrors the numeric parts of ``adelie.diagnostic``: ``predict`` (reference
+``adelie/diagnostic.py:30-121``), ``coefficient`` (``:577-646``), ``objective`` (``:124-278``, the parity fall-back
+metric of the reference's own tests, ``tests/test_solver.py:447-466``) and the KKT diagnostics ``residuals`` /
+``gradients`` / ``gradient_norms`` / ``gradient_scores`` / ``diagnostic(state)`` (``:279-574,1248-1415``): the L
+gradient sweeps ``X^T r_l`` go through one ABI call that streams the resident design once per eight vectors.
+Plotting is out of scope."""
 import logging
 
 import numpy as np
@@ -99,3 +101,106 @@ def objective(X, glm, betas, intercepts, lmdas, *, groups=None, alpha: float = 1
             pen += w * (alpha * nrm + 0.5 * (1 - alpha) * nrm ** 2)
         objs += np.asarray(lmdas) * pen
     return objs
+
+
+def residuals(glm, etas):
+    """``-grad loss(eta_l)`` for every row of ``etas`` (reference ``diagnostic.py:279-317``)."""
+    etas = np.asarray(etas)
+    resids = np.empty(etas.shape, dtype=glm.dtype)
+    for eta, resid in zip(etas, resids):
+        glm.gradient(eta, resid)
+    return resids
+
+
+def gradients(X, resids, *, n_threads: int = 1):
+    """``X^T r_l`` for every residual ``r_l``: (L, n) -> (L, p); multi-response (L, n, K) -> (L, p, K), i.e.
+    ``(X (x) I_K)^T vec(r_l^T)`` (reference ``diagnostic.py:320-387``, which calls ``X.mul`` once per residual and, for
+    the multi-response case, once per view column group).  Here all the vectors of a call go to the device together
+    (``adelie_hip_design_mul_batch``) and a dense design is read once per eight of them."""
+    resids = np.asarray(resids)
+    if isinstance(X, np.ndarray):
+        X = matrix.dense(X, method="naive", n_threads=n_threads)
+    if not hasattr(X, "mul_batch"):
+        raise NotImplementedError("adelie_amd: gradients() needs a device-resident design (matrix.dense / snp_unphased).")
+    dtype = X.dtype
+    if resids.ndim == 3:
+        L, n, K = resids.shape
+        V = np.ascontiguousarray(np.transpose(resids, (0, 2, 1)), dtype=dtype).reshape(L * K, n)
+        out = X.mul_batch(V).reshape(L, K, X.cols())
+        return np.ascontiguousarray(np.transpose(out, (0, 2, 1)))
+    return X.mul_batch(np.ascontiguousarray(resids, dtype=dtype))
+
+
+def gradient_norms(grads, betas, duals, lmdas, *, constraints=None, groups=None, alpha: float = 1, penalty=None):
+    """Group-wise norms ``|| gamma_g - lmda (1-alpha) w_g beta_g ||_2`` of the penalised gradient, (L, G)
+    (reference ``diagnostic.py:389-520``).  Constraints are outside this package's scope: pass ``None``."""
+    if constraints is not None and any(c is not None for c in constraints):
+        raise NotImplementedError("adelie_amd: per-group constraints are outside the grpnet hot path (pass None).")
+    grads = np.asarray(grads)
+    lmdas = np.asarray(lmdas)
+    if grads.ndim == 3:
+        p, K = grads.shape[1:]
+        groups = np.arange(p) if groups is None else np.asarray(groups)
+        groups = groups * K
+        total = p * K
+    else:
+        total = grads.shape[-1]
+        groups = np.arange(total) if groups is None else np.asarray(groups)
+    bounds = np.concatenate([groups, [total]]).astype(int)
+    group_sizes = bounds[1:] - bounds[:-1]
+    if penalty is None:
+        penalty = np.sqrt(group_sizes)
+    pen = np.repeat(np.asarray(penalty), group_sizes)
+    L = grads.shape[0]
+    B = betas if isinstance(betas, csr_matrix) else csr_matrix(np.atleast_2d(betas))
+    G = grads.reshape(L, -1) - B.multiply(lmdas[:, None] * (1 - alpha) * pen[None])
+    G = np.asarray(G)
+    sq = np.add.reduceat(np.square(G), bounds[:-1], axis=1) if len(groups) else np.zeros((L, 0), dtype=G.dtype)
+    return np.sqrt(sq)
+
+
+def gradient_scores(grad_norms, lmdas, *, alpha: float = 1, penalty=None):
+    """``h_g / (alpha w_g)`` where ``alpha w_g > 0`` and ``lmda`` elsewhere (reference ``diagnostic.py:523-574``): a
+    solution satisfies the KKT conditions when every score is at most its ``lmda``."""
+    grad_norms = np.asarray(grad_norms)
+    lmdas = np.asarray(lmdas)
+    denom = alpha * np.asarray(penalty, dtype=grad_norms.dtype)
+    pos = denom > 0
+    scores = np.empty_like(grad_norms)
+    scores[:, pos] = grad_norms[:, pos] / denom[pos][None]
+    scores[:, ~pos] = lmdas[:, None]
+    return scores
+
+
+class DiagnosticNaive:
+    """The quantities ``adelie.diagnostic.DiagnosticNaive`` computes for a solved naive state (reference
+    ``diagnostic.py:1248-1322``): linear predictions, residuals, gradients, gradient norms and scores along the path.
+    The plotting methods of the reference class are not provided."""
+
+    def __init__(self, state):
+        self.state = state
+        self.betas = state.betas
+        self.duals = getattr(state, "duals", None)
+        glm = state._glm
+        self._is_multi = bool(glm.is_multi)
+        self._n_classes = glm.y.shape[-1]
+        groups, penalty = np.asarray(state.groups), np.asarray(state.penalty)
+        if self._is_multi:  # drop the intercept columns of the view; groups are counted in features (diagnostic.py:1263-1270)
+            p_begin = int(state.multi_intercept) * self._n_classes
+            groups = groups[p_begin:] // self._n_classes - int(state.multi_intercept)
+            penalty = penalty[p_begin:]
+        self._args = {"groups": groups, "penalty": penalty, "constraints": None}
+        X = getattr(state, "_X_raw", state._X)
+        self.linear_preds = predict(X=X, betas=self.betas, intercepts=state.intercepts, offsets=state._offsets,
+                                    n_threads=state.n_threads)
+        self.residuals = residuals(glm=glm, etas=self.linear_preds)
+        self.gradients = gradients(X=X, resids=self.residuals, n_threads=state.n_threads)
+        self.gradient_norms = gradient_norms(grads=self.gradients, betas=self.betas, duals=self.duals, lmdas=state.lmdas,
+                                             groups=groups, alpha=state.alpha, penalty=penalty)
+        self.gradient_scores = gradient_scores(grad_norms=self.gradient_norms, lmdas=state.lmdas, alpha=state.alpha,
+                                               penalty=penalty)
+
+
+def diagnostic(state):
+    """Diagnostic object of a solved state (reference ``diagnostic.py:1393-1415``; only naive states exist here)."""
+    return DiagnosticNaive(state)

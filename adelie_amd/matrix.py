@@ -197,6 +197,15 @@ class _NativeMatrix:
         self._backend.check(self._backend.fn("design_mul")(self._handle, v.ctypes.data, w.ctypes.data, o.ctypes.data))
         self._writeback(o, out)
 
+    def mul_batch(self, V):
+        """``V @ X`` for an (L, n) array of vectors in one call (used by :func:`adelie_amd.diagnostic.gradients`; the
+        reference loops ``X.mul`` per vector, ``diagnostic.py:377-386``)."""
+        V = np.ascontiguousarray(V, dtype=self.dtype)
+        self._chk(V.ndim == 2 and V.shape[1] == self._rows, "mul_batch() is given inconsistent inputs!")
+        out = np.empty((V.shape[0], self._cols), dtype=self.dtype)
+        self._backend.check(self._backend.fn("design_mul_batch")(self._handle, V.ctypes.data, V.shape[0], out.ctypes.data))
+        return out
+
     def cov(self, j, q, sqrt_weights, out):
         self._chk(0 <= j <= self._cols - q and len(sqrt_weights) == self._rows and out.shape == (q, q),
                   "cov() is given inconsistent inputs!")

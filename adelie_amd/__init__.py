@@ -14,6 +14,10 @@ from . import diagnostic
 from . import cv
 from . import data
 from . import io
+try:  # the estimator wrapper needs scikit-learn's base classes; everything else does not
+    from . import sklearn
+except ImportError:  # pragma: no cover
+    pass
 from .configs import set_configs
 from .cv import cv_grpnet
 from .solver import grpnet

@@ -69,6 +69,38 @@ void create_dense_t(adelie_hip_design* d, const void* src, bool src_on_device, i
     AHIP_CHECK(hipStreamSynchronize(d->stream));
 }
 
+template <class T>
+void create_sparse_t(adelie_hip_design* d, const int64_t* indptr, const int32_t* indices, const void* values) {
+    constexpr int64_t kAlign = 32;
+    const int64_t n = d->n, p = d->p;
+    const int64_t nnz = indptr[p];
+    const int64_t ld = ((n + kAlign - 1) / kAlign) * kAlign;
+    T* X = nullptr;
+    AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&X), size_t(ld) * size_t(p) * sizeof(T)));
+    d->X = X;
+    d->ld = ld;
+    d->owned = true;
+    AHIP_CHECK(hipMemsetAsync(X, 0, size_t(ld) * size_t(p) * sizeof(T), d->stream));
+    int64_t* dptr = nullptr;
+    int32_t* didx = nullptr;
+    T* dval = nullptr;
+    auto release = [&] { (void)hipFree(dptr); (void)hipFree(didx); (void)hipFree(dval); };
+    try {
+        AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dptr), size_t(p + 1) * sizeof(int64_t)));
+        AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&didx), size_t(std::max<int64_t>(nnz, 1)) * sizeof(int32_t)));
+        AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dval), size_t(std::max<int64_t>(nnz, 1)) * sizeof(T)));
+        AHIP_CHECK(hipMemcpyAsync(dptr, indptr, size_t(p + 1) * sizeof(int64_t), hipMemcpyHostToDevice, d->stream));
+        AHIP_CHECK(hipMemcpyAsync(didx, indices, size_t(nnz) * sizeof(int32_t), hipMemcpyHostToDevice, d->stream));
+        AHIP_CHECK(hipMemcpyAsync(dval, values, size_t(nnz) * sizeof(T), hipMemcpyHostToDevice, d->stream));
+        launch_csc_scatter<T>(dptr, didx, dval, n, p, X, ld, d->stream);
+        AHIP_CHECK(hipStreamSynchronize(d->stream));
+    } catch (...) {
+        release();
+        throw;
+    }
+    release();
+}
+
 adelie_hip_design* new_design(int64_t n, int64_t p, int dtype, int device) {
     if (n <= 0 || p <= 0) throw make_core_error("matrix must have positive dimensions.");
     if (dtype != ADELIE_HIP_F32 && dtype != ADELIE_HIP_F64) throw make_core_error("dtype must be F32 or F64.");
@@ -399,6 +431,30 @@ int adelie_hip_design_create_dense(const void* host, int64_t n, int64_t p, int d
     try {
         if (dtype == ADELIE_HIP_F64) create_dense_t<double>(d, host, false, order);
         else create_dense_t<float>(d, host, false, order);
+    } catch (...) {
+        adelie_hip_design_destroy(d);
+        throw;
+    }
+    *out = d;
+    ABI_CATCH
+}
+
+int adelie_hip_design_create_sparse(const int64_t* indptr, const int32_t* indices, const void* values, int64_t n, int64_t p,
+                                    int dtype, int device, adelie_hip_design** out) {
+    ABI_TRY
+    if (!indptr || !out) throw make_core_error("null argument.");
+    if (n <= 0 || p <= 0) throw make_core_error("matrix must have positive dimensions.");
+    if (indptr[0] != 0) throw make_core_error("sparse(): indptr must start at 0.");
+    for (int64_t j = 0; j < p; ++j)
+        if (indptr[j + 1] < indptr[j]) throw make_core_error("sparse(): indptr must be non-decreasing.");
+    const int64_t nnz = indptr[p];
+    if (nnz > 0 && (!indices || !values)) throw make_core_error("null argument.");
+    for (int64_t k = 0; k < nnz; ++k)
+        if (indices[k] < 0 || indices[k] >= n) throw make_core_error("sparse(): row index out of range.");
+    adelie_hip_design* d = new_design(n, p, dtype, device);
+    try {
+        if (dtype == ADELIE_HIP_F64) create_sparse_t<double>(d, indptr, indices, values);
+        else create_sparse_t<float>(d, indptr, indices, values);
     } catch (...) {
         adelie_hip_design_destroy(d);
         throw;

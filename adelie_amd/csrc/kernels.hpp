@@ -343,6 +343,10 @@ template <class T> void launch_copy2d(const T* src, int64_t lds, T* dst, int64_t
 template <class T> void launch_diag_vars(const T* C, int64_t ldc, int32_t pos0, int32_t cnt, T* vars, hipStream_t s);
 // transpose row-major (n,p) into column-major with leading dimension ld
 template <class T> void launch_transpose(const T* src, int64_t n, int64_t p, T* dst, int64_t ld, hipStream_t s);
+// dst (zeroed, column-major, leading dimension ld) += the entries of a CSC matrix
+template <class T>
+void launch_csc_scatter(const int64_t* indptr, const int32_t* indices, const T* values, int64_t n, int64_t p, T* dst,
+                        int64_t ld, hipStream_t s);
 // new dense matrix from a resident design: optional row / column gather, optional per-column centre and scale
 template <class T>
 void launch_derive_dense(const DenseView<T>& X, int64_t nout, int64_t pout, const int64_t* rows, const int64_t* cols,

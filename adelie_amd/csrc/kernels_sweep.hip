@@ -601,6 +601,30 @@ void launch_derive_dense_snp(const SnpView& X, const T* impute, int64_t nout, in
     }
 }
 
+// CSC -> resident dense columns (matrix.sparse; reference matrix_naive_sparse.ipp keeps the CSC arrays and walks them per
+// operation -- with 288 GB of HBM the design is expanded once and every operation is the dense streaming kernel).
+// One workgroup per column; duplicate (row, col) entries add up, as they do in the reference's sparse dot products.
+template <class T>
+__global__ void csc_scatter_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                   const T* __restrict__ values, int64_t n, T* __restrict__ dst, int64_t ld) {
+    const int64_t c = blockIdx.x;
+    const int64_t b = indptr[c], e = indptr[c + 1];
+    T* col = dst + c * ld;
+    for (int64_t k = b + threadIdx.x; k < e; k += blockDim.x) {
+        const int64_t i = indices[k];
+        if (i >= 0 && i < n) atomicAdd(col + i, values[k]);
+    }
+}
+template <class T>
+void launch_csc_scatter(const int64_t* indptr, const int32_t* indices, const T* values, int64_t n, int64_t p, T* dst,
+                        int64_t ld, hipStream_t s) {
+    for (int64_t c0 = 0; c0 < p; c0 += 1 << 30) {
+        const int64_t pc = std::min<int64_t>(int64_t(1) << 30, p - c0);
+        hipLaunchKernelGGL((csc_scatter_kernel<T>), dim3((unsigned)pc), dim3(256), 0, s, indptr + c0, indices, values, n,
+                           dst + c0 * ld, ld);
+    }
+}
+
 template <class T>
 void launch_transpose(const T* src, int64_t n, int64_t p, T* dst, int64_t ld, hipStream_t s) {
     if (n <= 0 || p <= 0) return;
@@ -656,6 +680,7 @@ template void launch_snp_impute<float>(const uint8_t*, int64_t, int64_t, int64_t
                                      const T*, T, T*, hipStream_t);                                                    \
     template void launch_copy2d<T>(const T*, int64_t, T*, int64_t, int64_t, int64_t, hipStream_t);                     \
     template void launch_diag_vars<T>(const T*, int64_t, int32_t, int32_t, T*, hipStream_t);                           \
+    template void launch_csc_scatter<T>(const int64_t*, const int32_t*, const T*, int64_t, int64_t, T*, int64_t, hipStream_t);\
     template void launch_transpose<T>(const T*, int64_t, int64_t, T*, int64_t, hipStream_t);                            \
     template void launch_derive_dense<T>(const DenseView<T>&, int64_t, int64_t, const int64_t*, const int64_t*, const T*, \
                                          const T*, T*, int64_t, hipStream_t);                                          \

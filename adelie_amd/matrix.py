@@ -543,6 +543,40 @@ def dense(mat, *, method: str = "naive", copy: bool = False, n_threads: int = 1,
     return _wrap(backend, handle, dtype.type, n_threads, kind="dense")
 
 
+def sparse(mat, *, method: str = "naive", copy: bool = False, n_threads: int = 1, device: int = 0):
+    """Creates a design from a scipy sparse matrix (reference ``adelie.matrix.sparse``, ``matrix.py:1301-1385``).
+
+    The reference keeps the CSC arrays and walks them per operation (``matrix_naive_sparse.ipp``); here the entries are
+    scattered once into a dense column-major array in HBM (``adelie_hip_design_create_sparse``) and the design then
+    behaves as ``matrix.dense`` — same results up to the summation order of the dot products.  ``n * p`` values must fit
+    in device memory (288 GB per MI355X)."""
+    if not (isinstance(mat, csr_matrix) or isinstance(mat, csc_matrix)):
+        raise TypeError("mat must be scipy.sparse.csr_matrix or scipy.sparse.csc_matrix.")
+    if method != "naive":
+        raise NotImplementedError("adelie_amd.matrix.sparse: only method='naive' is on the grpnet hot path.")
+    if n_threads < 1:
+        raise RuntimeError("adelie_core: n_threads must be >= 1.")
+    if isinstance(mat, csr_matrix):
+        warnings.warn("Converting to CSC format.")
+        mat = mat.tocsc(copy=True)
+    elif copy:
+        mat = mat.copy()
+    mat.prune()
+    mat.sort_indices()
+    dtype = np.dtype(mat.dtype).type
+    if dtype not in (np.float32, np.float64):
+        raise RuntimeError("mat must have dtype float32 or float64.")
+    n, p = mat.shape
+    indptr = np.ascontiguousarray(mat.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(mat.indices, dtype=np.int32)
+    values = np.ascontiguousarray(mat.data, dtype=dtype)
+    backend = _abi.hip_backend()
+    handle = _abi.C.c_void_p()
+    backend.check(backend.fn("design_create_sparse")(
+        indptr.ctypes.data, indices.ctypes.data, values.ctypes.data, n, p, _abi.dtype_code(dtype), device, handle))
+    return _wrap(backend, handle, dtype, n_threads, kind="dense")
+
+
 def snp_unphased(io, *, dtype=np.float64, n_threads: int = 1, device: int = 0):
     """Creates an SNP-unphased design resident on an MI355X as dense 2-bit calls
     (reference ``adelie.matrix.snp_unphased``, ``matrix.py:1245-1298``).

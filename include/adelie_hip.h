@@ -72,6 +72,11 @@ int         adelie_hip_set_config(const char* name, double value);
 /* Copy an (n,p) host matrix to device `device`. */
 int adelie_hip_design_create_dense(const void* host, int64_t n, int64_t p, int dtype, int order,
                                    int device, adelie_hip_design** out);
+/* Replaces MatrixNaiveSparse{32,64}F (adelie/matrix.py:1301-1385, matrix_naive_sparse.ipp): a CSC matrix (indptr p+1
+ * int64, row indices int32, values of `dtype`; host pointers) becomes a resident dense design -- the entries are
+ * scattered into zeroed column-major HBM once, every later operation is the dense kernel.  Duplicate entries add up. */
+int adelie_hip_design_create_sparse(const int64_t* indptr, const int32_t* indices, const void* values, int64_t n, int64_t p,
+                                    int dtype, int device, adelie_hip_design** out);
 /* Adopt an (n,p) matrix that is ALREADY in device memory (e.g. a torch tensor's data_ptr);
  * not owned, must outlive the design. */
 int adelie_hip_design_adopt_dense_dev(const void* dev_ptr, int64_t n, int64_t p, int dtype, int order,

@@ -189,3 +189,43 @@ def test_standardize_and_subset_derived_designs(hip, oracle, kind):
     a = ad.grpnet(S, ad.glm.gaussian(y), tol=1e-12, early_exit=False, lmda_path_size=15)
     b = ad.grpnet(oracle.dense(Xs), ad.glm.gaussian(y), tol=1e-12, early_exit=False, lmda_path_size=15)
     assert a.error == "" and np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-9
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("fmt", ["csc", "csr"])
+def test_sparse_design_runs_the_reference_check_list(hip, dtype, fmt):
+    """matrix.sparse (reference matrix.py:1301-1385): the CSC entries are expanded on the device; every MatrixNaiveBase
+    operation then has to agree with the dense matrix, as the reference's tests/test_matrix.py::test_naive_sparse asks."""
+    import scipy.sparse as sp
+    import warnings
+
+    rng = np.random.RandomState(4)
+    n, p = 211, 37
+    D = (rng.normal(size=(n, p)) * (rng.uniform(size=(n, p)) < 0.15)).astype(dtype)
+    D[:, 5] = 0  # an empty column
+    M = sp.csc_matrix(D) if fmt == "csc" else sp.csr_matrix(D)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        X = ad.matrix.sparse(M)
+    assert (X.rows(), X.cols()) == (n, p)
+    run_naive(X, np.asfortranarray(D), dtype)
+    with pytest.raises(TypeError, match="scipy.sparse"):
+        ad.matrix.sparse(D)
+
+
+def test_sparse_design_adds_duplicate_entries_and_solves_like_dense(hip):
+    import scipy.sparse as sp
+
+    rng = np.random.RandomState(5)
+    n, p = 300, 60
+    D = rng.normal(size=(n, p)) * (rng.uniform(size=(n, p)) < 0.2)
+    y = D[:, :3] @ np.array([1.0, -2.0, 0.5]) + 0.1 * rng.normal(size=n)
+    s1 = ad.grpnet(ad.matrix.sparse(sp.csc_matrix(D)), ad.glm.gaussian(y=y), progress_bar=False)
+    s2 = ad.grpnet(ad.matrix.dense(np.asfortranarray(D)), ad.glm.gaussian(y=y), progress_bar=False)
+    assert np.array_equal(s1.lmdas, s2.lmdas)
+    assert np.array_equal(s1.betas.toarray(), s2.betas.toarray())   # same resident values, same kernels: identical
+    # a non-canonical CSC (the same cell stored twice): the entries add up, as in the reference's sparse dot products
+    M = sp.csc_matrix((np.array([1.0, 2.0, 5.0]), np.array([0, 0, 2]), np.array([0, 2, 3])), shape=(3, 2))
+    out = np.empty(2)
+    ad.matrix.sparse(M).mul(np.ones(3), np.array([1.0, 10.0, 100.0]), out)
+    assert np.array_equal(out, [3.0, 500.0])

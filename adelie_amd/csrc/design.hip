@@ -409,6 +409,33 @@ void derive_t(adelie_hip_design* src, adelie_hip_design* d, const int64_t* rows,
     else launch_derive_dense_snp<T>(src->snp(), static_cast<const T*>(src->impute), nout, pout, drows, dcols, dc, ds, X, ld, s);
     AHIP_CHECK(hipStreamSynchronize(s));
 }
+// concatenation of resident designs along the columns (axis 1) or the rows (axis 0): every source is copied (SNP sources
+// decoded) into its slice of a new dense array
+template <class T>
+void concat_t(adelie_hip_design* const* srcs, int64_t k, int axis, adelie_hip_design* d) {
+    constexpr int64_t kAlign = 32;
+    const int64_t nout = d->n, pout = d->p;
+    const int64_t ld = ((nout + kAlign - 1) / kAlign) * kAlign;
+    T* X = nullptr;
+    AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&X), size_t(ld) * size_t(pout) * sizeof(T)));
+    d->X = X;
+    d->ld = ld;
+    d->owned = true;
+    d->kind = 0;
+    hipStream_t s = d->stream;
+    AHIP_CHECK(hipMemsetAsync(X, 0, size_t(ld) * size_t(pout) * sizeof(T), s));
+    int64_t off = 0;
+    for (int64_t m = 0; m < k; ++m) {
+        adelie_hip_design* src = srcs[m];
+        AHIP_CHECK(hipStreamSynchronize(src->stream));
+        T* dst = axis == 1 ? X + off * ld : X + off;
+        if (src->kind == 0) launch_derive_dense<T>(src->dense<T>(), src->n, src->p, nullptr, nullptr, nullptr, nullptr, dst, ld, s);
+        else launch_derive_dense_snp<T>(src->snp(), static_cast<const T*>(src->impute), src->n, src->p, nullptr, nullptr,
+                                        nullptr, nullptr, dst, ld, s);
+        off += axis == 1 ? src->p : src->n;
+    }
+    AHIP_CHECK(hipStreamSynchronize(s));
+}
 } // namespace
 
 void adelie_hip_internal_free_batcher(void* b); // solver.hip
@@ -652,6 +679,37 @@ int adelie_hip_design_create_derived(adelie_hip_design* src, const int64_t* rows
     try {
         DTYPE_DISPATCH(src, derive_t<T>(src, d, rows, n_rows, cols, n_cols, centers, scales),
                        derive_t<T>(src, d, rows, n_rows, cols, n_cols, centers, scales))
+    } catch (...) {
+        adelie_hip_design_destroy(d);
+        throw;
+    }
+    *out = d;
+    ABI_CATCH
+}
+
+int adelie_hip_design_create_concat(adelie_hip_design* const* srcs, int64_t k, int axis, adelie_hip_design** out) {
+    ABI_TRY
+    if (!srcs || !out || k <= 0) throw make_core_error("null argument.");
+    if (axis != 0 && axis != 1) throw make_core_error("axis must be 0 or 1.");
+    int64_t n = 0, p = 0;
+    for (int64_t m = 0; m < k; ++m) {
+        if (!srcs[m]) throw make_core_error("null argument.");
+        no_view(srcs[m]);
+        if (srcs[m]->dtype != srcs[0]->dtype || srcs[m]->device != srcs[0]->device)
+            throw make_core_error("concatenate(): the matrices must share dtype and device.");
+        if (axis == 1) {
+            if (srcs[m]->n != srcs[0]->n) throw make_core_error("All matrices must have the same number of rows.");
+            p += srcs[m]->p;
+            n = srcs[0]->n;
+        } else {
+            if (srcs[m]->p != srcs[0]->p) throw make_core_error("All matrices must have the same number of columns.");
+            n += srcs[m]->n;
+            p = srcs[0]->p;
+        }
+    }
+    adelie_hip_design* d = new_design(n, p, srcs[0]->dtype, srcs[0]->device);
+    try {
+        DTYPE_DISPATCH(srcs[0], concat_t<T>(srcs, k, axis, d), concat_t<T>(srcs, k, axis, d))
     } catch (...) {
         adelie_hip_design_destroy(d);
         throw;

@@ -478,14 +478,36 @@ class _OnesKron:
 
 
 def concatenate(mats, *, axis: int = 0, n_threads: int = 1):
-    """Reference ``adelie.matrix.concatenate``.  The device path offers exactly the combination the multi-response
-    solver uses (``state.py:1110-1120``): ``[kronecker_eye(ones((n, 1)), K), kronecker_eye(X, K)]`` along ``axis=1``."""
+    """Reference ``adelie.matrix.concatenate`` (``matrix.py:214-310``).
+
+    * ``[kronecker_eye(ones((n, 1)), K), kronecker_eye(X, K)]`` along ``axis=1`` — the combination the multi-response
+      solver builds (``state.py:1110-1120``) — becomes the multi-response view of ``X`` (nothing materialised);
+    * resident designs (dense, SNP, sparse, derived; ndarrays are uploaded first) are copied side by side into one new
+      dense design on the device (``adelie_hip_design_create_concat``); the reference keeps a list of views and dispatches
+      every operation to the pieces (``matrix_naive_concatenate.ipp``)."""
+    mats = list(mats)
     if (axis == 1 and len(mats) == 2 and isinstance(mats[0], _OnesKron) and isinstance(mats[1], _MultiView)
             and mats[1]._icpt == 0 and mats[0].K == mats[1]._K and mats[0].n == mats[1]._base.rows()):
         return _multi_view(mats[1]._base, mats[1]._K, True)
-    raise NotImplementedError(
-        "adelie_amd.matrix.concatenate: only [kronecker_eye(ones((n,1)), K), kronecker_eye(X, K)], axis=1 is on the "
-        "device path.")
+    if n_threads < 1:
+        raise RuntimeError("adelie_core: n_threads must be >= 1.")
+    if axis not in (0, 1):
+        raise ValueError("axis must be 0 or 1.")
+    if len(mats) == 0:
+        raise RuntimeError("mats must be non-empty.")
+    mats = [dense(m, n_threads=n_threads) if isinstance(m, np.ndarray) else m for m in mats]
+    for m in mats:
+        if isinstance(m, (_MultiView, _OnesKron)) or not isinstance(m, _NativeMatrix):
+            raise NotImplementedError(
+                "adelie_amd.matrix.concatenate: the pieces must be resident designs (dense / snp / sparse / derived) or "
+                "the multi-response pair [kronecker_eye(ones((n,1)), K), kronecker_eye(X, K)].")
+    if len({np.dtype(m.dtype) for m in mats}) != 1:
+        raise RuntimeError("All matrices must have the same dtype.")
+    backend = mats[0]._backend
+    handles = (_abi.C.c_void_p * len(mats))(*[m._handle for m in mats])
+    handle = _abi.C.c_void_p()
+    backend.check(backend.fn("design_create_concat")(handles, len(mats), int(axis), handle))
+    return _wrap(backend, handle, mats[0].dtype, n_threads, kind="dense")
 
 
 def dense(mat, *, method: str = "naive", copy: bool = False, n_threads: int = 1, device: int = 0):

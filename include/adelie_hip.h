@@ -109,6 +109,10 @@ int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out);
  * materialised in HBM by one kernel (matrix views).  The result does not reference `src`. */
 int adelie_hip_design_create_derived(adelie_hip_design* src, const int64_t* rows, int64_t n_rows, const int64_t* cols,
                                      int64_t n_cols, const double* centers, const double* scales, adelie_hip_design** out);
+/* Replaces MatrixNaiveCConcatenate / MatrixNaiveRConcatenate (adelie/matrix.py:214-310, matrix_naive_concatenate.ipp):
+ * the k resident designs are copied side by side (axis 1: columns; axis 0: rows) into one new dense design; SNP sources
+ * are decoded.  The sources stay valid and independent.  The reference's error strings for mismatched shapes are kept. */
+int adelie_hip_design_create_concat(adelie_hip_design* const* srcs, int64_t k, int axis, adelie_hip_design** out);
 /* Multi-response view of a resident dense design: the (n*K) x ((p + intercept)*K) matrix
  *     [ 1_n (x) I_K ,  X (x) I_K ]      (the first block only when `intercept` != 0)
  * that adelie/state.py:1100-1125 (_render_multi_inputs) builds from matrix.kronecker_eye / matrix.concatenate

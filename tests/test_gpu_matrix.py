@@ -229,3 +229,45 @@ def test_sparse_design_adds_duplicate_entries_and_solves_like_dense(hip):
     out = np.empty(2)
     ad.matrix.sparse(M).mul(np.ones(3), np.array([1.0, 10.0, 100.0]), out)
     assert np.array_equal(out, [3.0, 500.0])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_concatenate_resident_designs(hip, dtype):
+    """matrix.concatenate (reference matrix.py:214-310; tests/test_matrix.py::test_naive_cconcatenate / _rconcatenate):
+    the pieces are copied into one dense design on the device and must then pass the reference's check list."""
+    import scipy.sparse as sp
+
+    rng = np.random.RandomState(6)
+    n = 203
+    A = np.asfortranarray(rng.normal(size=(n, 9)), dtype=dtype)
+    calls = rng.choice([0, 1, 2, -9], size=(n, 7), p=[0.6, 0.25, 0.1, 0.05]).astype(np.int8)
+    imp = ad.matrix.compute_impute(calls)
+    Bd = np.where(calls < 0, imp[None], calls).astype(dtype)
+    C = (rng.normal(size=(n, 5)) * (rng.uniform(size=(n, 5)) < 0.3)).astype(dtype)
+    X = ad.matrix.concatenate(
+        [ad.matrix.dense(A), ad.matrix.snp_calldata(calls, dtype=dtype), ad.matrix.sparse(sp.csc_matrix(C))], axis=1)
+    assert (X.rows(), X.cols()) == (n, 21)
+    run_naive(X, np.asfortranarray(np.concatenate([A, Bd, C], axis=1)), dtype)
+    A2 = np.asfortranarray(rng.normal(size=(58, 9)), dtype=dtype)
+    Xr = ad.matrix.concatenate([A, A2], axis=0)          # ndarrays are uploaded first
+    assert (Xr.rows(), Xr.cols()) == (n + 58, 9)
+    run_naive(Xr, np.asfortranarray(np.concatenate([A, A2], axis=0)), dtype)
+    with pytest.raises(RuntimeError, match="same number of rows"):
+        ad.matrix.concatenate([A, A2], axis=1)
+    with pytest.raises(RuntimeError, match="same number of columns"):
+        ad.matrix.concatenate([A, C], axis=0)
+
+
+def test_concatenated_design_solves_like_the_dense_matrix(hip):
+    """reference tests/test_solver.py:659-754 (test_solve_gaussian_concatenate): a path on the concatenation of designs
+    equals the path on the concatenated array."""
+    rng = np.random.RandomState(7)
+    n, ps = 150, [20, 35, 10]
+    Xs = [np.asfortranarray(rng.normal(size=(n, p))) for p in ps]
+    X = np.asfortranarray(np.concatenate(Xs, axis=1))
+    y = X[:, [1, 25, 60]] @ np.array([1.0, -1.0, 2.0]) + 0.2 * rng.normal(size=n)
+    groups = np.arange(0, X.shape[1], 5)
+    s1 = ad.grpnet(ad.matrix.concatenate([ad.matrix.dense(x) for x in Xs], axis=1), ad.glm.gaussian(y=y), groups=groups,
+                   progress_bar=False)
+    s2 = ad.grpnet(ad.matrix.dense(X), ad.glm.gaussian(y=y), groups=groups, progress_bar=False)
+    assert np.array_equal(s1.lmdas, s2.lmdas) and np.array_equal(s1.betas.toarray(), s2.betas.toarray())

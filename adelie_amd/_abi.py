@@ -113,7 +113,7 @@ HIP_SYMBOLS = [
     "abi_version", "last_error", "device_count", "set_config",
     "design_create_dense", "design_create_sparse", "design_adopt_dense_dev", "design_create_snp_unphased",
     "design_create_snp_calldata", "design_create_snp_bed", "design_alias", "design_create_multi", "design_create_derived", "design_create_concat", "design_impute", "design_destroy",
-    "design_glm_path_losses", "design_rows", "design_cols", "design_dtype",
+    "design_glm_path_losses", "design_multi_path_losses", "design_rows", "design_cols", "design_dtype",
     "design_device", "design_stream",
     "design_cmul", "design_ctmul", "design_bmul", "design_btmul", "design_mul", "design_mul_batch", "design_cov",
     "design_sq_mul", "design_sp_tmul",
@@ -175,6 +175,7 @@ class Backend:
         sig("design_create_derived", ci, [vp, vp, i64, vp, i64, vp, vp, p(vp)])
         sig("design_create_concat", ci, [vp, i64, ci, p(vp)])
         sig("design_glm_path_losses", ci, [vp, ci, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp])
+        sig("design_multi_path_losses", ci, [vp, ci, ci, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp])
         sig("design_destroy", ci, [vp])
         sig("design_rows", i64, [vp])
         sig("design_cols", i64, [vp])

@@ -287,6 +287,9 @@ namespace ahip {
 template <class T>
 void launch_glm_loss2(int kind, const T* y, const T* wa, const T* wb, const T* base, T b0, const T* off, int64_t n, T* sums,
                       hipStream_t s);
+template <class T>
+void launch_multi_loss2(int kind, const T* y, const T* wa, const T* wb, const T* base, const T* b0, const T* off, int64_t nb,
+                        int K, T* sums, hipStream_t s);
 }
 namespace {
 
@@ -323,6 +326,82 @@ void op_path_losses(adelie_hip_design* d, int kind, int64_t L, const int64_t* in
         else launch_sp_tmul_snp<T>(d->snp(), static_cast<const T*>(d->impute), lc, dptr + l0, dind, dval, dout, s);
         for (int64_t l = 0; l < lc; ++l) {
             launch_glm_loss2<T>(kind, dy, dwa, dwb, dout + l * n, intercepts[l0 + l], doff, n, sums, s);
+            AHIP_CHECK(hipMemcpyAsync(dres + 2 * (l0 + l), sums, 2 * sizeof(T), hipMemcpyDeviceToDevice, s));
+        }
+    }
+    std::vector<T> res(size_t(2) * L);
+    AHIP_CHECK(hipMemcpyAsync(res.data(), dres, res.size() * sizeof(T), hipMemcpyDeviceToHost, s));
+    AHIP_CHECK(hipStreamSynchronize(s));
+    for (int64_t l = 0; l < L; ++l) {
+        out[l] = double(res[2 * l]);
+        out[L + l] = double(res[2 * l + 1]);
+    }
+}
+
+// The same for multi-response fits on the base design `d`: row l of the CSR is a coefficient vector over the view columns
+// (feature*K + response, intercept columns already split off), intercepts (L, K), offsets / y (n, K) row-major.  Each row is
+// split into its K per-response rows over the base features, so that one sp_tmul yields eta_l response-major.
+template <class T>
+void op_multi_path_losses(adelie_hip_design* d, int kind, int K, int64_t L, const int64_t* indptr, const int64_t* indices,
+                          const T* values, const T* intercepts, const T* offsets, const T* y, const T* wa, const T* wb,
+                          double* out) {
+    set_device(d);
+    hipStream_t s = d->stream;
+    const int64_t n = d->n, p = d->p;
+    const int64_t nnz = indptr[L];
+    // per-response CSR rows (counting sort by response inside every row; the order of the features is kept)
+    const size_t nz = size_t(nnz);
+    std::vector<int64_t> ptr(size_t(L) * K + 1, 0), ind(nz);
+    std::vector<T> val(nz);
+    for (int64_t l = 0; l < L; ++l)
+        for (int64_t e = indptr[l]; e < indptr[l + 1]; ++e) {
+            if (indices[e] < 0 || indices[e] >= p * K) throw make_core_error("multi_path_losses: column index out of range.");
+            ++ptr[size_t(l) * K + size_t(indices[e] % K) + 1];
+        }
+    for (size_t r = 0; r < size_t(L) * K; ++r) ptr[r + 1] += ptr[r];
+    {
+        std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
+        for (int64_t l = 0; l < L; ++l)
+            for (int64_t e = indptr[l]; e < indptr[l + 1]; ++e) {
+                const size_t r = size_t(l) * K + size_t(indices[e] % K);
+                ind[size_t(fill[r])] = indices[e] / K;
+                val[size_t(fill[r])] = values[e];
+                ++fill[r];
+            }
+    }
+    // (n, K) row-major -> response-major
+    std::vector<T> ym(size_t(n) * K), om(size_t(n) * K);
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < K; ++k) {
+            ym[size_t(k) * n + i] = y[i * K + k];
+            om[size_t(k) * n + i] = offsets[i * K + k];
+        }
+    int64_t* dptr = scratch<int64_t>(d->s_idx1, size_t(L) * K + 1);
+    int64_t* dind = scratch<int64_t>(d->s_idx2, nnz);
+    T* dval = scratch<T>(d->s_p1, size_t(nnz) + size_t(L) * K);
+    T* dicpt = dval + nnz;
+    AHIP_CHECK(hipMemcpyAsync(dptr, ptr.data(), ptr.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    if (nnz) {
+        AHIP_CHECK(hipMemcpyAsync(dind, ind.data(), nnz * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        AHIP_CHECK(hipMemcpyAsync(dval, val.data(), nnz * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    AHIP_CHECK(hipMemcpyAsync(dicpt, intercepts, size_t(L) * K * sizeof(T), hipMemcpyHostToDevice, s));
+    const size_t SUMS = 16 + 4 * 256;
+    const size_t nK = size_t(n) * K;
+    T* vec = scratch<T>(d->s_n1, 2 * nK + 2 * size_t(n) + SUMS + size_t(2) * L);
+    T *dy = vec, *doff = vec + nK, *dwa = vec + 2 * nK, *dwb = dwa + n, *sums = dwb + n, *dres = sums + SUMS;
+    AHIP_CHECK(hipMemcpyAsync(dy, ym.data(), nK * sizeof(T), hipMemcpyHostToDevice, s));
+    AHIP_CHECK(hipMemcpyAsync(doff, om.data(), nK * sizeof(T), hipMemcpyHostToDevice, s));
+    AHIP_CHECK(hipMemcpyAsync(dwa, wa, n * sizeof(T), hipMemcpyHostToDevice, s));
+    AHIP_CHECK(hipMemcpyAsync(dwb, wb, n * sizeof(T), hipMemcpyHostToDevice, s));
+    const int64_t Lp = std::max<int64_t>(1, (int64_t(1) << 30) / int64_t(nK * sizeof(T)));
+    T* dout = scratch<T>(d->s_misc, size_t(std::min(Lp, L)) * nK);
+    for (int64_t l0 = 0; l0 < L; l0 += Lp) {
+        const int64_t lc = std::min(Lp, L - l0);
+        if (d->kind == 0) launch_sp_tmul<T>(d->dense<T>(), lc * K, dptr + l0 * K, dind, dval, dout, s);
+        else launch_sp_tmul_snp<T>(d->snp(), static_cast<const T*>(d->impute), lc * K, dptr + l0 * K, dind, dval, dout, s);
+        for (int64_t l = 0; l < lc; ++l) {
+            launch_multi_loss2<T>(kind, dy, dwa, dwb, dout + size_t(l) * nK, dicpt + (l0 + l) * K, doff, n, K, sums, s);
             AHIP_CHECK(hipMemcpyAsync(dres + 2 * (l0 + l), sums, 2 * sizeof(T), hipMemcpyDeviceToDevice, s));
         }
     }
@@ -840,6 +919,27 @@ int adelie_hip_design_glm_path_losses(adelie_hip_design* d, int glm_kind, int64_
                                             (const T*)offsets, (const T*)y, (const T*)weights_a, (const T*)weights_b, out),
                        op_path_losses<T>(d, glm_kind, L, indptr, indices, (const T*)values, (const T*)intercepts,
                                          (const T*)offsets, (const T*)y, (const T*)weights_a, (const T*)weights_b, out))
+    }
+    ABI_CATCH
+}
+
+int adelie_hip_design_multi_path_losses(adelie_hip_design* d, int glm_kind, int K, int64_t L, const int64_t* indptr,
+                                        const int64_t* indices, const void* values, const void* intercepts,
+                                        const void* offsets, const void* y, const void* weights_a, const void* weights_b,
+                                        double* out) {
+    ABI_TRY
+    no_view(d);
+    if (!d || !indptr || !intercepts || !offsets || !y || !weights_a || !weights_b || !out)
+        throw make_core_error("null argument.");
+    if (L < 0) throw make_core_error("L must be >= 0.");
+    if (K < 1) throw make_core_error("K must be >= 1.");
+    if (glm_kind != ADELIE_HIP_GLM_GAUSSIAN && glm_kind != ADELIE_HIP_GLM_MULTINOMIAL)
+        throw make_core_error("multi_path_losses: glm_kind must be GAUSSIAN (multigaussian) or MULTINOMIAL.");
+    if (L > 0) {
+        DTYPE_DISPATCH(d, op_multi_path_losses<T>(d, glm_kind, K, L, indptr, indices, (const T*)values, (const T*)intercepts,
+                                                  (const T*)offsets, (const T*)y, (const T*)weights_a, (const T*)weights_b, out),
+                       op_multi_path_losses<T>(d, glm_kind, K, L, indptr, indices, (const T*)values, (const T*)intercepts,
+                                               (const T*)offsets, (const T*)y, (const T*)weights_a, (const T*)weights_b, out))
     }
     ABI_CATCH
 }

@@ -237,6 +237,45 @@ __global__ __launch_bounds__(RT) void multinomial_loss_kernel(const T* __restric
     block_partials<T, 1>(acc, sums);
 }
 
+// multi-response loss of eta_k = base_k + b0[k] + off_k under two weight vectors (cv_grpnet over multigaussian / multinomial
+// fits): response-major (nb, K) arrays as above; glm_multigaussian.ipp:60-72, glm_multinomial.ipp:68-87
+template <class T>
+__global__ __launch_bounds__(RT) void multi_loss2_kernel(int kind, const T* __restrict__ y, const T* __restrict__ wa,
+                                                         const T* __restrict__ wb, const T* __restrict__ base,
+                                                         const T* __restrict__ b0, const T* __restrict__ off, int64_t nb,
+                                                         int K, T* sums) {
+    T acc[2] = {T(0), T(0)};
+    GRID_STRIDE(i, nb) {
+        T l;
+        if (kind == ADELIE_HIP_GLM_MULTINOMIAL) {
+            T mx = base[i] + b0[0] + off[i];
+            for (int k = 1; k < K; ++k) {
+                const int64_t q = int64_t(k) * nb + i;
+                mx = max(mx, base[q] + b0[k] + off[q]);
+            }
+            T ye = T(0), se = T(0);
+            for (int k = 0; k < K; ++k) {
+                const int64_t q = int64_t(k) * nb + i;
+                const T e = base[q] + b0[k] + off[q] - mx;
+                ye += y[q] * e;
+                se += exp(e);
+            }
+            l = (-ye + log(se)) / T(K);
+        } else {
+            T a = T(0);
+            for (int k = 0; k < K; ++k) {
+                const int64_t q = int64_t(k) * nb + i;
+                const T e = base[q] + b0[k] + off[q];
+                a += T(0.5) * e * e - y[q] * e;
+            }
+            l = a / T(K);
+        }
+        acc[0] += wa[i] * l;
+        acc[1] += wb[i] * l;
+    }
+    block_partials<T, 2>(acc, sums);
+}
+
 template <class T>
 __global__ __launch_bounds__(RT) void set_eta_kernel(const T* __restrict__ off, T beta0, int64_t n, T* __restrict__ eta) {
     GRID_STRIDE(i, n) eta[i] = beta0 + off[i];
@@ -310,6 +349,12 @@ void launch_glm_loss2(int kind, const T* y, const T* wa, const T* wb, const T* b
     finish(sums, 2, s);
 }
 template <class T>
+void launch_multi_loss2(int kind, const T* y, const T* wa, const T* wb, const T* base, const T* b0, const T* off, int64_t nb,
+                        int K, T* sums, hipStream_t s) {
+    hipLaunchKernelGGL((multi_loss2_kernel<T>), dim3(RB), dim3(RT), 0, s, kind, y, wa, wb, base, b0, off, nb, K, sums);
+    finish(sums, 2, s);
+}
+template <class T>
 void launch_null_step(int kind, const T* y, const T* w, const T* eta, const T* resid, const T* offsets, T hessian_min,
                       int64_t n, T* sums, hipStream_t s, int K) {
     hipLaunchKernelGGL((null_step_kernel<T>), dim3(RB), dim3(RT), 0, s, kind, y, w, eta, resid, offsets, hessian_min, n,
@@ -341,6 +386,8 @@ void launch_gather(const T* src, const int32_t* idx, int64_t cnt, T* dst, hipStr
     template void launch_glm_loss<T>(int, const T*, const T*, const T*, int64_t, T*, hipStream_t, int);                  \
     template void launch_glm_loss2<T>(int, const T*, const T*, const T*, const T*, T, const T*, int64_t, T*,           \
                                       hipStream_t);                                                                    \
+    template void launch_multi_loss2<T>(int, const T*, const T*, const T*, const T*, const T*, const T*, int64_t, int, T*, \
+                                        hipStream_t);                                                                  \
     template void launch_null_step<T>(int, const T*, const T*, const T*, const T*, const T*, T, int64_t, T*,           \
                                       hipStream_t, int);                                                                  \
     template void launch_set_eta<T>(const T*, T, int64_t, T*, hipStream_t);                                            \

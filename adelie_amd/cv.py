@@ -19,6 +19,9 @@ from .solver import grpnet
 
 logger = logging.getLogger("adelie_amd")
 
+# families whose per-lambda CV losses adelie_hip_design_multi_path_losses computes (glm_kind it expects)
+_MULTI_KINDS = {"multigaussian": 0, "multinomial": 3}
+
 
 @dataclass
 class CVGrpnetResult:
@@ -79,6 +82,12 @@ def _fold_loss(X, glm, fold_idx, full_lmdas, *, n_threads, early_exit, min_ratio
         # predictions and both losses per lambda on the device; only 2 L scalars come back
         full_data_losses, train = X.glm_path_losses(glm.core_kind, full_betas, full_intercepts, state._offsets, glm.y,
                                                     glm.weights, glm_c.weights)
+        train_losses = weights_sum * train
+    elif (getattr(glm, "is_multi", False) and hasattr(X, "multi_path_losses") and not isinstance(X, matrix._MultiView)
+          and X._backend.has("design_multi_path_losses") and getattr(glm, "name", None) in _MULTI_KINDS):
+        # multi-response fits: the (L, n, K) predictions stay on the device as well
+        full_data_losses, train = X.multi_path_losses(_MULTI_KINDS[glm.name], glm.y.shape[1], full_betas,
+                                                      full_intercepts, state._offsets, glm.y, glm.weights, glm_c.weights)
         train_losses = weights_sum * train
     else:
         etas = predict(X=X, betas=full_betas, intercepts=full_intercepts, offsets=state._offsets, n_threads=n_threads)

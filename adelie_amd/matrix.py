@@ -103,6 +103,27 @@ class _NativeMatrix:
             *[v.ctypes.data for v in vecs], out.ctypes.data))
         return out[:L], out[L:]
 
+    def multi_path_losses(self, glm_kind, K, betas, intercepts, offsets, y, weights_a, weights_b):
+        """:meth:`glm_path_losses` for multi-response fits on this (base) design: ``betas`` is CSR ``(L, p*K)`` over the view
+        columns ``feature*K + response``, ``intercepts`` ``(L, K)``, ``offsets`` / ``y`` ``(n, K)``
+        (``adelie_hip_design_multi_path_losses``).  Returns two ``(L,)`` arrays."""
+        dt = self.dtype
+        betas = betas.tocsr()
+        L = betas.shape[0]
+        self._chk(betas.shape[1] == self._cols * K, "multi_path_losses() is given inconsistent inputs!")
+        indptr = np.ascontiguousarray(betas.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(betas.indices, dtype=np.int64)
+        values = np.ascontiguousarray(betas.data, dtype=dt)
+        icpt = np.ascontiguousarray(np.asarray(intercepts, dtype=dt).reshape(L, K))
+        off = np.ascontiguousarray(np.asarray(offsets, dtype=dt).reshape(self._rows, K))
+        yy = np.ascontiguousarray(np.asarray(y, dtype=dt).reshape(self._rows, K))
+        wa, wb = (np.ascontiguousarray(v, dtype=dt) for v in (weights_a, weights_b))
+        out = np.empty(2 * L, dtype=np.float64)
+        self._backend.check(self._backend.fn("design_multi_path_losses")(
+            self._handle, int(glm_kind), int(K), L, indptr.ctypes.data, indices.ctypes.data, values.ctypes.data,
+            icpt.ctypes.data, off.ctypes.data, yy.ctypes.data, wa.ctypes.data, wb.ctypes.data, out.ctypes.data))
+        return out[:L], out[L:]
+
     def alias(self):
         """A second handle on the same resident matrix with its own stream (``adelie_hip_design_alias``): lets independent
         solves run concurrently from different threads.  Keeps this design alive."""

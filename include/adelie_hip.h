@@ -136,6 +136,14 @@ int adelie_hip_design_glm_path_losses(adelie_hip_design* d, int glm_kind, int64_
                                       const int64_t* indices, const void* values, const void* intercepts,
                                       const void* offsets, const void* y, const void* weights_a, const void* weights_b,
                                       double* out);
+/* The same for multi-response fits (glm.multigaussian: glm_kind GAUSSIAN; glm.multinomial: MULTINOMIAL) on the BASE design:
+ * row l of the CSR is a coefficient vector over the view columns feature*K + response (intercepts split off, as
+ * state.betas holds them), intercepts is (L,K), offsets and y are (n,K) row-major, the weights (n,).  Replaces
+ * diagnostic.predict through kronecker_eye + glm.loss per lambda in adelie/cv.py:281-314. */
+int adelie_hip_design_multi_path_losses(adelie_hip_design* d, int glm_kind, int K, int64_t L, const int64_t* indptr,
+                                        const int64_t* indices, const void* values, const void* intercepts,
+                                        const void* offsets, const void* y, const void* weights_a, const void* weights_b,
+                                        double* out);
 
 int64_t adelie_hip_design_rows(const adelie_hip_design* d);   /* MatrixNaiveBase::rows */
 int64_t adelie_hip_design_cols(const adelie_hip_design* d);   /* MatrixNaiveBase::cols */

@@ -436,3 +436,57 @@ def _abi_mul(V, out):
     from adelie_amd import _abi
     v = np.zeros(V.rows())
     V._backend.check(V._backend.fn("design_mul")(V._handle, v.ctypes.data, v.ctypes.data, out.ctypes.data))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["multigaussian", "multinomial"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_hip_multi_path_losses_equal_host_predictions(family, dtype):
+    """adelie_hip_design_multi_path_losses (cv.py:281-314 for multi-response fits): the per-lambda losses under two weight
+    vectors, computed on the device from the CSR coefficients, against diagnostic.predict + glm.loss on the host."""
+    rng = np.random.RandomState(11)
+    n, p, K, L = 257, 31, 3, 7
+    X = np.asfortranarray(rng.normal(size=(n, p)), dtype=dtype)
+    if family == "multinomial":
+        Y = np.eye(K)[rng.randint(0, K, n)].astype(dtype)
+    else:
+        Y = rng.normal(size=(n, K)).astype(dtype)
+    wa = rng.uniform(1, 2, n)
+    wa /= wa.sum()
+    wb = wa.copy()
+    wb[: n // 4] = 0
+    wb /= wb.sum()
+    B = (rng.normal(size=(L, p * K)) * (rng.uniform(size=(L, p * K)) < 0.2)).astype(dtype)
+    B[0] = 0                                      # an empty row
+    icpt = rng.normal(size=(L, K)).astype(dtype)
+    off = (0.1 * rng.normal(size=(n, K))).astype(dtype)
+    Xd = matrix.dense(X)
+    ga = getattr(ad.glm, family)(y=Y, weights=wa, dtype=dtype)
+    gb = getattr(ad.glm, family)(y=Y, weights=wb, dtype=dtype)
+    kind = {"multigaussian": 0, "multinomial": 3}[family]
+    la, lb = Xd.multi_path_losses(kind, K, csr_matrix(B), icpt, off, Y, ga.weights, gb.weights)
+    eta = (X.astype(np.float64) @ B.astype(np.float64).reshape(L, p, K).transpose(1, 0, 2).reshape(p, L * K)).reshape(n, L, K)
+    eta = eta.transpose(1, 0, 2) + icpt[:, None].astype(np.float64) + off.astype(np.float64)
+    g64a = getattr(ad.glm, family)(y=Y.astype(np.float64), weights=wa)
+    g64b = getattr(ad.glm, family)(y=Y.astype(np.float64), weights=wb)
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    assert np.allclose(la, [g64a.loss(e) for e in eta], rtol=tol, atol=tol)
+    assert np.allclose(lb, [g64b.loss(e) for e in eta], rtol=tol, atol=tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["multigaussian", "multinomial"])
+def test_hip_multi_cv_device_losses_equal_host_path(family, monkeypatch):
+    rng = np.random.RandomState(12)
+    n, p, K = 240, 25, 3
+    X = np.asfortranarray(rng.normal(size=(n, p)))
+    S = X[:, :3] @ rng.normal(size=(3, K)) + 0.5 * rng.normal(size=(n, K))
+    Y = np.eye(K)[np.argmax(S, axis=1)] if family == "multinomial" else S
+    glm = getattr(ad.glm, family)(y=Y)
+    Xd = matrix.dense(X)
+    a = ad.cv_grpnet(Xd, glm, n_folds=3, seed=0, lmda_path_size=20, progress_bar=False)
+    monkeypatch.setattr(ad.cv, "_MULTI_KINDS", {})            # host predictions + glm.loss, as before
+    b = ad.cv_grpnet(Xd, glm, n_folds=3, seed=0, lmda_path_size=20, progress_bar=False)
+    assert np.array_equal(a.lmdas, b.lmdas)
+    assert np.allclose(a.losses, b.losses, rtol=1e-10, atol=1e-13)
+    assert a.best_idx == b.best_idx

@@ -464,6 +464,10 @@ def _multi_view(base, K, intercept):
         raise RuntimeError("adelie_amd: the multi-response view needs a resident (dense) design as its base.")
     if int(K) < 1:
         raise RuntimeError("adelie_core: K must be >= 1.")
+    if getattr(base, "_kind", None) != "dense":
+        # the K-wide kernels read dense columns: a 2-bit SNP base is decoded once into a dense copy (8 or 4 bytes per call
+        # instead of a quarter byte -- n * p values must fit in HBM), which the view then owns
+        base = _derived(base, None, None, None, None, base._n_threads)
     backend = base._backend
     handle = _abi.C.c_void_p()
     backend.check(backend.fn("design_create_multi")(base._handle, int(K), 1 if intercept else 0, handle))

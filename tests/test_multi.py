@@ -490,3 +490,23 @@ def test_hip_multi_cv_device_losses_equal_host_path(family, monkeypatch):
     assert np.array_equal(a.lmdas, b.lmdas)
     assert np.allclose(a.losses, b.losses, rtol=1e-10, atol=1e-13)
     assert a.best_idx == b.best_idx
+
+
+@pytest.mark.gpu
+def test_hip_multi_response_on_snp_design_equals_densified():
+    """A 2-bit SNP base under the multi-response view (decoded once into a dense copy the view owns): same path as on the
+    densified matrix."""
+    rng = np.random.RandomState(13)
+    n, p, K = 300, 40, 3
+    calls = rng.choice([0, 1, 2, -9], size=(n, p), p=[0.55, 0.3, 0.1, 0.05]).astype(np.int8)
+    imp = matrix.compute_impute(calls)
+    D = np.asfortranarray(np.where(calls < 0, imp[None], calls).astype(np.float64))
+    Y = D[:, :3] @ rng.normal(size=(3, K)) + 0.5 * rng.normal(size=(n, K))
+    s1 = ad.grpnet(matrix.snp_calldata(calls), ad.glm.multigaussian(y=Y), progress_bar=False)
+    s2 = ad.grpnet(matrix.dense(D), ad.glm.multigaussian(y=Y), progress_bar=False)
+    assert np.array_equal(s1.lmdas, s2.lmdas)
+    assert np.allclose(s1.betas.toarray(), s2.betas.toarray(), atol=1e-13)
+    assert np.allclose(s1.intercepts, s2.intercepts, atol=1e-13)
+    cv = ad.cv_grpnet(matrix.snp_calldata(calls), ad.glm.multigaussian(y=Y), n_folds=3, seed=0, lmda_path_size=10,
+                      progress_bar=False)
+    assert np.all(np.isfinite(cv.losses))

@@ -316,7 +316,7 @@ def _wrap(backend, handle, dtype, n_threads, keep=None, kind=None):
     obj = _make_class(dtype)()
     obj._init_native(backend, handle, n_threads)
     obj._keep = keep
-    obj._kind = kind  # "dense" for dense designs (cv_grpnet batches their sweeps across concurrent folds)
+    obj._kind = kind  # "dense" (cv_grpnet batches the sweeps of concurrent folds on these) or "snp" (2-bit calls)
     return obj
 
 
@@ -464,7 +464,7 @@ def _multi_view(base, K, intercept):
         raise RuntimeError("adelie_amd: the multi-response view needs a resident (dense) design as its base.")
     if int(K) < 1:
         raise RuntimeError("adelie_core: K must be >= 1.")
-    if getattr(base, "_kind", None) != "dense":
+    if getattr(base, "_kind", None) == "snp":
         # the K-wide kernels read dense columns: a 2-bit SNP base is decoded once into a dense copy (8 or 4 bytes per call
         # instead of a quarter byte -- n * p values must fit in HBM), which the view then owns
         base = _derived(base, None, None, None, None, base._n_threads)
@@ -639,7 +639,7 @@ def snp_unphased(io, *, dtype=np.float64, n_threads: int = 1, device: int = 0):
     buf = io._buffer
     backend.check(backend.fn("design_create_snp_unphased")(
         buf.ctypes.data, buf.size, _abi.dtype_code(dtype), device, handle))
-    return _wrap(backend, handle, np.dtype(dtype).type, n_threads, keep=io)
+    return _wrap(backend, handle, np.dtype(dtype).type, n_threads, keep=io, kind="snp")
 
 
 def snp_calldata(calldata, impute=None, *, dtype=np.float64, n_threads: int = 1, device: int = 0):
@@ -670,7 +670,7 @@ def snp_calldata(calldata, impute=None, *, dtype=np.float64, n_threads: int = 1,
     handle = _abi.C.c_void_p()
     backend.check(backend.fn("design_create_snp_calldata")(
         ptr, n, p, impute.ctypes.data, _abi.dtype_code(dtype), device, handle))
-    return _wrap(backend, handle, np.dtype(dtype).type, n_threads)
+    return _wrap(backend, handle, np.dtype(dtype).type, n_threads, kind="snp")
 
 
 def snp_bed(bed, n: int, p: int = None, *, dtype=np.float64, n_threads: int = 1, device: int = 0):
@@ -690,7 +690,7 @@ def snp_bed(bed, n: int, p: int = None, *, dtype=np.float64, n_threads: int = 1,
     handle = _abi.C.c_void_p()
     backend.check(backend.fn("design_create_snp_bed")(
         buf.ctypes.data, buf.size, int(n), int(p), _abi.dtype_code(dtype), device, handle))
-    return _wrap(backend, handle, np.dtype(dtype).type, n_threads)
+    return _wrap(backend, handle, np.dtype(dtype).type, n_threads, kind="snp")
 
 
 def _derived(mat, rows, cols, centers, scales, n_threads):

@@ -178,14 +178,15 @@ void op_mul_batch(adelie_hip_design* d, const T* V, int64_t L, T* out) {
         T* dv = scratch<T>(d->s_n1, size_t(KB) * size_t(n));
         T* dout = scratch<T>(d->s_p1, size_t(KB) * size_t(p));
         const DenseView<T> X = d->dense<T>();
-        T* work = scratch<T>(d->s_work, size_t(multi_sweep_work_elems<T>(MultiView<T>{X.X, n, p, X.ld, nullptr, int32_t(KB), 0})));
+        // one work buffer for both kernels (a lone last vector goes through the single-vector sweep)
+        T* work = scratch<T>(d->s_work, std::max<size_t>(size_t(sweep_work_elems(n, p)),
+                                                         size_t(multi_sweep_work_elems<T>(MultiView<T>{X.X, n, p, X.ld, nullptr, int32_t(KB), 0}))));
         std::vector<T> hout(size_t(KB) * size_t(p));
         for (int64_t l0 = 0; l0 < L; l0 += KB) {
             const int64_t K = std::min(KB, L - l0);
             AHIP_CHECK(hipMemcpyAsync(dv, V + l0 * n, size_t(K) * size_t(n) * sizeof(T), hipMemcpyHostToDevice, s));
             if (K == 1) {
-                T* w1 = scratch<T>(d->s_work, std::max<size_t>(size_t(sweep_work_elems(n, p)), size_t(multi_sweep_work_elems<T>(MultiView<T>{X.X, n, p, X.ld, nullptr, int32_t(KB), 0}))));
-                launch_sweep<T>(X, dv, dout, 0, p, nullptr, nullptr, nullptr, false, w1, s);
+                launch_sweep<T>(X, dv, dout, 0, p, nullptr, nullptr, nullptr, false, work, s);
                 AHIP_CHECK(hipMemcpyAsync(out + l0 * p, dout, size_t(p) * sizeof(T), hipMemcpyDeviceToHost, s));
                 AHIP_CHECK(hipStreamSynchronize(s));
                 continue;

@@ -271,3 +271,29 @@ def test_concatenated_design_solves_like_the_dense_matrix(hip):
                    progress_bar=False)
     s2 = ad.grpnet(ad.matrix.dense(X), ad.glm.gaussian(y=y), groups=groups, progress_bar=False)
     assert np.array_equal(s1.lmdas, s2.lmdas) and np.array_equal(s1.betas.toarray(), s2.betas.toarray())
+
+
+def test_new_constructors_reject_bad_inputs(hip):
+    import scipy.sparse as sp
+
+    rng = np.random.RandomState(8)
+    X = ad.matrix.dense(np.asfortranarray(rng.normal(size=(20, 4))))
+    with pytest.raises(RuntimeError, match="mul_batch\\(\\) is given inconsistent inputs"):
+        X.mul_batch(np.zeros((3, 19)))
+    assert X.mul_batch(np.zeros((0, 20))).shape == (0, 4)
+    view = ad.matrix.kronecker_eye(X, 2)
+    with pytest.raises(NotImplementedError, match="resident designs"):
+        ad.matrix.concatenate([X, view], axis=1)
+    with pytest.raises(ValueError, match="axis must be 0 or 1"):
+        ad.matrix.concatenate([X, X], axis=2)
+    with pytest.raises(RuntimeError, match="non-empty"):
+        ad.matrix.concatenate([], axis=1)
+    with pytest.raises(RuntimeError, match="same dtype"):
+        ad.matrix.concatenate([X, ad.matrix.dense(np.asfortranarray(rng.normal(size=(20, 4)), dtype=np.float32))], axis=1)
+    with pytest.raises(RuntimeError, match="float32 or float64"):
+        ad.matrix.sparse(sp.csc_matrix(np.eye(3, dtype=np.int64)))
+    with pytest.raises(NotImplementedError, match="naive"):
+        ad.matrix.sparse(sp.csc_matrix(np.eye(3)), method="cov")
+    with pytest.raises(RuntimeError, match="multi_path_losses\\(\\) is given inconsistent inputs"):
+        X.multi_path_losses(0, 2, sp.csr_matrix(np.zeros((1, 7))), np.zeros((1, 2)), np.zeros((20, 2)), np.zeros((20, 2)),
+                            np.ones(20) / 20, np.ones(20) / 20)

@@ -167,48 +167,43 @@ void op_sweep(adelie_hip_design* d, int64_t c0, int64_t ncols, const T* v, const
 }
 
 // L sweeps at once (diagnostic.gradients, reference adelie/diagnostic.py:320-387: one X.mul per residual vector): the
-// vectors go through the K-wide sweep eight at a time, so a dense design is streamed once per eight vectors.
+// vectors go through the K-wide sweep eight at a time, so the design (dense or 2-bit SNP) is streamed once per eight vectors.
 template <class T>
 void op_mul_batch(adelie_hip_design* d, const T* V, int64_t L, T* out) {
     set_device(d);
     hipStream_t s = d->stream;
     const int64_t n = d->n, p = d->p;
     constexpr int64_t KB = 8;
-    if (d->kind == 0) {
-        T* dv = scratch<T>(d->s_n1, size_t(KB) * size_t(n));
-        T* dout = scratch<T>(d->s_p1, size_t(KB) * size_t(p));
-        const DenseView<T> X = d->dense<T>();
-        // one work buffer for both kernels (a lone last vector goes through the single-vector sweep)
-        T* work = scratch<T>(d->s_work, std::max<size_t>(size_t(sweep_work_elems(n, p)),
-                                                         size_t(multi_sweep_work_elems<T>(MultiView<T>{X.X, n, p, X.ld, nullptr, int32_t(KB), 0}))));
-        std::vector<T> hout(size_t(KB) * size_t(p));
-        for (int64_t l0 = 0; l0 < L; l0 += KB) {
-            const int64_t K = std::min(KB, L - l0);
-            AHIP_CHECK(hipMemcpyAsync(dv, V + l0 * n, size_t(K) * size_t(n) * sizeof(T), hipMemcpyHostToDevice, s));
-            if (K == 1) {
-                launch_sweep<T>(X, dv, dout, 0, p, nullptr, nullptr, nullptr, false, work, s);
-                AHIP_CHECK(hipMemcpyAsync(out + l0 * p, dout, size_t(p) * sizeof(T), hipMemcpyDeviceToHost, s));
-                AHIP_CHECK(hipStreamSynchronize(s));
-                continue;
-            }
-            launch_multi_sweep<T>(MultiView<T>{X.X, n, p, X.ld, nullptr, int32_t(K), 0}, dv, dout, work, s);
-            AHIP_CHECK(hipMemcpyAsync(hout.data(), dout, size_t(K) * size_t(p) * sizeof(T), hipMemcpyDeviceToHost, s));
+    const bool is_dense = d->kind == 0;
+    T* dv = scratch<T>(d->s_n1, size_t(KB) * size_t(n));
+    T* dout = scratch<T>(d->s_p1, size_t(KB) * size_t(p));
+    // one work buffer for both kernels (a lone last vector goes through the single-vector sweep); the K-wide sweep's
+    // work size only depends on (n, p, K)
+    const MultiView<T> shape{nullptr, n, p, n, nullptr, int32_t(KB), 0};
+    T* work = scratch<T>(d->s_work, std::max<size_t>(size_t(sweep_work_elems(n, p)), size_t(multi_sweep_work_elems<T>(shape))));
+    std::vector<T> hout(size_t(KB) * size_t(p));
+    for (int64_t l0 = 0; l0 < L; l0 += KB) {
+        const int64_t K = std::min(KB, L - l0);
+        AHIP_CHECK(hipMemcpyAsync(dv, V + l0 * n, size_t(K) * size_t(n) * sizeof(T), hipMemcpyHostToDevice, s));
+        if (K == 1) {
+            if (is_dense) launch_sweep<T>(d->dense<T>(), dv, dout, 0, p, nullptr, nullptr, nullptr, false, work, s);
+            else launch_sweep_snp<T>(d->snp(), static_cast<const T*>(d->impute), dv, dout, 0, p, nullptr, nullptr, nullptr, false,
+                                     work, s);
+            AHIP_CHECK(hipMemcpyAsync(out + l0 * p, dout, size_t(p) * sizeof(T), hipMemcpyDeviceToHost, s));
             AHIP_CHECK(hipStreamSynchronize(s));
-            for (int64_t l = 0; l < K; ++l) {
-                T* o = out + (l0 + l) * p;
-                for (int64_t u = 0; u < p; ++u) o[u] = hout[size_t(u) * size_t(K) + size_t(l)];
-            }
+            continue;
         }
-    } else {
-        T* dv = scratch<T>(d->s_n1, n);
-        T* dout = scratch<T>(d->s_p1, p);
-        T* work = scratch<T>(d->s_work, sweep_work_elems(n, p));
-        for (int64_t l = 0; l < L; ++l) {
-            AHIP_CHECK(hipMemcpyAsync(dv, V + l * n, size_t(n) * sizeof(T), hipMemcpyHostToDevice, s));
-            launch_sweep_snp<T>(d->snp(), static_cast<const T*>(d->impute), dv, dout, 0, p, nullptr, nullptr, nullptr, false,
-                                work, s);
-            AHIP_CHECK(hipMemcpyAsync(out + l * p, dout, size_t(p) * sizeof(T), hipMemcpyDeviceToHost, s));
-            AHIP_CHECK(hipStreamSynchronize(s));
+        if (is_dense) {
+            const DenseView<T> X = d->dense<T>();
+            launch_multi_sweep<T>(MultiView<T>{X.X, n, p, X.ld, nullptr, int32_t(K), 0}, dv, dout, work, s);
+        } else {
+            launch_multi_sweep_snp<T>(d->snp(), static_cast<const T*>(d->impute), int(K), dv, dout, work, s);
+        }
+        AHIP_CHECK(hipMemcpyAsync(hout.data(), dout, size_t(K) * size_t(p) * sizeof(T), hipMemcpyDeviceToHost, s));
+        AHIP_CHECK(hipStreamSynchronize(s));
+        for (int64_t l = 0; l < K; ++l) {
+            T* o = out + (l0 + l) * p;
+            for (int64_t u = 0; u < p; ++u) o[u] = hout[size_t(u) * size_t(K) + size_t(l)];
         }
     }
 }

@@ -284,6 +284,9 @@ struct MultiView {
 // out[u*K + l] = sum_i xcol(u)[i] * v[l*nb + i]  for every u in [0, pb + icpt): X is read ONCE for all K responses.
 template <class T> void launch_multi_sweep(const MultiView<T>& X, const T* v, T* out, T* work, hipStream_t s);
 template <class T> int64_t multi_sweep_work_elems(const MultiView<T>& X);
+// the same over a 2-bit SNP design: out[u*K + l] = x_u . v[l*n + :]; work sized as for the view {nb = n, pb = p, icpt = 0, K}
+template <class T>
+void launch_multi_sweep_snp(const SnpView& X, const T* impute, int K, const T* v, T* out, T* work, hipStream_t s);
 // panel step on view columns (same contract as launch_panel_step; `part` holds multi_panel_part_elems(nb) elements):
 //   r -= sum_{m < *nz_dev} dlt[m] X'[:, dcol[m]];   part[c][slice] = X'[slice, cols[c]] . (w*r)[slice]  for c < nb_cols
 // entries that share an extended feature (the K responses of a group) are served by one load of the column slice.

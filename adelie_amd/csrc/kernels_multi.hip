@@ -42,8 +42,8 @@ __device__ __forceinline__ T wsum(T x) {
 // ---- sweep ------------------------------------------------------------------------------------------------------------
 // grid (feature panels, row splits, response chunks of KT).  A block owns MCB features and walks its rows once; the KT
 // response vectors v_l are re-read per panel but from L2 (blocks of one row split are scheduled together and share them).
-template <class T, int VEC, int KT>
-__global__ __launch_bounds__(MT) void multi_sweep_kernel(DenseOnesAcc<T> X, const T* __restrict__ v, T* __restrict__ part,
+template <class T, class Acc, int VEC, int KT>
+__global__ __launch_bounds__(MT) void multi_sweep_kernel(Acc X, const T* __restrict__ v, T* __restrict__ part,
                                                         int64_t nb, int64_t nfeat, int K, int64_t rows_per_split) {
     const int tid = threadIdx.x;
     const int64_t cb = blockIdx.x;
@@ -51,9 +51,13 @@ __global__ __launch_bounds__(MT) void multi_sweep_kernel(DenseOnesAcc<T> X, cons
     const int l0 = blockIdx.z * KT;
     const int64_t r0 = int64_t(split) * rows_per_split;
     const int64_t r1 = min(nb, r0 + rows_per_split);
-    const T* cp[MCB];
+    decltype(X.colptr(0)) cp[MCB]; // dense: const T*; 2-bit SNP: const uint8_t*
+    int64_t cj[MCB];
 #pragma unroll
-    for (int k = 0; k < MCB; ++k) cp[k] = X.colptr(min(cb * MCB + k, nfeat - 1));
+    for (int k = 0; k < MCB; ++k) {
+        cj[k] = min(cb * MCB + k, nfeat - 1);
+        cp[k] = X.colptr(cj[k]);
+    }
     const T* vp[KT];
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk) vp[kk] = v + int64_t(min(l0 + kk, K - 1)) * nb; // clamped: duplicates are discarded below
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(MT) void multi_sweep_kernel(DenseOnesAcc<T> X, cons
     for (int64_t i = r0 + int64_t(tid) * VEC; i < body_end; i += int64_t(MT) * VEC) {
         Pack<T, VEC> xx[MCB];
 #pragma unroll
-        for (int k = 0; k < MCB; ++k) xx[k] = X.template load<VEC>(cp[k], i, 0);
+        for (int k = 0; k < MCB; ++k) xx[k] = X.template load<VEC>(cp[k], i, cj[k]);
 #pragma unroll
         for (int kk = 0; kk < KT; ++kk) {
 #pragma unroll
@@ -79,11 +83,14 @@ __global__ __launch_bounds__(MT) void multi_sweep_kernel(DenseOnesAcc<T> X, cons
         }
     }
     for (int64_t i = body_end + tid; i < r1; i += MT) {
+        T x1[MCB];
+#pragma unroll
+        for (int k = 0; k < MCB; ++k) x1[k] = X.template load<1>(cp[k], i, cj[k]).v[0];
 #pragma unroll
         for (int kk = 0; kk < KT; ++kk) {
             const T vv = vp[kk][i];
 #pragma unroll
-            for (int k = 0; k < MCB; ++k) acc[k][kk] = fma(cp[k][i], vv, acc[k][kk]);
+            for (int k = 0; k < MCB; ++k) acc[k][kk] = fma(x1[k], vv, acc[k][kk]);
         }
     }
 
@@ -450,7 +457,7 @@ void launch_multi_sweep(const MultiView<T>& X, const T* v, T* out, T* work, hipS
     const dim3 grid((unsigned)bc, (unsigned)ns, (unsigned)((X.K + KT - 1) / KT));
     const bool vok = multi_vecok(X);
 #define AHIP_MS(VV, KK)                                                                                                 \
-    hipLaunchKernelGGL((multi_sweep_kernel<T, VV, KK>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps)
+    hipLaunchKernelGGL((multi_sweep_kernel<T, DenseOnesAcc<T>, VV, KK>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps)
     if (vok) {
         if (KT == 8) AHIP_MS(V, 8); else if (KT == 4) AHIP_MS(V, 4); else AHIP_MS(V, 2);
     } else {
@@ -458,6 +465,28 @@ void launch_multi_sweep(const MultiView<T>& X, const T* v, T* out, T* work, hipS
     }
 #undef AHIP_MS
     const int64_t ncols = nfeat * X.K;
+    hipLaunchKernelGGL((multi_sweep_reduce_kernel<T>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, work, out,
+                       ncols, ns);
+}
+
+// the same sweep over a 2-bit SNP design (no ones column): out[u*K + l] = x_u . v_l; the calls of a column are decoded once
+// for all K vectors.  `work` holds multi_sweep_work_elems of the equivalent view (nb = n, pb = p, icpt = 0).
+template <class T>
+void launch_multi_sweep_snp(const SnpView& X, const T* impute, int K, const T* v, T* out, T* work, hipStream_t s) {
+    const int64_t nfeat = X.p;
+    if (nfeat <= 0 || K <= 0) return;
+    SnpAcc<T> acc{X.bits, X.ldb, impute};
+    constexpr int V = VecOf<T>::N; // 2 or 4 calls per load: a row split starts at a multiple of MT * V, so loads stay inside a byte
+    int64_t bc, rps;
+    int ns;
+    msweep_shape(X.n, nfeat, V, bc, ns, rps);
+    const int KT = kt_of(K);
+    const dim3 grid((unsigned)bc, (unsigned)ns, (unsigned)((K + KT - 1) / KT));
+#define AHIP_MSS(KK) \
+    hipLaunchKernelGGL((multi_sweep_kernel<T, SnpAcc<T>, V, KK>), grid, dim3(MT), 0, s, acc, v, work, X.n, nfeat, K, rps)
+    if (KT == 8) AHIP_MSS(8); else if (KT == 4) AHIP_MSS(4); else AHIP_MSS(2);
+#undef AHIP_MSS
+    const int64_t ncols = nfeat * K;
     hipLaunchKernelGGL((multi_sweep_reduce_kernel<T>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, work, out,
                        ncols, ns);
 }
@@ -572,6 +601,7 @@ void launch_multi_from_major(const T* src, int64_t nb, int K, T* dst, hipStream_
 #define INST(T)                                                                                                        \
     template int64_t multi_sweep_work_elems<T>(const MultiView<T>&);                                                   \
     template void launch_multi_sweep<T>(const MultiView<T>&, const T*, T*, T*, hipStream_t);                           \
+    template void launch_multi_sweep_snp<T>(const SnpView&, const T*, int, const T*, T*, T*, hipStream_t);             \
     template int launch_multi_panel_step<T>(const MultiView<T>&, const T*, T*, const int32_t*, const T*, const int32_t*, \
                                             const int32_t*, int, T*, hipStream_t);                                     \
     template int launch_multi_panel_fused<T>(const CdGrpBlkParams<T>&, int, const MultiView<T>&, const T*, T*,         \

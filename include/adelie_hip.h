@@ -165,7 +165,8 @@ int adelie_hip_design_btmul(adelie_hip_design* d, int64_t j, int64_t q, const vo
 /* mul   (:125-146): out = (v * weights)^T X */
 int adelie_hip_design_mul(adelie_hip_design* d, const void* v, const void* weights, void* out);
 /* L sweeps in one call: out[l,:] = V[l,:]^T X for l < L; V is (L,n) and out (L,p), both row-major.  Replaces the loop of
- * X.mul calls in adelie/diagnostic.py:377-386 (gradients); a dense design is streamed once per eight vectors. */
+ * X.mul calls in adelie/diagnostic.py:377-386 (gradients); the design (dense or 2-bit SNP) is streamed once per eight
+ * vectors. */
 int adelie_hip_design_mul_batch(adelie_hip_design* d, const void* V, int64_t L, void* out);
 /* cov   (:162-197): out = X[:, j:j+q]^T diag(sqrt_weights^2) X[:, j:j+q], (q,q) column-major */
 int adelie_hip_design_cov(adelie_hip_design* d, int64_t j, int64_t q, const void* sqrt_weights, void* out);

@@ -97,15 +97,22 @@ def test_gradients_batch_equals_matmul(dtype, L):
 
 
 @pytest.mark.gpu
-def test_gradients_snp_design():
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,p,L", [(500, 70, 5), (1003, 33, 21), (4099, 7, 8), (7, 3, 2)])
+def test_gradients_snp_design(dtype, n, p, L):
+    """2-bit SNP designs go through the same K-wide sweep (the calls of a column are decoded once per eight vectors)."""
     rng = np.random.RandomState(3)
-    n, p, L = 500, 70, 5
     calls = rng.choice([0, 1, 2, -9], size=(n, p), p=[0.6, 0.25, 0.1, 0.05]).astype(np.int8)
-    Xs = ad.matrix.snp_calldata(calls)
+    Xs = ad.matrix.snp_calldata(calls, dtype=dtype)
     imp = ad.matrix.compute_impute(calls)
     dense = np.where(calls < 0, imp[None], calls).astype(np.float64)
-    R = rng.normal(size=(L, n))
-    assert np.allclose(dg.gradients(Xs, R), R @ dense, atol=1e-11)
+    R = rng.normal(size=(L, n)).astype(dtype)
+    g = dg.gradients(Xs, R)
+    assert g.dtype == dtype
+    assert np.allclose(g, R.astype(np.float64) @ dense, atol=1e-11 if dtype == np.float64 else 5e-3)
+    one = np.empty(p, dtype=dtype)
+    Xs.mul(R[1], np.ones(n, dtype=dtype), one)
+    assert np.allclose(g[1], one, atol=1e-11 if dtype == np.float64 else 5e-3)
 
 
 def _check_kkt(state, d, rtol):

@@ -4,9 +4,7 @@ This is the only place where Python touches the native library.  It replaces wha
 ``adelie.adelie_core`` (the pybind11 module, reference ``adelie/src/py_adelie_core.cpp:6-44``)
 is for the reference: the boundary between the Python API layer and the native solver.
 
-The binding is written against a *symbol prefix* so that the test-suite can bind the CPU
-oracle (``oracle/liboracle.so``, prefix ``oracle_``) through the very same structures; the
-product itself only ever binds ``adelie_hip_`` and raises if the HIP library is missing.
+There is no CPU fallback: a missing ``libadelie_hip.so`` raises.
 """
 import ctypes as C
 import os
@@ -17,8 +15,19 @@ F32, F64 = 0, 1
 COL_MAJOR, ROW_MAJOR = 0, 1
 SCREEN_STRONG, SCREEN_PIVOT = 0, 1
 GLM_GAUSSIAN, GLM_BINOMIAL_LOGIT, GLM_GAUSSIAN_IRLS, GLM_MULTINOMIAL, GLM_POISSON, GLM_BINOMIAL_PROBIT = 0, 1, 2, 3, 4, 5
+GLM_CALLBACK = 6  # a Python subclass of glm.GlmBase64/32, evaluated by host callbacks
 
-POLL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int64)
+# int poll(void* user, int final, int64_t n_solutions, const adelie_hip_result* live)
+POLL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p)
+GLM_GRADIENT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+GLM_HESSIAN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+GLM_LOSS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double))
+
+
+class GlmCallbacks(C.Structure):
+    """``adelie_hip_glm_callbacks``."""
+
+    _fields_ = [("user", C.c_void_p), ("gradient", GLM_GRADIENT_FN), ("hessian", GLM_HESSIAN_FN), ("loss", GLM_LOSS_FN)]
 
 
 class GrpnetArgs(C.Structure):
@@ -83,6 +92,7 @@ class GrpnetArgs(C.Structure):
         ("lmda", C.c_double),
         ("poll", POLL_FN),
         ("poll_user", C.c_void_p),
+        ("glm_cb", C.POINTER(GlmCallbacks)),
     ]
 
 
@@ -117,7 +127,7 @@ HIP_SYMBOLS = [
     "design_device", "design_stream",
     "design_cmul", "design_ctmul", "design_bmul", "design_btmul", "design_mul", "design_mul_batch", "design_cov",
     "design_sq_mul", "design_sp_tmul",
-    "grpnet_solve", "result_destroy", "result_size", "result_copy", "result_scalar", "result_error",
+    "grpnet_solve", "result_destroy", "result_size", "result_copy", "result_scalar", "result_error", "result_sync",
     "bench_sweep",
 ]
 
@@ -136,19 +146,18 @@ def dtype_code(dtype):
 
 
 class Backend:
-    """A loaded native library exposing the adelie_hip ABI under ``prefix``."""
+    """``libadelie_hip.so`` with the argument types of include/adelie_hip.h attached."""
 
-    def __init__(self, path, prefix):
+    def __init__(self, path):
         self.path = path
-        self.prefix = prefix
         self.lib = C.CDLL(path)
         self._setup()
 
     def fn(self, name):
-        return getattr(self.lib, self.prefix + name)
+        return getattr(self.lib, "adelie_hip_" + name)
 
     def has(self, name):
-        return hasattr(self.lib, self.prefix + name)
+        return hasattr(self.lib, "adelie_hip_" + name)
 
     def _setup(self):
         p, i64, dbl, vp, ci = C.POINTER, C.c_int64, C.c_double, C.c_void_p, C.c_int
@@ -197,6 +206,7 @@ class Backend:
         sig("result_copy", ci, [vp, ci, vp, i64])
         sig("result_scalar", dbl, [vp, ci])
         sig("result_error", C.c_char_p, [vp])
+        sig("result_sync", ci, [vp])
         sig("bench_sweep", ci, [vp, i64, p(dbl)])
 
     def check(self, rc):
@@ -239,7 +249,7 @@ def hip_backend():
             import torch  # noqa: F401
         except Exception:  # torch is optional plumbing
             pass
-        _HIP = Backend(path, "adelie_hip_")
+        _HIP = Backend(path)
     return _HIP
 
 

@@ -113,10 +113,12 @@ __global__ __launch_bounds__(RT) void irls_prepare_kernel(int kind, const T* __r
                                                           T* __restrict__ hess, T* __restrict__ irls_resid,
                                                           T* __restrict__ irls_y, T* sums, int K) {
     T acc[1] = {T(0)};
+    // user-defined GLM (kind CALLBACK): hess and irls_resid arrive filled with glm.hessian() / glm.inv_hessian_gradient()
+    const bool cb = kind == ADELIE_HIP_GLM_CALLBACK;
     GRID_STRIDE(i, n) {
-        const T h0 = glm_hess(kind, y[i], w[i], resid[i], eta[i], K);
+        const T h0 = cb ? hess[i] : glm_hess(kind, y[i], w[i], resid[i], eta[i], K);
         const T h = (h0 > T(0) ? h0 : T(0)) + hmin * T(h0 <= T(0));
-        const T z = resid[i] / h; // inv_hessian_gradient uses the same raised hessian (glm_base.ipp:32-36)
+        const T z = cb ? irls_resid[i] : resid[i] / h; // inv_hessian_gradient uses the same raised hessian (glm_base.ipp:32-36)
         hess[i] = h;
         irls_resid[i] = z;
         irls_y[i] = z + eta[i] - off[i];
@@ -151,7 +153,8 @@ __global__ __launch_bounds__(RT) void irls_finish_kernel(int kind, const T* __re
     GRID_STRIDE(i, n) {
         const T e = irls_y[i] + off[i] - irls_resid[i] + shift;
         eta[i] = e;
-        if (kind != ADELIE_HIP_GLM_MULTINOMIAL) resid[i] = glm_grad(kind, y[i], w[i], e); // multinomial: row-coupled, below
+        // multinomial: row-coupled, below; a user-defined GLM's gradient is a host callback on the new eta
+        if (kind != ADELIE_HIP_GLM_MULTINOMIAL && kind != ADELIE_HIP_GLM_CALLBACK) resid[i] = glm_grad(kind, y[i], w[i], e);
     }
 }
 
@@ -189,12 +192,14 @@ __global__ __launch_bounds__(RT) void glm_loss2_kernel(int kind, const T* __rest
 template <class T>
 __global__ __launch_bounds__(RT) void null_step_kernel(int kind, const T* __restrict__ y, const T* __restrict__ w,
                                                        const T* __restrict__ eta, const T* __restrict__ resid,
-                                                       const T* __restrict__ off, T hmin, int64_t n, T* sums, int K) {
+                                                       const T* __restrict__ off, T hmin, int64_t n, T* sums, int K,
+                                                       const T* __restrict__ cb_hess, const T* __restrict__ cb_z) {
     T acc[2] = {T(0), T(0)};
+    const bool cb = kind == ADELIE_HIP_GLM_CALLBACK;
     GRID_STRIDE(i, n) {
-        const T h0 = glm_hess(kind, y[i], w[i], resid[i], eta[i], K);
+        const T h0 = cb ? cb_hess[i] : glm_hess(kind, y[i], w[i], resid[i], eta[i], K);
         const T h = (h0 > T(0) ? h0 : T(0)) + hmin * T(h0 <= T(0));
-        const T z = resid[i] / h;
+        const T z = cb ? cb_z[i] : resid[i] / h;
         acc[0] += h;
         acc[1] += h * (z + eta[i] - off[i]);
     }
@@ -356,9 +361,9 @@ void launch_multi_loss2(int kind, const T* y, const T* wa, const T* wb, const T*
 }
 template <class T>
 void launch_null_step(int kind, const T* y, const T* w, const T* eta, const T* resid, const T* offsets, T hessian_min,
-                      int64_t n, T* sums, hipStream_t s, int K) {
+                      int64_t n, T* sums, hipStream_t s, int K, const T* cb_hess, const T* cb_z) {
     hipLaunchKernelGGL((null_step_kernel<T>), dim3(RB), dim3(RT), 0, s, kind, y, w, eta, resid, offsets, hessian_min, n,
-                       sums, K);
+                       sums, K, cb_hess, cb_z);
     finish(sums, 2, s);
 }
 template <class T>
@@ -389,7 +394,7 @@ void launch_gather(const T* src, const int32_t* idx, int64_t cnt, T* dst, hipStr
     template void launch_multi_loss2<T>(int, const T*, const T*, const T*, const T*, const T*, const T*, int64_t, int, T*, \
                                         hipStream_t);                                                                  \
     template void launch_null_step<T>(int, const T*, const T*, const T*, const T*, const T*, T, int64_t, T*,           \
-                                      hipStream_t, int);                                                                  \
+                                      hipStream_t, int, const T*, const T*);                                                                \
     template void launch_set_eta<T>(const T*, T, int64_t, T*, hipStream_t);                                            \
     template void launch_dot_diff<T>(const T*, const T*, const T*, const T*, int64_t, T*, hipStream_t);                \
     template void launch_gather<T>(const T*, const int32_t*, int64_t, T*, hipStream_t);

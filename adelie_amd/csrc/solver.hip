@@ -46,7 +46,7 @@ template <class T>
 void launch_glm_loss(int kind, const T* y, const T* w, const T* eta, int64_t n, T* out1, hipStream_t s, int K = 1);
 template <class T>
 void launch_null_step(int kind, const T* y, const T* w, const T* eta, const T* resid, const T* offsets, T hessian_min,
-                      int64_t n, T* sums2, hipStream_t s, int K = 1);
+                      int64_t n, T* sums2, hipStream_t s, int K = 1, const T* cb_hess = nullptr, const T* cb_z = nullptr);
 template <class T>
 void launch_set_eta(const T* offsets, T beta0, int64_t n, T* eta, hipStream_t s);
 template <class T>
@@ -322,6 +322,9 @@ struct Solver {
     int glm_kind;
     adelie_hip_poll_fn poll;
     void* poll_user;
+    const adelie_hip_result* live = nullptr; // the handle poll() receives: the state being solved (py_state.cpp:62-91)
+    adelie_hip_glm_callbacks glm_cb{};       // glm_kind == CALLBACK: the user's GlmBase subclass, evaluated on the host
+    std::vector<T> cb_eta, cb_grad, cb_hess, cb_z;
     idx max_gs = 1;
     bool all_scalar = true;
     // ---- dynamic host state ----
@@ -1111,7 +1114,7 @@ struct Solver {
     }
 
     void poll_mid() {
-        if (poll && poll(poll_user, 0, int64_t(lmdas.size()))) throw core_error("interrupted");
+        if (poll && poll(poll_user, 0, int64_t(lmdas.size()), live)) throw core_error("interrupted");
     }
 
     // ---------------------------------------------------------------------------------------------------------
@@ -2056,6 +2059,54 @@ struct Solver {
         return h;
     }
 
+    // ---- GlmBase members: device kernels for the built-in families, host callbacks for a user-defined one ----
+    bool glm_is_cb() const { return glm_kind == ADELIE_HIP_GLM_CALLBACK; }
+    void cb_fetch(const T* dev, std::vector<T>& host) {
+        host.resize(size_t(n));
+        AHIP_CHECK(hipMemcpyAsync(host.data(), dev, size_t(n) * sizeof(T), hipMemcpyDeviceToHost, st));
+    }
+    void cb_store(const std::vector<T>& host, T* dev) {
+        AHIP_CHECK(hipMemcpyAsync(dev, host.data(), size_t(n) * sizeof(T), hipMemcpyHostToDevice, st));
+        sync(); // the host vector is reused by the next callback
+    }
+    // resid = glm.gradient(eta)
+    void glm_gradient_dev(const T* eta_dev, T* r_dev) {
+        if (!glm_is_cb()) {
+            launch_glm_gradient<T>(glm_kind, d_y.p, d_gw.p, eta_dev, n, r_dev, st, mk());
+            return;
+        }
+        cb_fetch(eta_dev, cb_eta);
+        sync();
+        cb_grad.resize(size_t(n));
+        if (glm_cb.gradient(glm_cb.user, cb_eta.data(), cb_grad.data())) throw make_solver_error("glm.gradient() raised.");
+        cb_store(cb_grad, r_dev);
+    }
+    // glm.loss(eta)
+    T glm_loss_dev(const T* eta_dev) {
+        if (!glm_is_cb()) {
+            launch_glm_loss<T>(glm_kind, d_y.p, d_gw.p, eta_dev, n, d_sums.p, st, mk());
+            return device_scalar(d_sums.p);
+        }
+        cb_fetch(eta_dev, cb_eta);
+        sync();
+        double l = 0;
+        if (glm_cb.loss(glm_cb.user, cb_eta.data(), &l)) throw make_solver_error("glm.loss() raised.");
+        return T(l);
+    }
+    // user-defined GLM: hess_dev = glm.hessian(eta, resid), z_dev = glm.inv_hessian_gradient(eta, resid, hess), which the
+    // CALLBACK branch of the IRLS kernels reads instead of evaluating a built-in family
+    void glm_hessian_cb(const T* eta_dev, const T* r_dev, T* hess_dev, T* z_dev) {
+        cb_fetch(eta_dev, cb_eta);
+        cb_fetch(r_dev, cb_grad);
+        sync();
+        cb_hess.resize(size_t(n));
+        cb_z.resize(size_t(n));
+        if (glm_cb.hessian(glm_cb.user, cb_eta.data(), cb_grad.data(), cb_hess.data(), cb_z.data()))
+            throw make_solver_error("glm.hessian() raised.");
+        cb_store(cb_hess, hess_dev);
+        cb_store(cb_z, z_dev);
+    }
+
     FitOut<T> glm_fit(T lm) {
         FitOut<T> o;
         size_t irls_it = 0;
@@ -2068,6 +2119,7 @@ struct Solver {
             sw_irls.start();
             // :336-348
             T sums[4];
+            if (glm_is_cb()) glm_hessian_cb(d_eta.p, d_r.p, d_hess.p, d_irls_resid.p);
             launch_irls_prepare<T>(glm_kind, d_y.p, d_gw.p, d_eta.p, d_r.p, d_off.p, hmin, n, d_hess.p, d_irls_resid.p,
                                    d_irls_y.p, d_sums.p, st, mk());
             d_sums.download(sums, 1, st);
@@ -2141,6 +2193,7 @@ struct Solver {
             std::swap(d_r.p, d_resid_prev.p);
             launch_irls_finish<T>(glm_kind, d_y.p, d_gw.p, d_irls_y.p, d_off.p, d_irls_resid.p,
                                   intercept ? (beta0 - ym) : T(0), n, d_eta.p, d_r.p, d_sums.p, st, mk());
+            if (glm_is_cb()) glm_gradient_dev(d_eta.p, d_r.p);
             launch_dot_diff<T>(d_r.p, d_resid_prev.p, d_eta.p, d_eta_prev.p, n, d_sums.p, st);
             const T conv = device_scalar(d_sums.p);
             if (std::abs(conv) <= irls_tol) {
@@ -2195,8 +2248,7 @@ struct Solver {
             }
         }
         if (!intercept) {
-            launch_glm_loss<T>(glm_kind, d_y.p, d_gw.p, d_off.p, n, d_sums.p, st, mk());
-            loss_null = device_scalar(d_sums.p);
+            loss_null = glm_loss_dev(d_off.p);
             return;
         }
         T b0 = beta0;
@@ -2209,19 +2261,19 @@ struct Solver {
         while (1) {
             if (it >= irls_max_iters) throw make_solver_error("Maximum IRLS iterations reached.");
             T sums[2];
-            launch_null_step<T>(glm_kind, d_y.p, d_gw.p, e.p, r.p, d_off.p, hmin, n, d_sums.p, st, mk());
+            if (glm_is_cb()) glm_hessian_cb(e.p, r.p, d_hess.p, d_irls_y.p);
+            launch_null_step<T>(glm_kind, d_y.p, d_gw.p, e.p, r.p, d_off.p, hmin, n, d_sums.p, st, mk(), d_hess.p, d_irls_y.p);
             d_sums.download(sums, 2, st);
             sync();
             b0 = sums[1] / sums[0];
             std::swap(e.p, e_prev.p);
             launch_set_eta<T>(d_off.p, b0, n, e.p, st);
             std::swap(r.p, r_prev.p);
-            launch_glm_gradient<T>(glm_kind, d_y.p, d_gw.p, e.p, n, r.p, st, mk());
+            glm_gradient_dev(e.p, r.p);
             launch_dot_diff<T>(r.p, r_prev.p, e.p, e_prev.p, n, d_sums.p, st);
             const T conv = device_scalar(d_sums.p);
             if (std::abs(conv) <= irls_tol) {
-                launch_glm_loss<T>(glm_kind, d_y.p, d_gw.p, e.p, n, d_sums.p, st, mk());
-                loss_null = device_scalar(d_sums.p);
+                loss_null = glm_loss_dev(e.p);
                 return;
             }
             ++it;
@@ -2286,8 +2338,7 @@ struct Solver {
         intercepts.push_back(fo.intercept);
         lmdas.push_back(lm);
         if (is_glm()) { // solver_glm_naive.hpp:153-157
-            launch_glm_loss<T>(glm_kind, d_y.p, d_gw.p, d_eta.p, n, d_sums.p, st, mk());
-            const T loss = device_scalar(d_sums.p);
+            const T loss = glm_loss_dev(d_eta.p);
             devs.push_back((loss_null - loss) / (loss_null - loss_full));
         } else {
             devs.push_back(fo.rsq / y_var);
@@ -2296,7 +2347,7 @@ struct Solver {
 
     bool early_exit_f() {
         const bool ee = early_exit();
-        const bool ec = poll && poll(poll_user, 1, int64_t(lmdas.size()));
+        const bool ec = poll && poll(poll_user, 1, int64_t(lmdas.size()), live);
         return ee || ec;
     }
 
@@ -2423,6 +2474,12 @@ struct Solver {
                              (long long)gram_shapes[i].second, t_gram.each[i], fl / (t_gram.each[i] * 1e-3) / 1e12);
             }
         }
+        download_invariants();
+    }
+
+    // host mirrors of the device-resident invariants (grad, resid, eta, screen_beta, screen_X_means, screen_vars); also what
+    // adelie_hip_result_sync does for the live state inside a poll callback
+    void download_invariants() {
         d_grad.download(grad.data(), size_t(p), st);
         d_r.download(resid.data(), size_t(n), st);
         if (is_glm()) d_eta.download(eta.data(), size_t(n), st);
@@ -2463,6 +2520,11 @@ struct Solver {
         early_exit_ = a->early_exit; setup_lmda_max = a->setup_lmda_max; setup_lmda_path = a->setup_lmda_path;
         intercept = a->intercept; glm_kind = a->glm_kind;
         poll = a->poll; poll_user = a->poll_user;
+        if (glm_kind == ADELIE_HIP_GLM_CALLBACK) {
+            if (!a->glm_cb || !a->glm_cb->gradient || !a->glm_cb->hessian || !a->glm_cb->loss)
+                throw make_core_error("glm_cb with gradient, hessian and loss is required for a user-defined GLM.");
+            glm_cb = *a->glm_cb;
+        }
         lmda_max = T(a->lmda_max);
         if (a->lmda_path && a->n_lmda_path > 0) lmda_path.assign((const T*)a->lmda_path, (const T*)a->lmda_path + a->n_lmda_path);
         screen_set.assign(a->screen_set, a->screen_set + a->screen_set_size);
@@ -2638,6 +2700,7 @@ struct Solver {
 
 struct ResultBase {
     virtual ~ResultBase() {}
+    virtual void sync_live() = 0;
     virtual int64_t size(int which) const = 0;
     virtual int copy(int which, void* out, int64_t cap) const = 0;
     virtual double scalar(int which) const = 0;
@@ -2658,6 +2721,7 @@ void cp_i(const V& v, int64_t* out, int64_t cap) {
 template <class T>
 struct Result : ResultBase {
     Solver<T> s;
+    void sync_live() override { s.download_invariants(); }
     int64_t size(int which) const override {
         switch (which) {
             case ADELIE_HIP_V_INTERCEPTS: return s.intercepts.size();
@@ -2788,14 +2852,23 @@ struct Result : ResultBase {
 };
 
 template <class T>
-ResultBase* run(adelie_hip_design* X, const adelie_hip_grpnet_args* a) {
+void run(adelie_hip_design* X, const adelie_hip_grpnet_args* a, adelie_hip_result* res);
+
+} // namespace
+
+struct adelie_hip_result {
+    ResultBase* r = nullptr;
+    ~adelie_hip_result() { delete r; }
+};
+
+namespace {
+
+template <class T>
+void run(adelie_hip_design* X, const adelie_hip_grpnet_args* a, adelie_hip_result* res) {
     auto* r = new Result<T>();
-    try {
-        r->s.build(X, a);
-    } catch (...) {
-        delete r;
-        throw;
-    }
+    res->r = r; // owned by `res` from here on (the poll callbacks read the live state through it)
+    r->s.live = res;
+    r->s.build(X, a);
     Stopwatch sw;
     sw.start();
     struct BatchGuard { // registered for sweep batching exactly while the path runs
@@ -2823,15 +2896,10 @@ ResultBase* run(adelie_hip_design* X, const adelie_hip_grpnet_args* a) {
         if (r->s.error.empty()) r->s.error = e.what();
     }
     r->s.total_time = sw.elapsed();
-    return r;
+    r->s.live = nullptr;
 }
 
 } // namespace
-
-struct adelie_hip_result {
-    ResultBase* r = nullptr;
-    ~adelie_hip_result() { delete r; }
-};
 
 void adelie_hip_internal_free_batcher(void* b) { delete static_cast<SweepBatcher*>(b); }
 
@@ -2854,7 +2922,8 @@ int adelie_hip_grpnet_solve(adelie_hip_design* X, const adelie_hip_grpnet_args* 
         if (!X || !args || !out) throw make_core_error("null argument.");
         auto* res = new adelie_hip_result();
         try {
-            res->r = (X->dtype == ADELIE_HIP_F64) ? run<double>(X, args) : run<float>(X, args);
+            if (X->dtype == ADELIE_HIP_F64) run<double>(X, args, res);
+            else run<float>(X, args, res);
         } catch (...) {
             delete res;
             throw;
@@ -2874,6 +2943,16 @@ int64_t adelie_hip_result_size(const adelie_hip_result* r, int which) { return r
 int adelie_hip_result_copy(const adelie_hip_result* r, int which, void* out, int64_t cap) { return r->r->copy(which, out, cap); }
 double adelie_hip_result_scalar(const adelie_hip_result* r, int which) { return r->r->scalar(which); }
 const char* adelie_hip_result_error(const adelie_hip_result* r) { return r->r->err(); }
+int adelie_hip_result_sync(const adelie_hip_result* live) {
+    try {
+        if (!live || !live->r) throw make_core_error("null argument.");
+        live->r->sync_live();
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return 1;
+    }
+    return 0;
+}
 
 // Times `reps` launches of the dominant kernel with HIP events on the design's own stream.
 int adelie_hip_bench_sweep(adelie_hip_design* d, int64_t reps, double* ms_per_launch) {

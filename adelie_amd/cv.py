@@ -9,6 +9,7 @@ rows at the end (RCCL over xGMI when the process group backend is ``nccl``, ``gl
 from dataclasses import dataclass
 import logging
 import os
+import threading
 
 import numpy as np
 import scipy.sparse
@@ -18,6 +19,22 @@ from .diagnostic import coefficient, predict
 from .solver import grpnet
 
 logger = logging.getLogger("adelie_amd")
+
+# concurrent folds share their sweeps while at least one cv_grpnet call with folds in flight is running in this process
+_batch_lock = threading.Lock()
+_batch_users = 0
+
+
+def _sweep_batch(backend, on):
+    """Reference-counted switch of the library-wide "sweep_batch" config: two cv_grpnet calls running in one process must not
+    turn it off under each other."""
+    global _batch_users
+    with _batch_lock:
+        _batch_users += 1 if on else -1
+        if (on and _batch_users == 1) or (not on and _batch_users == 0):
+            return backend.fn("set_config")(b"sweep_batch", 1.0 if on else 0.0) == 0
+    return True
+
 
 # families whose per-lambda CV losses adelie_hip_design_multi_path_losses computes (glm_kind it expects)
 _MULTI_KINDS = {"multigaussian": 0, "multinomial": 3}
@@ -111,21 +128,29 @@ def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio
     also share their full-gradient sweeps — those that reach a sweep within a short window are answered by one pass over X — so
     there the default is 8.  The result does not depend on it beyond the summation order of the shared sweeps (last bits).
     """
-    if isinstance(X, np.ndarray):
-        X = matrix.dense(X, method="naive", n_threads=n_threads)
-    assert isinstance(X, (matrix.MatrixNaiveBase64, matrix.MatrixNaiveBase32))
+    rank, world = 0, 1
+    dist = group = None
+    if process_group is not None:
+        import torch.distributed as dist  # noqa: F811
+        group = None if process_group is True else process_group
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+    if isinstance(X, np.ndarray) and world > 1 and dist.get_backend(group) == "nccl":
+        # one replica per rank, on the rank's own GPU (the device torch.distributed was initialised with)
+        import torch
+        X = matrix.dense(X, method="naive", n_threads=n_threads, device=torch.cuda.current_device())
+    X = matrix.as_design(X, n_threads=n_threads)
     n = X.rows()
 
     if seed is not None:
         np.random.seed(seed)
     order = np.random.choice(n, n, replace=False)
-
-    rank, world = 0, 1
-    dist = None
-    if process_group is not None:
-        import torch.distributed as dist  # noqa: F811
-        group = None if process_group is True else process_group
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if world > 1:
+        # the folds must be the same partition on every rank: rank 0's permutation is the one used (an unseeded call would
+        # otherwise draw a different one per process and the gathered loss table would mix folds of different partitions)
+        box = [order]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        order = np.asarray(box[0])
 
     logger_level = logger.level
     logger.setLevel(logging.ERROR)
@@ -170,14 +195,16 @@ def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio
             # by one pass over X (solver.hip::SweepBatcher)
             batch = X._backend.has("set_config") and os.environ.get("ADELIE_HIP_SWEEP_BATCH", "1") != "0"
             if batch:
-                batch = X._backend.fn("set_config")(b"sweep_batch", 1.0) == 0
+                _sweep_batch(X._backend, True)
+            # several folds in flight would interleave their progress bars: off unless asked for
+            grpnet_params.setdefault("progress_bar", False)
             try:
                 with ThreadPoolExecutor(max_workers=nc) as pool:
                     for fold, row in pool.map(run, my_folds):
                         cv_losses[fold] = row
             finally:
                 if batch:
-                    X._backend.fn("set_config")(b"sweep_batch", 0.0)
+                    _sweep_batch(X._backend, False)
     finally:
         logger.setLevel(logger_level)
 

@@ -34,7 +34,42 @@ def _coerce_dtype(y, dtype):
 
 
 class GlmBase:
+    """Base class of every family, and the plugin surface for user-defined ones (reference ``GlmBase{32,64}``,
+    ``glm/glm_base.hpp:19-93``, Python-subclassable through ``py_glm.cpp:8-92``).
+
+    A user-defined single-response family subclasses :class:`GlmBase64` (or :class:`GlmBase32`), calls
+    ``GlmBase64.__init__(self, name, y, weights)`` and implements ``gradient(eta, grad)`` (the NEGATIVE gradient of the
+    loss, written in place), ``hessian(eta, grad, hess)``, ``loss(eta)`` and ``loss_full()``; ``inv_hessian_gradient`` and
+    ``inv_link`` are optional.  ``grpnet`` runs such a family through the IRLS solver on the device and calls these methods
+    on host n-vectors once per IRLS iteration (``adelie_hip_glm_callbacks``)."""
+
     is_multi = False
+    opt = False
+
+    def __init__(self, name, y, weights):
+        self.name = name
+        self.y = y
+        self.weights = weights
+
+    def gradient(self, eta, grad):
+        raise NotImplementedError("gradient() must be implemented by the GLM subclass.")
+
+    def hessian(self, eta, grad, hess):
+        raise NotImplementedError("hessian() must be implemented by the GLM subclass.")
+
+    def loss(self, eta):
+        raise NotImplementedError("loss() must be implemented by the GLM subclass.")
+
+    def loss_full(self):
+        raise NotImplementedError("loss_full() must be implemented by the GLM subclass.")
+
+    def inv_link(self, eta, out):
+        raise NotImplementedError("inv_link() must be implemented by the GLM subclass.")
+
+    # glm_base.ipp:23-37
+    def inv_hessian_gradient(self, eta, grad, hess, inv_hess_grad):
+        hmin = _configs.Configs.hessian_min
+        inv_hess_grad[...] = grad / (np.maximum(hess, 0) + hmin * (hess <= 0))
 
 
 class GlmBase64(GlmBase):

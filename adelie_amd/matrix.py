@@ -780,3 +780,39 @@ def compute_impute(calldata):
     valid = calldata >= 0
     cnt = np.maximum(valid.sum(axis=0), 1)
     return (np.where(valid, calldata, 0).sum(axis=0) / cnt).astype(np.float64)
+
+
+def from_plugin(mat, *, n_threads: int = 1, device: int = 0):
+    """Brings a Python subclass of ``MatrixNaiveBase64/32`` onto the device.
+
+    The reference lets users subclass its matrix base class in Python and calls the overridden ``cmul`` / ``ctmul`` / ... from
+    the C++ solver, one interpreter round trip per coordinate visit (trampoline ``PyMatrixNaiveBase``,
+    ``py_matrix.cpp:626-825``).  A design that lives behind Python callbacks cannot feed a GPU; with 288 GB of HBM the
+    MI355X answer is to evaluate the user's matrix ONCE — column ``j`` is ``ctmul(j, 1, zeros(n))``, by definition of the
+    interface (``matrix_naive_base.hpp:49-59``: ``out += v * X[:, j]``) — and to run the path on the resident dense copy, which
+    is then exactly the matrix the user's methods describe."""
+    out = dense(densify_plugin(mat), method="naive", n_threads=n_threads, device=device)
+    out._plugin = mat
+    return out
+
+
+def densify_plugin(mat):
+    """The ``(n, p)`` F-ordered array a user-defined matrix class describes, column by column through its ``ctmul``."""
+    if not isinstance(mat, (MatrixNaiveBase64, MatrixNaiveBase32)):
+        raise RuntimeError("X must be an ndarray, an adelie_amd.matrix design or a subclass of MatrixNaiveBase64 / MatrixNaiveBase32.")
+    dtype = np.float64 if isinstance(mat, MatrixNaiveBase64) else np.float32
+    n, p = int(mat.rows()), int(mat.cols())
+    out = np.zeros((n, p), dtype=dtype, order="F")
+    for j in range(p):
+        mat.ctmul(j, dtype(1), out[:, j])
+    return out
+
+
+def as_design(X, *, n_threads: int = 1):
+    """What ``grpnet`` / ``cv_grpnet`` / the state constructors accept as ``X``: an ndarray or device tensor (wrapped by
+    :func:`dense`), a native design handle (returned as is), or a user-defined matrix class (:func:`from_plugin`)."""
+    if hasattr(X, "_backend"):
+        return X
+    if isinstance(X, np.ndarray) or type(X).__module__.startswith("torch"):
+        return dense(X, method="naive", n_threads=n_threads)
+    return from_plugin(X, n_threads=n_threads)

@@ -1,353 +1,283 @@
-"""``grpnet`` — mirrors ``adelie.solver.grpnet`` (reference ``adelie/solver.py:354-958``).
+"""``grpnet`` — the entry point ``adelie.solver.grpnet`` of the reference, on an MI355X.
 
-Same keyword arguments, same defaults, same preamble: the initial invariants are computed with two
-``X.mul`` sweeps through the matrix plugin surface (reference ``solver.py:891-904``), the state object
-is built by ``adelie_amd.state`` and ``state.solve()`` runs the whole lambda path on the MI355X.
+The reference's ``grpnet`` (``adelie/solver.py:354-958``) computes the invariants of the starting point in numpy
+(``X_means``, ``y_mean``, ``y_var``, the residual and its gradient: two sweeps over ``X``), fills the keyword
+arguments of a state constructor and calls ``state.solve()``.  The same happens here; the file is organised by *what
+is computed* rather than by family:
 
-``glm.multigaussian`` runs the same solver on the expanded design ``[1 (x) I_K, X (x) I_K]``
-(reference ``solver.py:700-816``); the IRLS route for other multi-response families (multinomial) raises.
+=====================  =====================================================================================
+``_Layout``            the grouping in solver coordinates (``groups``, ``group_sizes``, ``penalty``)
+``_start_*``           the invariants of a cold start for each of the four state kinds
+``_resume``            the same names read off a solved state (``warm_start``)
+``_STATE_OF``          which constructor of ``adelie_amd.state`` takes them
+=====================  =====================================================================================
+
+Every ``X.mul`` below is one C-ABI call into ``libadelie_hip.so`` = one full-gradient sweep kernel over the resident
+design.  Multi-response families (``glm.multigaussian``, ``glm.multinomial``) are solved in the
+coordinates of the expanded design ``[1 (x) I_K, X (x) I_K]`` (reference ``solver.py:700-844``).
 """
+from dataclasses import dataclass
 from typing import Callable
 
 import numpy as np
 
 from . import matrix
-from .state import gaussian_naive as state_gaussian_naive
-from .state import glm_naive as state_glm_naive
-from .state import multigaussian_naive as state_multigaussian_naive
-from .state import multiglm_naive as state_multiglm_naive
+from . import state as _state
+
+# What a warm start hands over, per state kind (attribute names of a solved state == constructor keywords).
+_SCREEN_FIELDS = ("lmda", "lmda_max", "screen_set", "screen_beta", "screen_is_active", "active_set_size", "active_set")
+_INVARIANT_FIELDS = {
+    "gaussian": ("X_means", "y_mean", "y_var", "rsq", "resid", "resid_sum", "grad"),
+    "glm": ("beta0", "eta", "resid", "grad", "loss_null", "loss_full"),
+    "multigaussian": ("X_means", "y_var", "rsq", "resid", "resid_sum", "grad"),
+    "multiglm": ("eta", "resid", "grad", "loss_null", "loss_full"),
+}
+_STATE_OF = {
+    "gaussian": _state.gaussian_naive,
+    "glm": _state.glm_naive,
+    "multigaussian": _state.multigaussian_naive,
+    "multiglm": _state.multiglm_naive,
+}
+
+
+@dataclass
+class _Layout:
+    """Grouping of the solver's coordinates."""
+
+    groups: np.ndarray       # (G,) first column of each group
+    group_sizes: np.ndarray  # (G,)
+    penalty: np.ndarray      # (G,)
+
+    @classmethod
+    def single(cls, groups, p, penalty, dtype):
+        groups = np.arange(p, dtype=int) if groups is None else np.asarray(groups, dtype=int)
+        sizes = np.diff(np.append(groups, p))
+        pen = np.sqrt(sizes).astype(dtype) if penalty is None else np.asarray(penalty, dtype=dtype)
+        return cls(groups, sizes, pen)
+
+    @classmethod
+    def multi(cls, groups, p, K, intercept, penalty, dtype):
+        """Feature groups become groups of ``size*K`` view columns; with an intercept the first ``K`` view columns are ``K``
+        unpenalised singleton groups (reference ``solver.py:705-727``)."""
+        groups = np.arange(p, dtype=int) if groups is None else np.asarray(groups, dtype=int)
+        groups = groups * K
+        if intercept:
+            groups = np.concatenate([np.arange(K), K + groups]).astype(int)
+        sizes = np.diff(np.append(groups, (p + bool(intercept)) * K))
+        if penalty is None:
+            pen = np.sqrt(sizes).astype(dtype)
+            if intercept:
+                pen[:K] = 0
+        else:
+            pen = np.asarray(penalty, dtype=dtype)
+            if intercept:
+                pen = np.concatenate([np.zeros(K, dtype=dtype), pen]).astype(dtype)
+        return cls(groups, sizes, pen)
+
+
+def _start_screen(layout, alpha, dtype):
+    """Cold start of the screen / active sets: every group the penalty cannot zero out (``penalty <= 0`` or no lasso part) is
+    screened and active from the beginning, at ``beta = 0``; ``lmda = inf`` marks "nothing solved yet" (reference
+    ``solver.py:855-866``)."""
+    G = len(layout.groups)
+    always_in = np.flatnonzero((layout.penalty <= 0) | (alpha <= 0))
+    k = len(always_in)
+    active_set = np.empty(G, dtype=int)
+    active_set[:k] = np.arange(k)
+    return {
+        "lmda": np.inf,
+        "lmda_max": None,
+        "screen_set": always_in,
+        "screen_beta": np.zeros(int(layout.group_sizes[always_in].sum()), dtype=dtype),
+        "screen_is_active": np.ones(k, dtype=bool),
+        "active_set_size": k,
+        "active_set": active_set,
+    }
+
+
+def _resume(warm_start, kind):
+    return {name: getattr(warm_start, name) for name in _SCREEN_FIELDS + _INVARIANT_FIELDS[kind]}
+
+
+def _sweep(X, v, weights, dtype):
+    """``X^T (v * weights)`` — one pass over the resident design."""
+    out = np.empty(X.cols(), dtype=dtype)
+    X.mul(np.ascontiguousarray(v, dtype=dtype), weights, out)
+    return out
+
+
+def _start_gaussian(X, glm, offsets, intercept, dtype):
+    """Invariants of ``beta = 0`` for the Gaussian loss ``sum_i w_i (eta_i^2 / 2 - y_i eta_i)`` (reference ``solver.py:886-906``).
+    ``grad`` is handed over WITHOUT the ``-resid_sum * X_means`` centring term: at the start ``resid_sum`` is zero when there
+    is an intercept, and without one the term does not exist."""
+    w = glm.weights
+    n = X.rows()
+    X_means = _sweep(X, np.ones(n, dtype=dtype), w, dtype)
+    y_off = glm.y - offsets
+    y_mean = np.sum(y_off * w)
+    resid = y_off - y_mean if intercept else y_off
+    return {
+        "X_means": X_means,
+        "y_mean": y_mean,
+        "y_var": np.sum(w * resid ** 2),
+        "rsq": 0,
+        "resid": resid,
+        "resid_sum": np.sum(w * resid),
+        "grad": _sweep(X, resid, w, dtype),
+    }
+
+
+def _start_glm(X, glm, offsets, dtype):
+    """Invariants of ``beta = 0, beta0 = 0`` for a general GLM: ``resid`` is the negative gradient of the loss at
+    ``eta = offsets`` and already carries the weights, hence the unit weights of the sweep (reference ``solver.py:925-937``)."""
+    n = X.rows()
+    resid = np.empty(n, dtype=dtype)
+    glm.gradient(offsets, resid)
+    return {
+        "beta0": 0,
+        "eta": offsets,
+        "resid": resid,
+        "grad": _sweep(X, resid, np.ones(n, dtype=dtype), dtype),
+        "loss_null": None,
+        "loss_full": glm.loss_full(),
+    }
+
+
+def _view_gradient(X, R, weights, intercept, dtype):
+    """``[1 (x) I_K, X (x) I_K]^T vec(weights * R)`` for an ``(n, K)`` matrix ``R``, in view-column order (feature-major,
+    response-minor): one sweep of the base design per response; the intercept block is the weighted column sums."""
+    p, K = X.cols(), R.shape[1]
+    out = np.empty((p + bool(intercept), K), dtype=dtype)
+    for l in range(K):
+        col = np.ascontiguousarray(R[:, l], dtype=dtype)
+        out[bool(intercept):, l] = _sweep(X, col, weights, dtype)
+        if intercept:
+            out[0, l] = np.sum(col * weights)
+    return out.ravel()
+
+
+def _start_multigaussian(X, glm, offsets, intercept, dtype):
+    """The multi-response Gaussian loss is the single-response one on the view with weights ``w_i / K`` (reference
+    ``solver.py:742-800``).  With an intercept, R^2 is reported relative to the intercept-only model: it starts at
+    ``-(gain of the intercepts)`` and the fit of the K unpenalised intercept columns brings it to zero."""
+    K = glm.y.shape[-1]
+    wK = glm.weights / K
+    n = X.rows()
+    means = np.repeat(_sweep(X, np.ones(n, dtype=dtype), wK, dtype), K)
+    if intercept:
+        means = np.concatenate([np.full(K, 1 / K), means]).astype(dtype)
+    y_off = glm.y - offsets
+    y_var = np.sum(wK[:, None] * y_off ** 2)
+    rsq = 0
+    if intercept:
+        centred = y_off - (y_off.T @ glm.weights)[None]  # full weights here, as the reference has it (solver.py:769)
+        centred_var = np.sum(wK[:, None] * centred ** 2)
+        rsq, y_var = centred_var - y_var, centred_var
+    return {
+        "X_means": means,
+        "y_var": y_var,
+        "rsq": rsq,
+        "resid": np.ascontiguousarray(y_off, dtype=dtype).ravel(),
+        "resid_sum": np.sum(wK[:, None] * y_off),
+        "grad": _view_gradient(X, y_off, wK, intercept, dtype),
+    }
+
+
+def _start_multiglm(X, glm, offsets, intercept, dtype):
+    """Reference ``solver.py:818-831``; arrays cross into the state flattened ``(n, K)`` row-major."""
+    resid = np.empty(offsets.shape, dtype=dtype)
+    glm.gradient(offsets, resid)
+    return {
+        "eta": offsets.ravel(),
+        "resid": resid.ravel(),
+        "grad": _view_gradient(X, resid, np.ones(X.rows(), dtype=dtype), intercept, dtype),
+        "loss_null": None,
+        "loss_full": glm.loss_full(),
+    }
 
 
 def grpnet(
-    X,
-    glm,
-    *,
-    constraints: list = None,
-    groups: np.ndarray = None,
-    alpha: float = 1,
-    penalty: np.ndarray = None,
-    offsets: np.ndarray = None,
-    lmda_path: np.ndarray = None,
-    irls_max_iters: int = int(1e4),
-    irls_tol: float = 1e-7,
-    max_iters: int = int(1e5),
-    tol: float = 1e-7,
-    adev_tol: float = 0.9,
-    ddev_tol: float = 0,
-    newton_tol: float = 1e-12,
-    newton_max_iters: int = 1000,
-    n_threads: int = 1,
-    early_exit: bool = True,
-    intercept: bool = True,
-    screen_rule: str = "pivot",
-    min_ratio: float = 1e-2,
-    lmda_path_size: int = 100,
-    max_screen_size: int = None,
-    max_active_size: int = None,
-    pivot_subset_ratio: float = 0.1,
-    pivot_subset_min: int = 1,
-    pivot_slack_ratio: float = 1.25,
-    check_state: bool = False,
-    progress_bar: bool = False,
-    warm_start=None,
-    exit_cond: Callable = None,
+    X, glm, *,
+    constraints: list = None, groups: np.ndarray = None, alpha: float = 1, penalty: np.ndarray = None,
+    offsets: np.ndarray = None, lmda_path: np.ndarray = None,
+    irls_max_iters: int = int(1e4), irls_tol: float = 1e-7,
+    max_iters: int = int(1e5), tol: float = 1e-7, adev_tol: float = 0.9, ddev_tol: float = 0,
+    newton_tol: float = 1e-12, newton_max_iters: int = 1000,
+    n_threads: int = 1, early_exit: bool = True, intercept: bool = True,
+    screen_rule: str = "pivot", min_ratio: float = 1e-2, lmda_path_size: int = 100,
+    max_screen_size: int = None, max_active_size: int = None,
+    pivot_subset_ratio: float = 0.1, pivot_subset_min: int = 1, pivot_slack_ratio: float = 1.25,
+    check_state: bool = False, progress_bar: bool = True, warm_start=None, exit_cond: Callable = None,
 ):
-    """Solves group elastic net via the naive method on an MI355X.
+    """Group elastic net along a decreasing path of ``lmda`` on an MI355X (naive method).
 
-    Minimises ``l(eta) + lmda * sum_g penalty_g (alpha ||beta_g|| + (1-alpha)/2 ||beta_g||^2)`` with
-    ``eta = X beta + beta0 + offsets`` along a decreasing path of ``lmda`` (see the reference docstring,
-    ``adelie/solver.py:388-620``, for the meaning of every argument; they are identical).
+    Minimises ``l(eta) + lmda * sum_g penalty_g (alpha ||beta_g|| + (1 - alpha) / 2 ||beta_g||^2)`` with
+    ``eta = X beta + beta0 + offsets``.  Arguments, defaults and the returned state are those of the reference
+    (``adelie/solver.py:388-620`` documents each of them); ``X`` may be an ndarray, a device tensor wrapped by
+    ``adelie_amd.matrix.dense``, any other ``adelie_amd.matrix`` design, or a Python subclass of
+    ``matrix.MatrixNaiveBase64/32`` (densified once into HBM through its own ``ctmul``); ``glm`` any ``adelie_amd.glm`` family
+    or a Python subclass of ``glm.GlmBase64/32`` (evaluated by host callbacks once per IRLS iteration).
 
     Returns
     -------
     state
         The solved state (``betas`` CSR ``(L, p)``, ``intercepts``, ``devs``, ``lmdas`` and the invariants).
     """
-    X_raw = X
-    if isinstance(X, np.ndarray):
-        X = matrix.dense(X, method="naive", n_threads=n_threads)
-    assert isinstance(X, (matrix.MatrixNaiveBase64, matrix.MatrixNaiveBase32))
-    dtype = np.float64 if isinstance(X, matrix.MatrixNaiveBase64) else np.float32
-    n, p = X.rows(), X.cols()
+    X = matrix.as_design(X, n_threads=n_threads)
+    dtype = X.dtype
+    p = X.cols()
 
-    is_multi = bool(getattr(glm, "is_multi", False))
-    if is_multi and not ((glm.name == "multigaussian" and glm.opt) or glm.name == "multinomial"):
-        raise NotImplementedError("adelie_amd.grpnet: of the multi-response GLMs, glm.multigaussian and glm.multinomial are on the device path.")
-    if isinstance(constraints, list) and any(c is not None for c in constraints):
-        raise NotImplementedError("adelie_amd.grpnet: constraints are outside the hot path (pass None).")
+    if isinstance(constraints, list):
+        for c in constraints:  # cached dual state of a previous solve must not leak into this one (solver.py:638-642)
+            if c is not None:
+                c.clear()
 
-    if offsets is not None:
-        offsets = np.asarray(offsets)
-        if offsets.shape != glm.y.shape:
+    if offsets is None:
+        offsets = np.zeros(glm.y.shape, dtype=dtype)
+    else:
+        if np.shape(offsets) != glm.y.shape:
             raise RuntimeError("offsets must be same shape as y if not None.")
         offsets = np.asarray(offsets, order="C", dtype=dtype)
-    else:
-        offsets = np.zeros(glm.y.shape, dtype=dtype)
-
     if lmda_path is not None:
-        lmda_path = np.array(np.flip(np.sort(lmda_path)), dtype=dtype)
+        lmda_path = np.sort(np.asarray(lmda_path))[::-1].astype(dtype)  # decreasing, materialised (not a view)
 
-    solver_args = {
-        "X": X,
-        "constraints": constraints,
-        "alpha": alpha,
-        "offsets": offsets,
-        "lmda_path": lmda_path,
-        "max_iters": max_iters,
-        "tol": tol,
-        "adev_tol": adev_tol,
-        "ddev_tol": ddev_tol,
-        "newton_tol": newton_tol,
-        "newton_max_iters": newton_max_iters,
-        "n_threads": n_threads,
-        "early_exit": early_exit,
-        "intercept": intercept,
-        "screen_rule": screen_rule,
-        "min_ratio": min_ratio,
-        "lmda_path_size": lmda_path_size,
-        "max_screen_size": max_screen_size,
-        "max_active_size": max_active_size,
-        "pivot_subset_ratio": pivot_subset_ratio,
-        "pivot_subset_min": pivot_subset_min,
-        "pivot_slack_ratio": pivot_slack_ratio,
-    }
-
-    is_gaussian_opt = (glm.name in ["gaussian", "multigaussian"]) and glm.opt  # solver.py:683-686
-    if not is_gaussian_opt:
-        solver_args["glm"] = glm
-        solver_args["irls_max_iters"] = irls_max_iters
-        solver_args["irls_tol"] = irls_tol
-    else:
-        solver_args["y"] = glm.y
-        solver_args["weights"] = glm.weights
-
-    if groups is None:
-        groups = np.arange(p, dtype=int)
-    groups = np.asarray(groups, dtype=int)
+    is_multi = bool(getattr(glm, "is_multi", False))
+    closed_form = getattr(glm, "name", None) in ("gaussian", "multigaussian") and bool(getattr(glm, "opt", False))
+    kind = ("multi" if is_multi else "") + ("gaussian" if closed_form else "glm")
 
     if is_multi:
-        return _grpnet_multi(X, glm, groups, penalty, offsets, intercept, alpha, warm_start, solver_args,
-                                     check_state, progress_bar, exit_cond, n, p, dtype, n_threads)
-
-    # single-response GLMs: solver.py:846-950
-    group_sizes = np.concatenate([groups, [p]], dtype=int)
-    group_sizes = group_sizes[1:] - group_sizes[:-1]
-    G = len(groups)
-    if penalty is None:
-        penalty = np.sqrt(group_sizes).astype(dtype)
-    penalty = np.asarray(penalty, dtype=dtype)
-
-    if warm_start is None:
-        lmda = np.inf
-        lmda_max = None
-        screen_set = np.arange(G)[(penalty <= 0) | (alpha <= 0)]
-        screen_beta = np.zeros(np.sum(group_sizes[screen_set]), dtype=dtype)
-        screen_is_active = np.ones(screen_set.shape[0], dtype=bool)
-        active_set_size = screen_set.shape[0]
-        active_set = np.empty(groups.shape[0], dtype=int)
-        active_set[:active_set_size] = np.arange(active_set_size)
+        layout = _Layout.multi(groups, p, glm.y.shape[-1], intercept, penalty, dtype)
     else:
-        lmda = warm_start.lmda
-        lmda_max = warm_start.lmda_max
-        screen_set = warm_start.screen_set
-        screen_beta = warm_start.screen_beta
-        screen_is_active = warm_start.screen_is_active
-        active_set_size = warm_start.active_set_size
-        active_set = warm_start.active_set
+        layout = _Layout.single(groups, p, penalty, dtype)
 
-    solver_args["groups"] = groups
-    solver_args["group_sizes"] = group_sizes
-    solver_args["penalty"] = penalty
-    solver_args["lmda"] = lmda
-    solver_args["lmda_max"] = lmda_max
-    solver_args["screen_set"] = screen_set
-    solver_args["screen_beta"] = screen_beta
-    solver_args["screen_is_active"] = screen_is_active
-    solver_args["active_set_size"] = active_set_size
-    solver_args["active_set"] = active_set
-
-    if is_gaussian_opt:
-        y = glm.y
-        weights = glm.weights
-        if warm_start is None:
-            ones = np.ones(n, dtype=dtype)
-            X_means = np.empty(p, dtype=dtype)
-            X.mul(ones, weights, X_means)
-            y_off = y - offsets
-            y_mean = np.sum(y_off * weights)
-            yc = y_off
-            if intercept:
-                yc = yc - y_mean
-            y_var = np.sum(weights * yc ** 2)
-            rsq = 0
-            resid = yc
-            resid_sum = np.sum(weights * resid)
-            grad = np.empty(p, dtype=dtype)
-            X.mul(resid, weights, grad)
-        else:
-            X_means = warm_start.X_means
-            y_mean = warm_start.y_mean
-            y_var = warm_start.y_var
-            rsq = warm_start.rsq
-            resid = warm_start.resid
-            resid_sum = warm_start.resid_sum
-            grad = warm_start.grad
-        solver_args["X_means"] = X_means
-        solver_args["y_mean"] = y_mean
-        solver_args["y_var"] = y_var
-        solver_args["rsq"] = rsq
-        solver_args["resid"] = resid
-        solver_args["resid_sum"] = resid_sum
-        solver_args["grad"] = grad
-        state = state_gaussian_naive(**solver_args)
+    kwargs = dict(
+        X=X, constraints=constraints, alpha=alpha, offsets=offsets, lmda_path=lmda_path,
+        groups=layout.groups, group_sizes=layout.group_sizes, penalty=layout.penalty,
+        max_iters=max_iters, tol=tol, adev_tol=adev_tol, ddev_tol=ddev_tol, newton_tol=newton_tol,
+        newton_max_iters=newton_max_iters, n_threads=n_threads, early_exit=early_exit, intercept=intercept,
+        screen_rule=screen_rule, min_ratio=min_ratio, lmda_path_size=lmda_path_size,
+        max_screen_size=max_screen_size, max_active_size=max_active_size, pivot_subset_ratio=pivot_subset_ratio,
+        pivot_subset_min=pivot_subset_min, pivot_slack_ratio=pivot_slack_ratio,
+    )
+    if closed_form:
+        kwargs.update(y=glm.y, weights=glm.weights)
     else:
-        if warm_start is None:
-            ones = np.ones(n, dtype=dtype)
-            beta0 = 0
-            eta = offsets
-            resid = np.empty(n, dtype=dtype)
-            glm.gradient(eta, resid)
-            grad = np.empty(p, dtype=dtype)
-            X.mul(resid, ones, grad)
-            loss_null = None
-            loss_full = glm.loss_full()
-        else:
-            beta0 = warm_start.beta0
-            eta = warm_start.eta
-            resid = warm_start.resid
-            grad = warm_start.grad
-            loss_null = warm_start.loss_null
-            loss_full = warm_start.loss_full
-        solver_args["beta0"] = beta0
-        solver_args["grad"] = grad
-        solver_args["eta"] = eta
-        solver_args["resid"] = resid
-        solver_args["loss_null"] = loss_null
-        solver_args["loss_full"] = loss_full
-        state = state_glm_naive(**solver_args)
+        kwargs.update(glm=glm, irls_max_iters=irls_max_iters, irls_tol=irls_tol)
 
+    if warm_start is not None:
+        kwargs.update(_resume(warm_start, kind))
+    else:
+        kwargs.update(_start_screen(layout, alpha, dtype))
+        if kind == "gaussian":
+            kwargs.update(_start_gaussian(X, glm, offsets, intercept, dtype))
+        elif kind == "glm":
+            kwargs.update(_start_glm(X, glm, offsets, dtype))
+        elif kind == "multigaussian":
+            kwargs.update(_start_multigaussian(X, glm, offsets, intercept, dtype))
+        else:
+            kwargs.update(_start_multiglm(X, glm, offsets, intercept, dtype))
+
+    state = _STATE_OF[kind](**kwargs)
     if check_state:
         state.check(method="assert")
-
-    return state.solve(progress_bar=progress_bar, exit_cond=exit_cond)
-
-
-def _grpnet_multi(X, glm, groups, penalty, offsets, intercept, alpha, warm_start, solver_args, check_state,
-                          progress_bar, exit_cond, n, p, dtype, n_threads):
-    """The multi-response branch of the reference's ``grpnet`` (``solver.py:700-844``): ``glm.multigaussian`` (Gaussian naive
-    solver on the expanded design) and ``glm.multinomial`` (IRLS on the expanded design)."""
-    K = glm.y.shape[-1]
-    groups = groups * K  # flatten the grouping index across the classes
-    if intercept:
-        groups = np.concatenate([np.arange(K), K + groups], dtype=int)
-    group_sizes = np.concatenate([groups, [(p + intercept) * K]], dtype=int)
-    group_sizes = group_sizes[1:] - group_sizes[:-1]
-    if penalty is None:
-        penalty = np.sqrt(group_sizes).astype(dtype)
-        if intercept:
-            penalty[:K] = 0
-    else:
-        penalty = np.asarray(penalty, dtype=dtype)
-        if intercept:
-            penalty = np.concatenate([np.zeros(K), penalty], dtype=dtype)
-
-    if warm_start is None:
-        lmda = np.inf
-        lmda_max = None
-        screen_set = np.arange(groups.shape[0])[(penalty <= 0) | (alpha <= 0)]
-        screen_beta = np.zeros(np.sum(group_sizes[screen_set]), dtype=dtype)
-        screen_is_active = np.ones(screen_set.shape[0], dtype=bool)
-        active_set_size = screen_set.shape[0]
-        active_set = np.empty(groups.shape[0], dtype=int)
-        active_set[:active_set_size] = np.arange(active_set_size)
-    else:
-        lmda = warm_start.lmda
-        lmda_max = warm_start.lmda_max
-        screen_set = warm_start.screen_set
-        screen_beta = warm_start.screen_beta
-        screen_is_active = warm_start.screen_is_active
-        active_set_size = warm_start.active_set_size
-        active_set = warm_start.active_set
-
-    solver_args.update(groups=groups, group_sizes=group_sizes, penalty=penalty, lmda=lmda, lmda_max=lmda_max,
-                       screen_set=screen_set, screen_beta=screen_beta, screen_is_active=screen_is_active,
-                       active_set_size=active_set_size, active_set=active_set)
-
-    if not (glm.name == "multigaussian" and glm.opt):  # IRLS route, solver.py:818-844
-        if warm_start is None:
-            eta = offsets
-            resid = np.empty(eta.shape, dtype=dtype)
-            glm.gradient(eta, resid)
-            G = np.empty((p + (1 if intercept else 0), K), dtype=dtype)
-            t = np.empty(p, dtype=dtype)
-            ones = np.ones(n, dtype=dtype)
-            for l in range(K):  # grad = X_aug^T resid, one sweep of the base design per class
-                rl = np.ascontiguousarray(resid[:, l], dtype=dtype)
-                X.mul(rl, ones, t)
-                if intercept:
-                    G[0, l] = np.sum(rl)
-                    G[1:, l] = t
-                else:
-                    G[:, l] = t
-            grad = G.ravel()
-            resid = resid.ravel()
-            loss_null = None
-            loss_full = glm.loss_full()
-            eta = eta.ravel()
-        else:
-            eta = warm_start.eta
-            resid = warm_start.resid
-            grad = warm_start.grad
-            loss_null = warm_start.loss_null
-            loss_full = warm_start.loss_full
-        solver_args.update(grad=grad, eta=eta, resid=resid, loss_null=loss_null, loss_full=loss_full)
-        state = state_multiglm_naive(**solver_args)
-        return state.solve(progress_bar=progress_bar, exit_cond=exit_cond)
-
-    y = glm.y
-    weights = glm.weights
-    weights_mscaled = weights / K
-    if warm_start is None:
-        ones = np.ones(n, dtype=dtype)
-        X_means = np.empty(p, dtype=dtype)
-        X.mul(ones, weights_mscaled, X_means)
-        X_means = np.repeat(X_means, K)
-        if intercept:
-            X_means = np.concatenate([np.full(K, 1 / K), X_means], dtype=dtype)
-        y_off = y - offsets
-        y_var = np.sum(weights_mscaled[:, None] * y_off ** 2)
-        # R^2 starts at (MSE of the intercept-only model) - y_var <= 0 and is brought to 0 by the fit of the unpenalised
-        # intercept columns; normalising by the centred variance then makes it relative to the intercept model
-        # (solver.py:760-772)
-        if intercept:
-            y_off_c = y_off - (y_off.T @ weights)[None]  # weights, not weights_mscaled (sic, solver.py:769)
-            yc_var = np.sum(weights_mscaled[:, None] * y_off_c ** 2)
-            rsq = yc_var - y_var
-            y_var = yc_var
-        else:
-            rsq = 0
-        resid = np.ascontiguousarray(y_off, dtype=dtype).ravel()
-        resid_sum = np.sum(weights_mscaled[:, None] * y_off)
-        # grad = X_aug^T (w' * resid): one sweep of the base design per response
-        G = np.empty((p + (1 if intercept else 0), K), dtype=dtype)
-        t = np.empty(p, dtype=dtype)
-        for l in range(K):
-            rl = np.ascontiguousarray(y_off[:, l], dtype=dtype)
-            X.mul(rl, weights_mscaled, t)
-            if intercept:
-                G[0, l] = np.sum(rl * weights_mscaled)
-                G[1:, l] = t
-            else:
-                G[:, l] = t
-        grad = G.ravel()
-    else:
-        X_means = warm_start.X_means
-        y_var = warm_start.y_var
-        rsq = warm_start.rsq
-        resid = warm_start.resid
-        resid_sum = warm_start.resid_sum
-        grad = warm_start.grad
-
-    solver_args.update(X_means=X_means, y_var=y_var, rsq=rsq, resid=resid, resid_sum=resid_sum, grad=grad)
-    state = state_multigaussian_naive(**solver_args)
     return state.solve(progress_bar=progress_bar, exit_cond=exit_cond)

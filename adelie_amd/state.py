@@ -55,6 +55,105 @@ _TIMERS = ["gram_flops", "t_sweep_ms", "t_gram_ms", "t_cd_ms", "t_axpy_ms", "n_s
            "t_host_screen_ms", "t_panel_step_ms", "n_panel_step_launches"]
 
 
+class _ProgressBar:
+    """The reference's progress bar (a tqdm-style line, ``util/tqdm.hpp``) with its suffix ``[dev:xx.x%]``
+    (``solver_base.hpp:225-239``), rendered on stderr once per saved lambda (at most every 50 ms)."""
+
+    def __init__(self, total, width=10):
+        import sys
+        import time
+
+        self._time = time
+        self._out = sys.stderr
+        self.total, self.width = total, width
+        self.t0 = self.t_last = time.perf_counter()
+        self.n, self.dev = 0, 0.0
+
+    @staticmethod
+    def _clock(sec):
+        sec = int(sec)
+        return "%02d:%02d:%02d" % (sec // 3600, (sec // 60) % 60, sec % 60)
+
+    def _render(self):
+        el = self._time.perf_counter() - self.t0
+        frac = self.n / self.total
+        rate = self.n / el if el > 0 else 0.0
+        left = (self.total - self.n) / rate if rate > 0 else 0.0
+        fill = int(round(frac * self.width))
+        self._out.write("\r%3d%%|%s%s| %d/%d [%s<%s, %.2fit/s] [dev:%.1f%%]" % (
+            int(100 * frac), "\u2588" * fill, " " * (self.width - fill), self.n, self.total, self._clock(el),
+            self._clock(left), rate, 100 * self.dev))
+        self._out.flush()
+
+    def update(self, n, dev):
+        self.n, self.dev, self.stale = n, dev, True
+        now = self._time.perf_counter()
+        if now - self.t_last >= 0.05 or n >= self.total:
+            self.t_last = now
+            self._render()
+            self.stale = False
+
+    def close(self):
+        if getattr(self, "stale", True):
+            self._render()
+        self._out.write("\n")
+        self._out.flush()
+
+
+class live_state:
+    """What ``exit_cond`` receives: the state *while it is being solved* (the reference hands the callback its live C++
+    state, ``py_state.cpp:62-91``).  Attributes are read from the solver on access through the result accessors of
+    include/adelie_hip.h on the ``live`` handle; constructor arguments (``alpha``, ``penalty``, ``groups`` ...) come from the
+    state ``solve()`` was called on.  Only valid inside the callback."""
+
+    _DEVICE_RESIDENT = ("grad", "resid", "eta", "screen_beta", "screen_X_means", "screen_vars")
+    _SCALARS = {"lmda_max": None, "lmda": None, "rsq": None, "resid_sum": None, "beta0": None, "loss_null": None,
+                "loss_full": None, "active_set_size": int}
+
+    def __init__(self, owner, backend, handle):
+        d = self.__dict__
+        d["_owner"], d["_backend"], d["_handle"], d["_synced"] = owner, backend, handle, False
+
+    def __setattr__(self, name, value):
+        raise AttributeError("the live state is read-only")
+
+    @property
+    def n_solutions(self):
+        return int(self._backend.fn("result_size")(self._handle, _abi.V["lmdas"]))
+
+    def _path(self):
+        b, r, o = self._backend, self._handle, self._owner
+        indptr = b.result_vec(r, _abi.I["betas_indptr"], index=True)
+        indices = b.result_vec(r, _abi.I["betas_indices"], index=True)
+        values = b.result_vec(r, _abi.V["betas_values"]).astype(o.dtype)
+        betas = csr_matrix((values, indices, indptr), shape=(len(indptr) - 1, o._X.cols()))
+        return o._tidy_path(betas, b.result_vec(r, _abi.V["intercepts"]).astype(o.dtype))
+
+    def __getattr__(self, name):
+        b, r, o = self._backend, self._handle, self._owner
+        if name == "betas":
+            return self._path()[0]
+        if name == "intercepts":
+            return self._path()[1]
+        if name in self._SCALARS:
+            v = b.fn("result_scalar")(r, _abi.S[name])
+            return int(v) if self._SCALARS[name] is int else o.dtype(v)
+        if name in self._DEVICE_RESIDENT:
+            if not self._synced:
+                b.check(b.fn("result_sync")(r))
+                self.__dict__["_synced"] = True
+            return b.result_vec(r, _abi.V[name]).astype(o.dtype)
+        if name in _abi.V:
+            v = b.result_vec(r, _abi.V[name])
+            return v if name.startswith("benchmark") else v.astype(o.dtype)
+        if name in _abi.I:
+            v = b.result_vec(r, _abi.I[name], index=True)
+            return v.astype(bool) if name == "screen_is_active" else v
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return getattr(o, name)
+
+
 class base:
     """Common machinery of the two naive states."""
 
@@ -64,28 +163,33 @@ class base:
     def _marshal(self):  # pragma: no cover - abstract
         raise NotImplementedError
 
-    def solve(self, progress_bar: bool = False, exit_cond=None):
-        """Runs the path solver; returns a new solved state (reference ``state.py:157-176``).
+    def solve(self, progress_bar: bool = True, exit_cond=None):
+        """Runs the path solver; returns a new solved state (reference ``state.py:157-176``; this state is left untouched).
 
-        ``exit_cond`` takes the number of solutions found so far wrapped in a light view object exposing
-        ``lmdas``-length via ``n_solutions`` (the reference passes the live C++ state; on device the live
-        state is not host-visible mid-path, so only the solution count is offered).
+        ``exit_cond`` is called after every saved lambda with the live state (reference ``py_state.cpp:62-91``,
+        ``solver_base.hpp:581,679``): a :class:`live_state` view whose attributes (``lmdas``, ``devs``, ``betas``,
+        ``intercepts``, ``lmda``, ``screen_set``, ``active_set_size``, ... and on request the device-resident ``grad`` /
+        ``resid`` / ``screen_beta``) are read from the solver at that moment.  An exception raised by it stops the path and is
+        re-raised here.  ``progress_bar`` renders the reference's bar with its ``[dev:xx.x%]`` suffix
+        (``solver_base.hpp:225-239``) on stderr.
         """
         backend = self._X._backend
         args, keep = self._marshal()
-
-        class _View:
-            n_solutions = 0
-
-        view = _View()
         pending = {}
+        total = int(self.lmda_path_size) if self.setup_lmda_path else len(self.lmda_path)
+        bar = _ProgressBar(total) if progress_bar and total > 0 else None
 
-        def _poll(user, final, n_solutions):
+        def _poll(user, final, n_solutions, live):
             try:
-                if final and exit_cond is not None:
-                    view.n_solutions = int(n_solutions)
+                if not final:
+                    return 0
+                view = live_state(self, backend, live) if (bar is not None or exit_cond is not None) else None
+                if bar is not None:
+                    devs = view.devs
+                    bar.update(int(n_solutions), float(devs[-1]) if len(devs) else 0.0)
+                if exit_cond is not None:
                     return 1 if exit_cond(view) else 0
-            except KeyboardInterrupt as e:  # pragma: no cover
+            except BaseException as e:  # noqa: BLE001 - ctypes would swallow it: stop the path, re-raise after the solve
                 pending["exc"] = e
                 return 1
             return 0
@@ -94,8 +198,14 @@ class base:
         args.poll = cb
         args.poll_user = None
         handle = _abi.C.c_void_p()
-        backend.check(backend.fn("grpnet_solve")(self._X._handle, _abi.C.byref(args), handle))
+        try:
+            backend.check(backend.fn("grpnet_solve")(self._X._handle, _abi.C.byref(args), handle))
+        finally:
+            if bar is not None:
+                bar.close()
         del keep
+        if "exc" not in pending and "exc" in getattr(self, "_glm_cb_pending", {}):
+            pending["exc"] = self._glm_cb_pending.pop("exc")
         if "exc" in pending:
             backend.fn("result_destroy")(handle)
             raise pending["exc"]
@@ -109,6 +219,10 @@ class base:
             else:
                 logger.warning(RuntimeError(out.error))
         return out
+
+    def _tidy_path(self, betas, intercepts):
+        """Hook of the multi-response states: splits the per-class intercepts off the coefficient rows."""
+        return betas, intercepts
 
     def _from_result(self, backend, r):
         new = object.__new__(type(self))
@@ -129,6 +243,7 @@ class base:
         values = backend.result_vec(r, _abi.V["betas_values"]).astype(dtype)
         p = self._X.cols()
         new.betas = csr_matrix((values, indices, indptr), shape=(len(indptr) - 1, p))
+        new.betas, new.intercepts = self._tidy_path(new.betas, new.intercepts)
         new.duals = csr_matrix((len(indptr) - 1, 0), dtype=dtype)
         sc = lambda nm: backend.fn("result_scalar")(r, _abi.S[nm])
         new.lmda_max = dtype(sc("lmda_max"))
@@ -314,7 +429,12 @@ class glm_naive_base(base):
         off = np.ascontiguousarray(self._offsets, dtype=dtype)
         eta = np.ascontiguousarray(self.eta, dtype=dtype)
         keep += [y, w, off, eta]
-        a.glm_kind = int(g.core_kind) if g.core_kind != _abi.GLM_GAUSSIAN else _abi.GLM_GAUSSIAN_IRLS
+        kind = getattr(g, "core_kind", _abi.GLM_CALLBACK)
+        a.glm_kind = int(kind) if kind != _abi.GLM_GAUSSIAN else _abi.GLM_GAUSSIAN_IRLS
+        if kind == _abi.GLM_CALLBACK:
+            cbs = self._glm_callbacks(g, len(y))
+            keep.append(cbs)
+            a.glm_cb = _abi.C.pointer(cbs)
         a.glm_y = y.ctypes.data
         a.glm_weights = w.ctypes.data
         a.offsets = off.ctypes.data
@@ -327,6 +447,43 @@ class glm_naive_base(base):
         a.setup_loss_null = int(self.setup_loss_null)
         return a, keep
 
+    def _glm_callbacks(self, glm, n):
+        """``adelie_hip_glm_callbacks`` over a Python subclass of ``glm.GlmBase64/32`` — the role of the reference's trampoline
+        ``PyGlmBase`` (``py_glm.cpp:8-92``): the solver hands host n-vectors, the methods write their outputs in place.  An
+        exception raised by a method aborts the solve and is re-raised by ``solve()``."""
+        ctype = _abi.C.c_double if np.dtype(self.dtype) == np.float64 else _abi.C.c_float
+        pending = self._glm_cb_pending = {}
+
+        def vec(address):
+            return np.ctypeslib.as_array((ctype * n).from_address(address))
+
+        def guarded(f):
+            def call(*args):
+                try:
+                    f(*args)
+                    return 0
+                except BaseException as e:  # noqa: BLE001
+                    pending.setdefault("exc", e)
+                    return 1
+            return call
+
+        @guarded
+        def gradient(user, eta, grad):
+            glm.gradient(vec(eta), vec(grad))
+
+        @guarded
+        def hessian(user, eta, grad, hess, inv_hess_grad):
+            e, g, h = vec(eta), vec(grad), vec(hess)
+            glm.hessian(e, g, h)
+            glm.inv_hessian_gradient(e, g, h, vec(inv_hess_grad))
+
+        @guarded
+        def loss(user, eta, out):
+            out[0] = float(glm.loss(vec(eta)))
+
+        return _abi.GlmCallbacks(None, _abi.GLM_GRADIENT_FN(gradient), _abi.GLM_HESSIAN_FN(hessian),
+                                 _abi.GLM_LOSS_FN(loss))
+
     def _from_result_extra(self, new, backend, r, sc):
         dtype = self.dtype
         new.beta0 = dtype(sc("beta0"))
@@ -336,14 +493,7 @@ class glm_naive_base(base):
 
 
 def _matrix_of(X, n_threads):
-    if isinstance(X, np.ndarray):
-        X = _matrix.dense(X, method="naive", n_threads=n_threads)
-    if not hasattr(X, "_backend"):
-        raise RuntimeError(
-            "adelie_amd: X must be an adelie_amd.matrix design (dense / snp_unphased) or an ndarray; "
-            "Python-subclassed matrices cannot run on the device path."
-        )
-    return X
+    return _matrix.as_design(X, n_threads=n_threads)
 
 
 def gaussian_naive(
@@ -417,21 +567,24 @@ def gaussian_naive(
     return s
 
 
+def _split_class_intercepts(state, betas):
+    """The first ``K`` view columns of a multi-response fit are the per-class intercepts: every solution is split into
+    ``(L, K)`` intercepts and coefficients over ``X (x) I_K`` (``solver_multigaussian_naive.hpp:31-44``,
+    ``py_state.cpp:1352-1366``)."""
+    K, L = state.n_classes, betas.shape[0]
+    if not state.multi_intercept:
+        return betas, np.zeros((L, K), dtype=state.dtype)
+    B = betas.tocsc()
+    return csr_matrix(B[:, K:].tocsr()), np.asarray(B[:, :K].todense(), dtype=state.dtype).reshape(L, K)
+
+
 class multigaussian_naive_base(gaussian_naive_base):
     """MultiGaussian naive state (reference ``state.py:2027-2391``): the Gaussian naive solver with the global intercept
     off on the expanded design ``[1 (x) I_K, X (x) I_K]``; the per-response intercepts are its first ``K`` (unpenalised)
     coefficients and are split off every solution (``solver_multigaussian_naive.hpp:31-44``, ``py_state.cpp:1352-1366``)."""
 
-    def _from_result_extra(self, new, backend, r, sc):
-        gaussian_naive_base._from_result_extra(self, new, backend, r, sc)
-        K = self.n_classes
-        L = new.betas.shape[0]
-        if self.multi_intercept:
-            B = new.betas.tocsc()
-            new.intercepts = np.asarray(B[:, :K].todense(), dtype=self.dtype).reshape(L, K)
-            new.betas = csr_matrix(B[:, K:].tocsr())
-        else:
-            new.intercepts = np.zeros((L, K), dtype=self.dtype)
+    def _tidy_path(self, betas, intercepts):
+        return _split_class_intercepts(self, betas)
 
     def check(self, method: str = None, logger=logger):
         raise NotImplementedError("adelie_amd: check() of the multi-response state.")
@@ -533,16 +686,8 @@ class multiglm_naive_base(glm_naive_base):
         a.glm_weights = w.ctypes.data
         return a, keep
 
-    def _from_result_extra(self, new, backend, r, sc):
-        glm_naive_base._from_result_extra(self, new, backend, r, sc)
-        K = self.n_classes
-        L = new.betas.shape[0]
-        if self.multi_intercept:
-            B = new.betas.tocsc()
-            new.intercepts = np.asarray(B[:, :K].todense(), dtype=self.dtype).reshape(L, K)
-            new.betas = csr_matrix(B[:, K:].tocsr())
-        else:
-            new.intercepts = np.zeros((L, K), dtype=self.dtype)
+    def _tidy_path(self, betas, intercepts):
+        return _split_class_intercepts(self, betas)
 
 
 def multiglm_naive(
@@ -601,10 +746,14 @@ def glm_naive(
     """Creates a GLM, naive method state object (reference ``adelie.state.glm_naive``, ``state.py:2407-2753``)."""
     X = _matrix_of(X, n_threads)
     dtype = X.dtype
-    if not hasattr(glm, "core_kind"):
-        raise RuntimeError(
-            "adelie_amd: glm must be one of adelie_amd.glm.gaussian / binomial / poisson; Python-subclassed GLMs cannot run on device."
-        )
+    if not hasattr(glm, "core_kind"):  # a user-defined family: evaluated through host callbacks (glm_naive_base._glm_callbacks)
+        if not isinstance(glm, (_glm.GlmBase64, _glm.GlmBase32)):
+            raise RuntimeError("glm must be an adelie_amd.glm family or a subclass of adelie_amd.glm.GlmBase64 / GlmBase32.")
+        if getattr(glm, "is_multi", False):
+            raise RuntimeError("adelie_amd: of the multi-response families glm.multigaussian and glm.multinomial run on device; "
+                               "user-defined multi-response GLMs are not supported.")
+        if (np.float64 if isinstance(glm, _glm.GlmBase64) else np.float32) != np.dtype(dtype).type:
+            raise RuntimeError("glm and X must have the same underlying value type (GlmBase64 with a float64 design).")
     (max_screen_size, max_active_size, lmda_path_size, setup_lmda_max, setup_lmda_path, lmda_max, lmda_path) = \
         _render_inputs(groups=groups, lmda_max=lmda_max, lmda_path=lmda_path, lmda_path_size=lmda_path_size,
                        max_screen_size=max_screen_size, max_active_size=max_active_size, dtype=dtype)

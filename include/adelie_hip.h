@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADELIE_HIP_ABI_VERSION 1
+#define ADELIE_HIP_ABI_VERSION 2
 
 enum adelie_hip_dtype { ADELIE_HIP_F32 = 0, ADELIE_HIP_F64 = 1 };
 enum adelie_hip_order { ADELIE_HIP_COL_MAJOR = 0, ADELIE_HIP_ROW_MAJOR = 1 };
@@ -39,6 +39,9 @@ enum adelie_hip_glm_kind {
     ADELIE_HIP_GLM_GAUSSIAN_IRLS = 2,   /* glm.gaussian(opt=False): Gaussian loss forced through StateGlmNaive */
     ADELIE_HIP_GLM_POISSON = 4,         /* glm.poisson (glm_poisson.ipp:14-58): StateGlmNaive + IRLS */
     ADELIE_HIP_GLM_BINOMIAL_PROBIT = 5, /* glm.binomial(link="probit") (glm_binomial.ipp:100-190) */
+    ADELIE_HIP_GLM_CALLBACK = 6,        /* a GlmBase subclass written by the user (Python trampoline PyGlmBase, py_glm.cpp:8-92):
+                                           StateGlmNaive + IRLS with gradient / hessian / loss evaluated by the host
+                                           callbacks of adelie_hip_glm_callbacks on n-vectors, once per IRLS iteration */
     ADELIE_HIP_GLM_MULTINOMIAL = 3      /* glm.multinomial: StateMultiGlmNaive (solver_multiglm_naive.hpp) + IRLS; the design must
                                            be a multi-response view (adelie_hip_design_create_multi).  glm_y is (n, K) row-major,
                                            glm_weights is (n,), offsets / eta / resid are (n, K) row-major (glm_multinomial.ipp) */
@@ -188,7 +191,24 @@ int adelie_hip_design_sp_tmul(adelie_hip_design* d, int64_t L, const int64_t* in
  * with `final`=1, and once per coordinate-descent fit with `final`=0 (the reference polls
  * PyErr_CheckSignals per CD sweep, py_state.cpp:70-74).  Return nonzero to stop:
  *   final=1 -> behaves as exit_cond() == True;  final=0 -> raises "interrupted" into error. */
-typedef int (*adelie_hip_poll_fn)(void* user, int final, int64_t n_solutions);
+typedef int (*adelie_hip_poll_fn)(void* user, int final, int64_t n_solutions, const adelie_hip_result* live);
+/* `live` is the state being solved (the reference hands exit_cond the live C++ state, py_state.cpp:62-91): inside the callback
+ * every adelie_hip_result_* accessor works on it -- lmdas, devs, intercepts, betas so far, screen / active sets, lmda, the
+ * counters.  The device-resident invariants (grad, resid, eta, screen_beta, screen_X_means, screen_vars) are copied to the
+ * host on request only: call adelie_hip_result_sync(live) first.  `live` must not be destroyed or kept by the callback. */
+int adelie_hip_result_sync(const adelie_hip_result* live);
+
+/* Host callbacks of a user-defined single-response GLM (glm_kind == ADELIE_HIP_GLM_CALLBACK).  They replace the virtuals of
+ * GlmBase that the solver calls (glm_base.hpp:19-93; call sites solver_glm_naive.hpp:153,199-231,336-339,439-449): all arrays
+ * are HOST pointers to n values of the design's dtype; return nonzero to abort the solve (recorded in the result's error
+ * string).  `hessian` fills BOTH hess (GlmBase::hessian) and inv_hess_grad (GlmBase::inv_hessian_gradient, which a subclass may
+ * override, glm_base.ipp:23-37) for the given eta and grad = gradient(eta).  loss_full crosses as the scalar in the args. */
+typedef struct adelie_hip_glm_callbacks {
+    void* user;
+    int (*gradient)(void* user, const void* eta, void* grad);
+    int (*hessian)(void* user, const void* eta, const void* grad, void* hess, void* inv_hess_grad);
+    int (*loss)(void* user, const void* eta, double* loss);
+} adelie_hip_glm_callbacks;
 
 typedef struct adelie_hip_grpnet_args {
     /* ---- problem (static) ---- */
@@ -257,6 +277,7 @@ typedef struct adelie_hip_grpnet_args {
     /* ---- callbacks ---- */
     adelie_hip_poll_fn poll;          /* may be NULL */
     void*          poll_user;
+    const adelie_hip_glm_callbacks* glm_cb; /* required iff glm_kind == ADELIE_HIP_GLM_CALLBACK */
 } adelie_hip_grpnet_args;
 
 /* Runs the whole path.  `*out` is always set on return code 0 (even when the solve recorded

@@ -19,6 +19,16 @@ _LIB = os.path.join(_HERE, "liboracle.so")
 _BACKEND = None
 
 
+class OracleBackend(_abi.Backend):
+    """The product's ctypes binding pointed at ``liboracle.so``: same structures and signatures, symbols ``oracle_*``."""
+
+    def fn(self, name):
+        return getattr(self.lib, "oracle_" + name)
+
+    def has(self, name):
+        return hasattr(self.lib, "oracle_" + name)
+
+
 def build(force: bool = False):
     """Compiles the oracle with the committed Makefile (gcc only, no GPU needed)."""
     src = os.path.join(_HERE, "grpnet_oracle.cpp")
@@ -34,7 +44,7 @@ def backend():
     if _BACKEND is None:
         if not os.path.exists(_LIB):
             build()
-        b = _abi.Backend(_LIB, "oracle_")
+        b = OracleBackend(_LIB)
         p, i64, dbl, vp, ci = C.POINTER, C.c_int64, C.c_double, C.c_void_p, C.c_int
         b.fn("design_create_dense").argtypes = [vp, i64, i64, ci, ci, ci, p(vp)]  # last int = n_threads
         b.fn("design_create_snp_calldata").argtypes = [vp, i64, i64, vp, ci, ci, p(vp)]

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in syms if not hasattr(b.lib, s)]
     assert not missing, missing
     assert sorted("adelie_hip_" + s for s in _abi.HIP_SYMBOLS) == syms
-    assert b.fn("abi_version")() == 1
+    assert b.fn("abi_version")() == 2
 
 
 def test_ctypes_struct_matches_c_layout():
@@ -66,7 +66,4 @@ def test_product_never_imports_oracle():
         for fn in files:
             if fn.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".sh")):
                 txt = open(os.path.join(dirpath, fn)).read()
-                assert "oracle" not in txt.lower() or fn == "_abi.py", (fn,)
-    # _abi.py only mentions the oracle in its docstring (prefix mechanism); it must not import or load it
-    txt = open(os.path.join(pkg, "_abi.py")).read()
-    assert "import oracle" not in txt and "liboracle" not in txt.replace("``oracle/liboracle.so``", "")
+                assert "oracle" not in txt.lower(), (fn,)

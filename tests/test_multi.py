@@ -158,7 +158,7 @@ def _solve_on(Xa, X, glm, kw, oracle):
     """Builds the multigaussian state through grpnet's preamble, then swaps in `Xa` (a plain dense design holding the
     materialised Kronecker matrix) as the matrix the solver runs on."""
     captured = {}
-    real = ad.solver.state_multigaussian_naive
+    real = ad.solver._STATE_OF["multigaussian"]
 
     def spy(**a):
         s = real(**a)
@@ -166,11 +166,11 @@ def _solve_on(Xa, X, glm, kw, oracle):
         captured["s"] = s
         return s
 
-    ad.solver.state_multigaussian_naive = spy
+    ad.solver._STATE_OF["multigaussian"] = spy
     try:
         return ad.grpnet(X=oracle.dense(X), glm=glm, **kw)
     finally:
-        ad.solver.state_multigaussian_naive = real
+        ad.solver._STATE_OF["multigaussian"] = real
 
 
 def test_cv_grpnet_multi_response(oracle):

@@ -113,7 +113,7 @@ S = dict(
     total_time=8,
     n_basil_iters=50, n_sweeps=51, n_cd_visits_screen=52, n_cd_visits_active=53, n_updates=54,
     n_irls_iters=55, n_new_screen_cols=56, n_cd_passes_screen=57, n_cd_passes_active=58,
-    n_gram_col_reads=59, n_resid_col_reads=60, gram_flops=61, n_panel_blocks=62, n_panel_grams=63, n_panel_cols=64,
+    n_gram_col_reads=59, n_resid_col_reads=60, gram_flops=61, n_panel_blocks=62, n_panel_grams=63, n_panel_cols=64, n_irls_screen_cols=65,
     t_sweep_ms=80, t_gram_ms=81, t_cd_ms=82, t_axpy_ms=83, n_sweep_launches=84, n_gram_launches=85,
     t_host_screen_ms=86, t_panel_step_ms=87, n_panel_step_launches=88,
 )
@@ -123,7 +123,7 @@ HIP_SYMBOLS = [
     "abi_version", "last_error", "device_count", "set_config",
     "design_create_dense", "design_create_sparse", "design_adopt_dense_dev", "design_create_snp_unphased",
     "design_create_snp_calldata", "design_create_snp_bed", "design_alias", "design_create_multi", "design_create_derived", "design_create_concat", "design_impute", "design_destroy",
-    "design_glm_path_losses", "design_multi_path_losses", "design_rows", "design_cols", "design_dtype",
+    "design_glm_path_losses", "design_multi_path_losses", "design_batch_stats", "design_rows", "design_cols", "design_dtype",
     "design_device", "design_stream",
     "design_cmul", "design_ctmul", "design_bmul", "design_btmul", "design_mul", "design_mul_batch", "design_cov",
     "design_sq_mul", "design_sp_tmul",
@@ -180,6 +180,7 @@ class Backend:
         sig("design_create_snp_bed", ci, [vp, i64, i64, i64, ci, ci, p(vp)])
         sig("design_impute", ci, [vp, vp])
         sig("design_alias", ci, [vp, p(vp)])
+        sig("design_batch_stats", ci, [vp, p(dbl)])
         sig("design_create_multi", ci, [vp, i64, ci, p(vp)])
         sig("design_create_derived", ci, [vp, vp, i64, vp, i64, vp, vp, p(vp)])
         sig("design_create_concat", ci, [vp, i64, ci, p(vp)])

@@ -514,6 +514,7 @@ void concat_t(adelie_hip_design* const* srcs, int64_t k, int axis, adelie_hip_de
 } // namespace
 
 void adelie_hip_internal_free_batcher(void* b); // solver.hip
+void adelie_hip_internal_batch_stats(void* b, double* out);
 
 extern "C" {
 
@@ -596,6 +597,32 @@ int adelie_hip_design_create_snp_calldata(const int8_t* calldata, int64_t n, int
     ABI_CATCH
 }
 
+// Decodes one column of a .snpdat image into int8 calls (missing = -9; `col` zeroed by the caller).  Every read is checked
+// against the end of the column BEFORE it happens (io_snp_unphased.ipp:117-135,225-274 is the layout).
+static void decode_snpdat_column(const uint8_t* buf, uint64_t base, uint64_t endc, uint64_t n, int8_t* col) {
+    for (int c = 0; c < 3; ++c) {
+        const uint64_t off = read_as<uint64_t>(buf + base + 8 * c);
+        if (off > endc - base || endc - base - off < 4) throw make_core_error("corrupt .snpdat category offset.");
+        uint64_t pos = base + off;
+        const uint32_t n_chunks = read_as<uint32_t>(buf + pos);
+        pos += 4;
+        const int8_t val = c == 0 ? int8_t(-9) : int8_t(c);
+        for (uint32_t k = 0; k < n_chunks; ++k) {
+            if (endc - pos < 5) throw make_core_error("corrupt .snpdat chunk (overrun).");
+            const uint32_t cidx = read_as<uint32_t>(buf + pos);
+            const uint32_t cnt = uint32_t(buf[pos + 4]) + 1;
+            pos += 5;
+            if (endc - pos < cnt) throw make_core_error("corrupt .snpdat chunk (overrun).");
+            for (uint32_t t = 0; t < cnt; ++t) {
+                const uint64_t row = uint64_t(cidx) * 256 + buf[pos + t];
+                if (row >= n) throw make_core_error("corrupt .snpdat chunk (row out of range).");
+                col[row] = val;
+            }
+            pos += cnt;
+        }
+    }
+}
+
 int adelie_hip_design_create_snp_unphased(const void* snpdat, int64_t n_bytes, int dtype, int device,
                                           adelie_hip_design** out) {
     ABI_TRY
@@ -603,41 +630,56 @@ int adelie_hip_design_create_snp_unphased(const void* snpdat, int64_t n_bytes, i
     const uint8_t* buf = static_cast<const uint8_t*>(snpdat);
     if (n_bytes < 17) throw make_core_error("buffer is too small to be a .snpdat image.");
     const uint64_t n = read_as<uint64_t>(buf + 1), p = read_as<uint64_t>(buf + 9);
+    // Nothing below is sized from the header before the header is bounded.  Every column costs 32 header bytes (nnz, nnm,
+    // impute, outer) plus its own 24-byte offset table, which bounds p by the image size; the rows are only bounded by what
+    // the format can address, so a plausibility cap stands in (2^32 rows; the largest biobanks have < 2^24).  The host side
+    // then never holds more than one panel of decoded columns (256 MB, or one column), whatever the header claims, and the
+    // packed matrix is allocated on the device BEFORE any decoding: an image whose counts were damaged fails there.
+    if (p == 0 || n == 0) throw make_core_error("corrupt .snpdat header (row / column counts).");
+    if (p > uint64_t(n_bytes) / 32 || n > (uint64_t(1) << 32)) throw make_core_error("corrupt .snpdat header (row / column counts).");
     const size_t hdr = 17 + 8 * p * 3 + 8 * (p + 1);
     if (size_t(n_bytes) < hdr) throw make_core_error("truncated .snpdat header.");
     const uint8_t* impute_p = buf + 17 + 16 * p;
     const uint8_t* outer_p = buf + 17 + 24 * p;
     std::vector<double> impute(p);
     std::memcpy(impute.data(), impute_p, 8 * p);
-    // decode to int8 calldata (missing = -9), then pack on device
-    std::vector<int8_t> calldata(size_t(n) * size_t(p), 0);
-    for (uint64_t j = 0; j < p; ++j) {
+    for (uint64_t j = 0; j < p; ++j) { // the column index, before anything is allocated
         const uint64_t base = read_as<uint64_t>(outer_p + 8 * j), endc = read_as<uint64_t>(outer_p + 8 * (j + 1));
-        if (endc > uint64_t(n_bytes) || base + 24 > endc) throw make_core_error("corrupt .snpdat column index.");
-        int8_t* col = calldata.data() + size_t(j) * size_t(n);
-        for (int c = 0; c < 3; ++c) {
-            uint64_t pos = base + read_as<uint64_t>(buf + base + 8 * c);
-            const uint32_t n_chunks = read_as<uint32_t>(buf + pos);
-            pos += 4;
-            const int8_t val = c == 0 ? int8_t(-9) : int8_t(c);
-            for (uint32_t k = 0; k < n_chunks; ++k) {
-                const uint32_t cidx = read_as<uint32_t>(buf + pos);
-                const uint32_t cnt = uint32_t(buf[pos + 4]) + 1;
-                pos += 5;
-                for (uint32_t t = 0; t < cnt; ++t) {
-                    const uint64_t row = uint64_t(cidx) * 256 + buf[pos + t];
-                    if (row >= n) throw make_core_error("corrupt .snpdat chunk (row out of range).");
-                    col[row] = val;
-                }
-                pos += cnt;
-                if (pos > endc) throw make_core_error("corrupt .snpdat chunk (overrun).");
-            }
-        }
+        if (endc > uint64_t(n_bytes) || base < hdr || base > endc || endc - base < 24)
+            throw make_core_error("corrupt .snpdat column index.");
     }
     adelie_hip_design* d = new_design(int64_t(n), int64_t(p), dtype, device);
+    int8_t* tmp = nullptr;
     try {
-        create_snp_from_calldata(d, calldata.data(), impute.data());
+        d->kind = 1;
+        d->ldb = int64_t((((n + 3) / 4 + 63) / 64) * 64);
+        AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->bits), size_t(d->ldb) * size_t(p)));
+        // decode -> int8 panel on the host -> 2-bit on the device, a panel of columns at a time
+        const uint64_t panel = std::min<uint64_t>(p, std::max<uint64_t>(1, (uint64_t(1) << 28) / n));
+        AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&tmp), size_t(n) * size_t(panel)));
+        std::vector<int8_t> calls(size_t(n) * size_t(panel));
+        for (uint64_t j0 = 0; j0 < p; j0 += panel) {
+            const uint64_t pc = std::min(panel, p - j0);
+            std::fill(calls.begin(), calls.begin() + size_t(n) * size_t(pc), int8_t(0));
+            for (uint64_t j = j0; j < j0 + pc; ++j)
+                decode_snpdat_column(buf, read_as<uint64_t>(outer_p + 8 * j), read_as<uint64_t>(outer_p + 8 * (j + 1)), n,
+                                     calls.data() + size_t(j - j0) * size_t(n));
+            AHIP_CHECK(hipMemcpyAsync(tmp, calls.data(), size_t(n) * size_t(pc), hipMemcpyHostToDevice, d->stream));
+            launch_pack_snp(tmp, int64_t(n), int64_t(pc), d->bits + int64_t(j0) * d->ldb, d->ldb, d->stream);
+            AHIP_CHECK(hipStreamSynchronize(d->stream));
+        }
+        (void)hipFree(tmp);
+        tmp = nullptr;
+        if (d->dtype == ADELIE_HIP_F64) {
+            AHIP_CHECK(hipMalloc(&d->impute, size_t(p) * sizeof(double)));
+            AHIP_CHECK(hipMemcpy(d->impute, impute.data(), size_t(p) * sizeof(double), hipMemcpyHostToDevice));
+        } else {
+            std::vector<float> f(impute.begin(), impute.end());
+            AHIP_CHECK(hipMalloc(&d->impute, size_t(p) * sizeof(float)));
+            AHIP_CHECK(hipMemcpy(d->impute, f.data(), size_t(p) * sizeof(float), hipMemcpyHostToDevice));
+        }
     } catch (...) {
+        if (tmp) (void)hipFree(tmp);
         adelie_hip_design_destroy(d);
         throw;
     }
@@ -687,10 +729,18 @@ int adelie_hip_design_create_snp_bed(const void* bed, int64_t n_bytes, int64_t n
     ABI_CATCH
 }
 
+int adelie_hip_design_batch_stats(adelie_hip_design* d, double* out) {
+    ABI_TRY
+    if (!d || !out) throw make_core_error("null argument.");
+    adelie_hip_design* owner = d->batch_owner ? d->batch_owner : d;
+    adelie_hip_internal_batch_stats(owner->batcher, out);
+    ABI_CATCH
+}
+
 int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out) {
     ABI_TRY
-    no_view(src);
     if (!src || !out) throw make_core_error("null argument.");
+    no_view(src);
     adelie_hip_design* d = new_design(src->n, src->p, src->dtype, src->device); // own stream, own scratch
     d->kind = src->kind;
     d->X = src->X;

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <exception>
 #include <type_traits>
 #include <chrono>
 #include <condition_variable>
@@ -154,7 +155,8 @@ struct KTimer {
 struct Counters {
     int64_t n_basil_iters = 0, n_sweeps = 0, n_cd_visits_screen = 0, n_cd_visits_active = 0, n_updates = 0,
             n_irls_iters = 0, n_new_screen_cols = 0, n_cd_passes_screen = 0, n_cd_passes_active = 0,
-            n_gram_col_reads = 0, n_resid_col_reads = 0, n_panel_blocks = 0, n_panel_grams = 0, n_panel_cols = 0;
+            n_gram_col_reads = 0, n_resid_col_reads = 0, n_panel_blocks = 0, n_panel_grams = 0, n_panel_cols = 0,
+            n_irls_screen_cols = 0;
     double gram_flops = 0;
 };
 
@@ -191,6 +193,10 @@ struct SweepBatcher {
     uint64_t cur = 0, launched_upto = 0; // generation collecting arrivals; generations < launched_upto have been launched
     hipStream_t stream = nullptr;
     DevBuf<char> vbuf[NGEN], obuf[NGEN], work;
+    // HIP-event timing of the shared sweeps on the batcher's stream (adelie_hip_design_batch_stats): launches, vectors
+    // answered, milliseconds
+    KTimer timer;
+    int64_t n_vectors = 0;
     SweepBatcher() {
         AHIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         for (auto& g : gen) {
@@ -232,10 +238,19 @@ struct SweepBatcher {
         const uint64_t g = cur;
         Gen& G = gen[g % NGEN];
         const int slot = G.count++;
-        char* vb = vbuf[g % NGEN].reserve(size_t(KMAX) * size_t(n) * sizeof(T));
-        if (G.done_set) AHIP_CHECK(hipStreamWaitEvent(ps, G.done, 0)); // the previous user of this buffer has been read
-        AHIP_CHECK(hipMemcpyAsync(vb + size_t(slot) * size_t(n) * sizeof(T), v, size_t(n) * sizeof(T), hipMemcpyDeviceToDevice, ps));
-        AHIP_CHECK(hipEventRecord(G.in_ev[slot], ps));
+        char* vb = nullptr;
+        try { // stage this solver's vector.  The mutex is held from the join above to the end of this block, so nobody has
+              // joined after us yet: a failure here is undone by leaving the generation again, and nobody ever waits for us
+            vb = vbuf[g % NGEN].reserve(size_t(KMAX) * size_t(n) * sizeof(T));
+            if (G.done_set) AHIP_CHECK(hipStreamWaitEvent(ps, G.done, 0)); // the previous user of this buffer has been read
+            AHIP_CHECK(hipMemcpyAsync(vb + size_t(slot) * size_t(n) * sizeof(T), v, size_t(n) * sizeof(T), hipMemcpyDeviceToDevice, ps));
+            AHIP_CHECK(hipEventRecord(G.in_ev[slot], ps));
+        } catch (...) {
+            --G.count;
+            lk.unlock();
+            cv.notify_all();
+            throw;
+        }
         if (slot == 0) {
             // leader: give the others a window of about four sweep times (a sweep moves n*p values at ~7 TB/s), then launch
             // for whoever has arrived: waiting costs a lone solver at most that, sharing saves K - 1 sweeps
@@ -256,7 +271,10 @@ struct SweepBatcher {
                     if (G.out_set[k]) { AHIP_CHECK(hipStreamWaitEvent(stream, G.out_ev[k], 0)); G.out_set[k] = false; }
                 MultiView<T> mv{X.X, n, p, X.ld, nullptr, int32_t(K), 0};
                 T* wk = reinterpret_cast<T*>(work.reserve(size_t(multi_sweep_work_elems<T>(MultiView<T>{X.X, n, p, X.ld, nullptr, KMAX, 0})) * sizeof(T)));
+                timer.begin(stream);
                 launch_multi_sweep<T>(mv, reinterpret_cast<const T*>(vb), ob, wk, stream);
+                timer.end(stream);
+                n_vectors += K;
                 AHIP_CHECK(hipEventRecord(G.done, stream));
                 G.done_set = true;
             } catch (...) {
@@ -272,21 +290,27 @@ struct SweepBatcher {
             cv.notify_all(); // the leader may be waiting for the last arrival
             cv.wait(lk, [&] { return launched_upto > g; });
         }
+        // every member of a launched generation accounts for itself in `pending` exactly once, whatever happens to its pick:
+        // a generation whose count of pending members never reaches zero would stall every solver once `cur` wraps to it
         const int K = G.K;
+        std::exception_ptr err;
         if (G.failed) {
-            --G.pending;
-            lk.unlock();
-            cv.notify_all();
-            throw core_error("adelie_hip: the shared sweep of a batch of concurrent solves failed to launch.");
+            err = std::make_exception_ptr(core_error("adelie_hip: the shared sweep of a batch of concurrent solves failed to launch."));
+        } else {
+            try {
+                const T* ob = reinterpret_cast<const T*>(obuf[g % NGEN].p);
+                AHIP_CHECK(hipStreamWaitEvent(ps, G.done, 0));
+                launch_batch_pick<T>(ob, p, K, slot, sub_scale, sub_vec, out, ps);
+                AHIP_CHECK(hipEventRecord(G.out_ev[slot], ps));
+                G.out_set[slot] = true;
+            } catch (...) {
+                err = std::current_exception();
+            }
         }
-        const T* ob = reinterpret_cast<const T*>(obuf[g % NGEN].p);
-        AHIP_CHECK(hipStreamWaitEvent(ps, G.done, 0));
-        launch_batch_pick<T>(ob, p, K, slot, sub_scale, sub_vec, out, ps);
-        AHIP_CHECK(hipEventRecord(G.out_ev[slot], ps));
-        G.out_set[slot] = true;
         --G.pending;
         lk.unlock();
         cv.notify_all();
+        if (err) std::rethrow_exception(err);
         return true;
     }
 };
@@ -2115,6 +2139,7 @@ struct Solver {
         while (1) {
             if (irls_it >= irls_max_iters) throw make_solver_error("Maximum IRLS iterations reached.");
             ++cnt.n_irls_iters;
+            cnt.n_irls_screen_cols += nv;
             Stopwatch sw_irls;
             sw_irls.start();
             // :336-348
@@ -2833,6 +2858,7 @@ struct Result : ResultBase {
             case ADELIE_HIP_S_N_PANEL_BLOCKS: return double(s.cnt.n_panel_blocks);
             case ADELIE_HIP_S_N_PANEL_GRAMS: return double(s.cnt.n_panel_grams);
             case ADELIE_HIP_S_N_PANEL_COLS: return double(s.cnt.n_panel_cols);
+            case ADELIE_HIP_S_N_IRLS_SCREEN_COLS: return double(s.cnt.n_irls_screen_cols);
             case ADELIE_HIP_S_T_PANEL_STEP_MS: return s.t_step.ms;
             case ADELIE_HIP_S_N_PANEL_STEP_LAUNCHES: return double(s.t_step.launches);
             case ADELIE_HIP_S_T_SWEEP_MS: return s.t_sweep.ms;
@@ -2902,6 +2928,16 @@ void run(adelie_hip_design* X, const adelie_hip_grpnet_args* a, adelie_hip_resul
 } // namespace
 
 void adelie_hip_internal_free_batcher(void* b) { delete static_cast<SweepBatcher*>(b); }
+void adelie_hip_internal_batch_stats(void* b, double* out) {
+    out[0] = out[1] = out[2] = 0;
+    if (!b) return;
+    auto* sb = static_cast<SweepBatcher*>(b);
+    std::lock_guard<std::mutex> lk(sb->m);
+    sb->timer.collect();
+    out[0] = double(sb->timer.launches);
+    out[1] = double(sb->n_vectors);
+    out[2] = sb->timer.ms;
+}
 
 extern "C" {
 

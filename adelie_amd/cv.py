@@ -48,6 +48,8 @@ class CVGrpnetResult:
     losses: np.ndarray
     avg_losses: np.ndarray
     best_idx: int
+    # not in the reference: counters / device timers / wall time of the solves behind each fold THIS rank ran (bench.py)
+    fold_stats: list = None
 
     def fit(self, X, glm, *, lmda_path_size: int = 100, **grpnet_params):
         """Fits the full data down to the best CV lambda (reference ``cv.py:95-127``)."""
@@ -73,7 +75,7 @@ def fold_ranges(n: int, n_folds: int):
     return out
 
 
-def _fold_loss(X, glm, fold_idx, full_lmdas, *, n_threads, early_exit, min_ratio, lmda_path_size, grpnet_params):
+def _fold_loss(X, glm, fold_idx, full_lmdas, *, n_threads, early_exit, min_ratio, lmda_path_size, grpnet_params, stats=None):
     """Body of the reference's fold loop (``cv.py:247-314``)."""
     weights = glm.weights.copy()
     weights[fold_idx] = 0
@@ -81,7 +83,7 @@ def _fold_loss(X, glm, fold_idx, full_lmdas, *, n_threads, early_exit, min_ratio
     weights /= weights_sum
     glm_c = glm.reweight(weights)
 
-    state = grpnet(X=X, glm=glm_c, n_threads=n_threads, lmda_path_size=0, progress_bar=False)
+    state0 = state = grpnet(X=X, glm=glm_c, n_threads=n_threads, lmda_path_size=0, progress_bar=False)
     curr_lmdas = state.lmda_max * np.logspace(0, np.log10(min_ratio), lmda_path_size)
     curr_lmdas = curr_lmdas[curr_lmdas > full_lmdas[0]]
     aug_lmdas = np.sort(np.concatenate([full_lmdas, curr_lmdas]))[::-1]
@@ -110,6 +112,12 @@ def _fold_loss(X, glm, fold_idx, full_lmdas, *, n_threads, early_exit, min_ratio
         etas = predict(X=X, betas=full_betas, intercepts=full_intercepts, offsets=state._offsets, n_threads=n_threads)
         full_data_losses = np.array([glm.loss(eta) for eta in etas])
         train_losses = weights_sum * np.array([glm_c.loss(eta) for eta in etas])
+    if stats is not None:  # both solves of the fold: the lmda_max bootstrap and the path
+        stats.append({
+            "counters": {k: state0.counters[k] + v for k, v in state.counters.items()},
+            "timers": {k: state0.timers[k] + v for k, v in state.timers.items()},
+            "total_time": state0.total_time + state.total_time,
+        })
     return (full_data_losses - train_losses) / weights_sum_val if weights_sum_val > 0 else np.zeros(len(full_lmdas))
 
 
@@ -159,6 +167,7 @@ def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio
         full_lmdas = state.lmda_max * np.logspace(0, np.log10(min_ratio), lmda_path_size)
 
         cv_losses = np.zeros((n_folds, full_lmdas.shape[0]))
+        fold_stats = [] if hasattr(state, "counters") else None
         ranges = fold_ranges(n, n_folds)
         my_folds = [fold for fold in range(n_folds) if fold % world == rank]
         can_alias = hasattr(X, "alias") and hasattr(X, "_backend") and X._backend.has("design_alias")
@@ -171,7 +180,8 @@ def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio
         def one(Xa, fold):
             b, e = ranges[fold]
             return _fold_loss(Xa, glm, order[b:e], full_lmdas, n_threads=n_threads, early_exit=early_exit,
-                              min_ratio=min_ratio, lmda_path_size=lmda_path_size, grpnet_params=grpnet_params)
+                              min_ratio=min_ratio, lmda_path_size=lmda_path_size, grpnet_params=grpnet_params,
+                              stats=fold_stats)
 
         if nc <= 1:
             for fold in my_folds:
@@ -214,7 +224,8 @@ def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio
 
     avg_losses = np.mean(cv_losses, axis=0)
     best_idx = int(np.argmin(avg_losses))
-    return CVGrpnetResult(lmdas=full_lmdas, losses=cv_losses, avg_losses=avg_losses, best_idx=best_idx)
+    return CVGrpnetResult(lmdas=full_lmdas, losses=cv_losses, avg_losses=avg_losses, best_idx=best_idx,
+                          fold_stats=fold_stats)
 
 
 def _gather_fold_rows(dist, group, local, n_folds, rank, world):

@@ -133,6 +133,13 @@ class _NativeMatrix:
         out._alias_of = self
         return out
 
+    def batch_stats(self):
+        """Shared sweeps of concurrent solves on this design and its aliases since it was created
+        (``adelie_hip_design_batch_stats``): ``{"launches", "vectors", "ms"}``."""
+        out = (_abi.C.c_double * 3)()
+        self._backend.check(self._backend.fn("design_batch_stats")(self._handle, out))
+        return {"launches": int(out[0]), "vectors": int(out[1]), "ms": float(out[2])}
+
     def impute(self):
         """The ``(p,)`` impute values of an SNP design (what a missing call contributes)."""
         out = np.empty(self._cols, dtype=np.float64)

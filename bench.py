@@ -1,18 +1,29 @@
 #!/usr/bin/env python
-"""bench.py — headline benchmark of the grpnet hot path on MI355X.
+"""bench.py — the grpnet hot path on MI355X, one JSON line per run.
 
-A *step* is one full 100-lambda ``grpnet`` path (Gaussian GLM, ungrouped lasso, ``early_exit=False``) on a dense
-synthetic Gaussian design that is already resident in HBM when the timed region starts.  At N=1 the workload is
-BASELINE.json ``configs[1]`` (100k x 10k, f64).  At N>1 every rank keeps a full replica of X (same seed) and solves
-its own paths — rank r trains on the complement of CV fold r%8, i.e. the fold shards of ``cv_grpnet`` — with no
-data-path collective; one RCCL all_gather of the per-lambda deviance rows at the end (the fold gather).  Per-GPU
-work is fixed as N grows: "scaling": "weak".  ``value`` = paths solved by all ranks / max-over-ranks wall time.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4,5}]
 
-Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     — dominant HBM-bound kernel (the full gradient sweep grad = X^T(w*r) - rsum*xbar), timed live
-                 with HIP events on the stream it is launched on, inside the timed steps;
-  cpu_baseline — the CPU oracle (oracle/, kind "port": a restatement of the reference algorithm, OpenMP) on the
-                 same data copied back to the host, rank 0 / N=1 only.
+``--config`` selects the BASELINE.json workload (default 2, the one the headline metric is quoted on):
+
+  2  Gaussian lasso, dense 100k x 10k f64, 100-lambda path, ``early_exit=False``                    step = one path
+  3  the same design, groups of 10, alpha = 0.5 (group elastic net)                                  step = one path
+  4  binomial lasso (IRLS) on a 2-bit SNP design 500k x 50k (25 % ones, 5 % twos, 10 % missing)      step = one path
+  5  ``cv_grpnet`` with 8 folds on the config-2 data                                                 step = one CV (8 fold paths)
+
+The design is resident in HBM when the timed region starts.  Every line carries ``roofline`` (the dominant kernel, timed live
+with HIP events on the stream it runs on, inside the timed steps), ``roofline_path`` (algorithmic matrix bytes
+of the whole path / wall time), the solver's counters, and — rank 0, N = 1 — ``cpu_baseline``: the CPU oracle (``oracle/``, a
+restatement of the reference algorithm with the reference's OpenMP flags; kind "port") on a bounded sample of the same
+workload, on the box's host cores.
+
+Multi-GPU (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``, one rank per GPU over RCCL):
+  * configs 2-4: every rank holds a replica of the design and solves its own paths; rank r trains on the complement of CV
+    fold r % 8 — the fold shards of ``cv_grpnet`` — no data-path collective, one all_gather of the per-lambda rows at the
+    end.  Per-GPU work is fixed: ``"scaling": "weak"``; ``value`` = paths of all ranks / max-over-ranks wall.
+  * config 5: ONE 8-fold CV whose folds are sharded over the ranks (fold k on rank k % N, one all_gather of the loss
+    table): total work is fixed, ``"scaling": "strong"``.
+  * the default line (config 2) additionally carries ``"cv_config5"``: the same sharded CV timed right after the headline
+    steps, so that a ``--gpus 1/2/4/8`` series holds BASELINE.json's second target (8-fold CV at 1/2/4/8 GPUs) as well.
 """
 import argparse
 import json
@@ -25,44 +36,125 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec (guides/MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0       # MI355X spec (guides/MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+MFMA_F64_PEAK_TFLOPS = 78.6  # dense f64 matrix-core peak (same guide)
+
+METRIC = "lambda-paths/sec (100-lambda grpnet); HBM GB/s vs peak"
 
 
+# -------------------------------------------------------------------------------------------------------------------------
+# synthetic data (mirrors adelie/data.py:84-235), generated on the device
+# -------------------------------------------------------------------------------------------------------------------------
 def make_data(n, p, seed, device, dtype):
+    """Dense Gaussian design (column-major) and a 95 %-sparse linear response at snr = 1."""
     import torch
 
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    # column-major (n, p): generate (p, n) row-major and view transposed
-    Xt = torch.randn((p, n), generator=g, device=device, dtype=dtype)
+    Xt = torch.randn((p, n), generator=g, device=device, dtype=dtype)   # (p, n) row-major == (n, p) column-major
     X = Xt.t()
     gb = torch.Generator(device="cpu")
     gb.manual_seed(seed + 1)
     beta = torch.randn(p, generator=gb, dtype=torch.float64)
-    mask = torch.rand(p, generator=gb) < 0.05  # 95% sparse truth (adelie.data.dense defaults)
+    mask = torch.rand(p, generator=gb) < 0.05
     beta = beta * mask
     eta = (X @ beta.to(device=device, dtype=dtype)).to(torch.float64).cpu().numpy()
     rng = np.random.default_rng(seed + 2)
-    noise_scale = float(np.sqrt(np.sum(beta.numpy() ** 2)))  # snr = 1
-    y = eta + noise_scale * rng.standard_normal(n)
+    y = eta + float(np.sqrt(np.sum(beta.numpy() ** 2))) * rng.standard_normal(n)
     return X, y
 
 
+def make_snp_data(n, p, seed, device):
+    """int8 calldata (n, p) column-major on the device with adelie.data.snp_unphased's default rates (25 % ones, 5 % twos,
+    10 % missing, data.py:222-235), its mean-impute vector, and a Bernoulli response from a sparse logistic model."""
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    cdt = torch.empty((p, n), dtype=torch.int8, device=device)
+    for j0 in range(0, p, 2048):
+        j1 = min(p, j0 + 2048)
+        u = torch.rand((j1 - j0, n), generator=g, device=device)
+        blk = torch.zeros_like(u, dtype=torch.int8)
+        blk[u < 0.25] = 1
+        blk[(u >= 0.25) & (u < 0.30)] = 2
+        blk[u >= 0.90] = -9
+        cdt[j0:j1] = blk
+        del u, blk
+    cd = cdt.t()
+    valid = cd >= 0
+    imp = (cd * valid).sum(dim=0, dtype=torch.float64) / valid.sum(dim=0).clamp(min=1)
+    del valid
+    rng = np.random.default_rng(seed)
+    beta = rng.standard_normal(p) * (rng.random(p) < min(0.05, 500 / p))
+    eta = torch.zeros(n, dtype=torch.float64, device=device)
+    for j in np.flatnonzero(beta):
+        c = cd[:, j].to(torch.float64)
+        eta += torch.where(c < 0, imp[j], c) * beta[j]
+    eta = ((eta - eta.mean()) / eta.std()).cpu().numpy()
+    y = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(np.float64)
+    return cd, imp.cpu().numpy(), y
+
+
+# -------------------------------------------------------------------------------------------------------------------------
+# algorithmic bytes of a path (SURVEY.md 8d): matrix bytes only; vectors are cache resident
+# -------------------------------------------------------------------------------------------------------------------------
+def path_bytes(counters, n, p, col_bytes_per_row, group_size):
+    """B_path = s*n*[p*N_sweep + sum_visits q_g + sum_new q_g] (+ IRLS: s*n*2*sum_irls |S|), N_sweep = 2 + n_basil_iters.
+    Visits are counted in groups by the group engines and in columns by the lasso engines: both are `group_size` columns."""
+    c = counters
+    n_sweep = 2 + c["n_basil_iters"]
+    visit_cols = (c["n_cd_visits_screen"] + c["n_cd_visits_active"]) * group_size
+    cols = p * n_sweep + visit_cols + c["n_new_screen_cols"] + 2 * c.get("n_irls_screen_cols", 0)
+    return float(n) * col_bytes_per_row * cols, {"n_sweep": int(n_sweep), "visit_cols": int(visit_cols),
+                                                 "new_screen_cols": int(c["n_new_screen_cols"]),
+                                                 "irls_screen_cols": int(c.get("n_irls_screen_cols", 0))}
+
+
+def measured_traffic(key):
+    """HBM bytes per launch from the PMC passes kept under profiles/ (FETCH_SIZE doubled as the gfx950 note in
+    guides/MI355X_MICROARCH.md prescribes, plus WRITE_SIZE); None when this kernel / shape was not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(key)
+    except Exception:
+        return None
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+# -------------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=100_000)
-    ap.add_argument("--p", type=int, default=10_000)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
+    ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--p", type=int, default=None)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--lmda-path-size", type=int, default=100)
-    ap.add_argument("--group-size", type=int, default=1)
-    ap.add_argument("--alpha", type=float, default=1.0)
+    ap.add_argument("--group-size", type=int, default=None, help="override the config's group size (configs 2/3)")
+    ap.add_argument("--alpha", type=float, default=None, help="override the config's alpha (configs 2/3)")
+    ap.add_argument("--n-folds", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=90.0)
+    ap.add_argument("--no-cv-leg", action="store_true", help="skip the cv_config5 object of the default line")
+    ap.add_argument("--cpu-budget-s", type=float, default=None)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
+    cfg = args.config
+    if args.steps is None:
+        args.steps = {2: 3, 3: 2, 4: 1, 5: 3}[cfg]
+    n = args.n or (500_000 if cfg == 4 else 100_000)
+    p = args.p or (50_000 if cfg == 4 else 10_000)
+    gs = args.group_size or (10 if cfg == 3 else 1)
+    alpha = args.alpha if args.alpha is not None else (0.5 if cfg == 3 else 1.0)
+    L = args.lmda_path_size
 
     import torch
 
@@ -76,43 +168,53 @@ def main():
     # multi-rank logic; the driver's multi-GPU runs use the defaults (RCCL, one device per rank)
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     dev_index = int(os.environ.get("BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(dev_index)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend=backend)
-    else:
-        torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     comm_device = device if backend == "nccl" else torch.device("cpu")
     tdtype = torch.float64 if args.dtype == "f64" else torch.float32
     npdtype = np.float64 if args.dtype == "f64" else np.float32
-    n, p = args.n, args.p
+    s_val = np.dtype(npdtype).itemsize
 
-    X, y = make_data(n, p, seed=0, device=device, dtype=tdtype)
-    Xd = ad.matrix.dense(X)  # adopts the resident tensor in place (no copy)
+    # ---- the workload -------------------------------------------------------------------------------------------------
+    keep = {}
+    if cfg == 4:
+        cd, imp, y = make_snp_data(n, p, 0, device)
+        Xd = ad.matrix.snp_calldata(cd, imp, dtype=npdtype)     # packed to 2 bits per call on the device
+        keep["cd"], keep["imp"] = cd, imp
+        col_bytes_per_row = 0.25
+        family = "binomial"
+    else:
+        X, y = make_data(n, p, seed=0, device=device, dtype=tdtype)
+        Xd = ad.matrix.dense(X)                                 # adopts the resident tensor in place (no copy)
+        keep["X"] = X
+        col_bytes_per_row = s_val
+        family = "gaussian"
     y = y.astype(npdtype)
 
-    # fold weights for the multi-GPU (CV-shard) workload; full-data weights at N=1
+    # fold weights for the weak-scaling replicas (the fold shards of cv_grpnet); full-data weights at N = 1
     weights = None
-    if world > 1:
+    if world > 1 and cfg != 5:
         order = np.random.RandomState(0).permutation(n)
-        from adelie_amd.cv import fold_ranges
-
-        b, e = fold_ranges(n, 8)[rank % 8]
+        b, e = ad.cv.fold_ranges(n, 8)[rank % 8]
         weights = np.full(n, 1.0, dtype=npdtype)
         weights[order[b:e]] = 0
         weights /= weights.sum()
-    glm = ad.glm.gaussian(y, weights=weights, dtype=npdtype)
-
-    groups = None if args.group_size == 1 else np.arange(0, p, args.group_size)
-    kw = dict(early_exit=False, lmda_path_size=args.lmda_path_size, groups=groups, alpha=args.alpha)
+    glm = (ad.glm.binomial if family == "binomial" else ad.glm.gaussian)(y, weights=weights, dtype=npdtype)
+    groups = None if gs == 1 else np.arange(0, p, gs)
+    kw = dict(early_exit=False, lmda_path_size=L, groups=groups, alpha=alpha, progress_bar=False)
+    cv_kw = dict(n_folds=args.n_folds, seed=0, lmda_path_size=L, process_group=(True if world > 1 else None))
 
     def step():
+        if cfg == 5:
+            return ad.cv_grpnet(Xd, glm, **cv_kw)
         return ad.grpnet(Xd, glm, **kw)
 
     def barrier():
@@ -120,102 +222,185 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        state = step()
-    barrier()
-    t0 = time.perf_counter()
-    sweep_ms = 0.0
-    sweep_launches = 0
-    states = []
-    for _ in range(args.steps):
-        state = step()
-        sweep_ms += state.timers["t_sweep_ms"]
-        sweep_launches += state.timers["n_sweep_launches"]
-        states.append(state)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=comm_device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # the fold gather of cv_grpnet: one small all_gather of the per-lambda rows
-        row = torch.from_numpy(np.asarray(state.devs, dtype=np.float64)).to(comm_device)
-        rows = [torch.empty_like(row) for _ in range(world)]
-        dist.all_gather(rows, row)
-    assert state.error == "", state.error
-    assert len(state.lmdas) == args.lmda_path_size
+    def timed(fn, steps):
+        barrier()
+        t0 = time.perf_counter()
+        outs = [fn() for _ in range(steps)]
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device=comm_device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return outs, el
 
-    # one extra, untimed step with per-launch events on the panel step kernel (second HBM-bound kernel of the path)
+    for _ in range(args.warmup):
+        step()
+    bs0 = Xd.batch_stats() if cfg == 5 else None
+    outs, elapsed = timed(step, args.steps)
+    bs1 = Xd.batch_stats() if cfg == 5 else None
+    last = outs[-1]
+
+    if cfg != 5:
+        assert last.error == "", last.error
+        assert len(last.lmdas) == L, len(last.lmdas)
+        if dist is not None:  # the fold gather of cv_grpnet: one small all_gather of the per-lambda rows
+            row = torch.from_numpy(np.asarray(last.devs, dtype=np.float64)).to(comm_device)
+            rows = [torch.empty_like(row) for _ in range(world)]
+            dist.all_gather(rows, row)
+        units = world * args.steps                      # paths
+        stats = [dict(counters=o.counters, timers=o.timers, total_time=o.total_time) for o in outs]
+    else:
+        assert last.losses.shape == (args.n_folds, L) and np.all(np.isfinite(last.losses))
+        units = args.n_folds * args.steps               # fold paths of ONE sharded CV per step
+        stats = [f for o in outs for f in o.fold_stats]
+
+    # ---- the secondary CV leg of the default line ---------------------------------------------------------------------
+    cv_leg = None
+    if cfg == 2 and not args.no_cv_leg and gs == 1 and alpha == 1.0:
+        glm_full = ad.glm.gaussian(y, dtype=npdtype)
+        cv_fn = lambda: ad.cv_grpnet(Xd, glm_full, **cv_kw)  # noqa: E731
+        cv_fn()
+        (cv_res,), cv_el = timed(cv_fn, 1)
+        cv_leg = {
+            "workload": f"cv_grpnet(n_folds={args.n_folds}, seed=0, min_ratio=0.1, {L} lambdas) on the same design; fold k on "
+                        f"rank k % {world}, one all_gather of the ({args.n_folds}, {L}) loss table",
+            "scaling": "strong", "n_gpus": world, "cv_wall_s": cv_el, "folds_per_s": args.n_folds / cv_el,
+            "folds_per_rank": [len(range(r, args.n_folds, world)) for r in range(world)],
+            "best_idx": int(cv_res.best_idx), "min_avg_loss": float(cv_res.avg_losses.min()),
+        }
+
+    # ---- one extra, untimed step with per-launch events on the panel step kernel (second HBM-bound kernel of the path) --
     panel = None
-    if rank == 0:
+    if rank == 0 and cfg in (2, 3):
         os.environ["ADELIE_HIP_TIME_PANEL"] = "1"
-        stp = step()
+        stp = ad.grpnet(Xd, glm, **kw)
         del os.environ["ADELIE_HIP_TIME_PANEL"]
         if stp.timers["n_panel_step_launches"] > 0:
-            s_ = np.dtype(npdtype).itemsize
             cols = stp.counters["n_panel_cols"] + stp.counters["n_updates"]  # gradient columns + residual-update columns
-            bytes_ = float(cols) * n * s_
+            bytes_ = float(cols) * n * s_val
             ms = stp.timers["t_panel_step_ms"]
             panel = {
                 "kernel": "panel_fused_kernel / panel_step_kernel (r -= X_B dbeta_B of the previous block; partial gradients of the "
                           "next block; the fused launch also carries the one-workgroup solve of the current block)",
                 "bound": "hbm", "achieved": bytes_ / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(n, p, args.dtype, "panel_step_kernel"),
+                "frac": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": measured_traffic(f"panel_step_kernel:{n}x{p}:{args.dtype}"),
                 "launches": int(stp.timers["n_panel_step_launches"]), "avg_launch_ms": ms / stp.timers["n_panel_step_launches"],
                 "algorithmic_bytes_per_launch": bytes_ / stp.timers["n_panel_step_launches"],
             }
 
     if rank == 0:
-        s = np.dtype(npdtype).itemsize
-        sweep_bytes = float(n) * p * s  # algorithmic bytes of one launch: X read once (vectors are cache resident)
-        avg_ms = sweep_ms / max(sweep_launches, 1)
-        achieved = sweep_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        c = state.counters
-        tm = state.timers
+        tot = lambda key, kind: sum(st[kind][key] for st in stats)  # noqa: E731
+        # sweep kernel, timed live with HIP events on the solver's stream inside the timed steps
+        sweep_launches = tot("n_sweep_launches", "timers")
+        sweep_ms = tot("t_sweep_ms", "timers")
+        sweep_bytes = float(n) * p * col_bytes_per_row      # one launch reads the design once
+        sweep_avg = sweep_ms / max(sweep_launches, 1)
+        sweep_roof = None
+        if sweep_launches:
+            ach = sweep_bytes / (sweep_avg * 1e-3) / 1e9
+            kname = "sweep_kernel" if cfg != 4 else "sweep_kernel<Snp2bit>"
+            sweep_roof = {
+                "kernel": kname + " (grad = X^T (w*r) - rsum*xbar, full design)", "bound": "hbm", "achieved": ach,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": measured_traffic(f"sweep_kernel:{n}x{p}:{args.dtype}" + (":snp" if cfg == 4 else "")),
+                "launches": int(sweep_launches), "avg_launch_ms": sweep_avg, "algorithmic_bytes_per_launch": sweep_bytes,
+            }
+        gram_ms, gram_flops = tot("t_gram_ms", "timers"), tot("gram_flops", "timers")
+        gram_roof = None
+        if gram_ms > 0:
+            tf = gram_flops / (gram_ms * 1e-3) / 1e12
+            gram_roof = {
+                "kernel": "syrk_kernel / gram_kernel (diagonal blocks X_b^T W X_b of the panel engine, f64 MFMA 16x16x4)",
+                "bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / MFMA_F64_PEAK_TFLOPS, "traffic": measured_traffic(f"syrk_kernel:{n}x{p}:{args.dtype}"),
+                "launches": int(tot("n_gram_launches", "timers")),
+                "avg_launch_ms": gram_ms / max(tot("n_gram_launches", "timers"), 1),
+                "algorithmic_flops_per_launch": gram_flops / max(tot("n_gram_launches", "timers"), 1),
+            }
+        # dominant kernel: by device time.  Config 4 spends most of it in the MFMA block builds; the others in the sweeps.
+        roofline = gram_roof if (cfg == 4 and gram_roof is not None) else sweep_roof
+        if cfg == 5 and bs1["launches"] > bs0["launches"]:
+            # the folds in flight share their sweeps: the dominant kernel is the K-wide sweep on the batcher's stream, one
+            # pass over X per launch for all the folds that reached their invariance sweep together
+            nl, nvec, ms = (bs1[k] - bs0[k] for k in ("launches", "vectors", "ms"))
+            ach = nl * sweep_bytes / (ms * 1e-3) / 1e9
+            roofline = {
+                "kernel": "multi_sweep_kernel (shared sweep of the folds in flight: grad_k = X^T v_k for the K folds that "
+                          "arrived together, X streamed once)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": measured_traffic(f"multi_sweep_kernel:{n}x{p}:{args.dtype}"), "launches": int(nl),
+                "avg_launch_ms": ms / nl, "algorithmic_bytes_per_launch": sweep_bytes,
+                "vectors_per_launch": nvec / nl,
+            }
+
+        # whole-path fraction: algorithmic bytes of everything the timed steps solved / their wall time
+        counters = {k: sum(st["counters"][k] for st in stats) for k in stats[0]["counters"]}
+        B, parts = path_bytes(counters, n, p, col_bytes_per_row, gs)
+        if cfg == 5:
+            wall = elapsed
+        else:
+            wall = elapsed  # rank 0's steps; at N > 1 every rank does the same amount
+        path_gbs = B / wall / 1e9
+        roofline_path = {"bound": "hbm", "achieved": path_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": path_gbs / HBM_PEAK_GBS, "algorithmic_bytes": B, "wall_s": wall,
+                         "terms_in_columns": parts,
+                         "note": "rank 0's paths over the timed steps; matrix bytes only (SURVEY.md 8d)" + (
+                             "; B_path charges every fold its own sweep per lambda, while the folds in flight SHARE theirs (one "
+                             "pass over X answers up to 8 folds): a fraction above 1 is bytes saved, not bandwidth" if cfg == 5 else "")}
+
+        last_stat = stats[-1]
+        tm = last_stat["timers"]
+        workloads = {
+            2: f"Gaussian GLM, dense X {n}x{p} {args.dtype} column-major resident in HBM, group size {gs}, alpha={alpha}, "
+               f"{L}-lambda path, early_exit=False",
+            3: f"Gaussian GLM, dense X {n}x{p} {args.dtype} column-major resident in HBM, group size {gs} ({p // gs} groups), "
+               f"alpha={alpha}, {L}-lambda path, early_exit=False",
+            4: f"Binomial GLM (IRLS), matrix.snp_unphased 2-bit packed {n}x{p} (25% ones, 5% twos, 10% missing, mean-imputed) "
+               f"resident in HBM, lasso, {L}-lambda path, early_exit=False",
+            5: f"cv_grpnet {args.n_folds}-fold, Gaussian GLM, dense X {n}x{p} {args.dtype} resident in HBM, lasso, "
+               f"min_ratio=0.1, {L} lambdas, folds sharded fold k -> rank k % {world}",
+        }
         out = {
-            "metric": "lambda-paths/sec (100-lambda grpnet, dense Gaussian)",
-            "value": world * args.steps / elapsed,
+            "metric": METRIC,
+            "value": units / elapsed,
             "unit": "paths/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if cfg == 5 else "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {
-                "workload": f"Gaussian GLM, dense X {n}x{p} {args.dtype} column-major resident in HBM, "
-                            f"group size {args.group_size}, alpha={args.alpha}, {args.lmda_path_size}-lambda path, "
-                            f"early_exit=False"
-                            + ("" if world == 1 else f"; rank r trains on the complement of CV fold r%8 (weak scaling)"),
-                "n": n, "p": p, "lmda_path_size": args.lmda_path_size,
-            },
-            "roofline": {
-                "kernel": "sweep_kernel (grad = X^T (w*r) - rsum*xbar, full design)",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(n, p, args.dtype),
-                "launches": int(sweep_launches),
-                "avg_launch_ms": avg_ms,
-                "algorithmic_bytes_per_launch": sweep_bytes,
-            },
+            "config": {"workload": workloads[cfg] + ("" if world == 1 or cfg == 5 else
+                                                      "; rank r trains on the complement of CV fold r%8 (weak scaling)"),
+                       "baseline_config": cfg, "n": n, "p": p, "lmda_path_size": L, "group_size": gs, "alpha": alpha},
+            "roofline": roofline,
+            "roofline_path": roofline_path,
+            "roofline_sweep": sweep_roof if roofline is not sweep_roof else None,
+            "roofline_gram_mfma": gram_roof if roofline is not gram_roof else None,
             "roofline_panel_step": panel,
-            "breakdown_ms_last_step": {
+            "breakdown_ms_last_path": {
                 "sweep": tm["t_sweep_ms"], "gram_mfma": tm["t_gram_ms"], "cd": tm["t_cd_ms"], "resid_axpy": tm["t_axpy_ms"],
-                "host_screen": tm["t_host_screen_ms"], "total": 1e3 * state.total_time,
-                "gram_tflops": (tm["gram_flops"] / (tm["t_gram_ms"] * 1e-3) / 1e12) if tm["t_gram_ms"] > 0 else None,
+                "host_screen": tm["t_host_screen_ms"], "total": 1e3 * last_stat["total_time"],
             },
-            "counters": c,
-            "final_active": int(state.active_set_size),
-            "final_screen": int(len(state.screen_set)),
+            "counters": counters,
         }
+        if cfg == 5:
+            out["cv"] = {"cv_wall_s": elapsed / args.steps, "folds_per_s": units / elapsed, "n_folds": args.n_folds,
+                         "folds_per_rank": [len(range(r, args.n_folds, world)) for r in range(world)],
+                         "best_idx": int(last.best_idx), "min_avg_loss": float(last.avg_losses.min()),
+                         "note": "counters / rooflines aggregate rank 0's folds only"}
+        else:
+            out["final_active"] = int(last.active_set_size)
+            out["final_screen"] = int(len(last.screen_set))
+        if cv_leg is not None:
+            out["cv_config5"] = cv_leg
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(X, y, glm, kw, args, npdtype, state)
+            out["cpu_baseline"] = cpu_baseline(cfg, args, keep, y, glm, kw, cv_kw, npdtype, last, Xd, n, p)
         print(json.dumps(out), flush=True)
 
     if dist is not None:
@@ -223,59 +408,88 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(n, p, dtype, kernel="sweep_kernel"):
-    """HBM bytes per sweep launch from the PMC passes kept under profiles/ (FETCH_SIZE doubled as the gfx950 note in
-    guides/MI355X_MICROARCH.md prescribes, plus WRITE_SIZE); None when this shape was not profiled."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f).get(f"{kernel}:{n}x{p}:{dtype}")
-    except Exception:
-        return None
-
-
-def cpu_baseline(X, y, glm, kw, args, npdtype, gpu_state):
-    """Times the CPU oracle (a port of the reference algorithm, same OpenMP flags) on the same data."""
+# -------------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (reference algorithm, OpenMP) on the same data, bounded
+# -------------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(cfg, args, keep, y, glm, kw, cv_kw, npdtype, gpu_last, Xd, n, p):
     from oracle import oracle
 
     import adelie_amd as ad
 
-    avail = os.cpu_count() or 1
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
     # Thread count: the reference documents that more threads are not faster for this solver (parallelism.ipynb cells
     # 10-18: its OpenMP regions are per column visit).  Probed on the 256-core GPU-box host (scripts/cpu_threads_probe.py,
-    # first 25 lambdas): 8 thr 2.27 s, 16 thr 1.31 s, 32 thr 1.65 s, 64 thr 3.2 s, 128 thr 6.3 s -> use 16.
-    cores = min(avail, args.cpu_threads)
+    # first 25 lambdas): 8 thr 2.27 s, 16 thr 1.31 s, 32 thr 1.65 s, 64 thr 3.2 s, 128 thr 6.3 s -> 16.
+    cores = min(host_cores(), args.cpu_threads)
     os.environ["ORACLE_COL_THREADS"] = str(cores)
     os.environ.setdefault("OMP_PROC_BIND", "TRUE")  # reference adelie/__init__.py:8-19
-    Xh = X.t().contiguous().cpu().numpy().T  # (n, p) F-ordered host copy of the same matrix
-    Xo = oracle.dense(Xh, n_threads=cores)
-    budget = args.cpu_budget_s
-    t0 = time.perf_counter()
-    done = {"n": 0}
-
-    def exit_cond(view):
-        done["n"] = view.n_solutions
-        return (time.perf_counter() - t0) > budget
-
-    st = ad.grpnet(Xo, glm, n_threads=cores, exit_cond=exit_cond, **kw)
-    el = time.perf_counter() - t0
-    n_sol = len(st.lmdas)
+    budget = args.cpu_budget_s if args.cpu_budget_s is not None else {2: 30.0, 3: 30.0, 4: 30.0, 5: 30.0}[cfg]
     L = args.lmda_path_size
-    full = n_sol == L
-    db = float(np.abs(st.betas.toarray() - gpu_state.betas[:n_sol].toarray()).max()) if n_sol else None
-    if full:
-        value = 1.0 / el
-        sample = f"full {L}-lambda path on the same {args.n}x{args.p} data (host copy), {cores} OpenMP threads"
-    else:
-        # time budget hit: report the rate on the solved prefix, scaled by the GPU path's own share of work on it
-        value = (n_sol / L) / el
-        sample = (f"first {n_sol} of {L} lambdas of the same path (time budget {budget:.0f}s), value scaled as "
-                  f"(solved fraction)/time: an UPPER bound on the CPU paths/s since later lambdas cost more")
-    return {"value": value, "unit": "paths/s", "cores": cores, "kind": "port", "sample": sample,
-            "seconds": el, "max_abs_dbeta_vs_gpu": db}
+    base = {"unit": "paths/s", "cores": cores, "kind": "port", "host_cores_available": host_cores()}
+
+    def bounded_path(Xo, glm_, kw_, gpu_state):
+        """Runs the oracle until the budget is spent; returns (solved lambdas, seconds, max|dbeta| vs the GPU path)."""
+        t0 = time.perf_counter()
+        st = ad.grpnet(Xo, glm_, n_threads=cores, exit_cond=lambda s: (time.perf_counter() - t0) > budget, **kw_)
+        el = time.perf_counter() - t0
+        k = len(st.lmdas)
+        db = float(np.abs(st.betas.toarray() - gpu_state.betas[:k].toarray()).max()) if k else None
+        return k, el, db
+
+    if cfg in (2, 3):
+        Xh = keep["X"].t().contiguous().cpu().numpy().T  # (n, p) F-ordered host copy of the same matrix
+        k, el, db = bounded_path(oracle.dense(Xh, n_threads=cores), glm, kw, gpu_last)
+        if k == L:
+            value, sample = 1.0 / el, f"full {L}-lambda path on the same {n}x{p} data (host copy), {cores} OpenMP threads"
+        else:
+            value = (k / L) / el
+            sample = (f"first {k} of {L} lambdas of the same path on the same data (time budget {budget:.0f} s), {cores} OpenMP "
+                      f"threads; value = (solved fraction)/time, an UPPER bound on the CPU paths/s: later lambdas cost more")
+        return dict(base, value=value, sample=sample, seconds=el, lambdas_solved=k, max_abs_dbeta_vs_gpu=db)
+
+    if cfg == 4:
+        # The oracle keeps the calldata as int8 on the host (25 GB at 500k x 50k) and its early lambdas are sweep-bound; the
+        # sample is the top-left sub-block of the SAME calldata, on which the GPU path is timed as well (like for like).
+        ns, ps = min(n, 100_000), min(p, 10_000)
+        cd_s = keep["cd"][:ns, :ps]
+        cd_h = np.asfortranarray(cd_s.cpu().numpy())
+        imp_s = keep["imp"][:ps]
+        y_s = np.ascontiguousarray(y[:ns])
+        glm_s = ad.glm.binomial(y_s, dtype=npdtype)
+        Xg = ad.matrix.snp_calldata(cd_h, imp_s, dtype=npdtype)
+        ad.grpnet(Xg, glm_s, **kw)
+        t0 = time.perf_counter()
+        g_state = ad.grpnet(Xg, glm_s, **kw)
+        g_el = time.perf_counter() - t0
+        k, el, db = bounded_path(oracle.snp_calldata(cd_h, imp_s, dtype=npdtype, n_threads=cores), glm_s, kw, g_state)
+        g_prefix = float(np.sum(g_state.benchmark_fit_screen[:k])) if k else None
+        return dict(base, value=(k / L) / el, seconds=el, lambdas_solved=k, max_abs_dbeta_vs_gpu=db,
+                    sample=(f"sub-block {ns}x{ps} (top-left) of the same calldata and response, first {k} of {L} lambdas in a "
+                            f"{budget:.0f} s budget, {cores} OpenMP threads; value = (solved fraction)/time on the SUB-BLOCK "
+                            f"problem (upper bound: later lambdas cost more); the GPU path solves that sub-block's full "
+                            f"{L}-lambda path in gpu_same_sample_s"),
+                    gpu_same_sample_s=g_el, gpu_same_sample_paths_per_s=1.0 / g_el)
+
+    # cfg 5: one fold of the same CV (the full-data lmda_max call + the fold's two grpnet calls) with the oracle
+    Xh = keep["X"].t().contiguous().cpu().numpy().T
+    Xo = oracle.dense(Xh, n_threads=cores)
+    np.random.seed(0)
+    order = np.random.choice(n, n, replace=False)
+    b, e = ad.cv.fold_ranges(n, args.n_folds)[0]
+    w = np.full(n, 1.0 / n)
+    w[order[b:e]] = 0
+    w /= w.sum()
+    glm_c = ad.glm.gaussian(y, weights=w, dtype=npdtype)
+    t0 = time.perf_counter()
+    full = ad.grpnet(Xo, glm, n_threads=cores, lmda_path_size=0, progress_bar=False)
+    lm = full.lmda_max * np.logspace(0, -1, L)
+    st = ad.grpnet(Xo, glm_c, n_threads=cores, lmda_path=lm, early_exit=False, progress_bar=False,
+                   exit_cond=lambda s: (time.perf_counter() - t0) > budget)
+    el = time.perf_counter() - t0
+    k = len(st.lmdas)
+    return dict(base, value=(k / L) / el, seconds=el, lambdas_solved=k,
+                sample=(f"fold 0 of the same {args.n_folds}-fold CV (training weights of fold 0, the CV's lambda grid down to "
+                        f"min_ratio 0.1), first {k} of {L} lambdas in a {budget:.0f} s budget, {cores} OpenMP threads; value = "
+                        f"fold paths/s as (solved fraction)/time (upper bound); the reference runs its folds one after another"))
 
 
 if __name__ == "__main__":

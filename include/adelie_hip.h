@@ -105,6 +105,11 @@ int adelie_hip_design_create_snp_bed(const void* bed, int64_t n_bytes, int64_t n
  * (the folds of cv_grpnet) can run concurrently from different host threads: one path leaves most of the chip idle
  * while its sequential block solves run, two or three paths interleave.  The alias must be destroyed before `src`. */
 int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out);
+/* Shared full-gradient sweeps of concurrent solves on this design and its aliases ("sweep_batch" config above), cumulative
+ * since the design was created: out[0] = launches of the K-wide sweep kernel, out[1] = vectors they answered (= the ordinary
+ * sweeps saved + launches), out[2] = their HIP-event time in ms on the batcher's stream.  Used by bench.py for the roofline of
+ * cv_grpnet's dominant kernel (one launch streams the design once: n*p*sizeof(value) algorithmic bytes). */
+int adelie_hip_design_batch_stats(adelie_hip_design* d, double* out);
 /* A new dense design derived from a resident one (dense or SNP): rows `rows[0..n_rows)` (NULL: all), columns
  * `cols[0..n_cols)` (NULL: all), every resulting column j centred by centers[j] and divided by scales[j] (NULL: no centring /
  * scaling).  This is what adelie.matrix.subset (matrix_naive_subset.ipp) and adelie.matrix.standardize
@@ -312,6 +317,8 @@ enum adelie_hip_scalar {
     ADELIE_HIP_S_N_GRAM_COL_READS, ADELIE_HIP_S_N_RESID_COL_READS, ADELIE_HIP_S_GRAM_FLOPS,
     ADELIE_HIP_S_N_PANEL_BLOCKS, ADELIE_HIP_S_N_PANEL_GRAMS, /* block visits / diagonal blocks built by the panel engine */
     ADELIE_HIP_S_N_PANEL_COLS, /* design columns streamed by the panel steps (gradient + residual update) */
+    ADELIE_HIP_S_N_IRLS_SCREEN_COLS, /* sum over IRLS iterations of the screened columns (their means and variances are
+                                        recomputed under every iteration's weights: the IRLS term of SURVEY.md 8d's B_path) */
     /* HIP-event time (ms) of the device phases on the design's stream, summed over the solve, and launch counts */
     ADELIE_HIP_S_T_SWEEP_MS = 80, ADELIE_HIP_S_T_GRAM_MS, ADELIE_HIP_S_T_CD_MS, ADELIE_HIP_S_T_AXPY_MS,
     ADELIE_HIP_S_N_SWEEP_LAUNCHES, ADELIE_HIP_S_N_GRAM_LAUNCHES, ADELIE_HIP_S_T_HOST_SCREEN_MS,

@@ -63,6 +63,10 @@ d = make_gaussian(90, 15, seed=1)
 res = ad.cv_grpnet(oracle.dense(d["X"]), ad.glm.gaussian(d["y"]), n_folds=5, seed=3, lmda_path_size=8, tol=1e-12,
                    process_group=True)
 np.save({str(tmp_path)!r} + f"/loss{{dist.get_rank()}}.npy", res.losses)
+np.random.seed(50 + dist.get_rank())   # unseeded call, different streams: rank 0's permutation is broadcast
+res = ad.cv_grpnet(oracle.dense(d["X"]), ad.glm.gaussian(d["y"]), n_folds=5, lmda_path_size=8, tol=1e-12,
+                   process_group=True)
+np.save({str(tmp_path)!r} + f"/uloss{{dist.get_rank()}}.npy", res.losses)
 dist.destroy_process_group()
 """)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
@@ -73,6 +77,11 @@ dist.destroy_process_group()
     d = make_gaussian(90, 15, seed=1)
     single = ad.cv_grpnet(oracle.dense(d["X"]), ad.glm.gaussian(d["y"]), n_folds=5, seed=3, lmda_path_size=8, tol=1e-12)
     assert np.allclose(l0, single.losses, rtol=1e-12, atol=0)
+    u0, u1 = np.load(tmp_path / "uloss0.npy"), np.load(tmp_path / "uloss1.npy")
+    assert np.array_equal(u0, u1)
+    np.random.seed(50)
+    usingle = ad.cv_grpnet(oracle.dense(d["X"]), ad.glm.gaussian(d["y"]), n_folds=5, lmda_path_size=8, tol=1e-12)
+    assert np.allclose(u0, usingle.losses, rtol=1e-12, atol=0)
 
 
 @pytest.mark.gpu
@@ -119,3 +128,37 @@ def test_cv_concurrent_folds_on_alias_handles(hip, kind, monkeypatch):
     np.testing.assert_array_equal(d.losses, e.losses)
     assert d.best_idx == a.best_idx
     del Xa
+
+
+@pytest.mark.gpu
+def test_cv_fold_sharding_two_ranks_on_device(hip, tmp_path):
+    """The multi-GPU path of cv_grpnet with DEVICE designs: two ranks (both on cuda:0 — the test box has one GPU — rendezvous
+    over gloo; the driver's multi-GPU runs use RCCL) shard the folds, draw their permutation WITHOUT a seed (rank 0's is
+    broadcast), all_gather the loss rows, and agree with each other and with the single-process result for that permutation."""
+    script = tmp_path / "run.py"
+    script.write_text(f"""
+import os, sys, numpy as np
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+import torch, torch.distributed as dist
+import adelie_amd as ad
+from util import make_gaussian
+torch.cuda.set_device(0)
+dist.init_process_group(backend="gloo")
+rank = dist.get_rank()
+d = make_gaussian(600, 80, seed=1)
+X = ad.matrix.dense(d["X"])
+np.random.seed(100 + rank)          # different streams per rank: the fold order must still be rank 0's
+res = ad.cv_grpnet(X, ad.glm.gaussian(d["y"]), n_folds=5, lmda_path_size=12, tol=1e-12, process_group=True)
+np.save({str(tmp_path)!r} + f"/loss{{rank}}.npy", res.losses)
+assert len(res.fold_stats) == len(range(rank, 5, 2))
+dist.destroy_process_group()
+""")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29618", str(script)], env=env, timeout=900)
+    l0, l1 = np.load(tmp_path / "loss0.npy"), np.load(tmp_path / "loss1.npy")
+    assert np.array_equal(l0, l1)
+    d = make_gaussian(600, 80, seed=1)
+    np.random.seed(100)                 # rank 0's stream
+    single = ad.cv_grpnet(ad.matrix.dense(d["X"]), ad.glm.gaussian(d["y"]), n_folds=5, lmda_path_size=12, tol=1e-12)
+    assert np.allclose(l0, single.losses, rtol=1e-9, atol=1e-12)

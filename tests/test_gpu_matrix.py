@@ -297,3 +297,43 @@ def test_new_constructors_reject_bad_inputs(hip):
     with pytest.raises(RuntimeError, match="multi_path_losses\\(\\) is given inconsistent inputs"):
         X.multi_path_losses(0, 2, sp.csr_matrix(np.zeros((1, 7))), np.zeros((1, 2)), np.zeros((20, 2)), np.zeros((20, 2)),
                             np.ones(20) / 20, np.ones(20) / 20)
+
+
+def test_snpdat_decoder_rejects_corrupt_images(hip, tmp_path):
+    """A truncated or corrupted ``.snpdat`` image must raise, never read outside the buffer: every byte of the header and of the
+    first column's offset table / chunk headers is damaged in turn (the offsets, counts and chunk sizes the decoder follows)."""
+    rng = np.random.RandomState(0)
+    n, p = 700, 5
+    cd = rng.choice(np.array([0, 1, 2, -9], dtype=np.int8), size=(n, p), p=[0.5, 0.3, 0.1, 0.1])
+    io = ad.io.snp_unphased(str(tmp_path / "a.snpdat"))
+    io.write(np.asfortranarray(cd))
+    io.read()
+    good = np.array(io._buffer, copy=True)
+    b = hip
+    h = _abi_handle = __import__("ctypes").c_void_p()
+
+    def attempt(buf):
+        rc = b.fn("design_create_snp_unphased")(buf.ctypes.data, buf.size, 1, 0, h)
+        if rc == 0:
+            b.fn("design_destroy")(h)
+        return rc
+
+    assert attempt(good) == 0
+    hdr = 17 + 24 * p + 8 * (p + 1)
+    n_rejected = 0
+    for cut in (0, 5, 16, hdr - 1, hdr + 10, good.size - 1):
+        assert attempt(good[:cut].copy()) != 0
+    # byte 4 is left alone: it turns n = 700 into ~4e9 rows, which is still below the decoder's plausibility cap (2^32) and
+    # would only make the test allocate gigabytes for a "valid" all-zero tail
+    for pos in [q for q in range(1, 17) if q != 4] + list(range(17 + 24 * p, hdr + 40)):
+        for val in (0xFF, 0x00, 0x7F):
+            bad = good.copy()
+            if bad[pos] == val:
+                continue
+            bad[pos] = val
+            n_rejected += attempt(bad) != 0
+    assert n_rejected > 50
+    # a row count beyond the cap is refused before anything is sized from it
+    bad = good.copy()
+    bad[1:9] = np.frombuffer(np.uint64(1 << 45).tobytes(), dtype=np.uint8)
+    assert attempt(bad) != 0 and b"row / column counts" in b.fn("last_error")()

@@ -101,3 +101,81 @@ def test_binomial_snp_properties(hip, n, p):
         # active coordinates: |grad_j - lm*sign(b_j)| small relative to lm (IRLS + CD stopping rules)
         assert np.abs(grad[~zero] - lm * np.sign(b[~zero])).max() < 2e-3 * lm + 1e-7
     assert st.active_set_size > 128
+
+
+def test_binomial_snp_full_size_config4(hip):
+    """BASELINE.json config 4 at FULL size: binomial lasso on a 2-bit SNP design 500k x 50k (6.25 GB packed), the 100-lambda path
+    with the solver's default tolerances.  Far beyond the oracle's reach in a test, so the path is certified on the device
+    design itself: sorted lambdas, monotone deviance, intercept stationarity and the lasso KKT conditions of the binomial
+    deviance at sampled lambdas (zero coordinates inside the lambda band, active ones on it to the resolution of the IRLS / CD
+    stopping rules)."""
+    import torch
+    import bench
+
+    n, p = 500_000, 50_000
+    cd, imp, y = bench.make_snp_data(n, p, 0, torch.device("cuda", 0))
+    Xd = ad.matrix.snp_calldata(cd, imp)
+    del cd
+    torch.cuda.empty_cache()
+    st = ad.grpnet(Xd, ad.glm.binomial(y), early_exit=False, progress_bar=False)
+    assert st.error == "" and len(st.lmdas) == 100
+    assert st.counters["n_panel_blocks"] > 0 and st.counters["n_irls_iters"] >= 100
+    assert np.all(np.diff(st.lmdas) < 0) and np.all(np.diff(st.devs) >= -1e-9)
+    assert abs(st.devs[0]) < 1e-6 and st.devs[-1] > 0.05
+    assert st.active_set_size > 5000
+    w = np.full(n, 1 / n)
+    for l in [10, 60, 99]:
+        b = st.betas[l].toarray().ravel()
+        e = (Xd @ b) + st.intercepts[l]
+        resid = w * (y - 1 / (1 + np.exp(-e)))
+        assert abs(resid.sum()) < 1e-7                      # intercept stationarity
+        grad = Xd.T @ resid
+        lm = st.lmdas[l]
+        zero = b == 0
+        viol_zero = (np.abs(grad[zero]) - lm).max() / lm
+        viol_act = np.abs(grad[~zero] - lm * np.sign(b[~zero])).max() / lm
+        print(f"config 4, lambda {l}: zero-coordinate excess {viol_zero:.2e} lm, active-coordinate residual {viol_act:.2e} lm")
+        assert viol_zero < 1e-3
+        assert viol_act < 5e-2
+    # the invariants the state hands back: eta and resid = glm.gradient(eta) of the last solution
+    e = (Xd @ st.betas[-1].toarray().ravel()) + st.intercepts[-1]
+    assert np.abs(st.eta - e).max() < 1e-8
+    assert np.abs(st.resid - w * (y - 1 / (1 + np.exp(-e)))).max() < 1e-12
+
+
+def test_cv_full_size_config5(hip):
+    """BASELINE.json config 5 at full size on one GPU: cv_grpnet(n_folds=8) on the dense 100k x 10k Gaussian design.
+    (a) the loss identity cv_loss[k, i] = sum_{fold k} w l(eta) / sum_{fold k} w on two sampled folds, from a direct grpnet fit
+    of that fold's training weights; (b) the table does not depend on how many folds are in flight (one at a time, separate
+    sweeps, shared sweeps) beyond the stopping-rule resolution."""
+    import torch
+    import bench
+    from adelie_amd.cv import fold_ranges
+
+    n, p, K = 100_000, 10_000, 8
+    X, y = bench.make_data(n, p, 0, torch.device("cuda", 0), torch.float64)
+    Xd = ad.matrix.dense(X)
+    glm = ad.glm.gaussian(y)
+    res = ad.cv_grpnet(Xd, glm, n_folds=K, seed=0)                       # default: 8 folds in flight, sweeps shared
+    assert res.losses.shape == (K, 100) and np.all(np.isfinite(res.losses))
+    assert res.best_idx == int(np.argmin(res.avg_losses)) and np.all(np.diff(res.avg_losses[:20]) < 0)
+    assert len(res.fold_stats) == K and all(f["counters"]["n_basil_iters"] >= 100 for f in res.fold_stats)
+    one = ad.cv_grpnet(Xd, glm, n_folds=K, seed=0, n_concurrent=1)
+    # the same folds, the same paths: differences are summation order inside the shared sweeps, amplified to the resolution
+    # of the CD stopping rule (tol = 1e-7) on the validation loss
+    assert np.abs(res.losses - one.losses).max() < 2e-6 * np.abs(one.losses).max()
+    assert res.best_idx == one.best_idx
+    np.random.seed(0)
+    order = np.random.choice(n, n, replace=False)
+    for k in (0, 5):
+        b, e = fold_ranges(n, K)[k]
+        val = order[b:e]
+        w = glm.weights.copy()
+        w[val] = 0
+        w /= w.sum()
+        st = ad.grpnet(Xd, glm.reweight(w), lmda_path=res.lmdas, early_exit=False, progress_bar=False)
+        assert st.error == "" and len(st.lmdas) == 100
+        for i in (0, 40, 99):
+            eta = (Xd @ st.betas[i].toarray().ravel()) + st.intercepts[i]
+            li = 0.5 * eta[val] ** 2 - y[val] * eta[val]
+            assert np.isclose(one.losses[k, i], li.mean(), rtol=2e-5, atol=1e-8), (k, i, one.losses[k, i], li.mean())

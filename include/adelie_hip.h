@@ -283,11 +283,35 @@ typedef struct adelie_hip_grpnet_args {
     adelie_hip_poll_fn poll;          /* may be NULL */
     void*          poll_user;
     const adelie_hip_glm_callbacks* glm_cb; /* required iff glm_kind == ADELIE_HIP_GLM_CALLBACK */
+    /* ---- covariance method (adelie_hip_gaussian_cov_solve only) ---- */
+    const void*    cov_v;             /* (p,) value_t: the linear term v of 1/2 b'Ab - v'b */
+    double         rdev_tol;          /* early exit on the relative change of the deviance (solver_gaussian_cov.hpp:183-201) */
 } adelie_hip_grpnet_args;
 
 /* Runs the whole path.  `*out` is always set on return code 0 (even when the solve recorded
  * an error string): the caller owns it and frees it with adelie_hip_result_destroy. */
 int adelie_hip_grpnet_solve(adelie_hip_design* X, const adelie_hip_grpnet_args* args, adelie_hip_result** out);
+
+/* ------------------------------------------------------------------------------------------
+ * Covariance method  
+ *   == adelie.matrix.dense(method="cov") / MatrixCovDense{32,64}{C,F}   (matrix_cov_dense.ipp:9-84)
+ *   == StateGaussianCov{32,64}(...).solve(pb, exit_cond)                (py_state.cpp, state_gaussian_cov.hpp:40-145,
+ *                                                                        solver_gaussian_cov.hpp:362-457)
+ * minimises 1/2 b'Ab - v'b + penalty along a lambda path from summary statistics: A is a symmetric positive semi-definite
+ * (p, p) matrix resident in HBM, the solver keeps grad = v - A b and never sees individual-level data.  The args struct is
+ * the one of grpnet_solve; of it the covariance state reads the problem, path, configuration and warm-start fields,
+ * `grad`, `rsq`, `cov_v` and `rdev_tol` (weights / X_means / resid / GLM fields are ignored; there is no intercept).
+ * Result accessors as above: devs holds rsq (the unnormalised decrease of the loss), intercepts are zero.
+ * ------------------------------------------------------------------------------------------ */
+int adelie_hip_design_create_cov_dense(const void* host, int64_t p, int dtype, int order, int device, adelie_hip_design** out);
+/* MatrixCovBase::bmul (matrix_cov_dense.ipp:23-41): out[j] = sum_i values[i] * A(indices[i], subset[j]) */
+int adelie_hip_design_cov_bmul(adelie_hip_design* A, const int64_t* subset, int64_t n_subset, const int64_t* indices,
+                               const void* values, int64_t n_indices, void* out);
+/* MatrixCovBase::mul (:43-62): out = sum_i values[i] * A[indices[i], :] */
+int adelie_hip_design_cov_mul(adelie_hip_design* A, const int64_t* indices, const void* values, int64_t n_indices, void* out);
+/* MatrixCovBase::to_dense (:64-74): out = A[i:i+q, i:i+q], (q, q) column-major */
+int adelie_hip_design_cov_to_dense(adelie_hip_design* A, int64_t i, int64_t q, void* out);
+int adelie_hip_gaussian_cov_solve(adelie_hip_design* A, const adelie_hip_grpnet_args* args, adelie_hip_result** out);
 int adelie_hip_result_destroy(adelie_hip_result* r);
 
 /* ---- result accessors: the read-only properties of py_state.cpp:763-1040,1156-1217 ---- */

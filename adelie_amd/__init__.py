@@ -20,6 +20,6 @@ except ImportError:  # pragma: no cover
     pass
 from .configs import set_configs
 from .cv import cv_grpnet
-from .solver import grpnet
+from .solver import gaussian_cov, grpnet
 
 __version__ = "0.1.0"

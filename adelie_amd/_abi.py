@@ -93,6 +93,8 @@ class GrpnetArgs(C.Structure):
         ("poll", POLL_FN),
         ("poll_user", C.c_void_p),
         ("glm_cb", C.POINTER(GlmCallbacks)),
+        ("cov_v", C.c_void_p),
+        ("rdev_tol", C.c_double),
     ]
 
 
@@ -127,6 +129,7 @@ HIP_SYMBOLS = [
     "design_device", "design_stream",
     "design_cmul", "design_ctmul", "design_bmul", "design_btmul", "design_mul", "design_mul_batch", "design_cov",
     "design_sq_mul", "design_sp_tmul",
+    "design_create_cov_dense", "design_cov_bmul", "design_cov_mul", "design_cov_to_dense", "gaussian_cov_solve",
     "grpnet_solve", "result_destroy", "result_size", "result_copy", "result_scalar", "result_error", "result_sync",
     "bench_sweep",
 ]
@@ -202,6 +205,11 @@ class Backend:
         sig("design_sq_mul", ci, [vp, vp, vp])
         sig("design_sp_tmul", ci, [vp, i64, vp, vp, vp, vp])
         sig("grpnet_solve", ci, [vp, p(GrpnetArgs), p(vp)])
+        sig("gaussian_cov_solve", ci, [vp, p(GrpnetArgs), p(vp)])
+        sig("design_create_cov_dense", ci, [vp, i64, ci, ci, ci, p(vp)])
+        sig("design_cov_bmul", ci, [vp, vp, i64, vp, vp, i64, vp])
+        sig("design_cov_mul", ci, [vp, vp, vp, i64, vp])
+        sig("design_cov_to_dense", ci, [vp, i64, i64, vp])
         sig("result_destroy", ci, [vp])
         sig("result_size", i64, [vp, ci])
         sig("result_copy", ci, [vp, ci, vp, i64])

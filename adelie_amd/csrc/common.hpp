@@ -81,6 +81,9 @@ struct adelie_hip_design {
     int dtype = ADELIE_HIP_F64;
     int device = 0;
     int kind = 0; // 0 dense, 1 snp (2-bit), 2 multi-response view of a dense design (adelie_hip_design_create_multi)
+    // covariance-method matrix A (adelie_hip_design_create_cov_dense): a dense (p, p) design with n == p that only
+    // adelie_hip_gaussian_cov_solve and the cov_* operations accept; cov == 2: the stored matrix is A^T (row-major input)
+    int cov = 0;
     int64_t n = 0, p = 0;
     // dense
     void* X = nullptr;

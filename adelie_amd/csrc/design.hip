@@ -414,6 +414,12 @@ void op_multi_path_losses(adelie_hip_design* d, int kind, int K, int64_t L, cons
 void no_view(const adelie_hip_design* d) {
     if (d && d->kind == 2)
         throw make_core_error("this entry point is not offered on a multi-response view; use the base design.");
+    if (d && d->cov)
+        throw make_core_error("this entry point takes a design matrix, not a covariance matrix (matrix.dense(method=\"cov\")).");
+}
+void need_cov(const adelie_hip_design* d) {
+    if (!d) throw make_core_error("null argument.");
+    if (!d->cov) throw make_core_error("A must be a covariance matrix (matrix.dense(method=\"cov\")).");
 }
 
 void check_col(const adelie_hip_design* d, int64_t j, int64_t q, const char* what) {
@@ -516,6 +522,49 @@ void concat_t(adelie_hip_design* const* srcs, int64_t k, int axis, adelie_hip_de
 void adelie_hip_internal_free_batcher(void* b); // solver.hip
 void adelie_hip_internal_batch_stats(void* b, double* out);
 
+namespace {
+template <class T>
+void op_cov_bmul(adelie_hip_design* d, const int64_t* subset, int64_t ns, const int64_t* indices, const T* values, int64_t ni,
+                 T* out) {
+    set_device(d);
+    hipStream_t s = d->stream;
+    int64_t* dsub = scratch<int64_t>(d->s_idx1, ns + 1);
+    int64_t* dind = scratch<int64_t>(d->s_idx2, ni + 1);
+    T* dval = scratch<T>(d->s_n1, ni + 1);
+    T* dout = scratch<T>(d->s_p1, ns + 1);
+    AHIP_CHECK(hipMemcpyAsync(dsub, subset, size_t(ns) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    AHIP_CHECK(hipMemcpyAsync(dind, indices, size_t(ni) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    AHIP_CHECK(hipMemcpyAsync(dval, values, size_t(ni) * sizeof(T), hipMemcpyHostToDevice, s));
+    launch_cov_bmul<T>(static_cast<const T*>(d->X), d->ld, d->cov == 2, dsub, ns, dind, dval, ni, dout, s);
+    AHIP_CHECK(hipMemcpyAsync(out, dout, size_t(ns) * sizeof(T), hipMemcpyDeviceToHost, s));
+    AHIP_CHECK(hipStreamSynchronize(s));
+}
+template <class T>
+void op_cov_mul(adelie_hip_design* d, const int64_t* indices, const T* values, int64_t ni, T* out) {
+    set_device(d);
+    hipStream_t s = d->stream;
+    int64_t* dind = scratch<int64_t>(d->s_idx2, ni + 1);
+    T* dval = scratch<T>(d->s_n1, ni + 1);
+    T* dout = scratch<T>(d->s_p1, d->p);
+    AHIP_CHECK(hipMemcpyAsync(dind, indices, size_t(ni) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    AHIP_CHECK(hipMemcpyAsync(dval, values, size_t(ni) * sizeof(T), hipMemcpyHostToDevice, s));
+    launch_cov_mul<T>(static_cast<const T*>(d->X), d->ld, d->p, dind, dval, ni, dout, s);
+    AHIP_CHECK(hipMemcpyAsync(out, dout, size_t(d->p) * sizeof(T), hipMemcpyDeviceToHost, s));
+    AHIP_CHECK(hipStreamSynchronize(s));
+}
+template <class T>
+void op_cov_to_dense(adelie_hip_design* d, int64_t i, int64_t q, T* out) {
+    set_device(d);
+    const T* S = static_cast<const T*>(d->X);
+    AHIP_CHECK(hipMemcpy2DAsync(out, size_t(q) * sizeof(T), S + i + i * d->ld, size_t(d->ld) * sizeof(T), size_t(q) * sizeof(T),
+                                size_t(q), hipMemcpyDeviceToHost, d->stream));
+    AHIP_CHECK(hipStreamSynchronize(d->stream));
+    if (d->cov == 2) // the stored block is the transpose
+        for (int64_t b = 0; b < q; ++b)
+            for (int64_t a = b + 1; a < q; ++a) std::swap(out[a + b * q], out[b + a * q]);
+}
+} // namespace
+
 extern "C" {
 
 int adelie_hip_abi_version(void) { return ADELIE_HIP_ABI_VERSION; }
@@ -539,6 +588,57 @@ int adelie_hip_design_create_dense(const void* host, int64_t n, int64_t p, int d
         throw;
     }
     *out = d;
+    ABI_CATCH
+}
+
+// adelie.matrix.dense(method="cov"): the (p, p) buffer is uploaded as it lies; a row-major input is therefore stored as A^T
+// (cov == 2), which the cov_* operations account for and which is the same matrix when A is symmetric, as the method assumes
+int adelie_hip_design_create_cov_dense(const void* host, int64_t p, int dtype, int order, int device, adelie_hip_design** out) {
+    ABI_TRY
+    if (!host || !out) throw make_core_error("null argument.");
+    if (p <= 0) throw make_core_error("mat must be (p, p).");
+    adelie_hip_design* d = new_design(p, p, dtype, device);
+    try {
+        if (dtype == ADELIE_HIP_F64) create_dense_t<double>(d, host, false, ADELIE_HIP_COL_MAJOR);
+        else create_dense_t<float>(d, host, false, ADELIE_HIP_COL_MAJOR);
+        d->cov = (order == ADELIE_HIP_ROW_MAJOR) ? 2 : 1;
+    } catch (...) {
+        adelie_hip_design_destroy(d);
+        throw;
+    }
+    *out = d;
+    ABI_CATCH
+}
+
+
+int adelie_hip_design_cov_bmul(adelie_hip_design* d, const int64_t* subset, int64_t ns, const int64_t* indices,
+                               const void* values, int64_t ni, void* out) {
+    ABI_TRY
+    need_cov(d);
+    if (ns < 0 || ni < 0 || ns > d->p || ni > d->p) throw make_core_error("bmul() is given inconsistent inputs!");
+    for (int64_t k = 0; k < ns; ++k)
+        if (subset[k] < 0 || subset[k] >= d->p) throw make_core_error("bmul(): subset index out of range.");
+    for (int64_t k = 0; k < ni; ++k)
+        if (indices[k] < 0 || indices[k] >= d->p) throw make_core_error("bmul(): index out of range.");
+    DTYPE_DISPATCH(d, op_cov_bmul<double>(d, subset, ns, indices, (const double*)values, ni, (double*)out),
+                   op_cov_bmul<float>(d, subset, ns, indices, (const float*)values, ni, (float*)out))
+    ABI_CATCH
+}
+int adelie_hip_design_cov_mul(adelie_hip_design* d, const int64_t* indices, const void* values, int64_t ni, void* out) {
+    ABI_TRY
+    need_cov(d);
+    if (ni < 0 || ni > d->p) throw make_core_error("mul() is given inconsistent inputs!");
+    for (int64_t k = 0; k < ni; ++k)
+        if (indices[k] < 0 || indices[k] >= d->p) throw make_core_error("mul(): index out of range.");
+    DTYPE_DISPATCH(d, op_cov_mul<double>(d, indices, (const double*)values, ni, (double*)out),
+                   op_cov_mul<float>(d, indices, (const float*)values, ni, (float*)out))
+    ABI_CATCH
+}
+int adelie_hip_design_cov_to_dense(adelie_hip_design* d, int64_t i, int64_t q, void* out) {
+    ABI_TRY
+    need_cov(d);
+    if (i < 0 || q < 0 || i + q > d->p) throw make_core_error("to_dense() is given inconsistent inputs!");
+    if (q > 0) { DTYPE_DISPATCH(d, op_cov_to_dense<double>(d, i, q, (double*)out), op_cov_to_dense<float>(d, i, q, (float*)out)) }
     ABI_CATCH
 }
 

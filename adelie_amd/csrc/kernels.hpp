@@ -341,6 +341,19 @@ struct IrlsScalars {
 
 // ---- misc -------------------------------------------------------------------------------------
 // copy a (rows x cols) block between column-major matrices with different leading dimensions
+// covariance-method matrix (kernels_cov.hip)
+template <class T>
+void launch_cov_gather(const T* S, int64_t lda, int tr, const int32_t* vcol, int32_t nv, int32_t pos0, int32_t N, T* C,
+                       int64_t ldc, hipStream_t s);
+template <class T>
+void launch_cov_bmul(const T* S, int64_t lda, int tr, const int64_t* subset, int64_t ns, const int64_t* indices,
+                     const T* values, int64_t ni, T* out, hipStream_t s);
+template <class T>
+void launch_cov_mul(const T* S, int64_t lda, int64_t p, const int64_t* indices, const T* values, int64_t ni, T* out,
+                    hipStream_t s);
+template <class T>
+void launch_cov_grad(const T* S, int64_t lda, int64_t p, const T* v, const int32_t* cols, const T* coef, const int32_t* cnt,
+                     T* grad, hipStream_t s);
 template <class T> void launch_copy2d(const T* src, int64_t lds, T* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s);
 // vars[pos0 + a] = max(C[(pos0+a)*(ldc+1)], 0) for a < cnt   (gs == 1 groups)
 template <class T> void launch_diag_vars(const T* C, int64_t ldc, int32_t pos0, int32_t cnt, T* vars, hipStream_t s);

@@ -347,6 +347,11 @@ struct Solver {
     adelie_hip_poll_fn poll;
     void* poll_user;
     const adelie_hip_result* live = nullptr; // the handle poll() receives: the state being solved (py_state.cpp:62-91)
+    // covariance method (StateGaussianCov, state_gaussian_cov.hpp:40-145): D holds A (p x p), there is no residual; the
+    // invariant is grad = v - A beta and the Gram engines iterate on C = A[S, S]
+    bool cov_mode = false;
+    T rdev_tol = 0;
+    DevBuf<T> d_covv, d_zero;
     adelie_hip_glm_callbacks glm_cb{};       // glm_kind == CALLBACK: the user's GlmBase subclass, evaluated on the host
     std::vector<T> cb_eta, cb_grad, cb_hess, cb_z;
     idx max_gs = 1;
@@ -806,7 +811,11 @@ struct Solver {
         screen_vars.resize(nv, 0);
         screen_transforms.resize(ns);
         if (N <= 0) return;
-        gram(w_dev, nv, pos0, N, xm_dev, intercept);
+        if (cov_mode) // the rows / columns of A of the new screen values (solver_gaussian_cov.hpp:63-97 reads A_gg from them)
+            launch_cov_gather<T>(static_cast<const T*>(D->X), D->ld, D->cov == 2, d_vcol.p, int32_t(nv), int32_t(pos0), int32_t(N),
+                                 d_C.p, ldc, st);
+        else
+            gram(w_dev, nv, pos0, N, xm_dev, intercept);
         gram_nv = nv;
         cnt.n_new_screen_cols += N;
         launch_diag_vars<T>(d_C.p, ldc, int32_t(pos0), int32_t(N), d_vars.p, st);
@@ -1128,6 +1137,11 @@ struct Solver {
     }
     // solver_base.hpp:241-263
     bool early_exit() const {
+        if (cov_mode) { // solver_gaussian_cov.hpp:183-201: relative change of the (unnormalised) deviance
+            if (!early_exit_ || devs.size() < 2) return false;
+            const T dev_u = devs[devs.size() - 1], dev_m = devs[devs.size() - 2];
+            return dev_u - dev_m <= rdev_tol * dev_u;
+        }
         if (!early_exit_ || devs.empty()) return false;
         const T dev_u = devs.back();
         if (dev_u >= adev_tol) return true;
@@ -1984,8 +1998,9 @@ struct Solver {
             if (sc.status == CD_MAX_ACTIVE) throw make_solver_error("Maximum number of active groups reached.");
             throw make_solver_error("Newton-ABS max iterations reached! Try increasing newton_max_iters.");
         }
-        // residual update r -= X_S (beta - beta0), once per fit
-        if (sc.n_delta > 0) {
+        // residual update r -= X_S (beta - beta0), once per fit (the covariance method has no residual: its invariant, the
+        // gradient, is recomputed from v and A by update_invariance)
+        if (sc.n_delta > 0 && !cov_mode) {
             t_axpy.begin(st);
             axpy_cols(d_dcols.p, d_dvals.p, &d_sc.p->n_delta, 0, T(-1), r_dev);
             t_axpy.end(st);
@@ -2054,6 +2069,17 @@ struct Solver {
     }
     // the sweep epilogue indexes sub_vec by design column -> use the by-column means
     const T* d_sxm_by_value() const { return d_xm.p; }
+
+    // gaussian::cov::fit, solver_gaussian_cov.hpp:232-357.  The reference's pin solver keeps `screen_grad` current with one
+    // A.bmul per coordinate update; here the screen gradient of every fit is read from the full gradient of the last
+    // invariance step (the same numbers in exact arithmetic) and the Gram kernels keep it current inside the fit.
+    FitOut<T> cov_fit(T lm) {
+        if (nv > 0) launch_gather<T>(d_grad.p, d_vcol.p, nv, d_g.p, st);
+        T rsum = 0;
+        FitOut<T> o = pin_solve(lm, tol, rsq, rsum, T(0), nullptr);
+        rsq = o.rsq;
+        return o;
+    }
 
     // gaussian::naive::fit, solver_gaussian_naive.hpp:209-349
     FitOut<T> gaussian_fit(T lm) {
@@ -2340,7 +2366,16 @@ struct Solver {
         CdScalars<T> sc{};
         sc.resid_sum = resid_sum;
         d_sc.upload(&sc, 1, st);
-        if (is_glm()) {
+        if (cov_mode) { // solver_gaussian_cov.hpp:392-418: grad = v - A beta over the non-zero coefficients
+            if (nv > 0) {
+                d_zero.reserve(size_t(nv));
+                AHIP_CHECK(hipMemsetAsync(d_zero.p, 0, size_t(nv) * sizeof(T), st));
+                launch_cd_compact<T>(d_beta.p, d_zero.p, d_vcol.p, int(nv), d_dcols.p, d_dvals.p, &d_sc.p->n_delta, st);
+            }
+            t_sweep.begin(st);
+            launch_cov_grad<T>(static_cast<const T*>(D->X), D->ld, p, d_covv.p, d_dcols.p, d_dvals.p, &d_sc.p->n_delta, d_grad.p, st);
+            t_sweep.end(st);
+        } else if (is_glm()) {
             t_sweep.begin(st);
             sweep(d_r.p, d_grad.p, nullptr, p, nullptr, nullptr); // resid already carries the weights
             t_sweep.end(st);
@@ -2362,7 +2397,9 @@ struct Solver {
         betas_val.emplace_back(std::move(fo.beta_val));
         intercepts.push_back(fo.intercept);
         lmdas.push_back(lm);
-        if (is_glm()) { // solver_glm_naive.hpp:153-157
+        if (cov_mode) { // solver_gaussian_cov.hpp:203-229: the deviance is rsq itself (the saturated loss is unknown)
+            devs.push_back(fo.rsq);
+        } else if (is_glm()) { // solver_glm_naive.hpp:153-157
             const T loss = glm_loss_dev(d_eta.p);
             devs.push_back((loss_null - loss) / (loss_null - loss_full));
         } else {
@@ -2401,7 +2438,7 @@ struct Solver {
     FitOut<T> fit_f(T lm) {
         Stopwatch sw;
         sw.start();
-        FitOut<T> o = is_glm() ? glm_fit(lm) : gaussian_fit(lm);
+        FitOut<T> o = cov_mode ? cov_fit(lm) : is_glm() ? glm_fit(lm) : gaussian_fit(lm);
         t_host[3] += sw.elapsed();
         return o;
     }
@@ -2506,7 +2543,7 @@ struct Solver {
     // adelie_hip_result_sync does for the live state inside a poll callback
     void download_invariants() {
         d_grad.download(grad.data(), size_t(p), st);
-        d_r.download(resid.data(), size_t(n), st);
+        if (!cov_mode) d_r.download(resid.data(), size_t(n), st);
         if (is_glm()) d_eta.download(eta.data(), size_t(n), st);
         if (nv > 0) {
             d_beta.download(screen_beta.data(), size_t(nv), st);
@@ -2531,6 +2568,7 @@ struct Solver {
         D = X;
         st = X->stream;
         n = X->n; p = X->p; G = a->G;
+        cov_mode = X->cov != 0;
         if (G <= 0) throw make_core_error("groups must be non-empty.");
         groups.assign(a->groups, a->groups + G);
         group_sizes.assign(a->group_sizes, a->group_sizes + G);
@@ -2607,6 +2645,13 @@ struct Solver {
             panel_bsz = std::atoi(e);
             if (panel_bsz != 32 && panel_bsz != 64 && panel_bsz != 128) panel_bsz = 0;
         }
+        if (cov_mode) { // base state of the covariance method: no intercept, adev_tol = ddev_tol = 0 (state_gaussian_cov.hpp:118)
+            engine_panel = false; // the panel engines work on the residual; the Gram engines on C = A[S, S] and its gradient
+            glm_kind = ADELIE_HIP_GLM_GAUSSIAN;
+            intercept = false;
+            adev_tol = 0; ddev_tol = 0;
+            rdev_tol = T(a->rdev_tol);
+        }
         if (multi()) {
             // StateMultiGaussianNaive (state.py:2300-2380): the Gaussian naive solver, global intercept off, on the view.
             // Everything runs on the group panel engine (its blocks are what lets a column slice serve K responses).
@@ -2644,7 +2689,16 @@ struct Solver {
         update_screen_derived_base();
         update_abs_grad_host(lmda);
 
-        if (!is_glm()) {
+        if (cov_mode) {
+            if (!a->cov_v) throw make_core_error("v must be (p,) where A is (p, p).");
+            d_covv.reserve(p); d_xm.reserve(p);
+            d_covv.upload((const T*)a->cov_v, p, st);
+            X_means.assign(size_t(p), T(0)); // no centring in the covariance method
+            d_xm.upload(X_means.data(), p, st);
+            rsq = T(a->rsq);
+            sync();
+            gaussian_update_screen_derived();
+        } else if (!is_glm()) {
             // state_gaussian_naive.hpp:40-160
             const T* w = (const T*)a->weights;
             if (!w || !a->X_means || !a->resid) throw make_core_error("weights, X_means and resid are required.");
@@ -2953,9 +3007,18 @@ int adelie_hip_set_config(const char* name, double value) {
     return 0;
 }
 
+static int solve_entry(adelie_hip_design* X, const adelie_hip_grpnet_args* args, adelie_hip_result** out, bool cov);
 int adelie_hip_grpnet_solve(adelie_hip_design* X, const adelie_hip_grpnet_args* args, adelie_hip_result** out) {
+    return solve_entry(X, args, out, false);
+}
+int adelie_hip_gaussian_cov_solve(adelie_hip_design* A, const adelie_hip_grpnet_args* args, adelie_hip_result** out) {
+    return solve_entry(A, args, out, true);
+}
+static int solve_entry(adelie_hip_design* X, const adelie_hip_grpnet_args* args, adelie_hip_result** out, bool cov) {
     try {
         if (!X || !args || !out) throw make_core_error("null argument.");
+        if (cov && !X->cov) throw make_core_error("A must be a covariance matrix (matrix.dense(method=\"cov\")).");
+        if (!cov && X->cov) throw make_core_error("X is a covariance matrix: use gaussian_cov for the covariance method.");
         auto* res = new adelie_hip_result();
         try {
             if (X->dtype == ADELIE_HIP_F64) run<double>(X, args, res);

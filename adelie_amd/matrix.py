@@ -31,6 +31,20 @@ class MatrixNaiveBase32(MatrixNaiveBase):
     dtype = np.float32
 
 
+class MatrixCovBase:
+    """Base of the covariance-method matrices (role of ``MatrixCovBase{32,64}``, ``matrix_cov_base.hpp:20-110``)."""
+
+    dtype = None
+
+
+class MatrixCovBase64(MatrixCovBase):
+    dtype = np.float64
+
+
+class MatrixCovBase32(MatrixCovBase):
+    dtype = np.float32
+
+
 def _as(v, dtype):
     return np.ascontiguousarray(v, dtype=dtype)
 
@@ -557,8 +571,10 @@ def dense(mat, *, method: str = "naive", copy: bool = False, n_threads: int = 1,
     device : int
         HIP device ordinal for host inputs.
     """
+    if method == "cov":
+        return _cov_dense(_abi.hip_backend(), "design_create_cov_dense", mat, n_threads, device)
     if method != "naive":
-        raise NotImplementedError("adelie_amd.matrix.dense: only method='naive' is on the grpnet hot path.")
+        raise ValueError("method must be one of 'naive' or 'cov'.")
     if n_threads < 1:
         raise RuntimeError("adelie_core: n_threads must be >= 1.")
     backend = _abi.hip_backend()
@@ -823,3 +839,101 @@ def as_design(X, *, n_threads: int = 1):
     if isinstance(X, np.ndarray) or type(X).__module__.startswith("torch"):
         return dense(X, method="naive", n_threads=n_threads)
     return from_plugin(X, n_threads=n_threads)
+
+
+class _CovMatrix:
+    """A symmetric ``(p, p)`` matrix resident in HBM for the covariance method (``adelie.matrix.dense(method="cov")``,
+    reference ``MatrixCovDense``, ``matrix_cov_dense.ipp:9-84``).  Methods are the ``MatrixCovBase`` virtuals, one C-ABI call
+    each, with the reference's argument conventions (pre-allocated outputs written in place)."""
+
+    def _init_native(self, backend, handle, n_threads, keep):
+        self._backend, self._handle, self._n_threads, self._keep = backend, handle, n_threads, keep
+        self._cols = int(backend.fn("design_cols")(handle))
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None:
+            try:
+                self._backend.fn("design_destroy")(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    def rows(self):
+        return self._cols
+
+    def cols(self):
+        return self._cols
+
+    @property
+    def ndim(self):
+        return 2
+
+    @property
+    def shape(self):
+        return (self._cols, self._cols)
+
+    def _chk(self, cond, msg):
+        if not cond:
+            raise RuntimeError("adelie_core: " + msg)
+
+    def bmul(self, subset, indices, values, out):
+        """``out[j] = sum_i values[i] * A[indices[i], subset[j]]`` (``matrix_cov_dense.ipp:23-41``)."""
+        r = self._cols
+        subset, indices = (np.ascontiguousarray(x, dtype=np.int64) for x in (subset, indices))
+        values = np.ascontiguousarray(values, dtype=self.dtype)
+        s, i, v, o = len(subset), len(indices), len(values), len(out)
+        self._chk(0 <= s <= r and 0 <= i <= r and i == v and o == s,
+                  "bmul() is given inconsistent inputs! Invoked check_bmul(s=%d, i=%d, v=%d, o=%d, r=%d, c=%d)" % (s, i, v, o, r, r))
+        buf = out if (isinstance(out, np.ndarray) and out.dtype == self.dtype and out.flags.c_contiguous) else np.empty(s, dtype=self.dtype)
+        self._backend.check(self._backend.fn("design_cov_bmul")(
+            self._handle, subset.ctypes.data, s, indices.ctypes.data, values.ctypes.data, i, buf.ctypes.data))
+        if buf is not out:
+            out[...] = buf
+
+    def mul(self, indices, values, out):
+        """``out = sum_i values[i] * A[indices[i], :]`` (``matrix_cov_dense.ipp:43-62``)."""
+        r = self._cols
+        indices = np.ascontiguousarray(indices, dtype=np.int64)
+        values = np.ascontiguousarray(values, dtype=self.dtype)
+        i, v, o = len(indices), len(values), len(out)
+        self._chk(0 <= i <= r and i == v and o == r,
+                  "mul() is given inconsistent inputs! Invoked check_mul(i=%d, v=%d, o=%d, r=%d, c=%d)" % (i, v, o, r, r))
+        buf = out if (isinstance(out, np.ndarray) and out.dtype == self.dtype and out.flags.c_contiguous) else np.empty(r, dtype=self.dtype)
+        self._backend.check(self._backend.fn("design_cov_mul")(self._handle, indices.ctypes.data, values.ctypes.data, i,
+                                                                buf.ctypes.data))
+        if buf is not out:
+            out[...] = buf
+
+    def to_dense(self, i, p, out):
+        """``out = A[i:i+p, i:i+p]`` (``matrix_cov_dense.ipp:64-74``); ``out`` is ``(p, p)`` F-ordered."""
+        r = self._cols
+        self._chk(0 <= i <= r - p and out.shape == (p, p),
+                  "to_dense() is given inconsistent inputs! Invoked check_to_dense(i=%d, p=%d, o_r=%d, o_c=%d, r=%d, c=%d)"
+                  % (i, p, out.shape[0], out.shape[1] if out.ndim > 1 else -1, r, r))
+        buf = np.empty((p, p), dtype=self.dtype, order="F")
+        self._backend.check(self._backend.fn("design_cov_to_dense")(self._handle, int(i), int(p), buf.ctypes.data))
+        out[...] = buf
+
+
+def _cov_dense(backend, ctor, mat, n_threads, device):
+    """``adelie.matrix.dense(mat, method="cov")`` (reference ``matrix.py:549-680``, cov branch): a dense symmetric matrix,
+    copied to HBM once."""
+    if n_threads < 1:
+        raise RuntimeError("adelie_core: n_threads must be >= 1.")
+    mat = np.asarray(mat)
+    if mat.ndim != 2 or mat.shape[0] != mat.shape[1]:
+        raise RuntimeError("adelie_core: mat must be (p, p).")
+    code = _abi.dtype_code(mat.dtype)
+    if mat.flags.f_contiguous:
+        order = _abi.COL_MAJOR
+    else:
+        order = _abi.ROW_MAJOR
+        mat = np.ascontiguousarray(mat)
+    handle = _abi.C.c_void_p()
+    backend.check(backend.fn(ctor)(mat.ctypes.data, mat.shape[0], code, order, device, handle))
+    base = MatrixCovBase64 if mat.dtype == np.float64 else MatrixCovBase32
+    cls = type("_cov_matrix", (_CovMatrix, base), {"dtype": base.dtype})
+    obj = cls()
+    obj._init_native(backend, handle, n_threads, mat)
+    return obj

@@ -281,3 +281,50 @@ def grpnet(
     if check_state:
         state.check(method="assert")
     return state.solve(progress_bar=progress_bar, exit_cond=exit_cond)
+
+
+def gaussian_cov(
+    A, v, *,
+    constraints: list = None, groups: np.ndarray = None, alpha: float = 1, penalty: np.ndarray = None,
+    lmda_path: np.ndarray = None, max_iters: int = int(1e5), tol: float = 1e-7, rdev_tol: float = 1e-3,
+    newton_tol: float = 1e-12, newton_max_iters: int = 1000, n_threads: int = 1, early_exit: bool = True,
+    screen_rule: str = "pivot", min_ratio: float = 1e-2, lmda_path_size: int = 100,
+    max_screen_size: int = None, max_active_size: int = None,
+    pivot_subset_ratio: float = 0.1, pivot_subset_min: int = 1, pivot_slack_ratio: float = 1.25,
+    check_state: bool = False, progress_bar: bool = True, warm_start=None, exit_cond: Callable = None,
+):
+    """Gaussian group elastic net from summary statistics (covariance method) on an MI355X.
+
+    Minimises ``1/2 beta' A beta - v' beta + lmda * sum_g penalty_g (alpha ||beta_g|| + (1 - alpha) / 2 ||beta_g||^2)``
+    along a decreasing path of ``lmda`` (reference ``adelie.solver.gaussian_cov``, ``adelie/solver.py:39-351``; arguments,
+    defaults and the returned state are the reference's).  ``A`` is a symmetric positive semi-definite ``(p, p)`` ndarray
+    or an ``adelie_amd.matrix.dense(A, method="cov")`` handle (resident in HBM); ``v`` is ``(p,)``.  With ``A = X_c' W X_c``
+    and ``v = X_c' W y_c`` this is the Gaussian ``grpnet`` problem (``devs`` then holds the unnormalised ``rsq``)."""
+    if isinstance(A, np.ndarray):
+        A = matrix.dense(A, method="cov", n_threads=n_threads)
+    if not isinstance(A, (matrix.MatrixCovBase64, matrix.MatrixCovBase32)):
+        raise ValueError("A must be an instance of MatrixCovBase32, MatrixCovBase64, or np.ndarray.")
+    dtype = A.dtype
+    p = A.cols()
+    if isinstance(constraints, list):
+        for c in constraints:
+            if c is not None:
+                c.clear()
+    if lmda_path is not None:
+        lmda_path = np.sort(np.asarray(lmda_path))[::-1].astype(dtype)
+    layout = _Layout.single(groups, p, penalty, dtype)
+    if warm_start is not None:
+        start = {name: getattr(warm_start, name) for name in _SCREEN_FIELDS + ("rsq", "grad")}
+    else:
+        start = _start_screen(layout, alpha, dtype)
+        # the gradient of beta = 0 is v (reference solver.py:279-290 subtracts A times the all-zero screen coefficients)
+        start.update(rsq=0, grad=np.array(v, dtype=dtype, copy=True))
+    state = _state.gaussian_cov(
+        A=A, v=v, constraints=constraints, groups=layout.groups, group_sizes=layout.group_sizes, alpha=alpha,
+        penalty=layout.penalty, lmda_path=lmda_path, max_iters=max_iters, tol=tol, rdev_tol=rdev_tol, newton_tol=newton_tol,
+        newton_max_iters=newton_max_iters, n_threads=n_threads, early_exit=early_exit, screen_rule=screen_rule,
+        min_ratio=min_ratio, lmda_path_size=lmda_path_size, max_screen_size=max_screen_size, max_active_size=max_active_size,
+        pivot_subset_ratio=pivot_subset_ratio, pivot_subset_min=pivot_subset_min, pivot_slack_ratio=pivot_slack_ratio, **start)
+    if check_state:
+        state.check(method="assert")
+    return state.solve(progress_bar=progress_bar, exit_cond=exit_cond)

@@ -67,7 +67,7 @@ class _ProgressBar:
         self._out = sys.stderr
         self.total, self.width = total, width
         self.t0 = self.t_last = time.perf_counter()
-        self.n, self.dev = 0, 0.0
+        self.n, self.dev, self.label = 0, 0.0, "dev"
 
     @staticmethod
     def _clock(sec):
@@ -80,9 +80,9 @@ class _ProgressBar:
         rate = self.n / el if el > 0 else 0.0
         left = (self.total - self.n) / rate if rate > 0 else 0.0
         fill = int(round(frac * self.width))
-        self._out.write("\r%3d%%|%s%s| %d/%d [%s<%s, %.2fit/s] [dev:%.1f%%]" % (
+        self._out.write("\r%3d%%|%s%s| %d/%d [%s<%s, %.2fit/s] [%s:%.1f%%]" % (
             int(100 * frac), "\u2588" * fill, " " * (self.width - fill), self.n, self.total, self._clock(el),
-            self._clock(left), rate, 100 * self.dev))
+            self._clock(left), rate, self.label, 100 * self.dev))
         self._out.flush()
 
     def update(self, n, dev):
@@ -185,8 +185,8 @@ class base:
                     return 0
                 view = live_state(self, backend, live) if (bar is not None or exit_cond is not None) else None
                 if bar is not None:
-                    devs = view.devs
-                    bar.update(int(n_solutions), float(devs[-1]) if len(devs) else 0.0)
+                    bar.label, shown = self._progress(view.devs)
+                    bar.update(int(n_solutions), shown)
                 if exit_cond is not None:
                     return 1 if exit_cond(view) else 0
             except BaseException as e:  # noqa: BLE001 - ctypes would swallow it: stop the path, re-raise after the solve
@@ -199,7 +199,7 @@ class base:
         args.poll_user = None
         handle = _abi.C.c_void_p()
         try:
-            backend.check(backend.fn("grpnet_solve")(self._X._handle, _abi.C.byref(args), handle))
+            backend.check(backend.fn(self._solve_entry)(self._X._handle, _abi.C.byref(args), handle))
         finally:
             if bar is not None:
                 bar.close()
@@ -223,6 +223,13 @@ class base:
     def _tidy_path(self, betas, intercepts):
         """Hook of the multi-response states: splits the per-class intercepts off the coefficient rows."""
         return betas, intercepts
+
+    _solve_entry = "grpnet_solve"
+
+    @staticmethod
+    def _progress(devs):
+        """What the progress bar shows next to the count: the fraction of deviance explained (``solver_base.hpp:225-239``)."""
+        return "dev", (float(devs[-1]) if len(devs) else 0.0)
 
     def _from_result(self, backend, r):
         new = object.__new__(type(self))
@@ -817,4 +824,122 @@ def glm_naive(
         raise RuntimeError("adelie_core: eta must be (n,) where X is (n, p).")
     if irls_tol <= 0:
         raise RuntimeError("adelie_core: irls_tol must be > 0.")
+    return s
+
+
+class gaussian_cov_base(base):
+    """Gaussian, covariance method state (reference ``state.py:1128-1418``; core ``state_gaussian_cov.hpp:40-145``)."""
+
+    _solve_entry = "gaussian_cov_solve"
+
+    @staticmethod
+    def _progress(devs):
+        """Relative change of the deviance explained (``solver_gaussian_cov.hpp:165-181``): the saturated loss is unknown here."""
+        if len(devs) < 2 or devs[-1] == 0:
+            return "rdev", 0.0
+        return "rdev", float((devs[-1] - devs[-2]) / devs[-1])
+
+    def _marshal(self):
+        keep = []
+        a = _abi.GrpnetArgs()
+        self.resid = np.empty(0, dtype=self.dtype)  # no residual in the covariance method; the common marshaller wants the name
+        self._common_args(a, keep)
+        del self.resid
+        v = np.ascontiguousarray(self.v, dtype=self.dtype)
+        keep.append(v)
+        a.glm_kind = _abi.GLM_GAUSSIAN
+        a.cov_v = v.ctypes.data
+        a.rsq = float(self.rsq)
+        a.rdev_tol = float(self.rdev_tol)
+        return a, keep
+
+    def _from_result_extra(self, new, backend, r, sc):
+        new.rsq = self.dtype(sc("rsq"))
+        del new.resid  # (the accessor returns an empty vector for this state)
+
+    def check(self, method: str = None, logger=logger):
+        """Invariants of reference ``state.py:1260-1327`` that do not need the solver: ``grad = v - A beta`` on the screen set."""
+        A, p = self._X, self._X.cols()
+        beta = np.zeros(p, dtype=self.dtype)
+        begins = np.concatenate([[0], np.cumsum(self.group_sizes[self.screen_set])])
+        for ss, g in enumerate(self.screen_set):
+            q = self.group_sizes[g]
+            beta[self.groups[g]:self.groups[g] + q] = self.screen_beta[begins[ss]:begins[ss] + q]
+        nz = np.flatnonzero(beta)
+        Ab = np.empty(p, dtype=self.dtype)
+        A.mul(nz, beta[nz], Ab)
+        ok = bool(np.allclose(self.grad, np.asarray(self.v) - Ab, atol=1e-6))
+        logger.log(logging.INFO if ok else logging.ERROR, f"check grad = v - A beta: {'pass' if ok else 'FAIL'}")
+        if method == "assert":
+            assert ok, "grad = v - A beta"
+        return ok
+
+
+def gaussian_cov(
+    *, A, v, constraints, groups, group_sizes, alpha, penalty, screen_set, screen_beta, screen_is_active, active_set_size,
+    active_set, rsq, lmda, grad, lmda_path=None, lmda_max=None, max_iters=int(1e5), tol=1e-7, rdev_tol=1e-3, newton_tol=1e-12,
+    newton_max_iters=1000, n_threads=1, early_exit=True, screen_rule="pivot", min_ratio=1e-2, lmda_path_size=100,
+    max_screen_size=None, max_active_size=None, pivot_subset_ratio=0.1, pivot_subset_min=1, pivot_slack_ratio=1.25,
+):
+    """Creates a Gaussian, covariance method state object (reference ``adelie.state.gaussian_cov``, ``state.py:1128-1418``;
+    argument meaning identical).  ``A`` is an ndarray or an ``adelie_amd.matrix.dense(method="cov")`` handle."""
+    if isinstance(A, np.ndarray):
+        A = _matrix.dense(A, method="cov", n_threads=n_threads)
+    if not isinstance(A, (_matrix.MatrixCovBase64, _matrix.MatrixCovBase32)) or not hasattr(A, "_backend"):
+        raise ValueError("A must be an instance of MatrixCovBase32, MatrixCovBase64, or np.ndarray.")
+    dtype = A.dtype
+    (max_screen_size, max_active_size, lmda_path_size, setup_lmda_max, setup_lmda_path, lmda_max, lmda_path) = \
+        _render_inputs(groups=groups, lmda_max=lmda_max, lmda_path=lmda_path, lmda_path_size=lmda_path_size,
+                       max_screen_size=max_screen_size, max_active_size=max_active_size, dtype=dtype)
+    s = gaussian_cov_base()
+    s.dtype = dtype
+    s._X = s.A = s._A = A
+    s.v = np.array(v, copy=True, dtype=dtype)
+    s.constraints = constraints
+    s.groups = np.array(groups, copy=True, dtype=int)
+    s.group_sizes = np.array(group_sizes, copy=True, dtype=int)
+    s.alpha = alpha
+    s.penalty = np.array(penalty, copy=True, dtype=dtype)
+    s.lmda_path = np.asarray(lmda_path, dtype=dtype)
+    s.lmda_max = lmda_max
+    s.min_ratio = min_ratio
+    s.lmda_path_size = lmda_path_size
+    s.max_screen_size = max_screen_size
+    s.max_active_size = max_active_size
+    s.pivot_subset_ratio = pivot_subset_ratio
+    s.pivot_subset_min = pivot_subset_min
+    s.pivot_slack_ratio = pivot_slack_ratio
+    s.screen_rule = screen_rule
+    s.max_iters = max_iters
+    s.tol = tol
+    s.rdev_tol = rdev_tol
+    s.adev_tol = 0          # the covariance state passes 0 for both to the base state (state_gaussian_cov.hpp:118)
+    s.ddev_tol = 0
+    s.newton_tol = newton_tol
+    s.newton_max_iters = newton_max_iters
+    s.early_exit = early_exit
+    s.setup_lmda_max = setup_lmda_max
+    s.setup_lmda_path = setup_lmda_path
+    s.intercept = False
+    s.n_threads = n_threads
+    s.screen_set = np.asarray(screen_set, dtype=int)
+    s.screen_beta = np.asarray(screen_beta, dtype=dtype)
+    s.screen_is_active = np.asarray(screen_is_active, dtype=bool)
+    s.active_set_size = active_set_size
+    s.active_set = np.asarray(active_set, dtype=int)
+    s.rsq = rsq
+    s.lmda = lmda
+    s.grad = np.asarray(grad, dtype=dtype)
+    s.error = ""
+    G, p = len(s.groups), A.cols()
+    if len(s.group_sizes) != G:
+        raise RuntimeError("adelie_core: group_sizes must be (G,) where groups is (G,).")
+    if len(s.penalty) != G:
+        raise RuntimeError("adelie_core: penalty must be (G,) where groups is (G,).")
+    if s.constraints is not None and any(c is not None for c in s.constraints):
+        raise NotImplementedError("adelie_amd: per-group constraints are not implemented (pass None).")
+    if len(s.v) != p:
+        raise RuntimeError("adelie_core: v must be (p,) where A is (p, p).")
+    if len(s.grad) != p:
+        raise RuntimeError("adelie_core: grad must be (p,) where A is (p, p).")
     return s

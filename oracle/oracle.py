@@ -107,3 +107,11 @@ def eigh(A):
     D = np.empty(q)
     b.lib.oracle_eigh(q, A.ctypes.data, V.ctypes.data, D.ctypes.data)
     return D, V
+
+
+def cov_dense(mat, *, n_threads: int = 1):
+    """CPU counterpart of ``adelie_amd.matrix.dense(mat, method="cov")`` (non-owning view, like the reference)."""
+    b = backend()
+    p, vp, i64, ci = C.POINTER, C.c_void_p, C.c_int64, C.c_int
+    b.fn("design_create_cov_dense").argtypes = [vp, i64, ci, ci, ci, p(vp)]  # last int = n_threads
+    return _matrix._cov_dense(b, "design_create_cov_dense", np.asarray(mat), n_threads, n_threads)

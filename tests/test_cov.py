@@ -1,0 +1,225 @@
+"""The covariance method: ``matrix.dense(method="cov")`` and ``gaussian_cov``.
+
+Reference: ``adelie/solver.py:39-351``, ``solver_gaussian_cov.hpp``, ``solver_gaussian_pin_cov.hpp``, ``matrix_cov_dense.ipp``;
+its tests ``tests/test_matrix.py:128-166`` (``run_cov``) and ``tests/test_solver.py:978-1028`` (``test_gaussian_cov``: the
+covariance path equals the naive path on the same lambdas); known answer ``quickstart.ipynb`` cell 29: ``63/100 ... [rdev:0.1%]``."""
+import numpy as np
+import pytest
+
+import adelie_amd as ad
+from util import make_gaussian
+
+
+def run_cov(A, cA, dtype, seed=0):
+    """The reference's check list for a MatrixCovBase (tests/test_matrix.py:128-166)."""
+    rng = np.random.RandomState(seed)
+    p = A.shape[0]
+    atol = 1e-5 if dtype == np.float32 else 1e-13
+    v = rng.normal(0, 1, p)
+    nnzs = rng.binomial(1, 0.7, p).astype(bool)
+    v[~nnzs] = 0
+    indices = np.arange(p)[nnzs]
+    values = v[indices].astype(dtype)
+    for i in range(1, p + 1):
+        subset = np.sort(rng.choice(p, i, replace=False))
+        out = np.empty(i, dtype=dtype)
+        cA.bmul(subset, indices, values, out)
+        assert np.allclose(v.T @ A[:, subset], out, atol=atol)
+    out = np.empty(p, dtype=dtype)
+    cA.mul(indices, values, out)
+    assert np.allclose(v.T @ A, out, atol=atol)
+    q = min(10, p)
+    out = np.empty((q, q), dtype=dtype, order="F")
+    for i in range(p - q + 1):
+        cA.to_dense(i, q, out)
+        assert np.allclose(A[i:i + q, i:i + q], out, atol=atol)
+    assert cA.rows() == p and cA.cols() == p and cA.shape == (p, p) and cA.ndim == 2
+    with pytest.raises(RuntimeError, match="bmul"):
+        cA.bmul(np.arange(2), indices, values, np.empty(3, dtype=dtype))
+    with pytest.raises(RuntimeError, match="mul"):
+        cA.mul(indices, values, np.empty(p + 1, dtype=dtype))
+    with pytest.raises(RuntimeError, match="to_dense"):
+        cA.to_dense(p - q + 1, q, out)
+
+
+def _cov_matrix(n, p, dtype, order, seed=0):
+    rng = np.random.RandomState(seed)
+    X = rng.normal(size=(n, p))
+    return np.asarray(X.T @ X / n, dtype=dtype, order=order)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("order", ["C", "F"])
+@pytest.mark.parametrize("n,p", [(10, 1), (30, 23)])
+def test_oracle_cov_dense(oracle, n, p, dtype, order):
+    A = _cov_matrix(n, p, dtype, order)
+    run_cov(A.astype(np.float64), oracle.cov_dense(A), dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("order", ["C", "F"])
+@pytest.mark.parametrize("n,p", [(10, 1), (30, 23), (50, 301)])
+def test_hip_cov_dense(hip, n, p, dtype, order):
+    A = _cov_matrix(n, p, dtype, order)
+    run_cov(A.astype(np.float64), ad.matrix.dense(A, method="cov"), dtype)
+    # a non-symmetric matrix keeps its orientation (the cov_* operations are those of the reference on any square matrix)
+    rng = np.random.RandomState(1)
+    B = np.asarray(rng.normal(size=(9, 9)), dtype=dtype, order=order)
+    cB = ad.matrix.dense(B, method="cov")
+    out = np.empty(4, dtype=dtype)
+    cB.bmul(np.array([1, 3, 4, 8]), np.array([0, 2]), np.array([1.0, -2.0], dtype=dtype), out)
+    assert np.allclose(out, B[0, [1, 3, 4, 8]] - 2 * B[2, [1, 3, 4, 8]], atol=1e-5)
+    blk = np.empty((3, 3), dtype=dtype, order="F")
+    cB.to_dense(2, 3, blk)
+    assert np.allclose(blk, B[2:5, 2:5])
+
+
+def _quickstart(dense, cov_dense):
+    """quickstart.ipynb cells 5, 19-20, 27-32."""
+    n, p = 100, 1000
+    np.random.seed(0)
+    X = np.random.normal(0, 1, (n, p))
+    y = X[:, -1] * np.random.normal(0, 1) + np.random.normal(0, 1, n)
+    groups = 10 * np.arange(p // 10)
+    state = ad.grpnet(dense(np.asfortranarray(X)), ad.glm.gaussian(y), groups=groups, progress_bar=False)
+    Xc = X - np.mean(X, axis=0)[None]
+    yc = y - np.mean(y)
+    A = Xc.T @ Xc / n
+    v = Xc.T @ yc / n
+    return state, ad.gaussian_cov(A=cov_dense(A), v=v, groups=groups)
+
+
+def _check_quickstart(state, state_cov, capsys):
+    err = capsys.readouterr().err.strip().split("\r")[-1]
+    assert state_cov.error == "" and len(state_cov.lmdas) == 63                   # cell 29: 63/100
+    assert "| 63/100 [" in err and err.endswith("[rdev:0.1%]"), err
+    k = min(state_cov.betas.shape[0], state.betas.shape[0])
+    assert np.allclose(state_cov.betas[:k].toarray(), state.betas[:k].toarray(), atol=1e-3)   # cell 32
+    assert np.all(state_cov.intercepts == 0)
+    assert np.all(np.diff(state_cov.devs) >= 0)
+    d = state_cov.devs
+    assert (d[-1] - d[-2]) <= 1e-3 * d[-1] and (d[-2] - d[-3]) > 1e-3 * d[-2]    # the rdev_tol exit rule, exactly once
+
+
+def test_oracle_reproduces_quickstart_cov(oracle, capsys):
+    _check_quickstart(*_quickstart(oracle.dense, oracle.cov_dense), capsys)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_quickstart_cov(hip, capsys):
+    _check_quickstart(*_quickstart(ad.matrix.dense, lambda A: ad.matrix.dense(A, method="cov")), capsys)
+
+
+def _cov_equals_naive(dense, cov_dense, n, p, G, alpha, dtype, tol):
+    """tests/test_solver.py:978-1028: the same problem through both methods, the covariance path on the naive path's lambdas."""
+    d = make_gaussian(n, p, G=G, seed=n + p, dtype=dtype)
+    X, y, groups = d["X"], d["y"], d["groups"]
+    # (p > n: stop where the reference's test stops, adev_tol = 0.2 — further down the minimiser is not unique)
+    sn = ad.grpnet(dense(X), ad.glm.gaussian(y, dtype=dtype), groups=groups, alpha=alpha, intercept=False,
+                   adev_tol=0.2 if p > n else 0.6, tol=tol, progress_bar=False)
+    A = np.asfortranarray(X.astype(np.float64).T @ X.astype(np.float64) / n).astype(dtype)
+    v = (X.astype(np.float64).T @ y.astype(np.float64) / n).astype(dtype)
+    sc = ad.gaussian_cov(A=cov_dense(A), v=v, groups=groups, alpha=alpha, lmda_path=sn.lmdas, tol=tol, early_exit=False,
+                         progress_bar=False)
+    assert sn.error == "" and sc.error == "" and len(sc.lmdas) == len(sn.lmdas) > 2
+    return sn, sc
+
+
+@pytest.mark.parametrize("n,p,G,alpha", [(10, 50, 10, 1.0), (40, 13, 7, 1.0), (60, 40, 40, 0.5), (80, 30, 9, 0.3)])
+def test_oracle_cov_equals_naive(oracle, n, p, G, alpha):
+    sn, sc = _cov_equals_naive(oracle.dense, oracle.cov_dense, n, p, G, alpha, np.float64, 1e-16)
+    # Stated tolerance 1e-6 (the reference's f64 threshold, tests/test_solver.py:444-445).  Where n < group size the
+    # within-group Gram is singular and the two methods stop a hair apart (tol * y_var vs tol): 2.3e-7 at tol = 1e-12 (hence 1e-16 here),
+    # 2.3e-9 at 1e-16, 2.2e-11 at 1e-20 on the first shape — the stopping rule's resolution, not a different minimiser.
+    assert np.abs(sn.betas.toarray() - sc.betas.toarray()).max() < 1e-6
+    # devs of the covariance state are the unnormalised rsq of the naive state
+    np.testing.assert_allclose(sc.devs, np.asarray(sn.devs) * sn.y_var, rtol=1e-6, atol=1e-10)
+
+
+def _cov_kkt(A, v, st, groups, group_sizes, penalty, alpha):
+    worst = 0.0
+    B = st.betas.toarray()
+    for l, lm in enumerate(st.lmdas):
+        b = B[l]
+        grad = v - A @ b
+        for g, gs, pen in zip(groups, group_sizes, penalty):
+            gg, bb = grad[g:g + gs], b[g:g + gs]
+            nb = np.linalg.norm(bb)
+            if nb == 0:
+                worst = max(worst, np.linalg.norm(gg) - lm * alpha * pen)
+            else:
+                worst = max(worst, np.linalg.norm(gg - lm * pen * (alpha * bb / nb + (1 - alpha) * bb)))
+    return worst
+
+
+@pytest.mark.parametrize("alpha", [1.0, 0.4])
+def test_oracle_cov_kkt_and_warm_start(oracle, alpha):
+    d = make_gaussian(70, 45, G=14, seed=5, zero_pen=0.1)
+    X, y = d["X"], d["y"]
+    A, v = X.T @ X / 70, X.T @ y / 70
+    cA = oracle.cov_dense(np.asfortranarray(A))
+    kw = dict(groups=d["groups"], penalty=d["penalty"], alpha=alpha, tol=1e-13, early_exit=False, lmda_path_size=25,
+              progress_bar=False)
+    st = ad.gaussian_cov(cA, v, **kw)
+    assert st.error == "" and len(st.lmdas) == 25
+    assert _cov_kkt(A, v, st, d["groups"], d["group_sizes"], d["penalty"], alpha) < 1e-6
+    assert np.abs(st.grad - (v - A @ st.betas[-1].toarray().ravel())).max() < 1e-10
+    # warm start: continue the first half of the path from its final state
+    half = ad.gaussian_cov(cA, v, **dict(kw, lmda_path=st.lmdas[:12]))
+    rest = ad.gaussian_cov(cA, v, warm_start=half, **dict(kw, lmda_path=st.lmdas[12:]))
+    assert np.abs(rest.betas.toarray() - st.betas[12:].toarray()).max() < 1e-9
+    assert rest.check(method="assert")
+
+
+def test_cov_argument_errors(oracle):
+    A = np.eye(4)
+    with pytest.raises(ValueError, match="MatrixCovBase"):
+        ad.gaussian_cov(A=oracle.dense(np.asfortranarray(A)), v=np.zeros(4))
+    with pytest.raises(RuntimeError, match=r"v must be \(p,\)"):
+        ad.gaussian_cov(A=oracle.cov_dense(A), v=np.zeros(3))
+    with pytest.raises(RuntimeError, match=r"mat must be \(p, p\)"):
+        oracle.cov_dense(np.zeros((3, 4)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,p,G,alpha", [(10, 50, 10, 1.0), (40, 13, 7, 1.0), (60, 40, 40, 0.5), (80, 30, 9, 0.3),
+                                         (400, 700, 700, 1.0), (300, 640, 64, 0.7)])
+def test_hip_cov_matches_oracle(hip, oracle, n, p, G, alpha, dtype):
+    """HIP covariance path vs the oracle's restatement of the reference algorithm on identical inputs; the last two shapes run
+    the multi-CU Gram engines (screen sets beyond 256 values), lasso and groups."""
+    tol = 1e-16 if dtype == np.float64 else 1e-7
+    hn, hc = _cov_equals_naive(ad.matrix.dense, lambda A: ad.matrix.dense(A, method="cov"), n, p, G, alpha, dtype, tol)
+    on, oc = _cov_equals_naive(oracle.dense, oracle.cov_dense, n, p, G, alpha, dtype, tol)
+    atol = 1e-7 if dtype == np.float64 else 2e-3
+    assert len(hc.lmdas) == len(oc.lmdas)
+    assert np.abs(hc.betas.toarray() - oc.betas.toarray()).max() < atol
+    assert np.abs(hc.betas.toarray() - hn.betas.toarray()).max() < (1e-6 if dtype == np.float64 else 5e-3)
+    np.testing.assert_allclose(hc.devs, oc.devs, rtol=1e-5 if dtype == np.float64 else 1e-2, atol=1e-9)
+    assert np.abs(hc.grad - oc.grad).max() < (1e-9 if dtype == np.float64 else 1e-3)
+    assert sorted(hc.screen_set.tolist()) == sorted(oc.screen_set.tolist()) or dtype == np.float32
+    if p >= 640:
+        assert len(hc.screen_set) * (p // G) >= 256
+
+
+@pytest.mark.gpu
+def test_hip_cov_warm_start_errors_and_exit_cond(hip):
+    d = make_gaussian(70, 45, G=14, seed=5, zero_pen=0.1)
+    X, y = d["X"], d["y"]
+    A, v = X.T @ X / 70, X.T @ y / 70
+    cA = ad.matrix.dense(np.asfortranarray(A), method="cov")
+    kw = dict(groups=d["groups"], penalty=d["penalty"], alpha=0.6, tol=1e-13, early_exit=False, lmda_path_size=25,
+              progress_bar=False)
+    st = ad.gaussian_cov(cA, v, **kw)
+    assert st.error == "" and len(st.lmdas) == 25
+    assert _cov_kkt(A, v, st, d["groups"], d["group_sizes"], d["penalty"], 0.6) < 1e-6
+    half = ad.gaussian_cov(cA, v, **dict(kw, lmda_path=st.lmdas[:12]))
+    rest = ad.gaussian_cov(cA, v, warm_start=half, check_state=True, **dict(kw, lmda_path=st.lmdas[12:]))
+    assert np.abs(rest.betas.toarray() - st.betas[12:].toarray()).max() < 1e-9
+    cut = ad.gaussian_cov(cA, v, exit_cond=lambda s: len(s.lmdas) >= 7 and s.grad.shape == (45,), **kw)
+    assert len(cut.lmdas) == 7
+    with pytest.raises(RuntimeError, match="covariance matrix"):
+        ad.grpnet(cA, ad.glm.gaussian(y))
+    small = ad.gaussian_cov(cA, v, max_active_size=2, **kw)
+    assert small.error.startswith("adelie_core solver: ") and 0 < len(small.lmdas) < 25

@@ -834,6 +834,8 @@ def densify_plugin(mat):
 def as_design(X, *, n_threads: int = 1):
     """What ``grpnet`` / ``cv_grpnet`` / the state constructors accept as ``X``: an ndarray or device tensor (wrapped by
     :func:`dense`), a native design handle (returned as is), or a user-defined matrix class (:func:`from_plugin`)."""
+    if isinstance(X, MatrixCovBase):
+        raise RuntimeError("X is a covariance matrix (matrix.dense(method=\"cov\")): use gaussian_cov for the covariance method.")
     if hasattr(X, "_backend"):
         return X
     if isinstance(X, np.ndarray) or type(X).__module__.startswith("torch"):

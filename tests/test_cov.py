@@ -116,12 +116,15 @@ def _cov_equals_naive(dense, cov_dense, n, p, G, alpha, dtype, tol):
     d = make_gaussian(n, p, G=G, seed=n + p, dtype=dtype)
     X, y, groups = d["X"], d["y"], d["groups"]
     # (p > n: stop where the reference's test stops, adev_tol = 0.2 — further down the minimiser is not unique)
+    # (the default newton_tol = 1e-12 is below float32 resolution: the reference's Newton root find then reports
+    # "max iterations reached", and so do the oracle and the HIP path)
+    nt = dict(newton_tol=1e-12 if dtype == np.float64 else 1e-5)
     sn = ad.grpnet(dense(X), ad.glm.gaussian(y, dtype=dtype), groups=groups, alpha=alpha, intercept=False,
-                   adev_tol=0.2 if p > n else 0.6, tol=tol, progress_bar=False)
+                   adev_tol=0.2 if p > n else 0.6, tol=tol, progress_bar=False, **nt)
     A = np.asfortranarray(X.astype(np.float64).T @ X.astype(np.float64) / n).astype(dtype)
     v = (X.astype(np.float64).T @ y.astype(np.float64) / n).astype(dtype)
     sc = ad.gaussian_cov(A=cov_dense(A), v=v, groups=groups, alpha=alpha, lmda_path=sn.lmdas, tol=tol, early_exit=False,
-                         progress_bar=False)
+                         progress_bar=False, **nt)
     assert sn.error == "" and sc.error == "" and len(sc.lmdas) == len(sn.lmdas) > 2
     return sn, sc
 
@@ -185,7 +188,7 @@ def test_cov_argument_errors(oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("n,p,G,alpha", [(10, 50, 10, 1.0), (40, 13, 7, 1.0), (60, 40, 40, 0.5), (80, 30, 9, 0.3),
-                                         (400, 700, 700, 1.0), (300, 640, 64, 0.7)])
+                                         (900, 700, 700, 1.0), (800, 640, 64, 0.7)])
 def test_hip_cov_matches_oracle(hip, oracle, n, p, G, alpha, dtype):
     """HIP covariance path vs the oracle's restatement of the reference algorithm on identical inputs; the last two shapes run
     the multi-CU Gram engines (screen sets beyond 256 values), lasso and groups."""
@@ -196,7 +199,8 @@ def test_hip_cov_matches_oracle(hip, oracle, n, p, G, alpha, dtype):
     assert len(hc.lmdas) == len(oc.lmdas)
     assert np.abs(hc.betas.toarray() - oc.betas.toarray()).max() < atol
     assert np.abs(hc.betas.toarray() - hn.betas.toarray()).max() < (1e-6 if dtype == np.float64 else 5e-3)
-    np.testing.assert_allclose(hc.devs, oc.devs, rtol=1e-5 if dtype == np.float64 else 1e-2, atol=1e-9)
+    np.testing.assert_allclose(hc.devs, oc.devs, rtol=1e-5 if dtype == np.float64 else 1e-2,
+                               atol=1e-9 if dtype == np.float64 else 1e-4)
     assert np.abs(hc.grad - oc.grad).max() < (1e-9 if dtype == np.float64 else 1e-3)
     assert sorted(hc.screen_set.tolist()) == sorted(oc.screen_set.tolist()) or dtype == np.float32
     if p >= 640:

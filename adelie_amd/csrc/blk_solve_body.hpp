@@ -29,9 +29,28 @@ __device__ __forceinline__ int blk_index(const CdBlkParams<T>& p, int pos) {
 }
 
 // `tid` in [0, 256): the calling workgroup's first 256 threads; smem_raw holds blk_solve_lds<T>() bytes, 16-byte aligned.
+// Sum of the slice partials of the block's columns (CdBlkParams::part) by the first 1024 / `nthreads` threads of the fused
+// workgroup: 8 threads per column, each over every 8th slice, combined through LDS in a fixed order.  gsum[c] (LDS, BLK
+// values) is complete after the next workgroup barrier.
+template <class T>
+__device__ __forceinline__ void blk_part_sum(const CdBlkParams<T>& p, int nb, T* gsum8 /* [8][BLK] in LDS */, int wtid) {
+    const int c = wtid & (BLK - 1), k0 = wtid >> 7; // wtid in [0, 1024)
+    T acc = T(0);
+    if (c < nb) {
+        const T* pc = p.part + int64_t(c) * p.part_ld;
+        int k = k0;
+        for (; k + 24 < p.part_n; k += 32) {
+            const T v0 = pc[k], v1 = pc[k + 8], v2 = pc[k + 16], v3 = pc[k + 24];
+            acc += v0; acc += v1; acc += v2; acc += v3;
+        }
+        for (; k < p.part_n; k += 8) acc += pc[k];
+    }
+    gsum8[k0 * BLK + c] = acc;
+}
+
 template <class T, bool NAIVE>
 __device__ __forceinline__ void blk_solve_body(const CdBlkParams<T>& p, int j, char* smem_raw, int tid,
-                                               const T* corr = nullptr, int ncorr = 0) {
+                                               const T* corr = nullptr, int ncorr = 0, const T* gsum8 = nullptr) {
     T* D = reinterpret_cast<T*>(smem_raw);   // BLK*BLK
     T* gB = D + BLK * BLK;
     T* bB = gB + BLK;
@@ -55,7 +74,7 @@ __device__ __forceinline__ void blk_solve_body(const CdBlkParams<T>& p, int j, c
             const T A = p.vars[idx], pk = p.spen[idx];
             const T den = A + p.l2 * pk;
             idxB[i] = idx;
-            gB[i] = NAIVE ? p.gblk[i] : p.g[idx];
+            gB[i] = NAIVE ? ((p.part && gsum8) ? T(0) : p.gblk[i]) : p.g[idx];
             bB[i] = p.beta[idx];
             AB[i] = A;
             l1B[i] = p.l1 * pk;
@@ -124,6 +143,16 @@ __device__ __forceinline__ void blk_solve_body(const CdBlkParams<T>& p, int j, c
     // is done lane-parallel afterwards (same quantities; the sums are wave reductions instead of running sums).
     static_assert(BLK == 128, "two coordinates per lane");
     T g0 = gB[lane], g1 = gB[lane + 64];
+    if (NAIVE && gsum8 != nullptr && p.part != nullptr) { // gradient from the slice partials (fixed order), intercept term
+        T s0 = T(0), s1 = T(0);
+        for (int q = 0; q < 8; ++q) {
+            s0 += gsum8[q * BLK + lane];
+            s1 += gsum8[q * BLK + lane + 64];
+        }
+        const T rs = p.part_rsum ? p.part_rsum[0] : T(0);
+        g0 = (lane < nb) ? s0 - rs * xmB[lane] : T(0);
+        g1 = (lane + 64 < nb) ? s1 - rs * xmB[lane + 64] : T(0);
+    }
     if (NAIVE && corr != nullptr && p.Cprev != nullptr) {
         T c0 = T(0), c1 = T(0);
         for (int q = 0; q < ncorr; ++q) { // fixed order
@@ -290,7 +319,7 @@ __device__ __forceinline__ void blk_corr_helper(const CdBlkParams<T>& p, T* corr
 template <class T>
 __host__ __device__ constexpr size_t blk_solve_lds_fused() {
     return size_t(BLK) * BLK * sizeof(T) + size_t(BLK) * 8 * sizeof(T) + size_t(BLK) * 2 * sizeof(int32_t) + 16 +
-           size_t(NCORR) * BLK * sizeof(T);
+           size_t(NCORR) * BLK * sizeof(T) + size_t(8) * BLK * sizeof(T);
 }
 
 template <class T>

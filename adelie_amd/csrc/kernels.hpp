@@ -65,6 +65,23 @@ void launch_gram_snp(const SnpView& X, const T* impute, const T* w, const int32_
 int64_t gram_work_elems(int64_t n, int64_t M, int64_t N);
 // symmetric diagonal block of M <= 128 columns: C[a + b*ldc] = C[b + a*ldc] = sum_i w_i X[i,cols[a]] X[i,cols[b]] (- xm xm^T);
 // only the lower-triangle MFMA tiles are computed.  `work` holds syrk_work_elems(n, M) elements.
+// Several diagonal blocks per launch (syrk_batch_kernel): block y of the batch has the nb[y] columns cols_base[off[y]...] and
+// goes to C_base + dst[y] (leading dimension ldc).  `work` holds syrk_batch_work_elems(n, count) elements.
+struct SyrkBatch {
+    static constexpr int MAX = 16;
+    int32_t off[MAX];
+    int32_t nb[MAX];
+    int64_t dst[MAX];
+    int32_t count;
+};
+int64_t syrk_batch_work_elems(int64_t n, int count);
+void set_small_gram_workgroups(int wgs); // kernels_gram.hip: spread of the next small builds launched by this host thread
+template <class T>
+void launch_syrk_batch(const DenseView<T>& X, const T* w, const int32_t* cols_base, const SyrkBatch& b, const T* xm_by_col,
+                       bool center, T* C_base, int64_t ldc, T* work, hipStream_t s);
+template <class T>
+void launch_syrk_batch_snp(const SnpView& X, const T* impute, const T* w, const int32_t* cols_base, const SyrkBatch& b,
+                           const T* xm_by_col, bool center, T* C_base, int64_t ldc, T* work, hipStream_t s);
 template <class T>
 void launch_syrk(const DenseView<T>& X, const T* w, const int32_t* cols, int32_t M, const T* xm_by_col, bool center, T* C,
                    int64_t ldc, T* work, hipStream_t s);
@@ -176,6 +193,13 @@ struct CdBlkParams {
     int32_t* dpos;
     int32_t* nz_out;
     T* rsum_out;
+    // `part` != nullptr: the gradient of the block is not in gblk yet but still in the slice partials of the panel step that
+    // ran in the PREVIOUS launch (part[c * part_ld + k], k < part_n): the solve sums them itself in its prologue — in a fixed
+    // order — and applies the intercept term  - part_rsum[0] * xbar_c  (what panel_reduce_kernel does as a launch of its own)
+    const T* part;
+    int64_t part_ld;
+    int32_t part_n;
+    const T* part_rsum; // nullptr: no intercept term
 };
 // group (q > 1) variant: a block = consecutive groups of the visiting list with <= 128 values in total
 template <class T>

@@ -95,7 +95,9 @@ template <class T, int VEC> struct RawOf<T, SnpAcc<T>, VEC> { using type = RawSn
 // is issued before phase (A) so that its round trip overlaps (A)'s.  The register budget is held at 128 VGPRs so that
 // 4 workgroups fit per CU: 1024 resident slots cover the 782 row slices of n = 100k in ONE round (at 3 per CU a
 // handful of stragglers cost a whole second round).
-template <class T, class Acc, int VEC, bool FULL>
+// WGRED: the slice's partial gradients go to `red[0][c]` (LDS, free after phase (A)) instead of `part`: the fused kernel sums
+// the four slices of its workgroup and writes ONE partial per column and workgroup.
+template <class T, class Acc, int VEC, bool FULL, bool WGRED = false>
 __device__ __forceinline__ void panel_step_body(const Acc& X, int64_t n, const T* __restrict__ w, T* __restrict__ r,
                                                 const int32_t* __restrict__ dcol, const T* __restrict__ dlt, int nz,
                                                 const int32_t* __restrict__ cols, int nb, T* __restrict__ part,
@@ -187,7 +189,10 @@ __device__ __forceinline__ void panel_step_body(const Acc& X, int64_t n, const T
         }
         static_assert(UB == 8, "reduce8");
         const T tot = reduce8(pu, lane);
-        if (lane < UB && c0 + 4 * lane < nb) part[int64_t(c0 + 4 * lane) * part_ld + slice] = tot;
+        if (lane < UB && c0 + 4 * lane < nb) {
+            if constexpr (WGRED) red[0][c0 + 4 * lane] = tot; // (64 * VEC >= 128 columns)
+            else part[int64_t(c0 + 4 * lane) * part_ld + slice] = tot;
+        }
     }
 }
 
@@ -227,9 +232,13 @@ __global__ __launch_bounds__(256 * FS) void panel_fused_kernel(CdBlkParams<T> sp
     constexpr int RS = 64 * VEC;
     if (blockIdx.x == 0) {
         static_assert(256 + BLK * NCORR == 256 * FS, "every thread of workgroup 0 has a role");
-        T* corr = reinterpret_cast<T*>(smem_raw + (blk_solve_lds_fused<T>() - size_t(NCORR) * BLK * sizeof(T)));
+        T* corr = reinterpret_cast<T*>(smem_raw + (blk_solve_lds_fused<T>() - size_t(NCORR + 8) * BLK * sizeof(T)));
+        T* gsum8 = corr + size_t(NCORR) * BLK;
+        // the block's gradient from the slice partials of the previous launch's step (when the solver asked for it): all
+        // 1024 threads, before they split into the solve and the correction helpers; complete at the barrier inside those
+        if (sp.part != nullptr) blk_part_sum<T>(sp, min(sp.bsz, sp.count - j * sp.bsz), gsum8, threadIdx.x);
         if (threadIdx.x >= 256) blk_corr_helper<T>(sp, corr, threadIdx.x - 256);
-        else blk_solve_body<T, true>(sp, j, smem_raw, threadIdx.x, corr, NCORR);
+        else blk_solve_body<T, true>(sp, j, smem_raw, threadIdx.x, corr, NCORR, gsum8);
         return;
     }
     const int sub = threadIdx.x >> 8, tid = threadIdx.x & 255;
@@ -238,12 +247,29 @@ __global__ __launch_bounds__(256 * FS) void panel_fused_kernel(CdBlkParams<T> sp
     T (*red)[RS] = reinterpret_cast<T (*)[RS]>(base);
     T* wrs = base + 4 * RS;
     const int nz = nz_dev[0];
+    static_assert(RS >= PB || VEC == 1, "a slice's LDS row holds the block's column partials");
     // all four slices of a workgroup take the same path (same number of barriers); slices past the end of the rows do
     // nothing through the ragged path's predication
-    if ((int64_t(blockIdx.x) * FS) * RS <= n)
-        panel_step_body<T, Acc, VEC, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
-    else
-        panel_step_body<T, Acc, VEC, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
+    if constexpr (RS >= PB) {
+        if ((int64_t(blockIdx.x) * FS) * RS <= n)
+            panel_step_body<T, Acc, VEC, true, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
+        else
+            panel_step_body<T, Acc, VEC, false, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
+        if (nb <= 0) return; // uniform: the step bodies returned before phase (B) as well
+        __syncthreads();
+        // one partial per column for the whole workgroup: the four slices in a fixed order
+        if (threadIdx.x < nb) {
+            const T* b0 = reinterpret_cast<const T*>(smem_raw);
+            const int c = threadIdx.x;
+            part[int64_t(c) * part_ld + (blockIdx.x - 1)] =
+                (b0[c] + b0[size_t(5) * RS + c]) + (b0[size_t(10) * RS + c] + b0[size_t(15) * RS + c]);
+        }
+    } else {
+        if ((int64_t(blockIdx.x) * FS) * RS <= n)
+            panel_step_body<T, Acc, VEC, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
+        else
+            panel_step_body<T, Acc, VEC, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
+    }
 }
 
 template <class T>
@@ -344,7 +370,9 @@ int fused_launch(const CdBlkParams<T>& sp, int j, const Acc& acc, int64_t n, con
     constexpr int RS = 64 * VEC;
     const int64_t ns = (n + RS - 1) / RS;
     const int64_t nwg = (ns + FS - 1) / FS;
-    const int64_t part_ld = nwg * FS; // slices past the end write zeros; the reduce only sums the first ns
+    // 64 * VEC >= 128: one partial per column and WORKGROUP (the four slices are summed in LDS); else one per slice
+    // (slices past the end write zeros)
+    const int64_t part_ld = (64 * VEC >= PB) ? nwg : nwg * FS;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fused_kernel<T, Acc, VEC>),

@@ -26,7 +26,15 @@ namespace {
 
 constexpr int BM = 128, KT = 32, LDK = KT + 2, GT = 256;
 
+// Workgroups a SMALL build (one diagonal block / one cross block / a batch of diagonal blocks) is spread over.  512 = one
+// full round of two resident workgroups per CU, the fastest for the build itself.  The panel engine lowers it for builds
+// that run on the side stream next to the look-ahead launches of a Gaussian pass (set_small_gram_workgroups): those launches
+// need ~200 whole CUs, and a build that occupies every CU makes each of them wait.  Per host thread: set right before the
+// launches it is meant for.
+thread_local int t_small_gram_wgs = 512;
+
 typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u4v_t __attribute__((ext_vector_type(4)));
 typedef float f4v_t __attribute__((ext_vector_type(4)));
 
 template <class T> struct Mfma;
@@ -271,18 +279,16 @@ __device__ __forceinline__ void syrk_store(T* __restrict__ P, int lane, const ty
             P[(Plan::C[t] * 16 + (lane & 15)) * SB + Plan::R[t] * 16 + Mfma<T>::row(lane, e)] = acc[t][e];
 }
 
+// one K-split [k0, kend) of one diagonal block: partial lower-triangle tiles into P (SB x SB)
 template <class T, class Acc, bool VECOK, int SB>
-__global__ __launch_bounds__(GT, 2) void syrk_kernel(Acc X, const T* __restrict__ w, const int32_t* __restrict__ cols,
-                                                     int32_t M, int64_t n, int64_t kchunk, T* __restrict__ part) {
+__device__ __forceinline__ void syrk_body(const Acc& X, const T* __restrict__ w, const int32_t* __restrict__ cols, int32_t M,
+                                          int64_t k0, int64_t kend, T* __restrict__ P) {
     constexpr int RA = KT * SB / GT; // rows of one column staged per thread (8 or 16)
     constexpr int NA = SB == 32 ? 1 : (SB == 64 ? 3 : 9);
     __shared__ T As[SB * LDK];
     __shared__ T Ws[KT];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sp = blockIdx.x;
-    const int64_t k0 = int64_t(sp) * kchunk;
-    const int64_t kend = min(n, k0 + kchunk);
     const int sc = tid / (KT / RA), sr = (tid % (KT / RA)) * RA;
     const bool c_ok = sc < M;
     const int64_t jc = c_ok ? int64_t(cols[sc]) : 0;
@@ -312,12 +318,167 @@ __global__ __launch_bounds__(GT, 2) void syrk_kernel(Acc X, const T* __restrict_
         else if (wv == 2) syrk_stage<T, SyrkPlan<2, SB>, NA>(As, Ws, fr, fk, acc);
         else syrk_stage<T, SyrkPlan<3, SB>, NA>(As, Ws, fr, fk, acc);
     }
-    // partial tiles -> part[sp][col][row] (SB x SB, only the lower-triangle tiles are written / ever read)
-    T* P = part + int64_t(sp) * SB * SB;
+    // partial tiles -> P[col][row] (SB x SB, only the lower-triangle tiles are written / ever read)
     if (wv == 0) syrk_store<T, SyrkPlan<0, SB>, NA, SB>(P, lane, acc);
     else if (wv == 1) syrk_store<T, SyrkPlan<1, SB>, NA, SB>(P, lane, acc);
     else if (wv == 2) syrk_store<T, SyrkPlan<2, SB>, NA, SB>(P, lane, acc);
     else syrk_store<T, SyrkPlan<3, SB>, NA, SB>(P, lane, acc);
+}
+
+// The same for a 2-bit SNP design.  A stage of the generic body is 32 rows x SB columns = 8 * SB BYTES of calls: loaded a byte
+// at a time one stage ahead, the MFMAs of a stage (0.6 - 1.3 us) are over long before its loads return from HBM, and the
+// matrix pipes idle two thirds of the time.  Here a workgroup brings a SUPER-stage of 256 rows (64 bytes per column) with one
+// 16-byte load per lane, a whole super-stage (8 stages) ahead, parks the raw bytes in LDS, and every stage decodes its 32 rows
+// from there (LDS latency instead of HBM latency).  k0 must be a multiple of 256 rows (syrk shapes round kchunk up to it for
+// SNP designs); columns are 64-byte aligned (ldb), so every 16-byte load is aligned and stays inside the column's padding.
+template <class T, int SB>
+__device__ __forceinline__ void syrk_body_snp(const SnpAcc<T>& X, const T* __restrict__ w, const int32_t* __restrict__ cols,
+                                              int32_t M, int64_t k0, int64_t kend, T* __restrict__ P) {
+    constexpr int RA = KT * SB / GT;       // rows of one column decoded per thread and stage (4, 8 or 16)
+    constexpr int NA = SB == 32 ? 1 : (SB == 64 ? 3 : 9);
+    constexpr int SS = 256;                // rows per super-stage
+    constexpr int NCH = SB * 4;            // 16-byte chunks per super-stage (4 per column)
+    constexpr int CPT = (NCH + GT - 1) / GT; // chunks per thread (1 or 2)
+    __shared__ T As[SB * LDK];
+    __shared__ T Ws[KT];
+    __shared__ u4v_t raw[2][NCH];          // raw[.][c * 4 + q]: bytes [16 q, 16 q + 16) of column c's super-stage
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sc = tid / (KT / RA), sr = (tid % (KT / RA)) * RA;
+    const bool c_ok = sc < M;
+    const T imp = c_ok ? X.impute[cols[sc]] : T(0);
+
+    typename Mfma<T>::acc_t acc[NA];
+#pragma unroll
+    for (int t = 0; t < NA; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = T(0);
+
+    // this thread's chunks of a super-stage
+    const uint8_t* gp[CPT];
+    bool g_ok[CPT];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const int ch = tid + u * GT;
+        const int c = ch >> 2, q = ch & 3;
+        g_ok[u] = ch < NCH && c < M;
+        gp[u] = g_ok[u] ? X.bits + int64_t(cols[c]) * X.ldb + q * 16 : X.bits;
+    }
+    u4v_t rg[CPT];
+    auto fetch_super = [&](int64_t k) { // rows [k, k + 256)
+#pragma unroll
+        for (int u = 0; u < CPT; ++u)
+            rg[u] = g_ok[u] ? __builtin_nontemporal_load(reinterpret_cast<const u4v_t*>(gp[u] + (k >> 2))) : u4v_t{0, 0, 0, 0};
+    };
+    T rw = T(0);
+    auto fetch_w = [&](int64_t k) { if (tid < KT) rw = (k + tid < kend) ? w[k + tid] : T(0); };
+
+    if (k0 < kend) { fetch_super(k0); fetch_w(k0); }
+    const int fr = (lane & 15), fk = (lane >> 4);
+    int buf = 0;
+    for (int64_t ks = k0; ks < kend; ks += SS, buf ^= 1) {
+        // park the super-stage (the buffer was last read two super-stages ago: the barriers of the stages in between order it)
+#pragma unroll
+        for (int u = 0; u < CPT; ++u)
+            if (tid + u * GT < NCH) raw[buf][tid + u * GT] = rg[u];
+        if (ks + SS < kend) fetch_super(ks + SS);
+        const unsigned char* rb = reinterpret_cast<const unsigned char*>(&raw[buf][0]) + sc * 64;
+#pragma unroll 1
+        for (int st = 0; st < SS / KT; ++st) {
+            const int64_t k = ks + int64_t(st) * KT;
+            if (k >= kend) break;
+            __syncthreads(); // raw[buf] visible (st == 0); As / Ws of the previous stage consumed
+            // decode this thread's RA rows of column sc: RA / 4 bytes at byte (32 st + sr) / 4 of the column's 64
+            unsigned bits = 0;
+            const int bo = (st * KT + sr) >> 2;
+            if constexpr (RA == 4) bits = rb[bo];
+            else if constexpr (RA == 8) bits = *reinterpret_cast<const unsigned short*>(rb + bo);
+            else bits = *reinterpret_cast<const unsigned*>(rb + bo);
+#pragma unroll
+            for (int e = 0; e < RA; ++e) {
+                const unsigned c = (bits >> (2 * e)) & 3u;
+                As[sc * LDK + sr + e] = c_ok ? (c == 3u ? imp : T(c)) : T(0);
+            }
+            if (tid < KT) Ws[tid] = rw;
+            __syncthreads();
+            fetch_w(k + KT);
+            if (wv == 0) syrk_stage<T, SyrkPlan<0, SB>, NA>(As, Ws, fr, fk, acc);
+            else if (wv == 1) syrk_stage<T, SyrkPlan<1, SB>, NA>(As, Ws, fr, fk, acc);
+            else if (wv == 2) syrk_stage<T, SyrkPlan<2, SB>, NA>(As, Ws, fr, fk, acc);
+            else syrk_stage<T, SyrkPlan<3, SB>, NA>(As, Ws, fr, fk, acc);
+        }
+    }
+    if (wv == 0) syrk_store<T, SyrkPlan<0, SB>, NA, SB>(P, lane, acc);
+    else if (wv == 1) syrk_store<T, SyrkPlan<1, SB>, NA, SB>(P, lane, acc);
+    else if (wv == 2) syrk_store<T, SyrkPlan<2, SB>, NA, SB>(P, lane, acc);
+    else syrk_store<T, SyrkPlan<3, SB>, NA, SB>(P, lane, acc);
+}
+
+template <class A> struct IsSnpAcc { static constexpr bool value = false; };
+template <class T> struct IsSnpAcc<SnpAcc<T>> { static constexpr bool value = true; };
+
+template <class T, class Acc, bool VECOK, int SB>
+__device__ __forceinline__ void syrk_any(const Acc& X, const T* __restrict__ w, const int32_t* __restrict__ cols, int32_t M,
+                                         int64_t k0, int64_t kend, T* __restrict__ P) {
+    if constexpr (IsSnpAcc<Acc>::value) syrk_body_snp<T, SB>(X, w, cols, M, k0, kend, P);
+    else syrk_body<T, Acc, VECOK, SB>(X, w, cols, M, k0, kend, P);
+}
+
+template <class T, class Acc, bool VECOK, int SB>
+__global__ __launch_bounds__(GT, 2) void syrk_kernel(Acc X, const T* __restrict__ w, const int32_t* __restrict__ cols,
+                                                     int32_t M, int64_t n, int64_t kchunk, T* __restrict__ part) {
+    const int sp = blockIdx.x;
+    const int64_t k0 = int64_t(sp) * kchunk;
+    syrk_any<T, Acc, VECOK, SB>(X, w, cols, M, k0, min(n, k0 + kchunk), part + int64_t(sp) * SB * SB);
+}
+
+// Several diagonal blocks in ONE launch (blockIdx.y = block, blockIdx.x = K-split).  Under IRLS weights every block of a pass
+// is stale at once: building them one launch (512 K-splits) at a time makes each workgroup stream ~1000 rows and then write
+// 20 KB of partial tiles — more bytes than it read — which a second kernel has to read back; with the blocks of a pass batched
+// the same 512-1024 workgroups cover `count` blocks with 512 / count splits each, i.e. count times fewer partials per block
+// and count times longer K loops per workgroup.
+template <class T, class Acc, bool VECOK, int SB>
+__global__ __launch_bounds__(GT, 2) void syrk_batch_kernel(Acc X, const T* __restrict__ w, const int32_t* __restrict__ cols_base,
+                                                           SyrkBatch b, int64_t n, int64_t kchunk, int nsplit,
+                                                           T* __restrict__ part) {
+    const int sp = blockIdx.x, y = blockIdx.y;
+    const int64_t k0 = int64_t(sp) * kchunk;
+    syrk_any<T, Acc, VECOK, SB>(X, w, cols_base + b.off[y], b.nb[y], k0, min(n, k0 + kchunk),
+                                part + (int64_t(y) * nsplit + sp) * SB * SB);
+}
+
+// deterministic sum of the K-split partials of every block of a batch, centring, symmetric write into the block's slot
+template <class T>
+__global__ void syrk_batch_reduce_kernel(const T* __restrict__ part, int nsplit, int SB, SyrkBatch b,
+                                         const int32_t* __restrict__ cols_base, const T* __restrict__ xm, int center,
+                                         T* __restrict__ C_base, int64_t ldc) {
+    __shared__ T red[4][64];
+    const int ta = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    const int y = blockIdx.z;
+    const int M = b.nb[y];
+    const int a = blockIdx.x * 64 + ta, bb = blockIdx.y;
+    const bool skip = !(a < M && bb < M) || a < bb; // lower triangle only; mirrored below
+    T s = T(0);
+    if (!skip) {
+        const int64_t stride = int64_t(SB) * SB;
+        const T* base = part + int64_t(y) * nsplit * stride + int64_t(bb) * SB + a;
+        int sp = tg;
+        for (; sp + 12 < nsplit; sp += 16) {
+            const T v0 = base[int64_t(sp) * stride], v1 = base[int64_t(sp + 4) * stride];
+            const T v2 = base[int64_t(sp + 8) * stride], v3 = base[int64_t(sp + 12) * stride];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; sp < nsplit; sp += 4) s += base[int64_t(sp) * stride];
+    }
+    red[tg][ta] = s;
+    __syncthreads();
+    if (tg != 0 || skip) return;
+    s = (red[0][ta] + red[1][ta]) + (red[2][ta] + red[3][ta]);
+    const int32_t* cols = cols_base + b.off[y];
+    if (center) s -= xm[cols[a]] * xm[cols[bb]];
+    T* C = C_base + b.dst[y];
+    C[a + int64_t(bb) * ldc] = s;
+    C[bb + int64_t(a) * ldc] = s;
 }
 
 inline void syrk_shape(int64_t n, int& nsplit, int64_t& kchunk) {
@@ -326,7 +487,7 @@ inline void syrk_shape(int64_t n, int& nsplit, int64_t& kchunk) {
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
     kchunk = (n + want - 1) / want;
-    kchunk = ((kchunk + KT - 1) / KT) * KT;
+    kchunk = ((kchunk + 255) / 256) * 256; // whole super-stages of the SNP body (a multiple of KT as well)
     const int64_t ns = (n + kchunk - 1) / kchunk;
     nsplit = int(ns < 1 ? 1 : ns);
 }
@@ -349,6 +510,39 @@ void syrk_launch(Acc acc, bool vecok, const T* w, const int32_t* cols, int32_t M
                        SB, M, M, cols, cols, 0, 0, xm, center ? 1 : 0, 1, C, ldc);
 }
 
+inline void syrk_batch_shape(int64_t n, int count, int& nsplit, int64_t& kchunk) {
+    // about one full round of 2 resident workgroups per CU over all the blocks of the batch (count = 1: the single-block shape)
+    int64_t want = (int64_t(t_small_gram_wgs) + count - 1) / count;
+    const int64_t max_split = (n + KT * 8 - 1) / (KT * 8);
+    if (want > max_split) want = max_split;
+    if (want < 1) want = 1;
+    kchunk = (n + want - 1) / want;
+    kchunk = ((kchunk + 255) / 256) * 256; // whole super-stages of the SNP body (a multiple of KT as well)
+    const int64_t ns = (n + kchunk - 1) / kchunk;
+    nsplit = int(ns < 1 ? 1 : ns);
+}
+
+template <class T, class Acc>
+void syrk_batch_launch(Acc acc, bool vecok, const T* w, const int32_t* cols_base, const SyrkBatch& b, int64_t n, const T* xm,
+                       bool center, T* C_base, int64_t ldc, T* work, hipStream_t s) {
+    if (b.count <= 0) return;
+    int nsplit;
+    int64_t kchunk;
+    syrk_batch_shape(n, b.count, nsplit, kchunk);
+    int mx = 0;
+    for (int y = 0; y < b.count; ++y) mx = std::max(mx, int(b.nb[y]));
+    const int SB = mx <= 32 ? 32 : (mx <= 64 ? 64 : 128);
+    const dim3 grid((unsigned)nsplit, (unsigned)b.count);
+#define AHIP_SYRKB(VOK, SBV) \
+    hipLaunchKernelGGL((syrk_batch_kernel<T, Acc, VOK, SBV>), grid, dim3(GT), 0, s, acc, w, cols_base, b, n, kchunk, nsplit, work)
+    if (SB == 32) { if (vecok) AHIP_SYRKB(true, 32); else AHIP_SYRKB(false, 32); }
+    else if (SB == 64) { if (vecok) AHIP_SYRKB(true, 64); else AHIP_SYRKB(false, 64); }
+    else { if (vecok) AHIP_SYRKB(true, 128); else AHIP_SYRKB(false, 128); }
+#undef AHIP_SYRKB
+    hipLaunchKernelGGL((syrk_batch_reduce_kernel<T>), dim3((unsigned)((mx + 63) / 64), (unsigned)mx, (unsigned)b.count), dim3(256),
+                       0, s, work, nsplit, SB, b, cols_base, xm, center ? 1 : 0, C_base, ldc);
+}
+
 // N tiling: full 128-wide tiles, then the remainder as one 64-wide tile when it fits (less padding than a 128 tile)
 struct GramShape {
     int64_t Mt, n128, n64, Npad, kchunk;
@@ -367,7 +561,7 @@ inline GramShape gram_shape(int64_t n, int64_t M, int64_t N) {
     // Many tiles: ~3072 blocks so that the last partial round over the 256 CUs x 2 resident blocks costs little.  A single
     // diagonal block of the panel engine: one full round (512 blocks) - more K-splits only add partial-tile traffic
     // (128 KB written and re-read per split; measured -18 % at n = 500k).
-    const int64_t target = tiles <= 4 ? 512 : 3072;
+    const int64_t target = tiles <= 4 ? int64_t(t_small_gram_wgs) : 3072;
     int64_t want = (target + tiles - 1) / tiles;
     const int64_t max_split = (n + KT * 8 - 1) / (KT * 8);
     if (want > max_split) want = max_split;
@@ -411,6 +605,32 @@ void gram_launch(Acc acc, bool vecok, const T* w, const int32_t* mcols, int32_t 
 }
 
 } // namespace
+
+void set_small_gram_workgroups(int wgs) { t_small_gram_wgs = wgs < 1 ? 512 : wgs; }
+
+int64_t syrk_batch_work_elems(int64_t n, int count) {
+    int nsplit;
+    int64_t kchunk;
+    const int keep = t_small_gram_wgs;
+    t_small_gram_wgs = 512; // the buffer is sized for the widest spread
+    syrk_batch_shape(n, count, nsplit, kchunk);
+    t_small_gram_wgs = keep;
+    return int64_t(nsplit) * count * 128 * 128;
+}
+template <class T>
+void launch_syrk_batch(const DenseView<T>& X, const T* w, const int32_t* cols_base, const SyrkBatch& b, const T* xm_by_col,
+                       bool center, T* C_base, int64_t ldc, T* work, hipStream_t s) {
+    DenseAcc<T> acc{X.X, X.ld};
+    constexpr int V = VecOf<T>::N;
+    const bool vecok = (X.ld % V == 0) && ((reinterpret_cast<uintptr_t>(X.X) % 16) == 0);
+    syrk_batch_launch<T, DenseAcc<T>>(acc, vecok, w, cols_base, b, X.n, xm_by_col, center, C_base, ldc, work, s);
+}
+template <class T>
+void launch_syrk_batch_snp(const SnpView& X, const T* impute, const T* w, const int32_t* cols_base, const SyrkBatch& b,
+                           const T* xm_by_col, bool center, T* C_base, int64_t ldc, T* work, hipStream_t s) {
+    SnpAcc<T> acc{X.bits, X.ldb, impute};
+    syrk_batch_launch<T, SnpAcc<T>>(acc, true, w, cols_base, b, X.n, xm_by_col, center, C_base, ldc, work, s);
+}
 
 int64_t syrk_work_elems(int64_t n, int64_t M) {
     int nsplit;
@@ -457,7 +677,10 @@ void launch_gram_multi(const MultiView<T>& X, const T* w, const int32_t* mcols, 
 
 int64_t gram_work_elems(int64_t n, int64_t M, int64_t N) {
     if (M <= 0 || N <= 0) return 0;
+    const int keep = t_small_gram_wgs;
+    t_small_gram_wgs = 512; // the buffer is sized for the widest spread
     const GramShape g = gram_shape(n, M, N);
+    t_small_gram_wgs = keep;
     return int64_t(g.nsplit) * g.Mt * BM * g.Npad;
 }
 
@@ -487,6 +710,10 @@ INST(double)
 INST(float)
 #undef INST
 #define INST2(T)                                                                                                       \
+    template void launch_syrk_batch<T>(const DenseView<T>&, const T*, const int32_t*, const SyrkBatch&, const T*, bool, T*, \
+                                       int64_t, T*, hipStream_t);                                                      \
+    template void launch_syrk_batch_snp<T>(const SnpView&, const T*, const T*, const int32_t*, const SyrkBatch&, const T*, \
+                                           bool, T*, int64_t, T*, hipStream_t);                                        \
     template void launch_syrk<T>(const DenseView<T>&, const T*, const int32_t*, int32_t, const T*, bool, T*, int64_t, \
                                    T*, hipStream_t);                                                                   \
     template void launch_syrk_snp<T>(const SnpView&, const T*, const T*, const int32_t*, int32_t, const T*, bool, T*, \

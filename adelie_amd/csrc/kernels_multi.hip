@@ -23,13 +23,17 @@
 #include "grp_solve_body.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace ahip {
 
 namespace {
 
 constexpr int MT = 256;  // threads of the sweep kernel
-constexpr int MCB = 4;   // features per sweep block
+// Features per sweep block.  The K vectors are re-read (from L2) once per block: with 4 features a K = 8 sweep pulls twice as
+// many bytes of v through L2 as it streams of X from HBM and ends up bound by L2 (1.73 ms = 4.6 TB/s at 100k x 10k f64); with
+// 8 the two are equal.  (ADELIE_HIP_MULTI_SWEEP_MCB=4 selects the old shape for an A/B run.)
+constexpr int MCB_MAX = 8;
 constexpr int MAXB = 128; // entries of a panel block (== cd_block_size())
 
 template <class T>
@@ -42,7 +46,7 @@ __device__ __forceinline__ T wsum(T x) {
 // ---- sweep ------------------------------------------------------------------------------------------------------------
 // grid (feature panels, row splits, response chunks of KT).  A block owns MCB features and walks its rows once; the KT
 // response vectors v_l are re-read per panel but from L2 (blocks of one row split are scheduled together and share them).
-template <class T, class Acc, int VEC, int KT>
+template <class T, class Acc, int VEC, int KT, int MCB>
 __global__ __launch_bounds__(MT) void multi_sweep_kernel(Acc X, const T* __restrict__ v, T* __restrict__ part,
                                                         int64_t nb, int64_t nfeat, int K, int64_t rows_per_split) {
     const int tid = threadIdx.x;
@@ -126,7 +130,12 @@ __global__ void multi_sweep_reduce_kernel(const T* __restrict__ part, T* __restr
     out[c] = s;
 }
 
+inline int msweep_mcb() {
+    static const int v = (std::getenv("ADELIE_HIP_MULTI_SWEEP_MCB") && std::atoi(std::getenv("ADELIE_HIP_MULTI_SWEEP_MCB")) == 4) ? 4 : 8;
+    return v;
+}
 inline void msweep_shape(int64_t nb, int64_t nfeat, int vec, int64_t& blocks_c, int& nsplit, int64_t& rows_per_split) {
+    const int MCB = msweep_mcb();
     blocks_c = (nfeat + MCB - 1) / MCB;
     const int64_t unit = int64_t(MT) * vec;
     const int64_t max_split = std::max<int64_t>(1, (nb + unit * 4 - 1) / (unit * 4));
@@ -457,7 +466,12 @@ void launch_multi_sweep(const MultiView<T>& X, const T* v, T* out, T* work, hipS
     const dim3 grid((unsigned)bc, (unsigned)ns, (unsigned)((X.K + KT - 1) / KT));
     const bool vok = multi_vecok(X);
 #define AHIP_MS(VV, KK)                                                                                                 \
-    hipLaunchKernelGGL((multi_sweep_kernel<T, DenseOnesAcc<T>, VV, KK>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps)
+    do {                                                                                                                \
+        if (msweep_mcb() == 8)                                                                                          \
+            hipLaunchKernelGGL((multi_sweep_kernel<T, DenseOnesAcc<T>, VV, KK, 8>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps); \
+        else                                                                                                            \
+            hipLaunchKernelGGL((multi_sweep_kernel<T, DenseOnesAcc<T>, VV, KK, 4>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps); \
+    } while (0)
     if (vok) {
         if (KT == 8) AHIP_MS(V, 8); else if (KT == 4) AHIP_MS(V, 4); else AHIP_MS(V, 2);
     } else {
@@ -482,8 +496,13 @@ void launch_multi_sweep_snp(const SnpView& X, const T* impute, int K, const T* v
     msweep_shape(X.n, nfeat, V, bc, ns, rps);
     const int KT = kt_of(K);
     const dim3 grid((unsigned)bc, (unsigned)ns, (unsigned)((K + KT - 1) / KT));
-#define AHIP_MSS(KK) \
-    hipLaunchKernelGGL((multi_sweep_kernel<T, SnpAcc<T>, V, KK>), grid, dim3(MT), 0, s, acc, v, work, X.n, nfeat, K, rps)
+#define AHIP_MSS(KK)                                                                                                    \
+    do {                                                                                                                \
+        if (msweep_mcb() == 8)                                                                                          \
+            hipLaunchKernelGGL((multi_sweep_kernel<T, SnpAcc<T>, V, KK, 8>), grid, dim3(MT), 0, s, acc, v, work, X.n, nfeat, K, rps); \
+        else                                                                                                            \
+            hipLaunchKernelGGL((multi_sweep_kernel<T, SnpAcc<T>, V, KK, 4>), grid, dim3(MT), 0, s, acc, v, work, X.n, nfeat, K, rps); \
+    } while (0)
     if (KT == 8) AHIP_MSS(8); else if (KT == 4) AHIP_MSS(4); else AHIP_MSS(2);
 #undef AHIP_MSS
     const int64_t ncols = nfeat * K;

@@ -445,38 +445,104 @@ struct Solver {
     int n_built_side = 0;
     std::vector<hipEvent_t> blk_ev; // per block of the current pass: event of its build on the side stream (or nullptr)
     // Builds the stale blocks among `nblk` blocks of a pass; block j has nb_of(j) members and columns cols_of(j).
+    // `prebuild`: enqueue the builds of a list whose pass comes LATER in this fit (the screen-order blocks under IRLS weights,
+    // enqueued while the active-set passes run): their events come from a pool of their own and are parked in `pre_ev` until
+    // that pass picks them up instead of finding the blocks fresh.
+    std::vector<hipEvent_t> pre_pool, pre_ev;
+    size_t pre_used = 0;
+    hipEvent_t next_pre_event() {
+        if (pre_used == pre_pool.size()) {
+            hipEvent_t e;
+            AHIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            pre_pool.push_back(e);
+        }
+        return pre_pool[pre_used++];
+    }
     template <class NbOf, class ColsOf>
     void build_stale_blocks(int nblk, std::vector<int32_t>& tab_nb, std::vector<uint64_t>& tab_ver, T* pool, NbOf nb_of,
-                            ColsOf cols_of) {
+                            ColsOf cols_of, bool prebuild = false, bool take_pre = false) {
         const int SL = cd_block_size();
-        blk_ev.assign(size_t(nblk), nullptr);
-        ev_used = 0;
+        if (prebuild) {
+            pre_ev.assign(size_t(nblk), nullptr);
+        } else {
+            blk_ev.assign(size_t(nblk), nullptr);
+            ev_used = 0;
+            if (take_pre) { // blocks that were built ahead of this pass: wait for their builds like for a fresh one
+                for (size_t j = 0; j < pre_ev.size() && j < size_t(nblk); ++j) blk_ev[j] = pre_ev[j];
+                pre_ev.clear();
+                pre_used = 0;
+            }
+        }
         bool first = true;
-        for (int j = 0; j < nblk; ++j) {
-            const int nb = nb_of(j);
-            if (tab_nb[j] == nb && tab_ver[j] == w_version) continue;
-            T* Dptr = pool + size_t(j) * SL * SL;
-            const bool side = side_grams && st2 != nullptr;
-            const int sidx = !side ? 0 : ((n_side >= 2 && st_x[0] && !multi()) ? 1 + (n_built_side++ % n_side) : 1);
+        const bool side = side_grams && st2 != nullptr;
+        auto pick_side = [&]() { return !side ? 0 : ((n_side >= 2 && st_x[0] && !multi()) ? 1 + (n_built_side++ % n_side) : 1); };
+        auto open_side = [&]() {
             if (side && first) { // the weights (and everything else the builds read) are final at this point of the main stream
-                hipEvent_t e0 = next_event();
+                hipEvent_t e0 = prebuild ? next_pre_event() : next_event();
                 AHIP_CHECK(hipEventRecord(e0, st));
                 AHIP_CHECK(hipStreamWaitEvent(st2, e0, 0));
                 for (int k = 0; k < kMaxExtra; ++k)
                     if (st_x[k]) AHIP_CHECK(hipStreamWaitEvent(st_x[k], e0, 0));
                 first = false;
             }
-            gram_block(cur_w, cols_of(j), nb, cur_xm, Dptr, sidx);
-            if (side) {
-                hipEvent_t e = next_event();
-                AHIP_CHECK(hipEventRecord(e, sidx >= 2 ? st_x[sidx - 2] : st2));
-                blk_ev[size_t(j)] = e;
+        };
+        // Stale blocks of the same tile class go out in batches of up to `batch_blocks` per launch (see syrk_batch_kernel);
+        // the chain waits for a block through the event of its batch.  The first batch of a pass is kept small so that the
+        // chain can start early.
+        stale.clear();
+        for (int j = 0; j < nblk; ++j)
+            if (!(tab_nb[j] == nb_of(j) && tab_ver[j] == w_version)) stale.push_back(j);
+        auto cls = [](int nb) { return nb <= 32 ? 32 : (nb <= 64 ? 64 : 128); };
+        size_t i = 0;
+        bool first_batch = true;
+        while (i < stale.size()) {
+            const int j0 = stale[i];
+            size_t cap = multi() ? 1 : size_t(first_batch ? std::min(batch_blocks, 4) : batch_blocks);
+            first_batch = false;
+            SyrkBatch sb{};
+            const int32_t* cols_base = cols_of(j0);
+            size_t k = i;
+            for (; k < stale.size() && k - i < cap; ++k) {
+                const int j = stale[k], nb = nb_of(j);
+                if (cls(nb) != cls(nb_of(j0))) break;
+                const int64_t off = cols_of(j) - cols_base;
+                if (off < 0 || off > (int64_t(1) << 30)) break;
+                sb.off[k - i] = int32_t(off);
+                sb.nb[k - i] = nb;
+                sb.dst[k - i] = int64_t(j - j0) * SL * SL;
             }
-            tab_nb[j] = nb;
-            tab_ver[j] = w_version;
-            ++cnt.n_panel_grams;
+            sb.count = int32_t(k - i);
+            const int sidx = pick_side();
+            open_side();
+            // Gaussian look-ahead passes: a build whose block the chain reaches late in the pass is confined to few CUs, so
+            // that the fused launches (whole-CU workgroups) running meanwhile never wait for one (see set_small_gram_workgroups)
+            set_small_gram_workgroups((side && side_wgs > 0 && !is_glm() && j0 >= side_wgs_from) ? side_wgs : 512);
+            if (multi()) gram_block(cur_w, cols_of(j0), nb_of(j0), cur_xm, pool + size_t(j0) * SL * SL, sidx);
+            else gram_block_batch(cur_w, cols_base, sb, cur_xm, pool + size_t(j0) * SL * SL, sidx);
+            hipEvent_t e = nullptr;
+            if (side) {
+                e = prebuild ? next_pre_event() : next_event();
+                AHIP_CHECK(hipEventRecord(e, sidx >= 2 ? st_x[sidx - 2] : st2));
+            }
+            set_small_gram_workgroups(512);
+            for (size_t t = i; t < k; ++t) {
+                const int j = stale[t];
+                (prebuild ? pre_ev : blk_ev)[size_t(j)] = e;
+                tab_nb[j] = nb_of(j);
+                tab_ver[j] = w_version;
+                ++cnt.n_panel_grams;
+            }
+            i = k;
         }
     }
+    bool prebuild_enabled = true; // A/B hook ADELIE_HIP_PREBUILD=0
+    bool fuse_reduce = false;     // look-ahead passes: the solve sums the previous launch's slice partials itself instead of a panel_reduce launch (hook ADELIE_HIP_FUSE_REDUCE=1; measured slower: 3.08 vs 3.20 paths/s, the solve's longer prologue lengthens the fused launch by more than the reduce launch cost)
+    DevBuf<T> d_part2;
+    size_t part2_half = 0;
+    int side_wgs = 0;             // >0: confine side-stream builds of Gaussian look-ahead passes to this many workgroups (hook ADELIE_HIP_SIDE_WGS; measured: 56 -> 2.69, 112 -> 2.99 vs 3.17 paths/s unconfined: the chain waits for the slower builds)
+    int side_wgs_from = 4;        // ... for blocks the chain reaches at this position of the pass or later (ADELIE_HIP_SIDE_WGS_FROM)
+    std::vector<int> stale;
+    int batch_blocks = 8; // diagonal blocks per build launch (tuning hook ADELIE_HIP_BATCH_BLOCKS, 1..16)
     // host-mapped end-of-pass report (state + sequence number), see CdBlkParams::host_st
     struct PassReport { CdBlkState<T> st; int32_t seq; int32_t pad[15]; };
     PassReport* h_report = nullptr;
@@ -495,6 +561,7 @@ struct Solver {
             }
 
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        for (hipEvent_t e : pre_pool) (void)hipEventDestroy(e);
     }
     // ---- look-ahead form of the Gaussian panel passes (run_panel_passes) ----
     // The solve of block j (one wavefront, strictly sequential) and the panel step that prepares block j+1 only meet through
@@ -534,6 +601,7 @@ struct Solver {
             T* work = (side ? d_work_gram2 : d_work_gram)
                           .reserve(size_t(std::max<int64_t>(gram_work_elems(n, SL, SL), syrk_work_elems(n, 128))));
             T* Cx = xpool + size_t(j) * SL * SL;
+            set_small_gram_workgroups((side && side_wgs > 0 && !is_glm() && j >= side_wgs_from) ? side_wgs : 512);
             t_gram.begin(gs);
             if (multi()) {
                 // Gram of the two blocks' distinct features, expanded to view columns (zero between different responses);
@@ -565,6 +633,7 @@ struct Solver {
                 launch_gram_snp<T>(D->snp(), static_cast<const T*>(D->impute), cur_w, cols_of(j), nb, 0, cols_of(j - 1), nbp, 0,
                                    cur_xm, intercept, Cx, SL, work, gs);
             t_gram.end(gs);
+            set_small_gram_workgroups(512);
             cnt.gram_flops += 2.0 * double(n) * double(nb) * double(nbp);
             cnt.n_gram_col_reads += nb + nbp;
             if (side) {
@@ -638,6 +707,23 @@ struct Solver {
         if (dense()) return launch_panel_step<T>(D->dense<T>(), w, r, dcol, dlt, nz_dev, cols, nb, d_part.p, st);
         return launch_panel_step_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, r, dcol, dlt, nz_dev, cols, nb,
                                         d_part.p, st);
+    }
+    // `sb.count` diagonal blocks in one launch (non-multi designs): block y = columns cols_base[sb.off[y] ...], into
+    // D0 + sb.dst[y] (ld = B)
+    void gram_block_batch(const T* w, const int32_t* cols_base, const SyrkBatch& sb, const T* xm, T* D0, int side) {
+        const int B = cd_block_size();
+        hipStream_t gs = side == 0 ? st : (side >= 2 ? st_x[side - 2] : st2);
+        T* work = (side == 0 ? d_work_gram : (side >= 2 ? d_work_x[side - 2] : d_work_gram2))
+                      .reserve(size_t(std::max(syrk_batch_work_elems(n, sb.count), syrk_work_elems(n, 128))));
+        t_gram.begin(gs);
+        if (dense()) launch_syrk_batch<T>(D->dense<T>(), w, cols_base, sb, xm, intercept, D0, B, work, gs);
+        else launch_syrk_batch_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols_base, sb, xm, intercept, D0, B, work, gs);
+        t_gram.end(gs);
+        for (int y = 0; y < sb.count; ++y) {
+            const int nb = sb.nb[y];
+            cnt.gram_flops += 2.0 * double(n) * 256.0 * (nb <= 32 ? 3.0 : (nb <= 64 ? 10.0 : 36.0));
+            cnt.n_gram_col_reads += 2 * nb;
+        }
     }
     // B x B block  X_cols^T W X_cols - xm xm^T  into Dptr (ld = B)
     void gram_block(const T* w, const int32_t* cols, int nb, const T* xm, T* Dptr, int side = 0) {
@@ -1318,6 +1404,14 @@ struct Solver {
         int64_t iters = 0;
         int status = CD_OK;
         int asz = sc.active_size;
+        // blocks prebuilt by a fit that ended before its screen pass (error paths): let them finish before anything reuses
+        // their slots
+        for (hipEvent_t e : pre_ev)
+            if (e) AHIP_CHECK(hipStreamWaitEvent(st, e, 0));
+        pre_ev.clear();
+        pre_used = 0;
+        const bool prebuild_screen = is_glm() && prebuild_enabled;
+        bool screen_prebuilt = false;
         // look-ahead only under fixed weights: the cross blocks are built once per block pair and re-used for the rest of the
         // path; under IRLS they would double the MFMA work of every iteration
         const bool la = lookahead && !is_glm() && B == SL;
@@ -1330,6 +1424,8 @@ struct Solver {
             d_la_dlt.reserve(size_t(2) * SL); d_la_g.reserve(size_t(2) * SL); d_la_rsum.reserve(2);
             d_la_dcol.reserve(size_t(2) * SL); d_la_dpos.reserve(size_t(2) * SL); d_la_nz.reserve(2);
             d_part.reserve(size_t(2 * panel_part_elems(n) + 2048));
+            part2_half = size_t(panel_part_elems(n));
+            d_part2.reserve(2 * part2_half);
             pending_slot = -1;
         }
         auto pass_la = [&](bool screen_pass) -> T {
@@ -1368,9 +1464,18 @@ struct Solver {
                 launch_panel_reduce<T>(d_part.p, nsl, nb01, cols_all, &d_blk.p->resid_sum, xm_c, d_la_g.p, st);
                 cnt.n_panel_cols += nb01;
             }
+            int prev_ld = 0;         // partials of block j left behind by the previous fused launch (0: none, gblk is ready)
             for (int j = 0; j < nblk; ++j) {
                 const int slot = j & 1, pslot = slot ^ 1;
                 bp.gblk = d_la_g.p + size_t(slot) * B;
+                // fuse_reduce: the solve of block j sums the slice partials that launch j-1 left in the buffer of parity
+                // (j-1)&1 itself (no panel_reduce launch in between); resid_sum of the residual they were taken from = the
+                // one after block j-2's solve, which sits in this block's own rsum slot until this solve overwrites it
+                bp.part = (fuse_reduce && prev_ld > 0) ? d_part2.p + size_t((j - 1) & 1) * part2_half : nullptr;
+                bp.part_ld = prev_ld;
+                bp.part_n = prev_ld;
+                bp.part_rsum = xm_c ? d_la_rsum.p + slot : nullptr;
+                prev_ld = 0;
                 bp.Dptr = pool + size_t(j) * SL * SL;
                 bp.Cprev = j > 0 ? xpool + size_t(j) * SL * SL : nullptr;
                 bp.pdlt = d_la_dlt.p + size_t(pslot) * SL;
@@ -1397,19 +1502,24 @@ struct Solver {
                 const int nbn = (j + 1 < nblk) ? nb_of(j + 1) : 0;
                 const int32_t* cols_n = cols_all + size_t(j + 1) * B;
                 int ld;
+                T* part_out = fuse_reduce ? d_part2.p + size_t(j & 1) * part2_half : d_part.p;
                 if (time_panel) t_step.begin(st);
                 if (dense())
                     ld = launch_panel_fused<T>(bp, j, D->dense<T>(), cur_w, r_dev, d_la_dcol.p + size_t(pslot) * SL,
-                                               d_la_dlt.p + size_t(pslot) * SL, d_la_nz.p + pslot, cols_n, nbn, d_part.p, st);
+                                               d_la_dlt.p + size_t(pslot) * SL, d_la_nz.p + pslot, cols_n, nbn, part_out, st);
                 else
                     ld = launch_panel_fused_snp<T>(bp, j, D->snp(), static_cast<const T*>(D->impute), cur_w, r_dev,
                                                    d_la_dcol.p + size_t(pslot) * SL, d_la_dlt.p + size_t(pslot) * SL,
-                                                   d_la_nz.p + pslot, cols_n, nbn, d_part.p, st);
+                                                   d_la_nz.p + pslot, cols_n, nbn, part_out, st);
                 if (time_panel) t_step.end(st);
                 if (nbn > 0) {
-                    // resid_sum as it was before block j's solve (the residual the partials were taken from)
-                    launch_panel_reduce_ld<T>(d_part.p, ld, ld, nbn, cols_n, d_la_rsum.p + pslot, xm_c,
-                                              d_la_g.p + size_t(pslot) * B, st);
+                    if (fuse_reduce) {
+                        prev_ld = ld; // summed by the next solve
+                    } else {
+                        // resid_sum as it was before block j's solve (the residual the partials were taken from)
+                        launch_panel_reduce_ld<T>(d_part.p, ld, ld, nbn, cols_n, d_la_rsum.p + pslot, xm_c,
+                                                  d_la_g.p + size_t(pslot) * B, st);
+                    }
                     cnt.n_panel_cols += nbn;
                 }
             }
@@ -1443,11 +1553,21 @@ struct Solver {
             Stopwatch sw_enq;
             sw_enq.start();
             build_stale_blocks(nblk, tab_nb, tab_ver, pool, [&](int j) { return std::min(B, count - j * B); },
-                               [&](int j) { return cols_all + size_t(j) * B; });
+                               [&](int j) { return cols_all + size_t(j) * B; }, false, screen_pass);
+            if (!screen_pass && prebuild_screen && !screen_prebuilt && side_grams && st2) {
+                // IRLS: every screen-order block is stale as well (new weights) and the screen pass follows the active-set
+                // passes of this fit: enqueue those builds now, behind the ones this pass waits for, so that they run while
+                // the active-set passes iterate
+                screen_prebuilt = true;
+                const int cnt_s = cp.nv, nblk_s = (cnt_s + B - 1) / B;
+                build_stale_blocks(nblk_s, dscr_nb, dscr_ver, d_Dpool.p, [&](int j) { return std::min(B, cnt_s - j * B); },
+                                   [&](int j) { return d_vcol.p + size_t(j) * B; }, true);
+            }
             t_cd.begin(st);
             // (a look-ahead pass may have run before: plain buffers for the solves, its pending changes for the first step)
             bp.gblk = d_gblk.p; bp.dlt = d_dlt.p; bp.dcol = d_dcolblk.p;
             bp.Cprev = nullptr; bp.dpos = nullptr; bp.nz_out = nullptr; bp.rsum_out = nullptr;
+            bp.part = nullptr;
             for (int j = 0; j < nblk; ++j) {
                 const int nb = std::min(B, count - j * B);
                 const int32_t* cols = cols_all + size_t(j) * B;
@@ -2641,6 +2761,11 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_GROUP_PANEL")) group_panel = std::atoi(e) != 0; // A/B hook
         if (const char* e = std::getenv("ADELIE_HIP_LOOKAHEAD")) lookahead = std::atoi(e) != 0; // A/B hook
         if (const char* e = std::getenv("ADELIE_HIP_LOOKAHEAD_MIN_BLOCKS")) la_min_blocks = std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("ADELIE_HIP_PREBUILD")) prebuild_enabled = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_FUSE_REDUCE")) fuse_reduce = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_SIDE_WGS")) side_wgs = std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("ADELIE_HIP_SIDE_WGS_FROM")) side_wgs_from = std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("ADELIE_HIP_BATCH_BLOCKS")) batch_blocks = std::max(1, std::min(int(SyrkBatch::MAX), std::atoi(e)));
         if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {
             panel_bsz = std::atoi(e);
             if (panel_bsz != 32 && panel_bsz != 64 && panel_bsz != 128) panel_bsz = 0;

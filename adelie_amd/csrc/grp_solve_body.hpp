@@ -109,8 +109,373 @@ __host__ __device__ constexpr size_t grp_solve_lds_total() {
     return ((grp_solve_lds<T>() + 15) / 16) * 16 + size_t(2) * GBLK * sizeof(T) + size_t(GBLK) * sizeof(int32_t);
 }
 
+// The panel solve in the eigen-coordinates of the block's groups (CdGrpBlkParams::rot): p.Dptr holds R^T D R.  Same iterates
+// as grp_solve_body in exact arithmetic — the reference rotates the gradient and the coefficients of a group into the
+// eigenbasis at every visit (pin_naive:123-140) and the new coefficients back (:156-157); here every VALUE of the block is
+// rotated once, lane-parallel, before the sequential loop, the loop keeps the rotated gradient current with the rotated
+// block, and the coefficients of the groups that changed are rotated back once, lane-parallel, after it.  The dependent
+// chain of a visit shrinks to: Newton root find -> change test -> gradient update of the following groups.
+template <class T>
+__device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, int j, char* smem_raw) {
+    T* D = reinterpret_cast<T*>(smem_raw); // GBLK*GBLK, rotated
+    T* gT = D + GBLK * GBLK;  // rotated gradient of the block's values, kept current
+    T* bT = gT + GBLK;        // rotated coefficients, current
+    T* b0B = bT + GBLK;       // coefficients at block entry (original coordinates)
+    T* AB = b0B + GBLK;
+    T* xmT = AB + GBLK;       // rotated column means
+    T* scr = xmT + GBLK;      // 8 * GBLK scratch
+    T* gO = scr;              // gradient as handed over (original coordinates)
+    T* xmO = scr + GBLK;
+    T* delT = scr + 2 * GBLK; // rotated change of the group just visited
+    T* gk_t = scr + 3 * GBLK; // (groups wider than a wavefront only)
+    T* ako_t = scr + 4 * GBLK;
+    T* ak_t = scr + 5 * GBLK;
+    T* buf1 = scr + 6 * GBLK;
+    T* buf2 = scr + 7 * GBLK;
+    int32_t* vmap = reinterpret_cast<int32_t*>(scr + 8 * GBLK);
+    int32_t* goff = vmap + GBLK;
+    int32_t* gq = goff + GBLK + 1;
+    int32_t* gss = gq + GBLK;
+    int32_t* meta = gss + GBLK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    block_layout(p, j, vmap, goff, gq, gss, meta);
+    const int ngrp = meta[0], nval = meta[1];
+    T* gpenB = reinterpret_cast<T*>(meta + 5);
+    int32_t* gactB = reinterpret_cast<int32_t*>(gpenB + GBLK);
+    int32_t* vgrp = gactB + GBLK;                       // value -> group of the block
+    int32_t* chg = vgrp + GBLK;                         // group changed in this pass
+    if (tid < GBLK && tid < ngrp) {
+        const int ss = gss[tid];
+        gpenB[tid] = p.spen[ss];
+        gactB[tid] = p.is_active[ss];
+        chg[tid] = 0;
+    }
+    for (int k = tid >> 1; k < ngrp; k += 128) {
+        const int o = goff[k], q = gq[k];
+        for (int t = tid & 1; t < q; t += 2) vgrp[o + t] = k;
+    }
+    if (tid < GBLK) {
+        const int i = tid;
+        if (i < nval) {
+            const int a = vmap[i];
+            gO[i] = p.gblk[i];
+            b0B[i] = p.beta[a];
+            AB[i] = p.vars[a];
+            xmO[i] = p.xmean[a];
+        } else {
+            gO[i] = 0; b0B[i] = 0; AB[i] = 0; xmO[i] = 0; gT[i] = 0; bT[i] = 0; xmT[i] = 0;
+        }
+    }
+    // look-ahead correction in original coordinates (Cprev and the previous block's changes are original-coordinate)
+    T* corr = reinterpret_cast<T*>(smem_raw + ((grp_solve_lds<T>() + 15) / 16) * 16);
+    const bool has_corr = p.Cprev != nullptr;
+    if (has_corr) {
+        const int row = tid & (GBLK - 1), half = tid >> 7;
+        const int nzp = p.pnz[0];
+        const int per = (nzp + 1) / 2;
+        const int m0 = half * per, m1 = min(nzp, m0 + per);
+        const T* Cp = p.Cprev + row;
+        T acc = T(0);
+        int m = m0;
+        for (; m + 8 <= m1; m += 8) {
+            T c[8], d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                c[u] = Cp[size_t(p.ppos[m + u]) * GBLK];
+                d[u] = p.pdlt[m + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fma(c[u], d[u], acc);
+        }
+        for (; m < m1; ++m) acc = fma(Cp[size_t(p.ppos[m]) * GBLK], p.pdlt[m], acc);
+        corr[half * GBLK + row] = acc;
+    }
+    {
+        const T* src = p.Dptr;
+        const int NE = nval * GBLK;
+        for (int e0 = tid; e0 < NE; e0 += 256 * 16) {
+            T v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = src[min(e0 + u * 256, NE - 1)];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (e0 + u * 256 < NE) D[e0 + u * 256] = v[u];
+        }
+    }
+    __syncthreads();
+    if (has_corr) { // uniform over the workgroup
+        if (tid < nval) gO[tid] -= corr[tid] + corr[GBLK + tid];
+        __syncthreads();
+    }
+    // every value into the eigenbasis of its group: (g V)_t, (beta V)_t, (xbar V)_t   (pin_naive:123-135)
+    if (tid < nval) {
+        const int i = tid, k = vgrp[i], o = goff[k], q = gq[k];
+        if (q == 1) {
+            gT[i] = gO[i]; bT[i] = b0B[i]; xmT[i] = xmO[i];
+        } else {
+            const T* Vt = p.V + p.voff[gss[k]] + int64_t(i - o) * q;
+            T s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll 4
+            for (int u = 0; u < q; ++u) {
+                const T v = Vt[u];
+                s1 = fma(gO[o + u], v, s1);
+                s2 = fma(b0B[o + u], v, s2);
+                s3 = fma(xmO[o + u], v, s3);
+            }
+            gT[i] = s1; bT[i] = s2; xmT[i] = s3;
+        }
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    __builtin_amdgcn_s_setprio(3);
+
+    CdBlkState<T>* st = p.st;
+    T rsq = st->rsq, rsum = st->resid_sum, cm = (j == 0) ? T(0) : st->cm;
+    int asz = st->active_size, status = st->status;
+    int64_t n_upd = st->n_updates;
+    T rs_acc = T(0), xs_acc = T(0); // lane partials of the rsq / resid_sum updates of the groups with q > 1 (summed once, below)
+
+    for (int k = 0; k < ngrp && status == CD_OK; ++k) {
+        const int o = goff[k], q = gq[k], ss = gss[k];
+        const T pk = gpenB[k];
+        const T l1p = p.l1 * pk, l2p = p.l2 * pk;
+        bool changed = false;
+        if (q == 1) {
+            const T gcur = gT[o], bi = bT[o], A = AB[o];
+            const T gk = fma(bi, A, gcur);                       // pin_naive:85-89
+            const T v = fabs(gk) - l1p;                          // pin_base:181-195
+            const T ak = (v > T(0)) ? copysign(v, gk) / (A + l2p) : T(0);
+            if (ak != bi) {                                      // pin_naive:97
+                changed = true;
+                const T d = ak - bi;
+                const T c1 = A * d * d;
+                cm = c1 > cm ? c1 : cm;
+                rsq += d * (T(2) * gcur - d * A);
+                rsum -= xmT[o] * d;
+                if (lane == 0) { bT[o] = ak; delT[0] = d; }
+            }
+        } else if (q <= 64) {
+            const bool on = lane < q;
+            const T A_r = on ? AB[o + lane] : T(0);
+            const T ako_r = on ? bT[o + lane] : T(0);
+            const T gk_r = on ? gT[o + lane] + A_r * ako_r : T(0); // gk_t += A * ak_old_t   (pin_naive:139-140)
+            // newton_solver (bcd/unconstrained/newton.hpp:35-142): v = gk_t, L = A
+            const T nrm2 = group_sum(on ? gk_r * gk_r : T(0), q);
+            T akt_r = T(0);
+            if (sqrt(nrm2) <= l1p) {
+                akt_r = T(0);
+            } else if (l1p <= T(0)) {
+                akt_r = on ? gk_r / (A_r + l2p) : T(0);
+            } else {
+                const T b1 = A_r + l2p;
+                T h = 0, fh, dfh, b2 = T(0);
+                { // isotropic block: start at the closed-form root (see grp_solve_body)
+                    const T a0 = first_lane(A_r);
+                    const bool iso = __ballot(on && A_r != a0) == 0ull && (a0 + l2p) > T(0);
+                    if (iso) h = (sqrt(nrm2) - l1p) / (a0 + l2p);
+                }
+                auto step = [&](T hh) {
+                    T t = 0, sx = 0;
+                    if (on) {
+                        b2 = T(1) / (b1 * hh + l1p);
+                        const T z = gk_r * b2;
+                        const T x = z * z;
+                        t = x;
+                        sx = x * b1 * b2;
+                    }
+                    t = group_sum(t, q);
+                    sx = group_sum(sx, q);
+                    fh = t - T(1);
+                    dfh = -sx * (T(1) + sqrt(t)) / t;
+                };
+                step(h);
+                int iters = 0;
+                while ((fabs(fh) > p.newton_tol) && (iters < p.newton_max_iters)) {
+                    h -= fh / dfh;
+                    h = h > T(0) ? h : T(0);
+                    step(h);
+                    ++iters;
+                }
+                akt_r = on ? h * gk_r * b2 : T(0);
+                if (iters >= p.newton_max_iters) { status = CD_NEWTON; break; }
+            }
+            // changed? ; convergence / rsq in rotated coordinates (pin_naive:144-154)
+            T d = T(0), rs = T(0), dn = T(0), c1 = T(0);
+            if (on) {
+                const T gg = gk_r - A_r * ako_r;
+                d = akt_r - ako_r;
+                dn = d * d;
+                c1 = (A_r * d) * d;
+                rs = d * (T(2) * gg - d * A_r);
+            }
+            dn = group_sum(dn, q);
+            c1 = group_sum(c1, q);
+            if (!(sqrt(dn) <= p.dbeta_tol * sqrt(T(q)))) {
+                changed = true;
+                c1 /= T(q);
+                cm = c1 > cm ? c1 : cm;
+                rs_acc += rs;
+                if (on) {
+                    xs_acc = fma(xmT[o + lane], d, xs_acc);   // resid_sum -= xbar . del = (xbar V) . del_t   (pin_naive:161-163)
+                    bT[o + lane] = akt_r;
+                    delT[lane] = d;
+                }
+            }
+        } else {
+            const T* A = AB + o;
+            for (int i = lane; i < q; i += 64) {
+                ako_t[i] = bT[o + i];
+                gk_t[i] = gT[o + i] + A[i] * bT[o + i];
+            }
+            __builtin_amdgcn_wave_barrier();
+            T nrm2 = 0;
+            for (int i = lane; i < q; i += 64) nrm2 = fma(gk_t[i], gk_t[i], nrm2);
+            nrm2 = gwsum(nrm2);
+            if (sqrt(nrm2) <= l1p) {
+                for (int i = lane; i < q; i += 64) ak_t[i] = 0;
+            } else if (l1p <= T(0)) {
+                for (int i = lane; i < q; i += 64) ak_t[i] = gk_t[i] / (A[i] + l2p);
+            } else {
+                for (int i = lane; i < q; i += 64) buf1[i] = A[i] + l2p;
+                T h = 0, fh, dfh;
+                auto step = [&](T hh) {
+                    T t = 0, sx = 0;
+                    for (int i = lane; i < q; i += 64) {
+                        const T b2 = T(1) / (buf1[i] * hh + l1p);
+                        const T z = gk_t[i] * b2;
+                        const T x = z * z;
+                        buf2[i] = b2;
+                        t += x;
+                        sx += x * buf1[i] * b2;
+                    }
+                    t = gwsum(t);
+                    sx = gwsum(sx);
+                    fh = t - T(1);
+                    dfh = -sx * (T(1) + sqrt(t)) / t;
+                };
+                step(h);
+                int iters = 0;
+                while ((fabs(fh) > p.newton_tol) && (iters < p.newton_max_iters)) {
+                    h -= fh / dfh;
+                    h = h > T(0) ? h : T(0);
+                    step(h);
+                    ++iters;
+                }
+                for (int i = lane; i < q; i += 64) ak_t[i] = h * gk_t[i] * buf2[i];
+                if (iters >= p.newton_max_iters) { status = CD_NEWTON; break; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            T dn = 0, c1 = 0, rs = 0;
+            for (int i = lane; i < q; i += 64) {
+                const T gg = gk_t[i] - A[i] * ako_t[i];
+                const T d = ak_t[i] - ako_t[i];
+                dn = fma(d, d, dn);
+                c1 = fma(A[i] * d, d, c1);
+                rs += d * (T(2) * gg - d * A[i]);
+            }
+            dn = gwsum(dn);
+            c1 = gwsum(c1);
+            if (!(sqrt(dn) <= p.dbeta_tol * sqrt(T(q)))) {
+                changed = true;
+                c1 /= T(q);
+                cm = c1 > cm ? c1 : cm;
+                rs_acc += rs;
+                for (int i = lane; i < q; i += 64) {
+                    const T d = ak_t[i] - ako_t[i];
+                    xs_acc = fma(xmT[o + i], d, xs_acc);
+                    bT[o + i] = ak_t[i];
+                    delT[i] = d;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (changed) {
+            if (lane == 0) chg[k] = 1;
+            if (p.mark && gactB[k] == 0) {                         // add_active_set, pin_naive:294-304
+                if (asz >= p.max_active_size) { status = CD_MAX_ACTIVE; break; }
+                if (lane == 0) { p.is_active[ss] = 1; p.active_set[asz] = ss; }
+                ++asz;
+            }
+            // keep the block's rotated gradient current: gT -= D~[:, o:o+q] del_t
+            for (int l = lane; l < GBLK; l += 64) {
+                T acc = gT[l];
+#pragma unroll 4
+                for (int t = 0; t < q; ++t) acc = fma(-D[l + (o + t) * GBLK], delT[t], acc);
+                gT[l] = acc;
+            }
+            __builtin_amdgcn_wave_barrier();
+            ++n_upd;
+        }
+    }
+    rsq += gwsum(rs_acc);
+    rsum -= gwsum(xs_acc);
+    __builtin_amdgcn_wave_barrier();
+    // back into original coordinates: ak = ak_t V^T for the groups that changed (pin_naive:156-157); the others keep their
+    // coefficients bit for bit.  Then the compacted non-zero value changes for the update kernel, as in grp_solve_body.
+    int nz = 0;
+    for (int i0 = 0; i0 < GBLK; i0 += 64) {
+        const int i = i0 + lane;
+        T bnew = T(0), b0 = T(0);
+        bool ch = false;
+        if (i < nval) {
+            const int k = vgrp[i], o = goff[k], q = gq[k];
+            b0 = b0B[i];
+            bnew = b0;
+            if (chg[k]) {
+                if (q == 1) {
+                    bnew = bT[i];
+                } else {
+                    const T* Vg = p.V + p.voff[gss[k]];
+                    T s = 0;
+#pragma unroll 4
+                    for (int jj = 0; jj < q; ++jj) s = fma(bT[o + jj], Vg[(i - o) + int64_t(jj) * q], s);
+                    bnew = s;
+                }
+            }
+            ch = bnew != b0;
+        }
+        if (ch) p.beta[vmap[i]] = bnew;
+        const unsigned long long m = __ballot(ch);
+        const int pos = nz + __popcll(m & ((1ull << lane) - 1ull));
+        if (ch) {
+            p.dcol[pos] = p.vcol[vmap[i]];
+            if (p.dpos) p.dpos[pos] = i;
+            p.dlt[pos] = bnew - b0;
+        }
+        nz += __popcll(m);
+    }
+    if (lane == 0) {
+        st->rsq = rsq;
+        st->resid_sum = rsum;
+        st->cm = cm;
+        st->active_size = asz;
+        st->status = status;
+        st->n_updates = n_upd;
+        st->nz = nz;
+        if (p.nz_out) {
+            p.nz_out[0] = nz;
+            p.rsum_out[0] = rsum;
+        }
+        if (p.host_st && j == p.report_j) {
+            CdBlkState<T> out;
+            out.rsq = rsq; out.resid_sum = rsum; out.cm = cm; out.n_updates = n_upd;
+            out.active_size = asz; out.status = status; out.nz = nz; out._pad = 0;
+            *p.host_st = out;
+            __threadfence_system();
+            __hip_atomic_store(p.host_seq, p.report_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 template <class T, bool NAIVE>
 __device__ __forceinline__ void grp_solve_body(const CdGrpBlkParams<T>& p, int j, char* smem_raw) {
+    if constexpr (NAIVE) {
+        if (p.rot) { // uniform over the workgroup
+            grp_solve_body_rot<T>(p, j, smem_raw);
+            return;
+        }
+    }
     T* D = reinterpret_cast<T*>(smem_raw); // GBLK*GBLK
     T* gB = D + GBLK * GBLK;
     T* bB = gB + GBLK;     // current beta of the block's values

@@ -244,7 +244,20 @@ struct CdGrpBlkParams {
     int32_t* dpos;
     int32_t* nz_out;
     T* rsum_out;
+    // rot != 0 (panel variant only): Dptr holds the block in the eigen-coordinates of its groups, R^T D R with
+    // R = blockdiag(V_g) (launch_grp_block_rotate, applied once per build): the sequential loop then works on rotated
+    // gradients / coefficients throughout and the per-visit rotations of pin_naive:123-157 happen once per block and value,
+    // lane-parallel, in the prologue and the epilogue of the solve
+    int32_t rot;
 };
+// D <- R^T D R for one 128 x 128 slot (ld 128): `ng` groups, group k = block values [goff[k], goff[k+1]) with eigenbasis
+// (q, q) column-major at V + voff[k] (ignored for q == 1).  `scratch` holds 128 * 128 elements, private to the stream.
+struct GrpRotArgs {
+    int32_t ng;
+    int32_t goff[129];
+    int64_t voff[128];
+};
+template <class T> void launch_grp_block_rotate(T* Dptr, const T* V, const GrpRotArgs& a, T* scratch, hipStream_t s);
 template <class T> void launch_cd_group_block_pass(const CdGrpBlkParams<T>& p, hipStream_t s);
 // the visits of block j against p.gblk / p.Dptr (one workgroup)
 template <class T> void launch_cd_group_panel_solve(const CdGrpBlkParams<T>& p, int j, hipStream_t s);

@@ -85,6 +85,66 @@ void launch_cd_group_block_pass(const CdGrpBlkParams<T>& p, hipStream_t s) {
     }
 }
 
+// D <- R^T D R, R = blockdiag(V_k): two passes over the slot, every thread one entry at a time with the row index fastest
+// (LDS reads conflict-free, global reads / writes coalesced, the q values of V_k broadcast).  T = D R goes through `scratch`.
+template <class T>
+__global__ __launch_bounds__(256) void grp_block_rotate_kernel(T* __restrict__ Dptr, const T* __restrict__ V, GrpRotArgs a,
+                                                               T* __restrict__ scratch) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* D = reinterpret_cast<T*>(smem_raw);
+    __shared__ int32_t vgrp[GBLK];
+    const int tid = threadIdx.x;
+    const int nval = a.goff[a.ng];
+    for (int k = tid; k < a.ng; k += 256)
+        for (int i = a.goff[k]; i < a.goff[k + 1]; ++i) vgrp[i] = k;
+    for (int e = tid; e < nval * GBLK; e += 256) D[e] = Dptr[e];
+    __syncthreads();
+    for (int e = tid; e < nval * nval; e += 256) { // T[l, c] = sum_u D[l, o + u] V[u, t],  c = o + t
+        const int l = e % nval, c = e / nval;
+        const int k = vgrp[c], o = a.goff[k], q = a.goff[k + 1] - o;
+        T s;
+        if (q == 1) {
+            s = D[l + c * GBLK];
+        } else {
+            const T* Vt = V + a.voff[k] + int64_t(c - o) * q;
+            s = T(0);
+            for (int u = 0; u < q; ++u) s = fma(D[l + (o + u) * GBLK], Vt[u], s);
+        }
+        scratch[l + c * GBLK] = s;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int e = tid; e < nval * nval; e += 256) { // D~[r, c] = sum_u V[u, s] T[o + u, c],  r = o + s
+        const int r = e % nval, c = e / nval;
+        const int k = vgrp[r], o = a.goff[k], q = a.goff[k + 1] - o;
+        T s;
+        if (q == 1) {
+            s = scratch[r + c * GBLK];
+        } else {
+            const T* Vs = V + a.voff[k] + int64_t(r - o) * q;
+            s = T(0);
+            for (int u = 0; u < q; ++u) s = fma(Vs[u], scratch[(o + u) + c * GBLK], s);
+        }
+        Dptr[r + c * GBLK] = s;
+    }
+}
+
+template <class T>
+void launch_grp_block_rotate(T* Dptr, const T* V, const GrpRotArgs& a, T* scratch, hipStream_t s) {
+    if (a.ng <= 0) return;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grp_block_rotate_kernel<double>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(GBLK * GBLK * sizeof(double)));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grp_block_rotate_kernel<float>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(GBLK * GBLK * sizeof(float)));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((grp_block_rotate_kernel<T>), dim3(1), dim3(256), size_t(GBLK) * GBLK * sizeof(T), s, Dptr, V, a, scratch);
+}
+template void launch_grp_block_rotate<double>(double*, const double*, const GrpRotArgs&, double*, hipStream_t);
+template void launch_grp_block_rotate<float>(float*, const float*, const GrpRotArgs&, float*, hipStream_t);
+
 template <class T>
 void launch_cd_group_panel_solve(const CdGrpBlkParams<T>& p, int j, hipStream_t s) {
     static bool attr_done = false;

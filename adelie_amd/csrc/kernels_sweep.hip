@@ -17,6 +17,7 @@
 // splits are combined by a second tiny kernel so results are deterministic (no float atomics).
 #include "kernels.hpp"
 #include "accessors.hpp"
+#include <cstdlib>
 
 namespace ahip {
 
@@ -136,9 +137,15 @@ __global__ void sweep_reduce_kernel(const T* __restrict__ part, T* __restrict__ 
 }
 
 constexpr int kSweepCB = 4;
+// columns per sweep block: 4, or 8 with ADELIE_HIP_SWEEP_CB=8 (tuning hook: halves the re-reads of v through L2)
+inline int sweep_cb() {
+    static const int v = (std::getenv("ADELIE_HIP_SWEEP_CB") && std::atoi(std::getenv("ADELIE_HIP_SWEEP_CB")) == 8) ? 8 : kSweepCB;
+    return v;
+}
 
 inline void sweep_shape(int64_t n, int64_t ncols, int vec, int64_t& blocks_c, int& nsplit, int64_t& rows_per_split) {
-    blocks_c = (ncols + kSweepCB - 1) / kSweepCB;
+    const int cbv = sweep_cb();
+    blocks_c = (ncols + cbv - 1) / cbv;
     const int64_t unit = int64_t(kThreads) * vec;      // rows per block iteration
     const int64_t max_split = (n + unit * 4 - 1) / (unit * 4); // >= 4 iterations per split
     int64_t want = (1024 + blocks_c - 1) / blocks_c;
@@ -162,8 +169,14 @@ void sweep_dispatch(Acc acc, const T* v, T* out, int64_t n, int64_t c0, int64_t 
     sweep_shape(n, ncols, VEC, blocks_c, nsplit, rows_per_split);
     dim3 grid((unsigned)blocks_c, (unsigned)nsplit);
     T* dst = nsplit == 1 ? out : work;
-    if (square)
+    if (square && sweep_cb() == 8)
+        hipLaunchKernelGGL((sweep_kernel<T, Acc, 8, VEC, true>), grid, dim3(kThreads), 0, s, acc, v, dst, n, c0,
+                           ncols, cols, rows_per_split, nsplit, sub_scale, sub_vec);
+    else if (square)
         hipLaunchKernelGGL((sweep_kernel<T, Acc, kSweepCB, VEC, true>), grid, dim3(kThreads), 0, s, acc, v, dst, n, c0,
+                           ncols, cols, rows_per_split, nsplit, sub_scale, sub_vec);
+    else if (sweep_cb() == 8)
+        hipLaunchKernelGGL((sweep_kernel<T, Acc, 8, VEC, false>), grid, dim3(kThreads), 0, s, acc, v, dst, n, c0,
                            ncols, cols, rows_per_split, nsplit, sub_scale, sub_vec);
     else
         hipLaunchKernelGGL((sweep_kernel<T, Acc, kSweepCB, VEC, false>), grid, dim3(kThreads), 0, s, acc, v, dst, n, c0,

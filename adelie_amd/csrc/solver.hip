@@ -458,6 +458,10 @@ struct Solver {
         }
         return pre_pool[pre_used++];
     }
+    // `rot_list` != nullptr or `rot_screen`: group passes with CdGrpBlkParams::rot — every block built here is rotated into the
+    // eigen-coordinates of its groups right behind its build (same stream), over the pass's visiting list.
+    const idx* rot_list = nullptr;
+    bool rot_on = false;
     template <class NbOf, class ColsOf>
     void build_stale_blocks(int nblk, std::vector<int32_t>& tab_nb, std::vector<uint64_t>& tab_ver, T* pool, NbOf nb_of,
                             ColsOf cols_of, bool prebuild = false, bool take_pre = false) {
@@ -519,6 +523,8 @@ struct Solver {
             set_small_gram_workgroups((side && side_wgs > 0 && !is_glm() && j0 >= side_wgs_from) ? side_wgs : 512);
             if (multi()) gram_block(cur_w, cols_of(j0), nb_of(j0), cur_xm, pool + size_t(j0) * SL * SL, sidx);
             else gram_block_batch(cur_w, cols_base, sb, cur_xm, pool + size_t(j0) * SL * SL, sidx);
+            if (rot_on)
+                for (size_t t = i; t < k; ++t) rotate_block(rot_list, stale[t], pool + size_t(stale[t]) * SL * SL, sidx);
             hipEvent_t e = nullptr;
             if (side) {
                 e = prebuild ? next_pre_event() : next_event();
@@ -943,6 +949,8 @@ struct Solver {
                 d_V.grow(v_used + size_t(q) * q, v_used, st);
                 d_V.upload(Vt.data(), Vt.size(), st, v_used);
                 voff[ss - g_begin] = idx(v_used);
+                if (h_voff.size() < size_t(ns)) h_voff.resize(size_t(ns), 0);
+                h_voff[size_t(ss)] = idx(v_used);
                 v_used += size_t(q) * q;
                 screen_transforms[ss] = std::move(Vt);
                 sync();
@@ -1014,6 +1022,7 @@ struct Solver {
         int j0 = 0;
         while (j0 + 1 < nblk && size_t(part_host[j0 + 1]) <= g_begin) ++j0;
         std::vector<T> hD(size_t(nblk - j0) * SL * SL);
+        std::vector<int> rebuilt_blocks;
         for (int j = j0; j < nblk; ++j) {
             const int nval = gp_vbeg[size_t(j) + 1] - gp_vbeg[j];
             T* Dptr = d_Dpool.p + size_t(j) * SL * SL;
@@ -1022,6 +1031,7 @@ struct Solver {
                 dscr_nb[j] = nval;
                 dscr_ver[j] = w_version;
                 ++cnt.n_panel_grams;
+                rebuilt_blocks.push_back(j);
             }
             AHIP_CHECK(hipMemcpyAsync(hD.data() + size_t(j - j0) * SL * SL, Dptr, size_t(SL) * SL * sizeof(T),
                                       hipMemcpyDeviceToHost, st));
@@ -1029,6 +1039,7 @@ struct Solver {
         sync();
         std::vector<T> vars_host(N), vnew;
         std::vector<idx> voff(size_t(ns) - g_begin, 0);
+        h_voff.resize(size_t(ns), 0);
         int j = j0;
         for (idx ss = idx(g_begin); ss < ns; ++ss) {
             while (j + 1 < nblk && part_host[j + 1] <= int32_t(ss)) ++j;
@@ -1047,6 +1058,7 @@ struct Solver {
             jacobi_eigh(int(q), A, V, Dv);
             for (idx t = 0; t < q; ++t) vars_host[b + t - pos0] = T(Dv[t] >= 0 ? Dv[t] : 0.0);
             voff[ss - g_begin] = idx(v_used + vnew.size());
+            h_voff[size_t(ss)] = voff[ss - g_begin];
             std::vector<T> Vt(V.begin(), V.end());
             vnew.insert(vnew.end(), Vt.begin(), Vt.end());
             screen_transforms[ss] = std::move(Vt);
@@ -1058,8 +1070,31 @@ struct Solver {
         }
         d_vars.upload(vars_host.data(), N, st, pos0);
         d_voff.upload(voff.data(), voff.size(), st, g_begin);
+        // the blocks built above, into the eigen-coordinates of their groups (the eigenbases are on the device now)
+        if (group_rot)
+            for (int jb : rebuilt_blocks) rotate_block(nullptr, jb, d_Dpool.p + size_t(jb) * SL * SL, 0);
         sync(); // the staging vectors go out of scope
         for (idx t = 0; t < N; ++t) screen_vars[pos0 + t] = vars_host[t];
+    }
+    // D <- R^T D R for block `jb` of the partition in part_host over `list` (nullptr: screen order), on the stream of build
+    // side `side` (0: main).  See CdGrpBlkParams::rot.
+    bool group_rot = true; // A/B hook ADELIE_HIP_GROUP_ROT=0
+    std::vector<idx> h_voff; // per screen group: offset of its eigenbasis in d_V
+    DevBuf<T> d_rot_scratch[2 + kMaxExtra];
+    void rotate_block(const idx* list, int jb, T* Dptr, int side) {
+        GrpRotArgs a{};
+        int ng = 0, o = 0;
+        for (int32_t pos = part_host[size_t(jb)]; pos < part_host[size_t(jb) + 1]; ++pos, ++ng) {
+            const idx ss = list ? list[pos] : idx(pos);
+            a.goff[ng] = o;
+            a.voff[ng] = (size_t(ss) < h_voff.size()) ? h_voff[size_t(ss)] : 0;
+            o += int32_t(group_sizes[screen_set[ss]]);
+        }
+        a.goff[ng] = o;
+        a.ng = ng;
+        hipStream_t gs = side == 0 ? st : (side >= 2 ? st_x[side - 2] : st2);
+        T* scratch = d_rot_scratch[side].reserve(size_t(cd_block_size()) * cd_block_size());
+        launch_grp_block_rotate<T>(Dptr, d_V.p, a, scratch, gs);
     }
 
     // solver_gaussian_naive.hpp:134-176
@@ -1777,6 +1812,11 @@ struct Solver {
         bp.dlt = d_dlt.p; bp.st = d_blk.p;
         bp.gblk = d_gblk.p; bp.vcol = cp.vcol; bp.dcol = d_dcolblk.p;
         bp.host_st = rep_st_dev; bp.host_seq = rep_seq_dev; bp.report_j = -1; bp.report_seq = 0;
+        bp.rot = group_rot ? 1 : 0;
+        struct RotGuard { // builds of this fit are rotated behind their launch (build_stale_blocks); off again on any exit
+            Solver* s;
+            ~RotGuard() { s->rot_on = false; s->rot_list = nullptr; }
+        } rot_guard{this};
         if (std::getenv("ADELIE_HIP_GRP_PROFILE")) {
             if (!d_grp_dbg.p) { d_grp_dbg.reserve(8); AHIP_CHECK(hipMemsetAsync(d_grp_dbg.p, 0, 8 * sizeof(int64_t), st)); }
             bp.dbg = d_grp_dbg.p;
@@ -1826,7 +1866,10 @@ struct Solver {
             bp.mark = screen_pass ? 1 : 0;
             auto nb_of = [&](int j) { return int(gp_vbeg[size_t(j) + 1] - gp_vbeg[j]); };
             auto cols_of = [&](int j) { return cols_all + gp_vbeg[j]; };
+            rot_on = group_rot;
+            rot_list = screen_pass ? nullptr : act_host.data();
             build_stale_blocks(nblk, tab_nb, tab_ver, pool, nb_of, cols_of);
+            rot_on = false;
             build_stale_cross(nblk, screen_pass ? xscr_key : xact_key, xpool, nb_of, cols_of);
             t_cd.begin(st);
             {   // first step of the pass: pending changes of the previous pass's last block; blocks 0 and 1 prepared
@@ -1927,6 +1970,8 @@ struct Solver {
             bp.list = screen_pass ? nullptr : cp.active_set;
             bp.nblk = nblk;
             bp.mark = screen_pass ? 1 : 0;
+            rot_on = group_rot;
+            rot_list = screen_pass ? nullptr : act_host.data();
             build_stale_blocks(nblk, tab_nb, tab_ver, pool, [&](int j) { return int(gp_vbeg[size_t(j) + 1] - gp_vbeg[j]); },
                                [&](int j) { return cols_all + gp_vbeg[j]; });
             t_cd.begin(st);
@@ -2762,6 +2807,7 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_LOOKAHEAD")) lookahead = std::atoi(e) != 0; // A/B hook
         if (const char* e = std::getenv("ADELIE_HIP_LOOKAHEAD_MIN_BLOCKS")) la_min_blocks = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("ADELIE_HIP_PREBUILD")) prebuild_enabled = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_GROUP_ROT")) group_rot = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_FUSE_REDUCE")) fuse_reduce = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_SIDE_WGS")) side_wgs = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("ADELIE_HIP_SIDE_WGS_FROM")) side_wgs_from = std::max(0, std::atoi(e));

@@ -36,6 +36,10 @@ __device__ __forceinline__ double first_lane(double x) {
 __device__ __forceinline__ float first_lane(float x) {
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
 }
+__device__ __forceinline__ double rdl(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ float rdl(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 template <class T>
 __device__ __forceinline__ T row16_sum(T x) {
     x += dpp_move<0xB1>(x);  // quad_perm [1,0,3,2]
@@ -241,6 +245,7 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
         const T pk = gpenB[k];
         const T l1p = p.l1 * pk, l2p = p.l2 * pk;
         bool changed = false;
+        T d_reg = T(0); // q <= 64: lane t holds the rotated change of the group's value t (q == 1: every lane)
         if (q == 1) {
             const T gcur = gT[o], bi = bT[o], A = AB[o];
             const T gk = fma(bi, A, gcur);                       // pin_naive:85-89
@@ -253,7 +258,8 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
                 cm = c1 > cm ? c1 : cm;
                 rsq += d * (T(2) * gcur - d * A);
                 rsum -= xmT[o] * d;
-                if (lane == 0) { bT[o] = ak; delT[0] = d; }
+                if (lane == 0) bT[o] = ak;
+                d_reg = d; // the same in every lane
             }
         } else if (q <= 64) {
             const bool on = lane < q;
@@ -269,11 +275,27 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
                 akt_r = on ? gk_r / (A_r + l2p) : T(0);
             } else {
                 const T b1 = A_r + l2p;
-                T h = 0, fh, dfh, b2 = T(0);
-                { // isotropic block: start at the closed-form root (see grp_solve_body)
-                    const T a0 = first_lane(A_r);
-                    const bool iso = __ballot(on && A_r != a0) == 0ull && (a0 + l2p) > T(0);
-                    if (iso) h = (sqrt(nrm2) - l1p) / (a0 + l2p);
+                T h = 0, fh, tt = T(0), sxx = T(0), b2 = T(0);
+                // Start of the root find.  The reference starts at h = 0 (bcd/unconstrained/newton.hpp:137); the secular
+                // function  f(h) = sum v_i^2 / (b_i h + l1)^2 - 1  is convex and decreasing, and
+                //     h_lb = (||v|| - l1) / max_i b_i
+                // has f(h_lb) >= 0 (replace every b_i by the largest), so Newton from h_lb converges monotonically from the
+                // left like from 0, only from much closer — the same root to newton_tol in fewer of the (strictly
+                // sequential) evaluations; an isotropic block (all b_i equal) starts AT its root.  Same stopping test, same
+                // error when newton_tol is unreachable.
+                {
+                    T bmx = on ? b1 : T(0);
+                    if (q <= 16) {
+                        T o1 = dpp_move<0xB1>(bmx); bmx = o1 > bmx ? o1 : bmx;
+                        o1 = dpp_move<0x4E>(bmx); bmx = o1 > bmx ? o1 : bmx;
+                        o1 = dpp_move<0x141>(bmx); bmx = o1 > bmx ? o1 : bmx;
+                        o1 = dpp_move<0x140>(bmx); bmx = o1 > bmx ? o1 : bmx;
+                        bmx = first_lane(bmx);
+                    } else {
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) { const T o1 = __shfl_xor(bmx, off, 64); bmx = o1 > bmx ? o1 : bmx; }
+                    }
+                    if (bmx > T(0)) h = (sqrt(nrm2) - l1p) / bmx;
                 }
                 auto step = [&](T hh) {
                     T t = 0, sx = 0;
@@ -284,15 +306,16 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
                         t = x;
                         sx = x * b1 * b2;
                     }
-                    t = group_sum(t, q);
-                    sx = group_sum(sx, q);
-                    fh = t - T(1);
-                    dfh = -sx * (T(1) + sqrt(t)) / t;
+                    tt = group_sum(t, q);
+                    sxx = group_sum(sx, q);
+                    fh = tt - T(1);
                 };
                 step(h);
                 int iters = 0;
                 while ((fabs(fh) > p.newton_tol) && (iters < p.newton_max_iters)) {
-                    h -= fh / dfh;
+                    // h -= f / f'  with  f' = -sx (1 + sqrt t) / t  (newton.hpp:83-93):  f / f' = -t (sqrt t - 1) / sx, one
+                    // division instead of two on the dependent chain
+                    h += tt * (sqrt(tt) - T(1)) / sxx;
                     h = h > T(0) ? h : T(0);
                     step(h);
                     ++iters;
@@ -319,8 +342,8 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
                 if (on) {
                     xs_acc = fma(xmT[o + lane], d, xs_acc);   // resid_sum -= xbar . del = (xbar V) . del_t   (pin_naive:161-163)
                     bT[o + lane] = akt_r;
-                    delT[lane] = d;
                 }
+                d_reg = d;
             }
         } else {
             const T* A = AB + o;
@@ -397,12 +420,23 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
                 if (lane == 0) { p.is_active[ss] = 1; p.active_set[asz] = ss; }
                 ++asz;
             }
-            // keep the block's rotated gradient current: gT -= D~[:, o:o+q] del_t
-            for (int l = lane; l < GBLK; l += 64) {
-                T acc = gT[l];
+            // keep the rotated gradient of the groups STILL TO COME current: gT[l] -= D~[l, o:o+q] del_t for l >= o + q (the
+            // values before that were visited already and are not read again in this solve).  q <= 64: the changes come out
+            // of the lanes' registers with v_readlane (uniform index), no LDS round trip on the chain.
+            if (q <= 64) {
+                for (int l = o + q + lane; l < nval; l += 64) {
+                    T acc = gT[l];
 #pragma unroll 4
-                for (int t = 0; t < q; ++t) acc = fma(-D[l + (o + t) * GBLK], delT[t], acc);
-                gT[l] = acc;
+                    for (int t = 0; t < q; ++t) acc = fma(-D[l + (o + t) * GBLK], rdl(d_reg, q == 1 ? 0 : t), acc);
+                    gT[l] = acc;
+                }
+            } else {
+                for (int l = o + q + lane; l < nval; l += 64) {
+                    T acc = gT[l];
+#pragma unroll 4
+                    for (int t = 0; t < q; ++t) acc = fma(-D[l + (o + t) * GBLK], delT[t], acc);
+                    gT[l] = acc;
+                }
             }
             __builtin_amdgcn_wave_barrier();
             ++n_upd;

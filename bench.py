@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--no-cv-leg", action="store_true", help="skip the cv_config5 object of the default line")
     ap.add_argument("--cpu-budget-s", type=float, default=None)
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-1thread-budget-s", type=float, default=12.0, help="config 2: extra CPU leg with one thread (0: skip)")
     args = ap.parse_args()
     cfg = args.config
     if args.steps is None:
@@ -444,7 +445,21 @@ def cpu_baseline(cfg, args, keep, y, glm, kw, cv_kw, npdtype, gpu_last, Xd, n, p
             value = (k / L) / el
             sample = (f"first {k} of {L} lambdas of the same path on the same data (time budget {budget:.0f} s), {cores} OpenMP "
                       f"threads; value = (solved fraction)/time, an UPPER bound on the CPU paths/s: later lambdas cost more")
-        return dict(base, value=value, sample=sample, seconds=el, lambdas_solved=k, max_abs_dbeta_vs_gpu=db)
+        out = dict(base, value=value, sample=sample, seconds=el, lambdas_solved=k, max_abs_dbeta_vs_gpu=db)
+        if cfg == 2 and args.cpu_1thread_budget_s > 0:
+            # the reference documents that one thread is often the fastest setting for this solver (parallelism.ipynb cell 18):
+            # the same path with n_threads = 1, on its own (shorter) budget
+            os.environ["ORACLE_COL_THREADS"] = "1"
+            b1 = args.cpu_1thread_budget_s
+            t0 = time.perf_counter()
+            st1 = ad.grpnet(oracle.dense(Xh, n_threads=1), glm, n_threads=1,
+                            exit_cond=lambda s: (time.perf_counter() - t0) > b1, **kw)
+            e1 = time.perf_counter() - t0
+            k1 = len(st1.lmdas)
+            out["one_thread"] = {"value": (k1 / L) / e1, "unit": "paths/s", "cores": 1, "seconds": e1, "lambdas_solved": k1,
+                                 "sample": f"first {k1} of {L} lambdas in a {b1:.0f} s budget, 1 thread; (solved fraction)/time, "
+                                           f"an upper bound on the 1-thread paths/s"}
+        return out
 
     if cfg == 4:
         # The oracle keeps the calldata as int8 on the host (25 GB at 500k x 50k) and its early lambdas are sweep-bound; the

@@ -85,38 +85,74 @@ void launch_cd_group_block_pass(const CdGrpBlkParams<T>& p, hipStream_t s) {
     }
 }
 
-// D <- R^T D R, R = blockdiag(V_k).  Groups of at most 16 values (the usual case): both passes run IN PLACE on the copy of the
-// block in LDS — pass 1 a work item = (row l, group k): the q entries D[l, o:o+q] into registers, q outputs back; pass 2 a
-// work item = (group k, column c) likewise on T[o:o+q, c] — and the result is written out once, coalesced.  No global memory on
-// the dependent loops (a first version that kept T = D R in a global scratch took 110 us per block: one L2 round trip per inner
-// iteration).  Blocks with a wider group take that path (`scratch`, 128 * 128 elements private to the stream).
+// D <- R^T D R, R = blockdiag(V_k).  ONE workgroup of 1024 threads per block.  Groups of at most 16 values (the usual case): the
+// block is copied into LDS with 16-byte loads, eight in flight per thread (leading dimension 129: both passes below are then
+// free of bank conflicts — pass 1 walks down a column across the lanes, pass 2 along a row), the eigenbases of its groups next
+// to it, and both passes run IN PLACE — pass 1 a work item = (row l, group k): the q entries D[l, o:o+q] into registers, q
+// outputs back; pass 2 a work item = (group k, column c) likewise on T[o:o+q, c] — before the result is written out once,
+// coalesced.  No global memory on the dependent loops (a first version that kept T = D R in a global scratch took 110 us per
+// block: one L2 round trip per inner iteration; the second, 256 threads with scalar copies and an LDS stride of 128, 81 us in
+// the path).  Blocks with a wider group take the scratch path (128 * 128 elements private to the stream).
+constexpr int GROT_LD = GBLK + 1, GROT_NT = 1024, GROT_QM = 16;
 template <class T>
-__global__ __launch_bounds__(256) void grp_block_rotate_kernel(T* __restrict__ Dptr, const T* __restrict__ V, GrpRotArgs a,
-                                                               T* __restrict__ scratch) {
+constexpr size_t grp_rotate_lds() { return (size_t(GBLK) * GROT_LD + size_t(GROT_QM) * GBLK) * sizeof(T); }
+
+template <class T>
+__global__ __launch_bounds__(GROT_NT) void grp_block_rotate_kernel(T* __restrict__ Dptr, const T* __restrict__ V, GrpRotArgs a,
+                                                                   T* __restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    typedef T vec2 __attribute__((ext_vector_type(2)));
+    constexpr int LD = GROT_LD, QM = GROT_QM, NT = GROT_NT;
     T* D = reinterpret_cast<T*>(smem_raw);
+    T* Vl = D + size_t(GBLK) * LD; // eigenbasis of group k at Vl + 16 * goff[k]  (q*q <= 16*q)
     __shared__ int32_t vgrp[GBLK];
     __shared__ int32_t wide;
     const int tid = threadIdx.x;
     const int nval = a.goff[a.ng];
     if (tid == 0) wide = 0;
     __syncthreads();
-    for (int k = tid; k < a.ng; k += 256) {
+    for (int k = tid; k < a.ng; k += NT) {
         for (int i = a.goff[k]; i < a.goff[k + 1]; ++i) vgrp[i] = k;
-        if (a.goff[k + 1] - a.goff[k] > 16) wide = 1;
+        if (a.goff[k + 1] - a.goff[k] > QM) wide = 1;
     }
-    for (int e = tid; e < nval * GBLK; e += 256) D[e] = Dptr[e];
+    {   // all rows of the first nval columns, two values per load
+        const int tot2 = nval * (GBLK / 2);
+        constexpr int U = 8;
+        const vec2* src = reinterpret_cast<const vec2*>(Dptr);
+        for (int e0 = tid; e0 < tot2; e0 += NT * U) {
+            vec2 tmp[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * NT;
+                tmp[u] = e < tot2 ? src[e] : vec2{T(0), T(0)};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * NT;
+                if (e < tot2) {
+                    const int c = e / (GBLK / 2), r = (e % (GBLK / 2)) * 2;
+                    D[r + c * LD] = tmp[u].x;
+                    D[r + 1 + c * LD] = tmp[u].y;
+                }
+            }
+        }
+    }
     __syncthreads();
     if (!wide) {
-        constexpr int QM = 16;
-        for (int it = tid; it < nval * a.ng; it += 256) { // T[l, o + t] = sum_u D[l, o + u] V[u, t]
+        for (int k = tid / 64; k < a.ng; k += NT / 64) {
+            const int o = a.goff[k], q = a.goff[k + 1] - o;
+            if (q == 1) continue;
+            for (int i = tid % 64; i < q * q; i += 64) Vl[QM * o + i] = V[a.voff[k] + i];
+        }
+        __syncthreads();
+        for (int it = tid; it < nval * a.ng; it += NT) { // T[l, o + t] = sum_u D[l, o + u] V[u, t]
             const int l = it % nval, k = it / nval;
             const int o = a.goff[k], q = a.goff[k + 1] - o;
             if (q == 1) continue;
-            const T* Vk = V + a.voff[k];
+            const T* Vk = Vl + QM * o;
             T x[QM], y[QM];
 #pragma unroll
-            for (int u = 0; u < QM; ++u) x[u] = u < q ? D[l + (o + u) * GBLK] : T(0);
+            for (int u = 0; u < QM; ++u) x[u] = u < q ? D[l + (o + u) * LD] : T(0);
 #pragma unroll
             for (int t = 0; t < QM; ++t) {
                 T sacc = T(0);
@@ -129,17 +165,17 @@ __global__ __launch_bounds__(256) void grp_block_rotate_kernel(T* __restrict__ D
             }
 #pragma unroll
             for (int t = 0; t < QM; ++t)
-                if (t < q) D[l + (o + t) * GBLK] = y[t];
+                if (t < q) D[l + (o + t) * LD] = y[t];
         }
         __syncthreads();
-        for (int it = tid; it < nval * a.ng; it += 256) { // D~[o + s, c] = sum_u V[u, s] T[o + u, c]
+        for (int it = tid; it < nval * a.ng; it += NT) { // D~[o + s, c] = sum_u V[u, s] T[o + u, c]
             const int c = it % nval, k = it / nval;
             const int o = a.goff[k], q = a.goff[k + 1] - o;
             if (q == 1) continue;
-            const T* Vk = V + a.voff[k];
+            const T* Vk = Vl + QM * o;
             T x[QM], y[QM];
 #pragma unroll
-            for (int u = 0; u < QM; ++u) x[u] = u < q ? D[(o + u) + c * GBLK] : T(0);
+            for (int u = 0; u < QM; ++u) x[u] = u < q ? D[(o + u) + c * LD] : T(0);
 #pragma unroll
             for (int sI = 0; sI < QM; ++sI) {
                 T sacc = T(0);
@@ -152,29 +188,34 @@ __global__ __launch_bounds__(256) void grp_block_rotate_kernel(T* __restrict__ D
             }
 #pragma unroll
             for (int sI = 0; sI < QM; ++sI)
-                if (sI < q) D[(o + sI) + c * GBLK] = y[sI];
+                if (sI < q) D[(o + sI) + c * LD] = y[sI];
         }
         __syncthreads();
-        for (int e = tid; e < nval * GBLK; e += 256)
-            if ((e % GBLK) < nval) Dptr[e] = D[e];
+        // rows [0, nval) in pairs (a pair may reach row nval, which still holds the value loaded above)
+        const int rp = (nval + 1) / 2, tot2 = nval * rp;
+        vec2* dst = reinterpret_cast<vec2*>(Dptr);
+        for (int e = tid; e < tot2; e += NT) {
+            const int c = e / rp, r = (e % rp) * 2;
+            dst[(r + c * GBLK) / 2] = vec2{D[r + c * LD], D[r + 1 + c * LD]};
+        }
         return;
     }
-    for (int e = tid; e < nval * nval; e += 256) { // T[l, c] = sum_u D[l, o + u] V[u, t],  c = o + t
+    for (int e = tid; e < nval * nval; e += NT) { // T[l, c] = sum_u D[l, o + u] V[u, t],  c = o + t
         const int l = e % nval, c = e / nval;
         const int k = vgrp[c], o = a.goff[k], q = a.goff[k + 1] - o;
         T s;
         if (q == 1) {
-            s = D[l + c * GBLK];
+            s = D[l + c * LD];
         } else {
             const T* Vt = V + a.voff[k] + int64_t(c - o) * q;
             s = T(0);
-            for (int u = 0; u < q; ++u) s = fma(D[l + (o + u) * GBLK], Vt[u], s);
+            for (int u = 0; u < q; ++u) s = fma(D[l + (o + u) * LD], Vt[u], s);
         }
         scratch[l + c * GBLK] = s;
     }
     __threadfence_block();
     __syncthreads();
-    for (int e = tid; e < nval * nval; e += 256) { // D~[r, c] = sum_u V[u, s] T[o + u, c],  r = o + s
+    for (int e = tid; e < nval * nval; e += NT) { // D~[r, c] = sum_u V[u, s] T[o + u, c],  r = o + s
         const int r = e % nval, c = e / nval;
         const int k = vgrp[r], o = a.goff[k], q = a.goff[k + 1] - o;
         T s;
@@ -195,12 +236,12 @@ void launch_grp_block_rotate(T* Dptr, const T* V, const GrpRotArgs& a, T* scratc
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grp_block_rotate_kernel<double>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(GBLK * GBLK * sizeof(double)));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_rotate_lds<double>()));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grp_block_rotate_kernel<float>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(GBLK * GBLK * sizeof(float)));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_rotate_lds<float>()));
         attr_done = true;
     }
-    hipLaunchKernelGGL((grp_block_rotate_kernel<T>), dim3(1), dim3(256), size_t(GBLK) * GBLK * sizeof(T), s, Dptr, V, a, scratch);
+    hipLaunchKernelGGL((grp_block_rotate_kernel<T>), dim3(1), dim3(GROT_NT), grp_rotate_lds<T>(), s, Dptr, V, a, scratch);
 }
 template void launch_grp_block_rotate<double>(double*, const double*, const GrpRotArgs&, double*, hipStream_t);
 template void launch_grp_block_rotate<float>(float*, const float*, const GrpRotArgs&, float*, hipStream_t);

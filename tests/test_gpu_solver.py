@@ -385,3 +385,36 @@ def test_exit_cond_on_panel_engine(hip, monkeypatch):
     st = ad.grpnet(ad.matrix.dense(d["X"]), ad.glm.gaussian(d["y"]), early_exit=False, lmda_path_size=30,
                    exit_cond=lambda s: s.n_solutions >= 9)
     assert st.error == "" and len(st.lmdas) == 9 and st.counters["n_panel_blocks"] > 0
+
+
+@pytest.mark.parametrize("hook,values", [("ADELIE_HIP_BATCH_BLOCKS", ["1", "3", "16"]), ("ADELIE_HIP_PREBUILD", ["0", "1"]),
+                                         ("ADELIE_HIP_GROUP_ROT", ["0", "1"]), ("ADELIE_HIP_FUSE_REDUCE", ["0", "1"]),
+                                         ("ADELIE_HIP_SIDE_WGS", ["0", "24"])])
+def test_round2_engine_hooks_do_not_change_results(hip, oracle, monkeypatch, hook, values):
+    """The build / solve variants added in round 2 (batched diagonal-block builds, IRLS screen-block prebuild, group solve in
+    eigen-coordinates, reduce fused into the solve, confined side builds) are scheduling / association changes only: every
+    setting gives the oracle's path on a lasso, a grouped and a binomial problem whose screen sets span several blocks of
+    different tile classes."""
+    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    rng = np.random.RandomState(11)
+    n, p = 700, 330
+    d = make_gaussian(n, p, seed=11, sparsity=0.5)
+    groups = np.concatenate([[0, 1, 2], np.arange(3, 300, 9), [300, 301, 320]])   # sizes 1,1,1, 9 x 33, 1, 19, 10
+    yb = (rng.uniform(size=n) < 1 / (1 + np.exp(-d["X"][:, :5] @ np.ones(5)))).astype(float)
+    cases = [
+        (lambda: ad.glm.gaussian(d["y"]), dict(early_exit=False, lmda_path_size=12, min_ratio=0.02, tol=1e-12)),
+        (lambda: ad.glm.gaussian(d["y"]), dict(groups=groups, alpha=0.6, early_exit=False, lmda_path_size=12, min_ratio=0.02,
+                                              tol=1e-12)),
+        (lambda: ad.glm.binomial(yb), dict(early_exit=False, lmda_path_size=10, min_ratio=0.05, tol=1e-12, irls_tol=1e-11)),
+    ]
+    for mk, kw in cases:
+        ref = ad.grpnet(oracle.dense(d["X"]), mk(), progress_bar=False, **kw)
+        for v in values:
+            monkeypatch.setenv(hook, v)
+            st = ad.grpnet(ad.matrix.dense(d["X"]), mk(), progress_bar=False, **kw)
+            assert st.error == "" and len(st.lmdas) == len(ref.lmdas)
+            assert st.counters["n_panel_blocks"] > 0
+            # the design is strongly collinear (p / n ~ 0.5, path down to 2 % of lambda_max): two correct runs may stop one
+            # pass apart, which is worth ~1e-7 in beta at this tol; a wrong block shows up at 1e-3 and above
+            assert np.abs(st.betas.toarray() - ref.betas.toarray()).max() < 1e-6, (hook, v)
+            assert np.abs(st.intercepts - ref.intercepts).max() < 1e-6

@@ -6,6 +6,7 @@ Mirrors the user-facing surface of JamesYang007/adelie for the ``grpnet`` hot pa
 kernels for gfx950 behind the C ABI declared in ``include/adelie_hip.h``.
 """
 from . import configs
+from . import constraint
 from . import glm
 from . import matrix
 from . import state

@@ -95,6 +95,10 @@ class GrpnetArgs(C.Structure):
         ("glm_cb", C.POINTER(GlmCallbacks)),
         ("cov_v", C.c_void_p),
         ("rdev_tol", C.c_double),
+        ("constraint_kind", C.c_void_p),
+        ("constraint_a", C.c_void_p),
+        ("constraint_b", C.c_void_p),
+        ("constraint_mu", C.c_void_p),
     ]
 
 
@@ -104,11 +108,12 @@ V = dict(
     screen_X_means=9, screen_vars=10, screen_transforms=11,
     benchmark_screen=12, benchmark_fit_screen=13, benchmark_fit_active=14, benchmark_kkt=15,
     benchmark_invariance=16,
-    betas_values=200,
+    betas_values=200, duals_values=201, constraint_mu=202,
 )
 I = dict(
     screen_set=100, screen_begins=101, screen_is_active=102, active_set=103, n_valid_solutions=104,
     active_sizes=105, screen_sizes=106, betas_indptr=107, betas_indices=108,
+    duals_indptr=109, duals_indices=110,
 )
 S = dict(
     lmda_max=0, lmda=1, rsq=2, resid_sum=3, active_set_size=4, beta0=5, loss_null=6, loss_full=7,

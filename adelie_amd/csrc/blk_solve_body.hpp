@@ -48,7 +48,12 @@ __device__ __forceinline__ void blk_part_sum(const CdBlkParams<T>& p, int nb, T*
     gsum8[k0 * BLK + c] = acc;
 }
 
-template <class T, bool NAIVE>
+// CONS: one-coefficient box constraints lo_i <= beta_i <= hi_i (CdBlkParams::clo / chi / cmu; ConstraintBox::solve_1d,
+// constraint_box.ipp:51-96, and ConstraintOneSided, constraint_one_sided.ipp:12-49, whose solution is the box form with one
+// side at infinity).  The minimiser of the one-dimensional problem over an interval is the unconstrained one clipped to it,
+// so a visit only gains a min/max; the multiplier  mu = mu_+ - mu_-  of every visited coordinate is computed after the loop,
+// lane-parallel, from the gradient its visit saw — the same quantities the reference's solve_1d leaves in the object.
+template <class T, bool NAIVE, bool CONS = false>
 __device__ __forceinline__ void blk_solve_body(const CdBlkParams<T>& p, int j, char* smem_raw, int tid,
                                                const T* corr = nullptr, int ncorr = 0, const T* gsum8 = nullptr) {
     T* D = reinterpret_cast<T*>(smem_raw);   // BLK*BLK
@@ -169,9 +174,16 @@ __device__ __forceinline__ void blk_solve_body(const CdBlkParams<T>& p, int j, c
     const T R0 = rdenB[lane], R1 = rdenB[lane + 64];
     const T X0 = xmB[lane], X1 = xmB[lane + 64];
     const int a0 = actB[lane], a1 = actB[lane + 64];
+    // CONS: bounds of this lane's two coordinates (+-inf where there is none; lanes beyond nb never visit)
+    const T INF = T(1) / T(0);
+    T lo0 = -INF, lo1 = -INF, hi0 = INF, hi1 = INF;
+    if (CONS) {
+        if (lane < nb) { lo0 = p.clo[idxB[lane]]; hi0 = p.chi[idxB[lane]]; }
+        if (lane + 64 < nb) { lo1 = p.clo[idxB[lane + 64]]; hi1 = p.chi[idxB[lane + 64]]; }
+    }
     T nb0 = b0, nb1 = b1; // new coefficients of this lane's two coordinates
     T gc0 = T(0), gc1 = T(0); // gradient seen by the visit of this lane's coordinates (only meaningful if they changed)
-#define AHIP_BLK_VISIT(GREG, BREG, AREG, LREG, NREG, RREG, NBREG, GCREG, IL)                                          \
+#define AHIP_BLK_VISIT(GREG, BREG, AREG, LREG, NREG, RREG, NBREG, GCREG, LOREG, HIREG, IL)                            \
     {                                                                                                                  \
         const T dc0 = D[i * BLK + lane], dc1 = D[i * BLK + lane + 64]; /* off the dependent chain: issued first */  \
         const T gcur = rdlane(GREG, IL);                                                                           \
@@ -186,6 +198,10 @@ __device__ __forceinline__ void blk_solve_body(const CdBlkParams<T>& p, int j, c
             const T r = fma(-q0, den, x);                                                                              \
             ak = fma(r, rden, q0);                                                                                     \
         }                                                                                                              \
+        if (CONS) {                                       /* constraint_box.ipp:75-80: clip to [lo, hi] */           \
+            ak = fmax(fmin(ak, rdlane(HIREG, IL)), rdlane(LOREG, IL));                                         \
+            if (lane == (IL)) GCREG = gcur;               /* the multiplier needs it for unchanged coordinates too */ \
+        }                                                                                                              \
         if (ak != bi) {                                   /* pin_naive:97 */                                          \
             const T del = ak - bi;                                                                                     \
             g0 = fma(-del, dc0, g0);                                                                                   \
@@ -195,10 +211,26 @@ __device__ __forceinline__ void blk_solve_body(const CdBlkParams<T>& p, int j, c
     }
     {
         const int n0 = nb < 64 ? nb : 64;
-        for (int i = 0; i < n0; ++i) AHIP_BLK_VISIT(g0, b0, A0, L0, N0, R0, nb0, gc0, i)
-        for (int i = 64; i < nb; ++i) AHIP_BLK_VISIT(g1, b1, A1, L1, N1, R1, nb1, gc1, i - 64)
+        for (int i = 0; i < n0; ++i) AHIP_BLK_VISIT(g0, b0, A0, L0, N0, R0, nb0, gc0, lo0, hi0, i)
+        for (int i = 64; i < nb; ++i) AHIP_BLK_VISIT(g1, b1, A1, L1, N1, R1, nb1, gc1, lo1, hi1, i - 64)
     }
 #undef AHIP_BLK_VISIT
+    if (CONS) {
+        // multipliers (constraint_box.ipp:66-95 with A = Q(0,0) = 1): v = gradient seen + beta_old * A_kk (pin_naive:85-89)
+        auto multiplier = [&](T gc, T bold, T A, T l1, T den, T x0, T lo, T hi) -> T {
+            const T v = fma(bold, A, gc);
+            const T mp0 = (hi > T(0)) ? T(0) : fmax(v, T(0));
+            const T mn0 = (lo < T(0)) ? T(0) : fmax(-v, T(0));
+            if (fabs(v - (mp0 - mn0)) <= l1) return mp0 - mn0;         // x = 0 is optimal
+            const T full = v - (den * x0 + copysign(l1, x0));
+            const T mp = (x0 < hi) ? T(0) : fmax(full, T(0));
+            const T mn = (x0 > lo) ? T(0) : fmax(-full, T(0));
+            return mp - mn;
+        };
+        if (lane < nb && (lo0 != -INF || hi0 != INF)) p.cmu[idxB[lane]] = multiplier(gc0, b0, A0, L0, N0, nb0, lo0, hi0);
+        if (lane + 64 < nb && (lo1 != -INF || hi1 != INF))
+            p.cmu[idxB[lane + 64]] = multiplier(gc1, b1, A1, L1, N1, nb1, lo1, hi1);
+    }
     // ---- bookkeeping of the block, lane-parallel --------------------------------------------------------------------
     {
         const T d0 = nb0 - b0, d1 = nb1 - b1; // lanes beyond nb hold b = nb = 0

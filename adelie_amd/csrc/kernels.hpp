@@ -96,6 +96,12 @@ int64_t syrk_work_elems(int64_t n, int64_t M);
 template <class T>
 void launch_abs_grad(const T* grad, const int64_t* groups, const int64_t* group_sizes, int64_t G, const int32_t* slot,
                      const T* screen_beta, const T* penalty, T one_minus_alpha_lmda, T* abs_grad, hipStream_t s);
+// the same when every group has one coefficient and some carry box constraints clo[g] <= beta <= chi[g] (+-inf: none); cmu: the
+// multipliers of the screen values, mu_out (G,): every group's multiplier afterwards
+template <class T>
+void launch_abs_grad_cons(const T* grad, const int64_t* groups, int64_t G, const int32_t* slot, const T* screen_beta,
+                          const T* penalty, T one_minus_alpha_lmda, const T* clo, const T* chi, const T* cmu, T* abs_grad,
+                          T* mu_out, hipStream_t s);
 
 // ---- coordinate descent (pin solver) ----------------------------------------------------------
 enum CdStatus : int32_t { CD_OK = 0, CD_MAX_CDS = 1, CD_MAX_ACTIVE = 2, CD_NEWTON = 3 };
@@ -200,6 +206,11 @@ struct CdBlkParams {
     int64_t part_ld;
     int32_t part_n;
     const T* part_rsum; // nullptr: no intercept term
+    // one-coefficient constraints (blk_solve_body<.., CONS = true>): bounds per screen value (-inf / +inf where there is none)
+    // and, out, the multiplier mu_+ - mu_- of every constrained coordinate the block visited
+    const T* clo;
+    const T* chi;
+    T* cmu;
 };
 // group (q > 1) variant: a block = consecutive groups of the visiting list with <= 128 values in total
 template <class T>

@@ -47,6 +47,13 @@ __global__ __launch_bounds__(256) void blk_solve_kernel(CdBlkParams<T> p, int j)
     blk_solve_body<T, NAIVE>(p, j, smem_raw, threadIdx.x);
 }
 
+// the panel solve with one-coefficient box constraints (CdBlkParams::clo / chi / cmu)
+template <class T>
+__global__ __launch_bounds__(256) void blk_solve_cons_kernel(CdBlkParams<T> p, int j) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    blk_solve_body<T, true, true>(p, j, smem_raw, threadIdx.x);
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void blk_update_kernel(CdBlkParams<T> p, int j) {
     __shared__ T red[4][64];
@@ -140,6 +147,18 @@ void launch_cd_panel_solve(const CdBlkParams<T>& p, int j, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk_solve_kernel<float, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(blk_solve_lds<float>()));
         attr_done = true;
+    }
+    if (p.clo != nullptr) {
+        static bool cons_attr_done = false;
+        if (!cons_attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk_solve_cons_kernel<double>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(blk_solve_lds<double>()));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk_solve_cons_kernel<float>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(blk_solve_lds<float>()));
+            cons_attr_done = true;
+        }
+        hipLaunchKernelGGL((blk_solve_cons_kernel<T>), dim3(1), dim3(256), blk_solve_lds<T>(), s, p, j);
+        return;
     }
     hipLaunchKernelGGL((blk_solve_kernel<T, true>), dim3(1), dim3(256), blk_solve_lds<T>(), s, p, j);
 }

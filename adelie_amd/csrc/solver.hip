@@ -352,6 +352,19 @@ struct Solver {
     bool cov_mode = false;
     T rdev_tol = 0;
     DevBuf<T> d_covv, d_zero;
+    // one-coefficient constraints (args constraint_*; ConstraintBox / ConstraintOneSided, adelie_core/constraint/): the host
+    // keeps them as passed (kind, a, b) for the dual's convention, the device sees the unified form lo <= beta <= hi with
+    // lo <= 0 <= hi (+-inf where there is no bound) and the signed multiplier mu_+ - mu_- (the term the constraint adds to
+    // the coordinate's gradient; a one-sided constraint's dual is sgn times it)
+    bool cons_on = false;
+    std::vector<int32_t> cons_kind;
+    std::vector<T> cons_a, cons_lo, cons_hi, cons_mu; // (G,)
+    std::vector<idx> dual_groups;
+    DevBuf<T> d_clo, d_chi, d_cmu;                    // per screen value
+    DevBuf<T> d_clo_g, d_chi_g, d_mu_g;               // per group (abs_grad of groups outside the screen set: solve_zero)
+    std::vector<std::vector<idx>> duals_idx;
+    std::vector<std::vector<T>> duals_val;
+    T cons_dual_of(idx g) const { return cons_kind[g] == 2 ? cons_a[g] * cons_mu[g] : cons_mu[g]; }
     adelie_hip_glm_callbacks glm_cb{};       // glm_kind == CALLBACK: the user's GlmBase subclass, evaluated on the host
     std::vector<T> cb_eta, cb_grad, cb_hess, cb_z;
     idx max_gs = 1;
@@ -804,6 +817,10 @@ struct Solver {
         for (size_t ss = 0; ss < screen_set.size(); ++ss) {
             const idx i = screen_set[ss], b = screen_begins[ss], k = groups[i], sz = group_sizes[i];
             const T regul = ((1 - alpha) * lm) * penalty[i];
+            if (cons_on && cons_kind[i]) { // :69-75: minus the constraint's gradient
+                abs_grad[i] = std::abs(grad[k] - regul * screen_beta[b] - cons_mu[i]);
+                continue;
+            }
             T acc = 0;
             for (idx t = 0; t < sz; ++t) {
                 const T e = grad[k + t] - regul * screen_beta[b + t];
@@ -814,10 +831,30 @@ struct Solver {
         for (idx i = 0; i < G; ++i) {
             if (is_screen(i)) continue;
             const idx k = groups[i];
+            if (cons_on && cons_kind[i]) { // :88-93 solve_zero (constraint_box.ipp:268-284, constraint_one_sided.ipp:269-279)
+                const T M = T(1e100), v = grad[k];
+                cons_mu[i] = std::min(std::max(v, cons_lo[i] >= 0 ? -M : T(0)), cons_hi[i] <= 0 ? M : T(0));
+                abs_grad[i] = std::abs(v - cons_mu[i]);
+                continue;
+            }
             T acc = 0;
             for (idx t = 0; t < group_sizes[i]; ++t) acc += grad[k + t] * grad[k + t];
             abs_grad[i] = std::sqrt(acc);
         }
+    }
+
+    // update_abs_grad on the device (solver_base.hpp:20-110) + the copy the host screens / checks KKT with; under constraints
+    // also every group's multiplier (screened: from its last visit; others: solve_zero)
+    void device_abs_grad(T lm) {
+        if (cons_on) {
+            launch_abs_grad_cons<T>(d_grad.p, d_groups.p, G, d_slot.p, d_beta.p, d_penalty.p, (1 - alpha) * lm, d_clo_g.p,
+                                    d_chi_g.p, d_cmu.p, d_absgrad.p, d_mu_g.p, st);
+            d_mu_g.download(cons_mu.data(), size_t(G), st);
+        } else {
+            launch_abs_grad<T>(d_grad.p, d_groups.p, d_gsizes.p, G, d_slot.p, d_beta.p, d_penalty.p, (1 - alpha) * lm,
+                               d_absgrad.p, st);
+        }
+        d_absgrad.download(abs_grad.data(), size_t(G), st);
     }
 
     // solver_base.hpp:120-153
@@ -865,6 +902,18 @@ struct Solver {
         d_ssize.upload(ssize.data(), ssize.size(), st, ns_dev);
         d_spen.upload(spen.data(), spen.size(), st, ns_dev);
         d_isact.upload(isact.data(), isact.size(), st, ns_dev);
+        std::vector<T> clo_new, chi_new, cmu_new; // all groups have one coefficient here: screen value = screen group
+        if (cons_on) {
+            for (idx ss = ns_dev; ss < ns; ++ss) {
+                const idx g = screen_set[ss];
+                clo_new.push_back(cons_lo[g]);
+                chi_new.push_back(cons_hi[g]);
+                cmu_new.push_back(cons_mu[g]);
+            }
+            d_clo.upload(clo_new.data(), clo_new.size(), st, nv_old);
+            d_chi.upload(chi_new.data(), chi_new.size(), st, nv_old);
+            d_cmu.upload(cmu_new.data(), cmu_new.size(), st, nv_old);
+        }
         // slots: group -> value offset (whole table re-uploaded: G * 4 bytes)
         if (slot_host.size() != size_t(G)) slot_host.assign(G, -1);
         for (idx ss = ns_dev; ss < ns; ++ss) slot_host[screen_set[ss]] = int32_t(screen_begins[ss]);
@@ -1432,6 +1481,7 @@ struct Solver {
         bp.max_active_size = cp.max_active_size;
         bp.dlt = d_dlt.p; bp.st = d_blk.p;
         bp.gblk = d_gblk.p; bp.vcol = cp.vcol; bp.dcol = d_dcolblk.p;
+        if (cons_on) { bp.clo = d_clo.p; bp.chi = d_chi.p; bp.cmu = d_cmu.p; } // -> blk_solve_cons_kernel
         bp.bsz = B;
         bp.host_st = rep_st_dev; bp.host_seq = rep_seq_dev; bp.report_j = -1; bp.report_seq = 0;
         const T* xm_c = intercept ? cur_xm : nullptr;
@@ -2121,9 +2171,7 @@ struct Solver {
                 t_sweep.begin(st);
                 sweep(d_v.p, d_grad.p, nullptr, p, &d_blk.p->resid_sum, intercept ? d_xm.p : nullptr);
                 t_sweep.end(st);
-                launch_abs_grad<T>(d_grad.p, d_groups.p, d_gsizes.p, G, d_slot.p, d_beta.p, d_penalty.p, (1 - alpha) * lm,
-                                   d_absgrad.p, st);
-                d_absgrad.download(abs_grad.data(), size_t(G), st);
+                device_abs_grad(lm);
                 inv_prelaunched = true;
                 inv_prelaunched_lm = lm;
             }
@@ -2551,9 +2599,7 @@ struct Solver {
             t_sweep.end(st);
             grad_valid = true;
         }
-        launch_abs_grad<T>(d_grad.p, d_groups.p, d_gsizes.p, G, d_slot.p, d_beta.p, d_penalty.p, (1 - alpha) * lm,
-                           d_absgrad.p, st);
-        d_absgrad.download(abs_grad.data(), size_t(G), st);
+        device_abs_grad(lm);
         sync();
     }
 
@@ -2562,6 +2608,18 @@ struct Solver {
         betas_val.emplace_back(std::move(fo.beta_val));
         intercepts.push_back(fo.intercept);
         lmdas.push_back(lm);
+        if (cons_on) { // sparsify_dual, solver_base.hpp:158-222: the non-zero multipliers of every constraint, screened or not
+            refresh_screen_multipliers();
+            std::vector<idx> di;
+            std::vector<T> dv;
+            for (idx g = 0; g < G; ++g)
+                if (cons_kind[g] && cons_mu[g] != 0) { di.push_back(dual_groups[g]); dv.push_back(cons_dual_of(g)); }
+            duals_idx.emplace_back(std::move(di));
+            duals_val.emplace_back(std::move(dv));
+        } else {
+            duals_idx.emplace_back();
+            duals_val.emplace_back();
+        }
         if (cov_mode) { // solver_gaussian_cov.hpp:203-229: the deviance is rsq itself (the saturated loss is unknown)
             devs.push_back(fo.rsq);
         } else if (is_glm()) { // solver_glm_naive.hpp:153-157
@@ -2704,6 +2762,17 @@ struct Solver {
         download_invariants();
     }
 
+    // multipliers of the screened coordinates as their last visits left them (device) -> host mirror
+    std::vector<T> cmu_stage;
+    void refresh_screen_multipliers() {
+        if (!cons_on || nv <= 0) return;
+        cmu_stage.resize(size_t(nv));
+        d_cmu.download(cmu_stage.data(), size_t(nv), st);
+        sync();
+        for (size_t ss = 0; ss < screen_set.size(); ++ss) // one coefficient per group: screen value = screen group
+            if (cons_kind[screen_set[ss]]) cons_mu[screen_set[ss]] = cmu_stage[size_t(screen_begins[ss])];
+    }
+
     // host mirrors of the device-resident invariants (grad, resid, eta, screen_beta, screen_X_means, screen_vars); also what
     // adelie_hip_result_sync does for the live state inside a poll callback
     void download_invariants() {
@@ -2839,6 +2908,60 @@ struct Solver {
             cd_block_min_nv = 0;
         } else if (glm_kind == ADELIE_HIP_GLM_MULTINOMIAL) {
             throw make_core_error("the multinomial family needs a multi-response view as its design.");
+        }
+        if (a->constraint_kind) {
+            bool any = false;
+            for (idx g = 0; g < G; ++g) any = any || a->constraint_kind[g] != 0;
+            if (any) {
+                if (cov_mode) throw make_core_error("constraints are not implemented for the covariance method.");
+                if (multi()) throw make_core_error("constraints are not implemented for multi-response problems.");
+                if (!all_scalar)
+                    throw make_core_error("constraints are implemented for problems whose groups all have one coefficient.");
+                if (!a->constraint_a || !a->constraint_b) throw make_core_error("constraint_a and constraint_b are required.");
+                const T* ca = static_cast<const T*>(a->constraint_a);
+                const T* cb = static_cast<const T*>(a->constraint_b);
+                const T* cm = static_cast<const T*>(a->constraint_mu);
+                const T INF = std::numeric_limits<T>::infinity();
+                cons_on = true;
+                cons_kind.assign(a->constraint_kind, a->constraint_kind + G);
+                cons_a.assign(ca, ca + G);
+                cons_lo.assign(G, -INF);
+                cons_hi.assign(G, INF);
+                cons_mu.assign(G, 0);
+                dual_groups.assign(G, 0);
+                idx nd = 0;
+                for (idx g = 0; g < G; ++g) {
+                    dual_groups[g] = nd;
+                    const int32_t kd = cons_kind[g];
+                    if (!kd) continue;
+                    if (kd == 1) { // constraint_box.ipp:30-37
+                        if (cb[g] < 0) throw make_core_error("upper must be >= 0.");
+                        if (ca[g] > 0) throw make_core_error("lower must be <= 0.");
+                        cons_lo[g] = ca[g];
+                        cons_hi[g] = cb[g];
+                        if (cm) cons_mu[g] = cm[g];
+                    } else if (kd == 2) { // constraint_one_sided.ipp:74-79: sgn * x <= b
+                        if (std::abs(ca[g]) != 1) throw make_core_error("sgn must be a vector of +/-1.");
+                        if (cb[g] < 0) throw make_core_error("b must be >= 0.");
+                        if (ca[g] > 0) cons_hi[g] = cb[g];
+                        else cons_lo[g] = -cb[g];
+                        if (cm) cons_mu[g] = ca[g] * cm[g];
+                    } else {
+                        throw make_core_error("unknown constraint kind.");
+                    }
+                    ++nd;
+                }
+                // the clipped coordinate update lives in the panel solve (blk_solve_body<.., CONS>): that engine from the first
+                // screened coefficient on, in its sequential form
+                engine_panel = true;
+                cd_block_min_nv = 1;
+                lookahead = false;
+                d_clo_g.reserve(G); d_chi_g.reserve(G); d_mu_g.reserve(G);
+                d_clo_g.upload(cons_lo.data(), size_t(G), st);
+                d_chi_g.upload(cons_hi.data(), size_t(G), st);
+                d_mu_g.upload(cons_mu.data(), size_t(G), st);
+                d_clo.reserve(p); d_chi.reserve(p); d_cmu.reserve(p);
+            }
         }
         // device allocations
         d_r.reserve(n); d_v.reserve(n); d_grad.reserve(p); d_absgrad.reserve(G); d_penalty.reserve(G);
@@ -3001,6 +3124,10 @@ struct Result : ResultBase {
             case ADELIE_HIP_I_BETAS_INDPTR: return s.betas_idx.size() + 1;
             case ADELIE_HIP_I_BETAS_INDICES:
             case ADELIE_HIP_V_BETAS_VALUES: { int64_t t = 0; for (auto& v : s.betas_idx) t += v.size(); return t; }
+            case ADELIE_HIP_I_DUALS_INDPTR: return s.duals_idx.size() + 1;
+            case ADELIE_HIP_I_DUALS_INDICES:
+            case ADELIE_HIP_V_DUALS_VALUES: { int64_t t = 0; for (auto& v : s.duals_idx) t += v.size(); return t; }
+            case ADELIE_HIP_V_CONSTRAINT_MU: return s.cons_on ? s.G : 0;
         }
         return -1;
     }
@@ -3052,6 +3179,28 @@ struct Result : ResultBase {
             case ADELIE_HIP_V_BETAS_VALUES: {
                 int64_t k = 0;
                 for (auto& v : s.betas_val) for (auto x : v) { if (k < cap) d[k] = double(x); ++k; }
+                return 0;
+            }
+            case ADELIE_HIP_I_DUALS_INDPTR: {
+                int64_t acc = 0, k = 0;
+                if (k < cap) ii[k] = 0;
+                ++k;
+                for (auto& v : s.duals_idx) { acc += v.size(); if (k < cap) ii[k] = acc; ++k; }
+                return 0;
+            }
+            case ADELIE_HIP_I_DUALS_INDICES: {
+                int64_t k = 0;
+                for (auto& v : s.duals_idx) for (auto x : v) { if (k < cap) ii[k] = x; ++k; }
+                return 0;
+            }
+            case ADELIE_HIP_V_DUALS_VALUES: {
+                int64_t k = 0;
+                for (auto& v : s.duals_val) for (auto x : v) { if (k < cap) d[k] = double(x); ++k; }
+                return 0;
+            }
+            case ADELIE_HIP_V_CONSTRAINT_MU: {
+                if (!s.cons_on) return 0;
+                for (idx g = 0; g < s.G && g < cap; ++g) d[g] = s.cons_kind[g] ? double(s.cons_dual_of(g)) : 0.0;
                 return 0;
             }
         }

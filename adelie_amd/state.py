@@ -16,6 +16,7 @@ import numpy as np
 from scipy.sparse import csr_matrix
 
 from . import _abi
+from . import constraint as _constraint
 from . import glm as _glm
 from . import matrix as _matrix
 
@@ -224,6 +225,18 @@ class base:
         """Hook of the multi-response states: splits the per-class intercepts off the coefficient rows."""
         return betas, intercepts
 
+    _supports_constraints = True
+
+    def _constraint_list(self):
+        """The (G,) list of constraint objects, or None when there is none (reference ``state.py:24-45`` render_constraints:
+        a shorter list is left-padded with None)."""
+        cons = getattr(self, "constraints", None)
+        if cons is None or not any(c is not None for c in cons):
+            return None
+        cons = list(cons)
+        G = len(self.groups)
+        return [None] * (G - len(cons)) + cons if len(cons) < G else cons
+
     _solve_entry = "grpnet_solve"
 
     @staticmethod
@@ -251,7 +264,20 @@ class base:
         p = self._X.cols()
         new.betas = csr_matrix((values, indices, indptr), shape=(len(indptr) - 1, p))
         new.betas, new.intercepts = self._tidy_path(new.betas, new.intercepts)
-        new.duals = csr_matrix((len(indptr) - 1, 0), dtype=dtype)
+        cons = self._constraint_list()
+        if cons is None:
+            new.duals = csr_matrix((len(indptr) - 1, 0), dtype=dtype)
+        else:  # state_base.hpp `duals`: row l = the non-zero multipliers at lmdas[l], column dual_groups[i] for group i
+            dp = backend.result_vec(r, _abi.I["duals_indptr"], index=True)
+            di = backend.result_vec(r, _abi.I["duals_indices"], index=True)
+            dv = backend.result_vec(r, _abi.V["duals_values"]).astype(dtype)
+            new.dual_groups = _constraint.render_dual_groups(cons)
+            n_duals = int(sum(c.dual_size for c in cons if c is not None))
+            new.duals = csr_matrix((dv, di, dp), shape=(len(dp) - 1, n_duals))
+            mu = backend.result_vec(r, _abi.V["constraint_mu"])
+            for c, m in zip(cons, mu):  # the objects are left holding the multipliers of the last fit, as the reference's are
+                if c is not None:
+                    c._mu[0] = m
         sc = lambda nm: backend.fn("result_scalar")(r, _abi.S[nm])
         new.lmda_max = dtype(sc("lmda_max"))
         new.lmda = dtype(sc("lmda"))
@@ -345,6 +371,19 @@ class base:
         keep.append(act)
         a.active_set = act.ctypes.data
         a.lmda = float(self.lmda)
+        cons = self._constraint_list()
+        if cons is not None:  # one-coefficient box / one-sided constraints: (kind, a, b) per group, multipliers held on entry
+            kind = np.zeros(a.G, dtype=np.int32)
+            ca, cb, mu = np.zeros(a.G, dtype=dtype), np.zeros(a.G, dtype=dtype), np.zeros(a.G, dtype=dtype)
+            for i, c in enumerate(cons):
+                if c is not None:
+                    kind[i], ca[i], cb[i] = c._abi()
+                    mu[i] = c._mu[0]
+            keep += [kind, ca, cb, mu]
+            a.constraint_kind = kind.ctypes.data
+            a.constraint_a = ca.ctypes.data
+            a.constraint_b = cb.ctypes.data
+            a.constraint_mu = mu.ctypes.data
 
     def _check_shapes(self):
         G = len(self.groups)
@@ -352,8 +391,26 @@ class base:
             raise RuntimeError("adelie_core: group_sizes must be (G,) where groups is (G,).")
         if len(self.penalty) != G:
             raise RuntimeError("adelie_core: penalty must be (G,) where groups is (G,).")
-        if self.constraints is not None and any(c is not None for c in self.constraints):
-            raise NotImplementedError("adelie_amd: per-group constraints are outside the grpnet hot path (pass None).")
+        cons = self._constraint_list()
+        if cons is not None:
+            if not self._supports_constraints:
+                raise NotImplementedError("adelie_amd: constraints are not implemented for this state (multi-response / covariance method).")
+            if len(cons) != G:
+                raise RuntimeError("adelie_core: constraints must be (G,) where groups is (G,).")
+            seen = set()
+            for c, q in zip(cons, np.asarray(self.group_sizes)):
+                if c is None:
+                    continue
+                if not isinstance(c, _constraint.ConstraintBase):
+                    raise NotImplementedError(
+                        "adelie_amd: constraints must come from adelie_amd.constraint (box / lower / upper / one_sided); "
+                        "user-defined constraint classes are not implemented.")
+                if id(c) in seen:
+                    raise RuntimeError("adelie_core: constraints must contain distinct objects or nullptr.")
+                seen.add(id(c))
+                if c.primal_size != q:
+                    raise RuntimeError("adelie_core: constraint of a group must have the group's size.")
+                c._abi()  # raises for groups of several coefficients
         n, p = self._X.rows(), self._X.cols()
         if len(self.resid) != n:
             raise RuntimeError("adelie_core: resid must be (n,) where X is (n, p).")
@@ -590,6 +647,8 @@ class multigaussian_naive_base(gaussian_naive_base):
     off on the expanded design ``[1 (x) I_K, X (x) I_K]``; the per-response intercepts are its first ``K`` (unpenalised)
     coefficients and are split off every solution (``solver_multigaussian_naive.hpp:31-44``, ``py_state.cpp:1352-1366``)."""
 
+    _supports_constraints = False
+
     def _tidy_path(self, betas, intercepts):
         return _split_class_intercepts(self, betas)
 
@@ -692,6 +751,8 @@ class multiglm_naive_base(glm_naive_base):
         a.glm_y = y.ctypes.data
         a.glm_weights = w.ctypes.data
         return a, keep
+
+    _supports_constraints = False
 
     def _tidy_path(self, betas, intercepts):
         return _split_class_intercepts(self, betas)
@@ -831,6 +892,7 @@ class gaussian_cov_base(base):
     """Gaussian, covariance method state (reference ``state.py:1128-1418``; core ``state_gaussian_cov.hpp:40-145``)."""
 
     _solve_entry = "gaussian_cov_solve"
+    _supports_constraints = False
 
     @staticmethod
     def _progress(devs):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADELIE_HIP_ABI_VERSION 2
+#define ADELIE_HIP_ABI_VERSION 3
 
 enum adelie_hip_dtype { ADELIE_HIP_F32 = 0, ADELIE_HIP_F64 = 1 };
 enum adelie_hip_order { ADELIE_HIP_COL_MAJOR = 0, ADELIE_HIP_ROW_MAJOR = 1 };
@@ -286,6 +286,18 @@ typedef struct adelie_hip_grpnet_args {
     /* ---- covariance method (adelie_hip_gaussian_cov_solve only) ---- */
     const void*    cov_v;             /* (p,) value_t: the linear term v of 1/2 b'Ab - v'b */
     double         rdev_tol;          /* early exit on the relative change of the deviance (solver_gaussian_cov.hpp:183-201) */
+    /* ---- per-group constraints (`constraints` of StateBase, state_base.hpp:60; adelie_core/constraint/) ----
+     * Offered for groups of ONE value, where ConstraintBox / ConstraintOneSided have closed forms (constraint_box.ipp:51-96,
+     * constraint_one_sided.ipp:12-49); a constrained group of more than one value (their proximal-Newton solvers), a linear
+     * constraint, or constraints on a multi-response view / the covariance method are refused with an error string.
+     *   kind 0: unconstrained;
+     *   kind 1: box        constraint_a[i] <= beta_i <= constraint_b[i]   (a <= 0 <= b, infinities allowed); dual = mu_+ - mu_-
+     *   kind 2: one-sided  constraint_a[i] * beta_i <= constraint_b[i]    (a = +-1, b >= 0);               dual = mu >= 0
+     * NULL kind (or all zeros): no constraints. */
+    const int32_t* constraint_kind;   /* (G,) */
+    const void*    constraint_a;      /* (G,) value_t */
+    const void*    constraint_b;      /* (G,) value_t */
+    const void*    constraint_mu;     /* (G,) value_t or NULL: the multipliers the constraint objects hold on entry (warm start) */
 } adelie_hip_grpnet_args;
 
 /* Runs the whole path.  `*out` is always set on return code 0 (even when the solve recorded
@@ -327,8 +339,14 @@ enum adelie_hip_vec {
     ADELIE_HIP_I_SCREEN_SET = 100, ADELIE_HIP_I_SCREEN_BEGINS, ADELIE_HIP_I_SCREEN_IS_ACTIVE,
     ADELIE_HIP_I_ACTIVE_SET, ADELIE_HIP_I_N_VALID_SOLUTIONS, ADELIE_HIP_I_ACTIVE_SIZES,
     ADELIE_HIP_I_SCREEN_SIZES, ADELIE_HIP_I_BETAS_INDPTR, ADELIE_HIP_I_BETAS_INDICES,
+    /* duals, CSR (L, n_duals) (state_base.hpp `duals`, filled by sparsify_dual, solver_base.hpp:158-222); n_duals = number
+     * of constrained groups here (one multiplier per singleton constraint) */
+    ADELIE_HIP_I_DUALS_INDPTR, ADELIE_HIP_I_DUALS_INDICES,
     /* betas values (double), CSR (L, p) like convert_sparse_to_dense's input, py_state.cpp:9-60 */
-    ADELIE_HIP_V_BETAS_VALUES = 200
+    ADELIE_HIP_V_BETAS_VALUES = 200,
+    ADELIE_HIP_V_DUALS_VALUES,
+    /* (G,) the multiplier each constraint object is left holding when the solve returns (0 for unconstrained groups) */
+    ADELIE_HIP_V_CONSTRAINT_MU
 };
 enum adelie_hip_scalar {
     ADELIE_HIP_S_LMDA_MAX = 0, ADELIE_HIP_S_LMDA, ADELIE_HIP_S_RSQ, ADELIE_HIP_S_RESID_SUM,

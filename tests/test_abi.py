@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in syms if not hasattr(b.lib, s)]
     assert not missing, missing
     assert sorted("adelie_hip_" + s for s in _abi.HIP_SYMBOLS) == syms
-    assert b.fn("abi_version")() == 2
+    assert b.fn("abi_version")() == 3
 
 
 def test_ctypes_struct_matches_c_layout():

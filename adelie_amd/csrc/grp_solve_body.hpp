@@ -119,8 +119,18 @@ __host__ __device__ constexpr size_t grp_solve_lds_total() {
 // rotated once, lane-parallel, before the sequential loop, the loop keeps the rotated gradient current with the rotated
 // block, and the coefficients of the groups that changed are rotated back once, lane-parallel, after it.  The dependent
 // chain of a visit shrinks to: Newton root find -> change test -> gradient update of the following groups.
+// Prologue: the workgroup (nt = 256 threads as its own kernel, all 1024 of workgroup 0 in the fused launches) fetches with as
+// few dependent round trips as the data allow — (1) the block's layout descriptor (launch_grp_layout, once per pass), the
+// gradient handed over, the previous block's dense changes; the rotated block D~ and the cross block stream in meanwhile, 16
+// independent loads per thread and batch; (2) per-value / per-group constants through the descriptor's indices; (3) the
+// eigenbasis column of every value — then rotates lane-parallel in LDS.  (The first version derived the layout in every solve
+// and gathered the correction through the changes' positions: ~28 dependent round trips, 17.5 of the launch's 52.9 us on
+// config 3, scripts/grp_profile.py.)
 template <class T>
-__device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, int j, char* smem_raw) {
+__device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, int j, char* smem_raw, int nt) {
+#ifdef AHIP_GRP_PROFILE
+    const long long t_entry = __builtin_readcyclecounter();
+#endif
     T* D = reinterpret_cast<T*>(smem_raw); // GBLK*GBLK, rotated
     T* gT = D + GBLK * GBLK;  // rotated gradient of the block's values, kept current
     T* bT = gT + GBLK;        // rotated coefficients, current
@@ -136,89 +146,122 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
     T* ak_t = scr + 5 * GBLK;
     T* buf1 = scr + 6 * GBLK;
     T* buf2 = scr + 7 * GBLK;
+    T* dl = buf2;             // prologue only: the previous block's dense changes
     int32_t* vmap = reinterpret_cast<int32_t*>(scr + 8 * GBLK);
     int32_t* goff = vmap + GBLK;
     int32_t* gq = goff + GBLK + 1;
     int32_t* gss = gq + GBLK;
     int32_t* meta = gss + GBLK;
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    block_layout(p, j, vmap, goff, gq, gss, meta);
-    const int ngrp = meta[0], nval = meta[1];
     T* gpenB = reinterpret_cast<T*>(meta + 5);
     int32_t* gactB = reinterpret_cast<int32_t*>(gpenB + GBLK);
     int32_t* vgrp = gactB + GBLK;                       // value -> group of the block
     int32_t* chg = vgrp + GBLK;                         // group changed in this pass
-    if (tid < GBLK && tid < ngrp) {
-        const int ss = gss[tid];
-        gpenB[tid] = p.spen[ss];
-        gactB[tid] = p.is_active[ss];
-        chg[tid] = 0;
-    }
-    for (int k = tid >> 1; k < ngrp; k += 128) {
-        const int o = goff[k], q = gq[k];
-        for (int t = tid & 1; t < q; t += 2) vgrp[o + t] = k;
-    }
-    if (tid < GBLK) {
-        const int i = tid;
-        if (i < nval) {
-            const int a = vmap[i];
-            gO[i] = p.gblk[i];
-            b0B[i] = p.beta[a];
-            AB[i] = p.vars[a];
-            xmO[i] = p.xmean[a];
-        } else {
-            gO[i] = 0; b0B[i] = 0; AB[i] = 0; xmO[i] = 0; gT[i] = 0; bT[i] = 0; xmT[i] = 0;
-        }
-    }
-    // look-ahead correction in original coordinates (Cprev and the previous block's changes are original-coordinate)
-    T* corr = reinterpret_cast<T*>(smem_raw + ((grp_solve_lds<T>() + 15) / 16) * 16);
+    // partial sums of the look-ahead correction, nt / GBLK <= 8 parts (the eigenbasis pool of grp_solve_body is free here)
+    T* corr = reinterpret_cast<T*>(chg + GBLK);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int32_t* dsc = p.desc + size_t(j) * GDESC_STRIDE;
+    const int ngrp = dsc[GDESC_NG], nval = dsc[GDESC_NVAL];
     const bool has_corr = p.Cprev != nullptr;
-    if (has_corr) {
-        const int row = tid & (GBLK - 1), half = tid >> 7;
-        const int nzp = p.pnz[0];
-        const int per = (nzp + 1) / 2;
-        const int m0 = half * per, m1 = min(nzp, m0 + per);
-        const T* Cp = p.Cprev + row;
-        T acc = T(0);
-        int m = m0;
-        for (; m + 8 <= m1; m += 8) {
-            T c[8], d[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                c[u] = Cp[size_t(p.ppos[m + u]) * GBLK];
-                d[u] = p.pdlt[m + u];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc = fma(c[u], d[u], acc);
-        }
-        for (; m < m1; ++m) acc = fma(Cp[size_t(p.ppos[m]) * GBLK], p.pdlt[m], acc);
-        corr[half * GBLK + row] = acc;
+    const int pnv = has_corr ? dsc[GDESC_NVAL - GDESC_STRIDE] : 0; // values of the previous block = columns of Cprev
+    // (1)
+    int vm = 0, vg = 0, vs = 0, go = 0, gqv = 0, gs = 0;
+    T gb = T(0), dlv = T(0);
+    if (tid < GBLK) {
+        vm = dsc[GDESC_VMAP + tid]; vg = dsc[GDESC_VGRP + tid]; vs = dsc[GDESC_VSS + tid];
+        go = dsc[GDESC_GOFF + tid]; gqv = dsc[GDESC_GQ + tid]; gs = dsc[GDESC_GSS + tid];
+        gb = p.gblk[tid];
+        if (has_corr) dlv = p.pdd[tid];
     }
-    {
+    {   // D~: columns [0, nval)
         const T* src = p.Dptr;
         const int NE = nval * GBLK;
-        for (int e0 = tid; e0 < NE; e0 += 256 * 16) {
+        for (int e0 = tid; e0 < NE; e0 += nt * 16) {
             T v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = src[min(e0 + u * 256, NE - 1)];
+            for (int u = 0; u < 16; ++u) v[u] = src[min(e0 + u * nt, NE - 1)];
 #pragma unroll
             for (int u = 0; u < 16; ++u)
-                if (e0 + u * 256 < NE) D[e0 + u * 256] = v[u];
+                if (e0 + u * nt < NE) D[e0 + u * nt] = v[u];
         }
     }
-    __syncthreads();
-    if (has_corr) { // uniform over the workgroup
-        if (tid < nval) gO[tid] -= corr[tid] + corr[GBLK + tid];
-        __syncthreads();
+    if (tid < GBLK) {
+        vmap[tid] = vm; vgrp[tid] = vg; goff[tid] = go; gq[tid] = gqv; gss[tid] = gs;
+        if (tid == 0) goff[GBLK] = dsc[GDESC_GOFF + GBLK];
+        dl[tid] = dlv;
+        gO[tid] = tid < nval ? gb : T(0);
     }
+    // (2)
+    T b0v = T(0), Av = T(0), xmv = T(0);
+    int64_t vo = 0;
+    if (tid < nval) {
+        b0v = p.beta[vm]; Av = p.vars[vm]; xmv = p.xmean[vm];
+        vo = p.voff[vs];
+    }
+    T penv = T(0);
+    int actv = 0;
+    if (tid < ngrp) { penv = p.spen[gs]; actv = p.is_active[gs]; }
+    __syncthreads(); // dl, the tables
+    // look-ahead correction in original coordinates: corr = Cprev[:, 0:pnv] dl[0:pnv], the columns split over nt / GBLK parts
+    const int nparts = nt / GBLK;
+    if (has_corr) {
+        const int row = tid & (GBLK - 1), part = tid / GBLK;
+        const int per = (pnv + nparts - 1) / nparts;
+        const int c0 = part * per, c1 = min(pnv, c0 + per);
+        const T* Cp = p.Cprev + row;
+        T acc = T(0);
+        for (int c = c0; c < c1; c += 16) {
+            T cv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) cv[u] = Cp[size_t(min(c + u, c1 - 1)) * GBLK];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (c + u < c1) acc = fma(cv[u], dl[c + u], acc);
+        }
+        corr[part * GBLK + row] = acc;
+    }
+    // (3) the eigenbasis column of this thread's value (groups of up to 16 values: one batch of loads)
+    constexpr int QM = 16;
+    T vcol_r[QM];
+    int o_v = 0, q_v = 1;
+    if (tid < nval) {
+        o_v = goff[vg]; q_v = gq[vg];
+        if (q_v > 1 && q_v <= QM) {
+            const T* Vt = p.V + vo + int64_t(tid - o_v) * q_v;
+#pragma unroll
+            for (int u = 0; u < QM; ++u) vcol_r[u] = u < q_v ? Vt[u] : T(0);
+        }
+    }
+    if (tid < GBLK) {
+        b0B[tid] = b0v; AB[tid] = Av; xmO[tid] = xmv;
+        if (tid >= nval) { gT[tid] = 0; bT[tid] = 0; xmT[tid] = 0; }
+        if (tid < ngrp) { gpenB[tid] = penv; gactB[tid] = actv; chg[tid] = 0; }
+    }
+    __syncthreads(); // corr parts, b0B / xmO
+    if (has_corr && tid < nval) {
+        T cs = T(0);
+        for (int q = 0; q < nparts; ++q) cs += corr[q * GBLK + tid]; // fixed order
+        gO[tid] -= cs;
+    }
+    __syncthreads();
     // every value into the eigenbasis of its group: (g V)_t, (beta V)_t, (xbar V)_t   (pin_naive:123-135)
     if (tid < nval) {
-        const int i = tid, k = vgrp[i], o = goff[k], q = gq[k];
+        const int i = tid, o = o_v, q = q_v;
         if (q == 1) {
             gT[i] = gO[i]; bT[i] = b0B[i]; xmT[i] = xmO[i];
+        } else if (q <= QM) {
+            T s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int u = 0; u < QM; ++u) {
+                if (u < q) {
+                    s1 = fma(gO[o + u], vcol_r[u], s1);
+                    s2 = fma(b0B[o + u], vcol_r[u], s2);
+                    s3 = fma(xmO[o + u], vcol_r[u], s3);
+                }
+            }
+            gT[i] = s1; bT[i] = s2; xmT[i] = s3;
         } else {
-            const T* Vt = p.V + p.voff[gss[k]] + int64_t(i - o) * q;
+            const T* Vt = p.V + vo + int64_t(i - o) * q;
             T s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll 4
             for (int u = 0; u < q; ++u) {
@@ -233,6 +276,16 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
     __syncthreads();
     if (wv != 0) return;
     __builtin_amdgcn_s_setprio(3);
+#ifdef AHIP_GRP_PROFILE
+    // cycle profile of the wave (scripts/grp_profile.py): 0 prologue (kernel entry to here), 1 operand loads + norm, 2 Newton,
+    // 3 change test, 4 marking + gradient update of the groups to come, 5 epilogue
+    long long tmark = t_entry;
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RP_MARK(k) { const long long tn = __builtin_readcyclecounter(); tacc[k] += tn - tmark; tmark = tn; }
+    RP_MARK(0)
+#else
+#define RP_MARK(k)
+#endif
 
     CdBlkState<T>* st = p.st;
     T rsq = st->rsq, rsum = st->resid_sum, cm = (j == 0) ? T(0) : st->cm;
@@ -269,6 +322,7 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             // newton_solver (bcd/unconstrained/newton.hpp:35-142): v = gk_t, L = A
             const T nrm2 = group_sum(on ? gk_r * gk_r : T(0), q);
             T akt_r = T(0);
+            RP_MARK(1)
             if (sqrt(nrm2) <= l1p) {
                 akt_r = T(0);
             } else if (l1p <= T(0)) {
@@ -323,6 +377,7 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
                 akt_r = on ? h * gk_r * b2 : T(0);
                 if (iters >= p.newton_max_iters) { status = CD_NEWTON; break; }
             }
+            RP_MARK(2)
             // changed? ; convergence / rsq in rotated coordinates (pin_naive:144-154)
             T d = T(0), rs = T(0), dn = T(0), c1 = T(0);
             if (on) {
@@ -413,6 +468,7 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             }
         }
         __builtin_amdgcn_wave_barrier();
+        RP_MARK(3)
         if (changed) {
             if (lane == 0) chg[k] = 1;
             if (p.mark && gactB[k] == 0) {                         // add_active_set, pin_naive:294-304
@@ -441,6 +497,7 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             __builtin_amdgcn_wave_barrier();
             ++n_upd;
         }
+        RP_MARK(4)
     }
     rsq += gwsum(rs_acc);
     rsum -= gwsum(xs_acc);
@@ -470,6 +527,7 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             ch = bnew != b0;
         }
         if (ch) p.beta[vmap[i]] = bnew;
+        if (p.dd) p.dd[i] = bnew - b0; // dense form for the next block's look-ahead correction (0 beyond the block)
         const unsigned long long m = __ballot(ch);
         const int pos = nz + __popcll(m & ((1ull << lane) - 1ull));
         if (ch) {
@@ -491,6 +549,11 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             p.nz_out[0] = nz;
             p.rsum_out[0] = rsum;
         }
+#ifdef AHIP_GRP_PROFILE
+        RP_MARK(5)
+        if (p.dbg) for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(p.dbg) + k, (unsigned long long)tacc[k]);
+        if (p.dbg) atomicAdd(reinterpret_cast<unsigned long long*>(p.dbg) + 7, 1ull);
+#endif
         if (p.host_st && j == p.report_j) {
             CdBlkState<T> out;
             out.rsq = rsq; out.resid_sum = rsum; out.cm = cm; out.n_updates = n_upd;
@@ -502,14 +565,16 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
     }
 }
 
+// nt: threads of the workgroup that call (>= 256, a multiple of 128); only the rotated form uses more than the first 256
 template <class T, bool NAIVE>
-__device__ __forceinline__ void grp_solve_body(const CdGrpBlkParams<T>& p, int j, char* smem_raw) {
+__device__ __forceinline__ void grp_solve_body(const CdGrpBlkParams<T>& p, int j, char* smem_raw, int nt = 256) {
     if constexpr (NAIVE) {
         if (p.rot) { // uniform over the workgroup
-            grp_solve_body_rot<T>(p, j, smem_raw);
+            grp_solve_body_rot<T>(p, j, smem_raw, nt);
             return;
         }
     }
+    if (threadIdx.x >= 256) return; // before any barrier: ended waves do not take part in them
     T* D = reinterpret_cast<T*>(smem_raw); // GBLK*GBLK
     T* gB = D + GBLK * GBLK;
     T* bB = gB + GBLK;     // current beta of the block's values

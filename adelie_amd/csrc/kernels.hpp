@@ -260,7 +260,24 @@ struct CdGrpBlkParams {
     // gradients / coefficients throughout and the per-visit rotations of pin_naive:123-157 happen once per block and value,
     // lane-parallel, in the prologue and the epilogue of the solve
     int32_t rot;
+    // rot != 0: per-block layout descriptors of the pass (launch_grp_layout, GDESC_* below: the value / group tables that
+    // block_layout would otherwise derive through a chain of dependent global loads in every solve's prologue), and the
+    // look-ahead correction in dense form: dd (out) / pdd (previous block's, in) = change of every value of the block by
+    // block-local position (0 where unchanged or beyond the block), so that the correction is Cprev * pdd with no index loads
+    const int32_t* desc;
+    const T* pdd;
+    T* dd;
 };
+// layout descriptor of one block (int32 words)
+constexpr int GDESC_VMAP = 0;    // [128] screen-value index of block value i
+constexpr int GDESC_VGRP = 128;  // [128] group (of the block) of value i
+constexpr int GDESC_VSS = 256;   // [128] screen-group index of value i
+constexpr int GDESC_GOFF = 384;  // [129] first value of group k; [ng] = nval
+constexpr int GDESC_GQ = 520;    // [128] size of group k
+constexpr int GDESC_GSS = 648;   // [128] screen-group index of group k
+constexpr int GDESC_NG = 776, GDESC_NVAL = 777, GDESC_STRIDE = 784;
+// descriptors of blocks 0..nblk-1 of the pass described by p (blk_g0, list, sbegin, ssize) into desc
+template <class T> void launch_grp_layout(const CdGrpBlkParams<T>& p, int nblk, int32_t* desc, hipStream_t s);
 // D <- R^T D R for one 128 x 128 slot (ld 128): `ng` groups, group k = block values [goff[k], goff[k+1]) with eigenbasis
 // (q, q) column-major at V + voff[k] (ignored for q == 1).  `scratch` holds 128 * 128 elements, private to the stream.
 struct GrpRotArgs {

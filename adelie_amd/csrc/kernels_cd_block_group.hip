@@ -85,6 +85,53 @@ void launch_cd_group_block_pass(const CdGrpBlkParams<T>& p, hipStream_t s) {
     }
 }
 
+// Layout descriptors of all blocks of a pass (CdGrpBlkParams::desc, GDESC_*): what block_layout derives per solve, once per
+// pass and for all blocks in parallel.  One 128-thread workgroup per block.
+template <class T>
+__global__ __launch_bounds__(GBLK) void grp_layout_kernel(CdGrpBlkParams<T> p, int32_t* __restrict__ desc) {
+    __shared__ int32_t gb_[GBLK], gq_[GBLK], gss_[GBLK], goff_[GBLK + 1];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    int32_t* d = desc + size_t(j) * GDESC_STRIDE;
+    const int g0 = p.blk_g0[j], g1 = p.blk_g0[j + 1];
+    const int ng = g1 - g0;
+    int ss = 0, b = 0, q = 0;
+    if (tid < ng) {
+        ss = p.list ? p.list[g0 + tid] : g0 + tid;
+        b = p.sbegin[ss];
+        q = p.ssize[ss];
+    }
+    gss_[tid] = ss; gb_[tid] = b; gq_[tid] = q;
+    __syncthreads();
+    if (tid == 0) {
+        int o = 0;
+        for (int k = 0; k < ng; ++k) { goff_[k] = o; o += gq_[k]; }
+        for (int k = ng; k <= GBLK; ++k) goff_[k] = o;
+    }
+    __syncthreads();
+    const int nval = goff_[ng];
+    d[GDESC_GOFF + tid] = goff_[tid];
+    if (tid == 0) { d[GDESC_GOFF + GBLK] = goff_[GBLK]; d[GDESC_NG] = ng; d[GDESC_NVAL] = nval; }
+    d[GDESC_GQ + tid] = gq_[tid];
+    d[GDESC_GSS + tid] = gss_[tid];
+    if (tid < ng) {
+        const int o = goff_[tid];
+        for (int t = 0; t < q; ++t) {
+            d[GDESC_VMAP + o + t] = b + t;
+            d[GDESC_VGRP + o + t] = tid;
+            d[GDESC_VSS + o + t] = ss;
+        }
+    }
+    if (tid >= nval) { d[GDESC_VMAP + tid] = 0; d[GDESC_VGRP + tid] = 0; d[GDESC_VSS + tid] = 0; }
+}
+
+template <class T>
+void launch_grp_layout(const CdGrpBlkParams<T>& p, int nblk, int32_t* desc, hipStream_t s) {
+    if (nblk <= 0) return;
+    hipLaunchKernelGGL((grp_layout_kernel<T>), dim3(unsigned(nblk)), dim3(GBLK), 0, s, p, desc);
+}
+template void launch_grp_layout<double>(const CdGrpBlkParams<double>&, int, int32_t*, hipStream_t);
+template void launch_grp_layout<float>(const CdGrpBlkParams<float>&, int, int32_t*, hipStream_t);
+
 // D <- R^T D R, R = blockdiag(V_k).  ONE workgroup of 1024 threads per block.  Groups of at most 16 values (the usual case): the
 // block is copied into LDS with 16-byte loads, eight in flight per thread (leading dimension 129: both passes below are then
 // free of bank conflicts — pass 1 walks down a column across the lanes, pass 2 along a row), the eigenbases of its groups next

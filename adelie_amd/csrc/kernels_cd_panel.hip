@@ -329,9 +329,8 @@ __global__ __launch_bounds__(256 * FS) void panel_fused_grp_kernel(CdGrpBlkParam
                                                                   T* __restrict__ part, int64_t part_ld) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int RS = 64 * VEC;
-    if (blockIdx.x == 0) {
-        if (threadIdx.x >= 256) return; // before any barrier: ended waves do not take part in them
-        grp_solve_body<T, true>(sp, j, smem_raw);
+    if (blockIdx.x == 0) { // all 256 * FS threads: the rotated solve spreads its prologue's loads over them
+        grp_solve_body<T, true>(sp, j, smem_raw, 256 * FS);
         return;
     }
     const int sub = threadIdx.x >> 8, tid = threadIdx.x & 255;

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64 * MFS) void multi_fused_kernel(CdGrpBlkParams<T>
                                                               T* __restrict__ part, int64_t part_ld) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if (blockIdx.x == 0) {
-        if (blockIdx.y == 0 && threadIdx.x < 256) grp_solve_body<T, true>(sp, j, smem_raw);
+        if (blockIdx.y == 0) grp_solve_body<T, true>(sp, j, smem_raw, 64 * MFS);
         return;
     }
     T* dA = reinterpret_cast<T*>(smem_raw);                 // MAXB * KT

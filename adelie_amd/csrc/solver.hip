@@ -592,7 +592,8 @@ struct Solver {
     // cross-queue hop, slower than no look-ahead at all.)
     bool lookahead = true;      // A/B hook ADELIE_HIP_LOOKAHEAD
     int la_min_blocks = 3;      // passes with fewer blocks run in the plain form (hook ADELIE_HIP_LOOKAHEAD_MIN_BLOCKS)
-    DevBuf<T> d_Xpool, d_la_dlt, d_la_g, d_la_rsum;
+    DevBuf<T> d_Xpool, d_la_dlt, d_la_g, d_la_rsum, d_la_dd;
+    DevBuf<int32_t> d_gdesc; // layout descriptors of the current group pass (launch_grp_layout)
     DevBuf<int32_t> d_la_dcol, d_la_dpos, d_la_nz;
     struct XKey { int32_t nb_prev = 0, nb = 0; uint64_t ver = 0; };
     std::vector<XKey> xscr_key, xact_key;
@@ -1887,9 +1888,11 @@ struct Solver {
             }
             d_la_dlt.reserve(size_t(2) * SL); d_la_g.reserve(size_t(2) * SL); d_la_rsum.reserve(2);
             d_la_dcol.reserve(size_t(2) * SL); d_la_dpos.reserve(size_t(2) * SL); d_la_nz.reserve(2);
+            d_la_dd.reserve(size_t(2) * SL);
             d_part.reserve(size_t(2 * panel_part_elems(n) + 2048));
             pending_slot = -1;
         }
+        d_gdesc.reserve(maxblk * size_t(GDESC_STRIDE));
         auto pass_la = [&](bool screen_pass) -> T {
             const idx count = screen_pass ? idx(cp.ns) : idx(asz);
             if (count <= 0) return T(0);
@@ -1914,6 +1917,8 @@ struct Solver {
             bp.list = screen_pass ? nullptr : cp.active_set;
             bp.nblk = nblk;
             bp.mark = screen_pass ? 1 : 0;
+            bp.desc = d_gdesc.p;
+            if (bp.rot) launch_grp_layout<T>(bp, nblk, d_gdesc.p, st);
             auto nb_of = [&](int j) { return int(gp_vbeg[size_t(j) + 1] - gp_vbeg[j]); };
             auto cols_of = [&](int j) { return cols_all + gp_vbeg[j]; };
             rot_on = group_rot;
@@ -1949,6 +1954,8 @@ struct Solver {
                 bp.dpos = d_la_dpos.p + size_t(slot) * SL;
                 bp.nz_out = d_la_nz.p + slot;
                 bp.rsum_out = d_la_rsum.p + slot;
+                bp.pdd = d_la_dd.p + size_t(pslot) * SL;
+                bp.dd = d_la_dd.p + size_t(slot) * SL;
                 if (h_report && j == nblk - 1) {
                     bp.report_j = j;
                     bp.report_seq = ++report_seq;
@@ -2020,6 +2027,9 @@ struct Solver {
             bp.list = screen_pass ? nullptr : cp.active_set;
             bp.nblk = nblk;
             bp.mark = screen_pass ? 1 : 0;
+            bp.desc = d_gdesc.p;
+            bp.pdd = nullptr; bp.dd = nullptr;
+            if (bp.rot) launch_grp_layout<T>(bp, nblk, d_gdesc.p, st);
             rot_on = group_rot;
             rot_list = screen_pass ? nullptr : act_host.data();
             build_stale_blocks(nblk, tab_nb, tab_ver, pool, [&](int j) { return int(gp_vbeg[size_t(j) + 1] - gp_vbeg[j]); },

@@ -10,7 +10,7 @@ from bench import make_data
 X, y = make_data(100000, 10000, 0, torch.device("cuda", 0), torch.float64)
 Xd = ad.matrix.dense(X); glm = ad.glm.gaussian(y)
 st = ad.grpnet(Xd, glm, groups=np.arange(0, 10000, 10), alpha=0.5, early_exit=False)
-names = ["prologue*", "rotation", "norm+newton", "changed+backrot", "mark+gupdate", "epilogue", "-", "blocks"]
+names = ["prologue", "loads+norm", "newton", "change test", "mark+gupdate", "epilogue", "-", "blocks"]  # grp_solve_body_rot's marks (ADELIE_HIP_GROUP_ROT=0: prologue*, rotation, norm+newton, changed+backrot, mark+gupdate, epilogue)
 tot = sum(st.timers[f"dbg{i}"] for i in range(6))
 nb = st.timers["dbg7"]
 print("blocks", nb, "updates", st.counters["n_updates"], "cd ms", st.timers["t_cd_ms"])

@@ -1,3 +1,5 @@
-mkdir -p gpurun_out
-bash scripts/prof_cmd.sh r02i 3 > gpurun_out/prof_r02i_cfg3.log 2>&1; head -14 gpurun_out/r02i_cfg3_rocprof_summary.txt | cut -c1-150
-timeout 1500 python -m pytest tests -m gpu -q -x > gpurun_out/r02i_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r02i_pytest.log | cut -c1-200
+run() { echo "== $*"; for i in 1 2; do env "$@" timeout 300 python bench.py --config 2 --steps 5 --warmup 1 --no-cpu-baseline --no-cv-leg 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; done; }
+run A=0
+run ADELIE_HIP_SIDE_CU_RESERVE=192 ADELIE_HIP_SIDE_CU_PATTERN=0
+run ADELIE_HIP_SIDE_CU_RESERVE=224 ADELIE_HIP_SIDE_CU_PATTERN=0
+run ADELIE_HIP_SIDE_CU_RESERVE=128 ADELIE_HIP_SIDE_CU_PATTERN=0

@@ -102,6 +102,28 @@ __device__ __forceinline__ void gather_group_block(const CdGrpBlkParams<T>& p, i
     }
 }
 
+// One-coefficient box constraint of a group of size one inside a grouped problem (CdGrpBlkParams::clo / chi / cmu, indexed by
+// screen value; see blk_solve_body<.., CONS>): clips the unconstrained update and leaves the multiplier mu_+ - mu_- of
+// constraint_box.ipp:66-95 (A = Q(0,0) = 1) in cmu.  Uniform over the wave; lane 0 stores.
+template <class T>
+__device__ __forceinline__ T grp_clip_1d(const CdGrpBlkParams<T>& p, int a, T ak, T gk, T l1, T den, int lane) {
+    const T INF = T(1) / T(0);
+    const T lo = p.clo[a], hi = p.chi[a];
+    if (lo == -INF && hi == INF) return ak;
+    const T x0 = fmax(fmin(ak, hi), lo);
+    const T mp0 = (hi > T(0)) ? T(0) : fmax(gk, T(0));
+    const T mn0 = (lo < T(0)) ? T(0) : fmax(-gk, T(0));
+    T mu;
+    if (fabs(gk - (mp0 - mn0)) <= l1) {
+        mu = mp0 - mn0;
+    } else {
+        const T full = gk - (den * x0 + copysign(l1, x0));
+        mu = ((x0 < hi) ? T(0) : fmax(full, T(0))) - ((x0 > lo) ? T(0) : fmax(-full, T(0)));
+    }
+    if (lane == 0) p.cmu[a] = mu;
+    return x0;
+}
+
 // LDS of the solve proper; the look-ahead correction partials (2 * GBLK values) follow it
 template <class T>
 __host__ __device__ constexpr size_t grp_solve_lds() {
@@ -303,7 +325,8 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             const T gcur = gT[o], bi = bT[o], A = AB[o];
             const T gk = fma(bi, A, gcur);                       // pin_naive:85-89
             const T v = fabs(gk) - l1p;                          // pin_base:181-195
-            const T ak = (v > T(0)) ? copysign(v, gk) / (A + l2p) : T(0);
+            T ak = (v > T(0)) ? copysign(v, gk) / (A + l2p) : T(0);
+            if (p.clo) ak = grp_clip_1d(p, vmap[o], ak, gk, l1p, A + l2p, lane); // constraint->solve, pin_naive:419-437
             if (ak != bi) {                                      // pin_naive:97
                 changed = true;
                 const T d = ak - bi;
@@ -718,7 +741,8 @@ __device__ __forceinline__ void grp_solve_body(const CdGrpBlkParams<T>& p, int j
             const T gcur = gB[o], bi = bB[o], A = AB[o];
             const T gk = fma(bi, A, gcur);                       // pin_naive:85-89
             const T v = fabs(gk) - l1p;                          // pin_base:181-195
-            const T ak = (v > T(0)) ? copysign(v, gk) / (A + l2p) : T(0);
+            T ak = (v > T(0)) ? copysign(v, gk) / (A + l2p) : T(0);
+            if (NAIVE && p.clo) ak = grp_clip_1d(p, vmap[o], ak, gk, l1p, A + l2p, lane); // constraint->solve, pin_naive:419-437
             if (ak != bi) {                                      // pin_naive:97
                 changed = true;
                 const T d = ak - bi;

@@ -96,10 +96,10 @@ int64_t syrk_work_elems(int64_t n, int64_t M);
 template <class T>
 void launch_abs_grad(const T* grad, const int64_t* groups, const int64_t* group_sizes, int64_t G, const int32_t* slot,
                      const T* screen_beta, const T* penalty, T one_minus_alpha_lmda, T* abs_grad, hipStream_t s);
-// the same when every group has one coefficient and some carry box constraints clo[g] <= beta <= chi[g] (+-inf: none); cmu: the
+// the same when some groups of one coefficient carry box constraints clo[g] <= beta <= chi[g] (+-inf: none); cmu: the
 // multipliers of the screen values, mu_out (G,): every group's multiplier afterwards
 template <class T>
-void launch_abs_grad_cons(const T* grad, const int64_t* groups, int64_t G, const int32_t* slot, const T* screen_beta,
+void launch_abs_grad_cons(const T* grad, const int64_t* groups, const int64_t* group_sizes, int64_t G, const int32_t* slot, const T* screen_beta,
                           const T* penalty, T one_minus_alpha_lmda, const T* clo, const T* chi, const T* cmu, T* abs_grad,
                           T* mu_out, hipStream_t s);
 
@@ -267,6 +267,10 @@ struct CdGrpBlkParams {
     const int32_t* desc;
     const T* pdd;
     T* dd;
+    // one-coefficient constraints of groups of size one (see CdBlkParams): per screen value, +-inf where there is none
+    const T* clo;
+    const T* chi;
+    T* cmu;
 };
 // layout descriptor of one block (int32 words)
 constexpr int GDESC_VMAP = 0;    // [128] screen-value index of block value i

@@ -320,13 +320,14 @@ __global__ void abs_grad_kernel(const T* __restrict__ grad, const int64_t* __res
     abs_grad[g] = sqrt(acc);
 }
 
-// update_abs_grad (solver_base.hpp:20-110) when every group has one coefficient and some carry a box constraint
+// update_abs_grad (solver_base.hpp:20-110) when some groups of one coefficient carry a box constraint
 // lo <= beta <= hi (lo <= 0 <= hi, +-inf: none): a screened coordinate subtracts its multiplier (the constraint's gradient,
 // :69-75), any other constrained one takes the multiplier that best explains its gradient at beta = 0 (solve_zero,
 // constraint_box.ipp:268-284: free in the directions whose bound is exactly zero, zero elsewhere).  mu_out: every group's
 // multiplier (what sparsify_dual reads off the constraint objects, :158-222).
 template <class T>
-__global__ void abs_grad_cons_kernel(const T* __restrict__ grad, const int64_t* __restrict__ groups, int64_t G,
+__global__ void abs_grad_cons_kernel(const T* __restrict__ grad, const int64_t* __restrict__ groups,
+                                     const int64_t* __restrict__ group_sizes, int64_t G,
                                      const int32_t* __restrict__ slot, const T* __restrict__ screen_beta,
                                      const T* __restrict__ penalty, T oma_lmda, const T* __restrict__ clo,
                                      const T* __restrict__ chi, const T* __restrict__ cmu, T* __restrict__ abs_grad,
@@ -334,6 +335,19 @@ __global__ void abs_grad_cons_kernel(const T* __restrict__ grad, const int64_t* 
     const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (g >= G) return;
     const T INF = T(1) / T(0), M = T(1e100); // Configs::max_solver_value (inf in single precision, as in the reference)
+    const int64_t sz = group_sizes[g];
+    if (sz != 1) { // groups of several coefficients carry no constraint: abs_grad_kernel's norm
+        const int64_t k = groups[g];
+        const int32_t sl0 = slot[g];
+        T acc = T(0);
+        for (int64_t t = 0; t < sz; ++t) {
+            const T e0 = sl0 >= 0 ? grad[k + t] - oma_lmda * penalty[g] * screen_beta[sl0 + t] : grad[k + t];
+            acc += e0 * e0;
+        }
+        abs_grad[g] = sqrt(acc);
+        mu_out[g] = T(0);
+        return;
+    }
     const T v = grad[groups[g]], lo = clo[g], hi = chi[g];
     const bool constrained = lo != -INF || hi != INF;
     const int32_t sl = slot[g];
@@ -590,12 +604,12 @@ void launch_abs_grad(const T* grad, const int64_t* groups, const int64_t* group_
 }
 
 template <class T>
-void launch_abs_grad_cons(const T* grad, const int64_t* groups, int64_t G, const int32_t* slot, const T* screen_beta,
-                          const T* penalty, T oma_lmda, const T* clo, const T* chi, const T* cmu, T* abs_grad, T* mu_out,
-                          hipStream_t s) {
+void launch_abs_grad_cons(const T* grad, const int64_t* groups, const int64_t* group_sizes, int64_t G, const int32_t* slot,
+                          const T* screen_beta, const T* penalty, T oma_lmda, const T* clo, const T* chi, const T* cmu,
+                          T* abs_grad, T* mu_out, hipStream_t s) {
     if (G <= 0) return;
-    hipLaunchKernelGGL((abs_grad_cons_kernel<T>), dim3(unsigned((G + 255) / 256)), dim3(256), 0, s, grad, groups, G, slot,
-                       screen_beta, penalty, oma_lmda, clo, chi, cmu, abs_grad, mu_out);
+    hipLaunchKernelGGL((abs_grad_cons_kernel<T>), dim3(unsigned((G + 255) / 256)), dim3(256), 0, s, grad, groups, group_sizes,
+                       G, slot, screen_beta, penalty, oma_lmda, clo, chi, cmu, abs_grad, mu_out);
 }
 
 template <class T>
@@ -729,8 +743,8 @@ template void launch_snp_impute<float>(const uint8_t*, int64_t, int64_t, int64_t
                                         T*, hipStream_t);                                                              \
     template void launch_abs_grad<T>(const T*, const int64_t*, const int64_t*, int64_t, const int32_t*, const T*,      \
                                      const T*, T, T*, hipStream_t);                                                    \
-    template void launch_abs_grad_cons<T>(const T*, const int64_t*, int64_t, const int32_t*, const T*, const T*, T,    \
-                                          const T*, const T*, const T*, T*, T*, hipStream_t);                          \
+    template void launch_abs_grad_cons<T>(const T*, const int64_t*, const int64_t*, int64_t, const int32_t*, const T*, \
+                                          const T*, T, const T*, const T*, const T*, T*, T*, hipStream_t);             \
     template void launch_copy2d<T>(const T*, int64_t, T*, int64_t, int64_t, int64_t, hipStream_t);                     \
     template void launch_diag_vars<T>(const T*, int64_t, int32_t, int32_t, T*, hipStream_t);                           \
     template void launch_csc_scatter<T>(const int64_t*, const int32_t*, const T*, int64_t, int64_t, T*, int64_t, hipStream_t);\

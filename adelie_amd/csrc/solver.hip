@@ -851,7 +851,7 @@ struct Solver {
     // also every group's multiplier (screened: from its last visit; others: solve_zero)
     void device_abs_grad(T lm) {
         if (cons_on) {
-            launch_abs_grad_cons<T>(d_grad.p, d_groups.p, G, d_slot.p, d_beta.p, d_penalty.p, (1 - alpha) * lm, d_clo_g.p,
+            launch_abs_grad_cons<T>(d_grad.p, d_groups.p, d_gsizes.p, G, d_slot.p, d_beta.p, d_penalty.p, (1 - alpha) * lm, d_clo_g.p,
                                     d_chi_g.p, d_cmu.p, d_absgrad.p, d_mu_g.p, st);
             d_mu_g.download(cons_mu.data(), size_t(G), st);
         } else {
@@ -906,13 +906,15 @@ struct Solver {
         d_ssize.upload(ssize.data(), ssize.size(), st, ns_dev);
         d_spen.upload(spen.data(), spen.size(), st, ns_dev);
         d_isact.upload(isact.data(), isact.size(), st, ns_dev);
-        std::vector<T> clo_new, chi_new, cmu_new; // all groups have one coefficient here: screen value = screen group
+        std::vector<T> clo_new, chi_new, cmu_new; // per screen value (only groups of one coefficient carry a constraint)
         if (cons_on) {
             for (idx ss = ns_dev; ss < ns; ++ss) {
                 const idx g = screen_set[ss];
-                clo_new.push_back(cons_lo[g]);
-                chi_new.push_back(cons_hi[g]);
-                cmu_new.push_back(cons_mu[g]);
+                for (idx t = 0; t < group_sizes[g]; ++t) {
+                    clo_new.push_back(cons_lo[g]);
+                    chi_new.push_back(cons_hi[g]);
+                    cmu_new.push_back(cons_mu[g]);
+                }
             }
             d_clo.upload(clo_new.data(), clo_new.size(), st, nv_old);
             d_chi.upload(chi_new.data(), chi_new.size(), st, nv_old);
@@ -1889,6 +1891,7 @@ struct Solver {
         bp.gblk = d_gblk.p; bp.vcol = cp.vcol; bp.dcol = d_dcolblk.p;
         bp.host_st = rep_st_dev; bp.host_seq = rep_seq_dev; bp.report_j = -1; bp.report_seq = 0;
         bp.rot = group_rot ? 1 : 0;
+        if (cons_on) { bp.clo = d_clo.p; bp.chi = d_chi.p; bp.cmu = d_cmu.p; }
         struct RotGuard { // builds of this fit are rotated behind their launch (build_stale_blocks); off again on any exit
             Solver* s;
             ~RotGuard() { s->rot_on = false; s->rot_list = nullptr; }
@@ -2804,7 +2807,7 @@ struct Solver {
         cmu_stage.resize(size_t(nv));
         d_cmu.download(cmu_stage.data(), size_t(nv), st);
         sync();
-        for (size_t ss = 0; ss < screen_set.size(); ++ss) // one coefficient per group: screen value = screen group
+        for (size_t ss = 0; ss < screen_set.size(); ++ss) // a constrained group has one coefficient: its screen value
             if (cons_kind[screen_set[ss]]) cons_mu[screen_set[ss]] = cmu_stage[size_t(screen_begins[ss])];
     }
 
@@ -2952,8 +2955,9 @@ struct Solver {
             if (any) {
                 if (cov_mode) throw make_core_error("constraints are not implemented for the covariance method.");
                 if (multi()) throw make_core_error("constraints are not implemented for multi-response problems.");
-                if (!all_scalar)
-                    throw make_core_error("constraints are implemented for problems whose groups all have one coefficient.");
+                if (!all_scalar && max_gs > idx(cd_block_size()))
+                    throw make_core_error("constraints are not implemented for problems with groups of more than " +
+                                          std::to_string(cd_block_size()) + " coefficients.");
                 if (!a->constraint_a || !a->constraint_b) throw make_core_error("constraint_a and constraint_b are required.");
                 const T* ca = static_cast<const T*>(a->constraint_a);
                 const T* cb = static_cast<const T*>(a->constraint_b);
@@ -2971,6 +2975,8 @@ struct Solver {
                     dual_groups[g] = nd;
                     const int32_t kd = cons_kind[g];
                     if (!kd) continue;
+                    if (group_sizes[g] != 1)
+                        throw make_core_error("constraints are implemented for groups of one coefficient.");
                     if (kd == 1) { // constraint_box.ipp:30-37
                         if (cb[g] < 0) throw make_core_error("upper must be >= 0.");
                         if (ca[g] > 0) throw make_core_error("lower must be <= 0.");
@@ -2991,6 +2997,7 @@ struct Solver {
                 // the clipped coordinate update lives in the panel solve (blk_solve_body<.., CONS>): that engine from the first
                 // screened coefficient on, in its sequential form
                 engine_panel = true;
+                group_panel = true;
                 cd_block_min_nv = 1;
                 lookahead = false;
                 d_clo_g.reserve(G); d_chi_g.reserve(G); d_mu_g.reserve(G);

@@ -289,11 +289,71 @@ def test_hip_nonnegative_lasso_f32_and_warm_start(hip, oracle):
     assert np.abs(cont.duals.toarray() - cold.duals.toarray()[-3:]).max() < 1e-6
 
 
+def _mixed_group_problem(p, rng):
+    """Groups of sizes 1 and 3 interleaved; every second group of size one carries a constraint."""
+    groups, j, k = [], 0, 0
+    while j < p:
+        groups.append(j)
+        j += 1 if (k % 2 == 0) else min(3, p - j)
+        k += 1
+    groups = np.array(groups)
+    sizes = np.diff(np.append(groups, p))
+    cons, lo, hi = [], np.full(p, -np.inf), np.full(p, np.inf)
+    n1 = 0
+    for g, q in zip(groups, sizes):
+        if q == 1 and n1 % 2 == 0:
+            if n1 % 4 == 0:
+                cons.append(constraint.lower(np.zeros(1)))
+                lo[g] = 0
+            else:
+                u = rng.uniform(0.02, 0.2)
+                cons.append(constraint.box(np.array([-u]), np.array([u])))
+                lo[g], hi[g] = -u, u
+        else:
+            cons.append(None)
+        n1 += q == 1
+    return groups, cons, lo, hi
+
+
+def test_oracle_constrained_singletons_inside_a_grouped_problem(oracle):
+    d = make_gaussian(200, 40, seed=4)
+    groups, cons, lo, hi = _mixed_group_problem(40, np.random.RandomState(0))
+    kw = dict(groups=groups, alpha=0.7, lmda_path_size=10, min_ratio=0.02, early_exit=False, tol=1e-13)
+    st = _fit(oracle.dense(d["X"]), ad.glm.gaussian(d["y"]), cons, **kw)
+    B = st.betas.toarray()
+    assert st.error == "" and (B >= lo - 1e-12).all() and (B <= hi + 1e-12).all()
+    assert ((B[-1] == lo) | (B[-1] == hi)).sum() >= 1
+    free = ad.grpnet(oracle.dense(d["X"]), ad.glm.gaussian(d["y"]), progress_bar=False, **kw)
+    assert np.abs(free.betas.toarray() - B).max() > 1e-3  # the constraints matter on this problem
+    assert st.duals.shape == (10, sum(c is not None for c in cons)) and st.duals.nnz > 0
+
+
 @pytest.mark.gpu
-def test_hip_constraint_errors(hip):
-    d = make_gaussian(80, 12, seed=1)
-    X = ad.matrix.dense(d["X"])
-    c = constraint.lower(np.zeros(1))
-    with pytest.raises(RuntimeError, match="all have one coefficient"):
-        ad.grpnet(X, ad.glm.gaussian(d["y"]), groups=np.array([0, 1, 2, 4, 6, 8, 10]),
-                  constraints=[c] + [None] * 6, progress_bar=False)
+@pytest.mark.parametrize("family", ["gaussian", "binomial"])
+@pytest.mark.parametrize("rot", ["1", "0"])
+def test_hip_constrained_singletons_inside_a_grouped_problem(hip, oracle, monkeypatch, family, rot):
+    monkeypatch.setenv("ADELIE_HIP_GROUP_ROT", rot)
+    n, p = 500, 260
+    d = make_gaussian(n, p, seed=12, sparsity=0.8)
+    X = d["X"]
+    rng = np.random.RandomState(3)
+    groups, cons_o, lo, hi = _mixed_group_problem(p, np.random.RandomState(0))
+    _, cons_h, _, _ = _mixed_group_problem(p, np.random.RandomState(0))
+    if family == "gaussian":
+        mk = lambda: ad.glm.gaussian(d["y"])
+        kw = dict(groups=groups, alpha=0.6, lmda_path_size=12, min_ratio=0.03, early_exit=False, tol=1e-13)
+    else:
+        yb = (rng.uniform(size=n) < 1 / (1 + np.exp(-X[:, :6] @ np.ones(6)))).astype(float)
+        mk = lambda: ad.glm.binomial(yb)
+        kw = dict(groups=groups, alpha=0.6, lmda_path_size=8, min_ratio=0.1, early_exit=False, tol=1e-13, irls_tol=1e-11)
+    ref = _fit(oracle.dense(X), mk(), cons_o, **kw)
+    st = _fit(ad.matrix.dense(X), mk(), cons_h, **kw)
+    assert st.error == "" and ref.error == "" and len(st.lmdas) == len(ref.lmdas)
+    B, R = st.betas.toarray(), ref.betas.toarray()
+    assert (B >= lo).all() and (B <= hi).all()
+    assert ((B[-1] == lo) | (B[-1] == hi)).sum() >= 3
+    assert np.abs(B - R).max() < 1e-7
+    assert np.abs((st.duals - ref.duals)).max() < 1e-6 and ref.duals.nnz > 0
+    assert np.abs(st.abs_grad - ref.abs_grad).max() < 1e-6
+    # same groups screened (the order inside one screening step follows the sort of scores that agree to rounding only)
+    assert np.array_equal(np.sort(st.screen_set), np.sort(ref.screen_set))

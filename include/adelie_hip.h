@@ -288,8 +288,9 @@ typedef struct adelie_hip_grpnet_args {
     double         rdev_tol;          /* early exit on the relative change of the deviance (solver_gaussian_cov.hpp:183-201) */
     /* ---- per-group constraints (`constraints` of StateBase, state_base.hpp:60; adelie_core/constraint/) ----
      * Offered for groups of ONE value, where ConstraintBox / ConstraintOneSided have closed forms (constraint_box.ipp:51-96,
-     * constraint_one_sided.ipp:12-49); a constrained group of more than one value (their proximal-Newton solvers), a linear
-     * constraint, or constraints on a multi-response view / the covariance method are refused with an error string.
+     * constraint_one_sided.ipp:12-49); the other groups of the problem may have any size up to 128.  A constrained group of
+     * more than one value (their proximal-Newton solvers), a linear constraint, or constraints on a multi-response view / the
+     * covariance method are refused with an error string.
      *   kind 0: unconstrained;
      *   kind 1: box        constraint_a[i] <= beta_i <= constraint_b[i]   (a <= 0 <= b, infinities allowed); dual = mu_+ - mu_-
      *   kind 2: one-sided  constraint_a[i] * beta_i <= constraint_b[i]    (a = +-1, b >= 0);               dual = mu >= 0

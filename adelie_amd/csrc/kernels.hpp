@@ -75,6 +75,22 @@ struct SyrkBatch {
     int32_t count;
 };
 int64_t syrk_batch_work_elems(int64_t n, int count);
+// Several rectangular blocks of at most 128 x 128 per launch (gram_batch_kernel; the cross blocks of the look-ahead passes):
+// block y = rows cols_base[moff[y] ...] (m[y] of them) x columns cols_base[noff[y] ...] (nn[y]), X_rows^T W X_cols -
+// xm_rows xm_cols^T into C_base + dst[y] (leading dimension ldc).  `work` holds gram_batch_work_elems(n, count) elements.
+struct GramBatch {
+    static constexpr int MAX = 16;
+    int32_t moff[MAX], m[MAX], noff[MAX], nn[MAX];
+    int64_t dst[MAX];
+    int32_t count;
+};
+int64_t gram_batch_work_elems(int64_t n, int count);
+template <class T>
+void launch_gram_batch(const DenseView<T>& X, const T* w, const int32_t* cols_base, const GramBatch& b, const T* xm_by_col,
+                       bool center, T* C_base, int64_t ldc, T* work, hipStream_t s);
+template <class T>
+void launch_gram_batch_snp(const SnpView& X, const T* impute, const T* w, const int32_t* cols_base, const GramBatch& b,
+                           const T* xm_by_col, bool center, T* C_base, int64_t ldc, T* work, hipStream_t s);
 void set_small_gram_workgroups(int wgs); // kernels_gram.hip: spread of the next small builds launched by this host thread
 template <class T>
 void launch_syrk_batch(const DenseView<T>& X, const T* w, const int32_t* cols_base, const SyrkBatch& b, const T* xm_by_col,

@@ -78,11 +78,11 @@ __device__ __forceinline__ void load_rows(const Acc& X, int64_t j, bool valid, i
 
 // Block tile BM x BN = 128 x {64,128}; 4 waves: 2x2 of 64x64 (BN=128) or 4x1 of 32x64 (BN=64).
 template <class T, class Acc, bool VECOK, int BN>
-__global__ __launch_bounds__(GT, 2) void gram_kernel(Acc X, const T* __restrict__ w, const int32_t* __restrict__ mcols,
-                                                  int32_t M, const int32_t* __restrict__ ncols, int32_t N, int64_t n,
-                                                  int64_t kchunk, int32_t m_pos0, int32_t n_pos0, int symmetric,
-                                                  T* __restrict__ part, int64_t Mpad, int64_t Npad, int32_t ncol0,
-                                                  int32_t Mt, int32_t Nt, int32_t nsplit) {
+__device__ __forceinline__ void gram_body(const Acc& X, const T* __restrict__ w, const int32_t* __restrict__ mcols,
+                                          int32_t M, const int32_t* __restrict__ ncols, int32_t N, int64_t n,
+                                          int64_t kchunk, int32_t m_pos0, int32_t n_pos0, int symmetric,
+                                          T* __restrict__ part, int64_t Mpad, int64_t Npad, int32_t ncol0,
+                                          int32_t Mt, int32_t Nt, int32_t nsplit) {
     constexpr int WN = BN / 64;            // waves along N
     constexpr int WM = 4 / WN;             // waves along M
     constexpr int TM = BM / WM / 16;       // MFMA tiles per wave along M (4 or 2)
@@ -180,11 +180,34 @@ __global__ __launch_bounds__(GT, 2) void gram_kernel(Acc X, const T* __restrict_
             }
 }
 
+template <class T, class Acc, bool VECOK, int BN>
+__global__ __launch_bounds__(GT, 2) void gram_kernel(Acc X, const T* __restrict__ w, const int32_t* __restrict__ mcols,
+                                                  int32_t M, const int32_t* __restrict__ ncols, int32_t N, int64_t n,
+                                                  int64_t kchunk, int32_t m_pos0, int32_t n_pos0, int symmetric,
+                                                  T* __restrict__ part, int64_t Mpad, int64_t Npad, int32_t ncol0,
+                                                  int32_t Mt, int32_t Nt, int32_t nsplit) {
+    gram_body<T, Acc, VECOK, BN>(X, w, mcols, M, ncols, N, n, kchunk, m_pos0, n_pos0, symmetric, part, Mpad, Npad, ncol0, Mt,
+                                 Nt, nsplit);
+}
+
+// Several M x N blocks (M, N <= 128: one tile each) per launch — the cross blocks of the look-ahead passes: block y of the
+// batch = rows cols_base[moff[y]...], columns cols_base[noff[y]...], partials at part + y * nsplit * 128 * 128.  The K-splits
+// of all blocks together make one round over the chip, so a block's partial-tile traffic (128 KB written and re-read per
+// split) shrinks with the batch: 512 splits = 134 MB for a block built alone, 17 MB in a batch of eight.
+template <class T, class Acc, bool VECOK>
+__global__ __launch_bounds__(GT, 2) void gram_batch_kernel(Acc X, const T* __restrict__ w, const int32_t* __restrict__ cols_base,
+                                                        GramBatch b, int64_t n, int64_t kchunk, T* __restrict__ part,
+                                                        int32_t nsplit) {
+    const int y = blockIdx.y;
+    gram_body<T, Acc, VECOK, 128>(X, w, cols_base + b.moff[y], b.m[y], cols_base + b.noff[y], b.nn[y], n, kchunk, 0, 0, 0,
+                                  part + int64_t(y) * nsplit * BM * 128, BM, 128, 0, 1, 1, nsplit);
+}
+
 template <class T>
-__global__ void gram_reduce_kernel(const T* __restrict__ part, int nsplit, int64_t Mpad, int64_t Npad, int32_t M,
-                                   int32_t N, const int32_t* __restrict__ mcols, const int32_t* __restrict__ ncols,
-                                   int32_t m_pos0, int32_t n_pos0, const T* __restrict__ xm, int center,
-                                   int symmetric, T* __restrict__ C, int64_t ldc) {
+__device__ __forceinline__ void gram_reduce_body(const T* __restrict__ part, int nsplit, int64_t Mpad, int64_t Npad, int32_t M,
+                                                 int32_t N, const int32_t* __restrict__ mcols, const int32_t* __restrict__ ncols,
+                                                 int32_t m_pos0, int32_t n_pos0, const T* __restrict__ xm, int center,
+                                                 int symmetric, T* __restrict__ C, int64_t ldc) {
     // 64 consecutive M indices per block (coalesced partial reads) x 4 interleaved groups of K-splits; the four group
     // sums are combined in a fixed order, so the result does not depend on scheduling
     __shared__ T red[4][64];
@@ -215,6 +238,24 @@ __global__ void gram_reduce_kernel(const T* __restrict__ part, int nsplit, int64
     if (center) s -= xm[mcols[a]] * xm[ncols[b]];
     C[rp + cp * ldc] = s;
     if (symmetric) C[cp + rp * ldc] = s;
+}
+
+template <class T>
+__global__ void gram_reduce_kernel(const T* __restrict__ part, int nsplit, int64_t Mpad, int64_t Npad, int32_t M,
+                                   int32_t N, const int32_t* __restrict__ mcols, const int32_t* __restrict__ ncols,
+                                   int32_t m_pos0, int32_t n_pos0, const T* __restrict__ xm, int center,
+                                   int symmetric, T* __restrict__ C, int64_t ldc) {
+    gram_reduce_body<T>(part, nsplit, Mpad, Npad, M, N, mcols, ncols, m_pos0, n_pos0, xm, center, symmetric, C, ldc);
+}
+
+// grid (2, 128, count): block z of the batch into C_base + dst[z]
+template <class T>
+__global__ void gram_batch_reduce_kernel(const T* __restrict__ part, int nsplit, GramBatch b,
+                                         const int32_t* __restrict__ cols_base, const T* __restrict__ xm, int center,
+                                         T* __restrict__ C_base, int64_t ldc) {
+    const int z = blockIdx.z;
+    gram_reduce_body<T>(part + int64_t(z) * nsplit * BM * 128, nsplit, BM, 128, b.m[z], b.nn[z], cols_base + b.moff[z],
+                        cols_base + b.noff[z], 0, 0, xm, center, 0, C_base + b.dst[z], ldc);
 }
 
 // ---- symmetric diagonal block of <= 64 or <= 128 columns (the panel engine's blocks) --------------------------------------------
@@ -608,6 +649,48 @@ void gram_launch(Acc acc, bool vecok, const T* w, const int32_t* mcols, int32_t 
 
 void set_small_gram_workgroups(int wgs) { t_small_gram_wgs = wgs < 1 ? 512 : wgs; }
 
+int64_t gram_batch_work_elems(int64_t n, int count) {
+    const int keep = t_small_gram_wgs;
+    t_small_gram_wgs = 512; // the buffer is sized for the widest spread
+    int ns;
+    int64_t kc;
+    syrk_batch_shape(n, count, ns, kc);
+    t_small_gram_wgs = keep;
+    return int64_t(count) * ns * BM * 128;
+}
+
+template <class T, class Acc>
+void gram_batch_launch(Acc acc, bool vecok, const T* w, const int32_t* cols_base, const GramBatch& b, int64_t n, const T* xm,
+                       bool center, T* C_base, int64_t ldc, T* work, hipStream_t s) {
+    if (b.count <= 0) return;
+    int nsplit;
+    int64_t kchunk;
+    syrk_batch_shape(n, b.count, nsplit, kchunk);
+    const dim3 grid(unsigned(((nsplit + 7) / 8) * 8), unsigned(b.count));
+    if (vecok)
+        hipLaunchKernelGGL((gram_batch_kernel<T, Acc, true>), grid, dim3(GT), 0, s, acc, w, cols_base, b, n, kchunk, work,
+                           int32_t(nsplit));
+    else
+        hipLaunchKernelGGL((gram_batch_kernel<T, Acc, false>), grid, dim3(GT), 0, s, acc, w, cols_base, b, n, kchunk, work,
+                           int32_t(nsplit));
+    hipLaunchKernelGGL((gram_batch_reduce_kernel<T>), dim3(2, 128, unsigned(b.count)), dim3(256), 0, s, work, nsplit, b,
+                       cols_base, xm, center ? 1 : 0, C_base, ldc);
+}
+
+template <class T>
+void launch_gram_batch(const DenseView<T>& X, const T* w, const int32_t* cols_base, const GramBatch& b, const T* xm_by_col,
+                       bool center, T* C_base, int64_t ldc, T* work, hipStream_t s) {
+    DenseAcc<T> acc{X.X, X.ld};
+    const bool vecok = (X.ld % VecOf<T>::N == 0) && ((reinterpret_cast<uintptr_t>(X.X) % 16) == 0);
+    gram_batch_launch<T, DenseAcc<T>>(acc, vecok, w, cols_base, b, X.n, xm_by_col, center, C_base, ldc, work, s);
+}
+template <class T>
+void launch_gram_batch_snp(const SnpView& X, const T* impute, const T* w, const int32_t* cols_base, const GramBatch& b,
+                           const T* xm_by_col, bool center, T* C_base, int64_t ldc, T* work, hipStream_t s) {
+    SnpAcc<T> acc{X.bits, X.ldb, impute};
+    gram_batch_launch<T, SnpAcc<T>>(acc, true, w, cols_base, b, X.n, xm_by_col, center, C_base, ldc, work, s);
+}
+
 int64_t syrk_batch_work_elems(int64_t n, int count) {
     int nsplit;
     int64_t kchunk;
@@ -710,6 +793,10 @@ INST(double)
 INST(float)
 #undef INST
 #define INST2(T)                                                                                                       \
+    template void launch_gram_batch<T>(const DenseView<T>&, const T*, const int32_t*, const GramBatch&, const T*, bool, T*, \
+                                       int64_t, T*, hipStream_t);                                                      \
+    template void launch_gram_batch_snp<T>(const SnpView&, const T*, const T*, const int32_t*, const GramBatch&, const T*, \
+                                           bool, T*, int64_t, T*, hipStream_t);                                        \
     template void launch_syrk_batch<T>(const DenseView<T>&, const T*, const int32_t*, const SyrkBatch&, const T*, bool, T*, \
                                        int64_t, T*, hipStream_t);                                                      \
     template void launch_syrk_batch_snp<T>(const SnpView&, const T*, const T*, const int32_t*, const SyrkBatch&, const T*, \

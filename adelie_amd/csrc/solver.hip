@@ -533,7 +533,7 @@ struct Solver {
             open_side();
             // Gaussian look-ahead passes: a build whose block the chain reaches late in the pass is confined to few CUs, so
             // that the fused launches (whole-CU workgroups) running meanwhile never wait for one (see set_small_gram_workgroups)
-            set_small_gram_workgroups((side && side_wgs > 0 && !is_glm() && j0 >= side_wgs_from) ? side_wgs : (side ? side_wgs_glm : 512));
+            set_small_gram_workgroups((side && side_wgs > 0 && !is_glm() && j0 >= side_wgs_from) ? side_wgs : 512);
             if (multi()) gram_block(cur_w, cols_of(j0), nb_of(j0), cur_xm, pool + size_t(j0) * SL * SL, sidx);
             else gram_block_batch(cur_w, cols_base, sb, cur_xm, pool + size_t(j0) * SL * SL, sidx);
             if (rot_on)
@@ -558,13 +558,12 @@ struct Solver {
     bool fuse_reduce = false;     // look-ahead passes: the solve sums the previous launch's slice partials itself instead of a panel_reduce launch (hook ADELIE_HIP_FUSE_REDUCE=1; measured slower: 3.08 vs 3.20 paths/s, the solve's longer prologue lengthens the fused launch by more than the reduce launch cost)
     DevBuf<T> d_part2;
     size_t part2_half = 0;
-    int side_cu_reserve = 0;      // IRLS: CUs kept free of side-stream builds for the chain's one-workgroup solves (hook ADELIE_HIP_SIDE_CU_RESERVE)
-    int side_cu_pattern = 0;      // which mask bits: 0 the first R, 1 every 8th, 2 spread evenly (ADELIE_HIP_SIDE_CU_PATTERN)
-    int side_wgs_glm = 512;       // workgroups per build launch on a masked stream: two per CU it may use
     int side_wgs = 0;             // >0: confine side-stream builds of Gaussian look-ahead passes to this many workgroups (hook ADELIE_HIP_SIDE_WGS; measured: 56 -> 2.69, 112 -> 2.99 vs 3.17 paths/s unconfined: the chain waits for the slower builds)
     int side_wgs_from = 4;        // ... for blocks the chain reaches at this position of the pass or later (ADELIE_HIP_SIDE_WGS_FROM)
     std::vector<int> stale;
     int batch_blocks = 8; // diagonal blocks per build launch (tuning hook ADELIE_HIP_BATCH_BLOCKS, 1..16)
+    int cross_batch = 8;  // cross blocks per build launch (hook ADELIE_HIP_CROSS_BATCH, 1 = one gram launch per block)
+    std::vector<int> stale_x;
     // host-mapped end-of-pass report (state + sequence number), see CdBlkParams::host_st
     struct PassReport { CdBlkState<T> st; int32_t seq; int32_t pad[15]; };
     PassReport* h_report = nullptr;
@@ -609,6 +608,61 @@ struct Solver {
         const int SL = cd_block_size();
         x_ev.assign(size_t(nblk), nullptr);
         bool first = true;
+        if (!multi() && cross_batch > 1) {
+            // several stale cross blocks per launch (gram_batch_kernel): their K-splits share one round over the chip, so the
+            // split-K partials written and re-read per block shrink with the batch (134 MB for a block built alone)
+            std::vector<int>& sx = stale_x;
+            sx.clear();
+            for (int j = 1; j < nblk; ++j) {
+                const XKey& k = tab[size_t(j)];
+                if (!(k.nb_prev == nb_of(j - 1) && k.nb == nb_of(j) && k.ver == w_version)) sx.push_back(j);
+            }
+            const bool side = side_grams && st2 != nullptr;
+            hipStream_t gs = side ? st2 : st;
+            const int32_t* cols_base = cols_of(0);
+            for (size_t i = 0; i < sx.size();) {
+                const size_t k = std::min(sx.size(), i + size_t(i == 0 ? std::min(cross_batch, 4) : cross_batch));
+                if (side && first) {
+                    hipEvent_t e0 = next_event();
+                    AHIP_CHECK(hipEventRecord(e0, st));
+                    AHIP_CHECK(hipStreamWaitEvent(st2, e0, 0));
+                    first = false;
+                }
+                GramBatch gb{};
+                gb.count = int32_t(k - i);
+                for (size_t t = i; t < k; ++t) {
+                    const int j = sx[t];
+                    gb.moff[t - i] = int32_t(cols_of(j) - cols_base);
+                    gb.m[t - i] = nb_of(j);
+                    gb.noff[t - i] = int32_t(cols_of(j - 1) - cols_base);
+                    gb.nn[t - i] = nb_of(j - 1);
+                    gb.dst[t - i] = int64_t(j) * SL * SL;
+                }
+                T* work = (side ? d_work_gram2 : d_work_gram)
+                              .reserve(size_t(std::max<int64_t>(gram_batch_work_elems(n, gb.count), syrk_work_elems(n, 128))));
+                t_gram.begin(gs);
+                if (dense()) launch_gram_batch<T>(D->dense<T>(), cur_w, cols_base, gb, cur_xm, intercept, xpool, SL, work, gs);
+                else launch_gram_batch_snp<T>(D->snp(), static_cast<const T*>(D->impute), cur_w, cols_base, gb, cur_xm, intercept,
+                                              xpool, SL, work, gs);
+                t_gram.end(gs);
+                hipEvent_t e = nullptr;
+                if (side) {
+                    e = next_event();
+                    AHIP_CHECK(hipEventRecord(e, st2));
+                }
+                for (size_t t = i; t < k; ++t) {
+                    const int j = sx[t];
+                    XKey& key = tab[size_t(j)];
+                    key.nb_prev = nb_of(j - 1); key.nb = nb_of(j); key.ver = w_version;
+                    x_ev[size_t(j)] = e;
+                    cnt.gram_flops += 2.0 * double(n) * double(nb_of(j)) * double(nb_of(j - 1));
+                    cnt.n_gram_col_reads += nb_of(j) + nb_of(j - 1);
+                    ++n_cross_blocks;
+                }
+                i = k;
+            }
+            return;
+        }
         for (int j = 1; j < nblk; ++j) {
             const int nbp = nb_of(j - 1), nb = nb_of(j);
             XKey& k = tab[size_t(j)];
@@ -624,7 +678,7 @@ struct Solver {
             T* work = (side ? d_work_gram2 : d_work_gram)
                           .reserve(size_t(std::max<int64_t>(gram_work_elems(n, SL, SL), syrk_work_elems(n, 128))));
             T* Cx = xpool + size_t(j) * SL * SL;
-            set_small_gram_workgroups((side && side_wgs > 0 && !is_glm() && j >= side_wgs_from) ? side_wgs : (side ? side_wgs_glm : 512));
+            set_small_gram_workgroups((side && side_wgs > 0 && !is_glm() && j >= side_wgs_from) ? side_wgs : 512);
             t_gram.begin(gs);
             if (multi()) {
                 // Gram of the two blocks' distinct features, expanded to view columns (zero between different responses);
@@ -1422,31 +1476,9 @@ struct Solver {
             dscr_ver.assign(maxblk, 0); dact_ver.assign(maxblk, 0);
             panel_maxblk = maxblk;
         }
-        auto make_side = [&](hipStream_t* out) {
-            // side_cu_reserve > 0 (A/B hook): the build streams are confined to all but that many CUs by a queue CU mask and size
-            // their grids for the CUs they have, so that the chain's kernels find CUs without build waves.  Measured: it works
-            // as intended (config 4, 64 CUs reserved: blk_solve 54 -> 14 us) and buys nothing.
-            if (side_cu_reserve > 0) {
-                int ncu = 0;
-                AHIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, D->device));
-                std::vector<uint32_t> mask(size_t((ncu + 31) / 32), 0u);
-                for (int c = 0; c < ncu; ++c) mask[size_t(c / 32)] |= 1u << (c % 32);
-                const int stride = side_cu_pattern == 1 ? 8 : (side_cu_pattern == 2 ? ncu / std::max(1, side_cu_reserve) : 1);
-                for (int r = 0; r < side_cu_reserve && r * stride < ncu; ++r) {
-                    const int c = r * stride;
-                    mask[size_t(c / 32)] &= ~(1u << (c % 32));
-                }
-                if (hipExtStreamCreateWithCUMask(out, uint32_t(mask.size()), mask.data()) == hipSuccess) {
-                    side_wgs_glm = 2 * (ncu - side_cu_reserve);
-                    return;
-                }
-                (void)hipGetLastError();
-            }
-            AHIP_CHECK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
-        };
-        if (side_grams && !st2) make_side(&st2);
+        if (side_grams && !st2) AHIP_CHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
         for (int k = 0; side_grams && k < std::min(n_side - 1, kMaxExtra); ++k)
-            if (!st_x[k]) make_side(&st_x[k]);
+            if (!st_x[k]) AHIP_CHECK(hipStreamCreateWithFlags(&st_x[k], hipStreamNonBlocking));
         if (use_report && !h_report) {
             void* hp = nullptr;
             void* dp = nullptr;
@@ -2918,9 +2950,8 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_FUSE_REDUCE")) fuse_reduce = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_SIDE_WGS")) side_wgs = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("ADELIE_HIP_SIDE_WGS_FROM")) side_wgs_from = std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("ADELIE_HIP_SIDE_CU_RESERVE")) side_cu_reserve = std::max(0, std::min(128, std::atoi(e)));
-        if (const char* e = std::getenv("ADELIE_HIP_SIDE_CU_PATTERN")) side_cu_pattern = std::atoi(e);
         if (const char* e = std::getenv("ADELIE_HIP_BATCH_BLOCKS")) batch_blocks = std::max(1, std::min(int(SyrkBatch::MAX), std::atoi(e)));
+        if (const char* e = std::getenv("ADELIE_HIP_CROSS_BATCH")) cross_batch = std::max(1, std::min(int(GramBatch::MAX), std::atoi(e)));
         if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {
             panel_bsz = std::atoi(e);
             if (panel_bsz != 32 && panel_bsz != 64 && panel_bsz != 128) panel_bsz = 0;

@@ -389,7 +389,7 @@ def test_exit_cond_on_panel_engine(hip, monkeypatch):
 
 @pytest.mark.parametrize("hook,values", [("ADELIE_HIP_BATCH_BLOCKS", ["1", "3", "16"]), ("ADELIE_HIP_PREBUILD", ["0", "1"]),
                                          ("ADELIE_HIP_GROUP_ROT", ["0", "1"]), ("ADELIE_HIP_FUSE_REDUCE", ["0", "1"]),
-                                         ("ADELIE_HIP_SIDE_WGS", ["0", "24"])])
+                                         ("ADELIE_HIP_SIDE_WGS", ["0", "24"]), ("ADELIE_HIP_CROSS_BATCH", ["1", "3", "16"])])
 def test_round2_engine_hooks_do_not_change_results(hip, oracle, monkeypatch, hook, values):
     """The build / solve variants added in round 2 (batched diagonal-block builds, IRLS screen-block prebuild, group solve in
     eigen-coordinates, reduce fused into the solve, confined side builds) are scheduling / association changes only: every

@@ -295,6 +295,20 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             gT[i] = s1; bT[i] = s2; xmT[i] = s3;
         }
     }
+    // per-group constants of the sequential loop, one group per thread (the correction partials are consumed: their space is
+    // free): the largest b_i = A_i + l2 (start of the root find), 1 / q (convergence measure), dbeta_tol * sqrt(q) (change test)
+    T* gbmx = corr;
+    T* grq = corr + GBLK;
+    T* gsq = corr + 2 * GBLK;
+    if (tid < ngrp) {
+        const int o = go, q = gqv;
+        const T l2p = p.l2 * penv;
+        T mx = T(0);
+        for (int t = 0; t < q; ++t) { const T b = AB[o + t] + l2p; mx = b > mx ? b : mx; }
+        gbmx[tid] = mx;
+        grq[tid] = T(1) / T(q);
+        gsq[tid] = p.dbeta_tol * sqrt(T(q));
+    }
     __syncthreads();
     if (wv != 0) return;
     __builtin_amdgcn_s_setprio(3);
@@ -315,9 +329,25 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
     int64_t n_upd = st->n_updates;
     T rs_acc = T(0), xs_acc = T(0); // lane partials of the rsq / resid_sum updates of the groups with q > 1 (summed once, below)
 
+    // operands of a group that do not depend on the groups before it (layout, penalty, variances, old coefficients) are read
+    // one group ahead, so that their LDS latency is not on the chain
+    int o_n = 0, q_n = 0, ss_n = 0;
+    T pk_n = T(0), A_n = T(0), ako_n = T(0);
+    auto prefetch = [&](int kk) {
+        if (kk < ngrp) {
+            o_n = goff[kk]; q_n = gq[kk]; ss_n = gss[kk];
+            pk_n = gpenB[kk];
+            const bool onn = lane < q_n;
+            A_n = onn ? AB[o_n + lane] : T(0);
+            ako_n = onn ? bT[o_n + lane] : T(0);
+        }
+    };
+    prefetch(0);
     for (int k = 0; k < ngrp && status == CD_OK; ++k) {
-        const int o = goff[k], q = gq[k], ss = gss[k];
-        const T pk = gpenB[k];
+        const int o = o_n, q = q_n, ss = ss_n;
+        const T pk = pk_n;
+        const T A_c = A_n, ako_c = ako_n;
+        prefetch(k + 1);
         const T l1p = p.l1 * pk, l2p = p.l2 * pk;
         bool changed = false;
         T d_reg = T(0); // q <= 64: lane t holds the rotated change of the group's value t (q == 1: every lane)
@@ -339,8 +369,8 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             }
         } else if (q <= 64) {
             const bool on = lane < q;
-            const T A_r = on ? AB[o + lane] : T(0);
-            const T ako_r = on ? bT[o + lane] : T(0);
+            const T A_r = A_c;
+            const T ako_r = ako_c;
             const T gk_r = on ? gT[o + lane] + A_r * ako_r : T(0); // gk_t += A * ak_old_t   (pin_naive:139-140)
             // newton_solver (bcd/unconstrained/newton.hpp:35-142): v = gk_t, L = A
             const T nrm2 = group_sum(on ? gk_r * gk_r : T(0), q);
@@ -361,17 +391,7 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
                 // sequential) evaluations; an isotropic block (all b_i equal) starts AT its root.  Same stopping test, same
                 // error when newton_tol is unreachable.
                 {
-                    T bmx = on ? b1 : T(0);
-                    if (q <= 16) {
-                        T o1 = dpp_move<0xB1>(bmx); bmx = o1 > bmx ? o1 : bmx;
-                        o1 = dpp_move<0x4E>(bmx); bmx = o1 > bmx ? o1 : bmx;
-                        o1 = dpp_move<0x141>(bmx); bmx = o1 > bmx ? o1 : bmx;
-                        o1 = dpp_move<0x140>(bmx); bmx = o1 > bmx ? o1 : bmx;
-                        bmx = first_lane(bmx);
-                    } else {
-#pragma unroll
-                        for (int off = 32; off > 0; off >>= 1) { const T o1 = __shfl_xor(bmx, off, 64); bmx = o1 > bmx ? o1 : bmx; }
-                    }
+                    const T bmx = gbmx[k]; // max_i b_i, from the prologue
                     if (bmx > T(0)) h = (sqrt(nrm2) - l1p) / bmx;
                 }
                 auto step = [&](T hh) {
@@ -412,9 +432,9 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             }
             dn = group_sum(dn, q);
             c1 = group_sum(c1, q);
-            if (!(sqrt(dn) <= p.dbeta_tol * sqrt(T(q)))) {
+            if (!(sqrt(dn) <= gsq[k])) {
                 changed = true;
-                c1 /= T(q);
+                c1 *= grq[k];
                 cm = c1 > cm ? c1 : cm;
                 rs_acc += rs;
                 if (on) {

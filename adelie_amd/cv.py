@@ -176,6 +176,9 @@ def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio
         shares = getattr(X, "_kind", None) == "dense" and not getattr(glm, "is_multi", False)
         nc = n_concurrent if n_concurrent is not None else ((8 if shares else 3) if can_alias else 1)
         nc = max(1, min(int(nc), len(my_folds))) if can_alias else 1
+        cons = grpnet_params.get("constraints")
+        if cons is not None and any(c is not None for c in cons):
+            nc = 1  # the constraint objects carry their multipliers between calls: folds sharing them run one at a time
 
         def one(Xa, fold):
             b, e = ranges[fold]

@@ -214,6 +214,16 @@ def test_constraint_errors(oracle):
         ad.grpnet(X, ad.glm.multigaussian(y2), constraints=[two] + [None] * 7, progress_bar=False)
 
 
+def test_cv_grpnet_passes_constraints_to_every_fold(oracle):
+    d = make_gaussian(150, 20, seed=2)
+    cons = [constraint.lower(np.zeros(1)) for _ in range(20)]
+    kw = dict(n_folds=3, seed=1, lmda_path_size=8, progress_bar=False)
+    a = ad.cv_grpnet(oracle.dense(d["X"]), ad.glm.gaussian(d["y"]), constraints=cons, **kw)
+    b = ad.cv_grpnet(oracle.dense(d["X"]), ad.glm.gaussian(d["y"]), **kw)
+    assert a.losses.shape == b.losses.shape == (3, 8)
+    assert np.abs(a.losses - b.losses).max() > 1e-6  # the non-negativity constraint changes the fits
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # HIP vs oracle
 # --------------------------------------------------------------------------------------------------------------------

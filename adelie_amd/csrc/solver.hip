@@ -581,6 +581,7 @@ struct Solver {
                 (void)hipStreamDestroy(st_x[k]);
             }
 
+        if (spec_ev) (void)hipEventDestroy(spec_ev);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         for (hipEvent_t e : pre_pool) (void)hipEventDestroy(e);
     }
@@ -1533,7 +1534,8 @@ struct Solver {
         bs.active_size = sc.active_size;
         bs.status = CD_OK;
         bs.nz = 0;
-        d_blk.upload(&bs, 1, st);
+        const int mode = spec_mode; // 1: enqueue one (speculative) active pass and return; 2: that pass is already in flight
+        if (mode != 2) d_blk.upload(&bs, 1, st);
         CdBlkParams<T> bp{};
         bp.nv = cp.nv; bp.vars = cp.vars; bp.xmean = cp.xmean; bp.spen = cp.spen;
         bp.beta = cp.beta; bp.is_active = cp.is_active; bp.active_set = cp.active_set;
@@ -1571,8 +1573,9 @@ struct Solver {
             d_part.reserve(size_t(2 * panel_part_elems(n) + 2048));
             part2_half = size_t(panel_part_elems(n));
             d_part2.reserve(2 * part2_half);
-            pending_slot = -1;
+            if (mode != 2) pending_slot = -1; // (mode 2: the pass in flight leaves its last block's changes pending)
         }
+        bool no_wait = false;
         auto pass_la = [&](bool screen_pass) -> T {
             const int count = screen_pass ? cp.nv : asz;
             if (count <= 0) return T(0);
@@ -1673,6 +1676,7 @@ struct Solver {
             AHIP_CHECK(hipGetLastError());
             cnt.n_panel_blocks += nblk;
             t_enq += sw_enq.elapsed();
+            if (no_wait) { spec_blocks = nblk; return T(0); }
             sw_enq.start();
             wait_pass_state(bs);
             t_wait += sw_enq.elapsed();
@@ -1752,10 +1756,32 @@ struct Solver {
         };
         // short passes gain nothing from the look-ahead (its first two blocks run as in the plain form) and would still pay
         // for the cross blocks
+        bool resume_first = mode == 2;
         auto pass = [&](bool screen_pass) -> T {
+            if (resume_first) { // the first active pass of this fit was enqueued behind the previous lambda's sweep
+                resume_first = false;
+                Stopwatch sw_w;
+                sw_w.start();
+                wait_pass_state(bs);
+                t_wait += sw_w.elapsed();
+                status = bs.status;
+                asz = bs.active_size;
+                return bs.cm;
+            }
             const int count = screen_pass ? cp.nv : asz;
             return (la && (count + B - 1) / B >= la_min_blocks) ? pass_la(screen_pass) : pass_plain(screen_pass);
         };
+        if (mode == 1) {
+            spec_enqueued = false;
+            if (la && (asz + B - 1) / B >= la_min_blocks) {
+                const int64_t cols0 = cnt.n_panel_cols;
+                no_wait = true;
+                pass_la(false);
+                spec_cols = cnt.n_panel_cols - cols0;
+                spec_enqueued = true;
+            }
+            return;
+        }
         while (status == CD_OK) {
             while (status == CD_OK) { // solve_active, pin_naive:173-215
                 ++iters;
@@ -2191,7 +2217,18 @@ struct Solver {
         poll_mid();
         const idx ns = idx(screen_set.size());
         FitOut<T> o;
-        AHIP_CHECK(hipMemcpyAsync(d_beta0.p, d_beta.p, size_t(nv) * sizeof(T), hipMemcpyDeviceToDevice, st));
+        bool resume = false;
+        if (spec_active) {
+            resume = lm == spec_lm && r_dev == d_r.p && !is_glm() && all_scalar && nv >= spec_nv && panel_mode() &&
+                     active_set_size == spec_asz;
+            if (!resume) spec_rollback();
+        }
+        if (!resume) {
+            AHIP_CHECK(hipMemcpyAsync(d_beta0.p, d_beta.p, size_t(nv) * sizeof(T), hipMemcpyDeviceToDevice, st));
+        } else if (nv > spec_nv) { // the screen values appended since: beta0 = beta at fit entry for them too
+            AHIP_CHECK(hipMemcpyAsync(d_beta0.p + spec_nv, d_beta.p + spec_nv, size_t(nv - spec_nv) * sizeof(T),
+                                      hipMemcpyDeviceToDevice, st));
+        }
         CdScalars<T> sc{};
         sc.rsq = rsq_in;
         sc.resid_sum = rsum_io;
@@ -2232,7 +2269,12 @@ struct Solver {
         Stopwatch sw;
         sw.start();
         if (nv > 0 && panel_mode()) {
-            if (all_scalar) run_panel_passes(cp, sc, r_dev);
+            if (all_scalar) {
+                spec_mode = resume ? 2 : 0;
+                spec_active = false; // consumed (or never there)
+                struct ModeGuard { int& m; ~ModeGuard() { m = 0; } } mode_guard{spec_mode};
+                run_panel_passes(cp, sc, r_dev);
+            }
             else run_group_panel_passes(cp, sc, r_dev);
             // Gaussian: the residual is final and current on the device -> enqueue the invariance sweep of this lambda now,
             // so that it runs while the host does the post-fit bookkeeping below (otherwise the GPU idles ~0.2 ms per lambda)
@@ -2296,16 +2338,42 @@ struct Solver {
         rsum_io = sc.resid_sum;
         o.rsq = sc.rsq;
         d_beta.download(screen_beta.data(), size_t(nv), st);
-        if (active_set_size > old_active) {
-            std::vector<int32_t> act(active_set_size - old_active);
-            d_actset.download(act.data(), act.size(), st, old_active);
-            sync();
-            for (size_t i = 0; i < act.size(); ++i) {
-                active_set[old_active + i] = act[i];
-                screen_is_active[act[i]] = 1;
+        std::vector<int32_t> act(active_set_size > old_active ? active_set_size - old_active : 0);
+        if (!act.empty()) d_actset.download(act.data(), act.size(), st, old_active);
+        // everything this fit hands back is enqueued; behind it, the first active pass of the next lambda (see spec_enabled)
+        bool waited = false;
+        if (spec_enabled && spec_next_lm > T(0) && inv_prelaunched && inv_prelaunched_lm == lm && all_scalar && !cons_on &&
+            lookahead && nv > 0 && panel_mode() && r_dev == d_r.p) {
+            if (!spec_ev) AHIP_CHECK(hipEventCreateWithFlags(&spec_ev, hipEventDisableTiming));
+            AHIP_CHECK(hipEventRecord(spec_ev, st));
+            d_r_snap.reserve(size_t(n));
+            AHIP_CHECK(hipMemcpyAsync(d_beta0.p, d_beta.p, size_t(nv) * sizeof(T), hipMemcpyDeviceToDevice, st));
+            AHIP_CHECK(hipMemcpyAsync(d_r_snap.p, d_r.p, size_t(n) * sizeof(T), hipMemcpyDeviceToDevice, st));
+            CdParams<T> cp2 = cp;
+            cp2.lmda = spec_next_lm;
+            CdScalars<T> sc2{};
+            sc2.rsq = sc.rsq;
+            sc2.resid_sum = sc.resid_sum;
+            sc2.active_size = sc.active_size;
+            spec_mode = 1;
+            {
+                struct ModeGuard { int& m; ~ModeGuard() { m = 0; } } mode_guard{spec_mode};
+                run_panel_passes(cp2, sc2, r_dev);
             }
-        } else {
-            sync();
+            if (spec_enqueued) {
+                spec_active = true;
+                spec_lm = spec_next_lm;
+                spec_nv = nv;
+                spec_asz = active_set_size;
+                ++n_spec;
+            }
+            AHIP_CHECK(hipEventSynchronize(spec_ev));
+            waited = true;
+        }
+        if (!waited) sync();
+        for (size_t i = 0; i < act.size(); ++i) {
+            active_set[old_active + i] = act[i];
+            screen_is_active[act[i]] = 1;
         }
         // pin_naive:359-394: active groups sorted by design column.  The active list only ever grows by appending, so the
         // sorted order is kept across fits and the newcomers are merged in (O(a + m log m) instead of a full sort per fit).
@@ -2635,13 +2703,44 @@ struct Solver {
     // update_invariance_f: solver_gaussian_naive.hpp:377-393 / solver_glm_naive.hpp:495-503, + update_abs_grad
     bool prelaunch_sweep = true, inv_prelaunched = false;
     T inv_prelaunched_lm = 0;
+    // ---- speculative first active-set pass of the NEXT lambda (Gaussian lasso on the look-ahead panel engine) ----
+    // Between the invariance sweep of lambda_k and the first kernel of the fit at lambda_{k+1} the host checks KKT, screens,
+    // appends the new screen groups and computes their variances: 0.2-0.4 ms per lambda with the GPU idle.  The fit at
+    // lambda_{k+1} always begins with a pass over the active set as lambda_k left it (pin_naive:173-215), which depends on
+    // none of that host work, so it is enqueued right behind the sweep and the next fit picks its result up instead of
+    // launching it.  Same operations in the same order: bit-identical paths.  If the next fit turns out to be something else
+    // (KKT failed: refit at lambda_k; early exit; the caller reads the live state) the coefficients and the residual are put
+    // back from the copies taken before the pass.
+    bool spec_enabled = true;    // A/B hook ADELIE_HIP_SPECULATE=0
+    T spec_next_lm = 0;          // set by solve() before a fit: the lambda that follows if KKT passes (0: none)
+    bool spec_active = false;    // a speculative pass is in flight / done and not yet consumed
+    T spec_lm = 0;
+    idx spec_nv = 0;
+    size_t spec_asz = 0;
+    int spec_mode = 0;           // read by run_panel_passes: 1 = enqueue one active pass and return, 2 = its first pass is in flight
+    bool spec_enqueued = false;
+    int64_t spec_blocks = 0, spec_cols = 0, n_spec = 0, n_spec_rollback = 0;
+    DevBuf<T> d_r_snap;
+    hipEvent_t spec_ev = nullptr;
+    void spec_rollback() {
+        if (!spec_active) return;
+        sync();
+        AHIP_CHECK(hipMemcpyAsync(d_beta.p, d_beta0.p, size_t(spec_nv) * sizeof(T), hipMemcpyDeviceToDevice, st));
+        AHIP_CHECK(hipMemcpyAsync(d_r.p, d_r_snap.p, size_t(n) * sizeof(T), hipMemcpyDeviceToDevice, st));
+        sync();
+        pending_slot = -1;
+        cnt.n_panel_blocks -= spec_blocks;
+        cnt.n_panel_cols -= spec_cols;
+        spec_active = false;
+        ++n_spec_rollback;
+    }
     void update_invariance(T lm) {
         lmda = lm;
         ++cnt.n_sweeps;
         if (inv_prelaunched) { // enqueued at the end of the fit (pin_solve); the fit's own synchronisation covered it
             inv_prelaunched = false;
             if (inv_prelaunched_lm == lm) {
-                sync();
+                if (!spec_active) sync(); // (pin_solve waited for the downloads; a full sync would wait for the speculative pass)
                 grad_valid = true;
                 return;
             }
@@ -2785,7 +2884,9 @@ struct Solver {
                 screen_f(lmda_curr, kkt_passed, n_new_active);
                 benchmark_screen.push_back(sw.elapsed());
                 t_host_screen += benchmark_screen.back();
+                spec_next_lm = (lmda_path_idx + 1 < L) ? lmda_path[lmda_path_idx + 1] : T(0);
                 auto fo = fit_f(lmda_curr);
+                spec_next_lm = T(0);
                 benchmark_fit_screen.push_back(fo.t_screen);
                 benchmark_fit_active.push_back(fo.t_active);
                 sw.start();
@@ -2814,8 +2915,8 @@ struct Solver {
     // pull the device-resident invariants back into the host mirrors that the result accessors expose
     void finalize() {
         if (std::getenv("ADELIE_HIP_TRACE_ENQ"))
-            std::fprintf(stderr, "[enq] panel passes: host enqueue %.1f ms, host wait %.1f ms, blocks %lld\n", t_enq * 1e3,
-                         t_wait * 1e3, (long long)cnt.n_panel_blocks);
+            std::fprintf(stderr, "[enq] panel passes: host enqueue %.1f ms, host wait %.1f ms, blocks %lld, speculated %lld (rolled back %lld)\n",
+                         t_enq * 1e3, t_wait * 1e3, (long long)cnt.n_panel_blocks, (long long)n_spec, (long long)n_spec_rollback);
         t_sweep.collect(); t_gram.collect(); t_cd.collect(); t_axpy.collect(); t_step.collect();
         if (d_grp_dbg.p) {
             sync();
@@ -2846,6 +2947,7 @@ struct Solver {
     // host mirrors of the device-resident invariants (grad, resid, eta, screen_beta, screen_X_means, screen_vars); also what
     // adelie_hip_result_sync does for the live state inside a poll callback
     void download_invariants() {
+        spec_rollback();
         d_grad.download(grad.data(), size_t(p), st);
         if (!cov_mode) d_r.download(resid.data(), size_t(n), st);
         if (is_glm()) d_eta.download(eta.data(), size_t(n), st);
@@ -2951,6 +3053,7 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_SIDE_WGS")) side_wgs = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("ADELIE_HIP_SIDE_WGS_FROM")) side_wgs_from = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("ADELIE_HIP_BATCH_BLOCKS")) batch_blocks = std::max(1, std::min(int(SyrkBatch::MAX), std::atoi(e)));
+        if (const char* e = std::getenv("ADELIE_HIP_SPECULATE")) spec_enabled = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_CROSS_BATCH")) cross_batch = std::max(1, std::min(int(GramBatch::MAX), std::atoi(e)));
         if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {
             panel_bsz = std::atoi(e);
@@ -3308,6 +3411,8 @@ struct Result : ResultBase {
             case ADELIE_HIP_S_N_PANEL_GRAMS: return double(s.cnt.n_panel_grams);
             case ADELIE_HIP_S_N_PANEL_COLS: return double(s.cnt.n_panel_cols);
             case ADELIE_HIP_S_N_IRLS_SCREEN_COLS: return double(s.cnt.n_irls_screen_cols);
+            case ADELIE_HIP_S_N_SPECULATED: return double(s.n_spec);
+            case ADELIE_HIP_S_N_SPEC_ROLLBACKS: return double(s.n_spec_rollback);
             case ADELIE_HIP_S_T_PANEL_STEP_MS: return s.t_step.ms;
             case ADELIE_HIP_S_N_PANEL_STEP_LAUNCHES: return double(s.t_step.launches);
             case ADELIE_HIP_S_T_SWEEP_MS: return s.t_sweep.ms;

@@ -362,6 +362,8 @@ enum adelie_hip_scalar {
     ADELIE_HIP_S_N_PANEL_COLS, /* design columns streamed by the panel steps (gradient + residual update) */
     ADELIE_HIP_S_N_IRLS_SCREEN_COLS, /* sum over IRLS iterations of the screened columns (their means and variances are
                                         recomputed under every iteration's weights: the IRLS term of SURVEY.md 8d's B_path) */
+    ADELIE_HIP_S_N_SPECULATED,       /* fits whose first active-set pass was enqueued behind the previous lambda's sweep */
+    ADELIE_HIP_S_N_SPEC_ROLLBACKS,   /* ... of which were taken back (KKT failure, early exit, live-state read) */
     /* HIP-event time (ms) of the device phases on the design's stream, summed over the solve, and launch counts */
     ADELIE_HIP_S_T_SWEEP_MS = 80, ADELIE_HIP_S_T_GRAM_MS, ADELIE_HIP_S_T_CD_MS, ADELIE_HIP_S_T_AXPY_MS,
     ADELIE_HIP_S_N_SWEEP_LAUNCHES, ADELIE_HIP_S_N_GRAM_LAUNCHES, ADELIE_HIP_S_T_HOST_SCREEN_MS,

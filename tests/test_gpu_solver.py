@@ -389,7 +389,8 @@ def test_exit_cond_on_panel_engine(hip, monkeypatch):
 
 @pytest.mark.parametrize("hook,values", [("ADELIE_HIP_BATCH_BLOCKS", ["1", "3", "16"]), ("ADELIE_HIP_PREBUILD", ["0", "1"]),
                                          ("ADELIE_HIP_GROUP_ROT", ["0", "1"]), ("ADELIE_HIP_FUSE_REDUCE", ["0", "1"]),
-                                         ("ADELIE_HIP_SIDE_WGS", ["0", "24"]), ("ADELIE_HIP_CROSS_BATCH", ["1", "3", "16"])])
+                                         ("ADELIE_HIP_SIDE_WGS", ["0", "24"]), ("ADELIE_HIP_CROSS_BATCH", ["1", "3", "16"]),
+                                         ("ADELIE_HIP_SPECULATE", ["0", "1"])])
 def test_round2_engine_hooks_do_not_change_results(hip, oracle, monkeypatch, hook, values):
     """The build / solve variants added in round 2 (batched diagonal-block builds, IRLS screen-block prebuild, group solve in
     eigen-coordinates, reduce fused into the solve, confined side builds) are scheduling / association changes only: every
@@ -418,3 +419,48 @@ def test_round2_engine_hooks_do_not_change_results(hip, oracle, monkeypatch, hoo
             # pass apart, which is worth ~1e-7 in beta at this tol; a wrong block shows up at 1e-3 and above
             assert np.abs(st.betas.toarray() - ref.betas.toarray()).max() < 1e-6, (hook, v)
             assert np.abs(st.intercepts - ref.intercepts).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_speculative_first_active_pass_is_bit_identical(hip, oracle, monkeypatch):
+    """The first active-set pass of the next lambda, enqueued behind the invariance sweep while the host screens
+    (Solver::spec_*), performs the same operations in the same order as the unspeculated path: identical bits, with and
+    without KKT failures (forced here by a tiny strong-rule screen budget), early exit and a live-state read in between."""
+    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    d = make_gaussian(1500, 1200, seed=21, sparsity=0.5)
+    X = ad.matrix.dense(d["X"])
+    runs = {}
+    for kw_name, kw in [("plain", dict(early_exit=False, lmda_path_size=30, min_ratio=0.02, tol=1e-10)),
+                        ("kkt_failures", dict(early_exit=False, lmda_path_size=30, min_ratio=0.02, tol=1e-10,
+                                              screen_rule="strong", max_screen_size=1200)),
+                        ("early_exit", dict(early_exit=True, lmda_path_size=40, min_ratio=0.001, tol=1e-10))]:
+        for spec in ("0", "1"):
+            monkeypatch.setenv("ADELIE_HIP_SPECULATE", spec)
+            st = ad.grpnet(X, ad.glm.gaussian(d["y"]), progress_bar=False, **kw)
+            assert st.error == ""
+            runs[kw_name, spec] = st
+        a, b = runs[kw_name, "0"], runs[kw_name, "1"]
+        assert a.counters["n_speculated"] == 0 and b.counters["n_speculated"] > 5
+        assert np.array_equal(a.betas.toarray(), b.betas.toarray())
+        assert np.array_equal(a.intercepts, b.intercepts) and np.array_equal(a.devs, b.devs)
+        assert np.array_equal(a.resid, b.resid) and np.array_equal(a.screen_beta, b.screen_beta)
+        assert np.array_equal(a.grad, b.grad) and a.rsq == b.rsq
+        for k in ("n_cd_passes_active", "n_cd_passes_screen", "n_updates", "n_panel_blocks", "n_panel_cols", "n_basil_iters"):
+            assert a.counters[k] == b.counters[k], k
+    assert runs["early_exit", "1"].counters["n_spec_rollbacks"] >= 1  # the pass enqueued before the exit was taken back
+    # a live-state read of the device-resident residual in the middle of the path takes the pass back and the path goes on
+    monkeypatch.setenv("ADELIE_HIP_SPECULATE", "1")
+    seen = []
+
+    def peek(s):
+        if s.n_solutions in (12, 20):
+            seen.append(np.array(s.resid, copy=True))
+        return False
+
+    c = ad.grpnet(X, ad.glm.gaussian(d["y"]), progress_bar=False, exit_cond=peek, early_exit=False, lmda_path_size=30,
+                  min_ratio=0.02, tol=1e-10)
+    assert len(seen) == 2 and c.counters["n_spec_rollbacks"] >= 2
+    assert np.array_equal(c.betas.toarray(), runs["plain", "0"].betas.toarray())
+    ref = ad.grpnet(oracle.dense(d["X"]), ad.glm.gaussian(d["y"]), progress_bar=False, early_exit=False, lmda_path_size=30,
+                    min_ratio=0.02, tol=1e-10)
+    assert np.abs(c.betas.toarray() - ref.betas.toarray()).max() < 1e-7

@@ -1744,6 +1744,7 @@ struct Solver {
             AHIP_CHECK(hipGetLastError()); // a failed launch would otherwise only show up as a stalled pass report
             cnt.n_panel_blocks += nblk;
             t_enq += sw_enq.elapsed();
+            if (no_wait) { spec_blocks = nblk; return T(0); }
             sw_enq.start();
             wait_pass_state(bs);
             t_wait += sw_enq.elapsed();
@@ -1773,10 +1774,11 @@ struct Solver {
         };
         if (mode == 1) {
             spec_enqueued = false;
-            if (la && (asz + B - 1) / B >= la_min_blocks) {
+            if (asz > 0 && !is_glm()) {
                 const int64_t cols0 = cnt.n_panel_cols;
                 no_wait = true;
-                pass_la(false);
+                if (la && (asz + B - 1) / B >= la_min_blocks) pass_la(false);
+                else pass_plain(false);
                 spec_cols = cnt.n_panel_cols - cols0;
                 spec_enqueued = true;
             }
@@ -1937,7 +1939,8 @@ struct Solver {
         bs.active_size = sc.active_size;
         bs.status = CD_OK;
         bs.nz = 0;
-        d_blk.upload(&bs, 1, st);
+        const int mode = spec_mode; // see run_panel_passes
+        if (mode != 2) d_blk.upload(&bs, 1, st);
         CdGrpBlkParams<T> bp{};
         bp.nv = cp.nv; bp.vars = cp.vars; bp.xmean = cp.xmean; bp.beta = cp.beta;
         bp.is_active = cp.is_active; bp.active_set = cp.active_set;
@@ -1976,8 +1979,9 @@ struct Solver {
             d_la_dcol.reserve(size_t(2) * SL); d_la_dpos.reserve(size_t(2) * SL); d_la_nz.reserve(2);
             d_la_dd.reserve(size_t(2) * SL);
             d_part.reserve(size_t(2 * panel_part_elems(n) + 2048));
-            pending_slot = -1;
+            if (mode != 2) pending_slot = -1;
         }
+        bool no_wait = false;
         d_gdesc.reserve(maxblk * size_t(GDESC_STRIDE));
         auto pass_la = [&](bool screen_pass) -> T {
             const idx count = screen_pass ? idx(cp.ns) : idx(asz);
@@ -2079,6 +2083,7 @@ struct Solver {
             t_cd.end(st);
             AHIP_CHECK(hipGetLastError());
             cnt.n_panel_blocks += nblk;
+            if (no_wait) { spec_blocks = nblk; return T(0); }
             wait_pass_state(bs);
             status = bs.status;
             if (bs.active_size > asz) {
@@ -2149,6 +2154,7 @@ struct Solver {
             t_cd.end(st);
             AHIP_CHECK(hipGetLastError()); // a failed launch would otherwise only show up as a stalled pass report
             cnt.n_panel_blocks += nblk;
+            if (no_wait) { spec_blocks = nblk; return T(0); }
             wait_pass_state(bs);
             status = bs.status;
             if (bs.active_size > asz) { // pick up the groups activated by this screen pass
@@ -2160,12 +2166,31 @@ struct Solver {
             asz = bs.active_size;
             return bs.cm;
         };
+        bool resume_first = mode == 2;
         auto pass = [&](bool screen_pass) -> T {
+            if (resume_first) { // the first active pass of this fit was enqueued behind the previous lambda's sweep
+                resume_first = false;
+                wait_pass_state(bs);
+                status = bs.status;
+                asz = bs.active_size;
+                return bs.cm;
+            }
             if (!la) return pass_plain(screen_pass);
             const idx count = screen_pass ? idx(cp.ns) : idx(asz);
             const int nblk = count > 0 ? build_partition(screen_pass ? nullptr : act_host.data(), count) : 0;
             return nblk >= la_min_blocks ? pass_la(screen_pass) : pass_plain(screen_pass);
         };
+        if (mode == 1) {
+            spec_enqueued = false;
+            if (asz > 0 && !is_glm()) {
+                const int64_t cols0 = cnt.n_panel_cols;
+                no_wait = true;
+                pass(false);
+                spec_cols = cnt.n_panel_cols - cols0;
+                spec_enqueued = true;
+            }
+            return;
+        }
         while (status == CD_OK) {
             while (status == CD_OK) { // solve_active, pin_naive:173-215
                 ++iters;
@@ -2219,7 +2244,7 @@ struct Solver {
         FitOut<T> o;
         bool resume = false;
         if (spec_active) {
-            resume = lm == spec_lm && r_dev == d_r.p && !is_glm() && all_scalar && nv >= spec_nv && panel_mode() &&
+            resume = lm == spec_lm && r_dev == d_r.p && !is_glm() && nv >= spec_nv && panel_mode() &&
                      active_set_size == spec_asz;
             if (!resume) spec_rollback();
         }
@@ -2269,12 +2294,10 @@ struct Solver {
         Stopwatch sw;
         sw.start();
         if (nv > 0 && panel_mode()) {
-            if (all_scalar) {
-                spec_mode = resume ? 2 : 0;
-                spec_active = false; // consumed (or never there)
-                struct ModeGuard { int& m; ~ModeGuard() { m = 0; } } mode_guard{spec_mode};
-                run_panel_passes(cp, sc, r_dev);
-            }
+            spec_mode = resume ? 2 : 0;
+            spec_active = false; // consumed (or never there)
+            struct ModeGuard { int& m; ~ModeGuard() { m = 0; } } mode_guard{spec_mode};
+            if (all_scalar) run_panel_passes(cp, sc, r_dev);
             else run_group_panel_passes(cp, sc, r_dev);
             // Gaussian: the residual is final and current on the device -> enqueue the invariance sweep of this lambda now,
             // so that it runs while the host does the post-fit bookkeeping below (otherwise the GPU idles ~0.2 ms per lambda)
@@ -2342,10 +2365,18 @@ struct Solver {
         if (!act.empty()) d_actset.download(act.data(), act.size(), st, old_active);
         // everything this fit hands back is enqueued; behind it, the first active pass of the next lambda (see spec_enabled)
         bool waited = false;
-        if (spec_enabled && spec_next_lm > T(0) && inv_prelaunched && inv_prelaunched_lm == lm && all_scalar && !cons_on &&
-            lookahead && nv > 0 && panel_mode() && r_dev == d_r.p) {
+        if (spec_enabled && spec_next_lm > T(0) && inv_prelaunched && inv_prelaunched_lm == lm && !cons_on && nv > 0 &&
+            panel_mode() && r_dev == d_r.p) {
             if (!spec_ev) AHIP_CHECK(hipEventCreateWithFlags(&spec_ev, hipEventDisableTiming));
             AHIP_CHECK(hipEventRecord(spec_ev, st));
+            if (!all_scalar) { // the group engine partitions the active list on the host: it needs the newcomers first
+                AHIP_CHECK(hipEventSynchronize(spec_ev));
+                for (size_t i = 0; i < act.size(); ++i) {
+                    active_set[old_active + i] = act[i];
+                    screen_is_active[act[i]] = 1;
+                }
+                act.clear();
+            }
             d_r_snap.reserve(size_t(n));
             AHIP_CHECK(hipMemcpyAsync(d_beta0.p, d_beta.p, size_t(nv) * sizeof(T), hipMemcpyDeviceToDevice, st));
             AHIP_CHECK(hipMemcpyAsync(d_r_snap.p, d_r.p, size_t(n) * sizeof(T), hipMemcpyDeviceToDevice, st));
@@ -2358,7 +2389,8 @@ struct Solver {
             spec_mode = 1;
             {
                 struct ModeGuard { int& m; ~ModeGuard() { m = 0; } } mode_guard{spec_mode};
-                run_panel_passes(cp2, sc2, r_dev);
+                if (all_scalar) run_panel_passes(cp2, sc2, r_dev);
+                else run_group_panel_passes(cp2, sc2, r_dev);
             }
             if (spec_enqueued) {
                 spec_active = true;

@@ -464,3 +464,35 @@ def test_speculative_first_active_pass_is_bit_identical(hip, oracle, monkeypatch
     ref = ad.grpnet(oracle.dense(d["X"]), ad.glm.gaussian(d["y"]), progress_bar=False, early_exit=False, lmda_path_size=30,
                     min_ratio=0.02, tol=1e-10)
     assert np.abs(c.betas.toarray() - ref.betas.toarray()).max() < 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["groups", "multigaussian", "short_active_sets"])
+def test_speculative_pass_group_engine_and_short_passes(hip, monkeypatch, kind):
+    """The same on the group panel engine (single- and multi-response) and for active sets shorter than the look-ahead's
+    minimum (plain passes)."""
+    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    d = make_gaussian(1200, 900, seed=23, sparsity=0.5)
+    X = ad.matrix.dense(d["X"])
+    kw = dict(early_exit=False, lmda_path_size=25, min_ratio=0.03, tol=1e-10, progress_bar=False)
+    if kind == "groups":
+        mk = lambda: ad.glm.gaussian(d["y"])
+        kw.update(groups=np.arange(0, 900, 6), alpha=0.7)
+    elif kind == "multigaussian":
+        rng = np.random.RandomState(5)
+        Y = np.stack([d["y"], d["y"][::-1] + rng.normal(size=1200), rng.normal(size=1200)], axis=1)
+        mk = lambda: ad.glm.multigaussian(Y)
+    else:
+        mk = lambda: ad.glm.gaussian(d["y"])
+        kw.update(lmda_path_size=12, min_ratio=0.5)  # the active set stays below three blocks
+    out = {}
+    for spec in ("0", "1"):
+        monkeypatch.setenv("ADELIE_HIP_SPECULATE", spec)
+        out[spec] = ad.grpnet(X, mk(), **kw)
+        assert out[spec].error == ""
+    a, b = out["0"], out["1"]
+    assert a.counters["n_speculated"] == 0 and b.counters["n_speculated"] > 3
+    assert np.array_equal(a.betas.toarray(), b.betas.toarray()) and np.array_equal(a.intercepts, b.intercepts)
+    assert np.array_equal(a.resid, b.resid) and np.array_equal(a.devs, b.devs)
+    for k in ("n_cd_passes_active", "n_cd_passes_screen", "n_updates", "n_panel_blocks", "n_panel_cols"):
+        assert a.counters[k] == b.counters[k], k

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -28,6 +29,12 @@ inline core_error make_solver_error(const std::string& m) { return core_error("a
                                      "' at " #expr);                                                       \
     } while (0)
 
+// wall-clock spent in hipMalloc / hipFree by the DevBufs of this process (tuning aid, printed under ADELIE_HIP_TRACE_ENQ)
+struct DevAllocStats {
+    static double& seconds() { static double s = 0; return s; }
+    static long& calls() { static long c = 0; return c; }
+};
+
 // Owning device buffer (grow-only).
 template <class T>
 struct DevBuf {
@@ -38,7 +45,12 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            const auto t0 = std::chrono::steady_clock::now();
+            (void)hipFree(p);
+            DevAllocStats::seconds() += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            ++DevAllocStats::calls();
+        }
         p = nullptr;
         cap = 0;
     }
@@ -47,7 +59,10 @@ struct DevBuf {
         if (n > cap) {
             release();
             size_t want = n < 16 ? 16 : n;
+            const auto t0 = std::chrono::steady_clock::now();
             AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T)));
+            DevAllocStats::seconds() += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            ++DevAllocStats::calls();
             cap = want;
         }
         return p;

@@ -2949,6 +2949,9 @@ struct Solver {
         if (std::getenv("ADELIE_HIP_TRACE_ENQ"))
             std::fprintf(stderr, "[enq] panel passes: host enqueue %.1f ms, host wait %.1f ms, blocks %lld, speculated %lld (rolled back %lld)\n",
                          t_enq * 1e3, t_wait * 1e3, (long long)cnt.n_panel_blocks, (long long)n_spec, (long long)n_spec_rollback);
+        if (std::getenv("ADELIE_HIP_TRACE_ENQ"))
+            std::fprintf(stderr, "[alloc] hipMalloc/hipFree so far in this process: %ld calls, %.1f ms\n", DevAllocStats::calls(),
+                         DevAllocStats::seconds() * 1e3);
         t_sweep.collect(); t_gram.collect(); t_cd.collect(); t_axpy.collect(); t_step.collect();
         if (d_grp_dbg.p) {
             sync();

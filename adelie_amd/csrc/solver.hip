@@ -2293,6 +2293,7 @@ struct Solver {
         cp.max_group_size = int32_t(max_gs);
         Stopwatch sw;
         sw.start();
+        bool small_fit = false; // the whole pin solve ran in the single-workgroup kernel (its scalars are in d_sc)
         if (nv > 0 && panel_mode()) {
             spec_mode = resume ? 2 : 0;
             spec_active = false; // consumed (or never there)
@@ -2301,7 +2302,7 @@ struct Solver {
             else run_group_panel_passes(cp, sc, r_dev);
             // Gaussian: the residual is final and current on the device -> enqueue the invariance sweep of this lambda now,
             // so that it runs while the host does the post-fit bookkeeping below (otherwise the GPU idles ~0.2 ms per lambda)
-            if (!is_glm() && sc.status == CD_OK && r_dev == d_r.p && prelaunch_sweep) {
+            if (!is_glm() && sc.status == CD_OK && r_dev == d_r.p && prelaunch_sweep && inv_wanted) {
                 launch_vmul<T>(d_w.p, d_r.p, d_v.p, n, st);
                 t_sweep.begin(st);
                 sweep(d_v.p, d_grad.p, nullptr, p, &d_blk.p->resid_sum, intercept ? d_xm.p : nullptr);
@@ -2322,6 +2323,7 @@ struct Solver {
             }
             d_sc.download(&sc, 1, st);
             sync();
+            small_fit = true;
         }
         const double t_cd = sw.elapsed();
         if (nv == 0) {
@@ -2353,6 +2355,18 @@ struct Solver {
             axpy_cols(d_dcols.p, d_dvals.p, &d_sc.p->n_delta, 0, T(-1), r_dev);
             t_axpy.end(st);
             cnt.n_resid_col_reads += sc.n_delta;
+        }
+        // small screen sets (single-workgroup kernel): the invariance sweep of this lambda goes out right behind the residual
+        // update as well, ahead of the downloads and the host bookkeeping below (the panel engines did this above)
+        if (small_fit && !is_glm() && !cov_mode && prelaunch_sweep && inv_wanted && sc.status == CD_OK && r_dev == d_r.p &&
+            !multi()) {
+            launch_vmul<T>(d_w.p, d_r.p, d_v.p, n, st);
+            t_sweep.begin(st);
+            sweep(d_v.p, d_grad.p, nullptr, p, &d_sc.p->resid_sum, intercept ? d_xm.p : nullptr);
+            t_sweep.end(st);
+            device_abs_grad(lm);
+            inv_prelaunched = true;
+            inv_prelaunched_lm = lm;
         }
         grad_valid = false;
         // host mirrors
@@ -2733,6 +2747,7 @@ struct Solver {
     bool is_glm() const { return glm_kind != ADELIE_HIP_GLM_GAUSSIAN; }
 
     // update_invariance_f: solver_gaussian_naive.hpp:377-393 / solver_glm_naive.hpp:495-503, + update_abs_grad
+    bool inv_wanted = true; // set by solve(): the fit about to run is followed by update_invariance at the same lambda
     bool prelaunch_sweep = true, inv_prelaunched = false;
     T inv_prelaunched_lm = 0;
     // ---- speculative first active-set pass of the NEXT lambda (Gaussian lasso on the look-ahead panel engine) ----
@@ -2893,7 +2908,9 @@ struct Solver {
             for (size_t i = 0; i < large_sz; ++i) large[i] = lmda_path[i];
             large[large_sz] = lmda_max;
             for (size_t i = 0; i < large.size(); ++i) {
+                inv_wanted = i + 1 == large.size(); // the solutions above lambda_max are saved without an invariance step
                 auto fo = fit_f(large[i]);
+                inv_wanted = true;
                 if (i < large.size() - 1) {
                     update_solutions(fo, large[i]);
                     ++pb_it;

@@ -608,6 +608,8 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
     }
 }
 
+#undef RP_MARK
+
 // nt: threads of the workgroup that call (>= 256, a multiple of 128); only the rotated form uses more than the first 256
 template <class T, bool NAIVE>
 __device__ __forceinline__ void grp_solve_body(const CdGrpBlkParams<T>& p, int j, char* smem_raw, int nt = 256) {
@@ -1030,6 +1032,8 @@ __device__ __forceinline__ void grp_solve_body(const CdGrpBlkParams<T>& p, int j
         }
     }
 }
+
+#undef GP_MARK
 
 } // namespace
 } // namespace ahip

@@ -134,7 +134,7 @@ HIP_SYMBOLS = [
     "design_device", "design_stream",
     "design_cmul", "design_ctmul", "design_bmul", "design_btmul", "design_mul", "design_mul_batch", "design_cov",
     "design_sq_mul", "design_sp_tmul",
-    "design_create_cov_dense", "design_cov_bmul", "design_cov_mul", "design_cov_to_dense", "gaussian_cov_solve",
+    "design_create_cov_dense", "design_create_cov_lazy", "design_cov_bmul", "design_cov_mul", "design_cov_to_dense", "gaussian_cov_solve",
     "grpnet_solve", "result_destroy", "result_size", "result_copy", "result_scalar", "result_error", "result_sync",
     "bench_sweep",
 ]
@@ -212,6 +212,7 @@ class Backend:
         sig("grpnet_solve", ci, [vp, p(GrpnetArgs), p(vp)])
         sig("gaussian_cov_solve", ci, [vp, p(GrpnetArgs), p(vp)])
         sig("design_create_cov_dense", ci, [vp, i64, ci, ci, ci, p(vp)])
+        sig("design_create_cov_lazy", ci, [vp, p(vp)])
         sig("design_cov_bmul", ci, [vp, vp, i64, vp, vp, i64, vp])
         sig("design_cov_mul", ci, [vp, vp, vp, i64, vp])
         sig("design_cov_to_dense", ci, [vp, i64, i64, vp])

@@ -252,6 +252,41 @@ void op_cov(adelie_hip_design* d, int64_t j, int64_t q, const T* sw, T* out) {
     AHIP_CHECK(hipStreamSynchronize(s));
 }
 
+// A = X^T X in column panels of 2048 columns (the Gram kernel's K-split partials stay bounded); unit weights, no centring
+template <class T>
+static void cov_lazy_t(adelie_hip_design* X, adelie_hip_design* A) {
+    constexpr int64_t kAlign = 32, PANEL = 2048;
+    const int64_t n = X->n, p = X->p;
+    const int64_t ld = ((p + kAlign - 1) / kAlign) * kAlign;
+    hipStream_t s = A->stream;
+    T* C = nullptr;
+    AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&C), size_t(ld) * size_t(p) * sizeof(T)));
+    A->X = C;
+    A->ld = ld;
+    A->owned = true;
+    AHIP_CHECK(hipMemsetAsync(C, 0, size_t(ld) * size_t(p) * sizeof(T), s));
+    DevBuf<T> ones, work;
+    DevBuf<int32_t> cols;
+    std::vector<T> h1(size_t(n), T(1));
+    std::vector<int32_t> hc(static_cast<size_t>(p));
+    for (int64_t j = 0; j < p; ++j) hc[size_t(j)] = int32_t(j);
+    ones.reserve(size_t(n));
+    cols.reserve(size_t(p));
+    ones.upload(h1.data(), size_t(n), s);
+    cols.upload(hc.data(), size_t(p), s);
+    work.reserve(size_t(gram_work_elems(n, p, std::min<int64_t>(p, PANEL))));
+    for (int64_t c0 = 0; c0 < p; c0 += PANEL) {
+        const int64_t nc = std::min<int64_t>(PANEL, p - c0);
+        if (X->kind == 0)
+            launch_gram<T>(X->dense<T>(), ones.p, cols.p, int32_t(p), 0, cols.p + c0, int32_t(nc), int32_t(c0), nullptr, false, C, ld,
+                           work.p, s);
+        else
+            launch_gram_snp<T>(X->snp(), static_cast<const T*>(X->impute), ones.p, cols.p, int32_t(p), 0, cols.p + c0, int32_t(nc),
+                               int32_t(c0), nullptr, false, C, ld, work.p, s);
+    }
+    AHIP_CHECK(hipStreamSynchronize(s));
+}
+
 template <class T>
 void op_sp_tmul(adelie_hip_design* d, int64_t L, const int64_t* indptr, const int64_t* indices, const T* values, T* out) {
     set_device(d);
@@ -610,6 +645,27 @@ int adelie_hip_design_create_cov_dense(const void* host, int64_t p, int dtype, i
     ABI_CATCH
 }
 
+
+int adelie_hip_design_create_cov_lazy(adelie_hip_design* X, adelie_hip_design** out) {
+    ABI_TRY
+    if (!X || !out) throw make_core_error("null argument.");
+    if (X->cov) throw make_core_error("mat must be a naive (n, p) matrix, not a covariance matrix.");
+    if (X->kind != 0 && X->kind != 1) throw make_core_error("lazy_cov takes a dense or SNP design.");
+    if (X->p > (int64_t(1) << 31) - 1) throw make_core_error("too many columns.");
+    set_device(X);
+    AHIP_CHECK(hipStreamSynchronize(X->stream));
+    adelie_hip_design* d = new_design(X->p, X->p, X->dtype, X->device);
+    try {
+        if (X->dtype == ADELIE_HIP_F64) cov_lazy_t<double>(X, d);
+        else cov_lazy_t<float>(X, d);
+        d->cov = 1;
+    } catch (...) {
+        adelie_hip_design_destroy(d);
+        throw;
+    }
+    *out = d;
+    ABI_CATCH
+}
 
 int adelie_hip_design_cov_bmul(adelie_hip_design* d, const int64_t* subset, int64_t ns, const int64_t* indices,
                                const void* values, int64_t ni, void* out) {

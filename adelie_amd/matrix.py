@@ -939,3 +939,24 @@ def _cov_dense(backend, ctor, mat, n_threads, device):
     obj = cls()
     obj._init_native(backend, handle, n_threads, mat)
     return obj
+
+
+def lazy_cov(mat, *, copy: bool = False, n_threads: int = 1, device: int = 0):
+    """``A = X^T X`` for the covariance method (reference ``adelie.matrix.lazy_cov``, ``matrix.py:1000-1065``,
+    ``MatrixCovLazyCov``).  The reference computes the rows of ``A`` that the solver asks for on demand, because ``A`` may not
+    fit in host memory; here ``A`` is formed once on the device by the MFMA Gram kernel from the resident design (dense ndarray,
+    device tensor, or any dense / SNP ``adelie_amd.matrix`` design) and then behaves like ``dense(A, method="cov")``.
+    ``copy`` is accepted for signature parity (the data matrix is copied to HBM in any case and released afterwards)."""
+    if n_threads < 1:
+        raise RuntimeError("adelie_core: n_threads must be >= 1.")
+    X = mat if isinstance(mat, _NativeMatrix) else dense(mat, method="naive", n_threads=n_threads, device=device)
+    backend = X._backend
+    if not backend.has("design_create_cov_lazy"):
+        raise NotImplementedError("adelie_amd: lazy_cov needs the device library.")
+    handle = _abi.C.c_void_p()
+    backend.check(backend.fn("design_create_cov_lazy")(X._handle, handle))
+    base = MatrixCovBase64 if X.dtype == np.float64 else MatrixCovBase32
+    cls = type("_cov_matrix", (_CovMatrix, base), {"dtype": base.dtype})
+    obj = cls()
+    obj._init_native(backend, handle, n_threads, None)
+    return obj

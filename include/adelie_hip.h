@@ -317,6 +317,11 @@ int adelie_hip_grpnet_solve(adelie_hip_design* X, const adelie_hip_grpnet_args* 
  * Result accessors as above: devs holds rsq (the unnormalised decrease of the loss), intercepts are zero.
  * ------------------------------------------------------------------------------------------ */
 int adelie_hip_design_create_cov_dense(const void* host, int64_t p, int dtype, int order, int device, adelie_hip_design** out);
+/* == adelie.matrix.lazy_cov(mat) / MatrixCovLazyCov{32,64}{C,F} (matrix_cov_lazy_cov.ipp): A = X^T X of a resident naive design
+ * (dense or 2-bit SNP).  The reference computes rows of A on demand and caches them because A may not fit in host memory;
+ * here the whole (p, p) matrix is formed once by the MFMA Gram kernel and kept in HBM (p = 100 000 is 80 GB of the 288),
+ * after which it is an ordinary covariance-method design.  X is not retained. */
+int adelie_hip_design_create_cov_lazy(adelie_hip_design* X, adelie_hip_design** out);
 /* MatrixCovBase::bmul (matrix_cov_dense.ipp:23-41): out[j] = sum_i values[i] * A(indices[i], subset[j]) */
 int adelie_hip_design_cov_bmul(adelie_hip_design* A, const int64_t* subset, int64_t n_subset, const int64_t* indices,
                                const void* values, int64_t n_indices, void* out);

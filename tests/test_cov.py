@@ -227,3 +227,44 @@ def test_hip_cov_warm_start_errors_and_exit_cond(hip):
         ad.grpnet(cA, ad.glm.gaussian(y))
     small = ad.gaussian_cov(cA, v, max_active_size=2, **kw)
     assert small.error.startswith("adelie_core solver: ") and 0 < len(small.lmdas) < 25
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["dense64", "dense32", "snp"])
+def test_lazy_cov_is_xtx_and_solves_like_the_dense_cov_matrix(hip, kind):
+    """matrix.lazy_cov (reference MatrixCovLazyCov): A = X^T X formed on the device; checked entry-wise through the
+    MatrixCovBase members and through a gaussian_cov path against dense(A, method="cov")."""
+    rng = np.random.RandomState(4)
+    n, p = 700, 2300   # more than one 2048-column panel
+    if kind == "snp":
+        cd = rng.choice(np.array([0, 1, 2, -9], dtype=np.int8), size=(n, p), p=[0.6, 0.2, 0.1, 0.1])
+        Xd = ad.matrix.snp_calldata(cd)
+        imp = np.asarray(Xd.impute())
+        X = np.where(cd < 0, imp[None, :], cd).astype(np.float64)
+        A = ad.matrix.lazy_cov(Xd)
+        tol = 1e-9
+    else:
+        dt = np.float64 if kind == "dense64" else np.float32
+        X = np.asfortranarray(rng.normal(size=(n, p)).astype(dt))
+        A = ad.matrix.lazy_cov(X)
+        tol = 1e-9 if dt == np.float64 else 2e-3
+    G = X.astype(np.float64).T @ X.astype(np.float64)
+    assert A.shape == (p, p)
+    for i, q in [(0, 5), (2040, 20), (p - 7, 7)]:
+        out = np.empty((q, q), dtype=A.dtype, order="F")
+        A.to_dense(i, q, out)
+        assert np.abs(out - G[i:i + q, i:i + q]).max() < tol * n
+    idx = np.array([3, 1000, 2047, 2048, p - 1])
+    vals = rng.normal(size=5).astype(A.dtype)
+    out = np.empty(p, dtype=A.dtype)
+    A.mul(idx, vals, out)
+    assert np.abs(out - vals.astype(np.float64) @ G[idx]).max() < tol * n * 5
+    if kind == "dense64":
+        y = X[:, :6] @ np.ones(6) + rng.normal(size=n)
+        v = X.T @ y / n
+        kw = dict(lmda_path_size=15, min_ratio=0.2, tol=1e-12, progress_bar=False)
+        Al = ad.matrix.lazy_cov(X / np.sqrt(n))
+        a = ad.gaussian_cov(Al, v, **kw)
+        b = ad.gaussian_cov(ad.matrix.dense(np.asfortranarray(G / n), method="cov"), v, **kw)
+        assert a.error == "" and len(a.lmdas) == len(b.lmdas)
+        assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-9

@@ -622,8 +622,12 @@ def sparse(mat, *, method: str = "naive", copy: bool = False, n_threads: int = 1
     in device memory (288 GB per MI355X)."""
     if not (isinstance(mat, csr_matrix) or isinstance(mat, csc_matrix)):
         raise TypeError("mat must be scipy.sparse.csr_matrix or scipy.sparse.csc_matrix.")
+    if method == "cov":  # MatrixCovSparse (matrix_cov_sparse.ipp): a symmetric sparse (p, p) matrix, dense in HBM here
+        if mat.shape[0] != mat.shape[1]:
+            raise RuntimeError("adelie_core: mat must be (p, p).")
+        return _cov_dense(_abi.hip_backend(), "design_create_cov_dense", np.asfortranarray(mat.toarray()), n_threads, device)
     if method != "naive":
-        raise NotImplementedError("adelie_amd.matrix.sparse: only method='naive' is on the grpnet hot path.")
+        raise ValueError("method must be one of 'naive' or 'cov'.")
     if n_threads < 1:
         raise RuntimeError("adelie_core: n_threads must be >= 1.")
     if isinstance(mat, csr_matrix):
@@ -960,3 +964,39 @@ def lazy_cov(mat, *, copy: bool = False, n_threads: int = 1, device: int = 0):
     obj = cls()
     obj._init_native(backend, handle, n_threads, None)
     return obj
+
+
+def block_diag(mats, *, method: str = "naive", n_threads: int = 1, device: int = 0):
+    """Block-diagonal matrix (reference ``adelie.matrix.block_diag``, ``matrix.py:198-300``).  ``method="cov"``
+    (``MatrixCovBlockDiag``): the blocks are symmetric matrices — ndarrays or covariance matrices of this module — and the result
+    is one resident ``(p, p)`` covariance matrix with them on its diagonal (dense in HBM; the reference keeps the list and
+    dispatches per block).  ``method="naive"`` is not implemented."""
+    if method == "naive":
+        raise NotImplementedError("adelie_amd.matrix.block_diag: only method='cov' is implemented.")
+    if method != "cov":
+        raise ValueError("method must be one of 'naive' or 'cov'.")
+    if len(mats) == 0:
+        raise RuntimeError("adelie_core: mats must be non-empty.")
+    blocks = []
+    for m in mats:
+        if isinstance(m, _CovMatrix):
+            q = m.cols()
+            out = np.empty((q, q), dtype=m.dtype, order="F")
+            m.to_dense(0, q, out)
+            blocks.append(out)
+        else:
+            m = np.asarray(m)
+            if m.ndim != 2 or m.shape[0] != m.shape[1]:
+                raise RuntimeError("adelie_core: every block must be (q, q).")
+            blocks.append(m)
+    dtype = blocks[0].dtype
+    if any(b.dtype != dtype for b in blocks):
+        raise RuntimeError("adelie_core: all blocks must have the same dtype.")
+    p = sum(b.shape[0] for b in blocks)
+    A = np.zeros((p, p), dtype=dtype, order="F")
+    o = 0
+    for b in blocks:
+        q = b.shape[0]
+        A[o:o + q, o:o + q] = b
+        o += q
+    return _cov_dense(_abi.hip_backend(), "design_create_cov_dense", A, n_threads, device)

@@ -268,3 +268,36 @@ def test_lazy_cov_is_xtx_and_solves_like_the_dense_cov_matrix(hip, kind):
         b = ad.gaussian_cov(ad.matrix.dense(np.asfortranarray(G / n), method="cov"), v, **kw)
         assert a.error == "" and len(a.lmdas) == len(b.lmdas)
         assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_block_diag_and_sparse_cov_matrices(hip):
+    """matrix.block_diag(method="cov") and matrix.sparse(method="cov") (reference MatrixCovBlockDiag / MatrixCovSparse):
+    materialised in HBM, the MatrixCovBase members agree with the dense matrix they stand for."""
+    from scipy.sparse import csc_matrix
+    rng = np.random.RandomState(8)
+    blocks = []
+    for q in (3, 17, 40):
+        B = rng.normal(size=(q + 5, q))
+        blocks.append(np.asfortranarray(B.T @ B / (q + 5)))
+    A = ad.matrix.block_diag([blocks[0], ad.matrix.dense(blocks[1], method="cov"), blocks[2]], method="cov")
+    p = 60
+    ref = np.zeros((p, p))
+    o = 0
+    for b in blocks:
+        ref[o:o + len(b), o:o + len(b)] = b
+        o += len(b)
+    out = np.empty((p, p), order="F")
+    A.to_dense(0, p, out)
+    assert np.array_equal(out, ref)
+    S = csc_matrix(np.where(np.abs(ref) > 0.3, ref, 0.0))
+    As = ad.matrix.sparse(S, method="cov")
+    As.to_dense(0, p, out)
+    assert np.array_equal(out, S.toarray())
+    v = rng.normal(size=p)
+    a = ad.gaussian_cov(A, v, lmda_path_size=10, min_ratio=0.1, tol=1e-12, progress_bar=False)
+    b = ad.gaussian_cov(ad.matrix.dense(np.asfortranarray(ref), method="cov"), v, lmda_path_size=10, min_ratio=0.1, tol=1e-12,
+                        progress_bar=False)
+    assert np.array_equal(a.betas.toarray(), b.betas.toarray())
+    with pytest.raises(NotImplementedError):
+        ad.matrix.block_diag(blocks, method="naive")

@@ -292,8 +292,10 @@ def test_new_constructors_reject_bad_inputs(hip):
         ad.matrix.concatenate([X, ad.matrix.dense(np.asfortranarray(rng.normal(size=(20, 4)), dtype=np.float32))], axis=1)
     with pytest.raises(RuntimeError, match="float32 or float64"):
         ad.matrix.sparse(sp.csc_matrix(np.eye(3, dtype=np.int64)))
-    with pytest.raises(NotImplementedError, match="naive"):
-        ad.matrix.sparse(sp.csc_matrix(np.eye(3)), method="cov")
+    with pytest.raises(ValueError, match="'naive' or 'cov'"):
+        ad.matrix.sparse(sp.csc_matrix(np.eye(3)), method="lazy")
+    with pytest.raises(RuntimeError, match=r"\(p, p\)"):
+        ad.matrix.sparse(sp.csc_matrix(np.ones((3, 4))), method="cov")
     with pytest.raises(RuntimeError, match="multi_path_losses\\(\\) is given inconsistent inputs"):
         X.multi_path_losses(0, 2, sp.csr_matrix(np.zeros((1, 7))), np.zeros((1, 2)), np.zeros((20, 2)), np.zeros((20, 2)),
                             np.ones(20) / 20, np.ones(20) / 20)

@@ -433,13 +433,16 @@ def test_speculative_first_active_pass_is_bit_identical(hip, oracle, monkeypatch
     for kw_name, kw in [("plain", dict(early_exit=False, lmda_path_size=30, min_ratio=0.02, tol=1e-10)),
                         ("kkt_failures", dict(early_exit=False, lmda_path_size=30, min_ratio=0.02, tol=1e-10,
                                               screen_rule="strong", max_screen_size=1200)),
-                        ("early_exit", dict(early_exit=True, lmda_path_size=40, min_ratio=0.001, tol=1e-10))]:
+                        ("early_exit", dict(early_exit=True, lmda_path_size=40, min_ratio=0.001, tol=1e-10)),
+                        ("error_mid_path", dict(early_exit=False, lmda_path_size=30, min_ratio=0.02, tol=1e-10,
+                                                max_screen_size=500))]:
         for spec in ("0", "1"):
             monkeypatch.setenv("ADELIE_HIP_SPECULATE", spec)
             st = ad.grpnet(X, ad.glm.gaussian(d["y"]), progress_bar=False, **kw)
-            assert st.error == ""
+            assert (st.error == "") == (kw_name != "error_mid_path"), st.error
             runs[kw_name, spec] = st
         a, b = runs[kw_name, "0"], runs[kw_name, "1"]
+        assert a.error == b.error and len(a.lmdas) == len(b.lmdas)
         assert a.counters["n_speculated"] == 0 and b.counters["n_speculated"] > 5
         assert np.array_equal(a.betas.toarray(), b.betas.toarray())
         assert np.array_equal(a.intercepts, b.intercepts) and np.array_equal(a.devs, b.devs)

@@ -296,7 +296,7 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
         }
     }
     // per-group constants of the sequential loop, one group per thread (the correction partials are consumed: their space is
-    // free): the largest b_i = A_i + l2 (start of the root find), 1 / q (convergence measure), dbeta_tol * sqrt(q) (change test)
+    // free): 1 / max b_i, b_i = A_i + l2 (start of the root find), 1 / q (convergence measure), (dbeta_tol * sqrt(q))^2 (change test)
     T* gbmx = corr;
     T* grq = corr + GBLK;
     T* gsq = corr + 2 * GBLK;
@@ -305,9 +305,10 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
         const T l2p = p.l2 * penv;
         T mx = T(0);
         for (int t = 0; t < q; ++t) { const T b = AB[o + t] + l2p; mx = b > mx ? b : mx; }
-        gbmx[tid] = mx;
+        gbmx[tid] = mx > T(0) ? T(1) / mx : T(0); // (reciprocal: the root find's start is (||v|| - l1) / max b_i)
         grq[tid] = T(1) / T(q);
-        gsq[tid] = p.dbeta_tol * sqrt(T(q));
+        const T thr = p.dbeta_tol * sqrt(T(q));
+        gsq[tid] = thr * thr;                     // ||delta||^2 against the squared threshold of pin_naive:144
     }
     __syncthreads();
     if (wv != 0) return;
@@ -331,8 +332,11 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
 
     // operands of a group that do not depend on the groups before it (layout, penalty, variances, old coefficients) are read
     // one group ahead, so that their LDS latency is not on the chain
+    // The rotated gradient of the next group's values travels the same way: lane t holds the value o_next + t (the whole
+    // 64-lane chunk behind the current group); the update of a changed group (q <= 64) leaves exactly that chunk in its
+    // accumulator registers, so the next visit starts from registers instead of an LDS store -> load round trip.
     int o_n = 0, q_n = 0, ss_n = 0;
-    T pk_n = T(0), A_n = T(0), ako_n = T(0);
+    T pk_n = T(0), A_n = T(0), ako_n = T(0), g_n = T(0);
     auto prefetch = [&](int kk) {
         if (kk < ngrp) {
             o_n = goff[kk]; q_n = gq[kk]; ss_n = gss[kk];
@@ -340,19 +344,20 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             const bool onn = lane < q_n;
             A_n = onn ? AB[o_n + lane] : T(0);
             ako_n = onn ? bT[o_n + lane] : T(0);
+            g_n = (o_n + lane < nval) ? gT[o_n + lane] : T(0);
         }
     };
     prefetch(0);
     for (int k = 0; k < ngrp && status == CD_OK; ++k) {
         const int o = o_n, q = q_n, ss = ss_n;
         const T pk = pk_n;
-        const T A_c = A_n, ako_c = ako_n;
+        const T A_c = A_n, ako_c = ako_n, g_c = g_n;
         prefetch(k + 1);
         const T l1p = p.l1 * pk, l2p = p.l2 * pk;
         bool changed = false;
         T d_reg = T(0); // q <= 64: lane t holds the rotated change of the group's value t (q == 1: every lane)
         if (q == 1) {
-            const T gcur = gT[o], bi = bT[o], A = AB[o];
+            const T gcur = rdl(g_c, 0), bi = rdl(ako_c, 0), A = rdl(A_c, 0);
             const T gk = fma(bi, A, gcur);                       // pin_naive:85-89
             const T v = fabs(gk) - l1p;                          // pin_base:181-195
             T ak = (v > T(0)) ? copysign(v, gk) / (A + l2p) : T(0);
@@ -371,12 +376,13 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             const bool on = lane < q;
             const T A_r = A_c;
             const T ako_r = ako_c;
-            const T gk_r = on ? gT[o + lane] + A_r * ako_r : T(0); // gk_t += A * ak_old_t   (pin_naive:139-140)
+            const T gk_r = on ? g_c + A_r * ako_r : T(0); // gk_t += A * ak_old_t   (pin_naive:139-140)
             // newton_solver (bcd/unconstrained/newton.hpp:35-142): v = gk_t, L = A
             const T nrm2 = group_sum(on ? gk_r * gk_r : T(0), q);
+            const T nrm = sqrt(nrm2);
             T akt_r = T(0);
             RP_MARK(1)
-            if (sqrt(nrm2) <= l1p) {
+            if (nrm <= l1p) {
                 akt_r = T(0);
             } else if (l1p <= T(0)) {
                 akt_r = on ? gk_r / (A_r + l2p) : T(0);
@@ -390,10 +396,7 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
                 // left like from 0, only from much closer — the same root to newton_tol in fewer of the (strictly
                 // sequential) evaluations; an isotropic block (all b_i equal) starts AT its root.  Same stopping test, same
                 // error when newton_tol is unreachable.
-                {
-                    const T bmx = gbmx[k]; // max_i b_i, from the prologue
-                    if (bmx > T(0)) h = (sqrt(nrm2) - l1p) / bmx;
-                }
+                h = (nrm - l1p) * gbmx[k]; // (1 / max_i b_i from the prologue; 0 when there is none)
                 auto step = [&](T hh) {
                     T t = 0, sx = 0;
                     if (on) {
@@ -432,7 +435,7 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             }
             dn = group_sum(dn, q);
             c1 = group_sum(c1, q);
-            if (!(sqrt(dn) <= gsq[k])) {
+            if (!(dn <= gsq[k])) {
                 changed = true;
                 c1 *= grq[k];
                 cm = c1 > cm ? c1 : cm;
@@ -523,11 +526,14 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             // values before that were visited already and are not read again in this solve).  q <= 64: the changes come out
             // of the lanes' registers with v_readlane (uniform index), no LDS round trip on the chain.
             if (q <= 64) {
+                bool first = true;
                 for (int l = o + q + lane; l < nval; l += 64) {
-                    T acc = gT[l];
+                    T acc = first ? g_n : gT[l]; // (the first chunk is the one prefetched for the next group)
 #pragma unroll 4
                     for (int t = 0; t < q; ++t) acc = fma(-D[l + (o + t) * GBLK], rdl(d_reg, q == 1 ? 0 : t), acc);
                     gT[l] = acc;
+                    if (first) g_n = acc;
+                    first = false;
                 }
             } else {
                 for (int l = o + q + lane; l < nval; l += 64) {
@@ -536,6 +542,8 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
                     for (int t = 0; t < q; ++t) acc = fma(-D[l + (o + t) * GBLK], delT[t], acc);
                     gT[l] = acc;
                 }
+                __builtin_amdgcn_wave_barrier();
+                if (k + 1 < ngrp) g_n = (o_n + lane < nval) ? gT[o_n + lane] : T(0);
             }
             __builtin_amdgcn_wave_barrier();
             ++n_upd;

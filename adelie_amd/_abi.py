@@ -153,6 +153,10 @@ def dtype_code(dtype):
     raise RuntimeError("dtype must be either np.float32 or np.float64.")
 
 
+# kept equal to ADELIE_HIP_ABI_VERSION in include/adelie_hip.h (tests/test_abi.py compares the two)
+ABI_VERSION = 3
+
+
 class Backend:
     """``libadelie_hip.so`` with the argument types of include/adelie_hip.h attached."""
 
@@ -160,6 +164,12 @@ class Backend:
         self.path = path
         self.lib = C.CDLL(path)
         self._setup()
+        # the structures below were written for exactly one layout of include/adelie_hip.h: a stale library that still
+        # exports every symbol would misread the newer fields
+        found = self.fn("abi_version")() if self.has("abi_version") else None
+        if found != ABI_VERSION:
+            raise RuntimeError(f"{path}: ABI version {found}, this package was written for {ABI_VERSION} "
+                               "(ADELIE_HIP_ABI_VERSION, include/adelie_hip.h) -- rebuild the library.")
 
     def fn(self, name):
         return getattr(self.lib, "adelie_hip_" + name)

@@ -24,11 +24,13 @@ __global__ __launch_bounds__(256) void cov_gather_kernel(const T* __restrict__ S
                                                          const int32_t* __restrict__ vcol, int32_t nv, int32_t pos0,
                                                          int32_t N, T* __restrict__ C, int64_t ldc) {
     const int32_t a = blockIdx.x * blockDim.x + threadIdx.x; // fastest index = row of C = row of A's column: coalesced-ish
-    const int32_t b = blockIdx.y;
-    if (a >= nv || b >= N) return;
-    const T val = a_at(S, lda, tr, int64_t(vcol[a]), int64_t(vcol[pos0 + b]));
-    C[a + int64_t(pos0 + b) * ldc] = val;
-    if (a < pos0) C[int64_t(pos0 + b) + int64_t(a) * ldc] = val;
+    if (a >= nv) return;
+    const int64_t ra = int64_t(vcol[a]);
+    for (int32_t b = blockIdx.y; b < N; b += gridDim.y) { // grid.y is capped at 65535: stride over the new values
+        const T val = a_at(S, lda, tr, ra, int64_t(vcol[pos0 + b]));
+        C[a + int64_t(pos0 + b) * ldc] = val;
+        if (a < pos0) C[int64_t(pos0 + b) + int64_t(a) * ldc] = val;
+    }
 }
 
 template <class T>
@@ -78,8 +80,9 @@ template <class T>
 void launch_cov_gather(const T* S, int64_t lda, int tr, const int32_t* vcol, int32_t nv, int32_t pos0, int32_t N, T* C,
                        int64_t ldc, hipStream_t s) {
     if (nv <= 0 || N <= 0) return;
-    hipLaunchKernelGGL((cov_gather_kernel<T>), dim3(unsigned((nv + 255) / 256), unsigned(N)), dim3(256), 0, s, S, lda, tr, vcol,
-                       nv, pos0, N, C, ldc);
+    hipLaunchKernelGGL((cov_gather_kernel<T>), dim3(unsigned((nv + 255) / 256), unsigned(N < 65535 ? N : 65535)), dim3(256),
+                       0, s, S, lda, tr, vcol, nv, pos0, N, C, ldc);
+    AHIP_CHECK(hipGetLastError());
 }
 template <class T>
 void launch_cov_bmul(const T* S, int64_t lda, int tr, const int64_t* subset, int64_t ns, const int64_t* indices,

@@ -3166,13 +3166,16 @@ struct Solver {
                     if (kd == 1) { // constraint_box.ipp:30-37
                         if (cb[g] < 0) throw make_core_error("upper must be >= 0.");
                         if (ca[g] > 0) throw make_core_error("lower must be <= 0.");
-                        cons_lo[g] = ca[g];
-                        cons_hi[g] = cb[g];
+                        // the Python classes clamp absent sides to +-max_solver_value (1e100, configs.hpp:13), which is +-inf
+                        // in f32 only: an absent side is +-INF here in either precision
+                        cons_lo[g] = (ca[g] <= -T(1e100)) ? -INF : ca[g];
+                        cons_hi[g] = (cb[g] >= T(1e100)) ? INF : cb[g];
                         if (cm) cons_mu[g] = cm[g];
                     } else if (kd == 2) { // constraint_one_sided.ipp:74-79: sgn * x <= b
                         if (std::abs(ca[g]) != 1) throw make_core_error("sgn must be a vector of +/-1.");
                         if (cb[g] < 0) throw make_core_error("b must be >= 0.");
-                        if (ca[g] > 0) cons_hi[g] = cb[g];
+                        if (cb[g] >= T(1e100)) { /* no bound on this side */ }
+                        else if (ca[g] > 0) cons_hi[g] = cb[g];
                         else cons_lo[g] = -cb[g];
                         if (cm) cons_mu[g] = ca[g] * cm[g];
                     } else {

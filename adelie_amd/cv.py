@@ -30,9 +30,15 @@ def _sweep_batch(backend, on):
     turn it off under each other."""
     global _batch_users
     with _batch_lock:
-        _batch_users += 1 if on else -1
-        if (on and _batch_users == 1) or (not on and _batch_users == 0):
-            return backend.fn("set_config")(b"sweep_batch", 1.0 if on else 0.0) == 0
+        if on:
+            if _batch_users == 0 and backend.fn("set_config")(b"sweep_batch", 1.0) != 0:
+                return False  # nothing was counted: the caller must not pair this with a disable
+            _batch_users += 1
+            return True
+        _batch_users = max(_batch_users - 1, 0)
+        if _batch_users == 0 and backend.fn("set_config")(b"sweep_batch", 0.0) != 0:
+            logger.warning("adelie_amd: could not switch the shared CV sweeps off again (set_config failed).")
+            return False
     return True
 
 
@@ -207,8 +213,9 @@ def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio
             # folds in flight share their full-gradient sweeps: the ones that reach a sweep within a short window are answered
             # by one pass over X (solver.hip::SweepBatcher)
             batch = X._backend.has("set_config") and os.environ.get("ADELIE_HIP_SWEEP_BATCH", "1") != "0"
-            if batch:
-                _sweep_batch(X._backend, True)
+            if batch and not _sweep_batch(X._backend, True):
+                logger.warning("adelie_amd: shared CV sweeps could not be enabled; the folds keep separate sweeps.")
+                batch = False
             # several folds in flight would interleave their progress bars: off unless asked for
             grpnet_params.setdefault("progress_bar", False)
             try:

@@ -14,64 +14,63 @@ from . import matrix
 logger = logging.getLogger("adelie_amd")
 
 
-def predict(X, betas, intercepts, offsets=None, n_threads: int = 1):
-    """Linear predictions ``eta_l = X beta_l + intercept_l + offsets`` for every row of ``betas``
-    (reference ``diagnostic.py:30-121``, single-response branch).  ``betas`` CSR goes through
-    ``X.sp_tmul`` — one device kernel over the resident design."""
-    intercepts = np.atleast_1d(intercepts)
-    is_multi = len(intercepts.shape) == 2
-    if isinstance(X, np.ndarray):
-        X = matrix.dense(X, method="naive", n_threads=n_threads)
-    if is_multi:  # (L, n, K) predictions through X (x) I_K  (diagnostic.py:84-88)
-        K = intercepts.shape[1]
-        n = X.rows()
-        X = matrix.kronecker_eye(X, K, n_threads=n_threads)
-        dtype = X.dtype
-        if offsets is None:
-            offsets = np.zeros((n, K), dtype=dtype)
-        if isinstance(betas, np.ndarray):
-            betas = csr_matrix(np.atleast_2d(betas))
-        L = betas.shape[0]
-        etas = np.zeros((L, n * K), order="C", dtype=dtype)
-        X.sp_tmul(betas, etas)
-        return etas.reshape(L, n, K) + intercepts[:, None] + np.asarray(offsets, dtype=dtype).reshape(n, K)
-    n = X.rows()
-    dtype = X.dtype
-    if offsets is None:
-        offsets = np.zeros((n,), dtype=dtype)
-    if isinstance(betas, np.ndarray):
-        betas = np.atleast_2d(betas)
-    L = betas.shape[0]
-    etas = np.zeros((L, n), order="C", dtype=dtype)
-    if isinstance(betas, np.ndarray):
-        for i in range(L):
-            X.btmul(0, X.cols(), betas[i], etas[i])
-    elif isinstance(betas, csr_matrix):
-        X.sp_tmul(betas, etas)
-    else:
+def _linear_maps(X, B, out):
+    """``out[l] = X @ B[l]`` for every row of ``B``: one ``sp_tmul`` kernel over the resident design for CSR rows, one
+    ``btmul`` per row for a dense array."""
+    if isinstance(B, csr_matrix):
+        X.sp_tmul(B, out)
+        return
+    if not isinstance(B, np.ndarray):
         raise RuntimeError("beta is not one of np.ndarray or scipy.sparse.csr_matrix.")
-    etas += intercepts[:, None] + offsets
+    ncol = X.cols()
+    for row, dst in zip(B, out):
+        X.btmul(0, ncol, row, dst)
+
+
+def predict(X, betas, intercepts, offsets=None, n_threads: int = 1):
+    """Linear predictions ``eta_l = X beta_l + intercept_l + offsets`` for every solution ``l`` (semantics of the
+    reference's ``diagnostic.py:30-121``): ``(L, n)`` for one response, ``(L, n, K)`` through the ``X (x) I_K`` view when
+    ``intercepts`` is two-dimensional."""
+    b0 = np.atleast_1d(intercepts)
+    design = matrix.dense(X, method="naive", n_threads=n_threads) if isinstance(X, np.ndarray) else X
+    n = design.rows()
+    K = b0.shape[1] if b0.ndim == 2 else None
+    if K is not None:
+        design = matrix.kronecker_eye(design, K, n_threads=n_threads)
+    dtype = design.dtype
+    B = np.atleast_2d(betas) if isinstance(betas, np.ndarray) else betas
+    if K is not None and isinstance(B, np.ndarray):
+        B = csr_matrix(B)
+    width = n if K is None else n * K
+    etas = np.zeros((B.shape[0], width), dtype=dtype)
+    _linear_maps(design, B, etas)
+    if K is not None:
+        etas = etas.reshape(-1, n, K)
+    shift = 0 if offsets is None else np.asarray(offsets, dtype=dtype).reshape(etas.shape[1:])
+    etas += b0[:, None] + shift
     return etas
 
 
 def coefficient(*, lmda: float, betas: csr_matrix, intercepts: np.ndarray, lmdas: np.ndarray):
-    """Linearly interpolated coefficient / intercept at ``lmda`` (reference ``diagnostic.py:577-646``)."""
-    if len(lmdas) == 0:
+    """Solution at ``lmda`` by linear interpolation between the two saved solutions that bracket it (semantics of the
+    reference's ``diagnostic.py:577-646``, including what it returns for a one-point path and its warning when ``lmda``
+    falls outside the saved range)."""
+    lmdas = np.asarray(lmdas)
+    L = lmdas.shape[0]
+    if L == 0:
         raise RuntimeError("lmdas must be non-empty!")
-    if len(lmdas) == 1:
-        return betas, lmdas  # (sic) reference diagnostic.py:623
-    order = np.argsort(lmdas)
-    idx = np.searchsorted(lmdas, lmda, sorter=order)
-    idx = lmdas.shape[0] - idx
-    if idx == 0 or idx == lmdas.shape[0]:
+    if L == 1:
+        return betas, lmdas  # the reference hands back (betas, lmdas) here, not (beta, intercept): diagnostic.py:623
+    # On a decreasing path the number of saved lambdas >= lmda is the index of the first solution below lmda.
+    below = int(np.count_nonzero(lmdas >= lmda))
+    if below == 0 or below == L:
         logger.warning("lmda is not within the range of the saved lambdas. Returning boundary solution.")
-        idx = np.clip(idx, 0, lmdas.shape[0] - 1)
-        return betas[idx], intercepts[idx]
-    left, right = betas[idx - 1], betas[idx]
-    weight = (lmda - lmdas[idx]) / (lmdas[idx - 1] - lmdas[idx])
-    beta = left.multiply(weight) + right.multiply(1 - weight)
-    left, right = intercepts[idx - 1], intercepts[idx]
-    intercept = weight * left + (1 - weight) * right
+        edge = min(below, L - 1)
+        return betas[edge], intercepts[edge]
+    above = below - 1
+    t = (lmda - lmdas[below]) / (lmdas[above] - lmdas[below])
+    beta = betas[above].multiply(t) + betas[below].multiply(1 - t)
+    intercept = t * intercepts[above] + (1 - t) * intercepts[below]
     return beta, intercept
 
 

@@ -57,21 +57,22 @@ class PyMatrixNaiveTranspose:
         self.T = mat
 
     def __matmul__(self, v):
-        dtype = self._mat.dtype
-        v = np.asarray(v, dtype=dtype)
-        if (len(v.shape) <= 0) or (len(v.shape) > 2):
+        """``X.T @ v`` for a vector (-> ``(p,)``) or an ``(n, m)`` array (-> ``(p, m)``).  Several right-hand sides go
+        to the device together when the design has the batched sweep (X read once per eight vectors)."""
+        X = self._mat
+        rhs = np.asarray(v, dtype=X.dtype)
+        if rhs.ndim not in (1, 2):
             raise ValueError("Right argument must be either 1 or 2-dimensional.")
-        n, p = self._mat.shape
-        ones = np.ones(n, dtype=dtype)
-        if len(v.shape) == 1:
-            out = np.empty(p, dtype=dtype)
-            self._mat.mul(v, ones, out)
-            return out
-        v = np.asfortranarray(v)
-        out = np.empty((v.shape[1], p), dtype=dtype)
-        for i in range(out.shape[0]):
-            self._mat.mul(v[:, i], ones, out[i])
-        return out.T
+        n, p = X.shape
+        cols = rhs.reshape(n, -1).T  # (m, n): one right-hand side per row
+        if rhs.ndim == 2 and hasattr(X, "mul_batch"):
+            res = np.asarray(X.mul_batch(np.ascontiguousarray(cols)))
+        else:
+            unit = np.ones(n, dtype=X.dtype)
+            res = np.empty((cols.shape[0], p), dtype=X.dtype)
+            for src, dst in zip(cols, res):
+                X.mul(np.ascontiguousarray(src), unit, dst)
+        return res[0] if rhs.ndim == 1 else res.T
 
 
 class _NativeMatrix:
@@ -291,25 +292,22 @@ class _NativeMatrix:
 
     # -- python sugar (matrix.py:79-191) ---------------------------------------------------
     def __matmul__(self, v):
-        dtype = self.dtype
+        """``X @ v``: ``(p,)`` -> ``(n,)``, dense ``(p, m)`` -> ``(n, m)``; a scipy CSR / CSC right-hand side is applied by
+        the sparse kernel (``sp_tmul`` on its transpose) in one call."""
         n, p = self.shape
         if isinstance(v, (csr_matrix, csc_matrix)):
-            v = v.tocsr().transpose()
-            out = np.empty((v.shape[0], n), dtype=dtype)
-            self.sp_tmul(v, out)
-            return out.T
-        v = np.asarray(v, dtype=dtype)
-        if (len(v.shape) <= 0) or (len(v.shape) > 2):
+            vt = v.tocsr().transpose()
+            res = np.empty((vt.shape[0], n), dtype=self.dtype)
+            self.sp_tmul(vt, res)
+            return res.T
+        rhs = np.asarray(v, dtype=self.dtype)
+        if rhs.ndim not in (1, 2):
             raise ValueError("Right argument must be either 1 or 2-dimensional.")
-        if len(v.shape) == 1:
-            out = np.zeros(n, dtype=dtype)
-            self.btmul(0, p, v, out)
-            return out
-        v = np.asfortranarray(v)
-        out = np.zeros((v.shape[1], n), dtype=dtype)
-        for i in range(out.shape[0]):
-            self.btmul(0, p, v[:, i], out[i])
-        return out.T
+        coefs = rhs.reshape(p, -1).T  # (m, p): one coefficient vector per row
+        res = np.zeros((coefs.shape[0], n), dtype=self.dtype)
+        for src, dst in zip(coefs, res):
+            self.btmul(0, p, np.ascontiguousarray(src), dst)
+        return res[0] if rhs.ndim == 1 else res.T
 
     # -- helpers ---------------------------------------------------------------------------
     def _out(self, out):

@@ -25,7 +25,9 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in syms if not hasattr(b.lib, s)]
     assert not missing, missing
     assert sorted("adelie_hip_" + s for s in _abi.HIP_SYMBOLS) == syms
-    assert b.fn("abi_version")() == 3
+    hdr = open(os.path.join(ROOT, "include", "adelie_hip.h")).read()
+    declared = int(re.search(r"#define\s+ADELIE_HIP_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert b.fn("abi_version")() == declared == _abi.ABI_VERSION
 
 
 def test_ctypes_struct_matches_c_layout():

@@ -36,7 +36,21 @@ template <class T>
 __device__ __forceinline__ void blk_part_sum(const CdBlkParams<T>& p, int nb, T* gsum8 /* [8][BLK] in LDS */, int wtid) {
     const int c = wtid & (BLK - 1), k0 = wtid >> 7; // wtid in [0, 1024)
     T acc = T(0);
-    if (c < nb) {
+    if (p.part_ld == 0) {
+        // slice-major partials part[k * BLK + c]: the 128 threads of a row read 1 KB contiguously; every thread issues its
+        // loads in batches of eight before it sums them (fixed order k0, k0 + 8, ...)
+        const T* pc = p.part + c;
+        int k = k0;
+        for (; k + 56 < p.part_n; k += 64) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = pc[int64_t(k + 8 * u) * BLK];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; k < p.part_n; k += 8) acc += pc[int64_t(k) * BLK];
+        if (c >= nb) acc = T(0);
+    } else if (c < nb) {
         const T* pc = p.part + int64_t(c) * p.part_ld;
         int k = k0;
         for (; k + 24 < p.part_n; k += 32) {

@@ -35,6 +35,72 @@ struct DevAllocStats {
     static long& calls() { static long c = 0; return c; }
 };
 
+// Pinned staging arena for the many small host<->device copies of a path (screen-set appends, per-fit scalars, coefficient
+// downloads: ~15 per lambda).  hipMemcpyAsync on pageable host memory costs the calling thread ~20 us per copy on this
+// platform (staging + an internal wait); from / to pinned memory it is an enqueue.  A solve installs its arena for the
+// calling thread (Staging::Scope) and DevBuf::upload / download on the arena's stream go through it: uploads snapshot the
+// host data into a slot, downloads land in a slot and reach their destination at the next Staging::flush() — which the
+// owner calls after every host wait that covers the staged copies (stream synchronisation, or an event recorded behind
+// them).  Slots are recycled after a full stream synchronisation (reset()) or up to a mark whose event was waited for (release()).  When the arena is exhausted the
+// copies fall back to the pageable path (correct, slower).
+struct Staging {
+    char* base = nullptr;
+    size_t cap = 0, head = 0, tail = 0; // ring: slots live in [tail, head) (modulo cap); head == tail: empty
+    hipStream_t stream = nullptr;
+    struct Pend { void* dst; const void* src; size_t bytes; };
+    std::vector<Pend> pend;
+    size_t n_fallback = 0; // copies on this arena's stream that did not fit and went the pageable way
+    Staging() = default;
+    Staging(const Staging&) = delete;
+    Staging& operator=(const Staging&) = delete;
+    ~Staging() { if (base) (void)hipHostFree(base); }
+    void init(size_t bytes, hipStream_t s) {
+        stream = s;
+        if (base) return;
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, bytes, hipHostMallocDefault) == hipSuccess) {
+            base = static_cast<char*>(hp);
+            cap = bytes;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    void* take(size_t bytes) {
+        if (!base) return nullptr;
+        bytes = (bytes + 63) & ~size_t(63);
+        size_t at;
+        if (head >= tail) { // free: [head, cap) and [0, tail)
+            if (head + bytes <= cap) at = head;
+            else if (bytes < tail) at = 0;
+            else return nullptr;
+        } else {            // free: [head, tail)
+            if (head + bytes < tail) at = head;
+            else return nullptr;
+        }
+        head = at + bytes;
+        return base + at;
+    }
+    // every staged download is complete (the owner waited for the stream, or for an event recorded behind them)
+    void flush() {
+        for (const Pend& q : pend) std::memcpy(q.dst, q.src, q.bytes);
+        pend.clear();
+    }
+    // `m = mark()` taken when an event was recorded; after waiting for that event the slots handed out before it are free
+    size_t mark() const { return head; }
+    void release(size_t m) { tail = m; }
+    // after a full stream synchronisation
+    void reset() {
+        flush();
+        head = tail = 0;
+    }
+    static Staging*& current() { static thread_local Staging* cur = nullptr; return cur; }
+    struct Scope {
+        Staging* prev;
+        explicit Scope(Staging* s) : prev(current()) { current() = s; }
+        ~Scope() { current() = prev; }
+    };
+};
+
 // Owning device buffer (grow-only).
 template <class T>
 struct DevBuf {
@@ -82,10 +148,30 @@ struct DevBuf {
         return p;
     }
     void upload(const T* h, size_t n, hipStream_t s, size_t off = 0) {
-        if (n) AHIP_CHECK(hipMemcpyAsync(p + off, h, n * sizeof(T), hipMemcpyHostToDevice, s));
+        if (!n) return;
+        Staging* sg = Staging::current();
+        if (sg && sg->stream == s) {
+            if (void* slot = sg->take(n * sizeof(T))) {
+                std::memcpy(slot, h, n * sizeof(T));
+                AHIP_CHECK(hipMemcpyAsync(p + off, slot, n * sizeof(T), hipMemcpyHostToDevice, s));
+                return;
+            }
+            ++sg->n_fallback;
+        }
+        AHIP_CHECK(hipMemcpyAsync(p + off, h, n * sizeof(T), hipMemcpyHostToDevice, s));
     }
+    // NOTE: with a staging arena installed the data reaches `h` at the owner's next Staging::flush() (Solver::sync()).
     void download(T* h, size_t n, hipStream_t s, size_t off = 0) const {
-        if (n) AHIP_CHECK(hipMemcpyAsync(h, p + off, n * sizeof(T), hipMemcpyDeviceToHost, s));
+        if (!n) return;
+        Staging* sg = Staging::current();
+        if (sg && sg->stream == s) {
+            if (void* slot = sg->take(n * sizeof(T))) {
+                AHIP_CHECK(hipMemcpyAsync(slot, p + off, n * sizeof(T), hipMemcpyDeviceToHost, s));
+                sg->pend.push_back(Staging::Pend{h, slot, n * sizeof(T)});
+                return;
+            }
+        }
+        AHIP_CHECK(hipMemcpyAsync(h, p + off, n * sizeof(T), hipMemcpyDeviceToHost, s));
     }
 };
 

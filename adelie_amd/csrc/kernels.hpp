@@ -331,13 +331,15 @@ void launch_panel_reduce_ld(const T* part, int64_t part_ld, int nslices, int nb,
                             const T* xm_by_col, T* gblk, hipStream_t s);
 // fused look-ahead step: the solve of block j (sp, as launch_cd_panel_solve) and a panel step in ONE launch; returns the
 // leading dimension of `part` (>= number of row slices; use launch_panel_reduce_ld).  `part` holds 2*panel_part_elems(n).
+// `tr`: slice-major partials part[k * 128 + c] (for a solve that sums them itself, CdBlkParams::part with part_ld == 0);
+// the return value is then the number of partials per column.
 template <class T>
 int launch_panel_fused(const CdBlkParams<T>& sp, int j, const DenseView<T>& X, const T* w, T* r, const int32_t* dcol,
-                       const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s);
+                       const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, bool tr, hipStream_t s);
 template <class T>
 int launch_panel_fused_snp(const CdBlkParams<T>& sp, int j, const SnpView& X, const T* impute, const T* w, T* r,
                            const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part,
-                           hipStream_t s);
+                           bool tr, hipStream_t s);
 template <class T>
 int launch_panel_fused_grp(const CdGrpBlkParams<T>& sp, int j, const DenseView<T>& X, const T* w, T* r, const int32_t* dcol,
                            const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s);

@@ -191,7 +191,7 @@ __device__ __forceinline__ void panel_step_body(const Acc& X, int64_t n, const T
         const T tot = reduce8(pu, lane);
         if (lane < UB && c0 + 4 * lane < nb) {
             if constexpr (WGRED) red[0][c0 + 4 * lane] = tot; // (64 * VEC >= 128 columns)
-            else part[int64_t(c0 + 4 * lane) * part_ld + slice] = tot;
+            else part[part_ld > 0 ? int64_t(c0 + 4 * lane) * part_ld + slice : slice * PB + (c0 + 4 * lane)] = tot;
         }
     }
 }
@@ -261,7 +261,8 @@ __global__ __launch_bounds__(256 * FS) void panel_fused_kernel(CdBlkParams<T> sp
         if (threadIdx.x < nb) {
             const T* b0 = reinterpret_cast<const T*>(smem_raw);
             const int c = threadIdx.x;
-            part[int64_t(c) * part_ld + (blockIdx.x - 1)] =
+            // part_ld == 0: slice-major layout part[k * PB + c] (coalesced here and in the solve that sums the partials itself)
+            part[part_ld > 0 ? int64_t(c) * part_ld + (blockIdx.x - 1) : int64_t(blockIdx.x - 1) * PB + c] =
                 (b0[c] + b0[size_t(5) * RS + c]) + (b0[size_t(10) * RS + c] + b0[size_t(15) * RS + c]);
         }
     } else {
@@ -365,7 +366,7 @@ int fused_grp_launch(const CdGrpBlkParams<T>& sp, int j, const Acc& acc, int64_t
 
 template <class T, class Acc, int VEC>
 int fused_launch(const CdBlkParams<T>& sp, int j, const Acc& acc, int64_t n, const T* w, T* r, const int32_t* dcol,
-                 const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s) {
+                 const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, bool tr, hipStream_t s) {
     constexpr int RS = 64 * VEC;
     const int64_t ns = (n + RS - 1) / RS;
     const int64_t nwg = (ns + FS - 1) / FS;
@@ -379,7 +380,7 @@ int fused_launch(const CdBlkParams<T>& sp, int j, const Acc& acc, int64_t n, con
         attr_done = true;
     }
     hipLaunchKernelGGL((panel_fused_kernel<T, Acc, VEC>), dim3((unsigned)(nwg + 1)), dim3(256 * FS), blk_solve_lds_fused<T>(), s, sp,
-                       j, acc, n, w, r, dcol, dlt, nz_dev, cols, nb, part, part_ld);
+                       j, acc, n, w, r, dcol, dlt, nz_dev, cols, nb, part, tr ? int64_t(0) : part_ld);
     return int(part_ld);
 }
 
@@ -387,19 +388,19 @@ int fused_launch(const CdBlkParams<T>& sp, int j, const Acc& acc, int64_t n, con
 
 template <class T>
 int launch_panel_fused(const CdBlkParams<T>& sp, int j, const DenseView<T>& X, const T* w, T* r, const int32_t* dcol,
-                       const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s) {
+                       const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, bool tr, hipStream_t s) {
     DenseAcc<T> acc{X.X, X.ld};
     constexpr int V = VecOf<T>::N;
     const bool vecok = (X.ld % V == 0) && ((reinterpret_cast<uintptr_t>(X.X) % 16) == 0);
-    if (vecok) return fused_launch<T, DenseAcc<T>, V>(sp, j, acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
-    return fused_launch<T, DenseAcc<T>, 1>(sp, j, acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
+    if (vecok) return fused_launch<T, DenseAcc<T>, V>(sp, j, acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, tr, s);
+    return fused_launch<T, DenseAcc<T>, 1>(sp, j, acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, tr, s);
 }
 template <class T>
 int launch_panel_fused_snp(const CdBlkParams<T>& sp, int j, const SnpView& X, const T* impute, const T* w, T* r,
                            const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part,
-                           hipStream_t s) {
+                           bool tr, hipStream_t s) {
     SnpAcc<T> acc{X.bits, X.ldb, impute};
-    return fused_launch<T, SnpAcc<T>, 4>(sp, j, acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
+    return fused_launch<T, SnpAcc<T>, 4>(sp, j, acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, tr, s);
 }
 
 template <class T>
@@ -471,7 +472,7 @@ void launch_gather_i32(const int32_t* src, const int32_t* idx, int cnt, int32_t*
     template void launch_panel_reduce_ld<T>(const T*, int64_t, int, int, const int32_t*, const T*, const T*, T*,       \
                                             hipStream_t);                                                              \
     template int launch_panel_fused<T>(const CdBlkParams<T>&, int, const DenseView<T>&, const T*, T*, const int32_t*,  \
-                                       const T*, const int32_t*, const int32_t*, int, T*, hipStream_t);                \
+                                       const T*, const int32_t*, const int32_t*, int, T*, bool, hipStream_t);          \
     template int launch_panel_fused_grp<T>(const CdGrpBlkParams<T>&, int, const DenseView<T>&, const T*, T*,           \
                                            const int32_t*, const T*, const int32_t*, const int32_t*, int, T*,          \
                                            hipStream_t);                                                               \
@@ -479,7 +480,7 @@ void launch_gather_i32(const int32_t* src, const int32_t* idx, int cnt, int32_t*
                                                const int32_t*, const T*, const int32_t*, const int32_t*, int, T*,      \
                                                hipStream_t);                                                           \
     template int launch_panel_fused_snp<T>(const CdBlkParams<T>&, int, const SnpView&, const T*, const T*, T*,         \
-                                           const int32_t*, const T*, const int32_t*, const int32_t*, int, T*,          \
+                                           const int32_t*, const T*, const int32_t*, const int32_t*, int, T*, bool,    \
                                            hipStream_t);                                                               \
     template void launch_center_vars<T>(T*, const T*, int, bool, hipStream_t);
 INST(double)

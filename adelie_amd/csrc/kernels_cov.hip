@@ -82,7 +82,6 @@ void launch_cov_gather(const T* S, int64_t lda, int tr, const int32_t* vcol, int
     if (nv <= 0 || N <= 0) return;
     hipLaunchKernelGGL((cov_gather_kernel<T>), dim3(unsigned((nv + 255) / 256), unsigned(N < 65535 ? N : 65535)), dim3(256),
                        0, s, S, lda, tr, vcol, nv, pos0, N, C, ldc);
-    AHIP_CHECK(hipGetLastError());
 }
 template <class T>
 void launch_cov_bmul(const T* S, int64_t lda, int tr, const int64_t* subset, int64_t ns, const int64_t* indices,

@@ -77,16 +77,21 @@ __device__ __forceinline__ void load_rows(const Acc& X, int64_t j, bool valid, i
 }
 
 // Block tile BM x BN = 128 x {64,128}; 4 waves: 2x2 of 64x64 (BN=128) or 4x1 of 32x64 (BN=64).
-template <class T, class Acc, bool VECOK, int BN>
+// WNX = 4 (BN = 128): the four waves side by side, each 128 rows x 32 columns (8 x 2 MFMA tiles) — the "row strip" form of
+// the batched cross blocks: the row tiles at or beyond M are skipped (MFMAs, fragment reads and the partial-tile stores), so
+// a strip of M new rows costs ceil(M / 16) / 8 of a full block.
+template <class T, class Acc, bool VECOK, int BN, int WNX = BN / 64>
 __device__ __forceinline__ void gram_body(const Acc& X, const T* __restrict__ w, const int32_t* __restrict__ mcols,
                                           int32_t M, const int32_t* __restrict__ ncols, int32_t N, int64_t n,
                                           int64_t kchunk, int32_t m_pos0, int32_t n_pos0, int symmetric,
                                           T* __restrict__ part, int64_t Mpad, int64_t Npad, int32_t ncol0,
                                           int32_t Mt, int32_t Nt, int32_t nsplit) {
-    constexpr int WN = BN / 64;            // waves along N
+    constexpr int WN = WNX;                // waves along N
     constexpr int WM = 4 / WN;             // waves along M
-    constexpr int TM = BM / WM / 16;       // MFMA tiles per wave along M (4 or 2)
-    constexpr int TN = 4;                  // 64 columns per wave along N
+    constexpr int TM = BM / WM / 16;       // MFMA tiles per wave along M (4, 2 or 8)
+    constexpr int CW = BN / WN;            // columns per wave along N (64 or 32)
+    constexpr int TN = CW / 16;
+    constexpr bool STRIP = (WNX == 4 && BN == 128);
     constexpr int RA = KT * BM / GT;       // rows of one A column staged per thread (16)
     constexpr int RB = KT * BN / GT;       // rows of one B column staged per thread (16 or 8)
     // XCD-aware block -> tile map: workgroup L runs on XCD L % 8 (guides/MI355X_MICROARCH.md).  The Nt tiles that share
@@ -142,6 +147,8 @@ __device__ __forceinline__ void gram_body(const Acc& X, const T* __restrict__ w,
 
     if (k0 < kend) fetch(k0);
     const int fr = (lane & 15), fk = (lane >> 4);
+    // STRIP: row tiles of this wave that hold rows below M (wave-uniform)
+    const int tm_live = STRIP ? min(TM, (M - bm * BM - wm * (BM / WM) + 15) / 16) : TM;
     for (int64_t k = k0; k < kend; k += KT) {
         __syncthreads(); // previous stage fully consumed
 #pragma unroll
@@ -153,31 +160,36 @@ __device__ __forceinline__ void gram_body(const Acc& X, const T* __restrict__ w,
         if (k + KT < kend) fetch(k + KT); // in flight while the MFMAs run
 #pragma unroll
         for (int kk = 0; kk < KT / 4; ++kk) {
-            T a[TM], b[TN];
+            T a[TM] = {}, b[TN];
             const T wk = Ws[kk * 4 + fk];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[(wm * (BM / WM) + i * 16 + fr) * LDK + kk * 4 + fk];
+            for (int i = 0; i < TM; ++i)
+                if (!STRIP || i < tm_live) a[i] = As[(wm * (BM / WM) + i * 16 + fr) * LDK + kk * 4 + fk];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[(wn * 64 + j * 16 + fr) * LDK + kk * 4 + fk] * wk;
+            for (int j = 0; j < TN; ++j) b[j] = Bs[(wn * CW + j * 16 + fr) * LDK + kk * 4 + fk] * wk;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
+                if (!STRIP || i < tm_live) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
+                }
         }
     }
 
     // partial tile -> part[sp][col][row]  (col = N index, row = M index)
     T* P = part + int64_t(sp) * Mpad * Npad;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+        if (STRIP && i >= tm_live) continue; // (the reduce only reads rows below M)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = bm * BM + wm * (BM / WM) + i * 16 + Mfma<T>::row(lane, e);
-                const int col = ncol0 + bn * BN + wn * 64 + j * 16 + (lane & 15);
+                const int col = ncol0 + bn * BN + wn * CW + j * 16 + (lane & 15);
                 P[int64_t(col) * Mpad + row] = acc[i][j][e];
             }
+    }
 }
 
 template <class T, class Acc, bool VECOK, int BN>
@@ -199,8 +211,8 @@ __global__ __launch_bounds__(GT, 2) void gram_batch_kernel(Acc X, const T* __res
                                                         GramBatch b, int64_t n, int64_t kchunk, T* __restrict__ part,
                                                         int32_t nsplit) {
     const int y = blockIdx.y;
-    gram_body<T, Acc, VECOK, 128>(X, w, cols_base + b.moff[y], b.m[y], cols_base + b.noff[y], b.nn[y], n, kchunk, 0, 0, 0,
-                                  part + int64_t(y) * nsplit * BM * 128, BM, 128, 0, 1, 1, nsplit);
+    gram_body<T, Acc, VECOK, 128, 4>(X, w, cols_base + b.moff[y], b.m[y], cols_base + b.noff[y], b.nn[y], n, kchunk, 0, 0, 0,
+                                     part + int64_t(y) * nsplit * BM * 128, BM, 128, 0, 1, 1, nsplit);
 }
 
 template <class T>

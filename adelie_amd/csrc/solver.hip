@@ -156,7 +156,7 @@ struct Counters {
     int64_t n_basil_iters = 0, n_sweeps = 0, n_cd_visits_screen = 0, n_cd_visits_active = 0, n_updates = 0,
             n_irls_iters = 0, n_new_screen_cols = 0, n_cd_passes_screen = 0, n_cd_passes_active = 0,
             n_gram_col_reads = 0, n_resid_col_reads = 0, n_panel_blocks = 0, n_panel_grams = 0, n_panel_cols = 0,
-            n_irls_screen_cols = 0;
+            n_irls_screen_cols = 0, n_sweeps_shared = 0, n_update_cols = 0;
     double gram_flops = 0;
 };
 
@@ -400,7 +400,7 @@ struct Solver {
     int64_t cd_dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<std::pair<idx, idx>> gram_shapes;
     double t_host[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // wall-clock split of solve(): screen logic, append, gram+vars, fit, invariance, kkt+solutions
-    double t_host_screen = 0;
+    double t_host_screen = 0, t_host_screen_wait = 0;
     std::string error;
     double total_time = 0;
 
@@ -492,6 +492,12 @@ struct Solver {
         }
         bool first = true;
         const bool side = side_grams && st2 != nullptr;
+        if (side && pass_e0_valid) { // the pass recorded "inputs final" on the main stream before its first step went out
+            AHIP_CHECK(hipStreamWaitEvent(st2, pass_e0, 0));
+            for (int k = 0; k < kMaxExtra; ++k)
+                if (st_x[k]) AHIP_CHECK(hipStreamWaitEvent(st_x[k], pass_e0, 0));
+            first = false;
+        }
         auto pick_side = [&]() { return !side ? 0 : ((n_side >= 2 && st_x[0] && !multi()) ? 1 + (n_built_side++ % n_side) : 1); };
         auto open_side = [&]() {
             if (side && first) { // the weights (and everything else the builds read) are final at this point of the main stream
@@ -554,6 +560,19 @@ struct Solver {
             i = k;
         }
     }
+    // Recorded by a panel pass on the main stream BEFORE it enqueues its first step: the side streams' builds wait for this
+    // event instead of one recorded behind the step, so the host can launch the step first (it does not depend on the builds)
+    // and enqueue the builds while it runs (the ~50 us of host time per pass that enqueueing them takes used to leave the
+    // chain idle: 6 ms per headline path)
+    hipEvent_t pass_e0 = nullptr;
+    bool pass_e0_valid = false;
+    void record_pass_e0() {
+        pass_e0_valid = false;
+        if (!(side_grams && st2 != nullptr)) return;
+        if (!pass_e0) AHIP_CHECK(hipEventCreateWithFlags(&pass_e0, hipEventDisableTiming));
+        AHIP_CHECK(hipEventRecord(pass_e0, st));
+        pass_e0_valid = true;
+    }
     bool prebuild_enabled = true; // A/B hook ADELIE_HIP_PREBUILD=0
     bool fuse_reduce = false;     // look-ahead passes: the solve sums the previous launch's slice partials itself instead of a panel_reduce launch (hook ADELIE_HIP_FUSE_REDUCE=1; measured slower: 3.08 vs 3.20 paths/s, the solve's longer prologue lengthens the fused launch by more than the reduce launch cost)
     DevBuf<T> d_part2;
@@ -564,6 +583,8 @@ struct Solver {
     int batch_blocks = 8; // diagonal blocks per build launch (tuning hook ADELIE_HIP_BATCH_BLOCKS, 1..16)
     int cross_batch = 8;  // cross blocks per build launch (hook ADELIE_HIP_CROSS_BATCH, 1 = one gram launch per block)
     std::vector<int> stale_x;
+    bool cross_incremental = true; // A/B hook ADELIE_HIP_CROSS_INCR=0: a cross block that gained rows is rebuilt whole
+    int x_rows_new[GramBatch::MAX] = {};
     // host-mapped end-of-pass report (state + sequence number), see CdBlkParams::host_st
     struct PassReport { CdBlkState<T> st; int32_t seq; int32_t pad[15]; };
     PassReport* h_report = nullptr;
@@ -582,6 +603,7 @@ struct Solver {
             }
 
         if (spec_ev) (void)hipEventDestroy(spec_ev);
+        if (pass_e0) (void)hipEventDestroy(pass_e0);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         for (hipEvent_t e : pre_pool) (void)hipEventDestroy(e);
     }
@@ -608,7 +630,7 @@ struct Solver {
     void build_stale_cross(int nblk, std::vector<XKey>& tab, T* xpool, NbOf nb_of, ColsOf cols_of) {
         const int SL = cd_block_size();
         x_ev.assign(size_t(nblk), nullptr);
-        bool first = true;
+        bool first = !(pass_e0_valid && side_grams && st2 != nullptr); // (the diagonal-block builder made st2 wait for pass_e0)
         if (!multi() && cross_batch > 1) {
             // several stale cross blocks per launch (gram_batch_kernel): their K-splits share one round over the chip, so the
             // split-K partials written and re-read per block shrink with the batch (134 MB for a block built alone)
@@ -633,11 +655,18 @@ struct Solver {
                 gb.count = int32_t(k - i);
                 for (size_t t = i; t < k; ++t) {
                     const int j = sx[t];
-                    gb.moff[t - i] = int32_t(cols_of(j) - cols_base);
-                    gb.m[t - i] = nb_of(j);
+                    // Both visiting lists only grow by appending, so the rows of a cross block that were built for this weight
+                    // version against the same (full) previous block stay valid when the block gains members: only the rows
+                    // of the newcomers are computed (the batch kernel skips the 16-row tiles beyond them)
+                    const XKey& key = tab[size_t(j)];
+                    const int have = (cross_incremental && key.ver == w_version && key.nb_prev == nb_of(j - 1) &&
+                                      key.nb > 0 && key.nb < nb_of(j)) ? key.nb : 0;
+                    gb.moff[t - i] = int32_t(cols_of(j) - cols_base) + have;
+                    gb.m[t - i] = nb_of(j) - have;
+                    x_rows_new[t - i] = nb_of(j) - have;
                     gb.noff[t - i] = int32_t(cols_of(j - 1) - cols_base);
                     gb.nn[t - i] = nb_of(j - 1);
-                    gb.dst[t - i] = int64_t(j) * SL * SL;
+                    gb.dst[t - i] = int64_t(j) * SL * SL + have;
                 }
                 T* work = (side ? d_work_gram2 : d_work_gram)
                               .reserve(size_t(std::max<int64_t>(gram_batch_work_elems(n, gb.count), syrk_work_elems(n, 128))));
@@ -656,8 +685,8 @@ struct Solver {
                     XKey& key = tab[size_t(j)];
                     key.nb_prev = nb_of(j - 1); key.nb = nb_of(j); key.ver = w_version;
                     x_ev[size_t(j)] = e;
-                    cnt.gram_flops += 2.0 * double(n) * double(nb_of(j)) * double(nb_of(j - 1));
-                    cnt.n_gram_col_reads += nb_of(j) + nb_of(j - 1);
+                    cnt.gram_flops += 2.0 * double(n) * double(x_rows_new[t - i]) * double(nb_of(j - 1));
+                    cnt.n_gram_col_reads += x_rows_new[t - i] + nb_of(j - 1);
                     ++n_cross_blocks;
                 }
                 i = k;
@@ -774,8 +803,10 @@ struct Solver {
             return;
         }
         if (batcher && dense() && !cols && ncols == p && !square &&
-            batcher->template sweep<T>(D->dense<T>(), v, out, sub_scale, sub_vec, st))
+            batcher->template sweep<T>(D->dense<T>(), v, out, sub_scale, sub_vec, st)) {
+            ++cnt.n_sweeps_shared;
             return;
+        }
         T* work = d_work_sweep.reserve(size_t(sweep_work_elems(n, ncols)));
         if (dense()) launch_sweep<T>(D->dense<T>(), v, out, 0, ncols, cols, sub_scale, sub_vec, square, work, st);
         else launch_sweep_snp<T>(D->snp(), static_cast<const T*>(D->impute), v, out, 0, ncols, cols, sub_scale, sub_vec, square, work, st);
@@ -868,7 +899,15 @@ struct Solver {
         cnt.gram_flops += 2.0 * double(n) * double(M) * double(N);
         gram_shapes.emplace_back(M, N);
     }
-    void sync() { AHIP_CHECK(hipStreamSynchronize(st)); }
+    // pinned staging for the small per-lambda copies (common.hpp::Staging; A/B hook ADELIE_HIP_STAGING=0)
+    Staging stage;
+    double t_sync_total = 0; // host seconds inside sync() (bench: splits the host phases into compute and waiting)
+    void sync() {
+        const auto t0 = std::chrono::steady_clock::now();
+        AHIP_CHECK(hipStreamSynchronize(st));
+        t_sync_total += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        stage.reset();
+    }
 
     // ---------------------------------------------------------------------------------------------------------
     // solver_base.hpp:20-110 on the host (used at construction only; later abs_grad comes from the device)
@@ -939,6 +978,7 @@ struct Solver {
         std::vector<int32_t> vcol, sbegin, ssize, slot_idx;
         std::vector<T> spen, beta_new;
         std::vector<int8_t> isact;
+        const size_t fallbacks0 = stage.n_fallback;
         const idx nv_old = nv;
         idx nv_new = nv_old;
         for (idx ss = ns_dev; ss < ns; ++ss) {
@@ -979,7 +1019,9 @@ struct Solver {
         if (slot_host.size() != size_t(G)) slot_host.assign(G, -1);
         for (idx ss = ns_dev; ss < ns; ++ss) slot_host[screen_set[ss]] = int32_t(screen_begins[ss]);
         d_slot.upload(slot_host.data(), size_t(G), st);
-        sync(); // the staging vectors above go out of scope
+        // the vectors above go out of scope: wait unless every upload took a snapshot into the pinned arena (a wait here also
+        // waits for the speculative pass that may be running in-stream: 0.3 ms per lambda on the headline path)
+        if (Staging::current() != &stage || !stage.base || stage.n_fallback != fallbacks0) sync();
         ns_dev = ns;
         nv = nv_new;
         // Gram capacity: `gcap` columns, leading dimension ldc = gcap rounded up to 2048 rows (the CD kernel reads
@@ -1018,6 +1060,7 @@ struct Solver {
                                  d_C.p, ldc, st);
         else
             gram(w_dev, nv, pos0, N, xm_dev, intercept);
+        AHIP_CHECK(hipGetLastError());
         gram_nv = nv;
         cnt.n_new_screen_cols += N;
         launch_diag_vars<T>(d_C.p, ldc, int32_t(pos0), int32_t(N), d_vars.p, st);
@@ -1596,11 +1639,11 @@ struct Solver {
             auto cols_of = [&](int j) { return cols_all + size_t(j) * B; };
             Stopwatch sw_enq;
             sw_enq.start();
-            build_stale_blocks(nblk, tab_nb, tab_ver, pool, nb_of, cols_of);
-            build_stale_cross(nblk, screen_pass ? xscr_key : xact_key, xpool, nb_of, cols_of);
+            record_pass_e0();
             t_cd.begin(st);
             // first step of the pass: applies the pending changes of the previous pass's last block and prepares blocks 0 AND 1
-            // (block 1 from a residual without block 0's changes)
+            // (block 1 from a residual without block 0's changes).  It goes out before the block builds are enqueued: it does
+            // not depend on them, and enqueueing them takes the host about as long as the step runs.
             const int nb01 = nb_of(0) + (nblk > 1 ? nb_of(1) : 0);
             {
                 const int ps = pending_slot;
@@ -1612,6 +1655,9 @@ struct Solver {
                 launch_panel_reduce<T>(d_part.p, nsl, nb01, cols_all, &d_blk.p->resid_sum, xm_c, d_la_g.p, st);
                 cnt.n_panel_cols += nb01;
             }
+            build_stale_blocks(nblk, tab_nb, tab_ver, pool, nb_of, cols_of);
+            build_stale_cross(nblk, screen_pass ? xscr_key : xact_key, xpool, nb_of, cols_of);
+            pass_e0_valid = false;
             int prev_ld = 0;         // partials of block j left behind by the previous fused launch (0: none, gblk is ready)
             for (int j = 0; j < nblk; ++j) {
                 const int slot = j & 1, pslot = slot ^ 1;
@@ -1620,7 +1666,7 @@ struct Solver {
                 // (j-1)&1 itself (no panel_reduce launch in between); resid_sum of the residual they were taken from = the
                 // one after block j-2's solve, which sits in this block's own rsum slot until this solve overwrites it
                 bp.part = (fuse_reduce && prev_ld > 0) ? d_part2.p + size_t((j - 1) & 1) * part2_half : nullptr;
-                bp.part_ld = prev_ld;
+                bp.part_ld = 0; // slice-major
                 bp.part_n = prev_ld;
                 bp.part_rsum = xm_c ? d_la_rsum.p + slot : nullptr;
                 prev_ld = 0;
@@ -1654,11 +1700,11 @@ struct Solver {
                 if (time_panel) t_step.begin(st);
                 if (dense())
                     ld = launch_panel_fused<T>(bp, j, D->dense<T>(), cur_w, r_dev, d_la_dcol.p + size_t(pslot) * SL,
-                                               d_la_dlt.p + size_t(pslot) * SL, d_la_nz.p + pslot, cols_n, nbn, part_out, st);
+                                               d_la_dlt.p + size_t(pslot) * SL, d_la_nz.p + pslot, cols_n, nbn, part_out, fuse_reduce, st);
                 else
                     ld = launch_panel_fused_snp<T>(bp, j, D->snp(), static_cast<const T*>(D->impute), cur_w, r_dev,
                                                    d_la_dcol.p + size_t(pslot) * SL, d_la_dlt.p + size_t(pslot) * SL,
-                                                   d_la_nz.p + pslot, cols_n, nbn, part_out, st);
+                                                   d_la_nz.p + pslot, cols_n, nbn, part_out, fuse_reduce, st);
                 if (time_panel) t_step.end(st);
                 if (nbn > 0) {
                     if (fuse_reduce) {
@@ -1701,8 +1747,24 @@ struct Solver {
             const int nblk = (count + B - 1) / B;
             Stopwatch sw_enq;
             sw_enq.start();
+            // the step of block 0 goes out before the builds are enqueued (it does not depend on them; see record_pass_e0)
+            auto step_of = [&](int j) {
+                const int nb = std::min(B, count - j * B);
+                const int32_t* cols = cols_all + size_t(j) * B;
+                const int ps = (j == 0) ? pending_slot : -1;
+                if (time_panel) t_step.begin(st);
+                const int nsl = panel_step(cur_w, r_dev, ps < 0 ? d_dcolblk.p : d_la_dcol.p + size_t(ps) * SL,
+                                           ps < 0 ? d_dlt.p : d_la_dlt.p + size_t(ps) * SL,
+                                           ps < 0 ? &d_blk.p->nz : d_la_nz.p + ps, cols, nb);
+                if (time_panel) t_step.end(st);
+                return nsl;
+            };
+            record_pass_e0();
+            t_cd.begin(st);
+            const int nsl0 = step_of(0);
             build_stale_blocks(nblk, tab_nb, tab_ver, pool, [&](int j) { return std::min(B, count - j * B); },
                                [&](int j) { return cols_all + size_t(j) * B; }, false, screen_pass);
+            pass_e0_valid = false;
             if (!screen_pass && prebuild_screen && !screen_prebuilt && side_grams && st2) {
                 // IRLS: every screen-order block is stale as well (new weights) and the screen pass follows the active-set
                 // passes of this fit: enqueue those builds now, behind the ones this pass waits for, so that they run while
@@ -1712,7 +1774,6 @@ struct Solver {
                 build_stale_blocks(nblk_s, dscr_nb, dscr_ver, d_Dpool.p, [&](int j) { return std::min(B, cnt_s - j * B); },
                                    [&](int j) { return d_vcol.p + size_t(j) * B; }, true);
             }
-            t_cd.begin(st);
             // (a look-ahead pass may have run before: plain buffers for the solves, its pending changes for the first step)
             bp.gblk = d_gblk.p; bp.dlt = d_dlt.p; bp.dcol = d_dcolblk.p;
             bp.Cprev = nullptr; bp.dpos = nullptr; bp.nz_out = nullptr; bp.rsum_out = nullptr;
@@ -1721,12 +1782,7 @@ struct Solver {
                 const int nb = std::min(B, count - j * B);
                 const int32_t* cols = cols_all + size_t(j) * B;
                 T* Dptr = pool + size_t(j) * SL * SL;
-                const int ps = (j == 0) ? pending_slot : -1;
-                if (time_panel) t_step.begin(st);
-                const int nsl = panel_step(cur_w, r_dev, ps < 0 ? d_dcolblk.p : d_la_dcol.p + size_t(ps) * SL,
-                                           ps < 0 ? d_dlt.p : d_la_dlt.p + size_t(ps) * SL,
-                                           ps < 0 ? &d_blk.p->nz : d_la_nz.p + ps, cols, nb);
-                if (time_panel) t_step.end(st);
+                const int nsl = (j == 0) ? nsl0 : step_of(j);
                 pending_slot = -1;
                 cnt.n_panel_cols += nb;
                 launch_panel_reduce<T>(d_part.p, nsl, nb, cols, &d_blk.p->resid_sum, xm_c, d_gblk.p, st);
@@ -2336,6 +2392,8 @@ struct Solver {
         cnt.n_cd_visits_screen += sc.n_visits_screen;
         cnt.n_cd_visits_active += sc.n_visits_active;
         cnt.n_updates += sc.n_updates;
+        // in columns: exact for groups of one size (the mean size of the screened groups otherwise)
+        cnt.n_update_cols += all_scalar ? sc.n_updates : int64_t(double(sc.n_updates) * double(nv) / double(std::max<idx>(ns, 1)) + 0.5);
         cnt.n_cd_passes_screen += sc.n_passes_screen;
         cnt.n_cd_passes_active += sc.n_passes_active;
         for (int i = 0; i < 8; ++i) cd_dbg[i] += sc.dbg[i];
@@ -2383,8 +2441,10 @@ struct Solver {
             panel_mode() && r_dev == d_r.p) {
             if (!spec_ev) AHIP_CHECK(hipEventCreateWithFlags(&spec_ev, hipEventDisableTiming));
             AHIP_CHECK(hipEventRecord(spec_ev, st));
+            const size_t stage_mark = stage.mark();
             if (!all_scalar) { // the group engine partitions the active list on the host: it needs the newcomers first
                 AHIP_CHECK(hipEventSynchronize(spec_ev));
+                stage.flush();
                 for (size_t i = 0; i < act.size(); ++i) {
                     active_set[old_active + i] = act[i];
                     screen_is_active[act[i]] = 1;
@@ -2414,6 +2474,8 @@ struct Solver {
                 ++n_spec;
             }
             AHIP_CHECK(hipEventSynchronize(spec_ev));
+            stage.flush(); // every staged download of this fit was enqueued ahead of the event
+            stage.release(stage_mark);
             waited = true;
         }
         if (!waited) sync();
@@ -2930,9 +2992,11 @@ struct Solver {
             while (1) {
                 ++cnt.n_basil_iters;
                 sw.start();
+                const double sync0 = t_sync_total;
                 screen_f(lmda_curr, kkt_passed, n_new_active);
                 benchmark_screen.push_back(sw.elapsed());
                 t_host_screen += benchmark_screen.back();
+                t_host_screen_wait += t_sync_total - sync0;
                 spec_next_lm = (lmda_path_idx + 1 < L) ? lmda_path[lmda_path_idx + 1] : T(0);
                 auto fo = fit_f(lmda_curr);
                 spec_next_lm = T(0);
@@ -3107,6 +3171,7 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_BATCH_BLOCKS")) batch_blocks = std::max(1, std::min(int(SyrkBatch::MAX), std::atoi(e)));
         if (const char* e = std::getenv("ADELIE_HIP_SPECULATE")) spec_enabled = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_CROSS_BATCH")) cross_batch = std::max(1, std::min(int(GramBatch::MAX), std::atoi(e)));
+        if (const char* e = std::getenv("ADELIE_HIP_CROSS_INCR")) cross_incremental = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {
             panel_bsz = std::atoi(e);
             if (panel_bsz != 32 && panel_bsz != 64 && panel_bsz != 128) panel_bsz = 0;
@@ -3477,6 +3542,9 @@ struct Result : ResultBase {
             case ADELIE_HIP_S_N_SWEEP_LAUNCHES: return double(s.t_sweep.launches);
             case ADELIE_HIP_S_N_GRAM_LAUNCHES: return double(s.t_gram.launches);
             case ADELIE_HIP_S_T_HOST_SCREEN_MS: return 1e3 * s.t_host_screen;
+            case ADELIE_HIP_S_T_HOST_SCREEN_WAIT_MS: return 1e3 * s.t_host_screen_wait;
+            case ADELIE_HIP_S_N_SWEEPS_SHARED: return double(s.cnt.n_sweeps_shared);
+            case ADELIE_HIP_S_N_UPDATE_COLS: return double(s.cnt.n_update_cols);
             default:
                 if (which >= 900 && which < 908) return double(s.cd_dbg[which - 900]);
                 if (which >= 910 && which < 918) return 1e3 * s.t_host[which - 910];
@@ -3503,6 +3571,9 @@ void run(adelie_hip_design* X, const adelie_hip_grpnet_args* a, adelie_hip_resul
     auto* r = new Result<T>();
     res->r = r; // owned by `res` from here on (the poll callbacks read the live state through it)
     r->s.live = res;
+    static const bool staging_on = !(std::getenv("ADELIE_HIP_STAGING") && std::atoi(std::getenv("ADELIE_HIP_STAGING")) == 0);
+    if (staging_on) r->s.stage.init(size_t(8) << 20, X->stream);
+    Staging::Scope stage_scope(staging_on ? &r->s.stage : nullptr);
     r->s.build(X, a);
     Stopwatch sw;
     sw.start();

@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X spec (guides/MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
 MFMA_F64_PEAK_TFLOPS = 78.6  # dense f64 matrix-core peak (same guide)
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32 matrix-core peak (same guide)
 
 METRIC = "lambda-paths/sec (100-lambda grpnet); HBM GB/s vs peak"
 
@@ -99,11 +100,13 @@ def make_snp_data(n, p, seed, device):
 # -------------------------------------------------------------------------------------------------------------------------
 # algorithmic bytes of a path: matrix bytes only; vectors are cache resident
 # -------------------------------------------------------------------------------------------------------------------------
-def path_bytes(counters, n, p, col_bytes_per_row, group_size):
+def path_bytes(counters, n, p, col_bytes_per_row, group_size, shared_launches=0):
     """B_path = s*n*[p*N_sweep + sum_visits q_g + sum_new q_g] (+ IRLS: s*n*2*sum_irls |S|), N_sweep = 2 + n_basil_iters.
-    Visits are counted in groups by the group engines and in columns by the lasso engines: both are `group_size` columns."""
+    Visits are counted in groups by the group engines and in columns by the lasso engines: both are `group_size` columns.
+    Concurrent CV folds answer several solvers' sweeps with ONE pass over X: those sweeps (`n_sweeps_shared`, summed over the
+    solvers) are replaced by the number of shared launches, so that bytes which were never moved are not counted."""
     c = counters
-    n_sweep = 2 + c["n_basil_iters"]
+    n_sweep = 2 + c["n_basil_iters"] - c.get("n_sweeps_shared", 0) + shared_launches
     visit_cols = (c["n_cd_visits_screen"] + c["n_cd_visits_active"]) * group_size
     cols = p * n_sweep + visit_cols + c["n_new_screen_cols"] + 2 * c.get("n_irls_screen_cols", 0)
     return float(n) * col_bytes_per_row * cols, {"n_sweep": int(n_sweep), "visit_cols": int(visit_cols),
@@ -129,6 +132,293 @@ def host_cores():
 
 
 # -------------------------------------------------------------------------------------------------------------------------
+class Ctx:
+    """Process-wide plumbing shared by every leg of a run: rank / world, the torch device and the (optional) process group."""
+
+    def __init__(self):
+        import torch
+
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        # test hooks (one-GPU boxes): BENCH_BACKEND=gloo + BENCH_DEVICE=0 run several ranks on one device to exercise the
+        # multi-rank logic; the driver's multi-GPU runs use the defaults (RCCL, one device per rank)
+        self.backend = os.environ.get("BENCH_BACKEND", "nccl")
+        dev_index = int(os.environ.get("BENCH_DEVICE", self.local_rank))
+        torch.cuda.set_device(dev_index)
+        if self.world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+            else:
+                dist.init_process_group(backend=self.backend)
+            self.dist = dist
+        self.device = torch.device("cuda", dev_index)
+        self.comm_device = self.device if self.backend == "nccl" else torch.device("cpu")
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed(self, fn, steps):
+        """EXACTLY `steps` calls bracketed by barrier + synchronize on both sides; the MAX over ranks."""
+        self.barrier()
+        t0 = time.perf_counter()
+        outs = [fn() for _ in range(steps)]
+        self.barrier()
+        el = time.perf_counter() - t0
+        if self.dist is not None:
+            t = self.torch.tensor([el], device=self.comm_device, dtype=self.torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            el = float(t.item())
+        return outs, el
+
+
+def measure(ctx, cfg, *, n, p, gs, alpha, dtype, L, steps, warmup, n_folds=8, cv_leg=False, data=None):
+    """One workload: builds (or re-uses) the resident design, runs `warmup` untimed and `steps` timed steps, and returns
+    (line, keep): `line` = the JSON object of this workload (value, rooflines, counters), `keep` = what the CPU baseline and a
+    following leg on the same data need (design, response, last result)."""
+    import adelie_amd as ad
+
+    torch, dist, world, rank = ctx.torch, ctx.dist, ctx.world, ctx.rank
+    tdtype = torch.float64 if dtype == "f64" else torch.float32
+    npdtype = np.float64 if dtype == "f64" else np.float32
+    s_val = np.dtype(npdtype).itemsize
+
+    # ---- the workload -------------------------------------------------------------------------------------------------
+    keep = dict(data or {})
+    if cfg == 4:
+        if "Xd" not in keep:
+            cd, imp, y = make_snp_data(n, p, 0, ctx.device)
+            keep.update(cd=cd, imp=imp, y=y, Xd=ad.matrix.snp_calldata(cd, imp, dtype=npdtype))  # packed to 2 bits on the device
+        col_bytes_per_row = 0.25
+        family = "binomial"
+    else:
+        if "Xd" not in keep:
+            X, y = make_data(n, p, seed=0, device=ctx.device, dtype=tdtype)
+            keep.update(X=X, y=y, Xd=ad.matrix.dense(X))        # adopts the resident tensor in place (no copy)
+        col_bytes_per_row = s_val
+        family = "gaussian"
+    Xd = keep["Xd"]
+    y = keep["y"].astype(npdtype)
+
+    # fold weights for the weak-scaling replicas (the fold shards of cv_grpnet); full-data weights at N = 1
+    weights = None
+    if world > 1 and cfg != 5:
+        order = np.random.RandomState(0).permutation(n)
+        b, e = ad.cv.fold_ranges(n, 8)[rank % 8]
+        weights = np.full(n, 1.0, dtype=npdtype)
+        weights[order[b:e]] = 0
+        weights /= weights.sum()
+    glm = (ad.glm.binomial if family == "binomial" else ad.glm.gaussian)(y, weights=weights, dtype=npdtype)
+    groups = None if gs == 1 else np.arange(0, p, gs)
+    kw = dict(early_exit=False, lmda_path_size=L, groups=groups, alpha=alpha, progress_bar=False)
+    cv_kw = dict(n_folds=n_folds, seed=0, lmda_path_size=L, process_group=(True if world > 1 else None))
+    keep.update(glm=glm, kw=kw, cv_kw=cv_kw, npdtype=npdtype)
+
+    def step():
+        if cfg == 5:
+            return ad.cv_grpnet(Xd, glm, **cv_kw)
+        return ad.grpnet(Xd, glm, **kw)
+
+    for _ in range(warmup):
+        step()
+    bs0 = Xd.batch_stats() if cfg == 5 else None
+    outs, elapsed = ctx.timed(step, steps)
+    bs1 = Xd.batch_stats() if cfg == 5 else None
+    last = outs[-1]
+    keep["last"] = last
+
+    if cfg != 5:
+        assert last.error == "", last.error
+        assert len(last.lmdas) == L, len(last.lmdas)
+        if dist is not None:  # the fold gather of cv_grpnet: one small all_gather of the per-lambda rows
+            row = torch.from_numpy(np.asarray(last.devs, dtype=np.float64)).to(ctx.comm_device)
+            rows = [torch.empty_like(row) for _ in range(world)]
+            dist.all_gather(rows, row)
+        units = world * steps                           # paths
+        stats = [dict(counters=o.counters, timers=o.timers, total_time=o.total_time) for o in outs]
+    else:
+        assert last.losses.shape == (n_folds, L) and np.all(np.isfinite(last.losses))
+        units = n_folds * steps                         # fold paths of ONE sharded CV per step
+        stats = [f for o in outs for f in o.fold_stats]
+        if dist is not None:
+            # the first real multi-GPU run must prove that RCCL carried the fold gather and that every rank contributed rows
+            if ctx.backend == "nccl":
+                assert dist.get_backend() == "nccl", dist.get_backend()
+            mine = torch.tensor([len(range(rank, n_folds, world))], device=ctx.comm_device, dtype=torch.int64)
+            per_rank = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(per_rank, mine)
+            per_rank = [int(t.item()) for t in per_rank]
+            assert sum(per_rank) == n_folds and all(c > 0 for c in per_rank[:min(world, n_folds)]), per_rank
+            keep["folds_per_rank_gathered"] = per_rank
+
+    # ---- the secondary CV leg of the default line ---------------------------------------------------------------------
+    cv_obj = None
+    if cv_leg:
+        glm_full = ad.glm.gaussian(y, dtype=npdtype)
+        cv_fn = lambda: ad.cv_grpnet(Xd, glm_full, **cv_kw)  # noqa: E731
+        cv_fn()
+        (cv_res,), cv_el = ctx.timed(cv_fn, 1)
+        cv_obj = {
+            "workload": f"cv_grpnet(n_folds={n_folds}, seed=0, min_ratio=0.1, {L} lambdas) on the same design; fold k on "
+                        f"rank k % {world}, one all_gather of the ({n_folds}, {L}) loss table",
+            "scaling": "strong", "n_gpus": world, "cv_wall_s": cv_el, "folds_per_s": n_folds / cv_el,
+            "folds_per_rank": [len(range(r, n_folds, world)) for r in range(world)],
+            "best_idx": int(cv_res.best_idx), "min_avg_loss": float(cv_res.avg_losses.min()),
+        }
+
+    # ---- one extra, untimed step with per-launch events on the panel step kernel (second HBM-bound kernel of the path) --
+    panel = None
+    if rank == 0 and cfg in (2, 3):
+        os.environ["ADELIE_HIP_TIME_PANEL"] = "1"
+        stp = ad.grpnet(Xd, glm, **kw)
+        del os.environ["ADELIE_HIP_TIME_PANEL"]
+        if stp.timers["n_panel_step_launches"] > 0:
+            # gradient columns + residual-update columns (n_update_cols: columns, not groups)
+            cols = stp.counters["n_panel_cols"] + stp.counters["n_update_cols"]
+            bytes_ = float(cols) * n * s_val
+            ms = stp.timers["t_panel_step_ms"]
+            panel = {
+                "kernel": "panel_fused_kernel / panel_step_kernel (r -= X_B dbeta_B of the previous block; partial gradients of the "
+                          "next block; the fused launch also carries the one-workgroup solve of the current block)",
+                "bound": "hbm", "achieved": bytes_ / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": measured_traffic(f"panel_step_kernel:{n}x{p}:{dtype}:g{gs}"),
+                "launches": int(stp.timers["n_panel_step_launches"]), "avg_launch_ms": ms / stp.timers["n_panel_step_launches"],
+                "algorithmic_bytes_per_launch": bytes_ / stp.timers["n_panel_step_launches"],
+            }
+
+    if rank != 0:
+        return None, keep
+
+    tot = lambda key, kind: sum(st[kind][key] for st in stats)  # noqa: E731
+    # sweep kernel, timed live with HIP events on the solver's stream inside the timed steps
+    sweep_launches = tot("n_sweep_launches", "timers")
+    sweep_ms = tot("t_sweep_ms", "timers")
+    sweep_bytes = float(n) * p * col_bytes_per_row      # one launch reads the design once
+    sweep_avg = sweep_ms / max(sweep_launches, 1)
+    sweep_roof = None
+    if sweep_launches:
+        ach = sweep_bytes / (sweep_avg * 1e-3) / 1e9
+        kname = "sweep_kernel" if cfg != 4 else "sweep_kernel<Snp2bit>"
+        sweep_roof = {
+            "kernel": kname + " (grad = X^T (w*r) - rsum*xbar, full design)", "bound": "hbm", "achieved": ach,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": measured_traffic(f"sweep_kernel:{n}x{p}:{dtype}" + (":snp" if cfg == 4 else "")),
+            "launches": int(sweep_launches), "avg_launch_ms": sweep_avg, "algorithmic_bytes_per_launch": sweep_bytes,
+        }
+    gram_ms, gram_flops = tot("t_gram_ms", "timers"), tot("gram_flops", "timers")
+    gram_roof = None
+    if gram_ms > 0:
+        tf = gram_flops / (gram_ms * 1e-3) / 1e12
+        peak = MFMA_F64_PEAK_TFLOPS if dtype == "f64" else MFMA_F32_PEAK_TFLOPS
+        gram_roof = {
+            "kernel": f"syrk_batch_kernel / gram_batch_kernel (diagonal and cross blocks X_b^T W X_b' of the panel engine, {dtype} "
+                      "MFMA 16x16x4)",
+            "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
+            "frac": tf / peak, "traffic": measured_traffic(f"syrk_kernel:{n}x{p}:{dtype}"),
+            "launches": int(tot("n_gram_launches", "timers")),
+            "avg_launch_ms": gram_ms / max(tot("n_gram_launches", "timers"), 1),
+            "algorithmic_flops_per_launch": gram_flops / max(tot("n_gram_launches", "timers"), 1),
+        }
+    # dominant kernel: by device time.  Config 4 spends most of it in the MFMA block builds; the others in the sweeps.
+    roofline = gram_roof if (cfg == 4 and gram_roof is not None) else sweep_roof
+    shared_launches = 0
+    if cfg == 5 and bs1["launches"] > bs0["launches"]:
+        # the folds in flight share their sweeps: the dominant kernel is the K-wide sweep on the batcher's stream, one
+        # pass over X per launch for all the folds that reached their invariance sweep together
+        nl, nvec, ms = (bs1[k] - bs0[k] for k in ("launches", "vectors", "ms"))
+        shared_launches = int(nl)
+        ach = nl * sweep_bytes / (ms * 1e-3) / 1e9
+        roofline = {
+            "kernel": "multi_sweep_kernel (shared sweep of the folds in flight: grad_k = X^T v_k for the K folds that "
+                      "arrived together, X streamed once)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": measured_traffic(f"multi_sweep_kernel:{n}x{p}:{dtype}"), "launches": int(nl),
+            "avg_launch_ms": ms / nl, "algorithmic_bytes_per_launch": sweep_bytes,
+            "vectors_per_launch": nvec / nl,
+        }
+
+    # whole-path fraction (SURVEY.md 8d): algorithmic bytes of everything the timed steps solved / their wall time
+    counters = {k: sum(st["counters"][k] for st in stats) for k in stats[0]["counters"]}
+    B, parts = path_bytes(counters, n, p, col_bytes_per_row, gs, shared_launches=shared_launches)
+    wall = elapsed  # rank 0's steps; at N > 1 every rank does the same amount (cfg 5: rank 0's folds)
+    path_gbs = B / wall / 1e9
+    roofline_path = {"bound": "hbm", "achieved": path_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": path_gbs / HBM_PEAK_GBS, "algorithmic_bytes": B, "wall_s": wall,
+                     "terms_in_columns": parts,
+                     "note": "rank 0's paths over the timed steps; matrix bytes only (SURVEY.md 8d)" + (
+                         "; sweeps that several folds shared are counted ONCE (one pass over X answers up to 8 folds), the "
+                         "sweeps a fold made alone and the two preamble sweeps of every grpnet call once each" if cfg == 5 else "")}
+
+    last_stat = stats[-1]
+    tm = last_stat["timers"]
+    workloads = {
+        2: f"Gaussian GLM, dense X {n}x{p} {dtype} column-major resident in HBM, group size {gs}, alpha={alpha}, "
+           f"{L}-lambda path, early_exit=False",
+        3: f"Gaussian GLM, dense X {n}x{p} {dtype} column-major resident in HBM, group size {gs} ({p // gs} groups), "
+           f"alpha={alpha}, {L}-lambda path, early_exit=False",
+        4: f"Binomial GLM (IRLS), matrix.snp_unphased 2-bit packed {n}x{p} (25% ones, 5% twos, 10% missing, mean-imputed) "
+           f"resident in HBM, lasso, {L}-lambda path, early_exit=False",
+        5: f"cv_grpnet {n_folds}-fold, Gaussian GLM, dense X {n}x{p} {dtype} resident in HBM, lasso, "
+           f"min_ratio=0.1, {L} lambdas, folds sharded fold k -> rank k % {world}",
+    }
+    out = {
+        "metric": METRIC,
+        "value": units / elapsed,
+        "unit": "paths/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / steps,
+        "higher_is_better": True,
+        "scaling": "strong" if cfg == 5 else "weak",
+        "vs_baseline": None,
+        "dtype": dtype,
+        "data": "synthetic",
+        "config": {"workload": workloads[cfg] + ("" if world == 1 or cfg == 5 else
+                                                  "; rank r trains on the complement of CV fold r%8 (weak scaling)"),
+                   "baseline_config": cfg, "n": n, "p": p, "lmda_path_size": L, "group_size": gs, "alpha": alpha},
+        "roofline": roofline,
+        "roofline_path": roofline_path,
+        "roofline_sweep": sweep_roof if roofline is not sweep_roof else None,
+        "roofline_gram_mfma": gram_roof if roofline is not gram_roof else None,
+        "roofline_panel_step": panel,
+        "breakdown_ms_last_path": {
+            "sweep": tm["t_sweep_ms"], "gram_mfma": tm["t_gram_ms"], "cd": tm["t_cd_ms"], "resid_axpy": tm["t_axpy_ms"],
+            # host time between the KKT check of one lambda and the fit of the next (screening rule, appends, launches of the
+            # new groups' variances), split into computing and waiting for the device (the in-stream speculative pass)
+            "host_screen_compute": tm["t_host_screen_ms"] - tm["t_host_screen_wait_ms"],
+            "host_screen_wait": tm["t_host_screen_wait_ms"],
+            "total": 1e3 * last_stat["total_time"],
+        },
+        "counters": counters,
+    }
+    if cfg == 5:
+        out["cv"] = {"cv_wall_s": elapsed / steps, "folds_per_s": units / elapsed, "n_folds": n_folds,
+                     "folds_per_rank": [len(range(r, n_folds, world)) for r in range(world)],
+                     "folds_per_rank_gathered": keep.get("folds_per_rank_gathered"),
+                     "comm_backend": (dist.get_backend() if dist is not None else None),
+                     "best_idx": int(last.best_idx), "min_avg_loss": float(last.avg_losses.min()),
+                     "note": "counters / rooflines aggregate rank 0's folds only"}
+    else:
+        out["final_active"] = int(last.active_set_size)
+        out["final_screen"] = int(len(last.screen_set))
+    if cv_obj is not None:
+        out["cv_config5"] = cv_obj
+    return out, keep
+
+
+LEG_KEYS = ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline", "roofline_path", "roofline_sweep",
+            "roofline_gram_mfma", "roofline_panel_step", "breakdown_ms_last_path", "final_active", "final_screen")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +434,8 @@ def main():
     ap.add_argument("--n-folds", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cv-leg", action="store_true", help="skip the cv_config5 object of the default line")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the cfg3 / f32 / cfg4 objects of the default line (N = 1 only)")
     ap.add_argument("--cpu-budget-s", type=float, default=None)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cpu-1thread-budget-s", type=float, default=12.0, help="config 2: extra CPU leg with one thread (0: skip)")
@@ -157,256 +449,44 @@ def main():
     alpha = args.alpha if args.alpha is not None else (0.5 if cfg == 3 else 1.0)
     L = args.lmda_path_size
 
-    import torch
+    ctx = Ctx()
+    default_line = (cfg == 2 and gs == 1 and alpha == 1.0 and args.dtype == "f64" and args.n is None and args.p is None)
+    out, keep = measure(ctx, cfg, n=n, p=p, gs=gs, alpha=alpha, dtype=args.dtype, L=L, steps=args.steps, warmup=args.warmup,
+                        n_folds=args.n_folds, cv_leg=(default_line and not args.no_cv_leg))
 
-    import adelie_amd as ad
+    if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, args, keep, keep["y"].astype(keep["npdtype"]), keep["glm"], keep["kw"],
+                                           keep["cv_kw"], keep["npdtype"], keep["last"], keep["Xd"], n, p)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    # test hooks (one-GPU boxes): BENCH_BACKEND=gloo + BENCH_DEVICE=0 run several ranks on one device to exercise the
-    # multi-rank logic; the driver's multi-GPU runs use the defaults (RCCL, one device per rank)
-    backend = os.environ.get("BENCH_BACKEND", "nccl")
-    dev_index = int(os.environ.get("BENCH_DEVICE", local_rank))
-    torch.cuda.set_device(dev_index)
-    if world > 1:
-        import torch.distributed as dist
+    # ---- the other BASELINE.json configurations, as objects of the default line (N = 1: they are single-GPU workloads) -----
+    if default_line and ctx.world == 1 and not args.no_extra_legs:
+        def leg(line):
+            return {k: line[k] for k in LEG_KEYS if k in line}
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend=backend)
-    device = torch.device("cuda", dev_index)
-    comm_device = device if backend == "nccl" else torch.device("cpu")
-    tdtype = torch.float64 if args.dtype == "f64" else torch.float32
-    npdtype = np.float64 if args.dtype == "f64" else np.float32
-    s_val = np.dtype(npdtype).itemsize
+        # config 3 re-uses the resident design of the headline (same X, grouped penalty)
+        line3, _ = measure(ctx, 3, n=n, p=p, gs=10, alpha=0.5, dtype="f64", L=L, steps=2, warmup=1,
+                           data={k: keep[k] for k in ("X", "y", "Xd")})
+        out["cfg3"] = leg(line3)
+        del keep, line3
+        import gc
+        gc.collect()
+        ctx.torch.cuda.empty_cache()
+        # the headline workload in single precision (SURVEY.md 8d asks for both arithmetic types)
+        line32, k32 = measure(ctx, 2, n=n, p=p, gs=1, alpha=1.0, dtype="f32", L=L, steps=3, warmup=1)
+        out["f32"] = leg(line32)
+        del k32, line32
+        gc.collect()
+        ctx.torch.cuda.empty_cache()
+        line4, k4 = measure(ctx, 4, n=500_000, p=50_000, gs=1, alpha=1.0, dtype="f64", L=L, steps=1, warmup=1)
+        out["cfg4"] = leg(line4)
+        del k4, line4
 
-    # ---- the workload -------------------------------------------------------------------------------------------------
-    keep = {}
-    if cfg == 4:
-        cd, imp, y = make_snp_data(n, p, 0, device)
-        Xd = ad.matrix.snp_calldata(cd, imp, dtype=npdtype)     # packed to 2 bits per call on the device
-        keep["cd"], keep["imp"] = cd, imp
-        col_bytes_per_row = 0.25
-        family = "binomial"
-    else:
-        X, y = make_data(n, p, seed=0, device=device, dtype=tdtype)
-        Xd = ad.matrix.dense(X)                                 # adopts the resident tensor in place (no copy)
-        keep["X"] = X
-        col_bytes_per_row = s_val
-        family = "gaussian"
-    y = y.astype(npdtype)
-
-    # fold weights for the weak-scaling replicas (the fold shards of cv_grpnet); full-data weights at N = 1
-    weights = None
-    if world > 1 and cfg != 5:
-        order = np.random.RandomState(0).permutation(n)
-        b, e = ad.cv.fold_ranges(n, 8)[rank % 8]
-        weights = np.full(n, 1.0, dtype=npdtype)
-        weights[order[b:e]] = 0
-        weights /= weights.sum()
-    glm = (ad.glm.binomial if family == "binomial" else ad.glm.gaussian)(y, weights=weights, dtype=npdtype)
-    groups = None if gs == 1 else np.arange(0, p, gs)
-    kw = dict(early_exit=False, lmda_path_size=L, groups=groups, alpha=alpha, progress_bar=False)
-    cv_kw = dict(n_folds=args.n_folds, seed=0, lmda_path_size=L, process_group=(True if world > 1 else None))
-
-    def step():
-        if cfg == 5:
-            return ad.cv_grpnet(Xd, glm, **cv_kw)
-        return ad.grpnet(Xd, glm, **kw)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(fn, steps):
-        barrier()
-        t0 = time.perf_counter()
-        outs = [fn() for _ in range(steps)]
-        barrier()
-        el = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([el], device=comm_device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return outs, el
-
-    for _ in range(args.warmup):
-        step()
-    bs0 = Xd.batch_stats() if cfg == 5 else None
-    outs, elapsed = timed(step, args.steps)
-    bs1 = Xd.batch_stats() if cfg == 5 else None
-    last = outs[-1]
-
-    if cfg != 5:
-        assert last.error == "", last.error
-        assert len(last.lmdas) == L, len(last.lmdas)
-        if dist is not None:  # the fold gather of cv_grpnet: one small all_gather of the per-lambda rows
-            row = torch.from_numpy(np.asarray(last.devs, dtype=np.float64)).to(comm_device)
-            rows = [torch.empty_like(row) for _ in range(world)]
-            dist.all_gather(rows, row)
-        units = world * args.steps                      # paths
-        stats = [dict(counters=o.counters, timers=o.timers, total_time=o.total_time) for o in outs]
-    else:
-        assert last.losses.shape == (args.n_folds, L) and np.all(np.isfinite(last.losses))
-        units = args.n_folds * args.steps               # fold paths of ONE sharded CV per step
-        stats = [f for o in outs for f in o.fold_stats]
-
-    # ---- the secondary CV leg of the default line ---------------------------------------------------------------------
-    cv_leg = None
-    if cfg == 2 and not args.no_cv_leg and gs == 1 and alpha == 1.0:
-        glm_full = ad.glm.gaussian(y, dtype=npdtype)
-        cv_fn = lambda: ad.cv_grpnet(Xd, glm_full, **cv_kw)  # noqa: E731
-        cv_fn()
-        (cv_res,), cv_el = timed(cv_fn, 1)
-        cv_leg = {
-            "workload": f"cv_grpnet(n_folds={args.n_folds}, seed=0, min_ratio=0.1, {L} lambdas) on the same design; fold k on "
-                        f"rank k % {world}, one all_gather of the ({args.n_folds}, {L}) loss table",
-            "scaling": "strong", "n_gpus": world, "cv_wall_s": cv_el, "folds_per_s": args.n_folds / cv_el,
-            "folds_per_rank": [len(range(r, args.n_folds, world)) for r in range(world)],
-            "best_idx": int(cv_res.best_idx), "min_avg_loss": float(cv_res.avg_losses.min()),
-        }
-
-    # ---- one extra, untimed step with per-launch events on the panel step kernel (second HBM-bound kernel of the path) --
-    panel = None
-    if rank == 0 and cfg in (2, 3):
-        os.environ["ADELIE_HIP_TIME_PANEL"] = "1"
-        stp = ad.grpnet(Xd, glm, **kw)
-        del os.environ["ADELIE_HIP_TIME_PANEL"]
-        if stp.timers["n_panel_step_launches"] > 0:
-            cols = stp.counters["n_panel_cols"] + stp.counters["n_updates"]  # gradient columns + residual-update columns
-            bytes_ = float(cols) * n * s_val
-            ms = stp.timers["t_panel_step_ms"]
-            panel = {
-                "kernel": "panel_fused_kernel / panel_step_kernel (r -= X_B dbeta_B of the previous block; partial gradients of the "
-                          "next block; the fused launch also carries the one-workgroup solve of the current block)",
-                "bound": "hbm", "achieved": bytes_ / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": measured_traffic(f"panel_step_kernel:{n}x{p}:{args.dtype}"),
-                "launches": int(stp.timers["n_panel_step_launches"]), "avg_launch_ms": ms / stp.timers["n_panel_step_launches"],
-                "algorithmic_bytes_per_launch": bytes_ / stp.timers["n_panel_step_launches"],
-            }
-
-    if rank == 0:
-        tot = lambda key, kind: sum(st[kind][key] for st in stats)  # noqa: E731
-        # sweep kernel, timed live with HIP events on the solver's stream inside the timed steps
-        sweep_launches = tot("n_sweep_launches", "timers")
-        sweep_ms = tot("t_sweep_ms", "timers")
-        sweep_bytes = float(n) * p * col_bytes_per_row      # one launch reads the design once
-        sweep_avg = sweep_ms / max(sweep_launches, 1)
-        sweep_roof = None
-        if sweep_launches:
-            ach = sweep_bytes / (sweep_avg * 1e-3) / 1e9
-            kname = "sweep_kernel" if cfg != 4 else "sweep_kernel<Snp2bit>"
-            sweep_roof = {
-                "kernel": kname + " (grad = X^T (w*r) - rsum*xbar, full design)", "bound": "hbm", "achieved": ach,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": measured_traffic(f"sweep_kernel:{n}x{p}:{args.dtype}" + (":snp" if cfg == 4 else "")),
-                "launches": int(sweep_launches), "avg_launch_ms": sweep_avg, "algorithmic_bytes_per_launch": sweep_bytes,
-            }
-        gram_ms, gram_flops = tot("t_gram_ms", "timers"), tot("gram_flops", "timers")
-        gram_roof = None
-        if gram_ms > 0:
-            tf = gram_flops / (gram_ms * 1e-3) / 1e12
-            gram_roof = {
-                "kernel": "syrk_kernel / gram_kernel (diagonal blocks X_b^T W X_b of the panel engine, f64 MFMA 16x16x4)",
-                "bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tf / MFMA_F64_PEAK_TFLOPS, "traffic": measured_traffic(f"syrk_kernel:{n}x{p}:{args.dtype}"),
-                "launches": int(tot("n_gram_launches", "timers")),
-                "avg_launch_ms": gram_ms / max(tot("n_gram_launches", "timers"), 1),
-                "algorithmic_flops_per_launch": gram_flops / max(tot("n_gram_launches", "timers"), 1),
-            }
-        # dominant kernel: by device time.  Config 4 spends most of it in the MFMA block builds; the others in the sweeps.
-        roofline = gram_roof if (cfg == 4 and gram_roof is not None) else sweep_roof
-        if cfg == 5 and bs1["launches"] > bs0["launches"]:
-            # the folds in flight share their sweeps: the dominant kernel is the K-wide sweep on the batcher's stream, one
-            # pass over X per launch for all the folds that reached their invariance sweep together
-            nl, nvec, ms = (bs1[k] - bs0[k] for k in ("launches", "vectors", "ms"))
-            ach = nl * sweep_bytes / (ms * 1e-3) / 1e9
-            roofline = {
-                "kernel": "multi_sweep_kernel (shared sweep of the folds in flight: grad_k = X^T v_k for the K folds that "
-                          "arrived together, X streamed once)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": measured_traffic(f"multi_sweep_kernel:{n}x{p}:{args.dtype}"), "launches": int(nl),
-                "avg_launch_ms": ms / nl, "algorithmic_bytes_per_launch": sweep_bytes,
-                "vectors_per_launch": nvec / nl,
-            }
-
-        # whole-path fraction: algorithmic bytes of everything the timed steps solved / their wall time
-        counters = {k: sum(st["counters"][k] for st in stats) for k in stats[0]["counters"]}
-        B, parts = path_bytes(counters, n, p, col_bytes_per_row, gs)
-        if cfg == 5:
-            wall = elapsed
-        else:
-            wall = elapsed  # rank 0's steps; at N > 1 every rank does the same amount
-        path_gbs = B / wall / 1e9
-        roofline_path = {"bound": "hbm", "achieved": path_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": path_gbs / HBM_PEAK_GBS, "algorithmic_bytes": B, "wall_s": wall,
-                         "terms_in_columns": parts,
-                         "note": "rank 0's paths over the timed steps; matrix bytes only (SURVEY.md 8d)" + (
-                             "; B_path charges every fold its own sweep per lambda, while the folds in flight SHARE theirs (one "
-                             "pass over X answers up to 8 folds): a fraction above 1 is bytes saved, not bandwidth" if cfg == 5 else "")}
-
-        last_stat = stats[-1]
-        tm = last_stat["timers"]
-        workloads = {
-            2: f"Gaussian GLM, dense X {n}x{p} {args.dtype} column-major resident in HBM, group size {gs}, alpha={alpha}, "
-               f"{L}-lambda path, early_exit=False",
-            3: f"Gaussian GLM, dense X {n}x{p} {args.dtype} column-major resident in HBM, group size {gs} ({p // gs} groups), "
-               f"alpha={alpha}, {L}-lambda path, early_exit=False",
-            4: f"Binomial GLM (IRLS), matrix.snp_unphased 2-bit packed {n}x{p} (25% ones, 5% twos, 10% missing, mean-imputed) "
-               f"resident in HBM, lasso, {L}-lambda path, early_exit=False",
-            5: f"cv_grpnet {args.n_folds}-fold, Gaussian GLM, dense X {n}x{p} {args.dtype} resident in HBM, lasso, "
-               f"min_ratio=0.1, {L} lambdas, folds sharded fold k -> rank k % {world}",
-        }
-        out = {
-            "metric": METRIC,
-            "value": units / elapsed,
-            "unit": "paths/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "strong" if cfg == 5 else "weak",
-            "vs_baseline": None,
-            "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {"workload": workloads[cfg] + ("" if world == 1 or cfg == 5 else
-                                                      "; rank r trains on the complement of CV fold r%8 (weak scaling)"),
-                       "baseline_config": cfg, "n": n, "p": p, "lmda_path_size": L, "group_size": gs, "alpha": alpha},
-            "roofline": roofline,
-            "roofline_path": roofline_path,
-            "roofline_sweep": sweep_roof if roofline is not sweep_roof else None,
-            "roofline_gram_mfma": gram_roof if roofline is not gram_roof else None,
-            "roofline_panel_step": panel,
-            "breakdown_ms_last_path": {
-                "sweep": tm["t_sweep_ms"], "gram_mfma": tm["t_gram_ms"], "cd": tm["t_cd_ms"], "resid_axpy": tm["t_axpy_ms"],
-                "host_screen": tm["t_host_screen_ms"], "total": 1e3 * last_stat["total_time"],
-            },
-            "counters": counters,
-        }
-        if cfg == 5:
-            out["cv"] = {"cv_wall_s": elapsed / args.steps, "folds_per_s": units / elapsed, "n_folds": args.n_folds,
-                         "folds_per_rank": [len(range(r, args.n_folds, world)) for r in range(world)],
-                         "best_idx": int(last.best_idx), "min_avg_loss": float(last.avg_losses.min()),
-                         "note": "counters / rooflines aggregate rank 0's folds only"}
-        else:
-            out["final_active"] = int(last.active_set_size)
-            out["final_screen"] = int(len(last.screen_set))
-        if cv_leg is not None:
-            out["cv_config5"] = cv_leg
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, args, keep, y, glm, kw, cv_kw, npdtype, last, Xd, n, p)
+    if ctx.rank == 0:
         print(json.dumps(out), flush=True)
 
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
 # -------------------------------------------------------------------------------------------------------------------------

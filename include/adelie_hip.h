@@ -369,11 +369,18 @@ enum adelie_hip_scalar {
                                         recomputed under every iteration's weights: the IRLS term of SURVEY.md 8d's B_path) */
     ADELIE_HIP_S_N_SPECULATED,       /* fits whose first active-set pass was enqueued behind the previous lambda's sweep */
     ADELIE_HIP_S_N_SPEC_ROLLBACKS,   /* ... of which were taken back (KKT failure, early exit, live-state read) */
+    ADELIE_HIP_S_N_SWEEPS_SHARED,    /* full-gradient sweeps of this solve that were answered by a launch shared with other
+                                        solvers on the same design (cv_grpnet folds in flight): X is streamed once for all */
+    ADELIE_HIP_S_N_UPDATE_COLS,      /* design columns streamed by the residual updates of the panel steps (n_updates counts
+                                        groups on grouped problems; this counts their columns) */
     /* HIP-event time (ms) of the device phases on the design's stream, summed over the solve, and launch counts */
     ADELIE_HIP_S_T_SWEEP_MS = 80, ADELIE_HIP_S_T_GRAM_MS, ADELIE_HIP_S_T_CD_MS, ADELIE_HIP_S_T_AXPY_MS,
     ADELIE_HIP_S_N_SWEEP_LAUNCHES, ADELIE_HIP_S_N_GRAM_LAUNCHES, ADELIE_HIP_S_T_HOST_SCREEN_MS,
     /* per-launch timing of the panel step kernel; only collected when ADELIE_HIP_TIME_PANEL=1 (adds two events per launch) */
-    ADELIE_HIP_S_T_PANEL_STEP_MS, ADELIE_HIP_S_N_PANEL_STEP_LAUNCHES
+    ADELIE_HIP_S_T_PANEL_STEP_MS, ADELIE_HIP_S_N_PANEL_STEP_LAUNCHES,
+    /* the part of T_HOST_SCREEN_MS the host spent waiting for the device (stream / event synchronisation) rather than
+     * computing the screening rule, the appends and the launches of the new groups' variances */
+    ADELIE_HIP_S_T_HOST_SCREEN_WAIT_MS
 };
 int64_t     adelie_hip_result_size(const adelie_hip_result* r, int which);
 /* Copies min(size, cap) elements: value vectors as double, index vectors as int64. */

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -101,6 +102,57 @@ struct Staging {
     };
 };
 
+// Process-wide cache of device allocations.  Every solve builds ~100 DevBufs and drops them again (2.7 ms of hipMalloc /
+// hipFree per headline path, 17 solves per 8-fold CV), and hipFree synchronises the device.  Released buffers are parked here by
+// (device, size) and handed to the next request of a similar size; consecutive solves on one design ask for the same sizes,
+// so after the first solve nothing is allocated.  Contents are NOT zeroed (neither does hipMalloc promise that).  A buffer is
+// only parked by its owner's destructor / release(), i.e. after the owner's streams were synchronised.  At most
+// `limit_bytes()` stay parked (default 6 GB; adelie_hip_set_config("pool_limit_mb", x); 0 disables the cache and
+// "pool_trim" frees what is parked).
+struct DevPool {
+    struct Entry { size_t bytes; void* p; int dev; };
+    static std::mutex& mu() { static std::mutex* m = new std::mutex; return *m; }
+    static std::vector<Entry>& parked() { static auto* v = new std::vector<Entry>; return *v; } // (never destroyed: no HIP calls at exit)
+    static size_t& parked_bytes() { static size_t b = 0; return b; }
+    static size_t& limit_bytes() { static size_t b = size_t(6) << 30; return b; }
+    static void* take(size_t bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+        std::lock_guard<std::mutex> lk(mu());
+        auto& v = parked();
+        size_t best = v.size();
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i].dev == dev && v[i].bytes >= bytes && v[i].bytes <= bytes + bytes / 8 + 4096 &&
+                (best == v.size() || v[i].bytes < v[best].bytes))
+                best = i;
+        if (best == v.size()) return nullptr;
+        void* p = v[best].p;
+        parked_bytes() -= v[best].bytes;
+        v[best] = v.back();
+        v.pop_back();
+        return p;
+    }
+    // returns false when the buffer was not parked (the caller frees it)
+    static bool give(void* p, size_t bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        std::lock_guard<std::mutex> lk(mu());
+        if (parked_bytes() + bytes > limit_bytes() || parked().size() >= 4096) return false;
+        parked().push_back(Entry{bytes, p, dev});
+        parked_bytes() += bytes;
+        return true;
+    }
+    static void trim() {
+        std::vector<Entry> v;
+        {
+            std::lock_guard<std::mutex> lk(mu());
+            v.swap(parked());
+            parked_bytes() = 0;
+        }
+        for (const Entry& e : v) (void)hipFree(e.p);
+    }
+};
+
 // Owning device buffer (grow-only).
 template <class T>
 struct DevBuf {
@@ -109,9 +161,11 @@ struct DevBuf {
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf() { release(); }
-    void release() {
-        if (p) {
+    // The destructor parks the block in the process-wide cache: the owner has synchronised its streams by then.  A release in
+    // the middle of a solve (growth) goes through hipFree, which waits for whatever may still be using the old block.
+    ~DevBuf() { release(true); }
+    void release(bool park = false) {
+        if (p && !(park && DevPool::give(p, cap * sizeof(T)))) {
             const auto t0 = std::chrono::steady_clock::now();
             (void)hipFree(p);
             DevAllocStats::seconds() += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -120,16 +174,34 @@ struct DevBuf {
         p = nullptr;
         cap = 0;
     }
+    // allocation through the process-wide cache; `cap` is set to what the block really holds
+    static T* alloc(size_t want, size_t& got) {
+        // sizes are rounded up so that requests that differ a little between solves (screen sets of slightly different
+        // lengths) still find their parked block
+        size_t bytes = want * sizeof(T);
+        const size_t gran = bytes < (size_t(1) << 16) ? 4096 : (bytes < (size_t(1) << 24) ? (size_t(1) << 16) : (size_t(1) << 21));
+        bytes = (bytes + gran - 1) / gran * gran;
+        void* q = DevPool::take(bytes);
+        if (!q) {
+            const auto t0 = std::chrono::steady_clock::now();
+            hipError_t e = hipMalloc(&q, bytes);
+            if (e != hipSuccess) { // out of memory with blocks parked: give them back and try once more
+                (void)hipGetLastError();
+                DevPool::trim();
+                AHIP_CHECK(hipMalloc(&q, bytes));
+            }
+            DevAllocStats::seconds() += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            ++DevAllocStats::calls();
+        }
+        got = bytes / sizeof(T);
+        return static_cast<T*>(q);
+    }
     // ensure capacity >= n elements; contents are NOT preserved
     T* reserve(size_t n) {
         if (n > cap) {
             release();
             size_t want = n < 16 ? 16 : n;
-            const auto t0 = std::chrono::steady_clock::now();
-            AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T)));
-            DevAllocStats::seconds() += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            ++DevAllocStats::calls();
-            cap = want;
+            p = alloc(want, cap);
         }
         return p;
     }
@@ -138,13 +210,13 @@ struct DevBuf {
         if (n <= cap) return p;
         size_t want = cap * 2 > n ? cap * 2 : n;
         if (want < 16) want = 16;
-        T* q = nullptr;
-        AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&q), want * sizeof(T)));
+        size_t got = 0;
+        T* q = alloc(want, got);
         if (p && keep) AHIP_CHECK(hipMemcpyAsync(q, p, keep * sizeof(T), hipMemcpyDeviceToDevice, s));
         AHIP_CHECK(hipStreamSynchronize(s));
         if (p) (void)hipFree(p);
         p = q;
-        cap = want;
+        cap = got;
         return p;
     }
     void upload(const T* h, size_t n, hipStream_t s, size_t off = 0) {

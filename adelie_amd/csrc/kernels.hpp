@@ -443,6 +443,13 @@ void launch_cov_grad(const T* S, int64_t lda, int64_t p, const T* v, const int32
                      T* grad, hipStream_t s);
 template <class T> void launch_copy2d(const T* src, int64_t lds, T* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s);
 // vars[pos0 + a] = max(C[(pos0+a)*(ldc+1)], 0) for a < cnt   (gs == 1 groups)
+// Eigen-decomposition of new screen groups' Gram blocks on the device (kernels_eig.hip): group `i` of the launch reads the
+// (q, q) block at src_base + src (leading dimension ld), writes its eigenvalues (ascending, clamped at 0) to
+// vars[vars_pos .. + q) and its eigenvectors (column-major, in the columns) to V[v_off .. + q*q).  q == 1: the variance only.
+struct EigDesc { int64_t src; int64_t vars_pos; int64_t v_off; int32_t ld; int32_t q; };
+constexpr int kEigMaxQ = 96; // 2 * q * q doubles of LDS
+template <class T>
+void launch_grp_eig(const T* src_base, const EigDesc* desc_dev, int count, int max_q, T* vars, T* V, hipStream_t s);
 template <class T> void launch_diag_vars(const T* C, int64_t ldc, int32_t pos0, int32_t cnt, T* vars, hipStream_t s);
 // transpose row-major (n,p) into column-major with leading dimension ld
 template <class T> void launch_transpose(const T* src, int64_t n, int64_t p, T* dst, int64_t ld, hipStream_t s);

@@ -327,8 +327,8 @@ SweepBatcher* batcher_of(adelie_hip_design* d) {
 // ------------------------------------------------------------------------------------------------------------
 template <class T>
 struct Solver {
-    adelie_hip_design* D;
-    hipStream_t st;
+    adelie_hip_design* D = nullptr;
+    hipStream_t st = nullptr;
     idx n, p, G;
     // ---- static inputs (host copies) ----
     std::vector<idx> groups, group_sizes;
@@ -591,6 +591,8 @@ struct Solver {
     int32_t report_seq = 0;
     bool use_report = true;
     ~Solver() {
+        // every DevBuf member is parked in the allocation cache by its destructor: nothing may still be running on them
+        if (st) (void)hipStreamSynchronize(st);
         if (h_report) (void)hipHostFree(h_report);
         if (st2) {
             (void)hipStreamSynchronize(st2);
@@ -1076,9 +1078,41 @@ struct Solver {
         d_sxm.upload(sxm.data(), sxm.size(), st, pos0);
         std::vector<idx> voff(ns - g_begin, 0);
         bool any_group = false;
+        idx max_q = 1;
         for (idx ss = idx(g_begin); ss < ns; ++ss) {
             const idx q = group_sizes[screen_set[ss]];
             if (q > 1) any_group = true;
+            max_q = std::max(max_q, q);
+        }
+        if (any_group && device_eig && max_q <= idx(kEigMaxQ)) {
+            // eigen-decompositions of the new groups' diagonal blocks of C on the device (kernels_eig.hip): no per-group copy
+            // to the host and back, no host wait
+            eig_desc.clear();
+            size_t v_new = 0;
+            if (h_voff.size() < size_t(ns)) h_voff.resize(size_t(ns), 0);
+            for (idx ss = idx(g_begin); ss < ns; ++ss) {
+                const idx q = group_sizes[screen_set[ss]], b = screen_begins[ss];
+                if (q == 1) continue; // (launch_diag_vars above wrote its variance)
+                EigDesc e{};
+                e.src = b + b * ldc;
+                e.ld = int32_t(ldc);
+                e.q = int32_t(q);
+                e.vars_pos = b;
+                e.v_off = int64_t(v_used + v_new);
+                voff[ss - g_begin] = idx(v_used + v_new);
+                h_voff[size_t(ss)] = voff[ss - g_begin];
+                v_new += size_t(q) * q;
+                eig_desc.push_back(e);
+            }
+            if (v_new) d_V.grow(v_used + v_new, v_used, st);
+            v_used += v_new;
+            d_eig_desc.reserve(eig_desc.size());
+            d_eig_desc.upload(eig_desc.data(), eig_desc.size(), st);
+            launch_grp_eig<T>(d_C.p, d_eig_desc.p, int(eig_desc.size()), int(max_q), d_vars.p, d_V.p, st);
+            d_voff.upload(voff.data(), voff.size(), st, g_begin);
+            host_mirrors_stale = true;
+            if (Staging::current() != &stage || !stage.base) sync();
+            return;
         }
         std::vector<T> vars_host(N);
         d_vars.download(vars_host.data(), N, st, pos0);
@@ -1174,7 +1208,10 @@ struct Solver {
         launch_gather<T>(xm_dev, d_vcol.p + pos0, N, d_sxm.p + pos0, st);
         int j0 = 0;
         while (j0 + 1 < nblk && size_t(part_host[j0 + 1]) <= g_begin) ++j0;
-        std::vector<T> hD(size_t(nblk - j0) * SL * SL);
+        idx max_q = 1;
+        for (idx ss = idx(g_begin); ss < ns; ++ss) max_q = std::max(max_q, group_sizes[screen_set[ss]]);
+        const bool dev_eig = device_eig && max_q <= idx(kEigMaxQ);
+        std::vector<T> hD(dev_eig ? size_t(0) : size_t(nblk - j0) * SL * SL);
         std::vector<int> rebuilt_blocks;
         for (int j = j0; j < nblk; ++j) {
             const int nval = gp_vbeg[size_t(j) + 1] - gp_vbeg[j];
@@ -1186,13 +1223,51 @@ struct Solver {
                 ++cnt.n_panel_grams;
                 rebuilt_blocks.push_back(j);
             }
-            AHIP_CHECK(hipMemcpyAsync(hD.data() + size_t(j - j0) * SL * SL, Dptr, size_t(SL) * SL * sizeof(T),
-                                      hipMemcpyDeviceToHost, st));
+            if (!dev_eig)
+                AHIP_CHECK(hipMemcpyAsync(hD.data() + size_t(j - j0) * SL * SL, Dptr, size_t(SL) * SL * sizeof(T),
+                                          hipMemcpyDeviceToHost, st));
+        }
+        std::vector<idx> voff(size_t(ns) - g_begin, 0);
+        h_voff.resize(size_t(ns), 0);
+        if (dev_eig) {
+            // eigen-decompositions on the device, one wavefront per new group, straight from the blocks built above: no copy
+            // of the blocks to the host, no host wait (the host mirrors of screen_vars / screen_transforms are filled by
+            // download_invariants)
+            eig_desc.clear();
+            size_t v_new = 0;
+            int j = j0;
+            for (idx ss = idx(g_begin); ss < ns; ++ss) {
+                while (j + 1 < nblk && part_host[j + 1] <= int32_t(ss)) ++j;
+                const idx q = group_sizes[screen_set[ss]], b = screen_begins[ss];
+                const idx o = b - gp_vbeg[j];
+                EigDesc e{};
+                e.src = int64_t(j) * SL * SL + o + o * SL;
+                e.ld = SL;
+                e.q = int32_t(q);
+                e.vars_pos = b;
+                e.v_off = 0;
+                if (q > 1) {
+                    voff[ss - g_begin] = idx(v_used + v_new);
+                    h_voff[size_t(ss)] = voff[ss - g_begin];
+                    e.v_off = int64_t(v_used + v_new);
+                    v_new += size_t(q) * q;
+                }
+                eig_desc.push_back(e);
+            }
+            if (v_new) d_V.grow(v_used + v_new, v_used, st);
+            v_used += v_new;
+            d_eig_desc.reserve(eig_desc.size());
+            d_eig_desc.upload(eig_desc.data(), eig_desc.size(), st);
+            launch_grp_eig<T>(d_Dpool.p, d_eig_desc.p, int(eig_desc.size()), int(max_q), d_vars.p, d_V.p, st);
+            d_voff.upload(voff.data(), voff.size(), st, g_begin);
+            if (group_rot)
+                for (int jb : rebuilt_blocks) rotate_block(nullptr, jb, d_Dpool.p + size_t(jb) * SL * SL, 0);
+            host_mirrors_stale = true;
+            if (Staging::current() != &stage || !stage.base) sync(); // (pageable uploads: the vectors go out of scope)
+            return;
         }
         sync();
         std::vector<T> vars_host(N), vnew;
-        std::vector<idx> voff(size_t(ns) - g_begin, 0);
-        h_voff.resize(size_t(ns), 0);
         int j = j0;
         for (idx ss = idx(g_begin); ss < ns; ++ss) {
             while (j + 1 < nblk && part_host[j + 1] <= int32_t(ss)) ++j;
@@ -1229,6 +1304,13 @@ struct Solver {
         sync(); // the staging vectors go out of scope
         for (idx t = 0; t < N; ++t) screen_vars[pos0 + t] = vars_host[t];
     }
+    // device-side eigen-decompositions of new screen groups (kernels_eig.hip; A/B hook ADELIE_HIP_DEVICE_EIG=0: host Jacobi on
+    // copies of the blocks, as in rounds 1-2).  `host_mirrors_stale`: screen_vars / screen_transforms on the host lag behind
+    // d_vars / d_V until download_invariants refreshes them.
+    bool device_eig = true;
+    bool host_mirrors_stale = false;
+    std::vector<EigDesc> eig_desc;
+    DevBuf<EigDesc> d_eig_desc;
     // D <- R^T D R for block `jb` of the partition in part_host over `list` (nullptr: screen order), on the stream of build
     // side `side` (0: main).  See CdGrpBlkParams::rot.
     bool group_rot = true; // A/B hook ADELIE_HIP_GROUP_ROT=0
@@ -3074,7 +3156,22 @@ struct Solver {
             d_sxm.download(screen_X_means.data(), size_t(nv), st);
             d_vars.download(screen_vars.data(), size_t(nv), st);
         }
+        std::vector<T> v_host;
+        if (host_mirrors_stale && v_used > 0) {
+            v_host.resize(v_used);
+            d_V.download(v_host.data(), v_used, st);
+        }
         sync();
+        if (host_mirrors_stale) { // eigenbases computed on the device: (1) for single coefficients, a slice of d_V otherwise
+            screen_transforms.resize(screen_set.size());
+            for (size_t ss = 0; ss < screen_set.size(); ++ss) {
+                const size_t q = size_t(group_sizes[screen_set[ss]]);
+                if (q == 1) screen_transforms[ss] = std::vector<T>{T(1)};
+                else if (ss < h_voff.size() && size_t(h_voff[ss]) + q * q <= v_host.size())
+                    screen_transforms[ss].assign(v_host.begin() + h_voff[ss], v_host.begin() + h_voff[ss] + q * q);
+            }
+            host_mirrors_stale = false;
+        }
         if (multi()) { // back to the ABI's (n, K) row-major layout
             std::vector<T> tmp(resid);
             from_major(tmp.data(), resid.data());
@@ -3172,6 +3269,7 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_SPECULATE")) spec_enabled = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_CROSS_BATCH")) cross_batch = std::max(1, std::min(int(GramBatch::MAX), std::atoi(e)));
         if (const char* e = std::getenv("ADELIE_HIP_CROSS_INCR")) cross_incremental = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_DEVICE_EIG")) device_eig = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {
             panel_bsz = std::atoi(e);
             if (panel_bsz != 32 && panel_bsz != 64 && panel_bsz != 128) panel_bsz = 0;
@@ -3626,6 +3724,10 @@ int adelie_hip_set_config(const char* name, double value) {
     if (nm == "hessian_min") g_hessian_min = value;
     else if (nm == "dbeta_tol") g_dbeta_tol = value;
     else if (nm == "sweep_batch") g_sweep_batch = value != 0.0 ? 1 : 0;
+    else if (nm == "pool_limit_mb") {
+        DevPool::limit_bytes() = value > 0 ? size_t(value) << 20 : 0;
+        if (value <= 0) DevPool::trim();
+    } else if (nm == "pool_trim") DevPool::trim();
     else {
         set_last_error("adelie_core: unknown config name.");
         return 1;

@@ -63,7 +63,10 @@ int         adelie_hip_device_count(void);
  * One name has no counterpart upstream: "sweep_batch" (0/1, default 0).  When 1, solves that run concurrently (from
  * different host threads) on one dense matrix -- a design and its aliases, e.g. the folds of cv_grpnet -- share their
  * full-gradient sweeps: those that reach a sweep within a short window are answered by one pass over X.  The gradients are
- * then accumulated in another (fixed) order than the ordinary sweep's, i.e. they differ from it in the last bits. */
+ * then accumulated in another (fixed) order than the ordinary sweep's, i.e. they differ from it in the last bits.
+ * Device memory: the working buffers of a finished solve are parked in a process-wide cache and handed to the next solve
+ * instead of going through hipFree / hipMalloc; "pool_limit_mb" (default 6144; 0 = no caching) bounds what stays parked,
+ * "pool_trim" (any value) returns the parked blocks to the driver. */
 int         adelie_hip_set_config(const char* name, double value);
 
 /* ------------------------------------------------------------------------------------------

@@ -302,6 +302,31 @@ __global__ void gather_kernel(const T* __restrict__ src, const int32_t* __restri
     if (i < cnt) dst[i] = src[idx[i]];
 }
 
+// out[0] = max_i |a_i - prev_i| / prev_i over prev_i > 0 (non-negative values compare like their bit patterns), then
+// prev <- a: how far the IRLS weights moved since the iteration the cached diagonal blocks were built for
+__device__ __forceinline__ void atomic_max_nonneg(double* out, double v) {
+    atomicMax(reinterpret_cast<unsigned long long*>(out), static_cast<unsigned long long>(__double_as_longlong(v)));
+}
+__device__ __forceinline__ void atomic_max_nonneg(float* out, float v) {
+    atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(v));
+}
+template <class T>
+__global__ __launch_bounds__(RT) void rel_change_kernel(const T* __restrict__ a, T* __restrict__ prev, int64_t n, T* out) {
+    T m = T(0);
+    GRID_STRIDE(i, n) {
+        const T x = a[i], y = prev[i];
+        prev[i] = x;
+        const T d = fabs(x - y);
+        const T r = y > T(0) ? d / y : (d > T(0) ? T(1e30) : T(0));
+        m = r > m ? r : m;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const T o = __shfl_xor(m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m > T(0)) atomic_max_nonneg(out, m);
+}
+
 template <class T>
 void finish(T* sums, int K, hipStream_t s) {
     hipLaunchKernelGGL((final_reduce_kernel<T>), dim3(1), dim3(RT), 0, s, sums, K);
@@ -376,6 +401,11 @@ void launch_dot_diff(const T* a, const T* a0, const T* b, const T* b0, int64_t n
     finish(sums, 1, s);
 }
 template <class T>
+void launch_rel_change(const T* a, T* prev, int64_t n, T* out, hipStream_t s) {
+    (void)hipMemsetAsync(out, 0, sizeof(T), s);
+    hipLaunchKernelGGL((rel_change_kernel<T>), dim3(RB), dim3(RT), 0, s, a, prev, n, out);
+}
+template <class T>
 void launch_gather(const T* src, const int32_t* idx, int64_t cnt, T* dst, hipStream_t s) {
     if (cnt <= 0) return;
     hipLaunchKernelGGL((gather_kernel<T>), dim3(unsigned((cnt + 255) / 256)), dim3(256), 0, s, src, idx, cnt, dst);
@@ -397,6 +427,7 @@ void launch_gather(const T* src, const int32_t* idx, int64_t cnt, T* dst, hipStr
                                       hipStream_t, int, const T*, const T*);                                                                \
     template void launch_set_eta<T>(const T*, T, int64_t, T*, hipStream_t);                                            \
     template void launch_dot_diff<T>(const T*, const T*, const T*, const T*, int64_t, T*, hipStream_t);                \
+    template void launch_rel_change<T>(const T*, T*, int64_t, T*, hipStream_t);                                        \
     template void launch_gather<T>(const T*, const int32_t*, int64_t, T*, hipStream_t);
 INST(double)
 INST(float)

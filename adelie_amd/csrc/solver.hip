@@ -53,6 +53,8 @@ void launch_set_eta(const T* offsets, T beta0, int64_t n, T* eta, hipStream_t s)
 template <class T>
 void launch_dot_diff(const T* a, const T* a0, const T* b, const T* b0, int64_t n, T* out1, hipStream_t s);
 template <class T>
+void launch_rel_change(const T* a, T* prev, int64_t n, T* out, hipStream_t s);
+template <class T>
 void launch_gather(const T* src, const int32_t* idx, int64_t cnt, T* dst, hipStream_t s);
 } // namespace ahip
 
@@ -513,8 +515,10 @@ struct Solver {
         // the chain waits for a block through the event of its batch.  The first batch of a pass is kept small so that the
         // chain can start early.
         stale.clear();
-        for (int j = 0; j < nblk; ++j)
-            if (!(tab_nb[j] == nb_of(j) && tab_ver[j] == w_version)) stale.push_back(j);
+        for (int j = 0; j < nblk; ++j) {
+            if (!(tab_nb[j] == nb_of(j) && ver_usable(tab_ver[j]))) stale.push_back(j);
+            else if (tab_ver[j] != w_version) ++n_blocks_reused;
+        }
         auto cls = [](int nb) { return nb <= 32 ? 32 : (nb <= 64 ? 64 : 128); };
         size_t i = 0;
         bool first_batch = true;
@@ -572,6 +576,34 @@ struct Solver {
         if (!pass_e0) AHIP_CHECK(hipEventCreateWithFlags(&pass_e0, hipEventDisableTiming));
         AHIP_CHECK(hipEventRecord(pass_e0, st));
         pass_e0_valid = true;
+    }
+    // ---- IRLS: diagonal blocks of an earlier iteration as the in-block operator (hook ADELIE_HIP_IRLS_REUSE=theta) ----
+    // Under IRLS every block is rebuilt per iteration and used about once (config 4: 54 k builds for 54 k block visits,
+    // half of the path's time).  A block only carries the coupling INSIDE its 64 visits: the gradient a block starts from
+    // comes from the residual, exactly, on every visit.  So a block built for weights that differ from the current ones by
+    // at most `irls_reuse` (relative, every observation; accumulated over the iterations since its build) still gives the
+    // exact solution of the weighted problem at the fixed point of the passes - the passes stop on the coefficient changes
+    // they actually make - and what changes is the iterate sequence inside a pass, by O(theta |delta|).  The later IRLS
+    // iterations of a lambda move the weights by 1e-3 or less.  Measured on config 4 (500k x 50k): theta = 0.01 builds
+    // 20.8 k blocks instead of 54.3 k, 7.05 -> 5.04 s, the same 222 IRLS iterations / 585 passes / screen and active sets,
+    // max |delta beta| against theta = 0 over the whole path 1.1e-9 (scripts/irls_reuse.py).  0 = always rebuild.
+    double irls_reuse = 0.01;
+    std::vector<double> ver_drift;       // ver_drift[v] = log(1 + max relative weight change between versions v-1 and v)
+    uint64_t min_usable_version = 1;     // blocks built at this weight version or later are within irls_reuse of the current weights
+    int64_t n_blocks_reused = 0;
+    DevBuf<T> d_irls_w_prev;
+    bool irls_w_prev_valid = false;
+    bool ver_usable(uint64_t v) const {
+        return v == w_version || (irls_reuse > 0 && all_scalar && v != 0 && v >= min_usable_version && v < w_version);
+    }
+    void note_weight_drift(double max_rel) { // called right after ++w_version
+        if (ver_drift.size() <= size_t(w_version)) ver_drift.resize(size_t(w_version) + 1, 1e300);
+        ver_drift[size_t(w_version)] = std::log1p(max_rel);
+        double acc = 0;
+        uint64_t v = w_version;
+        const double budget = std::log1p(irls_reuse);
+        while (v > 1 && acc + ver_drift[size_t(v)] <= budget) { acc += ver_drift[size_t(v)]; --v; }
+        min_usable_version = v;
     }
     bool prebuild_enabled = true; // A/B hook ADELIE_HIP_PREBUILD=0
     bool fuse_reduce = false;     // look-ahead passes: the solve sums the previous launch's slice partials itself instead of a panel_reduce launch (hook ADELIE_HIP_FUSE_REDUCE=1; measured slower: 3.08 vs 3.20 paths/s, the solve's longer prologue lengthens the fused launch by more than the reduce launch cost)
@@ -2747,6 +2779,14 @@ struct Solver {
                 }
                 std::vector<T> m(nv);
                 d_g.download(m.data(), size_t(nv), st);
+                T drift = T(1e30);
+                const bool track = irls_reuse > 0 && all_scalar && panel_mode();
+                if (track) { // how far the weights moved since the previous iteration (and keep a copy for the next one)
+                    d_irls_w_prev.reserve(size_t(n));
+                    if (!irls_w_prev_valid) AHIP_CHECK(hipMemsetAsync(d_irls_w_prev.p, 0, size_t(n) * sizeof(T), st));
+                    launch_rel_change<T>(d_irls_w.p, d_irls_w_prev.p, n, d_sums.p + 15, st);
+                    AHIP_CHECK(hipMemcpyAsync(&drift, d_sums.p + 15, sizeof(T), hipMemcpyDeviceToHost, st));
+                }
                 sync();
                 for (idx ss = 0; ss < idx(screen_set.size()); ++ss) {
                     const idx g = screen_set[ss];
@@ -2757,6 +2797,10 @@ struct Solver {
                 v_used = 0;
                 screen_transforms.clear();
                 ++w_version; // diagonal blocks built from here on belong to this iteration's weights
+                if (track) {
+                    note_weight_drift(irls_w_prev_valid ? double(drift) : 1e300);
+                    irls_w_prev_valid = true;
+                }
                 if (panel_mode()) update_vars_panel(d_irls_w.p, d_irls_xm.p, irls_xm_host, 0);
                 else update_gram_and_vars(d_irls_w.p, d_irls_xm.p, irls_xm_host, 0);
             }
@@ -3110,8 +3154,8 @@ struct Solver {
     // pull the device-resident invariants back into the host mirrors that the result accessors expose
     void finalize() {
         if (std::getenv("ADELIE_HIP_TRACE_ENQ"))
-            std::fprintf(stderr, "[enq] panel passes: host enqueue %.1f ms, host wait %.1f ms, blocks %lld, speculated %lld (rolled back %lld)\n",
-                         t_enq * 1e3, t_wait * 1e3, (long long)cnt.n_panel_blocks, (long long)n_spec, (long long)n_spec_rollback);
+            std::fprintf(stderr, "[enq] panel passes: host enqueue %.1f ms, host wait %.1f ms, blocks %lld (built %lld, reused across IRLS iterations %lld), speculated %lld (rolled back %lld)\n",
+                         t_enq * 1e3, t_wait * 1e3, (long long)cnt.n_panel_blocks, (long long)cnt.n_panel_grams, (long long)n_blocks_reused, (long long)n_spec, (long long)n_spec_rollback);
         if (std::getenv("ADELIE_HIP_TRACE_ENQ"))
             std::fprintf(stderr, "[alloc] hipMalloc/hipFree so far in this process: %ld calls, %.1f ms\n", DevAllocStats::calls(),
                          DevAllocStats::seconds() * 1e3);
@@ -3270,6 +3314,7 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_CROSS_BATCH")) cross_batch = std::max(1, std::min(int(GramBatch::MAX), std::atoi(e)));
         if (const char* e = std::getenv("ADELIE_HIP_CROSS_INCR")) cross_incremental = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_DEVICE_EIG")) device_eig = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_IRLS_REUSE")) irls_reuse = std::max(0.0, std::atof(e));
         if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {
             panel_bsz = std::atoi(e);
             if (panel_bsz != 32 && panel_bsz != 64 && panel_bsz != 128) panel_bsz = 0;

@@ -288,6 +288,7 @@ __device__ __forceinline__ void blk_solve_body(const CdBlkParams<T>& p, int j, c
     // net changes of the block (a coordinate is visited once per pass, so delta = new - old)
     bB[lane] = nb0; bB[lane + 64] = nb1;
     dB[lane] = nb0 - b0; dB[lane + 64] = nb1 - b1;
+    if (NAIVE && p.dd != nullptr) { p.dd[lane] = nb0 - b0; p.dd[lane + 64] = nb1 - b1; }
     // ---- write back the block: beta, and the compacted non-zero changes for the update kernel ---------------------------
     int nz = 0;
     for (int i0 = 0; i0 < BLK; i0 += 64) {
@@ -321,6 +322,272 @@ __device__ __forceinline__ void blk_solve_body(const CdBlkParams<T>& p, int j, c
             p.rsum_out[0] = rsum;
         }
         if (NAIVE && p.host_st && j == p.report_j) {
+            CdBlkState<T> out;
+            out.rsq = rsq; out.resid_sum = rsum; out.cm = cm; out.n_updates = n_upd;
+            out.active_size = asz; out.status = status; out.nz = nz; out._pad = 0;
+            *p.host_st = out;
+            __threadfence_system();
+            __hip_atomic_store(p.host_seq, p.report_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Solve of block j inside the fused look-ahead launch, for ALL 1024 threads of workgroup 0 (lasso, no constraints).
+// Same visits and bookkeeping as blk_solve_body; what differs is the prologue.  While the other workgroups of the launch
+// stream 190 MB, a dependent global round trip of this workgroup takes 3-5 us (it queues behind the step's loads), and
+// blk_solve_body + blk_corr_helper make four to five of them in a row (indices -> constants, the diagonal block in four
+// batches, change positions -> cross-block columns in three): the solve, not the step, set the length of the launch.  Here
+// every load of the prologue is independent of the others and issued up front by all sixteen waves:
+//   * the diagonal block, 128 KB, one batch of 16-byte loads per thread;
+//   * the cross block C_{j,j-1}, all of it, 128 KB likewise - the previous solve left its changes in DENSE form (pdd, zeros
+//     where nothing changed), so the correction is C * pdd with no index loads; each thread multiplies the pieces it holds by
+//     the entries of pdd (from LDS) and the 1024 / (BLK / VEC) partial sums per row are combined in a fixed order;
+//   * the slice partials of the block's gradient when the solver fused the reduction into this launch (p.part, slice-major),
+//     in two batches (register budget of a 1024-thread workgroup: 128 VGPRs);
+//   * the per-coordinate constants, straight into the registers of the visiting wave (two coordinates per lane).
+// LDS: D | corr[NG][BLK] | gsum[8][BLK] | bB | dB | idxB  (blk_solve_lds_la).
+template <class T> struct LaShape {
+    static constexpr int VEC = CbVec<T>::N;
+    static constexpr int CPC = BLK / VEC;            // 16-byte chunks per column
+    static constexpr int ND = BLK * BLK / VEC / 1024; // chunks per thread and block (f64: 8, f32: 4)
+    static constexpr int NG = 1024 / CPC;            // column groups = partial sums per row (f64: 16, f32: 32)
+};
+template <class T>
+__host__ __device__ constexpr size_t blk_solve_lds_la() {
+    return size_t(BLK) * BLK * sizeof(T) + size_t(LaShape<T>::NG) * BLK * sizeof(T) + size_t(8) * BLK * sizeof(T) +
+           size_t(2) * BLK * sizeof(T) + size_t(BLK) * sizeof(int32_t) + 16;
+}
+template <class T>
+__device__ __forceinline__ void blk_solve_la_body(const CdBlkParams<T>& p, int j, char* smem_raw, int tid) {
+    using V = typename CbVec<T>::type;
+    constexpr int VEC = LaShape<T>::VEC, CPC = LaShape<T>::CPC, ND = LaShape<T>::ND, NG = LaShape<T>::NG;
+    T* D = reinterpret_cast<T*>(smem_raw);
+    T* corr = D + BLK * BLK;       // [NG][BLK]
+    T* gsum = corr + NG * BLK;     // [8][BLK]
+    T* bB = gsum + 8 * BLK;
+    T* dB = bB + BLK;
+    int32_t* idxB = reinterpret_cast<int32_t*>(dB + BLK);
+    const int lane = tid & 63, wv = tid >> 6;
+    const int base = j * p.bsz;
+    const int nb = min(p.bsz, p.count - base);
+    const bool has_c = p.Cprev != nullptr;
+    const bool has_part = p.part != nullptr;
+
+    // ---- every load of the prologue ----------------------------------------------------------------------------------
+    V dreg[ND], creg[ND];
+    {
+        const V* dsrc = reinterpret_cast<const V*>(p.Dptr);
+#pragma unroll
+        for (int u = 0; u < ND; ++u) dreg[u] = dsrc[tid + u * 1024];
+        if (has_c) {
+            const V* csrc = reinterpret_cast<const V*>(p.Cprev);
+#pragma unroll
+            for (int u = 0; u < ND; ++u) creg[u] = csrc[tid + u * 1024];
+        }
+    }
+    T pd = T(0); // previous block's dense changes (first BLK threads)
+    if (has_c && tid < BLK) pd = p.pdd[tid];
+    // visiting wave: indices, then the per-coordinate constants (two coordinates per lane)
+    int i0 = 0, i1 = 0;
+    T g0 = T(0), g1 = T(0), b0 = T(0), b1 = T(0), A0 = T(0), A1 = T(0), L0 = T(0), L1 = T(0), N0 = T(1), N1 = T(1), X0 = T(0), X1 = T(0);
+    int a0 = 1, a1 = 1;
+    T rsq = T(0), rsum = T(0), cm = T(0), prs = T(0);
+    int asz = 0, status = 0;
+    int64_t n_upd = 0;
+    CdBlkState<T>* st = p.st;
+    if (wv == 0) {
+        const bool v0 = lane < nb, v1 = lane + 64 < nb;
+        i0 = v0 ? blk_index(p, base + lane) : 0;
+        i1 = v1 ? blk_index(p, base + lane + 64) : 0;
+        if (!has_part) {
+            g0 = v0 ? p.gblk[lane] : T(0);
+            g1 = v1 ? p.gblk[lane + 64] : T(0);
+        } else if (p.part_rsum) {
+            prs = p.part_rsum[0];
+        }
+        rsq = st->rsq; rsum = st->resid_sum; cm = (j == 0) ? T(0) : st->cm;
+        asz = st->active_size; status = st->status; n_upd = st->n_updates;
+        if (v0) {
+            const T pk = p.spen[i0];
+            A0 = p.vars[i0]; b0 = p.beta[i0]; X0 = p.xmean[i0]; a0 = p.is_active[i0];
+            L0 = p.l1 * pk; N0 = A0 + p.l2 * pk;
+        }
+        if (v1) {
+            const T pk = p.spen[i1];
+            A1 = p.vars[i1]; b1 = p.beta[i1]; X1 = p.xmean[i1]; a1 = p.is_active[i1];
+            L1 = p.l1 * pk; N1 = A1 + p.l2 * pk;
+        }
+    }
+
+    // ---- diagonal block and the previous changes into LDS ---------------------------------------------------------------
+    {
+        V* dst = reinterpret_cast<V*>(D);
+#pragma unroll
+        for (int u = 0; u < ND; ++u) dst[tid + u * 1024] = dreg[u];
+    }
+    if (tid < BLK) dB[tid] = pd; // (dB doubles as the staging of pdd until the loop is over)
+    __syncthreads();
+    // ---- correction C * pdd: this thread's rows rowc * VEC .. + VEC, columns cg + NG * u --------------------------------
+    if (has_c) {
+        const int rowc = tid % CPC, cg = tid / CPC;
+        T acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = T(0);
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const T dl = dB[cg + NG * u];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = fma(creg[u][e], dl, acc[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) corr[cg * BLK + rowc * VEC + e] = acc[e];
+    }
+    // ---- slice partials of the block's gradient (solver fused the reduction into this launch): a second round trip, with
+    //      the registers of the two blocks free again; k0, k0 + 8, ... in a fixed order per thread, eight threads per column
+    if (has_part) {
+        constexpr int PBN = 25;
+        const int pc_c = tid & (BLK - 1), pc_k0 = tid >> 7;
+        const T* pc = p.part + pc_c;
+        T pw[PBN];
+#pragma unroll
+        for (int u = 0; u < PBN; ++u) pw[u] = pc[int64_t(min(pc_k0 + 8 * u, p.part_n - 1)) * BLK];
+        T psum = T(0);
+#pragma unroll
+        for (int u = 0; u < PBN; ++u) psum += (pc_k0 + 8 * u < p.part_n) ? pw[u] : T(0);
+        for (int k = pc_k0 + 8 * PBN; k < p.part_n; k += 8) psum += pc[int64_t(k) * BLK]; // (more than 200 partials)
+        gsum[pc_k0 * BLK + pc_c] = (pc_c < nb) ? psum : T(0);
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    __builtin_amdgcn_s_setprio(3);
+
+    if (has_part) {
+        T s0 = T(0), s1 = T(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            s0 += gsum[q * BLK + lane];
+            s1 += gsum[q * BLK + lane + 64];
+        }
+        g0 = (lane < nb) ? s0 - prs * X0 : T(0);
+        g1 = (lane + 64 < nb) ? s1 - prs * X1 : T(0);
+    }
+    if (has_c) {
+        T c0 = T(0), c1 = T(0);
+#pragma unroll
+        for (int q = 0; q < NG; ++q) { // fixed order
+            c0 += corr[q * BLK + lane];
+            c1 += corr[q * BLK + lane + 64];
+        }
+        g0 -= c0;
+        g1 -= c1;
+    }
+    const T R0 = T(1) / N0, R1 = T(1) / N1;
+    T nb0 = b0, nb1 = b1;
+    T gc0 = T(0), gc1 = T(0);
+#define AHIP_LA_VISIT(GREG, BREG, AREG, LREG, NREG, RREG, NBREG, GCREG, IL)                                           \
+    {                                                                                                                  \
+        const T dc0 = D[i * BLK + lane], dc1 = D[i * BLK + lane + 64];                                                 \
+        const T gcur = rdlane(GREG, IL);                                                                               \
+        const T bi = rdlane(BREG, IL), A = rdlane(AREG, IL);                                                           \
+        const T gk = fma(bi, A, gcur);                    /* pin_naive:85-89 */                                       \
+        const T v = fabs(gk) - rdlane(LREG, IL);          /* pin_base:181-195 */                                      \
+        T ak = T(0);                                                                                                   \
+        if (v > T(0)) {                                                                                                \
+            const T x = copysign(v, gk);                                                                               \
+            const T den = rdlane(NREG, IL), rden = rdlane(RREG, IL);                                                   \
+            const T q0 = x * rden;                                                                                     \
+            const T r = fma(-q0, den, x);                                                                              \
+            ak = fma(r, rden, q0);                                                                                     \
+        }                                                                                                              \
+        if (ak != bi) {                                   /* pin_naive:97 */                                          \
+            const T del = ak - bi;                                                                                     \
+            g0 = fma(-del, dc0, g0);                                                                                   \
+            g1 = fma(-del, dc1, g1);                                                                                   \
+            if (lane == (IL)) { NBREG = ak; GCREG = gcur; }                                                            \
+        }                                                                                                              \
+    }
+    {
+        const int n0 = nb < 64 ? nb : 64;
+        for (int i = 0; i < n0; ++i) AHIP_LA_VISIT(g0, b0, A0, L0, N0, R0, nb0, gc0, i)
+        for (int i = 64; i < nb; ++i) AHIP_LA_VISIT(g1, b1, A1, L1, N1, R1, nb1, gc1, i - 64)
+    }
+#undef AHIP_LA_VISIT
+    // ---- bookkeeping of the block, lane-parallel (as blk_solve_body) ----------------------------------------------------
+    const T d0 = nb0 - b0, d1 = nb1 - b1; // lanes beyond nb hold b = nb = 0
+    const bool ch0 = d0 != T(0), ch1 = d1 != T(0);
+    {
+        const T rs = (ch0 ? d0 * (T(2) * gc0 - d0 * A0) : T(0)) + (ch1 ? d1 * (T(2) * gc1 - d1 * A1) : T(0));
+        const T xs = X0 * d0 + X1 * d1;
+        const T c0 = A0 * d0 * d0, c1 = A1 * d1 * d1;
+        T cmx = c0 > c1 ? c0 : c1;
+        T rs_t = rs, xs_t = xs;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            rs_t += __shfl_xor(rs_t, off, 64);
+            xs_t += __shfl_xor(xs_t, off, 64);
+            const T o = __shfl_xor(cmx, off, 64);
+            cmx = o > cmx ? o : cmx;
+        }
+        rsq += rs_t;
+        rsum -= xs_t;
+        cm = cmx > cm ? cmx : cm;
+        const unsigned long long m0 = __ballot(ch0), m1 = __ballot(ch1);
+        n_upd += __popcll(m0) + __popcll(m1);
+        if (p.mark) { // add_active_set in visiting order, pin_naive:294-304
+            const bool new0 = ch0 && a0 == 0, new1 = ch1 && a1 == 0;
+            const unsigned long long q0 = __ballot(new0), q1 = __ballot(new1);
+            const int cnt = __popcll(q0) + __popcll(q1);
+            if (asz + cnt > p.max_active_size) {
+                status = CD_MAX_ACTIVE;
+            } else {
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                if (new0) { const int pos = asz + __popcll(q0 & lt); p.is_active[i0] = 1; p.active_set[pos] = i0; }
+                if (new1) {
+                    const int pos = asz + __popcll(q0) + __popcll(q1 & lt);
+                    p.is_active[i1] = 1;
+                    p.active_set[pos] = i1;
+                }
+                asz += cnt;
+            }
+        }
+    }
+    // ---- write back: beta, the dense and the compacted changes ---------------------------------------------------------
+    if (ch0) p.beta[i0] = nb0;
+    if (ch1) p.beta[i1] = nb1;
+    if (p.dd != nullptr) { p.dd[lane] = d0; p.dd[lane + 64] = d1; }
+    int nz = 0;
+    {
+        const unsigned long long m0 = __ballot(ch0), m1 = __ballot(ch1);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        if (ch0) {
+            const int pos = __popcll(m0 & lt);
+            p.dcol[pos] = p.vcol[i0];
+            if (p.dpos) p.dpos[pos] = lane;
+            p.dlt[pos] = d0;
+        }
+        const int n0c = __popcll(m0);
+        if (ch1) {
+            const int pos = n0c + __popcll(m1 & lt);
+            p.dcol[pos] = p.vcol[i1];
+            if (p.dpos) p.dpos[pos] = lane + 64;
+            p.dlt[pos] = d1;
+        }
+        nz = n0c + __popcll(m1);
+    }
+    if (lane == 0) {
+        st->rsq = rsq;
+        st->resid_sum = rsum;
+        st->cm = cm;
+        st->active_size = asz;
+        st->status = status;
+        st->n_updates = n_upd;
+        st->nz = nz;
+        if (p.nz_out) {
+            p.nz_out[0] = nz;
+            p.rsum_out[0] = rsum;
+        }
+        if (p.host_st && j == p.report_j) {
             CdBlkState<T> out;
             out.rsq = rsq; out.resid_sum = rsum; out.cm = cm; out.n_updates = n_upd;
             out.active_size = asz; out.status = status; out.nz = nz; out._pad = 0;

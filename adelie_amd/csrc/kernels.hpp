@@ -222,6 +222,11 @@ struct CdBlkParams {
     int64_t part_ld;
     int32_t part_n;
     const T* part_rsum; // nullptr: no intercept term
+    // dense form of the changes, for the one-round-trip prologue of the fused look-ahead launch (blk_solve_la_body): every
+    // solve of a look-ahead pass leaves  dd[i] = new - old  of its BLK coordinates (0 where nothing changed / beyond the block),
+    // the next one reads the previous block's through pdd and forms the correction as Cprev * pdd without index loads
+    const T* pdd;
+    T* dd;
     // one-coefficient constraints (blk_solve_body<.., CONS = true>): bounds per screen value (-inf / +inf where there is none)
     // and, out, the multiplier mu_+ - mu_- of every constrained coordinate the block visited
     const T* clo;

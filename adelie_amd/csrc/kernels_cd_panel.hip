@@ -18,6 +18,7 @@
 // Compared with keeping the full |S| x |S| Gram matrix current, the MFMA work drops from n|S|^2/2 to 128 n |S| MACs and
 // nothing has to be recomputed per IRLS iteration except the blocks that are actually visited.  The iterates are the
 // Gauss-Seidel sequence of the reference in exact arithmetic.
+#include <cstdlib>
 #include "kernels.hpp"
 #include "accessors.hpp"
 #include "wavered.hpp"
@@ -221,55 +222,61 @@ __global__ __launch_bounds__(PT, 4) void panel_step_kernel(Acc X, int64_t n, con
 // that the 160 KB LDS request of the solve (one workgroup per CU for everybody) costs the step nothing: 196 step
 // workgroups of 16 waves occupy the CUs exactly like 782 workgroups of 4 waves did.
 constexpr int FS = 4; // step slices per fused workgroup
+// LDS of a fused launch: the solve's request, which also makes every workgroup of the launch the only one on its CU (a step
+// slice needs 5 * 64 * VEC values)
+template <class T>
+constexpr size_t fused_lds() {
+    return blk_solve_lds_la<T>() > size_t(148) * 1024 ? blk_solve_lds_la<T>() : size_t(148) * 1024;
+}
 template <class T, class Acc, int VEC>
 __global__ __launch_bounds__(256 * FS) void panel_fused_kernel(CdBlkParams<T> sp, int j, Acc X, int64_t n,
                                                               const T* __restrict__ w, T* __restrict__ r,
                                                               const int32_t* __restrict__ dcol, const T* __restrict__ dlt,
                                                               const int32_t* __restrict__ nz_dev,
                                                               const int32_t* __restrict__ cols, int nb,
-                                                              T* __restrict__ part, int64_t part_ld) {
+                                                              T* __restrict__ part, int64_t part_ld, int reps) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int RS = 64 * VEC;
-    if (blockIdx.x == 0) {
-        static_assert(256 + BLK * NCORR == 256 * FS, "every thread of workgroup 0 has a role");
-        T* corr = reinterpret_cast<T*>(smem_raw + (blk_solve_lds_fused<T>() - size_t(NCORR + 8) * BLK * sizeof(T)));
-        T* gsum8 = corr + size_t(NCORR) * BLK;
-        // the block's gradient from the slice partials of the previous launch's step (when the solver asked for it): all
-        // 1024 threads, before they split into the solve and the correction helpers; complete at the barrier inside those
-        if (sp.part != nullptr) blk_part_sum<T>(sp, min(sp.bsz, sp.count - j * sp.bsz), gsum8, threadIdx.x);
-        if (threadIdx.x >= 256) blk_corr_helper<T>(sp, corr, threadIdx.x - 256);
-        else blk_solve_body<T, true>(sp, j, smem_raw, threadIdx.x, corr, NCORR, gsum8);
+    if (blockIdx.x == 0) { // the solve of block j: all 1024 threads fetch, one wavefront visits (blk_solve_la_body)
+        blk_solve_la_body<T>(sp, j, smem_raw, threadIdx.x);
         return;
     }
     const int sub = threadIdx.x >> 8, tid = threadIdx.x & 255;
-    const int64_t slice = (int64_t(blockIdx.x) - 1) * FS + sub;
     T* base = reinterpret_cast<T*>(smem_raw) + size_t(sub) * 5 * RS;
     T (*red)[RS] = reinterpret_cast<T (*)[RS]>(base);
     T* wrs = base + 4 * RS;
     const int nz = nz_dev[0];
     static_assert(RS >= PB || VEC == 1, "a slice's LDS row holds the block's column partials");
-    // all four slices of a workgroup take the same path (same number of barriers); slices past the end of the rows do
-    // nothing through the ragged path's predication
-    if constexpr (RS >= PB) {
-        if ((int64_t(blockIdx.x) * FS) * RS <= n)
-            panel_step_body<T, Acc, VEC, true, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
-        else
-            panel_step_body<T, Acc, VEC, false, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
-        if (nb <= 0) return; // uniform: the step bodies returned before phase (B) as well
-        __syncthreads();
-        // one partial per column for the whole workgroup: the four slices in a fixed order
-        if (threadIdx.x < nb) {
-            const T* b0 = reinterpret_cast<const T*>(smem_raw);
-            const int c = threadIdx.x;
-            // part_ld == 0: slice-major layout part[k * PB + c] (coalesced here and in the solve that sums the partials itself)
-            part[part_ld > 0 ? int64_t(c) * part_ld + (blockIdx.x - 1) : int64_t(blockIdx.x - 1) * PB + c] =
-                (b0[c] + b0[size_t(5) * RS + c]) + (b0[size_t(10) * RS + c] + b0[size_t(15) * RS + c]);
+    // `reps` > 1 (hook ADELIE_HIP_STEP_REPS): a workgroup takes `reps` consecutive groups of four slices one after the other,
+    // so that the launch occupies 1 / reps of the CUs it would otherwise claim whole
+    for (int rep = 0; rep < reps; ++rep) {
+        const int64_t grp = (int64_t(blockIdx.x) - 1) * reps + rep; // group of FS slices
+        if (grp >= ((n + RS - 1) / RS + FS - 1) / FS) break;      // (uniform for the workgroup)
+        const int64_t slice = grp * FS + sub;
+        if (rep > 0) __syncthreads();
+        // all four slices of a workgroup take the same path (same number of barriers); slices past the end of the rows do
+        // nothing through the ragged path's predication
+        if constexpr (RS >= PB) {
+            if ((grp + 1) * FS * RS <= n)
+                panel_step_body<T, Acc, VEC, true, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
+            else
+                panel_step_body<T, Acc, VEC, false, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
+            if (nb <= 0) continue; // uniform: the step bodies returned before phase (B) as well
+            __syncthreads();
+            // one partial per column for the whole workgroup: the four slices in a fixed order
+            if (threadIdx.x < nb) {
+                const T* b0 = reinterpret_cast<const T*>(smem_raw);
+                const int c = threadIdx.x;
+                // part_ld == 0: slice-major layout part[k * PB + c] (coalesced here and in the solve that sums the partials itself)
+                part[part_ld > 0 ? int64_t(c) * part_ld + grp : grp * PB + c] =
+                    (b0[c] + b0[size_t(5) * RS + c]) + (b0[size_t(10) * RS + c] + b0[size_t(15) * RS + c]);
+            }
+        } else {
+            if ((grp + 1) * FS * RS <= n)
+                panel_step_body<T, Acc, VEC, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
+            else
+                panel_step_body<T, Acc, VEC, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
         }
-    } else {
-        if ((int64_t(blockIdx.x) * FS) * RS <= n)
-            panel_step_body<T, Acc, VEC, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
-        else
-            panel_step_body<T, Acc, VEC, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
     }
 }
 
@@ -376,11 +383,17 @@ int fused_launch(const CdBlkParams<T>& sp, int j, const Acc& acc, int64_t n, con
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fused_kernel<T, Acc, VEC>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(blk_solve_lds_fused<T>()));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(fused_lds<T>()));
         attr_done = true;
     }
-    hipLaunchKernelGGL((panel_fused_kernel<T, Acc, VEC>), dim3((unsigned)(nwg + 1)), dim3(256 * FS), blk_solve_lds_fused<T>(), s, sp,
-                       j, acc, n, w, r, dcol, dlt, nz_dev, cols, nb, part, tr ? int64_t(0) : part_ld);
+    static const int reps = [] {
+        const char* e = std::getenv("ADELIE_HIP_STEP_REPS");
+        const int v = e ? std::atoi(e) : 1;
+        return v < 1 ? 1 : (v > 8 ? 8 : v);
+    }();
+    hipLaunchKernelGGL((panel_fused_kernel<T, Acc, VEC>), dim3((unsigned)((nwg + reps - 1) / reps + 1)), dim3(256 * FS),
+                       fused_lds<T>(), s, sp, j, acc, n, w, r, dcol, dlt, nz_dev, cols, nb, part,
+                       tr ? int64_t(0) : part_ld, reps);
     return int(part_ld);
 }
 

@@ -606,7 +606,24 @@ struct Solver {
         min_usable_version = v;
     }
     bool prebuild_enabled = true; // A/B hook ADELIE_HIP_PREBUILD=0
-    bool fuse_reduce = false;     // look-ahead passes: the solve sums the previous launch's slice partials itself instead of a panel_reduce launch (hook ADELIE_HIP_FUSE_REDUCE=1; measured slower: 3.08 vs 3.20 paths/s, the solve's longer prologue lengthens the fused launch by more than the reduce launch cost)
+    // look-ahead passes: the solve of a fused launch sums the previous launch's slice partials itself (second round trip of
+    // blk_solve_la_body's prologue) instead of a panel_reduce launch between every two fused launches.  Round 2 measured this
+    // slower (3.08 vs 3.20 paths/s) with the solve's old prologue; with the one-round-trip prologue the fused launch grows by
+    // 1 us and the reduce launch + its boundary go away: 290.3 -> 285.9 ms (f32: 178.1 -> 174.6).  Hook ADELIE_HIP_FUSE_REDUCE=0.
+    // Only while a column has at most 200 partials (n <= 102 400 rows in f64): beyond, one workgroup summing them is slower
+    // than the reduce launch.
+    bool fuse_reduce_opt = true;
+    bool fuse_reduce = false;     // (set per solve from fuse_reduce_opt and the partial count)
+    int fused_partials() const {  // partials per column a fused launch leaves (kernels_cd_panel.hip::fused_launch)
+        int vec = 4;
+        if (dense()) {
+            constexpr int V = int(16 / sizeof(T));
+            const bool vecok = (D->ld % V == 0) && ((reinterpret_cast<uintptr_t>(D->X) % 16) == 0);
+            vec = vecok ? V : 1;
+        }
+        const int64_t rs = 64 * vec, ns = (n + rs - 1) / rs, nwg = (ns + 3) / 4;
+        return int(vec * 64 >= 128 ? nwg : nwg * 4);
+    }
     DevBuf<T> d_part2;
     size_t part2_half = 0;
     int side_wgs = 0;             // >0: confine side-stream builds of Gaussian look-ahead passes to this many workgroups (hook ADELIE_HIP_SIDE_WGS; measured: 56 -> 2.69, 112 -> 2.99 vs 3.17 paths/s unconfined: the chain waits for the slower builds)
@@ -1725,7 +1742,7 @@ struct Solver {
                 xscr_key.assign(maxblk, XKey{});
                 xact_key.assign(maxblk, XKey{});
             }
-            d_la_dlt.reserve(size_t(2) * SL); d_la_g.reserve(size_t(2) * SL); d_la_rsum.reserve(2);
+            d_la_dlt.reserve(size_t(2) * SL); d_la_g.reserve(size_t(2) * SL); d_la_rsum.reserve(2); d_la_dd.reserve(size_t(2) * SL);
             d_la_dcol.reserve(size_t(2) * SL); d_la_dpos.reserve(size_t(2) * SL); d_la_nz.reserve(2);
             d_part.reserve(size_t(2 * panel_part_elems(n) + 2048));
             part2_half = size_t(panel_part_elems(n));
@@ -1794,6 +1811,8 @@ struct Solver {
                 bp.dpos = d_la_dpos.p + size_t(slot) * SL;
                 bp.nz_out = d_la_nz.p + slot;
                 bp.rsum_out = d_la_rsum.p + slot;
+                bp.pdd = d_la_dd.p + size_t(pslot) * SL;
+                bp.dd = d_la_dd.p + size_t(slot) * SL;
                 if (h_report && j == nblk - 1) {
                     bp.report_j = j;
                     bp.report_seq = ++report_seq;
@@ -1891,7 +1910,7 @@ struct Solver {
             // (a look-ahead pass may have run before: plain buffers for the solves, its pending changes for the first step)
             bp.gblk = d_gblk.p; bp.dlt = d_dlt.p; bp.dcol = d_dcolblk.p;
             bp.Cprev = nullptr; bp.dpos = nullptr; bp.nz_out = nullptr; bp.rsum_out = nullptr;
-            bp.part = nullptr;
+            bp.part = nullptr; bp.pdd = nullptr; bp.dd = nullptr;
             for (int j = 0; j < nblk; ++j) {
                 const int nb = std::min(B, count - j * B);
                 const int32_t* cols = cols_all + size_t(j) * B;
@@ -2145,7 +2164,7 @@ struct Solver {
                 xscr_key.assign(maxblk, XKey{});
                 xact_key.assign(maxblk, XKey{});
             }
-            d_la_dlt.reserve(size_t(2) * SL); d_la_g.reserve(size_t(2) * SL); d_la_rsum.reserve(2);
+            d_la_dlt.reserve(size_t(2) * SL); d_la_g.reserve(size_t(2) * SL); d_la_rsum.reserve(2); d_la_dd.reserve(size_t(2) * SL);
             d_la_dcol.reserve(size_t(2) * SL); d_la_dpos.reserve(size_t(2) * SL); d_la_nz.reserve(2);
             d_la_dd.reserve(size_t(2) * SL);
             d_part.reserve(size_t(2 * panel_part_elems(n) + 2048));
@@ -3306,7 +3325,8 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_LOOKAHEAD_MIN_BLOCKS")) la_min_blocks = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("ADELIE_HIP_PREBUILD")) prebuild_enabled = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_GROUP_ROT")) group_rot = std::atoi(e) != 0;
-        if (const char* e = std::getenv("ADELIE_HIP_FUSE_REDUCE")) fuse_reduce = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_FUSE_REDUCE")) fuse_reduce_opt = std::atoi(e) != 0;
+        fuse_reduce = fuse_reduce_opt && !multi() && fused_partials() <= 200;
         if (const char* e = std::getenv("ADELIE_HIP_SIDE_WGS")) side_wgs = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("ADELIE_HIP_SIDE_WGS_FROM")) side_wgs_from = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("ADELIE_HIP_BATCH_BLOCKS")) batch_blocks = std::max(1, std::min(int(SyrkBatch::MAX), std::atoi(e)));

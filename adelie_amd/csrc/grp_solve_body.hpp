@@ -148,7 +148,7 @@ __host__ __device__ constexpr size_t grp_solve_lds_total() {
 // eigenbasis column of every value — then rotates lane-parallel in LDS.  (The first version derived the layout in every solve
 // and gathered the correction through the changes' positions: ~28 dependent round trips, 17.5 of the launch's 52.9 us on
 // config 3, scripts/grp_profile.py.)
-template <class T>
+template <class T, bool FRP = false>
 __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, int j, char* smem_raw, int nt) {
 #ifdef AHIP_GRP_PROFILE
     const long long t_entry = __builtin_readcyclecounter();
@@ -186,14 +186,33 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
     const int ngrp = dsc[GDESC_NG], nval = dsc[GDESC_NVAL];
     const bool has_corr = p.Cprev != nullptr;
     const int pnv = has_corr ? dsc[GDESC_NVAL - GDESC_STRIDE] : 0; // values of the previous block = columns of Cprev
-    // (1)
-    int vm = 0, vg = 0, vs = 0, go = 0, gqv = 0, gs = 0;
+    // (1) layout descriptor, the gradient handed over (or nothing: has_part), the previous block's dense changes; the rotated
+    //     block and - fused launch, 1024 threads - the whole cross block, 16 values per thread, stream in meanwhile
+    const bool wide = nt == 1024;
+    const bool has_part = FRP && p.part != nullptr && wide; // (FRP: only the fused launch of kernels_cd_panel.hip compiles this in)
+    int vm = 0, vg = 0, go = 0, gqv = 0, gs = 0, vof = 0, vps = 0, vq = 1;
     T gb = T(0), dlv = T(0);
     if (tid < GBLK) {
-        vm = dsc[GDESC_VMAP + tid]; vg = dsc[GDESC_VGRP + tid]; vs = dsc[GDESC_VSS + tid];
+        vm = dsc[GDESC_VMAP + tid]; vg = dsc[GDESC_VGRP + tid];
         go = dsc[GDESC_GOFF + tid]; gqv = dsc[GDESC_GQ + tid]; gs = dsc[GDESC_GSS + tid];
-        gb = p.gblk[tid];
+        vof = dsc[GDESC_VOFF + tid]; vps = dsc[GDESC_VPOS + tid]; vq = dsc[GDESC_VQ + tid];
+        if (!has_part) gb = p.gblk[tid];
         if (has_corr) dlv = p.pdd[tid];
+    }
+    const T prs = (has_part && p.part_rsum) ? p.part_rsum[0] : T(0);
+    // fused launch (1024 threads): the whole cross block, 16 values per thread (row tid % 128, columns 16 * part + u, part =
+    // tid / 128 uniform per wavefront), against the previous block's dense changes read as scalars: the partial sums are
+    // formed as the values arrive, no LDS staging and no barrier in between
+    constexpr int CW = 16;
+    T creg[CW];
+    T dls[CW];
+    const int part_u = __builtin_amdgcn_readfirstlane(tid >> 7);
+    if (wide && has_corr) {
+        const T* Cp = p.Cprev + (tid & (GBLK - 1)) + size_t(part_u) * CW * GBLK;
+#pragma unroll
+        for (int u = 0; u < CW; ++u) creg[u] = Cp[size_t(u) * GBLK];
+#pragma unroll
+        for (int u = 0; u < CW; ++u) dls[u] = p.pdd[part_u * CW + u];
     }
     {   // D~: columns [0, nval)
         const T* src = p.Dptr;
@@ -207,51 +226,74 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
                 if (e0 + u * nt < NE) D[e0 + u * nt] = v[u];
         }
     }
+    if (wide && has_corr) {
+        T acc = T(0);
+#pragma unroll
+        for (int u = 0; u < CW; ++u)
+            if (part_u * CW + u < pnv) acc = fma(creg[u], dls[u], acc);
+        corr[part_u * GBLK + (tid & (GBLK - 1))] = acc;
+    }
     if (tid < GBLK) {
         vmap[tid] = vm; vgrp[tid] = vg; goff[tid] = go; gq[tid] = gqv; gss[tid] = gs;
         if (tid == 0) goff[GBLK] = dsc[GDESC_GOFF + GBLK];
         dl[tid] = dlv;
-        gO[tid] = tid < nval ? gb : T(0);
+        if (!has_part) gO[tid] = tid < nval ? gb : T(0);
     }
-    // (2)
+    // (2) per-value / per-group constants and the eigenbasis column of every value through the descriptor's indices; the
+    //     slice partials of the block's gradient when the reduction is fused into this launch: eight adjacent lanes per column,
+    //     k = k0, k0 + 8, ... each, combined by a fixed shuffle tree
     T b0v = T(0), Av = T(0), xmv = T(0);
-    int64_t vo = 0;
-    if (tid < nval) {
-        b0v = p.beta[vm]; Av = p.vars[vm]; xmv = p.xmean[vm];
-        vo = p.voff[vs];
-    }
+    if (tid < nval) { b0v = p.beta[vm]; Av = p.vars[vm]; xmv = p.xmean[vm]; }
     T penv = T(0);
     int actv = 0;
     if (tid < ngrp) { penv = p.spen[gs]; actv = p.is_active[gs]; }
-    __syncthreads(); // dl, the tables
+    constexpr int QM = 16;
+    T vcol_r[QM];
+    const int o_v = tid - vps, q_v = vq;
+    auto load_vcol = [&]() {
+        if (tid < nval && q_v > 1 && q_v <= QM) {
+            const T* Vt = p.V + int64_t(vof) + int64_t(vps) * q_v;
+#pragma unroll
+            for (int u = 0; u < QM; ++u) vcol_r[u] = u < q_v ? Vt[u] : T(0);
+        }
+    };
+    if (!has_part) load_vcol();
+    if (has_part) {
+        constexpr int PBN = 25;
+        const int c = tid >> 3, k0 = tid & 7;
+        const T* pc = p.part + c;
+        T pw[PBN];
+#pragma unroll
+        for (int u = 0; u < PBN; ++u) pw[u] = pc[int64_t(min(k0 + 8 * u, p.part_n - 1)) * GBLK];
+        T ps = T(0);
+#pragma unroll
+        for (int u = 0; u < PBN; ++u) ps += (k0 + 8 * u < p.part_n) ? pw[u] : T(0);
+        for (int k = k0 + 8 * PBN; k < p.part_n; k += 8) ps += pc[int64_t(k) * GBLK];
+        ps += __shfl_xor(ps, 1, 64);
+        ps += __shfl_xor(ps, 2, 64);
+        ps += __shfl_xor(ps, 4, 64);
+        if (k0 == 0) gO[c] = c < nval ? ps : T(0);
+        load_vcol(); // (behind the partials: the register budget of the 1024-thread workgroup; lands during the barriers below)
+    }
+    __syncthreads(); // dl, the tables, gO
     // look-ahead correction in original coordinates: corr = Cprev[:, 0:pnv] dl[0:pnv], the columns split over nt / GBLK parts
     const int nparts = nt / GBLK;
     if (has_corr) {
         const int row = tid & (GBLK - 1), part = tid / GBLK;
-        const int per = (pnv + nparts - 1) / nparts;
-        const int c0 = part * per, c1 = min(pnv, c0 + per);
-        const T* Cp = p.Cprev + row;
         T acc = T(0);
-        for (int c = c0; c < c1; c += 16) {
-            T cv[16];
+        if (!wide) {
+            const int per = (pnv + nparts - 1) / nparts;
+            const int c0 = part * per, c1 = min(pnv, c0 + per);
+            const T* Cp = p.Cprev + row;
+            for (int c = c0; c < c1; c += 16) {
+                T cv[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) cv[u] = Cp[size_t(min(c + u, c1 - 1)) * GBLK];
+                for (int u = 0; u < 16; ++u) cv[u] = Cp[size_t(min(c + u, c1 - 1)) * GBLK];
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (c + u < c1) acc = fma(cv[u], dl[c + u], acc);
-        }
-        corr[part * GBLK + row] = acc;
-    }
-    // (3) the eigenbasis column of this thread's value (groups of up to 16 values: one batch of loads)
-    constexpr int QM = 16;
-    T vcol_r[QM];
-    int o_v = 0, q_v = 1;
-    if (tid < nval) {
-        o_v = goff[vg]; q_v = gq[vg];
-        if (q_v > 1 && q_v <= QM) {
-            const T* Vt = p.V + vo + int64_t(tid - o_v) * q_v;
-#pragma unroll
-            for (int u = 0; u < QM; ++u) vcol_r[u] = u < q_v ? Vt[u] : T(0);
+                for (int u = 0; u < 16; ++u)
+                    if (c + u < c1) acc = fma(cv[u], dl[c + u], acc);
+            }
+            corr[part * GBLK + row] = acc;
         }
     }
     if (tid < GBLK) {
@@ -260,10 +302,11 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
         if (tid < ngrp) { gpenB[tid] = penv; gactB[tid] = actv; chg[tid] = 0; }
     }
     __syncthreads(); // corr parts, b0B / xmO
-    if (has_corr && tid < nval) {
+    if (tid < nval && (has_corr || has_part)) {
         T cs = T(0);
-        for (int q = 0; q < nparts; ++q) cs += corr[q * GBLK + tid]; // fixed order
-        gO[tid] -= cs;
+        if (has_corr)
+            for (int q = 0; q < nparts; ++q) cs += corr[q * GBLK + tid]; // fixed order
+        gO[tid] = (has_part ? gO[tid] - prs * xmO[tid] : gO[tid]) - cs;
     }
     __syncthreads();
     // every value into the eigenbasis of its group: (g V)_t, (beta V)_t, (xbar V)_t   (pin_naive:123-135)
@@ -283,7 +326,7 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             }
             gT[i] = s1; bT[i] = s2; xmT[i] = s3;
         } else {
-            const T* Vt = p.V + vo + int64_t(i - o) * q;
+            const T* Vt = p.V + int64_t(vof) + int64_t(i - o) * q;
             T s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll 4
             for (int u = 0; u < q; ++u) {
@@ -619,11 +662,11 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
 #undef RP_MARK
 
 // nt: threads of the workgroup that call (>= 256, a multiple of 128); only the rotated form uses more than the first 256
-template <class T, bool NAIVE>
+template <class T, bool NAIVE, bool FRP = false>
 __device__ __forceinline__ void grp_solve_body(const CdGrpBlkParams<T>& p, int j, char* smem_raw, int nt = 256) {
     if constexpr (NAIVE) {
         if (p.rot) { // uniform over the workgroup
-            grp_solve_body_rot<T>(p, j, smem_raw, nt);
+            grp_solve_body_rot<T, FRP>(p, j, smem_raw, nt);
             return;
         }
     }

@@ -288,6 +288,12 @@ struct CdGrpBlkParams {
     const int32_t* desc;
     const T* pdd;
     T* dd;
+    // fused look-ahead launch, rot != 0: the block's gradient is still in the slice partials the previous launch's step left
+    // (slice-major, part[k * 128 + c], k < part_n) and the solve sums them itself in the second round trip of its prologue,
+    // in a fixed order, then applies the intercept term  - part_rsum[0] * xbar  (as CdBlkParams::part)
+    const T* part;
+    int32_t part_n;
+    const T* part_rsum;
     // one-coefficient constraints of groups of size one (see CdBlkParams): per screen value, +-inf where there is none
     const T* clo;
     const T* chi;
@@ -300,7 +306,11 @@ constexpr int GDESC_VSS = 256;   // [128] screen-group index of value i
 constexpr int GDESC_GOFF = 384;  // [129] first value of group k; [ng] = nval
 constexpr int GDESC_GQ = 520;    // [128] size of group k
 constexpr int GDESC_GSS = 648;   // [128] screen-group index of group k
-constexpr int GDESC_NG = 776, GDESC_NVAL = 777, GDESC_STRIDE = 784;
+constexpr int GDESC_NG = 776, GDESC_NVAL = 777;
+constexpr int GDESC_VOFF = 784;  // [128] offset of the eigenbasis of value i's group in CdGrpBlkParams::V
+constexpr int GDESC_VPOS = 912;  // [128] position of value i inside its group
+constexpr int GDESC_VQ = 1040;   // [128] size of value i's group
+constexpr int GDESC_STRIDE = 1168;
 // descriptors of blocks 0..nblk-1 of the pass described by p (blk_g0, list, sbegin, ssize) into desc
 template <class T> void launch_grp_layout(const CdGrpBlkParams<T>& p, int nblk, int32_t* desc, hipStream_t s);
 // D <- R^T D R for one 128 x 128 slot (ld 128): `ng` groups, group k = block values [goff[k], goff[k+1]) with eigenbasis
@@ -347,11 +357,11 @@ int launch_panel_fused_snp(const CdBlkParams<T>& sp, int j, const SnpView& X, co
                            bool tr, hipStream_t s);
 template <class T>
 int launch_panel_fused_grp(const CdGrpBlkParams<T>& sp, int j, const DenseView<T>& X, const T* w, T* r, const int32_t* dcol,
-                           const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s);
+                           const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, bool tr, hipStream_t s);
 template <class T>
 int launch_panel_fused_grp_snp(const CdGrpBlkParams<T>& sp, int j, const SnpView& X, const T* impute, const T* w, T* r,
                                const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb,
-                               T* part, hipStream_t s);
+                               T* part, bool tr, hipStream_t s);
 // the visits of block j of the pass (one workgroup); p.gblk / p.Dptr / p.vcol / p.dcol must be set
 template <class T> void launch_cd_panel_solve(const CdBlkParams<T>& p, int j, hipStream_t s);
 template <class T> void launch_center_vars(T* vars, const T* xm, int cnt, bool center, hipStream_t s);

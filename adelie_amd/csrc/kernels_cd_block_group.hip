@@ -115,13 +115,20 @@ __global__ __launch_bounds__(GBLK) void grp_layout_kernel(CdGrpBlkParams<T> p, i
     d[GDESC_GSS + tid] = gss_[tid];
     if (tid < ng) {
         const int o = goff_[tid];
+        const int32_t vo = q > 1 ? int32_t(p.voff[ss]) : 0;
         for (int t = 0; t < q; ++t) {
             d[GDESC_VMAP + o + t] = b + t;
             d[GDESC_VGRP + o + t] = tid;
             d[GDESC_VSS + o + t] = ss;
+            d[GDESC_VOFF + o + t] = vo;
+            d[GDESC_VPOS + o + t] = t;
+            d[GDESC_VQ + o + t] = q;
         }
     }
-    if (tid >= nval) { d[GDESC_VMAP + tid] = 0; d[GDESC_VGRP + tid] = 0; d[GDESC_VSS + tid] = 0; }
+    if (tid >= nval) {
+        d[GDESC_VMAP + tid] = 0; d[GDESC_VGRP + tid] = 0; d[GDESC_VSS + tid] = 0;
+        d[GDESC_VOFF + tid] = 0; d[GDESC_VPOS + tid] = 0; d[GDESC_VQ + tid] = 1;
+    }
 }
 
 template <class T>

@@ -228,19 +228,17 @@ template <class T>
 constexpr size_t fused_lds() {
     return blk_solve_lds_la<T>() > size_t(148) * 1024 ? blk_solve_lds_la<T>() : size_t(148) * 1024;
 }
+// The step part of a fused launch, workgroups 1.. (1024 threads = four 256-thread slices each): phase (A) with the changes of
+// the previous block, phase (B) partial gradients of the next one; the four slices of a workgroup are summed in LDS and ONE
+// partial per column and workgroup goes out (column-major part[c * part_ld + g], or slice-major part[g * 128 + c] when
+// part_ld == 0: for a solve that sums the partials itself).
 template <class T, class Acc, int VEC>
-__global__ __launch_bounds__(256 * FS) void panel_fused_kernel(CdBlkParams<T> sp, int j, Acc X, int64_t n,
-                                                              const T* __restrict__ w, T* __restrict__ r,
-                                                              const int32_t* __restrict__ dcol, const T* __restrict__ dlt,
-                                                              const int32_t* __restrict__ nz_dev,
-                                                              const int32_t* __restrict__ cols, int nb,
-                                                              T* __restrict__ part, int64_t part_ld, int reps) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+__device__ __forceinline__ void fused_step_part(char* smem_raw, const Acc& X, int64_t n, const T* __restrict__ w,
+                                                T* __restrict__ r, const int32_t* __restrict__ dcol,
+                                                const T* __restrict__ dlt, const int32_t* __restrict__ nz_dev,
+                                                const int32_t* __restrict__ cols, int nb, T* __restrict__ part,
+                                                int64_t part_ld, int reps) {
     constexpr int RS = 64 * VEC;
-    if (blockIdx.x == 0) { // the solve of block j: all 1024 threads fetch, one wavefront visits (blk_solve_la_body)
-        blk_solve_la_body<T>(sp, j, smem_raw, threadIdx.x);
-        return;
-    }
     const int sub = threadIdx.x >> 8, tid = threadIdx.x & 255;
     T* base = reinterpret_cast<T*>(smem_raw) + size_t(sub) * 5 * RS;
     T (*red)[RS] = reinterpret_cast<T (*)[RS]>(base);
@@ -278,6 +276,22 @@ __global__ __launch_bounds__(256 * FS) void panel_fused_kernel(CdBlkParams<T> sp
                 panel_step_body<T, Acc, VEC, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
         }
     }
+}
+
+template <class T, class Acc, int VEC>
+__global__ __launch_bounds__(256 * FS) void panel_fused_kernel(CdBlkParams<T> sp, int j, Acc X, int64_t n,
+                                                              const T* __restrict__ w, T* __restrict__ r,
+                                                              const int32_t* __restrict__ dcol, const T* __restrict__ dlt,
+                                                              const int32_t* __restrict__ nz_dev,
+                                                              const int32_t* __restrict__ cols, int nb,
+                                                              T* __restrict__ part, int64_t part_ld, int reps) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int RS = 64 * VEC;
+    if (blockIdx.x == 0) { // the solve of block j: all 1024 threads fetch, one wavefront visits (blk_solve_la_body)
+        blk_solve_la_body<T>(sp, j, smem_raw, threadIdx.x);
+        return;
+    }
+    fused_step_part<T, Acc, VEC>(smem_raw, X, n, w, r, dcol, dlt, nz_dev, cols, nb, part, part_ld, reps);
 }
 
 template <class T>
@@ -338,28 +352,19 @@ __global__ __launch_bounds__(256 * FS) void panel_fused_grp_kernel(CdGrpBlkParam
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int RS = 64 * VEC;
     if (blockIdx.x == 0) { // all 256 * FS threads: the rotated solve spreads its prologue's loads over them
-        grp_solve_body<T, true>(sp, j, smem_raw, 256 * FS);
+        grp_solve_body<T, true, true>(sp, j, smem_raw, 256 * FS);
         return;
     }
-    const int sub = threadIdx.x >> 8, tid = threadIdx.x & 255;
-    const int64_t slice = (int64_t(blockIdx.x) - 1) * FS + sub;
-    T* base = reinterpret_cast<T*>(smem_raw) + size_t(sub) * 5 * RS;
-    T (*red)[RS] = reinterpret_cast<T (*)[RS]>(base);
-    T* wrs = base + 4 * RS;
-    const int nz = nz_dev[0];
-    if ((int64_t(blockIdx.x) * FS) * RS <= n)
-        panel_step_body<T, Acc, VEC, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
-    else
-        panel_step_body<T, Acc, VEC, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
+    fused_step_part<T, Acc, VEC>(smem_raw, X, n, w, r, dcol, dlt, nz_dev, cols, nb, part, part_ld, 1);
 }
 
 template <class T, class Acc, int VEC>
 int fused_grp_launch(const CdGrpBlkParams<T>& sp, int j, const Acc& acc, int64_t n, const T* w, T* r, const int32_t* dcol,
-                     const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s) {
+                     const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, bool tr, hipStream_t s) {
     constexpr int RS = 64 * VEC;
     const int64_t ns = (n + RS - 1) / RS;
     const int64_t nwg = (ns + FS - 1) / FS;
-    const int64_t part_ld = nwg * FS;
+    const int64_t part_ld = (64 * VEC >= PB) ? nwg : nwg * FS; // (one partial per column and workgroup, as fused_launch)
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fused_grp_kernel<T, Acc, VEC>),
@@ -367,7 +372,8 @@ int fused_grp_launch(const CdGrpBlkParams<T>& sp, int j, const Acc& acc, int64_t
         attr_done = true;
     }
     hipLaunchKernelGGL((panel_fused_grp_kernel<T, Acc, VEC>), dim3((unsigned)(nwg + 1)), dim3(256 * FS),
-                       grp_solve_lds_total<T>(), s, sp, j, acc, n, w, r, dcol, dlt, nz_dev, cols, nb, part, part_ld);
+                       grp_solve_lds_total<T>(), s, sp, j, acc, n, w, r, dcol, dlt, nz_dev, cols, nb, part,
+                       tr ? int64_t(0) : part_ld);
     return int(part_ld);
 }
 
@@ -418,19 +424,19 @@ int launch_panel_fused_snp(const CdBlkParams<T>& sp, int j, const SnpView& X, co
 
 template <class T>
 int launch_panel_fused_grp(const CdGrpBlkParams<T>& sp, int j, const DenseView<T>& X, const T* w, T* r, const int32_t* dcol,
-                           const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s) {
+                           const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, bool tr, hipStream_t s) {
     DenseAcc<T> acc{X.X, X.ld};
     constexpr int V = VecOf<T>::N;
     const bool vecok = (X.ld % V == 0) && ((reinterpret_cast<uintptr_t>(X.X) % 16) == 0);
-    if (vecok) return fused_grp_launch<T, DenseAcc<T>, V>(sp, j, acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
-    return fused_grp_launch<T, DenseAcc<T>, 1>(sp, j, acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
+    if (vecok) return fused_grp_launch<T, DenseAcc<T>, V>(sp, j, acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, tr, s);
+    return fused_grp_launch<T, DenseAcc<T>, 1>(sp, j, acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, tr, s);
 }
 template <class T>
 int launch_panel_fused_grp_snp(const CdGrpBlkParams<T>& sp, int j, const SnpView& X, const T* impute, const T* w, T* r,
                                const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb,
-                               T* part, hipStream_t s) {
+                               T* part, bool tr, hipStream_t s) {
     SnpAcc<T> acc{X.bits, X.ldb, impute};
-    return fused_grp_launch<T, SnpAcc<T>, 4>(sp, j, acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
+    return fused_grp_launch<T, SnpAcc<T>, 4>(sp, j, acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, tr, s);
 }
 
 int64_t panel_part_elems(int64_t n) { return int64_t(PB) * ((n + 63) / 64) + 16; }
@@ -487,10 +493,10 @@ void launch_gather_i32(const int32_t* src, const int32_t* idx, int cnt, int32_t*
     template int launch_panel_fused<T>(const CdBlkParams<T>&, int, const DenseView<T>&, const T*, T*, const int32_t*,  \
                                        const T*, const int32_t*, const int32_t*, int, T*, bool, hipStream_t);          \
     template int launch_panel_fused_grp<T>(const CdGrpBlkParams<T>&, int, const DenseView<T>&, const T*, T*,           \
-                                           const int32_t*, const T*, const int32_t*, const int32_t*, int, T*,          \
+                                           const int32_t*, const T*, const int32_t*, const int32_t*, int, T*, bool,    \
                                            hipStream_t);                                                               \
     template int launch_panel_fused_grp_snp<T>(const CdGrpBlkParams<T>&, int, const SnpView&, const T*, const T*, T*,  \
-                                               const int32_t*, const T*, const int32_t*, const int32_t*, int, T*,      \
+                                               const int32_t*, const T*, const int32_t*, const int32_t*, int, T*, bool,\
                                                hipStream_t);                                                           \
     template int launch_panel_fused_snp<T>(const CdBlkParams<T>&, int, const SnpView&, const T*, const T*, T*,         \
                                            const int32_t*, const T*, const int32_t*, const int32_t*, int, T*, bool,    \

@@ -2168,8 +2168,16 @@ struct Solver {
             d_la_dcol.reserve(size_t(2) * SL); d_la_dpos.reserve(size_t(2) * SL); d_la_nz.reserve(2);
             d_la_dd.reserve(size_t(2) * SL);
             d_part.reserve(size_t(2 * panel_part_elems(n) + 2048));
+            part2_half = size_t(panel_part_elems(n));
+            d_part2.reserve(2 * part2_half);
             if (mode != 2) pending_slot = -1;
         }
+        // The group solve can sum the slice partials itself as the lasso solve does (fuse_reduce), in its eigen-coordinate form on
+        // single-response designs - but a group launch is bound by its solve (Newton root finds: 43 us against a 34 us step), so
+        // the extra round trip of the prologue lands on the chain: config 3 722.7 ms with, 654.1 ms without (hook
+        // ADELIE_HIP_GRP_FUSE_REDUCE=1).  Off.
+        static const bool grp_fr_opt = std::getenv("ADELIE_HIP_GRP_FUSE_REDUCE") && std::atoi(std::getenv("ADELIE_HIP_GRP_FUSE_REDUCE")) != 0;
+        const bool fr_grp = grp_fr_opt && fuse_reduce && bp.rot && !multi();
         bool no_wait = false;
         d_gdesc.reserve(maxblk * size_t(GDESC_STRIDE));
         auto pass_la = [&](bool screen_pass) -> T {
@@ -2200,13 +2208,10 @@ struct Solver {
             if (bp.rot) launch_grp_layout<T>(bp, nblk, d_gdesc.p, st);
             auto nb_of = [&](int j) { return int(gp_vbeg[size_t(j) + 1] - gp_vbeg[j]); };
             auto cols_of = [&](int j) { return cols_all + gp_vbeg[j]; };
-            rot_on = group_rot;
-            rot_list = screen_pass ? nullptr : act_host.data();
-            build_stale_blocks(nblk, tab_nb, tab_ver, pool, nb_of, cols_of);
-            rot_on = false;
-            build_stale_cross(nblk, screen_pass ? xscr_key : xact_key, xpool, nb_of, cols_of);
+            record_pass_e0();
             t_cd.begin(st);
-            {   // first step of the pass: pending changes of the previous pass's last block; blocks 0 and 1 prepared
+            {   // first step of the pass: pending changes of the previous pass's last block; blocks 0 and 1 prepared.  Enqueued
+                // before the block builds (it does not depend on them, see record_pass_e0)
                 const int nv0 = nb_of(0), nv1 = nblk > 1 ? nb_of(1) : 0;
                 const int ps = pending_slot;
                 if (time_panel) t_step.begin(st);
@@ -2220,6 +2225,13 @@ struct Solver {
                                            xm_c, d_la_g.p + SL, st);
                 cnt.n_panel_cols += nv0 + nv1;
             }
+            rot_on = group_rot;
+            rot_list = screen_pass ? nullptr : act_host.data();
+            build_stale_blocks(nblk, tab_nb, tab_ver, pool, nb_of, cols_of);
+            rot_on = false;
+            build_stale_cross(nblk, screen_pass ? xscr_key : xact_key, xpool, nb_of, cols_of);
+            pass_e0_valid = false;
+            int prev_ld = 0; // partials of block j left behind by the previous fused launch (fr_grp), see run_panel_passes
             for (int j = 0; j < nblk; ++j) {
                 const int slot = j & 1, pslot = slot ^ 1;
                 bp.gblk = d_la_g.p + size_t(slot) * SL;
@@ -2235,6 +2247,10 @@ struct Solver {
                 bp.rsum_out = d_la_rsum.p + slot;
                 bp.pdd = d_la_dd.p + size_t(pslot) * SL;
                 bp.dd = d_la_dd.p + size_t(slot) * SL;
+                bp.part = (fr_grp && prev_ld > 0) ? d_part2.p + size_t((j - 1) & 1) * part2_half : nullptr;
+                bp.part_n = prev_ld;
+                bp.part_rsum = xm_c ? d_la_rsum.p + slot : nullptr;
+                prev_ld = 0;
                 if (h_report && j == nblk - 1) {
                     bp.report_j = j;
                     bp.report_seq = ++report_seq;
@@ -2256,15 +2272,19 @@ struct Solver {
                                                      d_la_dlt.p + size_t(pslot) * SL, d_la_nz.p + pslot, cols_n, nbn, d_part.p, st);
                 else if (dense())
                     ld = launch_panel_fused_grp<T>(bp, j, D->dense<T>(), cur_w, r_dev, d_la_dcol.p + size_t(pslot) * SL,
-                                                   d_la_dlt.p + size_t(pslot) * SL, d_la_nz.p + pslot, cols_n, nbn, d_part.p, st);
+                                                   d_la_dlt.p + size_t(pslot) * SL, d_la_nz.p + pslot, cols_n, nbn,
+                                                   fr_grp ? d_part2.p + size_t(j & 1) * part2_half : d_part.p, fr_grp, st);
                 else
                     ld = launch_panel_fused_grp_snp<T>(bp, j, D->snp(), static_cast<const T*>(D->impute), cur_w, r_dev,
                                                        d_la_dcol.p + size_t(pslot) * SL, d_la_dlt.p + size_t(pslot) * SL,
-                                                       d_la_nz.p + pslot, cols_n, nbn, d_part.p, st);
+                                                       d_la_nz.p + pslot, cols_n, nbn,
+                                                       fr_grp ? d_part2.p + size_t(j & 1) * part2_half : d_part.p, fr_grp, st);
                 if (time_panel) t_step.end(st);
                 if (nbn > 0) {
-                    launch_panel_reduce_ld<T>(d_part.p, ld, ld, nbn, cols_n, d_la_rsum.p + pslot, xm_c,
-                                              d_la_g.p + size_t(pslot) * SL, st);
+                    if (fr_grp) prev_ld = ld; // summed by the next solve
+                    else
+                        launch_panel_reduce_ld<T>(d_part.p, ld, ld, nbn, cols_n, d_la_rsum.p + pslot, xm_c,
+                                                  d_la_g.p + size_t(pslot) * SL, st);
                     cnt.n_panel_cols += nbn;
                 }
             }

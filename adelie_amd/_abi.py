@@ -24,6 +24,20 @@ GLM_HESSIAN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_vo
 GLM_LOSS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double))
 
 
+CONS_SOLVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                           C.POINTER(C.c_double), C.c_double, C.c_double, C.POINTER(C.c_double))
+CONS_GRADIENT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double))
+CONS_SOLVE_ZERO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double))
+CONS_DUAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_double))
+
+
+class ConstraintCallbacks(C.Structure):
+    """``adelie_hip_constraint_callbacks``."""
+
+    _fields_ = [("user", C.c_void_p), ("solve", CONS_SOLVE_FN), ("gradient", CONS_GRADIENT_FN),
+                ("solve_zero", CONS_SOLVE_ZERO_FN), ("dual", CONS_DUAL_FN)]
+
+
 class GlmCallbacks(C.Structure):
     """``adelie_hip_glm_callbacks``."""
 
@@ -99,6 +113,12 @@ class GrpnetArgs(C.Structure):
         ("constraint_a", C.c_void_p),
         ("constraint_b", C.c_void_p),
         ("constraint_mu", C.c_void_p),
+        ("constraint_duals", C.c_void_p),
+        ("constraint_cb", C.POINTER(ConstraintCallbacks)),
+        ("constraint_native", C.c_void_p),
+        ("constraint_va", C.c_void_p),
+        ("constraint_vb", C.c_void_p),
+        ("constraint_cfg", C.c_void_p),
     ]
 
 
@@ -154,7 +174,7 @@ def dtype_code(dtype):
 
 
 # kept equal to ADELIE_HIP_ABI_VERSION in include/adelie_hip.h (tests/test_abi.py compares the two)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Backend:

@@ -1,14 +1,19 @@
 """Per-group constraints — the host-side mirror of reference ``adelie/constraint.py`` (``box`` :18-135, ``lower`` :309-338,
-``one_sided`` :341-480, ``upper`` :483-511) for the part of ``adelie_core/constraint/*`` that ``grpnet`` runs on the device:
-box and one-sided constraints on groups of ONE coefficient, where both classes have closed forms
-(``constraint_box.ipp:51-96``, ``constraint_one_sided.ipp:12-49``).
+``one_sided`` :341-480, ``upper`` :483-511) and of ``adelie_core/constraint/*``.
 
-The objects are descriptors: ``grpnet`` hands their bounds to the solver through the C ABI (``constraint_kind / _a / _b`` of
-``adelie_hip_grpnet_args``) and the coordinate updates, the multipliers, ``abs_grad`` and the ``duals`` of the state are
-computed on the GPU.  After a solve every object holds the multiplier of the last fit (``dual`` / ``duals_nnz``), as the
-reference's objects do.  The elementwise members (``gradient``, ``project``, ``evaluate``, ``solve_zero``) work for any size;
-``solve`` is the one-coefficient closed form.  Constraints over groups of several coefficients (the proximal-Newton / ADMM
-solvers of the reference) and ``linear`` constraints are not implemented: ``grpnet`` raises for them.
+Two routes into the solver (``adelie_hip_grpnet_args::constraint_kind``):
+
+* box / one-sided constraints on groups of ONE coefficient have closed forms (``constraint_box.ipp:51-96``,
+  ``constraint_one_sided.ipp:12-49``): their bounds travel through the C ABI and the clipped coordinate update, the multipliers,
+  ``abs_grad`` and the ``duals`` of the state are computed on the GPU;
+* every other object — box / one-sided on groups of several coefficients (the reference's proximal-Newton dual solver,
+  ``constraint/utils.hpp:24-243``, restated below in numpy), and any user subclass of :class:`ConstraintBase` — is visited on
+  the host: the solver hands the group's quadratic model (``quad``, ``linear``, eigenbasis ``Q``) to ``solve`` between two
+  panel steps and asks ``gradient`` / ``solve_zero`` / ``dual`` when it updates ``abs_grad`` and the duals, through the
+  callbacks of ``adelie_hip_constraint_callbacks`` — the role the reference's ``PyConstraintBase`` trampoline plays.
+
+After a solve every object holds the multipliers of the last fit (``dual`` / ``duals_nnz``), as the reference's objects do.
+``linear`` constraints are not implemented.
 """
 from typing import Union
 
@@ -16,7 +21,34 @@ import numpy as np
 
 MAX_SOLVER_VALUE = 1e100  # Configs.max_solver_value (configs.hpp:13)
 
-KIND_BOX, KIND_ONE_SIDED = 1, 2
+KIND_BOX, KIND_ONE_SIDED, KIND_HOST = 1, 2, 3
+NATIVE_BOX, NATIVE_ONE_SIDED = 4, 5  # adelie_hip_grpnet_args::constraint_native (read by the CPU checker only)
+
+_PROX_NEWTON_DEFAULTS = {"max_iters": 100, "tol": 1e-9, "pinball_max_iters": int(1e5), "pinball_tol": 1e-7, "slack": 1e-4}
+
+
+def _group_prox(quad, v, l1, l2, tol=1e-12, max_iters=100000):
+    """Minimiser of ``1/2 x' diag(quad) x - v' x + l1 |x|_2 + l2/2 |x|_2^2`` (the unconstrained group update,
+    ``bcd/unconstrained/newton.hpp:35-142``): Newton on ``h = |x|`` from ``h = 0``.  Returns ``x`` and the two vectors the
+    dual Hessian below is built from, ``quad + l2`` and ``1 / ((quad + l2) h + l1)``."""
+    b1 = quad + l2
+    if np.linalg.norm(v) <= l1:
+        return np.zeros_like(v), b1, 1.0 / np.maximum(l1, np.finfo(float).tiny) * np.ones_like(v)
+    if l1 <= 0:
+        x = v / b1
+        return x, b1, 1.0 / (b1 * np.linalg.norm(x))
+    h = 0.0
+    for _ in range(max_iters + 1):
+        b2 = 1.0 / (b1 * h + l1)
+        z = np.square(v * b2)
+        t = z.sum()
+        f = t - 1.0
+        if abs(f) <= tol:
+            break
+        df = -(z * b1 * b2).sum() * (1 + np.sqrt(t)) / t
+        h = max(h - f / df, 0.0)
+    b2 = 1.0 / (b1 * h + l1)
+    return h * v * b2, b1, b2
 
 
 def _coerce(x, dtype):
@@ -59,24 +91,165 @@ class ConstraintBase:
         indices[: len(nz)] = nz
         values[: len(nz)] = self._mu[nz]
 
-    # ABI descriptor of a one-coefficient constraint: (kind, a, b)
+    # ABI descriptor (kind, a, b): the one-coefficient closed forms override this; everything else is a host object
     def _abi(self):
+        return KIND_HOST, 0.0, 0.0
+
+    # (native code, per-coefficient a, per-coefficient b, settings) for the CPU checker's own restatement, or None
+    def _native(self):
+        return None
+
+    def solve(self, x, quad, linear, l1, l2, Q, buffer=None):
+        raise NotImplementedError("a constraint class must provide solve(x, quad, linear, l1, l2, Q).")
+
+    def gradient(self, x, *args):
+        raise NotImplementedError("a constraint class must provide gradient(x, out).")
+
+    def solve_zero(self, v, buffer=None):
+        raise NotImplementedError("a constraint class must provide solve_zero(v).")
+
+
+class _ProxNewton:
+    """The dual proximal-Newton solver of the reference for linear inequality constraints ``A Q x <= b`` on a group of several
+    coefficients (``constraint/utils.hpp:24-243``): ascent on the multipliers ``mu`` with the primal ``x*(mu)`` from the
+    unconstrained group update, a quadratic model of the dual whose Hessian is ``|x| Q D Q' + l1 kappa |x| a a'`` and a
+    coordinate-descent sub-solver that keeps ``mu`` feasible (pinball loss for a box, ``optimization/pinball_full.hpp:84-118``;
+    sign-constrained QP for one-sided bounds, ``optimization/nnqp_full.hpp:150-178``); backtracking towards the ellipse
+    ``|v - Q' A' mu| = l1`` when a step overshoots into the region where the primal is zero.  Subclasses give ``A`` (identity
+    or ``diag(sgn)``), the bounds and the feasible set of ``mu``."""
+
+    def _configure(self, configs):
+        cfg = dict(_PROX_NEWTON_DEFAULTS)
+        if configs:
+            unknown = set(configs) - set(cfg)
+            if unknown:
+                raise TypeError(f"unknown configs: {sorted(unknown)}")
+            cfg.update(configs)
+        if cfg["tol"] < 0:
+            raise RuntimeError("adelie_core: tol must be >= 0.")
+        if cfg["pinball_tol"] < 0:
+            raise RuntimeError("adelie_core: pinball_tol must be >= 0.")
+        if not (0 < cfg["slack"] < 1):
+            raise RuntimeError("adelie_core: slack must be in (0,1).")
+        self._cfg = cfg
+
+    # hooks ------------------------------------------------------------------------------------------------------------
+    def _At(self, mu):            # A' mu
         raise NotImplementedError
 
-    def _check_1d(self):
-        if self.primal_size != 1:
-            raise NotImplementedError(
-                "adelie_amd: constraints are implemented for groups of one coefficient (box / lower / upper / one_sided); "
-                "the proximal-Newton solvers for larger groups are not."
-            )
+    def _feasible_nearest(self, t):  # the feasible mu (under complementary slackness at x = 0) nearest to t in A-coordinates
+        raise NotImplementedError
+
+    def _slack_grad(self, x, Q):  # A Q x - b  (box: Q x, its two bounds are handled by the sub-solver)
+        raise NotImplementedError
+
+    def _is_optimal(self, g, mu):
+        raise NotImplementedError
+
+    def _zero_grad(self):         # the slack vector at x = 0 as the convergence measure wants it
+        raise NotImplementedError
+
+    def _qp(self, hess, var, mu, g):
+        raise NotImplementedError
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def _solve_multi(self, x, quad, linear, l1, l2, Q):
+        cfg = self._cfg
+        quad = np.asarray(quad, dtype=float)
+        v = np.asarray(linear, dtype=float)
+        Q = np.asarray(Q, dtype=float)
+        mu = self._mu.astype(float)
+        x0 = np.asarray(x, dtype=float).copy()
+
+        def finish(xv, muv):
+            x[...] = xv
+            self._mu[...] = muv
+
+        if np.linalg.norm(v) <= l1:
+            return finish(0.0, 0.0)
+        Qv = Q @ v
+
+        def nearest_at_zero(mu_now, may_restore):
+            """Multipliers that best explain v while the primal stays 0; keeps the old ones when even those do not."""
+            cand = self._feasible_nearest(Qv)
+            gap = float(np.sum(np.square(Qv - self._At(cand))))
+            if may_restore and gap > l1 * l1:
+                return mu_now, gap
+            return cand, gap
+
+        x_zero_start = not np.any(x0)
+        have_prev = False
+        zero_checked = False
+        mu_prev = g_prev = None
+        rn_prev = -1.0
+        if x_zero_start:
+            zero_checked = True
+            mu, gap = nearest_at_zero(mu, True)
+            if gap <= l1 * l1:
+                return finish(0.0, mu)
+        xv = x0
+        for it in range(1, int(cfg["max_iters"]) + 1):
+            resid = v - self._At(mu) @ Q
+            rn = float(np.linalg.norm(resid))
+            inside = rn <= l1
+            xn = -1.0
+            if not inside:
+                xv, b1, b2 = _group_prox(quad, resid, l1, l2)
+                xn = float(np.linalg.norm(xv))
+                inside = xn <= 0
+            if inside:
+                if it == 1 and x_zero_start:
+                    return finish(0.0, mu)
+                if have_prev and abs(np.mean((mu - mu_prev) * (g_prev - self._zero_grad()))) <= cfg["tol"]:
+                    return finish(0.0, mu)
+                if not zero_checked:
+                    zero_checked = True
+                    had_prev = have_prev
+                    if not had_prev:
+                        rn_prev, have_prev = rn, True
+                        mu_prev, g_prev = mu.copy(), self._zero_grad()
+                    mu, gap = nearest_at_zero(mu, had_prev)
+                    if gap <= l1 * l1:
+                        return finish(0.0, mu)
+                    if not had_prev:
+                        continue
+                if (not have_prev) or rn_prev <= l1 * 0.9999 or rn > l1 * 1.0001:
+                    raise RuntimeError("adelie_core: Possibly an unexpected error! Previous iterate should have been properly "
+                                       "initialized. ")
+                target = (1 - cfg["slack"]) * l1 + cfg["slack"] * rn_prev
+                step_dir = mu - mu_prev
+                a = float(step_dir @ step_dir)
+                b = float(np.sum((self._A_of(Qv) - mu) * step_dir))
+                c = rn * rn - target * target
+                t_star = (-b + np.sqrt(max(b * b - a * c, 0.0))) / a
+                mu = mu_prev + min(max(1 - t_star, 0.0), 1.0) * step_dir
+                continue
+            g = self._slack_grad(xv, Q)
+            if self._is_optimal(g, mu):
+                return finish(xv, mu)
+            if have_prev and abs(np.mean((mu - mu_prev) * (g_prev - g))) <= cfg["tol"]:
+                return finish(xv, mu)
+            rn_prev, have_prev = rn, True
+            mu_prev, g_prev = mu.copy(), g.copy()
+            # dual Hessian and the variance scale of the sub-solver's stopping rule (Woodbury)
+            a_t = xv * b2 / xn
+            kappa = 1.0 / float(np.sum(xv * b1 * a_t))
+            alpha = Q @ a_t
+            hess = xn * (Q * b2) @ Q.T + (l1 * kappa * xn) * np.outer(alpha, alpha)
+            xq = xv @ Q
+            xy = float(xv @ xq)
+            var = (float(np.sum(np.square(xq) / b2)) - xy * xy / (xn * xn / (l1 * kappa) + float(np.sum(np.square(xv) * b2)))) / xn
+            mu = self._qp(hess, max(var, 0.0), mu, g)
+        raise RuntimeError("adelie_core solver: ConstraintBase: proximal newton max iterations reached!")
 
 
-class _Box(ConstraintBase):
+class _Box(_ProxNewton, ConstraintBase):
     """``lower <= x <= upper`` with ``lower <= 0 <= upper`` (``ConstraintBox``; the class stores ``l = -lower``)."""
 
     kind = KIND_BOX
 
-    def __init__(self, lower, upper, dtype):
+    def __init__(self, lower, upper, dtype, configs=None):
+        self._configure(configs)
         if lower.shape != upper.shape:
             raise RuntimeError("adelie_core: lower must be (d,) where upper is (d,).")
         if np.any(upper < 0):
@@ -89,8 +262,57 @@ class _Box(ConstraintBase):
             self._upper = np.minimum(upper, MAX_SOLVER_VALUE).astype(dtype)
 
     def _abi(self):
-        self._check_1d()
+        if self.primal_size != 1:
+            return KIND_HOST, 0.0, 0.0
         return KIND_BOX, float(self._lower[0]), float(self._upper[0])
+
+    def _native(self):
+        c = self._cfg
+        return NATIVE_BOX, self._lower, self._upper, (c["max_iters"], c["tol"], c["pinball_max_iters"], c["pinball_tol"], c["slack"])
+
+    # hooks of _ProxNewton: A = I, multipliers mu = mu_+ - mu_-, free in sign only where the matching bound is 0
+    def _At(self, mu):
+        return mu
+
+    def _A_of(self, t):
+        return t
+
+    def _feasible_nearest(self, t):
+        lo = np.where(self._lower >= 0, -MAX_SOLVER_VALUE, 0.0)
+        hi = np.where(self._upper <= 0, MAX_SOLVER_VALUE, 0.0)
+        return np.minimum(np.maximum(t, lo), hi)
+
+    def _slack_grad(self, x, Q):
+        return Q @ x
+
+    def _zero_grad(self):
+        return np.zeros(self.primal_size)
+
+    def _is_optimal(self, g, mu):
+        u, l = self._upper.astype(float), self._lower.astype(float)
+        return bool(np.all((g <= u) & (g >= l)) and np.all(np.maximum(mu, 0) * (g - u) == 0)
+                    and np.all(np.minimum(mu, 0) * (g - l) == 0))
+
+    def _qp(self, hess, var, mu, g):
+        """Coordinate descent on ``1/2 m'Hm - (g + H mu)'m + u'(m)_+ + l'(m)_-`` from ``mu`` (pinball loss)."""
+        u, l = self._upper.astype(float), -self._lower.astype(float)
+        mu, g = mu.copy(), g.copy()
+        d = len(mu)
+        for _ in range(int(self._cfg["pinball_max_iters"])):
+            worst = 0.0
+            for i in range(d):
+                h = hess[i, i]
+                g0 = g[i] + h * mu[i]
+                new = np.copysign(max(-l[i] - g0, g0 - u[i], 0.0), g0 + l[i]) / h
+                dl = new - mu[i]
+                if dl == 0:
+                    continue
+                mu[i] = new
+                worst = max(worst, h * dl * dl)
+                g -= dl * hess[:, i]
+            if worst < var * self._cfg["pinball_tol"]:
+                return mu
+        raise RuntimeError("adelie_core solver: StatePinballFull: max iterations reached!")
 
     def evaluate(self, x):
         return np.concatenate([x - self._upper, self._lower - x])
@@ -109,7 +331,8 @@ class _Box(ConstraintBase):
         return float(np.linalg.norm(v - self._mu))
 
     def solve(self, x, quad, linear, l1, l2, Q, buffer=None):
-        self._check_1d()
+        if self.primal_size != 1:
+            return self._solve_multi(x, quad, linear, l1, l2, Q)
         A, q, v = float(np.asarray(Q).reshape(-1)[0]), float(quad[0]), float(linear[0])
         u, l = float(self._upper[0]), -float(self._lower[0])
         mp = 0.0 if u > 0 else max(A * v, 0.0)
@@ -126,12 +349,13 @@ class _Box(ConstraintBase):
         self._mu[0] = mp - mn
 
 
-class _OneSided(ConstraintBase):
+class _OneSided(_ProxNewton, ConstraintBase):
     """``D x <= b`` with ``D = diag(+-1)``, ``b >= 0`` (``ConstraintOneSided``)."""
 
     kind = KIND_ONE_SIDED
 
-    def __init__(self, D, b, dtype):
+    def __init__(self, D, b, dtype, configs=None):
+        self._configure(configs)
         if D.shape != b.shape:
             raise RuntimeError("adelie_core: sgn be (d,) where b is (d,).")
         if np.any(np.abs(D) != 1):
@@ -144,8 +368,54 @@ class _OneSided(ConstraintBase):
             self._b = np.minimum(b, MAX_SOLVER_VALUE).astype(dtype)
 
     def _abi(self):
-        self._check_1d()
+        if self.primal_size != 1:
+            return KIND_HOST, 0.0, 0.0
         return KIND_ONE_SIDED, float(self._D[0]), float(self._b[0])
+
+    def _native(self):
+        c = self._cfg
+        return NATIVE_ONE_SIDED, self._D, self._b, (c["max_iters"], c["tol"], c["pinball_max_iters"], c["pinball_tol"], c["slack"])
+
+    # hooks of _ProxNewton: A = diag(sgn), mu >= 0, positive only where the bound is 0 (at x = 0) or active
+    def _At(self, mu):
+        return self._D * mu
+
+    def _A_of(self, t):
+        return self._D * t
+
+    def _feasible_nearest(self, t):
+        hi = np.where(self._b <= 0, MAX_SOLVER_VALUE, 0.0)
+        return np.minimum(np.maximum(self._D * t, 0.0), hi)
+
+    def _slack_grad(self, x, Q):
+        return self._D * (Q @ x) - self._b
+
+    def _zero_grad(self):
+        return -self._b.astype(float)
+
+    def _is_optimal(self, g, mu):
+        return bool(np.all(g <= 0) and np.all(mu * g == 0))
+
+    def _qp(self, hess, var, mu, g):
+        """Coordinate ascent on the sign-constrained quadratic model, in the coordinates ``sgn * mu``."""
+        sgn = self._D.astype(float)
+        m, g = mu * sgn, g * sgn
+        d = len(m)
+        for _ in range(int(self._cfg["pinball_max_iters"])):
+            worst = 0.0
+            for i in range(d):
+                h = hess[i, i]
+                step = 0.0 if h <= 0 else g[i] / h
+                new = max(m[i] + step, 0.0) if sgn[i] > 0 else min(m[i] + step, 0.0)
+                dl = new - m[i]
+                if dl == 0:
+                    continue
+                m[i] = new
+                worst = max(worst, h * dl * dl)
+                g -= dl * hess[:, i]
+            if worst < var * self._cfg["pinball_tol"]:
+                return m * sgn
+        raise RuntimeError("adelie_core solver: StateNNQPFull: max iterations reached!")
 
     def evaluate(self, x):
         return self._D * x - self._b
@@ -163,7 +433,8 @@ class _OneSided(ConstraintBase):
         return float(np.linalg.norm(v - self._D * self._mu))
 
     def solve(self, x, quad, linear, l1, l2, Q, buffer=None):
-        self._check_1d()
+        if self.primal_size != 1:
+            return self._solve_multi(x, quad, linear, l1, l2, Q)
         A = float(self._D[0]) * float(np.asarray(Q).reshape(-1)[0])
         q, v, b = float(quad[0]), float(linear[0]), float(self._b[0])
         mu0 = 0.0 if b > 0 else max(A * v, 0.0)
@@ -186,7 +457,7 @@ def box(lower: np.ndarray, upper: np.ndarray, *, method: str = "proximal_newton"
     lower, ld = _coerce(lower, dtype)
     upper, ud = _coerce(upper, dtype)
     assert ld == ud
-    return _Box(lower, upper, ld)
+    return _Box(lower, upper, ld, configs)
 
 
 def one_sided(D: np.ndarray, b: np.ndarray, *, method: str = "proximal_newton", configs: dict = None,
@@ -194,8 +465,11 @@ def one_sided(D: np.ndarray, b: np.ndarray, *, method: str = "proximal_newton", 
     """One-sided bound ``D x <= b`` (``D = diag(+-1)``, ``b >= 0``); reference ``constraint.py:341-480``."""
     if method not in ("proximal_newton", "admm"):
         raise KeyError(method)
+    if method == "admm" and np.size(b) > 1:
+        raise NotImplementedError("adelie_amd: one_sided(method='admm') is not implemented for several coefficients; "
+                                  "use the default 'proximal_newton'.")
     b, dtype = _coerce(b, dtype)
-    return _OneSided(np.array(D, dtype=dtype, ndmin=1), b, dtype)
+    return _OneSided(np.array(D, dtype=dtype, ndmin=1), b, dtype, configs if method == "proximal_newton" else None)
 
 
 def lower(b: np.ndarray, **kwargs):

@@ -367,6 +367,13 @@ struct Solver {
     std::vector<std::vector<idx>> duals_idx;
     std::vector<std::vector<T>> duals_val;
     T cons_dual_of(idx g) const { return cons_kind[g] == 2 ? cons_a[g] * cons_mu[g] : cons_mu[g]; }
+    // Constraint objects on the caller's side (kind ADELIE_HIP_CONSTRAINT_HOST: several coefficients, user-defined classes):
+    // their group is a block of its own in every pass and is visited on the host between two panel steps (host_group_visit),
+    // abs_grad and the duals ask the object through the callbacks (host_cons_abs_grad, update_solutions)
+    bool cons_host = false;
+    const adelie_hip_constraint_callbacks* cons_cb = nullptr;
+    std::vector<idx> cons_m; // (G,) multipliers per group
+    bool host_cons(idx g) const { return cons_host && cons_kind[g] == ADELIE_HIP_CONSTRAINT_HOST; }
     adelie_hip_glm_callbacks glm_cb{};       // glm_kind == CALLBACK: the user's GlmBase subclass, evaluated on the host
     std::vector<T> cb_eta, cb_grad, cb_hess, cb_z;
     idx max_gs = 1;
@@ -966,7 +973,7 @@ struct Solver {
         for (size_t ss = 0; ss < screen_set.size(); ++ss) {
             const idx i = screen_set[ss], b = screen_begins[ss], k = groups[i], sz = group_sizes[i];
             const T regul = ((1 - alpha) * lm) * penalty[i];
-            if (cons_on && cons_kind[i]) { // :69-75: minus the constraint's gradient
+            if (cons_on && cons_kind[i] && !host_cons(i)) { // :69-75: minus the constraint's gradient
                 abs_grad[i] = std::abs(grad[k] - regul * screen_beta[b] - cons_mu[i]);
                 continue;
             }
@@ -980,7 +987,7 @@ struct Solver {
         for (idx i = 0; i < G; ++i) {
             if (is_screen(i)) continue;
             const idx k = groups[i];
-            if (cons_on && cons_kind[i]) { // :88-93 solve_zero (constraint_box.ipp:268-284, constraint_one_sided.ipp:269-279)
+            if (cons_on && cons_kind[i] && !host_cons(i)) { // :88-93 solve_zero (constraint_box.ipp:268-284, constraint_one_sided.ipp:269-279)
                 const T M = T(1e100), v = grad[k];
                 cons_mu[i] = std::min(std::max(v, cons_lo[i] >= 0 ? -M : T(0)), cons_hi[i] <= 0 ? M : T(0));
                 abs_grad[i] = std::abs(v - cons_mu[i]);
@@ -2028,11 +2035,13 @@ struct Solver {
         for (idx pos = 0; pos < count; ++pos) {
             const idx ss = list ? list[pos] : pos;
             const idx q = group_sizes[screen_set[ss]];
-            if (acc + q > B) {
+            const bool alone = host_cons(screen_set[ss]); // visited on the host: a block of its own
+            if (acc > 0 && (acc + q > B || alone)) {
                 part_host.push_back(int32_t(pos));
                 acc = 0;
             }
             acc += q;
+            if (alone) acc = B; // nothing joins it
         }
         if (count > 0) part_host.push_back(int32_t(count));
         return int(part_host.size()) - 1;
@@ -2118,6 +2127,123 @@ struct Solver {
 
     // Panel engine with groups: blocks = consecutive groups of the visiting list with <= 128 values (partition built on the
     // host, prefix-stable because both lists are append-only); otherwise the same data flow as run_panel_passes.
+    // One visit of a group whose constraint object lives on the caller's side (pin_naive:110-168 with update_coordinate_g1_f =
+    // constraint->solve, :439-458).  The group is a block of its own: its gradient was just formed by a panel step + reduce
+    // (d_gblk), its coefficients, variances and eigenbasis are read back, the object's solve runs through the callback, and the
+    // changes go out the way a device solve leaves them (d_beta, the compacted (column, delta) list of the next step's
+    // residual update, the pass state in d_blk).  Returns the pass state after the visit.
+    CdBlkState<T> host_group_visit(const CdParams<T>& cp, idx ss, bool mark) {
+        const idx g = screen_set[ss], q = group_sizes[g], b = screen_begins[ss];
+        const size_t uq = static_cast<size_t>(q);
+        std::vector<T> gk(uq), ak(uq), Ak(uq), Vk(uq * uq, T(1));
+        CdBlkState<T> bs{};
+        int8_t was_active = 0;
+        d_gblk.download(gk.data(), size_t(q), st);
+        d_beta.download(ak.data(), size_t(q), st, size_t(b));
+        d_vars.download(Ak.data(), size_t(q), st, size_t(b));
+        if (q > 1) d_V.download(Vk.data(), size_t(q) * q, st, size_t(h_voff[size_t(ss)]));
+        d_blk.download(&bs, 1, st);
+        d_isact.download(&was_active, 1, st, size_t(ss));
+        sync();
+        const T pk = penalty[g];
+        const double l1 = double(cp.lmda * cp.alpha) * double(pk), l2 = double(cp.lmda * (T(1) - cp.alpha)) * double(pk);
+        std::vector<double> gt(uq), a_old_t(uq), x(uq), quad(uq), lin(uq), Qd(uq * uq);
+        for (idx j = 0; j < q; ++j) { // into the eigenbasis: g V, beta V  (:123-135)
+            double s1 = 0, s2 = 0;
+            for (idx i = 0; i < q; ++i) {
+                s1 += double(gk[size_t(i)]) * double(Vk[size_t(i + j * q)]);
+                s2 += double(ak[size_t(i)]) * double(Vk[size_t(i + j * q)]);
+            }
+            gt[size_t(j)] = s1;
+            a_old_t[size_t(j)] = s2;
+            x[size_t(j)] = s2;
+            quad[size_t(j)] = double(Ak[size_t(j)]);
+            lin[size_t(j)] = s1 + double(Ak[size_t(j)]) * s2;
+        }
+        for (size_t e = 0; e < Qd.size(); ++e) Qd[e] = double(Vk[e]);
+        if (cons_cb->solve(cons_cb->user, g, q, x.data(), quad.data(), lin.data(), l1, l2, Qd.data()))
+            throw make_solver_error("constraint.solve() raised.");
+        double dn = 0;
+        for (idx j = 0; j < q; ++j) dn += (a_old_t[size_t(j)] - x[size_t(j)]) * (a_old_t[size_t(j)] - x[size_t(j)]);
+        bs.nz = 0;
+        if (!(std::sqrt(dn) <= g_dbeta_tol * std::sqrt(double(q)))) { // :144: the group changed
+            double cmv = 0, rs = 0;
+            for (idx j = 0; j < q; ++j) {
+                const double dl = x[size_t(j)] - a_old_t[size_t(j)];
+                cmv += quad[size_t(j)] * dl * dl;
+                rs += dl * (2 * gt[size_t(j)] - dl * quad[size_t(j)]);
+            }
+            bs.cm = std::max(bs.cm, T(cmv / double(q))); // pin_base:100-110
+            bs.rsq += T(rs);                              // pin_base:124-134
+            std::vector<T> a_new(uq), dlt(uq);
+            std::vector<int32_t> dcol(uq);
+            double rsum = 0;
+            for (idx i = 0; i < q; ++i) { // back: beta = x V^T  (:156-157)
+                double acc = 0;
+                for (idx j = 0; j < q; ++j) acc += x[size_t(j)] * double(Vk[size_t(i + j * q)]);
+                a_new[size_t(i)] = T(acc);
+                dlt[size_t(i)] = a_new[size_t(i)] - ak[size_t(i)];
+                dcol[size_t(i)] = int32_t(groups[g] + i);
+                rsum += double(screen_X_means[size_t(b + i)]) * double(ak[size_t(i)] - a_new[size_t(i)]);
+            }
+            bs.resid_sum += T(rsum);
+            bs.n_updates += 1;
+            bs.nz = int32_t(q);
+            d_beta.upload(a_new.data(), size_t(q), st, size_t(b));
+            d_dcolblk.upload(dcol.data(), size_t(q), st);
+            d_dlt.upload(dlt.data(), size_t(q), st);
+            if (mark && !was_active) { // add_active_set, pin_naive:294-304
+                if (size_t(bs.active_size) >= max_active_size) {
+                    bs.status = CD_MAX_ACTIVE;
+                } else {
+                    const int8_t one = 1;
+                    const int32_t ssi = int32_t(ss);
+                    d_isact.upload(&one, 1, st, size_t(ss));
+                    d_actset.upload(&ssi, 1, st, size_t(bs.active_size));
+                    bs.active_size += 1;
+                }
+            }
+        }
+        d_blk.upload(&bs, 1, st);
+        sync();
+        return bs;
+    }
+    // abs_grad of the groups with host constraint objects (solver_base.hpp:62-93): the constraint's gradient for screened groups,
+    // its solve_zero for the others; overrides what the device kernel wrote for them (it knows no bounds for these groups)
+    void host_cons_abs_grad(T lm) {
+        if (!cons_host) return;
+        d_grad.download(grad.data(), size_t(p), st);
+        sync();
+        std::vector<double> v, out;
+        std::vector<idx> begin_of(static_cast<size_t>(G), idx(-1));
+        for (size_t ss = 0; ss < screen_set.size() && ss < screen_begins.size(); ++ss) begin_of[size_t(screen_set[ss])] = screen_begins[ss];
+        for (idx g = 0; g < G; ++g) {
+            if (!host_cons(g)) continue;
+            const idx q = group_sizes[g], k = groups[g];
+            v.assign(size_t(q), 0);
+            if (begin_of[size_t(g)] >= 0) {
+                const idx b = begin_of[size_t(g)];
+                const double regul = double((1 - alpha) * lm) * double(penalty[g]);
+                for (idx t = 0; t < q; ++t) v[size_t(t)] = double(screen_beta[size_t(b + t)]);
+                out.assign(size_t(q), 0);
+                if (cons_cb->gradient(cons_cb->user, g, q, v.data(), out.data()))
+                    throw make_solver_error("constraint.gradient() raised.");
+                double acc = 0;
+                for (idx t = 0; t < q; ++t) {
+                    const double e = double(grad[size_t(k + t)]) - regul * v[size_t(t)] - out[size_t(t)];
+                    acc += e * e;
+                }
+                abs_grad[size_t(g)] = T(std::sqrt(acc));
+            } else {
+                for (idx t = 0; t < q; ++t) v[size_t(t)] = double(grad[size_t(k + t)]);
+                double nrm = 0;
+                if (cons_cb->solve_zero(cons_cb->user, g, q, v.data(), &nrm))
+                    throw make_solver_error("constraint.solve_zero() raised.");
+                abs_grad[size_t(g)] = T(nrm);
+            }
+        }
+    }
+
     void run_group_panel_passes(const CdParams<T>& cp, CdScalars<T>& sc, T* r_dev) {
         const int SL = cd_block_size();
         panel_setup(group_maxblk());
@@ -2304,9 +2430,12 @@ struct Solver {
             asz = bs.active_size;
             return bs.cm;
         };
+        CdBlkState<T> host_bs{};
+        bool last_on_host = false;
         auto pass_plain = [&](bool screen_pass) -> T {
             const idx count = screen_pass ? idx(cp.ns) : idx(asz);
             if (count <= 0) return T(0);
+            last_on_host = false;
             const int nblk = build_partition_values(screen_pass ? nullptr : act_host.data(), count);
             d_blk_g0.reserve(part_host.size());
             d_blk_g0.upload(part_host.data(), part_host.size(), st);
@@ -2350,6 +2479,16 @@ struct Solver {
                 pending_slot = -1;
                 cnt.n_panel_cols += nval;
                 launch_panel_reduce<T>(d_part.p, nsl, nval, cols, &d_blk.p->resid_sum, xm_c, d_gblk.p, st);
+                if (cons_host) { // a block that is one group with a constraint object on the caller's side: visited on the host
+                    const idx ss0 = screen_pass ? idx(part_host[size_t(j)]) : act_host[size_t(part_host[size_t(j)])];
+                    if (part_host[size_t(j) + 1] - part_host[size_t(j)] == 1 && host_cons(screen_set[ss0])) {
+                        if (blk_ev[size_t(j)]) AHIP_CHECK(hipStreamWaitEvent(st, blk_ev[size_t(j)], 0)); // (its eigenbasis)
+                        host_bs = host_group_visit(cp, ss0, screen_pass);
+                        last_on_host = (j == nblk - 1);
+                        continue;
+                    }
+                    last_on_host = false;
+                }
                 bp.Dptr = Dptr;
                 if (h_report && j == nblk - 1) {
                     bp.report_j = j;
@@ -2364,7 +2503,8 @@ struct Solver {
             AHIP_CHECK(hipGetLastError()); // a failed launch would otherwise only show up as a stalled pass report
             cnt.n_panel_blocks += nblk;
             if (no_wait) { spec_blocks = nblk; return T(0); }
-            wait_pass_state(bs);
+            if (last_on_host) bs = host_bs; // (no device solve published a report for this pass)
+            else wait_pass_state(bs);
             status = bs.status;
             if (bs.active_size > asz) { // pick up the groups activated by this screen pass
                 std::vector<int32_t> fresh(size_t(bs.active_size - asz));
@@ -3016,6 +3156,7 @@ struct Solver {
             if (inv_prelaunched_lm == lm) {
                 if (!spec_active) sync(); // (pin_solve waited for the downloads; a full sync would wait for the speculative pass)
                 grad_valid = true;
+                host_cons_abs_grad(lm);
                 return;
             }
         }
@@ -3044,6 +3185,7 @@ struct Solver {
         }
         device_abs_grad(lm);
         sync();
+        host_cons_abs_grad(lm);
     }
 
     void update_solutions(FitOut<T>& fo, T lm) {
@@ -3055,8 +3197,20 @@ struct Solver {
             refresh_screen_multipliers();
             std::vector<idx> di;
             std::vector<T> dv;
-            for (idx g = 0; g < G; ++g)
-                if (cons_kind[g] && cons_mu[g] != 0) { di.push_back(dual_groups[g]); dv.push_back(cons_dual_of(g)); }
+            std::vector<double> mu_obj;
+            for (idx g = 0; g < G; ++g) {
+                if (!cons_kind[g]) continue;
+                if (host_cons(g)) { // the object's own multipliers
+                    mu_obj.assign(size_t(cons_m[g]), 0.0);
+                    if (cons_m[g] > 0 && cons_cb->dual(cons_cb->user, g, cons_m[g], mu_obj.data()))
+                        throw make_solver_error("constraint.dual() raised.");
+                    for (idx t = 0; t < cons_m[g]; ++t)
+                        if (mu_obj[size_t(t)] != 0) { di.push_back(dual_groups[g] + t); dv.push_back(T(mu_obj[size_t(t)])); }
+                } else if (cons_mu[g] != 0) {
+                    di.push_back(dual_groups[g]);
+                    dv.push_back(cons_dual_of(g));
+                }
+            }
             duals_idx.emplace_back(std::move(di));
             duals_val.emplace_back(std::move(dv));
         } else {
@@ -3222,7 +3376,7 @@ struct Solver {
         d_cmu.download(cmu_stage.data(), size_t(nv), st);
         sync();
         for (size_t ss = 0; ss < screen_set.size(); ++ss) // a constrained group has one coefficient: its screen value
-            if (cons_kind[screen_set[ss]]) cons_mu[screen_set[ss]] = cmu_stage[size_t(screen_begins[ss])];
+            if (cons_kind[screen_set[ss]] && !host_cons(screen_set[ss])) cons_mu[screen_set[ss]] = cmu_stage[size_t(screen_begins[ss])];
     }
 
     // host mirrors of the device-resident invariants (grad, resid, eta, screen_beta, screen_X_means, screen_vars); also what
@@ -3393,6 +3547,19 @@ struct Solver {
                     throw make_core_error("constraints are not implemented for problems with groups of more than " +
                                           std::to_string(cd_block_size()) + " coefficients.");
                 if (!a->constraint_a || !a->constraint_b) throw make_core_error("constraint_a and constraint_b are required.");
+                cons_m.assign(G, 0);
+                for (idx g = 0; g < G; ++g)
+                    if (a->constraint_kind[g] == ADELIE_HIP_CONSTRAINT_HOST) cons_host = true;
+                if (cons_host) {
+                    if (!a->constraint_cb || !a->constraint_cb->solve || !a->constraint_cb->gradient ||
+                        !a->constraint_cb->solve_zero || !a->constraint_cb->dual)
+                        throw make_core_error("constraint_cb is required for host constraint objects.");
+                    cons_cb = a->constraint_cb;
+                    if (max_gs > idx(cd_block_size()))
+                        throw make_core_error("constraints are not implemented for problems with groups of more than " +
+                                              std::to_string(cd_block_size()) + " coefficients.");
+                    all_scalar = false; // the group engine carries the host visits (it handles groups of one coefficient too)
+                }
                 const T* ca = static_cast<const T*>(a->constraint_a);
                 const T* cb = static_cast<const T*>(a->constraint_b);
                 const T* cm = static_cast<const T*>(a->constraint_mu);
@@ -3409,8 +3576,15 @@ struct Solver {
                     dual_groups[g] = nd;
                     const int32_t kd = cons_kind[g];
                     if (!kd) continue;
+                    if (kd == ADELIE_HIP_CONSTRAINT_HOST) {
+                        cons_m[g] = a->constraint_duals ? a->constraint_duals[g] : group_sizes[g];
+                        if (cons_m[g] < 0) throw make_core_error("constraint_duals must be >= 0.");
+                        nd += cons_m[g];
+                        continue;
+                    }
                     if (group_sizes[g] != 1)
-                        throw make_core_error("constraints are implemented for groups of one coefficient.");
+                        throw make_core_error("box / one-sided closed forms are for groups of one coefficient (pass the object as a host constraint).");
+                    cons_m[g] = 1;
                     if (kd == 1) { // constraint_box.ipp:30-37
                         if (cb[g] < 0) throw make_core_error("upper must be >= 0.");
                         if (ca[g] > 0) throw make_core_error("lower must be <= 0.");
@@ -3463,6 +3637,7 @@ struct Solver {
 
         update_screen_derived_base();
         update_abs_grad_host(lmda);
+        host_cons_abs_grad(lmda);
 
         if (cov_mode) {
             if (!a->cov_v) throw make_core_error("v must be (p,) where A is (p, p).");

@@ -277,7 +277,7 @@ class base:
             new.duals = csr_matrix((dv, di, dp), shape=(len(dp) - 1, n_duals))
             mu = backend.result_vec(r, _abi.V["constraint_mu"])
             for c, m in zip(cons, mu):  # the objects are left holding the multipliers of the last fit, as the reference's are
-                if c is not None:
+                if c is not None and c._abi()[0] != _constraint.KIND_HOST:  # (host objects were the live objects all along)
                     c._mu[0] = m
         sc = lambda nm: backend.fn("result_scalar")(r, _abi.S[nm])
         new.lmda_max = dtype(sc("lmda_max"))
@@ -373,18 +373,94 @@ class base:
         a.active_set = act.ctypes.data
         a.lmda = float(self.lmda)
         cons = self._constraint_list()
-        if cons is not None:  # one-coefficient box / one-sided constraints: (kind, a, b) per group, multipliers held on entry
-            kind = np.zeros(a.G, dtype=np.int32)
-            ca, cb, mu = np.zeros(a.G, dtype=dtype), np.zeros(a.G, dtype=dtype), np.zeros(a.G, dtype=dtype)
+        if cons is not None:
+            # One-coefficient box / one-sided constraints: (kind, a, b) per group + the multipliers held on entry, solved on the
+            # device.  Every other object is reached through callbacks (kind 3); for the built-in box / one-sided classes on
+            # several coefficients the arguments also carry what the CPU checker needs to run its own restatement.
+            G, p = a.G, self._X.cols()
+            kind = np.zeros(G, dtype=np.int32)
+            ca, cb, mu = np.zeros(G, dtype=dtype), np.zeros(G, dtype=dtype), np.zeros(G, dtype=dtype)
+            ndual = np.zeros(G, dtype=np.int64)
+            native = np.zeros(G, dtype=np.int32)
+            va, vb = np.zeros(p, dtype=dtype), np.zeros(p, dtype=dtype)
+            cfg = np.zeros((G, 5), dtype=np.float64)
+            any_host = False
             for i, c in enumerate(cons):
-                if c is not None:
-                    kind[i], ca[i], cb[i] = c._abi()
+                if c is None:
+                    continue
+                kind[i], ca[i], cb[i] = c._abi()
+                ndual[i] = c.duals()
+                if kind[i] == _constraint.KIND_HOST:
+                    any_host = True
+                    nat = c._native()
+                    if nat is not None:
+                        g0, q = int(self.groups[i]), int(self.group_sizes[i])
+                        native[i] = nat[0]
+                        va[g0:g0 + q], vb[g0:g0 + q] = nat[1], nat[2]
+                        cfg[i] = nat[3]
+                else:
                     mu[i] = c._mu[0]
-            keep += [kind, ca, cb, mu]
+            keep += [kind, ca, cb, mu, ndual, native, va, vb, cfg]
             a.constraint_kind = kind.ctypes.data
             a.constraint_a = ca.ctypes.data
             a.constraint_b = cb.ctypes.data
             a.constraint_mu = mu.ctypes.data
+            a.constraint_duals = ndual.ctypes.data
+            if any_host:
+                a.constraint_native = native.ctypes.data
+                a.constraint_va = va.ctypes.data
+                a.constraint_vb = vb.ctypes.data
+                a.constraint_cfg = cfg.ctypes.data
+                cbs = self._constraint_callbacks(cons)
+                keep.append(cbs)
+                a.constraint_cb = _abi.C.pointer(cbs)
+
+    def _constraint_callbacks(self, cons):
+        """``adelie_hip_constraint_callbacks`` over the constraint objects that are not device closed forms — the role of the
+        reference's trampoline ``PyConstraintBase``: the solver hands host vectors in double precision, the methods work in
+        place.  An exception raised by a method aborts the solve and is re-raised by ``solve()``."""
+        pending = self._glm_cb_pending = getattr(self, "_glm_cb_pending", {})
+        as_arr = np.ctypeslib.as_array
+
+        def guarded(f):
+            def call(*args):
+                try:
+                    f(*args)
+                    return 0
+                except BaseException as e:  # noqa: BLE001
+                    pending.setdefault("exc", e)
+                    return 1
+            return call
+
+        @guarded
+        def solve(user, g, d, x, quad, linear, l1, l2, Q):
+            xv = as_arr(x, (d,))
+            work = xv.copy()
+            cons[g].solve(work, as_arr(quad, (d,)).copy(), as_arr(linear, (d,)).copy(), float(l1), float(l2),
+                          as_arr(Q, (d * d,)).reshape(d, d, order="F").copy())
+            xv[...] = work
+
+        @guarded
+        def gradient(user, g, d, x, out):
+            res = np.zeros(d)
+            cons[g].gradient(as_arr(x, (d,)).copy(), res)
+            as_arr(out, (d,))[...] = res
+
+        @guarded
+        def solve_zero(user, g, d, v, norm):
+            norm[0] = float(cons[g].solve_zero(as_arr(v, (d,)).copy()))
+
+        @guarded
+        def dual(user, g, m, mu_out):
+            idx, val = np.zeros(m, dtype=int), np.zeros(m)
+            nnz = cons[g].duals_nnz()
+            cons[g].dual(idx, val)
+            dense = np.zeros(m)
+            dense[idx[:nnz]] = val[:nnz]
+            as_arr(mu_out, (m,))[...] = dense
+
+        return _abi.ConstraintCallbacks(None, _abi.CONS_SOLVE_FN(solve), _abi.CONS_GRADIENT_FN(gradient),
+                                        _abi.CONS_SOLVE_ZERO_FN(solve_zero), _abi.CONS_DUAL_FN(dual))
 
     def _check_shapes(self):
         G = len(self.groups)
@@ -403,15 +479,14 @@ class base:
                 if c is None:
                     continue
                 if not isinstance(c, _constraint.ConstraintBase):
-                    raise NotImplementedError(
-                        "adelie_amd: constraints must come from adelie_amd.constraint (box / lower / upper / one_sided); "
-                        "user-defined constraint classes are not implemented.")
+                    raise RuntimeError("adelie_core: constraints must be instances of adelie_amd.constraint.ConstraintBase "
+                                       "(box / lower / upper / one_sided, or a subclass that provides solve / gradient / "
+                                       "solve_zero).")
                 if id(c) in seen:
                     raise RuntimeError("adelie_core: constraints must contain distinct objects or nullptr.")
                 seen.add(id(c))
                 if c.primal_size != q:
                     raise RuntimeError("adelie_core: constraint of a group must have the group's size.")
-                c._abi()  # raises for groups of several coefficients
         n, p = self._X.rows(), self._X.cols()
         if len(self.resid) != n:
             raise RuntimeError("adelie_core: resid must be (n,) where X is (n, p).")

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADELIE_HIP_ABI_VERSION 3
+#define ADELIE_HIP_ABI_VERSION 4
 
 enum adelie_hip_dtype { ADELIE_HIP_F32 = 0, ADELIE_HIP_F64 = 1 };
 enum adelie_hip_order { ADELIE_HIP_COL_MAJOR = 0, ADELIE_HIP_ROW_MAJOR = 1 };
@@ -218,6 +218,32 @@ typedef struct adelie_hip_glm_callbacks {
     int (*loss)(void* user, const void* eta, double* loss);
 } adelie_hip_glm_callbacks;
 
+/* Host callbacks of the constraint objects the solver cannot run as a closed form on the device (constraint kind
+ * ADELIE_HIP_CONSTRAINT_HOST): constraints on groups of several coefficients (the reference's ConstraintBox /
+ * ConstraintOneSided proximal-Newton solvers, ConstraintLinear) and user-defined subclasses of ConstraintBase.  They stand
+ * for the virtuals of ConstraintBase the solver calls (constraint_base.hpp:40-160; call sites
+ * solver_gaussian_pin_naive.hpp:419-458, solver_base.hpp:62-93,158-222), exactly as the reference's PyConstraintBase
+ * trampoline does (py_constraint.cpp).  `g` is the group, `d` its number of coefficients; all arrays are HOST doubles;
+ * return nonzero to abort the solve.
+ *   solve:      x (d) in/out in the coordinates of the group's eigenbasis Q (d x d, column-major), quad (d), linear (d)
+ *   gradient:   out (d) = the constraint's term of the group's gradient at its current multipliers
+ *   solve_zero: sets the multipliers that best explain v at x = 0; *norm = || v - gradient ||_2
+ *   dual:       mu_out (m) = the object's multipliers, m = constraint_duals[g] */
+typedef struct adelie_hip_constraint_callbacks {
+    void* user;
+    int (*solve)(void* user, int64_t g, int64_t d, double* x, const double* quad, const double* linear, double l1, double l2,
+                 const double* Q);
+    int (*gradient)(void* user, int64_t g, int64_t d, const double* x, double* out);
+    int (*solve_zero)(void* user, int64_t g, int64_t d, const double* v, double* norm);
+    int (*dual)(void* user, int64_t g, int64_t m, double* mu_out);
+} adelie_hip_constraint_callbacks;
+enum adelie_hip_constraint_kind {
+    ADELIE_HIP_CONSTRAINT_NONE = 0,
+    ADELIE_HIP_CONSTRAINT_BOX_1D = 1,       /* closed form on the device */
+    ADELIE_HIP_CONSTRAINT_ONE_SIDED_1D = 2, /* closed form on the device */
+    ADELIE_HIP_CONSTRAINT_HOST = 3          /* object on the caller's side, reached through adelie_hip_constraint_callbacks */
+};
+
 typedef struct adelie_hip_grpnet_args {
     /* ---- problem (static) ---- */
     int64_t        G;                 /* number of groups */
@@ -290,18 +316,32 @@ typedef struct adelie_hip_grpnet_args {
     const void*    cov_v;             /* (p,) value_t: the linear term v of 1/2 b'Ab - v'b */
     double         rdev_tol;          /* early exit on the relative change of the deviance (solver_gaussian_cov.hpp:183-201) */
     /* ---- per-group constraints (`constraints` of StateBase, state_base.hpp:60; adelie_core/constraint/) ----
-     * Offered for groups of ONE value, where ConstraintBox / ConstraintOneSided have closed forms (constraint_box.ipp:51-96,
-     * constraint_one_sided.ipp:12-49); the other groups of the problem may have any size up to 128.  A constrained group of
-     * more than one value (their proximal-Newton solvers), a linear constraint, or constraints on a multi-response view / the
-     * covariance method are refused with an error string.
+     * Groups of ONE value with a box / one-sided constraint run as closed forms on the device (constraint_box.ipp:51-96,
+     * constraint_one_sided.ipp:12-49); every other constraint object (several coefficients, linear, user-defined classes) is
+     * kind 3: its group is visited on the host between two panel steps through constraint_cb (see above).  Constraints on a
+     * multi-response view / the covariance method are refused with an error string.
      *   kind 0: unconstrained;
      *   kind 1: box        constraint_a[i] <= beta_i <= constraint_b[i]   (a <= 0 <= b, infinities allowed); dual = mu_+ - mu_-
      *   kind 2: one-sided  constraint_a[i] * beta_i <= constraint_b[i]    (a = +-1, b >= 0);               dual = mu >= 0
+     *   kind 3: host object; constraint_a / _b / _mu of the group are ignored.
      * NULL kind (or all zeros): no constraints. */
     const int32_t* constraint_kind;   /* (G,) */
     const void*    constraint_a;      /* (G,) value_t */
     const void*    constraint_b;      /* (G,) value_t */
     const void*    constraint_mu;     /* (G,) value_t or NULL: the multipliers the constraint objects hold on entry (warm start) */
+    /* ABI 4 */
+    const int64_t* constraint_duals;  /* (G,) number of multipliers of each group's constraint (ConstraintBase::duals; 0 = no
+                                         constraint); NULL: one per constrained group.  Their running sum is `dual_groups`. */
+    const adelie_hip_constraint_callbacks* constraint_cb; /* required when any kind is ADELIE_HIP_CONSTRAINT_HOST */
+    /* What the CPU checker (oracle/) needs to run a kind-3 box / one-sided constraint with its OWN restatement of the
+     * reference's solver instead of calling back (libadelie_hip.so ignores these): constraint_native[g] = 0 (call back),
+     * 4 (box: constraint_va = lower, constraint_vb = upper) or 5 (one-sided: va = sgn, vb = b), per COEFFICIENT (p,) arrays of
+     * value_t indexed like the design's columns, and the solver settings (max_iters, tol, pinball_max_iters, pinball_tol,
+     * slack) as 5 doubles per group. */
+    const int32_t* constraint_native; /* (G,) or NULL */
+    const void*    constraint_va;     /* (p,) value_t or NULL */
+    const void*    constraint_vb;     /* (p,) value_t or NULL */
+    const double*  constraint_cfg;    /* (G, 5) row-major or NULL */
 } adelie_hip_grpnet_args;
 
 /* Runs the whole path.  `*out` is always set on return code 0 (even when the solve recorded

@@ -1,8 +1,9 @@
-"""Per-group constraints on one-coefficient groups (reference adelie_core/constraint/*,
-adelie/constraint.py): the descriptor objects against the KKT properties the reference's own tests/test_constraint.py:6-64
-checks (d = 1 rows of its grid), the oracle's constrained path against an independent bound-constrained solve (the reference's
-test_solver.py does this with cvxpy, which is not in this image: L-BFGS-B on the split problem instead), the error behaviour,
-and — on the GPU — the HIP path against the oracle."""
+"""Per-group constraints (reference adelie_core/constraint/*, adelie/constraint.py): the objects
+against the KKT properties the reference's own tests/test_constraint.py:6-64 checks (its d = 1 rows, and d > 1 for the
+proximal-Newton solvers: the numpy classes of the product against the CPU checker's independent C++ restatement and against
+first principles), the oracle's constrained paths against an independent bound-constrained solve / KKT certificates built from
+the returned duals (the reference's test_solver.py does this with cvxpy, which is not in this image), user-defined constraint
+classes through the callback route, the error behaviour, and — on the GPU — the HIP path against the oracle."""
 import numpy as np
 import pytest
 from scipy.optimize import minimize
@@ -193,21 +194,19 @@ def test_constraint_errors(oracle):
     d = make_gaussian(60, 8, seed=1)
     X, glm = oracle.dense(d["X"]), ad.glm.gaussian(d["y"])
     two = constraint.box(np.array([-1.0, -1.0]), np.array([1.0, 1.0]))
-    with pytest.raises(NotImplementedError, match="one coefficient"):
-        ad.grpnet(X, glm, groups=np.arange(0, 8, 2), constraints=[two, None, None, None], progress_bar=False)
     c = constraint.lower(np.zeros(1))
     with pytest.raises(RuntimeError, match="distinct objects"):
         ad.grpnet(X, glm, constraints=[c, c] + [None] * 6, progress_bar=False)
     with pytest.raises(RuntimeError, match="group's size"):
         ad.grpnet(X, glm, groups=np.arange(0, 8, 2), constraints=[c, None, None, None], progress_bar=False)
 
-    class mine:
+    class mine:  # not a ConstraintBase
         primal_size = dual_size = 1
 
         def clear(self):
             pass
 
-    with pytest.raises(NotImplementedError, match="user-defined"):
+    with pytest.raises(RuntimeError, match="ConstraintBase"):
         ad.grpnet(X, glm, constraints=[mine()] + [None] * 7, progress_bar=False)
     y2 = np.stack([d["y"], -d["y"]], axis=1)
     with pytest.raises(NotImplementedError, match="multi-response"):
@@ -367,3 +366,292 @@ def test_hip_constrained_singletons_inside_a_grouped_problem(hip, oracle, monkey
     assert np.abs(st.abs_grad - ref.abs_grad).max() < 1e-6
     # same groups screened (the order inside one screening step follows the sort of scores that agree to rounding only)
     assert np.array_equal(np.sort(st.screen_set), np.sort(ref.screen_set))
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# groups of several coefficients: the proximal-Newton solvers (constraint/utils.hpp:24-243, constraint_box.ipp:98-250,
+# constraint_one_sided.ipp:140-262)
+# --------------------------------------------------------------------------------------------------------------------
+def _checker_solve(oracle, kind, a, b, x, quad, linear, l1, l2, Q, mu):
+    import ctypes as C
+
+    be = oracle.backend()
+    f = be.lib.oracle_constraint_solve
+    vp = C.c_void_p
+    f.argtypes = [C.c_int, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp]
+    Qf = np.asfortranarray(Q, dtype=float)
+    rc = f(kind, len(x), a.ctypes.data, b.ctypes.data, None, x.ctypes.data, quad.ctypes.data, linear.ctypes.data, l1, l2,
+           Qf.ctypes.data, mu.ctypes.data)
+    assert rc == 0, be.fn("last_error")()
+
+
+def _random_group_problem(rng, d, box):
+    Q = np.linalg.qr(rng.randn(d, d))[0]
+    quad = rng.uniform(0.1, 2, d)
+    lin = rng.randn(d) * rng.choice([0.3, 1, 3])
+    l1, l2 = rng.uniform(0, 1), rng.uniform(0, 0.5)
+    if box:
+        lo = -rng.uniform(0, 1, d) * (rng.rand(d) < 0.8)
+        up = rng.uniform(0, 1, d) * (rng.rand(d) < 0.8)
+        return Q, quad, lin, l1, l2, constraint.box(lo, up), 4, lo, up
+    sg = rng.choice([-1.0, 1.0], d)
+    bb = rng.uniform(0, 1, d) * (rng.rand(d) < 0.8)
+    return Q, quad, lin, l1, l2, constraint.one_sided(sg, bb), 5, sg, bb
+
+
+@pytest.mark.parametrize("box", [True, False])
+def test_prox_newton_objects_match_the_checker_and_first_principles(oracle, box):
+    """The product's numpy restatement of the reference's solver and the checker's C++ one are written independently of each
+    other: they agree to rounding on random group problems, and the result satisfies the KKT system of
+    min 1/2 x'Dx - v'x + l1|x| + l2/2|x|^2  s.t.  A Q x <= b  (reference tests/test_constraint.py:6-64 for d > 1)."""
+    rng = np.random.RandomState(11 if box else 12)
+    worst, n_active, n_zero = 0.0, 0, 0
+    for trial in range(200):
+        d = rng.randint(2, 9)
+        Q, quad, lin, l1, l2, obj, kind, a, b = _random_group_problem(rng, d, box)
+        assert obj.primals() == obj.duals() == d
+        x0 = rng.randn(d) * (rng.rand() < 0.5)
+        xp = x0.copy()
+        obj.solve(xp, quad, lin, l1, l2, Q)
+        xo, muo = x0.copy(), np.zeros(d)
+        _checker_solve(oracle, kind, a, b, xo, quad, lin, l1, l2, Q, muo)
+        worst = max(worst, np.abs(xp - xo).max(), np.abs(obj._mu - muo).max())
+        # first principles
+        z = Q @ xp
+        g = np.empty(d)
+        obj.gradient(xp, g)                      # A' mu
+        lagr = (quad + l2) * xp - lin + Q.T @ g
+        nx = np.linalg.norm(xp)
+        if nx > 0:
+            assert np.linalg.norm(lagr + l1 * xp / nx) < 2e-5
+        else:
+            n_zero += 1
+            assert np.linalg.norm(lagr) <= l1 + 2e-5
+        assert np.max(obj.evaluate(z)) < 1e-4    # primal feasibility
+        mu = obj._mu
+        if box:
+            assert np.all(np.maximum(mu, 0) * (b - z) < 1e-3) and np.all(np.maximum(-mu, 0) * (z - a) < 1e-3)
+        else:
+            assert np.all(mu >= 0) and np.all(mu * (b - a * z) < 1e-3)
+        n_active += int(np.any(mu != 0))
+    assert worst < 1e-9, worst
+    assert n_active > 40 and n_zero > 5          # the grid exercises binding constraints and the x = 0 branches
+
+
+def _group_problem(p, rng, G, frac=0.5, zero_boxes=False):
+    """Random grouping; every other constrained group a box (some sides at 0 or absent), the rest one-sided.  Two identical
+    lists (one per engine: the objects keep state)."""
+    groups = np.sort(np.concatenate([[0], rng.choice(np.arange(1, p), size=G - 1, replace=False)])).astype(int)
+    sizes = np.diff(np.concatenate([groups, [p]]))
+    chosen = set(rng.choice(G, int(frac * G), replace=False).tolist())
+    spec = []
+    for g, q in enumerate(sizes):
+        if g not in chosen:
+            spec.append(None)
+        elif zero_boxes:
+            spec.append(("box", np.zeros(q), np.zeros(q)))   # the reference's own test constraint (test_solver.py zero_constraint)
+        elif g % 2 == 0:
+            lo = -rng.uniform(0.02, 0.3, q) * (rng.rand(q) < 0.7)
+            up = rng.uniform(0.02, 0.3, q) * (rng.rand(q) < 0.7)
+            spec.append(("box", lo, up))
+        else:
+            spec.append(("one", rng.choice([-1.0, 1.0], q), rng.uniform(0.0, 0.3, q) * (rng.rand(q) < 0.8)))
+
+    def make():
+        return [None if s is None else (constraint.box(s[1], s[2]) if s[0] == "box" else constraint.one_sided(s[1], s[2]))
+                for s in spec]
+
+    return groups, sizes, spec, make
+
+
+def _constrained_kkt(X, y, groups, sizes, penalty, alpha, st, cons, tol):
+    """First-principles certificate of a constrained Gaussian path from the returned coefficients and duals: stationarity of
+    every group with its multipliers, feasibility, dual feasibility, complementary slackness."""
+    n = X.shape[0]
+    B = st.betas.toarray()
+    D = st.duals.toarray()
+    dg = np.asarray(st.dual_groups)
+    worst = 0.0
+    for l, lm in enumerate(st.lmdas):
+        b = B[l]
+        r = y - X @ b - st.intercepts[l]
+        worst = max(worst, abs(r.mean()))
+        grad = X.T @ r / n
+        for g, (k, q, pen) in enumerate(zip(groups, sizes, penalty)):
+            gg, bb = grad[k:k + q], b[k:k + q]
+            c = cons[g]
+            if c is None:
+                Atmu = np.zeros(q)
+            else:
+                mu = D[l, dg[g]:dg[g] + c.duals()]
+                Atmu = np.empty(q)
+                c.gradient(bb, mu, Atmu)
+                worst = max(worst, np.max(c.evaluate(bb)))                       # feasibility
+                ev = c.evaluate(bb)
+                if len(ev) == len(mu):                                           # one-sided: mu >= 0, mu * slack = 0
+                    worst = max(worst, np.max(-mu), np.max(np.abs(mu * ev)))
+                else:                                                            # box: (mu)_+ with the upper, (mu)_- with the lower side
+                    worst = max(worst, np.max(np.abs(np.maximum(mu, 0) * ev[:q])), np.max(np.abs(np.maximum(-mu, 0) * ev[q:])))
+            e = gg - lm * (1 - alpha) * pen * bb - Atmu
+            nb = np.linalg.norm(bb)
+            if nb == 0:
+                worst = max(worst, np.linalg.norm(e) - lm * alpha * pen)
+            else:
+                worst = max(worst, np.linalg.norm(e - lm * alpha * pen * bb / nb))
+    assert worst < tol, worst
+
+
+@pytest.mark.parametrize("n, p, G", [[10, 50, 10], [40, 13, 7], [120, 60, 14]])
+@pytest.mark.parametrize("zero_boxes", [False, True])
+def test_oracle_paths_with_constrained_groups_are_optimal(oracle, n, p, G, zero_boxes):
+    """The reference's recipe (tests/test_solver.py:899-975: random grouping, half of the groups constrained — there with a
+    box pinned at zero — tol = 1e-10), checked through the KKT system with the returned duals instead of cvxpy."""
+    d = make_gaussian(n, p, seed=3)
+    X, y = d["X"], d["y"]
+    groups, sizes, spec, make = _group_problem(p, np.random.RandomState(5), G, zero_boxes=zero_boxes)
+    cons = make()
+    penalty = np.sqrt(sizes)
+    st = ad.grpnet(oracle.dense(X), ad.glm.gaussian(y), groups=groups, constraints=cons, alpha=0.8, tol=1e-12,
+                   lmda_path_size=12, min_ratio=0.05, early_exit=False, progress_bar=False)
+    assert st.error == "" and len(st.lmdas) == 12
+    assert st.duals.shape == (12, sum(0 if c is None else c.duals() for c in cons))
+    _constrained_kkt(X, y, groups, sizes, penalty, 0.8, st, cons, 5e-5)
+    B = st.betas.toarray()
+    for g, c in enumerate(cons):
+        if c is not None:
+            assert np.max(c.evaluate(B[-1, groups[g]:groups[g] + sizes[g]])) < 1e-5
+    if zero_boxes:
+        for g, c in enumerate(cons):
+            if c is not None:
+                assert np.all(B[:, groups[g]:groups[g] + sizes[g]] == 0)
+    else:
+        assert st.duals.nnz > 0  # constraints bind somewhere on the path
+
+
+class _Disc(constraint.ConstraintBase):
+    """A user-defined constraint the library knows nothing about: ||x||_inf <= r written as 2d one-sided rows, solved by
+    delegating to a box object but reporting its multipliers in its own 2d layout (mu_+ first, mu_- second)."""
+
+    def __init__(self, d, r):
+        super().__init__(d, np.float64)
+        self.dual_size = 2 * d
+        self._inner = constraint.box(np.full(d, -r), np.full(d, r))
+        self._r = r
+        self.calls = 0
+
+    def duals(self):
+        return 2 * self.primal_size
+
+    def solve(self, x, quad, linear, l1, l2, Q, buffer=None):
+        self.calls += 1
+        self._inner.solve(x, quad, linear, l1, l2, Q)
+
+    def gradient(self, x, *args):
+        if len(args) == 1:
+            self._inner.gradient(x, args[0])
+        else:
+            mu, out = args
+            d = self.primal_size
+            out[...] = mu[:d] - mu[d:]
+
+    def solve_zero(self, v, buffer=None):
+        return self._inner.solve_zero(v)
+
+    def evaluate(self, x):
+        return np.concatenate([x - self._r, -x - self._r])
+
+    def clear(self):
+        self._inner.clear()
+
+    def duals_nnz(self):
+        return int(np.count_nonzero(self._inner._mu))
+
+    def dual(self, indices, values):
+        mu = self._inner._mu
+        d = self.primal_size
+        k = 0
+        for i in np.flatnonzero(mu > 0):
+            indices[k], values[k] = i, mu[i]
+            k += 1
+        for i in np.flatnonzero(mu < 0):
+            indices[k], values[k] = d + i, -mu[i]
+            k += 1
+
+
+def test_user_defined_constraint_class_through_the_callbacks(oracle):
+    d = make_gaussian(150, 24, seed=8)
+    X, y = d["X"], d["y"]
+    groups = np.arange(0, 24, 4)
+    mine = [_Disc(4, 0.15) if g % 2 == 0 else None for g in range(6)]
+    builtin = [constraint.box(np.full(4, -0.15), np.full(4, 0.15)) if g % 2 == 0 else None for g in range(6)]
+    kw = dict(groups=groups, alpha=0.9, tol=1e-12, lmda_path_size=10, min_ratio=0.05, early_exit=False, progress_bar=False)
+    a = ad.grpnet(oracle.dense(X), ad.glm.gaussian(y), constraints=mine, **kw)        # calls back into Python
+    b = ad.grpnet(oracle.dense(X), ad.glm.gaussian(y), constraints=builtin, **kw)     # the checker's own C++ solver
+    assert a.error == "" and b.error == "" and mine[0].calls > 0
+    assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-9
+    assert a.duals.shape == (10, 3 * 8) and b.duals.shape == (10, 3 * 4)
+    A, Bd = a.duals.toarray(), b.duals.toarray()
+    for k in range(3):  # mu_+ - mu_- of the user class = the box multiplier
+        assert np.abs((A[:, 8 * k:8 * k + 4] - A[:, 8 * k + 4:8 * k + 8]) - Bd[:, 4 * k:4 * k + 4]).max() < 1e-9
+    assert b.duals.nnz > 0
+
+    class Broken(_Disc):
+        def solve(self, *args, **kwargs):
+            raise ValueError("no solution today")
+
+    with pytest.raises(ValueError, match="no solution today"):
+        ad.grpnet(oracle.dense(X), ad.glm.gaussian(y), constraints=[Broken(4, 0.1)] + [None] * 5, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["gaussian", "binomial"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_hip_constrained_groups_match_oracle(hip, oracle, family, dtype):
+    """Groups of several coefficients with box / one-sided constraints: the HIP path (group visits on the host through the
+    callbacks, everything else on the device) against the oracle (its own C++ restatement of the constraint solvers)."""
+    n, p, G = 400, 120, 30
+    d = make_gaussian(n, p, seed=21, sparsity=0.7, dtype=dtype)
+    X = d["X"]
+    groups, sizes, spec, make = _group_problem(p, np.random.RandomState(9), G)
+    f32 = dtype == np.float32
+    if family == "gaussian":
+        mk = lambda: ad.glm.gaussian(d["y"], dtype=dtype)
+        kw = dict(lmda_path_size=10, min_ratio=0.05, tol=1e-7 if f32 else 1e-13)
+    else:
+        rng = np.random.RandomState(2)
+        yb = (rng.uniform(size=n) < 1 / (1 + np.exp(-X[:, :6].astype(float) @ np.ones(6)))).astype(dtype)
+        mk = lambda: ad.glm.binomial(yb, dtype=dtype)
+        kw = dict(lmda_path_size=8, min_ratio=0.1, tol=1e-7 if f32 else 1e-13, irls_tol=1e-6 if f32 else 1e-11)
+    kw.update(groups=groups, alpha=0.7, early_exit=False)
+    co, ch = make(), make()
+    ref = _fit(oracle.dense(X), mk(), co, **kw)
+    st = _fit(ad.matrix.dense(X), mk(), ch, **kw)
+    assert st.error == "" and ref.error == "" and len(st.lmdas) == len(ref.lmdas)
+    tol = 2e-3 if f32 else 1e-7
+    B, R = st.betas.toarray(), ref.betas.toarray()
+    assert np.abs(B - R).max() < tol
+    assert np.abs(st.intercepts - ref.intercepts).max() < tol
+    assert st.duals.shape == ref.duals.shape and ref.duals.nnz > 0
+    assert np.abs((st.duals - ref.duals)).max() < (5e-3 if f32 else 1e-5)
+    assert np.abs(st.abs_grad - ref.abs_grad).max() < (1e-3 if f32 else 1e-6)
+    assert np.array_equal(np.sort(st.screen_set), np.sort(ref.screen_set))
+    for g, c in enumerate(ch):  # feasible, and the objects hold the multipliers of the last fit
+        if c is not None:
+            assert np.max(c.evaluate(B[-1, groups[g]:groups[g] + sizes[g]].astype(float))) < (1e-3 if f32 else 1e-5)
+            assert np.abs(c._mu - co[g]._mu).max() < (5e-3 if f32 else 1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_user_defined_constraint_class(hip, oracle):
+    d = make_gaussian(300, 48, seed=8)
+    X, y = d["X"], d["y"]
+    groups = np.arange(0, 48, 4)
+    mk = lambda: [_Disc(4, 0.1) if g % 3 == 0 else None for g in range(12)]
+    kw = dict(groups=groups, alpha=0.9, tol=1e-13, lmda_path_size=10, min_ratio=0.05, early_exit=False)
+    mine = mk()
+    st = _fit(ad.matrix.dense(X), ad.glm.gaussian(y), mine, **kw)
+    ref = _fit(oracle.dense(X), ad.glm.gaussian(y), mk(), **kw)
+    assert st.error == "" and mine[0].calls > 0
+    assert np.abs(st.betas.toarray() - ref.betas.toarray()).max() < 1e-7
+    assert st.duals.shape == ref.duals.shape == (10, 4 * 8)
+    assert np.abs((st.duals - ref.duals)).max() < 1e-5 and ref.duals.nnz > 0

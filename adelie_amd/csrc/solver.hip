@@ -1239,7 +1239,10 @@ struct Solver {
     // needed by the next screen pass anyway), copied to the host once, and the eigen-decompositions
     // (solver_gaussian_naive.hpp:105-125) are done on the host copies.
     std::vector<int32_t> gp_vbeg; // per block of the current partition: offset of its first value in the pass's column list
-    size_t group_maxblk() const { return size_t(2 * p / cd_block_size() + 2); }
+    // blocks a visiting list can be cut into: runs of groups with <= 128 values, plus the cuts before and after every group
+    // that is a block of its own (constraint objects visited on the host)
+    size_t n_host_cons = 0;
+    size_t group_maxblk() const { return size_t(2 * p / cd_block_size() + 2) + 2 * n_host_cons; }
     int build_partition_values(const idx* list, idx count) {
         const int nblk = build_partition(list, count);
         gp_vbeg.assign(size_t(nblk) + 1, 0);
@@ -2132,9 +2135,12 @@ struct Solver {
     // (d_gblk), its coefficients, variances and eigenbasis are read back, the object's solve runs through the callback, and the
     // changes go out the way a device solve leaves them (d_beta, the compacted (column, delta) list of the next step's
     // residual update, the pass state in d_blk).  Returns the pass state after the visit.
-    CdBlkState<T> host_group_visit(const CdParams<T>& cp, idx ss, bool mark) {
+    CdBlkState<T> host_group_visit(const CdParams<T>& cp, idx ss, bool mark, bool first_of_pass) {
         const idx g = screen_set[ss], q = group_sizes[g], b = screen_begins[ss];
         const size_t uq = static_cast<size_t>(q);
+        static const bool trace_hv = std::getenv("ADELIE_HIP_TRACE") != nullptr;
+        if (trace_hv) std::fprintf(stderr, "[host visit] ss=%lld g=%lld q=%lld b=%lld voff=%lld v_used=%zu nv=%lld\n", (long long)ss, (long long)g,
+                                   (long long)q, (long long)b, (long long)(size_t(ss) < h_voff.size() ? h_voff[size_t(ss)] : -1), v_used, (long long)nv);
         std::vector<T> gk(uq), ak(uq), Ak(uq), Vk(uq * uq, T(1));
         CdBlkState<T> bs{};
         int8_t was_active = 0;
@@ -2145,6 +2151,7 @@ struct Solver {
         d_blk.download(&bs, 1, st);
         d_isact.download(&was_active, 1, st, size_t(ss));
         sync();
+        if (first_of_pass) bs.cm = T(0); // the convergence measure is per pass (the device solves reset it in block 0)
         const T pk = penalty[g];
         const double l1 = double(cp.lmda * cp.alpha) * double(pk), l2 = double(cp.lmda * (T(1) - cp.alpha)) * double(pk);
         std::vector<double> gt(uq), a_old_t(uq), x(uq), quad(uq), lin(uq), Qd(uq * uq);
@@ -2483,7 +2490,7 @@ struct Solver {
                     const idx ss0 = screen_pass ? idx(part_host[size_t(j)]) : act_host[size_t(part_host[size_t(j)])];
                     if (part_host[size_t(j) + 1] - part_host[size_t(j)] == 1 && host_cons(screen_set[ss0])) {
                         if (blk_ev[size_t(j)]) AHIP_CHECK(hipStreamWaitEvent(st, blk_ev[size_t(j)], 0)); // (its eigenbasis)
-                        host_bs = host_group_visit(cp, ss0, screen_pass);
+                        host_bs = host_group_visit(cp, ss0, screen_pass, j == 0);
                         last_on_host = (j == nblk - 1);
                         continue;
                     }
@@ -3549,7 +3556,7 @@ struct Solver {
                 if (!a->constraint_a || !a->constraint_b) throw make_core_error("constraint_a and constraint_b are required.");
                 cons_m.assign(G, 0);
                 for (idx g = 0; g < G; ++g)
-                    if (a->constraint_kind[g] == ADELIE_HIP_CONSTRAINT_HOST) cons_host = true;
+                    if (a->constraint_kind[g] == ADELIE_HIP_CONSTRAINT_HOST) { cons_host = true; ++n_host_cons; }
                 if (cons_host) {
                     if (!a->constraint_cb || !a->constraint_cb->solve || !a->constraint_cb->gradient ||
                         !a->constraint_cb->solve_zero || !a->constraint_cb->dual)

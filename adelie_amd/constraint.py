@@ -13,7 +13,7 @@ Two routes into the solver (``adelie_hip_grpnet_args::constraint_kind``):
   callbacks of ``adelie_hip_constraint_callbacks`` — the role the reference's ``PyConstraintBase`` trampoline plays.
 
 After a solve every object holds the multipliers of the last fit (``dual`` / ``duals_nnz``), as the reference's objects do.
-``linear`` constraints are not implemented.
+``linear`` (a general matrix ``A``) is such a host object too.
 """
 from typing import Union
 
@@ -134,22 +134,19 @@ class _ProxNewton:
         self._cfg = cfg
 
     # hooks ------------------------------------------------------------------------------------------------------------
-    def _At(self, mu):            # A' mu
+    def _At(self, mu):            # A' mu, a vector of the group's size
         raise NotImplementedError
 
-    def _feasible_nearest(self, t):  # the feasible mu (under complementary slackness at x = 0) nearest to t in A-coordinates
+    def _nearest_at_zero(self, Qv, mu):
+        """Feasible multipliers (under complementary slackness at x = 0) whose ``A' mu`` is nearest to ``Qv``."""
         raise NotImplementedError
 
-    def _slack_grad(self, x, Q):  # A Q x - b  (box: Q x, its two bounds are handled by the sub-solver)
-        raise NotImplementedError
+    def _is_optimal(self, z, mu):  # z = Q x
+        return False
 
-    def _is_optimal(self, g, mu):
-        raise NotImplementedError
-
-    def _zero_grad(self):         # the slack vector at x = 0 as the convergence measure wants it
-        raise NotImplementedError
-
-    def _qp(self, hess, var, mu, g):
+    def _qp(self, hess, var, mu, z):
+        """One proximal-Newton step: the minimiser over the feasible multipliers of the quadratic model with Hessian
+        ``A hess A'`` around ``mu``, where ``z = Q x*(mu)``."""
         raise NotImplementedError
 
     # -----------------------------------------------------------------------------------------------------------------
@@ -171,7 +168,7 @@ class _ProxNewton:
 
         def nearest_at_zero(mu_now, may_restore):
             """Multipliers that best explain v while the primal stays 0; keeps the old ones when even those do not."""
-            cand = self._feasible_nearest(Qv)
+            cand = self._nearest_at_zero(Qv, mu_now)
             gap = float(np.sum(np.square(Qv - self._At(cand))))
             if may_restore and gap > l1 * l1:
                 return mu_now, gap
@@ -180,7 +177,7 @@ class _ProxNewton:
         x_zero_start = not np.any(x0)
         have_prev = False
         zero_checked = False
-        mu_prev = g_prev = None
+        Atmu_prev = z_prev = mu_prev = None
         rn_prev = -1.0
         if x_zero_start:
             zero_checked = True
@@ -189,7 +186,8 @@ class _ProxNewton:
                 return finish(0.0, mu)
         xv = x0
         for it in range(1, int(cfg["max_iters"]) + 1):
-            resid = v - self._At(mu) @ Q
+            Atmu = self._At(mu)
+            resid = v - Atmu @ Q
             rn = float(np.linalg.norm(resid))
             inside = rn <= l1
             xn = -1.0
@@ -200,37 +198,38 @@ class _ProxNewton:
             if inside:
                 if it == 1 and x_zero_start:
                     return finish(0.0, mu)
-                if have_prev and abs(np.mean((mu - mu_prev) * (g_prev - self._zero_grad()))) <= cfg["tol"]:
+                if have_prev and abs(np.mean((Atmu - Atmu_prev) * z_prev)) <= cfg["tol"]:
                     return finish(0.0, mu)
                 if not zero_checked:
                     zero_checked = True
                     had_prev = have_prev
                     if not had_prev:
                         rn_prev, have_prev = rn, True
-                        mu_prev, g_prev = mu.copy(), self._zero_grad()
+                        mu_prev, Atmu_prev, z_prev = mu.copy(), Atmu.copy(), np.zeros(len(v))
                     mu, gap = nearest_at_zero(mu, had_prev)
                     if gap <= l1 * l1:
                         return finish(0.0, mu)
                     if not had_prev:
                         continue
+                    Atmu = self._At(mu)
                 if (not have_prev) or rn_prev <= l1 * 0.9999 or rn > l1 * 1.0001:
                     raise RuntimeError("adelie_core: Possibly an unexpected error! Previous iterate should have been properly "
                                        "initialized. ")
                 target = (1 - cfg["slack"]) * l1 + cfg["slack"] * rn_prev
-                step_dir = mu - mu_prev
-                a = float(step_dir @ step_dir)
-                b = float(np.sum((self._A_of(Qv) - mu) * step_dir))
+                dAt = Atmu - Atmu_prev
+                a = float(dAt @ dAt)
+                b = float((Qv - Atmu) @ dAt)
                 c = rn * rn - target * target
                 t_star = (-b + np.sqrt(max(b * b - a * c, 0.0))) / a
-                mu = mu_prev + min(max(1 - t_star, 0.0), 1.0) * step_dir
+                mu = mu_prev + min(max(1 - t_star, 0.0), 1.0) * (mu - mu_prev)
                 continue
-            g = self._slack_grad(xv, Q)
-            if self._is_optimal(g, mu):
+            z = Q @ xv
+            if self._is_optimal(z, mu):
                 return finish(xv, mu)
-            if have_prev and abs(np.mean((mu - mu_prev) * (g_prev - g))) <= cfg["tol"]:
+            if have_prev and abs(np.mean((Atmu - Atmu_prev) * (z_prev - z))) <= cfg["tol"]:
                 return finish(xv, mu)
             rn_prev, have_prev = rn, True
-            mu_prev, g_prev = mu.copy(), g.copy()
+            mu_prev, Atmu_prev, z_prev = mu.copy(), Atmu.copy(), z.copy()
             # dual Hessian and the variance scale of the sub-solver's stopping rule (Woodbury)
             a_t = xv * b2 / xn
             kappa = 1.0 / float(np.sum(xv * b1 * a_t))
@@ -239,8 +238,30 @@ class _ProxNewton:
             xq = xv @ Q
             xy = float(xv @ xq)
             var = (float(np.sum(np.square(xq) / b2)) - xy * xy / (xn * xn / (l1 * kappa) + float(np.sum(np.square(xv) * b2)))) / xn
-            mu = self._qp(hess, max(var, 0.0), mu, g)
+            mu = self._qp(hess, max(var, 0.0), mu, z)
         raise RuntimeError("adelie_core solver: ConstraintBase: proximal newton max iterations reached!")
+
+    def _pinball(self, H, var, mu, g, lo_pen, up_pen):
+        """Coordinate descent from ``mu`` on ``1/2 m'Hm - (g + H mu)'m + up_pen'(m)_+ + lo_pen'(m)_-`` (pinball loss,
+        ``optimization/pinball_full.hpp:84-118``); ``g`` is the current gradient and is kept current."""
+        mu, g = mu.copy(), g.copy()
+        for _ in range(int(self._cfg["pinball_max_iters"])):
+            worst = 0.0
+            for i in range(len(mu)):
+                h = H[i, i]
+                if h <= 0:
+                    continue
+                g0 = g[i] + h * mu[i]
+                new = np.copysign(max(-lo_pen[i] - g0, g0 - up_pen[i], 0.0), g0 + lo_pen[i]) / h
+                dl = new - mu[i]
+                if dl == 0:
+                    continue
+                mu[i] = new
+                worst = max(worst, h * dl * dl)
+                g -= dl * H[:, i]
+            if worst < var * self._cfg["pinball_tol"]:
+                return mu
+        raise RuntimeError("adelie_core solver: StatePinballFull: max iterations reached!")
 
 
 class _Box(_ProxNewton, ConstraintBase):
@@ -274,45 +295,18 @@ class _Box(_ProxNewton, ConstraintBase):
     def _At(self, mu):
         return mu
 
-    def _A_of(self, t):
-        return t
-
-    def _feasible_nearest(self, t):
+    def _nearest_at_zero(self, Qv, mu):
         lo = np.where(self._lower >= 0, -MAX_SOLVER_VALUE, 0.0)
         hi = np.where(self._upper <= 0, MAX_SOLVER_VALUE, 0.0)
-        return np.minimum(np.maximum(t, lo), hi)
+        return np.minimum(np.maximum(Qv, lo), hi)
 
-    def _slack_grad(self, x, Q):
-        return Q @ x
-
-    def _zero_grad(self):
-        return np.zeros(self.primal_size)
-
-    def _is_optimal(self, g, mu):
+    def _is_optimal(self, z, mu):
         u, l = self._upper.astype(float), self._lower.astype(float)
-        return bool(np.all((g <= u) & (g >= l)) and np.all(np.maximum(mu, 0) * (g - u) == 0)
-                    and np.all(np.minimum(mu, 0) * (g - l) == 0))
+        return bool(np.all((z <= u) & (z >= l)) and np.all(np.maximum(mu, 0) * (z - u) == 0)
+                    and np.all(np.minimum(mu, 0) * (z - l) == 0))
 
-    def _qp(self, hess, var, mu, g):
-        """Coordinate descent on ``1/2 m'Hm - (g + H mu)'m + u'(m)_+ + l'(m)_-`` from ``mu`` (pinball loss)."""
-        u, l = self._upper.astype(float), -self._lower.astype(float)
-        mu, g = mu.copy(), g.copy()
-        d = len(mu)
-        for _ in range(int(self._cfg["pinball_max_iters"])):
-            worst = 0.0
-            for i in range(d):
-                h = hess[i, i]
-                g0 = g[i] + h * mu[i]
-                new = np.copysign(max(-l[i] - g0, g0 - u[i], 0.0), g0 + l[i]) / h
-                dl = new - mu[i]
-                if dl == 0:
-                    continue
-                mu[i] = new
-                worst = max(worst, h * dl * dl)
-                g -= dl * hess[:, i]
-            if worst < var * self._cfg["pinball_tol"]:
-                return mu
-        raise RuntimeError("adelie_core solver: StatePinballFull: max iterations reached!")
+    def _qp(self, hess, var, mu, z):
+        return self._pinball(hess, var, mu, z, -self._lower.astype(float), self._upper.astype(float))
 
     def evaluate(self, x):
         return np.concatenate([x - self._upper, self._lower - x])
@@ -380,26 +374,19 @@ class _OneSided(_ProxNewton, ConstraintBase):
     def _At(self, mu):
         return self._D * mu
 
-    def _A_of(self, t):
-        return self._D * t
-
-    def _feasible_nearest(self, t):
+    def _nearest_at_zero(self, Qv, mu):
         hi = np.where(self._b <= 0, MAX_SOLVER_VALUE, 0.0)
-        return np.minimum(np.maximum(self._D * t, 0.0), hi)
+        return np.minimum(np.maximum(self._D * Qv, 0.0), hi)
 
-    def _slack_grad(self, x, Q):
-        return self._D * (Q @ x) - self._b
-
-    def _zero_grad(self):
-        return -self._b.astype(float)
-
-    def _is_optimal(self, g, mu):
+    def _is_optimal(self, z, mu):
+        g = self._D * z - self._b
         return bool(np.all(g <= 0) and np.all(mu * g == 0))
 
-    def _qp(self, hess, var, mu, g):
-        """Coordinate ascent on the sign-constrained quadratic model, in the coordinates ``sgn * mu``."""
+    def _qp(self, hess, var, mu, z):
+        """Coordinate ascent on the sign-constrained quadratic model, in the coordinates ``sgn * mu``
+        (``optimization/nnqp_full.hpp:150-178``)."""
         sgn = self._D.astype(float)
-        m, g = mu * sgn, g * sgn
+        m, g = mu * sgn, (sgn * z - self._b) * sgn
         d = len(m)
         for _ in range(int(self._cfg["pinball_max_iters"])):
             worst = 0.0
@@ -484,8 +471,94 @@ def upper(b: np.ndarray, **kwargs):
     return one_sided(D=np.full(np.atleast_1d(b).shape[0], 1.0), b=np.atleast_1d(b), **kwargs)
 
 
-def linear(*args, **kwargs):
-    raise NotImplementedError("adelie_amd: linear constraints (constraint_linear.ipp) are not implemented.")
+class _Linear(_ProxNewton, ConstraintBase):
+    """``lower <= A x <= upper`` with ``lower <= 0 <= upper`` and a general ``(m, d)`` matrix ``A`` (``ConstraintLinear``,
+    ``constraint_linear.ipp``): ``m`` multipliers ``mu = mu_+ - mu_-``, the same dual proximal-Newton iteration with
+    ``A' mu`` in place of ``mu`` (``:275-470``).  The Newton step minimises the pinball-penalised quadratic model with Hessian
+    ``A hess A'`` (the reference's ``m < d`` branch, ``:408-418``; for ``m >= d`` it solves the same sub-problem through a
+    low-rank active-set variant), the multipliers at ``x = 0`` come from a sign-bounded least-squares fit of ``A' mu`` to
+    ``Q v`` (``:283-349``, the reference's NNLS; here :func:`scipy.optimize.lsq_linear`).  Always a host object."""
+
+    kind = KIND_HOST
+
+    def __init__(self, A, lower, upper, dtype, configs=None):
+        cfg = dict(configs or {})
+        for k in ("nnls_max_iters", "nnls_tol", "n_threads"):  # accepted for compatibility; the bounded least squares has its own
+            cfg.pop(k, None)
+        self._configure(cfg)
+        A = np.asarray(A.toarray() if hasattr(A, "toarray") else A, dtype=float)
+        if A.ndim != 2:
+            raise RuntimeError("adelie_core: A must be (m, d).")
+        m, d = A.shape
+        if lower.shape != (m,) or upper.shape != (m,):
+            raise RuntimeError("adelie_core: lower and upper must be (m,) where A is (m, d).")
+        if np.any(upper < 0):
+            raise RuntimeError("adelie_core: upper must be >= 0.")
+        if np.any(lower > 0):
+            raise RuntimeError("adelie_core: lower must be <= 0.")
+        ConstraintBase.__init__(self, d, dtype)
+        self.dual_size = m
+        self._mu = np.zeros(m, dtype=dtype)
+        self._A = A
+        self._lower = np.maximum(lower.astype(float), -MAX_SOLVER_VALUE)
+        self._upper = np.minimum(upper.astype(float), MAX_SOLVER_VALUE)
+
+    def duals(self):
+        return self.dual_size
+
+    def _abi(self):
+        return KIND_HOST, 0.0, 0.0
+
+    def _At(self, mu):
+        return self._A.T @ mu
+
+    def _sign_bounds(self):
+        lo = np.where(self._lower >= 0, -MAX_SOLVER_VALUE, 0.0)   # a negative multiplier needs an active lower bound at 0
+        hi = np.where(self._upper <= 0, MAX_SOLVER_VALUE, 0.0)
+        return lo, hi
+
+    def _nearest_at_zero(self, Qv, mu):
+        from scipy.optimize import lsq_linear
+
+        lo, hi = self._sign_bounds()
+        free = (lo < 0) | (hi > 0)
+        out = np.zeros_like(mu, dtype=float)
+        if np.any(free):
+            res = lsq_linear(self._A[free].T, Qv, bounds=(np.where(lo[free] < 0, -np.inf, 0.0), np.where(hi[free] > 0, np.inf, 0.0)),
+                             tol=1e-14, max_iter=1000)
+            out[free] = res.x
+        return out
+
+    def _qp(self, hess, var, mu, z):
+        A = self._A
+        return self._pinball(A @ hess @ A.T, var, mu, A @ z, -self._lower, self._upper)
+
+    def evaluate(self, x):
+        Ax = self._A @ x
+        return np.concatenate([Ax - self._upper, self._lower - Ax])
+
+    def gradient(self, x, *args):
+        mu, out = (self._mu, args[0]) if len(args) == 1 else args
+        out[...] = self._A.T @ mu
+
+    def solve_zero(self, v, buffer=None):
+        v = np.asarray(v, dtype=float)
+        self._mu[...] = self._nearest_at_zero(v, np.zeros(self.dual_size))
+        return float(np.linalg.norm(v - self._A.T @ self._mu))
+
+    def solve(self, x, quad, linear, l1, l2, Q, buffer=None):
+        return self._solve_multi(x, quad, linear, l1, l2, Q)
+
+
+def linear(A, lower: np.ndarray, upper: np.ndarray, *, vars: np.ndarray = None, copy: bool = False,
+           method: str = "proximal_newton", configs: dict = None, dtype: Union[np.float32, np.float64] = None):
+    """Linear constraint ``lower <= A x <= upper`` (``lower <= 0 <= upper``) for a dense / scipy-sparse ``(m, d)`` matrix ``A``;
+    reference ``constraint.py:137-306``.  ``vars`` (``diag(A A')``) and ``copy`` are accepted and not needed here."""
+    if method != "proximal_newton":
+        raise KeyError(method)
+    lower, ld = _coerce(lower, dtype)
+    upper, _ = _coerce(upper, ld)
+    return _Linear(A, lower, upper, ld, configs)
 
 
 def render_dual_groups(constraints):

@@ -79,8 +79,10 @@ def test_constructor_errors():
         constraint.one_sided(np.array([2.0]), np.array([1.0]))
     with pytest.raises(RuntimeError, match="b must be >= 0"):
         constraint.upper(np.array([-1.0]))
-    with pytest.raises(NotImplementedError):
-        constraint.linear(np.eye(2), np.zeros(2), np.ones(2))
+    with pytest.raises(RuntimeError, match="lower must be <= 0"):
+        constraint.linear(np.eye(2), np.ones(2), np.ones(2))
+    with pytest.raises(RuntimeError, match=r"must be \(m,\)"):
+        constraint.linear(np.eye(2), np.zeros(3), np.ones(3))
 
 
 def test_solve_zero_any_size():
@@ -490,8 +492,9 @@ def _constrained_kkt(X, y, groups, sizes, penalty, alpha, st, cons, tol):
                 ev = c.evaluate(bb)
                 if len(ev) == len(mu):                                           # one-sided: mu >= 0, mu * slack = 0
                     worst = max(worst, np.max(-mu), np.max(np.abs(mu * ev)))
-                else:                                                            # box: (mu)_+ with the upper, (mu)_- with the lower side
-                    worst = max(worst, np.max(np.abs(np.maximum(mu, 0) * ev[:q])), np.max(np.abs(np.maximum(-mu, 0) * ev[q:])))
+                else:                                                            # box / linear: (mu)_+ with the upper, (mu)_- with the lower side
+                    h = len(ev) // 2
+                    worst = max(worst, np.max(np.abs(np.maximum(mu, 0) * ev[:h])), np.max(np.abs(np.maximum(-mu, 0) * ev[h:])))
             e = gg - lm * (1 - alpha) * pen * bb - Atmu
             nb = np.linalg.norm(bb)
             if nb == 0:
@@ -664,3 +667,99 @@ def test_hip_user_defined_constraint_class(hip, oracle):
     assert np.abs(st.betas.toarray() - ref.betas.toarray()).max() < 1e-6
     assert st.duals.shape == ref.duals.shape == (10, 4 * 8)
     assert np.abs((st.duals - ref.duals)).max() < 1e-4 and ref.duals.nnz > 0
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# linear constraints  lower <= A x <= upper  (constraint_linear.ipp)
+# --------------------------------------------------------------------------------------------------------------------
+def test_linear_object_first_principles_and_box_equivalence():
+    rng = np.random.RandomState(31)
+    n_bind = 0
+    for trial in range(120):
+        d = rng.randint(2, 7)
+        m = rng.randint(1, 2 * d)
+        A = rng.randn(m, d)
+        lo = -rng.uniform(0, 0.5, m) * (rng.rand(m) < 0.8)
+        up = rng.uniform(0, 0.5, m) * (rng.rand(m) < 0.8)
+        Q = np.linalg.qr(rng.randn(d, d))[0]
+        quad = rng.uniform(0.1, 2, d)
+        lin = rng.randn(d) * rng.choice([0.5, 1, 3])
+        l1, l2 = rng.uniform(0, 1), rng.uniform(0, 0.5)
+        # (the sub-solver's default tolerance, 1e-7 as in the reference, leaves the bounds violated by up to ~2e-4 when m > d)
+        c = constraint.linear(A, lo, up, configs={"pinball_tol": 1e-12})
+        assert c.primals() == d and c.duals() == m
+        x = rng.randn(d) * (rng.rand() < 0.4)
+        c.solve(x, quad, lin, l1, l2, Q)
+        z = Q @ x
+        Az = A @ z
+        assert np.all(Az <= up + 1e-4) and np.all(Az >= lo - 1e-4)
+        mu = c._mu
+        g = np.empty(d)
+        c.gradient(x, g)
+        assert np.allclose(g, A.T @ mu)
+        lagr = (quad + l2) * x - lin + Q.T @ g
+        nx = np.linalg.norm(x)
+        if nx > 0:
+            assert np.linalg.norm(lagr + l1 * x / nx) < 1e-4
+        else:
+            assert np.linalg.norm(lagr) <= l1 + 1e-4
+        assert np.all(np.maximum(mu, 0) * (up - Az) < 2e-3) and np.all(np.maximum(-mu, 0) * (Az - lo) < 2e-3)
+        n_bind += int(np.any(mu != 0))
+    assert n_bind > 30
+    # A = I is the box constraint
+    for trial in range(40):
+        d = rng.randint(2, 6)
+        lo = -rng.uniform(0, 0.5, d)
+        up = rng.uniform(0, 0.5, d)
+        Q = np.linalg.qr(rng.randn(d, d))[0]
+        quad, lin = rng.uniform(0.1, 2, d), rng.randn(d) * 2
+        l1, l2 = rng.uniform(0, 1), rng.uniform(0, 0.5)
+        xa, xb = np.zeros(d), np.zeros(d)
+        ca, cb = constraint.linear(np.eye(d), lo, up), constraint.box(lo, up)
+        ca.solve(xa, quad, lin, l1, l2, Q)
+        cb.solve(xb, quad, lin, l1, l2, Q)
+        assert np.abs(xa - xb).max() < 1e-9 and np.abs(ca._mu - cb._mu).max() < 1e-8
+
+
+def _linear_problem(rng, p, gsz):
+    groups = np.arange(0, p, gsz)
+    spec = []
+    for g in range(len(groups)):
+        if g % 2 == 0:
+            m = rng.randint(1, gsz + 2)
+            spec.append((rng.randn(m, gsz), -rng.uniform(0, 0.2, m) * (rng.rand(m) < 0.7), rng.uniform(0.02, 0.2, m)))
+        else:
+            spec.append(None)
+    make = lambda: [None if s is None else constraint.linear(*s) for s in spec]
+    return groups, make
+
+
+def test_oracle_path_with_linear_constraints_is_optimal(oracle):
+    d = make_gaussian(150, 30, seed=13)
+    X, y = d["X"], d["y"]
+    groups, make = _linear_problem(np.random.RandomState(3), 30, 3)
+    cons = make()
+    st = ad.grpnet(oracle.dense(X), ad.glm.gaussian(y), groups=groups, constraints=cons, alpha=0.8, tol=1e-10,
+                   lmda_path_size=10, min_ratio=0.05, early_exit=False, progress_bar=False)
+    assert st.error == "" and len(st.lmdas) == 10
+    assert st.duals.shape == (10, sum(c.duals() for c in cons if c is not None)) and st.duals.nnz > 0
+    _constrained_kkt(X, y, groups, np.full(10, 3), np.sqrt(np.full(10, 3.0)), 0.8, st, cons, 5e-4)
+
+
+@pytest.mark.gpu
+def test_hip_linear_constraints_match_oracle(hip, oracle):
+    d = make_gaussian(300, 60, seed=14, sparsity=0.7)
+    X, y = d["X"], d["y"]
+    groups, make = _linear_problem(np.random.RandomState(4), 60, 4)
+    kw = dict(groups=groups, alpha=0.8, tol=1e-10, lmda_path_size=10, min_ratio=0.05, early_exit=False)
+    ch = make()
+    st = _fit(ad.matrix.dense(X), ad.glm.gaussian(y), ch, **kw)
+    ref = _fit(oracle.dense(X), ad.glm.gaussian(y), make(), **kw)
+    assert st.error == "" and ref.error == ""
+    assert np.abs(st.betas.toarray() - ref.betas.toarray()).max() < 1e-6
+    assert st.duals.shape == ref.duals.shape and ref.duals.nnz > 0
+    assert np.abs((st.duals - ref.duals)).max() < 1e-4
+    B = st.betas.toarray()
+    for g, c in enumerate(ch):
+        if c is not None:
+            assert np.max(c.evaluate(B[-1, groups[g]:groups[g] + 4])) < 1e-4

@@ -431,7 +431,7 @@ struct Solver {
     DevBuf<CdBlkState<T>> d_blk;
     DevBuf<T> d_Dbuf, d_dlt;
     DevBuf<int32_t> d_didx;
-    int64_t cd_block_min_nv = 256; // screen sets at least this large use the multi-CU block passes
+    int64_t cd_block_min_nv = 128; // screen sets at least this large use the multi-CU block passes (256 until round 3: 128 lets the speculative first pass cover ten more lambdas of the headline path, 292.9 -> 287.8 ms)
     // panel engine (kernels_cd_panel.hip): residual-based block passes with cached B x B diagonal blocks
     bool engine_panel = true;
     int panel_bsz = 0;          // 0: automatic (128 Gaussian, 64 IRLS); test/tuning hook ADELIE_HIP_PANEL_BSZ
@@ -1965,6 +1965,10 @@ struct Solver {
                 wait_pass_state(bs);
                 t_wait += sw_w.elapsed();
                 status = bs.status;
+                // an active-set pass never marks (CdBlkParams::mark == 0): the active list it leaves is the one it was
+                // speculated on, which is what makes spec_rollback's restore of beta and the residual complete
+                if (bs.active_size != int32_t(spec_asz))
+                    throw make_core_error("speculative pass changed the active set (internal error).");
                 asz = bs.active_size;
                 return bs.cm;
             }

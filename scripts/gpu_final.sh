@@ -1,5 +1,5 @@
 # End-of-round artefacts: full -m gpu suite, one bench line per config (with CPU baselines), rocprof summaries.
-TAG=${1:-r02}
+TAG=${1:-r03}
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_final_pytest.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/${TAG}_final_pytest.log
 tail -3 gpurun_out/${TAG}_final_pytest.log

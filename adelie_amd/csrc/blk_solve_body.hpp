@@ -379,7 +379,8 @@ __device__ __forceinline__ void blk_solve_la_body(const CdBlkParams<T>& p, int j
     {
         const V* dsrc = reinterpret_cast<const V*>(p.Dptr);
 #pragma unroll
-        for (int u = 0; u < ND; ++u) dreg[u] = dsrc[tid + u * 1024];
+        for (int u = 0; u < ND; ++u) // (columns [0, nb) of the slot; blocks of 64 visits fetch half of it)
+            if ((tid + u * 1024) / CPC < nb) dreg[u] = dsrc[tid + u * 1024];
         if (has_c) {
             const V* csrc = reinterpret_cast<const V*>(p.Cprev);
 #pragma unroll
@@ -424,7 +425,8 @@ __device__ __forceinline__ void blk_solve_la_body(const CdBlkParams<T>& p, int j
     {
         V* dst = reinterpret_cast<V*>(D);
 #pragma unroll
-        for (int u = 0; u < ND; ++u) dst[tid + u * 1024] = dreg[u];
+        for (int u = 0; u < ND; ++u)
+            if ((tid + u * 1024) / CPC < nb) dst[tid + u * 1024] = dreg[u];
     }
     if (tid < BLK) dB[tid] = pd; // (dB doubles as the staging of pdd until the loop is over)
     __syncthreads();

@@ -15,6 +15,7 @@
 // Kernel boundaries on the stream are the only synchronisation (cheaper than any grid barrier on this chip, see
 // guides/MI355X_MICROARCH.md "boundary" vs "barrier-xcd").  The result is the same Gauss–Seidel sequence: inside a block
 // every coordinate sees all earlier changes of the block through D_j, across blocks through the update kernel.
+#include <cstdlib>
 #include "kernels.hpp"
 #include "blk_solve_body.hpp"
 
@@ -113,6 +114,15 @@ __global__ __launch_bounds__(1024) void cd_compact_kernel(const T* __restrict__ 
 }
 
 
+// The panel solve of one block as its own launch, with the one-round-trip prologue of the fused launch (blk_solve_la_body: all
+// 1024 threads fetch, one wavefront visits): the plain passes of the IRLS paths run it once per block (config 4: 54 k
+// launches per path, 29 us each with the 256-thread body and its four to five dependent round trips)
+template <class T>
+__global__ __launch_bounds__(1024) void blk_solve_la_kernel(CdBlkParams<T> p, int j) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    blk_solve_la_body<T>(p, j, smem_raw, threadIdx.x);
+}
+
 } // namespace
 
 int cd_block_size() { return BLK; }
@@ -158,6 +168,19 @@ void launch_cd_panel_solve(const CdBlkParams<T>& p, int j, hipStream_t s) {
             cons_attr_done = true;
         }
         hipLaunchKernelGGL((blk_solve_cons_kernel<T>), dim3(1), dim3(256), blk_solve_lds<T>(), s, p, j);
+        return;
+    }
+    static const bool wide = !(std::getenv("ADELIE_HIP_SOLVE_WIDE") && std::atoi(std::getenv("ADELIE_HIP_SOLVE_WIDE")) == 0);
+    if (wide) {
+        static bool la_attr_done = false;
+        if (!la_attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk_solve_la_kernel<double>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(blk_solve_lds_la<double>()));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk_solve_la_kernel<float>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(blk_solve_lds_la<float>()));
+            la_attr_done = true;
+        }
+        hipLaunchKernelGGL((blk_solve_la_kernel<T>), dim3(1), dim3(1024), blk_solve_lds_la<T>(), s, p, j);
         return;
     }
     hipLaunchKernelGGL((blk_solve_kernel<T, true>), dim3(1), dim3(256), blk_solve_lds<T>(), s, p, j);

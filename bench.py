@@ -22,7 +22,10 @@ Multi-GPU (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus 
     end.  Per-GPU work is fixed: ``"scaling": "weak"``; ``value`` = paths of all ranks / max-over-ranks wall.
   * config 5: ONE 8-fold CV whose folds are sharded over the ranks (fold k on rank k % N, one all_gather of the loss
     table): total work is fixed, ``"scaling": "strong"``.
-  * the default line (config 2) additionally carries ``"cv_config5"``: the same sharded CV timed right after the headline
+  * the default line (config 2) additionally carries the legs ``"cfg3"``, ``"f32"`` (config 2 in single precision) and
+    ``"cfg4"`` — the same measurement as ``--config 3 / 4`` with fewer steps, each with its own roofline objects — unless
+    ``--no-extra-legs`` is given (profiling runs), and
+  * ``"cv_config5"``: the same sharded CV timed right after the headline
     steps, so that a ``--gpus 1/2/4/8`` series holds BASELINE.json's second target (8-fold CV at 1/2/4/8 GPUs) as well.
 """
 import argparse

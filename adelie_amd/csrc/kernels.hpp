@@ -91,6 +91,23 @@ void launch_gram_batch(const DenseView<T>& X, const T* w, const int32_t* cols_ba
 template <class T>
 void launch_gram_batch_snp(const SnpView& X, const T* impute, const T* w, const int32_t* cols_base, const GramBatch& b,
                            const T* xm_by_col, bool center, T* C_base, int64_t ldc, T* work, hipStream_t s);
+// The new rows of a panel block (kernels_strip.hip): strip y = the m[y] <= 64 columns cols_base[voff[y] ...] against the c0n[y]
+// columns cols_base[c0off[y] ...] of the previous block and the c1n[y] columns cols_base[c1off[y] ...] of the block itself
+// (c0n + c1n <= 256; the new columns are the last m[y] of the own block, i.e. its members [row0, row0 + m)):
+//   X_base[dstX[y] + (row0 + r) + c ldc]            = v_r^T W x_c - xm xm     c <  c0n   (rows of the cross block)
+//   D_base[dstD[y] + (row0 + r) + c' ldc] and mirror = v_r^T W x_c' - xm xm   c' < c1n   (rows / columns of the diagonal block)
+struct StripBatch {
+    static constexpr int MAX = 8;
+    int32_t voff[MAX], m[MAX], c0off[MAX], c0n[MAX], c1off[MAX], c1n[MAX], row0[MAX];
+    int64_t dstX[MAX], dstD[MAX];
+    int32_t count;
+};
+int strip_row_tiles(int m);                 // 16-row tiles the strip kernel is instantiated for (0: more rows than it takes)
+int64_t strip_work_elems(int64_t n, int count, int m_max);
+void set_strip_workgroups(int wgs);         // spread of the next strip builds launched by this host thread (default 512)
+template <class T>
+void launch_strip_batch(const DenseView<T>& X, const T* w, const int32_t* cols_base, const StripBatch& b, const T* xm_by_col,
+                        bool center, T* D_base, T* X_base, int64_t ldc, T* work, hipStream_t s);
 void set_small_gram_workgroups(int wgs); // kernels_gram.hip: spread of the next small builds launched by this host thread
 template <class T>
 void launch_syrk_batch(const DenseView<T>& X, const T* w, const int32_t* cols_base, const SyrkBatch& b, const T* xm_by_col,

@@ -17,8 +17,7 @@
 // ds_read_b64 from rows padded to 34 elements (conflict free for the 16x4 fragment shape), the weights of the stage
 // sit in LDS and scale the B fragment.  Global loads for stage t+1 are issued before the MFMAs of stage t.
 // K-splits write partial tiles; a second kernel sums them (deterministic), centres, and writes C symmetrically.
-#include "kernels.hpp"
-#include "accessors.hpp"
+#include "gram_common.hpp"
 
 namespace ahip {
 
@@ -32,49 +31,6 @@ constexpr int BM = 128, KT = 32, LDK = KT + 2, GT = 256;
 // need ~200 whole CUs, and a build that occupies every CU makes each of them wait.  Per host thread: set right before the
 // launches it is meant for.
 thread_local int t_small_gram_wgs = 512;
-
-typedef double d4_t __attribute__((ext_vector_type(4)));
-typedef unsigned u4v_t __attribute__((ext_vector_type(4)));
-typedef float f4v_t __attribute__((ext_vector_type(4)));
-
-template <class T> struct Mfma;
-template <> struct Mfma<double> {
-    using acc_t = d4_t;
-    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
-        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
-};
-template <> struct Mfma<float> {
-    using acc_t = f4v_t;
-    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
-        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) * 4 + reg; }
-};
-
-// Loads R consecutive rows [k, k+R) of column j (zero beyond kend / for an invalid column).
-template <class T, class Acc, bool VECOK, int R>
-__device__ __forceinline__ void load_rows(const Acc& X, int64_t j, bool valid, int64_t k, int64_t kend, T (&r)[R]) {
-    if (!valid || k >= kend) {
-#pragma unroll
-        for (int e = 0; e < R; ++e) r[e] = T(0);
-        return;
-    }
-    auto cp = X.colptr(j);
-    constexpr int V = VecOf<T>::N;
-    if (VECOK && k + R <= kend) {
-#pragma unroll
-        for (int u = 0; u < R / V; ++u) {
-            const Pack<T, V> x = X.template load<V>(cp, k + u * V, j);
-#pragma unroll
-            for (int e = 0; e < V; ++e) r[u * V + e] = x.v[e];
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < R; ++e) r[e] = (k + e < kend) ? X.template load<1>(cp, k + e, j).v[0] : T(0);
-    }
-}
 
 // Block tile BM x BN = 128 x {64,128}; 4 waves: 2x2 of 64x64 (BN=128) or 4x1 of 32x64 (BN=64).
 // WNX = 4 (BN = 128): the four waves side by side, each 128 rows x 32 columns (8 x 2 MFMA tiles) — the "row strip" form of

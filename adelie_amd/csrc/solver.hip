@@ -664,6 +664,7 @@ struct Solver {
         if (pass_e0) (void)hipEventDestroy(pass_e0);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         for (hipEvent_t e : pre_pool) (void)hipEventDestroy(e);
+        for (hipEvent_t e : strip_pool) (void)hipEventDestroy(e);
     }
     // ---- look-ahead form of the Gaussian panel passes (run_panel_passes) ----
     // The solve of block j (one wavefront, strictly sequential) and the panel step that prepares block j+1 only meet through
@@ -809,6 +810,127 @@ struct Solver {
             k.nb_prev = nbp; k.nb = nb; k.ver = w_version;
             ++n_cross_blocks;
         }
+    }
+    // ---- strip builds (kernels_strip.hip): only the NEW rows of a block's diagonal and cross block ----
+    // Gaussian passes over a dense design: both visiting lists are append-only and the weights are fixed, so a block that
+    // gained m <= 64 members since its blocks were built needs the m x (|previous block| + |block|) strip of the newcomers
+    // and nothing else.  One HBM-bound launch (+ reduce) per batch of strips replaces a full syrk build (128 x 128, 36 MFMA
+    // tiles) plus a staged cross build whose cost does not shrink with the row count: 71 us against 282 us for 16 new
+    // members of a full block pair at n = 100k (scripts/ubench/strip.hip).  Runs before build_stale_blocks /
+    // build_stale_cross, which then find these blocks fresh; blocks with more new members stay with them.
+    // Hook ADELIE_HIP_STRIP_BUILDS=0.
+    bool strip_builds = true;
+    int strip_max_m = 128;
+    std::vector<hipEvent_t> strip_pool, strip_ev;
+    size_t strip_used = 0;
+    int64_t n_strip_builds = 0;
+    hipEvent_t next_strip_event() {
+        if (strip_used == strip_pool.size()) {
+            hipEvent_t e;
+            AHIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            strip_pool.push_back(e);
+        }
+        return strip_pool[strip_used++];
+    }
+    bool strips_apply() const { return strip_builds && dense() && !is_glm() && !rot_on; }
+    template <class NbOf, class ColsOf>
+    void build_stale_strips(int nblk, std::vector<int32_t>& tab_nb, std::vector<uint64_t>& tab_ver, std::vector<XKey>* xtab,
+                            T* pool, T* xpool, NbOf nb_of, ColsOf cols_of) {
+        strip_ev.assign(size_t(nblk), nullptr);
+        strip_used = 0;
+        if (!strips_apply()) return;
+        const int SL = cd_block_size();
+        const bool side = side_grams && st2 != nullptr;
+        hipStream_t gs = side ? st2 : st;
+        bool first = true;
+        const int32_t* cols_base = cols_of(0);
+        StripBatch sb{};
+        int js[StripBatch::MAX];
+        auto flush = [&]() {
+            if (sb.count == 0) return;
+            if (side && first) {
+                if (pass_e0_valid) {
+                    AHIP_CHECK(hipStreamWaitEvent(st2, pass_e0, 0));
+                } else {
+                    hipEvent_t e0 = next_strip_event();
+                    AHIP_CHECK(hipEventRecord(e0, st));
+                    AHIP_CHECK(hipStreamWaitEvent(st2, e0, 0));
+                }
+                first = false;
+            }
+            int mx = 0;
+            for (int y = 0; y < sb.count; ++y) mx = std::max(mx, int(sb.m[y]));
+            T* work = (side ? d_work_gram2 : d_work_gram).reserve(size_t(strip_work_elems(n, sb.count, mx)));
+            t_gram.begin(gs);
+            launch_strip_batch<T>(D->dense<T>(), cur_w, cols_base, sb, cur_xm, intercept, pool, xpool, SL, work, gs);
+            t_gram.end(gs);
+            hipEvent_t e = nullptr;
+            if (side) {
+                e = next_strip_event();
+                AHIP_CHECK(hipEventRecord(e, st2));
+            }
+            for (int y = 0; y < sb.count; ++y) {
+                const int j = js[y];
+                strip_ev[size_t(j)] = e;
+                tab_nb[size_t(j)] = nb_of(j);
+                tab_ver[size_t(j)] = w_version;
+                if (xtab && j > 0) {
+                    XKey& key = (*xtab)[size_t(j)];
+                    key.nb_prev = nb_of(j - 1); key.nb = nb_of(j); key.ver = w_version;
+                }
+                cnt.gram_flops += 2.0 * double(n) * double(sb.m[y]) * double(sb.c0n[y] + sb.c1n[y]);
+                cnt.n_gram_col_reads += sb.m[y] + sb.c0n[y] + sb.c1n[y];
+                if (y == 0 || js[y - 1] != j) ++n_strip_builds;
+            }
+            sb = StripBatch{};
+        };
+        for (int j = 0; j < nblk; ++j) {
+            const int nb = nb_of(j);
+            const bool want_x = xtab != nullptr && j > 0;
+            const bool d_ok = tab_nb[size_t(j)] == nb && tab_ver[size_t(j)] == w_version;
+            bool x_ok = true;
+            int have = (tab_ver[size_t(j)] == w_version && tab_nb[size_t(j)] <= nb) ? tab_nb[size_t(j)] : 0;
+            if (want_x) {
+                const XKey& key = (*xtab)[size_t(j)];
+                const bool base = key.ver == w_version && key.nb_prev == nb_of(j - 1) && key.nb <= nb;
+                x_ok = base && key.nb == nb;
+                have = std::min(have, base ? int(key.nb) : 0);
+            }
+            if (d_ok && x_ok) continue;
+            const int m = nb - have;
+            if (m <= 0 || m > strip_max_m) continue; // (left to the staged builders)
+            const int64_t off1 = cols_of(j) - cols_base, off0 = want_x ? cols_of(j - 1) - cols_base : 0;
+            if (off1 < 0 || off1 > (int64_t(1) << 30)) continue;
+            // more than 64 new members: two strips of the same launch.  A strip only needs the columns of its block up to
+            // its own last row: the rest of its rows of D lies above the diagonal of the new x new square and comes from
+            // the mirror of the other strip's rows.
+            const int pieces = m > 64 ? 2 : 1;
+            if (sb.count + pieces > StripBatch::MAX) flush();
+            for (int q = 0; q < pieces; ++q) {
+                const int r0 = have + (q == 0 ? 0 : (m + 1) / 2), r1 = (q + 1 == pieces) ? nb : have + (m + 1) / 2;
+                const int y = sb.count++;
+                js[y] = j;
+                sb.voff[y] = int32_t(off1) + r0;
+                sb.m[y] = r1 - r0;
+                sb.c0off[y] = int32_t(off0);
+                sb.c0n[y] = want_x ? nb_of(j - 1) : 0;
+                sb.c1off[y] = int32_t(off1);
+                sb.c1n[y] = r1;
+                sb.row0[y] = r0;
+                sb.dstX[y] = int64_t(j) * SL * SL;
+                sb.dstD[y] = int64_t(j) * SL * SL;
+            }
+            if (sb.count == StripBatch::MAX) flush();
+        }
+        flush();
+    }
+    // after the staged builders ran (they reset blk_ev / x_ev): the chain waits for a strip-built block through its strip's event
+    void merge_strip_events(bool with_cross) {
+        for (size_t j = 0; j < strip_ev.size() && j < blk_ev.size(); ++j)
+            if (strip_ev[j]) {
+                if (!blk_ev[j]) blk_ev[j] = strip_ev[j];
+                else if (with_cross && j < x_ev.size() && !x_ev[j]) x_ev[j] = strip_ev[j];
+            }
     }
     std::vector<int32_t> dscr_nb, dact_nb;      // cached block: number of members it was built for
     std::vector<uint64_t> dscr_ver, dact_ver;   // ... and the weight version
@@ -1796,8 +1918,10 @@ struct Solver {
                 launch_panel_reduce<T>(d_part.p, nsl, nb01, cols_all, &d_blk.p->resid_sum, xm_c, d_la_g.p, st);
                 cnt.n_panel_cols += nb01;
             }
+            build_stale_strips(nblk, tab_nb, tab_ver, screen_pass ? &xscr_key : &xact_key, pool, xpool, nb_of, cols_of);
             build_stale_blocks(nblk, tab_nb, tab_ver, pool, nb_of, cols_of);
             build_stale_cross(nblk, screen_pass ? xscr_key : xact_key, xpool, nb_of, cols_of);
+            merge_strip_events(true);
             pass_e0_valid = false;
             int prev_ld = 0;         // partials of block j left behind by the previous fused launch (0: none, gblk is ready)
             for (int j = 0; j < nblk; ++j) {
@@ -1905,8 +2029,11 @@ struct Solver {
             record_pass_e0();
             t_cd.begin(st);
             const int nsl0 = step_of(0);
+            build_stale_strips(nblk, tab_nb, tab_ver, nullptr, pool, static_cast<T*>(nullptr),
+                               [&](int j) { return std::min(B, count - j * B); }, [&](int j) { return cols_all + size_t(j) * B; });
             build_stale_blocks(nblk, tab_nb, tab_ver, pool, [&](int j) { return std::min(B, count - j * B); },
                                [&](int j) { return cols_all + size_t(j) * B; }, false, screen_pass);
+            merge_strip_events(false);
             pass_e0_valid = false;
             if (!screen_pass && prebuild_screen && !screen_prebuilt && side_grams && st2) {
                 // IRLS: every screen-order block is stale as well (new weights) and the screen pass follows the active-set
@@ -3358,8 +3485,8 @@ struct Solver {
     // pull the device-resident invariants back into the host mirrors that the result accessors expose
     void finalize() {
         if (std::getenv("ADELIE_HIP_TRACE_ENQ"))
-            std::fprintf(stderr, "[enq] panel passes: host enqueue %.1f ms, host wait %.1f ms, blocks %lld (built %lld, reused across IRLS iterations %lld), speculated %lld (rolled back %lld)\n",
-                         t_enq * 1e3, t_wait * 1e3, (long long)cnt.n_panel_blocks, (long long)cnt.n_panel_grams, (long long)n_blocks_reused, (long long)n_spec, (long long)n_spec_rollback);
+            std::fprintf(stderr, "[enq] panel passes: host enqueue %.1f ms, host wait %.1f ms, blocks %lld (built %lld + %lld cross + %lld strips, reused across IRLS iterations %lld), speculated %lld (rolled back %lld)\n",
+                         t_enq * 1e3, t_wait * 1e3, (long long)cnt.n_panel_blocks, (long long)cnt.n_panel_grams, (long long)n_cross_blocks, (long long)n_strip_builds, (long long)n_blocks_reused, (long long)n_spec, (long long)n_spec_rollback);
         if (std::getenv("ADELIE_HIP_TRACE_ENQ"))
             std::fprintf(stderr, "[alloc] hipMalloc/hipFree so far in this process: %ld calls, %.1f ms\n", DevAllocStats::calls(),
                          DevAllocStats::seconds() * 1e3);
@@ -3518,6 +3645,9 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_SPECULATE")) spec_enabled = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_CROSS_BATCH")) cross_batch = std::max(1, std::min(int(GramBatch::MAX), std::atoi(e)));
         if (const char* e = std::getenv("ADELIE_HIP_CROSS_INCR")) cross_incremental = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_STRIP_BUILDS")) strip_builds = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_STRIP_MAX_M")) strip_max_m = std::max(1, std::min(128, std::atoi(e)));
+        if (const char* e = std::getenv("ADELIE_HIP_STRIP_WGS")) set_strip_workgroups(std::atoi(e));
         if (const char* e = std::getenv("ADELIE_HIP_DEVICE_EIG")) device_eig = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_IRLS_REUSE")) irls_reuse = std::max(0.0, std::atof(e));
         if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {

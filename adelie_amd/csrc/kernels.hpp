@@ -105,6 +105,7 @@ struct StripBatch {
 int strip_row_tiles(int m);                 // 16-row tiles the strip kernel is instantiated for (0: more rows than it takes)
 int64_t strip_work_elems(int64_t n, int count, int m_max);
 void set_strip_workgroups(int wgs);         // spread of the next strip builds launched by this host thread (default 512)
+void set_strip_lds(bool on);                // f64: fragments through the wave-private LDS transpose (default) or straight from HBM
 template <class T>
 void launch_strip_batch(const DenseView<T>& X, const T* w, const int32_t* cols_base, const StripBatch& b, const T* xm_by_col,
                         bool center, T* D_base, T* X_base, int64_t ldc, T* work, hipStream_t s);
@@ -311,6 +312,14 @@ struct CdGrpBlkParams {
     const T* part;
     int32_t part_n;
     const T* part_rsum;
+    // fused look-ahead launch: the LAST step workgroup to finish sums the slice partials of the next block (slice-major) in a
+    // fixed order, applies  - tail_rsum[0] * tail_xm[col]  and leaves the block's gradient in tail_g — in the shadow of the
+    // solve, which outlasts the step in a group launch — instead of a panel_reduce launch between two fused launches.
+    // tail_counter: one int32 that is 0 between launches (the reducing workgroup resets it); nullptr: off.
+    int32_t* tail_counter;
+    T* tail_g;
+    const T* tail_rsum;
+    const T* tail_xm; // nullptr: no intercept term
     // one-coefficient constraints of groups of size one (see CdBlkParams): per screen value, +-inf where there is none
     const T* clo;
     const T* chi;

@@ -237,7 +237,7 @@ __device__ __forceinline__ void fused_step_part(char* smem_raw, const Acc& X, in
                                                 T* __restrict__ r, const int32_t* __restrict__ dcol,
                                                 const T* __restrict__ dlt, const int32_t* __restrict__ nz_dev,
                                                 const int32_t* __restrict__ cols, int nb, T* __restrict__ part,
-                                                int64_t part_ld, int reps) {
+                                                int64_t part_ld, int reps, bool coh = false) {
     constexpr int RS = 64 * VEC;
     const int sub = threadIdx.x >> 8, tid = threadIdx.x & 255;
     T* base = reinterpret_cast<T*>(smem_raw) + size_t(sub) * 5 * RS;
@@ -266,8 +266,11 @@ __device__ __forceinline__ void fused_step_part(char* smem_raw, const Acc& X, in
                 const T* b0 = reinterpret_cast<const T*>(smem_raw);
                 const int c = threadIdx.x;
                 // part_ld == 0: slice-major layout part[k * PB + c] (coalesced here and in the solve that sums the partials itself)
-                part[part_ld > 0 ? int64_t(c) * part_ld + grp : grp * PB + c] =
-                    (b0[c] + b0[size_t(5) * RS + c]) + (b0[size_t(10) * RS + c] + b0[size_t(15) * RS + c]);
+                const T tot = (b0[c] + b0[size_t(5) * RS + c]) + (b0[size_t(10) * RS + c] + b0[size_t(15) * RS + c]);
+                T* dst = part + (part_ld > 0 ? int64_t(c) * part_ld + grp : grp * PB + c);
+                // coh: device-coherent store (written through: another workgroup of this launch reads it, see the tail reduce)
+                if (coh) __hip_atomic_store(dst, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *dst = tot;
             }
         } else {
             if ((grp + 1) * FS * RS <= n)
@@ -288,6 +291,14 @@ __global__ __launch_bounds__(256 * FS) void panel_fused_kernel(CdBlkParams<T> sp
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int RS = 64 * VEC;
     if (blockIdx.x == 0) { // the solve of block j: all 1024 threads fetch, one wavefront visits (blk_solve_la_body)
+        if (j < 0) { // opening launch of a pass: no solve; both look-ahead slots get the residual sum the pass starts from
+            if (threadIdx.x == 0 && sp.part_rsum) {
+                const T v = sp.part_rsum[0];
+                sp.rsum_out[0] = v;
+                sp.rsum_out[1] = v;
+            }
+            return;
+        }
         blk_solve_la_body<T>(sp, j, smem_raw, threadIdx.x);
         return;
     }
@@ -355,7 +366,48 @@ __global__ __launch_bounds__(256 * FS) void panel_fused_grp_kernel(CdGrpBlkParam
         grp_solve_body<T, true, true>(sp, j, smem_raw, 256 * FS);
         return;
     }
-    fused_step_part<T, Acc, VEC>(smem_raw, X, n, w, r, dcol, dlt, nz_dev, cols, nb, part, part_ld, 1);
+    fused_step_part<T, Acc, VEC>(smem_raw, X, n, w, r, dcol, dlt, nz_dev, cols, nb, part, part_ld, 1, sp.tail_counter != nullptr);
+    if constexpr (RS >= PB) {
+        if (sp.tail_counter == nullptr || nb <= 0) return; // (uniform)
+        // ---- tail: the last step workgroup to get here sums the partials of all of them ----
+        // The partials were stored device-coherently (written through) and are read back the same way, so no cache
+        // write-back / invalidate is needed (an agent-scope fence per workgroup costs more than the reduce launch it replaces:
+        // measured +15 us per fused launch); the workgroup-scope fence + barrier make the stores complete before the counter
+        // moves.
+        __shared__ int s_last;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int prev = __hip_atomic_fetch_add(sp.tail_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (prev == int(gridDim.x) - 2) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int nwg = int(gridDim.x) - 1;
+        T* red = reinterpret_cast<T*>(smem_raw); // [8][128]
+        const int c = threadIdx.x & (PB - 1), q = threadIdx.x >> 7;
+        T s = T(0);
+        for (int k0 = q; k0 < nwg; k0 += 8 * 16) { // 16 loads in flight per thread
+            T v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = k0 + 8 * u;
+                v[u] = k < nwg ? __hip_atomic_load(part + int64_t(k) * PB + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : T(0);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        red[q * PB + c] = s;
+        __syncthreads();
+        if (threadIdx.x < nb) {
+            T g = ((red[c] + red[PB + c]) + (red[2 * PB + c] + red[3 * PB + c])) +
+                  ((red[4 * PB + c] + red[5 * PB + c]) + (red[6 * PB + c] + red[7 * PB + c]));
+            if (sp.tail_xm) g -= sp.tail_rsum[0] * sp.tail_xm[cols[c]];
+            sp.tail_g[c] = g;
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(sp.tail_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 template <class T, class Acc, int VEC>

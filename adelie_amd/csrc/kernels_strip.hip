@@ -24,6 +24,7 @@
 // the cross block and (mirrored, the new x new square from its lower triangle only) the diagonal block.
 #include "gram_common.hpp"
 #include "common.hpp"
+#include <type_traits>
 
 namespace ahip {
 
@@ -172,6 +173,173 @@ __global__ __launch_bounds__(SGT, (MT <= 2 ? 2 : 1)) void strip_kernel(Acc X, co
     else strip_wave<T, Acc, VECOK, MT, 1>(X, w, cols_base, b, y, wv, lane, k0, k1, P);
 }
 
+// ---- f64, 16-byte aligned columns: full cache lines per load, fragments through a wave-private LDS transpose -----------------
+// In the direct form above a load instruction touches 16 columns x 64 bytes — half a cache line per column — and the texture
+// path, not HBM, bounds the kernel (13-15 GB/s per CU whatever MT).  Here lane L of a load instruction takes bytes
+// [16 (L & 7), +16) of the 128-byte run of column L >> 3 (8 columns x one whole line per instruction), parks them in the
+// wavefront's own LDS region ([column][16 rows + 2 pad]) and reads its MFMA fragment back from there (lane (c, q): rows
+// 2 q, 2 q + 1 and 8 + 2 q, 9 + 2 q of column c — conflict-free with the 144-byte column pitch).  No workgroup barrier: a
+// wavefront's LDS operations execute in order, the fences below only keep the compiler from reordering them.
+constexpr int SLP = 18; // doubles per column in LDS (16 rows + 2 pad)
+
+template <class Acc, int MT, int TGL>
+__device__ __forceinline__ void strip_wave_lt(const Acc& X, const double* __restrict__ w, const int32_t* __restrict__ cols_base,
+                                              const StripBatch& b, int y, int wv, int lane, int64_t k0, int64_t k1,
+                                              double* __restrict__ P, double* __restrict__ L) {
+    using T = double;
+    constexpr int NF = MT + TGL; // fragments: rows first, then this wave's column tiles
+    const int fr = lane & 15, fq = lane >> 4;
+    const int lc = lane >> 3, lp = lane & 7;
+    const int m = b.m[y], c0n = b.c0n[y], ncol = c0n + b.c1n[y];
+    // coalesced role: instruction h of fragment f brings column 8 h + lc of the fragment
+    const T* pg[NF][2];
+    int64_t jg[NF][2];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c16 = h * 8 + lc;
+            int64_t j;
+            if (f < MT) {
+                j = int64_t(cols_base[b.voff[y] + min(f * 16 + c16, m - 1)]);
+            } else {
+                const int c = min(wv * 64 + (f - MT) * 16 + c16, ncol - 1);
+                j = int64_t(c < c0n ? cols_base[b.c0off[y] + c] : cols_base[b.c1off[y] + c - c0n]);
+            }
+            jg[f][h] = j;
+            pg[f][h] = X.colptr(j) + lp * 2;
+        }
+    // fragment role (ragged tail only): column fr of fragment f
+    typename Mfma<T>::acc_t acc[MT][TGL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < TGL; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][t][e] = T(0);
+
+    T g[NF][2][2], fv[NF][SKC], rw[SKC], rwn[SKC];
+    auto fetch = [&](int64_t k) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const Pack<T, 2> x = X.template load<2>(pg[f][h], k, jg[f][h]);
+                g[f][h][0] = x.v[0];
+                g[f][h][1] = x.v[1];
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) rwn[u * 2 + e] = w[k + u * 8 + fq * 2 + e];
+    };
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    auto park = [&]() {
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                d2_t v = {g[f][h][0], g[f][h][1]};
+                *reinterpret_cast<d2_t*>(L + (f * 16 + h * 8 + lc) * SLP + lp * 2) = v;
+            }
+#pragma unroll
+        for (int e = 0; e < SKC; ++e) rw[e] = rwn[e];
+    };
+    auto frags = [&]() {
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const d2_t v = *reinterpret_cast<const d2_t*>(L + (f * 16 + fr) * SLP + u * 8 + fq * 2);
+                fv[f][u * 2] = v[0];
+                fv[f][u * 2 + 1] = v[1];
+            }
+    };
+    auto run = [&]() {
+#pragma unroll
+        for (int e = 0; e < SKC; ++e) {
+            T a[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = fv[i][e] * rw[e];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int t = 0; t < TGL; ++t) acc[i][t] = Mfma<T>::run(a[i], fv[MT + t][e], acc[i][t]);
+        }
+    };
+    const int64_t kfull = k0 + ((k1 - k0) / SCH) * SCH;
+    int64_t k = k0;
+    if (k < kfull) {
+        fetch(k);
+        while (k < kfull) {
+            park(); // (waits for the loads of chunk k)
+            fetch((k + 2 * SCH <= kfull) ? k + SCH : k); // chunk k + 16 in flight during the MFMAs (none left: a harmless re-load)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            frags();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            run();
+            k += SCH;
+        }
+    }
+    if (k < k1) { // ragged tail (fewer than 16 rows): guarded loads straight into the fragment layout
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int64_t kk = k + u * 8 + fq * 2 + e;
+                const bool in = kk < k1;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    int64_t j;
+                    if (f < MT) {
+                        j = int64_t(cols_base[b.voff[y] + min(f * 16 + fr, m - 1)]);
+                    } else {
+                        const int c = min(wv * 64 + (f - MT) * 16 + fr, ncol - 1);
+                        j = int64_t(c < c0n ? cols_base[b.c0off[y] + c] : cols_base[b.c1off[y] + c - c0n]);
+                    }
+                    fv[f][u * 2 + e] = in ? X.template load<1>(X.colptr(j), kk, j).v[0] : T(0);
+                }
+                rw[u * 2 + e] = in ? w[kk] : T(0);
+            }
+        run();
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < TGL; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = i * 16 + Mfma<T>::row(lane, e);
+                const int col = wv * 64 + t * 16 + fr;
+                P[int64_t(row) * SW + col] = acc[i][t][e];
+            }
+}
+
+template <class Acc, int MT>
+__global__ __launch_bounds__(SGT, (MT <= 2 ? 2 : 1)) void strip_lt_kernel(Acc X, const double* __restrict__ w,
+                                                                         const int32_t* __restrict__ cols_base, StripBatch b,
+                                                                         int64_t n, int64_t kchunk, int nsplit,
+                                                                         double* __restrict__ part) {
+    __shared__ double lds[4][(MT + STG) * 16 * SLP];
+    const int y = blockIdx.y, sp = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    const int ncol = b.c0n[y] + b.c1n[y];
+    const int tg_live = min(STG, (ncol - wv * 64 + 15) >> 4);
+    if (tg_live <= 0 || b.m[y] <= 0) return;
+    const int64_t k0 = int64_t(sp) * kchunk, k1 = min(n, k0 + kchunk);
+    if (k0 >= k1) return;
+    double* P = part + (int64_t(y) * nsplit + sp) * (16 * MT) * SW;
+    double* L = &lds[wv][0];
+    if (tg_live == 4) strip_wave_lt<Acc, MT, 4>(X, w, cols_base, b, y, wv, lane, k0, k1, P, L);
+    else if (tg_live == 3) strip_wave_lt<Acc, MT, 3>(X, w, cols_base, b, y, wv, lane, k0, k1, P, L);
+    else if (tg_live == 2) strip_wave_lt<Acc, MT, 2>(X, w, cols_base, b, y, wv, lane, k0, k1, P, L);
+    else strip_wave_lt<Acc, MT, 1>(X, w, cols_base, b, y, wv, lane, k0, k1, P, L);
+}
+
 // grid (16, m_max, count), 256 threads = 16 groups of K-splits x 16 consecutive columns.  Entry (row, col) of strip y:
 // sum of the K-split partials in a fixed order (each group its splits in ascending order, the 16 group sums as a fixed tree).
 template <class T>
@@ -233,10 +401,12 @@ inline void strip_shape(int64_t n, int count, int wgs, int& nsplit, int64_t& kch
 }
 
 thread_local int t_strip_wgs = 512;
+thread_local bool t_strip_lds = true;
 
 } // namespace
 
 void set_strip_workgroups(int wgs) { t_strip_wgs = wgs < 1 ? 512 : wgs; }
+void set_strip_lds(bool on) { t_strip_lds = on; }
 
 int strip_row_tiles(int m) { return m <= 16 ? 1 : (m <= 32 ? 2 : (m <= 64 ? 4 : 0)); }
 
@@ -265,9 +435,24 @@ void launch_strip_batch(const DenseView<T>& Xv, const T* w, const int32_t* cols_
 #define AHIP_STRIP(VOK, MTV)                                                                                            \
     hipLaunchKernelGGL((strip_kernel<T, DenseAcc<T>, VOK, MTV>), grid, dim3(SGT), 0, s, acc, w, cols_base, b, Xv.n, kchunk, \
                        nsplit, work)
-    if (MTv == 1) { if (vecok) AHIP_STRIP(true, 1); else AHIP_STRIP(false, 1); }
-    else if (MTv == 2) { if (vecok) AHIP_STRIP(true, 2); else AHIP_STRIP(false, 2); }
-    else { if (vecok) AHIP_STRIP(true, 4); else AHIP_STRIP(false, 4); }
+    bool done = false;
+    if constexpr (std::is_same<T, double>::value) {
+        if (vecok && t_strip_lds) {
+#define AHIP_STRIP_LT(MTV)                                                                                              \
+    hipLaunchKernelGGL((strip_lt_kernel<DenseAcc<double>, MTV>), grid, dim3(SGT), 0, s, acc, w, cols_base, b, Xv.n, kchunk, \
+                       nsplit, work)
+            if (MTv == 1) AHIP_STRIP_LT(1);
+            else if (MTv == 2) AHIP_STRIP_LT(2);
+            else AHIP_STRIP_LT(4);
+#undef AHIP_STRIP_LT
+            done = true;
+        }
+    }
+    if (!done) {
+        if (MTv == 1) { if (vecok) AHIP_STRIP(true, 1); else AHIP_STRIP(false, 1); }
+        else if (MTv == 2) { if (vecok) AHIP_STRIP(true, 2); else AHIP_STRIP(false, 2); }
+        else { if (vecok) AHIP_STRIP(true, 4); else AHIP_STRIP(false, 4); }
+    }
 #undef AHIP_STRIP
     hipLaunchKernelGGL((strip_reduce_kernel<T>), dim3(16, (unsigned)mx, (unsigned)b.count), dim3(256), 0, s, work, nsplit,
                        16 * MTv, b, cols_base, xm_by_col, center ? 1 : 0, D_base, X_base, ldc);

@@ -679,6 +679,10 @@ struct Solver {
     DevBuf<T> d_Xpool, d_la_dlt, d_la_g, d_la_rsum, d_la_dd;
     DevBuf<int32_t> d_gdesc; // layout descriptors of the current group pass (launch_grp_layout)
     DevBuf<int32_t> d_la_dcol, d_la_dpos, d_la_nz;
+    DevBuf<int32_t> d_tail_counter; // CdGrpBlkParams::tail_counter
+    DevBuf<int32_t> d_zero_i32; // one int32 that stays 0 ("no changes to apply" for the step of a pass's first fused launch)
+    bool la_fused_open = true;  // look-ahead passes open with (step: pending changes + block 0) -> fused (solve 0 || block 1) instead of
+                                // (step: blocks 0 and 1) -> reduce -> solve 0; hook ADELIE_HIP_LA_FUSED_OPEN=0
     struct XKey { int32_t nb_prev = 0, nb = 0; uint64_t ver = 0; };
     std::vector<XKey> xscr_key, xact_key;
     std::vector<hipEvent_t> x_ev;
@@ -1876,6 +1880,10 @@ struct Solver {
             }
             d_la_dlt.reserve(size_t(2) * SL); d_la_g.reserve(size_t(2) * SL); d_la_rsum.reserve(2); d_la_dd.reserve(size_t(2) * SL);
             d_la_dcol.reserve(size_t(2) * SL); d_la_dpos.reserve(size_t(2) * SL); d_la_nz.reserve(2);
+            if (!d_zero_i32.p) {
+                d_zero_i32.reserve(1);
+                AHIP_CHECK(hipMemsetAsync(d_zero_i32.p, 0, sizeof(int32_t), st));
+            }
             d_part.reserve(size_t(2 * panel_part_elems(n) + 2048));
             part2_half = size_t(panel_part_elems(n));
             d_part2.reserve(2 * part2_half);
@@ -1907,8 +1915,31 @@ struct Solver {
             // first step of the pass: applies the pending changes of the previous pass's last block and prepares blocks 0 AND 1
             // (block 1 from a residual without block 0's changes).  It goes out before the block builds are enqueued: it does
             // not depend on them, and enqueueing them takes the host about as long as the step runs.
-            const int nb01 = nb_of(0) + (nblk > 1 ? nb_of(1) : 0);
-            {
+            // Fused opening (fuse_reduce): the first launch is a fused launch WITHOUT a solve (j = -1) that prepares block 0
+            // only and leaves slice partials; block 0 is then solved by a regular fused launch whose step applies nothing and
+            // prepares block 1 — one launch, one boundary and 93 MB of the first step less per pass than step + reduce + solve.
+            const bool fr_open = fuse_reduce && la_fused_open;
+            int prev_ld = 0;         // partials of block j left behind by the previous fused launch (0: none, gblk is ready)
+            if (fr_open) {
+                const int ps = pending_slot;
+                CdBlkParams<T> op = bp;
+                op.report_j = -1;
+                op.rsum_out = d_la_rsum.p;                                 // both slots <- resid_sum at the start of the pass
+                op.part_rsum = xm_c ? &d_blk.p->resid_sum : nullptr;
+                const int32_t* dc = ps < 0 ? d_dcolblk.p : d_la_dcol.p + size_t(ps) * SL;
+                const T* dl = ps < 0 ? d_dlt.p : d_la_dlt.p + size_t(ps) * SL;
+                const int32_t* nzp = ps < 0 ? &d_blk.p->nz : d_la_nz.p + ps;
+                T* part_out = d_part2.p + part2_half; // parity of "launch -1"
+                if (time_panel) t_step.begin(st);
+                if (dense())
+                    prev_ld = launch_panel_fused<T>(op, -1, D->dense<T>(), cur_w, r_dev, dc, dl, nzp, cols_all, nb_of(0), part_out, true, st);
+                else
+                    prev_ld = launch_panel_fused_snp<T>(op, -1, D->snp(), static_cast<const T*>(D->impute), cur_w, r_dev, dc, dl, nzp,
+                                                        cols_all, nb_of(0), part_out, true, st);
+                if (time_panel) t_step.end(st);
+                cnt.n_panel_cols += nb_of(0);
+            } else {
+                const int nb01 = nb_of(0) + (nblk > 1 ? nb_of(1) : 0);
                 const int ps = pending_slot;
                 if (time_panel) t_step.begin(st);
                 const int nsl = panel_step(cur_w, r_dev, ps < 0 ? d_dcolblk.p : d_la_dcol.p + size_t(ps) * SL,
@@ -1923,7 +1954,6 @@ struct Solver {
             build_stale_cross(nblk, screen_pass ? xscr_key : xact_key, xpool, nb_of, cols_of);
             merge_strip_events(true);
             pass_e0_valid = false;
-            int prev_ld = 0;         // partials of block j left behind by the previous fused launch (0: none, gblk is ready)
             for (int j = 0; j < nblk; ++j) {
                 const int slot = j & 1, pslot = slot ^ 1;
                 bp.gblk = d_la_g.p + size_t(slot) * B;
@@ -1955,23 +1985,25 @@ struct Solver {
                 }
                 if (blk_ev[size_t(j)]) AHIP_CHECK(hipStreamWaitEvent(st, blk_ev[size_t(j)], 0));
                 if (x_ev[size_t(j)]) AHIP_CHECK(hipStreamWaitEvent(st, x_ev[size_t(j)], 0));
-                if (j == 0) { // nothing to overlap with: the step above already prepared block 1
+                if (j == 0 && !fr_open) { // nothing to overlap with: the step above already prepared block 1
                     launch_cd_panel_solve<T>(bp, 0, st);
                     continue;
                 }
                 // solve of block j  ||  step: apply block j-1's changes, partial gradients of block j+1
+                // (j = 0 of a fused opening: nothing to apply)
                 const int nbn = (j + 1 < nblk) ? nb_of(j + 1) : 0;
                 const int32_t* cols_n = cols_all + size_t(j + 1) * B;
+                const int32_t* nz_apply = (j == 0) ? d_zero_i32.p : d_la_nz.p + pslot;
                 int ld;
                 T* part_out = fuse_reduce ? d_part2.p + size_t(j & 1) * part2_half : d_part.p;
                 if (time_panel) t_step.begin(st);
                 if (dense())
                     ld = launch_panel_fused<T>(bp, j, D->dense<T>(), cur_w, r_dev, d_la_dcol.p + size_t(pslot) * SL,
-                                               d_la_dlt.p + size_t(pslot) * SL, d_la_nz.p + pslot, cols_n, nbn, part_out, fuse_reduce, st);
+                                               d_la_dlt.p + size_t(pslot) * SL, nz_apply, cols_n, nbn, part_out, fuse_reduce, st);
                 else
                     ld = launch_panel_fused_snp<T>(bp, j, D->snp(), static_cast<const T*>(D->impute), cur_w, r_dev,
                                                    d_la_dcol.p + size_t(pslot) * SL, d_la_dlt.p + size_t(pslot) * SL,
-                                                   d_la_nz.p + pslot, cols_n, nbn, part_out, fuse_reduce, st);
+                                                   nz_apply, cols_n, nbn, part_out, fuse_reduce, st);
                 if (time_panel) t_step.end(st);
                 if (nbn > 0) {
                     if (fuse_reduce) {
@@ -2442,6 +2474,25 @@ struct Solver {
         // ADELIE_HIP_GRP_FUSE_REDUCE=1).  Off.
         static const bool grp_fr_opt = std::getenv("ADELIE_HIP_GRP_FUSE_REDUCE") && std::atoi(std::getenv("ADELIE_HIP_GRP_FUSE_REDUCE")) != 0;
         const bool fr_grp = grp_fr_opt && fuse_reduce && bp.rot && !multi();
+        // ... but the LAST STEP WORKGROUP of a fused launch can: it finishes ~9 us before the solve does, and summing 196 x 128
+        // partials takes one workgroup 3 us (CdGrpBlkParams::tail_counter).  No panel_reduce launch between two fused launches
+        // (5.3 us + two boundaries per block).  One partial per column and workgroup is what the kernel sums: 16-byte
+        // aligned dense designs in double precision / any SNP design.  Hook ADELIE_HIP_GRP_TAIL_REDUCE=0.
+        static const bool grp_tail_opt = !(std::getenv("ADELIE_HIP_GRP_TAIL_REDUCE") && std::atoi(std::getenv("ADELIE_HIP_GRP_TAIL_REDUCE")) == 0);
+        bool tail_ok = false;
+        if (grp_tail_opt && !fr_grp && !multi()) {
+            if (dense()) {
+                constexpr int V = int(16 / sizeof(T));
+                tail_ok = (64 * V >= 128) && (D->ld % V == 0) && ((reinterpret_cast<uintptr_t>(D->X) % 16) == 0);
+            } else {
+                tail_ok = true; // (SNP: 4 rows per lane and load, 256-row slices)
+            }
+        }
+        if (tail_ok && !d_tail_counter.p) {
+            d_tail_counter.reserve(1);
+            AHIP_CHECK(hipMemsetAsync(d_tail_counter.p, 0, sizeof(int32_t), st));
+        }
+        if (tail_ok) d_part2.reserve(2 * size_t(panel_part_elems(n)));
         bool no_wait = false;
         d_gdesc.reserve(maxblk * size_t(GDESC_STRIDE));
         auto pass_la = [&](bool screen_pass) -> T {
@@ -2515,6 +2566,11 @@ struct Solver {
                 bp.part_n = prev_ld;
                 bp.part_rsum = xm_c ? d_la_rsum.p + slot : nullptr;
                 prev_ld = 0;
+                // tail reduce of this launch's partials (block j + 1): resid_sum as it was before block j's solve
+                bp.tail_counter = tail_ok ? d_tail_counter.p : nullptr;
+                bp.tail_g = d_la_g.p + size_t(pslot) * SL;
+                bp.tail_rsum = d_la_rsum.p + pslot;
+                bp.tail_xm = xm_c;
                 if (h_report && j == nblk - 1) {
                     bp.report_j = j;
                     bp.report_seq = ++report_seq;
@@ -2537,15 +2593,18 @@ struct Solver {
                 else if (dense())
                     ld = launch_panel_fused_grp<T>(bp, j, D->dense<T>(), cur_w, r_dev, d_la_dcol.p + size_t(pslot) * SL,
                                                    d_la_dlt.p + size_t(pslot) * SL, d_la_nz.p + pslot, cols_n, nbn,
-                                                   fr_grp ? d_part2.p + size_t(j & 1) * part2_half : d_part.p, fr_grp, st);
+                                                   fr_grp ? d_part2.p + size_t(j & 1) * part2_half : (tail_ok ? d_part2.p : d_part.p),
+                                                   fr_grp || tail_ok, st);
                 else
                     ld = launch_panel_fused_grp_snp<T>(bp, j, D->snp(), static_cast<const T*>(D->impute), cur_w, r_dev,
                                                        d_la_dcol.p + size_t(pslot) * SL, d_la_dlt.p + size_t(pslot) * SL,
                                                        d_la_nz.p + pslot, cols_n, nbn,
-                                                       fr_grp ? d_part2.p + size_t(j & 1) * part2_half : d_part.p, fr_grp, st);
+                                                       fr_grp ? d_part2.p + size_t(j & 1) * part2_half : (tail_ok ? d_part2.p : d_part.p),
+                                                       fr_grp || tail_ok, st);
                 if (time_panel) t_step.end(st);
                 if (nbn > 0) {
                     if (fr_grp) prev_ld = ld; // summed by the next solve
+                    else if (tail_ok) { /* summed by the launch's last step workgroup */ }
                     else
                         launch_panel_reduce_ld<T>(d_part.p, ld, ld, nbn, cols_n, d_la_rsum.p + pslot, xm_c,
                                                   d_la_g.p + size_t(pslot) * SL, st);
@@ -3646,8 +3705,10 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_CROSS_BATCH")) cross_batch = std::max(1, std::min(int(GramBatch::MAX), std::atoi(e)));
         if (const char* e = std::getenv("ADELIE_HIP_CROSS_INCR")) cross_incremental = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_STRIP_BUILDS")) strip_builds = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_LA_FUSED_OPEN")) la_fused_open = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_STRIP_MAX_M")) strip_max_m = std::max(1, std::min(128, std::atoi(e)));
         if (const char* e = std::getenv("ADELIE_HIP_STRIP_WGS")) set_strip_workgroups(std::atoi(e));
+        if (const char* e = std::getenv("ADELIE_HIP_STRIP_LDS")) set_strip_lds(std::atoi(e) != 0);
         if (const char* e = std::getenv("ADELIE_HIP_DEVICE_EIG")) device_eig = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_IRLS_REUSE")) irls_reuse = std::max(0.0, std::atof(e));
         if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {

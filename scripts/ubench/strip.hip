@@ -97,6 +97,8 @@ int run(int64_t n, int64_t p) {
 }
 int main(int argc, char** argv) {
     const int64_t n = argc > 1 ? atoll(argv[1]) : 100000, p = argc > 2 ? atoll(argv[2]) : 4096;
+    if (const char* e = getenv("STRIP_LDS")) set_strip_lds(atoi(e) != 0);
+    if (const char* e = getenv("STRIP_WGS")) set_strip_workgroups(atoi(e));
     if (run<double>(n, p)) return 1;
     if (run<float>(n, p)) return 1;
     return 0;

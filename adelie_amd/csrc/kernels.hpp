@@ -339,14 +339,14 @@ constexpr int GDESC_VQ = 1040;   // [128] size of value i's group
 constexpr int GDESC_STRIDE = 1168;
 // descriptors of blocks 0..nblk-1 of the pass described by p (blk_g0, list, sbegin, ssize) into desc
 template <class T> void launch_grp_layout(const CdGrpBlkParams<T>& p, int nblk, int32_t* desc, hipStream_t s);
-// D <- R^T D R for one 128 x 128 slot (ld 128): `ng` groups, group k = block values [goff[k], goff[k+1]) with eigenbasis
+// Dptr <- R^T Dsrc R for one 128 x 128 slot (ld 128; Dsrc == Dptr: in place): `ng` groups, group k = block values [goff[k], goff[k+1]) with eigenbasis
 // (q, q) column-major at V + voff[k] (ignored for q == 1).  `scratch` holds 128 * 128 elements, private to the stream.
 struct GrpRotArgs {
     int32_t ng;
     int32_t goff[129];
     int64_t voff[128];
 };
-template <class T> void launch_grp_block_rotate(T* Dptr, const T* V, const GrpRotArgs& a, T* scratch, hipStream_t s);
+template <class T> void launch_grp_block_rotate(T* Dptr, const T* Dsrc, const T* V, const GrpRotArgs& a, T* scratch, hipStream_t s);
 template <class T> void launch_cd_group_block_pass(const CdGrpBlkParams<T>& p, hipStream_t s);
 // the visits of block j against p.gblk / p.Dptr (one workgroup)
 template <class T> void launch_cd_group_panel_solve(const CdGrpBlkParams<T>& p, int j, hipStream_t s);

@@ -152,7 +152,7 @@ template <class T>
 constexpr size_t grp_rotate_lds() { return (size_t(GBLK) * GROT_LD + size_t(GROT_QM) * GBLK) * sizeof(T); }
 
 template <class T>
-__global__ __launch_bounds__(GROT_NT) void grp_block_rotate_kernel(T* __restrict__ Dptr, const T* __restrict__ V, GrpRotArgs a,
+__global__ __launch_bounds__(GROT_NT) void grp_block_rotate_kernel(T* Dptr, const T* Dsrc, const T* __restrict__ V, GrpRotArgs a,
                                                                    T* __restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     typedef T vec2 __attribute__((ext_vector_type(2)));
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(GROT_NT) void grp_block_rotate_kernel(T* __restrict
     {   // all rows of the first nval columns, two values per load
         const int tot2 = nval * (GBLK / 2);
         constexpr int U = 8;
-        const vec2* src = reinterpret_cast<const vec2*>(Dptr);
+        const vec2* src = reinterpret_cast<const vec2*>(Dsrc);
         for (int e0 = tid; e0 < tot2; e0 += NT * U) {
             vec2 tmp[U];
 #pragma unroll
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(GROT_NT) void grp_block_rotate_kernel(T* __restrict
 }
 
 template <class T>
-void launch_grp_block_rotate(T* Dptr, const T* V, const GrpRotArgs& a, T* scratch, hipStream_t s) {
+void launch_grp_block_rotate(T* Dptr, const T* Dsrc, const T* V, const GrpRotArgs& a, T* scratch, hipStream_t s) {
     if (a.ng <= 0) return;
     static bool attr_done = false;
     if (!attr_done) {
@@ -295,10 +295,10 @@ void launch_grp_block_rotate(T* Dptr, const T* V, const GrpRotArgs& a, T* scratc
                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_rotate_lds<float>()));
         attr_done = true;
     }
-    hipLaunchKernelGGL((grp_block_rotate_kernel<T>), dim3(1), dim3(GROT_NT), grp_rotate_lds<T>(), s, Dptr, V, a, scratch);
+    hipLaunchKernelGGL((grp_block_rotate_kernel<T>), dim3(1), dim3(GROT_NT), grp_rotate_lds<T>(), s, Dptr, Dsrc, V, a, scratch);
 }
-template void launch_grp_block_rotate<double>(double*, const double*, const GrpRotArgs&, double*, hipStream_t);
-template void launch_grp_block_rotate<float>(float*, const float*, const GrpRotArgs&, float*, hipStream_t);
+template void launch_grp_block_rotate<double>(double*, const double*, const double*, const GrpRotArgs&, double*, hipStream_t);
+template void launch_grp_block_rotate<float>(float*, const float*, const float*, const GrpRotArgs&, float*, hipStream_t);
 
 template <class T>
 void launch_cd_group_panel_solve(const CdGrpBlkParams<T>& p, int j, hipStream_t s) {

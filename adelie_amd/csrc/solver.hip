@@ -826,6 +826,7 @@ struct Solver {
     bool strip_builds = true;
     int strip_max_m = 128;
     std::vector<hipEvent_t> strip_pool, strip_ev;
+    std::vector<int> strip_built; // blocks the last build_stale_strips call built
     size_t strip_used = 0;
     int64_t n_strip_builds = 0;
     hipEvent_t next_strip_event() {
@@ -836,15 +837,21 @@ struct Solver {
         }
         return strip_pool[strip_used++];
     }
-    bool strips_apply() const { return strip_builds && dense() && !is_glm() && !rot_on; }
+    bool strips_apply() const { return strip_builds && dense() && !is_glm(); }
+    // `rot_dst` != nullptr (group passes with CdGrpBlkParams::rot): `pool` holds the blocks in the design's own coordinates
+    // (d_Draw: what the strips extend), and every block a strip touched is rotated into the eigen-coordinates of its groups
+    // right behind it on the same stream, out of place into rot_dst (the pool the solves read), over the visiting list `rlist`.
+    DevBuf<T> d_Draw;
     template <class NbOf, class ColsOf>
     void build_stale_strips(int nblk, std::vector<int32_t>& tab_nb, std::vector<uint64_t>& tab_ver, std::vector<XKey>* xtab,
-                            T* pool, T* xpool, NbOf nb_of, ColsOf cols_of) {
+                            T* pool, T* xpool, NbOf nb_of, ColsOf cols_of, T* rot_dst = nullptr, const idx* rlist = nullptr,
+                            bool force_main = false) {
         strip_ev.assign(size_t(nblk), nullptr);
         strip_used = 0;
+        strip_built.clear();
         if (!strips_apply()) return;
         const int SL = cd_block_size();
-        const bool side = side_grams && st2 != nullptr;
+        const bool side = !force_main && side_grams && st2 != nullptr;
         hipStream_t gs = side ? st2 : st;
         bool first = true;
         const int32_t* cols_base = cols_of(0);
@@ -867,6 +874,10 @@ struct Solver {
             T* work = (side ? d_work_gram2 : d_work_gram).reserve(size_t(strip_work_elems(n, sb.count, mx)));
             t_gram.begin(gs);
             launch_strip_batch<T>(D->dense<T>(), cur_w, cols_base, sb, cur_xm, intercept, pool, xpool, SL, work, gs);
+            if (rot_dst)
+                for (int y = 0; y < sb.count; ++y)
+                    if (y == 0 || js[y - 1] != js[y])
+                        rotate_block(rlist, js[y], rot_dst + size_t(js[y]) * SL * SL, side ? 1 : 0, pool + size_t(js[y]) * SL * SL);
             t_gram.end(gs);
             hipEvent_t e = nullptr;
             if (side) {
@@ -884,7 +895,10 @@ struct Solver {
                 }
                 cnt.gram_flops += 2.0 * double(n) * double(sb.m[y]) * double(sb.c0n[y] + sb.c1n[y]);
                 cnt.n_gram_col_reads += sb.m[y] + sb.c0n[y] + sb.c1n[y];
-                if (y == 0 || js[y - 1] != j) ++n_strip_builds;
+                if (y == 0 || js[y - 1] != j) {
+                    ++n_strip_builds;
+                    strip_built.push_back(j);
+                }
             }
             sb = StripBatch{};
         };
@@ -1398,9 +1412,22 @@ struct Solver {
         const bool dev_eig = device_eig && max_q <= idx(kEigMaxQ);
         std::vector<T> hD(dev_eig ? size_t(0) : size_t(nblk - j0) * SL * SL);
         std::vector<int> rebuilt_blocks;
+        // Gaussian dense designs: only the rows of the new groups (strip builds), with the rows of the cross blocks when the
+        // look-ahead tables exist, into the unrotated pool; the staged builder below then finds the blocks fresh
+        if (!is_glm()) { cur_w = w_dev; cur_xm = xm_dev; } // (Gaussian: the weights / means every pin solve of the path runs under)
+        const bool use_strips = strips_apply();
+        const bool raw_split = use_strips && group_rot;
+        T* const rawbase = raw_split ? d_Draw.p : d_Dpool.p;
+        if (use_strips) {
+            const bool with_x = lookahead && xscr_key.size() == panel_maxblk && d_Xpool.p != nullptr;
+            build_stale_strips(nblk, dscr_nb, dscr_ver, with_x ? &xscr_key : nullptr, rawbase, with_x ? d_Xpool.p : static_cast<T*>(nullptr),
+                               [&](int j) { return int(gp_vbeg[size_t(j) + 1] - gp_vbeg[j]); },
+                               [&](int j) { return d_vcol.p + gp_vbeg[j]; }, nullptr, nullptr, true);
+            rebuilt_blocks = strip_built;
+        }
         for (int j = j0; j < nblk; ++j) {
             const int nval = gp_vbeg[size_t(j) + 1] - gp_vbeg[j];
-            T* Dptr = d_Dpool.p + size_t(j) * SL * SL;
+            T* Dptr = rawbase + size_t(j) * SL * SL;
             if (dscr_nb[j] != nval || dscr_ver[j] != w_version) {
                 gram_block(w_dev, d_vcol.p + gp_vbeg[j], nval, xm_dev, Dptr);
                 dscr_nb[j] = nval;
@@ -1443,10 +1470,11 @@ struct Solver {
             v_used += v_new;
             d_eig_desc.reserve(eig_desc.size());
             d_eig_desc.upload(eig_desc.data(), eig_desc.size(), st);
-            launch_grp_eig<T>(d_Dpool.p, d_eig_desc.p, int(eig_desc.size()), int(max_q), d_vars.p, d_V.p, st);
+            launch_grp_eig<T>(rawbase, d_eig_desc.p, int(eig_desc.size()), int(max_q), d_vars.p, d_V.p, st);
             d_voff.upload(voff.data(), voff.size(), st, g_begin);
             if (group_rot)
-                for (int jb : rebuilt_blocks) rotate_block(nullptr, jb, d_Dpool.p + size_t(jb) * SL * SL, 0);
+                for (int jb : rebuilt_blocks)
+                    rotate_block(nullptr, jb, d_Dpool.p + size_t(jb) * SL * SL, 0, rawbase + size_t(jb) * SL * SL);
             host_mirrors_stale = true;
             if (Staging::current() != &stage || !stage.base) sync(); // (pageable uploads: the vectors go out of scope)
             return;
@@ -1485,7 +1513,8 @@ struct Solver {
         d_voff.upload(voff.data(), voff.size(), st, g_begin);
         // the blocks built above, into the eigen-coordinates of their groups (the eigenbases are on the device now)
         if (group_rot)
-            for (int jb : rebuilt_blocks) rotate_block(nullptr, jb, d_Dpool.p + size_t(jb) * SL * SL, 0);
+            for (int jb : rebuilt_blocks)
+                rotate_block(nullptr, jb, d_Dpool.p + size_t(jb) * SL * SL, 0, rawbase + size_t(jb) * SL * SL);
         sync(); // the staging vectors go out of scope
         for (idx t = 0; t < N; ++t) screen_vars[pos0 + t] = vars_host[t];
     }
@@ -1501,7 +1530,7 @@ struct Solver {
     bool group_rot = true; // A/B hook ADELIE_HIP_GROUP_ROT=0
     std::vector<idx> h_voff; // per screen group: offset of its eigenbasis in d_V
     DevBuf<T> d_rot_scratch[2 + kMaxExtra];
-    void rotate_block(const idx* list, int jb, T* Dptr, int side) {
+    void rotate_block(const idx* list, int jb, T* Dptr, int side, const T* Dsrc = nullptr) {
         GrpRotArgs a{};
         int ng = 0, o = 0;
         for (int32_t pos = part_host[size_t(jb)]; pos < part_host[size_t(jb) + 1]; ++pos, ++ng) {
@@ -1514,7 +1543,7 @@ struct Solver {
         a.ng = ng;
         hipStream_t gs = side == 0 ? st : (side >= 2 ? st_x[side - 2] : st2);
         T* scratch = d_rot_scratch[side].reserve(size_t(cd_block_size()) * cd_block_size());
-        launch_grp_block_rotate<T>(Dptr, d_V.p, a, scratch, gs);
+        launch_grp_block_rotate<T>(Dptr, Dsrc ? Dsrc : Dptr, d_V.p, a, scratch, gs);
     }
 
     // solver_gaussian_naive.hpp:134-176
@@ -1785,6 +1814,10 @@ struct Solver {
             AHIP_CHECK(hipMemsetAsync(d_Dpool.p, 0, size_t(2) * maxblk * SL * SL * sizeof(T), st));
             dscr_nb.assign(maxblk, 0); dact_nb.assign(maxblk, 0);
             dscr_ver.assign(maxblk, 0); dact_ver.assign(maxblk, 0);
+            if (strips_apply() && !all_scalar) { // unrotated copies of the group engine's blocks (build_stale_strips)
+                d_Draw.reserve(size_t(2) * maxblk * SL * SL);
+                AHIP_CHECK(hipMemsetAsync(d_Draw.p, 0, size_t(2) * maxblk * SL * SL * sizeof(T), st));
+            }
             panel_maxblk = maxblk;
         }
         if (side_grams && !st2) AHIP_CHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
@@ -2540,11 +2573,19 @@ struct Solver {
                                            xm_c, d_la_g.p + SL, st);
                 cnt.n_panel_cols += nv0 + nv1;
             }
+            if (strips_apply() && !multi()) {
+                T* raw = group_rot ? d_Draw.reserve(size_t(2) * maxblk * SL * SL) + (screen_pass ? size_t(0) : maxblk * SL * SL) : pool;
+                build_stale_strips(nblk, tab_nb, tab_ver, screen_pass ? &xscr_key : &xact_key, raw, xpool, nb_of, cols_of,
+                                   group_rot ? pool : nullptr, screen_pass ? nullptr : act_host.data());
+            } else {
+                strip_ev.clear();
+            }
             rot_on = group_rot;
             rot_list = screen_pass ? nullptr : act_host.data();
             build_stale_blocks(nblk, tab_nb, tab_ver, pool, nb_of, cols_of);
             rot_on = false;
             build_stale_cross(nblk, screen_pass ? xscr_key : xact_key, xpool, nb_of, cols_of);
+            merge_strip_events(true);
             pass_e0_valid = false;
             int prev_ld = 0; // partials of block j left behind by the previous fused launch (fr_grp), see run_panel_passes
             for (int j = 0; j < nblk; ++j) {
@@ -2656,10 +2697,20 @@ struct Solver {
             bp.desc = d_gdesc.p;
             bp.pdd = nullptr; bp.dd = nullptr;
             if (bp.rot) launch_grp_layout<T>(bp, nblk, d_gdesc.p, st);
+            if (strips_apply()) {
+                T* raw = group_rot ? d_Draw.reserve(size_t(2) * maxblk * SL * SL) + (screen_pass ? size_t(0) : maxblk * SL * SL) : pool;
+                build_stale_strips(nblk, tab_nb, tab_ver, nullptr, raw, static_cast<T*>(nullptr),
+                                   [&](int j) { return int(gp_vbeg[size_t(j) + 1] - gp_vbeg[j]); },
+                                   [&](int j) { return cols_all + gp_vbeg[j]; }, group_rot ? pool : nullptr,
+                                   screen_pass ? nullptr : act_host.data());
+            } else {
+                strip_ev.clear();
+            }
             rot_on = group_rot;
             rot_list = screen_pass ? nullptr : act_host.data();
             build_stale_blocks(nblk, tab_nb, tab_ver, pool, [&](int j) { return int(gp_vbeg[size_t(j) + 1] - gp_vbeg[j]); },
                                [&](int j) { return cols_all + gp_vbeg[j]; });
+            merge_strip_events(false);
             t_cd.begin(st);
             bp.gblk = d_gblk.p; bp.dlt = d_dlt.p; bp.dcol = d_dcolblk.p;
             bp.Cprev = nullptr; bp.dpos = nullptr; bp.nz_out = nullptr; bp.rsum_out = nullptr;

@@ -662,6 +662,8 @@ struct Solver {
 
         if (spec_ev) (void)hipEventDestroy(spec_ev);
         if (pass_e0) (void)hipEventDestroy(pass_e0);
+        if (uv_ev) (void)hipEventDestroy(uv_ev);
+        if (uv_in_ev) (void)hipEventDestroy(uv_in_ev);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         for (hipEvent_t e : pre_pool) (void)hipEventDestroy(e);
         for (hipEvent_t e : strip_pool) (void)hipEventDestroy(e);
@@ -857,6 +859,7 @@ struct Solver {
         const int32_t* cols_base = cols_of(0);
         StripBatch sb{};
         int js[StripBatch::MAX];
+        bool ent_d[StripBatch::MAX] = {}, ent_x[StripBatch::MAX] = {};
         auto flush = [&]() {
             if (sb.count == 0) return;
             if (side && first) {
@@ -876,7 +879,7 @@ struct Solver {
             launch_strip_batch<T>(D->dense<T>(), cur_w, cols_base, sb, cur_xm, intercept, pool, xpool, SL, work, gs);
             if (rot_dst)
                 for (int y = 0; y < sb.count; ++y)
-                    if (y == 0 || js[y - 1] != js[y])
+                    if (ent_d[y] && (y == 0 || js[y - 1] != js[y]))
                         rotate_block(rlist, js[y], rot_dst + size_t(js[y]) * SL * SL, side ? 1 : 0, pool + size_t(js[y]) * SL * SL);
             t_gram.end(gs);
             hipEvent_t e = nullptr;
@@ -887,9 +890,11 @@ struct Solver {
             for (int y = 0; y < sb.count; ++y) {
                 const int j = js[y];
                 strip_ev[size_t(j)] = e;
-                tab_nb[size_t(j)] = nb_of(j);
-                tab_ver[size_t(j)] = w_version;
-                if (xtab && j > 0) {
+                if (ent_d[y]) {
+                    tab_nb[size_t(j)] = nb_of(j);
+                    tab_ver[size_t(j)] = w_version;
+                }
+                if (ent_x[y] && xtab && j > 0) {
                     XKey& key = (*xtab)[size_t(j)];
                     key.nb_prev = nb_of(j - 1); key.nb = nb_of(j); key.ver = w_version;
                 }
@@ -905,16 +910,17 @@ struct Solver {
         for (int j = 0; j < nblk; ++j) {
             const int nb = nb_of(j);
             const bool want_x = xtab != nullptr && j > 0;
-            const bool d_ok = tab_nb[size_t(j)] == nb && tab_ver[size_t(j)] == w_version;
-            bool x_ok = true;
-            int have = (tab_ver[size_t(j)] == w_version && tab_nb[size_t(j)] <= nb) ? tab_nb[size_t(j)] : 0;
+            // rows the diagonal / the cross block of this block already hold for the current weights and member lists
+            const int have_d = (tab_ver[size_t(j)] == w_version && tab_nb[size_t(j)] <= nb) ? tab_nb[size_t(j)] : 0;
+            int have_x = nb;
             if (want_x) {
                 const XKey& key = (*xtab)[size_t(j)];
-                const bool base = key.ver == w_version && key.nb_prev == nb_of(j - 1) && key.nb <= nb;
-                x_ok = base && key.nb == nb;
-                have = std::min(have, base ? int(key.nb) : 0);
+                have_x = (key.ver == w_version && key.nb_prev == nb_of(j - 1) && key.nb <= nb) ? int(key.nb) : 0;
             }
-            if (d_ok && x_ok) continue;
+            const bool need_d = have_d < nb, need_x = have_x < nb;
+            if (!need_d && !need_x) continue;
+            // one of the two only: a strip over that block's columns alone; both: from the smaller of the two row counts
+            const int have = (need_d && need_x) ? std::min(have_d, have_x) : (need_d ? have_d : have_x);
             const int m = nb - have;
             if (m <= 0 || m > strip_max_m) continue; // (left to the staged builders)
             const int64_t off1 = cols_of(j) - cols_base, off0 = want_x ? cols_of(j - 1) - cols_base : 0;
@@ -928,12 +934,14 @@ struct Solver {
                 const int r0 = have + (q == 0 ? 0 : (m + 1) / 2), r1 = (q + 1 == pieces) ? nb : have + (m + 1) / 2;
                 const int y = sb.count++;
                 js[y] = j;
+                ent_d[y] = need_d;
+                ent_x[y] = need_x;
                 sb.voff[y] = int32_t(off1) + r0;
                 sb.m[y] = r1 - r0;
                 sb.c0off[y] = int32_t(off0);
-                sb.c0n[y] = want_x ? nb_of(j - 1) : 0;
+                sb.c0n[y] = need_x ? nb_of(j - 1) : 0;
                 sb.c1off[y] = int32_t(off1);
-                sb.c1n[y] = r1;
+                sb.c1n[y] = need_d ? r1 : 0;
                 sb.row0[y] = r0;
                 sb.dstX[y] = int64_t(j) * SL * SL;
                 sb.dstD[y] = int64_t(j) * SL * SL;
@@ -1100,7 +1108,19 @@ struct Solver {
     // pinned staging for the small per-lambda copies (common.hpp::Staging; A/B hook ADELIE_HIP_STAGING=0)
     Staging stage;
     double t_sync_total = 0; // host seconds inside sync() (bench: splits the host phases into compute and waiting)
+    // update_vars_panel_groups on the side stream (strip builds of the new screen groups' rows, their eigen-decompositions,
+    // the rotations): everything a SCREEN pass needs and an active-set pass does not, so the active-set passes of the fit run
+    // meanwhile and the screen pass (or any host read) joins through this event.  Hook ADELIE_HIP_UV_SIDE=0.
+    bool uv_side = true;
+    hipEvent_t uv_ev = nullptr, uv_in_ev = nullptr;
+    bool uv_pending = false;
+    void join_uv() {
+        if (!uv_pending) return;
+        AHIP_CHECK(hipStreamWaitEvent(st, uv_ev, 0));
+        uv_pending = false;
+    }
     void sync() {
+        join_uv();
         const auto t0 = std::chrono::steady_clock::now();
         AHIP_CHECK(hipStreamSynchronize(st));
         t_sync_total += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1418,11 +1438,14 @@ struct Solver {
         const bool use_strips = strips_apply();
         const bool raw_split = use_strips && group_rot;
         T* const rawbase = raw_split ? d_Draw.p : d_Dpool.p;
+        const bool on_side = use_strips && dev_eig && uv_side && side_grams && st2 != nullptr;
         if (use_strips) {
+            // (diagonal rows only here and the cross rows on the side stream in the pass that needs them: measured slower,
+            // config 3 634 vs 621 ms — two launches per block instead of one)
             const bool with_x = lookahead && xscr_key.size() == panel_maxblk && d_Xpool.p != nullptr;
             build_stale_strips(nblk, dscr_nb, dscr_ver, with_x ? &xscr_key : nullptr, rawbase, with_x ? d_Xpool.p : static_cast<T*>(nullptr),
                                [&](int j) { return int(gp_vbeg[size_t(j) + 1] - gp_vbeg[j]); },
-                               [&](int j) { return d_vcol.p + gp_vbeg[j]; }, nullptr, nullptr, true);
+                               [&](int j) { return d_vcol.p + gp_vbeg[j]; }, nullptr, nullptr, !on_side);
             rebuilt_blocks = strip_built;
         }
         for (int j = j0; j < nblk; ++j) {
@@ -1466,15 +1489,41 @@ struct Solver {
                 }
                 eig_desc.push_back(e);
             }
-            if (v_new) d_V.grow(v_used + v_new, v_used, st);
+            if (v_new && v_used + v_new > d_V.cap) {
+                // (a reallocation: nothing may be running on the old buffer; sized for every group of the problem at once so
+                // that it happens once)
+                sync();
+                if (st2) AHIP_CHECK(hipStreamSynchronize(st2));
+                size_t total = 0;
+                for (idx q : group_sizes) total += q > 1 ? size_t(q) * size_t(q) : 0;
+                d_V.grow(std::max(total, v_used + v_new), v_used, st);
+            }
             v_used += v_new;
+            if (on_side && d_eig_desc.cap < eig_desc.size()) { // (the previous descriptors may still be read on the side stream)
+                join_uv();
+                d_eig_desc.reserve(std::max<size_t>(eig_desc.size(), size_t(ns)));
+            }
             d_eig_desc.reserve(eig_desc.size());
             d_eig_desc.upload(eig_desc.data(), eig_desc.size(), st);
-            launch_grp_eig<T>(rawbase, d_eig_desc.p, int(eig_desc.size()), int(max_q), d_vars.p, d_V.p, st);
             d_voff.upload(voff.data(), voff.size(), st, g_begin);
+            hipStream_t es = st;
+            if (on_side) {
+                if (!uv_in_ev) {
+                    AHIP_CHECK(hipEventCreateWithFlags(&uv_in_ev, hipEventDisableTiming));
+                    AHIP_CHECK(hipEventCreateWithFlags(&uv_ev, hipEventDisableTiming));
+                }
+                AHIP_CHECK(hipEventRecord(uv_in_ev, st)); // the descriptors (and everything before) are on their way
+                AHIP_CHECK(hipStreamWaitEvent(st2, uv_in_ev, 0));
+                es = st2;
+            }
+            launch_grp_eig<T>(rawbase, d_eig_desc.p, int(eig_desc.size()), int(max_q), d_vars.p, d_V.p, es);
             if (group_rot)
                 for (int jb : rebuilt_blocks)
-                    rotate_block(nullptr, jb, d_Dpool.p + size_t(jb) * SL * SL, 0, rawbase + size_t(jb) * SL * SL);
+                    rotate_block(nullptr, jb, d_Dpool.p + size_t(jb) * SL * SL, on_side ? 1 : 0, rawbase + size_t(jb) * SL * SL);
+            if (on_side) {
+                AHIP_CHECK(hipEventRecord(uv_ev, st2));
+                uv_pending = true;
+            }
             host_mirrors_stale = true;
             if (Staging::current() != &stage || !stage.base) sync(); // (pageable uploads: the vectors go out of scope)
             return;
@@ -2587,6 +2636,7 @@ struct Solver {
             build_stale_cross(nblk, screen_pass ? xscr_key : xact_key, xpool, nb_of, cols_of);
             merge_strip_events(true);
             pass_e0_valid = false;
+            if (screen_pass) join_uv(); // the new screen groups' blocks / variances / eigenbases (update_vars_panel_groups)
             int prev_ld = 0; // partials of block j left behind by the previous fused launch (fr_grp), see run_panel_passes
             for (int j = 0; j < nblk; ++j) {
                 const int slot = j & 1, pslot = slot ^ 1;
@@ -2711,6 +2761,7 @@ struct Solver {
             build_stale_blocks(nblk, tab_nb, tab_ver, pool, [&](int j) { return int(gp_vbeg[size_t(j) + 1] - gp_vbeg[j]); },
                                [&](int j) { return cols_all + gp_vbeg[j]; });
             merge_strip_events(false);
+            if (screen_pass) join_uv();
             t_cd.begin(st);
             bp.gblk = d_gblk.p; bp.dlt = d_dlt.p; bp.dcol = d_dcolblk.p;
             bp.Cprev = nullptr; bp.dpos = nullptr; bp.nz_out = nullptr; bp.rsum_out = nullptr;
@@ -2891,6 +2942,7 @@ struct Solver {
         Stopwatch sw;
         sw.start();
         bool small_fit = false; // the whole pin solve ran in the single-workgroup kernel (its scalars are in d_sc)
+        if (!(nv > 0 && panel_mode() && !all_scalar)) join_uv(); // (only the group panel passes know which of them need it)
         if (nv > 0 && panel_mode()) {
             spec_mode = resume ? 2 : 0;
             spec_active = false; // consumed (or never there)
@@ -3756,6 +3808,7 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_CROSS_BATCH")) cross_batch = std::max(1, std::min(int(GramBatch::MAX), std::atoi(e)));
         if (const char* e = std::getenv("ADELIE_HIP_CROSS_INCR")) cross_incremental = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_STRIP_BUILDS")) strip_builds = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_UV_SIDE")) uv_side = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_LA_FUSED_OPEN")) la_fused_open = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_STRIP_MAX_M")) strip_max_m = std::max(1, std::min(128, std::atoi(e)));
         if (const char* e = std::getenv("ADELIE_HIP_STRIP_WGS")) set_strip_workgroups(std::atoi(e));

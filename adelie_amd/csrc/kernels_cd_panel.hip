@@ -363,6 +363,14 @@ __global__ __launch_bounds__(256 * FS) void panel_fused_grp_kernel(CdGrpBlkParam
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int RS = 64 * VEC;
     if (blockIdx.x == 0) { // all 256 * FS threads: the rotated solve spreads its prologue's loads over them
+        if (j < 0) { // opening launch of a pass: no solve; both look-ahead slots get the residual sum the pass starts from
+            if (threadIdx.x == 0 && sp.part_rsum) {
+                const T v = sp.part_rsum[0];
+                sp.rsum_out[0] = v;
+                sp.rsum_out[1] = v;
+            }
+            return;
+        }
         grp_solve_body<T, true, true>(sp, j, smem_raw, 256 * FS);
         return;
     }

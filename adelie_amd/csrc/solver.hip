@@ -2574,6 +2574,10 @@ struct Solver {
             d_tail_counter.reserve(1);
             AHIP_CHECK(hipMemsetAsync(d_tail_counter.p, 0, sizeof(int32_t), st));
         }
+        if (!d_zero_i32.p) {
+            d_zero_i32.reserve(1);
+            AHIP_CHECK(hipMemsetAsync(d_zero_i32.p, 0, sizeof(int32_t), st));
+        }
         if (tail_ok) d_part2.reserve(2 * size_t(panel_part_elems(n)));
         bool no_wait = false;
         d_gdesc.reserve(maxblk * size_t(GDESC_STRIDE));
@@ -2607,8 +2611,29 @@ struct Solver {
             auto cols_of = [&](int j) { return cols_all + gp_vbeg[j]; };
             record_pass_e0();
             t_cd.begin(st);
-            {   // first step of the pass: pending changes of the previous pass's last block; blocks 0 and 1 prepared.  Enqueued
-                // before the block builds (it does not depend on them, see record_pass_e0)
+            // first step of the pass: pending changes of the previous pass's last block; blocks 0 and 1 prepared.  Enqueued
+            // before the block builds (it does not depend on them, see record_pass_e0).
+            // Fused opening (tail reduce available): a fused launch without a solve (j = -1) applies the pending changes and
+            // prepares block 0 (its last step workgroup leaves the gradient); block 0 is then solved by a regular fused
+            // launch whose step applies nothing and prepares block 1 - instead of step + two reduces + a stand-alone solve.
+            const bool fr_open = tail_ok && la_fused_open && dense();
+            if (fr_open) {
+                const int ps = pending_slot;
+                CdGrpBlkParams<T> op = bp;
+                op.report_j = -1;
+                op.rsum_out = d_la_rsum.p;
+                op.part_rsum = xm_c ? &d_blk.p->resid_sum : nullptr;
+                op.tail_counter = d_tail_counter.p;
+                op.tail_g = d_la_g.p;
+                op.tail_rsum = &d_blk.p->resid_sum;
+                op.tail_xm = xm_c;
+                if (time_panel) t_step.begin(st);
+                launch_panel_fused_grp<T>(op, -1, D->dense<T>(), cur_w, r_dev, ps < 0 ? d_dcolblk.p : d_la_dcol.p + size_t(ps) * SL,
+                                          ps < 0 ? d_dlt.p : d_la_dlt.p + size_t(ps) * SL, ps < 0 ? &d_blk.p->nz : d_la_nz.p + ps,
+                                          cols_all, nb_of(0), d_part2.p, true, st);
+                if (time_panel) t_step.end(st);
+                cnt.n_panel_cols += nb_of(0);
+            } else {
                 const int nv0 = nb_of(0), nv1 = nblk > 1 ? nb_of(1) : 0;
                 const int ps = pending_slot;
                 if (time_panel) t_step.begin(st);
@@ -2670,12 +2695,13 @@ struct Solver {
                 }
                 if (blk_ev[size_t(j)]) AHIP_CHECK(hipStreamWaitEvent(st, blk_ev[size_t(j)], 0));
                 if (x_ev[size_t(j)]) AHIP_CHECK(hipStreamWaitEvent(st, x_ev[size_t(j)], 0));
-                if (j == 0) {
+                if (j == 0 && !fr_open) {
                     launch_cd_group_panel_solve<T>(bp, 0, st);
                     continue;
                 }
                 const int nbn = (j + 1 < nblk) ? nb_of(j + 1) : 0;
                 const int32_t* cols_n = cols_all + gp_vbeg[size_t(j) + 1];
+                const int32_t* nz_apply = (j == 0) ? d_zero_i32.p : d_la_nz.p + pslot; // (j = 0 of a fused opening: nothing to apply)
                 int ld;
                 if (time_panel) t_step.begin(st);
                 if (multi())
@@ -2683,7 +2709,7 @@ struct Solver {
                                                      d_la_dlt.p + size_t(pslot) * SL, d_la_nz.p + pslot, cols_n, nbn, d_part.p, st);
                 else if (dense())
                     ld = launch_panel_fused_grp<T>(bp, j, D->dense<T>(), cur_w, r_dev, d_la_dcol.p + size_t(pslot) * SL,
-                                                   d_la_dlt.p + size_t(pslot) * SL, d_la_nz.p + pslot, cols_n, nbn,
+                                                   d_la_dlt.p + size_t(pslot) * SL, nz_apply, cols_n, nbn,
                                                    fr_grp ? d_part2.p + size_t(j & 1) * part2_half : (tail_ok ? d_part2.p : d_part.p),
                                                    fr_grp || tail_ok, st);
                 else

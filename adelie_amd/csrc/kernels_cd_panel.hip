@@ -66,10 +66,16 @@ __device__ __forceinline__ RawDense<T, VEC> praw(const DenseAcc<T>& X, int64_t j
 }
 template <class T, int VEC>
 __device__ __forceinline__ RawSnp praw(const SnpAcc<T>& X, int64_t j, int64_t i, int64_t n, bool full) {
-    static_assert(VEC == 4, "one byte of calls per lane");
+    static_assert(VEC == 4 || VEC == 16, "one byte (4 calls) or one 32-bit word (16 calls) per lane");
     RawSnp r;
-    const unsigned b = unsigned(X.colptr(j)[((full || i < n) ? i : 0) >> 2]);
-    r.byte = (full || i < n) ? b : 0u;
+    if constexpr (VEC == 4) {
+        const unsigned b = unsigned(X.colptr(j)[((full || i < n) ? i : 0) >> 2]);
+        r.byte = (full || i < n) ? b : 0u;
+    } else {
+        // columns are 64-byte aligned and padded (SnpView::ldb), i is a multiple of 16: an aligned word inside the column
+        const unsigned b = reinterpret_cast<const unsigned*>(X.colptr(j))[((full || i < n) ? i : 0) >> 4];
+        r.byte = (full || i < n) ? b : 0u;
+    }
     return r;
 }
 template <class T, int VEC>
@@ -198,7 +204,7 @@ __device__ __forceinline__ void panel_step_body(const Acc& X, int64_t n, const T
 }
 
 template <class T, class Acc, int VEC>
-__global__ __launch_bounds__(PT, 4) void panel_step_kernel(Acc X, int64_t n, const T* __restrict__ w, T* __restrict__ r,
+__global__ __launch_bounds__(PT, (VEC >= 16 ? 2 : 4)) void panel_step_kernel(Acc X, int64_t n, const T* __restrict__ w, T* __restrict__ r,
                                                         const int32_t* __restrict__ dcol, const T* __restrict__ dlt,
                                                         const int32_t* __restrict__ nz_dev,
                                                         const int32_t* __restrict__ cols, int nb, T* __restrict__ part,
@@ -514,6 +520,15 @@ template <class T>
 int launch_panel_step_snp(const SnpView& X, const T* impute, const T* w, T* r, const int32_t* dcol, const T* dlt,
                           const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s) {
     SnpAcc<T> acc{X.bits, X.ldb, impute};
+    // 16 calls (one 32-bit word) per lane and column instead of 4 (one byte): a quarter of the workgroups, four times the
+    // bytes per load instruction - the byte form is bound by the number of workgroups and load instructions, not by bytes.
+    // Hook ADELIE_HIP_SNP_STEP_VEC=4.
+    static const int vec = [] {
+        const char* e = std::getenv("ADELIE_HIP_SNP_STEP_VEC");
+        return (e && std::atoi(e) == 4) ? 4 : 16;
+    }();
+    if (vec == 16 && X.n >= 16384 && X.ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(X.bits) % 4) == 0)
+        return step_launch<T, SnpAcc<T>, 16>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
     return step_launch<T, SnpAcc<T>, 4>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
 }
 template <class T>

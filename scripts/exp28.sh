@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+B="python bench.py --no-cpu-baseline --no-cv-leg --no-extra-legs"
+$B --config 4 --steps 1 --warmup 1 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg4', round(d['value'],4), round(d['ms_per_step'],1), {k: round(v,1) for k,v in d['breakdown_ms_last_path'].items()})"
+$B --config 5 --steps 3 --warmup 1 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg5', round(d['value'],4), round(d['ms_per_step'],1))"
+$B --config 2 --dtype f32 --steps 5 --warmup 2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('f32', round(d['value'],4), round(d['ms_per_step'],1))"
+python scripts/bench_multi.py 20000 2000 4 2>&1 | tail -2

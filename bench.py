@@ -321,14 +321,21 @@ def measure(ctx, cfg, *, n, p, gs, alpha, dtype, L, steps, warmup, n_folds=8, cv
     if gram_ms > 0:
         tf = gram_flops / (gram_ms * 1e-3) / 1e12
         peak = MFMA_F64_PEAK_TFLOPS if dtype == "f64" else MFMA_F32_PEAK_TFLOPS
+        strips = cfg != 4   # Gaussian dense designs: every block build is a strip build (kernels_strip.hip)
+        gram_bytes = float(tot("n_gram_col_reads", "counters")) * n * col_bytes_per_row
         gram_roof = {
-            "kernel": f"syrk_batch_kernel / gram_batch_kernel (diagonal and cross blocks X_b^T W X_b' of the panel engine, {dtype} "
-                      "MFMA 16x16x4)",
+            "kernel": (f"strip_lt_kernel / strip_kernel (the new rows of a panel block's diagonal and cross block, {dtype} MFMA "
+                       "16x16x4 fed from HBM: bound by the column reads, see hbm_gbs)" if strips else
+                       f"syrk_batch_kernel / gram_batch_kernel (diagonal and cross blocks X_b^T W X_b' of the panel engine, "
+                       f"{dtype} MFMA 16x16x4)"),
             "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
             "frac": tf / peak, "traffic": measured_traffic(f"syrk_kernel:{n}x{p}:{dtype}"),
             "launches": int(tot("n_gram_launches", "timers")),
             "avg_launch_ms": gram_ms / max(tot("n_gram_launches", "timers"), 1),
             "algorithmic_flops_per_launch": gram_flops / max(tot("n_gram_launches", "timers"), 1),
+            # the same launches against the HBM roofline: columns read (rows of the strip + the columns they meet) * n * s
+            "hbm_gbs": gram_bytes / (gram_ms * 1e-3) / 1e9, "hbm_frac": gram_bytes / (gram_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": gram_bytes / max(tot("n_gram_launches", "timers"), 1),
         }
     # dominant kernel: by device time.  Config 4 spends most of it in the MFMA block builds; the others in the sweeps.
     roofline = gram_roof if (cfg == 4 and gram_roof is not None) else sweep_roof

@@ -36,6 +36,82 @@ struct DevAllocStats {
     static long& calls() { static long c = 0; return c; }
 };
 
+// Process-wide caches of what a solve would otherwise create and destroy every time: pinned host blocks (the staging arena,
+// the host-mapped pass report: hipHostMalloc / hipHostFree pin and unpin pages, ~1 ms for the 8 MB arena) and non-blocking
+// streams.  Same contract as DevPool below: an owner hands a block / stream back only after it synchronised what used it.
+struct HostPool {
+    struct Entry { size_t bytes; unsigned flags; void* p; };
+    static std::mutex& mu() { static std::mutex* m = new std::mutex; return *m; }
+    static std::vector<Entry>& parked() { static auto* v = new std::vector<Entry>; return *v; }
+    static void* take(size_t bytes, unsigned flags) {
+        {
+            std::lock_guard<std::mutex> lk(mu());
+            auto& v = parked();
+            for (size_t i = 0; i < v.size(); ++i)
+                if (v[i].bytes == bytes && v[i].flags == flags) {
+                    void* p = v[i].p;
+                    v[i] = v.back();
+                    v.pop_back();
+                    return p;
+                }
+        }
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, bytes, flags) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        return hp;
+    }
+    static void give(void* p, size_t bytes, unsigned flags) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lk(mu());
+            if (parked().size() < 64) {
+                parked().push_back(Entry{bytes, flags, p});
+                return;
+            }
+        }
+        (void)hipHostFree(p);
+    }
+};
+struct StreamPool {
+    struct Entry { int dev; hipStream_t s; };
+    static std::mutex& mu() { static std::mutex* m = new std::mutex; return *m; }
+    static std::vector<Entry>& parked() { static auto* v = new std::vector<Entry>; return *v; }
+    static hipStream_t take() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) throw core_error("adelie_hip: hipGetDevice failed");
+        {
+            std::lock_guard<std::mutex> lk(mu());
+            auto& v = parked();
+            for (size_t i = 0; i < v.size(); ++i)
+                if (v[i].dev == dev) {
+                    hipStream_t s = v[i].s;
+                    v[i] = v.back();
+                    v.pop_back();
+                    return s;
+                }
+        }
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess)
+            throw core_error("adelie_hip: hipStreamCreateWithFlags failed");
+        return s;
+    }
+    // `s` is idle (the owner synchronised it)
+    static void give(hipStream_t s) {
+        if (!s) return;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(mu());
+            if (parked().size() < 64) {
+                parked().push_back(Entry{dev, s});
+                return;
+            }
+        }
+        (void)hipStreamDestroy(s);
+    }
+};
+
 // Pinned staging arena for the many small host<->device copies of a path (screen-set appends, per-fit scalars, coefficient
 // downloads: ~15 per lambda).  hipMemcpyAsync on pageable host memory costs the calling thread ~20 us per copy on this
 // platform (staging + an internal wait); from / to pinned memory it is an enqueue.  A solve installs its arena for the
@@ -54,16 +130,13 @@ struct Staging {
     Staging() = default;
     Staging(const Staging&) = delete;
     Staging& operator=(const Staging&) = delete;
-    ~Staging() { if (base) (void)hipHostFree(base); }
+    ~Staging() { HostPool::give(base, cap, hipHostMallocDefault); } // (the owner synchronised its stream)
     void init(size_t bytes, hipStream_t s) {
         stream = s;
         if (base) return;
-        void* hp = nullptr;
-        if (hipHostMalloc(&hp, bytes, hipHostMallocDefault) == hipSuccess) {
+        if (void* hp = HostPool::take(bytes, hipHostMallocDefault)) {
             base = static_cast<char*>(hp);
             cap = bytes;
-        } else {
-            (void)hipGetLastError();
         }
     }
     void* take(size_t bytes) {
@@ -153,6 +226,33 @@ struct DevPool {
     }
 };
 
+// Device blocks a DevBuf outgrew in the middle of a solve.  hipFree waits for the whole device, i.e. it drains the queue the
+// host has built up (≈ 5 growth events per headline path); with a list installed for the calling thread (run<T>) the old
+// block is kept until the end of the solve instead and parked in DevPool once the solve's streams are idle, where the next
+// solve's same growth step finds it.
+struct DeferredFrees {
+    struct Blk { void* p; size_t bytes; };
+    std::vector<Blk> v;
+    static DeferredFrees*& current() { static thread_local DeferredFrees* cur = nullptr; return cur; }
+    struct Scope {
+        DeferredFrees* prev;
+        explicit Scope(DeferredFrees* d) : prev(current()) { current() = d; }
+        ~Scope() { current() = prev; }
+    };
+    // nothing on the device uses the blocks any more
+    void drain() {
+        for (const Blk& b : v)
+            if (!DevPool::give(b.p, b.bytes)) {
+                const auto t0 = std::chrono::steady_clock::now();
+                (void)hipFree(b.p);
+                DevAllocStats::seconds() += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                ++DevAllocStats::calls();
+            }
+        v.clear();
+    }
+    ~DeferredFrees() { drain(); }
+};
+
 // Owning device buffer (grow-only).
 template <class T>
 struct DevBuf {
@@ -165,7 +265,9 @@ struct DevBuf {
     // the middle of a solve (growth) goes through hipFree, which waits for whatever may still be using the old block.
     ~DevBuf() { release(true); }
     void release(bool park = false) {
-        if (p && !(park && DevPool::give(p, cap * sizeof(T)))) {
+        if (p && !park && DeferredFrees::current()) {
+            DeferredFrees::current()->v.push_back(DeferredFrees::Blk{p, cap * sizeof(T)});
+        } else if (p && !(park && DevPool::give(p, cap * sizeof(T)))) {
             const auto t0 = std::chrono::steady_clock::now();
             (void)hipFree(p);
             DevAllocStats::seconds() += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -213,8 +315,12 @@ struct DevBuf {
         size_t got = 0;
         T* q = alloc(want, got);
         if (p && keep) AHIP_CHECK(hipMemcpyAsync(q, p, keep * sizeof(T), hipMemcpyDeviceToDevice, s));
-        AHIP_CHECK(hipStreamSynchronize(s));
-        if (p) (void)hipFree(p);
+        if (p && DeferredFrees::current()) { // the copy is ordered on `s`; the old block lives until the end of the solve
+            DeferredFrees::current()->v.push_back(DeferredFrees::Blk{p, cap * sizeof(T)});
+        } else if (p) {
+            AHIP_CHECK(hipStreamSynchronize(s));
+            (void)hipFree(p);
+        }
         p = q;
         cap = got;
         return p;

@@ -125,14 +125,41 @@ void jacobi_eigh(int q, std::vector<double>& A, std::vector<double>& V, std::vec
 }
 
 // HIP-event timing of the device phases on the design's own stream (read by bench.py for the roofline object)
+// (timing events are recycled through a process-wide free list: a headline path records ~2000 pairs)
+struct TimingEvents {
+    static std::mutex& mu() { static std::mutex* m = new std::mutex; return *m; }
+    static std::vector<hipEvent_t>& idle() { static auto* v = new std::vector<hipEvent_t>; return *v; }
+    static hipEvent_t take() {
+        {
+            std::lock_guard<std::mutex> lk(mu());
+            auto& v = idle();
+            if (!v.empty()) {
+                hipEvent_t e = v.back();
+                v.pop_back();
+                return e;
+            }
+        }
+        hipEvent_t e;
+        AHIP_CHECK(hipEventCreate(&e));
+        return e;
+    }
+    static void give(hipEvent_t e) {
+        {
+            std::lock_guard<std::mutex> lk(mu());
+            if (idle().size() < 16384) {
+                idle().push_back(e);
+                return;
+            }
+        }
+        (void)hipEventDestroy(e);
+    }
+};
 struct KTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     double ms = 0;
     int64_t launches = 0;
     void begin(hipStream_t st) {
-        hipEvent_t a, b;
-        AHIP_CHECK(hipEventCreate(&a));
-        AHIP_CHECK(hipEventCreate(&b));
+        hipEvent_t a = TimingEvents::take(), b = TimingEvents::take();
         AHIP_CHECK(hipEventRecord(a, st));
         ev.emplace_back(a, b);
     }
@@ -146,8 +173,8 @@ struct KTimer {
                 ++launches;
                 each.push_back(t);
             }
-            (void)hipEventDestroy(e.first);
-            (void)hipEventDestroy(e.second);
+            TimingEvents::give(e.first);
+            TimingEvents::give(e.second);
         }
         ev.clear();
     }
@@ -649,16 +676,17 @@ struct Solver {
     ~Solver() {
         // every DevBuf member is parked in the allocation cache by its destructor: nothing may still be running on them
         if (st) (void)hipStreamSynchronize(st);
-        if (h_report) (void)hipHostFree(h_report);
         if (st2) {
             (void)hipStreamSynchronize(st2);
-            (void)hipStreamDestroy(st2);
+            StreamPool::give(st2);
         }
         for (int k = 0; k < kMaxExtra; ++k)
             if (st_x[k]) {
                 (void)hipStreamSynchronize(st_x[k]);
-                (void)hipStreamDestroy(st_x[k]);
+                StreamPool::give(st_x[k]);
             }
+        HostPool::give(h_report, sizeof(PassReport), hipHostMallocMapped);
+        deferred.drain(); // blocks outgrown during the solve: every stream that may have used them is idle now
 
         if (spec_ev) (void)hipEventDestroy(spec_ev);
         if (pass_e0) (void)hipEventDestroy(pass_e0);
@@ -1107,6 +1135,7 @@ struct Solver {
     }
     // pinned staging for the small per-lambda copies (common.hpp::Staging; A/B hook ADELIE_HIP_STAGING=0)
     Staging stage;
+    DeferredFrees deferred; // installed for the solving thread by run<T>; drained by ~Solver
     double t_sync_total = 0; // host seconds inside sync() (bench: splits the host phases into compute and waiting)
     // update_vars_panel_groups on the side stream (strip builds of the new screen groups' rows, their eigen-decompositions,
     // the rotations): everything a SCREEN pass needs and an active-set pass does not, so the active-set passes of the fit run
@@ -1869,21 +1898,20 @@ struct Solver {
             }
             panel_maxblk = maxblk;
         }
-        if (side_grams && !st2) AHIP_CHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+        if (side_grams && !st2) st2 = StreamPool::take();
         for (int k = 0; side_grams && k < std::min(n_side - 1, kMaxExtra); ++k)
-            if (!st_x[k]) AHIP_CHECK(hipStreamCreateWithFlags(&st_x[k], hipStreamNonBlocking));
+            if (!st_x[k]) st_x[k] = StreamPool::take();
         if (use_report && !h_report) {
-            void* hp = nullptr;
+            void* hp = HostPool::take(sizeof(PassReport), hipHostMallocMapped);
             void* dp = nullptr;
-            if (hipHostMalloc(&hp, sizeof(PassReport), hipHostMallocMapped) == hipSuccess &&
-                hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            if (hp && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
                 h_report = static_cast<PassReport*>(hp);
                 std::memset(h_report, 0, sizeof(PassReport));
                 rep_st_dev = &static_cast<PassReport*>(dp)->st;
                 rep_seq_dev = &static_cast<PassReport*>(dp)->seq;
             } else {
                 (void)hipGetLastError();
-                if (hp) (void)hipHostFree(hp);
+                HostPool::give(hp, sizeof(PassReport), hipHostMallocMapped);
                 use_report = false;
             }
         }
@@ -4264,6 +4292,7 @@ void run(adelie_hip_design* X, const adelie_hip_grpnet_args* a, adelie_hip_resul
     static const bool staging_on = !(std::getenv("ADELIE_HIP_STAGING") && std::atoi(std::getenv("ADELIE_HIP_STAGING")) == 0);
     if (staging_on) r->s.stage.init(size_t(8) << 20, X->stream);
     Staging::Scope stage_scope(staging_on ? &r->s.stage : nullptr);
+    DeferredFrees::Scope deferred_scope(&r->s.deferred);
     r->s.build(X, a);
     Stopwatch sw;
     sw.start();

@@ -484,6 +484,26 @@ void launch_cov_grad(const T* S, int64_t lda, int64_t p, const T* v, const int32
                      T* grad, hipStream_t s);
 template <class T> void launch_copy2d(const T* src, int64_t lds, T* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s);
 // vars[pos0 + a] = max(C[(pos0+a)*(ldc+1)], 0) for a < cnt   (gs == 1 groups)
+// Screening step on the device (kernels_screen.hip; solver_base.hpp:273-403, optimization/search_pivot.hpp:7-62).  Both
+// outcomes of the KKT check are prepared by the host ([0]: failed -> the same lambda again, [1]: passed -> the next one);
+// the select kernel takes the check itself and picks.  Result block `out` (host-mapped): [0] sequence number (written last),
+// [1] KKT passed, [2] number of new screen groups, [3] pivot index within the subset (-1: none), then from kScreenHeader on
+// the new groups in the order the host routine would append them.
+constexpr int kScreenHeader = 8;
+template <class T>
+struct ScreenArgs {
+    const T* abs_grad; const T* penalty; const int32_t* slot; // slot[g] >= 0: g is in the screen set
+    int32_t G, rule;                                          // rule: 0 strong, 1 pivot
+    T alpha, lmda;                                            // lmda: the lambda of the invariance step just taken
+    T lmda_next[2];
+    int32_t n_new_active[2], take[2];                         // take: ceil(pivot_slack_ratio * n_new_active), as the host loop counts
+    int32_t subset, seq;                                      // subset: size of the pivot subset (top of the order)
+    T* wt; uint64_t* key; int32_t* rank; int32_t* order; T* sorted; T* pre; // scratch: G, G, G, G, G, 4 * subset
+    int32_t* flags;                                           // one word, zero between requests (bit 0: a KKT violation)
+    int32_t* out;                                             // kScreenHeader + G (device pointer of host-mapped memory)
+    int32_t* dev_list;                                        // optional copy of the list in device memory (G)
+};
+template <class T> void launch_screen(const ScreenArgs<T>& a, bool need_order, hipStream_t s);
 // Eigen-decomposition of new screen groups' Gram blocks on the device (kernels_eig.hip): group `i` of the launch reads the
 // (q, q) block at src_base + src (leading dimension ld), writes its eigenvalues (ascending, clamped at 0) to
 // vars[vars_pos .. + q) and its eigenvectors (column-major, in the columns) to V[v_off .. + q*q).  q == 1: the variance only.

@@ -52,7 +52,8 @@ _RESULT_INDEX_VECS = ["screen_set", "screen_begins", "screen_is_active", "active
 _COUNTERS = ["n_basil_iters", "n_sweeps", "n_cd_visits_screen", "n_cd_visits_active", "n_updates", "n_irls_iters",
              "n_new_screen_cols", "n_cd_passes_screen", "n_cd_passes_active", "n_gram_col_reads",
              "n_resid_col_reads", "n_panel_blocks", "n_panel_grams", "n_panel_cols", "n_irls_screen_cols",
-             "n_speculated", "n_spec_rollbacks", "n_sweeps_shared", "n_update_cols"]
+             "n_speculated", "n_spec_rollbacks", "n_sweeps_shared", "n_update_cols", "n_device_screens",
+             "n_host_screens"]
 _TIMERS = ["gram_flops", "t_sweep_ms", "t_gram_ms", "t_cd_ms", "t_axpy_ms", "n_sweep_launches", "n_gram_launches",
            "t_host_screen_ms", "t_panel_step_ms", "n_panel_step_launches", "t_host_screen_wait_ms"]
 

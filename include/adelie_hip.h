@@ -416,6 +416,9 @@ enum adelie_hip_scalar {
                                         solvers on the same design (cv_grpnet folds in flight): X is streamed once for all */
     ADELIE_HIP_S_N_UPDATE_COLS,      /* design columns streamed by the residual updates of the panel steps (n_updates counts
                                         groups on grouped problems; this counts their columns) */
+    ADELIE_HIP_S_N_DEVICE_SCREENS,   /* screening steps (solver_base.hpp:273-403) whose decision was taken on the device
+                                        (kernels_screen.hip) ... */
+    ADELIE_HIP_S_N_HOST_SCREENS,     /* ... and by the host routine (first iteration, host constraint objects, G > 2^18) */
     /* HIP-event time (ms) of the device phases on the design's stream, summed over the solve, and launch counts */
     ADELIE_HIP_S_T_SWEEP_MS = 80, ADELIE_HIP_S_T_GRAM_MS, ADELIE_HIP_S_T_CD_MS, ADELIE_HIP_S_T_AXPY_MS,
     ADELIE_HIP_S_N_SWEEP_LAUNCHES, ADELIE_HIP_S_N_GRAM_LAUNCHES, ADELIE_HIP_S_T_HOST_SCREEN_MS,

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_device_screen.py -m gpu -x -q 2>&1 | tail -15
+B="python bench.py --no-cpu-baseline --no-cv-leg --no-extra-legs"
+for v in 1 0 1 0; do
+ADELIE_HIP_DEVICE_SCREEN=$v $B --steps 5 --warmup 2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg2 devscreen=$v', round(d['value'],4), round(d['ms_per_step'],1), {k: round(v,1) for k,v in d['breakdown_ms_last_path'].items()}, d['counters'].get('n_device_screens'), d['counters'].get('n_host_screens'))"
+done

@@ -46,11 +46,16 @@ __device__ __forceinline__ T wsum(T x) {
 // ---- sweep ------------------------------------------------------------------------------------------------------------
 // grid (feature panels, row splits, response chunks of KT).  A block owns MCB features and walks its rows once; the KT
 // response vectors v_l are re-read per panel but from L2 (blocks of one row split are scheduled together and share them).
-template <class T, class Acc, int VEC, int KT, int MCB>
+// WPC ("wave per column group"): the four wavefronts of a block own MCB features each and all walk the same rows, so a
+// block covers 4 * MCB features and its waves read the same addresses of the K vectors at about the same time — the vectors
+// then cross L2 -> L1 once per 32 features instead of once per 8 (the kernel's time goes with that traffic, see MCB above).
+template <class T, class Acc, int VEC, int KT, int MCB, bool WPC = false>
 __global__ __launch_bounds__(MT) void multi_sweep_kernel(Acc X, const T* __restrict__ v, T* __restrict__ part,
                                                         int64_t nb, int64_t nfeat, int K, int64_t rows_per_split) {
     const int tid = threadIdx.x;
-    const int64_t cb = blockIdx.x;
+    const int64_t cb = WPC ? int64_t(blockIdx.x) * (MT / 64) + (tid >> 6) : int64_t(blockIdx.x);
+    constexpr int RT = WPC ? 64 : MT;         // threads that share the rows of one feature group
+    const int rtid = WPC ? (tid & 63) : tid;
     const int split = blockIdx.y;
     const int l0 = blockIdx.z * KT;
     const int64_t r0 = int64_t(split) * rows_per_split;
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(MT) void multi_sweep_kernel(Acc X, const T* __restr
         for (int kk = 0; kk < KT; ++kk) acc[k][kk] = T(0);
 
     const int64_t body_end = r0 + ((r1 - r0) / VEC) * VEC;
-    for (int64_t i = r0 + int64_t(tid) * VEC; i < body_end; i += int64_t(MT) * VEC) {
+    for (int64_t i = r0 + int64_t(rtid) * VEC; i < body_end; i += int64_t(RT) * VEC) {
         Pack<T, VEC> xx[MCB];
 #pragma unroll
         for (int k = 0; k < MCB; ++k) xx[k] = X.template load<VEC>(cp[k], i, cj[k]);
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(MT) void multi_sweep_kernel(Acc X, const T* __restr
             }
         }
     }
-    for (int64_t i = body_end + tid; i < r1; i += MT) {
+    for (int64_t i = body_end + rtid; i < r1; i += RT) {
         T x1[MCB];
 #pragma unroll
         for (int k = 0; k < MCB; ++k) x1[k] = X.template load<1>(cp[k], i, cj[k]).v[0];
@@ -98,6 +103,19 @@ __global__ __launch_bounds__(MT) void multi_sweep_kernel(Acc X, const T* __restr
         }
     }
 
+    if (WPC) { // every wavefront has its own features: no exchange between them
+        const int lane = tid & 63;
+#pragma unroll
+        for (int k = 0; k < MCB; ++k)
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk) {
+                const T s = wsum(acc[k][kk]);
+                const int64_t u = cb * MCB + k;
+                const int l = l0 + kk;
+                if (lane == 0 && u < nfeat && l < K) part[(int64_t(split) * nfeat + u) * K + l] = s;
+            }
+        return;
+    }
     __shared__ T red[MT / 64][MCB * KT];
     const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
@@ -121,6 +139,97 @@ __global__ __launch_bounds__(MT) void multi_sweep_kernel(Acc X, const T* __restr
     }
 }
 
+// The K = 8 sweep with the vectors staged through LDS.  The plain kernel's time goes with the bytes of the K vectors that
+// cross L2 -> L1 (measured: 1.73 ms with 4 features per block, 1.28-1.38 ms with 8; re-mapping the four waves onto feature
+// groups of their own without sharing changes nothing, i.e. waves do not meet in L1).  Here a block of four waves covers
+// 32 features: all waves walk the same rows, the block fetches each 8 KB tile of the vectors (64*VEC rows x 8 vectors) ONCE,
+// double-buffered in LDS with one barrier per tile, and every wave reads it from there — the vectors cross L2 -> L1 once per
+// 32 features instead of once per 8.
+template <class T, class Acc, int VEC>
+__global__ __launch_bounds__(MT) void multi_sweep_lds_kernel(Acc X, const T* __restrict__ v, T* __restrict__ part,
+                                                            int64_t nb, int64_t nfeat, int K, int64_t rows_per_split) {
+    constexpr int KT = 8, MCB = 8, TR = 64 * VEC;
+    using V = typename VecOf<T>::type; // 16 bytes = VEC rows
+    static_assert(MT == 256 && sizeof(V) == 16, "staging map below: 256 threads x 32 bytes = one 8 KB tile");
+    __shared__ V tile[2][KT][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t cb = int64_t(blockIdx.x) * (MT / 64) + (tid >> 6);
+    const int split = blockIdx.y;
+    const int l0 = blockIdx.z * KT;
+    const int64_t r0 = int64_t(split) * rows_per_split;
+    const int64_t r1 = min(nb, r0 + rows_per_split);
+    decltype(X.colptr(0)) cp[MCB];
+    int64_t cj[MCB];
+#pragma unroll
+    for (int k = 0; k < MCB; ++k) {
+        cj[k] = min(cb * MCB + k, nfeat - 1);
+        cp[k] = X.colptr(cj[k]);
+    }
+    T acc[MCB][KT];
+#pragma unroll
+    for (int k = 0; k < MCB; ++k)
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) acc[k][kk] = T(0);
+
+    const int64_t n_tiles = (r1 - r0) / TR;
+    // staging role of this thread: vector sk, the two 16-byte pieces sc, sc + 1 of its tile row
+    const int sk = tid >> 5, sc = (tid & 31) * 2;
+    const T* svp = v + int64_t(min(l0 + sk, K - 1)) * nb; // clamped: duplicates are discarded below
+    V s0, s1;
+    if (n_tiles > 0) {
+        s0 = *reinterpret_cast<const V*>(svp + r0 + int64_t(sc) * VEC);
+        s1 = *reinterpret_cast<const V*>(svp + r0 + int64_t(sc + 1) * VEC);
+        tile[0][sk][sc] = s0;
+        tile[0][sk][sc + 1] = s1;
+    }
+    __syncthreads();
+    for (int64_t it = 0; it < n_tiles; ++it) {
+        const int64_t base = r0 + it * TR, i = base + int64_t(lane) * VEC;
+        const bool more = it + 1 < n_tiles;
+        if (more) {
+            s0 = *reinterpret_cast<const V*>(svp + base + TR + int64_t(sc) * VEC);
+            s1 = *reinterpret_cast<const V*>(svp + base + TR + int64_t(sc + 1) * VEC);
+        }
+        Pack<T, VEC> xx[MCB];
+#pragma unroll
+        for (int k = 0; k < MCB; ++k) xx[k] = X.template load<VEC>(cp[k], i, cj[k]);
+        const int b = int(it & 1);
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            const V vv = tile[b][kk][lane];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+#pragma unroll
+                for (int k = 0; k < MCB; ++k) acc[k][kk] = fma(xx[k].v[e], vv[e], acc[k][kk]);
+        }
+        if (more) {
+            tile[b ^ 1][sk][sc] = s0;
+            tile[b ^ 1][sk][sc + 1] = s1;
+        }
+        __syncthreads();
+    }
+    for (int64_t i = r0 + n_tiles * TR + lane; i < r1; i += 64) { // rows beyond the last whole tile
+        T x1[MCB];
+#pragma unroll
+        for (int k = 0; k < MCB; ++k) x1[k] = X.template load<1>(cp[k], i, cj[k]).v[0];
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            const T vv = v[int64_t(min(l0 + kk, K - 1)) * nb + i];
+#pragma unroll
+            for (int k = 0; k < MCB; ++k) acc[k][kk] = fma(x1[k], vv, acc[k][kk]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MCB; ++k)
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            const T s = wsum(acc[k][kk]);
+            const int64_t u = cb * MCB + k;
+            const int l = l0 + kk;
+            if (lane == 0 && u < nfeat && l < K) part[(int64_t(split) * nfeat + u) * K + l] = s;
+        }
+}
+
 template <class T>
 __global__ void multi_sweep_reduce_kernel(const T* __restrict__ part, T* __restrict__ out, int64_t ncols, int nsplit) {
     const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -134,8 +243,15 @@ inline int msweep_mcb() {
     static const int v = (std::getenv("ADELIE_HIP_MULTI_SWEEP_MCB") && std::atoi(std::getenv("ADELIE_HIP_MULTI_SWEEP_MCB")) == 4) ? 4 : 8;
     return v;
 }
-inline void msweep_shape(int64_t nb, int64_t nfeat, int vec, int64_t& blocks_c, int& nsplit, int64_t& rows_per_split) {
-    const int MCB = msweep_mcb();
+// 0: one feature group per block; 1: four waves x 8 features; 2: four waves x 4 features (half the accumulators, twice the
+// waves per SIMD: 2.2 ms, the vectors' L2 traffic doubles); 3: four waves x 8 features with the vectors staged through LDS
+inline int msweep_wpc() {
+    static const int v = std::getenv("ADELIE_HIP_MULTI_SWEEP_WPC") ? std::atoi(std::getenv("ADELIE_HIP_MULTI_SWEEP_WPC")) : 3;
+    return v;
+}
+inline void msweep_shape(int64_t nb, int64_t nfeat, int vec, int64_t& blocks_c, int& nsplit, int64_t& rows_per_split,
+                         int wpc = 0) {
+    const int MCB = wpc == 2 ? 4 * (MT / 64) : wpc ? 8 * (MT / 64) : msweep_mcb();
     blocks_c = (nfeat + MCB - 1) / MCB;
     const int64_t unit = int64_t(MT) * vec;
     const int64_t max_split = std::max<int64_t>(1, (nb + unit * 4 - 1) / (unit * 4));
@@ -450,7 +566,12 @@ int64_t multi_sweep_work_elems(const MultiView<T>& X) {
     int64_t bc, rps;
     int ns;
     msweep_shape(X.nb, X.pb + X.icpt, VecOf<T>::N, bc, ns, rps);
-    return int64_t(ns) * (X.pb + X.icpt) * X.K + 16;
+    int64_t bc2, rps2;
+    int ns2;
+    msweep_shape(X.nb, X.pb + X.icpt, VecOf<T>::N, bc2, ns2, rps2, 1);
+    ns = std::max(ns, ns2);
+    msweep_shape(X.nb, X.pb + X.icpt, VecOf<T>::N, bc2, ns2, rps2, 2);
+    return int64_t(std::max(ns, ns2)) * (X.pb + X.icpt) * X.K + 16;
 }
 
 template <class T>
@@ -461,18 +582,26 @@ void launch_multi_sweep(const MultiView<T>& X, const T* v, T* out, T* work, hipS
     constexpr int V = VecOf<T>::N;
     int64_t bc, rps;
     int ns;
-    msweep_shape(X.nb, nfeat, V, bc, ns, rps); // shape for the vector width (also valid for scalar loads)
     const int KT = kt_of(X.K);
+    const int wpc = (KT == 8 && msweep_mcb() == 8) ? msweep_wpc() : 0;
+    msweep_shape(X.nb, nfeat, V, bc, ns, rps, wpc); // shape for the vector width (also valid for scalar loads)
     const dim3 grid((unsigned)bc, (unsigned)ns, (unsigned)((X.K + KT - 1) / KT));
     const bool vok = multi_vecok(X);
 #define AHIP_MS(VV, KK)                                                                                                 \
     do {                                                                                                                \
-        if (msweep_mcb() == 8)                                                                                          \
+        if (wpc == 2)                                                                                                   \
+            hipLaunchKernelGGL((multi_sweep_kernel<T, DenseOnesAcc<T>, VV, KK, 4, true>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps); \
+        else if (wpc)                                                                                                   \
+            hipLaunchKernelGGL((multi_sweep_kernel<T, DenseOnesAcc<T>, VV, KK, 8, true>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps); \
+        else if (msweep_mcb() == 8)                                                                                     \
             hipLaunchKernelGGL((multi_sweep_kernel<T, DenseOnesAcc<T>, VV, KK, 8>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps); \
         else                                                                                                            \
             hipLaunchKernelGGL((multi_sweep_kernel<T, DenseOnesAcc<T>, VV, KK, 4>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps); \
     } while (0)
-    if (vok) {
+    const bool v_al = X.nb % V == 0 && (reinterpret_cast<uintptr_t>(v) % 16) == 0; // each of the K vectors starts 16-byte aligned
+    if (vok && v_al && wpc == 3) {
+        hipLaunchKernelGGL((multi_sweep_lds_kernel<T, DenseOnesAcc<T>, V>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps);
+    } else if (vok) {
         if (KT == 8) AHIP_MS(V, 8); else if (KT == 4) AHIP_MS(V, 4); else AHIP_MS(V, 2);
     } else {
         if (KT == 8) AHIP_MS(1, 8); else if (KT == 4) AHIP_MS(1, 4); else AHIP_MS(1, 2);

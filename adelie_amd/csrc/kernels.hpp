@@ -504,6 +504,35 @@ struct ScreenArgs {
     int32_t* dev_list;                                        // optional copy of the list in device memory (G)
 };
 template <class T> void launch_screen(const ScreenArgs<T>& a, bool need_order, hipStream_t s);
+// Appending new screen groups to the device mirrors (solver.hip::device_append_screen): ONE packed upload + one scatter
+// launch instead of seven to ten small copies per lambda.  Packed image (8-byte aligned throughout):
+//   T      pen[Ng], beta[Nv], (lo[Nv], hi[Nv], mu[Nv] when `cons`)
+//   int32  begin[Ng], size[Ng], isact[Ng], group[Ng], vcol[Nv]
+template <class T>
+struct AppendDst {
+    T* spen; T* beta; T* clo; T* chi; T* cmu;
+    int32_t* sbegin; int32_t* ssize; int8_t* isact; int32_t* slot; int32_t* vcol;
+    int32_t ns_old, nv_old, Ng, Nv, cons;
+};
+template <class T>
+struct AppendImage { // offsets (bytes) of the arrays inside the packed image
+    size_t pen, beta, lo, hi, mu, begin, size, isact, group, vcol, total;
+    __host__ __device__ AppendImage(int Ng, int Nv, bool cons) {
+        size_t o = 0;
+        pen = o; o += sizeof(T) * size_t(Ng);
+        beta = o; o += sizeof(T) * size_t(Nv);
+        lo = hi = mu = o;
+        if (cons) { lo = o; o += sizeof(T) * size_t(Nv); hi = o; o += sizeof(T) * size_t(Nv); mu = o; o += sizeof(T) * size_t(Nv); }
+        o = (o + 7) & ~size_t(7);
+        begin = o; o += 4 * size_t(Ng);
+        size = o; o += 4 * size_t(Ng);
+        isact = o; o += 4 * size_t(Ng);
+        group = o; o += 4 * size_t(Ng);
+        vcol = o; o += 4 * size_t(Nv);
+        total = (o + 7) & ~size_t(7);
+    }
+};
+template <class T> void launch_screen_append(const void* image_dev, const AppendDst<T>& d, hipStream_t s);
 // Eigen-decomposition of new screen groups' Gram blocks on the device (kernels_eig.hip): group `i` of the launch reads the
 // (q, q) block at src_base + src (leading dimension ld), writes its eigenvalues (ascending, clamped at 0) to
 // vars[vars_pos .. + q) and its eigenvectors (column-major, in the columns) to V[v_off .. + q*q).  q == 1: the variance only.

@@ -448,6 +448,8 @@ struct Solver {
     DevBuf<int32_t> d_vcol, d_sbegin, d_ssize, d_actset, d_dcols;
     DevBuf<T> d_spen, d_beta, d_beta0, d_g, d_vars, d_sxm, d_dvals;
     DevBuf<int8_t> d_isact;
+    DevBuf<char> d_app;          // packed image of the new screen groups (device_append_screen)
+    std::vector<char> app_img;
     DevBuf<idx> d_voff;
     DevBuf<T> d_V;
     size_t v_used = 0;
@@ -1378,16 +1380,17 @@ struct Solver {
             }
             nv_new += group_sizes[g];
         }
-        d_vcol.upload(vcol.data(), vcol.size(), st, nv_old);
         h_vcol.resize(size_t(nv_old));
         h_vcol.insert(h_vcol.end(), vcol.begin(), vcol.end());
-        d_beta.upload(beta_new.data(), beta_new.size(), st, nv_old);
-        d_sbegin.upload(sbegin.data(), sbegin.size(), st, ns_dev);
-        d_ssize.upload(ssize.data(), ssize.size(), st, ns_dev);
-        d_spen.upload(spen.data(), spen.size(), st, ns_dev);
-        d_isact.upload(isact.data(), isact.size(), st, ns_dev);
-        std::vector<T> clo_new, chi_new, cmu_new; // per screen value (only groups of one coefficient carry a constraint)
-        if (cons_on) {
+        // one packed image of everything the new groups add to the device mirrors, one upload, one scatter launch
+        const int Ng = int(ns - ns_dev), Nv = int(nv_new - nv_old);
+        const AppendImage<T> L(Ng, Nv, cons_on);
+        app_img.assign(L.total, 0);
+        auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes) std::memcpy(app_img.data() + off, src, bytes); };
+        put(L.pen, spen.data(), sizeof(T) * spen.size());
+        put(L.beta, beta_new.data(), sizeof(T) * beta_new.size());
+        if (cons_on) { // per screen value (only groups of one coefficient carry a constraint)
+            std::vector<T> clo_new, chi_new, cmu_new;
             for (idx ss = ns_dev; ss < ns; ++ss) {
                 const idx g = screen_set[ss];
                 for (idx t = 0; t < group_sizes[g]; ++t) {
@@ -1396,14 +1399,26 @@ struct Solver {
                     cmu_new.push_back(cons_mu[g]);
                 }
             }
-            d_clo.upload(clo_new.data(), clo_new.size(), st, nv_old);
-            d_chi.upload(chi_new.data(), chi_new.size(), st, nv_old);
-            d_cmu.upload(cmu_new.data(), cmu_new.size(), st, nv_old);
+            put(L.lo, clo_new.data(), sizeof(T) * clo_new.size());
+            put(L.hi, chi_new.data(), sizeof(T) * chi_new.size());
+            put(L.mu, cmu_new.data(), sizeof(T) * cmu_new.size());
         }
-        // slots: group -> value offset (whole table re-uploaded: G * 4 bytes)
-        if (slot_host.size() != size_t(G)) slot_host.assign(G, -1);
+        std::vector<int32_t> isact32(isact.begin(), isact.end()), grp32;
+        for (idx ss = ns_dev; ss < ns; ++ss) grp32.push_back(int32_t(screen_set[ss]));
+        put(L.begin, sbegin.data(), 4 * sbegin.size());
+        put(L.size, ssize.data(), 4 * ssize.size());
+        put(L.isact, isact32.data(), 4 * isact32.size());
+        put(L.group, grp32.data(), 4 * grp32.size());
+        put(L.vcol, vcol.data(), 4 * vcol.size());
+        if (slot_host.size() != size_t(G)) slot_host.assign(G, -1); // (host mirror of d_slot; the device table starts at -1)
         for (idx ss = ns_dev; ss < ns; ++ss) slot_host[screen_set[ss]] = int32_t(screen_begins[ss]);
-        d_slot.upload(slot_host.data(), size_t(G), st);
+        d_app.reserve(L.total);
+        d_app.upload(app_img.data(), L.total, st);
+        AppendDst<T> ad{};
+        ad.spen = d_spen.p; ad.beta = d_beta.p; ad.clo = d_clo.p; ad.chi = d_chi.p; ad.cmu = d_cmu.p;
+        ad.sbegin = d_sbegin.p; ad.ssize = d_ssize.p; ad.isact = d_isact.p; ad.slot = d_slot.p; ad.vcol = d_vcol.p;
+        ad.ns_old = int32_t(ns_dev); ad.nv_old = int32_t(nv_old); ad.Ng = Ng; ad.Nv = Nv; ad.cons = cons_on ? 1 : 0;
+        launch_screen_append<T>(d_app.p, ad, st);
         // the vectors above go out of scope: wait unless every upload took a snapshot into the pinned arena (a wait here also
         // waits for the speculative pass that may be running in-stream: 0.3 ms per lambda on the headline path)
         if (Staging::current() != &stage || !stage.base || stage.n_fallback != fallbacks0) sync();

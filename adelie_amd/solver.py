@@ -106,16 +106,34 @@ def _sweep(X, v, weights, dtype):
     return out
 
 
+def _has_batched_sweep(X):
+    """``X.mul_batch`` exists and the library behind ``X`` exports the batched sweep (user-defined matrix classes and
+    libraries without the entry point take one ``X.mul`` per vector)."""
+    backend = getattr(X, "_backend", None)
+    if not hasattr(X, "mul_batch") or backend is None:
+        return False
+    try:
+        backend.fn("design_mul_batch")
+    except AttributeError:
+        return False
+    return True
+
+
 def _start_gaussian(X, glm, offsets, intercept, dtype):
     """Invariants of ``beta = 0`` for the Gaussian loss ``sum_i w_i (eta_i^2 / 2 - y_i eta_i)`` (reference ``solver.py:886-906``).
     ``grad`` is handed over WITHOUT the ``-resid_sum * X_means`` centring term: at the start ``resid_sum`` is zero when there
     is an intercept, and without one the term does not exist."""
     w = glm.weights
     n = X.rows()
-    X_means = _sweep(X, np.ones(n, dtype=dtype), w, dtype)
     y_off = glm.y - offsets
     y_mean = np.sum(y_off * w)
     resid = y_off - y_mean if intercept else y_off
+    if _has_batched_sweep(X):
+        # both sweeps in ONE pass over the resident design (two vectors side by side): the reference makes two X.mul calls
+        X_means, grad = X.mul_batch(np.stack([np.asarray(w, dtype=dtype), np.asarray(resid * w, dtype=dtype)]))
+    else:
+        X_means = _sweep(X, np.ones(n, dtype=dtype), w, dtype)
+        grad = _sweep(X, resid, w, dtype)
     return {
         "X_means": X_means,
         "y_mean": y_mean,
@@ -123,7 +141,7 @@ def _start_gaussian(X, glm, offsets, intercept, dtype):
         "rsq": 0,
         "resid": resid,
         "resid_sum": np.sum(w * resid),
-        "grad": _sweep(X, resid, w, dtype),
+        "grad": grad,
     }
 
 

@@ -2157,8 +2157,9 @@ struct Solver {
             const int count = screen_pass ? cp.nv : asz;
             if (count <= 0) return T(0);
             const int32_t* cols_all = d_vcol.p;
-            if (!screen_pass) {
-                launch_gather_i32(d_vcol.p, cp.active_set, count, d_actcols.p, st);
+            if (!screen_pass) { // (the active list only grows by appending: the gathered columns of `count` entries stay valid)
+                if (actcols_key != count) launch_gather_i32(d_vcol.p, cp.active_set, count, d_actcols.p, st);
+                actcols_key = count;
                 cols_all = d_actcols.p;
             }
             auto& tab_nb = screen_pass ? dscr_nb : dact_nb;
@@ -2296,8 +2297,9 @@ struct Solver {
             const int count = screen_pass ? cp.nv : asz;
             if (count <= 0) return T(0);
             const int32_t* cols_all = d_vcol.p;
-            if (!screen_pass) {
-                launch_gather_i32(d_vcol.p, cp.active_set, count, d_actcols.p, st);
+            if (!screen_pass) { // (the active list only grows by appending: the gathered columns of `count` entries stay valid)
+                if (actcols_key != count) launch_gather_i32(d_vcol.p, cp.active_set, count, d_actcols.p, st);
+                actcols_key = count;
                 cols_all = d_actcols.p;
             }
             auto& tab_nb = screen_pass ? dscr_nb : dact_nb;
@@ -2455,6 +2457,14 @@ struct Solver {
 
     // Same for problems with groups: blocks of consecutive groups (<= 128 values), partition built on the host.
     DevBuf<int32_t> d_blk_g0;
+    // Per-pass tables of the panel engines, kept across passes: both visiting lists only grow by appending, so the partition
+    // of the first `count` entries, the design columns behind them and the layout descriptors of their blocks are those of the
+    // previous pass over the same list unless the list grew.  One copy per list (the screen list uses d_blk_g0 / d_gdesc).
+    int64_t actcols_key = -1;                 // lasso engine: entries of the active list gathered into d_actcols
+    struct PassTables { int64_t count = -1; int nblk = 0; };
+    PassTables ptab_scr, ptab_act;
+    DevBuf<int32_t> d_blk_g0_act, d_gdesc_act;
+    bool pass_tables_cached = true;           // A/B hook ADELIE_HIP_PASS_TABLES=0
     std::vector<int32_t> part_host;
     int build_partition(const idx* list, idx count) { // returns nblk; fills part_host with nblk+1 list positions
         const int B = cd_block_size();
@@ -2505,6 +2515,7 @@ struct Solver {
             const int nblk = build_partition(screen_pass ? nullptr : act_host.data(), count);
             d_blk_g0.reserve(part_host.size());
             d_blk_g0.upload(part_host.data(), part_host.size(), st);
+            ptab_scr.count = -1; // (this engine shares d_blk_g0 with the panel engine's screen-list tables)
             bp.blk_g0 = d_blk_g0.p;
             bp.list = screen_pass ? nullptr : cp.active_set;
             bp.nblk = nblk;
@@ -2766,28 +2777,39 @@ struct Solver {
             const idx count = screen_pass ? idx(cp.ns) : idx(asz);
             if (count <= 0) return T(0);
             const int nblk = build_partition_values(screen_pass ? nullptr : act_host.data(), count);
-            d_blk_g0.reserve(part_host.size());
-            d_blk_g0.upload(part_host.data(), part_host.size(), st);
+            PassTables& ptab = screen_pass ? ptab_scr : ptab_act;
+            DevBuf<int32_t>& g0buf = screen_pass ? d_blk_g0 : d_blk_g0_act;
+            DevBuf<int32_t>& descbuf = screen_pass ? d_gdesc : d_gdesc_act;
+            const bool tables_hit = pass_tables_cached && ptab.count == int64_t(count) && ptab.nblk == nblk && g0buf.p && descbuf.p;
+            if (!tables_hit) {
+                g0buf.reserve(std::max<size_t>(part_host.size(), maxblk + 2));
+                g0buf.upload(part_host.data(), part_host.size(), st);
+            }
             const int32_t* cols_all = d_vcol.p;
             if (!screen_pass) {
-                acols.clear();
-                for (idx pos = 0; pos < count; ++pos) {
-                    const idx g = screen_set[act_host[pos]];
-                    for (idx t = 0; t < group_sizes[g]; ++t) acols.push_back(int32_t(groups[g] + t));
+                if (!tables_hit) {
+                    acols.clear();
+                    for (idx pos = 0; pos < count; ++pos) {
+                        const idx g = screen_set[act_host[pos]];
+                        for (idx t = 0; t < group_sizes[g]; ++t) acols.push_back(int32_t(groups[g] + t));
+                    }
+                    d_actcols.upload(acols.data(), acols.size(), st);
                 }
-                d_actcols.upload(acols.data(), acols.size(), st);
                 cols_all = d_actcols.p;
             }
             auto& tab_nb = screen_pass ? dscr_nb : dact_nb;
             auto& tab_ver = screen_pass ? dscr_ver : dact_ver;
             T* pool = d_Dpool.p + (screen_pass ? size_t(0) : maxblk * SL * SL);
             T* xpool = d_Xpool.p + (screen_pass ? size_t(0) : maxblk * SL * SL);
-            bp.blk_g0 = d_blk_g0.p;
+            bp.blk_g0 = g0buf.p;
             bp.list = screen_pass ? nullptr : cp.active_set;
             bp.nblk = nblk;
             bp.mark = screen_pass ? 1 : 0;
-            bp.desc = d_gdesc.p;
-            if (bp.rot) launch_grp_layout<T>(bp, nblk, d_gdesc.p, st);
+            descbuf.reserve(maxblk * size_t(GDESC_STRIDE));
+            bp.desc = descbuf.p;
+            if (bp.rot && !tables_hit) launch_grp_layout<T>(bp, nblk, descbuf.p, st);
+            ptab.count = int64_t(count);
+            ptab.nblk = nblk;
             auto nb_of = [&](int j) { return int(gp_vbeg[size_t(j) + 1] - gp_vbeg[j]); };
             auto cols_of = [&](int j) { return cols_all + gp_vbeg[j]; };
             record_pass_e0();
@@ -2932,28 +2954,39 @@ struct Solver {
             if (count <= 0) return T(0);
             last_on_host = false;
             const int nblk = build_partition_values(screen_pass ? nullptr : act_host.data(), count);
-            d_blk_g0.reserve(part_host.size());
-            d_blk_g0.upload(part_host.data(), part_host.size(), st);
+            PassTables& ptab = screen_pass ? ptab_scr : ptab_act;
+            DevBuf<int32_t>& g0buf = screen_pass ? d_blk_g0 : d_blk_g0_act;
+            DevBuf<int32_t>& descbuf = screen_pass ? d_gdesc : d_gdesc_act;
+            const bool tables_hit = pass_tables_cached && ptab.count == int64_t(count) && ptab.nblk == nblk && g0buf.p && descbuf.p;
+            if (!tables_hit) {
+                g0buf.reserve(std::max<size_t>(part_host.size(), maxblk + 2));
+                g0buf.upload(part_host.data(), part_host.size(), st);
+            }
             const int32_t* cols_all = d_vcol.p;
             if (!screen_pass) { // design columns of the active values in visiting order
-                acols.clear();
-                for (idx pos = 0; pos < count; ++pos) {
-                    const idx g = screen_set[act_host[pos]];
-                    for (idx t = 0; t < group_sizes[g]; ++t) acols.push_back(int32_t(groups[g] + t));
+                if (!tables_hit) {
+                    acols.clear();
+                    for (idx pos = 0; pos < count; ++pos) {
+                        const idx g = screen_set[act_host[pos]];
+                        for (idx t = 0; t < group_sizes[g]; ++t) acols.push_back(int32_t(groups[g] + t));
+                    }
+                    d_actcols.upload(acols.data(), acols.size(), st);
                 }
-                d_actcols.upload(acols.data(), acols.size(), st);
                 cols_all = d_actcols.p;
             }
             auto& tab_nb = screen_pass ? dscr_nb : dact_nb;
             auto& tab_ver = screen_pass ? dscr_ver : dact_ver;
             T* pool = d_Dpool.p + (screen_pass ? size_t(0) : maxblk * SL * SL);
-            bp.blk_g0 = d_blk_g0.p;
+            bp.blk_g0 = g0buf.p;
             bp.list = screen_pass ? nullptr : cp.active_set;
             bp.nblk = nblk;
             bp.mark = screen_pass ? 1 : 0;
-            bp.desc = d_gdesc.p;
+            descbuf.reserve(maxblk * size_t(GDESC_STRIDE));
+            bp.desc = descbuf.p;
             bp.pdd = nullptr; bp.dd = nullptr;
-            if (bp.rot) launch_grp_layout<T>(bp, nblk, d_gdesc.p, st);
+            if (bp.rot && !tables_hit) launch_grp_layout<T>(bp, nblk, descbuf.p, st);
+            ptab.count = int64_t(count);
+            ptab.nblk = nblk;
             if (strips_apply()) {
                 T* raw = group_rot ? d_Draw.reserve(size_t(2) * maxblk * SL * SL) + (screen_pass ? size_t(0) : maxblk * SL * SL) : pool;
                 build_stale_strips(nblk, tab_nb, tab_ver, nullptr, raw, static_cast<T*>(nullptr),
@@ -4032,6 +4065,7 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_STRIP_LDS")) set_strip_lds(std::atoi(e) != 0);
         if (const char* e = std::getenv("ADELIE_HIP_DEVICE_EIG")) device_eig = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_DEVICE_SCREEN")) dev_screen = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_PASS_TABLES")) pass_tables_cached = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_IRLS_REUSE")) irls_reuse = std::max(0.0, std::atof(e));
         if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {
             panel_bsz = std::atoi(e);

@@ -363,6 +363,10 @@ template <class T>
 int launch_panel_step_snp(const SnpView& X, const T* impute, const T* w, T* r, const int32_t* dcol, const T* dlt,
                           const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s);
 int64_t panel_part_elems(int64_t n);
+// Opening of a look-ahead pass whose block-0 gradient already exists: g[c] = grad[cols[c]] (c < nb) out of the full gradient
+// the invariance sweep left for the same residual, and both look-ahead residual-sum slots <- rsum_src[0] (nullptr: skip).
+template <class T>
+void launch_la_open_from_grad(const T* grad, const int32_t* cols, int nb, T* g, const T* rsum_src, T* rsum_out, hipStream_t s);
 // gblk[c] = sum_slices part[c][.] - (xm_by_col ? rsum_dev[0] * xm_by_col[cols[c]] : 0)
 template <class T>
 void launch_panel_reduce(const T* part, int nslices, int nb, const int32_t* cols, const T* rsum_dev, const T* xm_by_col,

@@ -505,6 +505,26 @@ int launch_panel_fused_grp_snp(const CdGrpBlkParams<T>& sp, int j, const SnpView
     return fused_grp_launch<T, SnpAcc<T>, 4>(sp, j, acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, tr, s);
 }
 
+namespace {
+template <class T>
+__global__ void la_open_kernel(const T* __restrict__ grad, const int32_t* __restrict__ cols, int nb, T* __restrict__ g,
+                               const T* __restrict__ rsum_src, T* __restrict__ rsum_out) {
+    const int c = threadIdx.x;
+    if (c < nb) g[c] = grad[cols[c]];
+    if (c == 0 && rsum_src) {
+        const T v = rsum_src[0];
+        rsum_out[0] = v;
+        rsum_out[1] = v;
+    }
+}
+} // namespace
+template <class T>
+void launch_la_open_from_grad(const T* grad, const int32_t* cols, int nb, T* g, const T* rsum_src, T* rsum_out, hipStream_t s) {
+    hipLaunchKernelGGL((la_open_kernel<T>), dim3(1), dim3(PB), 0, s, grad, cols, nb, g, rsum_src, rsum_out);
+}
+template void launch_la_open_from_grad<double>(const double*, const int32_t*, int, double*, const double*, double*, hipStream_t);
+template void launch_la_open_from_grad<float>(const float*, const int32_t*, int, float*, const float*, float*, hipStream_t);
+
 int64_t panel_part_elems(int64_t n) { return int64_t(PB) * ((n + 63) / 64) + 16; }
 
 template <class T>

@@ -1003,6 +1003,10 @@ struct Solver {
     }
     DevBuf<T> d_work_sweep, d_work_gram;
     bool grad_valid = false; // d_grad == X^T W r - rsum*xbar for the current r
+    // In stream order, d_grad holds the full Gaussian gradient of the CURRENT d_r (an invariance sweep was enqueued and nothing
+    // touched the residual since): the first look-ahead pass of the next fit takes block 0's gradient from it instead of
+    // streaming the block's columns (open_from_grad, consumed by run_panel_passes).  Hook ADELIE_HIP_OPEN_FROM_GRAD=0.
+    bool grad_fresh = false, open_from_grad = false, open_from_grad_opt = true, spec_used_grad = false;
     // glm device vectors
     DevBuf<T> d_y, d_gw, d_off, d_eta, d_hess, d_irls_y, d_irls_resid, d_eta_prev, d_resid_prev, d_sums, d_ones;
     // host mirrors of per-screen arrays used to append
@@ -2109,6 +2113,8 @@ struct Solver {
         bs.nz = 0;
         const int mode = spec_mode; // 1: enqueue one (speculative) active pass and return; 2: that pass is already in flight
         if (mode != 2) d_blk.upload(&bs, 1, st);
+        bool first_open = open_from_grad && mode != 2 && !cons_on; // block 0 of the first pass: gradient from the sweep
+        open_from_grad = false;
         CdBlkParams<T> bp{};
         bp.nv = cp.nv; bp.vars = cp.vars; bp.xmean = cp.xmean; bp.spen = cp.spen;
         bp.beta = cp.beta; bp.is_active = cp.is_active; bp.active_set = cp.active_set;
@@ -2154,6 +2160,8 @@ struct Solver {
         }
         bool no_wait = false;
         auto pass_la = [&](bool screen_pass) -> T {
+            const bool first_pass = first_open;
+            first_open = false;
             const int count = screen_pass ? cp.nv : asz;
             if (count <= 0) return T(0);
             const int32_t* cols_all = d_vcol.p;
@@ -2184,7 +2192,13 @@ struct Solver {
             // prepares block 1 — one launch, one boundary and 93 MB of the first step less per pass than step + reduce + solve.
             const bool fr_open = fuse_reduce && la_fused_open;
             int prev_ld = 0;         // partials of block j left behind by the previous fused launch (0: none, gblk is ready)
-            if (fr_open) {
+            const bool from_grad = fr_open && first_pass && pending_slot < 0;
+            if (from_grad) {
+                // first pass of a fit right behind the invariance sweep: nothing is pending and the sweep's gradient IS the
+                // block-entry gradient of block 0 — no opening launch (93 MB of columns and a launch less per fit)
+                launch_la_open_from_grad<T>(d_grad.p, cols_all, nb_of(0), d_la_g.p, xm_c ? &d_blk.p->resid_sum : nullptr,
+                                            d_la_rsum.p, st);
+            } else if (fr_open) {
                 const int ps = pending_slot;
                 CdBlkParams<T> op = bp;
                 op.report_j = -1;
@@ -2294,6 +2308,7 @@ struct Solver {
             return bs.cm;
         };
         auto pass_plain = [&](bool screen_pass) -> T {
+            first_open = false; // (only the very first pass of a fit starts from the residual the sweep saw)
             const int count = screen_pass ? cp.nv : asz;
             if (count <= 0) return T(0);
             const int32_t* cols_all = d_vcol.p;
@@ -3182,6 +3197,8 @@ struct Solver {
         Stopwatch sw;
         sw.start();
         bool small_fit = false; // the whole pin solve ran in the single-workgroup kernel (its scalars are in d_sc)
+        open_from_grad = grad_fresh && open_from_grad_opt && !is_glm() && !cov_mode && r_dev == d_r.p && !resume;
+        grad_fresh = false; // (whatever engine runs, the residual moves)
         if (!(nv > 0 && panel_mode() && !all_scalar)) join_uv(); // (only the group panel passes know which of them need it)
         if (nv > 0 && panel_mode()) {
             spec_mode = resume ? 2 : 0;
@@ -3197,6 +3214,7 @@ struct Solver {
                 sweep(d_v.p, d_grad.p, nullptr, p, &d_blk.p->resid_sum, intercept ? d_xm.p : nullptr);
                 t_sweep.end(st);
                 device_abs_grad(lm, int(sc.active_size));
+                grad_fresh = true;
                 inv_prelaunched = true;
                 inv_prelaunched_lm = lm;
             }
@@ -3215,6 +3233,7 @@ struct Solver {
             small_fit = true;
         }
         const double t_cd = sw.elapsed();
+        open_from_grad = false; // (only the lasso panel engine takes it)
         if (nv == 0) {
             // one (empty) active pass + one (empty) screen pass; their convergence measure is 0, so with a zero
             // tolerance (y_var == 0) the reference never leaves the loop and reports max_iters (pin_naive:317-357)
@@ -3256,6 +3275,7 @@ struct Solver {
             sweep(d_v.p, d_grad.p, nullptr, p, &d_sc.p->resid_sum, intercept ? d_xm.p : nullptr);
             t_sweep.end(st);
             device_abs_grad(lm, int(sc.active_size));
+            grad_fresh = true;
             inv_prelaunched = true;
             inv_prelaunched_lm = lm;
         }
@@ -3294,6 +3314,9 @@ struct Solver {
             sc2.resid_sum = sc.resid_sum;
             sc2.active_size = sc.active_size;
             spec_mode = 1;
+            open_from_grad = grad_fresh && open_from_grad_opt; // (the sweep of this lambda went out just above, on the residual the pass starts from)
+            spec_used_grad = grad_fresh;
+            grad_fresh = false;
             {
                 struct ModeGuard { int& m; ~ModeGuard() { m = 0; } } mode_guard{spec_mode};
                 if (all_scalar) run_panel_passes(cp2, sc2, r_dev);
@@ -3686,6 +3709,7 @@ struct Solver {
         cnt.n_panel_blocks -= spec_blocks;
         cnt.n_panel_cols -= spec_cols;
         spec_active = false;
+        grad_fresh = spec_used_grad; // the residual is the one the sweep saw again: the refit opens as the pass taken back did
         ++n_spec_rollback;
     }
     void update_invariance(T lm) {
@@ -3722,6 +3746,7 @@ struct Solver {
             sweep(d_v.p, d_grad.p, nullptr, p, &d_sc.p->resid_sum, intercept ? d_xm.p : nullptr);
             t_sweep.end(st);
             grad_valid = true;
+            grad_fresh = true;
         }
         device_abs_grad(lm, int(active_set_size));
         sync();
@@ -4066,6 +4091,7 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_DEVICE_EIG")) device_eig = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_DEVICE_SCREEN")) dev_screen = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_PASS_TABLES")) pass_tables_cached = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_OPEN_FROM_GRAD")) open_from_grad_opt = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_IRLS_REUSE")) irls_reuse = std::max(0.0, std::atof(e));
         if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {
             panel_bsz = std::atoi(e);

@@ -2715,6 +2715,8 @@ struct Solver {
         bs.nz = 0;
         const int mode = spec_mode; // see run_panel_passes
         if (mode != 2) d_blk.upload(&bs, 1, st);
+        bool first_open = open_from_grad && mode != 2 && !cons_on && !multi(); // see run_panel_passes
+        open_from_grad = false;
         CdGrpBlkParams<T> bp{};
         bp.nv = cp.nv; bp.vars = cp.vars; bp.xmean = cp.xmean; bp.beta = cp.beta;
         bp.is_active = cp.is_active; bp.active_set = cp.active_set;
@@ -2789,6 +2791,8 @@ struct Solver {
         bool no_wait = false;
         d_gdesc.reserve(maxblk * size_t(GDESC_STRIDE));
         auto pass_la = [&](bool screen_pass) -> T {
+            const bool first_pass = first_open;
+            first_open = false;
             const idx count = screen_pass ? idx(cp.ns) : idx(asz);
             if (count <= 0) return T(0);
             const int nblk = build_partition_values(screen_pass ? nullptr : act_host.data(), count);
@@ -2835,7 +2839,11 @@ struct Solver {
             // prepares block 0 (its last step workgroup leaves the gradient); block 0 is then solved by a regular fused
             // launch whose step applies nothing and prepares block 1 - instead of step + two reduces + a stand-alone solve.
             const bool fr_open = tail_ok && la_fused_open && dense();
-            if (fr_open) {
+            if (fr_open && first_pass && pending_slot < 0) {
+                // (as in run_panel_passes: block 0's gradient out of the sweep's result, no opening launch)
+                launch_la_open_from_grad<T>(d_grad.p, cols_all, nb_of(0), d_la_g.p, xm_c ? &d_blk.p->resid_sum : nullptr,
+                                            d_la_rsum.p, st);
+            } else if (fr_open) {
                 const int ps = pending_slot;
                 CdGrpBlkParams<T> op = bp;
                 op.report_j = -1;
@@ -2965,6 +2973,7 @@ struct Solver {
         CdBlkState<T> host_bs{};
         bool last_on_host = false;
         auto pass_plain = [&](bool screen_pass) -> T {
+            first_open = false;
             const idx count = screen_pass ? idx(cp.ns) : idx(asz);
             if (count <= 0) return T(0);
             last_on_host = false;
@@ -3233,7 +3242,7 @@ struct Solver {
             small_fit = true;
         }
         const double t_cd = sw.elapsed();
-        open_from_grad = false; // (only the lasso panel engine takes it)
+        open_from_grad = false; // (only the panel engines take it)
         if (nv == 0) {
             // one (empty) active pass + one (empty) screen pass; their convergence measure is 0, so with a zero
             // tolerance (y_var == 0) the reference never leaves the loop and reports max_iters (pin_naive:317-357)

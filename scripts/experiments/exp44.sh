@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+timeout 1400 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+B="python bench.py --no-cpu-baseline --no-cv-leg --no-extra-legs"
+for v in 1 0 1 0; do
+ADELIE_HIP_OPEN_FROM_GRAD=$v $B --config 3 --steps 3 --warmup 1 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg3 fromgrad=$v', round(d['value'],4), round(d['ms_per_step'],1), {k: round(v,1) for k,v in d['breakdown_ms_last_path'].items()}, d['counters']['n_updates'])"
+done

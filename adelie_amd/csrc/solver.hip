@@ -4528,7 +4528,10 @@ void run(adelie_hip_design* X, const adelie_hip_grpnet_args* a, adelie_hip_resul
     if (staging_on) r->s.stage.init(size_t(8) << 20, X->stream);
     Staging::Scope stage_scope(staging_on ? &r->s.stage : nullptr);
     DeferredFrees::Scope deferred_scope(&r->s.deferred);
+    Stopwatch sw_build;
+    sw_build.start();
     r->s.build(X, a);
+    if (std::getenv("ADELIE_HIP_TRACE_ENQ")) std::fprintf(stderr, "[build] state set-up %.2f ms\n", sw_build.elapsed() * 1e3);
     Stopwatch sw;
     sw.start();
     struct BatchGuard { // registered for sweep batching exactly while the path runs
@@ -4556,6 +4559,7 @@ void run(adelie_hip_design* X, const adelie_hip_grpnet_args* a, adelie_hip_resul
         if (r->s.error.empty()) r->s.error = e.what();
     }
     r->s.total_time = sw.elapsed();
+    if (std::getenv("ADELIE_HIP_TRACE_ENQ")) std::fprintf(stderr, "[run] solve + finalize %.2f ms\n", r->s.total_time * 1e3);
     r->s.live = nullptr;
 }
 

@@ -294,8 +294,10 @@ class base:
         tr, off = [], 0
         qs = np.asarray(self.group_sizes)[new.screen_set]
         if len(flat) == int(np.sum(np.square(qs))):
-            if len(qs) and np.all(qs == 1):
-                tr = list(flat.reshape(-1, 1, 1))  # lasso: one (1,1) block per screened coordinate, no Python loop
+            if len(qs) and np.all(qs == qs[0]):
+                # groups of one size (lasso: (1,1) blocks): all blocks at once, each a column-major (q,q) view, no Python loop
+                q = int(qs[0])
+                tr = list(flat.reshape(len(qs), q, q).transpose(0, 2, 1))
             else:
                 for q in qs.tolist():
                     tr.append(flat[off:off + q * q].reshape(q, q, order="F"))

@@ -390,7 +390,9 @@ def test_exit_cond_on_panel_engine(hip, monkeypatch):
 @pytest.mark.parametrize("hook,values", [("ADELIE_HIP_BATCH_BLOCKS", ["1", "3", "16"]), ("ADELIE_HIP_PREBUILD", ["0", "1"]),
                                          ("ADELIE_HIP_GROUP_ROT", ["0", "1"]), ("ADELIE_HIP_FUSE_REDUCE", ["0", "1"]),
                                          ("ADELIE_HIP_SIDE_WGS", ["0", "24"]), ("ADELIE_HIP_CROSS_BATCH", ["1", "3", "16"]),
-                                         ("ADELIE_HIP_SPECULATE", ["0", "1"])])
+                                         ("ADELIE_HIP_SPECULATE", ["0", "1"]), ("ADELIE_HIP_OPEN_FROM_GRAD", ["0", "1"]),
+                                         ("ADELIE_HIP_PASS_TABLES", ["0", "1"]), ("ADELIE_HIP_SIDE_GRAMS", ["0", "1"]),
+                                         ("ADELIE_HIP_DEVICE_SCREEN", ["0", "1"])])
 def test_round2_engine_hooks_do_not_change_results(hip, oracle, monkeypatch, hook, values):
     """The build / solve variants added in round 2 (batched diagonal-block builds, IRLS screen-block prebuild, group solve in
     eigen-coordinates, reduce fused into the solve, confined side builds) are scheduling / association changes only: every
@@ -419,6 +421,29 @@ def test_round2_engine_hooks_do_not_change_results(hip, oracle, monkeypatch, hoo
             # pass apart, which is worth ~1e-7 in beta at this tol; a wrong block shows up at 1e-3 and above
             assert np.abs(st.betas.toarray() - ref.betas.toarray()).max() < 1e-6, (hook, v)
             assert np.abs(st.intercepts - ref.intercepts).max() < 1e-6
+
+
+def test_pass_tables_kept_across_passes_are_bit_identical(hip, monkeypatch):
+    """ADELIE_HIP_PASS_TABLES: the partition of a visiting list, the design columns of the active list and the group layout
+    descriptors are kept across passes while the list did not grow — pure caching, so the paths are bit-identical (lasso and
+    grouped, with KKT failures forcing re-screens of the same lambda)."""
+    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    d = make_gaussian(900, 700, seed=31, sparsity=0.6)
+    X = ad.matrix.dense(d["X"])
+    for kw in [dict(early_exit=False, lmda_path_size=25, min_ratio=0.02, tol=1e-10),
+               dict(groups=np.arange(0, 700, 7), alpha=0.5, early_exit=False, lmda_path_size=25, min_ratio=0.02, tol=1e-10),
+               dict(groups=np.arange(0, 700, 7), alpha=0.8, early_exit=False, lmda_path_size=25, min_ratio=0.02, tol=1e-10,
+                    screen_rule="strong")]:
+        runs = []
+        for v in ("0", "1"):
+            monkeypatch.setenv("ADELIE_HIP_PASS_TABLES", v)
+            runs.append(ad.grpnet(X, ad.glm.gaussian(d["y"]), progress_bar=False, **kw))
+        a, b = runs
+        assert a.error == "" and b.error == "" and b.counters["n_panel_blocks"] > 0
+        assert np.array_equal(a.betas.toarray(), b.betas.toarray()) and np.array_equal(a.intercepts, b.intercepts)
+        assert np.array_equal(a.resid, b.resid) and np.array_equal(a.grad, b.grad) and list(a.screen_set) == list(b.screen_set)
+        for k in ("n_cd_passes_active", "n_cd_passes_screen", "n_updates", "n_panel_blocks"):
+            assert a.counters[k] == b.counters[k], k
 
 
 @pytest.mark.gpu

@@ -3262,6 +3262,8 @@ struct Solver {
             // restore the pre-fit invariants (solver_gaussian_naive.hpp:286-290,326-329)
             AHIP_CHECK(hipMemcpyAsync(d_beta.p, d_beta0.p, size_t(nv) * sizeof(T), hipMemcpyDeviceToDevice, st));
             d_isact.upload(screen_is_active.data(), screen_is_active.size(), st);
+            actcols_key = -1; // (the failed fit may have appended to the device's active list: nothing cached about it survives)
+            ptab_act.count = -1;
             sync();
             if (sc.status == CD_MAX_CDS) throw max_cds_error(0);
             if (sc.status == CD_MAX_ACTIVE) throw make_solver_error("Maximum number of active groups reached.");

@@ -400,12 +400,17 @@ inline void strip_shape(int64_t n, int count, int wgs, int& nsplit, int64_t& kch
     nsplit = int(ns < 1 ? 1 : ns);
 }
 
-thread_local int t_strip_wgs = 512;
+// K-splits of a strip launch (per entry).  Each split writes a partial strip of 16 MT x 256 values that the reduce kernel reads
+// back (512 splits: 53 MB written per launch of the headline's screen strips, PMC), and in the path the strips only get the
+// ~60 CUs the fused launches leave, so more splits than that buy nothing: 192 instead of 512 is worth 1.5 ms per headline path
+// and 4.7 ms on config 3 (the chain starts to wait for the strips below ~112).  Hook ADELIE_HIP_STRIP_WGS.
+constexpr int kStripWgsDefault = 192;
+thread_local int t_strip_wgs = kStripWgsDefault;
 thread_local bool t_strip_lds = true;
 
 } // namespace
 
-void set_strip_workgroups(int wgs) { t_strip_wgs = wgs < 1 ? 512 : wgs; }
+void set_strip_workgroups(int wgs) { t_strip_wgs = wgs < 1 ? kStripWgsDefault : wgs; }
 void set_strip_lds(bool on) { t_strip_lds = on; }
 
 int strip_row_tiles(int m) { return m <= 16 ? 1 : (m <= 32 ? 2 : (m <= 64 ? 4 : 0)); }

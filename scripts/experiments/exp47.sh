@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+B="python bench.py --no-cpu-baseline --no-cv-leg --no-extra-legs"
+for v in 512 256 128 96 64 512 192; do
+ADELIE_HIP_STRIP_WGS=$v $B --steps 4 --warmup 2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg2 strip_wgs=$v', round(d['value'],4), round(d['ms_per_step'],1), {k: round(v,1) for k,v in d['breakdown_ms_last_path'].items()}, round(d['roofline_panel_step']['avg_launch_ms']*1e3,2))"
+done
+for v in 512 128; do
+ADELIE_HIP_STRIP_WGS=$v $B --config 3 --steps 3 --warmup 1 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg3 strip_wgs=$v', round(d['value'],4), round(d['ms_per_step'],1), {k: round(v,1) for k,v in d['breakdown_ms_last_path'].items()})"
+done

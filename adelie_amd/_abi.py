@@ -274,6 +274,11 @@ _HIP = None
 
 
 def hip_library_path():
+    """In-tree ``libadelie_hip.so``; ``ADELIE_HIP_LIB`` names another build of the same sources (A/B runs of compile-time
+    variants, ``scripts/ab.sh``) — still a HIP build of this library, never a fallback."""
+    alt = os.environ.get("ADELIE_HIP_LIB")
+    if alt:
+        return alt if os.path.isabs(alt) else os.path.join(os.path.dirname(os.path.abspath(__file__)), alt)
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadelie_hip.so")
 
 

@@ -2,8 +2,10 @@
 # Builds adelie_amd/libadelie_hip.so for gfx950 (cross-compiles without a GPU).
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-OUT="$HERE/../libadelie_hip.so"
-OBJ="$HERE/build"
+# AHIP_VARIANT=name builds libadelie_hip_name.so from objects under build_name/ (compile-time A/B variants, with AHIP_EXTRA_FLAGS)
+V="${AHIP_VARIANT:-}"
+OUT="$HERE/../libadelie_hip${V:+_$V}.so"
+OBJ="$HERE/build${V:+_$V}"
 mkdir -p "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${AHIP_EXTRA_FLAGS:-}"

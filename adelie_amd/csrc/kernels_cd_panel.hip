@@ -42,7 +42,15 @@ struct RawSnp { unsigned byte; };
 // `full` == false (only in the ragged last slice): lanes whose rows lie beyond n read from row 0 instead (a valid
 // address) and every out-of-range element is zeroed by a select — no branches, so the loads of a batch stay in flight
 // together (a branchy tail path made the one ragged workgroup the slowest of the launch by ~10 us).
-template <class T, int VEC>
+// Load policy of the two phases (dense designs).  Phase (B) is the FIRST read of a block's columns, phase (A) of the step two
+// launches later the SECOND and last one: 1 = non-temporal (streaming) load, 0 = plain (allocating) load.
+#ifndef AHIP_PANEL_NT_A
+#define AHIP_PANEL_NT_A 1
+#endif
+#ifndef AHIP_PANEL_NT_B
+#define AHIP_PANEL_NT_B 1
+#endif
+template <class T, int VEC, bool NTL = true>
 __device__ __forceinline__ RawDense<T, VEC> praw(const DenseAcc<T>& X, int64_t j, int64_t i, int64_t n, bool full) {
     RawDense<T, VEC> r;
     const T* col = X.colptr(j);
@@ -54,17 +62,15 @@ __device__ __forceinline__ RawDense<T, VEC> praw(const DenseAcc<T>& X, int64_t j
         static_assert(VEC == VecOf<T>::N, "dense vector width");
         // vector path requires ld % VEC == 0, so a lane starting below n may read up to VEC-1 pad elements: in bounds
         const int64_t ii = (full || i < n) ? i : 0;
-#ifdef AHIP_PANEL_TEMPORAL
-        const V x = *reinterpret_cast<const V*>(col + ii);
-#else
-        const V x = __builtin_nontemporal_load(reinterpret_cast<const V*>(col + ii));
-#endif
+        V x;
+        if constexpr (NTL) x = __builtin_nontemporal_load(reinterpret_cast<const V*>(col + ii));
+        else x = *reinterpret_cast<const V*>(col + ii);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) r.v.v[e] = (full || i + e < n) ? x[e] : T(0);
     }
     return r;
 }
-template <class T, int VEC>
+template <class T, int VEC, bool NTL = true>
 __device__ __forceinline__ RawSnp praw(const SnpAcc<T>& X, int64_t j, int64_t i, int64_t n, bool full) {
     static_assert(VEC == 4 || VEC == 16, "one byte (4 calls) or one 32-bit word (16 calls) per lane");
     RawSnp r;
@@ -124,7 +130,7 @@ __device__ __forceinline__ void panel_step_body(const Acc& X, int64_t n, const T
 #pragma unroll
         for (int u = 0; u < UB; ++u) jb[u] = cols[min(wv + 4 * u, nb - 1)];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) xb[u] = praw<T, VEC>(X, jb[u], i, n, full);
+        for (int u = 0; u < UB; ++u) xb[u] = praw<T, VEC, AHIP_PANEL_NT_B != 0>(X, jb[u], i, n, full);
     }
 
     // ---- (A) residual slice -= X[slice, changed columns] * del ---------------------------------------------------------
@@ -143,7 +149,7 @@ __device__ __forceinline__ void panel_step_body(const Acc& X, int64_t n, const T
                 cf[u] = m < nz ? dlt[min(m, nz - 1)] : T(0);
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) xa[u] = praw<T, VEC>(X, ja[u], i, n, full);
+            for (int u = 0; u < U; ++u) xa[u] = praw<T, VEC, AHIP_PANEL_NT_A != 0>(X, ja[u], i, n, full);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const Pack<T, VEC> xx = pdecode<T, VEC>(X, xa[u], ja[u], i, n);
@@ -183,7 +189,7 @@ __device__ __forceinline__ void panel_step_body(const Acc& X, int64_t n, const T
 #pragma unroll
             for (int u = 0; u < UB; ++u) jb[u] = cols[min(c0 + 4 * u, nb - 1)];
 #pragma unroll
-            for (int u = 0; u < UB; ++u) xb[u] = praw<T, VEC>(X, jb[u], i, n, full);
+            for (int u = 0; u < UB; ++u) xb[u] = praw<T, VEC, AHIP_PANEL_NT_B != 0>(X, jb[u], i, n, full);
         }
         T pu[UB];
 #pragma unroll

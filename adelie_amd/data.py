@@ -22,35 +22,56 @@ def _sample_y(glm, eta, beta, rho, snr):
     raise NotImplementedError(glm)
 
 
+def _group_layout(p, G, equal_groups):
+    """Group start columns and widths.  Unequal groups: G - 1 distinct cut points drawn from 1..p-1 (one ``choice`` draw)."""
+    if equal_groups:
+        starts = np.arange(G) * (p // G)
+    else:
+        cuts = np.random.choice(np.arange(1, p), size=G - 1, replace=False)
+        starts = np.sort(np.concatenate([[0], cuts])).astype(int)
+    widths = np.diff(np.append(starts, p)).astype(int)
+    return starts, widths
+
+
+def _penalty_factors(widths, p, zero_penalty):
+    """sqrt(width) per group, a random ``zero_penalty`` share of them zeroed, rescaled to squared norm p."""
+    G = widths.shape[0]
+    w = np.sqrt(widths)
+    unpenalised = np.random.choice(G, int(zero_penalty * G), replace=False)
+    w[unpenalised] = 0
+    return w / (np.linalg.norm(w) / np.sqrt(p))
+
+
+def _equicorrelated_normal(n, p, rho):
+    """n x p standard normal columns sharing one factor so that every pair has correlation rho (column-major)."""
+    noise = np.random.normal(0, 1, (n, p))
+    factor = np.random.normal(0, 1, n)
+    return np.asfortranarray(np.sqrt(rho) * factor[:, None] + np.sqrt(1 - rho) * noise)
+
+
 def dense(n: int, p: int, G: int, *, K: int = 1, glm: str = "gaussian", equal_groups: bool = False, rho: float = 0,
           sparsity: float = 0.95, zero_penalty: float = 0, snr: float = 1, seed: int = 0):
-    """Dense Gaussian design with ``G`` groups (reference ``adelie.data.dense``, ``data.py:84-219``)."""
-    assert n >= 1 and p >= 1 and G >= 1 and snr > 0 and seed >= 0 and K == 1
+    """Dense Gaussian design with ``G`` groups: the recipe of reference ``adelie.data.dense`` (``data.py:84-219``).
+
+    The legacy global stream is consumed in the reference's order — group cuts, unpenalised groups, the design, its shared
+    factor, the coefficients, the zeroed coefficients, the response noise — so that a seed gives the reference's data
+    (the notebook replays of ``tests/test_reference_known_answers.py`` depend on it)."""
+    if not (n >= 1 and p >= 1 and G >= 1 and snr > 0 and seed >= 0):
+        raise ValueError("n, p, G >= 1, snr > 0 and seed >= 0 are required")
+    if K != 1:
+        raise NotImplementedError("single-response families only")
     np.random.seed(seed)
-    if equal_groups:
-        groups = (p // G) * np.arange(G)
-    else:
-        groups = np.concatenate([[0], np.random.choice(np.arange(1, p), size=G - 1, replace=False)])
-        groups = np.sort(groups).astype(int)
-    group_sizes = np.concatenate([groups, [p]], dtype=int)
-    group_sizes = group_sizes[1:] - group_sizes[:-1]
-    penalty = np.sqrt(group_sizes)
-    penalty[np.random.choice(G, int(zero_penalty * G), replace=False)] = 0
-    penalty /= np.linalg.norm(penalty) / np.sqrt(p)
+    groups, group_sizes = _group_layout(p, G, equal_groups)
+    penalty = _penalty_factors(group_sizes, p, zero_penalty)
+    X = _equicorrelated_normal(n, p, rho)
 
-    X = np.random.normal(0, 1, (n, p))
-    Z = np.random.normal(0, 1, n)
-    X = np.sqrt(rho) * Z[:, None] + np.sqrt(1 - rho) * X
-    X = np.asfortranarray(X)
-
-    beta = np.random.normal(0, 1, (p, K))
-    beta_zero_indices = np.random.choice(p, int(sparsity * p), replace=False)
-    beta_nnz_indices = np.array(sorted(set(np.arange(p)) - set(beta_zero_indices)), dtype=int)
-    X_sub = X[:, beta_nnz_indices]
-    beta_sub = beta[beta_nnz_indices]
-    eta = X_sub @ beta_sub
-    glm_o = _sample_y(glm, eta, beta_sub, rho, snr)
-    return {"X": X, "glm": glm_o, "groups": groups, "group_sizes": group_sizes, "penalty": penalty}
+    coef = np.random.normal(0, 1, (p, K))
+    in_model = np.ones(p, dtype=bool)
+    in_model[np.random.choice(p, int(sparsity * p), replace=False)] = False
+    support = np.flatnonzero(in_model)
+    signal = coef[support]
+    response = _sample_y(glm, X[:, support] @ signal, signal, rho, snr)
+    return {"X": X, "glm": response, "groups": groups, "group_sizes": group_sizes, "penalty": penalty}
 
 
 def snp_unphased(n: int, p: int, G: int = None, *, glm: str = "gaussian", sparsity: float = 0.95,

@@ -177,6 +177,7 @@ class base:
         (``solver_base.hpp:225-239``) on stderr.
         """
         backend = self._X._backend
+        self._glm_cb_pending = {}  # one per solve, shared by every callback factory of _marshal (_callback_errors)
         args, keep = self._marshal()
         pending = {}
         total = int(self.lmda_path_size) if self.setup_lmda_path else len(self.lmda_path)
@@ -418,12 +419,30 @@ class base:
                 keep.append(cbs)
                 a.constraint_cb = _abi.C.pointer(cbs)
 
+    def _callback_errors(self):
+        """The one dict per marshalled solve in which every host callback (GLM methods, constraint methods) parks the first
+        exception it raised; ``solve()`` re-raises it.  ``_common_args`` runs before ``_glm_callbacks``: both must see the
+        SAME dict, so neither creates its own."""
+        d = getattr(self, "_glm_cb_pending", None)
+        if d is None:
+            d = self._glm_cb_pending = {}
+        return d
+
     def _constraint_callbacks(self, cons):
         """``adelie_hip_constraint_callbacks`` over the constraint objects that are not device closed forms — the role of the
         reference's trampoline ``PyConstraintBase``: the solver hands host vectors in double precision, the methods work in
         place.  An exception raised by a method aborts the solve and is re-raised by ``solve()``."""
-        pending = self._glm_cb_pending = getattr(self, "_glm_cb_pending", {})
+        pending = self._callback_errors()
         as_arr = np.ctypeslib.as_array
+        # the reference's trampoline (py_constraint.cpp:19-36,77-90) hands every solve / solve_zero a uint64 scratch vector
+        # of the object's own buffer_size() as the last positional argument: a class written against that API has a
+        # mandatory `buffer` parameter
+        scratch = {}
+
+        def buf(g):
+            if g not in scratch:
+                scratch[g] = np.zeros(int(cons[g].buffer_size()), dtype=np.uint64)
+            return scratch[g]
 
         def guarded(f):
             def call(*args):
@@ -440,7 +459,7 @@ class base:
             xv = as_arr(x, (d,))
             work = xv.copy()
             cons[g].solve(work, as_arr(quad, (d,)).copy(), as_arr(linear, (d,)).copy(), float(l1), float(l2),
-                          as_arr(Q, (d * d,)).reshape(d, d, order="F").copy())
+                          as_arr(Q, (d * d,)).reshape(d, d, order="F").copy(), buf(g))
             xv[...] = work
 
         @guarded
@@ -451,7 +470,7 @@ class base:
 
         @guarded
         def solve_zero(user, g, d, v, norm):
-            norm[0] = float(cons[g].solve_zero(as_arr(v, (d,)).copy()))
+            norm[0] = float(cons[g].solve_zero(as_arr(v, (d,)).copy(), buf(g)))
 
         @guarded
         def dual(user, g, m, mu_out):
@@ -595,7 +614,7 @@ class glm_naive_base(base):
         ``PyGlmBase`` (``py_glm.cpp:8-92``): the solver hands host n-vectors, the methods write their outputs in place.  An
         exception raised by a method aborts the solve and is re-raised by ``solve()``."""
         ctype = _abi.C.c_double if np.dtype(self.dtype) == np.float64 else _abi.C.c_float
-        pending = self._glm_cb_pending = {}
+        pending = self._callback_errors()
 
         def vec(address):
             return np.ctypeslib.as_array((ctype * n).from_address(address))

@@ -606,6 +606,47 @@ def test_user_defined_constraint_class_through_the_callbacks(oracle):
         ad.grpnet(oracle.dense(X), ad.glm.gaussian(y), constraints=[Broken(4, 0.1)] + [None] * 5, **kw)
 
 
+class _StrictDisc(_Disc):
+    """Written against the reference's trampoline (``py_constraint.cpp:19-36,77-90``): ``buffer`` is a MANDATORY positional
+    uint64 vector of ``buffer_size()`` entries, for solve and for solve_zero."""
+
+    def buffer_size(self):
+        return 5 * self.primal_size + 3
+
+    def solve(self, x, quad, linear, l1, l2, Q, buffer):
+        assert buffer.dtype == np.uint64 and buffer.shape == (self.buffer_size(),)
+        super().solve(x, quad, linear, l1, l2, Q)
+
+    def solve_zero(self, v, buffer):
+        assert buffer.dtype == np.uint64 and buffer.shape == (self.buffer_size(),)
+        return super().solve_zero(v)
+
+
+def test_user_constraint_with_mandatory_buffer_and_errors_next_to_a_glm_callback(oracle):
+    """(1) solve / solve_zero receive the reference's positional ``buffer``; (2) an exception raised by a
+    constraint method is re-raised by grpnet also when the family is a Python GLM (both callback sets share one error
+    slot per solve)."""
+    from test_plugins import Gaussian
+
+    d = make_gaussian(150, 24, seed=8)
+    X, y = d["X"], d["y"]
+    groups = np.arange(0, 24, 4)
+    kw = dict(groups=groups, alpha=0.9, tol=1e-12, lmda_path_size=8, min_ratio=0.05, early_exit=False, progress_bar=False)
+    strict = [_StrictDisc(4, 0.15) if g % 2 == 0 else None for g in range(6)]
+    loose = [_Disc(4, 0.15) if g % 2 == 0 else None for g in range(6)]
+    a = ad.grpnet(oracle.dense(X), ad.glm.gaussian(y), constraints=strict, **kw)
+    b = ad.grpnet(oracle.dense(X), ad.glm.gaussian(y), constraints=loose, **kw)
+    assert a.error == "" and strict[0].calls > 0
+    assert np.array_equal(a.betas.toarray(), b.betas.toarray())
+
+    class Broken(_Disc):
+        def solve(self, *args, **kwargs):
+            raise ValueError("no solution today")
+
+    with pytest.raises(ValueError, match="no solution today"):
+        ad.grpnet(oracle.dense(X), Gaussian(y), constraints=[Broken(4, 0.1)] + [None] * 5, **kw)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("family", ["gaussian", "binomial"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

@@ -38,6 +38,13 @@ class ConstraintCallbacks(C.Structure):
                 ("solve_zero", CONS_SOLVE_ZERO_FN), ("dual", CONS_DUAL_FN)]
 
 
+class LinearConstraint(C.Structure):
+    """``adelie_hip_linear_constraint`` (ABI 5)."""
+
+    _fields_ = [("m", C.c_int64), ("d", C.c_int64), ("A", C.c_void_p), ("lower", C.c_void_p), ("upper", C.c_void_p),
+                ("vars", C.c_void_p), ("cfg", C.c_double * 7)]
+
+
 class GlmCallbacks(C.Structure):
     """``adelie_hip_glm_callbacks``."""
 
@@ -119,6 +126,7 @@ class GrpnetArgs(C.Structure):
         ("constraint_va", C.c_void_p),
         ("constraint_vb", C.c_void_p),
         ("constraint_cfg", C.c_void_p),
+        ("constraint_lin", C.c_void_p),
     ]
 
 
@@ -174,7 +182,7 @@ def dtype_code(dtype):
 
 
 # kept equal to ADELIE_HIP_ABI_VERSION in include/adelie_hip.h (tests/test_abi.py compares the two)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class Backend:

@@ -22,7 +22,7 @@ import numpy as np
 MAX_SOLVER_VALUE = 1e100  # Configs.max_solver_value (configs.hpp:13)
 
 KIND_BOX, KIND_ONE_SIDED, KIND_HOST = 1, 2, 3
-NATIVE_BOX, NATIVE_ONE_SIDED = 4, 5  # adelie_hip_grpnet_args::constraint_native (read by the CPU checker only)
+NATIVE_BOX, NATIVE_ONE_SIDED, NATIVE_LINEAR = 4, 5, 6  # adelie_hip_grpnet_args::constraint_native (read by the CPU checker only)
 
 _PROX_NEWTON_DEFAULTS = {"max_iters": 100, "tol": 1e-9, "pinball_max_iters": int(1e5), "pinball_tol": 1e-7, "slack": 1e-4}
 
@@ -481,10 +481,14 @@ class _Linear(_ProxNewton, ConstraintBase):
 
     kind = KIND_HOST
 
-    def __init__(self, A, lower, upper, dtype, configs=None):
+    def __init__(self, A, lower, upper, dtype, configs=None, vars=None):
         cfg = dict(configs or {})
-        for k in ("nnls_max_iters", "nnls_tol", "n_threads"):  # accepted for compatibility; the bounded least squares has its own
-            cfg.pop(k, None)
+        # the bounded least squares here is scipy's; the reference's own settings for it are kept for the description of the
+        # object that the CPU checker's restatement of the reference solver reads (_linear_descriptor)
+        self._nnls_cfg = (int(cfg.pop("nnls_max_iters", int(1e5))), float(cfg.pop("nnls_tol", 1e-7)))
+        cfg.pop("n_threads", None)
+        if self._nnls_cfg[1] < 0:
+            raise RuntimeError("adelie_core: nnls_tol must be >= 0.")
         self._configure(cfg)
         A = np.asarray(A.toarray() if hasattr(A, "toarray") else A, dtype=float)
         if A.ndim != 2:
@@ -502,12 +506,34 @@ class _Linear(_ProxNewton, ConstraintBase):
         self._A = A
         self._lower = np.maximum(lower.astype(float), -MAX_SOLVER_VALUE)
         self._upper = np.minimum(upper.astype(float), MAX_SOLVER_VALUE)
+        self._vars = np.sum(A ** 2, axis=1) if vars is None else np.asarray(vars, dtype=float).reshape(m)
 
     def duals(self):
         return self.dual_size
 
     def _abi(self):
         return KIND_HOST, 0.0, 0.0
+
+    def _native(self):
+        c = self._cfg
+        return NATIVE_LINEAR, None, None, (c["max_iters"], c["tol"], c["pinball_max_iters"], c["pinball_tol"], c["slack"])
+
+    def _linear_descriptor(self):
+        """``adelie_hip_linear_constraint`` of this object (ABI 5) and the arrays it points into."""
+        from . import _abi
+
+        c = self._cfg
+        A = np.ascontiguousarray(self._A, dtype=np.float64)
+        lo = np.ascontiguousarray(self._lower, dtype=np.float64)
+        up = np.ascontiguousarray(self._upper, dtype=np.float64)
+        va = np.ascontiguousarray(self._vars, dtype=np.float64)
+        d = _abi.LinearConstraint()
+        d.m, d.d = A.shape
+        d.A, d.lower, d.upper, d.vars = A.ctypes.data, lo.ctypes.data, up.ctypes.data, va.ctypes.data
+        for i, v in enumerate((c["max_iters"], c["tol"], self._nnls_cfg[0], self._nnls_cfg[1], c["pinball_max_iters"],
+                               c["pinball_tol"], c["slack"])):
+            d.cfg[i] = float(v)
+        return d, (A, lo, up, va)
 
     def _At(self, mu):
         return self._A.T @ mu
@@ -553,12 +579,13 @@ class _Linear(_ProxNewton, ConstraintBase):
 def linear(A, lower: np.ndarray, upper: np.ndarray, *, vars: np.ndarray = None, copy: bool = False,
            method: str = "proximal_newton", configs: dict = None, dtype: Union[np.float32, np.float64] = None):
     """Linear constraint ``lower <= A x <= upper`` (``lower <= 0 <= upper``) for a dense / scipy-sparse ``(m, d)`` matrix ``A``;
-    reference ``constraint.py:137-306``.  ``vars`` (``diag(A A')``) and ``copy`` are accepted and not needed here."""
+    reference ``constraint.py:137-306``.  ``vars`` (``diag(A A')``, computed when absent) scales the coordinate steps of the
+    reference's bounded least squares; ``copy`` is accepted and not needed here."""
     if method != "proximal_newton":
         raise KeyError(method)
     lower, ld = _coerce(lower, dtype)
     upper, _ = _coerce(upper, ld)
-    return _Linear(A, lower, upper, ld, configs)
+    return _Linear(A, lower, upper, ld, configs, vars)
 
 
 def render_dual_groups(constraints):

@@ -413,7 +413,7 @@ thread_local bool t_strip_lds = true;
 void set_strip_workgroups(int wgs) { t_strip_wgs = wgs < 1 ? kStripWgsDefault : wgs; }
 void set_strip_lds(bool on) { t_strip_lds = on; }
 
-int strip_row_tiles(int m) { return m <= 16 ? 1 : (m <= 32 ? 2 : (m <= 64 ? 4 : 0)); }
+int strip_row_tiles(int m) { return m <= 16 ? 1 : (m <= 32 ? 2 : (m <= 48 ? 3 : (m <= 64 ? 4 : 0))); }
 
 int64_t strip_work_elems(int64_t n, int count, int m_max) {
     int ns;
@@ -448,6 +448,7 @@ void launch_strip_batch(const DenseView<T>& Xv, const T* w, const int32_t* cols_
                        nsplit, work)
             if (MTv == 1) AHIP_STRIP_LT(1);
             else if (MTv == 2) AHIP_STRIP_LT(2);
+            else if (MTv == 3) AHIP_STRIP_LT(3);
             else AHIP_STRIP_LT(4);
 #undef AHIP_STRIP_LT
             done = true;
@@ -456,6 +457,7 @@ void launch_strip_batch(const DenseView<T>& Xv, const T* w, const int32_t* cols_
     if (!done) {
         if (MTv == 1) { if (vecok) AHIP_STRIP(true, 1); else AHIP_STRIP(false, 1); }
         else if (MTv == 2) { if (vecok) AHIP_STRIP(true, 2); else AHIP_STRIP(false, 2); }
+        else if (MTv == 3) { if (vecok) AHIP_STRIP(true, 3); else AHIP_STRIP(false, 3); }
         else { if (vecok) AHIP_STRIP(true, 4); else AHIP_STRIP(false, 4); }
     }
 #undef AHIP_STRIP

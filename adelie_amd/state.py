@@ -388,7 +388,8 @@ class base:
             native = np.zeros(G, dtype=np.int32)
             va, vb = np.zeros(p, dtype=dtype), np.zeros(p, dtype=dtype)
             cfg = np.zeros((G, 5), dtype=np.float64)
-            any_host = False
+            lin = (_abi.C.c_void_p * G)()
+            any_host = any_lin = False
             for i, c in enumerate(cons):
                 if c is None:
                     continue
@@ -400,8 +401,14 @@ class base:
                     if nat is not None:
                         g0, q = int(self.groups[i]), int(self.group_sizes[i])
                         native[i] = nat[0]
-                        va[g0:g0 + q], vb[g0:g0 + q] = nat[1], nat[2]
+                        if nat[1] is not None:
+                            va[g0:g0 + q], vb[g0:g0 + q] = nat[1], nat[2]
                         cfg[i] = nat[3]
+                        if nat[0] == _constraint.NATIVE_LINEAR:  # (m, d) objects do not fit per-coefficient arrays
+                            desc, arrays = c._linear_descriptor()
+                            keep += [desc, arrays]
+                            lin[i] = _abi.C.addressof(desc)
+                            any_lin = True
                 else:
                     mu[i] = c._mu[0]
             keep += [kind, ca, cb, mu, ndual, native, va, vb, cfg]
@@ -415,6 +422,9 @@ class base:
                 a.constraint_va = va.ctypes.data
                 a.constraint_vb = vb.ctypes.data
                 a.constraint_cfg = cfg.ctypes.data
+                if any_lin:
+                    keep.append(lin)
+                    a.constraint_lin = _abi.C.addressof(lin)
                 cbs = self._constraint_callbacks(cons)
                 keep.append(cbs)
                 a.constraint_cb = _abi.C.pointer(cbs)

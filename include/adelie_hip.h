@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADELIE_HIP_ABI_VERSION 4
+#define ADELIE_HIP_ABI_VERSION 5
 
 enum adelie_hip_dtype { ADELIE_HIP_F32 = 0, ADELIE_HIP_F64 = 1 };
 enum adelie_hip_order { ADELIE_HIP_COL_MAJOR = 0, ADELIE_HIP_ROW_MAJOR = 1 };
@@ -244,6 +244,19 @@ enum adelie_hip_constraint_kind {
     ADELIE_HIP_CONSTRAINT_HOST = 3          /* object on the caller's side, reached through adelie_hip_constraint_callbacks */
 };
 
+/* ABI 5.  Description of a `linear` constraint object (reference ConstraintLinear, adelie/constraint.py:137-306,
+ * constraint_linear.ipp:142-217):  lower <= A z <= upper  on the group's d coefficients, m rows, with the settings of the
+ * reference's proximal-Newton solver.  Like constraint_native / _va / _vb / _cfg it is read by the CPU checker (oracle/) only,
+ * which runs such a group with its own restatement of that solver; libadelie_hip.so visits the group through constraint_cb. */
+typedef struct adelie_hip_linear_constraint {
+    int64_t        m, d;
+    const double*  A;       /* (m, d) row-major */
+    const double*  lower;   /* (m,) <= 0 (-1e100 and below: no bound) */
+    const double*  upper;   /* (m,) >= 0 */
+    const double*  vars;    /* (m,) squared row norms of A */
+    double         cfg[7];  /* max_iters, tol, nnls_max_iters, nnls_tol, pinball_max_iters, pinball_tol, slack */
+} adelie_hip_linear_constraint;
+
 typedef struct adelie_hip_grpnet_args {
     /* ---- problem (static) ---- */
     int64_t        G;                 /* number of groups */
@@ -342,6 +355,8 @@ typedef struct adelie_hip_grpnet_args {
     const void*    constraint_va;     /* (p,) value_t or NULL */
     const void*    constraint_vb;     /* (p,) value_t or NULL */
     const double*  constraint_cfg;    /* (G, 5) row-major or NULL */
+    /* ABI 5: constraint_native[g] = 6 (linear): constraint_lin[g] describes the object (NULL entries elsewhere) */
+    const adelie_hip_linear_constraint* const* constraint_lin; /* (G,) or NULL */
 } adelie_hip_grpnet_args;
 
 /* Runs the whole path.  `*out` is always set on return code 0 (even when the solve recorded

@@ -33,7 +33,9 @@ def build(force: bool = False):
     """Compiles the oracle with the committed Makefile (gcc only, no GPU needed)."""
     src = os.path.join(_HERE, "grpnet_oracle.cpp")
     hdr = os.path.join(_HERE, "..", "include", "adelie_hip.h")
-    if (not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+    lin = os.path.join(_HERE, "linear_constraint.hpp")
+    if (not force and os.path.exists(_LIB)
+            and os.path.getmtime(_LIB) >= max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(lin))):
         return _LIB
     subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return _LIB

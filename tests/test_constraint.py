@@ -762,6 +762,127 @@ def test_linear_object_first_principles_and_box_equivalence():
         assert np.abs(xa - xb).max() < 1e-9 and np.abs(ca._mu - cb._mu).max() < 1e-8
 
 
+def _checker_linear(oracle, op, A, lower, upper, x, quad, lin, l1, l2, Q, mu, configs=None, vars=None):
+    """One call of the checker's own ConstraintLinear restatement (oracle/linear_constraint.hpp)."""
+    import ctypes as C
+
+    from adelie_amd import _abi
+
+    c = constraint.linear(A, lower, upper, configs=configs, vars=vars)
+    desc, keep = c._linear_descriptor()
+    be = oracle.backend()
+    f = be.lib.oracle_linear_constraint
+    vp = C.c_void_p
+    f.argtypes = [C.c_int, C.POINTER(_abi.LinearConstraint), vp, vp, vp, C.c_double, C.c_double, vp, vp, vp]
+    Qf = np.asfortranarray(Q, dtype=float)
+    grad = np.zeros(A.shape[1])
+    rc = f(op, C.byref(desc), x.ctypes.data, quad.ctypes.data, lin.ctypes.data, l1, l2, Qf.ctypes.data, mu.ctypes.data,
+           grad.ctypes.data)
+    assert rc == 0, be.fn("last_error")()
+    del keep
+    return grad
+
+
+@pytest.mark.parametrize("m", [1, 2, 5, 10, 20, 50])
+@pytest.mark.parametrize("lower", [-1, -1e-14, 0])
+@pytest.mark.parametrize("upper", [1, 1e-14, 0])
+def test_checker_linear_restatement_replays_the_reference_recipe(oracle, m, lower, upper):
+    """The reference's own test of ConstraintLinear (tests/test_constraint.py:6-64,105-135: its data recipe, its solver
+    settings, its three assertions and its tolerance 5e-7) replayed on the checker's C++ restatement of that class, m < d
+    (dense pinball step) and m >= d (screened pinball step) alike, 10 seeds per shape."""
+    d, atol = 10, 5e-7
+    cfg = {"max_iters": 1000, "tol": 1e-16, "nnls_tol": 1e-16, "pinball_max_iters": 1000000, "pinball_tol": 1e-9}
+    n_bound = 0
+    for seed in range(10):
+        np.random.seed(seed)
+        A = np.random.normal(0, 1, (m, d))
+        A[0, 0] = 0
+        lo = np.random.uniform(lower, 0, m)
+        up = np.random.uniform(0, upper, m)
+        np.random.seed(seed)
+        quad = np.random.uniform(0, 1, d)
+        lin = np.sqrt(quad) * np.random.normal(0, 1, d)
+        l1, l2 = 0.5 * np.linalg.norm(lin), 0.0
+        Q = np.linalg.svd(np.random.normal(0, 1, (d, d)))[0]
+        x, mu = np.zeros(d), np.zeros(m)
+        grad = _checker_linear(oracle, 0, A, lo, up, x, quad, lin, l1, l2, Q, mu, configs=cfg)
+        assert np.allclose(grad, A.T @ mu)                                        # gradient(x) == A' mu
+        lagr = (quad + l2) * x - lin + Q.T @ (A.T @ mu)                           # KKT first-order condition
+        assert max(np.linalg.norm(lagr) - l1, 0) <= atol
+        Ax = A @ (Q @ x)                                                          # primal feasibility
+        assert max(np.max(np.concatenate([Ax - up, lo - Ax])), 0) <= atol
+        n_bound += int(np.any(mu != 0))
+    assert n_bound > 0 or (lower == -1 and upper == 1 and m <= 2)
+
+
+def test_linear_objects_product_and_checker_agree(oracle):
+    """adelie_amd.constraint.linear (numpy: one dual driver, scipy's bounded least squares at x = 0, the dense pinball step) and
+    the checker's restatement of ConstraintLinear (sparse multipliers, coordinate-descent BVLS, both pinball branches) are two
+    implementations: same primal to solver precision on random group problems, warm starts included; A' mu agrees where the
+    primal is non-zero (the multipliers themselves are not unique when rows of A are dependent, m > d)."""
+    rng = np.random.RandomState(5)
+    cfg = {"max_iters": 1000, "tol": 1e-14, "nnls_tol": 1e-14, "pinball_max_iters": 1000000, "pinball_tol": 1e-13}
+    worst_x, worst_g, n_nz, n_act = 0.0, 0.0, 0, 0
+    for trial in range(120):
+        d = rng.randint(2, 8)
+        m = rng.randint(1, 12)
+        A = rng.randn(m, d)
+        lo = -rng.uniform(0, 1, m) * (rng.rand(m) < 0.8)
+        up = rng.uniform(0, 1, m) * (rng.rand(m) < 0.8)
+        Q = np.linalg.qr(rng.randn(d, d))[0]
+        quad = rng.uniform(0.1, 2, d)
+        lin = rng.randn(d) * rng.choice([0.3, 1, 3])
+        l1, l2 = rng.uniform(0, 1), rng.uniform(0, 0.5)
+        x0 = rng.randn(d) * (rng.rand() < 0.4)
+        obj = constraint.linear(A, lo, up, configs=cfg)
+        xp = x0.copy()
+        obj.solve(xp, quad, lin, l1, l2, Q)
+        xo, muo = x0.copy(), np.zeros(m)
+        go = _checker_linear(oracle, 0, A, lo, up, xo, quad, lin, l1, l2, Q, muo, configs=cfg)
+        worst_x = max(worst_x, np.abs(xp - xo).max())
+        if np.any(xp != 0):
+            n_nz += 1
+            gp = np.empty(d)
+            obj.gradient(xp, gp)
+            worst_g = max(worst_g, np.abs(gp - go).max())
+        n_act += int(np.any(muo != 0))
+        # the checker's answer against first principles as well
+        lagr = (quad + l2) * xo - lin + Q.T @ go
+        nx = np.linalg.norm(xo)
+        assert (np.linalg.norm(lagr + l1 * xo / nx) < 1e-6) if nx > 0 else (np.linalg.norm(lagr) <= l1 + 1e-6)
+        Az = A @ (Q @ xo)
+        assert np.max(np.concatenate([Az - up, lo - Az])) < 1e-5
+        assert np.all(np.maximum(muo, 0) * (up - Az) < 1e-5) and np.all(np.maximum(-muo, 0) * (Az - lo) < 1e-5)
+    # (both stop on the reference's convergence measure of the dual iteration; its own test accepts 5e-7 on the KKT residual)
+    assert worst_x < 2e-6 and worst_g < 2e-6, (worst_x, worst_g)
+    assert n_nz > 40 and n_act > 30
+
+
+def test_checker_linear_solve_zero(oracle):
+    """solve_zero (constraint_linear.ipp:520-603): the sign-bounded least-squares fit of A' mu to v, against scipy."""
+    from scipy.optimize import lsq_linear
+
+    rng = np.random.RandomState(8)
+    for trial in range(40):
+        d, m = rng.randint(2, 8), rng.randint(1, 10)
+        A = rng.randn(m, d)
+        lo = -rng.uniform(0, 1, m) * (rng.rand(m) < 0.5)
+        up = rng.uniform(0, 1, m) * (rng.rand(m) < 0.5)
+        v = rng.randn(d)
+        out, mu = np.zeros(d), np.zeros(m)
+        _checker_linear(oracle, 1, A, lo, up, out, np.ones(d), v, 0.0, 0.0, np.eye(d), mu,
+                        configs={"nnls_tol": 1e-15, "nnls_max_iters": 1000000})
+        lb = np.where(lo >= 0, -np.inf, 0.0)   # a negative multiplier needs the lower bound at exactly 0
+        ub = np.where(up <= 0, np.inf, 0.0)
+        free = (lb < 0) | (ub > 0)
+        best = np.linalg.norm(v)
+        if np.any(free):
+            best = np.linalg.norm(A[free].T @ lsq_linear(A[free].T, v, bounds=(lb[free], ub[free]), tol=1e-14).x - v)
+        assert np.all(mu >= lb - 1e-12) and np.all(mu <= ub + 1e-12)
+        assert abs(out[0] - np.linalg.norm(v - A.T @ mu)) < 1e-7   # (sqrt(2 loss) with the loss tracked incrementally, like the reference)
+        assert out[0] <= best + 1e-6 and out[0] >= best - 1e-6
+
+
 def _linear_problem(rng, p, gsz):
     groups = np.arange(0, p, gsz)
     spec = []

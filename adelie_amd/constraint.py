@@ -137,9 +137,20 @@ class _ProxNewton:
     def _At(self, mu):            # A' mu, a vector of the group's size
         raise NotImplementedError
 
-    def _nearest_at_zero(self, Qv, mu):
-        """Feasible multipliers (under complementary slackness at x = 0) whose ``A' mu`` is nearest to ``Qv``."""
+    def _nearest_at_zero(self, Qv, mu, l1=None):
+        """Feasible multipliers (under complementary slackness at x = 0) whose ``A' mu`` is nearest to ``Qv``; ``l1``: any point
+        with ``|Qv - A' mu| <= l1`` will do (the reference's iterative solver for ``linear`` stops there)."""
         raise NotImplementedError
+
+    # bookkeeping hooks of classes that keep more than the dense vector of multipliers (``linear``: their insertion order)
+    def _zero_fit_taken(self, taken):
+        pass
+
+    def _saved_prev(self):
+        pass
+
+    def _backtracked(self, mu, mu_prev):
+        pass
 
     def _is_optimal(self, z, mu):  # z = Q x
         return False
@@ -168,10 +179,12 @@ class _ProxNewton:
 
         def nearest_at_zero(mu_now, may_restore):
             """Multipliers that best explain v while the primal stays 0; keeps the old ones when even those do not."""
-            cand = self._nearest_at_zero(Qv, mu_now)
+            cand = self._nearest_at_zero(Qv, mu_now, l1)
             gap = float(np.sum(np.square(Qv - self._At(cand))))
             if may_restore and gap > l1 * l1:
+                self._zero_fit_taken(False)
                 return mu_now, gap
+            self._zero_fit_taken(True)
             return cand, gap
 
         x_zero_start = not np.any(x0)
@@ -206,6 +219,7 @@ class _ProxNewton:
                     if not had_prev:
                         rn_prev, have_prev = rn, True
                         mu_prev, Atmu_prev, z_prev = mu.copy(), Atmu.copy(), np.zeros(len(v))
+                        self._saved_prev()
                     mu, gap = nearest_at_zero(mu, had_prev)
                     if gap <= l1 * l1:
                         return finish(0.0, mu)
@@ -222,6 +236,7 @@ class _ProxNewton:
                 c = rn * rn - target * target
                 t_star = (-b + np.sqrt(max(b * b - a * c, 0.0))) / a
                 mu = mu_prev + min(max(1 - t_star, 0.0), 1.0) * (mu - mu_prev)
+                self._backtracked(mu, mu_prev)
                 continue
             z = Q @ xv
             if self._is_optimal(z, mu):
@@ -230,6 +245,7 @@ class _ProxNewton:
                 return finish(xv, mu)
             rn_prev, have_prev = rn, True
             mu_prev, Atmu_prev, z_prev = mu.copy(), Atmu.copy(), z.copy()
+            self._saved_prev()
             # dual Hessian and the variance scale of the sub-solver's stopping rule (Woodbury)
             a_t = xv * b2 / xn
             kappa = 1.0 / float(np.sum(xv * b1 * a_t))
@@ -295,7 +311,7 @@ class _Box(_ProxNewton, ConstraintBase):
     def _At(self, mu):
         return mu
 
-    def _nearest_at_zero(self, Qv, mu):
+    def _nearest_at_zero(self, Qv, mu, l1=None):
         lo = np.where(self._lower >= 0, -MAX_SOLVER_VALUE, 0.0)
         hi = np.where(self._upper <= 0, MAX_SOLVER_VALUE, 0.0)
         return np.minimum(np.maximum(Qv, lo), hi)
@@ -374,7 +390,7 @@ class _OneSided(_ProxNewton, ConstraintBase):
     def _At(self, mu):
         return self._D * mu
 
-    def _nearest_at_zero(self, Qv, mu):
+    def _nearest_at_zero(self, Qv, mu, l1=None):
         hi = np.where(self._b <= 0, MAX_SOLVER_VALUE, 0.0)
         return np.minimum(np.maximum(self._D * Qv, 0.0), hi)
 
@@ -477,7 +493,7 @@ class _Linear(_ProxNewton, ConstraintBase):
     ``A' mu`` in place of ``mu`` (``:275-470``).  The Newton step minimises the pinball-penalised quadratic model with Hessian
     ``A hess A'`` (the reference's ``m < d`` branch, ``:408-418``; for ``m >= d`` it solves the same sub-problem through a
     low-rank active-set variant), the multipliers at ``x = 0`` come from a sign-bounded least-squares fit of ``A' mu`` to
-    ``Q v`` (``:283-349``, the reference's NNLS; here :func:`scipy.optimize.lsq_linear`).  Always a host object."""
+    ``Q v`` (``:283-349``) by the reference's warm-started coordinate descent (``_bvls``).  Always a host object."""
 
     kind = KIND_HOST
 
@@ -507,6 +523,7 @@ class _Linear(_ProxNewton, ConstraintBase):
         self._lower = np.maximum(lower.astype(float), -MAX_SOLVER_VALUE)
         self._upper = np.minimum(upper.astype(float), MAX_SOLVER_VALUE)
         self._vars = np.sum(A ** 2, axis=1) if vars is None else np.asarray(vars, dtype=float).reshape(m)
+        self._order = []   # the non-zero multipliers in the order they became non-zero (the reference keeps them sparse)
 
     def duals(self):
         return self.dual_size
@@ -543,21 +560,137 @@ class _Linear(_ProxNewton, ConstraintBase):
         hi = np.where(self._upper <= 0, MAX_SOLVER_VALUE, 0.0)
         return lo, hi
 
-    def _nearest_at_zero(self, Qv, mu):
-        from scipy.optimize import lsq_linear
-
+    # ---- bounded least squares  min |target - A' mu|^2, lo <= mu <= hi, by coordinate descent with a screen / active set ----
+    # The reference's solver for this sub-problem (solver_bvls.hpp through optimization/nnls.hpp) is iterative, warm-started
+    # from the multipliers the object holds IN THE ORDER THEY BECAME NON-ZERO, and inside solve() it stops at the first
+    # iterate whose residual is within l1 — so WHICH multipliers a group with x = 0 ends up with (state.duals) depends on
+    # exactly this iteration; a direct least-squares solve returns a different, equally valid set.  Same loops here.
+    def _bvls(self, target, mu, order, y_var, good_enough):
+        A, va = self._A, self._vars
+        m, d = A.shape
         lo, hi = self._sign_bounds()
-        free = (lo < 0) | (hi > 0)
-        out = np.zeros_like(mu, dtype=float)
-        if np.any(free):
-            res = lsq_linear(self._A[free].T, Qv, bounds=(np.where(lo[free] < 0, -np.inf, 0.0), np.where(hi[free] > 0, np.inf, 0.0)),
-                             tol=1e-14, max_iter=1000)
-            out[free] = res.x
+        tol, max_iters = self._nnls_cfg[1], self._nnls_cfg[0]
+        beta = np.array(mu, dtype=float)
+        resid = target - A.T @ beta
+        loss = 0.5 * float(resid @ resid)
+        screen, active = list(order), list(order)
+        is_screen, is_active = np.zeros(m, bool), np.zeros(m, bool)
+        is_screen[screen] = True
+        is_active[active] = True
+        kappa = min(m, d)
+        state = {"loss": loss, "iters": 0}
+
+        def sweep(idx, add_active):
+            worst = 0.0
+            for k in idx:
+                if good_enough(state["loss"]):
+                    return worst
+                vk = va[k]
+                gk = float(A[k] @ resid)
+                old = beta[k]
+                new = min(max(old + (0.0 if vk <= 0 else gk / vk), lo[k]), hi[k])
+                if new == old:
+                    continue
+                beta[k] = new
+                dl = new - old
+                sds = vk * dl * dl
+                worst = max(worst, sds)
+                state["loss"] -= dl * gk - 0.5 * sds
+                resid[...] -= dl * A[k]
+                if add_active and not is_active[k]:
+                    active.append(k)
+                    is_active[k] = True
+            return worst
+
+        def prune():
+            keep = [k for k in active if lo[k] < beta[k] < hi[k]]
+            for k in active:
+                is_active[k] = False
+            for k in keep:
+                is_active[k] = True
+            active[:] = keep
+
+        def fit():
+            while True:
+                state["iters"] += 1
+                worst = sweep(list(screen), True)
+                if state["iters"] >= max_iters:
+                    raise RuntimeError("adelie_core solver: bvls: max iterations reached!")
+                if worst <= tol * y_var or good_enough(state["loss"]):
+                    prune()
+                    return
+                while True:
+                    state["iters"] += 1
+                    worst = sweep(list(active), False)
+                    if state["iters"] >= max_iters:
+                        raise RuntimeError("adelie_core solver: bvls: max iterations reached!")
+                    if worst <= tol * y_var:
+                        break
+                prune()
+
+        n_kkt = 0
+        by_violation = np.arange(m)
+        while True:
+            before = state["loss"]
+            fit()
+            if good_enough(state["loss"]):
+                break
+            if n_kkt > 0 and abs(state["loss"] - before) < 1e-6 * abs(y_var):
+                break
+            n_kkt += 1
+            g = A @ resid
+            viol = np.maximum(g, 0) * (beta < hi) - np.minimum(g, 0) * (beta > lo)
+            by_violation = np.array(sorted(by_violation, key=lambda i: -viol[i]), dtype=int)
+            n_old, passed = len(screen), True
+            for k in by_violation:
+                if is_screen[k] or viol[k] <= 0:
+                    continue
+                passed = False
+                if len(screen) >= n_old + kappa:
+                    break
+                screen.append(int(k))
+                is_screen[k] = True
+            if passed:
+                break
+        kept = [k for k in active if abs(beta[k]) > 1e-16]
+        out = np.zeros(m)
+        out[kept] = beta[kept]
+        return out, kept, state["loss"]
+
+    def _active_order(self, mu):
+        """The multipliers' insertion order, brought up to date with ``mu`` (``mu_to_sparse``, constraint_linear.ipp:94-108)."""
+        order = [k for k in self._order if abs(mu[k]) > 1e-16]
+        seen = set(self._order)
+        order += [int(k) for k in np.flatnonzero(mu) if k not in seen and abs(mu[k]) > 1e-16]
+        return order
+
+    def _nearest_at_zero(self, Qv, mu, l1=None):
+        self._order = self._active_order(mu)
+        if l1 is not None and float(np.sum(np.square(Qv - self._A.T @ mu))) <= l1 * l1:   # constraint_linear.ipp:281-283
+            self._order_cand = list(self._order)
+            return np.array(mu, dtype=float)
+        stop = (lambda loss: False) if l1 is None else (lambda loss: 2 * loss <= l1 * l1)
+        out, self._order_cand, _ = self._bvls(Qv, mu, self._order, float(Qv @ Qv), stop)
         return out
+
+    def _zero_fit_taken(self, taken):
+        if taken:
+            self._order = list(self._order_cand)
+
+    def _saved_prev(self):
+        self._order_prev = list(self._order)
+
+    def _backtracked(self, mu, mu_prev):   # constraint_linear.ipp:364-382: the current multipliers first, then the previous ones
+        order = list(self._order)
+        order += [k for k in getattr(self, "_order_prev", []) if k not in set(order)]
+        self._order = order
 
     def _qp(self, hess, var, mu, z):
         A = self._A
-        return self._pinball(A @ hess @ A.T, var, mu, A @ z, -self._lower, self._upper)
+        self._order = self._active_order(mu)
+        out = self._pinball(A @ hess @ A.T, var, mu, A @ z, -self._lower, self._upper)
+        self._order = self._active_order(out)
+        return out
 
     def evaluate(self, x):
         Ax = self._A @ x
@@ -567,13 +700,23 @@ class _Linear(_ProxNewton, ConstraintBase):
         mu, out = (self._mu, args[0]) if len(args) == 1 else args
         out[...] = self._A.T @ mu
 
-    def solve_zero(self, v, buffer=None):
+    def solve_zero(self, v, buffer=None):   # constraint_linear.ipp:520-603: warm-started from the multipliers held, run to the end
         v = np.asarray(v, dtype=float)
-        self._mu[...] = self._nearest_at_zero(v, np.zeros(self.dual_size))
-        return float(np.linalg.norm(v - self._A.T @ self._mu))
+        mu = self._mu.astype(float)
+        out, self._order, loss = self._bvls(v, mu, self._active_order(mu), float(v @ v), lambda loss: False)
+        self._mu[...] = out
+        return float(np.sqrt(max(2 * loss, 0.0)))
 
     def solve(self, x, quad, linear, l1, l2, Q, buffer=None):
-        return self._solve_multi(x, quad, linear, l1, l2, Q)
+        if np.linalg.norm(linear) <= l1:
+            self._order = []
+        out = self._solve_multi(x, quad, linear, l1, l2, Q)
+        self._order = self._active_order(self._mu.astype(float))
+        return out
+
+    def clear(self):
+        super().clear()
+        self._order = []
 
 
 def linear(A, lower: np.ndarray, upper: np.ndarray, *, vars: np.ndarray = None, copy: bool = False,

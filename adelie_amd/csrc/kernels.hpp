@@ -488,26 +488,6 @@ void launch_cov_grad(const T* S, int64_t lda, int64_t p, const T* v, const int32
                      T* grad, hipStream_t s);
 template <class T> void launch_copy2d(const T* src, int64_t lds, T* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s);
 // vars[pos0 + a] = max(C[(pos0+a)*(ldc+1)], 0) for a < cnt   (gs == 1 groups)
-// Screening step on the device (kernels_screen.hip; solver_base.hpp:273-403, optimization/search_pivot.hpp:7-62).  Both
-// outcomes of the KKT check are prepared by the host ([0]: failed -> the same lambda again, [1]: passed -> the next one);
-// the select kernel takes the check itself and picks.  Result block `out` (host-mapped): [0] sequence number (written last),
-// [1] KKT passed, [2] number of new screen groups, [3] pivot index within the subset (-1: none), then from kScreenHeader on
-// the new groups in the order the host routine would append them.
-constexpr int kScreenHeader = 8;
-template <class T>
-struct ScreenArgs {
-    const T* abs_grad; const T* penalty; const int32_t* slot; // slot[g] >= 0: g is in the screen set
-    int32_t G, rule;                                          // rule: 0 strong, 1 pivot
-    T alpha, lmda;                                            // lmda: the lambda of the invariance step just taken
-    T lmda_next[2];
-    int32_t n_new_active[2], take[2];                         // take: ceil(pivot_slack_ratio * n_new_active), as the host loop counts
-    int32_t subset, seq;                                      // subset: size of the pivot subset (top of the order)
-    T* wt; uint64_t* key; int32_t* rank; int32_t* order; T* sorted; T* pre; // scratch: G, G, G, G, G, 4 * subset
-    int32_t* flags;                                           // one word, zero between requests (bit 0: a KKT violation)
-    int32_t* out;                                             // kScreenHeader + G (device pointer of host-mapped memory)
-    int32_t* dev_list;                                        // optional copy of the list in device memory (G)
-};
-template <class T> void launch_screen(const ScreenArgs<T>& a, bool need_order, hipStream_t s);
 // Appending new screen groups to the device mirrors (solver.hip::device_append_screen): ONE packed upload + one scatter
 // launch instead of seven to ten small copies per lambda.  Packed image (8-byte aligned throughout):
 //   T      pen[Ng], beta[Nv], (lo[Nv], hi[Nv], mu[Nv] when `cons`)

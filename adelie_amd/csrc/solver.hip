@@ -688,13 +688,6 @@ struct Solver {
                 StreamPool::give(st_x[k]);
             }
         HostPool::give(h_report, sizeof(PassReport), hipHostMallocMapped);
-        if (st_scr) {
-            (void)hipStreamSynchronize(st_scr);
-            StreamPool::give(st_scr);
-        }
-        if (scr_in_ev) (void)hipEventDestroy(scr_in_ev);
-        if (scr_ev) (void)hipEventDestroy(scr_ev);
-        HostPool::give(h_scr, h_scr_bytes, hipHostMallocMapped);
         deferred.drain(); // blocks outgrown during the solve: every stream that may have used them is idle now
 
         if (spec_ev) (void)hipEventDestroy(spec_ev);
@@ -1214,137 +1207,10 @@ struct Solver {
             launch_abs_grad<T>(d_grad.p, d_groups.p, d_gsizes.p, G, d_slot.p, d_beta.p, d_penalty.p, (1 - alpha) * lm,
                                d_absgrad.p, st);
         }
-        device_screen_enqueue(active_now);
         d_absgrad.download(abs_grad.data(), size_t(G), st);
     }
 
-    // ---- screening on the device (kernels_screen.hip) -------------------------------------------------------------------
-    // solve()'s loop arms a request before every fit (scr_ctx: what the NEXT call of screen() will be given, for either outcome
-    // of the KKT check); device_abs_grad, which runs behind every invariance sweep, enqueues the kernels on a side stream, so
-    // they run next to the speculative pass; screen_f takes the result when the call it gets is the one that was prepared and
-    // falls back to the host routine otherwise (first iteration, solutions above lambda_max, host constraint objects, G above
-    // the counting sort's range).  Decisions and their order are the host routine's bit for bit (tests/test_device_screen.py).
-    // OFF by default: measured 1-2 % slower on every configuration — the host's 0.1 ms per lambda is already
-    // hidden behind the speculative pass, while a third stream with its cross-stream events stretches sweeps and fused
-    // launches; ADELIE_HIP_DEVICE_SCREEN=1 turns it on.
-    bool dev_screen = false;
-    static constexpr idx kDevScreenMaxG = idx(1) << 18;
-    struct ScrCtx {
-        bool armed = false;
-        bool has_next = false;     // a lambda follows the current one on the path
-        T lmda_next_pass = 0;      // ... this one
-        int nna_fail = 0;          // n_new_active if the KKT check fails (it keeps its value)
-        int active_before = 0;     // active set size at the last accepted solution
-    } scr_ctx;
-    struct ScrReq {
-        bool pending = false;
-        int32_t seq = 0;
-        T lmda = 0, lnext[2] = {0, 0};
-        int nna[2] = {0, 0};
-        size_t old_size = 0;
-    } scr_req;
-    hipStream_t st_scr = nullptr;
-    hipEvent_t scr_in_ev = nullptr, scr_ev = nullptr;
-    int32_t* h_scr = nullptr;      // host-mapped result block: header + list
-    int32_t* h_scr_dev = nullptr;
-    size_t h_scr_bytes = 0;
-    DevBuf<T> d_scr_wt, d_scr_pre;
-    DevBuf<uint64_t> d_scr_key;
-    DevBuf<int32_t> d_scr_rank, d_scr_order, d_scr_flags;
-    DevBuf<T> d_scr_sorted;
-    int64_t n_dev_screens = 0, n_host_screens = 0;
-
-    bool dev_screen_applies() const { return dev_screen && n_host_cons == 0 && G <= kDevScreenMaxG && G > 0; }
-    int pivot_subset_size(size_t old_size) const { // solver_base.hpp:331-334
-        return std::min<int>(std::max<int>(int(old_size * (1 + pivot_subset_ratio)), int(pivot_subset_min)), int(G));
-    }
-    // how many groups the slack loop of the pivot rule takes: the smallest count c with c >= pivot_slack_ratio * n_new_active
-    int pivot_slack_take(int n_new_active) const {
-        const T lim = pivot_slack_ratio * n_new_active;
-        if (!(lim > T(0))) return 0;
-        if (lim >= T(G)) return int(G);
-        int c = int(std::ceil(lim));
-        while (c > 0 && T(c - 1) >= lim) --c;
-        while (T(c) < lim) ++c;
-        return std::min<int>(c, int(G));
-    }
-    void device_screen_enqueue(int active_now) {
-        scr_req.pending = false;
-        if (!scr_ctx.armed || !dev_screen_applies()) return;
-        if (screen_rule != ADELIE_HIP_SCREEN_STRONG && screen_rule != ADELIE_HIP_SCREEN_PIVOT) return;
-        if (!st_scr) {
-            st_scr = StreamPool::take();
-            AHIP_CHECK(hipEventCreateWithFlags(&scr_in_ev, hipEventDisableTiming));
-            AHIP_CHECK(hipEventCreateWithFlags(&scr_ev, hipEventDisableTiming));
-            h_scr_bytes = (size_t(kScreenHeader) + size_t(G)) * sizeof(int32_t);
-            void* hp = HostPool::take(h_scr_bytes, hipHostMallocMapped);
-            void* dp = nullptr;
-            if (!hp || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
-                (void)hipGetLastError();
-                HostPool::give(hp, h_scr_bytes, hipHostMallocMapped);
-                dev_screen = false;
-                return;
-            }
-            h_scr = static_cast<int32_t*>(hp);
-            h_scr_dev = static_cast<int32_t*>(dp);
-            h_scr[0] = 0;
-        }
-        const size_t old_size = screen_set.size();
-        ScreenArgs<T> a{};
-        a.abs_grad = d_absgrad.p; a.penalty = d_penalty.p; a.slot = d_slot.p;
-        a.G = int32_t(G);
-        a.rule = screen_rule == ADELIE_HIP_SCREEN_STRONG ? 0 : 1;
-        a.alpha = alpha; a.lmda = lmda_of_sweep;
-        a.lmda_next[0] = lmda_of_sweep;                                   // KKT failed: the same lambda again
-        a.lmda_next[1] = scr_ctx.has_next ? scr_ctx.lmda_next_pass : lmda_of_sweep;
-        a.n_new_active[0] = scr_ctx.nna_fail;
-        a.n_new_active[1] = active_now - scr_ctx.active_before;
-        a.take[0] = pivot_slack_take(a.n_new_active[0]);
-        a.take[1] = pivot_slack_take(a.n_new_active[1]);
-        a.subset = pivot_subset_size(old_size);
-        a.seq = ++scr_req.seq;
-        const bool need_order = a.rule == 1 && (a.n_new_active[0] != 0 || a.n_new_active[1] != 0);
-        if (!d_scr_flags.p) {
-            d_scr_flags.reserve(16);
-            AHIP_CHECK(hipMemsetAsync(d_scr_flags.p, 0, 16 * sizeof(int32_t), st_scr));
-            d_scr_wt.reserve(size_t(G)); d_scr_key.reserve(size_t(G)); d_scr_rank.reserve(size_t(G)); d_scr_order.reserve(size_t(G));
-            d_scr_sorted.reserve(size_t(G));
-            d_scr_pre.reserve(size_t(4) * size_t(G));
-        }
-        a.wt = d_scr_wt.p; a.key = d_scr_key.p; a.rank = d_scr_rank.p; a.order = d_scr_order.p; a.pre = d_scr_pre.p;
-        a.sorted = d_scr_sorted.p; a.flags = d_scr_flags.p;
-        a.out = h_scr_dev;
-        a.dev_list = nullptr;
-        AHIP_CHECK(hipEventRecord(scr_in_ev, st));
-        AHIP_CHECK(hipStreamWaitEvent(st_scr, scr_in_ev, 0));
-        launch_screen<T>(a, need_order, st_scr);
-        AHIP_CHECK(hipEventRecord(scr_ev, st_scr));
-        scr_req.pending = true;
-        scr_req.lmda = a.lmda;
-        scr_req.lnext[0] = a.lmda_next[0]; scr_req.lnext[1] = a.lmda_next[1];
-        scr_req.nna[0] = a.n_new_active[0]; scr_req.nna[1] = a.n_new_active[1];
-        scr_req.old_size = old_size;
-    }
-    // the device's answer to screen(lmda_next, all_kkt_passed, n_new_active), if that is the call that was prepared
-    bool device_screen_take(T lmda_next, bool all_kkt_passed, int n_new_active) {
-        if (!scr_req.pending) return false;
-        scr_req.pending = false;
-        AHIP_CHECK(hipEventSynchronize(scr_ev)); // (also when the answer is not used: the kernels read d_slot / d_absgrad)
-        const int k = all_kkt_passed ? 1 : 0;
-        if (!(scr_req.lmda == lmda && scr_req.lnext[k] == lmda_next && scr_req.nna[k] == n_new_active &&
-              scr_req.old_size == screen_set.size()))
-            return false;
-        if (__atomic_load_n(&h_scr[0], __ATOMIC_ACQUIRE) != scr_req.seq || h_scr[1] != k) return false;
-        const int32_t n_new = h_scr[2];
-        if (n_new < 0 || idx(n_new) > G) return false;
-        const size_t old_size = screen_set.size();
-        for (int32_t t = 0; t < n_new; ++t) screen_set.push_back(idx(h_scr[kScreenHeader + t]));
-        if (screen_set.size() > max_screen_size) {
-            screen_set.resize(old_size);
-            throw max_screen_set_error();
-        }
-        return true;
-    }
+    int64_t n_host_screens = 0;
 
     // solver_base.hpp:120-153
     void update_screen_derived_base() {
@@ -3812,11 +3678,8 @@ struct Solver {
     void screen_f(T lm, bool kkt_passed, int n_new_active) {
         Stopwatch sw;
         sw.start();
-        if (device_screen_take(lm, kkt_passed, n_new_active)) ++n_dev_screens;
-        else {
-            screen(lm, kkt_passed, n_new_active);
-            ++n_host_screens;
-        }
+        screen(lm, kkt_passed, n_new_active);
+        ++n_host_screens;
         t_host[0] += sw.elapsed();
         sw.start();
         if (is_glm()) {
@@ -3897,18 +3760,12 @@ struct Solver {
                 t_host_screen += benchmark_screen.back();
                 t_host_screen_wait += t_sync_total - sync0;
                 spec_next_lm = (lmda_path_idx + 1 < L) ? lmda_path[lmda_path_idx + 1] : T(0);
-                scr_ctx.armed = true; // what the next screen() call will be given, whichever way the KKT check goes
-                scr_ctx.has_next = lmda_path_idx + 1 < L;
-                scr_ctx.lmda_next_pass = scr_ctx.has_next ? lmda_path[lmda_path_idx + 1] : T(0);
-                scr_ctx.nna_fail = n_new_active;
-                scr_ctx.active_before = current_active_size;
                 auto fo = fit_f(lmda_curr);
                 spec_next_lm = T(0);
                 benchmark_fit_screen.push_back(fo.t_screen);
                 benchmark_fit_active.push_back(fo.t_active);
                 sw.start();
                 update_invariance(lmda_curr);
-                scr_ctx.armed = false;
                 benchmark_invariance.push_back(sw.elapsed());
                 t_host[4] += benchmark_invariance.back();
                 sw.start();
@@ -4100,7 +3957,6 @@ struct Solver {
         if (const char* e = std::getenv("ADELIE_HIP_STRIP_WGS")) set_strip_workgroups(std::atoi(e));
         if (const char* e = std::getenv("ADELIE_HIP_STRIP_LDS")) set_strip_lds(std::atoi(e) != 0);
         if (const char* e = std::getenv("ADELIE_HIP_DEVICE_EIG")) device_eig = std::atoi(e) != 0;
-        if (const char* e = std::getenv("ADELIE_HIP_DEVICE_SCREEN")) dev_screen = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_PASS_TABLES")) pass_tables_cached = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_OPEN_FROM_GRAD")) open_from_grad_opt = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_IRLS_REUSE")) irls_reuse = std::max(0.0, std::atof(e));
@@ -4137,7 +3993,6 @@ struct Solver {
             for (idx g = 0; g < G; ++g) any = any || a->constraint_kind[g] != 0;
             if (any) {
                 if (cov_mode) throw make_core_error("constraints are not implemented for the covariance method.");
-                if (multi()) throw make_core_error("constraints are not implemented for multi-response problems.");
                 if (!all_scalar && max_gs > idx(cd_block_size()))
                     throw make_core_error("constraints are not implemented for problems with groups of more than " +
                                           std::to_string(cd_block_size()) + " coefficients.");
@@ -4498,7 +4353,7 @@ struct Result : ResultBase {
             case ADELIE_HIP_S_T_HOST_SCREEN_WAIT_MS: return 1e3 * s.t_host_screen_wait;
             case ADELIE_HIP_S_N_SWEEPS_SHARED: return double(s.cnt.n_sweeps_shared);
             case ADELIE_HIP_S_N_UPDATE_COLS: return double(s.cnt.n_update_cols);
-            case ADELIE_HIP_S_N_DEVICE_SCREENS: return double(s.n_dev_screens);
+            case ADELIE_HIP_S_N_DEVICE_SCREENS: return 0.0; /* (screening on the device was measured slower and removed in round 4) */
             case ADELIE_HIP_S_N_HOST_SCREENS: return double(s.n_host_screens);
             default:
                 if (which >= 900 && which < 908) return double(s.cd_dbg[which - 900]);

@@ -755,7 +755,6 @@ class multigaussian_naive_base(gaussian_naive_base):
     off on the expanded design ``[1 (x) I_K, X (x) I_K]``; the per-response intercepts are its first ``K`` (unpenalised)
     coefficients and are split off every solution (``solver_multigaussian_naive.hpp:31-44``, ``py_state.cpp:1352-1366``)."""
 
-    _supports_constraints = False
 
     def _tidy_path(self, betas, intercepts):
         return _split_class_intercepts(self, betas)
@@ -860,7 +859,6 @@ class multiglm_naive_base(glm_naive_base):
         a.glm_weights = w.ctypes.data
         return a, keep
 
-    _supports_constraints = False
 
     def _tidy_path(self, betas, intercepts):
         return _split_class_intercepts(self, betas)

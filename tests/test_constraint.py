@@ -211,8 +211,11 @@ def test_constraint_errors(oracle):
     with pytest.raises(RuntimeError, match="ConstraintBase"):
         ad.grpnet(X, glm, constraints=[mine()] + [None] * 7, progress_bar=False)
     y2 = np.stack([d["y"], -d["y"]], axis=1)
-    with pytest.raises(NotImplementedError, match="multi-response"):
-        ad.grpnet(X, ad.glm.multigaussian(y2), constraints=[two] + [None] * 7, progress_bar=False)
+    # multi-response fits take the list as the reference does (a group of a K = 2 fit has two coefficients)
+    st = ad.grpnet(X, ad.glm.multigaussian(y2), constraints=[two] + [None] * 7, lmda_path_size=4, progress_bar=False)
+    assert st.error == "" and st.duals.shape == (4, 2)
+    with pytest.raises(NotImplementedError, match="constraints are not implemented"):
+        ad.solver.gaussian_cov(oracle.cov_dense(np.eye(8)), np.ones(8), constraints=[c] + [None] * 7, progress_bar=False)
 
 
 def test_cv_grpnet_passes_constraints_to_every_fold(oracle):
@@ -883,7 +886,7 @@ def test_checker_linear_solve_zero(oracle):
         assert out[0] <= best + 1e-6 and out[0] >= best - 1e-6
 
 
-def _linear_problem(rng, p, gsz):
+def _linear_problem(rng, p, gsz, configs=None):
     groups = np.arange(0, p, gsz)
     spec = []
     for g in range(len(groups)):
@@ -892,7 +895,7 @@ def _linear_problem(rng, p, gsz):
             spec.append((rng.randn(m, gsz), -rng.uniform(0, 0.2, m) * (rng.rand(m) < 0.7), rng.uniform(0.02, 0.2, m)))
         else:
             spec.append(None)
-    make = lambda: [None if s is None else constraint.linear(*s) for s in spec]
+    make = lambda: [None if s is None else constraint.linear(*s, configs=configs) for s in spec]
     return groups, make
 
 
@@ -910,9 +913,15 @@ def test_oracle_path_with_linear_constraints_is_optimal(oracle):
 
 @pytest.mark.gpu
 def test_hip_linear_constraints_match_oracle(hip, oracle):
+    """Two implementations of ``linear`` meet here: the HIP path visits the groups through adelie_amd.constraint's numpy class,
+    the oracle runs its own C++ restatement of ConstraintLinear (oracle/linear_constraint.hpp).  Both iterate on the
+    multipliers, so the constraint solvers' own tolerances are set tight (at their defaults, 1e-9 / 1e-7, two correct runs
+    differ by 2e-5 in the coefficients); the multipliers of groups that sit at zero agree because both sides run the
+    reference's warm-started bounded least squares in the same order."""
     d = make_gaussian(300, 60, seed=14, sparsity=0.7)
     X, y = d["X"], d["y"]
-    groups, make = _linear_problem(np.random.RandomState(4), 60, 4)
+    tight = {"tol": 1e-13, "pinball_tol": 1e-12, "nnls_tol": 1e-12, "max_iters": 1000}
+    groups, make = _linear_problem(np.random.RandomState(4), 60, 4, tight)
     kw = dict(groups=groups, alpha=0.8, tol=1e-10, lmda_path_size=10, min_ratio=0.05, early_exit=False)
     ch = make()
     st = _fit(ad.matrix.dense(X), ad.glm.gaussian(y), ch, **kw)
@@ -920,7 +929,7 @@ def test_hip_linear_constraints_match_oracle(hip, oracle):
     assert st.error == "" and ref.error == ""
     assert np.abs(st.betas.toarray() - ref.betas.toarray()).max() < 1e-6
     assert st.duals.shape == ref.duals.shape and ref.duals.nnz > 0
-    assert np.abs((st.duals - ref.duals)).max() < 1e-4
+    assert np.abs((st.duals - ref.duals)).max() < 1e-5
     B = st.betas.toarray()
     for g, c in enumerate(ch):
         if c is not None:

@@ -510,3 +510,104 @@ def test_hip_multi_response_on_snp_design_equals_densified():
     cv = ad.cv_grpnet(matrix.snp_calldata(calls), ad.glm.multigaussian(y=Y), n_folds=3, seed=0, lmda_path_size=10,
                       progress_bar=False)
     assert np.all(np.isfinite(cv.losses))
+
+
+# ---- per-group constraints on multi-response fits (reference solver.py:640-659: the list goes through to the view's solver;
+# ---- state.py:24-45 left-pads it with None for the K intercept columns) ------------------------------------------------------
+def _multi_constraints(p, K, rng, with_linear=True):
+    from adelie_amd import constraint
+
+    spec = [None] * p
+    for j in rng.choice(p, 6, replace=False):
+        spec[j] = ("box", -rng.uniform(0.02, 0.2, K), rng.uniform(0.02, 0.2, K))
+    if with_linear:
+        free = [j for j in range(p) if spec[j] is None]
+        for j in rng.choice(free, 2, replace=False):
+            spec[j] = ("linear", rng.normal(size=(2, K)), -rng.uniform(0.02, 0.1, 2), rng.uniform(0.02, 0.1, 2))
+
+    def make():
+        out = []
+        for s in spec:
+            if s is None:
+                out.append(None)
+            elif s[0] == "box":
+                out.append(constraint.box(s[1], s[2]))
+            else:
+                out.append(constraint.linear(s[1], s[2], s[3]))
+        return out
+    return spec, make
+
+
+@pytest.mark.parametrize("icpt", [False, True])
+def test_oracle_multigaussian_constrained_path_is_optimal(oracle, icpt):
+    """KKT system of the constrained multigaussian problem from first principles, with the returned duals: stationarity
+    grad_g - lmda pen (alpha b/|b| + (1 - alpha) b) - A_g' mu_g = 0 on non-zero groups, |grad_g - A_g' mu_g| <= lmda alpha pen on
+    zero groups, feasibility, sign and complementarity of the multipliers."""
+    K, p = 3, 16
+    X, Y, w = make_multi(250, p, K, seed=5, nnz=6, weights=True)
+    spec, make = _multi_constraints(p, K, np.random.RandomState(2))
+    cons = make()
+    st = ad.grpnet(X=oracle.dense(X), glm=ad.glm.multigaussian(Y, weights=w), constraints=cons, intercept=icpt, alpha=0.8,
+                   tol=1e-13, early_exit=False, lmda_path_size=12, min_ratio=0.03, progress_bar=False)
+    assert st.error == ""
+    n_d = sum(0 if c is None else c.duals() for c in cons)
+    assert st.duals.shape == (12, n_d) and st.duals.nnz > 0
+    Bs, Ds = st.betas.toarray(), st.duals.toarray()
+    pen = np.sqrt(K)
+    worst, bound = 0.0, 0
+    for l, lm in enumerate(st.lmdas):
+        B = Bs[l].reshape(p, K)
+        R = Y - X @ B - st.intercepts[l]
+        if icpt:
+            worst = max(worst, np.abs(w @ R).max() / K)
+        Gr = X.T @ (w[:, None] * R) / K
+        off = 0
+        for j in range(p):
+            g, b = Gr[j], B[j]
+            atmu = np.zeros(K)
+            if spec[j] is not None:
+                m = cons[j].duals()
+                mu = Ds[l, off:off + m]
+                off += m
+                if spec[j][0] == "box":
+                    atmu, z, lo, up = mu, b, spec[j][1], spec[j][2]
+                else:
+                    atmu, z, lo, up = spec[j][1].T @ mu, spec[j][1] @ b, spec[j][2], spec[j][3]
+                # (the constraint solvers stop on their own tolerances: tol 1e-9 on the dual iteration, 1e-7 on its sub-problem)
+                assert np.all(z <= up + 5e-5) and np.all(z >= lo - 5e-5)
+                assert np.all(np.maximum(mu, 0) * (up - z) < 1e-4) and np.all(np.maximum(-mu, 0) * (z - lo) < 1e-4)
+                bound += int(np.any(mu != 0))
+            nb = np.linalg.norm(b)
+            if nb == 0:
+                worst = max(worst, np.linalg.norm(g - atmu) - lm * 0.8 * pen)
+            else:
+                worst = max(worst, np.linalg.norm(g - atmu - lm * pen * (0.8 * b / nb + 0.2 * b)))
+    assert worst < 5e-5, worst
+    assert bound >= 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["multigaussian", "multinomial"])
+def test_hip_multi_constraints_match_oracle(hip, oracle, family):
+    """Constraint objects on the groups of a multi-response view: the HIP path (group visits through the callbacks between two
+    K-wide panel steps) against the oracle (its own C++ box / linear solvers)."""
+    K, p = 3, 24
+    if family == "multigaussian":
+        X, Y, w = make_multi(300, p, K, seed=9, nnz=6, weights=True)
+        mk = lambda: ad.glm.multigaussian(Y, weights=w)
+        kw = dict(tol=1e-13)
+    else:
+        X, Y, w = make_multinomial(400, p, K, seed=9, nnz=5)
+        mk = lambda: ad.glm.multinomial(Y)
+        kw = dict(tol=1e-13, irls_tol=1e-11)
+    _, make = _multi_constraints(p, K, np.random.RandomState(4))
+    kw.update(alpha=0.9, early_exit=False, lmda_path_size=10, min_ratio=0.05, progress_bar=False)
+    a = ad.grpnet(X=ad.matrix.dense(X), glm=mk(), constraints=make(), **kw)
+    b = ad.grpnet(X=oracle.dense(X), glm=mk(), constraints=make(), **kw)
+    assert a.error == "" and b.error == "", (a.error, b.error)
+    assert len(a.lmdas) == len(b.lmdas) == 10
+    assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 2e-6
+    assert np.abs(a.intercepts - b.intercepts).max() < 2e-6
+    assert a.duals.shape == b.duals.shape and b.duals.nnz > 0
+    scale = max(1.0, float(np.abs(b.duals).max()))
+    assert np.abs((a.duals - b.duals)).max() < 1e-4 * scale

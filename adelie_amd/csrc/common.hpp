@@ -1,5 +1,7 @@
 // common.hpp — host-side helpers shared by the C-ABI translation units.
 #pragma once
+#include <cstdlib>
+#include <algorithm>
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -14,6 +16,43 @@
 #include "kernels.hpp"
 
 namespace ahip {
+
+// ---- every environment hook of libadelie_hip.so, in one place ------------------------------------------------------------------
+// Seven variables.  They are read when a solve starts (Hooks::from_env, one call per solve): the tests force the multi-CU engines
+// at sizes the CPU checker finishes in seconds and compare variants between two solves of ONE process, so reading them once at
+// library load would freeze the first test's setting.  None changes results beyond rounding.  (Python side: ADELIE_HIP_LIB picks
+// another build of this library, ADELIE_HIP_SWEEP_BATCH=0 keeps concurrent CV folds from sharing their sweeps.)
+//   ADELIE_HIP_CD_BLOCK_MIN_NV=n  screen sets of at least n coefficients use the panel engine (default 128)       [test hook]
+//   ADELIE_HIP_PANEL_BSZ=32|64|128  visits per lasso panel block (default 128, 64 under IRLS)                      [test hook]
+//   ADELIE_HIP_LOOKAHEAD=0        Gaussian passes in the sequential form (step -> reduce -> solve) that IRLS and
+//                                 constrained problems always use                                                   [test hook]
+//   ADELIE_HIP_SPECULATE=0        no speculative first active-set pass behind the invariance sweep                  [A/B, bit-identity test]
+//   ADELIE_HIP_IRLS_REUSE=theta   IRLS diagonal-block reuse threshold (default 0.01, 0 = rebuild per iteration)     [documented deviation]
+//   ADELIE_HIP_TIME_PANEL=1       per-launch HIP events around the panel step (bench.py's roofline leg)
+//   ADELIE_HIP_TRACE=1|2          1: per-pass trace on stderr; 2: + enqueue / allocation / build timings
+struct Hooks {
+    long long cd_block_min_nv = -1; // -1: unset
+    int panel_bsz = 0;
+    int lookahead = -1, speculate = -1;
+    double irls_reuse = -1;
+    bool time_panel = false;
+    int trace = 0;
+    static Hooks from_env() {
+        Hooks h;
+        if (const char* e = std::getenv("ADELIE_HIP_CD_BLOCK_MIN_NV")) h.cd_block_min_nv = std::atoll(e);
+        if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {
+            const int v = std::atoi(e);
+            h.panel_bsz = (v == 32 || v == 64 || v == 128) ? v : 0;
+        }
+        if (const char* e = std::getenv("ADELIE_HIP_LOOKAHEAD")) h.lookahead = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_SPECULATE")) h.speculate = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_IRLS_REUSE")) h.irls_reuse = std::max(0.0, std::atof(e));
+        h.time_panel = std::getenv("ADELIE_HIP_TIME_PANEL") != nullptr;
+        if (const char* e = std::getenv("ADELIE_HIP_TRACE")) h.trace = std::max(1, std::atoi(e));
+        return h;
+    }
+};
+
 
 // util/exceptions.hpp:8-55 — same prefixes so that the Python layer's error-vs-warning split keeps working
 struct core_error : std::runtime_error {
@@ -101,7 +140,10 @@ struct StreamPool {
     static void give(hipStream_t s) {
         if (!s) return;
         int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess) {
+        hipDevice_t sd;
+        // the stream's own device (see DevPool::give); older runtimes without the query fall back to the current device
+        const bool known = hipStreamGetDevice(s, &sd) == hipSuccess ? (dev = int(sd), true) : (hipGetDevice(&dev) == hipSuccess);
+        if (known) {
             std::lock_guard<std::mutex> lk(mu());
             if (parked().size() < 64) {
                 parked().push_back(Entry{dev, s});
@@ -207,8 +249,14 @@ struct DevPool {
     }
     // returns false when the buffer was not parked (the caller frees it)
     static bool give(void* p, size_t bytes) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return false;
+        // the device the block LIVES on, not the calling thread's current one: a result may be destroyed from any thread
+        // (C-ABI users, a garbage collector), and a block parked under the wrong device would be handed to a later solve there
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        const int dev = at.device;
         std::lock_guard<std::mutex> lk(mu());
         if (parked_bytes() + bytes > limit_bytes() || parked().size() >= 4096) return false;
         parked().push_back(Entry{bytes, p, dev});

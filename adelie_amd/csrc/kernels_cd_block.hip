@@ -170,8 +170,7 @@ void launch_cd_panel_solve(const CdBlkParams<T>& p, int j, hipStream_t s) {
         hipLaunchKernelGGL((blk_solve_cons_kernel<T>), dim3(1), dim3(256), blk_solve_lds<T>(), s, p, j);
         return;
     }
-    static const bool wide = !(std::getenv("ADELIE_HIP_SOLVE_WIDE") && std::atoi(std::getenv("ADELIE_HIP_SOLVE_WIDE")) == 0);
-    if (wide) {
+    {
         static bool la_attr_done = false;
         if (!la_attr_done) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk_solve_la_kernel<double>),

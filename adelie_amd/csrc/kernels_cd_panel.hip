@@ -464,11 +464,7 @@ int fused_launch(const CdBlkParams<T>& sp, int j, const Acc& acc, int64_t n, con
                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(fused_lds<T>()));
         attr_done = true;
     }
-    static const int reps = [] {
-        const char* e = std::getenv("ADELIE_HIP_STEP_REPS");
-        const int v = e ? std::atoi(e) : 1;
-        return v < 1 ? 1 : (v > 8 ? 8 : v);
-    }();
+    constexpr int reps = 1; // (workgroups that take several groups of slices in turn: 287.3 -> 314.9 ms on the headline, round 3)
     hipLaunchKernelGGL((panel_fused_kernel<T, Acc, VEC>), dim3((unsigned)((nwg + reps - 1) / reps + 1)), dim3(256 * FS),
                        fused_lds<T>(), s, sp, j, acc, n, w, r, dcol, dlt, nz_dev, cols, nb, part,
                        tr ? int64_t(0) : part_ld, reps);
@@ -548,12 +544,7 @@ int launch_panel_step_snp(const SnpView& X, const T* impute, const T* w, T* r, c
     SnpAcc<T> acc{X.bits, X.ldb, impute};
     // 16 calls (one 32-bit word) per lane and column instead of 4 (one byte): a quarter of the workgroups, four times the
     // bytes per load instruction - the byte form is bound by the number of workgroups and load instructions, not by bytes.
-    // Hook ADELIE_HIP_SNP_STEP_VEC=4.
-    static const int vec = [] {
-        const char* e = std::getenv("ADELIE_HIP_SNP_STEP_VEC");
-        return (e && std::atoi(e) == 4) ? 4 : 16;
-    }();
-    if (vec == 16 && X.n >= 16384 && X.ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(X.bits) % 4) == 0)
+    if (X.n >= 16384 && X.ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(X.bits) % 4) == 0)
         return step_launch<T, SnpAcc<T>, 16>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
     return step_launch<T, SnpAcc<T>, 4>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
 }

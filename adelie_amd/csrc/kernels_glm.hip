@@ -317,7 +317,8 @@ __global__ __launch_bounds__(RT) void rel_change_kernel(const T* __restrict__ a,
         const T x = a[i], y = prev[i];
         prev[i] = x;
         const T d = fabs(x - y);
-        const T r = y > T(0) ? d / y : (d > T(0) ? T(1e30) : T(0));
+        T r = y > T(0) ? d / y : (d > T(0) ? T(1e30) : T(0));
+        if (!(r == r) || !(d == d)) r = T(1e30); // a non-finite weight is "moved by everything": never a reason to reuse a block
         m = r > m ? r : m;
     }
     for (int off = 32; off > 0; off >>= 1) {

@@ -240,14 +240,12 @@ __global__ void multi_sweep_reduce_kernel(const T* __restrict__ part, T* __restr
 }
 
 inline int msweep_mcb() {
-    static const int v = (std::getenv("ADELIE_HIP_MULTI_SWEEP_MCB") && std::atoi(std::getenv("ADELIE_HIP_MULTI_SWEEP_MCB")) == 4) ? 4 : 8;
-    return v;
+    return 8; // features per block (4 was the round-1 shape: the K vectors re-read from L2 twice as often)
 }
 // 0: one feature group per block; 1: four waves x 8 features; 2: four waves x 4 features (half the accumulators, twice the
 // waves per SIMD: 2.2 ms, the vectors' L2 traffic doubles); 3: four waves x 8 features with the vectors staged through LDS
 inline int msweep_wpc() {
-    static const int v = std::getenv("ADELIE_HIP_MULTI_SWEEP_WPC") ? std::atoi(std::getenv("ADELIE_HIP_MULTI_SWEEP_WPC")) : 3;
-    return v;
+    return 3; // (the unstaged forms 1 / 2 measured 1.36 / 2.23 ms against 1.335 ms at K = 8)
 }
 inline void msweep_shape(int64_t nb, int64_t nfeat, int vec, int64_t& blocks_c, int& nsplit, int64_t& rows_per_split,
                          int wpc = 0) {

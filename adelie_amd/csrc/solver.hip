@@ -284,9 +284,8 @@ struct SweepBatcher {
             // leader: give the others a window of about four sweep times (a sweep moves n*p values at ~7 TB/s), then launch
             // for whoever has arrived: waiting costs a lone solver at most that, sharing saves K - 1 sweeps
             // (8-fold CV, 100k x 10k: 1.05 s with a 0.25 ms window, 0.84 s with 0.8 ms, 0.70 s with 5 ms, no better beyond)
-            static const int window_env = std::getenv("ADELIE_HIP_BATCH_WINDOW_US") ? std::atoi(std::getenv("ADELIE_HIP_BATCH_WINDOW_US")) : 0;
             const double sweep_us = double(n) * double(p) * double(sizeof(T)) / 7.0e6;
-            const int window_us = window_env > 0 ? window_env : int(std::min(5000.0, std::max(100.0, 4.0 * sweep_us)));
+            const int window_us = int(std::min(5000.0, std::max(100.0, 4.0 * sweep_us)));
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us);
             cv.wait_until(lk, deadline, [&] { return G.count >= std::min(registered, KMAX); });
             const int K = G.count;
@@ -385,6 +384,7 @@ struct Solver {
     // keeps them as passed (kind, a, b) for the dual's convention, the device sees the unified form lo <= beta <= hi with
     // lo <= 0 <= hi (+-inf where there is no bound) and the signed multiplier mu_+ - mu_- (the term the constraint adds to
     // the coordinate's gradient; a one-sided constraint's dual is sgn times it)
+    Hooks hooks;
     bool cons_on = false;
     std::vector<int32_t> cons_kind;
     std::vector<T> cons_a, cons_lo, cons_hi, cons_mu; // (G,)
@@ -1992,7 +1992,7 @@ struct Solver {
         bp.bsz = B;
         bp.host_st = rep_st_dev; bp.host_seq = rep_seq_dev; bp.report_j = -1; bp.report_seq = 0;
         const T* xm_c = intercept ? cur_xm : nullptr;
-        static const bool trace = std::getenv("ADELIE_HIP_TRACE") != nullptr;
+        const bool trace = hooks.trace >= 1;
         int64_t iters = 0;
         int status = CD_OK;
         int asz = sc.active_size;
@@ -2456,7 +2456,7 @@ struct Solver {
     CdBlkState<T> host_group_visit(const CdParams<T>& cp, idx ss, bool mark, bool first_of_pass) {
         const idx g = screen_set[ss], q = group_sizes[g], b = screen_begins[ss];
         const size_t uq = static_cast<size_t>(q);
-        static const bool trace_hv = std::getenv("ADELIE_HIP_TRACE") != nullptr;
+        const bool trace_hv = hooks.trace >= 1;
         if (trace_hv) std::fprintf(stderr, "[host visit] ss=%lld g=%lld q=%lld b=%lld voff=%lld v_used=%zu nv=%lld\n", (long long)ss, (long long)g,
                                    (long long)q, (long long)b, (long long)(size_t(ss) < h_voff.size() ? h_voff[size_t(ss)] : -1), v_used, (long long)nv);
         std::vector<T> gk(uq), ak(uq), Ak(uq), Vk(uq * uq, T(1));
@@ -2599,10 +2599,10 @@ struct Solver {
             Solver* s;
             ~RotGuard() { s->rot_on = false; s->rot_list = nullptr; }
         } rot_guard{this};
-        if (std::getenv("ADELIE_HIP_GRP_PROFILE")) {
-            if (!d_grp_dbg.p) { d_grp_dbg.reserve(8); AHIP_CHECK(hipMemsetAsync(d_grp_dbg.p, 0, 8 * sizeof(int64_t), st)); }
-            bp.dbg = d_grp_dbg.p;
-        }
+#ifdef AHIP_GRP_PROFILE // (profile build, scripts/grp_profile.py: cycle counters of the group solve)
+        if (!d_grp_dbg.p) { d_grp_dbg.reserve(8); AHIP_CHECK(hipMemsetAsync(d_grp_dbg.p, 0, 8 * sizeof(int64_t), st)); }
+        bp.dbg = d_grp_dbg.p;
+#endif
         const T* xm_c = intercept ? cur_xm : nullptr;
         int64_t iters = 0;
         int status = CD_OK;
@@ -2625,19 +2625,14 @@ struct Solver {
             d_part2.reserve(2 * part2_half);
             if (mode != 2) pending_slot = -1;
         }
-        // The group solve can sum the slice partials itself as the lasso solve does (fuse_reduce), in its eigen-coordinate form on
-        // single-response designs - but a group launch is bound by its solve (Newton root finds: 43 us against a 34 us step), so
-        // the extra round trip of the prologue lands on the chain: config 3 722.7 ms with, 654.1 ms without (hook
-        // ADELIE_HIP_GRP_FUSE_REDUCE=1).  Off.
-        static const bool grp_fr_opt = std::getenv("ADELIE_HIP_GRP_FUSE_REDUCE") && std::atoi(std::getenv("ADELIE_HIP_GRP_FUSE_REDUCE")) != 0;
-        const bool fr_grp = grp_fr_opt && fuse_reduce && bp.rot && !multi();
-        // ... but the LAST STEP WORKGROUP of a fused launch can: it finishes ~9 us before the solve does, and summing 196 x 128
-        // partials takes one workgroup 3 us (CdGrpBlkParams::tail_counter).  No panel_reduce launch between two fused launches
-        // (5.3 us + two boundaries per block).  One partial per column and workgroup is what the kernel sums: 16-byte
-        // aligned dense designs in double precision / any SNP design.  Hook ADELIE_HIP_GRP_TAIL_REDUCE=0.
-        static const bool grp_tail_opt = !(std::getenv("ADELIE_HIP_GRP_TAIL_REDUCE") && std::atoi(std::getenv("ADELIE_HIP_GRP_TAIL_REDUCE")) == 0);
+        // (The group solve summing the slice partials itself, as the lasso solve does, was measured slower — config 3: 722.7 ms
+        // with, 654.1 ms without: a group launch is bound by its solve — and removed in round 4.)
+        // The LAST STEP WORKGROUP of a fused launch sums them instead: it finishes ~9 us before the solve does, and summing
+        // 196 x 128 partials takes one workgroup 3 us (CdGrpBlkParams::tail_counter).  No panel_reduce launch between two fused
+        // launches (5.3 us + two boundaries per block).  One partial per column and workgroup is what the kernel sums: 16-byte
+        // aligned dense designs in double precision / any SNP design.
         bool tail_ok = false;
-        if (grp_tail_opt && !fr_grp && !multi()) {
+        if (!multi()) {
             if (dense()) {
                 constexpr int V = int(16 / sizeof(T));
                 tail_ok = (64 * V >= 128) && (D->ld % V == 0) && ((reinterpret_cast<uintptr_t>(D->X) % 16) == 0);
@@ -2770,7 +2765,7 @@ struct Solver {
                 bp.rsum_out = d_la_rsum.p + slot;
                 bp.pdd = d_la_dd.p + size_t(pslot) * SL;
                 bp.dd = d_la_dd.p + size_t(slot) * SL;
-                bp.part = (fr_grp && prev_ld > 0) ? d_part2.p + size_t((j - 1) & 1) * part2_half : nullptr;
+                bp.part = nullptr;
                 bp.part_n = prev_ld;
                 bp.part_rsum = xm_c ? d_la_rsum.p + slot : nullptr;
                 prev_ld = 0;
@@ -2802,18 +2797,17 @@ struct Solver {
                 else if (dense())
                     ld = launch_panel_fused_grp<T>(bp, j, D->dense<T>(), cur_w, r_dev, d_la_dcol.p + size_t(pslot) * SL,
                                                    d_la_dlt.p + size_t(pslot) * SL, nz_apply, cols_n, nbn,
-                                                   fr_grp ? d_part2.p + size_t(j & 1) * part2_half : (tail_ok ? d_part2.p : d_part.p),
-                                                   fr_grp || tail_ok, st);
+                                                   tail_ok ? d_part2.p : d_part.p,
+                                                   tail_ok, st);
                 else
                     ld = launch_panel_fused_grp_snp<T>(bp, j, D->snp(), static_cast<const T*>(D->impute), cur_w, r_dev,
                                                        d_la_dcol.p + size_t(pslot) * SL, d_la_dlt.p + size_t(pslot) * SL,
                                                        d_la_nz.p + pslot, cols_n, nbn,
-                                                       fr_grp ? d_part2.p + size_t(j & 1) * part2_half : (tail_ok ? d_part2.p : d_part.p),
-                                                       fr_grp || tail_ok, st);
+                                                       tail_ok ? d_part2.p : d_part.p,
+                                                       tail_ok, st);
                 if (time_panel) t_step.end(st);
                 if (nbn > 0) {
-                    if (fr_grp) prev_ld = ld; // summed by the next solve
-                    else if (tail_ok) { /* summed by the launch's last step workgroup */ }
+                    if (tail_ok) { /* summed by the launch's last step workgroup */ }
                     else
                         launch_panel_reduce_ld<T>(d_part.p, ld, ld, nbn, cols_n, d_la_rsum.p + pslot, xm_c,
                                                   d_la_g.p + size_t(pslot) * SL, st);
@@ -3789,10 +3783,10 @@ struct Solver {
 
     // pull the device-resident invariants back into the host mirrors that the result accessors expose
     void finalize() {
-        if (std::getenv("ADELIE_HIP_TRACE_ENQ"))
+        if (hooks.trace >= 2)
             std::fprintf(stderr, "[enq] panel passes: host enqueue %.1f ms, host wait %.1f ms, blocks %lld (built %lld + %lld cross + %lld strips, reused across IRLS iterations %lld), speculated %lld (rolled back %lld)\n",
                          t_enq * 1e3, t_wait * 1e3, (long long)cnt.n_panel_blocks, (long long)cnt.n_panel_grams, (long long)n_cross_blocks, (long long)n_strip_builds, (long long)n_blocks_reused, (long long)n_spec, (long long)n_spec_rollback);
-        if (std::getenv("ADELIE_HIP_TRACE_ENQ"))
+        if (hooks.trace >= 2)
             std::fprintf(stderr, "[alloc] hipMalloc/hipFree so far in this process: %ld calls, %.1f ms\n", DevAllocStats::calls(),
                          DevAllocStats::seconds() * 1e3);
         t_sweep.collect(); t_gram.collect(); t_cd.collect(); t_axpy.collect(); t_step.collect();
@@ -3801,7 +3795,7 @@ struct Solver {
             d_grp_dbg.download(cd_dbg, 8, st);
             sync();
         }
-        if (std::getenv("ADELIE_HIP_DEBUG_GRAM")) {
+        if (hooks.trace >= 2) {
             for (size_t i = 0; i < gram_shapes.size() && i < t_gram.each.size(); ++i) {
                 const double fl = 2.0 * double(n) * double(gram_shapes[i].first) * double(gram_shapes[i].second);
                 std::fprintf(stderr, "gram M=%lld N=%lld ms=%.3f TF=%.1f\n", (long long)gram_shapes[i].first,
@@ -3927,43 +3921,17 @@ struct Solver {
             if (i < 0 || i >= G) throw make_core_error("screen_set contains an out-of-range group index.");
 
         AHIP_CHECK(hipSetDevice(X->device));
-        if (const char* e = std::getenv("ADELIE_HIP_CD_BLOCK_MIN_NV")) cd_block_min_nv = std::atoll(e); // test hook
-        if (const char* e = std::getenv("ADELIE_HIP_CD_ENGINE")) engine_panel = std::string(e) != "gram"; // A/B hook
-        time_panel = std::getenv("ADELIE_HIP_TIME_PANEL") != nullptr;
-        if (const char* e = std::getenv("ADELIE_HIP_PASS_REPORT")) use_report = std::atoi(e) != 0; // A/B hook
-        if (const char* e = std::getenv("ADELIE_HIP_SIDE_GRAMS")) side_grams = std::atoi(e) != 0; // A/B hook
+        hooks = Hooks::from_env(); // (common.hpp: the library's seven environment hooks)
+        if (hooks.cd_block_min_nv >= 0) cd_block_min_nv = hooks.cd_block_min_nv;
+        time_panel = hooks.time_panel;
         // two build streams under IRLS (config 4: 8.2 -> 7.2 s; three or four are no better), one under fixed weights (the
         // few builds of a Gaussian path only add contention for the look-ahead launches: 3.13 vs 3.08 paths/s)
         n_side = is_glm() ? 2 : 1;
-        if (const char* e = std::getenv("ADELIE_HIP_SIDE_STREAMS")) n_side = std::max(1, std::min(1 + kMaxExtra, std::atoi(e))); // tuning hook
-        if (const char* e = std::getenv("ADELIE_HIP_PRELAUNCH_SWEEP")) prelaunch_sweep = std::atoi(e) != 0; // A/B hook
-        if (const char* e = std::getenv("ADELIE_HIP_GROUP_PANEL")) group_panel = std::atoi(e) != 0; // A/B hook
-        if (const char* e = std::getenv("ADELIE_HIP_LOOKAHEAD")) lookahead = std::atoi(e) != 0; // A/B hook
-        if (const char* e = std::getenv("ADELIE_HIP_LOOKAHEAD_MIN_BLOCKS")) la_min_blocks = std::max(1, std::atoi(e));
-        if (const char* e = std::getenv("ADELIE_HIP_PREBUILD")) prebuild_enabled = std::atoi(e) != 0;
-        if (const char* e = std::getenv("ADELIE_HIP_GROUP_ROT")) group_rot = std::atoi(e) != 0;
-        if (const char* e = std::getenv("ADELIE_HIP_FUSE_REDUCE")) fuse_reduce_opt = std::atoi(e) != 0;
-        fuse_reduce = fuse_reduce_opt && !multi() && fused_partials() <= 200;
-        if (const char* e = std::getenv("ADELIE_HIP_SIDE_WGS")) side_wgs = std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("ADELIE_HIP_SIDE_WGS_FROM")) side_wgs_from = std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("ADELIE_HIP_BATCH_BLOCKS")) batch_blocks = std::max(1, std::min(int(SyrkBatch::MAX), std::atoi(e)));
-        if (const char* e = std::getenv("ADELIE_HIP_SPECULATE")) spec_enabled = std::atoi(e) != 0;
-        if (const char* e = std::getenv("ADELIE_HIP_CROSS_BATCH")) cross_batch = std::max(1, std::min(int(GramBatch::MAX), std::atoi(e)));
-        if (const char* e = std::getenv("ADELIE_HIP_CROSS_INCR")) cross_incremental = std::atoi(e) != 0;
-        if (const char* e = std::getenv("ADELIE_HIP_STRIP_BUILDS")) strip_builds = std::atoi(e) != 0;
-        if (const char* e = std::getenv("ADELIE_HIP_UV_SIDE")) uv_side = std::atoi(e) != 0;
-        if (const char* e = std::getenv("ADELIE_HIP_LA_FUSED_OPEN")) la_fused_open = std::atoi(e) != 0;
-        if (const char* e = std::getenv("ADELIE_HIP_STRIP_MAX_M")) strip_max_m = std::max(1, std::min(128, std::atoi(e)));
-        if (const char* e = std::getenv("ADELIE_HIP_STRIP_WGS")) set_strip_workgroups(std::atoi(e));
-        if (const char* e = std::getenv("ADELIE_HIP_STRIP_LDS")) set_strip_lds(std::atoi(e) != 0);
-        if (const char* e = std::getenv("ADELIE_HIP_DEVICE_EIG")) device_eig = std::atoi(e) != 0;
-        if (const char* e = std::getenv("ADELIE_HIP_PASS_TABLES")) pass_tables_cached = std::atoi(e) != 0;
-        if (const char* e = std::getenv("ADELIE_HIP_OPEN_FROM_GRAD")) open_from_grad_opt = std::atoi(e) != 0;
-        if (const char* e = std::getenv("ADELIE_HIP_IRLS_REUSE")) irls_reuse = std::max(0.0, std::atof(e));
-        if (const char* e = std::getenv("ADELIE_HIP_PANEL_BSZ")) {
-            panel_bsz = std::atoi(e);
-            if (panel_bsz != 32 && panel_bsz != 64 && panel_bsz != 128) panel_bsz = 0;
-        }
+        if (hooks.lookahead >= 0) lookahead = hooks.lookahead != 0;
+        fuse_reduce = !multi() && fused_partials() <= 200;
+        if (hooks.speculate >= 0) spec_enabled = hooks.speculate != 0;
+        if (hooks.irls_reuse >= 0) irls_reuse = hooks.irls_reuse;
+        panel_bsz = hooks.panel_bsz;
         if (cov_mode) { // base state of the covariance method: no intercept, adev_tol = ddev_tol = 0 (state_gaussian_cov.hpp:118)
             engine_panel = false; // the panel engines work on the residual; the Gram engines on C = A[S, S] and its gradient
             glm_kind = ADELIE_HIP_GLM_GAUSSIAN;
@@ -4178,6 +4146,7 @@ struct Solver {
 };
 
 struct ResultBase {
+    int device = -1; // the device the solve ran on
     virtual ~ResultBase() {}
     virtual void sync_live() = 0;
     virtual int64_t size(int which) const = 0;
@@ -4380,15 +4349,15 @@ template <class T>
 void run(adelie_hip_design* X, const adelie_hip_grpnet_args* a, adelie_hip_result* res) {
     auto* r = new Result<T>();
     res->r = r; // owned by `res` from here on (the poll callbacks read the live state through it)
+    r->device = X->device;
     r->s.live = res;
-    static const bool staging_on = !(std::getenv("ADELIE_HIP_STAGING") && std::atoi(std::getenv("ADELIE_HIP_STAGING")) == 0);
-    if (staging_on) r->s.stage.init(size_t(8) << 20, X->stream);
-    Staging::Scope stage_scope(staging_on ? &r->s.stage : nullptr);
+    r->s.stage.init(size_t(8) << 20, X->stream);
+    Staging::Scope stage_scope(&r->s.stage);
     DeferredFrees::Scope deferred_scope(&r->s.deferred);
     Stopwatch sw_build;
     sw_build.start();
     r->s.build(X, a);
-    if (std::getenv("ADELIE_HIP_TRACE_ENQ")) std::fprintf(stderr, "[build] state set-up %.2f ms\n", sw_build.elapsed() * 1e3);
+    if (r->s.hooks.trace >= 2) std::fprintf(stderr, "[build] state set-up %.2f ms\n", sw_build.elapsed() * 1e3);
     Stopwatch sw;
     sw.start();
     struct BatchGuard { // registered for sweep batching exactly while the path runs
@@ -4416,7 +4385,7 @@ void run(adelie_hip_design* X, const adelie_hip_grpnet_args* a, adelie_hip_resul
         if (r->s.error.empty()) r->s.error = e.what();
     }
     r->s.total_time = sw.elapsed();
-    if (std::getenv("ADELIE_HIP_TRACE_ENQ")) std::fprintf(stderr, "[run] solve + finalize %.2f ms\n", r->s.total_time * 1e3);
+    if (r->s.hooks.trace >= 2) std::fprintf(stderr, "[run] solve + finalize %.2f ms\n", r->s.total_time * 1e3);
     r->s.live = nullptr;
 }
 
@@ -4480,6 +4449,7 @@ static int solve_entry(adelie_hip_design* X, const adelie_hip_grpnet_args* args,
     return 0;
 }
 int adelie_hip_result_destroy(adelie_hip_result* r) {
+    if (r && r->r && r->r->device >= 0) (void)hipSetDevice(r->r->device); // (its buffers and streams are parked per device)
     delete r;
     return 0;
 }

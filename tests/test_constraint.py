@@ -344,9 +344,7 @@ def test_oracle_constrained_singletons_inside_a_grouped_problem(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("family", ["gaussian", "binomial"])
-@pytest.mark.parametrize("rot", ["1", "0"])
-def test_hip_constrained_singletons_inside_a_grouped_problem(hip, oracle, monkeypatch, family, rot):
-    monkeypatch.setenv("ADELIE_HIP_GROUP_ROT", rot)
+def test_hip_constrained_singletons_inside_a_grouped_problem(hip, oracle, family):
     n, p = 500, 260
     d = make_gaussian(n, p, seed=12, sparsity=0.8)
     X = d["X"]

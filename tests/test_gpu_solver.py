@@ -196,17 +196,16 @@ def test_caller_state_untouched_and_result_surface(hip):
     assert st.screen_is_active.dtype == bool and st.active_set.shape == (30,)
 
 
-@pytest.mark.parametrize("engine", ["panel", "panel-seq", "gram"])
+@pytest.mark.parametrize("engine", ["panel", "panel-seq"])
 @pytest.mark.parametrize("n,p,alpha", [(400, 300, 1.0), (1500, 700, 0.6), (1027, 520, 1.0)])
 def test_block_cd_passes_match_oracle(hip, oracle, monkeypatch, n, p, alpha, engine):
     """Forces the multi-CU block Gauss-Seidel passes at sizes the oracle checks in seconds: several 128-visit blocks per
     pass, ragged last block, active-set growth inside screen passes, n not a multiple of the row slice.
     engine "panel": residual-based blocks with cached diagonal Gram blocks and the look-ahead launches (solve of block j
     fused with the step for block j+1, cross-block correction; kernels_cd_panel.hip, the default);
-    engine "panel-seq": the same without look-ahead (step -> reduce -> solve strictly in sequence);
-    engine "gram": full screen-set Gram kept current (kernels_cd_block.hip)."""
+    engine "panel-seq": the same without look-ahead (step -> reduce -> solve strictly in sequence, the form IRLS and constrained
+    problems run).  (The full-Gram block engines of kernels_cd_block*.hip are the covariance method's pin solver: tests/test_cov.py.)"""
     monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
-    monkeypatch.setenv("ADELIE_HIP_CD_ENGINE", "gram" if engine == "gram" else "panel")
     monkeypatch.setenv("ADELIE_HIP_LOOKAHEAD", "0" if engine == "panel-seq" else "1")
     d = make_gaussian(n, p, seed=11, sparsity=0.5, weights=True)
     # beta is resolved to ~sqrt(tol) by the stopping rule; 1e-14 makes two trajectories that differ in the order of
@@ -225,14 +224,13 @@ def test_block_cd_passes_match_oracle(hip, oracle, monkeypatch, n, p, alpha, eng
     assert e2.error.startswith("adelie_core solver: max coordinate descents")
 
 
-@pytest.mark.parametrize("engine", ["panel", "panel-seq", "gram"])
+@pytest.mark.parametrize("engine", ["panel", "panel-seq"])
 @pytest.mark.parametrize("alpha", [1.0, 0.5])
 def test_group_block_cd_passes_match_oracle(hip, oracle, monkeypatch, alpha, engine):
     """Forces the multi-CU block passes for grouped problems (kernels_cd_block_group.hip): mixed group sizes
     (1..40), several blocks per pass, groups activated inside screen passes.  engine "panel": residual-based blocks with
-    cached diagonal Gram blocks, eigenbases from those blocks (the default); "gram": full screen-set Gram kept current."""
+    cached diagonal Gram blocks, eigenbases from those blocks (the default); "panel-seq": without look-ahead."""
     monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
-    monkeypatch.setenv("ADELIE_HIP_GROUP_PANEL", "0" if engine == "gram" else "1")
     monkeypatch.setenv("ADELIE_HIP_LOOKAHEAD", "0" if engine == "panel-seq" else "1")
     rng = np.random.RandomState(7)
     n, p = 1200, 640
@@ -250,7 +248,7 @@ def test_group_block_cd_passes_match_oracle(hip, oracle, monkeypatch, alpha, eng
     assert_same_path(a, b, 1e-6)
     assert a.active_set_size > 30
     assert abs(a.counters["n_updates"] - b.counters["n_updates"]) <= 0.02 * b.counters["n_updates"] + 5
-    assert (a.counters["n_panel_blocks"] > 0) == (engine != "gram")
+    assert a.counters["n_panel_blocks"] > 0
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -278,21 +276,6 @@ def test_panel_engine_binomial_snp(hip, oracle, monkeypatch, dtype):
     assert a.error == "" and b.error == ""
     assert a.counters["n_panel_blocks"] > 0 and a.counters["n_panel_grams"] > 0
     assert_same_path(a, b, 1e-6 if dtype == np.float64 else 5e-3)
-
-
-def test_panel_engine_matches_gram_engine(hip, monkeypatch):
-    """Both engines run the same Gauss-Seidel sequence: same path to rounding, same number of coordinate updates."""
-    d = make_gaussian(3000, 1500, seed=21, sparsity=0.7)
-    kw = dict(early_exit=False, lmda_path_size=30, min_ratio=1e-2, tol=1e-14)
-    out = {}
-    for eng in ["panel", "gram"]:
-        monkeypatch.setenv("ADELIE_HIP_CD_ENGINE", eng)
-        out[eng] = ad.grpnet(ad.matrix.dense(d["X"]), ad.glm.gaussian(d["y"]), **kw)
-    a, b = out["panel"], out["gram"]
-    assert a.counters["n_panel_blocks"] > 0 and b.counters["n_panel_blocks"] == 0
-    assert_same_path(a, b, 1e-7)
-    assert abs(a.counters["n_updates"] - b.counters["n_updates"]) <= 0.01 * b.counters["n_updates"]
-    np.testing.assert_allclose(a.resid, b.resid, atol=1e-9)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -387,17 +370,12 @@ def test_exit_cond_on_panel_engine(hip, monkeypatch):
     assert st.error == "" and len(st.lmdas) == 9 and st.counters["n_panel_blocks"] > 0
 
 
-@pytest.mark.parametrize("hook,values", [("ADELIE_HIP_BATCH_BLOCKS", ["1", "3", "16"]), ("ADELIE_HIP_PREBUILD", ["0", "1"]),
-                                         ("ADELIE_HIP_GROUP_ROT", ["0", "1"]), ("ADELIE_HIP_FUSE_REDUCE", ["0", "1"]),
-                                         ("ADELIE_HIP_SIDE_WGS", ["0", "24"]), ("ADELIE_HIP_CROSS_BATCH", ["1", "3", "16"]),
-                                         ("ADELIE_HIP_SPECULATE", ["0", "1"]), ("ADELIE_HIP_OPEN_FROM_GRAD", ["0", "1"]),
-                                         ("ADELIE_HIP_PASS_TABLES", ["0", "1"]), ("ADELIE_HIP_SIDE_GRAMS", ["0", "1"]),
-                                         ("ADELIE_HIP_DEVICE_SCREEN", ["0", "1"])])
-def test_round2_engine_hooks_do_not_change_results(hip, oracle, monkeypatch, hook, values):
-    """The build / solve variants added in round 2 (batched diagonal-block builds, IRLS screen-block prebuild, group solve in
-    eigen-coordinates, reduce fused into the solve, confined side builds) are scheduling / association changes only: every
-    setting gives the oracle's path on a lasso, a grouped and a binomial problem whose screen sets span several blocks of
-    different tile classes."""
+@pytest.mark.parametrize("hook,values", [("ADELIE_HIP_SPECULATE", ["0", "1"]), ("ADELIE_HIP_LOOKAHEAD", ["0", "1"]),
+                                         ("ADELIE_HIP_IRLS_REUSE", ["0", "0.01", "0.2"])])
+def test_engine_hooks_do_not_change_results(hip, oracle, monkeypatch, hook, values):
+    """The hooks that survive (common.hpp::Hooks) are scheduling changes (speculative pass, look-ahead) or a bounded change of the
+    iterate sequence (IRLS block reuse): every setting gives the oracle's path on a lasso, a grouped and a binomial
+    problem whose screen sets span several blocks of different tile classes."""
     monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
     rng = np.random.RandomState(11)
     n, p = 700, 330
@@ -421,29 +399,6 @@ def test_round2_engine_hooks_do_not_change_results(hip, oracle, monkeypatch, hoo
             # pass apart, which is worth ~1e-7 in beta at this tol; a wrong block shows up at 1e-3 and above
             assert np.abs(st.betas.toarray() - ref.betas.toarray()).max() < 1e-6, (hook, v)
             assert np.abs(st.intercepts - ref.intercepts).max() < 1e-6
-
-
-def test_pass_tables_kept_across_passes_are_bit_identical(hip, monkeypatch):
-    """ADELIE_HIP_PASS_TABLES: the partition of a visiting list, the design columns of the active list and the group layout
-    descriptors are kept across passes while the list did not grow — pure caching, so the paths are bit-identical (lasso and
-    grouped, with KKT failures forcing re-screens of the same lambda)."""
-    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
-    d = make_gaussian(900, 700, seed=31, sparsity=0.6)
-    X = ad.matrix.dense(d["X"])
-    for kw in [dict(early_exit=False, lmda_path_size=25, min_ratio=0.02, tol=1e-10),
-               dict(groups=np.arange(0, 700, 7), alpha=0.5, early_exit=False, lmda_path_size=25, min_ratio=0.02, tol=1e-10),
-               dict(groups=np.arange(0, 700, 7), alpha=0.8, early_exit=False, lmda_path_size=25, min_ratio=0.02, tol=1e-10,
-                    screen_rule="strong")]:
-        runs = []
-        for v in ("0", "1"):
-            monkeypatch.setenv("ADELIE_HIP_PASS_TABLES", v)
-            runs.append(ad.grpnet(X, ad.glm.gaussian(d["y"]), progress_bar=False, **kw))
-        a, b = runs
-        assert a.error == "" and b.error == "" and b.counters["n_panel_blocks"] > 0
-        assert np.array_equal(a.betas.toarray(), b.betas.toarray()) and np.array_equal(a.intercepts, b.intercepts)
-        assert np.array_equal(a.resid, b.resid) and np.array_equal(a.grad, b.grad) and list(a.screen_set) == list(b.screen_set)
-        for k in ("n_cd_passes_active", "n_cd_passes_screen", "n_updates", "n_panel_blocks"):
-            assert a.counters[k] == b.counters[k], k
 
 
 @pytest.mark.gpu
@@ -524,3 +479,36 @@ def test_speculative_pass_group_engine_and_short_passes(hip, monkeypatch, kind):
     assert np.array_equal(a.resid, b.resid) and np.array_equal(a.devs, b.devs)
     for k in ("n_cd_passes_active", "n_cd_passes_screen", "n_updates", "n_panel_blocks", "n_panel_cols"):
         assert a.counters[k] == b.counters[k], k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["binomial", "poisson"])
+def test_irls_block_reuse_against_rebuild_every_iteration(hip, monkeypatch, family):
+    """DESIGN 4, third deliberate deviation: with ADELIE_HIP_IRLS_REUSE=theta a diagonal block built under earlier IRLS weights
+    stays in use while every weight moved by at most theta; the fixed point of the passes is unchanged, the iterates inside a
+    pass move by O(theta).  theta = 0 (rebuild per iteration, the reference's arithmetic) against the default on a problem with
+    near-saturated working weights (large linear predictor: binomial weights down to 1e-9, poisson means up to e^9)."""
+    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    rng = np.random.RandomState(17)
+    n, p = 900, 300
+    X = np.asfortranarray(rng.normal(size=(n, p)))
+    beta = np.zeros(p)
+    beta[:6] = [4.0, -3.0, 2.5, 2.0, -2.0, 1.5] if family == "binomial" else [0.9, -0.8, 0.7, 0.6, -0.5, 0.4]
+    eta = X @ beta
+    if family == "binomial":
+        y = (rng.uniform(size=n) < 1 / (1 + np.exp(-eta))).astype(float)
+        mk = lambda: ad.glm.binomial(y)
+    else:
+        y = rng.poisson(np.exp(np.clip(eta, None, 9.0))).astype(float)
+        mk = lambda: ad.glm.poisson(y)
+    kw = dict(early_exit=False, lmda_path_size=15, min_ratio=0.02, tol=1e-12, irls_tol=1e-11, progress_bar=False)
+    out = {}
+    for theta in ("0", "0.01"):
+        monkeypatch.setenv("ADELIE_HIP_IRLS_REUSE", theta)
+        out[theta] = ad.grpnet(ad.matrix.dense(X), mk(), **kw)
+    a, b = out["0"], out["0.01"]
+    assert a.error == "" and b.error == "" and len(a.lmdas) == len(b.lmdas) == 15
+    assert a.counters["n_panel_blocks"] > 0
+    assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-7
+    assert np.abs(a.intercepts - b.intercepts).max() < 1e-7
+    assert sorted(a.screen_set.tolist()) == sorted(b.screen_set.tolist())

@@ -13,7 +13,7 @@ pids=()
 for f in kernels_append kernels_eig kernels_strip kernels_cov kernels_sweep kernels_gram kernels_cd kernels_cd_lasso kernels_cd_block kernels_cd_block_group kernels_cd_panel kernels_multi kernels_glm design solver; do
   src="$HERE/$f.hip"; obj="$OBJ/$f.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/kernels.hpp" -nt "$obj" ] || [ "$HERE/common.hpp" -nt "$obj" ] \
-     || [ "$HERE/accessors.hpp" -nt "$obj" ] || [ "$HERE/wavered.hpp" -nt "$obj" ] || [ "$HERE/gram_common.hpp" -nt "$obj" ] || [ "$HERE/blk_solve_body.hpp" -nt "$obj" ] || [ "$HERE/grp_solve_body.hpp" -nt "$obj" ] || [ "$HERE/../../include/adelie_hip.h" -nt "$obj" ]; then
+     || [ "$HERE/accessors.hpp" -nt "$obj" ] || [ "$HERE/wavered.hpp" -nt "$obj" ] || [ "$HERE/gram_common.hpp" -nt "$obj" ] || [ "$HERE/blk_solve_body.hpp" -nt "$obj" ] || [ "$HERE/grp_solve_body.hpp" -nt "$obj" ] || { [ "$f" = solver ] && [ -n "$(find "$HERE" -name "solver_*.hpp" -newer "$obj" 2>/dev/null)" ]; } || [ "$HERE/../../include/adelie_hip.h" -nt "$obj" ]; then
     timeout 600 $HIPCC $FLAGS -c "$src" -o "$obj" &
     pids+=($!)
   fi

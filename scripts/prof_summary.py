@@ -38,6 +38,25 @@ def stats(db):
         print(f"{k:100s} grid=({r[1]},{r[2]},{r[3]}) wg={r[4]} lds={r[5]} vgpr={r[6]} agpr={r[7]} sgpr={r[8]} scratch={r[9]}")
 
 
+def by_grid(db, patterns=("sweep_kernel", "multi_sweep")):
+    """Launches of one template differ by orders of magnitude in work (a full-design sweep and a 200-column one share a name):
+    per (kernel, grid) class the call count and average duration, so that a per-launch roofline figure can be recomputed from
+    this file for the class it was quoted on (config 4's sweep could not be)."""
+    c = sqlite3.connect(db)
+    print("\n# sweep-type kernels by launch geometry (grid in threads; the largest grid of a template is the full design)")
+    print(f"{'kernel':100s} {'grid':>22s} {'calls':>7s} {'avg_us':>10s} {'total_ms':>10s}")
+    cond = " or ".join(f"name like '%{p}%'" for p in patterns)
+    q = (f"select name, grid_x, grid_y, grid_z, count(*), avg(end - start), sum(end - start) from kernels where {cond} "
+         "group by name, grid_x, grid_y, grid_z order by name, sum(end - start) desc")
+    shown = {}
+    for name, gx, gy, gz, n, av, tot in c.execute(q):
+        k = short(name)
+        shown[k] = shown.get(k, 0) + 1
+        if shown[k] > 6:
+            continue
+        print(f"{k:100s} {f'({gx},{gy},{gz})':>22s} {n:7d} {av / 1e3:10.2f} {tot / 1e6:10.2f}")
+
+
 def pmc(db):
     c = sqlite3.connect(db)
     print(f"\n# PMC pass ({db}): per-dispatch counter, averaged per kernel (value unit as reported by rocprofv3: KB)")
@@ -51,5 +70,9 @@ def pmc(db):
 
 if __name__ == "__main__":
     stats(sys.argv[1])
+    try:
+        by_grid(sys.argv[1])
+    except sqlite3.Error as e:  # (older rocpd schemas)
+        print(f"# by_grid: {e}")
     for db in sys.argv[2:]:
         pmc(db)

@@ -427,10 +427,10 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             // newton_solver (bcd/unconstrained/newton.hpp:35-142): v = gk_t, L = A
             const T gk2 = on ? gk_r * gk_r : T(0);
             const T nrm2 = group_sum(gk2, q);
-#ifndef AHIP_GRP_START_LB
-            const T gb1 = on ? gk2 * (A_r + l2p) : T(0);
-            const T sb1 = group_sum(gb1, q); // (independent of the line above: the reductions overlap)
-#endif
+            // (double precision only, see below; the second reduction is independent of the first: they overlap)
+            constexpr bool kMeanStart = sizeof(T) == 8;
+            T sb1 = T(0);
+            if constexpr (kMeanStart) sb1 = group_sum(on ? gk2 * (A_r + l2p) : T(0), q);
             const T nrm = sqrt(nrm2);
             T akt_r = T(0);
             RP_MARK(1)
@@ -448,9 +448,7 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
                 // left like from 0, only from much closer — the same root to newton_tol in fewer of the (strictly
                 // sequential) evaluations; an isotropic block (all b_i equal) starts AT its root.  Same stopping test, same
                 // error when newton_tol is unreachable.
-#ifdef AHIP_GRP_START_LB
                 h = (nrm - l1p) * gbmx[k]; // (1 / max_i b_i from the prologue; 0 when there is none)
-#else
                 // Round 4: start at (||v|| - l1) / b_eff with the v^2-weighted mean  b_eff = sum v_i^2 b_i / sum v_i^2  instead of
                 // the largest b_i.  Exact for an isotropic block like h_lb, and second-order accurate in the spread of the b_i
                 // (h_lb is first-order): on groups of 10 columns of a random design (spread ~ sqrt(q / n) = 1 %) the start is
@@ -459,14 +457,16 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
                 // 586 ms: its extra reduction costs more than it saves).  It may lie
                 // to the RIGHT of the root; the iteration below is safe from either side (one step brings it to the left, from
                 // where it is monotone; h is clamped at 0 as in the reference).  Same stopping test, same result to newton_tol.
-                if (sb1 > T(0)) {
-                    const T rb = nrm2 * fast_rcp(sb1); // 1 / b_eff (a start only has to be close: the hardware approximation, off
-                                                       // the IEEE division's dependent chain: 581 -> 569 ms on config 3)
-                    h = (nrm - l1p) * rb;
-                } else {
-                    h = T(0);
+                // Double precision only: in single precision newton_tol has to be loose (1e-5) and a start that may already
+                // pass it from the right accepts a different point of the tolerance interval than the reference's approach from
+                // the left — on constrained problems enough to move multipliers (tests/test_constraint.py, f32).
+                if constexpr (kMeanStart) {
+                    if (sb1 > T(0)) {
+                        const T rb = nrm2 * fast_rcp(sb1); // 1 / b_eff (a start only has to be close: the hardware approximation,
+                                                           // off the IEEE division's dependent chain: 581 -> 569 ms on config 3)
+                        h = (nrm - l1p) * rb;
+                    }
                 }
-#endif
                 auto step = [&](T hh) {
                     T t = 0, sx = 0;
                     if (on) {
@@ -842,7 +842,7 @@ __device__ __forceinline__ void grp_solve_body(const CdGrpBlkParams<T>& p, int j
             const T gk = fma(bi, A, gcur);                       // pin_naive:85-89
             const T v = fabs(gk) - l1p;                          // pin_base:181-195
             T ak = (v > T(0)) ? copysign(v, gk) / (A + l2p) : T(0);
-            if (NAIVE && p.clo) ak = grp_clip_1d(p, vmap[o], ak, gk, l1p, A + l2p, lane); // constraint->solve, pin_naive:419-437
+            if (p.clo) ak = grp_clip_1d(p, vmap[o], ak, gk, l1p, A + l2p, lane); // constraint->solve, pin_naive:419-437 / pin_cov:723-741
             if (ak != bi) {                                      // pin_naive:97
                 changed = true;
                 const T d = ak - bi;

@@ -348,6 +348,8 @@ struct GrpRotArgs {
 };
 template <class T> void launch_grp_block_rotate(T* Dptr, const T* Dsrc, const T* V, const GrpRotArgs& a, T* scratch, hipStream_t s);
 template <class T> void launch_cd_group_block_pass(const CdGrpBlkParams<T>& p, hipStream_t s);
+template <class T> void launch_cd_group_block_range(const CdGrpBlkParams<T>& p, int j0, int j1, hipStream_t s);
+template <class T> void launch_cd_group_block_update(const CdGrpBlkParams<T>& p, int j, hipStream_t s);
 // the visits of block j against p.gblk / p.Dptr (one workgroup)
 template <class T> void launch_cd_group_panel_solve(const CdGrpBlkParams<T>& p, int j, hipStream_t s);
 int cd_block_size();

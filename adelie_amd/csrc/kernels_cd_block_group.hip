@@ -85,6 +85,28 @@ void launch_cd_group_block_pass(const CdGrpBlkParams<T>& p, hipStream_t s) {
     }
 }
 
+// Blocks [j0, j1) of a pass (a pass whose list holds groups that are visited on the host is enqueued in pieces): the first piece
+// of a pass gathers block 0's diagonal block itself, every update kernel gathers the one of the block behind it.
+template <class T>
+void launch_cd_group_block_range(const CdGrpBlkParams<T>& p, int j0, int j1, hipStream_t s) {
+    if (j1 <= j0) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(grp_solve_kernel<T, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(grp_solve_lds_total<T>()));
+    const unsigned ug = unsigned((p.nv + 63) / 64);
+    const size_t lds = grp_solve_lds_total<T>();
+    if (j0 == 0) hipLaunchKernelGGL((grp_gather_kernel<T>), dim3(64), dim3(256), 0, s, p, 0);
+    for (int j = j0; j < j1; ++j) {
+        hipLaunchKernelGGL((grp_solve_kernel<T, false>), dim3(1), dim3(256), lds, s, p, j);
+        hipLaunchKernelGGL((grp_update_kernel<T>), dim3(ug), dim3(256), 0, s, p, j);
+    }
+}
+// the gradient update (and the gather of block j + 1) behind a block whose changes the HOST left in p.didx / p.dlt / st->nz
+template <class T>
+void launch_cd_group_block_update(const CdGrpBlkParams<T>& p, int j, hipStream_t s) {
+    const unsigned ug = unsigned((p.nv + 63) / 64);
+    hipLaunchKernelGGL((grp_update_kernel<T>), dim3(ug), dim3(256), 0, s, p, j);
+}
+
 // Layout descriptors of all blocks of a pass (CdGrpBlkParams::desc, GDESC_*): what block_layout derives per solve, once per
 // pass and for all blocks in parallel.  One 128-thread workgroup per block.
 template <class T>
@@ -317,5 +339,9 @@ template void launch_cd_group_panel_solve<float>(const CdGrpBlkParams<float>&, i
 
 template void launch_cd_group_block_pass<double>(const CdGrpBlkParams<double>&, hipStream_t);
 template void launch_cd_group_block_pass<float>(const CdGrpBlkParams<float>&, hipStream_t);
+template void launch_cd_group_block_range<double>(const CdGrpBlkParams<double>&, int, int, hipStream_t);
+template void launch_cd_group_block_range<float>(const CdGrpBlkParams<float>&, int, int, hipStream_t);
+template void launch_cd_group_block_update<double>(const CdGrpBlkParams<double>&, int, hipStream_t);
+template void launch_cd_group_block_update<float>(const CdGrpBlkParams<float>&, int, hipStream_t);
 
 } // namespace ahip

@@ -562,6 +562,7 @@
         bp.max_active_size = cp.max_active_size;
         bp.V = cp.V; bp.voff = cp.voff; bp.spen = cp.spen; bp.sbegin = cp.sbegin; bp.ssize = cp.ssize;
         bp.Dbuf = d_Dbuf.p; bp.dlt = d_dlt.p; bp.didx = d_didx.p; bp.st = d_blk.p;
+        if (cons_on) { bp.clo = d_clo.p; bp.chi = d_chi.p; bp.cmu = d_cmu.p; } // one-coefficient closed forms (grp_clip_1d)
         int64_t iters = 0;
         int status = CD_OK;
         int asz = sc.active_size;
@@ -578,7 +579,20 @@
             bp.nblk = nblk;
             bp.mark = screen_pass ? 1 : 0;
             t_cd.begin(st);
-            launch_cd_group_block_pass<T>(bp, st);
+            if (!cons_host) {
+                launch_cd_group_block_pass<T>(bp, st);
+            } else { // blocks that are one group with a constraint object on the caller's side are visited on the host
+                int j0 = 0;
+                for (int j = 0; j < nblk; ++j) {
+                    const idx ss0 = screen_pass ? idx(part_host[size_t(j)]) : act_host[size_t(part_host[size_t(j)])];
+                    if (!(part_host[size_t(j) + 1] - part_host[size_t(j)] == 1 && host_cons(screen_set[ss0]))) continue;
+                    launch_cd_group_block_range<T>(bp, j0, j, st);
+                    (void)host_group_visit(cp, ss0, screen_pass, j == 0, true);
+                    launch_cd_group_block_update<T>(bp, j, st);
+                    j0 = j + 1;
+                }
+                launch_cd_group_block_range<T>(bp, j0, nblk, st);
+            }
             t_cd.end(st);
             d_blk.download(&bs, 1, st);
             sync();
@@ -629,7 +643,10 @@
     // (d_gblk), its coefficients, variances and eigenbasis are read back, the object's solve runs through the callback, and the
     // changes go out the way a device solve leaves them (d_beta, the compacted (column, delta) list of the next step's
     // residual update, the pass state in d_blk).  Returns the pass state after the visit.
-    CdBlkState<T> host_group_visit(const CdParams<T>& cp, idx ss, bool mark, bool first_of_pass) {
+    // `gram`: the covariance method's engine — the group's gradient is its slice of the screen gradient d_g (kept current by the
+    // Gram updates), there is no residual and no intercept, and the changes go out as (screen value, delta) pairs for
+    // grp_update_kernel (solver_gaussian_pin_cov.hpp:287-355) instead of (design column, delta) pairs for the next panel step.
+    CdBlkState<T> host_group_visit(const CdParams<T>& cp, idx ss, bool mark, bool first_of_pass, bool gram = false) {
         const idx g = screen_set[ss], q = group_sizes[g], b = screen_begins[ss];
         const size_t uq = static_cast<size_t>(q);
         const bool trace_hv = hooks.trace >= 1;
@@ -638,7 +655,8 @@
         std::vector<T> gk(uq), ak(uq), Ak(uq), Vk(uq * uq, T(1));
         CdBlkState<T> bs{};
         int8_t was_active = 0;
-        d_gblk.download(gk.data(), size_t(q), st);
+        if (gram) d_g.download(gk.data(), size_t(q), st, size_t(b));
+        else d_gblk.download(gk.data(), size_t(q), st);
         d_beta.download(ak.data(), size_t(q), st, size_t(b));
         d_vars.download(Ak.data(), size_t(q), st, size_t(b));
         if (q > 1) d_V.download(Vk.data(), size_t(q) * q, st, size_t(h_voff[size_t(ss)]));
@@ -684,14 +702,15 @@
                 for (idx j = 0; j < q; ++j) acc += x[size_t(j)] * double(Vk[size_t(i + j * q)]);
                 a_new[size_t(i)] = T(acc);
                 dlt[size_t(i)] = a_new[size_t(i)] - ak[size_t(i)];
-                dcol[size_t(i)] = int32_t(groups[g] + i);
-                rsum += double(screen_X_means[size_t(b + i)]) * double(ak[size_t(i)] - a_new[size_t(i)]);
+                dcol[size_t(i)] = gram ? int32_t(b + i) : int32_t(groups[g] + i);
+                if (!gram) rsum += double(screen_X_means[size_t(b + i)]) * double(ak[size_t(i)] - a_new[size_t(i)]);
             }
             bs.resid_sum += T(rsum);
             bs.n_updates += 1;
             bs.nz = int32_t(q);
             d_beta.upload(a_new.data(), size_t(q), st, size_t(b));
-            d_dcolblk.upload(dcol.data(), size_t(q), st);
+            if (gram) d_didx.upload(dcol.data(), size_t(q), st);
+            else d_dcolblk.upload(dcol.data(), size_t(q), st);
             d_dlt.upload(dlt.data(), size_t(q), st);
             if (mark && !was_active) { // add_active_set, pin_naive:294-304
                 if (size_t(bs.active_size) >= max_active_size) {

@@ -433,7 +433,6 @@
             bool any = false;
             for (idx g = 0; g < G; ++g) any = any || a->constraint_kind[g] != 0;
             if (any) {
-                if (cov_mode) throw make_core_error("constraints are not implemented for the covariance method.");
                 if (!all_scalar && max_gs > idx(cd_block_size()))
                     throw make_core_error("constraints are not implemented for problems with groups of more than " +
                                           std::to_string(cd_block_size()) + " coefficients.");
@@ -498,8 +497,14 @@
                 }
                 // the clipped coordinate update lives in the panel solve (blk_solve_body<.., CONS>): that engine from the first
                 // screened coefficient on, in its sequential form
-                engine_panel = true;
-                group_panel = true;
+                engine_panel = !cov_mode; // (covariance method: the Gram group engine carries clips and host visits,
+                group_panel = true;       //  solver_gaussian_pin_cov.hpp:287-355,723-763)
+                if (cov_mode) {
+                    if (max_gs > idx(cd_block_size()))
+                        throw make_core_error("constraints are not implemented for problems with groups of more than " +
+                                              std::to_string(cd_block_size()) + " coefficients.");
+                    all_scalar = false;
+                }
                 cd_block_min_nv = 1;
                 lookahead = false;
                 d_clo_g.reserve(G); d_chi_g.reserve(G); d_mu_g.reserve(G);

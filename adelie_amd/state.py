@@ -228,7 +228,6 @@ class base:
         """Hook of the multi-response states: splits the per-class intercepts off the coefficient rows."""
         return betas, intercepts
 
-    _supports_constraints = True
 
     def _constraint_list(self):
         """The (G,) list of constraint objects, or None when there is none (reference ``state.py:24-45`` render_constraints:
@@ -494,31 +493,34 @@ class base:
         return _abi.ConstraintCallbacks(None, _abi.CONS_SOLVE_FN(solve), _abi.CONS_GRADIENT_FN(gradient),
                                         _abi.CONS_SOLVE_ZERO_FN(solve_zero), _abi.CONS_DUAL_FN(dual))
 
+    def _check_constraints(self, G):
+        """The constructor checks of the reference on ``constraints`` (``state_base.ipp:39-49`` and the object sizes)."""
+        cons = self._constraint_list()
+        if cons is None:
+            return
+        if len(cons) != G:
+            raise RuntimeError("adelie_core: constraints must be (G,) where groups is (G,).")
+        seen = set()
+        for c, q in zip(cons, np.asarray(self.group_sizes)):
+            if c is None:
+                continue
+            if not isinstance(c, _constraint.ConstraintBase):
+                raise RuntimeError("adelie_core: constraints must be instances of adelie_amd.constraint.ConstraintBase "
+                                   "(box / lower / upper / one_sided, or a subclass that provides solve / gradient / "
+                                   "solve_zero).")
+            if id(c) in seen:
+                raise RuntimeError("adelie_core: constraints must contain distinct objects or nullptr.")
+            seen.add(id(c))
+            if c.primal_size != q:
+                raise RuntimeError("adelie_core: constraint of a group must have the group's size.")
+
     def _check_shapes(self):
         G = len(self.groups)
         if len(self.group_sizes) != G:
             raise RuntimeError("adelie_core: group_sizes must be (G,) where groups is (G,).")
         if len(self.penalty) != G:
             raise RuntimeError("adelie_core: penalty must be (G,) where groups is (G,).")
-        cons = self._constraint_list()
-        if cons is not None:
-            if not self._supports_constraints:
-                raise NotImplementedError("adelie_amd: constraints are not implemented for this state (multi-response / covariance method).")
-            if len(cons) != G:
-                raise RuntimeError("adelie_core: constraints must be (G,) where groups is (G,).")
-            seen = set()
-            for c, q in zip(cons, np.asarray(self.group_sizes)):
-                if c is None:
-                    continue
-                if not isinstance(c, _constraint.ConstraintBase):
-                    raise RuntimeError("adelie_core: constraints must be instances of adelie_amd.constraint.ConstraintBase "
-                                       "(box / lower / upper / one_sided, or a subclass that provides solve / gradient / "
-                                       "solve_zero).")
-                if id(c) in seen:
-                    raise RuntimeError("adelie_core: constraints must contain distinct objects or nullptr.")
-                seen.add(id(c))
-                if c.primal_size != q:
-                    raise RuntimeError("adelie_core: constraint of a group must have the group's size.")
+        self._check_constraints(G)
         n, p = self._X.rows(), self._X.cols()
         if len(self.resid) != n:
             raise RuntimeError("adelie_core: resid must be (n,) where X is (n, p).")
@@ -998,7 +1000,6 @@ class gaussian_cov_base(base):
     """Gaussian, covariance method state (reference ``state.py:1128-1418``; core ``state_gaussian_cov.hpp:40-145``)."""
 
     _solve_entry = "gaussian_cov_solve"
-    _supports_constraints = False
 
     @staticmethod
     def _progress(devs):
@@ -1104,8 +1105,7 @@ def gaussian_cov(
         raise RuntimeError("adelie_core: group_sizes must be (G,) where groups is (G,).")
     if len(s.penalty) != G:
         raise RuntimeError("adelie_core: penalty must be (G,) where groups is (G,).")
-    if s.constraints is not None and any(c is not None for c in s.constraints):
-        raise NotImplementedError("adelie_amd: per-group constraints are not implemented (pass None).")
+    s._check_constraints(G)
     if len(s.v) != p:
         raise RuntimeError("adelie_core: v must be (p,) where A is (p, p).")
     if len(s.grad) != p:

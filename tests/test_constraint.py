@@ -214,8 +214,8 @@ def test_constraint_errors(oracle):
     # multi-response fits take the list as the reference does (a group of a K = 2 fit has two coefficients)
     st = ad.grpnet(X, ad.glm.multigaussian(y2), constraints=[two] + [None] * 7, lmda_path_size=4, progress_bar=False)
     assert st.error == "" and st.duals.shape == (4, 2)
-    with pytest.raises(NotImplementedError, match="constraints are not implemented"):
-        ad.solver.gaussian_cov(oracle.cov_dense(np.eye(8)), np.ones(8), constraints=[c] + [None] * 7, progress_bar=False)
+    with pytest.raises(RuntimeError, match="distinct objects"):   # the covariance method checks the list the same way
+        ad.solver.gaussian_cov(oracle.cov_dense(np.eye(8)), np.ones(8), constraints=[c, c] + [None] * 6, progress_bar=False)
 
 
 def test_cv_grpnet_passes_constraints_to_every_fold(oracle):

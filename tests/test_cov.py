@@ -301,3 +301,85 @@ def test_block_diag_and_sparse_cov_matrices(hip):
     assert np.array_equal(a.betas.toarray(), b.betas.toarray())
     with pytest.raises(NotImplementedError):
         ad.matrix.block_diag(blocks, method="naive")
+
+
+# ---- per-group constraints with the covariance method (solver_gaussian_pin_cov.hpp:287-355,723-763) -------------------------
+def _cov_constrained_problem(seed, n=400, p=48, gsz=3, tight=None):
+    from adelie_amd import constraint
+
+    rng = np.random.RandomState(seed)
+    X = rng.randn(n, p)
+    y = X[:, :8] @ rng.randn(8) + rng.randn(n)
+    Xc, yc = X - X.mean(0), y - y.mean()
+    A, v = Xc.T @ Xc / n, Xc.T @ yc / n
+    groups = np.arange(0, p, gsz)
+    G = len(groups)
+    spec = [None] * G
+    for g in rng.choice(G, 5, replace=False):
+        spec[g] = ("box", -rng.uniform(0.01, 0.1, gsz), rng.uniform(0.01, 0.1, gsz))
+    free = [g for g in range(G) if spec[g] is None]
+    for g in rng.choice(free, 2, replace=False):
+        spec[g] = ("linear", rng.randn(2, gsz), -rng.uniform(0.01, 0.05, 2), rng.uniform(0.01, 0.05, 2))
+
+    def make():
+        out = []
+        for s in spec:
+            if s is None:
+                out.append(None)
+            elif s[0] == "box":
+                out.append(constraint.box(s[1], s[2], configs=tight))
+            else:
+                out.append(constraint.linear(s[1], s[2], s[3], configs=({**tight, "nnls_tol": 1e-12} if tight else None)))
+        return out
+    return np.asfortranarray(X), y, A, v, groups, make
+
+
+def test_oracle_cov_with_constraints_equals_naive(oracle):
+    """The covariance method with constraint objects against the naive method on the same (centred, 1/n-weighted) problem and
+    lambdas: same coefficients and multipliers (the reference's test_gaussian_cov idea, tests/test_solver.py:978-1040, with its
+    constraints list non-empty)."""
+    tight = {"tol": 1e-13, "pinball_tol": 1e-12, "max_iters": 1000}
+    X, y, A, v, groups, make = _cov_constrained_problem(3, tight=tight)
+    kw = dict(groups=groups, alpha=0.8, tol=1e-13, early_exit=False, progress_bar=False)
+    sc = ad.gaussian_cov(oracle.cov_dense(A), v, constraints=make(), lmda_path_size=12, min_ratio=0.05, **kw)
+    sn = ad.grpnet(oracle.dense(X), ad.glm.gaussian(y), constraints=make(), lmda_path=sc.lmdas, **kw)
+    assert sc.error == "" and sn.error == "" and sc.duals.nnz > 0
+    # (the two methods stop on different scalings of the same rule: tol for the covariance method, tol * y_var for the naive one)
+    assert np.abs(sc.betas.toarray() - sn.betas.toarray()).max() < 1e-6
+    assert sc.duals.shape == sn.duals.shape and np.abs((sc.duals - sn.duals)).max() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_hip_cov_with_constraints_matches_oracle(hip, oracle, dtype):
+    """Constraint objects (host visits between Gram-engine blocks) and one-coefficient closed forms (clips in the group solve)
+    under the covariance method: HIP vs the oracle."""
+    from adelie_amd import constraint
+
+    f32 = dtype == np.float32
+    tight = None if f32 else {"tol": 1e-13, "pinball_tol": 1e-12, "max_iters": 1000}
+    X, y, A, v, groups, make = _cov_constrained_problem(5, tight=tight)
+    A, v = A.astype(dtype), v.astype(dtype)
+    kw = dict(groups=groups, alpha=0.8, tol=1e-7 if f32 else 1e-13, early_exit=False, progress_bar=False, lmda_path_size=10,
+              min_ratio=0.05)
+    if f32:
+        kw["newton_tol"] = 1e-5
+    a = ad.gaussian_cov(ad.matrix.dense(A, method="cov"), v, constraints=make(), **kw)
+    b = ad.gaussian_cov(oracle.cov_dense(A), v, constraints=make(), **kw)
+    assert a.error == "" and b.error == "", (a.error, b.error)
+    tol = 5e-3 if f32 else 1e-6
+    assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < tol
+    assert a.duals.shape == b.duals.shape and b.duals.nnz > 0
+    assert np.abs((a.duals - b.duals)).max() < (5e-2 if f32 else 1e-5)
+    # singletons with closed-form bounds next to unconstrained singletons
+    p = A.shape[0]
+    mk1 = lambda: [constraint.box(np.array([-0.02]), np.array([0.03]), dtype=dtype) if j % 3 == 0 else
+                   (constraint.lower(np.zeros(1), dtype=dtype) if j % 3 == 1 else None) for j in range(p)]
+    kw1 = dict(alpha=1.0, tol=1e-7 if f32 else 1e-13, early_exit=False, progress_bar=False, lmda_path_size=10, min_ratio=0.05)
+    a1 = ad.gaussian_cov(ad.matrix.dense(A, method="cov"), v, constraints=mk1(), **kw1)
+    b1 = ad.gaussian_cov(oracle.cov_dense(A), v, constraints=mk1(), **kw1)
+    assert a1.error == "" and b1.error == ""
+    B = a1.betas.toarray()
+    assert (B[:, 0::3] >= -0.02 - 1e-7).all() and (B[:, 0::3] <= 0.03 + 1e-7).all() and (B[:, 1::3] >= -1e-7).all()
+    assert np.abs(B - b1.betas.toarray()).max() < tol
+    assert np.abs((a1.duals - b1.duals)).max() < (5e-2 if f32 else 1e-6) and b1.duals.nnz > 0

@@ -331,8 +331,8 @@ typedef struct adelie_hip_grpnet_args {
     /* ---- per-group constraints (`constraints` of StateBase, state_base.hpp:60; adelie_core/constraint/) ----
      * Groups of ONE value with a box / one-sided constraint run as closed forms on the device (constraint_box.ipp:51-96,
      * constraint_one_sided.ipp:12-49); every other constraint object (several coefficients, linear, user-defined classes) is
-     * kind 3: its group is visited on the host between two panel steps through constraint_cb (see above).  Constraints on a
-     * multi-response view / the covariance method are refused with an error string.
+     * kind 3: its group is visited on the host between two panel steps through constraint_cb (see above).  Accepted on every
+     * state kind (naive, multi-response view, covariance method).
      *   kind 0: unconstrained;
      *   kind 1: box        constraint_a[i] <= beta_i <= constraint_b[i]   (a <= 0 <= b, infinities allowed); dual = mu_+ - mu_-
      *   kind 2: one-sided  constraint_a[i] * beta_i <= constraint_b[i]    (a = +-1, b >= 0);               dual = mu >= 0

@@ -12,9 +12,9 @@
  * row-major here; the class stores l = -lower >= 0 and u = upper >= 0 like the reference's Python wrapper hands them over
  * (adelie/constraint.py:262-263).  The multipliers are kept sparse in insertion order (`mu_active`, `mu_value`): that order IS
  * the visiting order of the two coordinate-descent sub-solvers, so it is restated, not replaced by a dense vector.
- * Independent of adelie_amd/constraint.py (numpy, scipy's lsq_linear for the bounded least squares, one dense pinball
- * branch): tests/test_constraint.py compares the two and replays the reference's own recipe (tests/test_constraint.py:73-135)
- * on this one. */
+ * Written independently of adelie_amd/constraint.py (numpy: one dual driver in A' mu terms for three classes, dense multipliers
+ * with an order list, one dense pinball branch): tests/test_constraint.py compares the two and replays the reference's own
+ * recipe (tests/test_constraint.py:73-135) on this one. */
 #pragma once
 
 template <class T>

@@ -1,7 +1,7 @@
 """Cycle profile of the group solve on a multi-response view (needs a build with AHIP_EXTRA_FLAGS=-DAHIP_GRP_PROFILE)."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["ADELIE_HIP_GRP_PROFILE"] = "1"
+# (needs a build with AHIP_EXTRA_FLAGS=-DAHIP_GRP_PROFILE: the counters are compiled in, no environment variable)
 import adelie_amd as ad
 from adelie_amd import _abi
 import adelie_amd.state as S_

@@ -19,7 +19,7 @@ kw = dict(early_exit=False, lmda_path_size=100, progress_bar=False)
 ref = None
 for th in thetas:
     os.environ["ADELIE_HIP_IRLS_REUSE"] = str(th)
-    os.environ["ADELIE_HIP_TRACE_ENQ"] = "1"
+    os.environ["ADELIE_HIP_TRACE"] = "2"
     if ref is None:
         ad.grpnet(Xd, glm, **kw)  # warm-up
     torch.cuda.synchronize()

@@ -1,5 +1,6 @@
 // design.hip — C ABI: library info, design-matrix handles and the MatrixNaiveBase operations.
 // (include/adelie_hip.h documents which reference method each entry point replaces.)
+#include <atomic>
 #include "common.hpp"
 
 #include <mutex>
@@ -101,6 +102,11 @@ void create_sparse_t(adelie_hip_design* d, const int64_t* indptr, const int32_t*
     release();
 }
 
+// Designs alive in this process.  When the last one goes, the device blocks that finished solves parked for re-use (DevPool,
+// up to 6 GB) are released: nothing of this library keeps device memory that another library in the process might want once
+// the caller holds no design any more.
+std::atomic<int>& live_designs() { static std::atomic<int> c{0}; return c; }
+
 adelie_hip_design* new_design(int64_t n, int64_t p, int dtype, int device) {
     if (n <= 0 || p <= 0) throw make_core_error("matrix must have positive dimensions.");
     if (dtype != ADELIE_HIP_F32 && dtype != ADELIE_HIP_F64) throw make_core_error("dtype must be F32 or F64.");
@@ -112,6 +118,7 @@ adelie_hip_design* new_design(int64_t n, int64_t p, int dtype, int device) {
     d->n = n;
     d->p = p;
     AHIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    live_designs().fetch_add(1);
     return d;
 }
 
@@ -1028,6 +1035,7 @@ int adelie_hip_design_destroy(adelie_hip_design* d) {
     if (d->ones) (void)hipFree(d->ones);
     if (d->batcher) adelie_hip_internal_free_batcher(d->batcher);
     delete d;
+    if (live_designs().fetch_sub(1) == 1) DevPool::trim();
     return 0;
 }
 

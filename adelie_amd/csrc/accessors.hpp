@@ -85,4 +85,26 @@ struct SnpAcc {
     }
 };
 
+// 2-bit SNP design preceded by `shift` (0 or 1) columns of ones: the extended features of the multi-response view over an
+// SNP base.  Same interface as SnpAcc (the K-wide sweep and the MFMA Gram kernels take it unchanged); the ones columns are
+// never dereferenced.
+template <class T>
+struct SnpOnesAcc {
+    const uint8_t* bits;
+    int64_t ldb;
+    const T* impute;
+    int64_t shift;
+    __device__ __forceinline__ const uint8_t* colptr(int64_t u) const { return u < shift ? bits : bits + (u - shift) * ldb; }
+    template <int VEC>
+    __device__ __forceinline__ Pack<T, VEC> load(const uint8_t* col, int64_t i, int64_t u) const {
+        if (u < shift) {
+            Pack<T, VEC> r;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r.v[e] = T(1);
+            return r;
+        }
+        return SnpAcc<T>{bits, ldb, impute}.template load<VEC>(col, i, u - shift);
+    }
+};
+
 } // namespace ahip

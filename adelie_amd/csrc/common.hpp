@@ -407,7 +407,7 @@ struct DevBuf {
 struct adelie_hip_design {
     int dtype = ADELIE_HIP_F64;
     int device = 0;
-    int kind = 0; // 0 dense, 1 snp (2-bit), 2 multi-response view of a dense design (adelie_hip_design_create_multi)
+    int kind = 0; // 0 dense, 1 snp (2-bit), 2 multi-response view of a dense or 2-bit design (adelie_hip_design_create_multi)
     // covariance-method matrix A (adelie_hip_design_create_cov_dense): a dense (p, p) design with n == p that only
     // adelie_hip_gaussian_cov_solve and the cov_* operations accept; cov == 2: the stored matrix is A^T (row-major input)
     int cov = 0;
@@ -436,6 +436,7 @@ struct adelie_hip_design {
     template <class T> ahip::DenseView<T> dense() const { return ahip::DenseView<T>{static_cast<const T*>(X), n, p, ld}; }
     ahip::SnpView snp() const { return ahip::SnpView{bits, n, p, ldb}; }
     template <class T> ahip::MultiView<T> multi() const {
-        return ahip::MultiView<T>{static_cast<const T*>(X), nb, pb, ld, static_cast<const T*>(ones), int32_t(mK), int32_t(micpt)};
+        return ahip::MultiView<T>{static_cast<const T*>(X), nb, pb, ld, static_cast<const T*>(ones), int32_t(mK), int32_t(micpt),
+                                  bits, ldb, static_cast<const T*>(impute)};
     }
 };

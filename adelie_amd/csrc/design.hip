@@ -921,7 +921,8 @@ int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out) {
 int adelie_hip_design_create_multi(adelie_hip_design* base, int64_t K, int intercept, adelie_hip_design** out) {
     ABI_TRY
     if (!base || !out) throw make_core_error("null argument.");
-    if (base->kind != 0) throw make_core_error("the multi-response view needs a dense base design.");
+    if ((base->kind != 0 && base->kind != 1) || base->cov)
+        throw make_core_error("the multi-response view needs a dense or 2-bit SNP base design.");
     if (K < 1) throw make_core_error("K must be >= 1.");
     const int64_t icpt = intercept ? 1 : 0;
     if ((base->p + icpt) * K > int64_t(0x7fffffff) || base->n * K > (int64_t(1) << 40))
@@ -930,6 +931,9 @@ int adelie_hip_design_create_multi(adelie_hip_design* base, int64_t K, int inter
     d->kind = 2;
     d->X = base->X;
     d->ld = base->ld;
+    d->bits = base->bits; // (2-bit base: the K-wide kernels decode the calls themselves, MultiView::bits)
+    d->ldb = base->ldb;
+    d->impute = base->impute;
     d->owned = false;
     d->alias = true;
     d->mK = K;

@@ -414,6 +414,11 @@ struct MultiView {
     int64_t nb, pb, ld;
     const T* ones; // nb ones
     int32_t K, icpt;
+    // 2-bit SNP base (matrix_naive_kronecker_eye.ipp over matrix_naive_snp_unphased.ipp): bits != nullptr, X unused — the
+    // K-wide kernels decode the calls of a column once for all K responses (accessors.hpp::SnpOnesAcc)
+    const uint8_t* bits = nullptr;
+    int64_t ldb = 0;
+    const T* impute = nullptr;
 };
 // out[u*K + l] = sum_i xcol(u)[i] * v[l*nb + i]  for every u in [0, pb + icpt): X is read ONCE for all K responses.
 template <class T> void launch_multi_sweep(const MultiView<T>& X, const T* v, T* out, T* work, hipStream_t s);

@@ -708,6 +708,11 @@ void launch_syrk_snp(const SnpView& X, const T* impute, const T* w, const int32_
 template <class T>
 void launch_syrk_multi(const MultiView<T>& X, const T* w, const int32_t* ucols, int32_t M, T* C, int64_t ldc, T* work,
                        hipStream_t s) {
+    if (X.bits) { // 2-bit base: as launch_syrk_snp
+        SnpOnesAcc<T> sacc{X.bits, X.ldb, X.impute, int64_t(X.icpt)};
+        syrk_launch<T, SnpOnesAcc<T>>(sacc, true, w, ucols, M, X.nb, nullptr, false, C, ldc, work, s);
+        return;
+    }
     DenseOnesAcc<T> acc{X.X, X.ld, X.ones, int64_t(X.icpt)};
     constexpr int V = VecOf<T>::N;
     const bool vecok = (X.ld % V == 0) && ((reinterpret_cast<uintptr_t>(X.X) % 16) == 0) &&
@@ -719,6 +724,11 @@ void launch_syrk_multi(const MultiView<T>& X, const T* w, const int32_t* ucols, 
 template <class T>
 void launch_gram_multi(const MultiView<T>& X, const T* w, const int32_t* mcols, int32_t M, const int32_t* ncols, int32_t N,
                        T* C, int64_t ldc, T* work, hipStream_t s) {
+    if (X.bits) {
+        SnpOnesAcc<T> sacc{X.bits, X.ldb, X.impute, int64_t(X.icpt)};
+        gram_launch<T, SnpOnesAcc<T>>(sacc, true, w, mcols, M, 0, ncols, N, 0, X.nb, nullptr, false, C, ldc, work, s);
+        return;
+    }
     DenseOnesAcc<T> acc{X.X, X.ld, X.ones, int64_t(X.icpt)};
     constexpr int V = VecOf<T>::N;
     const bool vecok = (X.ld % V == 0) && ((reinterpret_cast<uintptr_t>(X.X) % 16) == 0) &&

@@ -264,6 +264,7 @@ inline void msweep_shape(int64_t nb, int64_t nfeat, int vec, int64_t& blocks_c, 
 template <class T>
 bool multi_vecok(const MultiView<T>& X) {
     constexpr int V = VecOf<T>::N;
+    if (X.bits) return true; // (2-bit base: a lane's V calls lie in one byte whatever the column's address)
     return (X.ld % V == 0) && ((reinterpret_cast<uintptr_t>(X.X) % 16) == 0) &&
            ((reinterpret_cast<uintptr_t>(X.ones) % 16) == 0);
 }
@@ -289,6 +290,22 @@ __device__ __forceinline__ Pack<T, VEC> mload(const T* col, int64_t i, int64_t n
     return r;
 }
 
+// VEC rows of extended feature u starting at row i (see mload for `full`)
+template <class T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> mcol(const DenseOnesAcc<T>& X, int u, int64_t i, int64_t nb, bool full) {
+    return mload<T, VEC>(X.colptr(u), i, nb, full);
+}
+template <class T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> mcol(const SnpOnesAcc<T>& X, int u, int64_t i, int64_t nb, bool full) {
+    // (i is a multiple of VEC: the 2 or 4 calls of a lane lie in one byte)
+    const int64_t ii = (full || i < nb) ? i : 0;
+    const Pack<T, VEC> x = X.template load<VEC>(X.colptr(u), ii, u);
+    Pack<T, VEC> r;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) r.v[e] = (full || i + e < nb) ? x.v[e] : T(0);
+    return r;
+}
+
 // slots of a list of view columns: returns the number of slots; feat[slot] = extended feature; for every entry m the
 // callback gets (m, slot, response)
 template <class F>
@@ -311,8 +328,8 @@ __device__ __forceinline__ int build_slots(const int32_t* __restrict__ list, int
 }
 
 // phases (A) and (B) of the multi-response panel step for one wave (64 * VEC rows starting at row i, responses l0..l0+KT)
-template <class T, int VEC, int KT>
-__device__ __forceinline__ void multi_step_phases(const DenseOnesAcc<T>& X, int64_t nb, int K, const T* __restrict__ w,
+template <class T, class Acc, int VEC, int KT>
+__device__ __forceinline__ void multi_step_phases(const Acc& X, int64_t nb, int K, const T* __restrict__ w,
                                                   T* __restrict__ r, const int* featA, const int* featB, const T* dA,
                                                   const int* valB, int nsA, int nsB, int l0, int lane, int64_t i,
                                                   bool full, int64_t slice, T* __restrict__ part, int64_t part_ld) {
@@ -326,7 +343,7 @@ __device__ __forceinline__ void multi_step_phases(const DenseOnesAcc<T>& X, int6
     for (int s0 = 0; s0 < nsA; s0 += U) {
         Pack<T, VEC> xa[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) xa[u] = mload<T, VEC>(X.colptr(featA[min(s0 + u, nsA - 1)]), i, nb, full);
+        for (int u = 0; u < U; ++u) xa[u] = mcol<T, VEC>(X, featA[min(s0 + u, nsA - 1)], i, nb, full);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (s0 + u < nsA) {
@@ -362,7 +379,7 @@ __device__ __forceinline__ void multi_step_phases(const DenseOnesAcc<T>& X, int6
     for (int s0 = 0; s0 < nsB; s0 += U) {
         Pack<T, VEC> xb[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) xb[u] = mload<T, VEC>(X.colptr(featB[min(s0 + u, nsB - 1)]), i, nb, full);
+        for (int u = 0; u < U; ++u) xb[u] = mcol<T, VEC>(X, featB[min(s0 + u, nsB - 1)], i, nb, full);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (s0 + u < nsB) {
@@ -386,8 +403,8 @@ __device__ __forceinline__ void multi_step_phases(const DenseOnesAcc<T>& X, int6
     }
 }
 
-template <class T, int VEC, int KT>
-__global__ __launch_bounds__(64) void multi_panel_step_kernel(DenseOnesAcc<T> X, int64_t nb, int K,
+template <class T, class Acc, int VEC, int KT>
+__global__ __launch_bounds__(64) void multi_panel_step_kernel(Acc X, int64_t nb, int K,
                                                               const T* __restrict__ w, T* __restrict__ r,
                                                               const int32_t* __restrict__ dcol,
                                                               const T* __restrict__ dlt,
@@ -418,8 +435,8 @@ __global__ __launch_bounds__(64) void multi_panel_step_kernel(DenseOnesAcc<T> X,
     });
     __syncthreads();
 
-    multi_step_phases<T, VEC, KT>(X, nb, K, w, r, featA, featB, dA, valB, nsA, nsB, l0, lane, i, full, blockIdx.x, part,
-                                  part_ld);
+    multi_step_phases<T, Acc, VEC, KT>(X, nb, K, w, r, featA, featB, dA, valB, nsA, nsB, l0, lane, i, full, blockIdx.x, part,
+                                       part_ld);
 }
 
 // Fused look-ahead launch on the view (solver.hip::run_group_panel_passes): workgroup (0, 0) runs the group solve of block j,
@@ -427,8 +444,8 @@ __global__ __launch_bounds__(64) void multi_panel_step_kernel(DenseOnesAcc<T> X,
 // lists are built once per workgroup.  1024-thread workgroups for the same reason as panel_fused_kernel (the solve's LDS
 // request makes it one workgroup per CU for everybody).
 constexpr int MFS = 16; // waves (row slices) per fused step workgroup
-template <class T, int VEC, int KT>
-__global__ __launch_bounds__(64 * MFS) void multi_fused_kernel(CdGrpBlkParams<T> sp, int j, DenseOnesAcc<T> X, int64_t nb,
+template <class T, class Acc, int VEC, int KT>
+__global__ __launch_bounds__(64 * MFS) void multi_fused_kernel(CdGrpBlkParams<T> sp, int j, Acc X, int64_t nb,
                                                               int K, const T* __restrict__ w, T* __restrict__ r,
                                                               const int32_t* __restrict__ dcol,
                                                               const T* __restrict__ dlt,
@@ -467,7 +484,7 @@ __global__ __launch_bounds__(64 * MFS) void multi_fused_kernel(CdGrpBlkParams<T>
     const int64_t slice = (int64_t(blockIdx.x) - 1) * MFS + wave;
     const int64_t i = slice * (64 * VEC) + int64_t(lane) * VEC;
     const bool full = (slice + 1) * (64 * VEC) <= nb;
-    multi_step_phases<T, VEC, KT>(X, nb, K, w, r, featA, featB, dA, valB, nsA, nsB, l0, lane, i, full, slice, part, part_ld);
+    multi_step_phases<T, Acc, VEC, KT>(X, nb, K, w, r, featA, featB, dA, valB, nsA, nsB, l0, lane, i, full, slice, part, part_ld);
 }
 
 // cross block over view columns from the Gram of the two blocks' distinct features: rows = block b, columns = block b-1
@@ -516,8 +533,8 @@ __global__ __launch_bounds__(MAXB) void multi_block_lists_kernel(const int32_t* 
     }
 }
 
-template <class T>
-__global__ void multi_axpy_kernel(DenseOnesAcc<T> X, int64_t nb, int K, const int32_t* __restrict__ cols,
+template <class T, class Acc>
+__global__ void multi_axpy_kernel(Acc X, int64_t nb, int K, const int32_t* __restrict__ cols,
                                   const T* __restrict__ coef, const int32_t* __restrict__ cnt_dev, T sign,
                                   T* __restrict__ out) {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -526,7 +543,7 @@ __global__ void multi_axpy_kernel(DenseOnesAcc<T> X, int64_t nb, int K, const in
     for (int m = 0; m < cnt; ++m) {
         const int col = cols[m];
         const int u = col / K, l = col - u * K;
-        out[int64_t(l) * nb + i] += sign * coef[m] * X.colptr(u)[i];
+        out[int64_t(l) * nb + i] += sign * coef[m] * mcol<T, 1>(X, u, i, nb, true).v[0];
     }
 }
 
@@ -572,11 +589,10 @@ int64_t multi_sweep_work_elems(const MultiView<T>& X) {
     return int64_t(std::max(ns, ns2)) * (X.pb + X.icpt) * X.K + 16;
 }
 
-template <class T>
-void launch_multi_sweep(const MultiView<T>& X, const T* v, T* out, T* work, hipStream_t s) {
+namespace {
+template <class T, class Acc>
+void multi_sweep_launch(const Acc& acc, const MultiView<T>& X, const T* v, T* out, T* work, hipStream_t s) {
     const int64_t nfeat = X.pb + X.icpt;
-    if (nfeat <= 0 || X.K <= 0) return;
-    DenseOnesAcc<T> acc{X.X, X.ld, X.ones, int64_t(X.icpt)};
     constexpr int V = VecOf<T>::N;
     int64_t bc, rps;
     int ns;
@@ -588,17 +604,17 @@ void launch_multi_sweep(const MultiView<T>& X, const T* v, T* out, T* work, hipS
 #define AHIP_MS(VV, KK)                                                                                                 \
     do {                                                                                                                \
         if (wpc == 2)                                                                                                   \
-            hipLaunchKernelGGL((multi_sweep_kernel<T, DenseOnesAcc<T>, VV, KK, 4, true>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps); \
+            hipLaunchKernelGGL((multi_sweep_kernel<T, Acc, VV, KK, 4, true>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps); \
         else if (wpc)                                                                                                   \
-            hipLaunchKernelGGL((multi_sweep_kernel<T, DenseOnesAcc<T>, VV, KK, 8, true>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps); \
+            hipLaunchKernelGGL((multi_sweep_kernel<T, Acc, VV, KK, 8, true>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps); \
         else if (msweep_mcb() == 8)                                                                                     \
-            hipLaunchKernelGGL((multi_sweep_kernel<T, DenseOnesAcc<T>, VV, KK, 8>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps); \
+            hipLaunchKernelGGL((multi_sweep_kernel<T, Acc, VV, KK, 8>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps); \
         else                                                                                                            \
-            hipLaunchKernelGGL((multi_sweep_kernel<T, DenseOnesAcc<T>, VV, KK, 4>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps); \
+            hipLaunchKernelGGL((multi_sweep_kernel<T, Acc, VV, KK, 4>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps); \
     } while (0)
     const bool v_al = X.nb % V == 0 && (reinterpret_cast<uintptr_t>(v) % 16) == 0; // each of the K vectors starts 16-byte aligned
     if (vok && v_al && wpc == 3) {
-        hipLaunchKernelGGL((multi_sweep_lds_kernel<T, DenseOnesAcc<T>, V>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps);
+        hipLaunchKernelGGL((multi_sweep_lds_kernel<T, Acc, V>), grid, dim3(MT), 0, s, acc, v, work, X.nb, nfeat, int(X.K), rps);
     } else if (vok) {
         if (KT == 8) AHIP_MS(V, 8); else if (KT == 4) AHIP_MS(V, 4); else AHIP_MS(V, 2);
     } else {
@@ -608,6 +624,13 @@ void launch_multi_sweep(const MultiView<T>& X, const T* v, T* out, T* work, hipS
     const int64_t ncols = nfeat * X.K;
     hipLaunchKernelGGL((multi_sweep_reduce_kernel<T>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, work, out,
                        ncols, ns);
+}
+} // namespace
+template <class T>
+void launch_multi_sweep(const MultiView<T>& X, const T* v, T* out, T* work, hipStream_t s) {
+    if (X.pb + X.icpt <= 0 || X.K <= 0) return;
+    if (X.bits) multi_sweep_launch<T, SnpOnesAcc<T>>(SnpOnesAcc<T>{X.bits, X.ldb, X.impute, int64_t(X.icpt)}, X, v, out, work, s);
+    else multi_sweep_launch<T, DenseOnesAcc<T>>(DenseOnesAcc<T>{X.X, X.ld, X.ones, int64_t(X.icpt)}, X, v, out, work, s);
 }
 
 // the same sweep over a 2-bit SNP design (no ones column): out[u*K + l] = x_u . v_l; the calls of a column are decoded once
@@ -639,10 +662,10 @@ void launch_multi_sweep_snp(const SnpView& X, const T* impute, int K, const T* v
 
 int64_t multi_panel_part_elems(int64_t nb) { return int64_t(MAXB) * ((nb + 63) / 64) + 16; }
 
-template <class T>
-int launch_multi_panel_step(const MultiView<T>& X, const T* w, T* r, const int32_t* dcol, const T* dlt,
-                            const int32_t* nz_dev, const int32_t* cols, int nb_cols, T* part, hipStream_t s) {
-    DenseOnesAcc<T> acc{X.X, X.ld, X.ones, int64_t(X.icpt)};
+namespace {
+template <class T, class Acc>
+int multi_step_launch(const Acc& acc, const MultiView<T>& X, const T* w, T* r, const int32_t* dcol, const T* dlt,
+                      const int32_t* nz_dev, const int32_t* cols, int nb_cols, T* part, hipStream_t s) {
     constexpr int V = VecOf<T>::N;
     const bool vok = multi_vecok(X);
     const int RS = 64 * (vok ? V : 1);
@@ -650,7 +673,7 @@ int launch_multi_panel_step(const MultiView<T>& X, const T* w, T* r, const int32
     const int KT = kt_of(X.K);
     const dim3 grid((unsigned)nsl, (unsigned)((X.K + KT - 1) / KT));
 #define AHIP_MP(VV, KK)                                                                                                 \
-    hipLaunchKernelGGL((multi_panel_step_kernel<T, VV, KK>), grid, dim3(64), 0, s, acc, X.nb, int(X.K), w, r, dcol, dlt, \
+    hipLaunchKernelGGL((multi_panel_step_kernel<T, Acc, VV, KK>), grid, dim3(64), 0, s, acc, X.nb, int(X.K), w, r, dcol, dlt, \
                        nz_dev, cols, nb_cols, part, nsl)
     if (vok) {
         if (KT == 8) AHIP_MP(V, 8); else if (KT == 4) AHIP_MP(V, 4); else AHIP_MP(V, 2);
@@ -660,12 +683,10 @@ int launch_multi_panel_step(const MultiView<T>& X, const T* w, T* r, const int32
 #undef AHIP_MP
     return int(nsl);
 }
-
-template <class T>
-int launch_multi_panel_fused(const CdGrpBlkParams<T>& sp, int j, const MultiView<T>& X, const T* w, T* r,
-                             const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb_cols,
-                             T* part, hipStream_t s) {
-    DenseOnesAcc<T> acc{X.X, X.ld, X.ones, int64_t(X.icpt)};
+template <class T, class Acc>
+int multi_fused_launch(const Acc& acc, const CdGrpBlkParams<T>& sp, int j, const MultiView<T>& X, const T* w, T* r,
+                       const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb_cols, T* part,
+                       hipStream_t s) {
     constexpr int V = VecOf<T>::N;
     const bool vok = multi_vecok(X);
     const int RS = 64 * (vok ? V : 1);
@@ -679,11 +700,11 @@ int launch_multi_panel_fused(const CdGrpBlkParams<T>& sp, int j, const MultiView
     {                                                                                                                  \
         static bool done = false;                                                                                      \
         if (!done) {                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(multi_fused_kernel<T, VV, KK>),                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(multi_fused_kernel<T, Acc, VV, KK>),               \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));                           \
             done = true;                                                                                               \
         }                                                                                                              \
-        hipLaunchKernelGGL((multi_fused_kernel<T, VV, KK>), grid, dim3(64 * MFS), lds, s, sp, j, acc, X.nb, int(X.K), w, r,    \
+        hipLaunchKernelGGL((multi_fused_kernel<T, Acc, VV, KK>), grid, dim3(64 * MFS), lds, s, sp, j, acc, X.nb, int(X.K), w, r, \
                            dcol, dlt, nz_dev, cols, nb_cols, part, part_ld);                                           \
     }
     if (vok) {
@@ -693,6 +714,28 @@ int launch_multi_panel_fused(const CdGrpBlkParams<T>& sp, int j, const MultiView
     }
 #undef AHIP_MF
     return int(part_ld);
+}
+} // namespace
+
+template <class T>
+int launch_multi_panel_step(const MultiView<T>& X, const T* w, T* r, const int32_t* dcol, const T* dlt,
+                            const int32_t* nz_dev, const int32_t* cols, int nb_cols, T* part, hipStream_t s) {
+    if (X.bits)
+        return multi_step_launch<T, SnpOnesAcc<T>>(SnpOnesAcc<T>{X.bits, X.ldb, X.impute, int64_t(X.icpt)}, X, w, r, dcol, dlt,
+                                                   nz_dev, cols, nb_cols, part, s);
+    return multi_step_launch<T, DenseOnesAcc<T>>(DenseOnesAcc<T>{X.X, X.ld, X.ones, int64_t(X.icpt)}, X, w, r, dcol, dlt, nz_dev,
+                                                 cols, nb_cols, part, s);
+}
+
+template <class T>
+int launch_multi_panel_fused(const CdGrpBlkParams<T>& sp, int j, const MultiView<T>& X, const T* w, T* r,
+                             const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb_cols,
+                             T* part, hipStream_t s) {
+    if (X.bits)
+        return multi_fused_launch<T, SnpOnesAcc<T>>(SnpOnesAcc<T>{X.bits, X.ldb, X.impute, int64_t(X.icpt)}, sp, j, X, w, r, dcol,
+                                                    dlt, nz_dev, cols, nb_cols, part, s);
+    return multi_fused_launch<T, DenseOnesAcc<T>>(DenseOnesAcc<T>{X.X, X.ld, X.ones, int64_t(X.icpt)}, sp, j, X, w, r, dcol, dlt,
+                                                  nz_dev, cols, nb_cols, part, s);
 }
 
 template <class T>
@@ -706,9 +749,16 @@ void launch_multi_expand_cross(const T* G, int64_t ldg, const int32_t* slot_r, c
 template <class T>
 void launch_multi_axpy_cols(const MultiView<T>& X, const int32_t* cols, const T* coef, const int32_t* cnt_dev, T sign,
                             T* out, hipStream_t s) {
+    const dim3 grid((unsigned)((X.nb + 255) / 256));
+    if (X.bits) {
+        SnpOnesAcc<T> acc{X.bits, X.ldb, X.impute, int64_t(X.icpt)};
+        hipLaunchKernelGGL((multi_axpy_kernel<T, SnpOnesAcc<T>>), grid, dim3(256), 0, s, acc, X.nb, int(X.K), cols, coef, cnt_dev,
+                           sign, out);
+        return;
+    }
     DenseOnesAcc<T> acc{X.X, X.ld, X.ones, int64_t(X.icpt)};
-    hipLaunchKernelGGL((multi_axpy_kernel<T>), dim3((unsigned)((X.nb + 255) / 256)), dim3(256), 0, s, acc, X.nb, int(X.K),
-                       cols, coef, cnt_dev, sign, out);
+    hipLaunchKernelGGL((multi_axpy_kernel<T, DenseOnesAcc<T>>), grid, dim3(256), 0, s, acc, X.nb, int(X.K), cols, coef, cnt_dev,
+                       sign, out);
 }
 
 template <class T>

@@ -480,13 +480,11 @@ class _MultiView(_NativeMatrix):
 
 def _multi_view(base, K, intercept):
     if not isinstance(base, _NativeMatrix) or isinstance(base, _MultiView):
-        raise RuntimeError("adelie_amd: the multi-response view needs a resident (dense) design as its base.")
+        raise RuntimeError("adelie_amd: the multi-response view needs a resident (dense or 2-bit SNP) design as its base.")
     if int(K) < 1:
         raise RuntimeError("adelie_core: K must be >= 1.")
-    if getattr(base, "_kind", None) == "snp":
-        # the K-wide kernels read dense columns: a 2-bit SNP base is decoded once into a dense copy (8 or 4 bytes per call
-        # instead of a quarter byte -- n * p values must fit in HBM), which the view then owns
-        base = _derived(base, None, None, None, None, base._n_threads)
+    # (a 2-bit SNP base stays 2-bit: the K-wide sweep, panel step and Gram kernels decode a column's calls once for all K
+    # responses -- matrix_naive_kronecker_eye.ipp over matrix_naive_snp_unphased.ipp)
     backend = base._backend
     handle = _abi.C.c_void_p()
     backend.check(backend.fn("design_create_multi")(base._handle, int(K), 1 if intercept else 0, handle))

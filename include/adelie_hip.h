@@ -124,15 +124,15 @@ int adelie_hip_design_create_derived(adelie_hip_design* src, const int64_t* rows
  * the k resident designs are copied side by side (axis 1: columns; axis 0: rows) into one new dense design; SNP sources
  * are decoded.  The sources stay valid and independent.  The reference's error strings for mismatched shapes are kept. */
 int adelie_hip_design_create_concat(adelie_hip_design* const* srcs, int64_t k, int axis, adelie_hip_design** out);
-/* Multi-response view of a resident dense design: the (n*K) x ((p + intercept)*K) matrix
+/* Multi-response view of a resident dense or 2-bit SNP design: the (n*K) x ((p + intercept)*K) matrix
  *     [ 1_n (x) I_K ,  X (x) I_K ]      (the first block only when `intercept` != 0)
  * that adelie/state.py:1100-1125 (_render_multi_inputs) builds from matrix.kronecker_eye / matrix.concatenate
  * (matrix_naive_kronecker_eye.ipp:27-47, matrix_naive_concatenate.ipp) and hands to StateMultiGaussianNaive.  Column j is
  * (extended feature j / K, response j % K); vectors over the rows are (n, K) row-major, as in the reference.  Nothing is
  * materialised: the view shares `base`'s matrix (which must outlive it) and owns a stream, scratch space and one column of
  * ones.  adelie_hip_grpnet_solve on the view runs the Gaussian naive solver with every kernel reading a column of X once
- * for all K responses.  The matrix-op entry points (cmul ... sp_tmul) are not offered on the view: the Python layer
- * reaches them through `base`. */
+ * for all K responses (a 2-bit base stays 2-bit: its calls are decoded once per column for all K).  The matrix-op entry
+ * points (cmul ... sp_tmul) are not offered on the view: the Python layer reaches them through `base`. */
 int adelie_hip_design_create_multi(adelie_hip_design* base, int64_t K, int intercept, adelie_hip_design** out);
 /* Copies the (p,) impute vector of an SNP design (as double). */
 int adelie_hip_design_impute(adelie_hip_design* d, double* out);

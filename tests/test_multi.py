@@ -494,8 +494,7 @@ def test_hip_multi_cv_device_losses_equal_host_path(family, monkeypatch):
 
 @pytest.mark.gpu
 def test_hip_multi_response_on_snp_design_equals_densified():
-    """A 2-bit SNP base under the multi-response view (decoded once into a dense copy the view owns): same path as on the
-    densified matrix."""
+    """A 2-bit SNP base under the multi-response view: same path as on the densified matrix."""
     rng = np.random.RandomState(13)
     n, p, K = 300, 40, 3
     calls = rng.choice([0, 1, 2, -9], size=(n, p), p=[0.55, 0.3, 0.1, 0.05]).astype(np.int8)
@@ -510,6 +509,46 @@ def test_hip_multi_response_on_snp_design_equals_densified():
     cv = ad.cv_grpnet(matrix.snp_calldata(calls), ad.glm.multigaussian(y=Y), n_folds=3, seed=0, lmda_path_size=10,
                       progress_bar=False)
     assert np.all(np.isfinite(cv.losses))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("family,n,p,K", [("multigaussian", 1031, 90, 4), ("multigaussian", 517, 60, 9),
+                                          ("multinomial", 802, 70, 3)])
+def test_hip_multi_response_kernels_on_2bit_base(monkeypatch, oracle, family, n, p, K, dtype):
+    """The K-wide kernels on the 2-bit layout (SnpOnesAcc: sweep, panel step, fused look-ahead launch, Gram builds, residual
+    update) with the panel engine forced: the view over the SNP design against the view over its densified copy (the same
+    kernels through DenseOnesAcc: equal to rounding) and against the CPU oracle on the dense matrix.  Row counts that are not
+    multiples of the 4 calls of a byte, missing calls in every column."""
+    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    rng = np.random.RandomState(n + K)
+    calls = rng.choice([0, 1, 2, -9], size=(n, p), p=[0.5, 0.3, 0.15, 0.05]).astype(np.int8)
+    imp = matrix.compute_impute(calls)
+    D = np.asfortranarray(np.where(calls < 0, imp[None], calls).astype(dtype))
+    B = np.zeros((p, K))
+    B[rng.choice(p, 8, replace=False)] = rng.normal(size=(8, K))
+    eta = (D - D.mean(0)) @ B
+    if family == "multigaussian":
+        Y = (eta + 0.5 * rng.normal(size=(n, K))).astype(dtype)
+    else:
+        P = np.exp(eta - eta.max(1, keepdims=True))
+        P /= P.sum(1, keepdims=True)
+        Y = np.stack([rng.multinomial(1, P[i]) for i in range(n)]).astype(dtype)
+    kw = dict(early_exit=False, lmda_path_size=12, min_ratio=0.1, progress_bar=False)
+    if dtype == np.float32:
+        kw.update(tol=1e-6, newton_tol=1e-5)
+    glm = lambda: getattr(ad.glm, family)(y=Y, dtype=dtype)
+    s1 = ad.grpnet(matrix.snp_calldata(calls, dtype=dtype), glm(), **kw)
+    s2 = ad.grpnet(matrix.dense(D), glm(), **kw)
+    so = ad.grpnet(oracle.dense(D), glm(), **kw)
+    assert s1.error == "" and s2.error == "" and so.error == ""
+    assert np.array_equal(s1.lmdas, s2.lmdas)
+    f32 = dtype == np.float32
+    assert np.abs(s1.betas.toarray() - s2.betas.toarray()).max() < (2e-4 if f32 else 1e-11)
+    assert np.abs(s1.intercepts - s2.intercepts).max() < (2e-4 if f32 else 1e-11)
+    assert len(so.lmdas) == len(s1.lmdas)
+    assert np.abs(s1.betas.toarray() - so.betas.toarray()).max() < (5e-3 if f32 else 1e-6)
+    assert (s1.betas[-1].toarray() != 0).sum() >= 8 * K
 
 
 # ---- per-group constraints on multi-response fits (reference solver.py:640-659: the list goes through to the view's solver;

@@ -480,6 +480,18 @@ inline unsigned grid1d(int64_t n, int bt, int64_t cap = 4096) {
 
 } // namespace
 
+// row splits of the nibble-table sweep of a 2-bit design (sweep_snp_lut_kernel): ~8000 workgroups of 256 columns (five are
+// resident per compute unit: six or more rounds, so that the last, partial round costs little), at least eight 256-row tiles
+// per split
+constexpr int kLutTile = 256;
+inline void lut_shape(int64_t n, int64_t ncols, int64_t& blocks_c, int64_t& ns, int64_t& rps) {
+    blocks_c = (ncols + kThreads - 1) / kThreads;
+    ns = std::max<int64_t>(1, (8192 + blocks_c - 1) / blocks_c);
+    ns = std::min(ns, std::max<int64_t>(1, n / (int64_t(kLutTile) * 8)));
+    rps = (n + ns - 1) / ns;
+    rps = ((rps + kLutTile - 1) / kLutTile) * kLutTile;
+    ns = (n + rps - 1) / rps;
+}
 int64_t sweep_work_elems(int64_t n, int64_t ncols) {
     if (ncols <= 0) return 0;
     int64_t blocks_c, rps;
@@ -488,7 +500,9 @@ int64_t sweep_work_elems(int64_t n, int64_t ncols) {
     int64_t a = int64_t(ns) * ncols;
     sweep_shape(n, ncols, 4, blocks_c, ns, rps);
     int64_t b = int64_t(ns) * ncols;
-    return (a > b ? a : b) + 16;
+    int64_t lns;
+    lut_shape(n, ncols, blocks_c, lns, rps);
+    return std::max(std::max(a, b), lns * ncols) + 16;
 }
 
 template <class T>
@@ -517,9 +531,98 @@ void launch_sweep(const DenseView<T>& X, const T* v, T* out, int64_t c0, int64_t
     else
         sweep_dispatch<T, DenseAcc<T>, 1>(acc, v, out, X.n, c0, ncols, cols, sub_scale, sub_vec, square, work, s);
 }
+// ---- 2-bit sweep through nibble tables ------------------------------------------------------------------------------
+// out[c] = sum_i x_ic v_i with x in {0, 1, 2, impute_c}.  The decode-and-multiply form above spends five integer / convert
+// instructions and a multiply-add per call and is bound by their issue (5.8 ms for the 500k x 50k design of config 4, 1.08 TB/s).
+// Here a thread owns a COLUMN and a workgroup walks row tiles of TR = 256 rows: per tile it first builds, in LDS, for every
+// pair of rows (i, i+1) the 16 possible contributions of a nibble (two calls),
+//     T012[b] = c0' v_i + c1' v_{i+1}   (c' = code if code < 3 else 0),     T3[b] = [c0 = 3] v_i + [c1 = 3] v_{i+1},
+// — the vector v is the same for all columns, so a table serves every column of the workgroup — and then every thread adds
+// one T012 and one T3 entry per nibble of its column (two shifts/masks, two LDS reads, two additions for two calls); the
+// imputed value enters once at the end, S012 + impute_c * S3.  A table of 16 entries of 8 bytes is one row of LDS banks:
+// any mix of indices over the lanes is conflict-free.  Columns are 64-byte aligned and padded (SnpView::ldb): a tile of a
+// column is four 16-byte loads.  Fixed summation order; row splits leave partials for sweep_reduce_kernel as above.
+constexpr int LUT_TR = 256;
+static_assert(LUT_TR == 256, "lut_shape's tile");
+template <class T>
+__global__ __launch_bounds__(kThreads) void sweep_snp_lut_kernel(const uint8_t* __restrict__ bits, int64_t ldb,
+                                                                 const T* __restrict__ impute, const T* __restrict__ v,
+                                                                 T* __restrict__ out, int64_t n, int64_t c0, int64_t ncols,
+                                                                 const int32_t* __restrict__ cols, int64_t rows_per_split,
+                                                                 int nsplit, const T* __restrict__ sub_scale,
+                                                                 const T* __restrict__ sub_vec) {
+    constexpr int NP = LUT_TR / 2;              // row pairs per tile
+    __shared__ T t012[NP][16];
+    __shared__ T t3[NP][16];
+    const int tid = threadIdx.x;
+    const int split = blockIdx.y;
+    const int64_t r0 = int64_t(split) * rows_per_split; // (a multiple of LUT_TR)
+    const int64_t r1 = min(n, r0 + rows_per_split);
+    int64_t c = int64_t(blockIdx.x) * kThreads + tid;
+    const bool live = c < ncols;
+    if (!live) c = ncols - 1;
+    const int64_t cj = cols ? int64_t(cols[c]) : c0 + c;
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    const u4_t* colp = reinterpret_cast<const u4_t*>(bits + cj * ldb);
+    // table role of this thread: pair tid / 2, entries 8 * (tid & 1) .. + 8
+    const int tp = tid >> 1, te0 = (tid & 1) * 8;
+    T a = T(0), b = T(0);
+    for (int64_t base = r0; base < r1; base += LUT_TR) {
+        const int64_t q0 = base / 64; // tile offset in 16-byte units (LUT_TR calls = 64 bytes = 4 units)
+        u4_t w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = __builtin_nontemporal_load(colp + q0 + u);
+        const int64_t i0 = base + 2 * tp;
+        const T v0 = i0 < n ? v[i0] : T(0), v1 = i0 + 1 < n ? v[i0 + 1] : T(0);
+        __syncthreads(); // the previous tile's lookups are done
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = te0 + e, k0 = idx & 3, k1 = idx >> 2;
+            t012[tp][idx] = (k0 < 3 ? T(k0) : T(0)) * v0 + (k1 < 3 ? T(k1) : T(0)) * v1;
+            t3[tp][idx] = (k0 == 3 ? v0 : T(0)) + (k1 == 3 ? v1 : T(0));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int pr = (u * 4 + h) * 8 + k; // row pair of this nibble (compile-time)
+                    const unsigned idx = (w[u][h] >> (4 * k)) & 15u;
+                    a += t012[pr][idx];
+                    b += t3[pr][idx];
+                }
+            }
+        }
+    }
+    if (!live) return;
+    T sres = fma(impute[cj], b, a);
+    if (nsplit == 1) {
+        if (sub_vec) sres -= sub_scale[0] * sub_vec[cj];
+        out[c] = sres;
+    } else {
+        out[int64_t(split) * ncols + c] = sres; // partial
+    }
+}
+
 template <class T>
 void launch_sweep_snp(const SnpView& X, const T* impute, const T* v, T* out, int64_t c0, int64_t ncols,
                       const int32_t* cols, const T* sub_scale, const T* sub_vec, bool square, T* work, hipStream_t s) {
+    if (!square && ncols >= 2048 && X.n >= 4096 && X.ldb % 64 == 0 && (reinterpret_cast<uintptr_t>(X.bits) % 64) == 0) {
+        // the same partial layout and reduce as sweep_dispatch (`work`: sweep_work_elems covers lut_shape's splits)
+        int64_t blocks_c, ns, rps;
+        lut_shape(X.n, ncols, blocks_c, ns, rps);
+        T* dst = ns == 1 ? out : work;
+        hipLaunchKernelGGL((sweep_snp_lut_kernel<T>), dim3((unsigned)blocks_c, (unsigned)ns), dim3(kThreads), 0, s, X.bits,
+                           X.ldb, impute, v, dst, X.n, c0, ncols, cols, rps, int(ns), sub_scale, sub_vec);
+        if (ns > 1) {
+            const int bt = 256;
+            hipLaunchKernelGGL((sweep_reduce_kernel<T>), dim3((unsigned)((ncols + bt - 1) / bt)), dim3(bt), 0, s, work, out,
+                               ncols, int(ns), c0, cols, sub_scale, sub_vec);
+        }
+        return;
+    }
     SnpAcc<T> acc{X.bits, X.ldb, impute};
     sweep_dispatch<T, SnpAcc<T>, VecOf<T>::N>(acc, v, out, X.n, c0, ncols, cols, sub_scale, sub_vec, square, work, s);
 }

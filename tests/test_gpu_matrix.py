@@ -46,6 +46,35 @@ def test_snp_calldata(hip, n, p, dtype):
     run_naive(ad.matrix.snp_calldata(calldata, dtype=dtype), Xd, dtype)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,p", [(4099, 2050), (9000, 2600), (4096, 2048)])
+def test_snp_wide_sweep_through_nibble_tables(hip, n, p, dtype):
+    """Sizes that take the nibble-table form of the 2-bit sweep (sweep_snp_lut_kernel: >= 2048 columns, >= 4096 rows): rows
+    that do not fill the last 256-row tile, columns that do not fill the last 256-column workgroup, several row splits; an
+    all-missing and an all-zero column; full products and a column range."""
+    rng = np.random.RandomState(n + p)
+    calldata = rng.choice([0, 1, 2, -9], size=(n, p), p=[0.55, 0.3, 0.1, 0.05]).astype(np.int8)
+    calldata[:, 5] = -9
+    calldata[:, 6] = 0
+    imp = ad.matrix.compute_impute(calldata)
+    Xd = np.where(calldata < 0, imp[None], calldata).astype(np.float64)
+    X = ad.matrix.snp_calldata(calldata, dtype=dtype)
+    v = rng.normal(size=n).astype(dtype)
+    w = rng.uniform(0.5, 1.5, n).astype(dtype)
+    tol = 1e-11 if dtype == np.float64 else 2e-4
+    out = np.empty(p, dtype=dtype)
+    X.mul(v, w, out)
+    ref = Xd.T @ (v.astype(np.float64) * w)
+    assert np.abs(out - ref).max() <= tol * np.abs(ref).max()
+    j, q = 37, p - 137
+    outb = np.empty(q, dtype=dtype)
+    X.bmul(j, q, v, w, outb)
+    assert np.abs(outb - ref[j:j + q]).max() <= tol * np.abs(ref).max()
+    short = np.empty(100, dtype=dtype)                                # (the decode form, for comparison in one design)
+    X.bmul(j, 100, v, w, short)
+    assert np.abs(short - outb[:100]).max() <= tol * np.abs(ref).max()
+
+
 def test_snp_from_snpdat_file(hip, tmp_path):
     rng = np.random.RandomState(2)
     n, p = 700, 21

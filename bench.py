@@ -309,7 +309,7 @@ def measure(ctx, cfg, *, n, p, gs, alpha, dtype, L, steps, warmup, n_folds=8, cv
     sweep_roof = None
     if sweep_launches:
         ach = sweep_bytes / (sweep_avg * 1e-3) / 1e9
-        kname = "sweep_kernel" if cfg != 4 else "sweep_kernel<Snp2bit>"
+        kname = "sweep_kernel" if cfg != 4 else "sweep_snp_lut_kernel<Snp2bit, nibble tables>"
         sweep_roof = {
             "kernel": kname + " (grad = X^T (w*r) - rsum*xbar, full design)", "bound": "hbm", "achieved": ach,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

@@ -487,7 +487,7 @@ constexpr int kLutTile = 256;
 inline void lut_shape(int64_t n, int64_t ncols, int64_t& blocks_c, int64_t& ns, int64_t& rps) {
     blocks_c = (ncols + kThreads - 1) / kThreads;
     ns = std::max<int64_t>(1, (8192 + blocks_c - 1) / blocks_c);
-    ns = std::min(ns, std::max<int64_t>(1, n / (int64_t(kLutTile) * 8)));
+    ns = std::min<int64_t>(std::min(ns, std::max<int64_t>(1, n / (int64_t(kLutTile) * 8))), 65535);
     rps = (n + ns - 1) / ns;
     rps = ((rps + kLutTile - 1) / kLutTile) * kLutTile;
     ns = (n + rps - 1) / rps;
@@ -544,7 +544,8 @@ void launch_sweep(const DenseView<T>& X, const T* v, T* out, int64_t c0, int64_t
 // column is four 16-byte loads.  Fixed summation order; row splits leave partials for sweep_reduce_kernel as above.
 constexpr int LUT_TR = 256;
 static_assert(LUT_TR == 256, "lut_shape's tile");
-template <class T>
+// SQ: the squared design (x^2: the weighted column variances of an IRLS iteration): the table holds c'^2, the end impute^2.
+template <class T, bool SQ>
 __global__ __launch_bounds__(kThreads) void sweep_snp_lut_kernel(const uint8_t* __restrict__ bits, int64_t ldb,
                                                                  const T* __restrict__ impute, const T* __restrict__ v,
                                                                  T* __restrict__ out, int64_t n, int64_t c0, int64_t ncols,
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(kThreads) void sweep_snp_lut_kernel(const uint8_t* 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int idx = te0 + e, k0 = idx & 3, k1 = idx >> 2;
-            t012[tp][idx] = (k0 < 3 ? T(k0) : T(0)) * v0 + (k1 < 3 ? T(k1) : T(0)) * v1;
+            t012[tp][idx] = (k0 < 3 ? T(SQ ? k0 * k0 : k0) : T(0)) * v0 + (k1 < 3 ? T(SQ ? k1 * k1 : k1) : T(0)) * v1;
             t3[tp][idx] = (k0 == 3 ? v0 : T(0)) + (k1 == 3 ? v1 : T(0));
         }
         __syncthreads();
@@ -597,7 +598,8 @@ __global__ __launch_bounds__(kThreads) void sweep_snp_lut_kernel(const uint8_t* 
         }
     }
     if (!live) return;
-    T sres = fma(impute[cj], b, a);
+    const T imp = impute[cj];
+    T sres = fma(SQ ? imp * imp : imp, b, a);
     if (nsplit == 1) {
         if (sub_vec) sres -= sub_scale[0] * sub_vec[cj];
         out[c] = sres;
@@ -609,13 +611,17 @@ __global__ __launch_bounds__(kThreads) void sweep_snp_lut_kernel(const uint8_t* 
 template <class T>
 void launch_sweep_snp(const SnpView& X, const T* impute, const T* v, T* out, int64_t c0, int64_t ncols,
                       const int32_t* cols, const T* sub_scale, const T* sub_vec, bool square, T* work, hipStream_t s) {
-    if (!square && ncols >= 2048 && X.n >= 4096 && X.ldb % 64 == 0 && (reinterpret_cast<uintptr_t>(X.bits) % 64) == 0) {
+    if (ncols >= 512 && X.n >= 4096 && X.ldb % 64 == 0 && (reinterpret_cast<uintptr_t>(X.bits) % 64) == 0) {
         // the same partial layout and reduce as sweep_dispatch (`work`: sweep_work_elems covers lut_shape's splits)
         int64_t blocks_c, ns, rps;
         lut_shape(X.n, ncols, blocks_c, ns, rps);
         T* dst = ns == 1 ? out : work;
-        hipLaunchKernelGGL((sweep_snp_lut_kernel<T>), dim3((unsigned)blocks_c, (unsigned)ns), dim3(kThreads), 0, s, X.bits,
-                           X.ldb, impute, v, dst, X.n, c0, ncols, cols, rps, int(ns), sub_scale, sub_vec);
+        if (square)
+            hipLaunchKernelGGL((sweep_snp_lut_kernel<T, true>), dim3((unsigned)blocks_c, (unsigned)ns), dim3(kThreads), 0, s,
+                               X.bits, X.ldb, impute, v, dst, X.n, c0, ncols, cols, rps, int(ns), sub_scale, sub_vec);
+        else
+            hipLaunchKernelGGL((sweep_snp_lut_kernel<T, false>), dim3((unsigned)blocks_c, (unsigned)ns), dim3(kThreads), 0, s,
+                               X.bits, X.ldb, impute, v, dst, X.n, c0, ncols, cols, rps, int(ns), sub_scale, sub_vec);
         if (ns > 1) {
             const int bt = 256;
             hipLaunchKernelGGL((sweep_reduce_kernel<T>), dim3((unsigned)((ncols + bt - 1) / bt)), dim3(bt), 0, s, work, out,

@@ -49,7 +49,7 @@ def test_snp_calldata(hip, n, p, dtype):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("n,p", [(4099, 2050), (9000, 2600), (4096, 2048)])
 def test_snp_wide_sweep_through_nibble_tables(hip, n, p, dtype):
-    """Sizes that take the nibble-table form of the 2-bit sweep (sweep_snp_lut_kernel: >= 2048 columns, >= 4096 rows): rows
+    """Sizes that take the nibble-table form of the 2-bit sweep (sweep_snp_lut_kernel: >= 512 columns, >= 4096 rows): rows
     that do not fill the last 256-row tile, columns that do not fill the last 256-column workgroup, several row splits; an
     all-missing and an all-zero column; full products and a column range."""
     rng = np.random.RandomState(n + p)
@@ -70,6 +70,10 @@ def test_snp_wide_sweep_through_nibble_tables(hip, n, p, dtype):
     outb = np.empty(q, dtype=dtype)
     X.bmul(j, q, v, w, outb)
     assert np.abs(outb - ref[j:j + q]).max() <= tol * np.abs(ref).max()
+    sq = np.empty(p, dtype=dtype)                                     # (the squared design: weighted column variances)
+    X.sq_mul(w, sq)
+    ref2 = (Xd ** 2).T @ w.astype(np.float64)
+    assert np.abs(sq - ref2).max() <= tol * np.abs(ref2).max()
     short = np.empty(100, dtype=dtype)                                # (the decode form, for comparison in one design)
     X.bmul(j, 100, v, w, short)
     assert np.abs(short - outb[:100]).max() <= tol * np.abs(ref).max()

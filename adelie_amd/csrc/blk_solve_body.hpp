@@ -487,17 +487,35 @@ __device__ __forceinline__ void blk_solve_la_body(const CdBlkParams<T>& p, int j
     const T R0 = T(1) / N0, R1 = T(1) / N1;
     T nb0 = b0, nb1 = b1;
     T gc0 = T(0), gc1 = T(0);
-#define AHIP_LA_VISIT(GREG, BREG, AREG, LREG, NREG, RREG, NBREG, GCREG, IL)                                           \
+    // The per-coordinate constants of a visit (variance, threshold, denominator and its reciprocal, old coefficient) go through
+    // LDS — six values per coordinate in the space of the consumed correction partials, read by all lanes at one address
+    // (broadcast) ONE VISIT AHEAD — instead of ten v_readlane out of the lanes' registers on the dependent chain of the visit;
+    // only the current gradient, which the visits before it changed, still comes out of a register.  Same arithmetic, bit for
+    // bit (config 4: cd 3488 -> 3444 ms; the 128-visit launches of the Gaussian paths are bound elsewhere: unchanged).
+    T* cst = corr; // [BLK][6]
+    static_assert(6 <= NG, "the constants fit where the correction partials were");
+    {
+        T* c0p = cst + lane * 6;
+        c0p[0] = A0; c0p[1] = L0; c0p[2] = N0; c0p[3] = R0; c0p[4] = b0;
+        T* c1p = cst + (lane + 64) * 6;
+        c1p[0] = A1; c1p[1] = L1; c1p[2] = N1; c1p[3] = R1; c1p[4] = b1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    T pA = cst[0], pL = cst[1], pN = cst[2], pR = cst[3], pB = cst[4];
+#define AHIP_LA_VISIT(GREG, NBREG, GCREG, IL)                                                                         \
     {                                                                                                                  \
+        const T A = pA, thr = pL, den = pN, rden = pR, bi = pB;                                                        \
+        {                                                                                                              \
+            const T* cn = cst + min(i + 1, BLK - 1) * 6;  /* the next visit's constants */                             \
+            pA = cn[0]; pL = cn[1]; pN = cn[2]; pR = cn[3]; pB = cn[4];                                                \
+        }                                                                                                              \
         const T dc0 = D[i * BLK + lane], dc1 = D[i * BLK + lane + 64];                                                 \
         const T gcur = rdlane(GREG, IL);                                                                               \
-        const T bi = rdlane(BREG, IL), A = rdlane(AREG, IL);                                                           \
         const T gk = fma(bi, A, gcur);                    /* pin_naive:85-89 */                                       \
-        const T v = fabs(gk) - rdlane(LREG, IL);          /* pin_base:181-195 */                                      \
+        const T v = fabs(gk) - thr;                       /* pin_base:181-195 */                                      \
         T ak = T(0);                                                                                                   \
         if (v > T(0)) {                                                                                                \
             const T x = copysign(v, gk);                                                                               \
-            const T den = rdlane(NREG, IL), rden = rdlane(RREG, IL);                                                   \
             const T q0 = x * rden;                                                                                     \
             const T r = fma(-q0, den, x);                                                                              \
             ak = fma(r, rden, q0);                                                                                     \
@@ -511,8 +529,8 @@ __device__ __forceinline__ void blk_solve_la_body(const CdBlkParams<T>& p, int j
     }
     {
         const int n0 = nb < 64 ? nb : 64;
-        for (int i = 0; i < n0; ++i) AHIP_LA_VISIT(g0, b0, A0, L0, N0, R0, nb0, gc0, i)
-        for (int i = 64; i < nb; ++i) AHIP_LA_VISIT(g1, b1, A1, L1, N1, R1, nb1, gc1, i - 64)
+        for (int i = 0; i < n0; ++i) AHIP_LA_VISIT(g0, nb0, gc0, i)
+        for (int i = 64; i < nb; ++i) AHIP_LA_VISIT(g1, nb1, gc1, i - 64)
     }
 #undef AHIP_LA_VISIT
     // ---- bookkeeping of the block, lane-parallel (as blk_solve_body) ----------------------------------------------------

@@ -278,6 +278,36 @@ def test_panel_engine_binomial_snp(hip, oracle, monkeypatch, dtype):
     assert_same_path(a, b, 1e-6 if dtype == np.float64 else 5e-3)
 
 
+@pytest.mark.parametrize("family", ["gaussian", "binomial"])
+def test_snp_paths_with_the_nibble_table_sweeps(hip, oracle, family):
+    """A 2-bit design large enough that the solver's own sweeps (full design, column lists of the KKT check, the squared design
+    of the IRLS variances) take the nibble-table form (>= 4096 rows, >= 512 columns) at the default engine thresholds."""
+    rng = np.random.default_rng(17)
+    n, p = 4500, 1500
+    u = rng.random((n, p))
+    cd = np.zeros((n, p), dtype=np.int8, order="F")
+    cd[u < 0.25] = 1
+    cd[(u >= 0.25) & (u < 0.30)] = 2
+    cd[u >= 0.93] = -9
+    imp = ad.matrix.compute_impute(cd)
+    Xd = np.where(cd < 0, imp[None, :], cd).astype(np.float64)
+    beta = rng.standard_normal(p) * (rng.random(p) < 0.05)
+    eta = Xd @ beta
+    eta = (eta - eta.mean()) / eta.std()
+    if family == "gaussian":
+        yg = eta + 0.5 * rng.standard_normal(n)
+        glm = lambda: ad.glm.gaussian(yg)
+    else:
+        y = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(np.float64)
+        glm = lambda: ad.glm.binomial(y)
+    kw = dict(early_exit=False, lmda_path_size=15, min_ratio=0.05, tol=1e-12, irls_tol=1e-10, progress_bar=False)
+    a = ad.grpnet(ad.matrix.snp_calldata(cd, imp), glm(), **kw)
+    b = ad.grpnet(oracle.snp_calldata(cd, imp), glm(), **kw)
+    assert a.error == "" and b.error == ""
+    assert (a.betas[-1].toarray() != 0).sum() > 50
+    assert_same_path(a, b, 1e-6)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("bsz", [32, 64])
 def test_panel_engine_small_blocks(hip, oracle, monkeypatch, bsz, dtype):

@@ -423,13 +423,116 @@ __device__ __forceinline__ void syrk_body_snp(const SnpAcc<T>& X, const T* __res
     else syrk_store<T, SyrkPlan<3, SB>, NA, SB>(P, lane, acc);
 }
 
+// SB = 64 on a 2-bit design, fed from registers.  The staged body above decodes every call once per workgroup but pays two
+// barriers and an LDS round trip per 32 rows: alone it reaches 0.44 of the f64 MFMA rate, in a config-4 path 0.28.  Here every
+// WAVE owns a quarter of the workgroup's rows and all ten lower-triangle tiles: lane (fr, fk) loads the 32-bit word (16 calls)
+// of column 16 t + fr for the four column tiles t, decodes call 4 s + fk of each for s = 0..3 — the element it has to supply to
+// v_mfma_16x16x4 both as the row-tile operand and, times the row's weight, as the column-tile operand — and issues ten MFMAs
+// per s: 16 decodes and 16 multiplies feed 40 MFMAs, nothing goes through LDS and nothing waits at a barrier until the four
+// waves add up their tiles at the end.  Same partial layout as syrk_store.
+template <class T>
+__device__ __forceinline__ void syrk_body_snp_reg64(const SnpAcc<T>& X, const T* __restrict__ w, const int32_t* __restrict__ cols,
+                                                    int32_t M, int64_t k0, int64_t kend, T* __restrict__ P) {
+    constexpr int SB = 64, NT = 10;
+    constexpr int TR[NT] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3};
+    constexpr int TC[NT] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
+    __shared__ T red[2][NT * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    typename Mfma<T>::acc_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = T(0);
+    // this wave's rows: a quarter of [k0, kend), whole 16-row words (k0 is a multiple of 256)
+    const int64_t len = kend > k0 ? kend - k0 : 0;
+    const int64_t q16 = ((len + 63) / 64) * 16; // rows per wave, a multiple of 16
+    const int64_t r0 = k0 + int64_t(wv) * q16, r1 = min(kend, r0 + q16);
+    const unsigned* cp[4];
+    T imp[4];
+    bool ok[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int c = 16 * t + fr;
+        ok[t] = c < M;
+        const int64_t col = cols[ok[t] ? c : 0];
+        cp[t] = reinterpret_cast<const unsigned*>(X.bits + col * X.ldb);
+        imp[t] = X.impute[col];
+    }
+    unsigned wd[4];
+    T wr[4];
+    auto fetch = [&](int64_t r) { // the 16 rows from r on
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wd[t] = ok[t] ? __builtin_nontemporal_load(cp[t] + (r >> 4)) : 0u;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int64_t i = r + 4 * s4 + fk;
+            wr[s4] = i < kend ? w[i] : T(0);
+        }
+    };
+    if (r0 < r1) fetch(r0);
+    for (int64_t r = r0; r < r1; r += 16) {
+        unsigned cw[4];
+        T cwr[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { cw[t] = wd[t]; cwr[t] = wr[t]; }
+        if (r + 16 < r1) fetch(r + 16);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            T a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const unsigned c = (cw[t] >> (2 * (4 * s4 + fk))) & 3u;
+                const T x = ok[t] ? (c == 3u ? imp[t] : T(c)) : T(0);
+                a[t] = x;
+                b[t] = x * cwr[s4];
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = Mfma<T>::run(a[TR[t]], b[TC[t]], acc[t]);
+        }
+    }
+    // the four waves' tiles, added in a fixed order: (w0 + w2) + (w1 + w3), two 20 KB slots of LDS
+    auto put = [&](int slot) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[slot][(t * 4 + e) * 64 + lane] = acc[t][e];
+    };
+    auto add = [&](int slot) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][e] += red[slot][(t * 4 + e) * 64 + lane];
+    };
+    if (wv >= 2) put(wv - 2);
+    __syncthreads();
+    if (wv < 2) add(wv);
+    __syncthreads();
+    if (wv == 1) put(0);
+    __syncthreads();
+    if (wv == 0) {
+        add(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) P[(TC[t] * 16 + fr) * SB + TR[t] * 16 + Mfma<T>::row(lane, e)] = acc[t][e];
+    }
+}
+
 template <class A> struct IsSnpAcc { static constexpr bool value = false; };
 template <class T> struct IsSnpAcc<SnpAcc<T>> { static constexpr bool value = true; };
 
 template <class T, class Acc, bool VECOK, int SB>
 __device__ __forceinline__ void syrk_any(const Acc& X, const T* __restrict__ w, const int32_t* __restrict__ cols, int32_t M,
                                          int64_t k0, int64_t kend, T* __restrict__ P) {
-    if constexpr (IsSnpAcc<Acc>::value) syrk_body_snp<T, SB>(X, w, cols, M, k0, kend, P);
+    if constexpr (IsSnpAcc<Acc>::value && SB == 64) {
+#ifdef AHIP_SYRK_STAGED
+        syrk_body_snp<T, SB>(X, w, cols, M, k0, kend, P);
+#else
+        syrk_body_snp_reg64<T>(X, w, cols, M, k0, kend, P);
+#endif
+    } else if constexpr (IsSnpAcc<Acc>::value) syrk_body_snp<T, SB>(X, w, cols, M, k0, kend, P);
     else syrk_body<T, Acc, VECOK, SB>(X, w, cols, M, k0, kend, P);
 }
 

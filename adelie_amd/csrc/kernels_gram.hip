@@ -445,11 +445,12 @@ __device__ __forceinline__ void syrk_body_snp_reg64(const SnpAcc<T>& X, const T*
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[t][e] = T(0);
-    // this wave's rows: a quarter of [k0, kend), whole 16-row words (k0 is a multiple of 256)
+    // this wave's rows: a quarter of [k0, kend) in whole 64-row units (k0 is a multiple of 256): one 16-byte load per column
+    // tile and lane brings 64 rows, requested a whole unit (1.3 k MFMA cycles x 4) ahead of its use
     const int64_t len = kend > k0 ? kend - k0 : 0;
-    const int64_t q16 = ((len + 63) / 64) * 16; // rows per wave, a multiple of 16
-    const int64_t r0 = k0 + int64_t(wv) * q16, r1 = min(kend, r0 + q16);
-    const unsigned* cp[4];
+    const int64_t q64 = ((len + 255) / 256) * 64; // rows per wave
+    const int64_t r0 = k0 + int64_t(wv) * q64, r1 = min(kend, r0 + q64);
+    const u4v_t* cp[4];
     T imp[4];
     bool ok[4];
 #pragma unroll
@@ -457,39 +458,47 @@ __device__ __forceinline__ void syrk_body_snp_reg64(const SnpAcc<T>& X, const T*
         const int c = 16 * t + fr;
         ok[t] = c < M;
         const int64_t col = cols[ok[t] ? c : 0];
-        cp[t] = reinterpret_cast<const unsigned*>(X.bits + col * X.ldb);
+        cp[t] = reinterpret_cast<const u4v_t*>(X.bits + col * X.ldb);
         imp[t] = X.impute[col];
     }
-    unsigned wd[4];
-    T wr[4];
-    auto fetch = [&](int64_t r) { // the 16 rows from r on
+    u4v_t wd[4];
+    T wr[16];
+    auto fetch = [&](int64_t r) { // the 64 rows from r on
 #pragma unroll
-        for (int t = 0; t < 4; ++t) wd[t] = ok[t] ? __builtin_nontemporal_load(cp[t] + (r >> 4)) : 0u;
+        for (int t = 0; t < 4; ++t) wd[t] = ok[t] ? __builtin_nontemporal_load(cp[t] + (r >> 6)) : u4v_t{0, 0, 0, 0};
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
+        for (int s4 = 0; s4 < 16; ++s4) {
             const int64_t i = r + 4 * s4 + fk;
             wr[s4] = i < kend ? w[i] : T(0);
         }
     };
     if (r0 < r1) fetch(r0);
-    for (int64_t r = r0; r < r1; r += 16) {
-        unsigned cw[4];
-        T cwr[4];
+    for (int64_t r = r0; r < r1; r += 64) {
+        u4v_t cw[4];
+        T cwr[16];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { cw[t] = wd[t]; cwr[t] = wr[t]; }
-        if (r + 16 < r1) fetch(r + 16);
+        for (int t = 0; t < 4; ++t) cw[t] = wd[t];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            T a[4], b[4];
+        for (int s4 = 0; s4 < 16; ++s4) cwr[s4] = wr[s4];
+        if (r + 64 < r1) fetch(r + 64);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const unsigned c = (cw[t] >> (2 * (4 * s4 + fk))) & 3u;
-                const T x = ok[t] ? (c == 3u ? imp[t] : T(c)) : T(0);
-                a[t] = x;
-                b[t] = x * cwr[s4];
+        for (int g = 0; g < 4; ++g) {     // 16-row word g of the unit
+            unsigned sh[4];               // the word with this lane's four calls at bits 0, 8, 16, 24
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sh[t] = cw[t][g] >> (2 * fk);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                T a[4], b[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const unsigned c = (sh[t] >> (8 * s4)) & 3u; // (a column beyond M was fetched as zeros: code 0)
+                    const T x = c == 3u ? imp[t] : T(c);
+                    a[t] = x;
+                    b[t] = x * cwr[4 * g + s4];
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = Mfma<T>::run(a[TR[t]], b[TC[t]], acc[t]);
             }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = Mfma<T>::run(a[TR[t]], b[TC[t]], acc[t]);
         }
     }
     // the four waves' tiles, added in a fixed order: (w0 + w2) + (w1 + w3), two 20 KB slots of LDS

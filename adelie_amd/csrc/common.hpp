@@ -407,7 +407,8 @@ struct DevBuf {
 struct adelie_hip_design {
     int dtype = ADELIE_HIP_F64;
     int device = 0;
-    int kind = 0; // 0 dense, 1 snp (2-bit), 2 multi-response view of a dense or 2-bit design (adelie_hip_design_create_multi)
+    int kind = 0; // 0 dense, 1 snp (2-bit), 2 multi-response view of a dense or 2-bit design (adelie_hip_design_create_multi),
+                  // 3 sparse kept sparse (adelie_hip_design_create_csc: CSC + CSR copies of the entries, kernels_sparse.hip)
     // covariance-method matrix A (adelie_hip_design_create_cov_dense): a dense (p, p) design with n == p that only
     // adelie_hip_gaussian_cov_solve and the cov_* operations accept; cov == 2: the stored matrix is A^T (row-major input)
     int cov = 0;
@@ -420,7 +421,15 @@ struct adelie_hip_design {
     uint8_t* bits = nullptr;
     int64_t ldb = 0;
     void* impute = nullptr; // (p,) value_t on device
-    bool alias = false;     // shares X / bits / impute with another design (adelie_hip_design_alias): never frees them
+    bool alias = false;     // shares X / bits / impute / the sparse arrays with another design (adelie_hip_design_alias): never frees them
+    // sparse (kind 3): column-compressed and row-compressed copies of the stored entries
+    int64_t* cptr = nullptr;
+    int32_t* cidx = nullptr;
+    void* cval = nullptr;
+    int64_t* rptr = nullptr;
+    int32_t* rcol = nullptr;
+    void* rval = nullptr;
+    int64_t nnz = 0;
     // multi-response view: [1 (x) I_K, X (x) I_K] over the base's X (nb x pb); n = nb*K, p = (pb + micpt)*K
     int64_t mK = 0, nb = 0, pb = 0;
     int micpt = 0;
@@ -435,6 +444,9 @@ struct adelie_hip_design {
 
     template <class T> ahip::DenseView<T> dense() const { return ahip::DenseView<T>{static_cast<const T*>(X), n, p, ld}; }
     ahip::SnpView snp() const { return ahip::SnpView{bits, n, p, ldb}; }
+    template <class T> ahip::CscView<T> csc() const {
+        return ahip::CscView<T>{cptr, cidx, static_cast<const T*>(cval), rptr, rcol, static_cast<const T*>(rval), n, p, nnz};
+    }
     template <class T> ahip::MultiView<T> multi() const {
         return ahip::MultiView<T>{static_cast<const T*>(X), nb, pb, ld, static_cast<const T*>(ones), int32_t(mK), int32_t(micpt),
                                   bits, ldb, static_cast<const T*>(impute)};

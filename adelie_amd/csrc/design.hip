@@ -166,6 +166,8 @@ void op_sweep(adelie_hip_design* d, int64_t c0, int64_t ncols, const T* v, const
     }
     if (d->kind == 0)
         launch_sweep<T>(d->dense<T>(), dv, dout, c0, ncols, nullptr, nullptr, nullptr, square, work, s);
+    else if (d->kind == 3)
+        launch_sweep_csc<T>(d->csc<T>(), dv, dout, c0, ncols, nullptr, nullptr, nullptr, square, s);
     else
         launch_sweep_snp<T>(d->snp(), static_cast<const T*>(d->impute), dv, dout, c0, ncols, nullptr, nullptr, nullptr,
                             square, work, s);
@@ -182,6 +184,17 @@ void op_mul_batch(adelie_hip_design* d, const T* V, int64_t L, T* out) {
     const int64_t n = d->n, p = d->p;
     constexpr int64_t KB = 8;
     const bool is_dense = d->kind == 0;
+    if (d->kind == 3) { // sparse: one pass over the stored entries per vector
+        T* dv1 = scratch<T>(d->s_n1, size_t(n));
+        T* dout1 = scratch<T>(d->s_p1, size_t(p));
+        for (int64_t l = 0; l < L; ++l) {
+            AHIP_CHECK(hipMemcpyAsync(dv1, V + l * n, size_t(n) * sizeof(T), hipMemcpyHostToDevice, s));
+            launch_sweep_csc<T>(d->csc<T>(), dv1, dout1, 0, p, nullptr, nullptr, nullptr, false, s);
+            AHIP_CHECK(hipMemcpyAsync(out + l * p, dout1, size_t(p) * sizeof(T), hipMemcpyDeviceToHost, s));
+            AHIP_CHECK(hipStreamSynchronize(s));
+        }
+        return;
+    }
     T* dv = scratch<T>(d->s_n1, size_t(KB) * size_t(n));
     T* dout = scratch<T>(d->s_p1, size_t(KB) * size_t(p));
     // one work buffer for both kernels (a lone last vector goes through the single-vector sweep); the K-wide sweep's
@@ -228,10 +241,15 @@ void op_axpy(adelie_hip_design* d, int64_t j, int64_t q, const T* coef, T* out) 
     AHIP_CHECK(hipMemcpyAsync(dout, out, n * sizeof(T), hipMemcpyHostToDevice, s));
     AHIP_CHECK(hipMemcpyAsync(dcoef, coef, q * sizeof(T), hipMemcpyHostToDevice, s));
     AHIP_CHECK(hipMemcpyAsync(dcols, cols.data(), q * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    if (d->kind == 0)
+    if (d->kind == 0) {
         launch_axpy_cols<T>(d->dense<T>(), dcols, dcoef, nullptr, int32_t(q), T(1), dout, s);
-    else
+    } else if (d->kind == 3) {
+        T* delta = scratch<T>(d->s_misc, size_t(d->p));
+        AHIP_CHECK(hipMemsetAsync(delta, 0, size_t(d->p) * sizeof(T), s));
+        launch_axpy_cols_csc<T>(d->csc<T>(), dcols, dcoef, nullptr, int32_t(q), T(1), dout, delta, s);
+    } else {
         launch_axpy_cols_snp<T>(d->snp(), static_cast<const T*>(d->impute), dcols, dcoef, nullptr, int32_t(q), T(1), dout, s);
+    }
     AHIP_CHECK(hipMemcpyAsync(out, dout, n * sizeof(T), hipMemcpyDeviceToHost, s));
     AHIP_CHECK(hipStreamSynchronize(s));
 }
@@ -243,7 +261,7 @@ void op_cov(adelie_hip_design* d, int64_t j, int64_t q, const T* sw, T* out) {
     const int64_t n = d->n;
     T* dw = scratch<T>(d->s_n1, n);
     T* dC = scratch<T>(d->s_p1, q * q);
-    T* work = scratch<T>(d->s_work, gram_work_elems(n, q, q));
+    T* work = scratch<T>(d->s_work, d->kind == 3 ? gram_work_elems_csc(n) : gram_work_elems(n, q, q));
     int32_t* dcols = scratch<int32_t>(d->s_idx1, q);
     std::vector<int32_t> cols(q);
     for (int64_t k = 0; k < q; ++k) cols[k] = int32_t(j + k);
@@ -252,6 +270,8 @@ void op_cov(adelie_hip_design* d, int64_t j, int64_t q, const T* sw, T* out) {
     AHIP_CHECK(hipMemcpyAsync(dcols, cols.data(), q * sizeof(int32_t), hipMemcpyHostToDevice, s));
     if (d->kind == 0)
         launch_gram<T>(d->dense<T>(), dw, dcols, int32_t(q), 0, dcols, int32_t(q), 0, nullptr, false, dC, q, work, s);
+    else if (d->kind == 3)
+        launch_gram_csc<T>(d->csc<T>(), dw, dcols, int32_t(q), 0, dcols, int32_t(q), 0, nullptr, false, dC, q, work, s);
     else
         launch_gram_snp<T>(d->snp(), static_cast<const T*>(d->impute), dw, dcols, int32_t(q), 0, dcols, int32_t(q), 0,
                            nullptr, false, dC, q, work, s);
@@ -281,12 +301,15 @@ static void cov_lazy_t(adelie_hip_design* X, adelie_hip_design* A) {
     cols.reserve(size_t(p));
     ones.upload(h1.data(), size_t(n), s);
     cols.upload(hc.data(), size_t(p), s);
-    work.reserve(size_t(gram_work_elems(n, p, std::min<int64_t>(p, PANEL))));
+    work.reserve(size_t(X->kind == 3 ? gram_work_elems_csc(n) : gram_work_elems(n, p, std::min<int64_t>(p, PANEL))));
     for (int64_t c0 = 0; c0 < p; c0 += PANEL) {
         const int64_t nc = std::min<int64_t>(PANEL, p - c0);
         if (X->kind == 0)
             launch_gram<T>(X->dense<T>(), ones.p, cols.p, int32_t(p), 0, cols.p + c0, int32_t(nc), int32_t(c0), nullptr, false, C, ld,
                            work.p, s);
+        else if (X->kind == 3)
+            launch_gram_csc<T>(X->csc<T>(), ones.p, cols.p, int32_t(p), 0, cols.p + c0, int32_t(nc), int32_t(c0), nullptr, false, C,
+                               ld, work.p, s);
         else
             launch_gram_snp<T>(X->snp(), static_cast<const T*>(X->impute), ones.p, cols.p, int32_t(p), 0, cols.p + c0, int32_t(nc),
                                int32_t(c0), nullptr, false, C, ld, work.p, s);
@@ -314,6 +337,8 @@ void op_sp_tmul(adelie_hip_design* d, int64_t L, const int64_t* indptr, const in
     for (int64_t l0 = 0; l0 < L; l0 += Lp) {
         const int64_t lc = std::min(Lp, L - l0);
         if (d->kind == 0) launch_sp_tmul<T>(d->dense<T>(), lc, dptr + l0, dind, dval, dout, s);
+        else if (d->kind == 3)
+            launch_sp_tmul_csc<T>(d->csc<T>(), lc, dptr + l0, dind, dval, dout, scratch<T>(d->s_work, sp_tmul_work_elems_csc(d->p)), s);
         else launch_sp_tmul_snp<T>(d->snp(), static_cast<const T*>(d->impute), lc, dptr + l0, dind, dval, dout, s);
         AHIP_CHECK(hipMemcpyAsync(out + l0 * n, dout, size_t(lc) * n * sizeof(T), hipMemcpyDeviceToHost, s));
         AHIP_CHECK(hipStreamSynchronize(s));
@@ -361,6 +386,8 @@ void op_path_losses(adelie_hip_design* d, int kind, int64_t L, const int64_t* in
     for (int64_t l0 = 0; l0 < L; l0 += Lp) {
         const int64_t lc = std::min(Lp, L - l0);
         if (d->kind == 0) launch_sp_tmul<T>(d->dense<T>(), lc, dptr + l0, dind, dval, dout, s);
+        else if (d->kind == 3)
+            launch_sp_tmul_csc<T>(d->csc<T>(), lc, dptr + l0, dind, dval, dout, scratch<T>(d->s_work, sp_tmul_work_elems_csc(d->p)), s);
         else launch_sp_tmul_snp<T>(d->snp(), static_cast<const T*>(d->impute), lc, dptr + l0, dind, dval, dout, s);
         for (int64_t l = 0; l < lc; ++l) {
             launch_glm_loss2<T>(kind, dy, dwa, dwb, dout + l * n, intercepts[l0 + l], doff, n, sums, s);
@@ -437,6 +464,8 @@ void op_multi_path_losses(adelie_hip_design* d, int kind, int K, int64_t L, cons
     for (int64_t l0 = 0; l0 < L; l0 += Lp) {
         const int64_t lc = std::min(Lp, L - l0);
         if (d->kind == 0) launch_sp_tmul<T>(d->dense<T>(), lc * K, dptr + l0 * K, dind, dval, dout, s);
+        else if (d->kind == 3)
+            launch_sp_tmul_csc<T>(d->csc<T>(), lc * K, dptr + l0 * K, dind, dval, dout, scratch<T>(d->s_work, sp_tmul_work_elems_csc(d->p)), s);
         else launch_sp_tmul_snp<T>(d->snp(), static_cast<const T*>(d->impute), lc * K, dptr + l0 * K, dind, dval, dout, s);
         for (int64_t l = 0; l < lc; ++l) {
             launch_multi_loss2<T>(kind, dy, dwa, dwb, dout + size_t(l) * nK, dicpt + (l0 + l) * K, doff, n, K, sums, s);
@@ -528,6 +557,7 @@ void derive_t(adelie_hip_design* src, adelie_hip_design* d, const int64_t* rows,
     }
     // the source's stream may still be writing it (e.g. its own creation): order after it
     AHIP_CHECK(hipStreamSynchronize(src->stream));
+    if (src->kind == 3) throw make_core_error("derived designs of a sparse design are composed on the host (adelie_amd.matrix).");
     if (src->kind == 0) launch_derive_dense<T>(src->dense<T>(), nout, pout, drows, dcols, dc, ds, X, ld, s);
     else launch_derive_dense_snp<T>(src->snp(), static_cast<const T*>(src->impute), nout, pout, drows, dcols, dc, ds, X, ld, s);
     AHIP_CHECK(hipStreamSynchronize(s));
@@ -552,6 +582,7 @@ void concat_t(adelie_hip_design* const* srcs, int64_t k, int axis, adelie_hip_de
         adelie_hip_design* src = srcs[m];
         AHIP_CHECK(hipStreamSynchronize(src->stream));
         T* dst = axis == 1 ? X + off * ld : X + off;
+        if (src->kind == 3) throw make_core_error("concatenations with a sparse design are composed on the host (adelie_amd.matrix).");
         if (src->kind == 0) launch_derive_dense<T>(src->dense<T>(), src->n, src->p, nullptr, nullptr, nullptr, nullptr, dst, ld, s);
         else launch_derive_dense_snp<T>(src->snp(), static_cast<const T*>(src->impute), src->n, src->p, nullptr, nullptr,
                                         nullptr, nullptr, dst, ld, s);
@@ -721,6 +752,58 @@ int adelie_hip_design_create_sparse(const int64_t* indptr, const int32_t* indice
     try {
         if (dtype == ADELIE_HIP_F64) create_sparse_t<double>(d, indptr, indices, values);
         else create_sparse_t<float>(d, indptr, indices, values);
+    } catch (...) {
+        adelie_hip_design_destroy(d);
+        throw;
+    }
+    *out = d;
+    ABI_CATCH
+}
+
+int adelie_hip_design_create_csc(const int64_t* indptr, const int32_t* indices, const void* values, const int64_t* row_indptr,
+                                 const int32_t* row_indices, const void* row_values, int64_t n, int64_t p, int dtype, int device,
+                                 adelie_hip_design** out) {
+    ABI_TRY
+    if (!indptr || !row_indptr || !out) throw make_core_error("null argument.");
+    if (n <= 0 || p <= 0) throw make_core_error("matrix must have positive dimensions.");
+    if (n >= (int64_t(1) << 31)) throw make_core_error("number of rows must fit in int32.");
+    if (indptr[0] != 0 || row_indptr[0] != 0) throw make_core_error("sparse(): indptr must start at 0.");
+    for (int64_t j = 0; j < p; ++j)
+        if (indptr[j + 1] < indptr[j]) throw make_core_error("sparse(): indptr must be non-decreasing.");
+    for (int64_t i = 0; i < n; ++i)
+        if (row_indptr[i + 1] < row_indptr[i]) throw make_core_error("sparse(): indptr must be non-decreasing.");
+    const int64_t nnz = indptr[p];
+    if (row_indptr[n] != nnz) throw make_core_error("sparse(): the two compressed forms must hold the same entries.");
+    if (nnz > 0 && (!indices || !values || !row_indices || !row_values)) throw make_core_error("null argument.");
+    for (int64_t j = 0; j < p; ++j) // rows ascending and distinct inside a column (scipy: sort_indices + sum_duplicates)
+        for (int64_t k = indptr[j]; k < indptr[j + 1]; ++k) {
+            if (indices[k] < 0 || indices[k] >= n) throw make_core_error("sparse(): row index out of range.");
+            if (k > indptr[j] && indices[k] <= indices[k - 1]) throw make_core_error("sparse(): row indices must be sorted and distinct inside a column.");
+        }
+    for (int64_t k = 0; k < nnz; ++k)
+        if (row_indices[k] < 0 || row_indices[k] >= p) throw make_core_error("sparse(): column index out of range.");
+    adelie_hip_design* d = new_design(n, p, dtype, device);
+    try {
+        d->kind = 3;
+        d->nnz = nnz;
+        const size_t vs = dtype == ADELIE_HIP_F64 ? sizeof(double) : sizeof(float);
+        const size_t nz1 = size_t(std::max<int64_t>(nnz, 1));
+        AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->cptr), size_t(p + 1) * sizeof(int64_t)));
+        AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->cidx), nz1 * sizeof(int32_t)));
+        AHIP_CHECK(hipMalloc(&d->cval, nz1 * vs));
+        AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->rptr), size_t(n + 1) * sizeof(int64_t)));
+        AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->rcol), nz1 * sizeof(int32_t)));
+        AHIP_CHECK(hipMalloc(&d->rval, nz1 * vs));
+        hipStream_t s = d->stream;
+        AHIP_CHECK(hipMemcpyAsync(d->cptr, indptr, size_t(p + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        AHIP_CHECK(hipMemcpyAsync(d->rptr, row_indptr, size_t(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        if (nnz) {
+            AHIP_CHECK(hipMemcpyAsync(d->cidx, indices, size_t(nnz) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            AHIP_CHECK(hipMemcpyAsync(d->cval, values, size_t(nnz) * vs, hipMemcpyHostToDevice, s));
+            AHIP_CHECK(hipMemcpyAsync(d->rcol, row_indices, size_t(nnz) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            AHIP_CHECK(hipMemcpyAsync(d->rval, row_values, size_t(nnz) * vs, hipMemcpyHostToDevice, s));
+        }
+        AHIP_CHECK(hipStreamSynchronize(s));
     } catch (...) {
         adelie_hip_design_destroy(d);
         throw;
@@ -912,6 +995,9 @@ int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out) {
     d->bits = src->bits;
     d->ldb = src->ldb;
     d->impute = src->impute;
+    d->cptr = src->cptr; d->cidx = src->cidx; d->cval = src->cval;
+    d->rptr = src->rptr; d->rcol = src->rcol; d->rval = src->rval;
+    d->nnz = src->nnz;
     d->alias = true;
     d->batch_owner = src->batch_owner ? src->batch_owner : src;
     *out = d;
@@ -1036,6 +1122,10 @@ int adelie_hip_design_destroy(adelie_hip_design* d) {
     if (d->owned && d->X && !d->alias) (void)hipFree(d->X);
     if (d->bits && !d->alias) (void)hipFree(d->bits);
     if (d->impute && !d->alias) (void)hipFree(d->impute);
+    if (!d->alias) {
+        (void)hipFree(d->cptr); (void)hipFree(d->cidx); (void)hipFree(d->cval);
+        (void)hipFree(d->rptr); (void)hipFree(d->rcol); (void)hipFree(d->rval);
+    }
     if (d->ones) (void)hipFree(d->ones);
     if (d->batcher) adelie_hip_internal_free_batcher(d->batcher);
     delete d;

@@ -19,6 +19,19 @@ struct SnpView {
     int64_t n, p, ldb; // ldb = bytes per column (padded)
 };
 
+// Sparse design kept sparse (kernels_sparse.hip): the same matrix column-compressed (cptr / cidx / cval, row indices ascending
+// inside a column) and row-compressed (rptr / rcol / rval).
+template <class T>
+struct CscView {
+    const int64_t* cptr;
+    const int32_t* cidx;
+    const T* cval;
+    const int64_t* rptr;
+    const int32_t* rcol;
+    const T* rval;
+    int64_t n, p, nnz;
+};
+
 // ---- vector helpers -------------------------------------------------------------------------
 // out[i] = a[i] * b[i]
 template <class T> void launch_vmul(const T* a, const T* b, T* out, int64_t n, hipStream_t s);
@@ -34,6 +47,24 @@ template <class T>
 void launch_sweep_snp(const SnpView& X, const T* impute, const T* v, T* out, int64_t c0, int64_t ncols,
                       const int32_t* cols, const T* sub_scale, const T* sub_vec, bool square, T* work, hipStream_t s);
 int64_t sweep_work_elems(int64_t n, int64_t ncols);
+// sparse design: one wavefront per column over its stored entries (no work buffer)
+template <class T>
+void launch_sweep_csc(const CscView<T>& X, const T* v, T* out, int64_t c0, int64_t ncols, const int32_t* cols,
+                      const T* sub_scale, const T* sub_vec, bool square, hipStream_t s);
+// launch_gram on a sparse design; `work` holds gram_work_elems_csc(n) elements
+int64_t gram_work_elems_csc(int64_t n);
+template <class T>
+void launch_gram_csc(const CscView<T>& X, const T* w, const int32_t* mcols, int32_t M, int32_t m_pos0, const int32_t* ncols,
+                     int32_t N, int32_t n_pos0, const T* xm_by_col, bool center, T* C, int64_t ldc, T* work, hipStream_t s);
+// launch_axpy_cols on a sparse design (cols must be distinct); `delta_zeroed`: p elements, all zero on entry and on exit
+template <class T>
+void launch_axpy_cols_csc(const CscView<T>& X, const int32_t* cols, const T* coef, const int32_t* count_dev, int32_t count,
+                          T sign, T* out, T* delta_zeroed, hipStream_t s);
+// launch_sp_tmul on a sparse design; `work` holds sp_tmul_work_elems_csc(p) elements
+int64_t sp_tmul_work_elems_csc(int64_t p);
+template <class T>
+void launch_sp_tmul_csc(const CscView<T>& X, int64_t L, const int64_t* indptr, const int64_t* indices, const T* values, T* out,
+                        T* work, hipStream_t s);
 
 // ---- panel axpy: out[i] += sign * sum_k coef[k] * X[i, cols[k]],  k < *count_dev (or count if count_dev null)
 template <class T>

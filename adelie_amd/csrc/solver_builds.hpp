@@ -656,6 +656,10 @@
     SweepBatcher* batcher = nullptr; // non-null while this solver is registered for sweep batching
     bool is_screen(idx i) const { return in_screen[i] != 0; }
     bool dense() const { return D->kind == 0; }
+    // sparse design kept sparse (adelie_hip_design_create_csc): sweeps, Gram rows and residual updates walk its compressed
+    // forms; the solve runs on the full-Gram engines (the panel engines stream dense column slices)
+    bool sparse() const { return D->kind == 3; }
+    DevBuf<T> d_sp_delta; // p zeros between two residual updates
     // multi-response view (adelie_hip_design_create_multi): residual / weights live response-major on the device
     bool multi() const { return D->kind == 2; }
     int mk() const { return D->kind == 2 ? int(D->mK) : 1; } // class count handed to the GLM kernels

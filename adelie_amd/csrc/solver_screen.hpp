@@ -16,6 +16,10 @@
             ++cnt.n_sweeps_shared;
             return;
         }
+        if (sparse()) { // one wavefront per column over its stored entries (kernels_sparse.hip)
+            launch_sweep_csc<T>(D->csc<T>(), v, out, 0, ncols, cols, sub_scale, sub_vec, square, st);
+            return;
+        }
         T* work = d_work_sweep.reserve(size_t(sweep_work_elems(n, ncols)));
         if (dense()) launch_sweep<T>(D->dense<T>(), v, out, 0, ncols, cols, sub_scale, sub_vec, square, work, st);
         else launch_sweep_snp<T>(D->snp(), static_cast<const T*>(D->impute), v, out, 0, ncols, cols, sub_scale, sub_vec, square, work, st);
@@ -91,13 +95,24 @@
             launch_multi_axpy_cols<T>(D->multi<T>(), cols, coef, cnt_dev, sign, out, st);
             return;
         }
+        if (sparse()) { // coefficients scattered into a p-vector that is all zero between calls, then one CSR pass
+            if (d_sp_delta.cap < size_t(p)) {
+                d_sp_delta.reserve(size_t(p));
+                AHIP_CHECK(hipMemsetAsync(d_sp_delta.p, 0, size_t(p) * sizeof(T), st));
+            }
+            launch_axpy_cols_csc<T>(D->csc<T>(), cols, coef, cnt_dev, count, sign, out, d_sp_delta.p, st);
+            return;
+        }
         if (dense()) launch_axpy_cols<T>(D->dense<T>(), cols, coef, cnt_dev, count, sign, out, st);
         else launch_axpy_cols_snp<T>(D->snp(), static_cast<const T*>(D->impute), cols, coef, cnt_dev, count, sign, out, st);
     }
     void gram(const T* w, idx M, idx pos0, idx N, const T* xm, bool center) {
-        T* work = d_work_gram.reserve(size_t(gram_work_elems(n, M, N)));
+        T* work = d_work_gram.reserve(size_t(sparse() ? gram_work_elems_csc(n) : gram_work_elems(n, M, N)));
         t_gram.begin(st);
-        if (dense())
+        if (sparse())
+            launch_gram_csc<T>(D->csc<T>(), w, d_vcol.p, int32_t(M), 0, d_vcol.p + pos0, int32_t(N), int32_t(pos0), xm, center, d_C.p,
+                               ldc, work, st);
+        else if (dense())
             launch_gram<T>(D->dense<T>(), w, d_vcol.p, int32_t(M), 0, d_vcol.p + pos0, int32_t(N), int32_t(pos0), xm, center,
                            d_C.p, ldc, work, st);
         else

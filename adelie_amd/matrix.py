@@ -146,6 +146,8 @@ class _NativeMatrix:
         self._backend.check(self._backend.fn("design_alias")(self._handle, handle))
         out = _wrap(self._backend, handle, self.dtype, self._n_threads, kind=getattr(self, "_kind", None))
         out._alias_of = self
+        if hasattr(self, "_scipy"):
+            out._scipy, out._device = self._scipy, getattr(self, "_device", 0)
         return out
 
     def batch_stats(self):
@@ -483,6 +485,8 @@ def _multi_view(base, K, intercept):
         raise RuntimeError("adelie_amd: the multi-response view needs a resident (dense or 2-bit SNP) design as its base.")
     if int(K) < 1:
         raise RuntimeError("adelie_core: K must be >= 1.")
+    if _is_kept_sparse(base):  # the K-wide kernels stream dense or 2-bit column slices
+        base = _expanded(base)
     # (a 2-bit SNP base stays 2-bit: the K-wide sweep, panel step and Gram kernels decode a column's calls once for all K
     # responses -- matrix_naive_kronecker_eye.ipp over matrix_naive_snp_unphased.ipp)
     backend = base._backend
@@ -538,6 +542,18 @@ def concatenate(mats, *, axis: int = 0, n_threads: int = 1):
     if len(mats) == 0:
         raise RuntimeError("mats must be non-empty.")
     mats = [dense(m, n_threads=n_threads) if isinstance(m, np.ndarray) else m for m in mats]
+    if all(_is_kept_sparse(m) for m in mats):  # sparse pieces stay sparse (stacked on the host)
+        import scipy.sparse as _sp
+
+        if len({np.dtype(m.dtype) for m in mats}) != 1:
+            raise RuntimeError("All matrices must have the same dtype.")
+        if axis == 1 and len({m.rows() for m in mats}) != 1:
+            raise RuntimeError("All matrices must have the same number of rows.")
+        if axis == 0 and len({m.cols() for m in mats}) != 1:
+            raise RuntimeError("All matrices must have the same number of columns.")
+        stacked = (_sp.hstack if axis == 1 else _sp.vstack)([m._scipy for m in mats], format="csc")
+        return sparse(stacked, n_threads=n_threads, device=getattr(mats[0], "_device", 0), resident="csc")
+    mats = [_expanded(m) if _is_kept_sparse(m) else m for m in mats]
     for m in mats:
         if isinstance(m, (_MultiView, _OnesKron)) or not isinstance(m, _NativeMatrix):
             raise NotImplementedError(
@@ -609,13 +625,27 @@ def dense(mat, *, method: str = "naive", copy: bool = False, n_threads: int = 1,
     return _wrap(backend, handle, dtype.type, n_threads, kind="dense")
 
 
-def sparse(mat, *, method: str = "naive", copy: bool = False, n_threads: int = 1, device: int = 0):
+# matrix.sparse(resident="auto"): kept sparse below this density or above this dense size, expanded to a dense design otherwise
+_SPARSE_AUTO_DENSITY = 0.02
+_SPARSE_AUTO_DENSE_BYTES = 32 << 30
+
+
+def sparse(mat, *, method: str = "naive", copy: bool = False, n_threads: int = 1, device: int = 0, resident: str = "auto"):
     """Creates a design from a scipy sparse matrix (reference ``adelie.matrix.sparse``, ``matrix.py:1301-1385``).
 
-    The reference keeps the CSC arrays and walks them per operation (``matrix_naive_sparse.ipp``); here the entries are
-    scattered once into a dense column-major array in HBM (``adelie_hip_design_create_sparse``) and the design then
-    behaves as ``matrix.dense`` — same results up to the summation order of the dot products.  ``n * p`` values must fit
-    in device memory (288 GB per MI355X)."""
+    ``resident`` chooses what lives in HBM:
+
+    * ``"csc"`` — the matrix stays sparse, as in the reference (``matrix_naive_sparse.ipp`` walks the CSC arrays per
+      operation): the stored entries are uploaded column- and row-compressed (``adelie_hip_design_create_csc``, 24 bytes
+      per entry in f64), every operation streams the entries it needs, and ``grpnet`` runs its full-Gram engines on it.  A
+      design whose ``n * p`` values do not fit in device memory can run this way.  Duplicate entries are summed first.
+    * ``"dense"`` — the entries are scattered once into a dense column-major array (``adelie_hip_design_create_sparse``)
+      and the design then behaves as ``matrix.dense`` (panel engines, MFMA Gram builds): faster while ``n * p`` fits and
+      the matrix is not very sparse.
+    * ``"auto"`` (default) — ``"csc"`` when fewer than 2 % of the cells are stored or the dense form would exceed 32 GiB,
+      ``"dense"`` otherwise.
+
+    Same results either way up to the summation order of the dot products."""
     if not (isinstance(mat, csr_matrix) or isinstance(mat, csc_matrix)):
         raise TypeError("mat must be scipy.sparse.csr_matrix or scipy.sparse.csc_matrix.")
     if method == "cov":  # MatrixCovSparse (matrix_cov_sparse.ipp): a symmetric sparse (p, p) matrix, dense in HBM here
@@ -637,14 +667,48 @@ def sparse(mat, *, method: str = "naive", copy: bool = False, n_threads: int = 1
     if dtype not in (np.float32, np.float64):
         raise RuntimeError("mat must have dtype float32 or float64.")
     n, p = mat.shape
+    if resident not in ("auto", "csc", "dense"):
+        raise ValueError("resident must be one of 'auto', 'csc' or 'dense'.")
+    if resident == "auto":
+        cells = float(n) * float(p)
+        resident = "csc" if (mat.nnz < _SPARSE_AUTO_DENSITY * cells
+                             or cells * np.dtype(dtype).itemsize > _SPARSE_AUTO_DENSE_BYTES) else "dense"
+    backend = _abi.hip_backend()
+    handle = _abi.C.c_void_p()
+    if resident == "csc":
+        if not mat.has_canonical_format:
+            mat = mat.copy()
+            mat.sum_duplicates()
+        rows = mat.tocsr()
+        rows.sort_indices()
+        c_ptr = np.ascontiguousarray(mat.indptr, dtype=np.int64)
+        c_idx = np.ascontiguousarray(mat.indices, dtype=np.int32)
+        c_val = np.ascontiguousarray(mat.data, dtype=dtype)
+        r_ptr = np.ascontiguousarray(rows.indptr, dtype=np.int64)
+        r_idx = np.ascontiguousarray(rows.indices, dtype=np.int32)
+        r_val = np.ascontiguousarray(rows.data, dtype=dtype)
+        backend.check(backend.fn("design_create_csc")(
+            c_ptr.ctypes.data, c_idx.ctypes.data, c_val.ctypes.data, r_ptr.ctypes.data, r_idx.ctypes.data, r_val.ctypes.data,
+            n, p, _abi.dtype_code(dtype), device, handle))
+        out = _wrap(backend, handle, dtype, n_threads, kind="sparse")
+        out._scipy = mat  # derived designs (subset / concatenate / standardize / the multi-response view) start from it
+        out._device = device
+        return out
     indptr = np.ascontiguousarray(mat.indptr, dtype=np.int64)
     indices = np.ascontiguousarray(mat.indices, dtype=np.int32)
     values = np.ascontiguousarray(mat.data, dtype=dtype)
-    backend = _abi.hip_backend()
-    handle = _abi.C.c_void_p()
     backend.check(backend.fn("design_create_sparse")(
         indptr.ctypes.data, indices.ctypes.data, values.ctypes.data, n, p, _abi.dtype_code(dtype), device, handle))
     return _wrap(backend, handle, dtype, n_threads, kind="dense")
+
+
+def _is_kept_sparse(m):
+    return isinstance(m, _NativeMatrix) and getattr(m, "_kind", None) == "sparse"
+
+
+def _expanded(m):
+    """The dense-resident form of a design that is kept sparse (for the operations that need dense column slices)."""
+    return sparse(m._scipy, n_threads=m._n_threads, device=getattr(m, "_device", 0), resident="dense")
 
 
 def snp_unphased(io, *, dtype=np.float64, n_threads: int = 1, device: int = 0):
@@ -719,6 +783,21 @@ def snp_bed(bed, n: int, p: int = None, *, dtype=np.float64, n_threads: int = 1,
 def _derived(mat, rows, cols, centers, scales, n_threads):
     if not isinstance(mat, _NativeMatrix) or isinstance(mat, _MultiView):
         raise RuntimeError("adelie_amd: subset / standardize need a resident dense or SNP design.")
+    if _is_kept_sparse(mat):
+        if centers is None and scales is None:  # a subset of a sparse matrix is sparse: composed on the host, kept sparse
+            sub = mat._scipy
+            if rows is not None:
+                rows = np.asarray(rows, dtype=np.int64)
+                if rows.size and (rows.min() < 0 or rows.max() >= sub.shape[0]):
+                    raise RuntimeError("adelie_core: subset contains an out-of-range row index.")
+                sub = sub[rows]
+            if cols is not None:
+                cols = np.asarray(cols, dtype=np.int64)
+                if cols.size and (cols.min() < 0 or cols.max() >= sub.shape[1]):
+                    raise RuntimeError("adelie_core: subset contains an out-of-range column index.")
+                sub = sub[:, cols]
+            return sparse(sub.tocsc(), n_threads=n_threads, device=getattr(mat, "_device", 0), resident="csc")
+        mat = _expanded(mat)  # centring fills every cell: the standardized design is dense
     backend = mat._backend
     if not backend.has("design_create_derived"):
         raise NotImplementedError("this backend does not derive designs.")

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADELIE_HIP_ABI_VERSION 5
+#define ADELIE_HIP_ABI_VERSION 6
 
 enum adelie_hip_dtype { ADELIE_HIP_F32 = 0, ADELIE_HIP_F64 = 1 };
 enum adelie_hip_order { ADELIE_HIP_COL_MAJOR = 0, ADELIE_HIP_ROW_MAJOR = 1 };
@@ -83,6 +83,16 @@ int adelie_hip_design_create_dense(const void* host, int64_t n, int64_t p, int d
  * scattered into zeroed column-major HBM once, every later operation is the dense kernel.  Duplicate entries add up. */
 int adelie_hip_design_create_sparse(const int64_t* indptr, const int32_t* indices, const void* values, int64_t n, int64_t p,
                                     int dtype, int device, adelie_hip_design** out);
+/* Replaces MatrixNaiveSparse{32,64}F with the matrix KEPT SPARSE in HBM (matrix_naive_sparse.ipp walks the CSC arrays per
+ * operation, and so does this design): the stored entries are uploaded column-compressed (indptr p+1 int64, row indices int32
+ * ascending and distinct inside a column, values of `dtype`) and row-compressed (row_indptr n+1, column indices, values: the
+ * same entries, e.g. scipy's .tocsr()).  12 bytes per stored entry each way instead of n*p values: a design whose dense form
+ * does not fit can run.  Gradients and Gram rows stream the CSC copy (one wavefront per column), residual updates and X beta
+ * the CSR copy; grpnet_solve runs its full-Gram engines on it (the panel engines need dense column slices), constraints are
+ * not offered.  All MatrixNaiveBase operations below accept it; derived designs are composed on the host. */
+int adelie_hip_design_create_csc(const int64_t* indptr, const int32_t* indices, const void* values, const int64_t* row_indptr,
+                                 const int32_t* row_indices, const void* row_values, int64_t n, int64_t p, int dtype, int device,
+                                 adelie_hip_design** out);
 /* Adopt an (n,p) matrix that is ALREADY in device memory (e.g. a torch tensor's data_ptr);
  * not owned, must outlive the design. */
 int adelie_hip_design_adopt_dense_dev(const void* dev_ptr, int64_t n, int64_t p, int dtype, int order,

@@ -1,0 +1,200 @@
+"""A sparse design KEPT SPARSE in HBM (``matrix.sparse(..., resident="csc")``, ``adelie_hip_design_create_csc``,
+``kernels_sparse.hip``) — reference ``MatrixNaiveSparse`` (``matrix_naive_sparse.ipp``, ``adelie/matrix.py:1301-1385``).
+
+The reference's own check list for the class (``tests/test_matrix.py::test_naive_sparse`` -> ``run_naive``) runs against numpy
+on the densified matrix; paths solved on the sparse-resident design are compared with the CPU oracle on the dense copy of the
+same data (the oracle has no sparse class: it checks the numbers, not the storage)."""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import adelie_amd as ad
+from matrix_checks import run_naive
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_sparse(rng, n, p, density, dtype=np.float64):
+    D = (rng.normal(size=(n, p)) * (rng.uniform(size=(n, p)) < density)).astype(dtype)
+    return D
+
+
+def _csc(M, **kw):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return ad.matrix.sparse(M, resident="csc", **kw)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("fmt", ["csc", "csr"])
+@pytest.mark.parametrize("n,p,density", [(211, 37, 0.15), (1030, 90, 0.03), (70, 300, 0.4), (5, 3, 1.0)])
+def test_kept_sparse_design_runs_the_reference_check_list(hip, dtype, fmt, n, p, density):
+    rng = np.random.RandomState(4)
+    D = _rand_sparse(rng, n, p, density, dtype)
+    if p > 6:
+        D[:, 5] = 0  # an empty column
+    if n > 9:
+        D[7] = 0     # an empty row
+    M = sp.csc_matrix(D) if fmt == "csc" else sp.csr_matrix(D)
+    X = _csc(M)
+    assert X._kind == "sparse" and (X.rows(), X.cols()) == (n, p)
+    run_naive(X, np.asfortranarray(D), dtype)
+
+
+def test_kept_sparse_design_sums_duplicates_and_validates(hip):
+    # the same cell stored twice: the entries add up, as in the reference's sparse dot products
+    M = sp.csc_matrix((np.array([1.0, 2.0, 5.0]), np.array([0, 0, 2]), np.array([0, 2, 3])), shape=(3, 2))
+    out = np.empty(2)
+    _csc(M).mul(np.ones(3), np.array([1.0, 10.0, 100.0]), out)
+    assert np.array_equal(out, [3.0, 500.0])
+    with pytest.raises(TypeError, match="scipy.sparse"):
+        ad.matrix.sparse(np.eye(3), resident="csc")
+    with pytest.raises(ValueError, match="resident"):
+        ad.matrix.sparse(sp.csc_matrix(np.eye(3)), resident="hbm")
+    # the default keeps very sparse matrices sparse and expands the others
+    rng = np.random.RandomState(0)
+    assert ad.matrix.sparse(sp.csc_matrix(_rand_sparse(rng, 400, 50, 0.005)))._kind == "sparse"
+    assert ad.matrix.sparse(sp.csc_matrix(_rand_sparse(rng, 400, 50, 0.3)))._kind == "dense"
+
+
+def _problem(rng, n, p, density, k=6):
+    D = _rand_sparse(rng, n, p, density)
+    beta = np.zeros(p)
+    beta[rng.choice(p, k, replace=False)] = rng.normal(size=k) * 2
+    y = D @ beta + 0.3 * rng.normal(size=n)
+    return D, y
+
+
+@pytest.mark.parametrize("case", ["lasso", "enet_groups", "weights_no_intercept", "wide"])
+def test_gaussian_paths_on_a_kept_sparse_design_match_the_oracle(hip, oracle, case):
+    """StateGaussianNaive on MatrixNaiveSparse (reference tests/test_solver.py solves on every matrix class): screen sets
+    below and above the 128 values where the multi-CU Gram engine takes over from the single-workgroup kernel."""
+    rng = np.random.RandomState(11)
+    kw = dict(tol=1e-12, early_exit=False, lmda_path_size=25, min_ratio=1e-2, progress_bar=False)
+    if case == "lasso":
+        D, y = _problem(rng, 400, 60, 0.1)
+        glm = ad.glm.gaussian(y)
+    elif case == "enet_groups":
+        D, y = _problem(rng, 500, 90, 0.08)
+        glm = ad.glm.gaussian(y)
+        kw.update(groups=np.arange(0, 90, 3), alpha=0.6)
+    elif case == "weights_no_intercept":
+        D, y = _problem(rng, 350, 80, 0.1)
+        w = rng.uniform(0.2, 1.0, 350)
+        glm = ad.glm.gaussian(y, weights=w / w.sum())
+        kw.update(intercept=False, penalty=rng.uniform(0.5, 2.0, 80))
+    else:  # p > n, screen sets of several hundred values
+        D, y = _problem(rng, 300, 900, 0.05, k=40)
+        glm = ad.glm.gaussian(y)
+        kw.update(lmda_path_size=30, min_ratio=5e-2)
+    a = ad.grpnet(_csc(sp.csc_matrix(D)), glm, **kw)
+    b = ad.grpnet(oracle.dense(np.asfortranarray(D)), glm, **kw)
+    assert a.error == "" and b.error == ""
+    assert np.allclose(a.lmdas, b.lmdas, rtol=1e-12)
+    assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-8
+    assert np.abs(a.intercepts - b.intercepts).max() < 1e-8
+    assert np.abs(np.asarray(a.devs) - np.asarray(b.devs)).max() < 1e-9
+    if case == "wide":
+        assert max(a.screen_sizes) > 128  # the multi-CU Gram block passes ran
+
+
+@pytest.mark.parametrize("family", ["binomial", "poisson"])
+def test_glm_paths_on_a_kept_sparse_design_match_the_oracle(hip, oracle, family):
+    rng = np.random.RandomState(12)
+    n, p = 600, 70
+    D = _rand_sparse(rng, n, p, 0.1)
+    eta = D[:, :4] @ np.array([1.0, -1.5, 0.7, 0.5])
+    if family == "binomial":
+        y = (rng.uniform(size=n) < 1 / (1 + np.exp(-eta))).astype(float)
+        glm = ad.glm.binomial(y)
+    else:
+        y = rng.poisson(np.exp(0.3 * eta)).astype(float)
+        glm = ad.glm.poisson(y)
+    kw = dict(tol=1e-10, irls_tol=1e-10, early_exit=False, lmda_path_size=15, min_ratio=5e-2, progress_bar=False)
+    a = ad.grpnet(_csc(sp.csc_matrix(D)), glm, **kw)
+    b = ad.grpnet(oracle.dense(np.asfortranarray(D)), glm, **kw)
+    assert a.error == "" and b.error == ""
+    assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-6
+    assert np.abs(a.intercepts - b.intercepts).max() < 1e-6
+
+
+def test_kept_sparse_equals_expanded_on_the_device_and_f32(hip):
+    """The same entries kept sparse and expanded to a dense design (other engines, other summation order): the paths agree
+    to the solver tolerance in both precisions."""
+    rng = np.random.RandomState(13)
+    D, y = _problem(rng, 800, 150, 0.05)
+    for dtype, tol in [(np.float64, 1e-8), (np.float32, 2e-3)]:
+        M = sp.csc_matrix(D.astype(dtype))
+        kw = dict(tol=1e-12 if dtype == np.float64 else 1e-7, early_exit=False, lmda_path_size=20, min_ratio=2e-2,
+                  progress_bar=False)
+        a = ad.grpnet(_csc(M), ad.glm.gaussian(y.astype(dtype), dtype=dtype), **kw)
+        b = ad.grpnet(ad.matrix.sparse(M, resident="dense"), ad.glm.gaussian(y.astype(dtype), dtype=dtype), **kw)
+        assert a.error == "" and b.error == ""
+        assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < tol
+
+
+def test_derived_designs_of_a_kept_sparse_design(hip):
+    """subset / concatenate of sparse pieces stay sparse (composed on the host); standardize and mixed concatenations expand
+    (reference matrix.py:1414-1640, 214-310)."""
+    rng = np.random.RandomState(14)
+    n, p = 230, 41
+    D = _rand_sparse(rng, n, p, 0.1)
+    X = _csc(sp.csc_matrix(D))
+    rows = rng.choice(n, 77, replace=False)
+    cols = rng.choice(p, 13, replace=False)
+    Sr, Sc = ad.matrix.subset(X, rows, axis=0), ad.matrix.subset(X, cols, axis=1)
+    assert Sr._kind == "sparse" and Sc._kind == "sparse"
+    run_naive(Sr, np.asfortranarray(D[rows]), np.float64)
+    run_naive(Sc, np.asfortranarray(D[:, cols]), np.float64)
+    run_naive(X[rows, cols], np.asfortranarray(D[rows][:, cols]), np.float64)
+    with pytest.raises(RuntimeError):
+        ad.matrix.subset(X, [p], axis=1)
+    D2 = _rand_sparse(rng, n, 9, 0.2)
+    H = ad.matrix.concatenate([X, _csc(sp.csc_matrix(D2))], axis=1)
+    assert H._kind == "sparse"
+    run_naive(H, np.asfortranarray(np.concatenate([D, D2], axis=1)), np.float64)
+    A = np.asfortranarray(rng.normal(size=(n, 4)))
+    Hm = ad.matrix.concatenate([X, A], axis=1)  # a dense piece: everything is expanded
+    run_naive(Hm, np.asfortranarray(np.concatenate([D, A], axis=1)), np.float64)
+    Z = ad.matrix.standardize(X)
+    c, s = D.mean(axis=0), D.std(axis=0)
+    keep = s > 0
+    assert np.abs(Z._centers - c).max() < 1e-12
+    v = rng.normal(size=n)
+    out = np.empty(p)
+    Z.mul(v, np.ones(n), out)
+    assert np.abs(out[keep] - (((D - c) / np.where(keep, s, 1))[:, keep].T @ v)).max() < 1e-9
+    # an alias (what cv_grpnet hands every fold) shares the resident arrays
+    run_naive(X.alias(), np.asfortranarray(D), np.float64)
+
+
+def test_kept_sparse_design_refuses_constraints_and_serves_multi_response_fits(hip, oracle):
+    rng = np.random.RandomState(15)
+    D, y = _problem(rng, 300, 40, 0.15)
+    X = _csc(sp.csc_matrix(D))
+    cons = [None] * 40
+    cons[3] = ad.constraint.lower(np.array([0.5]))
+    with pytest.raises(RuntimeError, match="kept sparse"):
+        ad.grpnet(X, ad.glm.gaussian(y), constraints=cons, progress_bar=False)
+    # multi-response fits need dense column slices: the view is built over the expanded copy
+    Y = np.stack([y, -y + 0.1 * rng.normal(size=300)], axis=1)
+    kw = dict(tol=1e-12, early_exit=False, lmda_path_size=10, min_ratio=0.1, progress_bar=False)
+    a = ad.grpnet(X, ad.glm.multigaussian(Y), **kw)
+    b = ad.grpnet(ad.matrix.dense(np.asfortranarray(D)), ad.glm.multigaussian(Y), **kw)
+    assert a.error == "" and np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-9
+
+
+def test_cv_grpnet_on_a_kept_sparse_design(hip):
+    """cv_grpnet (reference adelie/cv.py:239-314) on aliases of the sparse-resident design, per-lambda losses through the
+    device's sp_tmul: the same table as on the expanded copy."""
+    rng = np.random.RandomState(16)
+    D, y = _problem(rng, 500, 60, 0.1)
+    M = sp.csc_matrix(D)
+    kw = dict(n_folds=4, seed=3, lmda_path_size=12, min_ratio=0.05, progress_bar=False)
+    a = ad.cv_grpnet(_csc(M), ad.glm.gaussian(y), **kw)
+    b = ad.cv_grpnet(ad.matrix.sparse(M, resident="dense"), ad.glm.gaussian(y), **kw)
+    assert np.allclose(a.lmdas, b.lmdas, rtol=1e-10)
+    assert np.abs(a.losses - b.losses).max() < 1e-7 * max(1.0, np.abs(b.losses).max())
+    assert a.best_idx == b.best_idx

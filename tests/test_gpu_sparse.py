@@ -67,7 +67,7 @@ def _problem(rng, n, p, density, k=6):
     return D, y
 
 
-@pytest.mark.parametrize("case", ["lasso", "enet_groups", "weights_no_intercept", "wide"])
+@pytest.mark.parametrize("case", ["lasso", "enet_groups", "weights_no_intercept", "wide", "wide_groups"])
 def test_gaussian_paths_on_a_kept_sparse_design_match_the_oracle(hip, oracle, case):
     """StateGaussianNaive on MatrixNaiveSparse (reference tests/test_solver.py solves on every matrix class): screen sets
     below and above the 128 values where the multi-CU Gram engine takes over from the single-workgroup kernel."""
@@ -88,7 +88,9 @@ def test_gaussian_paths_on_a_kept_sparse_design_match_the_oracle(hip, oracle, ca
     else:  # p > n, screen sets of several hundred values
         D, y = _problem(rng, 300, 900, 0.05, k=40)
         glm = ad.glm.gaussian(y)
-        kw.update(lmda_path_size=30, min_ratio=5e-2)
+        kw.update(lmda_path_size=40, min_ratio=2e-3)
+        if case == "wide_groups":
+            kw.update(groups=np.arange(0, 900, 3), alpha=0.8)
     a = ad.grpnet(_csc(sp.csc_matrix(D)), glm, **kw)
     b = ad.grpnet(oracle.dense(np.asfortranarray(D)), glm, **kw)
     assert a.error == "" and b.error == ""
@@ -96,8 +98,8 @@ def test_gaussian_paths_on_a_kept_sparse_design_match_the_oracle(hip, oracle, ca
     assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-8
     assert np.abs(a.intercepts - b.intercepts).max() < 1e-8
     assert np.abs(np.asarray(a.devs) - np.asarray(b.devs)).max() < 1e-9
-    if case == "wide":
-        assert max(a.screen_sizes) > 128  # the multi-CU Gram block passes ran
+    if case.startswith("wide"):
+        assert max(a.screen_sizes) * (3 if case == "wide_groups" else 1) > 128  # the multi-CU Gram block passes ran
 
 
 @pytest.mark.parametrize("family", ["binomial", "poisson"])
@@ -175,7 +177,7 @@ def test_kept_sparse_design_refuses_constraints_and_serves_multi_response_fits(h
     D, y = _problem(rng, 300, 40, 0.15)
     X = _csc(sp.csc_matrix(D))
     cons = [None] * 40
-    cons[3] = ad.constraint.lower(np.array([0.5]))
+    cons[3] = ad.constraint.lower(np.array([-0.5]))
     with pytest.raises(RuntimeError, match="kept sparse"):
         ad.grpnet(X, ad.glm.gaussian(y), constraints=cons, progress_bar=False)
     # multi-response fits need dense column slices: the view is built over the expanded copy

@@ -167,7 +167,8 @@ void op_sweep(adelie_hip_design* d, int64_t c0, int64_t ncols, const T* v, const
     if (d->kind == 0)
         launch_sweep<T>(d->dense<T>(), dv, dout, c0, ncols, nullptr, nullptr, nullptr, square, work, s);
     else if (d->kind == 3)
-        launch_sweep_csc<T>(d->csc<T>(), dv, dout, c0, ncols, nullptr, nullptr, nullptr, square, s);
+        launch_sweep_csc<T>(d->csc<T>(), dv, dout, c0, ncols, nullptr, nullptr, nullptr, square,
+                            scratch<T>(d->s_misc, size_t(sweep_work_elems_csc(d->sp_nb, ncols))), s);
     else
         launch_sweep_snp<T>(d->snp(), static_cast<const T*>(d->impute), dv, dout, c0, ncols, nullptr, nullptr, nullptr,
                             square, work, s);
@@ -189,7 +190,8 @@ void op_mul_batch(adelie_hip_design* d, const T* V, int64_t L, T* out) {
         T* dout1 = scratch<T>(d->s_p1, size_t(p));
         for (int64_t l = 0; l < L; ++l) {
             AHIP_CHECK(hipMemcpyAsync(dv1, V + l * n, size_t(n) * sizeof(T), hipMemcpyHostToDevice, s));
-            launch_sweep_csc<T>(d->csc<T>(), dv1, dout1, 0, p, nullptr, nullptr, nullptr, false, s);
+            launch_sweep_csc<T>(d->csc<T>(), dv1, dout1, 0, p, nullptr, nullptr, nullptr, false,
+                                scratch<T>(d->s_misc, size_t(sweep_work_elems_csc(d->sp_nb, p))), s);
             AHIP_CHECK(hipMemcpyAsync(out + l * p, dout1, size_t(p) * sizeof(T), hipMemcpyDeviceToHost, s));
             AHIP_CHECK(hipStreamSynchronize(s));
         }
@@ -803,6 +805,11 @@ int adelie_hip_design_create_csc(const int64_t* indptr, const int32_t* indices, 
             AHIP_CHECK(hipMemcpyAsync(d->rcol, row_indices, size_t(nnz) * sizeof(int32_t), hipMemcpyHostToDevice, s));
             AHIP_CHECK(hipMemcpyAsync(d->rval, row_values, size_t(nnz) * vs, hipMemcpyHostToDevice, s));
         }
+        csc_block_layout(n, vs, &d->sp_nb, &d->sp_rb);
+        if (d->sp_nb > 1) {
+            AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->bptr), size_t(p) * size_t(d->sp_nb + 1) * sizeof(int64_t)));
+            launch_csc_block_ptr(d->cptr, d->cidx, p, d->sp_nb, d->sp_rb, d->bptr, s);
+        }
         AHIP_CHECK(hipStreamSynchronize(s));
     } catch (...) {
         adelie_hip_design_destroy(d);
@@ -998,6 +1005,7 @@ int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out) {
     d->cptr = src->cptr; d->cidx = src->cidx; d->cval = src->cval;
     d->rptr = src->rptr; d->rcol = src->rcol; d->rval = src->rval;
     d->nnz = src->nnz;
+    d->bptr = src->bptr; d->sp_nb = src->sp_nb; d->sp_rb = src->sp_rb;
     d->alias = true;
     d->batch_owner = src->batch_owner ? src->batch_owner : src;
     *out = d;
@@ -1125,6 +1133,7 @@ int adelie_hip_design_destroy(adelie_hip_design* d) {
     if (!d->alias) {
         (void)hipFree(d->cptr); (void)hipFree(d->cidx); (void)hipFree(d->cval);
         (void)hipFree(d->rptr); (void)hipFree(d->rcol); (void)hipFree(d->rval);
+        (void)hipFree(d->bptr);
     }
     if (d->ones) (void)hipFree(d->ones);
     if (d->batcher) adelie_hip_internal_free_batcher(d->batcher);

@@ -30,6 +30,10 @@ struct CscView {
     const int32_t* rcol;
     const T* rval;
     int64_t n, p, nnz;
+    // row blocks of rb rows for the sweeps (nb > 1): bptr[c * (nb + 1) + b] = first entry of column c with row >= b * rb
+    const int64_t* bptr;
+    int nb;
+    int64_t rb;
 };
 
 // ---- vector helpers -------------------------------------------------------------------------
@@ -47,10 +51,15 @@ template <class T>
 void launch_sweep_snp(const SnpView& X, const T* impute, const T* v, T* out, int64_t c0, int64_t ncols,
                       const int32_t* cols, const T* sub_scale, const T* sub_vec, bool square, T* work, hipStream_t s);
 int64_t sweep_work_elems(int64_t n, int64_t ncols);
-// sparse design: one wavefront per column over its stored entries (no work buffer)
+// sparse design: one wavefront per (column, row block) over its stored entries; `work` holds sweep_work_elems_csc(X.nb, ncols)
+int64_t sweep_work_elems_csc(int nb, int64_t ncols);
 template <class T>
 void launch_sweep_csc(const CscView<T>& X, const T* v, T* out, int64_t c0, int64_t ncols, const int32_t* cols,
-                      const T* sub_scale, const T* sub_vec, bool square, hipStream_t s);
+                      const T* sub_scale, const T* sub_vec, bool square, T* work, hipStream_t s);
+// row-block layout of a sparse design with n rows (blocks whose slice of an n-vector is about 1 MB, at most 64 of them) and
+// the per-column block pointers
+void csc_block_layout(int64_t n, size_t value_size, int* nb, int64_t* rb);
+void launch_csc_block_ptr(const int64_t* cptr, const int32_t* cidx, int64_t p, int nb, int64_t rb, int64_t* bptr, hipStream_t s);
 // launch_gram on a sparse design; `work` holds gram_work_elems_csc(n) elements
 int64_t gram_work_elems_csc(int64_t n);
 template <class T>

@@ -18,23 +18,83 @@ namespace ahip {
 namespace {
 constexpr int KB = 8; // right-hand sides per pass of the slab kernels
 
-template <class T, bool SQ>
+// Row blocks (CscView::bptr): blockIdx.y = row block.  Workgroups are dispatched x-fastest, so the whole chip works on one
+// block of rows at a time and the slice of v it gathers from (rb rows, about 1 MB) stays in every XCD's L2; without blocks
+// every stored entry pulls its own 128-byte line of an n-vector that does not fit there (1M x 100k, 1e8 entries: 1.06 ms per
+// sweep unblocked, 0.68 ms with 1 MB slices; 0.70 / 0.71 / 0.77 ms at 0.5 / 2 / 4 MB).
+// LPC lanes per (column, row block) segment, 64 / LPC segments per wavefront, chosen from the mean segment length (measured on
+// the same design: 0.65 / 0.65 / 0.68 ms at 64 / 16 / 4 lanes — the kernel is bound by the rate at which L2 answers one gather
+// per stored entry, about 150 G/s, not by wavefront launches or the 1.2 GB stream).
+template <class T, bool SQ, int LPC>
 __global__ __launch_bounds__(256) void csc_sweep_kernel(CscView<T> X, const T* __restrict__ v, T* __restrict__ out, int64_t c0,
                                                          int64_t ncols, const int32_t* __restrict__ cols,
-                                                         const T* __restrict__ sub_scale, const T* __restrict__ sub_vec) {
-    const int lane = threadIdx.x & 63;
-    const int64_t k = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
-    if (k >= ncols) return;
-    const int64_t c = cols ? int64_t(cols[k]) : c0 + k;
-    const int64_t b = X.cptr[c], e = X.cptr[c + 1];
+                                                         const T* __restrict__ sub_scale, const T* __restrict__ sub_vec,
+                                                         T* __restrict__ part) {
+    constexpr int CPW = 64 / LPC;
+    const int lane = threadIdx.x & 63, sub = lane % LPC;
+    const int64_t k = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * CPW + lane / LPC;
+    const bool valid = k < ncols;
+    int64_t c = 0, b = 0, e = 0;
+    if (valid) {
+        c = cols ? int64_t(cols[k]) : c0 + k;
+        if (X.nb > 1) {
+            const int64_t* bp = X.bptr + c * (X.nb + 1) + blockIdx.y;
+            b = bp[0];
+            e = bp[1];
+        } else {
+            b = X.cptr[c];
+            e = X.cptr[c + 1];
+        }
+    }
     T acc = T(0);
-    for (int64_t t = b + lane; t < e; t += 64) {
+#pragma unroll 4
+    for (int64_t t = b + sub; t < e; t += LPC) {
         T x = X.cval[t];
         if (SQ) x *= x;
         acc = fma(x, v[X.cidx[t]], acc);
     }
-    acc = wave_sum64(acc);
-    if (lane == 0) out[k] = sub_vec ? acc - sub_scale[0] * sub_vec[c] : acc;
+    if constexpr (LPC == 64) {
+        acc = wave_sum64(acc);
+    } else { // fixed-order sum inside the segment's lanes (a quad, or a row of 16)
+        acc += pdpp<0xB1>(acc); // quad_perm [1,0,3,2]
+        acc += pdpp<0x4E>(acc); // quad_perm [2,3,0,1]
+        if constexpr (LPC == 16) {
+            acc += pdpp<0x141>(acc); // row_half_mirror
+            acc += pdpp<0x140>(acc); // row_mirror
+        }
+    }
+    if (valid && sub == 0) {
+        if (X.nb > 1) part[int64_t(blockIdx.y) * ncols + k] = acc;
+        else out[k] = sub_vec ? acc - sub_scale[0] * sub_vec[c] : acc;
+    }
+}
+// out[k] = sum over the row blocks, in block order, minus the centring term
+template <class T>
+__global__ __launch_bounds__(256) void csc_sweep_reduce_kernel(const T* __restrict__ part, int nb, T* __restrict__ out, int64_t c0,
+                                                                int64_t ncols, const int32_t* __restrict__ cols,
+                                                                const T* __restrict__ sub_scale, const T* __restrict__ sub_vec) {
+    const int64_t k = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (k >= ncols) return;
+    T acc = part[k];
+    for (int b = 1; b < nb; ++b) acc += part[int64_t(b) * ncols + k];
+    const int64_t c = cols ? int64_t(cols[k]) : c0 + k;
+    out[k] = sub_vec ? acc - sub_scale[0] * sub_vec[c] : acc;
+}
+// bptr[c * (nb + 1) + b] = first stored entry of column c with row >= b * rb  (b = nb: the column's end)
+__global__ __launch_bounds__(256) void csc_block_ptr_kernel(const int64_t* __restrict__ cptr, const int32_t* __restrict__ cidx,
+                                                             int64_t p, int nb, int64_t rb, int64_t* __restrict__ bptr) {
+    const int64_t id = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (id >= p * (nb + 1)) return;
+    const int64_t c = id / (nb + 1);
+    const int b = int(id - c * (nb + 1));
+    int64_t lo = cptr[c], hi = cptr[c + 1];
+    const int64_t key = int64_t(b) * rb;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cidx[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    bptr[id] = lo;
 }
 
 // slab[row * KB + kb] = w[row] * x[row, ncols[b0 + kb]]   (or 0 with CLEAR: puts the slab back to all zeros)
@@ -93,22 +153,47 @@ __global__ __launch_bounds__(256) void vec_scatter_kernel(const int32_t* __restr
     for (int32_t m = blockIdx.x * 256 + threadIdx.x; m < cnt; m += gridDim.x * 256) delta[cols[m]] = clear ? T(0) : coef[m];
 }
 
-// out[i] += sign * sum_t rval[t] delta[rcol[t]]: 8 lanes per row
-template <class T>
-__global__ __launch_bounds__(256) void csr_axpy_kernel(CscView<T> X, const T* __restrict__ delta, const int32_t* __restrict__ count_dev,
-                                                        T sign, T* __restrict__ out) {
-    if (count_dev && count_dev[0] <= 0) return;
-    const int sub = threadIdx.x & 7;
-    const int64_t i = (int64_t(blockIdx.x) * 256 + threadIdx.x) >> 3;
-    T acc = T(0);
-    if (i < X.n) {
-        const int64_t b = X.rptr[i], e = X.rptr[i + 1];
-        for (int64_t t = b + sub; t < e; t += 8) acc = fma(X.rval[t], delta[X.rcol[t]], acc);
+// out[i] += sign * sum_t rval[t] delta[rcol[t]]: 8 lanes per row.  Almost every delta is zero (a fit changes the coefficients
+// of its active set), and one gather per stored entry is what bounds a pass (see the sweep).  BITS: the workgroup first marks
+// the changed columns in a bitmap in LDS (p bits) and only entries of marked columns load their value and gather their
+// coefficient: the pass streams the column indices (4 of the 12 bytes per entry) and nothing else.  Skipped terms are exact
+// zeros, so the sums are those of the plain pass bit for bit.
+template <class T, bool BITS>
+__global__ __launch_bounds__(512) void csr_axpy_kernel(CscView<T> X, const T* __restrict__ delta, const int32_t* __restrict__ cols,
+                                                        const int32_t* __restrict__ count_dev, int32_t count, T sign,
+                                                        T* __restrict__ out) {
+    extern __shared__ uint32_t bm[];
+    const int32_t cnt = count_dev ? count_dev[0] : count;
+    if (cnt <= 0) return;
+    if constexpr (BITS) {
+        const int64_t words = (X.p + 31) >> 5;
+        for (int64_t wd = threadIdx.x; wd < words; wd += 512) bm[wd] = 0u;
+        __syncthreads();
+        for (int32_t m = threadIdx.x; m < cnt; m += 512) atomicOr(&bm[cols[m] >> 5], 1u << (cols[m] & 31));
+        __syncthreads();
     }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
-    if (i < X.n && sub == 0 && acc != T(0)) out[i] = fma(sign, acc, out[i]);
+    const int sub = threadIdx.x & 7;
+    const int64_t groups = (X.n + 63) / 64; // 64 rows per workgroup step
+    for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+        const int64_t i = g * 64 + (threadIdx.x >> 3);
+        T acc = T(0);
+        if (i < X.n) {
+            const int64_t b = X.rptr[i], e = X.rptr[i + 1];
+#pragma unroll 4
+            for (int64_t t = b + sub; t < e; t += 8) {
+                const int32_t c = X.rcol[t];
+                if constexpr (BITS) {
+                    if ((bm[c >> 5] >> (c & 31)) & 1u) acc = fma(X.rval[t], delta[c], acc);
+                } else {
+                    acc = fma(X.rval[t], delta[c], acc);
+                }
+            }
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (i < X.n && sub == 0 && acc != T(0)) out[i] = fma(sign, acc, out[i]);
+    }
 }
 
 // slab[j * KB + kb] = V[l0 + kb, j] for the stored entries of rows l0 .. l0 + nl of a host-made CSR (or 0 with CLEAR)
@@ -155,13 +240,37 @@ inline unsigned blocks_for(int64_t items, int per_block) {
 }
 } // namespace
 
+int64_t sweep_work_elems_csc(int nb, int64_t ncols) { return nb > 1 ? int64_t(nb) * ncols : 1; }
+
 template <class T>
 void launch_sweep_csc(const CscView<T>& X, const T* v, T* out, int64_t c0, int64_t ncols, const int32_t* cols, const T* sub_scale,
-                      const T* sub_vec, bool square, hipStream_t s) {
+                      const T* sub_vec, bool square, T* work, hipStream_t s) {
     if (ncols <= 0) return;
-    const dim3 grid(blocks_for(ncols, 4)), wg(256);
-    if (square) hipLaunchKernelGGL((csc_sweep_kernel<T, true>), grid, wg, 0, s, X, v, out, c0, ncols, cols, sub_scale, sub_vec);
-    else hipLaunchKernelGGL((csc_sweep_kernel<T, false>), grid, wg, 0, s, X, v, out, c0, ncols, cols, sub_scale, sub_vec);
+    // lanes per segment from the mean number of stored entries of a (column, row block) segment
+    const int64_t seg = X.nnz / std::max<int64_t>(1, X.p * std::max(X.nb, 1));
+    const int lpc = seg >= 192 ? 64 : (seg >= 24 ? 16 : 4);
+    const dim3 grid(blocks_for(ncols, 4 * (64 / lpc)), unsigned(std::max(X.nb, 1))), wg(256);
+#define AHIP_CSC_SWEEP(SQ, LPC) \
+    hipLaunchKernelGGL((csc_sweep_kernel<T, SQ, LPC>), grid, wg, 0, s, X, v, out, c0, ncols, cols, sub_scale, sub_vec, work)
+    if (square) {
+        if (lpc == 64) AHIP_CSC_SWEEP(true, 64); else if (lpc == 16) AHIP_CSC_SWEEP(true, 16); else AHIP_CSC_SWEEP(true, 4);
+    } else {
+        if (lpc == 64) AHIP_CSC_SWEEP(false, 64); else if (lpc == 16) AHIP_CSC_SWEEP(false, 16); else AHIP_CSC_SWEEP(false, 4);
+    }
+#undef AHIP_CSC_SWEEP
+    if (X.nb > 1)
+        hipLaunchKernelGGL((csc_sweep_reduce_kernel<T>), dim3(blocks_for(ncols, 256)), wg, 0, s, work, X.nb, out, c0, ncols, cols,
+                           sub_scale, sub_vec);
+}
+
+void csc_block_layout(int64_t n, size_t value_size, int* nb, int64_t* rb) {
+    int64_t r = (int64_t(1) << 20) / int64_t(value_size); // a slice of v of about 1 MB
+    while ((n + r - 1) / r > 64) r *= 2;
+    *rb = r;
+    *nb = int((n + r - 1) / r);
+}
+void launch_csc_block_ptr(const int64_t* cptr, const int32_t* cidx, int64_t p, int nb, int64_t rb, int64_t* bptr, hipStream_t s) {
+    hipLaunchKernelGGL(csc_block_ptr_kernel, dim3(blocks_for(p * (nb + 1), 256)), dim3(256), 0, s, cptr, cidx, p, nb, rb, bptr);
 }
 
 int64_t gram_work_elems_csc(int64_t n) { return n * KB; }
@@ -188,7 +297,20 @@ void launch_axpy_cols_csc(const CscView<T>& X, const int32_t* cols, const T* coe
     if (!count_dev && count <= 0) return;
     const unsigned gs = count_dev ? 64u : blocks_for(count, 256);
     hipLaunchKernelGGL((vec_scatter_kernel<T>), dim3(gs), dim3(256), 0, s, cols, coef, count_dev, count, false, delta_zeroed);
-    hipLaunchKernelGGL((csr_axpy_kernel<T>), dim3(blocks_for(X.n * 8, 256)), dim3(256), 0, s, X, delta_zeroed, count_dev, sign, out);
+    const int64_t bm_bytes = ((X.p + 31) >> 5) * 4;
+    const unsigned wgs = unsigned(std::min<int64_t>((X.n + 63) / 64, 2048));
+    if (bm_bytes <= 128 * 1024) { // the bitmap of the changed columns fits in LDS (p <= 1M columns)
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(csr_axpy_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      128 * 1024);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((csr_axpy_kernel<T, true>), dim3(wgs), dim3(512), size_t(bm_bytes), s, X, delta_zeroed, cols, count_dev,
+                           count, sign, out);
+    } else {
+        hipLaunchKernelGGL((csr_axpy_kernel<T, false>), dim3(wgs), dim3(512), 0, s, X, delta_zeroed, cols, count_dev, count, sign, out);
+    }
     hipLaunchKernelGGL((vec_scatter_kernel<T>), dim3(gs), dim3(256), 0, s, cols, coef, count_dev, count, true, delta_zeroed);
 }
 
@@ -209,7 +331,7 @@ void launch_sp_tmul_csc(const CscView<T>& X, int64_t L, const int64_t* indptr, c
 
 #define INST(T)                                                                                                                  \
     template void launch_sweep_csc<T>(const CscView<T>&, const T*, T*, int64_t, int64_t, const int32_t*, const T*, const T*, bool, \
-                                      hipStream_t);                                                                              \
+                                      T*, hipStream_t);                                                                              \
     template void launch_gram_csc<T>(const CscView<T>&, const T*, const int32_t*, int32_t, int32_t, const int32_t*, int32_t,      \
                                      int32_t, const T*, bool, T*, int64_t, T*, hipStream_t);                                     \
     template void launch_axpy_cols_csc<T>(const CscView<T>&, const int32_t*, const T*, const int32_t*, int32_t, T, T*, T*,         \

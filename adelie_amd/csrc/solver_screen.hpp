@@ -17,7 +17,8 @@
             return;
         }
         if (sparse()) { // one wavefront per column over its stored entries (kernels_sparse.hip)
-            launch_sweep_csc<T>(D->csc<T>(), v, out, 0, ncols, cols, sub_scale, sub_vec, square, st);
+            launch_sweep_csc<T>(D->csc<T>(), v, out, 0, ncols, cols, sub_scale, sub_vec, square,
+                                d_work_sweep.reserve(size_t(sweep_work_elems_csc(D->sp_nb, ncols))), st);
             return;
         }
         T* work = d_work_sweep.reserve(size_t(sweep_work_elems(n, ncols)));

@@ -43,6 +43,25 @@ def test_kept_sparse_design_runs_the_reference_check_list(hip, dtype, fmt, n, p,
     run_naive(X, np.asfortranarray(D), dtype)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_kept_sparse_design_with_row_blocks(hip, oracle, dtype):
+    """More rows than one row block of the sweeps (about 1 MB of an n-vector: 131072 f64 / 262144 f32 rows): the sweeps run
+    per (column, row block) with a fixed-order sum over the blocks."""
+    rng = np.random.RandomState(5)
+    n, p = (140_001 if dtype == np.float64 else 300_017), 24
+    D = _rand_sparse(rng, n, p, 0.002, dtype)
+    D[:, 3] = 0
+    D[n - 1, 4] = 2.5  # an entry in the last row of the last block
+    X = _csc(sp.csc_matrix(D))
+    run_naive(X, np.asfortranarray(D), dtype)
+    if dtype == np.float64:
+        y = D[:, :3] @ np.array([1.0, -2.0, 0.5]) + 0.05 * rng.normal(size=n)
+        kw = dict(tol=1e-12, early_exit=False, lmda_path_size=12, min_ratio=0.05, progress_bar=False)
+        a = ad.grpnet(X, ad.glm.gaussian(y), **kw)
+        b = ad.grpnet(oracle.dense(np.asfortranarray(D)), ad.glm.gaussian(y), **kw)
+        assert a.error == "" and np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-9
+
+
 def test_kept_sparse_design_sums_duplicates_and_validates(hip):
     # the same cell stored twice: the entries add up, as in the reference's sparse dot products
     M = sp.csc_matrix((np.array([1.0, 2.0, 5.0]), np.array([0, 0, 2]), np.array([0, 2, 3])), shape=(3, 2))

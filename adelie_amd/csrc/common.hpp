@@ -433,6 +433,10 @@ struct adelie_hip_design {
     int64_t* bptr = nullptr; // per-column row-block pointers (p x (sp_nb + 1)) when sp_nb > 1
     int sp_nb = 1;
     int64_t sp_rb = 0;
+    // standardized view of a sparse design (adelie_hip_design_create_csc_standardized): (p,) value_t each, owned unless alias
+    void* std_center = nullptr;
+    void* std_iscale = nullptr;
+    bool std_owned = false;
     // multi-response view: [1 (x) I_K, X (x) I_K] over the base's X (nb x pb); n = nb*K, p = (pb + micpt)*K
     int64_t mK = 0, nb = 0, pb = 0;
     int micpt = 0;
@@ -449,7 +453,7 @@ struct adelie_hip_design {
     ahip::SnpView snp() const { return ahip::SnpView{bits, n, p, ldb}; }
     template <class T> ahip::CscView<T> csc() const {
         return ahip::CscView<T>{cptr, cidx, static_cast<const T*>(cval), rptr, rcol, static_cast<const T*>(rval), n, p, nnz,
-                                bptr, sp_nb, sp_rb};
+                                bptr, sp_nb, sp_rb, static_cast<const T*>(std_center), static_cast<const T*>(std_iscale)};
     }
     template <class T> ahip::MultiView<T> multi() const {
         return ahip::MultiView<T>{static_cast<const T*>(X), nb, pb, ld, static_cast<const T*>(ones), int32_t(mK), int32_t(micpt),

@@ -246,8 +246,8 @@ void op_axpy(adelie_hip_design* d, int64_t j, int64_t q, const T* coef, T* out) 
     if (d->kind == 0) {
         launch_axpy_cols<T>(d->dense<T>(), dcols, dcoef, nullptr, int32_t(q), T(1), dout, s);
     } else if (d->kind == 3) {
-        T* delta = scratch<T>(d->s_misc, size_t(d->p));
-        AHIP_CHECK(hipMemsetAsync(delta, 0, size_t(d->p) * sizeof(T), s));
+        T* delta = scratch<T>(d->s_misc, size_t(d->p) + 8);
+        AHIP_CHECK(hipMemsetAsync(delta, 0, (size_t(d->p) + 8) * sizeof(T), s));
         launch_axpy_cols_csc<T>(d->csc<T>(), dcols, dcoef, nullptr, int32_t(q), T(1), dout, delta, s);
     } else {
         launch_axpy_cols_snp<T>(d->snp(), static_cast<const T*>(d->impute), dcols, dcoef, nullptr, int32_t(q), T(1), dout, s);
@@ -263,7 +263,7 @@ void op_cov(adelie_hip_design* d, int64_t j, int64_t q, const T* sw, T* out) {
     const int64_t n = d->n;
     T* dw = scratch<T>(d->s_n1, n);
     T* dC = scratch<T>(d->s_p1, q * q);
-    T* work = scratch<T>(d->s_work, d->kind == 3 ? gram_work_elems_csc(n) : gram_work_elems(n, q, q));
+    T* work = scratch<T>(d->s_work, d->kind == 3 ? gram_work_elems_csc(n, q, q, d->sp_nb) : gram_work_elems(n, q, q));
     int32_t* dcols = scratch<int32_t>(d->s_idx1, q);
     std::vector<int32_t> cols(q);
     for (int64_t k = 0; k < q; ++k) cols[k] = int32_t(j + k);
@@ -303,7 +303,8 @@ static void cov_lazy_t(adelie_hip_design* X, adelie_hip_design* A) {
     cols.reserve(size_t(p));
     ones.upload(h1.data(), size_t(n), s);
     cols.upload(hc.data(), size_t(p), s);
-    work.reserve(size_t(X->kind == 3 ? gram_work_elems_csc(n) : gram_work_elems(n, p, std::min<int64_t>(p, PANEL))));
+    work.reserve(size_t(X->kind == 3 ? gram_work_elems_csc(n, p, std::min<int64_t>(p, PANEL), X->sp_nb)
+                                     : gram_work_elems(n, p, std::min<int64_t>(p, PANEL))));
     for (int64_t c0 = 0; c0 < p; c0 += PANEL) {
         const int64_t nc = std::min<int64_t>(PANEL, p - c0);
         if (X->kind == 0)
@@ -819,6 +820,41 @@ int adelie_hip_design_create_csc(const int64_t* indptr, const int32_t* indices, 
     ABI_CATCH
 }
 
+int adelie_hip_design_create_csc_standardized(adelie_hip_design* src, const double* centers, const double* scales,
+                                              adelie_hip_design** out) {
+    ABI_TRY
+    if (!src || !centers || !scales || !out) throw make_core_error("null argument.");
+    if (src->kind != 3) throw make_core_error("the standardized view is offered on a design kept sparse (adelie_hip_design_create_csc).");
+    if (src->std_center) throw make_core_error("the design is a standardized view already.");
+    for (int64_t j = 0; j < src->p; ++j)
+        if (!(scales[j] != 0.0)) throw make_core_error("scales must be non-zero.");
+    adelie_hip_design* d = nullptr;
+    if (adelie_hip_design_alias(src, &d)) throw make_core_error(g_last_error);
+    try {
+        const int64_t p = src->p;
+        const size_t vs = src->dtype == ADELIE_HIP_F64 ? sizeof(double) : sizeof(float);
+        AHIP_CHECK(hipMalloc(&d->std_center, size_t(p) * vs));
+        d->std_owned = true;
+        AHIP_CHECK(hipMalloc(&d->std_iscale, size_t(p) * vs));
+        if (src->dtype == ADELIE_HIP_F64) {
+            std::vector<double> is(static_cast<size_t>(p));
+            for (int64_t j = 0; j < p; ++j) is[size_t(j)] = 1.0 / scales[j];
+            AHIP_CHECK(hipMemcpy(d->std_center, centers, size_t(p) * vs, hipMemcpyHostToDevice));
+            AHIP_CHECK(hipMemcpy(d->std_iscale, is.data(), size_t(p) * vs, hipMemcpyHostToDevice));
+        } else {
+            std::vector<float> ce(static_cast<size_t>(p)), is(static_cast<size_t>(p));
+            for (int64_t j = 0; j < p; ++j) { ce[size_t(j)] = float(centers[j]); is[size_t(j)] = float(1.0 / scales[j]); }
+            AHIP_CHECK(hipMemcpy(d->std_center, ce.data(), size_t(p) * vs, hipMemcpyHostToDevice));
+            AHIP_CHECK(hipMemcpy(d->std_iscale, is.data(), size_t(p) * vs, hipMemcpyHostToDevice));
+        }
+    } catch (...) {
+        adelie_hip_design_destroy(d);
+        throw;
+    }
+    *out = d;
+    ABI_CATCH
+}
+
 int adelie_hip_design_adopt_dense_dev(const void* dev_ptr, int64_t n, int64_t p, int dtype, int order, int device,
                                       adelie_hip_design** out) {
     ABI_TRY
@@ -1006,6 +1042,7 @@ int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out) {
     d->rptr = src->rptr; d->rcol = src->rcol; d->rval = src->rval;
     d->nnz = src->nnz;
     d->bptr = src->bptr; d->sp_nb = src->sp_nb; d->sp_rb = src->sp_rb;
+    d->std_center = src->std_center; d->std_iscale = src->std_iscale; // (not owned: std_owned stays false)
     d->alias = true;
     d->batch_owner = src->batch_owner ? src->batch_owner : src;
     *out = d;
@@ -1135,6 +1172,7 @@ int adelie_hip_design_destroy(adelie_hip_design* d) {
         (void)hipFree(d->rptr); (void)hipFree(d->rcol); (void)hipFree(d->rval);
         (void)hipFree(d->bptr);
     }
+    if (d->std_owned) { (void)hipFree(d->std_center); (void)hipFree(d->std_iscale); }
     if (d->ones) (void)hipFree(d->ones);
     if (d->batcher) adelie_hip_internal_free_batcher(d->batcher);
     delete d;

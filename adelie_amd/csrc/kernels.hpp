@@ -34,6 +34,9 @@ struct CscView {
     const int64_t* bptr;
     int nb;
     int64_t rb;
+    // standardized view (both null: the plain matrix): the design is (x_ij - center[j]) * inv_scale[j], entries untouched
+    const T* center;
+    const T* inv_scale;
 };
 
 // ---- vector helpers -------------------------------------------------------------------------
@@ -60,12 +63,12 @@ void launch_sweep_csc(const CscView<T>& X, const T* v, T* out, int64_t c0, int64
 // the per-column block pointers
 void csc_block_layout(int64_t n, size_t value_size, int* nb, int64_t* rb);
 void launch_csc_block_ptr(const int64_t* cptr, const int32_t* cidx, int64_t p, int nb, int64_t rb, int64_t* bptr, hipStream_t s);
-// launch_gram on a sparse design; `work` holds gram_work_elems_csc(n) elements
-int64_t gram_work_elems_csc(int64_t n);
+// launch_gram on a sparse design; `work` holds gram_work_elems_csc(n, M, N, X.nb) elements
+int64_t gram_work_elems_csc(int64_t n, int64_t M, int64_t N, int nb);
 template <class T>
 void launch_gram_csc(const CscView<T>& X, const T* w, const int32_t* mcols, int32_t M, int32_t m_pos0, const int32_t* ncols,
                      int32_t N, int32_t n_pos0, const T* xm_by_col, bool center, T* C, int64_t ldc, T* work, hipStream_t s);
-// launch_axpy_cols on a sparse design (cols must be distinct); `delta_zeroed`: p elements, all zero on entry and on exit
+// launch_axpy_cols on a sparse design (cols must be distinct); `delta_zeroed`: p + 8 elements, the first p all zero on entry and on exit
 template <class T>
 void launch_axpy_cols_csc(const CscView<T>& X, const int32_t* cols, const T* coef, const int32_t* count_dev, int32_t count,
                           T sign, T* out, T* delta_zeroed, hipStream_t s);

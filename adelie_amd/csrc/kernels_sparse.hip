@@ -8,6 +8,13 @@
 //                                                           then one 8-wide sweep over the columns a
 //   axpy       out[i] += sign sum_m coef[m] x[i, cols[m]]   coefficients scattered into a dense p-vector, one CSR pass
 //   sp_tmul    out[l, i] = sum_j V[l, j] x[i, j]            8 rows l per CSR pass over a dense (p, 8) slab
+//
+// Standardized view (CscView::center / inv_scale non-null; reference matrix_naive_standardize.ipp over a sparse matrix): the
+// design is  x~_ij = (x_ij - c_j) / s_j  with the stored entries untouched — centring would fill every cell.  Every operation
+// is the raw one plus a rank-one correction in its epilogue:
+//   sweep      (x_j . v - c_j sum(v)) / s_j ;   squares: (sum v x^2 - 2 c_j sum v x + c_j^2 sum(v)) / s_j^2
+//   Gram       (C_ab - c_a m_b - c_b m_a + c_a c_b W) / (s_a s_b),  m = X^T w (raw),  W = sum(w)
+//   axpy       coefficients scaled by 1 / s_j on their way into the p-vector, and  kappa = sum_m coef_m c_m / s_m  off every row
 #include "kernels.hpp"
 #include "wavered.hpp"
 
@@ -97,6 +104,36 @@ __global__ __launch_bounds__(256) void csc_block_ptr_kernel(const int64_t* __res
     bptr[id] = lo;
 }
 
+// out[0] = sum_i v[i]  (one workgroup, fixed order)
+template <class T>
+__global__ __launch_bounds__(1024) void vec_sum_kernel(const T* __restrict__ v, int64_t n, T* __restrict__ out) {
+    __shared__ T sh[1024];
+    T a = T(0);
+    for (int64_t i = threadIdx.x; i < n; i += 1024) a += v[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (int(threadIdx.x) < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+// the standardized view's sweep from the raw dot products (see the header)
+template <class T>
+__global__ __launch_bounds__(256) void std_sweep_epilogue_kernel(CscView<T> X, const T* __restrict__ raw, const T* __restrict__ raw_plain,
+                                                                  const T* __restrict__ vsum, bool square, T* __restrict__ out,
+                                                                  int64_t c0, int64_t ncols, const int32_t* __restrict__ cols,
+                                                                  const T* __restrict__ sub_scale, const T* __restrict__ sub_vec) {
+    const int64_t k = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (k >= ncols) return;
+    const int64_t c = cols ? int64_t(cols[k]) : c0 + k;
+    const T ce = X.center[c], is = X.inv_scale[c], s0 = vsum[0];
+    T val;
+    if (square) val = ((raw[k] - T(2) * ce * raw_plain[k]) + ce * ce * s0) * (is * is);
+    else val = (raw[k] - ce * s0) * is;
+    out[k] = sub_vec ? val - sub_scale[0] * sub_vec[c] : val;
+}
+
 // slab[row * KB + kb] = w[row] * x[row, ncols[b0 + kb]]   (or 0 with CLEAR: puts the slab back to all zeros)
 template <class T, bool CLEAR>
 __global__ __launch_bounds__(256) void csc_slab_kernel(CscView<T> X, const T* __restrict__ w, const int32_t* __restrict__ ncols,
@@ -116,7 +153,8 @@ template <class T>
 __global__ __launch_bounds__(256) void csc_gram_kernel(CscView<T> X, const T* __restrict__ slab, const int32_t* __restrict__ mcols,
                                                         int32_t M, int32_t m_pos0, const int32_t* __restrict__ ncols, int32_t nb,
                                                         int32_t n_pos, int32_t n_lo, int32_t n_hi, const T* __restrict__ xm,
-                                                        bool center, T* __restrict__ C, int64_t ldc) {
+                                                        bool center, T* __restrict__ C, int64_t ldc, const T* __restrict__ mM,
+                                                        const T* __restrict__ mN, const T* __restrict__ wsum) {
     const int lane = threadIdx.x & 63;
     const int64_t a = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (a >= M) return;
@@ -134,7 +172,13 @@ __global__ __launch_bounds__(256) void csc_gram_kernel(CscView<T> X, const T* __
     const T tot = reduce8(acc, lane); // lane l: total of right-hand side l & 7
     if (lane < nb) {
         const int64_t rp = m_pos0 + a, cp = n_pos + lane;
-        const T val = center ? tot - xm[c] * xm[ncols[lane]] : tot;
+        const int64_t cb = ncols[lane];
+        T raw = tot;
+        if (X.center) { // standardized view: rank-one corrections from the raw weighted column sums
+            const T ca = X.center[c], cbv = X.center[cb];
+            raw = (((tot - ca * mN[lane]) - cbv * mM[a]) + ca * cbv * wsum[0]) * (X.inv_scale[c] * X.inv_scale[cb]);
+        }
+        const T val = center ? raw - xm[c] * xm[cb] : raw;
         // Entries whose mirror image is itself computed by this call (both positions inside both ranges) are written by the
         // pair below the diagonal only, to both places: the panel is exactly symmetric and no entry is written twice.
         const bool both = rp >= n_lo && rp < n_hi && cp >= m_pos0 && cp < int64_t(m_pos0) + M;
@@ -148,9 +192,26 @@ __global__ __launch_bounds__(256) void csc_gram_kernel(CscView<T> X, const T* __
 template <class T>
 __global__ __launch_bounds__(256) void vec_scatter_kernel(const int32_t* __restrict__ cols, const T* __restrict__ coef,
                                                            const int32_t* __restrict__ count_dev, int32_t count, bool clear,
-                                                           T* __restrict__ delta) {
+                                                           const T* __restrict__ inv_scale, T* __restrict__ delta) {
     const int32_t cnt = count_dev ? count_dev[0] : count;
-    for (int32_t m = blockIdx.x * 256 + threadIdx.x; m < cnt; m += gridDim.x * 256) delta[cols[m]] = clear ? T(0) : coef[m];
+    for (int32_t m = blockIdx.x * 256 + threadIdx.x; m < cnt; m += gridDim.x * 256)
+        delta[cols[m]] = clear ? T(0) : (inv_scale ? coef[m] * inv_scale[cols[m]] : coef[m]);
+}
+// kappa[0] = sum_m coef[m] center[cols[m]] inv_scale[cols[m]]  (one workgroup, fixed order)
+template <class T>
+__global__ __launch_bounds__(256) void std_kappa_kernel(CscView<T> X, const int32_t* __restrict__ cols, const T* __restrict__ coef,
+                                                         const int32_t* __restrict__ count_dev, int32_t count, T* __restrict__ kappa) {
+    __shared__ T sh[256];
+    const int32_t cnt = count_dev ? count_dev[0] : count;
+    T a = T(0);
+    for (int32_t m = threadIdx.x; m < cnt; m += 256) a = fma(coef[m] * X.inv_scale[cols[m]], X.center[cols[m]], a);
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (int(threadIdx.x) < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) kappa[0] = sh[0];
 }
 
 // out[i] += sign * sum_t rval[t] delta[rcol[t]]: 8 lanes per row.  Almost every delta is zero (a fit changes the coefficients
@@ -161,7 +222,7 @@ __global__ __launch_bounds__(256) void vec_scatter_kernel(const int32_t* __restr
 template <class T, bool BITS>
 __global__ __launch_bounds__(512) void csr_axpy_kernel(CscView<T> X, const T* __restrict__ delta, const int32_t* __restrict__ cols,
                                                         const int32_t* __restrict__ count_dev, int32_t count, T sign,
-                                                        T* __restrict__ out) {
+                                                        const T* __restrict__ kappa, T* __restrict__ out) {
     extern __shared__ uint32_t bm[];
     const int32_t cnt = count_dev ? count_dev[0] : count;
     if (cnt <= 0) return;
@@ -192,6 +253,7 @@ __global__ __launch_bounds__(512) void csr_axpy_kernel(CscView<T> X, const T* __
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);
+        if (kappa) acc -= kappa[0];
         if (i < X.n && sub == 0 && acc != T(0)) out[i] = fma(sign, acc, out[i]);
     }
 }
@@ -199,17 +261,37 @@ __global__ __launch_bounds__(512) void csr_axpy_kernel(CscView<T> X, const T* __
 // slab[j * KB + kb] = V[l0 + kb, j] for the stored entries of rows l0 .. l0 + nl of a host-made CSR (or 0 with CLEAR)
 template <class T, bool CLEAR>
 __global__ __launch_bounds__(256) void csr_rows_slab_kernel(const int64_t* __restrict__ indptr, const int64_t* __restrict__ indices,
-                                                             const T* __restrict__ values, int nl, T* __restrict__ slab) {
+                                                             const T* __restrict__ values, int nl, const T* __restrict__ inv_scale,
+                                                             T* __restrict__ slab) {
     const int kb = blockIdx.y;
     if (kb >= nl) return;
     const int64_t b = indptr[kb], e = indptr[kb + 1];
     for (int64_t t = b + int64_t(blockIdx.x) * 256 + threadIdx.x; t < e; t += int64_t(gridDim.x) * 256)
-        slab[indices[t] * KB + kb] = CLEAR ? T(0) : values[t];
+        slab[indices[t] * KB + kb] = CLEAR ? T(0) : (inv_scale ? values[t] * inv_scale[indices[t]] : values[t]);
+}
+// kappa[kb] = sum_j V[l0 + kb, j] center[j] inv_scale[j]  (one workgroup per row, fixed order)
+template <class T>
+__global__ __launch_bounds__(256) void std_rows_kappa_kernel(CscView<T> X, const int64_t* __restrict__ indptr,
+                                                              const int64_t* __restrict__ indices, const T* __restrict__ values,
+                                                              T* __restrict__ kappa) {
+    __shared__ T sh[256];
+    const int kb = blockIdx.x;
+    const int64_t b = indptr[kb], e = indptr[kb + 1];
+    T a = T(0);
+    for (int64_t t = b + threadIdx.x; t < e; t += 256) a = fma(values[t] * X.inv_scale[indices[t]], X.center[indices[t]], a);
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (int(threadIdx.x) < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) kappa[kb] = sh[0];
 }
 
 // out[kb * n + i] = sum_t rval[t] slab[rcol[t] * KB + kb]: 8 lanes per row, KB results each
 template <class T>
-__global__ __launch_bounds__(256) void csr_tmul_kernel(CscView<T> X, const T* __restrict__ slab, int nl, T* __restrict__ out) {
+__global__ __launch_bounds__(256) void csr_tmul_kernel(CscView<T> X, const T* __restrict__ slab, int nl, const T* __restrict__ kappa,
+                                                        T* __restrict__ out) {
     const int sub = threadIdx.x & 7;
     const int64_t i = (int64_t(blockIdx.x) * 256 + threadIdx.x) >> 3;
     T acc[KB];
@@ -231,7 +313,7 @@ __global__ __launch_bounds__(256) void csr_tmul_kernel(CscView<T> X, const T* __
         acc[k] += __shfl_xor(acc[k], 4, 64);
     }
     if (i < X.n && sub == 0)
-        for (int k = 0; k < nl; ++k) out[int64_t(k) * X.n + i] = acc[k];
+        for (int k = 0; k < nl; ++k) out[int64_t(k) * X.n + i] = kappa ? acc[k] - kappa[k] : acc[k];
 }
 
 inline unsigned blocks_for(int64_t items, int per_block) {
@@ -240,18 +322,20 @@ inline unsigned blocks_for(int64_t items, int per_block) {
 }
 } // namespace
 
-int64_t sweep_work_elems_csc(int nb, int64_t ncols) { return nb > 1 ? int64_t(nb) * ncols : 1; }
+// [0, nb * ncols): per-block partials; then two raw vectors of ncols and eight scalars (standardized view)
+int64_t sweep_work_elems_csc(int nb, int64_t ncols) { return int64_t(std::max(nb, 1)) * ncols + 2 * ncols + 8; }
 
+namespace {
+// raw dot products of the stored entries (no centring term of the caller, no standardization) into `dst`
 template <class T>
-void launch_sweep_csc(const CscView<T>& X, const T* v, T* out, int64_t c0, int64_t ncols, const int32_t* cols, const T* sub_scale,
-                      const T* sub_vec, bool square, T* work, hipStream_t s) {
-    if (ncols <= 0) return;
+void raw_sweep(const CscView<T>& X, const T* v, T* dst, int64_t c0, int64_t ncols, const int32_t* cols, const T* sub_scale,
+               const T* sub_vec, bool square, T* part, hipStream_t s) {
     // lanes per segment from the mean number of stored entries of a (column, row block) segment
     const int64_t seg = X.nnz / std::max<int64_t>(1, X.p * std::max(X.nb, 1));
     const int lpc = seg >= 192 ? 64 : (seg >= 24 ? 16 : 4);
     const dim3 grid(blocks_for(ncols, 4 * (64 / lpc)), unsigned(std::max(X.nb, 1))), wg(256);
 #define AHIP_CSC_SWEEP(SQ, LPC) \
-    hipLaunchKernelGGL((csc_sweep_kernel<T, SQ, LPC>), grid, wg, 0, s, X, v, out, c0, ncols, cols, sub_scale, sub_vec, work)
+    hipLaunchKernelGGL((csc_sweep_kernel<T, SQ, LPC>), grid, wg, 0, s, X, v, dst, c0, ncols, cols, sub_scale, sub_vec, part)
     if (square) {
         if (lpc == 64) AHIP_CSC_SWEEP(true, 64); else if (lpc == 16) AHIP_CSC_SWEEP(true, 16); else AHIP_CSC_SWEEP(true, 4);
     } else {
@@ -259,8 +343,27 @@ void launch_sweep_csc(const CscView<T>& X, const T* v, T* out, int64_t c0, int64
     }
 #undef AHIP_CSC_SWEEP
     if (X.nb > 1)
-        hipLaunchKernelGGL((csc_sweep_reduce_kernel<T>), dim3(blocks_for(ncols, 256)), wg, 0, s, work, X.nb, out, c0, ncols, cols,
+        hipLaunchKernelGGL((csc_sweep_reduce_kernel<T>), dim3(blocks_for(ncols, 256)), wg, 0, s, part, X.nb, dst, c0, ncols, cols,
                            sub_scale, sub_vec);
+}
+} // namespace
+
+template <class T>
+void launch_sweep_csc(const CscView<T>& X, const T* v, T* out, int64_t c0, int64_t ncols, const int32_t* cols, const T* sub_scale,
+                      const T* sub_vec, bool square, T* work, hipStream_t s) {
+    if (ncols <= 0) return;
+    if (!X.center) {
+        raw_sweep<T>(X, v, out, c0, ncols, cols, sub_scale, sub_vec, square, work, s);
+        return;
+    }
+    T* raw = work + int64_t(std::max(X.nb, 1)) * ncols;
+    T* raw_plain = raw + ncols;
+    T* vsum = raw_plain + ncols;
+    raw_sweep<T>(X, v, raw, c0, ncols, cols, nullptr, nullptr, square, work, s);
+    if (square) raw_sweep<T>(X, v, raw_plain, c0, ncols, cols, nullptr, nullptr, false, work, s);
+    hipLaunchKernelGGL((vec_sum_kernel<T>), dim3(1), dim3(1024), 0, s, v, X.n, vsum);
+    hipLaunchKernelGGL((std_sweep_epilogue_kernel<T>), dim3(blocks_for(ncols, 256)), dim3(256), 0, s, X, raw, raw_plain, vsum, square,
+                       out, c0, ncols, cols, sub_scale, sub_vec);
 }
 
 void csc_block_layout(int64_t n, size_t value_size, int* nb, int64_t* rb) {
@@ -273,30 +376,50 @@ void launch_csc_block_ptr(const int64_t* cptr, const int32_t* cidx, int64_t p, i
     hipLaunchKernelGGL(csc_block_ptr_kernel, dim3(blocks_for(p * (nb + 1), 256)), dim3(256), 0, s, cptr, cidx, p, nb, rb, bptr);
 }
 
-int64_t gram_work_elems_csc(int64_t n) { return n * KB; }
+// the (n, KB) slab; then (standardized view) the raw weighted sums of the row and the column members, eight scalars and
+// the work of their sweeps
+int64_t gram_work_elems_csc(int64_t n, int64_t M, int64_t N, int nb) {
+    return n * KB + M + N + 8 + sweep_work_elems_csc(nb, std::max(M, N));
+}
 
 template <class T>
 void launch_gram_csc(const CscView<T>& X, const T* w, const int32_t* mcols, int32_t M, int32_t m_pos0, const int32_t* ncols,
                      int32_t N, int32_t n_pos0, const T* xm_by_col, bool center, T* C, int64_t ldc, T* work, hipStream_t s) {
     if (M <= 0 || N <= 0) return;
     (void)hipMemsetAsync(work, 0, size_t(X.n) * KB * sizeof(T), s);
+    T *mM = nullptr, *mN = nullptr, *wsum = nullptr;
+    if (X.center) {
+        mM = work + X.n * KB;
+        mN = mM + M;
+        wsum = mN + N;
+        T* sw = wsum + 8;
+        raw_sweep<T>(X, w, mM, 0, M, mcols, nullptr, nullptr, false, sw, s);
+        raw_sweep<T>(X, w, mN, 0, N, ncols, nullptr, nullptr, false, sw, s);
+        hipLaunchKernelGGL((vec_sum_kernel<T>), dim3(1), dim3(1024), 0, s, w, X.n, wsum);
+    }
     // entries per column are not known on the host: a fixed spread of workgroups strides each column
     const unsigned spread = unsigned(std::max<int64_t>(1, std::min<int64_t>(64, (X.nnz / std::max<int64_t>(X.p, 1) + 255) / 256)));
     for (int32_t b0 = 0; b0 < N; b0 += KB) {
         const int32_t nb = std::min<int32_t>(KB, N - b0);
         hipLaunchKernelGGL((csc_slab_kernel<T, false>), dim3(spread, unsigned(nb)), dim3(256), 0, s, X, w, ncols + b0, nb, work);
         hipLaunchKernelGGL((csc_gram_kernel<T>), dim3(blocks_for(M, 4)), dim3(256), 0, s, X, work, mcols, M, m_pos0, ncols + b0, nb,
-                           n_pos0 + b0, n_pos0, n_pos0 + N, xm_by_col, center, C, ldc);
+                           n_pos0 + b0, n_pos0, n_pos0 + N, xm_by_col, center, C, ldc, mM, mN ? mN + b0 : nullptr, wsum);
         hipLaunchKernelGGL((csc_slab_kernel<T, true>), dim3(spread, unsigned(nb)), dim3(256), 0, s, X, w, ncols + b0, nb, work);
     }
 }
 
+// `delta_zeroed`: p + 8 elements, the first p all zero on entry and on exit (the rest is scratch)
 template <class T>
 void launch_axpy_cols_csc(const CscView<T>& X, const int32_t* cols, const T* coef, const int32_t* count_dev, int32_t count, T sign,
                           T* out, T* delta_zeroed, hipStream_t s) {
     if (!count_dev && count <= 0) return;
     const unsigned gs = count_dev ? 64u : blocks_for(count, 256);
-    hipLaunchKernelGGL((vec_scatter_kernel<T>), dim3(gs), dim3(256), 0, s, cols, coef, count_dev, count, false, delta_zeroed);
+    T* kappa = nullptr;
+    if (X.center) {
+        kappa = delta_zeroed + X.p;
+        hipLaunchKernelGGL((std_kappa_kernel<T>), dim3(1), dim3(256), 0, s, X, cols, coef, count_dev, count, kappa);
+    }
+    hipLaunchKernelGGL((vec_scatter_kernel<T>), dim3(gs), dim3(256), 0, s, cols, coef, count_dev, count, false, X.inv_scale, delta_zeroed);
     const int64_t bm_bytes = ((X.p + 31) >> 5) * 4;
     const unsigned wgs = unsigned(std::min<int64_t>((X.n + 63) / 64, 2048));
     if (bm_bytes <= 128 * 1024) { // the bitmap of the changed columns fits in LDS (p <= 1M columns)
@@ -307,25 +430,30 @@ void launch_axpy_cols_csc(const CscView<T>& X, const int32_t* cols, const T* coe
             attr_done = true;
         }
         hipLaunchKernelGGL((csr_axpy_kernel<T, true>), dim3(wgs), dim3(512), size_t(bm_bytes), s, X, delta_zeroed, cols, count_dev,
-                           count, sign, out);
+                           count, sign, kappa, out);
     } else {
-        hipLaunchKernelGGL((csr_axpy_kernel<T, false>), dim3(wgs), dim3(512), 0, s, X, delta_zeroed, cols, count_dev, count, sign, out);
+        hipLaunchKernelGGL((csr_axpy_kernel<T, false>), dim3(wgs), dim3(512), 0, s, X, delta_zeroed, cols, count_dev, count, sign,
+                           kappa, out);
     }
-    hipLaunchKernelGGL((vec_scatter_kernel<T>), dim3(gs), dim3(256), 0, s, cols, coef, count_dev, count, true, delta_zeroed);
+    hipLaunchKernelGGL((vec_scatter_kernel<T>), dim3(gs), dim3(256), 0, s, cols, coef, count_dev, count, true, X.inv_scale, delta_zeroed);
 }
 
-int64_t sp_tmul_work_elems_csc(int64_t p) { return p * KB; }
+int64_t sp_tmul_work_elems_csc(int64_t p) { return p * KB + KB; }
 
 template <class T>
 void launch_sp_tmul_csc(const CscView<T>& X, int64_t L, const int64_t* indptr, const int64_t* indices, const T* values, T* out,
                         T* work, hipStream_t s) {
     if (L <= 0) return;
     (void)hipMemsetAsync(work, 0, size_t(X.p) * KB * sizeof(T), s);
+    T* kappa = X.center ? work + X.p * KB : nullptr;
     for (int64_t l0 = 0; l0 < L; l0 += KB) {
         const int nl = int(std::min<int64_t>(KB, L - l0));
-        hipLaunchKernelGGL((csr_rows_slab_kernel<T, false>), dim3(16, unsigned(nl)), dim3(256), 0, s, indptr + l0, indices, values, nl, work);
-        hipLaunchKernelGGL((csr_tmul_kernel<T>), dim3(blocks_for(X.n * 8, 256)), dim3(256), 0, s, X, work, nl, out + l0 * X.n);
-        hipLaunchKernelGGL((csr_rows_slab_kernel<T, true>), dim3(16, unsigned(nl)), dim3(256), 0, s, indptr + l0, indices, values, nl, work);
+        if (kappa) hipLaunchKernelGGL((std_rows_kappa_kernel<T>), dim3(unsigned(nl)), dim3(256), 0, s, X, indptr + l0, indices, values, kappa);
+        hipLaunchKernelGGL((csr_rows_slab_kernel<T, false>), dim3(16, unsigned(nl)), dim3(256), 0, s, indptr + l0, indices, values, nl,
+                           X.inv_scale, work);
+        hipLaunchKernelGGL((csr_tmul_kernel<T>), dim3(blocks_for(X.n * 8, 256)), dim3(256), 0, s, X, work, nl, kappa, out + l0 * X.n);
+        hipLaunchKernelGGL((csr_rows_slab_kernel<T, true>), dim3(16, unsigned(nl)), dim3(256), 0, s, indptr + l0, indices, values, nl,
+                           X.inv_scale, work);
     }
 }
 

@@ -97,9 +97,9 @@
             return;
         }
         if (sparse()) { // coefficients scattered into a p-vector that is all zero between calls, then one CSR pass
-            if (d_sp_delta.cap < size_t(p)) {
-                d_sp_delta.reserve(size_t(p));
-                AHIP_CHECK(hipMemsetAsync(d_sp_delta.p, 0, size_t(p) * sizeof(T), st));
+            if (d_sp_delta.cap < size_t(p) + 8) {
+                d_sp_delta.reserve(size_t(p) + 8);
+                AHIP_CHECK(hipMemsetAsync(d_sp_delta.p, 0, (size_t(p) + 8) * sizeof(T), st));
             }
             launch_axpy_cols_csc<T>(D->csc<T>(), cols, coef, cnt_dev, count, sign, out, d_sp_delta.p, st);
             return;
@@ -108,7 +108,7 @@
         else launch_axpy_cols_snp<T>(D->snp(), static_cast<const T*>(D->impute), cols, coef, cnt_dev, count, sign, out, st);
     }
     void gram(const T* w, idx M, idx pos0, idx N, const T* xm, bool center) {
-        T* work = d_work_gram.reserve(size_t(sparse() ? gram_work_elems_csc(n) : gram_work_elems(n, M, N)));
+        T* work = d_work_gram.reserve(size_t(sparse() ? gram_work_elems_csc(n, M, N, D->sp_nb) : gram_work_elems(n, M, N)));
         t_gram.begin(st);
         if (sparse())
             launch_gram_csc<T>(D->csc<T>(), w, d_vcol.p, int32_t(M), 0, d_vcol.p + pos0, int32_t(N), int32_t(pos0), xm, center, d_C.p,

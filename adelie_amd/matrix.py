@@ -148,6 +148,8 @@ class _NativeMatrix:
         out._alias_of = self
         if hasattr(self, "_scipy"):
             out._scipy, out._device = self._scipy, getattr(self, "_device", 0)
+            if getattr(self, "_std", None) is not None:
+                out._std = self._std
         return out
 
     def batch_stats(self):
@@ -542,7 +544,7 @@ def concatenate(mats, *, axis: int = 0, n_threads: int = 1):
     if len(mats) == 0:
         raise RuntimeError("mats must be non-empty.")
     mats = [dense(m, n_threads=n_threads) if isinstance(m, np.ndarray) else m for m in mats]
-    if all(_is_kept_sparse(m) for m in mats):  # sparse pieces stay sparse (stacked on the host)
+    if all(_is_kept_sparse(m) and getattr(m, "_std", None) is None for m in mats):  # sparse pieces stay sparse (stacked on the host)
         import scipy.sparse as _sp
 
         if len({np.dtype(m.dtype) for m in mats}) != 1:
@@ -708,7 +710,11 @@ def _is_kept_sparse(m):
 
 def _expanded(m):
     """The dense-resident form of a design that is kept sparse (for the operations that need dense column slices)."""
-    return sparse(m._scipy, n_threads=m._n_threads, device=getattr(m, "_device", 0), resident="dense")
+    out = sparse(m._scipy, n_threads=m._n_threads, device=getattr(m, "_device", 0), resident="dense")
+    std = getattr(m, "_std", None)
+    if std is not None:  # a standardized view: the same centres / scales on the expanded copy
+        out = _derived(out, None, None, std[0], std[1], m._n_threads)
+    return out
 
 
 def snp_unphased(io, *, dtype=np.float64, n_threads: int = 1, device: int = 0):
@@ -783,7 +789,19 @@ def snp_bed(bed, n: int, p: int = None, *, dtype=np.float64, n_threads: int = 1,
 def _derived(mat, rows, cols, centers, scales, n_threads):
     if not isinstance(mat, _NativeMatrix) or isinstance(mat, _MultiView):
         raise RuntimeError("adelie_amd: subset / standardize need a resident dense or SNP design.")
+    if _is_kept_sparse(mat) and getattr(mat, "_std", None) is not None:
+        mat = _expanded(mat)  # (derived designs of a standardized view are built from its expanded copy)
     if _is_kept_sparse(mat):
+        if centers is not None and scales is not None and rows is None and cols is None:
+            # standardize: the entries stay as they are, centring / scaling become rank-one corrections of every operation
+            backend = mat._backend
+            ce = np.ascontiguousarray(centers, dtype=np.float64)
+            sc = np.ascontiguousarray(scales, dtype=np.float64)
+            handle = _abi.C.c_void_p()
+            backend.check(backend.fn("design_create_csc_standardized")(mat._handle, ce.ctypes.data, sc.ctypes.data, handle))
+            out = _wrap(backend, handle, mat.dtype, n_threads, keep=mat, kind="sparse")
+            out._scipy, out._device, out._std = mat._scipy, getattr(mat, "_device", 0), (ce, sc)
+            return out
         if centers is None and scales is None:  # a subset of a sparse matrix is sparse: composed on the host, kept sparse
             sub = mat._scipy
             if rows is not None:

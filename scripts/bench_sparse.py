@@ -4,6 +4,7 @@ the full-gradient sweep's rate over the stored entries, and (when n*p*8 fits) th
     python scripts/bench_sparse.py [n p density lambdas]      (default 1000000 100000 0.001 100)
 """
 import json
+import os
 import sys
 import time
 
@@ -57,6 +58,13 @@ res = {
     "dev_ratio_last": float(st.devs[-1]),
     "generate_s": t_gen, "upload_s": t_up,
 }
+if os.environ.get("SPARSE_BINOMIAL"):  # IRLS on the same design: the screen set's Gram is rebuilt under every iteration's weights
+    yb = (rng.uniform(size=n) < 1 / (1 + np.exp(-(y - y.mean()) / y.std()))).astype(float)
+    kwb = dict(lmda_path_size=int(os.environ["SPARSE_BINOMIAL"]), min_ratio=5e-2, early_exit=False, progress_bar=False)
+    t0 = time.time()
+    sb = ad.grpnet(X, ad.glm.binomial(yb), **kwb)
+    res["binomial"] = {"path_s": time.time() - t0, "lambdas": len(sb.lmdas), "final_active": int(sb.active_set_size),
+                       "error": sb.error}
 if n * p * 8 < 100 * 2**30:
     Xd = ad.matrix.sparse(M, resident="dense")
     ad.grpnet(Xd, ad.glm.gaussian(y), lmda_path_size=5, min_ratio=0.5, early_exit=False, progress_bar=False)

@@ -179,16 +179,61 @@ def test_derived_designs_of_a_kept_sparse_design(hip):
     A = np.asfortranarray(rng.normal(size=(n, 4)))
     Hm = ad.matrix.concatenate([X, A], axis=1)  # a dense piece: everything is expanded
     run_naive(Hm, np.asfortranarray(np.concatenate([D, A], axis=1)), np.float64)
-    Z = ad.matrix.standardize(X)
-    c, s = D.mean(axis=0), D.std(axis=0)
-    keep = s > 0
-    assert np.abs(Z._centers - c).max() < 1e-12
-    v = rng.normal(size=n)
-    out = np.empty(p)
-    Z.mul(v, np.ones(n), out)
-    assert np.abs(out[keep] - (((D - c) / np.where(keep, s, 1))[:, keep].T @ v)).max() < 1e-9
+    Hz = ad.matrix.concatenate([ad.matrix.standardize(X), _csc(sp.csc_matrix(D2))], axis=1)  # a standardized piece: expanded
+    run_naive(Hz, np.asfortranarray(np.concatenate([(D - D.mean(axis=0)) / D.std(axis=0), D2], axis=1)), np.float64)
     # an alias (what cv_grpnet hands every fold) shares the resident arrays
     run_naive(X.alias(), np.asfortranarray(D), np.float64)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_standardized_view_of_a_kept_sparse_design(hip, oracle, dtype):
+    """matrix.standardize over a sparse design (reference matrix.py:1414-1533, matrix_naive_standardize.ipp): the entries stay
+    compressed, centring and scaling are rank-one corrections in every operation's epilogue.  The reference's check list for
+    the class (tests/test_matrix.py::test_naive_standardize) against the dense standardized matrix, with default and with
+    given centres / scales, over one and over several row blocks; paths against the oracle on the dense standardized copy."""
+    rng = np.random.RandomState(21)
+    for n, p, dens in [(333, 29, 0.12), (140_003, 11, 0.004)]:
+        if dtype == np.float32 and n > 1000:
+            continue
+        D = _rand_sparse(rng, n, p, dens, dtype)
+        X = _csc(sp.csc_matrix(D))
+        Z = ad.matrix.standardize(X)
+        assert Z._kind == "sparse" and Z._std is not None
+        D64 = D.astype(np.float64)
+        c, s = D64.mean(axis=0), D64.std(axis=0)
+        assert np.abs(Z._centers - c).max() < (1e-12 if dtype == np.float64 else 1e-6)
+        assert np.abs(Z._scales - s).max() < (1e-12 if dtype == np.float64 else 1e-5)
+        run_naive(Z, np.asfortranarray(((D64 - c) / s).astype(dtype)), dtype)
+        run_naive(Z.alias(), np.asfortranarray(((D64 - c) / s).astype(dtype)), dtype)
+        c2, s2 = rng.normal(size=p), rng.uniform(0.5, 2.0, p)
+        Z2 = ad.matrix.standardize(X, centers=c2, scales=s2)
+        run_naive(Z2, np.asfortranarray(((D64 - c2) / s2).astype(dtype)), dtype)
+    with pytest.raises(RuntimeError, match="non-zero"):
+        ad.matrix.standardize(X, centers=np.zeros(p), scales=np.zeros(p))
+    if dtype == np.float32:
+        return
+    n, p = 500, 80
+    D, y = _problem(rng, n, p, 0.1)
+    Zd = (D - D.mean(axis=0)) / D.std(axis=0)
+    Z = ad.matrix.standardize(_csc(sp.csc_matrix(D)))
+    w = rng.uniform(0.2, 1.0, n)
+    for glm, kw in [
+        (ad.glm.gaussian(y), dict(tol=1e-12)),
+        (ad.glm.gaussian(y, weights=w / w.sum()), dict(tol=1e-12, groups=np.arange(0, p, 4), alpha=0.7)),
+        (ad.glm.gaussian(y), dict(tol=1e-12, intercept=False)),
+        (ad.glm.binomial((y > np.median(y)).astype(float)), dict(tol=1e-10, irls_tol=1e-10)),
+    ]:
+        kw.update(early_exit=False, lmda_path_size=15, min_ratio=2e-2, progress_bar=False)
+        a = ad.grpnet(Z, glm, **kw)
+        b = ad.grpnet(oracle.dense(np.asfortranarray(Zd)), glm, **kw)
+        assert a.error == "" and b.error == ""
+        tol = 1e-8 if "irls_tol" not in kw else 1e-6
+        assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < tol
+        assert np.abs(a.intercepts - b.intercepts).max() < tol
+    kwc = dict(n_folds=3, seed=1, lmda_path_size=8, min_ratio=0.1, progress_bar=False)
+    ca = ad.cv_grpnet(Z, ad.glm.gaussian(y), **kwc)
+    cb = ad.cv_grpnet(ad.matrix.dense(np.asfortranarray(Zd)), ad.glm.gaussian(y), **kwc)
+    assert np.abs(ca.losses - cb.losses).max() < 1e-7 * max(1.0, np.abs(cb.losses).max())
 
 
 def test_kept_sparse_design_refuses_constraints_and_serves_multi_response_fits(hip, oracle):

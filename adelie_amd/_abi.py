@@ -156,7 +156,7 @@ S = dict(
 # every symbol include/adelie_hip.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = [
     "abi_version", "last_error", "device_count", "set_config",
-    "design_create_dense", "design_create_sparse", "design_create_csc", "design_create_csc_standardized", "design_adopt_dense_dev", "design_create_snp_unphased",
+    "design_create_dense", "design_create_sparse", "design_create_csc", "design_create_standardized", "design_adopt_dense_dev", "design_create_snp_unphased",
     "design_create_snp_calldata", "design_create_snp_bed", "design_alias", "design_create_multi", "design_create_derived", "design_create_concat", "design_impute", "design_destroy",
     "design_glm_path_losses", "design_multi_path_losses", "design_batch_stats", "design_rows", "design_cols", "design_dtype",
     "design_device", "design_stream",
@@ -222,7 +222,7 @@ class Backend:
         sig("design_adopt_dense_dev", ci, [vp, i64, i64, ci, ci, ci, p(vp)])
         sig("design_create_sparse", ci, [vp, vp, vp, i64, i64, ci, ci, p(vp)])
         sig("design_create_csc", ci, [vp, vp, vp, vp, vp, vp, i64, i64, ci, ci, p(vp)])
-        sig("design_create_csc_standardized", ci, [vp, vp, vp, p(vp)])
+        sig("design_create_standardized", ci, [vp, vp, vp, p(vp)])
         sig("design_create_snp_unphased", ci, [vp, i64, ci, ci, p(vp)])
         sig("design_create_snp_calldata", ci, [vp, i64, i64, vp, ci, ci, p(vp)])
         sig("design_create_snp_bed", ci, [vp, i64, i64, i64, ci, ci, p(vp)])

@@ -486,6 +486,9 @@ void op_multi_path_losses(adelie_hip_design* d, int kind, int K, int64_t L, cons
 
 // the multi-response view (kind 2) only serves grpnet_solve; its matrix ops go through the base design
 void no_view(const adelie_hip_design* d) {
+    if (d && d->std_center && d->kind != 3)
+        throw make_core_error("the matrix operations of a standardized view over a dense or SNP design are composed by the caller "
+                              "(adelie_amd.matrix); the handle only serves grpnet_solve.");
     if (d && d->kind == 2)
         throw make_core_error("this entry point is not offered on a multi-response view; use the base design.");
     if (d && d->cov)
@@ -820,11 +823,11 @@ int adelie_hip_design_create_csc(const int64_t* indptr, const int32_t* indices, 
     ABI_CATCH
 }
 
-int adelie_hip_design_create_csc_standardized(adelie_hip_design* src, const double* centers, const double* scales,
-                                              adelie_hip_design** out) {
+int adelie_hip_design_create_standardized(adelie_hip_design* src, const double* centers, const double* scales,
+                                          adelie_hip_design** out) {
     ABI_TRY
     if (!src || !centers || !scales || !out) throw make_core_error("null argument.");
-    if (src->kind != 3) throw make_core_error("the standardized view is offered on a design kept sparse (adelie_hip_design_create_csc).");
+    if (src->kind == 2 || src->cov) no_view(src);
     if (src->std_center) throw make_core_error("the design is a standardized view already.");
     for (int64_t j = 0; j < src->p; ++j)
         if (!(scales[j] != 0.0)) throw make_core_error("scales must be non-zero.");
@@ -1029,7 +1032,7 @@ int adelie_hip_design_batch_stats(adelie_hip_design* d, double* out) {
 int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out) {
     ABI_TRY
     if (!src || !out) throw make_core_error("null argument.");
-    no_view(src);
+    if (src->kind == 2 || src->cov) no_view(src);
     adelie_hip_design* d = new_design(src->n, src->p, src->dtype, src->device); // own stream, own scratch
     d->kind = src->kind;
     d->X = src->X;
@@ -1052,7 +1055,7 @@ int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out) {
 int adelie_hip_design_create_multi(adelie_hip_design* base, int64_t K, int intercept, adelie_hip_design** out) {
     ABI_TRY
     if (!base || !out) throw make_core_error("null argument.");
-    if ((base->kind != 0 && base->kind != 1) || base->cov)
+    if ((base->kind != 0 && base->kind != 1) || base->cov || base->std_center)
         throw make_core_error("the multi-response view needs a dense or 2-bit SNP base design.");
     if (K < 1) throw make_core_error("K must be >= 1.");
     const int64_t icpt = intercept ? 1 : 0;

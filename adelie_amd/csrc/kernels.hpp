@@ -59,6 +59,20 @@ int64_t sweep_work_elems_csc(int nb, int64_t ncols);
 template <class T>
 void launch_sweep_csc(const CscView<T>& X, const T* v, T* out, int64_t c0, int64_t ncols, const int32_t* cols,
                       const T* sub_scale, const T* sub_vec, bool square, T* work, hipStream_t s);
+// Pieces of the standardized view (x_ij - center[j]) * inv_scale[j] over ANY base design (kernels_sparse.hip): the solver composes
+// the base design's raw sweep / Gram / axpy with them.
+template <class T> void launch_vec_sum(const T* v, int64_t n, T* out, hipStream_t s);
+template <class T>
+void launch_std_sweep_epilogue(const T* center, const T* inv_scale, const T* raw, const T* raw_plain, const T* vsum, bool square,
+                               T* out, int64_t c0, int64_t ncols, const int32_t* cols, const T* sub_scale, const T* sub_vec,
+                               hipStream_t s);
+template <class T>
+void launch_std_gram_fix(const T* center, const T* inv_scale, T* C, int64_t ldc, int32_t M, int32_t pos0, int32_t N,
+                         const int32_t* vcol, const T* m, const T* wsum, const T* xm, bool centered, hipStream_t s);
+template <class T>
+void launch_std_scale_coef(const T* center, const T* inv_scale, const int32_t* cols, const T* coef, const int32_t* count_dev,
+                           int32_t count, T* coef2, T* kappa, hipStream_t s);
+template <class T> void launch_vec_shift(T* out, int64_t n, const T* kappa, T sign, const int32_t* count_dev, hipStream_t s);
 // row-block layout of a sparse design with n rows (blocks whose slice of an n-vector is about 1 MB, at most 64 of them) and
 // the per-column block pointers
 void csc_block_layout(int64_t n, size_t value_size, int* nb, int64_t* rb);

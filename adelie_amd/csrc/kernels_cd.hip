@@ -16,6 +16,8 @@
 // update itself is evaluated redundantly by every lane so no broadcast is needed.  The residual is brought up to
 // date once per fit from the list of net coefficient changes this kernel emits (axpy_cols kernel).
 #include "kernels.hpp"
+#include <stdexcept>
+#include <string>
 
 namespace ahip {
 
@@ -313,15 +315,24 @@ void launch_cd(const CdParams<T>& p, hipStream_t s) {
     const size_t base = size_t(8 * p.max_group_size + 8) * sizeof(T);
     const size_t with_g = base + size_t(p.nv) * sizeof(T);
     const size_t lds_cap = 150 * 1024; // of the 160 KiB per CU; the static cnt[] array takes ~1 KiB
+    // the dynamic-LDS limit of both instantiations is raised once, to the cap (see launch_k in kernels_cd_lasso.hip: a
+    // per-call value races between the threads of concurrent solves)
+    static const bool raised = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cd_kernel<T, NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cd_kernel<T, NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  150 * 1024);
+        return true;
+    }();
+    (void)raised;
     if (with_g <= lds_cap) {
-        auto k = cd_kernel<T, NT, true>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(with_g));
-        hipLaunchKernelGGL(k, dim3(1), dim3(NT), with_g, s, p);
+        hipLaunchKernelGGL((cd_kernel<T, NT, true>), dim3(1), dim3(NT), with_g, s, p);
     } else {
-        auto k = cd_kernel<T, NT, false>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(base));
-        hipLaunchKernelGGL(k, dim3(1), dim3(NT), base, s, p);
+        if (base > lds_cap) throw std::runtime_error("adelie_core: a group is too large for the single-workgroup coordinate descent.");
+        hipLaunchKernelGGL((cd_kernel<T, NT, false>), dim3(1), dim3(NT), base, s, p);
     }
+    if (const hipError_t e = hipGetLastError(); e != hipSuccess) // a refused launch must not pass for a solve
+        throw std::runtime_error(std::string("adelie_hip: HIP error '") + hipGetErrorString(e) + "' launching cd_kernel");
 }
 
 template void launch_cd<double>(const CdParams<double>&, hipStream_t);

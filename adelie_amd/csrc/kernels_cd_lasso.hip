@@ -15,6 +15,8 @@
 //     beta / active_set go to global memory from lane 0 and are only re-read in a LATER pass, after the full
 //     __syncthreads() that opens every pass.
 #include "kernels.hpp"
+#include <stdexcept>
+#include <string>
 
 namespace ahip {
 
@@ -259,8 +261,20 @@ __global__ __launch_bounds__(NT) void cd_lasso_kernel(CdParams<T> p) {
 template <class T, int NT, int K>
 static void launch_k(const CdParams<T>& p, size_t bytes, bool tail, hipStream_t s) {
     auto k = tail ? cd_lasso_kernel<T, NT, K, true> : cd_lasso_kernel<T, NT, K, false>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
+    // The limit is raised ONCE per instantiation, to the most any launch asks for (thread-safe static initialisation).  It used
+    // to be set to this launch's size on every call: with several solves in flight (the folds of cv_grpnet run on threads) one
+    // thread could lower it between another thread's call and its launch, and a launch above the limit does not run.
+    static const bool raised = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cd_lasso_kernel<T, NT, K, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cd_lasso_kernel<T, NT, K, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        return true;
+    }();
+    (void)raised;
     hipLaunchKernelGGL(k, dim3(1), dim3(NT), bytes, s, p);
+    if (const hipError_t e = hipGetLastError(); e != hipSuccess) // a refused launch must not pass for a solve
+        throw std::runtime_error(std::string("adelie_hip: HIP error '") + hipGetErrorString(e) + "' launching cd_lasso_kernel");
 }
 
 template <class T>

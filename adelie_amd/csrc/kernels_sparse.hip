@@ -120,14 +120,15 @@ __global__ __launch_bounds__(1024) void vec_sum_kernel(const T* __restrict__ v, 
 }
 // the standardized view's sweep from the raw dot products (see the header)
 template <class T>
-__global__ __launch_bounds__(256) void std_sweep_epilogue_kernel(CscView<T> X, const T* __restrict__ raw, const T* __restrict__ raw_plain,
+__global__ __launch_bounds__(256) void std_sweep_epilogue_kernel(const T* __restrict__ center, const T* __restrict__ inv_scale,
+                                                                  const T* __restrict__ raw, const T* __restrict__ raw_plain,
                                                                   const T* __restrict__ vsum, bool square, T* __restrict__ out,
                                                                   int64_t c0, int64_t ncols, const int32_t* __restrict__ cols,
                                                                   const T* __restrict__ sub_scale, const T* __restrict__ sub_vec) {
     const int64_t k = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (k >= ncols) return;
     const int64_t c = cols ? int64_t(cols[k]) : c0 + k;
-    const T ce = X.center[c], is = X.inv_scale[c], s0 = vsum[0];
+    const T ce = center[c], is = inv_scale[c], s0 = vsum[0];
     T val;
     if (square) val = ((raw[k] - T(2) * ce * raw_plain[k]) + ce * ce * s0) * (is * is);
     else val = (raw[k] - ce * s0) * is;
@@ -322,6 +323,87 @@ inline unsigned blocks_for(int64_t items, int per_block) {
 }
 } // namespace
 
+// ---- standardized view over a dense or 2-bit design (solver_screen.hpp composes the base kernels with these) ----------------
+namespace {
+// C[a, b] (a < M rows by screen position, b in [pos0, pos0 + N)) and its mirror image, from the raw X^T W X the base Gram kernel
+// left there: (C_ab - c_a m_b - c_b m_a + c_a c_b W) / (s_a s_b) - xm_a xm_b.  Pairs inside the new x new square are handled by
+// the one below the diagonal only.
+template <class T>
+__global__ __launch_bounds__(256) void std_gram_fix_kernel(const T* __restrict__ center, const T* __restrict__ inv_scale,
+                                                            T* __restrict__ C, int64_t ldc, int32_t M, int32_t pos0, int32_t N,
+                                                            const int32_t* __restrict__ vcol, const T* __restrict__ m,
+                                                            const T* __restrict__ wsum, const T* __restrict__ xm, bool centered) {
+    const int64_t id = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (id >= int64_t(M) * N) return;
+    const int64_t a = id % M, b = pos0 + id / M;
+    if (a >= pos0 && a < int64_t(pos0) + N && a < b) return;
+    const int64_t ca_ = vcol[a], cb_ = vcol[b];
+    const T ca = center[ca_], cb = center[cb_];
+    T val = (((C[a + b * ldc] - ca * m[b]) - cb * m[a]) + ca * cb * wsum[0]) * (inv_scale[ca_] * inv_scale[cb_]);
+    if (centered) val -= xm[ca_] * xm[cb_];
+    C[a + b * ldc] = val;
+    C[b + a * ldc] = val;
+}
+// coef2[m] = coef[m] / s_col(m);  kappa[0] = sum_m coef[m] c_col(m) / s_col(m)   (one workgroup, fixed order)
+template <class T>
+__global__ __launch_bounds__(256) void std_scale_coef_kernel(const T* __restrict__ center, const T* __restrict__ inv_scale,
+                                                              const int32_t* __restrict__ cols, const T* __restrict__ coef,
+                                                              const int32_t* __restrict__ count_dev, int32_t count,
+                                                              T* __restrict__ coef2, T* __restrict__ kappa) {
+    __shared__ T sh[256];
+    const int32_t cnt = count_dev ? count_dev[0] : count;
+    T a = T(0);
+    for (int32_t i = threadIdx.x; i < cnt; i += 256) {
+        const T sc = coef[i] * inv_scale[cols[i]];
+        coef2[i] = sc;
+        a = fma(sc, center[cols[i]], a);
+    }
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (int(threadIdx.x) < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) kappa[0] = sh[0];
+}
+template <class T>
+__global__ __launch_bounds__(256) void vec_shift_kernel(T* __restrict__ out, int64_t n, const T* __restrict__ kappa, T sign,
+                                                         const int32_t* __restrict__ count_dev) {
+    if (count_dev && count_dev[0] <= 0) return;
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) out[i] -= sign * kappa[0];
+}
+} // namespace
+
+template <class T>
+void launch_vec_sum(const T* v, int64_t n, T* out, hipStream_t s) {
+    hipLaunchKernelGGL((vec_sum_kernel<T>), dim3(1), dim3(1024), 0, s, v, n, out);
+}
+template <class T>
+void launch_std_sweep_epilogue(const T* center, const T* inv_scale, const T* raw, const T* raw_plain, const T* vsum, bool square,
+                               T* out, int64_t c0, int64_t ncols, const int32_t* cols, const T* sub_scale, const T* sub_vec,
+                               hipStream_t s) {
+    if (ncols <= 0) return;
+    hipLaunchKernelGGL((std_sweep_epilogue_kernel<T>), dim3(blocks_for(ncols, 256)), dim3(256), 0, s, center, inv_scale, raw, raw_plain,
+                       vsum, square, out, c0, ncols, cols, sub_scale, sub_vec);
+}
+template <class T>
+void launch_std_gram_fix(const T* center, const T* inv_scale, T* C, int64_t ldc, int32_t M, int32_t pos0, int32_t N,
+                         const int32_t* vcol, const T* m, const T* wsum, const T* xm, bool centered, hipStream_t s) {
+    if (M <= 0 || N <= 0) return;
+    hipLaunchKernelGGL((std_gram_fix_kernel<T>), dim3(blocks_for(int64_t(M) * N, 256)), dim3(256), 0, s, center, inv_scale, C, ldc, M,
+                       pos0, N, vcol, m, wsum, xm, centered);
+}
+template <class T>
+void launch_std_scale_coef(const T* center, const T* inv_scale, const int32_t* cols, const T* coef, const int32_t* count_dev,
+                           int32_t count, T* coef2, T* kappa, hipStream_t s) {
+    hipLaunchKernelGGL((std_scale_coef_kernel<T>), dim3(1), dim3(256), 0, s, center, inv_scale, cols, coef, count_dev, count, coef2, kappa);
+}
+template <class T>
+void launch_vec_shift(T* out, int64_t n, const T* kappa, T sign, const int32_t* count_dev, hipStream_t s) {
+    hipLaunchKernelGGL((vec_shift_kernel<T>), dim3(blocks_for(n, 256)), dim3(256), 0, s, out, n, kappa, sign, count_dev);
+}
+
 // [0, nb * ncols): per-block partials; then two raw vectors of ncols and eight scalars (standardized view)
 int64_t sweep_work_elems_csc(int nb, int64_t ncols) { return int64_t(std::max(nb, 1)) * ncols + 2 * ncols + 8; }
 
@@ -361,9 +443,8 @@ void launch_sweep_csc(const CscView<T>& X, const T* v, T* out, int64_t c0, int64
     T* vsum = raw_plain + ncols;
     raw_sweep<T>(X, v, raw, c0, ncols, cols, nullptr, nullptr, square, work, s);
     if (square) raw_sweep<T>(X, v, raw_plain, c0, ncols, cols, nullptr, nullptr, false, work, s);
-    hipLaunchKernelGGL((vec_sum_kernel<T>), dim3(1), dim3(1024), 0, s, v, X.n, vsum);
-    hipLaunchKernelGGL((std_sweep_epilogue_kernel<T>), dim3(blocks_for(ncols, 256)), dim3(256), 0, s, X, raw, raw_plain, vsum, square,
-                       out, c0, ncols, cols, sub_scale, sub_vec);
+    launch_vec_sum<T>(v, X.n, vsum, s);
+    launch_std_sweep_epilogue<T>(X.center, X.inv_scale, raw, raw_plain, vsum, square, out, c0, ncols, cols, sub_scale, sub_vec, s);
 }
 
 void csc_block_layout(int64_t n, size_t value_size, int* nb, int64_t* rb) {
@@ -395,7 +476,7 @@ void launch_gram_csc(const CscView<T>& X, const T* w, const int32_t* mcols, int3
         T* sw = wsum + 8;
         raw_sweep<T>(X, w, mM, 0, M, mcols, nullptr, nullptr, false, sw, s);
         raw_sweep<T>(X, w, mN, 0, N, ncols, nullptr, nullptr, false, sw, s);
-        hipLaunchKernelGGL((vec_sum_kernel<T>), dim3(1), dim3(1024), 0, s, w, X.n, wsum);
+        launch_vec_sum<T>(w, X.n, wsum, s);
     }
     // entries per column are not known on the host: a fixed spread of workgroups strides each column
     const unsigned spread = unsigned(std::max<int64_t>(1, std::min<int64_t>(64, (X.nnz / std::max<int64_t>(X.p, 1) + 255) / 256)));
@@ -464,7 +545,15 @@ void launch_sp_tmul_csc(const CscView<T>& X, int64_t L, const int64_t* indptr, c
                                      int32_t, const T*, bool, T*, int64_t, T*, hipStream_t);                                     \
     template void launch_axpy_cols_csc<T>(const CscView<T>&, const int32_t*, const T*, const int32_t*, int32_t, T, T*, T*,         \
                                           hipStream_t);                                                                          \
-    template void launch_sp_tmul_csc<T>(const CscView<T>&, int64_t, const int64_t*, const int64_t*, const T*, T*, T*, hipStream_t);
+    template void launch_sp_tmul_csc<T>(const CscView<T>&, int64_t, const int64_t*, const int64_t*, const T*, T*, T*, hipStream_t); \
+    template void launch_vec_sum<T>(const T*, int64_t, T*, hipStream_t);                                                         \
+    template void launch_std_sweep_epilogue<T>(const T*, const T*, const T*, const T*, const T*, bool, T*, int64_t, int64_t,     \
+                                               const int32_t*, const T*, const T*, hipStream_t);                                 \
+    template void launch_std_gram_fix<T>(const T*, const T*, T*, int64_t, int32_t, int32_t, int32_t, const int32_t*, const T*,    \
+                                         const T*, const T*, bool, hipStream_t);                                                 \
+    template void launch_std_scale_coef<T>(const T*, const T*, const int32_t*, const T*, const int32_t*, int32_t, T*, T*,         \
+                                           hipStream_t);                                                                         \
+    template void launch_vec_shift<T>(T*, int64_t, const T*, T, const int32_t*, hipStream_t);
 INST(double)
 INST(float)
 #undef INST

@@ -660,6 +660,10 @@
     // forms; the solve runs on the full-Gram engines (the panel engines stream dense column slices)
     bool sparse() const { return D->kind == 3; }
     DevBuf<T> d_sp_delta; // p zeros between two residual updates
+    // standardized view over a dense or 2-bit design (adelie_hip_design_create_standardized): the base kernels run on the raw
+    // matrix, centring and scaling are applied around them (solver_screen.hpp: sweep / gram / axpy_cols); Gram engines only
+    bool std_generic() const { return D->std_center != nullptr && D->kind != 3; }
+    DevBuf<T> d_std_tmp, d_std_coef;
     // multi-response view (adelie_hip_design_create_multi): residual / weights live response-major on the device
     bool multi() const { return D->kind == 2; }
     int mk() const { return D->kind == 2 ? int(D->mK) : 1; } // class count handed to the GLM kernels

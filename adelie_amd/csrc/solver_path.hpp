@@ -412,7 +412,7 @@
             adev_tol = 0; ddev_tol = 0;
             rdev_tol = T(a->rdev_tol);
         }
-        if (sparse()) engine_panel = false; // Gram engines: C = X_S^T W X_S from launch_gram_csc, residual updated once per fit
+        if (sparse() || std_generic()) engine_panel = false; // Gram engines: C = X_S^T W X_S from launch_gram_csc, residual updated once per fit
         if (multi()) {
             // StateMultiGaussianNaive (state.py:2300-2380): the Gaussian naive solver, global intercept off, on the view.
             // Everything runs on the group panel engine (its blocks are what lets a column slice serve K responses).
@@ -436,6 +436,8 @@
             if (any) {
                 if (sparse())
                     throw make_core_error("constraints are not implemented on a design kept sparse; use matrix.sparse(..., resident=\"dense\").");
+                if (std_generic())
+                    throw make_core_error("constraints are not implemented on a lazily standardized design; use matrix.standardize(..., lazy=False).");
                 if (!all_scalar && max_gs > idx(cd_block_size()))
                     throw make_core_error("constraints are not implemented for problems with groups of more than " +
                                           std::to_string(cd_block_size()) + " coefficients.");

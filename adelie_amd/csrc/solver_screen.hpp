@@ -11,6 +11,22 @@
             launch_multi_sweep<T>(mv, v, out, d_work_sweep.reserve(size_t(multi_sweep_work_elems<T>(mv))), st);
             return;
         }
+        if (std_generic()) { // raw sweep(s) of the base design, then the view's epilogue (kernels_sparse.hip, header)
+            const T* ce = static_cast<const T*>(D->std_center);
+            const T* is = static_cast<const T*>(D->std_iscale);
+            T* tmp = d_std_tmp.reserve(size_t(2 * ncols + 8));
+            T *raw = tmp, *raw_plain = tmp + ncols, *vsum = tmp + 2 * ncols;
+            T* work = d_work_sweep.reserve(size_t(sweep_work_elems(n, ncols)));
+            auto base = [&](T* dst, bool sq) {
+                if (dense()) launch_sweep<T>(D->dense<T>(), v, dst, 0, ncols, cols, nullptr, nullptr, sq, work, st);
+                else launch_sweep_snp<T>(D->snp(), static_cast<const T*>(D->impute), v, dst, 0, ncols, cols, nullptr, nullptr, sq, work, st);
+            };
+            base(raw, square);
+            if (square) base(raw_plain, false);
+            launch_vec_sum<T>(v, n, vsum, st);
+            launch_std_sweep_epilogue<T>(ce, is, raw, raw_plain, vsum, square, out, 0, ncols, cols, sub_scale, sub_vec, st);
+            return;
+        }
         if (batcher && dense() && !cols && ncols == p && !square &&
             batcher->template sweep<T>(D->dense<T>(), v, out, sub_scale, sub_vec, st)) {
             ++cnt.n_sweeps_shared;
@@ -104,13 +120,41 @@
             launch_axpy_cols_csc<T>(D->csc<T>(), cols, coef, cnt_dev, count, sign, out, d_sp_delta.p, st);
             return;
         }
+        if (std_generic()) { // coefficients over the scales into the base design's update, then kappa off every row
+            const T* ce = static_cast<const T*>(D->std_center);
+            const T* is = static_cast<const T*>(D->std_iscale);
+            const size_t cap = size_t(std::max<idx>(nv, idx(count))) + 8;
+            T* c2 = d_std_coef.reserve(cap + 8);
+            T* kappa = c2 + cap;
+            launch_std_scale_coef<T>(ce, is, cols, coef, cnt_dev, count, c2, kappa, st);
+            if (dense()) launch_axpy_cols<T>(D->dense<T>(), cols, c2, cnt_dev, count, sign, out, st);
+            else launch_axpy_cols_snp<T>(D->snp(), static_cast<const T*>(D->impute), cols, c2, cnt_dev, count, sign, out, st);
+            launch_vec_shift<T>(out, n, kappa, sign, cnt_dev, st);
+            return;
+        }
         if (dense()) launch_axpy_cols<T>(D->dense<T>(), cols, coef, cnt_dev, count, sign, out, st);
         else launch_axpy_cols_snp<T>(D->snp(), static_cast<const T*>(D->impute), cols, coef, cnt_dev, count, sign, out, st);
     }
     void gram(const T* w, idx M, idx pos0, idx N, const T* xm, bool center) {
         T* work = d_work_gram.reserve(size_t(sparse() ? gram_work_elems_csc(n, M, N, D->sp_nb) : gram_work_elems(n, M, N)));
         t_gram.begin(st);
-        if (sparse())
+        if (std_generic()) { // raw X^T W X of the base design in place, then the view's rank-one corrections over the panel
+            const T* ce = static_cast<const T*>(D->std_center);
+            const T* is = static_cast<const T*>(D->std_iscale);
+            if (dense())
+                launch_gram<T>(D->dense<T>(), w, d_vcol.p, int32_t(M), 0, d_vcol.p + pos0, int32_t(N), int32_t(pos0), xm, false, d_C.p,
+                               ldc, work, st);
+            else
+                launch_gram_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, d_vcol.p, int32_t(M), 0, d_vcol.p + pos0, int32_t(N),
+                                   int32_t(pos0), xm, false, d_C.p, ldc, work, st);
+            T* tmp = d_std_tmp.reserve(size_t(M + 8));
+            T *mv = tmp, *wsum = tmp + M;
+            T* swork = d_work_sweep.reserve(size_t(sweep_work_elems(n, M)));
+            if (dense()) launch_sweep<T>(D->dense<T>(), w, mv, 0, M, d_vcol.p, nullptr, nullptr, false, swork, st);
+            else launch_sweep_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, mv, 0, M, d_vcol.p, nullptr, nullptr, false, swork, st);
+            launch_vec_sum<T>(w, n, wsum, st);
+            launch_std_gram_fix<T>(ce, is, d_C.p, ldc, int32_t(M), int32_t(pos0), int32_t(N), d_vcol.p, mv, wsum, xm, center, st);
+        } else if (sparse())
             launch_gram_csc<T>(D->csc<T>(), w, d_vcol.p, int32_t(M), 0, d_vcol.p + pos0, int32_t(N), int32_t(pos0), xm, center, d_C.p,
                                ldc, work, st);
         else if (dense())

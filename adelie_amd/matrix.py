@@ -482,6 +482,136 @@ class _MultiView(_NativeMatrix):
         raise NotImplementedError("adelie_amd: alias() of a multi-response view; alias the base design instead.")
 
 
+class _StdView(_NativeMatrix):
+    """``(Z - 1 c^T) diag(s)^-1`` over a resident dense or 2-bit SNP design ``Z``, nothing materialised — the reference's lazy
+    ``MatrixNaiveStandardize`` (``matrix_naive_standardize.ipp``).  The native handle (``adelie_hip_design_create_standardized``)
+    serves ``grpnet`` (the solver composes the base design's kernels with the centring / scaling corrections and runs its
+    full-Gram engines); the matrix operations below are the base design's plus the same rank-one corrections in numpy, as the
+    reference's wrapper does around its wrapped matrix."""
+
+    _is_std_view = True
+
+    def _init_view(self, base, centers, scales):
+        self._base = base
+        self._c = np.array(centers, dtype=self.dtype)
+        self._s = np.array(scales, dtype=self.dtype)
+        self._centers, self._scales = self._c.copy(), self._s.copy()
+
+    def _materialize(self):
+        return _derived(self._base, None, None, self._c, self._s, self._n_threads)
+
+    def alias(self):
+        out = _std_view(self._base.alias(), self._c, self._s, self._n_threads)
+        out._alias_of = self
+        return out
+
+    def cmul(self, j, v, weights):
+        self._chk(0 <= j < self._cols and len(v) == self._rows and len(weights) == self._rows,
+                  "cmul() is given inconsistent inputs!")
+        vw = np.sum(np.asarray(v, dtype=np.float64) * np.asarray(weights, dtype=np.float64))
+        return self.dtype((self._base.cmul(j, v, weights) - self._c[j] * vw) / self._s[j])
+
+    cmul_safe = cmul
+
+    def ctmul(self, j, v, out):
+        self._chk(0 <= j < self._cols and len(out) == self._rows, "ctmul() is given inconsistent inputs!")
+        t = v / self._s[j]
+        self._base.ctmul(j, t, out)
+        out -= self.dtype(t * self._c[j])
+
+    def bmul(self, j, q, v, weights, out):
+        self._chk(0 <= j <= self._cols - q and len(v) == self._rows and len(weights) == self._rows and len(out) == q,
+                  "bmul() is given inconsistent inputs!")
+        raw = np.empty(q, dtype=self.dtype)
+        self._base.bmul(j, q, v, weights, raw)
+        vw = np.sum(np.asarray(v, dtype=np.float64) * np.asarray(weights, dtype=np.float64))
+        out[...] = (raw - self._c[j:j + q] * vw) / self._s[j:j + q]
+
+    bmul_safe = bmul
+
+    def btmul(self, j, q, v, out):
+        self._chk(0 <= j <= self._cols - q and len(v) == q and len(out) == self._rows,
+                  "btmul() is given inconsistent inputs!")
+        t = np.asarray(v, dtype=self.dtype) / self._s[j:j + q]
+        self._base.btmul(j, q, t, out)
+        out -= self.dtype(np.dot(t, self._c[j:j + q]))
+
+    def mul(self, v, weights, out):
+        self.bmul(0, self._cols, v, weights, out)
+
+    def mul_batch(self, V):
+        V = np.ascontiguousarray(V, dtype=self.dtype)
+        raw = self._base.mul_batch(V)
+        return ((raw - np.sum(V, axis=1, dtype=np.float64)[:, None] * self._c[None]) / self._s[None]).astype(self.dtype)
+
+    def cov(self, j, q, sqrt_weights, out):
+        self._chk(0 <= j <= self._cols - q and len(sqrt_weights) == self._rows and out.shape == (q, q),
+                  "cov() is given inconsistent inputs!")
+        raw = np.empty((q, q), dtype=self.dtype, order="F")
+        self._base.cov(j, q, sqrt_weights, raw)
+        w = np.asarray(sqrt_weights, dtype=self.dtype) ** 2
+        m = np.empty(q, dtype=self.dtype)
+        self._base.bmul(j, q, np.ones(self._rows, dtype=self.dtype), w, m)
+        c, s = self._c[j:j + q], self._s[j:j + q]
+        k = np.outer(c, m)  # (k + k.T, c c^T and s s^T are symmetric bit for bit, and so is the result)
+        out[...] = (raw - (k + k.T) + np.outer(c, c) * np.sum(w, dtype=np.float64)) / np.outer(s, s)
+
+    def sq_mul(self, weights, out):
+        self._chk(len(weights) == self._rows and len(out) == self._cols, "sq_mul() is given inconsistent inputs!")
+        w = np.asarray(weights, dtype=self.dtype)
+        sq = np.empty(self._cols, dtype=self.dtype)
+        m = np.empty(self._cols, dtype=self.dtype)
+        self._base.sq_mul(w, sq)
+        self._base.mul(np.ones(self._rows, dtype=self.dtype), w, m)
+        out[...] = (sq - 2 * self._c * m + self._c ** 2 * np.sum(w, dtype=np.float64)) / self._s ** 2
+
+    def sp_tmul(self, v, out):
+        v = v.tocsr()
+        self._chk(v.shape[1] == self._cols and out.shape == (v.shape[0], self._rows), "sp_tmul() is given inconsistent inputs!")
+        scaled = v.multiply(1 / self._s[None]).tocsr().astype(self.dtype)
+        self._base.sp_tmul(scaled, out)
+        out -= np.asarray(scaled @ self._c, dtype=self.dtype).reshape(-1, 1)
+
+    def glm_path_losses(self, glm_kind, betas, intercepts, offsets, y, weights_a, weights_b):
+        # eta = Z (beta / s) + (intercept - sum_j beta_j c_j / s_j): the base design's device path with transformed inputs
+        scaled = betas.tocsr().multiply(1 / self._s[None]).tocsr()
+        shift = np.asarray(scaled @ self._c).reshape(-1)
+        return self._base.glm_path_losses(glm_kind, scaled, np.asarray(intercepts) - shift, offsets, y, weights_a, weights_b)
+
+    def multi_path_losses(self, glm_kind, K, betas, intercepts, offsets, y, weights_a, weights_b):
+        betas = betas.tocsr()
+        scaled = betas.multiply(1 / np.repeat(self._s, K)[None]).tocsr()
+        sel = csr_matrix((np.ones(self._cols * K), (np.arange(self._cols * K), np.arange(self._cols * K) % K)),
+                         shape=(self._cols * K, K))
+        shift = np.asarray((scaled.multiply(np.repeat(self._c, K)[None]).tocsr() @ sel).todense())
+        L = betas.shape[0]
+        return self._base.multi_path_losses(glm_kind, K, scaled, np.asarray(intercepts).reshape(L, K) - shift, offsets, y,
+                                            weights_a, weights_b)
+
+    def impute(self):
+        raise RuntimeError("adelie_amd: impute() belongs to the SNP design under the standardized view (view._base).")
+
+
+def _std_view(base, centers, scales, n_threads):
+    backend = base._backend
+    ce = np.ascontiguousarray(centers, dtype=np.float64)
+    sc = np.ascontiguousarray(scales, dtype=np.float64)
+    handle = _abi.C.c_void_p()
+    backend.check(backend.fn("design_create_standardized")(base._handle, ce.ctypes.data, sc.ctypes.data, handle))
+    mixin = MatrixNaiveBase64 if np.dtype(base.dtype) == np.float64 else MatrixNaiveBase32
+
+    class _view(_StdView, mixin):
+        pass
+
+    _view.dtype = mixin.dtype
+    obj = _view()
+    obj._init_native(backend, handle, n_threads)
+    obj._init_view(base, ce, sc)
+    obj._keep = base
+    obj._kind = "std"
+    return obj
+
+
 def _multi_view(base, K, intercept):
     if not isinstance(base, _NativeMatrix) or isinstance(base, _MultiView):
         raise RuntimeError("adelie_amd: the multi-response view needs a resident (dense or 2-bit SNP) design as its base.")
@@ -489,6 +619,8 @@ def _multi_view(base, K, intercept):
         raise RuntimeError("adelie_core: K must be >= 1.")
     if _is_kept_sparse(base):  # the K-wide kernels stream dense or 2-bit column slices
         base = _expanded(base)
+    if isinstance(base, _StdView):
+        base = base._materialize()
     # (a 2-bit SNP base stays 2-bit: the K-wide sweep, panel step and Gram kernels decode a column's calls once for all K
     # responses -- matrix_naive_kronecker_eye.ipp over matrix_naive_snp_unphased.ipp)
     backend = base._backend
@@ -555,7 +687,7 @@ def concatenate(mats, *, axis: int = 0, n_threads: int = 1):
             raise RuntimeError("All matrices must have the same number of columns.")
         stacked = (_sp.hstack if axis == 1 else _sp.vstack)([m._scipy for m in mats], format="csc")
         return sparse(stacked, n_threads=n_threads, device=getattr(mats[0], "_device", 0), resident="csc")
-    mats = [_expanded(m) if _is_kept_sparse(m) else m for m in mats]
+    mats = [_expanded(m) if _is_kept_sparse(m) else (m._materialize() if isinstance(m, _StdView) else m) for m in mats]
     for m in mats:
         if isinstance(m, (_MultiView, _OnesKron)) or not isinstance(m, _NativeMatrix):
             raise NotImplementedError(
@@ -787,6 +919,8 @@ def snp_bed(bed, n: int, p: int = None, *, dtype=np.float64, n_threads: int = 1,
 
 
 def _derived(mat, rows, cols, centers, scales, n_threads):
+    if isinstance(mat, _StdView):  # derived designs of a lazily standardized design start from its materialised form
+        mat = mat._materialize()
     if not isinstance(mat, _NativeMatrix) or isinstance(mat, _MultiView):
         raise RuntimeError("adelie_amd: subset / standardize need a resident dense or SNP design.")
     if _is_kept_sparse(mat) and getattr(mat, "_std", None) is not None:
@@ -798,7 +932,7 @@ def _derived(mat, rows, cols, centers, scales, n_threads):
             ce = np.ascontiguousarray(centers, dtype=np.float64)
             sc = np.ascontiguousarray(scales, dtype=np.float64)
             handle = _abi.C.c_void_p()
-            backend.check(backend.fn("design_create_csc_standardized")(mat._handle, ce.ctypes.data, sc.ctypes.data, handle))
+            backend.check(backend.fn("design_create_standardized")(mat._handle, ce.ctypes.data, sc.ctypes.data, handle))
             out = _wrap(backend, handle, mat.dtype, n_threads, keep=mat, kind="sparse")
             out._scipy, out._device, out._std = mat._scipy, getattr(mat, "_device", 0), (ce, sc)
             return out
@@ -837,12 +971,21 @@ def _derived(mat, rows, cols, centers, scales, n_threads):
     return _wrap(backend, handle, mat.dtype, n_threads, kind="dense")
 
 
-def standardize(mat, centers=None, scales=None, ddof: int = 0, *, n_threads: int = 1):
+def standardize(mat, centers=None, scales=None, ddof: int = 0, *, n_threads: int = 1, lazy="auto"):
     """``X = (Z - 1 c^T) diag(s)^-1`` (reference ``adelie.matrix.standardize``, ``matrix.py:1414-1533``,
     ``matrix_naive_standardize.ipp``).  ``centers`` / ``scales`` default to the column means and standard deviations of ``mat``
-    under equal weights (``ddof`` as in the reference).  A numpy input gives a numpy result, as in the reference; a resident
-    design gives a new resident dense design (materialised by one kernel rather than wrapped lazily), with ``_centers`` /
-    ``_scales`` attached."""
+    under equal weights (``ddof`` as in the reference).  A numpy input gives a numpy result, as in the reference.  For a
+    resident design, ``lazy`` chooses between the reference's wrapper and a copy:
+
+    * ``lazy=True`` — a view that shares the resident matrix (``adelie_hip_design_create_standardized``): centring and scaling
+      are applied as rank-one corrections around the base design's kernels, ``grpnet`` runs its full-Gram engines on it.  A
+      standardized 2-bit SNP design stays 2 bits per call (the copy is 8 bytes per call: 32 times the memory);
+    * ``lazy=False`` — a new resident dense design materialised by one kernel: twice the memory of a dense base, but the panel
+      engines and MFMA Gram builds run on it (faster for dense bases that fit);
+    * ``lazy="auto"`` (default) — a view over SNP designs and over designs kept sparse (always: centring would fill every
+      cell), a copy of dense ones.
+
+    ``_centers`` / ``_scales`` are attached to the result."""
     if isinstance(mat, (list, np.ndarray)):
         mat = np.array(mat, order="F", copy=True)
         if centers is None:
@@ -863,6 +1006,14 @@ def standardize(mat, centers=None, scales=None, ddof: int = 0, *, n_threads: int
         v = np.empty(p, dtype=dtype)
         mat.var(centers, weights, v)
         scales = np.sqrt((n / (n - ddof)) * v)
+    if lazy not in (True, False, "auto"):
+        raise ValueError("lazy must be True, False or 'auto'.")
+    plain = (isinstance(mat, _NativeMatrix) and not isinstance(mat, (_MultiView, _StdView)) and not _is_kept_sparse(mat)
+             and mat._backend.has("design_create_standardized"))
+    if plain and (lazy is True or (lazy == "auto" and getattr(mat, "_kind", None) == "snp")):
+        if np.any(np.asarray(scales) == 0):
+            raise RuntimeError("adelie_core: scales must be non-zero.")
+        return _std_view(mat, centers, scales, n_threads)
     out = _derived(mat, None, None, centers, scales, n_threads)
     out._centers = np.array(centers, copy=True, dtype=dtype)
     out._scales = np.array(scales, copy=True, dtype=dtype)

@@ -93,12 +93,15 @@ int adelie_hip_design_create_sparse(const int64_t* indptr, const int32_t* indice
 int adelie_hip_design_create_csc(const int64_t* indptr, const int32_t* indices, const void* values, const int64_t* row_indptr,
                                  const int32_t* row_indices, const void* row_values, int64_t n, int64_t p, int dtype, int device,
                                  adelie_hip_design** out);
-/* Replaces MatrixNaiveStandardize (adelie/matrix.py:1414-1533, matrix_naive_standardize.ipp) over a design kept sparse:
- * the view  (x_ij - centers[j]) / scales[j]  of `src` (adelie_hip_design_create_csc) with the stored entries untouched and
- * shared -- centring would fill every cell.  Every operation applies the centring / scaling as a rank-one correction in its
- * epilogue (kernels_sparse.hip).  `src` must outlive the view. */
-int adelie_hip_design_create_csc_standardized(adelie_hip_design* src, const double* centers, const double* scales,
-                                              adelie_hip_design** out);
+/* Replaces MatrixNaiveStandardize (adelie/matrix.py:1414-1533, matrix_naive_standardize.ipp), the lazy wrapper: the view
+ * (x_ij - centers[j]) / scales[j]  of `src` (dense, 2-bit SNP or kept sparse) with the resident matrix untouched and shared.
+ * Over a design kept sparse every operation below applies the centring / scaling as a rank-one correction in its epilogue
+ * (kernels_sparse.hip: centring would fill every cell).  Over a dense or 2-bit design the handle serves grpnet_solve only,
+ * which composes the base design's kernels with those corrections and runs its full-Gram engines (a standardized 2-bit design
+ * stays 2 bits per call instead of 8 bytes); its matrix operations are composed by the caller from the base design's
+ * (adelie_amd.matrix does).  `src` must outlive the view; constraints and the multi-response view are not offered on it. */
+int adelie_hip_design_create_standardized(adelie_hip_design* src, const double* centers, const double* scales,
+                                          adelie_hip_design** out);
 /* Adopt an (n,p) matrix that is ALREADY in device memory (e.g. a torch tensor's data_ptr);
  * not owned, must outlive the design. */
 int adelie_hip_design_adopt_dense_dev(const void* dev_ptr, int64_t n, int64_t p, int dtype, int order,

@@ -58,6 +58,15 @@ res = {
     "dev_ratio_last": float(st.devs[-1]),
     "generate_s": t_gen, "upload_s": t_up,
 }
+if os.environ.get("SPARSE_STANDARDIZE"):  # the standardized view of the same design (entries shared, epilogue corrections)
+    t0 = time.time()
+    Z = ad.matrix.standardize(X)
+    t_std = time.time() - t0
+    ad.grpnet(Z, ad.glm.gaussian(y), lmda_path_size=5, min_ratio=0.5, early_exit=False, progress_bar=False)
+    t0 = time.time()
+    sz = ad.grpnet(Z, ad.glm.gaussian(y), **kw)
+    res["standardized"] = {"path_s": time.time() - t0, "lambdas": len(sz.lmdas), "final_active": int(sz.active_set_size),
+                           "centers_scales_s": t_std, "error": sz.error}
 if os.environ.get("SPARSE_BINOMIAL"):  # IRLS on the same design: the screen set's Gram is rebuilt under every iteration's weights
     yb = (rng.uniform(size=n) < 1 / (1 + np.exp(-(y - y.mean()) / y.std()))).astype(float)
     kwb = dict(lmda_path_size=int(os.environ["SPARSE_BINOMIAL"]), min_ratio=5e-2, early_exit=False, progress_bar=False)

@@ -224,6 +224,79 @@ def test_standardize_and_subset_derived_designs(hip, oracle, kind):
     assert a.error == "" and np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-9
 
 
+@pytest.mark.parametrize("kind,dtype", [("dense", np.float64), ("snp", np.float64), ("dense", np.float32), ("snp", np.float32)])
+def test_lazy_standardized_view(hip, oracle, kind, dtype):
+    """matrix.standardize(lazy=True) (reference MatrixNaiveStandardize, matrix_naive_standardize.ipp: a wrapper, nothing
+    materialised): the view shares the resident dense / 2-bit matrix; its operations are the base design's plus rank-one
+    corrections, grpnet composes the base kernels with the same corrections on its full-Gram engines.  Checked against the
+    numpy-standardized matrix (the reference's check list) and, for paths, against the oracle on that matrix and against the
+    materialised copy (lazy=False: the panel engines)."""
+    rng = np.random.RandomState(23)
+    n, p = 420, 260
+    if kind == "dense":
+        Z = np.asfortranarray((rng.normal(size=(n, p)) * rng.uniform(0.5, 3, p) + rng.normal(size=p)).astype(dtype))
+        M = ad.matrix.dense(Z)
+    else:
+        cd = rng.choice(np.array([0, 1, 2, -9], dtype=np.int8), size=(n, p), p=[0.5, 0.3, 0.1, 0.1])
+        imp = ad.matrix.compute_impute(cd)
+        Z = np.asfortranarray(np.where(cd < 0, imp[None], cd).astype(dtype))
+        M = ad.matrix.snp_calldata(cd, imp, dtype=dtype)
+    S = ad.matrix.standardize(M, lazy=True)
+    assert S._kind == "std" and (S.rows(), S.cols()) == (n, p)
+    assert ad.matrix.standardize(M)._kind == ("std" if kind == "snp" else "dense")   # lazy="auto"
+    Z64 = Z.astype(np.float64)
+    c, s = Z64.mean(0), Z64.std(0)
+    np.testing.assert_allclose(S._centers, c, atol=1e-12 if dtype == np.float64 else 1e-5)
+    Xs = np.asfortranarray(((Z64 - c) / s).astype(dtype))
+    run_naive(S, Xs, dtype)
+    run_naive(S.alias(), Xs, dtype)
+    c2, s2 = rng.normal(size=p), rng.uniform(0.5, 2.0, p)
+    run_naive(ad.matrix.standardize(M, centers=c2, scales=s2, lazy=True), np.asfortranarray(((Z64 - c2) / s2).astype(dtype)), dtype)
+    # derived designs of a view start from its materialised form
+    cols = rng.choice(p, 17, replace=False)
+    run_naive(ad.matrix.subset(S, cols, axis=1), np.asfortranarray(Xs[:, cols]), dtype)
+    with pytest.raises(RuntimeError, match="non-zero"):
+        ad.matrix.standardize(M, centers=np.zeros(p), scales=np.zeros(p), lazy=True)
+    if dtype == np.float32:
+        y = (Xs[:, :3] @ np.array([1.0, -2.0, 0.5]) + 0.3 * rng.normal(size=n)).astype(dtype)
+        kw = dict(tol=1e-7, early_exit=False, lmda_path_size=12, min_ratio=0.05, progress_bar=False)
+        a = ad.grpnet(S, ad.glm.gaussian(y, dtype=dtype), **kw)
+        b = ad.grpnet(ad.matrix.standardize(M, lazy=False), ad.glm.gaussian(y, dtype=dtype), **kw)
+        assert a.error == "" and np.abs(a.betas.toarray() - b.betas.toarray()).max() < 2e-3
+        return
+    beta = np.zeros(p)
+    beta[rng.choice(p, 30, replace=False)] = rng.normal(size=30)
+    y = Xs @ beta + 0.5 * rng.normal(size=n)
+    w = rng.uniform(0.2, 1.0, n)
+    for glm, kw in [
+        (ad.glm.gaussian(y), dict(tol=1e-12, min_ratio=1e-3, lmda_path_size=30)),     # screen sets past 128 values
+        (ad.glm.gaussian(y, weights=w / w.sum()), dict(tol=1e-12, groups=np.arange(0, p, 4), alpha=0.7)),
+        (ad.glm.gaussian(y), dict(tol=1e-12, intercept=False)),
+        (ad.glm.binomial((y > np.median(y)).astype(float)), dict(tol=1e-10, irls_tol=1e-10, lmda_path_size=10, min_ratio=0.1)),
+    ]:
+        kw = dict(dict(early_exit=False, lmda_path_size=15, min_ratio=2e-2, progress_bar=False), **kw)
+        a = ad.grpnet(S, glm, **kw)
+        b = ad.grpnet(oracle.dense(Xs), glm, **kw)
+        assert a.error == "" and b.error == ""
+        tol = 1e-8 if "irls_tol" not in kw else 1e-6
+        assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < tol
+        assert np.abs(a.intercepts - b.intercepts).max() < tol
+    assert max(a.screen_sizes) >= 0
+    kwc = dict(n_folds=3, seed=1, lmda_path_size=8, min_ratio=0.1, progress_bar=False)
+    ca = ad.cv_grpnet(S, ad.glm.gaussian(y), **kwc)
+    cb = ad.cv_grpnet(ad.matrix.dense(Xs), ad.glm.gaussian(y), **kwc)
+    assert np.abs(ca.losses - cb.losses).max() < 1e-7 * max(1.0, np.abs(cb.losses).max())
+    cons = [None] * p
+    cons[3] = ad.constraint.lower(np.array([-0.5]))
+    with pytest.raises(RuntimeError, match="lazily standardized"):
+        ad.grpnet(S, ad.glm.gaussian(y), constraints=cons, progress_bar=False)
+    Y = np.stack([y, -y], axis=1)   # multi-response fits: the view is materialised first
+    kwm = dict(tol=1e-12, early_exit=False, lmda_path_size=8, min_ratio=0.2, progress_bar=False)
+    ma = ad.grpnet(S, ad.glm.multigaussian(Y), **kwm)
+    mb = ad.grpnet(ad.matrix.dense(Xs), ad.glm.multigaussian(Y), **kwm)
+    assert ma.error == "" and np.abs(ma.betas.toarray() - mb.betas.toarray()).max() < 1e-9
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("fmt", ["csc", "csr"])
 def test_sparse_design_runs_the_reference_check_list(hip, dtype, fmt):

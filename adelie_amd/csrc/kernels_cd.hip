@@ -325,6 +325,7 @@ void launch_cd(const CdParams<T>& p, hipStream_t s) {
         return true;
     }();
     (void)raised;
+    (void)hipGetLastError(); // (whatever an earlier call of this thread left behind, e.g. an allocation the pool retried)
     if (with_g <= lds_cap) {
         hipLaunchKernelGGL((cd_kernel<T, NT, true>), dim3(1), dim3(NT), with_g, s, p);
     } else {

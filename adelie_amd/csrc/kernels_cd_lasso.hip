@@ -272,6 +272,7 @@ static void launch_k(const CdParams<T>& p, size_t bytes, bool tail, hipStream_t 
         return true;
     }();
     (void)raised;
+    (void)hipGetLastError(); // (whatever an earlier call of this thread left behind, e.g. an allocation the pool retried)
     hipLaunchKernelGGL(k, dim3(1), dim3(NT), bytes, s, p);
     if (const hipError_t e = hipGetLastError(); e != hipSuccess) // a refused launch must not pass for a solve
         throw std::runtime_error(std::string("adelie_hip: HIP error '") + hipGetErrorString(e) + "' launching cd_lasso_kernel");

@@ -84,7 +84,13 @@ class _NativeMatrix:
         self._n_threads = n_threads
         self._rows = int(backend.fn("design_rows")(handle))
         self._cols = int(backend.fn("design_cols")(handle))
-        self.T = PyMatrixNaiveTranspose(self)
+
+    @property
+    def T(self):
+        """``X.T @ v`` sugar (reference ``matrix.py:79-100``).  Made on demand: a stored wrapper would tie the design into a
+        reference cycle, and its device memory (gigabytes) would wait for the cycle collector instead of going when the last
+        user reference goes."""
+        return PyMatrixNaiveTranspose(self)
 
     def __del__(self):
         h = getattr(self, "_handle", None)

@@ -86,9 +86,12 @@ def make_snp_data(n, p, seed, device):
         cdt[j0:j1] = blk
         del u, blk
     cd = cdt.t()
-    valid = cd >= 0
-    imp = (cd * valid).sum(dim=0, dtype=torch.float64) / valid.sum(dim=0).clamp(min=1)
-    del valid
+    imp = torch.empty(p, dtype=torch.float64, device=device)
+    for j0 in range(0, p, 2048):  # (column chunks: a whole-matrix mask / product / f64 reduction input would be 10x the calldata)
+        blk = cdt[j0:j0 + 2048]
+        valid = blk >= 0
+        imp[j0:j0 + 2048] = (blk * valid).sum(dim=1, dtype=torch.float64) / valid.sum(dim=1).clamp(min=1)
+        del blk, valid
     rng = np.random.default_rng(seed)
     beta = rng.standard_normal(p) * (rng.random(p) < min(0.05, 500 / p))
     eta = torch.zeros(n, dtype=torch.float64, device=device)

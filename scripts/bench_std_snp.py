@@ -1,0 +1,50 @@
+"""matrix.standardize over a 2-bit SNP design, lazily (the view shares the 2-bit matrix: 2 bits per call) and materialised
+(a dense f64 copy: 8 bytes per call): wall of a Gaussian lasso path on both, resident bytes, max|dbeta|.
+
+    python scripts/bench_std_snp.py [n p lambdas]      (default 200000 20000 100)
+"""
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+import adelie_amd as ad
+
+n, p, L = (int(float(sys.argv[1])), int(float(sys.argv[2])), int(sys.argv[3])) if len(sys.argv) > 3 else (200_000, 20_000, 100)
+g = torch.Generator(device="cuda").manual_seed(0)
+u = torch.rand((p, n), device="cuda", generator=g)
+cd = torch.zeros((p, n), dtype=torch.int8, device="cuda")
+cd[u > 0.60] = 1
+cd[u > 0.85] = 2
+cd[u > 0.90] = -9
+del u
+cd = cd.t()  # (n, p) with strides (1, n)
+X = ad.matrix.snp_calldata(cd)
+del cd
+torch.cuda.empty_cache()
+rng = np.random.default_rng(0)
+beta = np.zeros(p)
+beta[rng.choice(p, 50, replace=False)] = rng.normal(size=50)
+eta = np.zeros(n)
+X.btmul(0, p, beta, eta)
+y = eta + np.std(eta) * rng.normal(size=n)
+kw = dict(lmda_path_size=L, min_ratio=2e-2, early_exit=False, progress_bar=False)
+res = {"workload": f"Gaussian lasso on standardize(snp {n}x{p}), {L} lambdas", "bytes_2bit": int(n * p / 4), "bytes_dense_copy": int(n * p * 8)}
+for name, lazy in (("lazy_view", True), ("materialised", False)):
+    if not lazy and n * p * 8 > 150 * 2**30:
+        continue
+    t0 = time.time()
+    Z = ad.matrix.standardize(X, lazy=lazy)
+    t_make = time.time() - t0
+    ad.grpnet(Z, ad.glm.gaussian(y), lmda_path_size=5, min_ratio=0.5, early_exit=False, progress_bar=False)
+    t0 = time.time()
+    st = ad.grpnet(Z, ad.glm.gaussian(y), **kw)
+    res[name] = {"path_s": time.time() - t0, "make_s": t_make, "final_active": int(st.active_set_size), "error": st.error}
+    if lazy:
+        ref = st.betas.toarray()
+    else:
+        res["max_abs_dbeta"] = float(np.abs(ref - st.betas.toarray()).max())
+    del Z
+print(json.dumps(res))

@@ -29,3 +29,4 @@ def hip():
     b = _abi.hip_backend()
     assert b.fn("device_count")() > 0, "no HIP device visible"
     return b
+

@@ -4,6 +4,7 @@
     python scripts/bench_std_snp.py [n p lambdas]      (default 200000 20000 100)
 """
 import json
+import os
 import sys
 import time
 
@@ -13,15 +14,11 @@ import torch
 import adelie_amd as ad
 
 n, p, L = (int(float(sys.argv[1])), int(float(sys.argv[2])), int(sys.argv[3])) if len(sys.argv) > 3 else (200_000, 20_000, 100)
-g = torch.Generator(device="cuda").manual_seed(0)
-u = torch.rand((p, n), device="cuda", generator=g)
-cd = torch.zeros((p, n), dtype=torch.int8, device="cuda")
-cd[u > 0.60] = 1
-cd[u > 0.85] = 2
-cd[u > 0.90] = -9
-del u
-cd = cd.t()  # (n, p) with strides (1, n)
-X = ad.matrix.snp_calldata(cd)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (the calldata generator of config 4: rates of adelie.data.snp_unphased, built by column chunks)
+
+cd, imp, _ = bench.make_snp_data(n, p, 0, torch.device("cuda", 0))
+X = ad.matrix.snp_calldata(cd, imp)
 del cd
 torch.cuda.empty_cache()
 rng = np.random.default_rng(0)
@@ -29,8 +26,8 @@ beta = np.zeros(p)
 beta[rng.choice(p, 50, replace=False)] = rng.normal(size=50)
 eta = np.zeros(n)
 X.btmul(0, p, beta, eta)
-y = eta + np.std(eta) * rng.normal(size=n)
-kw = dict(lmda_path_size=L, min_ratio=2e-2, early_exit=False, progress_bar=False)
+y = eta + float(os.environ.get("NOISE", "1.0")) * np.std(eta) * rng.normal(size=n)
+kw = dict(lmda_path_size=L, min_ratio=float(os.environ.get("MIN_RATIO", "2e-2")), early_exit=False, progress_bar=False)
 res = {"workload": f"Gaussian lasso on standardize(snp {n}x{p}), {L} lambdas", "bytes_2bit": int(n * p / 4), "bytes_dense_copy": int(n * p * 8)}
 for name, lazy in (("lazy_view", True), ("materialised", False)):
     if not lazy and n * p * 8 > 150 * 2**30:

@@ -2,6 +2,7 @@
 TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 export PYTHONPATH=$R
+export SPARSE_STANDARDIZE=1
 cd /tmp && export TMPDIR=/tmp
 timeout 900 python $R/scripts/bench_sparse.py > $R/gpurun_out/${TAG}_sparse_bench.json 2> $R/gpurun_out/${TAG}_sparse_bench.err
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_sparse_k -o k -- python $R/scripts/bench_sparse.py > $R/gpurun_out/${TAG}_sparse_bench_under_rocprof.json 2> $R/gpurun_out/prof_${TAG}_sparse.err

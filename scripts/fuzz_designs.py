@@ -32,7 +32,8 @@ for case in range(N):
             M = ad.matrix.snp_calldata(calls, dtype=dtype)
         elif kind == "sparse":
             D = (rng.normal(size=(n, p)) * (rng.uniform(size=(n, p)) < 0.3)).astype(dtype)
-            M = ad.matrix.sparse(sp.csc_matrix(D) if rng.uniform() < 0.5 else sp.csr_matrix(D))
+            M = ad.matrix.sparse(sp.csc_matrix(D) if rng.uniform() < 0.5 else sp.csr_matrix(D),
+                                 resident=str(rng.choice(["csc", "dense", "auto"])))  # kept sparse / expanded
         else:
             D = np.asfortranarray(rng.normal(size=(n, p)), dtype=dtype)
             M = ad.matrix.dense(D) if kind == "dense" else D
@@ -48,7 +49,7 @@ for case in range(N):
             X = X[:, cols]; D = D[:, cols]
         if rng.uniform() < 0.4:
             c = rng.normal(size=D.shape[1]); s_ = rng.uniform(0.5, 2, D.shape[1])
-            X = ad.matrix.standardize(X, centers=c, scales=s_)
+            X = ad.matrix.standardize(X, centers=c, scales=s_, lazy=[True, False, "auto"][int(rng.randint(3))])  # view / copy
             D = ((D.astype(np.float64) - c[None]) / s_[None]).astype(dtype)
         if ONLY is not None:
             w = np.random.RandomState(42).uniform(0, 1, D.shape[0]).astype(dtype)

@@ -24,7 +24,9 @@ Multi-GPU (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus 
     table): total work is fixed, ``"scaling": "strong"``.
   * the default line (config 2) additionally carries the legs ``"cfg3"``, ``"f32"`` (config 2 in single precision) and
     ``"cfg4"`` — the same measurement as ``--config 3 / 4`` with fewer steps, each with its own roofline objects — unless
-    ``--no-extra-legs`` is given (profiling runs), and
+    ``--no-extra-legs`` is given (profiling runs); at N = 1 also ``"standardized_snp_view"`` (a Gaussian path on config 4's
+    2-bit design under the lazy standardized view: 6.25 GB resident instead of a 200 GB copy) and ``"sparse_resident"`` (a
+    1M x 100k sparse design with 1e8 stored entries kept sparse: 745 GiB as dense f64), DESIGN.md 9.9, and
   * ``"cv_config5"``: the same sharded CV timed right after the headline
     steps, so that a ``--gpus 1/2/4/8`` series holds BASELINE.json's second target (8-fold CV at 1/2/4/8 GPUs) as well.
 """
@@ -492,7 +494,13 @@ def main():
         ctx.torch.cuda.empty_cache()
         line4, k4 = measure(ctx, 4, n=500_000, p=50_000, gs=1, alpha=1.0, dtype="f64", L=L, steps=1, warmup=1)
         out["cfg4"] = leg(line4)
+        # two designs whose dense f64 form does not fit (or barely fits) in HBM, as further objects of the default line
+        # (DESIGN.md 9.9): config 4's 2-bit design under the lazy standardized view, and a sparse design kept sparse
+        out["standardized_snp_view"] = lazy_views_leg(ad_design=k4["Xd"], L=L)
         del k4, line4
+        gc.collect()
+        ctx.torch.cuda.empty_cache()
+        out["sparse_resident"] = sparse_leg(L)
 
     if ctx.rank == 0:
         print(json.dumps(out), flush=True)
@@ -500,6 +508,66 @@ def main():
     if ctx.dist is not None:
         ctx.dist.barrier()
         ctx.dist.destroy_process_group()
+
+
+# -------------------------------------------------------------------------------------------------------------------------
+# designs that do not fit dense (extra objects of the default line; a failure is recorded, it does not cost the headline)
+# -------------------------------------------------------------------------------------------------------------------------
+def lazy_views_leg(ad_design, L):
+    """Gaussian lasso path on matrix.standardize(<config 4's 500k x 50k 2-bit design>) as a view (6.25 GB resident; the
+    materialised copy would be 200 GB)."""
+    import adelie_amd as ad
+
+    try:
+        X = ad_design
+        n, p = X.shape
+        rng = np.random.default_rng(7)
+        beta = np.zeros(p)
+        beta[rng.choice(p, 50, replace=False)] = rng.standard_normal(50)
+        eta = np.zeros(n)
+        X.btmul(0, p, beta, eta)
+        y = eta + np.std(eta) * rng.standard_normal(n)
+        Z = ad.matrix.standardize(X, lazy=True)
+        kw = dict(lmda_path_size=L, min_ratio=2e-2, early_exit=False, progress_bar=False)
+        ad.grpnet(Z, ad.glm.gaussian(y), **dict(kw, lmda_path_size=5, min_ratio=0.5))
+        t0 = time.perf_counter()
+        st = ad.grpnet(Z, ad.glm.gaussian(y), **kw)
+        el = time.perf_counter() - t0
+        return {"workload": f"Gaussian lasso, {L} lambdas, standardize(snp_unphased {n}x{p}) as a view sharing the 2-bit matrix",
+                "value": 1.0 / el, "unit": "paths/s", "ms_per_step": el * 1e3, "resident_bytes": int(n * p / 4),
+                "dense_copy_bytes": int(n * p * 8), "lambdas": len(st.lmdas), "final_active": int(st.active_set_size),
+                "error": st.error}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
+
+
+def sparse_leg(L, n=1_000_000, p=100_000, density=1e-3):
+    """Gaussian lasso path on a sparse design kept sparse in HBM (matrix.sparse(resident="csc")): 745 GiB as dense f64."""
+    import scipy.sparse as sp
+
+    import adelie_amd as ad
+
+    try:
+        rng = np.random.default_rng(0)
+        nnz = int(n * p * density)
+        M = sp.csc_matrix((rng.standard_normal(nnz), (rng.integers(0, n, size=nnz), rng.integers(0, p, size=nnz))), shape=(n, p))
+        M.sum_duplicates()
+        M.sort_indices()
+        beta = np.zeros(p)
+        beta[rng.choice(p, 50, replace=False)] = rng.standard_normal(50) * 3
+        y = M @ beta + rng.standard_normal(n)
+        X = ad.matrix.sparse(M, resident="csc")
+        kw = dict(lmda_path_size=L, min_ratio=1e-2, early_exit=False, progress_bar=False)
+        ad.grpnet(X, ad.glm.gaussian(y), **dict(kw, lmda_path_size=5, min_ratio=0.5))
+        t0 = time.perf_counter()
+        st = ad.grpnet(X, ad.glm.gaussian(y), **kw)
+        el = time.perf_counter() - t0
+        return {"workload": f"Gaussian lasso, {L} lambdas, sparse design {n}x{p} with {M.nnz} stored entries kept sparse (CSC + CSR)",
+                "value": 1.0 / el, "unit": "paths/s", "ms_per_step": el * 1e3, "resident_bytes": int(M.nnz * 24 + (n + p + 2) * 8),
+                "dense_copy_bytes": int(n * p * 8), "lambdas": len(st.lmdas), "final_active": int(st.active_set_size),
+                "n_sweeps": int(st.counters["n_sweeps"]), "error": st.error}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
 
 
 # -------------------------------------------------------------------------------------------------------------------------

@@ -3,7 +3,8 @@
 // (CSR: residual updates, X beta), 12 bytes per stored entry each way: every operation below is one stream over the entries
 // it needs, HBM-bound on nnz, with a fixed summation order (no atomics on the data path of a solve).
 //
-//   sweep      out[k] = sum_t val[t](^2) v[row[t]]          one wavefront per column, lanes stride the column's entries
+//   sweep      out[k] = sum_t val[t](^2) v[row[t]]          64 / 16 / 4 lanes per (column, row block) segment stride its entries;
+//                                                           row blocks keep the gathered slice of v in L2
 //   Gram       C[a, b] = sum_i w_i x_ia x_ib - xm_a xm_b    up to 8 columns b scattered (times w) into a dense (n, 8) slab,
 //                                                           then one 8-wide sweep over the columns a
 //   axpy       out[i] += sign sum_m coef[m] x[i, cols[m]]   coefficients scattered into a dense p-vector, one CSR pass

@@ -752,6 +752,9 @@
     }
 
     // solver_base.hpp:273-403
+    std::vector<std::pair<T, idx>> screen_keyed; // (kept between calls: no allocation per lambda)
+    T screen_thr = 0;                            // see the pivot rule below
+    bool screen_thr_valid = false;
     void screen(T lmda_next, bool all_kkt_passed, int n_new_active) {
         const int old_size = int(screen_set.size());
         if (screen_rule == ADELIE_HIP_SCREEN_STRONG) {
@@ -763,40 +766,60 @@
         } else if (screen_rule == ADELIE_HIP_SCREEN_PIVOT) {
             if (n_new_active) {
                 const int Gi = int(G);
-                // sort (score, group) pairs in place: contiguous keys instead of an indirect comparator
-                std::vector<std::pair<T, idx>> keyed(Gi);
-                for (int i = 0; i < Gi; ++i) {
-                    const T wt = (penalty[i] <= 0) ? alpha * lmda : std::min(abs_grad[i] / penalty[i], alpha * lmda);
-                    keyed[i] = std::make_pair(wt, idx(i));
+                const int subset_size =
+                    std::min<int>(std::max<int>(int(old_size * (1 + pivot_subset_ratio)), int(pivot_subset_min)), Gi);
+                // The rule reads the sorted scores only from the top: the `subset_size` largest for the pivot search, and below
+                // the pivot as many more as it takes to find slack * n_new_active groups outside the screen set — at most
+                // `need` positions in all.  With a lower bound on the need-th largest score (what the previous lambda's list
+                // had at twice that depth: the scores of unscreened groups grow as lambda falls) one pass collects every
+                // group at or above it, in group order, and only those are sorted; whenever they are fewer than `need`
+                // (or there is no bound yet) all G are sorted as before.  Same pairs in the same order either way.
+                const int64_t need = int64_t(subset_size) + int64_t(std::ceil(pivot_slack_ratio * n_new_active)) + old_size + 2;
+                auto score = [&](int i) {
+                    return (penalty[i] <= 0) ? alpha * lmda : std::min(abs_grad[i] / penalty[i], alpha * lmda);
+                };
+                // (score, group) pairs, sorted in place: contiguous keys instead of an indirect comparator
+                std::vector<std::pair<T, idx>>& keyed = screen_keyed;
+                keyed.clear();
+                bool partial = false;
+                if (screen_thr_valid && need * 4 < Gi) {
+                    for (int i = 0; i < Gi; ++i) {
+                        const T wt = score(i);
+                        if (wt >= screen_thr) keyed.emplace_back(wt, idx(i));
+                    }
+                    partial = int64_t(keyed.size()) >= need;
+                }
+                if (!partial) {
+                    keyed.resize(size_t(Gi));
+                    for (int i = 0; i < Gi; ++i) keyed[size_t(i)] = std::make_pair(score(i), idx(i));
                 }
                 // The reference sorts with `weights[i] < weights[j]` only (solver_base.hpp:320-326): every group whose score is
                 // capped at alpha*lmda ties exactly, and std::sort leaves the order of ties unspecified.  Ties are broken by
                 // group index here (pair comparison) so that the screen insertion order (= CD visiting order) is reproducible.
                 sort_keyed(keyed);
-                std::vector<idx> order(Gi);
-                std::vector<T> wts(Gi);
-                for (int i = 0; i < Gi; ++i) {
-                    order[i] = keyed[i].second;
-                    wts[keyed[i].second] = keyed[i].first;
+                const int M = int(keyed.size()); // position ii of the full order is keyed[ii - (Gi - M)]
+                const int base = Gi - M;
+                {   // bound for the next lambda: the score twice as deep as this call could have read
+                    const int64_t depth = std::min<int64_t>(2 * need, M);
+                    screen_thr = keyed[size_t(M - depth)].first;
+                    screen_thr_valid = depth >= need;
                 }
-                const int subset_size =
-                    std::min<int>(std::max<int>(int(old_size * (1 + pivot_subset_ratio)), int(pivot_subset_min)), Gi);
                 std::vector<T> sub(subset_size), mses(subset_size), ind(subset_size);
                 for (int i = 0; i < subset_size; ++i) {
-                    sub[i] = wts[order[Gi - subset_size + i]];
+                    sub[i] = keyed[size_t(Gi - subset_size + i - base)].first;
                     ind[i] = T(i);
                 }
                 const int pivot_idx = search_pivot(ind, sub, mses);
                 const int full_pivot_idx = Gi - subset_size + pivot_idx;
                 for (int ii = Gi - 1; ii >= full_pivot_idx; --ii) {
-                    const idx i = order[ii];
+                    const idx i = keyed[size_t(ii - base)].second;
                     if (is_screen(i)) continue;
                     screen_set.push_back(i);
                 }
                 int count = 0;
-                for (int ii = full_pivot_idx - 1; ii >= 0; --ii) {
+                for (int ii = full_pivot_idx - 1; ii >= base; --ii) {
                     if (count >= pivot_slack_ratio * n_new_active) break;
-                    const idx i = order[ii];
+                    const idx i = keyed[size_t(ii - base)].second;
                     if (is_screen(i)) continue;
                     screen_set.push_back(i);
                     ++count;

@@ -61,6 +61,8 @@ void launch_sweep_csc(const CscView<T>& X, const T* v, T* out, int64_t c0, int64
                       const T* sub_scale, const T* sub_vec, bool square, T* work, hipStream_t s);
 // Pieces of the standardized view (x_ij - center[j]) * inv_scale[j] over ANY base design (kernels_sparse.hip): the solver composes
 // the base design's raw sweep / Gram / axpy with them.
+// out[0] = sum_i v[i], fixed order; `out` holds kVecSumScratch elements (the result, then the chunk sums)
+constexpr int kVecSumScratch = 8 + 256;
 template <class T> void launch_vec_sum(const T* v, int64_t n, T* out, hipStream_t s);
 template <class T>
 void launch_std_sweep_epilogue(const T* center, const T* inv_scale, const T* raw, const T* raw_plain, const T* vsum, bool square,

@@ -14,7 +14,7 @@
         if (std_generic()) { // raw sweep(s) of the base design, then the view's epilogue (kernels_sparse.hip, header)
             const T* ce = static_cast<const T*>(D->std_center);
             const T* is = static_cast<const T*>(D->std_iscale);
-            T* tmp = d_std_tmp.reserve(size_t(2 * ncols + 8));
+            T* tmp = d_std_tmp.reserve(size_t(2 * ncols + kVecSumScratch));
             T *raw = tmp, *raw_plain = tmp + ncols, *vsum = tmp + 2 * ncols;
             T* work = d_work_sweep.reserve(size_t(sweep_work_elems(n, ncols)));
             auto base = [&](T* dst, bool sq) {
@@ -147,7 +147,7 @@
             else
                 launch_gram_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, d_vcol.p, int32_t(M), 0, d_vcol.p + pos0, int32_t(N),
                                    int32_t(pos0), xm, false, d_C.p, ldc, work, st);
-            T* tmp = d_std_tmp.reserve(size_t(M + 8));
+            T* tmp = d_std_tmp.reserve(size_t(M + kVecSumScratch));
             T *mv = tmp, *wsum = tmp + M;
             T* swork = d_work_sweep.reserve(size_t(sweep_work_elems(n, M)));
             if (dense()) launch_sweep<T>(D->dense<T>(), w, mv, 0, M, d_vcol.p, nullptr, nullptr, false, swork, st);

@@ -531,6 +531,27 @@ void derive_t(adelie_hip_design* src, adelie_hip_design* d, const int64_t* rows,
               int64_t ncols, const double* centers, const double* scales) {
     constexpr int64_t kAlign = 32;
     const int64_t nout = d->n, pout = d->p;
+    if (src->kind == 1 && !centers && !scales) { // a subset of a 2-bit design stays 2 bits per call
+        hipStream_t s = d->stream;
+        d->kind = 1;
+        d->ldb = (((nout + 3) / 4 + 63) / 64) * 64;
+        AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->bits), size_t(d->ldb) * size_t(pout)));
+        AHIP_CHECK(hipMalloc(&d->impute, size_t(pout) * sizeof(T)));
+        int64_t *drows = nullptr, *dcols = nullptr;
+        if (rows) {
+            drows = scratch<int64_t>(d->s_idx1, size_t(nrows));
+            AHIP_CHECK(hipMemcpyAsync(drows, rows, size_t(nrows) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        }
+        if (cols) {
+            dcols = scratch<int64_t>(d->s_idx2, size_t(ncols));
+            AHIP_CHECK(hipMemcpyAsync(dcols, cols, size_t(ncols) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        }
+        AHIP_CHECK(hipStreamSynchronize(src->stream));
+        launch_snp_subset(src->snp(), nout, pout, drows, dcols, d->bits, d->ldb, s);
+        launch_gather_cols<T>(static_cast<const T*>(src->impute), dcols, pout, static_cast<T*>(d->impute), s);
+        AHIP_CHECK(hipStreamSynchronize(s));
+        return;
+    }
     const int64_t ld = ((nout + kAlign - 1) / kAlign) * kAlign;
     T* X = nullptr;
     AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&X), size_t(ld) * size_t(pout) * sizeof(T)));
@@ -574,6 +595,25 @@ template <class T>
 void concat_t(adelie_hip_design* const* srcs, int64_t k, int axis, adelie_hip_design* d) {
     constexpr int64_t kAlign = 32;
     const int64_t nout = d->n, pout = d->p;
+    bool all_snp = axis == 1;
+    for (int64_t m = 0; m < k && all_snp; ++m) all_snp = srcs[m]->kind == 1 && !srcs[m]->std_center && srcs[m]->ldb == srcs[0]->ldb;
+    if (all_snp) { // 2-bit designs side by side stay a 2-bit design: their columns are copied as they are
+        hipStream_t s = d->stream;
+        d->kind = 1;
+        d->ldb = srcs[0]->ldb;
+        AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->bits), size_t(d->ldb) * size_t(pout)));
+        AHIP_CHECK(hipMalloc(&d->impute, size_t(pout) * sizeof(T)));
+        int64_t off = 0;
+        for (int64_t m = 0; m < k; ++m) {
+            adelie_hip_design* src = srcs[m];
+            AHIP_CHECK(hipStreamSynchronize(src->stream));
+            AHIP_CHECK(hipMemcpyAsync(d->bits + off * d->ldb, src->bits, size_t(src->ldb) * size_t(src->p), hipMemcpyDeviceToDevice, s));
+            AHIP_CHECK(hipMemcpyAsync(static_cast<T*>(d->impute) + off, src->impute, size_t(src->p) * sizeof(T), hipMemcpyDeviceToDevice, s));
+            off += src->p;
+        }
+        AHIP_CHECK(hipStreamSynchronize(s));
+        return;
+    }
     const int64_t ld = ((nout + kAlign - 1) / kAlign) * kAlign;
     T* X = nullptr;
     AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&X), size_t(ld) * size_t(pout) * sizeof(T)));

@@ -593,6 +593,10 @@ void launch_grp_eig(const T* src_base, const EigDesc* desc_dev, int count, int m
 template <class T> void launch_diag_vars(const T* C, int64_t ldc, int32_t pos0, int32_t cnt, T* vars, hipStream_t s);
 // transpose row-major (n,p) into column-major with leading dimension ld
 template <class T> void launch_transpose(const T* src, int64_t n, int64_t p, T* dst, int64_t ld, hipStream_t s);
+// rows / columns of a 2-bit design re-packed as a 2-bit design (dst: pout columns of ldb_dst bytes)
+void launch_snp_subset(const SnpView& X, int64_t nout, int64_t pout, const int64_t* rows, const int64_t* cols, uint8_t* dst,
+                       int64_t ldb_dst, hipStream_t s);
+template <class T> void launch_gather_cols(const T* src, const int64_t* cols, int64_t pout, T* out, hipStream_t s);
 // dst (zeroed, column-major, leading dimension ld) += the entries of a CSC matrix
 template <class T>
 void launch_csc_scatter(const int64_t* indptr, const int32_t* indices, const T* values, int64_t n, int64_t p, T* dst,

@@ -772,6 +772,47 @@ void launch_derive_dense_snp(const SnpView& X, const T* impute, int64_t nout, in
     }
 }
 
+// Rows / columns of a 2-bit design as another 2-bit design (matrix.subset on an SNP design: reference matrix_naive_subset.ipp
+// wraps lazily; here the selected calls are re-packed, 2 bits per call, instead of being decoded into a dense copy).
+// One thread per output byte: four calls gathered from the source column.
+__global__ __launch_bounds__(256) void snp_subset_kernel(const uint8_t* __restrict__ src, int64_t ldb_src, int64_t nout, int64_t pout,
+                                                          const int64_t* __restrict__ rows, const int64_t* __restrict__ cols,
+                                                          uint8_t* __restrict__ dst, int64_t ldb_dst) {
+    const int64_t bo = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t c = blockIdx.y;
+    if (c >= pout || bo >= ldb_dst) return;
+    const uint8_t* col = src + (cols ? cols[c] : c) * ldb_src;
+    unsigned out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = bo * 4 + k;
+        if (i < nout) {
+            const int64_t r = rows ? rows[i] : i;
+            out |= ((unsigned(col[r >> 2]) >> (2 * (r & 3))) & 3u) << (2 * k);
+        }
+    }
+    dst[c * ldb_dst + bo] = uint8_t(out); // (padding bytes and padding calls are zeros)
+}
+void launch_snp_subset(const SnpView& X, int64_t nout, int64_t pout, const int64_t* rows, const int64_t* cols, uint8_t* dst,
+                       int64_t ldb_dst, hipStream_t s) {
+    for (int64_t c0 = 0; c0 < pout; c0 += 65535) {
+        const int64_t pc = std::min<int64_t>(65535, pout - c0);
+        hipLaunchKernelGGL(snp_subset_kernel, dim3((unsigned)((ldb_dst + 255) / 256), (unsigned)pc), dim3(256), 0, s,
+                           X.bits + (cols ? 0 : c0 * X.ldb), X.ldb, nout, pc, rows, cols ? cols + c0 : nullptr, dst + c0 * ldb_dst,
+                           ldb_dst);
+    }
+}
+// out[c] = src[cols ? cols[c] : c]
+template <class T>
+__global__ void gather_cols_kernel(const T* __restrict__ src, const int64_t* __restrict__ cols, int64_t pout, T* __restrict__ out) {
+    const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c < pout) out[c] = src[cols ? cols[c] : c];
+}
+template <class T>
+void launch_gather_cols(const T* src, const int64_t* cols, int64_t pout, T* out, hipStream_t s) {
+    hipLaunchKernelGGL((gather_cols_kernel<T>), dim3((unsigned)((pout + 255) / 256)), dim3(256), 0, s, src, cols, pout, out);
+}
+
 // CSC -> resident dense columns (matrix.sparse; reference matrix_naive_sparse.ipp keeps the CSC arrays and walks them per
 // operation -- with 288 GB of HBM the design is expanded once and every operation is the dense streaming kernel).
 // One workgroup per column; duplicate (row, col) entries add up, as they do in the reference's sparse dot products.
@@ -858,7 +899,8 @@ template void launch_snp_impute<float>(const uint8_t*, int64_t, int64_t, int64_t
     template void launch_derive_dense<T>(const DenseView<T>&, int64_t, int64_t, const int64_t*, const int64_t*, const T*, \
                                          const T*, T*, int64_t, hipStream_t);                                          \
     template void launch_derive_dense_snp<T>(const SnpView&, const T*, int64_t, int64_t, const int64_t*, const int64_t*, \
-                                             const T*, const T*, T*, int64_t, hipStream_t);
+                                             const T*, const T*, T*, int64_t, hipStream_t);                              \
+    template void launch_gather_cols<T>(const T*, const int64_t*, int64_t, T*, hipStream_t);
 INST(double)
 INST(float)
 #undef INST

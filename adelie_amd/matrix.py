@@ -705,7 +705,9 @@ def concatenate(mats, *, axis: int = 0, n_threads: int = 1):
     handles = (_abi.C.c_void_p * len(mats))(*[m._handle for m in mats])
     handle = _abi.C.c_void_p()
     backend.check(backend.fn("design_create_concat")(handles, len(mats), int(axis), handle))
-    return _wrap(backend, handle, mats[0].dtype, n_threads, kind="dense")
+    # (2-bit designs side by side stay a 2-bit design; every other combination is copied into one dense design)
+    stays_snp = axis == 1 and all(getattr(m, "_kind", None) == "snp" for m in mats)
+    return _wrap(backend, handle, mats[0].dtype, n_threads, kind="snp" if stays_snp else "dense")
 
 
 def dense(mat, *, method: str = "naive", copy: bool = False, n_threads: int = 1, device: int = 0):
@@ -974,7 +976,9 @@ def _derived(mat, rows, cols, centers, scales, n_threads):
     sc, _ = arr(scales, np.float64)
     handle = _abi.C.c_void_p()
     backend.check(backend.fn("design_create_derived")(mat._handle, r, nr, c, nc, ce, sc, handle))
-    return _wrap(backend, handle, mat.dtype, n_threads, kind="dense")
+    # (rows / columns of a 2-bit design are re-packed as a 2-bit design; everything else is a dense design)
+    stays_snp = getattr(mat, "_kind", None) == "snp" and centers is None and scales is None
+    return _wrap(backend, handle, mat.dtype, n_threads, kind="snp" if stays_snp else "dense")
 
 
 def standardize(mat, centers=None, scales=None, ddof: int = 0, *, n_threads: int = 1, lazy="auto"):

@@ -215,6 +215,12 @@ def test_standardize_and_subset_derived_designs(hip, oracle, kind):
     run_naive(ad.matrix.subset(M, rows, axis=0), np.asfortranarray(Z[rows]), np.float64)
     run_naive(ad.matrix.subset(M, cols, axis=1), np.asfortranarray(Z[:, cols]), np.float64)
     run_naive(M[rows, cols], np.asfortranarray(Z[rows][:, cols]), np.float64)
+    if kind == "snp":  # rows / columns of a 2-bit design are re-packed as a 2-bit design (2 bits per call, not a dense copy)
+        sub = M[rows, cols]
+        assert sub._kind == "snp" and ad.matrix.subset(M, cols, axis=1)._kind == "snp"
+        np.testing.assert_allclose(sub.impute(), imp[cols], rtol=1e-14)
+        big = ad.matrix.subset(M, np.arange(n)[::-1], axis=0)     # every row, reversed: ragged last byte (n = 211)
+        run_naive(big, np.asfortranarray(Z[::-1]), np.float64)
     assert M[:, 3:9].shape == (n, 6) and M[::2].shape == ((n + 1) // 2, p)
     with pytest.raises(RuntimeError):
         ad.matrix.subset(M, [p], axis=1)
@@ -358,6 +364,11 @@ def test_concatenate_resident_designs(hip, dtype):
     Xr = ad.matrix.concatenate([A, A2], axis=0)          # ndarrays are uploaded first
     assert (Xr.rows(), Xr.cols()) == (n + 58, 9)
     run_naive(Xr, np.asfortranarray(np.concatenate([A, A2], axis=0)), dtype)
+    calls2 = rng.choice([0, 1, 2, -9], size=(n, 4), p=[0.5, 0.3, 0.1, 0.1]).astype(np.int8)
+    imp2 = ad.matrix.compute_impute(calls2)
+    S2 = ad.matrix.concatenate([ad.matrix.snp_calldata(calls, dtype=dtype), ad.matrix.snp_calldata(calls2, dtype=dtype)], axis=1)
+    assert S2._kind == "snp"   # 2-bit designs side by side stay 2 bits per call
+    run_naive(S2, np.asfortranarray(np.concatenate([Bd, np.where(calls2 < 0, imp2[None], calls2).astype(dtype)], axis=1)), dtype)
     with pytest.raises(RuntimeError, match="same number of rows"):
         ad.matrix.concatenate([A, A2], axis=1)
     with pytest.raises(RuntimeError, match="same number of columns"):

@@ -132,7 +132,8 @@ int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out);
  * sweeps saved + launches), out[2] = their HIP-event time in ms on the batcher's stream.  Used by bench.py for the roofline of
  * cv_grpnet's dominant kernel (one launch streams the design once: n*p*sizeof(value) algorithmic bytes). */
 int adelie_hip_design_batch_stats(adelie_hip_design* d, double* out);
-/* A new dense design derived from a resident one (dense or SNP): rows `rows[0..n_rows)` (NULL: all), columns
+/* A new design derived from a resident one (dense or SNP; a subset of an SNP design without centring / scaling is again a
+ * 2-bit design, the selected calls re-packed four per byte; everything else is dense): rows `rows[0..n_rows)` (NULL: all), columns
  * `cols[0..n_cols)` (NULL: all), every resulting column j centred by centers[j] and divided by scales[j] (NULL: no centring /
  * scaling).  This is what adelie.matrix.subset (matrix_naive_subset.ipp) and adelie.matrix.standardize
  * (matrix_naive_standardize.ipp: X = (Z - 1 c^T) diag(s)^-1) describe; the reference wraps the parent lazily, here the result is
@@ -141,7 +142,8 @@ int adelie_hip_design_create_derived(adelie_hip_design* src, const int64_t* rows
                                      int64_t n_cols, const double* centers, const double* scales, adelie_hip_design** out);
 /* Replaces MatrixNaiveCConcatenate / MatrixNaiveRConcatenate (adelie/matrix.py:214-310, matrix_naive_concatenate.ipp):
  * the k resident designs are copied side by side (axis 1: columns; axis 0: rows) into one new dense design; SNP sources
- * are decoded.  The sources stay valid and independent.  The reference's error strings for mismatched shapes are kept. */
+ * are decoded, except that 2-bit designs side by side (axis 1, all of them SNP) give a 2-bit design.  The sources stay valid and
+ * independent.  The reference's error strings for mismatched shapes are kept. */
 int adelie_hip_design_create_concat(adelie_hip_design* const* srcs, int64_t k, int axis, adelie_hip_design** out);
 /* Multi-response view of a resident dense or 2-bit SNP design: the (n*K) x ((p + intercept)*K) matrix
  *     [ 1_n (x) I_K ,  X (x) I_K ]      (the first block only when `intercept` != 0)

@@ -179,3 +179,31 @@ def test_cv_full_size_config5(hip):
             eta = (Xd @ st.betas[i].toarray().ravel()) + st.intercepts[i]
             li = 0.5 * eta[val] ** 2 - y[val] * eta[val]
             assert np.isclose(one.losses[k, i], li.mean(), rtol=2e-5, atol=1e-8), (k, i, one.losses[k, i], li.mean())
+
+
+def test_sparse_resident_design_at_scale(hip):
+    """A sparse design kept sparse in HBM (matrix.sparse(resident="csc"), kernels_sparse.hip) at a size where its sweeps run
+    over several row blocks and its screen sets pass the multi-CU Gram engine's threshold: the 100-lambda path equals the one on
+    the expanded dense copy (other engines, other summation order) to rounding, with and without the standardized view."""
+    import scipy.sparse as sp
+
+    n, p, dens = 300_000, 6_000, 0.004
+    rng = np.random.default_rng(3)
+    nnz = int(n * p * dens)
+    M = sp.csc_matrix((rng.standard_normal(nnz), (rng.integers(0, n, size=nnz), rng.integers(0, p, size=nnz))), shape=(n, p))
+    M.sum_duplicates()
+    M.sort_indices()
+    beta = np.zeros(p)
+    beta[rng.choice(p, 300, replace=False)] = rng.standard_normal(300) * 2
+    y = M @ beta + rng.standard_normal(n)
+    Xs = ad.matrix.sparse(M, resident="csc")
+    Xd = ad.matrix.sparse(M, resident="dense")
+    kw = dict(early_exit=False, min_ratio=1e-2, progress_bar=False)
+    a = ad.grpnet(Xs, ad.glm.gaussian(y), **kw)
+    b = ad.grpnet(Xd, ad.glm.gaussian(y), **kw)
+    assert a.error == "" and b.error == "" and len(a.lmdas) == 100
+    assert max(a.screen_sizes) > 128
+    assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-9
+    za = ad.grpnet(ad.matrix.standardize(Xs), ad.glm.gaussian(y), **kw)
+    zb = ad.grpnet(ad.matrix.standardize(Xd), ad.glm.gaussian(y), **kw)
+    assert za.error == "" and np.abs(za.betas.toarray() - zb.betas.toarray()).max() < 1e-9

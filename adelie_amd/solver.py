@@ -95,6 +95,54 @@ def _start_screen(layout, alpha, dtype):
     }
 
 
+def _lasso_in_raw_coordinates(X, glm, constraints, groups, alpha, intercept, warm_start):
+    """``(base design, scales, centers)`` when a fit on the lazily standardized view ``X`` is a lasso that can run on the base
+    design's own columns (see :func:`grpnet`), else ``None``."""
+    if not isinstance(X, matrix._StdView) or warm_start is not None or not intercept or alpha != 1:
+        return None
+    if getattr(glm, "is_multi", False):
+        return None
+    if constraints is not None and any(c is not None for c in constraints):
+        return None
+    p = X.cols()
+    if groups is not None and not (len(groups) == p and np.array_equal(np.asarray(groups), np.arange(p))):
+        return None
+    return X._base, X._s, X._c
+
+
+def _to_standardized_coordinates(state, view, s, c, penalty):
+    """The state of a lasso solved on the raw columns, re-expressed for the standardized view: ``beta~ = s beta``, the
+    intercepts take ``sum_j beta_j c_j``, gradients divide by ``s`` (``grad`` of the Gaussian state is the centred gradient,
+    that of a GLM state ``X' resid``), means and variances of the screened columns follow."""
+    dtype = state.dtype
+    s = np.asarray(s, dtype=dtype)
+    c = np.asarray(c, dtype=dtype)
+    cols = np.asarray(state.groups)[np.asarray(state.screen_set, dtype=np.int64)]
+    raw_screen = np.asarray(state.screen_beta)
+    shift_now = float(np.dot(raw_screen, c[cols])) if len(cols) else 0.0
+    state.intercepts = (np.asarray(state.intercepts) + np.asarray(state.betas @ c).reshape(-1)).astype(dtype)
+    state.betas = state.betas.multiply(s[None]).tocsr().astype(dtype)
+    state.screen_beta = (raw_screen * s[cols]).astype(dtype)
+    if hasattr(state, "X_means"):   # Gaussian state: `grad` is centred (X_c' W r), so the centres drop out
+        state.grad = (np.asarray(state.grad) / s).astype(dtype)
+        state.X_means = ((np.asarray(state.X_means) - c) / s).astype(dtype)
+        # its residual carries no intercept term (y_c - X beta; the intercept lives in resid_sum): X~ beta~ = X beta - sum_j beta_j c_j
+        state.resid = (np.asarray(state.resid) + dtype(shift_now)).astype(dtype)
+        state.resid_sum = dtype(state.resid_sum + shift_now * np.sum(state.weights))
+    else:                           # GLM state: grad = X' resid with the weights inside resid
+        state.grad = ((np.asarray(state.grad) - c * np.sum(state.resid)) / s).astype(dtype)
+        if hasattr(state, "beta0"):
+            state.beta0 = dtype(state.beta0 + shift_now)
+    state.abs_grad = np.abs(state.grad)
+    state.screen_X_means = ((np.asarray(state.screen_X_means) - c[cols]) / s[cols]).astype(dtype)
+    state.screen_vars = (np.asarray(state.screen_vars) / s[cols] ** 2).astype(dtype)
+    state.penalty = np.asarray(penalty, dtype=dtype)
+    state._X = view
+    if hasattr(state, "X"):
+        state.X = view
+    return state
+
+
 def _resume(warm_start, kind):
     return {name: getattr(warm_start, name) for name in _SCREEN_FIELDS + _INVARIANT_FIELDS[kind]}
 
@@ -253,6 +301,26 @@ def grpnet(
     X = matrix.as_design(X, n_threads=n_threads)
     dtype = X.dtype
     p = X.cols()
+
+    raw = _lasso_in_raw_coordinates(X, glm, constraints, groups, alpha, intercept, warm_start)
+    if raw is not None:
+        # A lasso (alpha = 1, groups of one, intercept) on the standardized view (Z - 1 c') diag(s)^-1 of a resident design Z is the
+        # lasso on Z itself with the penalty factors times |s|: beta~ = s beta, and the intercept absorbs the centres.  Every
+        # coordinate update, the convergence measure A_jj d_j^2, the screening scores |g_j| / penalty_j and the KKT test are
+        # the same numbers in both coordinate systems (eta is the same vector), so the solver runs its panel engines on the raw
+        # columns -- the view itself only has the full-Gram engines -- and the state comes back in the
+        # standardized coordinates.
+        base, sc, ce = raw
+        pen = np.ones(p, dtype=dtype) if penalty is None else np.asarray(penalty, dtype=dtype)
+        state = grpnet(
+            base, glm, groups=None, alpha=alpha, penalty=pen * np.abs(sc), offsets=offsets, lmda_path=lmda_path,
+            irls_max_iters=irls_max_iters, irls_tol=irls_tol, max_iters=max_iters, tol=tol, adev_tol=adev_tol, ddev_tol=ddev_tol,
+            newton_tol=newton_tol, newton_max_iters=newton_max_iters, n_threads=n_threads, early_exit=early_exit,
+            intercept=True, screen_rule=screen_rule, min_ratio=min_ratio, lmda_path_size=lmda_path_size,
+            max_screen_size=max_screen_size, max_active_size=max_active_size, pivot_subset_ratio=pivot_subset_ratio,
+            pivot_subset_min=pivot_subset_min, pivot_slack_ratio=pivot_slack_ratio, check_state=check_state,
+            progress_bar=progress_bar, exit_cond=exit_cond)
+        return _to_standardized_coordinates(state, X, sc, ce, pen)
 
     if isinstance(constraints, list):
         for c in constraints:  # cached dual state of a previous solve must not leak into this one (solver.py:638-642)

@@ -17,7 +17,7 @@ n, p, L = (int(float(sys.argv[1])), int(float(sys.argv[2])), int(sys.argv[3])) i
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (the calldata generator of config 4: rates of adelie.data.snp_unphased, built by column chunks)
 
-cd, imp, _ = bench.make_snp_data(n, p, 0, torch.device("cuda", 0))
+cd, imp, y_bin = bench.make_snp_data(n, p, 0, torch.device("cuda", 0))
 X = ad.matrix.snp_calldata(cd, imp)
 del cd
 torch.cuda.empty_cache()
@@ -44,4 +44,11 @@ for name, lazy in (("lazy_view", True), ("materialised", False)):
     else:
         res["max_abs_dbeta"] = float(np.abs(ref - st.betas.toarray()).max())
     del Z
+if os.environ.get("BINOMIAL"):  # config 4's own response on the standardized view: IRLS on the panel engines of the 2-bit matrix
+    Z = ad.matrix.standardize(X, lazy=True)
+    t0 = time.time()
+    sb = ad.grpnet(Z, ad.glm.binomial(y_bin), lmda_path_size=L, early_exit=False, progress_bar=False)
+    res["binomial_lazy_view"] = {"path_s": time.time() - t0, "lambdas": len(sb.lmdas), "final_active": int(sb.active_set_size),
+                                 "n_irls_iters": int(sb.counters["n_irls_iters"]), "n_panel_blocks": int(sb.counters["n_panel_blocks"]),
+                                 "error": sb.error}
 print(json.dumps(res))

@@ -288,6 +288,29 @@ def test_lazy_standardized_view(hip, oracle, kind, dtype):
         assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < tol
         assert np.abs(a.intercepts - b.intercepts).max() < tol
     assert max(a.screen_sizes) >= 0
+    # A lasso with an intercept on the view runs on the base design's own columns with the penalty factors times |s| (the
+    # panel engines; solver._lasso_in_raw_coordinates) and comes back in standardized coordinates: every field of the state
+    # against the fit on the materialised copy, and a warm start from it (which takes the view's own engines).
+    Sm = ad.matrix.standardize(M, lazy=False)
+    for glm, extra in [(ad.glm.gaussian(y), {}), (ad.glm.binomial((y > np.median(y)).astype(float)), dict(irls_tol=1e-10))]:
+        kw = dict(tol=1e-11, early_exit=False, lmda_path_size=14, min_ratio=2e-3 if not extra else 5e-2, progress_bar=False, **extra)
+        a = ad.grpnet(S, glm, **kw)
+        b = ad.grpnet(Sm, glm, **kw)
+        assert a.error == "" and b.error == "" and a._X is S
+        assert extra or a.counters["n_panel_blocks"] > 0   # (Gaussian case: screen sets past 128 values, the panel engines ran)
+        assert np.allclose(a.lmdas, b.lmdas, rtol=1e-10) and abs(a.lmda_max - b.lmda_max) <= 1e-10 * b.lmda_max
+        assert np.array_equal(a.screen_set, b.screen_set)
+        for name, tol in [("intercepts", 1e-7), ("devs", 1e-8), ("screen_beta", 1e-7), ("grad", 1e-7), ("abs_grad", 1e-7),
+                          ("screen_X_means", 1e-9), ("screen_vars", 1e-9), ("resid", 1e-7)]:
+            assert np.abs(np.asarray(getattr(a, name)) - np.asarray(getattr(b, name))).max() < tol, name
+        assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-7
+        half = a.lmdas[:7]
+        first = ad.grpnet(S, glm, **dict(kw, lmda_path=half))
+        rest = ad.grpnet(S, glm, warm_start=first, **dict(kw, lmda_path=a.lmdas[7:]))
+        # (a continued path differs from the uninterrupted one by the stopping rule's resolution, 1e-5 here on the
+        # materialised copy as well: the warm start from the re-expressed state must do no worse)
+        assert rest.error == "" and np.abs(rest.betas.toarray() - a.betas.toarray()[7:]).max() < 5e-5
+        assert np.abs(rest.intercepts - a.intercepts[7:]).max() < 5e-5
     kwc = dict(n_folds=3, seed=1, lmda_path_size=8, min_ratio=0.1, progress_bar=False)
     ca = ad.cv_grpnet(S, ad.glm.gaussian(y), **kwc)
     cb = ad.cv_grpnet(ad.matrix.dense(Xs), ad.glm.gaussian(y), **kwc)

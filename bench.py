@@ -496,7 +496,7 @@ def main():
         out["cfg4"] = leg(line4)
         # two designs whose dense f64 form does not fit (or barely fits) in HBM, as further objects of the default line
         # (DESIGN.md 9.9): config 4's 2-bit design under the lazy standardized view, and a sparse design kept sparse
-        out["standardized_snp_view"] = lazy_views_leg(ad_design=k4["Xd"], L=L)
+        out["standardized_snp_view"] = lazy_views_leg(ad_design=k4["Xd"], L=L, y_binomial=k4["y"])
         del k4, line4
         gc.collect()
         ctx.torch.cuda.empty_cache()
@@ -513,9 +513,10 @@ def main():
 # -------------------------------------------------------------------------------------------------------------------------
 # designs that do not fit dense (extra objects of the default line; a failure is recorded, it does not cost the headline)
 # -------------------------------------------------------------------------------------------------------------------------
-def lazy_views_leg(ad_design, L):
-    """Gaussian lasso path on matrix.standardize(<config 4's 500k x 50k 2-bit design>) as a view (6.25 GB resident; the
-    materialised copy would be 200 GB)."""
+def lazy_views_leg(ad_design, L, y_binomial=None):
+    """Gaussian lasso path, and config 4's own binomial path, on matrix.standardize(<config 4's 500k x 50k 2-bit design>) as a
+    view (6.25 GB resident; the materialised copy would be 200 GB).  A lasso with an intercept on the view runs on the 2-bit
+    matrix's own columns with rescaled penalty factors (adelie_amd/solver.py::_lasso_in_raw_coordinates): the panel engines."""
     import adelie_amd as ad
 
     try:
@@ -533,10 +534,20 @@ def lazy_views_leg(ad_design, L):
         t0 = time.perf_counter()
         st = ad.grpnet(Z, ad.glm.gaussian(y), **kw)
         el = time.perf_counter() - t0
-        return {"workload": f"Gaussian lasso, {L} lambdas, standardize(snp_unphased {n}x{p}) as a view sharing the 2-bit matrix",
-                "value": 1.0 / el, "unit": "paths/s", "ms_per_step": el * 1e3, "resident_bytes": int(n * p / 4),
-                "dense_copy_bytes": int(n * p * 8), "lambdas": len(st.lmdas), "final_active": int(st.active_set_size),
-                "error": st.error}
+        out = {"workload": f"Gaussian lasso, {L} lambdas, standardize(snp_unphased {n}x{p}) as a view sharing the 2-bit matrix",
+               "value": 1.0 / el, "unit": "paths/s", "ms_per_step": el * 1e3, "resident_bytes": int(n * p / 4),
+               "dense_copy_bytes": int(n * p * 8), "lambdas": len(st.lmdas), "final_active": int(st.active_set_size),
+               "error": st.error}
+        if y_binomial is not None:
+            t0 = time.perf_counter()
+            sb = ad.grpnet(Z, ad.glm.binomial(np.asarray(y_binomial, dtype=np.float64)), lmda_path_size=L, early_exit=False,
+                           progress_bar=False)
+            el = time.perf_counter() - t0
+            out["binomial"] = {"workload": "config 4's binomial lasso on the same standardized view", "value": 1.0 / el,
+                               "unit": "paths/s", "ms_per_step": el * 1e3, "lambdas": len(sb.lmdas),
+                               "final_active": int(sb.active_set_size), "n_irls_iters": int(sb.counters["n_irls_iters"]),
+                               "error": sb.error}
+        return out
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)}
 

@@ -98,7 +98,8 @@ def _start_screen(layout, alpha, dtype):
 def _lasso_in_raw_coordinates(X, glm, constraints, groups, alpha, intercept, warm_start):
     """``(base design, scales, centers)`` when a fit on the lazily standardized view ``X`` is a lasso that can run on the base
     design's own columns (see :func:`grpnet`), else ``None``."""
-    if not isinstance(X, matrix._StdView) or warm_start is not None or not intercept or alpha != 1:
+    sparse_view = getattr(X, "_kind", None) == "sparse" and getattr(X, "_std", None) is not None and getattr(X, "_keep", None) is not None
+    if not (isinstance(X, matrix._StdView) or sparse_view) or warm_start is not None or not intercept or alpha != 1:
         return None
     if getattr(glm, "is_multi", False):
         return None
@@ -107,6 +108,8 @@ def _lasso_in_raw_coordinates(X, glm, constraints, groups, alpha, intercept, war
     p = X.cols()
     if groups is not None and not (len(groups) == p and np.array_equal(np.asarray(groups), np.arange(p))):
         return None
+    if sparse_view:  # the standardized view of a design kept sparse: its plain design, without the epilogue corrections
+        return X._keep, np.asarray(X._std[1], dtype=X.dtype), np.asarray(X._std[0], dtype=X.dtype)
     return X._base, X._s, X._c
 
 

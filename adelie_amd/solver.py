@@ -137,8 +137,10 @@ def _to_standardized_coordinates(state, view, s, c, penalty):
         if hasattr(state, "beta0"):
             state.beta0 = dtype(state.beta0 + shift_now)
     state.abs_grad = np.abs(state.grad)
-    state.screen_X_means = ((np.asarray(state.screen_X_means) - c[cols]) / s[cols]).astype(dtype)
-    state.screen_vars = (np.asarray(state.screen_vars) / s[cols] ** 2).astype(dtype)
+    if len(np.asarray(state.screen_X_means)) == len(cols):  # (a GLM state keeps none: IRLS recomputes them per iteration)
+        state.screen_X_means = ((np.asarray(state.screen_X_means) - c[cols]) / s[cols]).astype(dtype)
+    if len(np.asarray(state.screen_vars)) == len(cols):
+        state.screen_vars = (np.asarray(state.screen_vars) / s[cols] ** 2).astype(dtype)
     state.penalty = np.asarray(penalty, dtype=dtype)
     state._X = view
     if hasattr(state, "X"):

@@ -244,3 +244,40 @@ def test_basil_loop_terminates_when_kkt_and_fallback_round_differently(oracle):
     st = ad.grpnet(oracle.snp_calldata(cd, imp, dtype=np.float32), ad.glm.gaussian(y, dtype=np.float32), groups=groups,
                    alpha=alpha, early_exit=False, lmda_path_size=15, min_ratio=0.3, tol=1e-7, max_iters=4000)
     assert st.error == "" or st.error.startswith("adelie_core solver: Newton-ABS max iterations reached")
+
+
+@pytest.mark.parametrize("family", ["gaussian", "binomial"])
+def test_lasso_on_standardized_columns_is_the_lasso_on_raw_columns_with_scaled_penalties(oracle, family):
+    """The identity ``adelie_amd.solver._lasso_in_raw_coordinates`` rests on (a lasso with an intercept on a lazily
+    standardized view is solved on the base design with ``penalty * |s|``), on the CPU checker alone: the path on
+    ``(Z - 1 c') diag(s)^-1`` and the path on ``Z`` with the rescaled penalty factors are the same iterates in two
+    coordinate systems — same lambdas, deviances, screen and active sets, ``beta~ = s beta``, intercepts shifted by
+    ``sum_j beta_j c_j`` — and the product's re-expression of the state reproduces every invariant."""
+    from adelie_amd.solver import _to_standardized_coordinates
+
+    rng = np.random.RandomState(3)
+    n, p = 150, 40
+    Z = np.asfortranarray(rng.normal(size=(n, p)) * rng.uniform(0.3, 4.0, p) + rng.normal(size=p) * 2)
+    c, s = rng.normal(size=p), rng.uniform(0.5, 3.0, p) * rng.choice([-1.0, 1.0], p)   # any centres, scales of either sign
+    Xs = np.asfortranarray((Z - c) / s)
+    eta = Xs[:, :4] @ np.array([1.0, -2.0, 0.7, 0.4])
+    if family == "gaussian":
+        glm = ad.glm.gaussian(eta + 0.3 * rng.normal(size=n))
+    else:
+        glm = ad.glm.binomial((rng.uniform(size=n) < 1 / (1 + np.exp(-eta))).astype(float))
+    pen = rng.uniform(0.5, 2.0, p)
+    kw = dict(tol=1e-12, irls_tol=1e-11, early_exit=False, lmda_path_size=20, min_ratio=1e-2, progress_bar=False)
+    a = ad.grpnet(oracle.dense(Xs), glm, penalty=pen, **kw)
+    b = ad.grpnet(oracle.dense(Z), glm, penalty=pen * np.abs(s), **kw)
+    assert a.error == "" and b.error == ""
+    assert np.allclose(a.lmdas, b.lmdas, rtol=1e-11) and np.allclose(a.devs, b.devs, atol=1e-9)
+    assert np.array_equal(a.screen_set, b.screen_set) and np.array_equal(a.active_set[:a.active_set_size], b.active_set[:b.active_set_size])
+    b = _to_standardized_coordinates(b, None, s, c, pen)
+    assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-8
+    for name in ("intercepts", "screen_beta", "grad", "abs_grad", "resid", "screen_X_means", "screen_vars"):
+        u, v = np.asarray(getattr(a, name)), np.asarray(getattr(b, name))
+        assert u.shape == v.shape and (u.size == 0 or np.abs(u - v).max() < 1e-8), name
+    if family == "gaussian":
+        assert abs(a.resid_sum - b.resid_sum) < 1e-9 and np.abs(a.X_means - b.X_means).max() < 1e-9
+    else:
+        assert abs(a.beta0 - b.beta0) < 1e-8

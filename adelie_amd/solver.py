@@ -307,8 +307,8 @@ def grpnet(
     dtype = X.dtype
     p = X.cols()
 
-    raw = _lasso_in_raw_coordinates(X, glm, constraints, groups, alpha, intercept, warm_start)
-    if raw is not None:
+    raw = None if exit_cond is not None else _lasso_in_raw_coordinates(X, glm, constraints, groups, alpha, intercept, warm_start)
+    if raw is not None:  # (an exit_cond callback reads the live state: it gets the view's own coordinates, i.e. the view's engines)
         # A lasso (alpha = 1, groups of one, intercept) on the standardized view (Z - 1 c') diag(s)^-1 of a resident design Z is the
         # lasso on Z itself with the penalty factors times |s|: beta~ = s beta, and the intercept absorbs the centres.  Every
         # coordinate update, the convergence measure A_jj d_j^2, the screening scores |g_j| / penalty_j and the KKT test are
@@ -324,7 +324,7 @@ def grpnet(
             intercept=True, screen_rule=screen_rule, min_ratio=min_ratio, lmda_path_size=lmda_path_size,
             max_screen_size=max_screen_size, max_active_size=max_active_size, pivot_subset_ratio=pivot_subset_ratio,
             pivot_subset_min=pivot_subset_min, pivot_slack_ratio=pivot_slack_ratio, check_state=check_state,
-            progress_bar=progress_bar, exit_cond=exit_cond)
+            progress_bar=progress_bar)
         return _to_standardized_coordinates(state, X, sc, ce, pen)
 
     if isinstance(constraints, list):

@@ -434,6 +434,13 @@ struct adelie_hip_design {
     int sp_nb = 1;
     int64_t sp_rb = 0;
     // standardized view of a sparse design (adelie_hip_design_create_csc_standardized): (p,) value_t each, owned unless alias
+    // tile-major copy of the entries for the full sweeps (kernels_sparse.hip: csc_tile_sweep_kernel), sp_nt > 0
+    int64_t* tptr = nullptr;
+    uint16_t* trow = nullptr;
+    void* tval = nullptr;
+    int sp_nt = 0;
+    int64_t sp_th = 0;
+    int sp_parts() const { return sp_nb > sp_nt ? sp_nb : sp_nt; } // partial sums per column a sweep may leave
     void* std_center = nullptr;
     void* std_iscale = nullptr;
     bool std_owned = false;
@@ -453,7 +460,8 @@ struct adelie_hip_design {
     ahip::SnpView snp() const { return ahip::SnpView{bits, n, p, ldb}; }
     template <class T> ahip::CscView<T> csc() const {
         return ahip::CscView<T>{cptr, cidx, static_cast<const T*>(cval), rptr, rcol, static_cast<const T*>(rval), n, p, nnz,
-                                bptr, sp_nb, sp_rb, static_cast<const T*>(std_center), static_cast<const T*>(std_iscale)};
+                                bptr, sp_nb, sp_rb, static_cast<const T*>(std_center), static_cast<const T*>(std_iscale),
+                                tptr, trow, static_cast<const T*>(tval), sp_nt, sp_th};
     }
     template <class T> ahip::MultiView<T> multi() const {
         return ahip::MultiView<T>{static_cast<const T*>(X), nb, pb, ld, static_cast<const T*>(ones), int32_t(mK), int32_t(micpt),

@@ -168,7 +168,7 @@ void op_sweep(adelie_hip_design* d, int64_t c0, int64_t ncols, const T* v, const
         launch_sweep<T>(d->dense<T>(), dv, dout, c0, ncols, nullptr, nullptr, nullptr, square, work, s);
     else if (d->kind == 3)
         launch_sweep_csc<T>(d->csc<T>(), dv, dout, c0, ncols, nullptr, nullptr, nullptr, square,
-                            scratch<T>(d->s_misc, size_t(sweep_work_elems_csc(d->sp_nb, ncols))), s);
+                            scratch<T>(d->s_misc, size_t(sweep_work_elems_csc(d->sp_parts(), ncols))), s);
     else
         launch_sweep_snp<T>(d->snp(), static_cast<const T*>(d->impute), dv, dout, c0, ncols, nullptr, nullptr, nullptr,
                             square, work, s);
@@ -191,7 +191,7 @@ void op_mul_batch(adelie_hip_design* d, const T* V, int64_t L, T* out) {
         for (int64_t l = 0; l < L; ++l) {
             AHIP_CHECK(hipMemcpyAsync(dv1, V + l * n, size_t(n) * sizeof(T), hipMemcpyHostToDevice, s));
             launch_sweep_csc<T>(d->csc<T>(), dv1, dout1, 0, p, nullptr, nullptr, nullptr, false,
-                                scratch<T>(d->s_misc, size_t(sweep_work_elems_csc(d->sp_nb, p))), s);
+                                scratch<T>(d->s_misc, size_t(sweep_work_elems_csc(d->sp_parts(), p))), s);
             AHIP_CHECK(hipMemcpyAsync(out + l * p, dout1, size_t(p) * sizeof(T), hipMemcpyDeviceToHost, s));
             AHIP_CHECK(hipStreamSynchronize(s));
         }
@@ -263,7 +263,7 @@ void op_cov(adelie_hip_design* d, int64_t j, int64_t q, const T* sw, T* out) {
     const int64_t n = d->n;
     T* dw = scratch<T>(d->s_n1, n);
     T* dC = scratch<T>(d->s_p1, q * q);
-    T* work = scratch<T>(d->s_work, d->kind == 3 ? gram_work_elems_csc(n, q, q, d->sp_nb) : gram_work_elems(n, q, q));
+    T* work = scratch<T>(d->s_work, d->kind == 3 ? gram_work_elems_csc(n, q, q, d->sp_parts()) : gram_work_elems(n, q, q));
     int32_t* dcols = scratch<int32_t>(d->s_idx1, q);
     std::vector<int32_t> cols(q);
     for (int64_t k = 0; k < q; ++k) cols[k] = int32_t(j + k);
@@ -303,7 +303,7 @@ static void cov_lazy_t(adelie_hip_design* X, adelie_hip_design* A) {
     cols.reserve(size_t(p));
     ones.upload(h1.data(), size_t(n), s);
     cols.upload(hc.data(), size_t(p), s);
-    work.reserve(size_t(X->kind == 3 ? gram_work_elems_csc(n, p, std::min<int64_t>(p, PANEL), X->sp_nb)
+    work.reserve(size_t(X->kind == 3 ? gram_work_elems_csc(n, p, std::min<int64_t>(p, PANEL), X->sp_parts())
                                      : gram_work_elems(n, p, std::min<int64_t>(p, PANEL))));
     for (int64_t c0 = 0; c0 < p; c0 += PANEL) {
         const int64_t nc = std::min<int64_t>(PANEL, p - c0);
@@ -854,6 +854,50 @@ int adelie_hip_design_create_csc(const int64_t* indptr, const int32_t* indices, 
             AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->bptr), size_t(p) * size_t(d->sp_nb + 1) * sizeof(int64_t)));
             launch_csc_block_ptr(d->cptr, d->cidx, p, d->sp_nb, d->sp_rb, d->bptr, s);
         }
+        // Tile-major copy for the full sweeps (csc_tile_sweep_kernel): tiles of kCscTileBytes of an n-vector.  Built on the
+        // device from the per-column tile pointers; the tile-major offsets are a prefix sum over (tile, column) on the host.
+        {
+            const int64_t th = kCscTileBytes / int64_t(vs);
+            const int64_t nt = (n + th - 1) / th;
+            const bool worth = nt > 1 && nt <= 4096 && nnz >= (int64_t(1) << 16) && nt * (p + 1) * 8 <= (int64_t(1) << 30) &&
+                               nnz / (nt * p) >= 4; // (segments of a few entries at least: below, the pointers outweigh the entries)
+            if (worth) {
+                int64_t* colptr = nullptr;
+                AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&colptr), size_t(p) * size_t(nt + 1) * sizeof(int64_t)));
+                try {
+                    launch_csc_block_ptr(d->cptr, d->cidx, p, int(nt), th, colptr, s);
+                    std::vector<int64_t> cp(size_t(p) * size_t(nt + 1)), tp(size_t(nt) * size_t(p + 1));
+                    AHIP_CHECK(hipMemcpyAsync(cp.data(), colptr, cp.size() * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+                    AHIP_CHECK(hipStreamSynchronize(s));
+                    int64_t run = 0;
+                    for (int64_t t = 0; t < nt; ++t) {
+                        int64_t* row = tp.data() + size_t(t) * size_t(p + 1);
+                        for (int64_t c = 0; c < p; ++c) {
+                            row[c] = run;
+                            run += cp[size_t(c) * size_t(nt + 1) + size_t(t) + 1] - cp[size_t(c) * size_t(nt + 1) + size_t(t)];
+                        }
+                        row[p] = run;
+                    }
+                    AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->tptr), tp.size() * sizeof(int64_t)));
+                    AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->trow), nz1 * sizeof(uint16_t)));
+                    AHIP_CHECK(hipMalloc(&d->tval, nz1 * vs));
+                    AHIP_CHECK(hipMemcpyAsync(d->tptr, tp.data(), tp.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+                    if (dtype == ADELIE_HIP_F64)
+                        launch_csc_tile_scatter<double>(colptr, d->cidx, static_cast<const double*>(d->cval), p, int(nt), th, d->tptr,
+                                                        d->trow, static_cast<double*>(d->tval), s);
+                    else
+                        launch_csc_tile_scatter<float>(colptr, d->cidx, static_cast<const float*>(d->cval), p, int(nt), th, d->tptr,
+                                                       d->trow, static_cast<float*>(d->tval), s);
+                    AHIP_CHECK(hipStreamSynchronize(s));
+                    d->sp_nt = int(nt);
+                    d->sp_th = th;
+                } catch (...) {
+                    (void)hipFree(colptr);
+                    throw;
+                }
+                (void)hipFree(colptr);
+            }
+        }
         AHIP_CHECK(hipStreamSynchronize(s));
     } catch (...) {
         adelie_hip_design_destroy(d);
@@ -1085,6 +1129,7 @@ int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out) {
     d->rptr = src->rptr; d->rcol = src->rcol; d->rval = src->rval;
     d->nnz = src->nnz;
     d->bptr = src->bptr; d->sp_nb = src->sp_nb; d->sp_rb = src->sp_rb;
+    d->tptr = src->tptr; d->trow = src->trow; d->tval = src->tval; d->sp_nt = src->sp_nt; d->sp_th = src->sp_th;
     d->std_center = src->std_center; d->std_iscale = src->std_iscale; // (not owned: std_owned stays false)
     d->alias = true;
     d->batch_owner = src->batch_owner ? src->batch_owner : src;
@@ -1214,6 +1259,7 @@ int adelie_hip_design_destroy(adelie_hip_design* d) {
         (void)hipFree(d->cptr); (void)hipFree(d->cidx); (void)hipFree(d->cval);
         (void)hipFree(d->rptr); (void)hipFree(d->rcol); (void)hipFree(d->rval);
         (void)hipFree(d->bptr);
+        (void)hipFree(d->tptr); (void)hipFree(d->trow); (void)hipFree(d->tval);
     }
     if (d->std_owned) { (void)hipFree(d->std_center); (void)hipFree(d->std_iscale); }
     if (d->ones) (void)hipFree(d->ones);

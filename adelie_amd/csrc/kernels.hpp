@@ -37,6 +37,13 @@ struct CscView {
     // standardized view (both null: the plain matrix): the design is (x_ij - center[j]) * inv_scale[j], entries untouched
     const T* center;
     const T* inv_scale;
+    // tile-major copy for the full sweeps (nt > 0): the entries of row tile t (th rows) stand together, by column;
+    // tptr[t * (p + 1) + c] = first entry of (tile t, column c), trow = row inside the tile, tval = value
+    const int64_t* tptr;
+    const uint16_t* trow;
+    const T* tval;
+    int nt;
+    int64_t th;
 };
 
 // ---- vector helpers -------------------------------------------------------------------------
@@ -75,6 +82,12 @@ template <class T>
 void launch_std_scale_coef(const T* center, const T* inv_scale, const int32_t* cols, const T* coef, const int32_t* count_dev,
                            int32_t count, T* coef2, T* kappa, hipStream_t s);
 template <class T> void launch_vec_shift(T* out, int64_t n, const T* kappa, T sign, const int32_t* count_dev, hipStream_t s);
+// tile-major copy of a sparse design (see CscView): from the per-column tile pointers colptr[c * (nt + 1) + t] (what
+// launch_csc_block_ptr gives with rb = th) and the tile-major offsets tptr, the entries are copied to their places
+template <class T>
+void launch_csc_tile_scatter(const int64_t* colptr, const int32_t* cidx, const T* cval, int64_t p, int nt, int64_t th,
+                             const int64_t* tptr, uint16_t* trow, T* tval, hipStream_t s);
+constexpr int64_t kCscTileBytes = 128 * 1024; // a tile of v in LDS
 // row-block layout of a sparse design with n rows (blocks whose slice of an n-vector is about 1 MB, at most 64 of them) and
 // the per-column block pointers
 void csc_block_layout(int64_t n, size_t value_size, int* nb, int64_t* rb);

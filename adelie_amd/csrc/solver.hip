@@ -695,7 +695,7 @@ int adelie_hip_bench_sweep(adelie_hip_design* d, int64_t reps, double* ms_per_la
             using T = decltype(tag);
             DevBuf<T> v, out, xm, work, sc;
             v.reserve(d->n); out.reserve(d->p); xm.reserve(d->p); sc.reserve(1);
-            work.reserve(size_t(d->kind == 3 ? sweep_work_elems_csc(d->sp_nb, d->p) : sweep_work_elems(d->n, d->p)));
+            work.reserve(size_t(d->kind == 3 ? sweep_work_elems_csc(d->sp_parts(), d->p) : sweep_work_elems(d->n, d->p)));
             launch_fill<T>(v.p, T(1) / T(d->n), d->n, s);
             launch_fill<T>(xm.p, T(0.5), d->p, s);
             launch_fill<T>(sc.p, T(0.25), 1, s);

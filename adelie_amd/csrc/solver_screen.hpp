@@ -34,7 +34,7 @@
         }
         if (sparse()) { // one wavefront per column over its stored entries (kernels_sparse.hip)
             launch_sweep_csc<T>(D->csc<T>(), v, out, 0, ncols, cols, sub_scale, sub_vec, square,
-                                d_work_sweep.reserve(size_t(sweep_work_elems_csc(D->sp_nb, ncols))), st);
+                                d_work_sweep.reserve(size_t(sweep_work_elems_csc(D->sp_parts(), ncols))), st);
             return;
         }
         T* work = d_work_sweep.reserve(size_t(sweep_work_elems(n, ncols)));
@@ -136,7 +136,7 @@
         else launch_axpy_cols_snp<T>(D->snp(), static_cast<const T*>(D->impute), cols, coef, cnt_dev, count, sign, out, st);
     }
     void gram(const T* w, idx M, idx pos0, idx N, const T* xm, bool center) {
-        T* work = d_work_gram.reserve(size_t(sparse() ? gram_work_elems_csc(n, M, N, D->sp_nb) : gram_work_elems(n, M, N)));
+        T* work = d_work_gram.reserve(size_t(sparse() ? gram_work_elems_csc(n, M, N, D->sp_parts()) : gram_work_elems(n, M, N)));
         t_gram.begin(st);
         if (std_generic()) { // raw X^T W X of the base design in place, then the view's rank-one corrections over the panel
             const T* ce = static_cast<const T*>(D->std_center);

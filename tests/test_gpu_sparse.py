@@ -62,6 +62,31 @@ def test_kept_sparse_design_with_row_blocks(hip, oracle, dtype):
         assert a.error == "" and np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-9
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_kept_sparse_design_with_row_tiles(hip, oracle, dtype):
+    """Enough stored entries for the tile-major copy (full sweeps from tiles of v in LDS, csc_tile_sweep_kernel): 16384 f64 /
+    32768 f32 rows per tile, a ragged last tile, an empty column, an empty tile inside a column."""
+    rng = np.random.RandomState(6)
+    n, p = 70_001, 60
+    D = _rand_sparse(rng, n, p, 0.05, dtype)
+    D[:, 3] = 0
+    D[16384:32768, 4] = 0      # column 4 has nothing in its second f64 tile
+    D[n - 1, 5] = 1.5
+    X = _csc(sp.csc_matrix(D))
+    run_naive(X, np.asfortranarray(D), dtype)
+    D64 = D.astype(np.float64)
+    c, s = D64.mean(axis=0), D64.std(axis=0)
+    s[3] = 1.0                 # (the empty column has no spread)
+    Z = ad.matrix.standardize(X, centers=c, scales=s)
+    run_naive(Z, np.asfortranarray(((D64 - c) / s).astype(dtype)), dtype)
+    if dtype == np.float64:
+        y = D[:, :3] @ np.array([1.0, -2.0, 0.5]) + 0.05 * rng.normal(size=n)
+        kw = dict(tol=1e-12, early_exit=False, lmda_path_size=12, min_ratio=0.05, progress_bar=False)
+        a = ad.grpnet(X, ad.glm.gaussian(y), **kw)
+        b = ad.grpnet(oracle.dense(np.asfortranarray(D)), ad.glm.gaussian(y), **kw)
+        assert a.error == "" and np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-9
+
+
 def test_kept_sparse_design_sums_duplicates_and_validates(hip):
     # the same cell stored twice: the entries add up, as in the reference's sparse dot products
     M = sp.csc_matrix((np.array([1.0, 2.0, 5.0]), np.array([0, 0, 2]), np.array([0, 2, 3])), shape=(3, 2))

@@ -779,7 +779,8 @@ def sparse(mat, *, method: str = "naive", copy: bool = False, n_threads: int = 1
 
     * ``"csc"`` — the matrix stays sparse, as in the reference (``matrix_naive_sparse.ipp`` walks the CSC arrays per
       operation): the stored entries are uploaded column- and row-compressed (``adelie_hip_design_create_csc``, 24 bytes
-      per entry in f64), every operation streams the entries it needs, and ``grpnet`` runs its full-Gram engines on it.  A
+      per entry in f64, 34 with the tile-major copy the library adds for its full sweeps on larger designs), every operation
+      streams the entries it needs, and ``grpnet`` runs its full-Gram engines on it.  A
       design whose ``n * p`` values do not fit in device memory can run this way.  Duplicate entries are summed first.
     * ``"dense"`` — the entries are scattered once into a dense column-major array (``adelie_hip_design_create_sparse``)
       and the design then behaves as ``matrix.dense`` (panel engines, MFMA Gram builds): faster while ``n * p`` fits and

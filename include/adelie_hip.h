@@ -86,8 +86,9 @@ int adelie_hip_design_create_sparse(const int64_t* indptr, const int32_t* indice
 /* Replaces MatrixNaiveSparse{32,64}F with the matrix KEPT SPARSE in HBM (matrix_naive_sparse.ipp walks the CSC arrays per
  * operation, and so does this design): the stored entries are uploaded column-compressed (indptr p+1 int64, row indices int32
  * ascending and distinct inside a column, values of `dtype`) and row-compressed (row_indptr n+1, column indices, values: the
- * same entries, e.g. scipy's .tocsr()).  12 bytes per stored entry each way instead of n*p values: a design whose dense form
- * does not fit can run.  Gradients and Gram rows stream the CSC copy (one wavefront per column), residual updates and X beta
+ * same entries, e.g. scipy's .tocsr()).  12 bytes per stored entry each way instead of n*p values (plus, for designs of more
+ * than one tile of 16384 rows and at least a few entries per tile and column, a tile-major copy of 10 bytes per entry that
+ * the library builds on the device for its full sweeps): a design whose dense form does not fit can run.  Gradients and Gram rows stream the CSC copy (one wavefront per column), residual updates and X beta
  * the CSR copy; grpnet_solve runs its full-Gram engines on it (the panel engines need dense column slices), constraints are
  * not offered.  All MatrixNaiveBase operations below accept it; derived designs are composed on the host. */
 int adelie_hip_design_create_csc(const int64_t* indptr, const int32_t* indices, const void* values, const int64_t* row_indptr,

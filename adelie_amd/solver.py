@@ -166,7 +166,7 @@ def _has_batched_sweep(X):
     if not hasattr(X, "mul_batch") or backend is None:
         return False
     # the entry point takes resident dense / 2-bit designs; covariance matrices and multi-response views go one vector at a time
-    if isinstance(X, (matrix.MatrixCovBase64, matrix.MatrixCovBase32)) or getattr(X, "_is_view", False):
+    if isinstance(X, (matrix.MatrixCovBase64, matrix.MatrixCovBase32, matrix._MultiView, matrix._StdView)):
         return False
     try:
         backend.fn("design_mul_batch")
@@ -189,10 +189,7 @@ def _start_gaussian(X, glm, offsets, intercept, dtype):
         # both sweeps in ONE pass over the resident design (two vectors side by side): the reference makes two X.mul calls.
         # (The two-vector kernel sums in another order than the one-vector sweep the solver uses later: the starting
         # invariants agree with it to rounding, not bit for bit.)
-        try:
-            X_means, grad = X.mul_batch(np.stack([np.asarray(w, dtype=dtype), np.asarray(resid * w, dtype=dtype)]))
-        except RuntimeError:  # a design kind the batched entry point refuses
-            X_means = grad = None
+        X_means, grad = X.mul_batch(np.stack([np.asarray(w, dtype=dtype), np.asarray(resid * w, dtype=dtype)]))
     if grad is None:
         X_means = _sweep(X, np.ones(n, dtype=dtype), w, dtype)
         grad = _sweep(X, resid, w, dtype)
@@ -307,6 +304,15 @@ def grpnet(
     dtype = X.dtype
     p = X.cols()
 
+    if constraints is not None and any(c is not None for c in constraints) and warm_start is None:
+        # The constrained group solves live in the panel engines, which stream dense / 2-bit column slices: a lazily
+        # standardized view or a design kept sparse is materialised for such a fit (the reference composes any matrix with any
+        # constraint, adelie/solver.py:257-313), with a warning because the copy costs n * p values of HBM.
+        if isinstance(X, matrix._StdView) or matrix._is_kept_sparse(X):
+            warnings.warn(
+                "adelie_amd: constraints on a lazily standardized / sparse-resident design run on its materialised dense copy "
+                f"({X.rows()} x {X.cols()} values of device memory).", RuntimeWarning, stacklevel=2)
+            X = X._materialize() if isinstance(X, matrix._StdView) else matrix._expanded(X)
     raw = None if exit_cond is not None else _lasso_in_raw_coordinates(X, glm, constraints, groups, alpha, intercept, warm_start)
     if raw is not None:  # (an exit_cond callback reads the live state: it gets the view's own coordinates, i.e. the view's engines)
         # A lasso (alpha = 1, groups of one, intercept) on the standardized view (Z - 1 c') diag(s)^-1 of a resident design Z is the

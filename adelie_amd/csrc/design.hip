@@ -826,8 +826,38 @@ int adelie_hip_design_create_csc(const int64_t* indptr, const int32_t* indices, 
             if (indices[k] < 0 || indices[k] >= n) throw make_core_error("sparse(): row index out of range.");
             if (k > indptr[j] && indices[k] <= indices[k - 1]) throw make_core_error("sparse(): row indices must be sorted and distinct inside a column.");
         }
-    for (int64_t k = 0; k < nnz; ++k)
-        if (row_indices[k] < 0 || row_indices[k] >= p) throw make_core_error("sparse(): column index out of range.");
+    if (p >= (int64_t(1) << 31)) throw make_core_error("number of columns must fit in int32.");
+    {
+        // The two forms must hold the SAME entries: gradients read the column form, residual updates the row form, and an
+        // inconsistent pair would make them disagree silently.  Columns ascending and distinct inside a row, the same number of
+        // entries per column in both forms, and an order-independent checksum over (row, column, value bits).
+        const size_t vsz = dtype == ADELIE_HIP_F64 ? sizeof(double) : sizeof(float);
+        auto mix = [](uint64_t r, uint64_t c, uint64_t v) {
+            uint64_t h = (r * 0x9E3779B97F4A7C15ull) ^ (c * 0xC2B2AE3D27D4EB4Full) ^ (v * 0x165667B19E3779F9ull);
+            h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+            return h;
+        };
+        auto bits = [&](const void* vals, int64_t k) {
+            uint64_t b = 0;
+            std::memcpy(&b, static_cast<const char*>(vals) + size_t(k) * vsz, vsz);
+            return b;
+        };
+        std::vector<int64_t> per_col(static_cast<size_t>(p), 0);
+        uint64_t sum_r = 0, sum_c = 0;
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t k = row_indptr[i]; k < row_indptr[i + 1]; ++k) {
+                const int32_t c = row_indices[k];
+                if (c < 0 || c >= p) throw make_core_error("sparse(): column index out of range.");
+                if (k > row_indptr[i] && c <= row_indices[k - 1]) throw make_core_error("sparse(): column indices must be sorted and distinct inside a row.");
+                ++per_col[size_t(c)];
+                sum_r += mix(uint64_t(i), uint64_t(c), bits(row_values, k));
+            }
+        for (int64_t j = 0; j < p; ++j) {
+            if (per_col[size_t(j)] != indptr[j + 1] - indptr[j]) throw make_core_error("sparse(): the two compressed forms must hold the same entries.");
+            for (int64_t k = indptr[j]; k < indptr[j + 1]; ++k) sum_c += mix(uint64_t(indices[k]), uint64_t(j), bits(values, k));
+        }
+        if (sum_r != sum_c) throw make_core_error("sparse(): the two compressed forms must hold the same entries.");
+    }
     adelie_hip_design* d = new_design(n, p, dtype, device);
     try {
         d->kind = 3;
@@ -859,6 +889,8 @@ int adelie_hip_design_create_csc(const int64_t* indptr, const int32_t* indices, 
         {
             const int64_t th = kCscTileBytes / int64_t(vs);
             const int64_t nt = (n + th - 1) / th;
+            // (the tile of v is 128 KB of dynamic LDS — gfx950 has 160 KB per workgroup, the only target of this library; a launch
+            // the device refuses raises in raw_sweep)
             const bool worth = nt > 1 && nt <= 4096 && nnz >= (int64_t(1) << 16) && nt * (p + 1) * 8 <= (int64_t(1) << 30) &&
                                nnz / (nt * p) >= 4; // (segments of a few entries at least: below, the pointers outweigh the entries)
             if (worth) {

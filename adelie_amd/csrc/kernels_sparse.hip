@@ -17,6 +17,8 @@
 //   sweep      (x_j . v - c_j sum(v)) / s_j ;   squares: (sum v x^2 - 2 c_j sum v x + c_j^2 sum(v)) / s_j^2
 //   Gram       (C_ab - c_a m_b - c_b m_a + c_a c_b W) / (s_a s_b),  m = X^T w (raw),  W = sum(w)
 //   axpy       coefficients scaled by 1 / s_j on their way into the p-vector, and  kappa = sum_m coef_m c_m / s_m  off every row
+#include <stdexcept>
+#include <string>
 #include "kernels.hpp"
 #include "wavered.hpp"
 
@@ -514,8 +516,11 @@ void raw_sweep(const CscView<T>& X, const T* v, T* dst, int64_t c0, int64_t ncol
         // U = 4 / 8 / 16 segments in flight per lane group
         const unsigned chunks = unsigned(std::max<int64_t>(1, std::min<int64_t>(1024 / X.nt, (X.p + 255) / 256)));
         const dim3 grid(chunks, unsigned(X.nt));
+        (void)hipGetLastError(); // (whatever an earlier call of this thread left behind)
         if (square) hipLaunchKernelGGL((csc_tile_sweep_kernel<T, true, 8>), grid, dim3(1024), size_t(kCscTileBytes), s, X, v, part);
         else hipLaunchKernelGGL((csc_tile_sweep_kernel<T, false, 8>), grid, dim3(1024), size_t(kCscTileBytes), s, X, v, part);
+        if (const hipError_t e = hipGetLastError(); e != hipSuccess) // a refused launch must not pass for a sweep (stale partials)
+            throw std::runtime_error(std::string("adelie_hip: csc_tile_sweep_kernel launch refused: ") + hipGetErrorString(e));
         hipLaunchKernelGGL((csc_sweep_reduce_kernel<T>), dim3(blocks_for(ncols, 256)), dim3(256), 0, s, part, X.nt, dst, c0, ncols, cols,
                            sub_scale, sub_vec);
         return;
@@ -619,14 +624,17 @@ void launch_axpy_cols_csc(const CscView<T>& X, const int32_t* cols, const T* coe
     const int64_t bm_bytes = ((X.p + 31) >> 5) * 4;
     const unsigned wgs = unsigned(std::min<int64_t>((X.n + 63) / 64, 2048));
     if (bm_bytes <= 128 * 1024) { // the bitmap of the changed columns fits in LDS (p <= 1M columns)
-        static bool attr_done = false;
-        if (!attr_done) {
+        static const bool raised = [] { // (thread-safe once-init, like raw_sweep: concurrent solves share the launcher)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(csr_axpy_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       128 * 1024);
-            attr_done = true;
-        }
+            return true;
+        }();
+        (void)raised;
+        (void)hipGetLastError();
         hipLaunchKernelGGL((csr_axpy_kernel<T, true>), dim3(wgs), dim3(512), size_t(bm_bytes), s, X, delta_zeroed, cols, count_dev,
                            count, sign, kappa, out);
+        if (const hipError_t e = hipGetLastError(); e != hipSuccess) // (a refused launch would leave the residual stale)
+            throw std::runtime_error(std::string("adelie_hip: csr_axpy_kernel launch refused: ") + hipGetErrorString(e));
     } else {
         hipLaunchKernelGGL((csr_axpy_kernel<T, false>), dim3(wgs), dim3(512), 0, s, X, delta_zeroed, cols, count_dev, count, sign,
                            kappa, out);

@@ -16,6 +16,7 @@ Every ``X.mul`` below is one C-ABI call into ``libadelie_hip.so`` = one full-gra
 design.  Multi-response families (``glm.multigaussian``, ``glm.multinomial``) are solved in the
 coordinates of the expanded design ``[1 (x) I_K, X (x) I_K]`` (reference ``solver.py:700-844``).
 """
+import warnings
 from dataclasses import dataclass
 from typing import Callable
 

@@ -454,6 +454,10 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=None)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cpu-1thread-budget-s", type=float, default=12.0, help="config 2: extra CPU leg with one thread (0: skip)")
+    ap.add_argument("--tight-tol-budget-s", type=float, default=30.0,
+                    help="config 3: CPU budget of the tol = 1e-10 comparison of a lambda prefix (0: skip)")
+    ap.add_argument("--cfg4-parity-budget-s", type=float, default=200.0,
+                    help="config 4: CPU budget of the coarse-path parity sample with non-zero coefficients (0: skip)")
     args = ap.parse_args()
     cfg = args.config
     if args.steps is None:
@@ -500,7 +504,7 @@ def main():
         del k4, line4
         gc.collect()
         ctx.torch.cuda.empty_cache()
-        out["sparse_resident"] = sparse_leg(L)
+        out["sparse_resident"] = sparse_leg(L, cpu_budget_s=(0.0 if args.no_cpu_baseline else 15.0))
 
     if ctx.rank == 0:
         print(json.dumps(out), flush=True)
@@ -552,7 +556,7 @@ def lazy_views_leg(ad_design, L, y_binomial=None):
         return {"error": repr(e)}
 
 
-def sparse_leg(L, n=1_000_000, p=100_000, density=1e-3):
+def sparse_leg(L, n=1_000_000, p=100_000, density=1e-3, cpu_budget_s=0.0):
     """Gaussian lasso path on a sparse design kept sparse in HBM (matrix.sparse(resident="csc")): 745 GiB as dense f64."""
     import scipy.sparse as sp
 
@@ -573,12 +577,56 @@ def sparse_leg(L, n=1_000_000, p=100_000, density=1e-3):
         t0 = time.perf_counter()
         st = ad.grpnet(X, ad.glm.gaussian(y), **kw)
         el = time.perf_counter() - t0
-        return {"workload": f"Gaussian lasso, {L} lambdas, sparse design {n}x{p} with {M.nnz} stored entries kept sparse (CSC + CSR)",
-                "value": 1.0 / el, "unit": "paths/s", "ms_per_step": el * 1e3, "resident_bytes": int(M.nnz * 24 + (n + p + 2) * 8),
-                "dense_copy_bytes": int(n * p * 8), "lambdas": len(st.lmdas), "final_active": int(st.active_set_size),
-                "n_sweeps": int(st.counters["n_sweeps"]), "error": st.error}
+        out = {"workload": f"Gaussian lasso, {L} lambdas, sparse design {n}x{p} with {M.nnz} stored entries kept sparse (CSC + CSR)",
+               "value": 1.0 / el, "unit": "paths/s", "ms_per_step": el * 1e3, "resident_bytes": int(M.nnz * 24 + (n + p + 2) * 8),
+               "dense_copy_bytes": int(n * p * 8), "lambdas": len(st.lmdas), "final_active": int(st.active_set_size),
+               "n_sweeps": int(st.counters["n_sweeps"]), "error": st.error}
+        # dominant kernel: the full sweep over the tile-major copy (csc_tile_sweep_kernel: 2-byte row + value per stored entry,
+        # the tile of v through LDS), timed live with HIP events on the solver's stream like the dense sweep
+        nl, ms = st.timers["n_sweep_launches"], st.timers["t_sweep_ms"]
+        if nl > 0:
+            sweep_bytes = float(M.nnz) * 10 + 8.0 * n + 8.0 * p
+            ach = sweep_bytes / (ms / nl * 1e-3) / 1e9
+            out["roofline"] = {"kernel": "csc_tile_sweep_kernel (+ csc_sweep_reduce_kernel): grad = X^T v over the tile-major copy, "
+                                         "full design", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(f"csc_tile_sweep_kernel:{n}x{p}:f64"),
+                               "launches": int(nl), "avg_launch_ms": ms / nl, "algorithmic_bytes_per_launch": sweep_bytes}
+        if cpu_budget_s > 0:
+            out["cpu_baseline"] = sparse_cpu_baseline(M, y, st, cpu_budget_s)
+        return out
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)}
+
+
+def sparse_cpu_baseline(M, y, gpu_state, budget_s):
+    """The oracle restates the reference's dense and SNP matrices only, so the CPU figure next to the sparse-resident leg is an
+    INDEPENDENT solver on the same scipy CSC matrix: scikit-learn's coordinate-descent Lasso (same objective: adelie's
+    Gaussian loss with weights 1/n is sklearn's (1/2n)||y - Xb - b0||^2, alpha = lmda), warm-started down the GPU path's own
+    lambda grid until the budget is spent; its coefficients double as a full-size parity sample for the sparse kernels."""
+    from sklearn.linear_model import Lasso
+
+    n, p = M.shape
+    lm = np.asarray(gpu_state.lmdas)
+    Bg = gpu_state.betas
+    mdl = Lasso(alpha=float(lm[0]), fit_intercept=True, warm_start=True, tol=1e-10, max_iter=100000, selection="cyclic")
+    t0 = time.perf_counter()
+    k, db, nnz_cmp = 0, 0.0, 0
+    for i, a in enumerate(lm):
+        mdl.set_params(alpha=float(a))
+        mdl.fit(M, y)
+        k = i + 1
+        bg = np.asarray(Bg[i].toarray()).reshape(-1)
+        db = max(db, float(np.abs(mdl.coef_ - bg).max()))
+        nnz_cmp += int(np.count_nonzero(mdl.coef_))
+        if time.perf_counter() - t0 > budget_s:
+            break
+    el = time.perf_counter() - t0
+    L = len(lm)
+    return {"value": (k / L) / el, "unit": "paths/s", "cores": 1, "kind": "independent",
+            "sample": (f"scikit-learn Lasso (cyclic coordinate descent, tol 1e-10, warm starts) on the same {n}x{p} scipy CSC matrix and "
+                       f"response, first {k} of {L} lambdas of the GPU path's grid in a {budget_s:.0f} s budget, 1 thread; value = (solved "
+                       f"fraction)/time, an upper bound on its paths/s; the oracle has no sparse design"),
+            "seconds": el, "lambdas_solved": k, "max_abs_dbeta_vs_gpu": db, "nonzero_coefficients_compared": nnz_cmp}
 
 
 # -------------------------------------------------------------------------------------------------------------------------
@@ -599,18 +647,43 @@ def cpu_baseline(cfg, args, keep, y, glm, kw, cv_kw, npdtype, gpu_last, Xd, n, p
     L = args.lmda_path_size
     base = {"unit": "paths/s", "cores": cores, "kind": "port", "host_cores_available": host_cores()}
 
-    def bounded_path(Xo, glm_, kw_, gpu_state):
-        """Runs the oracle until the budget is spent; returns (solved lambdas, seconds, max|dbeta| vs the GPU path)."""
+    parity = {}
+
+    def bounded_path(Xo, glm_, kw_, gpu_state, budget_s=None, X_eval=None, tag=None):
+        """Runs the oracle until the budget is spent; returns (solved lambdas, seconds, max|dbeta| vs the GPU path) and
+        records, under `parity[tag]`, what the reference's own fall-back criterion compares (tests/test_solver.py:446-466):
+        the objective of both solutions at every solved lambda, evaluated by ONE evaluator (diagnostic.objective on the
+        resident design), plus how many coefficients the comparison covered."""
+        b = budget if budget_s is None else budget_s
         t0 = time.perf_counter()
-        st = ad.grpnet(Xo, glm_, n_threads=cores, exit_cond=lambda s: (time.perf_counter() - t0) > budget, **kw_)
+        st = ad.grpnet(Xo, glm_, n_threads=cores, exit_cond=lambda s: (time.perf_counter() - t0) > b, **kw_)
         el = time.perf_counter() - t0
         k = len(st.lmdas)
-        db = float(np.abs(st.betas.toarray() - gpu_state.betas[:k].toarray()).max()) if k else None
+        db = None
+        if k:
+            Bc, Bg = st.betas.toarray(), gpu_state.betas[:k].toarray()
+            db = float(np.abs(Bc - Bg).max())
+            info = {"lambdas_compared": k, "coefficients_compared": int(Bc.size),
+                    "nonzero_cpu": int(np.count_nonzero(Bc)), "nonzero_gpu": int(np.count_nonzero(Bg)),
+                    "lambdas_with_nonzero_coefficients": int(np.count_nonzero(np.any(Bc != 0, axis=1))),
+                    "max_abs_dbeta": db,
+                    "max_abs_dintercept": float(np.abs(np.asarray(st.intercepts) - np.asarray(gpu_state.intercepts)[:k]).max())}
+            if X_eval is not None:
+                okw = dict(lmdas=np.asarray(st.lmdas), groups=kw_.get("groups"), alpha=kw_.get("alpha", 1))
+                o_c = ad.diagnostic.objective(X_eval, glm_, st.betas, np.asarray(st.intercepts), **okw)
+                o_g = ad.diagnostic.objective(X_eval, glm_, gpu_state.betas[:k], np.asarray(gpu_state.intercepts)[:k], **okw)
+                rel = (o_g - o_c) / np.maximum(np.abs(o_c), np.finfo(np.float64).tiny)
+                info.update(max_rel_objective_gap_gpu_minus_cpu=float(rel.max()),
+                            min_rel_objective_gap_gpu_minus_cpu=float(rel.min()),
+                            reference_criterion_obj_gpu_le_obj_cpu_x_1p1e8=bool(np.all(o_g <= o_c * (1 + 1e-8) + 1e-300)
+                                                                                or np.all(np.abs(rel) <= 1e-8)))
+            parity[tag or "default_tol"] = info
         return k, el, db
 
     if cfg in (2, 3):
         Xh = keep["X"].t().contiguous().cpu().numpy().T  # (n, p) F-ordered host copy of the same matrix
-        k, el, db = bounded_path(oracle.dense(Xh, n_threads=cores), glm, kw, gpu_last)
+        Xo = oracle.dense(Xh, n_threads=cores)
+        k, el, db = bounded_path(Xo, glm, kw, gpu_last, X_eval=Xd)
         if k == L:
             value, sample = 1.0 / el, f"full {L}-lambda path on the same {n}x{p} data (host copy), {cores} OpenMP threads"
         else:
@@ -618,6 +691,13 @@ def cpu_baseline(cfg, args, keep, y, glm, kw, cv_kw, npdtype, gpu_last, Xd, n, p
             sample = (f"first {k} of {L} lambdas of the same path on the same data (time budget {budget:.0f} s), {cores} OpenMP "
                       f"threads; value = (solved fraction)/time, an UPPER bound on the CPU paths/s: later lambdas cost more")
         out = dict(base, value=value, sample=sample, seconds=el, lambdas_solved=k, max_abs_dbeta_vs_gpu=db)
+        if cfg == 3 and args.tight_tol_budget_s > 0:
+            # At the default tol = 1e-7 two correct group-elastic-net runs differ by the stopping rule's resolution (DESIGN.md,
+            # numerics); the same path at tol = 1e-10 on both sides (a lambda prefix, own budget) separates that from a defect
+            kw_t = dict(kw, tol=1e-10)
+            g_t = ad.grpnet(Xd, glm, **kw_t)
+            bounded_path(Xo, glm, kw_t, g_t, budget_s=args.tight_tol_budget_s, X_eval=Xd, tag="tol_1e-10")
+        out["parity"] = parity
         if cfg == 2 and args.cpu_1thread_budget_s > 0:
             # the reference documents that one thread is often the fastest setting for this solver (parallelism.ipynb cell 18):
             # the same path with n_threads = 1, on its own (shorter) budget
@@ -656,10 +736,19 @@ def cpu_baseline(cfg, args, keep, y, glm, kw, cv_kw, npdtype, gpu_last, Xd, n, p
             t0 = time.perf_counter()
             g_state = ad.grpnet(Xg, glm_s, **kw)
             g_el = time.perf_counter() - t0
-        k, el, db = bounded_path(oracle.snp_calldata(cd_h, imp_s, dtype=npdtype, n_threads=cores), glm_s, kw, g_state)
+        Xo4 = oracle.snp_calldata(cd_h, imp_s, dtype=npdtype, n_threads=cores)
+        k, el, db = bounded_path(Xo4, glm_s, kw, g_state, X_eval=(Xd if full else Xg))
+        if args.cfg4_parity_budget_s > 0:
+            # The path's first lambdas have nothing active, and the oracle solves only a few of them in the throughput budget:
+            # a COARSE path over the same data (12 lambdas down to 0.5 lmda_max: non-zero coefficients from the second one on)
+            # solved by both sides is the full-size parity sample
+            kw_c = dict(kw, lmda_path_size=12, min_ratio=0.5)
+            g_c = ad.grpnet(Xd if full else Xg, glm_s, **kw_c)
+            bounded_path(Xo4, glm_s, kw_c, g_c, budget_s=args.cfg4_parity_budget_s, X_eval=(Xd if full else Xg),
+                         tag="coarse_path_12_lambdas_min_ratio_0.5")
         g_prefix = float(np.sum(g_state.benchmark_fit_screen[:k]) + np.sum(g_state.benchmark_fit_active[:k])) if k else None
         out = dict(base, value=(k / L) / el, seconds=el, lambdas_solved=k, max_abs_dbeta_vs_gpu=db, full_size=bool(full),
-                   gpu_fit_seconds_same_prefix=g_prefix)
+                   gpu_fit_seconds_same_prefix=g_prefix, parity=parity)
         if full:
             out["sample"] = (f"the SAME {n}x{p} calldata and response (host int8 copy), first {k} of {L} lambdas in a {budget:.0f} s "
                              f"budget, {cores} OpenMP threads; value = (solved fraction)/time, an UPPER bound on the CPU paths/s "

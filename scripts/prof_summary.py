@@ -38,10 +38,11 @@ def stats(db):
         print(f"{k:100s} grid=({r[1]},{r[2]},{r[3]}) wg={r[4]} lds={r[5]} vgpr={r[6]} agpr={r[7]} sgpr={r[8]} scratch={r[9]}")
 
 
-def by_grid(db, patterns=("sweep_kernel", "multi_sweep")):
+def by_grid(db, patterns=("sweep", "syrk_batch", "csr_axpy", "csr_tmul")):
     """Launches of one template differ by orders of magnitude in work (a full-design sweep and a 200-column one share a name):
     per (kernel, grid) class the call count and average duration, so that a per-launch roofline figure can be recomputed from
-    this file for the class it was quoted on (config 4's sweep could not be)."""
+    this file for the class it was quoted on (config 4's sweep could not be; r4: every sweep-type template —
+    sweep_kernel, sweep_snp_lut_kernel, csc_*sweep*, multi_sweep* — and the batched block builds, whose launches carry 1..16 blocks)."""
     c = sqlite3.connect(db)
     print("\n# sweep-type kernels by launch geometry (grid in threads; the largest grid of a template is the full design)")
     print(f"{'kernel':100s} {'grid':>22s} {'calls':>7s} {'avg_us':>10s} {'total_ms':>10s}")
@@ -52,7 +53,7 @@ def by_grid(db, patterns=("sweep_kernel", "multi_sweep")):
     for name, gx, gy, gz, n, av, tot in c.execute(q):
         k = short(name)
         shown[k] = shown.get(k, 0) + 1
-        if shown[k] > 6:
+        if shown[k] > 8:
             continue
         print(f"{k:100s} {f'({gx},{gy},{gz})':>22s} {n:7d} {av / 1e3:10.2f} {tot / 1e6:10.2f}")
 

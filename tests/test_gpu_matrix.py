@@ -317,8 +317,13 @@ def test_lazy_standardized_view(hip, oracle, kind, dtype):
     assert np.abs(ca.losses - cb.losses).max() < 1e-7 * max(1.0, np.abs(cb.losses).max())
     cons = [None] * p
     cons[3] = ad.constraint.lower(np.array([-0.5]))
-    with pytest.raises(RuntimeError, match="lazily standardized"):
-        ad.grpnet(S, ad.glm.gaussian(y), constraints=cons, progress_bar=False)
+    kwk = dict(tol=1e-12, early_exit=False, lmda_path_size=8, min_ratio=0.2, progress_bar=False)
+    with pytest.warns(RuntimeWarning, match="materialised dense copy"):   # constrained fits run on the materialised copy
+        ka = ad.grpnet(S, ad.glm.gaussian(y), constraints=cons, **kwk)
+    cons_b = [None] * p
+    cons_b[3] = ad.constraint.lower(np.array([-0.5]))
+    kb = ad.grpnet(ad.matrix.dense(Xs), ad.glm.gaussian(y), constraints=cons_b, **kwk)
+    assert ka.error == "" and np.abs(ka.betas.toarray() - kb.betas.toarray()).max() < 1e-9
     Y = np.stack([y, -y], axis=1)   # multi-response fits: the view is materialised first
     kwm = dict(tol=1e-12, early_exit=False, lmda_path_size=8, min_ratio=0.2, progress_bar=False)
     ma = ad.grpnet(S, ad.glm.multigaussian(Y), **kwm)

@@ -97,6 +97,17 @@ def test_kept_sparse_design_sums_duplicates_and_validates(hip):
         ad.matrix.sparse(np.eye(3), resident="csc")
     with pytest.raises(ValueError, match="resident"):
         ad.matrix.sparse(sp.csc_matrix(np.eye(3)), resident="hbm")
+    # a C-ABI caller's row form that does not hold the column form's entries is refused
+    from adelie_amd import _abi
+    b = _abi.hip_backend()
+    Mc = sp.csc_matrix(np.array([[1.0, 0.0], [0.0, 2.0], [3.0, 0.0]]))
+    Mr = sp.csr_matrix(np.array([[1.0, 0.0], [0.0, 2.5], [3.0, 0.0]]))  # one value differs
+    h = _abi.C.c_void_p()
+    ip, ix, vv = Mc.indptr.astype(np.int64), Mc.indices.astype(np.int32), Mc.data.astype(np.float64)
+    rp, rx, rv = Mr.indptr.astype(np.int64), Mr.indices.astype(np.int32), Mr.data.astype(np.float64)
+    with pytest.raises(RuntimeError, match="same entries"):
+        b.check(b.fn("design_create_csc")(ip.ctypes.data, ix.ctypes.data, vv.ctypes.data, rp.ctypes.data, rx.ctypes.data,
+                                          rv.ctypes.data, 3, 2, _abi.dtype_code(np.float64), 0, h))
     # the default keeps very sparse matrices sparse and expands the others
     rng = np.random.RandomState(0)
     assert ad.matrix.sparse(sp.csc_matrix(_rand_sparse(rng, 400, 50, 0.005)))._kind == "sparse"
@@ -261,14 +272,21 @@ def test_standardized_view_of_a_kept_sparse_design(hip, oracle, dtype):
     assert np.abs(ca.losses - cb.losses).max() < 1e-7 * max(1.0, np.abs(cb.losses).max())
 
 
-def test_kept_sparse_design_refuses_constraints_and_serves_multi_response_fits(hip, oracle):
+def test_kept_sparse_design_serves_constrained_and_multi_response_fits(hip, oracle):
     rng = np.random.RandomState(15)
     D, y = _problem(rng, 300, 40, 0.15)
     X = _csc(sp.csc_matrix(D))
     cons = [None] * 40
     cons[3] = ad.constraint.lower(np.array([-0.5]))
-    with pytest.raises(RuntimeError, match="kept sparse"):
-        ad.grpnet(X, ad.glm.gaussian(y), constraints=cons, progress_bar=False)
+    # constraints live in the panel engines: the fit runs on the expanded copy (with a warning), as the reference composes any
+    # matrix with any constraint
+    kwc = dict(tol=1e-12, early_exit=False, lmda_path_size=10, min_ratio=0.1, progress_bar=False)
+    with pytest.warns(RuntimeWarning, match="materialised dense copy"):
+        ca = ad.grpnet(X, ad.glm.gaussian(y), constraints=cons, **kwc)
+    cons2 = [None] * 40
+    cons2[3] = ad.constraint.lower(np.array([-0.5]))
+    cb = ad.grpnet(ad.matrix.dense(np.asfortranarray(D)), ad.glm.gaussian(y), constraints=cons2, **kwc)
+    assert ca.error == "" and np.abs(ca.betas.toarray() - cb.betas.toarray()).max() < 1e-9
     # multi-response fits need dense column slices: the view is built over the expanded copy
     Y = np.stack([y, -y + 0.1 * rng.normal(size=300)], axis=1)
     kw = dict(tol=1e-12, early_exit=False, lmda_path_size=10, min_ratio=0.1, progress_bar=False)

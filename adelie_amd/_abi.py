@@ -127,6 +127,7 @@ class GrpnetArgs(C.Structure):
         ("constraint_vb", C.c_void_p),
         ("constraint_cfg", C.c_void_p),
         ("constraint_lin", C.c_void_p),
+        ("constraint_vmu", C.c_void_p),
     ]
 
 
@@ -136,7 +137,7 @@ V = dict(
     screen_X_means=9, screen_vars=10, screen_transforms=11,
     benchmark_screen=12, benchmark_fit_screen=13, benchmark_fit_active=14, benchmark_kkt=15,
     benchmark_invariance=16,
-    betas_values=200, duals_values=201, constraint_mu=202,
+    betas_values=200, duals_values=201, constraint_mu=202, constraint_vmu=203,
 )
 I = dict(
     screen_set=100, screen_begins=101, screen_is_active=102, active_set=103, n_valid_solutions=104,
@@ -148,7 +149,7 @@ S = dict(
     total_time=8,
     n_basil_iters=50, n_sweeps=51, n_cd_visits_screen=52, n_cd_visits_active=53, n_updates=54,
     n_irls_iters=55, n_new_screen_cols=56, n_cd_passes_screen=57, n_cd_passes_active=58,
-    n_gram_col_reads=59, n_resid_col_reads=60, gram_flops=61, n_panel_blocks=62, n_panel_grams=63, n_panel_cols=64, n_irls_screen_cols=65, n_speculated=66, n_spec_rollbacks=67, n_sweeps_shared=68, n_update_cols=69, n_device_screens=70, n_host_screens=71,
+    n_gram_col_reads=59, n_resid_col_reads=60, gram_flops=61, n_panel_blocks=62, n_panel_grams=63, n_panel_cols=64, n_irls_screen_cols=65, n_speculated=66, n_spec_rollbacks=67, n_sweeps_shared=68, n_update_cols=69, n_device_screens=70, n_host_screens=71, n_host_cons_visits=72, n_dev_cons_visits=73,
     t_sweep_ms=80, t_gram_ms=81, t_cd_ms=82, t_axpy_ms=83, n_sweep_launches=84, n_gram_launches=85,
     t_host_screen_ms=86, t_panel_step_ms=87, n_panel_step_launches=88, t_host_screen_wait_ms=89,
 )
@@ -182,7 +183,7 @@ def dtype_code(dtype):
 
 
 # kept equal to ADELIE_HIP_ABI_VERSION in include/adelie_hip.h (tests/test_abi.py compares the two)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class Backend:

@@ -210,7 +210,13 @@ void launch_abs_grad_cons(const T* grad, const int64_t* groups, const int64_t* g
                           T* mu_out, hipStream_t s);
 
 // ---- coordinate descent (pin solver) ----------------------------------------------------------
-enum CdStatus : int32_t { CD_OK = 0, CD_MAX_CDS = 1, CD_MAX_ACTIVE = 2, CD_NEWTON = 3 };
+enum CdStatus : int32_t {
+    CD_OK = 0, CD_MAX_CDS = 1, CD_MAX_ACTIVE = 2, CD_NEWTON = 3,
+    // constraint objects solved on the device (kernels_cons.hip): the errors of constraint/utils.hpp:24-243 and its sub-solvers
+    CD_CONS_PN = 4, CD_CONS_QP_BOX = 5, CD_CONS_QP_NNQP = 6, CD_CONS_UNEXPECTED = 7
+};
+// adelie_hip_grpnet_args::constraint_native
+constexpr int32_t ADELIE_HIP_NATIVE_BOX = 4, ADELIE_HIP_NATIVE_ONE_SIDED = 5, ADELIE_HIP_NATIVE_LINEAR = 6;
 
 template <class T>
 struct CdScalars { // one instance in device memory, read back by the host after the kernel
@@ -323,6 +329,37 @@ struct CdBlkParams {
     const T* chi;
     T* cmu;
 };
+// One visit of a group whose box / one-sided constraint object is solved on the device (kernels_cons.hip): the group is a block
+// of its own; pointers are already offset to the group (its screen begin `b`, its first design column `col0`).
+template <class T>
+struct ConsVisitParams {
+    int32_t q, ss, b, col0, native;       // group size, screen position, screen begin, first design column, NATIVE_BOX / _ONE_SIDED
+    const T* gsrc;                        // [q] gradient of the group (panel reduce output, or the Gram engines' g + b)
+    T* beta;                              // [q] screen_beta + b
+    const T* vars;                        // [q] eigenvalues
+    const T* V;                           // [q * q] eigenbasis, column-major (ignored for q = 1)
+    const T* sxm;                         // [q] screen_X_means + b, or nullptr
+    int8_t* is_active;                    // (whole array, indexed by ss)
+    int32_t* active_set;
+    CdBlkState<T>* st;
+    double l1, l2, dbeta_tol;
+    int32_t mark, first_of_pass, gram, max_active_size;
+    int32_t* dcol; T* dlt;                // [q] out: the changes for the next residual update / Gram update
+    const T* va; const T* vb;             // [q] box: lower, upper; one-sided: sgn, b
+    T* mu;                                // [q] in/out: the object's multipliers
+    double cfg[5];                        // max_iters, tol, pinball / nnqp max_iters, its tol, slack
+    CdBlkState<T>* host_st; int32_t* host_seq; int32_t report_seq; // end-of-pass report (report_seq = 0: none)
+    int64_t* n_visits;                    // device counter or nullptr
+};
+size_t cons_visit_lds(int q);
+template <class T>
+void launch_grp_cons_visit(const ConsVisitParams<T>& p, hipStream_t s);
+// abs_grad (and, outside the screen set, the solve_zero multipliers) of the `count` groups in `list` with device constraint objects
+template <class T>
+void launch_cons_abs_grad(const int32_t* list, int count, const int32_t* native, const int64_t* groups, const int64_t* gsizes,
+                          const int32_t* slot, const T* grad, const T* beta, const T* penalty, T regul_scale,
+                          const T* va, const T* vb, T* mu, T* abs_grad, hipStream_t s);
+
 // group (q > 1) variant: a block = consecutive groups of the visiting list with <= 128 values in total
 template <class T>
 struct CdGrpBlkParams {

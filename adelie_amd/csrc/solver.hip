@@ -420,6 +420,7 @@ struct Result : ResultBase {
             case ADELIE_HIP_I_DUALS_INDICES:
             case ADELIE_HIP_V_DUALS_VALUES: { int64_t t = 0; for (auto& v : s.duals_idx) t += v.size(); return t; }
             case ADELIE_HIP_V_CONSTRAINT_MU: return s.cons_on ? s.G : 0;
+            case ADELIE_HIP_V_CONSTRAINT_VMU: return s.cons_dev ? s.p : 0;
         }
         return -1;
     }
@@ -495,6 +496,11 @@ struct Result : ResultBase {
                 for (idx g = 0; g < s.G && g < cap; ++g) d[g] = s.cons_kind[g] ? double(s.cons_dual_of(g)) : 0.0;
                 return 0;
             }
+            case ADELIE_HIP_V_CONSTRAINT_VMU: {
+                if (!s.cons_dev) return 0;
+                cp_d(s.cons_vmu, d, cap);
+                return 0;
+            }
         }
         return 1;
     }
@@ -541,6 +547,8 @@ struct Result : ResultBase {
             case ADELIE_HIP_S_N_UPDATE_COLS: return double(s.cnt.n_update_cols);
             case ADELIE_HIP_S_N_DEVICE_SCREENS: return 0.0; /* (screening on the device was measured slower and removed in round 4) */
             case ADELIE_HIP_S_N_HOST_SCREENS: return double(s.n_host_screens);
+            case ADELIE_HIP_S_N_HOST_CONS_VISITS: return double(s.n_host_cons_visits);
+            case ADELIE_HIP_S_N_DEV_CONS_VISITS: return double(s.n_dev_cons_visits_final);
             default:
                 if (which >= 900 && which < 908) return double(s.cd_dbg[which - 900]);
                 if (which >= 910 && which < 918) return 1e3 * s.t_host[which - 910];

@@ -48,6 +48,22 @@
     const adelie_hip_constraint_callbacks* cons_cb = nullptr;
     std::vector<idx> cons_m; // (G,) multipliers per group
     bool host_cons(idx g) const { return cons_host && cons_kind[g] == ADELIE_HIP_CONSTRAINT_HOST; }
+    // ... of which the built-in box / one-sided classes (constraint_native 4 / 5) on groups of <= 64 coefficients run on the
+    // device (kernels_cons.hip): same block structure, the visit is a one-wavefront launch instead of a host round trip, the
+    // multipliers live in d_cons_mu (per design coefficient) and abs_grad / the duals read them there
+    bool cons_dev = false;
+    std::vector<int32_t> cons_native;          // (G,) or empty
+    std::vector<double> cons_cfg;              // (G, 5)
+    std::vector<int32_t> devcons_list;         // the groups with on_device()
+    std::vector<T> cons_vmu;                   // (p,) host mirror of d_cons_mu
+    DevBuf<T> d_cons_va, d_cons_vb, d_cons_mu; // (p,)
+    DevBuf<int32_t> d_cons_native, d_devcons_list;
+    DevBuf<int64_t> d_cons_nvis;
+    int64_t n_host_cons_visits = 0, n_dev_cons_visits_final = 0;
+    bool on_device(idx g) const {
+        return cons_dev && host_cons(g) && (cons_native[g] == ADELIE_HIP_NATIVE_BOX || cons_native[g] == ADELIE_HIP_NATIVE_ONE_SIDED) &&
+               group_sizes[g] <= 64;
+    }
     adelie_hip_glm_callbacks glm_cb{};       // glm_kind == CALLBACK: the user's GlmBase subclass, evaluated on the host
     std::vector<T> cb_eta, cb_grad, cb_hess, cb_z;
     idx max_gs = 1;

@@ -123,6 +123,12 @@
             sync();
             if (sc.status == CD_MAX_CDS) throw max_cds_error(0);
             if (sc.status == CD_MAX_ACTIVE) throw make_solver_error("Maximum number of active groups reached.");
+            // constraint objects solved on the device (kernels_cons.hip): the errors of constraint/utils.hpp and its sub-solvers
+            if (sc.status == CD_CONS_PN) throw make_solver_error("ConstraintBase: proximal newton max iterations reached!");
+            if (sc.status == CD_CONS_QP_BOX) throw make_solver_error("StatePinballFull: max iterations reached!");
+            if (sc.status == CD_CONS_QP_NNQP) throw make_solver_error("StateNNQPFull: max iterations reached!");
+            if (sc.status == CD_CONS_UNEXPECTED)
+                throw make_core_error("Possibly an unexpected error! Previous iterate should have been properly initialized. ");
             throw make_solver_error("Newton-ABS max iterations reached! Try increasing newton_max_iters.");
         }
         // residual update r -= X_S (beta - beta0), once per fit (the covariance method has no residual: its invariant, the

@@ -587,7 +587,8 @@
                     const idx ss0 = screen_pass ? idx(part_host[size_t(j)]) : act_host[size_t(part_host[size_t(j)])];
                     if (!(part_host[size_t(j) + 1] - part_host[size_t(j)] == 1 && host_cons(screen_set[ss0]))) continue;
                     launch_cd_group_block_range<T>(bp, j0, j, st);
-                    (void)host_group_visit(cp, ss0, screen_pass, j == 0, true);
+                    if (on_device(screen_set[ss0])) dev_group_visit(cp, ss0, screen_pass, j == 0, true, false);
+                    else (void)host_group_visit(cp, ss0, screen_pass, j == 0, true);
                     launch_cd_group_block_update<T>(bp, j, st);
                     j0 = j + 1;
                 }
@@ -650,6 +651,7 @@
         const idx g = screen_set[ss], q = group_sizes[g], b = screen_begins[ss];
         const size_t uq = static_cast<size_t>(q);
         const bool trace_hv = hooks.trace >= 1;
+        ++n_host_cons_visits;
         if (trace_hv) std::fprintf(stderr, "[host visit] ss=%lld g=%lld q=%lld b=%lld voff=%lld v_used=%zu nv=%lld\n", (long long)ss, (long long)g,
                                    (long long)q, (long long)b, (long long)(size_t(ss) < h_voff.size() ? h_voff[size_t(ss)] : -1), v_used, (long long)nv);
         std::vector<T> gk(uq), ak(uq), Ak(uq), Vk(uq * uq, T(1));
@@ -728,17 +730,47 @@
         sync();
         return bs;
     }
+    // The same visit for a box / one-sided object that runs on the device (on_device(g); kernels_cons.hip): one launch on the
+    // solver's stream, no host round trip.  `report`: this block is the last one of the pass, the kernel publishes the pass state.
+    void dev_group_visit(const CdParams<T>& cp, idx ss, bool mark, bool first_of_pass, bool gram, bool report) {
+        const idx g = screen_set[ss], q = group_sizes[g], b = screen_begins[ss];
+        ConsVisitParams<T> vp{};
+        vp.q = int32_t(q); vp.ss = int32_t(ss); vp.b = int32_t(b); vp.col0 = int32_t(groups[g]); vp.native = cons_native[g];
+        vp.gsrc = gram ? d_g.p + b : d_gblk.p;
+        vp.beta = d_beta.p + b;
+        vp.vars = d_vars.p + b;
+        vp.V = q > 1 ? d_V.p + h_voff[size_t(ss)] : nullptr;
+        vp.sxm = gram ? nullptr : cp.xmean + b;
+        vp.is_active = d_isact.p;
+        vp.active_set = d_actset.p;
+        vp.st = d_blk.p;
+        const T pk = penalty[g];
+        vp.l1 = double(cp.lmda * cp.alpha) * double(pk);
+        vp.l2 = double(cp.lmda * (T(1) - cp.alpha)) * double(pk);
+        vp.dbeta_tol = double(g_dbeta_tol);
+        vp.mark = mark ? 1 : 0; vp.first_of_pass = first_of_pass ? 1 : 0; vp.gram = gram ? 1 : 0;
+        vp.max_active_size = int32_t(std::min<size_t>(max_active_size, size_t(std::numeric_limits<int32_t>::max())));
+        vp.dcol = gram ? d_didx.p : d_dcolblk.p;
+        vp.dlt = d_dlt.p;
+        vp.va = d_cons_va.p + groups[g]; vp.vb = d_cons_vb.p + groups[g]; vp.mu = d_cons_mu.p + groups[g];
+        for (int e = 0; e < 5; ++e) vp.cfg[e] = cons_cfg[size_t(g) * 5 + e];
+        vp.host_st = rep_st_dev; vp.host_seq = rep_seq_dev;
+        vp.report_seq = (report && h_report) ? ++report_seq : 0;
+        vp.n_visits = d_cons_nvis.p;
+        launch_grp_cons_visit<T>(vp, st);
+    }
     // abs_grad of the groups with host constraint objects (solver_base.hpp:62-93): the constraint's gradient for screened groups,
     // its solve_zero for the others; overrides what the device kernel wrote for them (it knows no bounds for these groups)
     void host_cons_abs_grad(T lm) {
         if (!cons_host) return;
+        if (cons_dev && devcons_list.size() == n_host_cons) return; // every object runs on the device
         d_grad.download(grad.data(), size_t(p), st);
         sync();
         std::vector<double> v, out;
         std::vector<idx> begin_of(static_cast<size_t>(G), idx(-1));
         for (size_t ss = 0; ss < screen_set.size() && ss < screen_begins.size(); ++ss) begin_of[size_t(screen_set[ss])] = screen_begins[ss];
         for (idx g = 0; g < G; ++g) {
-            if (!host_cons(g)) continue;
+            if (!host_cons(g) || on_device(g)) continue; // (device objects: cons_abs_grad_kernel, device_abs_grad)
             const idx q = group_sizes[g], k = groups[g];
             v.assign(size_t(q), 0);
             if (begin_of[size_t(g)] >= 0) {
@@ -1101,6 +1133,11 @@
                     const idx ss0 = screen_pass ? idx(part_host[size_t(j)]) : act_host[size_t(part_host[size_t(j)])];
                     if (part_host[size_t(j) + 1] - part_host[size_t(j)] == 1 && host_cons(screen_set[ss0])) {
                         if (blk_ev[size_t(j)]) AHIP_CHECK(hipStreamWaitEvent(st, blk_ev[size_t(j)], 0)); // (its eigenbasis)
+                        if (on_device(screen_set[ss0])) { // one launch, the pass report included when it is the last block
+                            dev_group_visit(cp, ss0, screen_pass, j == 0, false, j == nblk - 1);
+                            last_on_host = false;
+                            continue;
+                        }
                         host_bs = host_group_visit(cp, ss0, screen_pass, j == 0);
                         last_on_host = (j == nblk - 1);
                         continue;

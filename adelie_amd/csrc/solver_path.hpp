@@ -109,7 +109,12 @@
             std::vector<double> mu_obj;
             for (idx g = 0; g < G; ++g) {
                 if (!cons_kind[g]) continue;
-                if (host_cons(g)) { // the object's own multipliers
+                if (on_device(g)) { // multipliers per coefficient, in the object's order (the gradient convention: box mu, one-sided mu >= 0)
+                    for (idx t = 0; t < group_sizes[g]; ++t) {
+                        const T m = cons_vmu[size_t(groups[g] + t)];
+                        if (m != 0) { di.push_back(dual_groups[g] + t); dv.push_back(m); }
+                    }
+                } else if (host_cons(g)) { // the object's own multipliers
                     mu_obj.assign(size_t(cons_m[g]), 0.0);
                     if (cons_m[g] > 0 && cons_cb->dual(cons_cb->user, g, cons_m[g], mu_obj.data()))
                         throw make_solver_error("constraint.dual() raised.");
@@ -281,6 +286,10 @@
     // multipliers of the screened coordinates as their last visits left them (device) -> host mirror
     std::vector<T> cmu_stage;
     void refresh_screen_multipliers() {
+        if (cons_on && cons_dev) { // the device objects' multipliers, screened or not (cons_abs_grad_kernel keeps the others)
+            d_cons_mu.download(cons_vmu.data(), size_t(p), st);
+            if (nv <= 0) sync();
+        }
         if (!cons_on || nv <= 0) return;
         cmu_stage.resize(size_t(nv));
         d_cmu.download(cmu_stage.data(), size_t(nv), st);
@@ -296,6 +305,10 @@
         d_grad.download(grad.data(), size_t(p), st);
         if (!cov_mode) d_r.download(resid.data(), size_t(n), st);
         if (is_glm()) d_eta.download(eta.data(), size_t(n), st);
+        if (cons_dev) { // what the device-side constraint objects hold, and how often they were visited
+            d_cons_mu.download(cons_vmu.data(), size_t(p), st);
+            d_cons_nvis.download(&n_dev_cons_visits_final, 1, st);
+        }
         if (nv > 0) {
             d_beta.download(screen_beta.data(), size_t(nv), st);
             screen_X_means.resize(nv);
@@ -517,6 +530,45 @@
                 d_chi_g.upload(cons_hi.data(), size_t(G), st);
                 d_mu_g.upload(cons_mu.data(), size_t(G), st);
                 d_clo.reserve(p); d_chi.reserve(p); d_cmu.reserve(p);
+                // box / one-sided objects on several coefficients: on the device when their description came along (ABI 7)
+                if (cons_host && a->constraint_native && a->constraint_va && a->constraint_vb && a->constraint_cfg && !hooks.cons_host) {
+                    cons_native.assign(a->constraint_native, a->constraint_native + G);
+                    cons_cfg.assign(a->constraint_cfg, a->constraint_cfg + size_t(G) * 5);
+                    cons_dev = true; // (on_device() reads cons_native)
+                    devcons_list.clear();
+                    for (idx g = 0; g < G; ++g)
+                        if (on_device(g)) devcons_list.push_back(int32_t(g));
+                    cons_dev = !devcons_list.empty();
+                    if (cons_dev) {
+                        const T* va = static_cast<const T*>(a->constraint_va);
+                        const T* vb = static_cast<const T*>(a->constraint_vb);
+                        for (int32_t g : devcons_list)
+                            for (idx t = 0; t < group_sizes[g]; ++t) {
+                                const idx k = groups[g] + t;
+                                if (cons_native[g] == ADELIE_HIP_NATIVE_BOX) { // constraint_box.ipp:30-37
+                                    if (vb[k] < 0) throw make_core_error("upper must be >= 0.");
+                                    if (va[k] > 0) throw make_core_error("lower must be <= 0.");
+                                } else {                                       // constraint_one_sided.ipp:74-79
+                                    if (std::abs(va[k]) != 1) throw make_core_error("sgn must be a vector of +/-1.");
+                                    if (vb[k] < 0) throw make_core_error("b must be >= 0.");
+                                }
+                            }
+                        cons_vmu.assign(size_t(p), T(0));
+                        if (a->constraint_vmu) {
+                            const T* vm = static_cast<const T*>(a->constraint_vmu);
+                            for (int32_t g : devcons_list)
+                                for (idx t = 0; t < group_sizes[g]; ++t) cons_vmu[size_t(groups[g] + t)] = vm[groups[g] + t];
+                        }
+                        d_cons_va.reserve(p); d_cons_vb.reserve(p); d_cons_mu.reserve(p); d_cons_native.reserve(G);
+                        d_devcons_list.reserve(devcons_list.size()); d_cons_nvis.reserve(1);
+                        d_cons_va.upload(va, size_t(p), st);
+                        d_cons_vb.upload(vb, size_t(p), st);
+                        d_cons_mu.upload(cons_vmu.data(), size_t(p), st);
+                        d_cons_native.upload(cons_native.data(), size_t(G), st);
+                        d_devcons_list.upload(devcons_list.data(), devcons_list.size(), st);
+                        AHIP_CHECK(hipMemsetAsync(d_cons_nvis.p, 0, sizeof(int64_t), st));
+                    }
+                }
             }
         }
         // device allocations

@@ -232,6 +232,9 @@
             launch_abs_grad_cons<T>(d_grad.p, d_groups.p, d_gsizes.p, G, d_slot.p, d_beta.p, d_penalty.p, (1 - alpha) * lm, d_clo_g.p,
                                     d_chi_g.p, d_cmu.p, d_absgrad.p, d_mu_g.p, st);
             d_mu_g.download(cons_mu.data(), size_t(G), st);
+            if (cons_dev) // box / one-sided objects on several coefficients: their gradient term / solve_zero (kernels_cons.hip)
+                launch_cons_abs_grad<T>(d_devcons_list.p, int(devcons_list.size()), d_cons_native.p, d_groups.p, d_gsizes.p, d_slot.p,
+                                        d_grad.p, d_beta.p, d_penalty.p, (1 - alpha) * lm, d_cons_va.p, d_cons_vb.p, d_cons_mu.p, d_absgrad.p, st);
         } else {
             launch_abs_grad<T>(d_grad.p, d_groups.p, d_gsizes.p, G, d_slot.p, d_beta.p, d_penalty.p, (1 - alpha) * lm,
                                d_absgrad.p, st);

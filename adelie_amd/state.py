@@ -53,7 +53,7 @@ _COUNTERS = ["n_basil_iters", "n_sweeps", "n_cd_visits_screen", "n_cd_visits_act
              "n_new_screen_cols", "n_cd_passes_screen", "n_cd_passes_active", "n_gram_col_reads",
              "n_resid_col_reads", "n_panel_blocks", "n_panel_grams", "n_panel_cols", "n_irls_screen_cols",
              "n_speculated", "n_spec_rollbacks", "n_sweeps_shared", "n_update_cols", "n_device_screens",
-             "n_host_screens"]
+             "n_host_screens", "n_host_cons_visits", "n_dev_cons_visits"]
 _TIMERS = ["gram_flops", "t_sweep_ms", "t_gram_ms", "t_cd_ms", "t_axpy_ms", "n_sweep_launches", "n_gram_launches",
            "t_host_screen_ms", "t_panel_step_ms", "n_panel_step_launches", "t_host_screen_wait_ms"]
 
@@ -280,6 +280,13 @@ class base:
             for c, m in zip(cons, mu):  # the objects are left holding the multipliers of the last fit, as the reference's are
                 if c is not None and c._abi()[0] != _constraint.KIND_HOST:  # (host objects were the live objects all along)
                     c._mu[0] = m
+            vmu = backend.result_vec(r, _abi.V["constraint_vmu"])
+            if len(vmu):  # box / one-sided objects on several coefficients that the device solved: the same courtesy
+                for i, c in enumerate(cons):
+                    nat = None if c is None or c._abi()[0] != _constraint.KIND_HOST else c._native()
+                    if nat is not None and nat[1] is not None and c.primal_size <= 64:
+                        g0 = int(self.groups[i])
+                        c._mu[...] = vmu[g0:g0 + c.primal_size]
         sc = lambda nm: backend.fn("result_scalar")(r, _abi.S[nm])
         new.lmda_max = dtype(sc("lmda_max"))
         new.lmda = dtype(sc("lmda"))
@@ -385,7 +392,7 @@ class base:
             ca, cb, mu = np.zeros(G, dtype=dtype), np.zeros(G, dtype=dtype), np.zeros(G, dtype=dtype)
             ndual = np.zeros(G, dtype=np.int64)
             native = np.zeros(G, dtype=np.int32)
-            va, vb = np.zeros(p, dtype=dtype), np.zeros(p, dtype=dtype)
+            va, vb, vmu = np.zeros(p, dtype=dtype), np.zeros(p, dtype=dtype), np.zeros(p, dtype=dtype)
             cfg = np.zeros((G, 5), dtype=np.float64)
             lin = (_abi.C.c_void_p * G)()
             any_host = any_lin = False
@@ -402,6 +409,7 @@ class base:
                         native[i] = nat[0]
                         if nat[1] is not None:
                             va[g0:g0 + q], vb[g0:g0 + q] = nat[1], nat[2]
+                            vmu[g0:g0 + q] = c._mu   # (ABI 7: box / one-sided objects are solved on the device; what they hold on entry)
                         cfg[i] = nat[3]
                         if nat[0] == _constraint.NATIVE_LINEAR:  # (m, d) objects do not fit per-coefficient arrays
                             desc, arrays = c._linear_descriptor()
@@ -410,7 +418,7 @@ class base:
                             any_lin = True
                 else:
                     mu[i] = c._mu[0]
-            keep += [kind, ca, cb, mu, ndual, native, va, vb, cfg]
+            keep += [kind, ca, cb, mu, ndual, native, va, vb, cfg, vmu]
             a.constraint_kind = kind.ctypes.data
             a.constraint_a = ca.ctypes.data
             a.constraint_b = cb.ctypes.data
@@ -421,6 +429,7 @@ class base:
                 a.constraint_va = va.ctypes.data
                 a.constraint_vb = vb.ctypes.data
                 a.constraint_cfg = cfg.ctypes.data
+                a.constraint_vmu = vmu.ctypes.data
                 if any_lin:
                     keep.append(lin)
                     a.constraint_lin = _abi.C.addressof(lin)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADELIE_HIP_ABI_VERSION 6
+#define ADELIE_HIP_ABI_VERSION 7
 
 enum adelie_hip_dtype { ADELIE_HIP_F32 = 0, ADELIE_HIP_F64 = 1 };
 enum adelie_hip_order { ADELIE_HIP_COL_MAJOR = 0, ADELIE_HIP_ROW_MAJOR = 1 };
@@ -369,7 +369,7 @@ typedef struct adelie_hip_grpnet_args {
                                          constraint); NULL: one per constrained group.  Their running sum is `dual_groups`. */
     const adelie_hip_constraint_callbacks* constraint_cb; /* required when any kind is ADELIE_HIP_CONSTRAINT_HOST */
     /* What the CPU checker (oracle/) needs to run a kind-3 box / one-sided constraint with its OWN restatement of the
-     * reference's solver instead of calling back (libadelie_hip.so ignores these): constraint_native[g] = 0 (call back),
+     * reference's solver instead of calling back (ABI 7: libadelie_hip.so solves 4 / 5 on the device from them too): constraint_native[g] = 0 (call back),
      * 4 (box: constraint_va = lower, constraint_vb = upper) or 5 (one-sided: va = sgn, vb = b), per COEFFICIENT (p,) arrays of
      * value_t indexed like the design's columns, and the solver settings (max_iters, tol, pinball_max_iters, pinball_tol,
      * slack) as 5 doubles per group. */
@@ -379,6 +379,11 @@ typedef struct adelie_hip_grpnet_args {
     const double*  constraint_cfg;    /* (G, 5) row-major or NULL */
     /* ABI 5: constraint_native[g] = 6 (linear): constraint_lin[g] describes the object (NULL entries elsewhere) */
     const adelie_hip_linear_constraint* const* constraint_lin; /* (G,) or NULL */
+    /* ABI 7: kind-3 groups whose constraint_native is 4 (box) or 5 (one-sided) and that hold <= 64 coefficients are solved ON
+     * THE DEVICE from constraint_va / _vb / _cfg (kernels_cons.hip: the reference's proximal-Newton dual solver in one
+     * wavefront; no callback is made for them).  constraint_vmu: the multipliers those objects hold on entry, per COEFFICIENT
+     * (p,) value_t, or NULL for zeros; what they hold on return is the result vector ADELIE_HIP_V_CONSTRAINT_VMU. */
+    const void*    constraint_vmu;
 } adelie_hip_grpnet_args;
 
 /* Runs the whole path.  `*out` is always set on return code 0 (even when the solve recorded
@@ -432,7 +437,9 @@ enum adelie_hip_vec {
     ADELIE_HIP_V_BETAS_VALUES = 200,
     ADELIE_HIP_V_DUALS_VALUES,
     /* (G,) the multiplier each constraint object is left holding when the solve returns (0 for unconstrained groups) */
-    ADELIE_HIP_V_CONSTRAINT_MU
+    ADELIE_HIP_V_CONSTRAINT_MU,
+    /* ABI 7: (p,) per coefficient, the multipliers of the box / one-sided objects that were solved on the device (0 elsewhere) */
+    ADELIE_HIP_V_CONSTRAINT_VMU
 };
 enum adelie_hip_scalar {
     ADELIE_HIP_S_LMDA_MAX = 0, ADELIE_HIP_S_LMDA, ADELIE_HIP_S_RSQ, ADELIE_HIP_S_RESID_SUM,
@@ -456,6 +463,8 @@ enum adelie_hip_scalar {
     ADELIE_HIP_S_N_DEVICE_SCREENS,   /* screening steps (solver_base.hpp:273-403) whose decision was taken on the device
                                         (kernels_screen.hip) ... */
     ADELIE_HIP_S_N_HOST_SCREENS,     /* ... and by the host routine (first iteration, host constraint objects, G > 2^18) */
+    ADELIE_HIP_S_N_HOST_CONS_VISITS, /* ABI 7: visits of constrained groups made on the host through the callbacks ... */
+    ADELIE_HIP_S_N_DEV_CONS_VISITS,  /* ... and by the device kernel (box / one-sided objects, kernels_cons.hip) */
     /* HIP-event time (ms) of the device phases on the design's stream, summed over the solve, and launch counts */
     ADELIE_HIP_S_T_SWEEP_MS = 80, ADELIE_HIP_S_T_GRAM_MS, ADELIE_HIP_S_T_CD_MS, ADELIE_HIP_S_T_AXPY_MS,
     ADELIE_HIP_S_N_SWEEP_LAUNCHES, ADELIE_HIP_S_N_GRAM_LAUNCHES, ADELIE_HIP_S_T_HOST_SCREEN_MS,

@@ -4,6 +4,8 @@ proximal-Newton solvers: the numpy classes of the product against the CPU checke
 first principles), the oracle's constrained paths against an independent bound-constrained solve / KKT certificates built from
 the returned duals (the reference's test_solver.py does this with cvxpy, which is not in this image), user-defined constraint
 classes through the callback route, the error behaviour, and — on the GPU — the HIP path against the oracle."""
+import os
+
 import numpy as np
 import pytest
 from scipy.optimize import minimize
@@ -652,8 +654,10 @@ def test_user_constraint_with_mandatory_buffer_and_errors_next_to_a_glm_callback
 @pytest.mark.parametrize("family", ["gaussian", "binomial"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_hip_constrained_groups_match_oracle(hip, oracle, family, dtype):
-    """Groups of several coefficients with box / one-sided constraints: the HIP path (group visits on the host through the
-    callbacks, everything else on the device) against the oracle (its own C++ restatement of the constraint solvers)."""
+    """Groups of several coefficients with box / one-sided constraints: the HIP path (ABI 7: every visit of such a group is a
+    one-wavefront launch of the reference's proximal-Newton dual solver, kernels_cons.hip — no host visit, no callback) against
+    the oracle (its own C++ restatement of the constraint solvers), and against the same path with the visits forced back onto
+    the host objects (ADELIE_HIP_CONS_HOST=1: the numpy classes through the callbacks)."""
     n, p, G = 400, 120, 30
     d = make_gaussian(n, p, seed=21, sparsity=0.7, dtype=dtype)
     X = d["X"]
@@ -691,6 +695,17 @@ def test_hip_constrained_groups_match_oracle(hip, oracle, family, dtype):
         if c is not None:
             assert np.max(c.evaluate(B[-1, groups[g]:groups[g] + sizes[g]].astype(float))) < (1e-3 if f32 else 1e-5)
             assert np.abs(c._mu - last[dg[g]:dg[g] + c.duals()]).max() < (1e-6 if f32 else 1e-12)
+    # zero host visits: every constrained group of this problem is a box / one-sided object of <= 64 coefficients
+    assert st.counters["n_host_cons_visits"] == 0 and st.counters["n_dev_cons_visits"] > 0, st.counters
+    os.environ["ADELIE_HIP_CONS_HOST"] = "1"
+    try:
+        chh = make()
+        sth = _fit(ad.matrix.dense(X), mk(), chh, **kw)
+    finally:
+        del os.environ["ADELIE_HIP_CONS_HOST"]
+    assert sth.error == "" and sth.counters["n_dev_cons_visits"] == 0 and sth.counters["n_host_cons_visits"] > 0
+    assert np.abs(sth.betas.toarray() - B).max() < tol
+    assert np.abs((sth.duals - st.duals)).max() < (2e-2 if f32 else 1e-5) * dscale
 
 
 @pytest.mark.gpu

@@ -650,3 +650,5 @@ def test_hip_multi_constraints_match_oracle(hip, oracle, family):
     assert a.duals.shape == b.duals.shape and b.duals.nnz > 0
     scale = max(1.0, float(np.abs(b.duals).max()))
     assert np.abs((a.duals - b.duals)).max() < 1e-4 * scale
+    # the box / one-sided objects of the view's groups are visited on the device (kernels_cons.hip); `linear` ones on the host
+    assert a.counters["n_dev_cons_visits"] > 0, a.counters

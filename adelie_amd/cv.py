@@ -15,7 +15,7 @@ import numpy as np
 import scipy.sparse
 
 from . import matrix
-from .diagnostic import coefficient, predict
+from .diagnostic import coefficient, coefficients, predict
 from .solver import grpnet
 
 logger = logging.getLogger("adelie_amd")
@@ -99,9 +99,13 @@ def _fold_loss(X, glm, fold_idx, full_lmdas, *, n_threads, early_exit, min_ratio
 
     weights_sum_val = np.sum(glm.weights[fold_idx])
     betas, intercepts, lmdas = state.betas, state.intercepts, state.lmdas
-    beta_ints = [coefficient(lmda=lmda, betas=betas, intercepts=intercepts, lmdas=lmdas) for lmda in full_lmdas]
-    full_betas = scipy.sparse.vstack([x[0] for x in beta_ints]).tocsr()
-    full_intercepts = np.array([x[1] for x in beta_ints])
+    if len(lmdas) >= 2 and np.asarray(intercepts).ndim == 1:
+        # every full-data lambda at once (diagnostic.coefficients: the numbers of one coefficient() call per lambda)
+        full_betas, full_intercepts = coefficients(lmdas_new=full_lmdas, betas=betas, intercepts=intercepts, lmdas=lmdas)
+    else:
+        beta_ints = [coefficient(lmda=lmda, betas=betas, intercepts=intercepts, lmdas=lmdas) for lmda in full_lmdas]
+        full_betas = scipy.sparse.vstack([x[0] for x in beta_ints]).tocsr()
+        full_intercepts = np.array([x[1] for x in beta_ints])
     if (hasattr(X, "glm_path_losses") and X._backend.has("design_glm_path_losses") and hasattr(glm, "core_kind")
             and not getattr(glm, "is_multi", False)):
         # predictions and both losses per lambda on the device; only 2 L scalars come back

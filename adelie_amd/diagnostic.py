@@ -74,6 +74,36 @@ def coefficient(*, lmda: float, betas: csr_matrix, intercepts: np.ndarray, lmdas
     return beta, intercept
 
 
+def coefficients(*, lmdas_new, betas: csr_matrix, intercepts: np.ndarray, lmdas: np.ndarray):
+    """``coefficient`` for a whole vector of ``lmdas_new`` at once: ``(len(lmdas_new), p)`` CSR and the intercepts.  The same
+    numbers as one call per value (``t * above + (1 - t) * below`` with the reference's ``t``, the boundary solution outside the
+    saved range) through ONE sparse product with the (queries, L) interpolation matrix — ``cv_grpnet`` evaluates every fold at
+    the full-data grid, and 100 calls of ``coefficient`` per fold, serialised by the interpreter lock across the folds in
+    flight, were a fifth of an 8-fold CV's wall time."""
+    lmdas = np.asarray(lmdas)
+    q = np.atleast_1d(np.asarray(lmdas_new, dtype=lmdas.dtype))
+    L = lmdas.shape[0]
+    if L < 2:
+        raise RuntimeError("coefficients() needs a path of at least two saved lambdas.")
+    # lmdas is decreasing: the number of saved lambdas >= query is the index of the first solution below it
+    below = L - np.searchsorted(lmdas[::-1], q, side="left")
+    outside = (below == 0) | (below == L)
+    if np.any(outside):
+        logger.warning("lmda is not within the range of the saved lambdas. Returning boundary solution.")
+    lo = np.clip(below, 1, L - 1)
+    up = lo - 1
+    t = (q - lmdas[lo]) / (lmdas[up] - lmdas[lo])
+    edge = np.minimum(below, L - 1)
+    t = np.where(outside, 1.0, t)
+    up = np.where(outside, edge, up)
+    lo = np.where(outside, edge, lo)
+    one_minus = np.where(outside, 0.0, 1 - t)
+    rows = np.arange(len(q))
+    W = csr_matrix((np.concatenate([t, one_minus]), (np.concatenate([rows, rows]), np.concatenate([up, lo]))), shape=(len(q), L))
+    ic = np.asarray(intercepts)
+    return (W @ betas).tocsr(), t * ic[up] + one_minus * ic[lo]
+
+
 def objective(X, glm, betas, intercepts, lmdas, *, groups=None, alpha: float = 1, penalty=None, offsets=None,
               relative: bool = True, add_penalty: bool = True, n_threads: int = 1):
     """Group elastic net objective ``loss(eta) - loss_full + lmda * sum_g w_g (alpha|b_g| + (1-alpha)/2 |b_g|^2)``

@@ -486,6 +486,9 @@ def main():
         line3, _ = measure(ctx, 3, n=n, p=p, gs=10, alpha=0.5, dtype="f64", L=L, steps=2, warmup=1,
                            data={k: keep[k] for k in ("X", "y", "Xd")})
         out["cfg3"] = leg(line3)
+        # box / one-sided constraint objects on 200 of config 3's 1000 groups: every visit of such a group is a device launch
+        # (kernels_cons.hip); the same path with the visits on the host objects beside it (constraints)
+        out["constrained_groups"] = constrained_leg(keep["Xd"], keep["y"], n, p)
         del keep, line3
         import gc
         gc.collect()
@@ -593,6 +596,47 @@ def sparse_leg(L, n=1_000_000, p=100_000, density=1e-3, cpu_budget_s=0.0):
                                "launches": int(nl), "avg_launch_ms": ms / nl, "algorithmic_bytes_per_launch": sweep_bytes}
         if cpu_budget_s > 0:
             out["cpu_baseline"] = sparse_cpu_baseline(M, y, st, cpu_budget_s)
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
+
+
+def constrained_leg(Xd, y, n, p, gs=10, ncons=200, L=50):
+    """Config 3's design and grouping with constraint objects on `ncons` groups (half boxes, half non-negativity), `L` lambdas:
+    device visits against host visits (ADELIE_HIP_CONS_HOST=1), same iterates."""
+    import adelie_amd as ad
+
+    try:
+        G = p // gs
+        groups = np.arange(0, p, gs)
+        which = np.sort(np.random.default_rng(3).choice(G, ncons, replace=False))
+
+        def make():
+            cons = [None] * G
+            for k, g in enumerate(which):
+                cons[g] = (ad.constraint.box(np.full(gs, -0.02), np.full(gs, 0.05)) if k % 2 == 0 else ad.constraint.lower(np.zeros(gs)))
+            return cons
+
+        kw = dict(groups=groups, alpha=0.5, early_exit=False, lmda_path_size=L, progress_bar=False)
+        out = {"workload": f"Gaussian group elastic net {n}x{p} f64, groups of {gs}, alpha 0.5, {L} lambdas, {ncons} of {G} groups "
+                           f"carry a box / one-sided constraint object (ConstraintBox / ConstraintOneSided, proximal Newton)"}
+        B = {}
+        for arm, env in (("device_visits", None), ("host_visits", "1")):
+            if env:
+                os.environ["ADELIE_HIP_CONS_HOST"] = env
+            try:
+                ad.grpnet(Xd, ad.glm.gaussian(y), constraints=make(), **dict(kw, lmda_path_size=5, min_ratio=0.5))
+                t0 = time.perf_counter()
+                st = ad.grpnet(Xd, ad.glm.gaussian(y), constraints=make(), **kw)
+                el = time.perf_counter() - t0
+            finally:
+                os.environ.pop("ADELIE_HIP_CONS_HOST", None)
+            B[arm] = st.betas
+            out[arm] = {"value": 1.0 / el, "unit": "paths/s", "ms_per_step": el * 1e3, "lambdas": len(st.lmdas), "error": st.error,
+                        "n_dev_cons_visits": int(st.counters["n_dev_cons_visits"]),
+                        "n_host_cons_visits": int(st.counters["n_host_cons_visits"]), "final_active": int(st.active_set_size),
+                        "duals_nnz_last": int(st.duals[-1].nnz)}
+        out["max_abs_dbeta_device_vs_host_visits"] = float(np.abs(B["device_visits"] - B["host_visits"]).max())
         return out
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)}

@@ -166,3 +166,26 @@ def test_diagnostic_binomial_and_multigaussian():
     B = state.betas.toarray().reshape(L, p, K)
     act = np.any(B[-1] != 0, axis=1)
     assert act.any() and np.allclose(sc[-1, act], lm[-1], rtol=1e-6)
+
+
+def test_coefficients_equals_one_coefficient_call_per_lambda():
+    """``diagnostic.coefficients`` (what cv_grpnet evaluates every fold with) is ``diagnostic.coefficient`` (reference
+    ``diagnostic.py:577-646``) for every query at once: interior points, saved lambdas themselves, both boundary solutions."""
+    import logging
+    import scipy.sparse as sp
+    from adelie_amd.diagnostic import coefficient, coefficients
+
+    rng = np.random.default_rng(0)
+    L, p = 40, 200
+    lm = np.sort(rng.uniform(0.1, 2, L))[::-1]
+    B = sp.random(L, p, 0.2, format="csr", random_state=1)
+    ic = rng.standard_normal(L)
+    q = np.concatenate([lm[[0, 5, L - 1]], rng.uniform(0.05, 2.2, 60), [lm[3] * (1 - 1e-16)]])
+    logging.getLogger("adelie_amd").setLevel(logging.ERROR)
+    Bq, iq = coefficients(lmdas_new=q, betas=B, intercepts=ic, lmdas=lm)
+    assert Bq.shape == (len(q), p)
+    for k, l in enumerate(q):
+        b, i0 = coefficient(lmda=l, betas=B, intercepts=ic, lmdas=lm)
+        assert np.array_equal(b.toarray(), Bq[k].toarray()) and i0 == iq[k]
+    with pytest.raises(RuntimeError):
+        coefficients(lmdas_new=q, betas=B[:1], intercepts=ic[:1], lmdas=lm[:1])

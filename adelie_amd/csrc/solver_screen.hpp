@@ -834,7 +834,7 @@
                     if (abs_grad[i] > lmda_next * penalty[i] * alpha) screen_set.push_back(i);
                 }
             }
-            // Progress guard (deliberate deviation, DESIGN.md section 4): the KKT check multiplies in the order
+            // Progress guard (deliberate deviation, DESIGN.md section 7): the KKT check multiplies in the order
             // lmda * alpha * penalty (solver_base.hpp:428) and the fallback above in the order lmda * penalty * alpha
             // (:369), which can round differently; a gradient that falls between the two fails KKT forever without ever
             // being screened (seen in f32 at lambda_0 == lmda_max with alpha < 1).  Screen it with KKT's own expression.

@@ -320,7 +320,7 @@ def grpnet(
         # lasso on Z itself with the penalty factors times |s|: beta~ = s beta, and the intercept absorbs the centres.  Every
         # coordinate update, the convergence measure A_jj d_j^2, the screening scores |g_j| / penalty_j and the KKT test are
         # the same numbers in both coordinate systems (eta is the same vector), so the solver runs its panel engines on the raw
-        # columns -- the view itself only has the full-Gram engines -- and the state comes back in the
+        # columns -- the view itself only has the full-Gram engines (ROUNDS.md 9.9) -- and the state comes back in the
         # standardized coordinates.
         base, sc, ce = raw
         pen = np.ones(p, dtype=dtype) if penalty is None else np.asarray(penalty, dtype=dtype)

@@ -26,7 +26,7 @@ Multi-GPU (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus 
     ``"cfg4"`` — the same measurement as ``--config 3 / 4`` with fewer steps, each with its own roofline objects — unless
     ``--no-extra-legs`` is given (profiling runs); at N = 1 also ``"standardized_snp_view"`` (a Gaussian path on config 4's
     2-bit design under the lazy standardized view: 6.25 GB resident instead of a 200 GB copy) and ``"sparse_resident"`` (a
-    1M x 100k sparse design with 1e8 stored entries kept sparse: 745 GiB as dense f64), DESIGN.md 9.9, and
+    1M x 100k sparse design with 1e8 stored entries kept sparse: 745 GiB as dense f64), ROUNDS.md 9.9, and
   * ``"cv_config5"``: the same sharded CV timed right after the headline
     steps, so that a ``--gpus 1/2/4/8`` series holds BASELINE.json's second target (8-fold CV at 1/2/4/8 GPUs) as well.
 """
@@ -502,7 +502,7 @@ def main():
         line4, k4 = measure(ctx, 4, n=500_000, p=50_000, gs=1, alpha=1.0, dtype="f64", L=L, steps=1, warmup=1)
         out["cfg4"] = leg(line4)
         # two designs whose dense f64 form does not fit (or barely fits) in HBM, as further objects of the default line
-        # (DESIGN.md 9.9): config 4's 2-bit design under the lazy standardized view, and a sparse design kept sparse
+        # (ROUNDS.md 9.9): config 4's 2-bit design under the lazy standardized view, and a sparse design kept sparse
         out["standardized_snp_view"] = lazy_views_leg(ad_design=k4["Xd"], L=L, y_binomial=k4["y"])
         del k4, line4
         gc.collect()

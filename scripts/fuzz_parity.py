@@ -82,7 +82,7 @@ for case in range(N):
             ok, msg = True, f"blocks {a.counters['n_panel_blocks']} upd {a.counters['n_updates']}"
     except AssertionError as e:
         # same solutions but a different screen / active set: a near-tie in the pivot rule or in the stopping rule flipped
-        # (DESIGN.md section 4); counted separately, not as a failure
+        # (DESIGN.md section 7); counted separately, not as a failure
         try:
             db = float(np.abs(a.betas.toarray() - b.betas.toarray()).max()) if len(a.lmdas) == len(b.lmdas) else np.inf
         except Exception:

@@ -1,5 +1,7 @@
 """Randomised parity sweep of constrained paths: HIP against the CPU oracle on random shapes, families, group layouts and
-mixes of box / lower / upper / one-sided constraints on the groups of one coefficient (FUZZ_N cases, default 40)."""
+mixes of box / lower / upper / one-sided constraints on the groups of one coefficient (FUZZ_N cases, default 40).
+FUZZ_GROUPS=1: also objects on the groups of several coefficients (solved on the device by kernels_cons.hip), with bounds that
+are zero, tiny, large or absent per coefficient; the run then also checks that no such group was visited on the host."""
 import os
 import sys
 
@@ -48,6 +50,13 @@ for case in (ONLY if ONLY is not None else range(N)):
         out = []
         for q in sizes:
             k = r2.randint(0, 6) if q == 1 else 0
+            if q > 1 and os.environ.get("FUZZ_GROUPS") and r2.uniform() < 0.6:
+                bnd = lambda: r2.choice([0.0, 0.02, 0.3, 1e100], size=q, p=[0.25, 0.3, 0.3, 0.15]).astype(dtype)  # noqa: E731
+                if r2.uniform() < 0.5:
+                    out.append(constraint.box(-bnd(), bnd()))
+                else:
+                    out.append(constraint.one_sided(r2.choice([-1.0, 1.0], size=q).astype(dtype), bnd()))
+                continue
             if k <= 1:
                 out.append(None)
             elif k == 2:
@@ -74,8 +83,11 @@ for case in (ONLY if ONLY is not None else range(N)):
         db = np.abs(st.betas.toarray() - ref.betas.toarray()).max() if len(st.lmdas) == len(ref.lmdas) else np.inf
         dd = np.abs((st.duals - ref.duals)).max() if st.duals.shape == ref.duals.shape and st.duals.shape[1] else 0.0
         ok = st.error == ref.error and db < lim and dd < 10 * lim
+        if os.environ.get("FUZZ_GROUPS"):
+            ok = ok and st.counters["n_host_cons_visits"] == 0
         print(f"{'ok  ' if ok else 'FAIL'} case {case}: n={n} p={p} {fam} {np.dtype(dtype).name} grouped={grouped} G={len(groups)} "
-              f"ncons={sum(c is not None for c in make())} | max|dbeta| {db:.2e} max|ddual| {dd:.2e} err '{st.error[:40]}'")
+              f"ncons={sum(c is not None for c in make())} dev_visits={st.counters['n_dev_cons_visits']} | max|dbeta| {db:.2e} max|ddual| {dd:.2e} "
+              f"err '{st.error[:40]}' / '{ref.error[:40]}'")
         bad += not ok
     except Exception as e:  # noqa: BLE001
         print(f"FAIL case {case}: exception {type(e).__name__}: {e}")

@@ -796,6 +796,53 @@
         }
     }
 
+    // The same for the objects that run on the device, on the HOST mirrors (state construction only: abs_grad of the state that
+    // was handed in decides lmda_max and the first screening step; afterwards cons_abs_grad_kernel does this on the device).
+    // Leaves the multipliers solve_zero gives the groups outside the screen set, as the reference's objects would hold them.
+    void dev_cons_abs_grad_host(T lm) {
+        if (!cons_dev) return;
+        const double M = 1e100;
+        std::vector<idx> begin_of(static_cast<size_t>(G), idx(-1));
+        for (size_t ss = 0; ss < screen_set.size() && ss < screen_begins.size(); ++ss) begin_of[size_t(screen_set[ss])] = screen_begins[ss];
+        std::vector<T> va(static_cast<size_t>(p), T(0)), vb(static_cast<size_t>(p), T(0));
+        d_cons_va.download(va.data(), size_t(p), st);
+        d_cons_vb.download(vb.data(), size_t(p), st);
+        sync();
+        for (int32_t g : devcons_list) {
+            const idx q = group_sizes[g], k = groups[g];
+            const bool box = cons_native[g] == ADELIE_HIP_NATIVE_BOX;
+            double acc = 0;
+            if (begin_of[size_t(g)] >= 0) {
+                const idx b = begin_of[size_t(g)];
+                const double regul = double((1 - alpha) * lm) * double(penalty[g]);
+                for (idx t = 0; t < q; ++t) {
+                    const double cg = box ? double(cons_vmu[size_t(k + t)]) : double(va[size_t(k + t)]) * double(cons_vmu[size_t(k + t)]);
+                    const double e = double(grad[size_t(k + t)]) - regul * double(screen_beta[size_t(b + t)]) - cg;
+                    acc += e * e;
+                }
+            } else {
+                for (idx t = 0; t < q; ++t) {
+                    const double v = double(grad[size_t(k + t)]);
+                    double m, e;
+                    if (box) {
+                        const double lo = -std::max(double(va[size_t(k + t)]), -M), up = std::min(double(vb[size_t(k + t)]), M);
+                        m = std::min(std::max(v, (lo <= 0) ? -M : 0.0), (up <= 0) ? M : 0.0);
+                        e = v - m;
+                    } else {
+                        const double sg = double(va[size_t(k + t)]), bb = std::min(double(vb[size_t(k + t)]), M);
+                        m = std::min(std::max(sg * v, 0.0), (bb <= 0) ? M : 0.0);
+                        e = v - sg * m;
+                    }
+                    cons_vmu[size_t(k + t)] = T(m);
+                    acc += e * e;
+                }
+            }
+            abs_grad[size_t(g)] = T(std::sqrt(acc));
+        }
+        d_cons_mu.upload(cons_vmu.data(), size_t(p), st);
+        sync();
+    }
+
     void run_group_panel_passes(const CdParams<T>& cp, CdScalars<T>& sc, T* r_dev) {
         const int SL = cd_block_size();
         panel_setup(group_maxblk());

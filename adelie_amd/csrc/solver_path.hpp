@@ -591,6 +591,7 @@
         update_screen_derived_base();
         update_abs_grad_host(lmda);
         host_cons_abs_grad(lmda);
+        dev_cons_abs_grad_host(lmda);
 
         if (cov_mode) {
             if (!a->cov_v) throw make_core_error("v must be (p,) where A is (p, p).");

@@ -221,10 +221,16 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
     {   // D~: columns [0, nval)
         const T* src = p.Dptr;
         const int NE = nval * GBLK;
+        // Only entries BELOW the diagonal are ever read (the loop updates the gradient of the groups still to come: rows past
+        // the visited group's columns): the prologue is bound by what one CU pulls while 196 others stream (D~ and the cross
+        // block, 256 KB at ~60 GB/s), so the upper triangle is not fetched
         for (int e0 = tid; e0 < NE; e0 += nt * 16) {
             T v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = src[min(e0 + u * nt, NE - 1)];
+            for (int u = 0; u < 16; ++u) {
+                const int e = min(e0 + u * nt, NE - 1);
+                v[u] = ((e & (GBLK - 1)) > (e / GBLK)) ? src[e] : T(0);
+            }
 #pragma unroll
             for (int u = 0; u < 16; ++u)
                 if (e0 + u * nt < NE) D[e0 + u * nt] = v[u];

@@ -36,6 +36,7 @@ struct Hooks {
     int lookahead = -1, speculate = -1;
     double irls_reuse = -1;
     bool time_panel = false;
+    int group_next_corr = -1; // ADELIE_HIP_GROUP_NEXT_CORR=0: every group solve forms its own look-ahead correction (A/B)
     bool cons_host = false; // ADELIE_HIP_CONS_HOST=1: box / one-sided objects on several coefficients visited on the host (A/B, tests)
     int trace = 0;
     static Hooks from_env() {
@@ -50,6 +51,7 @@ struct Hooks {
         if (const char* e = std::getenv("ADELIE_HIP_IRLS_REUSE")) h.irls_reuse = std::max(0.0, std::atof(e));
         h.time_panel = std::getenv("ADELIE_HIP_TIME_PANEL") != nullptr;
         if (const char* e = std::getenv("ADELIE_HIP_CONS_HOST")) h.cons_host = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_GROUP_NEXT_CORR")) h.group_next_corr = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_TRACE")) h.trace = std::max(1, std::atoi(e));
         return h;
     }

@@ -188,7 +188,9 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int32_t* dsc = p.desc + size_t(j) * GDESC_STRIDE;
     const int ngrp = dsc[GDESC_NG], nval = dsc[GDESC_NVAL];
-    const bool has_corr = p.Cprev != nullptr;
+    const bool wide0 = nt == 1024;
+    const bool has_cin = wide0 && p.corr_in != nullptr;  // the previous solve left the look-ahead correction (CdGrpBlkParams::Cnext)
+    const bool has_corr = p.Cprev != nullptr && !has_cin;
     const int pnv = has_corr ? dsc[GDESC_NVAL - GDESC_STRIDE] : 0; // values of the previous block = columns of Cprev
     // (1) layout descriptor, the gradient handed over (or nothing: has_part), the previous block's dense changes; the rotated
     //     block and - fused launch, 1024 threads - the whole cross block, 16 values per thread, stream in meanwhile
@@ -202,6 +204,7 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
         vof = dsc[GDESC_VOFF + tid]; vps = dsc[GDESC_VPOS + tid]; vq = dsc[GDESC_VQ + tid];
         if (!has_part) gb = p.gblk[tid];
         if (has_corr) dlv = p.pdd[tid];
+        if (has_cin) dlv = p.corr_in[tid]; // (the correction itself; dl is not used on this route)
     }
     const T prs = (has_part && p.part_rsum) ? p.part_rsum[0] : T(0);
     // fused launch (1024 threads): the whole cross block, 16 values per thread (row tid % 128, columns 16 * part + u, part =
@@ -312,10 +315,11 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
         if (tid < ngrp) { gpenB[tid] = penv; gactB[tid] = actv; chg[tid] = 0; }
     }
     __syncthreads(); // corr parts, b0B / xmO
-    if (tid < nval && (has_corr || has_part)) {
+    if (tid < nval && (has_corr || has_part || has_cin)) {
         T cs = T(0);
         if (has_corr)
             for (int q = 0; q < nparts; ++q) cs += corr[q * GBLK + tid]; // fixed order
+        if (has_cin) cs = dlv;
         gO[tid] = (has_part ? gO[tid] - prs * xmO[tid] : gO[tid]) - cs;
     }
     __syncthreads();
@@ -364,7 +368,43 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
         gsq[tid] = thr * thr;                     // ||delta||^2 against the squared threshold of pin_naive:144
     }
     __syncthreads();
-    if (wv != 0) return;
+    // correction of the NEXT block by the idle waves (CdGrpBlkParams::Cnext): partition and order of blk.. the prologue's own
+    // form above — thread (part = tid / 128, row = tid % 128) owns columns 16 part .. 16 part + 15; wavefront 1 also takes the
+    // rows of wavefront 0, which is busy visiting
+    const bool mk_next = wide0 && p.Cnext != nullptr;
+    T* dnx = corr + 8 * GBLK;    // this block's dense changes (written by the visiting wave's epilogue)
+    if (wv != 0) {
+        if (!mk_next) return;
+        const int row = tid & (GBLK - 1), part = __builtin_amdgcn_readfirstlane(tid >> 7);
+        T cn[CW], cn0[CW];
+        const T* Cp = p.Cnext + row + size_t(part) * CW * GBLK;
+#pragma unroll
+        for (int u = 0; u < CW; ++u) cn[u] = Cp[size_t(u) * GBLK];
+        if (wv == 1) {
+#pragma unroll
+            for (int u = 0; u < CW; ++u) cn0[u] = Cp[size_t(u) * GBLK - 64];
+        }
+        __syncthreads(); // (A) the visits are over: dnx is complete, the loop's per-group constants in `corr` are dead
+        T acc = T(0), acc0 = T(0);
+#pragma unroll
+        for (int u = 0; u < CW; ++u)
+            if (part * CW + u < nval) acc = fma(cn[u], dnx[part * CW + u], acc);
+        if (wv == 1) {
+#pragma unroll
+            for (int u = 0; u < CW; ++u)
+                if (u < nval) acc0 = fma(cn0[u], dnx[u], acc0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        corr[part * GBLK + row] = acc;
+        if (wv == 1) corr[row - 64] = acc0;
+        __syncthreads(); // (B)
+        if (tid < GBLK) {
+            T cs = T(0);
+            for (int q = 0; q < 8; ++q) cs += corr[q * GBLK + tid]; // fixed order, as the prologue's
+            p.corr_out[tid] = cs;
+        }
+        return;
+    }
     __builtin_amdgcn_s_setprio(3);
 #ifdef AHIP_GRP_PROFILE
     // cycle profile of the wave (scripts/grp_profile.py): 0 prologue (kernel entry to here), 1 operand loads + norm, 2 Newton,
@@ -655,6 +695,7 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
         }
         if (ch) p.beta[vmap[i]] = bnew;
         if (p.dd) p.dd[i] = bnew - b0; // dense form for the next block's look-ahead correction (0 beyond the block)
+        if (mk_next) dnx[i] = bnew - b0;
         const unsigned long long m = __ballot(ch);
         const int pos = nz + __popcll(m & ((1ull << lane) - 1ull));
         if (ch) {
@@ -689,6 +730,13 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             __threadfence_system();
             __hip_atomic_store(p.host_seq, p.report_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+    }
+    if (mk_next) { // the visiting wave's side of the two barriers above; its rows are summed by wavefront 1, stored here
+        __syncthreads(); // (A)
+        __syncthreads(); // (B)
+        T cs = T(0);
+        for (int q = 0; q < 8; ++q) cs += corr[q * GBLK + lane];
+        p.corr_out[lane] = cs;
     }
 }
 

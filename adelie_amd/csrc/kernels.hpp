@@ -433,6 +433,13 @@ struct CdGrpBlkParams {
     const T* clo;
     const T* chi;
     T* cmu;
+    // Fused look-ahead launch, rot != 0: the look-ahead correction of the NEXT block is formed by THIS solve's otherwise idle
+    // waves — they fetch the cross block Cnext = C_{j+1,j} while the visiting wave runs, multiply it with this block's dense
+    // changes when those exist and leave the 128 sums in corr_out; the next solve then reads corr_in (1 KB) instead of pulling
+    // 128 KB of cross block through its own CU at the head of its prologue.  Same products, same order of summation.
+    const T* Cnext;   // nullptr: the next solve forms the correction itself from Cprev / pdd
+    T* corr_out;
+    const T* corr_in; // nullptr: as before
 };
 // layout descriptor of one block (int32 words)
 constexpr int GDESC_VMAP = 0;    // [128] screen-value index of block value i

@@ -521,6 +521,8 @@
     struct PassTables { int64_t count = -1; int nblk = 0; };
     PassTables ptab_scr, ptab_act;
     DevBuf<int32_t> d_blk_g0_act, d_gdesc_act;
+    DevBuf<T> d_la_corr;                      // look-ahead corrections left by the previous solve (CdGrpBlkParams::corr_out), by block parity
+    bool group_next_corr = true;              // A/B: ADELIE_HIP_GROUP_NEXT_CORR=0
     bool pass_tables_cached = true;           // A/B hook ADELIE_HIP_PASS_TABLES=0
     std::vector<int32_t> part_host;
     int build_partition(const idx* list, idx count) { // returns nblk; fills part_host with nblk+1 list positions
@@ -1024,11 +1026,21 @@
             pass_e0_valid = false;
             if (screen_pass) join_uv(); // the new screen groups' blocks / variances / eigenbases (update_vars_panel_groups)
             int prev_ld = 0; // partials of block j left behind by the previous fused launch (fr_grp), see run_panel_passes
+            // the correction of block j + 1 formed by the idle waves of solve j (CdGrpBlkParams::Cnext): fused launches of the
+            // rotated single-response form
+            const bool next_corr = group_next_corr && bp.rot && !multi();
+            if (next_corr) d_la_corr.reserve(size_t(2) * SL);
+            bool prev_made_corr = false;
             for (int j = 0; j < nblk; ++j) {
                 const int slot = j & 1, pslot = slot ^ 1;
                 bp.gblk = d_la_g.p + size_t(slot) * SL;
                 bp.Dptr = pool + size_t(j) * SL * SL;
                 bp.Cprev = j > 0 ? xpool + size_t(j) * SL * SL : nullptr;
+                bp.corr_in = (prev_made_corr && j > 0) ? d_la_corr.p + size_t(pslot) * SL : nullptr;
+                const bool fused_j = !(j == 0 && !fr_open);
+                bp.Cnext = (next_corr && fused_j && j + 1 < nblk) ? xpool + size_t(j + 1) * SL * SL : nullptr;
+                bp.corr_out = d_la_corr.p ? d_la_corr.p + size_t(slot) * SL : nullptr;
+                prev_made_corr = bp.Cnext != nullptr;
                 bp.pdlt = d_la_dlt.p + size_t(pslot) * SL;
                 bp.ppos = d_la_dpos.p + size_t(pslot) * SL;
                 bp.pnz = d_la_nz.p + pslot;
@@ -1056,6 +1068,10 @@
                 }
                 if (blk_ev[size_t(j)]) AHIP_CHECK(hipStreamWaitEvent(st, blk_ev[size_t(j)], 0));
                 if (x_ev[size_t(j)]) AHIP_CHECK(hipStreamWaitEvent(st, x_ev[size_t(j)], 0));
+                if (bp.Cnext) { // the next cross block is read by THIS launch: whatever builds or extends it (strips record into either list)
+                    if (x_ev[size_t(j) + 1]) AHIP_CHECK(hipStreamWaitEvent(st, x_ev[size_t(j) + 1], 0));
+                    if (blk_ev[size_t(j) + 1]) AHIP_CHECK(hipStreamWaitEvent(st, blk_ev[size_t(j) + 1], 0));
+                }
                 if (j == 0 && !fr_open) {
                     launch_cd_group_panel_solve<T>(bp, 0, st);
                     continue;

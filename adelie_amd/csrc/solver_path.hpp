@@ -414,6 +414,7 @@
         // few builds of a Gaussian path only add contention for the look-ahead launches: 3.13 vs 3.08 paths/s)
         n_side = is_glm() ? 2 : 1;
         if (hooks.lookahead >= 0) lookahead = hooks.lookahead != 0;
+        if (hooks.group_next_corr >= 0) group_next_corr = hooks.group_next_corr != 0;
         fuse_reduce = !multi() && fused_partials() <= 200;
         if (hooks.speculate >= 0) spec_enabled = hooks.speculate != 0;
         if (hooks.irls_reuse >= 0) irls_reuse = hooks.irls_reuse;

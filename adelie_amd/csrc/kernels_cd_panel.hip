@@ -249,7 +249,7 @@ __device__ __forceinline__ void fused_step_part(char* smem_raw, const Acc& X, in
                                                 T* __restrict__ r, const int32_t* __restrict__ dcol,
                                                 const T* __restrict__ dlt, const int32_t* __restrict__ nz_dev,
                                                 const int32_t* __restrict__ cols, int nb, T* __restrict__ part,
-                                                int64_t part_ld, int reps, bool coh = false) {
+                                                int64_t part_ld, int fsa, bool coh = false) {
     constexpr int RS = 64 * VEC;
     const int sub = threadIdx.x >> 8, tid = threadIdx.x & 255;
     T* base = reinterpret_cast<T*>(smem_raw) + size_t(sub) * 5 * RS;
@@ -257,40 +257,51 @@ __device__ __forceinline__ void fused_step_part(char* smem_raw, const Acc& X, in
     T* wrs = base + 4 * RS;
     const int nz = nz_dev[0];
     static_assert(RS >= PB || VEC == 1, "a slice's LDS row holds the block's column partials");
-    // `reps` > 1 (hook ADELIE_HIP_STEP_REPS): a workgroup takes `reps` consecutive groups of four slices one after the other,
-    // so that the launch occupies 1 / reps of the CUs it would otherwise claim whole
-    for (int rep = 0; rep < reps; ++rep) {
-        const int64_t grp = (int64_t(blockIdx.x) - 1) * reps + rep; // group of FS slices
-        if (grp >= ((n + RS - 1) / RS + FS - 1) / FS) break;      // (uniform for the workgroup)
-        const int64_t slice = grp * FS + sub;
-        if (rep > 0) __syncthreads();
-        // all four slices of a workgroup take the same path (same number of barriers); slices past the end of the rows do
-        // nothing through the ragged path's predication
-        if constexpr (RS >= PB) {
-            if ((grp + 1) * FS * RS <= n)
-                panel_step_body<T, Acc, VEC, true, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
-            else
-                panel_step_body<T, Acc, VEC, false, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
-            if (nb <= 0) continue; // uniform: the step bodies returned before phase (B) as well
+    // `fsa` (1, 2 or 4) of the workgroup's four 256-thread parts carry a row slice each; the others only keep the barriers.
+    // The launch wants about one workgroup per CU: with 256-row slices (single precision, 2-bit designs of moderate n) or few
+    // rows, four slices per workgroup would leave half of the chip or more without work (fused_fsa).
+    const int64_t grp = int64_t(blockIdx.x) - 1;
+    const int64_t slice = grp * fsa + sub;
+    if constexpr (RS >= PB) {
+        if (sub >= fsa) { // idle part: the barriers of panel_step_body, zeros where the workgroup's sum reads
+            if (nz > 0) __syncthreads();
+            if (nb <= 0) return;
             __syncthreads();
-            // one partial per column for the whole workgroup: the four slices in a fixed order
-            if (threadIdx.x < nb) {
-                const T* b0 = reinterpret_cast<const T*>(smem_raw);
-                const int c = threadIdx.x;
-                // part_ld == 0: slice-major layout part[k * PB + c] (coalesced here and in the solve that sums the partials itself)
-                const T tot = (b0[c] + b0[size_t(5) * RS + c]) + (b0[size_t(10) * RS + c] + b0[size_t(15) * RS + c]);
-                T* dst = part + (part_ld > 0 ? int64_t(c) * part_ld + grp : grp * PB + c);
-                // coh: device-coherent store (written through: another workgroup of this launch reads it, see the tail reduce)
-                if (coh) __hip_atomic_store(dst, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else *dst = tot;
-            }
+            if (tid < PB) red[0][tid] = T(0);
+        } else if ((grp + 1) * fsa * RS <= n) {
+            panel_step_body<T, Acc, VEC, true, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
         } else {
-            if ((grp + 1) * FS * RS <= n)
-                panel_step_body<T, Acc, VEC, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
-            else
-                panel_step_body<T, Acc, VEC, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
+            panel_step_body<T, Acc, VEC, false, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice);
         }
+        if (nb <= 0) return; // uniform: the step bodies returned before phase (B) as well
+        __syncthreads();
+        // one partial per column for the whole workgroup: the four parts in a fixed order
+        if (threadIdx.x < nb) {
+            const T* b0 = reinterpret_cast<const T*>(smem_raw);
+            const int c = threadIdx.x;
+            // part_ld == 0: slice-major layout part[k * PB + c] (coalesced here and in the solve that sums the partials itself)
+            const T tot = (b0[c] + b0[size_t(5) * RS + c]) + (b0[size_t(10) * RS + c] + b0[size_t(15) * RS + c]);
+            T* dst = part + (part_ld > 0 ? int64_t(c) * part_ld + grp : grp * PB + c);
+            // coh: device-coherent store (written through: another workgroup of this launch reads it, see the tail reduce)
+            if (coh) __hip_atomic_store(dst, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *dst = tot;
+        }
+    } else {
+        const int64_t slice4 = grp * FS + sub; // (unaligned designs, one row per lane: always four slices, one partial per slice)
+        if ((grp + 1) * FS * RS <= n)
+            panel_step_body<T, Acc, VEC, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice4);
+        else
+            panel_step_body<T, Acc, VEC, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, tid, slice4);
     }
+}
+
+// active parts per fused workgroup: the largest of 4, 2, 1 that still gives the launch at most ~250 workgroups ... and the
+// smallest that does not exceed them (one round of whole-CU workgroups); beyond 4 x 250 slices: 4
+inline int fused_fsa(int64_t ns) {
+    if ((ns + 3) / 4 > 250) return 4;
+    if (ns <= 250) return 1;
+    if ((ns + 1) / 2 <= 250) return 2;
+    return 4;
 }
 
 template <class T, class Acc, int VEC>
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(256 * FS) void panel_fused_kernel(CdBlkParams<T> sp
                                                               const int32_t* __restrict__ dcol, const T* __restrict__ dlt,
                                                               const int32_t* __restrict__ nz_dev,
                                                               const int32_t* __restrict__ cols, int nb,
-                                                              T* __restrict__ part, int64_t part_ld, int reps) {
+                                                              T* __restrict__ part, int64_t part_ld, int fsa) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int RS = 64 * VEC;
     if (blockIdx.x == 0) { // the solve of block j: all 1024 threads fetch, one wavefront visits (blk_solve_la_body)
@@ -314,7 +325,7 @@ __global__ __launch_bounds__(256 * FS) void panel_fused_kernel(CdBlkParams<T> sp
         blk_solve_la_body<T>(sp, j, smem_raw, threadIdx.x);
         return;
     }
-    fused_step_part<T, Acc, VEC>(smem_raw, X, n, w, r, dcol, dlt, nz_dev, cols, nb, part, part_ld, reps);
+    fused_step_part<T, Acc, VEC>(smem_raw, X, n, w, r, dcol, dlt, nz_dev, cols, nb, part, part_ld, fsa);
 }
 
 template <class T>
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(256 * FS) void panel_fused_grp_kernel(CdGrpBlkParam
                                                                   const T* __restrict__ dlt,
                                                                   const int32_t* __restrict__ nz_dev,
                                                                   const int32_t* __restrict__ cols, int nb,
-                                                                  T* __restrict__ part, int64_t part_ld) {
+                                                                  T* __restrict__ part, int64_t part_ld, int fsa) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int RS = 64 * VEC;
     if (blockIdx.x == 0) { // all 256 * FS threads: the rotated solve spreads its prologue's loads over them
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(256 * FS) void panel_fused_grp_kernel(CdGrpBlkParam
         grp_solve_body<T, true, true>(sp, j, smem_raw, 256 * FS);
         return;
     }
-    fused_step_part<T, Acc, VEC>(smem_raw, X, n, w, r, dcol, dlt, nz_dev, cols, nb, part, part_ld, 1, sp.tail_counter != nullptr);
+    fused_step_part<T, Acc, VEC>(smem_raw, X, n, w, r, dcol, dlt, nz_dev, cols, nb, part, part_ld, fsa, sp.tail_counter != nullptr);
     if constexpr (RS >= PB) {
         if (sp.tail_counter == nullptr || nb <= 0) return; // (uniform)
         // ---- tail: the last step workgroup to get here sums the partials of all of them ----
@@ -435,7 +446,8 @@ int fused_grp_launch(const CdGrpBlkParams<T>& sp, int j, const Acc& acc, int64_t
                      const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, bool tr, hipStream_t s) {
     constexpr int RS = 64 * VEC;
     const int64_t ns = (n + RS - 1) / RS;
-    const int64_t nwg = (ns + FS - 1) / FS;
+    const int fsa = (64 * VEC >= PB) ? fused_fsa(ns) : FS;
+    const int64_t nwg = (ns + fsa - 1) / fsa;
     const int64_t part_ld = (64 * VEC >= PB) ? nwg : nwg * FS; // (one partial per column and workgroup, as fused_launch)
     static bool attr_done = false;
     if (!attr_done) {
@@ -445,7 +457,7 @@ int fused_grp_launch(const CdGrpBlkParams<T>& sp, int j, const Acc& acc, int64_t
     }
     hipLaunchKernelGGL((panel_fused_grp_kernel<T, Acc, VEC>), dim3((unsigned)(nwg + 1)), dim3(256 * FS),
                        grp_solve_lds_total<T>(), s, sp, j, acc, n, w, r, dcol, dlt, nz_dev, cols, nb, part,
-                       tr ? int64_t(0) : part_ld);
+                       tr ? int64_t(0) : part_ld, fsa);
     return int(part_ld);
 }
 
@@ -454,7 +466,8 @@ int fused_launch(const CdBlkParams<T>& sp, int j, const Acc& acc, int64_t n, con
                  const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb, T* part, bool tr, hipStream_t s) {
     constexpr int RS = 64 * VEC;
     const int64_t ns = (n + RS - 1) / RS;
-    const int64_t nwg = (ns + FS - 1) / FS;
+    const int fsa = (64 * VEC >= PB) ? fused_fsa(ns) : FS;
+    const int64_t nwg = (ns + fsa - 1) / fsa;
     // 64 * VEC >= 128: one partial per column and WORKGROUP (the four slices are summed in LDS); else one per slice
     // (slices past the end write zeros)
     const int64_t part_ld = (64 * VEC >= PB) ? nwg : nwg * FS;
@@ -464,10 +477,9 @@ int fused_launch(const CdBlkParams<T>& sp, int j, const Acc& acc, int64_t n, con
                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(fused_lds<T>()));
         attr_done = true;
     }
-    constexpr int reps = 1; // (workgroups that take several groups of slices in turn: 287.3 -> 314.9 ms on the headline, round 3)
-    hipLaunchKernelGGL((panel_fused_kernel<T, Acc, VEC>), dim3((unsigned)((nwg + reps - 1) / reps + 1)), dim3(256 * FS),
+    hipLaunchKernelGGL((panel_fused_kernel<T, Acc, VEC>), dim3((unsigned)(nwg + 1)), dim3(256 * FS),
                        fused_lds<T>(), s, sp, j, acc, n, w, r, dcol, dlt, nz_dev, cols, nb, part,
-                       tr ? int64_t(0) : part_ld, reps);
+                       tr ? int64_t(0) : part_ld, fsa);
     return int(part_ld);
 }
 

@@ -286,7 +286,11 @@
     // iterations of a lambda move the weights by 1e-3 or less.  Measured on config 4 (500k x 50k): theta = 0.01 builds
     // 20.8 k blocks instead of 54.3 k, 7.05 -> 5.04 s, the same 222 IRLS iterations / 585 passes / screen and active sets,
     // max |delta beta| against theta = 0 over the whole path 1.1e-9 (scripts/irls_reuse.py).  0 = always rebuild.
-    double irls_reuse = 0.01;
+    // Round 5 (profiles/r05_irls_reuse.txt, same script): theta = 0 / 0.01 / 0.1 / 0.2 / 0.4 build 54.4 / 20.9 / 10.7 / 7.3 / 4.5 k
+    // blocks, 5.69 / 4.21 / 3.78 / 3.60 / 3.48 s, max |delta beta| against theta = 0 over the path - / 1.1e-9 / 2.3e-8 / 5.2e-8 /
+    // 1.1e-7 on coefficients of size 0.25, the same 222 IRLS iterations and 585 passes throughout; at 0.2 one group enters the
+    // screen set one lambda apart.  Default 0.1: identical sets, 40 times below the stated tolerance of 1e-6.
+    double irls_reuse = 0.1;
     std::vector<double> ver_drift;       // ver_drift[v] = log(1 + max relative weight change between versions v-1 and v)
     uint64_t min_usable_version = 1;     // blocks built at this weight version or later are within irls_reuse of the current weights
     int64_t n_blocks_reused = 0;

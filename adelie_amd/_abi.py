@@ -128,6 +128,7 @@ class GrpnetArgs(C.Structure):
         ("constraint_cfg", C.c_void_p),
         ("constraint_lin", C.c_void_p),
         ("constraint_vmu", C.c_void_p),
+        ("penalty_l2", C.c_void_p),
     ]
 
 
@@ -183,7 +184,7 @@ def dtype_code(dtype):
 
 
 # kept equal to ADELIE_HIP_ABI_VERSION in include/adelie_hip.h (tests/test_abi.py compares the two)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class Backend:

@@ -91,7 +91,7 @@ __device__ __forceinline__ void blk_solve_body(const CdBlkParams<T>& p, int j, c
         if (i < nb) {
             const int idx = blk_index(p, base + i);
             const T A = p.vars[idx], pk = p.spen[idx];
-            const T den = A + p.l2 * pk;
+            const T den = A + p.l2 * (p.spen2 ? p.spen2[idx] : pk); // (penalty_l2, ABI 8)
             idxB[i] = idx;
             gB[i] = NAIVE ? ((p.part && gsum8) ? T(0) : p.gblk[i]) : p.g[idx];
             bB[i] = p.beta[idx];
@@ -412,12 +412,12 @@ __device__ __forceinline__ void blk_solve_la_body(const CdBlkParams<T>& p, int j
         if (v0) {
             const T pk = p.spen[i0];
             A0 = p.vars[i0]; b0 = p.beta[i0]; X0 = p.xmean[i0]; a0 = p.is_active[i0];
-            L0 = p.l1 * pk; N0 = A0 + p.l2 * pk;
+            L0 = p.l1 * pk; N0 = A0 + p.l2 * (p.spen2 ? p.spen2[i0] : pk);
         }
         if (v1) {
             const T pk = p.spen[i1];
             A1 = p.vars[i1]; b1 = p.beta[i1]; X1 = p.xmean[i1]; a1 = p.is_active[i1];
-            L1 = p.l1 * pk; N1 = A1 + p.l2 * pk;
+            L1 = p.l1 * pk; N1 = A1 + p.l2 * (p.spen2 ? p.spen2[i1] : pk);
         }
     }
 

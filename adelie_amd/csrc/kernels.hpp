@@ -237,6 +237,7 @@ struct CdParams {
     const int32_t* sbegin;   // [ns]
     const int32_t* ssize;    // [ns]
     const T* spen;           // [ns] penalty per screen group
+    const T* spen2 = nullptr; // [ns] or nullptr (= spen): factors of the quadratic part (adelie_hip_grpnet_args::penalty_l2, scalars only)
     const T* C;              // centred Gram, screen-value order
     int64_t ldc;
     const T* vars;           // [nv]
@@ -275,6 +276,7 @@ struct CdBlkParams {
     const T* vars;
     const T* xmean;
     const T* spen;
+    const T* spen2 = nullptr; // factors of the quadratic part, or nullptr (= spen): adelie_hip_grpnet_args::penalty_l2
     T* beta;
     T* g;
     int8_t* is_active;

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NT) void cd_kernel(CdParams<T> p) {
                 const T A = p.vars[b];
                 const T gcur = gl[b];
                 const T gk = fma(ak_old, A, gcur);                 // pin_naive:85-89
-                const T denom = A + l2 * pk;                       // pin_base:181-195
+                const T denom = A + l2 * (p.spen2 ? p.spen2[ss] : pk);                    // pin_base:181-195
                 const T v = fabs(gk) - l1 * pk;
                 const T ak = (v > T(0)) ? copysign(v, gk) / denom : T(0);
                 if (ak != ak_old) {                                // pin_naive:97

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NT) void cd_lasso_kernel(CdParams<T> p) {
 
     struct Slot {
         int ss;       // coordinate (-1: past the end of the list)
-        T beta, A, pk, xm;
+        T beta, A, pk, pk2, xm;
         bool have;    // col[] holds the coordinate's Gram column (else a dummy column was loaded)
         V col[K];
     };
@@ -119,6 +119,7 @@ __global__ __launch_bounds__(NT) void cd_lasso_kernel(CdParams<T> p) {
             s.ss = ss;
             const int sc = ss < 0 ? 0 : ss;
             s.pk = p.spen[sc];
+            s.pk2 = p.spen2 ? p.spen2[sc] : s.pk; // (penalty_l2, ABI 8)
             s.beta = p.beta[sc];
             s.A = p.vars[sc];
             s.xm = p.xmean[sc];
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(NT) void cd_lasso_kernel(CdParams<T> p) {
             const bool valid = s.ss >= 0;
             const int b = valid ? s.ss : 0;
             const T gcur = gl[b];
-            const T denom = s.A + l2 * s.pk;                 // pin_base:181-195
+            const T denom = s.A + l2 * s.pk2;                // pin_base:181-195
             const T rden = T(1) / denom;                     // independent of g: overlaps the LDS read
             const T gk = fma(s.beta, s.A, gcur);             // pin_naive:85-89
             const T v = fabs(gk) - l1 * s.pk;

@@ -8,6 +8,9 @@
     // ---- static inputs (host copies) ----
     std::vector<idx> groups, group_sizes;
     std::vector<T> penalty;
+    std::vector<T> penalty2; // adelie_hip_grpnet_args::penalty_l2 (factors of the quadratic part), == penalty when absent
+    bool has_pen2 = false;
+    std::vector<T> h_spen2;
     T alpha, min_ratio;
     size_t lmda_path_size, max_screen_size, max_active_size;
     T pivot_subset_ratio;
@@ -109,6 +112,7 @@
     DevBuf<int32_t> d_slot;
     // per screen value / group (sized p / G up front: a few hundred KB)
     DevBuf<int32_t> d_vcol, d_sbegin, d_ssize, d_actset, d_dcols;
+    DevBuf<T> d_spen2, d_penalty2; // (penalty_l2: per screen group / per group)
     DevBuf<T> d_spen, d_beta, d_beta0, d_g, d_vars, d_sxm, d_dvals;
     DevBuf<int8_t> d_isact;
     DevBuf<char> d_app;          // packed image of the new screen groups (device_append_screen)

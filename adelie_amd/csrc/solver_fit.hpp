@@ -33,6 +33,7 @@
         cp.sbegin = d_sbegin.p;
         cp.ssize = d_ssize.p;
         cp.spen = d_spen.p;
+        cp.spen2 = has_pen2 ? d_spen2.p : nullptr;
         cp.C = d_C.p;
         cp.ldc = ldc;
         cp.vars = d_vars.p;

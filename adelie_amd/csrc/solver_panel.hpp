@@ -21,7 +21,7 @@
         bs.status = CD_OK;
         d_blk.upload(&bs, 1, st);
         CdBlkParams<T> bp{};
-        bp.nv = cp.nv; bp.C = cp.C; bp.ldc = cp.ldc; bp.vars = cp.vars; bp.xmean = cp.xmean; bp.spen = cp.spen;
+        bp.nv = cp.nv; bp.C = cp.C; bp.ldc = cp.ldc; bp.vars = cp.vars; bp.xmean = cp.xmean; bp.spen = cp.spen; bp.spen2 = cp.spen2;
         bp.beta = cp.beta; bp.g = cp.g; bp.is_active = cp.is_active; bp.active_set = cp.active_set;
         bp.l1 = cp.lmda * cp.alpha; bp.l2 = cp.lmda * (T(1) - cp.alpha);
         bp.max_active_size = cp.max_active_size;
@@ -158,7 +158,7 @@
         bool first_open = open_from_grad && mode != 2 && !cons_on; // block 0 of the first pass: gradient from the sweep
         open_from_grad = false;
         CdBlkParams<T> bp{};
-        bp.nv = cp.nv; bp.vars = cp.vars; bp.xmean = cp.xmean; bp.spen = cp.spen;
+        bp.nv = cp.nv; bp.vars = cp.vars; bp.xmean = cp.xmean; bp.spen = cp.spen; bp.spen2 = cp.spen2;
         bp.beta = cp.beta; bp.is_active = cp.is_active; bp.active_set = cp.active_set;
         bp.l1 = cp.lmda * cp.alpha; bp.l2 = cp.lmda * (T(1) - cp.alpha);
         bp.max_active_size = cp.max_active_size;

@@ -352,6 +352,9 @@
         groups.assign(a->groups, a->groups + G);
         group_sizes.assign(a->group_sizes, a->group_sizes + G);
         penalty.assign((const T*)a->penalty, (const T*)a->penalty + G);
+        has_pen2 = a->penalty_l2 != nullptr;
+        if (has_pen2) penalty2.assign((const T*)a->penalty_l2, (const T*)a->penalty_l2 + G);
+        else penalty2 = penalty;
         alpha = T(a->alpha); min_ratio = T(a->min_ratio);
         lmda_path_size = size_t(a->lmda_path_size);
         max_screen_size = size_t(a->max_screen_size); max_active_size = size_t(a->max_active_size);
@@ -380,6 +383,15 @@
         for (idx g = 0; g < G; ++g) {
             max_gs = std::max(max_gs, group_sizes[g]);
             if (group_sizes[g] != 1) all_scalar = false;
+        }
+        if (has_pen2) { // (ABI 8) the separate quadratic factors live in the one-coefficient solves only
+            if (!all_scalar) throw make_core_error("penalty_l2 needs groups of one coefficient.");
+            if (cov_mode || X->kind == 2) throw make_core_error("penalty_l2 is not offered by the covariance method / the multi-response view.");
+            if (a->constraint_kind)
+                for (idx g = 0; g < G; ++g)
+                    if (a->constraint_kind[g] != 0) throw make_core_error("penalty_l2 is not offered with constraints.");
+            for (idx g = 0; g < G; ++g)
+                if (!(penalty2[g] >= 0)) throw make_core_error("penalty_l2 must be >= 0.");
         }
 
         // state_base.ipp:9-116
@@ -579,6 +591,10 @@
         d_spen.reserve(G); d_beta.reserve(p); d_beta0.reserve(p); d_g.reserve(p); d_vars.reserve(p); d_sxm.reserve(p);
         d_dvals.reserve(p); d_isact.reserve(G); d_voff.reserve(G); d_V.reserve(16); d_sc.reserve(1); d_sums.reserve(16 + 4 * 256);
         d_penalty.upload(penalty.data(), G, st);
+        if (has_pen2) {
+            d_penalty2.reserve(G); d_spen2.reserve(G);
+            d_penalty2.upload(penalty2.data(), G, st);
+        }
         d_groups.upload(groups.data(), G, st);
         d_gsizes.upload(group_sizes.data(), G, st);
         AHIP_CHECK(hipMemsetAsync(d_slot.p, 0xFF, size_t(G) * sizeof(int32_t), st)); // -1

@@ -196,7 +196,7 @@
     void update_abs_grad_host(T lm) {
         for (size_t ss = 0; ss < screen_set.size(); ++ss) {
             const idx i = screen_set[ss], b = screen_begins[ss], k = groups[i], sz = group_sizes[i];
-            const T regul = ((1 - alpha) * lm) * penalty[i];
+            const T regul = ((1 - alpha) * lm) * penalty2[i];
             if (cons_on && cons_kind[i] && !host_cons(i)) { // :69-75: minus the constraint's gradient
                 abs_grad[i] = std::abs(grad[k] - regul * screen_beta[b] - cons_mu[i]);
                 continue;
@@ -236,8 +236,8 @@
                 launch_cons_abs_grad<T>(d_devcons_list.p, int(devcons_list.size()), d_cons_native.p, d_groups.p, d_gsizes.p, d_slot.p,
                                         d_grad.p, d_beta.p, d_penalty.p, (1 - alpha) * lm, d_cons_va.p, d_cons_vb.p, d_cons_mu.p, d_absgrad.p, st);
         } else {
-            launch_abs_grad<T>(d_grad.p, d_groups.p, d_gsizes.p, G, d_slot.p, d_beta.p, d_penalty.p, (1 - alpha) * lm,
-                               d_absgrad.p, st);
+            launch_abs_grad<T>(d_grad.p, d_groups.p, d_gsizes.p, G, d_slot.p, d_beta.p, has_pen2 ? d_penalty2.p : d_penalty.p,
+                               (1 - alpha) * lm, d_absgrad.p, st);
         }
         d_absgrad.download(abs_grad.data(), size_t(G), st);
     }
@@ -290,6 +290,12 @@
         app_img.assign(L.total, 0);
         auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes) std::memcpy(app_img.data() + off, src, bytes); };
         put(L.pen, spen.data(), sizeof(T) * spen.size());
+        if (has_pen2) { // (groups of one coefficient: screen group == screen value; the host copy outlives the upload)
+            h_spen2.reserve(size_t(G));
+            h_spen2.resize(size_t(ns_dev));
+            for (idx ss = ns_dev; ss < ns; ++ss) h_spen2.push_back(penalty2[screen_set[ss]]);
+            d_spen2.upload(h_spen2.data() + ns_dev, size_t(ns - ns_dev), st, size_t(ns_dev));
+        }
         put(L.beta, beta_new.data(), sizeof(T) * beta_new.size());
         if (cons_on) { // per screen value (only groups of one coefficient carry a constraint)
             std::vector<T> clo_new, chi_new, cmu_new;

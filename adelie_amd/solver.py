@@ -100,7 +100,7 @@ def _lasso_in_raw_coordinates(X, glm, constraints, groups, alpha, intercept, war
     """``(base design, scales, centers)`` when a fit on the lazily standardized view ``X`` is a lasso that can run on the base
     design's own columns (see :func:`grpnet`), else ``None``."""
     sparse_view = getattr(X, "_kind", None) == "sparse" and getattr(X, "_std", None) is not None and getattr(X, "_keep", None) is not None
-    if not (isinstance(X, matrix._StdView) or sparse_view) or warm_start is not None or not intercept or alpha != 1:
+    if not (isinstance(X, matrix._StdView) or sparse_view) or warm_start is not None or not intercept or not (0 < alpha <= 1):
         return None
     if getattr(glm, "is_multi", False):
         return None
@@ -114,7 +114,7 @@ def _lasso_in_raw_coordinates(X, glm, constraints, groups, alpha, intercept, war
     return X._base, X._s, X._c
 
 
-def _to_standardized_coordinates(state, view, s, c, penalty):
+def _to_standardized_coordinates(state, view, s, c, penalty, alpha=1):
     """The state of a lasso solved on the raw columns, re-expressed for the standardized view: ``beta~ = s beta``, the
     intercepts take ``sum_j beta_j c_j``, gradients divide by ``s`` (``grad`` of the Gaussian state is the centred gradient,
     that of a GLM state ``X' resid``), means and variances of the screened columns follow."""
@@ -138,11 +138,17 @@ def _to_standardized_coordinates(state, view, s, c, penalty):
         if hasattr(state, "beta0"):
             state.beta0 = dtype(state.beta0 + shift_now)
     state.abs_grad = np.abs(state.grad)
+    if alpha != 1 and len(cols) and np.any(state.screen_beta != 0):  # solver_base.hpp:20-110: minus the quadratic part's gradient
+        shrink = np.zeros(len(s), dtype=dtype)
+        shrink[cols] = dtype((1 - alpha) * state.lmda) * np.asarray(penalty, dtype=dtype)[cols] * state.screen_beta
+        state.abs_grad = np.abs(state.grad - shrink)
     if len(np.asarray(state.screen_X_means)) == len(cols):  # (a GLM state keeps none: IRLS recomputes them per iteration)
         state.screen_X_means = ((np.asarray(state.screen_X_means) - c[cols]) / s[cols]).astype(dtype)
     if len(np.asarray(state.screen_vars)) == len(cols):
         state.screen_vars = (np.asarray(state.screen_vars) / s[cols] ** 2).astype(dtype)
     state.penalty = np.asarray(penalty, dtype=dtype)
+    if getattr(state, "_penalty_l2", None) is not None:  # (the view's own coordinates have one factor per group again)
+        state._penalty_l2 = None
     state._X = view
     if hasattr(state, "X"):
         state.X = view
@@ -286,6 +292,7 @@ def grpnet(
     max_screen_size: int = None, max_active_size: int = None,
     pivot_subset_ratio: float = 0.1, pivot_subset_min: int = 1, pivot_slack_ratio: float = 1.25,
     check_state: bool = False, progress_bar: bool = True, warm_start=None, exit_cond: Callable = None,
+    _penalty_l2: np.ndarray = None,
 ):
     """Group elastic net along a decreasing path of ``lmda`` on an MI355X (naive method).
 
@@ -322,6 +329,9 @@ def grpnet(
         # the same numbers in both coordinate systems (eta is the same vector), so the solver runs its panel engines on the raw
         # columns -- the view itself only has the full-Gram engines (ROUNDS.md 9.9) -- and the state comes back in the
         # standardized coordinates.
+        # An elastic net (0 < alpha < 1) is the same statement with the quadratic part's factors times s^2: the library takes
+        # them as a separate vector (adelie_hip_grpnet_args::penalty_l2, ABI 8; the reference has one factor per group, hence
+        # no public argument here).
         base, sc, ce = raw
         pen = np.ones(p, dtype=dtype) if penalty is None else np.asarray(penalty, dtype=dtype)
         state = grpnet(
@@ -331,8 +341,8 @@ def grpnet(
             intercept=True, screen_rule=screen_rule, min_ratio=min_ratio, lmda_path_size=lmda_path_size,
             max_screen_size=max_screen_size, max_active_size=max_active_size, pivot_subset_ratio=pivot_subset_ratio,
             pivot_subset_min=pivot_subset_min, pivot_slack_ratio=pivot_slack_ratio, check_state=check_state,
-            progress_bar=progress_bar)
-        return _to_standardized_coordinates(state, X, sc, ce, pen)
+            progress_bar=progress_bar, _penalty_l2=None if alpha == 1 else (pen * sc * sc).astype(dtype))
+        return _to_standardized_coordinates(state, X, sc, ce, pen, alpha)
 
     if isinstance(constraints, list):
         for c in constraints:  # cached dual state of a previous solve must not leak into this one (solver.py:638-642)
@@ -385,6 +395,8 @@ def grpnet(
             kwargs.update(_start_multiglm(X, glm, offsets, intercept, dtype))
 
     state = _STATE_OF[kind](**kwargs)
+    if _penalty_l2 is not None:
+        state._penalty_l2 = np.ascontiguousarray(_penalty_l2, dtype=dtype)
     if check_state:
         state.check(method="assert")
     return state.solve(progress_bar=progress_bar, exit_cond=exit_cond)

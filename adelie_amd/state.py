@@ -334,6 +334,11 @@ class base:
         a.group_sizes = idx(self.group_sizes)
         a.alpha = float(self.alpha)
         a.penalty = val(self.penalty)
+        pl2 = getattr(self, "_penalty_l2", None)   # (ABI 8; set by solver.grpnet for an elastic net on a standardized view)
+        if pl2 is not None:
+            if len(pl2) != len(self.groups):
+                raise RuntimeError("adelie_amd: _penalty_l2 must be (G,) where groups is (G,).")
+            a.penalty_l2 = val(pl2)
         a.resid = val(self.resid)
         a.grad = val(self.grad)
         lp = np.ascontiguousarray(self.lmda_path, dtype=dtype)

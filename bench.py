@@ -554,6 +554,17 @@ def lazy_views_leg(ad_design, L, y_binomial=None):
                                "unit": "paths/s", "ms_per_step": el * 1e3, "lambdas": len(sb.lmdas),
                                "final_active": int(sb.active_set_size), "n_irls_iters": int(sb.counters["n_irls_iters"]),
                                "error": sb.error}
+            # the same as an elastic net: penalty * |s| and penalty * s^2 as separate factors (adelie_hip_grpnet_args::penalty_l2);
+            # the view's own engines would rebuild the screen set's full Gram (12 GB at 39 k screened columns) per IRLS iteration
+            t0 = time.perf_counter()
+            se = ad.grpnet(Z, ad.glm.binomial(np.asarray(y_binomial, dtype=np.float64)), lmda_path_size=L, early_exit=False,
+                           progress_bar=False, alpha=0.5)
+            el = time.perf_counter() - t0
+            out["binomial_elastic_net"] = {"workload": "the same with alpha = 0.5 (elastic net)", "value": 1.0 / el, "unit": "paths/s",
+                                           "ms_per_step": el * 1e3, "lambdas": len(se.lmdas),
+                                           "final_active": int(se.active_set_size),
+                                           "n_irls_iters": int(se.counters["n_irls_iters"]),
+                                           "n_panel_blocks": int(se.counters["n_panel_blocks"]), "error": se.error}
         return out
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)}

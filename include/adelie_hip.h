@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADELIE_HIP_ABI_VERSION 7
+#define ADELIE_HIP_ABI_VERSION 8
 
 enum adelie_hip_dtype { ADELIE_HIP_F32 = 0, ADELIE_HIP_F64 = 1 };
 enum adelie_hip_order { ADELIE_HIP_COL_MAJOR = 0, ADELIE_HIP_ROW_MAJOR = 1 };
@@ -384,6 +384,12 @@ typedef struct adelie_hip_grpnet_args {
      * wavefront; no callback is made for them).  constraint_vmu: the multipliers those objects hold on entry, per COEFFICIENT
      * (p,) value_t, or NULL for zeros; what they hold on return is the result vector ADELIE_HIP_V_CONSTRAINT_VMU. */
     const void*    constraint_vmu;
+    /* ABI 8: separate factors for the quadratic part of the penalty, (G,) value_t or NULL (= penalty): the objective's penalty
+     * term becomes  lmda * sum_g (alpha * penalty[g] * |b_g| + (1 - alpha) / 2 * penalty_l2[g] * b_g^2).  Groups of one
+     * coefficient only.  The reference has no such argument; it is what an elastic net on the standardized view
+     * (Z - 1 c') diag(s)^-1 of a resident design needs to run on Z's own columns (penalty * |s|, penalty * s^2: every
+     * coordinate update, screening score and KKT test is the same number in both coordinate systems, adelie_amd/solver.py). */
+    const void*    penalty_l2;
 } adelie_hip_grpnet_args;
 
 /* Runs the whole path.  `*out` is always set on return code 0 (even when the solve recorded

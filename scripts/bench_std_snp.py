@@ -2,6 +2,10 @@
 (a dense f64 copy: 8 bytes per call): wall of a Gaussian lasso path on both, resident bytes, max|dbeta|.
 
     python scripts/bench_std_snp.py [n p lambdas]      (default 200000 20000 100)
+
+ALPHA=0.5: an elastic net (round 5: runs on the base design's panel engines through penalty_l2); VIEW_ENGINES=1 forces the view's
+own full-Gram engines (an exit_cond that never fires keeps grpnet in the view's coordinates) for a before / after on one build;
+BINOMIAL=1 adds config 4's response; SKIP_COPY=1 leaves the materialised copy out.
 """
 import json
 import os
@@ -27,10 +31,13 @@ beta[rng.choice(p, 50, replace=False)] = rng.normal(size=50)
 eta = np.zeros(n)
 X.btmul(0, p, beta, eta)
 y = eta + float(os.environ.get("NOISE", "1.0")) * np.std(eta) * rng.normal(size=n)
-kw = dict(lmda_path_size=L, min_ratio=float(os.environ.get("MIN_RATIO", "2e-2")), early_exit=False, progress_bar=False)
-res = {"workload": f"Gaussian lasso on standardize(snp {n}x{p}), {L} lambdas", "bytes_2bit": int(n * p / 4), "bytes_dense_copy": int(n * p * 8)}
+alpha = float(os.environ.get("ALPHA", "1"))
+kw = dict(lmda_path_size=L, min_ratio=float(os.environ.get("MIN_RATIO", "2e-2")), early_exit=False, progress_bar=False, alpha=alpha)
+if os.environ.get("VIEW_ENGINES"):
+    kw["exit_cond"] = lambda state: False
+res = {"workload": f"Gaussian {'lasso' if alpha == 1 else 'elastic net alpha=%g' % alpha} on standardize(snp {n}x{p}), {L} lambdas", "view_engines": bool(os.environ.get("VIEW_ENGINES")), "bytes_2bit": int(n * p / 4), "bytes_dense_copy": int(n * p * 8)}
 for name, lazy in (("lazy_view", True), ("materialised", False)):
-    if not lazy and n * p * 8 > 150 * 2**30:
+    if not lazy and (n * p * 8 > 150 * 2**30 or os.environ.get("SKIP_COPY")):
         continue
     t0 = time.time()
     Z = ad.matrix.standardize(X, lazy=lazy)
@@ -38,7 +45,8 @@ for name, lazy in (("lazy_view", True), ("materialised", False)):
     ad.grpnet(Z, ad.glm.gaussian(y), lmda_path_size=5, min_ratio=0.5, early_exit=False, progress_bar=False)
     t0 = time.time()
     st = ad.grpnet(Z, ad.glm.gaussian(y), **kw)
-    res[name] = {"path_s": time.time() - t0, "make_s": t_make, "final_active": int(st.active_set_size), "error": st.error}
+    res[name] = {"path_s": time.time() - t0, "make_s": t_make, "final_active": int(st.active_set_size), "error": st.error,
+                 "n_panel_blocks": int(st.counters["n_panel_blocks"])}
     if lazy:
         ref = st.betas.toarray()
     else:
@@ -47,7 +55,7 @@ for name, lazy in (("lazy_view", True), ("materialised", False)):
 if os.environ.get("BINOMIAL"):  # config 4's own response on the standardized view: IRLS on the panel engines of the 2-bit matrix
     Z = ad.matrix.standardize(X, lazy=True)
     t0 = time.time()
-    sb = ad.grpnet(Z, ad.glm.binomial(y_bin), lmda_path_size=L, early_exit=False, progress_bar=False)
+    sb = ad.grpnet(Z, ad.glm.binomial(y_bin), **kw)
     res["binomial_lazy_view"] = {"path_s": time.time() - t0, "lambdas": len(sb.lmdas), "final_active": int(sb.active_set_size),
                                  "n_irls_iters": int(sb.counters["n_irls_iters"]), "n_panel_blocks": int(sb.counters["n_panel_blocks"]),
                                  "error": sb.error}

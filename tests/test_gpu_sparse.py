@@ -258,6 +258,9 @@ def test_standardized_view_of_a_kept_sparse_design(hip, oracle, dtype):
         (ad.glm.gaussian(y, weights=w / w.sum()), dict(tol=1e-12, groups=np.arange(0, p, 4), alpha=0.7)),
         (ad.glm.gaussian(y), dict(tol=1e-12, intercept=False)),
         (ad.glm.binomial((y > np.median(y)).astype(float)), dict(tol=1e-10, irls_tol=1e-10)),
+        # elastic nets with an intercept: solved on the sparse base's own columns, penalty |s| and penalty s^2 (penalty_l2, ABI 8)
+        (ad.glm.gaussian(y, weights=w / w.sum()), dict(tol=1e-12, alpha=0.4, penalty=rng.uniform(0.5, 2.0, p))),
+        (ad.glm.binomial((y > np.median(y)).astype(float)), dict(tol=1e-10, irls_tol=1e-10, alpha=0.5)),
     ]:
         kw.update(early_exit=False, lmda_path_size=15, min_ratio=2e-2, progress_bar=False)
         a = ad.grpnet(Z, glm, **kw)

@@ -123,6 +123,14 @@
     DevBuf<T> d_C;
     idx ldc = 0, gcap = 0;
     idx gram_nv = 0; // number of screen values whose Gram rows/cols are valid (for the current weights)
+    // IRLS on the full-Gram engines (designs kept sparse, standardized views; groups of one): the screen set's Gram is kept
+    // while the weights have drifted by at most `irls_reuse` since it was built (the rule of the panel engines' blocks,
+    // note_weight_drift) instead of being rebuilt per IRLS iteration.  A kept Gram only carries the coupling INSIDE a pass:
+    // every pass then starts from the exact gradient of the current residual (run_block_passes: residual update with the
+    // pass's changes, X_S' W r), so the fixed point is the exact one and the iterates inside a pass differ by O(theta |delta|).
+    uint64_t gram_version = 0; // w_version the bulk of C was built under (0: none)
+    bool gram_stale = false;   // C belongs to older weights than the fit's: refresh the gradient per pass
+    DevBuf<T> d_beta_ref;      // coefficients the residual currently reflects (stale mode)
     DevBuf<CdScalars<T>> d_sc;
     DevBuf<CdBlkState<T>> d_blk;
     DevBuf<T> d_Dbuf, d_dlt;

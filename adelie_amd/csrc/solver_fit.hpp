@@ -85,7 +85,7 @@
                 inv_prelaunched_lm = lm;
             }
         } else if (nv > 0 && all_scalar && nv >= cd_block_min_nv) {
-            run_block_passes(cp, sc);
+            run_block_passes(cp, sc, (is_glm() && gram_stale) ? r_dev : nullptr);
         } else if (nv > 0 && !all_scalar && max_gs <= cd_block_size() && nv >= cd_block_min_nv) {
             run_group_block_passes(cp, sc);
         } else {
@@ -396,7 +396,9 @@
                 std::vector<T> m(nv);
                 d_g.download(m.data(), size_t(nv), st);
                 T drift = T(1e30);
-                const bool track = irls_reuse > 0 && all_scalar && panel_mode();
+                const bool gram_keep_mode = irls_reuse > 0 && all_scalar && !panel_mode() && !cov_mode && !multi() &&
+                                            (sparse() || std_generic()) && nv >= cd_block_min_nv;
+                const bool track = irls_reuse > 0 && all_scalar && (panel_mode() || gram_keep_mode);
                 if (track) { // how far the weights moved since the previous iteration (and keep a copy for the next one)
                     d_irls_w_prev.reserve(size_t(n));
                     if (!irls_w_prev_valid) AHIP_CHECK(hipMemsetAsync(d_irls_w_prev.p, 0, size_t(n) * sizeof(T), st));
@@ -409,16 +411,32 @@
                     for (idx t = 0; t < group_sizes[g]; ++t) irls_xm_host[groups[g] + t] = m[screen_begins[ss] + t];
                 }
                 d_irls_xm.upload(irls_xm_host.data(), size_t(p), st);
-                gram_nv = 0;
-                v_used = 0;
-                screen_transforms.clear();
                 ++w_version; // diagonal blocks built from here on belong to this iteration's weights
                 if (track) {
                     note_weight_drift(irls_w_prev_valid ? double(drift) : 1e300);
                     irls_w_prev_valid = true;
                 }
-                if (panel_mode()) update_vars_panel(d_irls_w.p, d_irls_xm.p, irls_xm_host, 0);
-                else update_gram_and_vars(d_irls_w.p, d_irls_xm.p, irls_xm_host, 0);
+                const bool keep = gram_keep_mode && gram_version != 0 && gram_version >= min_usable_version && gram_nv > 0 &&
+                                  gram_nv <= nv;
+                if (!keep) {
+                    gram_nv = 0;
+                    v_used = 0;
+                    screen_transforms.clear();
+                }
+                if (panel_mode()) {
+                    update_vars_panel(d_irls_w.p, d_irls_xm.p, irls_xm_host, 0);
+                } else if (keep) { // rows of the members that joined since, under the current weights; the means of ALL values
+                    // are the current ones (the gradient's centring and the residual-sum tracking read them)
+                    update_gram_and_vars(d_irls_w.p, d_irls_xm.p, irls_xm_host, size_t(gram_nv));
+                    d_sxm.upload(m.data(), size_t(nv), st);
+                    for (idx a = 0; a < nv; ++a) screen_X_means[a] = m[a];
+                    gram_stale = true;
+                    sync(); // (`m` goes out of scope below)
+                } else {
+                    update_gram_and_vars(d_irls_w.p, d_irls_xm.p, irls_xm_host, 0);
+                    gram_version = gram_keep_mode ? w_version : 0;
+                    gram_stale = false;
+                }
             }
             cur_w = d_irls_w.p;
             cur_xm = d_irls_xm.p;

@@ -6,8 +6,15 @@
     // Lasso pin solve as a sequence of block passes spread over the chip (kernels_cd_block.hip).  The pass structure
     // (solve_active until convergence, one screen pass, repeat; pin_naive:317-357) is driven from the host, which reads
     // one small scalar block per pass.  Fills `sc` like the single-workgroup kernel does.
-    void run_block_passes(const CdParams<T>& cp, CdScalars<T>& sc) {
+    // `r_stale` != nullptr (IRLS with a Gram kept from earlier weights, Solver::gram_stale): every pass but the first of the fit
+    // first brings the residual up to date with the changes made so far and takes the exact gradient X_S' W r from it.
+    void run_block_passes(const CdParams<T>& cp, CdScalars<T>& sc, T* r_stale = nullptr) {
         const int B = cd_block_size();
+        if (r_stale) {
+            d_beta_ref.reserve(size_t(cp.nv) + 8);
+            AHIP_CHECK(hipMemcpyAsync(d_beta_ref.p, cp.beta, size_t(cp.nv) * sizeof(T), hipMemcpyDeviceToDevice, st));
+        }
+        int64_t n_pass = 0;
         d_blk.reserve(1);
         d_Dbuf.reserve(size_t(2) * B * B);
         d_dlt.reserve(B);
@@ -33,6 +40,15 @@
         auto pass = [&](const int32_t* list, int count, bool mark) -> T {
             if (count <= 0) return T(0);
             bp.list = list; bp.count = count; bp.mark = mark ? 1 : 0;
+            if (r_stale && n_pass++ > 0) {
+                launch_cd_compact<T>(cp.beta, d_beta_ref.p, cp.vcol, cp.nv, cp.dcols, cp.dvals, &cp.sc->n_delta, st);
+                t_axpy.begin(st);
+                axpy_cols(cp.dcols, cp.dvals, &cp.sc->n_delta, 0, T(-1), r_stale);
+                t_axpy.end(st);
+                AHIP_CHECK(hipMemcpyAsync(d_beta_ref.p, cp.beta, size_t(cp.nv) * sizeof(T), hipMemcpyDeviceToDevice, st));
+                launch_vmul<T>(cur_w, r_stale, d_v.p, n, st);
+                sweep(d_v.p, cp.g, d_vcol.p, cp.nv, &d_blk.p->resid_sum, intercept ? cur_xm : nullptr);
+            }
             t_cd.begin(st);
             launch_cd_block_pass<T>(bp, st);
             t_cd.end(st);
@@ -68,7 +84,7 @@
         sc.active_size = asz;
         sc.status = status;
         // (column, delta) list of the residual update + the device copy of resid_sum for the sweep epilogue
-        launch_cd_compact<T>(cp.beta, cp.beta0, cp.vcol, cp.nv, cp.dcols, cp.dvals, &cp.sc->n_delta, st);
+        launch_cd_compact<T>(cp.beta, r_stale ? d_beta_ref.p : cp.beta0, cp.vcol, cp.nv, cp.dcols, cp.dvals, &cp.sc->n_delta, st);
         AHIP_CHECK(hipMemcpyAsync(&sc.n_delta, &cp.sc->n_delta, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         sync();
     }

@@ -73,7 +73,9 @@ if os.environ.get("SPARSE_BINOMIAL"):  # IRLS on the same design: the screen set
     t0 = time.time()
     sb = ad.grpnet(X, ad.glm.binomial(yb), **kwb)
     res["binomial"] = {"path_s": time.time() - t0, "lambdas": len(sb.lmdas), "final_active": int(sb.active_set_size),
-                       "error": sb.error}
+                       "error": sb.error, "timers": {k: round(float(v), 1) for k, v in sb.timers.items()},
+                       "counters": {k: int(sb.counters[k]) for k in ("n_irls_iters", "n_cd_passes_screen", "n_cd_passes_active",
+                                                                       "n_cd_visits_screen", "n_cd_visits_active", "n_panel_blocks")}}
 if n * p * 8 < 100 * 2**30:
     Xd = ad.matrix.sparse(M, resident="dense")
     ad.grpnet(Xd, ad.glm.gaussian(y), lmda_path_size=5, min_ratio=0.5, early_exit=False, progress_bar=False)

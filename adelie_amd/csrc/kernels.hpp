@@ -147,6 +147,14 @@ struct SyrkBatch {
     int32_t count;
 };
 int64_t syrk_batch_work_elems(int64_t n, int count);
+// the panel engine over compressed columns (kernels_sparse.hip): the panel step (phase (A) as launch_panel_step; the block's gradient straight
+// into gblk, centring included: no reduce launch) and the diagonal blocks of a batch (both triangles, leading dimension ldb)
+template <class T>
+void launch_panel_step_csc(const CscView<T>& X, const T* w, T* r, const int32_t* dcol, const T* dlt, const int32_t* nz_dev,
+                           const int32_t* cols, int nb, const T* rsum_dev, const T* xm_by_col, T* gblk, hipStream_t s);
+template <class T>
+void launch_block_gram_csc(const CscView<T>& X, const T* w, const int32_t* cols_base, const SyrkBatch& sb, const T* xm_by_col,
+                           bool center, T* D0, int ldb, hipStream_t s);
 // Several rectangular blocks of at most 128 x 128 per launch (gram_batch_kernel; the cross blocks of the look-ahead passes):
 // block y = rows cols_base[moff[y] ...] (m[y] of them) x columns cols_base[noff[y] ...] (nn[y]), X_rows^T W X_cols -
 // xm_rows xm_cols^T into C_base + dst[y] (leading dimension ldc).  `work` holds gram_batch_work_elems(n, count) elements.

@@ -642,6 +642,126 @@ void launch_axpy_cols_csc(const CscView<T>& X, const int32_t* cols, const T* coe
     hipLaunchKernelGGL((vec_scatter_kernel<T>), dim3(gs), dim3(256), 0, s, cols, coef, count_dev, count, true, X.inv_scale, delta_zeroed);
 }
 
+// ---- panel engine over compressed columns (IRLS on a design kept sparse, Solver::run_panel_passes) ------------------------------
+// The panel step of kernels_cd_panel.hip streams dense column slices; on compressed columns its two phases are
+//   (A) r[row] -= x * delta over the stored entries of the changed columns of the previous block      (csc_panel_update_kernel)
+//   (B) part[c] = sum_e x_e w[row_e] r[row_e] for the columns of the next block                       (csc_panel_grad_kernel)
+// -- a thousand entries per column instead of a million rows.  Two changed columns of one block may share a row: phase (A) adds
+// with hardware f64 atomics, so where that happens the order of the two additions is not fixed and runs agree to rounding, not
+// bit for bit (everything else in this library is order-deterministic).  The diagonal blocks X_b' W X_b - xbar xbar' of 64
+// visits come from csc_block_gram_kernel: one thread per pair of columns merges the two sorted row lists.
+template <class T>
+__global__ __launch_bounds__(256) void csc_panel_update_kernel(CscView<T> X, const int32_t* __restrict__ dcol,
+                                                               const T* __restrict__ dlt, const int32_t* __restrict__ nz_dev,
+                                                               T* __restrict__ r) {
+    const int nz = nz_dev[0];
+    const int lane = threadIdx.x & 63;
+    const int wv = int((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nw = int((gridDim.x * blockDim.x) >> 6);
+    for (int m = wv; m < nz; m += nw) {
+        const int32_t c = dcol[m];
+        const T d = dlt[m];
+        const int64_t e1 = X.cptr[c + 1];
+        for (int64_t e = X.cptr[c] + lane; e < e1; e += 64) unsafeAtomicAdd(r + X.cidx[e], -X.cval[e] * d);
+    }
+}
+template <class T>
+__global__ __launch_bounds__(256) void csc_panel_grad_kernel(CscView<T> X, const T* __restrict__ w, const T* __restrict__ r,
+                                                             const int32_t* __restrict__ cols, int nb, const T* __restrict__ rsum,
+                                                             const T* __restrict__ xm_by_col, T* __restrict__ gblk) {
+    const int lane = threadIdx.x & 63;
+    const int a = int((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (a >= nb) return;
+    const int32_t c = cols[a];
+    const int64_t e1 = X.cptr[c + 1];
+    T acc = T(0);
+    for (int64_t e = X.cptr[c] + lane; e < e1; e += 64) {
+        const int32_t i = X.cidx[e];
+        acc = fma(X.cval[e], w[i] * r[i], acc);
+    }
+    acc = wave_sum64(acc);
+    if (lane == 0) gblk[a] = xm_by_col ? acc - rsum[0] * xm_by_col[c] : acc; // (what panel_reduce_kernel does for the dense step)
+}
+// the whole step: the gradient of the block's columns goes straight to gblk (no slice partials, no reduce launch)
+template <class T>
+void launch_panel_step_csc(const CscView<T>& X, const T* w, T* r, const int32_t* dcol, const T* dlt, const int32_t* nz_dev,
+                           const int32_t* cols, int nb, const T* rsum_dev, const T* xm_by_col, T* gblk, hipStream_t s) {
+    hipLaunchKernelGGL((csc_panel_update_kernel<T>), dim3(32), dim3(256), 0, s, X, dcol, dlt, nz_dev, r);
+    if (nb > 0)
+        hipLaunchKernelGGL((csc_panel_grad_kernel<T>), dim3(unsigned((nb + 3) / 4)), dim3(256), 0, s, X, w, r, cols, nb, rsum_dev,
+                           xm_by_col, gblk);
+}
+
+// diagonal blocks of the panel engine: block y = columns cols_base[sb.off[y] ...] (sb.nb[y] of them), X' W X - xm xm' into
+// D0 + sb.dst[y] (leading dimension ldb, both triangles)
+// One workgroup per (column b of the block, block y): the stored entries of column b go into an LDS hash table (row ->
+// w[row] * value; columns longer than a table load go through it in chunks), then every column a >= b of the block probes it,
+// one wavefront per column, lanes over its entries.  2 M LDS probes per block of 64 columns of a thousand entries.
+constexpr int HJ_SLOTS = 4096, HJ_CHUNK = 2560; // (load factor <= 0.625)
+template <class T>
+__global__ __launch_bounds__(256) void csc_block_gram_kernel(CscView<T> X, const T* __restrict__ w, const int32_t* __restrict__ cols_base,
+                                                             SyrkBatch sb, const T* __restrict__ xm_by_col, int center,
+                                                             T* __restrict__ D0, int ldb) {
+    __shared__ int32_t keys[HJ_SLOTS];
+    __shared__ T vals[HJ_SLOTS];
+    __shared__ T accs[128];
+    const int y = blockIdx.y, b = blockIdx.x;
+    const int nb = sb.nb[y];
+    if (b >= nb) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int32_t* cols = cols_base + sb.off[y];
+    const int32_t cb = cols[b];
+    const int64_t eb0 = X.cptr[cb], eb1 = X.cptr[cb + 1];
+    if (tid < 128) accs[tid] = T(0);
+    for (int64_t c0 = eb0; c0 < eb1 || c0 == eb0; c0 += HJ_CHUNK) {
+        __syncthreads();
+        for (int k = tid; k < HJ_SLOTS; k += 256) keys[k] = -1;
+        __syncthreads();
+        const int64_t c1 = c0 + HJ_CHUNK < eb1 ? c0 + HJ_CHUNK : eb1;
+        for (int64_t e = c0 + tid; e < c1; e += 256) {
+            const int32_t row = X.cidx[e];
+            unsigned slot = (unsigned(row) * 2654435761u) >> 20;
+            while (atomicCAS(&keys[slot], -1, row) != -1) slot = (slot + 1) & (HJ_SLOTS - 1);
+            vals[slot] = w[row] * X.cval[e];
+        }
+        __syncthreads();
+        for (int a = b + wv; a < nb; a += 4) {
+            const int32_t ca = cols[a];
+            const int64_t ea1 = X.cptr[ca + 1];
+            T acc = T(0);
+            for (int64_t e = X.cptr[ca] + lane; e < ea1; e += 64) {
+                const int32_t row = X.cidx[e];
+                unsigned slot = (unsigned(row) * 2654435761u) >> 20;
+                int32_t k;
+                while ((k = keys[slot]) != -1) {
+                    if (k == row) { acc = fma(X.cval[e], vals[slot], acc); break; }
+                    slot = (slot + 1) & (HJ_SLOTS - 1);
+                }
+            }
+            acc = wave_sum64(acc);
+            if (lane == 0) accs[a] += acc; // (column a belongs to this wavefront in every chunk)
+        }
+        if (eb1 == eb0) break;
+    }
+    __syncthreads();
+    T* D = D0 + sb.dst[y];
+    for (int a = b + tid; a < nb; a += 256) {
+        T v = accs[a];
+        if (center) v -= xm_by_col[cols[a]] * xm_by_col[cb];
+        D[a + int64_t(b) * ldb] = v;
+        D[b + int64_t(a) * ldb] = v;
+    }
+}
+template <class T>
+void launch_block_gram_csc(const CscView<T>& X, const T* w, const int32_t* cols_base, const SyrkBatch& sb, const T* xm_by_col,
+                           bool center, T* D0, int ldb, hipStream_t s) {
+    if (sb.count <= 0) return;
+    int mx = 0;
+    for (int y = 0; y < sb.count; ++y) mx = std::max(mx, int(sb.nb[y]));
+    if (mx <= 0) return;
+    hipLaunchKernelGGL((csc_block_gram_kernel<T>), dim3(unsigned(mx), unsigned(sb.count)), dim3(256), 0, s, X, w, cols_base, sb,
+                       xm_by_col, center ? 1 : 0, D0, ldb);
+}
+
 int64_t sp_tmul_work_elems_csc(int64_t p) { return p * KB + KB; }
 
 template <class T>
@@ -668,6 +788,10 @@ void launch_sp_tmul_csc(const CscView<T>& X, int64_t L, const int64_t* indptr, c
                                      int32_t, const T*, bool, T*, int64_t, T*, hipStream_t);                                     \
     template void launch_axpy_cols_csc<T>(const CscView<T>&, const int32_t*, const T*, const int32_t*, int32_t, T, T*, T*,         \
                                           hipStream_t);                                                                          \
+    template void launch_panel_step_csc<T>(const CscView<T>&, const T*, T*, const int32_t*, const T*, const int32_t*,             \
+                                           const int32_t*, int, const T*, const T*, T*, hipStream_t);                            \
+    template void launch_block_gram_csc<T>(const CscView<T>&, const T*, const int32_t*, const SyrkBatch&, const T*, bool, T*,     \
+                                           int, hipStream_t);                                                                    \
     template void launch_sp_tmul_csc<T>(const CscView<T>&, int64_t, const int64_t*, const int64_t*, const T*, T*, T*, hipStream_t); \
     template void launch_csc_tile_scatter<T>(const int64_t*, const int32_t*, const T*, int64_t, int, int64_t, const int64_t*,     \
                                              uint16_t*, T*, hipStream_t);                                                       \

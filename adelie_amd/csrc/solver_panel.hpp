@@ -425,7 +425,7 @@
                 const int nsl = (j == 0) ? nsl0 : step_of(j);
                 pending_slot = -1;
                 cnt.n_panel_cols += nb;
-                launch_panel_reduce<T>(d_part.p, nsl, nb, cols, &d_blk.p->resid_sum, xm_c, d_gblk.p, st);
+                if (nsl > 0) launch_panel_reduce<T>(d_part.p, nsl, nb, cols, &d_blk.p->resid_sum, xm_c, d_gblk.p, st);
                 bp.Dptr = Dptr;
                 if (h_report && j == nblk - 1) {
                     bp.report_j = j;

@@ -43,6 +43,11 @@
     }
     int panel_step(const T* w, T* r, const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb) {
         if (multi()) return launch_multi_panel_step<T>(D->multi<T>(), w, r, dcol, dlt, nz_dev, cols, nb, d_part.p, st);
+        if (sparse()) { // compressed columns: the gradient goes straight to d_gblk (returns 0: no partials to reduce)
+            launch_panel_step_csc<T>(D->csc<T>(), w, r, dcol, dlt, nz_dev, cols, nb, &d_blk.p->resid_sum, intercept ? cur_xm : nullptr,
+                                     d_gblk.p, st);
+            return 0;
+        }
         if (dense()) return launch_panel_step<T>(D->dense<T>(), w, r, dcol, dlt, nz_dev, cols, nb, d_part.p, st);
         return launch_panel_step_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, r, dcol, dlt, nz_dev, cols, nb,
                                         d_part.p, st);
@@ -52,6 +57,13 @@
     void gram_block_batch(const T* w, const int32_t* cols_base, const SyrkBatch& sb, const T* xm, T* D0, int side) {
         const int B = cd_block_size();
         hipStream_t gs = side == 0 ? st : (side >= 2 ? st_x[side - 2] : st2);
+        if (sparse()) { // compressed columns: one thread per pair of columns merges the two row lists (kernels_sparse.hip)
+            t_gram.begin(gs);
+            launch_block_gram_csc<T>(D->csc<T>(), w, cols_base, sb, xm, intercept, D0, B, gs);
+            t_gram.end(gs);
+            for (int y = 0; y < sb.count; ++y) cnt.n_gram_col_reads += 2 * sb.nb[y];
+            return;
+        }
         T* work = (side == 0 ? d_work_gram : (side >= 2 ? d_work_x[side - 2] : d_work_gram2))
                       .reserve(size_t(std::max(syrk_batch_work_elems(n, sb.count), syrk_work_elems(n, 128))));
         t_gram.begin(gs);

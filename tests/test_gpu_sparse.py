@@ -316,12 +316,14 @@ def test_cv_grpnet_on_a_kept_sparse_design(hip):
     assert a.best_idx == b.best_idx
 
 
-@pytest.mark.parametrize("view", [False, True])
-def test_irls_keeps_the_gram_of_a_sparse_design_under_small_weight_drift(hip, oracle, monkeypatch, view):
-    """IRLS on the full-Gram engines (a design kept sparse, or its standardized view, with groups of several / no intercept
-    excluded): the screen set's Gram is kept while the weights drift by at most 10 % (the rule of the panel engines' blocks)
-    and every pass starts from the exact gradient of the current residual, so the fixed point is the exact one.  Against the
-    oracle, against always-rebuild (ADELIE_HIP_IRLS_REUSE=0), and the saved Gram work by counter."""
+@pytest.mark.parametrize("engine", ["gram_sparse", "gram_view", "panel_sparse"])
+def test_irls_on_a_sparse_design_reuses_its_blocks_under_small_weight_drift(hip, oracle, monkeypatch, engine):
+    """IRLS on a design kept sparse.  Groups of one on the plain matrix: the panel engine over compressed columns (step over
+    the stored entries, 64-visit diagonal blocks by row-list merges; ADELIE_HIP_SPARSE_PANEL=0 keeps the full-Gram engines).
+    Full-Gram engines (that hook, or a standardized view with no intercept): the screen set's Gram is kept while the weights
+    drift by at most 10 % (the rule of the panel blocks) and every pass starts from the exact gradient of the current residual,
+    so the fixed point is the exact one.  Against the oracle, against always-rebuild (ADELIE_HIP_IRLS_REUSE=0), and the saved
+    work by counter."""
     rng = np.random.RandomState(5)
     n, p = 900, 400
     D, y = _problem(rng, n, p, 0.08, k=25)
@@ -329,11 +331,13 @@ def test_irls_keeps_the_gram_of_a_sparse_design_under_small_weight_drift(hip, or
     X = _csc(sp.csc_matrix(D))
     Xd = D
     kw = dict(tol=1e-12, irls_tol=1e-12, early_exit=False, lmda_path_size=20, min_ratio=5e-2, progress_bar=False)
-    if view:   # elastic net without an intercept: stays on the view's own (full-Gram) engines
+    if engine == "gram_view":   # elastic net without an intercept: stays on the view's own (full-Gram) engines
         X = ad.matrix.standardize(X)
         Xd = (D - D.mean(axis=0)) / D.std(axis=0)
         kw.update(alpha=0.7, intercept=False)
-    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")   # the multi-CU block passes from the first screen value on
+    if engine == "gram_sparse":
+        monkeypatch.setenv("ADELIE_HIP_SPARSE_PANEL", "0")
+    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")   # the multi-CU engines from the first screen value on
     a = ad.grpnet(X, ad.glm.binomial(yb), **kw)
     monkeypatch.setenv("ADELIE_HIP_IRLS_REUSE", "0")
     b = ad.grpnet(X, ad.glm.binomial(yb), **kw)
@@ -341,7 +345,10 @@ def test_irls_keeps_the_gram_of_a_sparse_design_under_small_weight_drift(hip, or
     o = ad.grpnet(oracle.dense(np.asfortranarray(Xd)), ad.glm.binomial(yb), **kw)
     assert a.error == "" and b.error == "" and o.error == ""
     assert a.counters["n_irls_iters"] > 30
-    assert a.timers["gram_flops"] < 0.7 * b.timers["gram_flops"]            # Grams were kept
+    if engine == "panel_sparse":
+        assert a.counters["n_panel_blocks"] > 0 and a.counters["n_panel_grams"] < 0.7 * b.counters["n_panel_grams"]
+    else:
+        assert a.counters["n_panel_blocks"] == 0 and a.timers["gram_flops"] < 0.7 * b.timers["gram_flops"]   # Grams were kept
     # (a kept Gram couples the coordinates of a pass approximately: the passes contract more slowly and stop, by the same rule,
     # a little further from the common fixed point: 2e-7 here)
     assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-6

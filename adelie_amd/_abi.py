@@ -159,7 +159,7 @@ S = dict(
 HIP_SYMBOLS = [
     "abi_version", "last_error", "device_count", "set_config",
     "design_create_dense", "design_create_sparse", "design_create_csc", "design_create_standardized", "design_adopt_dense_dev", "design_create_snp_unphased",
-    "design_create_snp_calldata", "design_create_snp_bed", "design_alias", "design_create_multi", "design_create_derived", "design_create_concat", "design_impute", "design_destroy",
+    "design_create_snp_calldata", "design_create_snp_bed", "design_alias", "design_create_slice", "design_create_multi", "design_create_derived", "design_create_concat", "design_impute", "design_destroy",
     "design_glm_path_losses", "design_multi_path_losses", "design_batch_stats", "design_rows", "design_cols", "design_dtype",
     "design_device", "design_stream",
     "design_cmul", "design_ctmul", "design_bmul", "design_btmul", "design_mul", "design_mul_batch", "design_cov",
@@ -230,6 +230,7 @@ class Backend:
         sig("design_create_snp_bed", ci, [vp, i64, i64, i64, ci, ci, p(vp)])
         sig("design_impute", ci, [vp, vp])
         sig("design_alias", ci, [vp, p(vp)])
+        sig("design_create_slice", ci, [vp, i64, i64, i64, i64, p(vp)])
         sig("design_batch_stats", ci, [vp, p(dbl)])
         sig("design_create_multi", ci, [vp, i64, ci, p(vp)])
         sig("design_create_derived", ci, [vp, vp, i64, vp, i64, vp, vp, p(vp)])

@@ -1169,6 +1169,33 @@ int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out) {
     ABI_CATCH
 }
 
+int adelie_hip_design_create_slice(adelie_hip_design* base, int64_t r0, int64_t nr, int64_t c0, int64_t nc,
+                                   adelie_hip_design** out) {
+    ABI_TRY
+    if (!base || !out) throw make_core_error("null argument.");
+    if ((base->kind != 0 && base->kind != 1) || base->cov || base->std_center)
+        throw make_core_error("only dense and 2-bit SNP designs are sliced in place.");
+    if (r0 < 0 || nr < 1 || c0 < 0 || nc < 1 || r0 + nr > base->n || c0 + nc > base->p)
+        throw make_core_error("slice out of range.");
+    const int64_t es = base->dtype == ADELIE_HIP_F64 ? 8 : 4;
+    if (base->kind == 1 && (r0 != 0 || nr != base->n)) throw make_core_error("a 2-bit design is sliced by columns only.");
+    if (base->kind == 0 && (r0 * es) % 16 != 0) throw make_core_error("a row slice must start on a 16-byte boundary.");
+    adelie_hip_design* d = new_design(nr, nc, base->dtype, base->device); // own stream, own scratch
+    d->kind = base->kind;
+    d->owned = false;
+    d->alias = true; // never frees what it points into
+    if (base->kind == 0) {
+        d->X = static_cast<char*>(base->X) + (c0 * base->ld + r0) * es;
+        d->ld = base->ld;
+    } else {
+        d->bits = base->bits + c0 * base->ldb;
+        d->ldb = base->ldb;
+        d->impute = static_cast<char*>(base->impute) + c0 * es;
+    }
+    *out = d;
+    ABI_CATCH
+}
+
 int adelie_hip_design_create_multi(adelie_hip_design* base, int64_t K, int intercept, adelie_hip_design** out) {
     ABI_TRY
     if (!base || !out) throw make_core_error("null argument.");

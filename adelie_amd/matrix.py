@@ -1040,11 +1040,45 @@ def subset(mat, indices, *, axis: int = 0, n_threads: int = 1):
     indices = np.asarray(indices)
     if indices.dtype == bool:
         indices = np.flatnonzero(indices)
+    if axis not in (0, 1):
+        raise RuntimeError("axis must be 0 or 1.")
+    view = _slice_view(mat, indices, axis, n_threads)
+    if view is not None:
+        return view
     if axis == 0:
         return _derived(mat, indices, None, None, None, n_threads)
     if axis == 1:
         return _derived(mat, None, indices, None, None, n_threads)
     raise RuntimeError("axis must be 0 or 1.")
+
+
+def _slice_view(mat, indices, axis, n_threads):
+    """A contiguous ascending index range of a resident dense (either axis; rows from a 16-byte boundary) or 2-bit SNP design
+    (columns) as a design that SHARES the matrix (``adelie_hip_design_create_slice``) -- the reference's ``subset`` is a lazy
+    wrapper too (``matrix_naive_subset.ipp``); ``None`` when the range or the design does not allow it (the caller copies)."""
+    if (not isinstance(mat, _NativeMatrix) or isinstance(mat, (_MultiView, _StdView)) or _is_kept_sparse(mat)
+            or getattr(mat, "_kind", None) not in ("dense", "snp") or isinstance(mat, (MatrixCovBase64, MatrixCovBase32))):
+        return None
+    idx = np.asarray(indices)
+    if idx.ndim != 1 or idx.size == 0 or not np.issubdtype(idx.dtype, np.integer):
+        return None
+    if idx.size > 1 and not np.all(np.diff(idx) == 1):
+        return None
+    i0, cnt = int(idx[0]), int(idx.size)
+    size = mat.rows() if axis == 0 else mat.cols()
+    if i0 < 0 or i0 + cnt > size:
+        return None   # (the copying route raises the reference's out-of-range error)
+    if axis == 0 and (mat._kind != "dense" or (i0 * np.dtype(mat.dtype).itemsize) % 16 != 0):
+        return None
+    backend = mat._backend
+    if not backend.has("design_create_slice"):
+        return None
+    handle = _abi.C.c_void_p()
+    r0, nr, c0, nc = (i0, cnt, 0, mat.cols()) if axis == 0 else (0, mat.rows(), i0, cnt)
+    backend.check(backend.fn("design_create_slice")(mat._handle, r0, nr, c0, nc, handle))
+    out = _wrap(backend, handle, mat.dtype, n_threads, keep=mat, kind=mat._kind)
+    out._slice_of = mat
+    return out
 
 
 def snp_plink(prefix, *, dtype=np.float64, n_threads: int = 1, device: int = 0):

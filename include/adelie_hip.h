@@ -128,6 +128,13 @@ int adelie_hip_design_create_snp_bed(const void* bed, int64_t n_bytes, int64_t n
  * (the folds of cv_grpnet) can run concurrently from different host threads: one path leaves most of the chip idle
  * while its sequential block solves run, two or three paths interleave.  The alias must be destroyed before `src`. */
 int adelie_hip_design_alias(adelie_hip_design* src, adelie_hip_design** out);
+/* A rectangular slice  base[r0 : r0 + nr, c0 : c0 + nc]  as a design that SHARES the resident matrix (nothing is copied; own
+ * stream and scratch; must be destroyed before `base`): what adelie.matrix.subset gives for a contiguous index range
+ * (matrix_naive_subset.ipp wraps lazily as well; matrix.py:1538-1640).  Dense designs: any column range, row ranges that start on
+ * a 16-byte boundary (r0 a multiple of 2 in f64, of 4 in f32); 2-bit SNP designs: column ranges over all rows.  Other designs
+ * (sparse, views, covariance matrices) and other ranges are refused: the caller copies (adelie_hip_design_create_derived). */
+int adelie_hip_design_create_slice(adelie_hip_design* base, int64_t r0, int64_t nr, int64_t c0, int64_t nc,
+                                   adelie_hip_design** out);
 /* Shared full-gradient sweeps of concurrent solves on this design and its aliases ("sweep_batch" config above), cumulative
  * since the design was created: out[0] = launches of the K-wide sweep kernel, out[1] = vectors they answered (= the ordinary
  * sweeps saved + launches), out[2] = their HIP-event time in ms on the batcher's stream.  Used by bench.py for the roofline of

@@ -501,3 +501,49 @@ def test_snpdat_decoder_rejects_corrupt_images(hip, tmp_path):
     bad = good.copy()
     bad[1:9] = np.frombuffer(np.uint64(1 << 45).tobytes(), dtype=np.uint8)
     assert attempt(bad) != 0 and b"row / column counts" in b.fn("last_error")()
+
+
+@pytest.mark.parametrize("kind", ["dense", "snp"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_contiguous_subsets_share_the_resident_matrix(hip, oracle, kind, dtype):
+    """matrix.subset over a contiguous index range (reference matrix_naive_subset.ipp: a lazy wrapper): a slice of the resident
+    matrix, nothing copied (adelie_hip_design_create_slice) -- every matrix operation against numpy on the sliced array, a path
+    on the slice against the oracle; other index sets (and row ranges off a 16-byte boundary, rows of a 2-bit design) copy."""
+    rng = np.random.RandomState(3)
+    n, p = 333, 57
+    if kind == "dense":
+        Z = np.asfortranarray(rng.normal(size=(n, p)).astype(dtype))
+        M = ad.matrix.dense(Z)
+    else:
+        cd = rng.choice(np.array([0, 1, 2, -9], dtype=np.int8), size=(n, p), p=[0.5, 0.3, 0.1, 0.1])
+        imp = ad.matrix.compute_impute(cd)
+        Z = np.asfortranarray(np.where(cd < 0, imp[None], cd).astype(dtype))
+        M = ad.matrix.snp_calldata(cd, imp, dtype=dtype)
+    c = ad.matrix.subset(M, np.arange(11, 40), axis=1)
+    assert getattr(c, "_slice_of", None) is M and c._kind == kind and c.shape == (n, 29)
+    run_naive(c, np.asfortranarray(Z[:, 11:40]), dtype)
+    run_naive(ad.matrix.subset(c, np.arange(5, 9), axis=1), np.asfortranarray(Z[:, 16:20]), dtype)   # a slice of a slice
+    one = ad.matrix.subset(M, [p - 1], axis=1)
+    assert getattr(one, "_slice_of", None) is M
+    run_naive(one, np.asfortranarray(Z[:, p - 1:]), dtype)
+    r = ad.matrix.subset(M, np.arange(64, 300), axis=0)
+    if kind == "dense":
+        assert getattr(r, "_slice_of", None) is M
+        assert getattr(ad.matrix.subset(M, np.arange(1, 300), axis=0), "_slice_of", None) is None   # off the boundary: a copy
+    else:
+        assert getattr(r, "_slice_of", None) is None                                                # 2-bit rows: re-packed copy
+    run_naive(r, np.asfortranarray(Z[64:300]), dtype)
+    run_naive(ad.matrix.subset(M, np.arange(1, 300), axis=0), np.asfortranarray(Z[1:300]), dtype)
+    assert getattr(ad.matrix.subset(M, [3, 5, 6], axis=1), "_slice_of", None) is None
+    if dtype == np.float64:
+        Zs = Z[64:300, 11:40] if kind == "dense" else Z[:, 11:40]
+        S = ad.matrix.subset(r, np.arange(11, 40), axis=1) if kind == "dense" else c
+        y = Zs[:, :3] @ np.array([1.0, -2.0, 0.5]) + 0.3 * rng.normal(size=Zs.shape[0])
+        kw = dict(tol=1e-12, early_exit=False, lmda_path_size=12, min_ratio=0.02, progress_bar=False)
+        a = ad.grpnet(S, ad.glm.gaussian(y), **kw)
+        b = ad.grpnet(oracle.dense(np.asfortranarray(Zs)), ad.glm.gaussian(y), **kw)
+        assert a.error == "" and np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-9
+        cvs = ad.cv_grpnet(S, ad.glm.gaussian(y), n_folds=3, seed=0, lmda_path_size=6, min_ratio=0.2, progress_bar=False)
+        cvd = ad.cv_grpnet(ad.matrix.dense(np.asfortranarray(Zs)), ad.glm.gaussian(y), n_folds=3, seed=0, lmda_path_size=6,
+                           min_ratio=0.2, progress_bar=False)
+        assert np.abs(cvs.losses - cvd.losses).max() < 1e-9 * max(1.0, np.abs(cvd.losses).max())

@@ -1207,7 +1207,7 @@
                 if (time_panel) t_step.end(st);
                 pending_slot = -1;
                 cnt.n_panel_cols += nval;
-                launch_panel_reduce<T>(d_part.p, nsl, nval, cols, &d_blk.p->resid_sum, xm_c, d_gblk.p, st);
+                if (nsl > 0) launch_panel_reduce<T>(d_part.p, nsl, nval, cols, &d_blk.p->resid_sum, xm_c, d_gblk.p, st);
                 if (cons_host) { // a block that is one group with a constraint object on the caller's side: visited on the host
                     const idx ss0 = screen_pass ? idx(part_host[size_t(j)]) : act_host[size_t(part_host[size_t(j)])];
                     if (part_host[size_t(j) + 1] - part_host[size_t(j)] == 1 && host_cons(screen_set[ss0])) {

@@ -439,10 +439,10 @@
             rdev_tol = T(a->rdev_tol);
         }
         if (sparse() || std_generic()) engine_panel = false; // Gram engines: C = X_S^T W X_S from launch_gram_csc, residual updated once per fit
-        // ... except IRLS on the plain compressed columns with groups of one: the panel engine's sequential form (step over
+        // ... except IRLS on the plain compressed columns (groups of one, or groups of at most 128): the panel engine's sequential form (step over
         // the stored entries, 64-visit diagonal blocks by row-list merges; kernels_sparse.hip) -- a Gram of the whole screen set
         // per IRLS iteration is what such a path spends its time on otherwise (hook ADELIE_HIP_SPARSE_PANEL=0)
-        if (sparse() && is_glm() && all_scalar && !cov_mode && D->std_center == nullptr && hooks.sparse_panel != 0) engine_panel = true;
+        if (sparse() && is_glm() && !cov_mode && D->std_center == nullptr && hooks.sparse_panel != 0) engine_panel = true;
         if (multi()) {
             // StateMultiGaussianNaive (state.py:2300-2380): the Gaussian naive solver, global intercept off, on the view.
             // Everything runs on the group panel engine (its blocks are what lets a column slice serve K responses).

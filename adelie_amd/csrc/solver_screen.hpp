@@ -81,6 +81,14 @@
         const int B = cd_block_size();
         hipStream_t gs = side == 0 ? st : (side >= 2 ? st_x[side - 2] : st2);
         t_gram.begin(gs);
+        if (sparse()) { // compressed columns (kernels_sparse.hip: LDS hash join per column of the block)
+            SyrkBatch sb{};
+            sb.count = 1; sb.off[0] = 0; sb.nb[0] = nb; sb.dst[0] = 0;
+            launch_block_gram_csc<T>(D->csc<T>(), w, cols, sb, xm, intercept, Dptr, B, gs);
+            t_gram.end(gs);
+            cnt.n_gram_col_reads += 2 * nb;
+            return;
+        }
         if (multi()) {
             // Gram over the block's distinct extended features (MFMA syrk), expanded to the view columns: entries between
             // different responses are zero.  One syrk when all responses carry the same weights (always so for

@@ -65,8 +65,13 @@ for case in range(N):
         glm = ad.glm.poisson(y, weights=w, dtype=dtype)
     kw = dict(early_exit=False, lmda_path_size=int(rng.choice([6, 12])), min_ratio=float(rng.choice([0.2, 0.05])), progress_bar=False,
               alpha=float(rng.choice([1.0, 1.0, 0.5, 0.2])), intercept=bool(rng.uniform() < 0.75))
+    G = p
+    if rng.uniform() < 0.3:   # groups of 2 or 5 coefficients (every p in the draw is a multiple of 10)
+        gsz = int(rng.choice([2, 5]))
+        kw["groups"] = np.arange(0, p, gsz)
+        G = p // gsz
     if rng.uniform() < 0.4:
-        kw["penalty"] = rng.uniform(0.5, 2.0, p).astype(dtype)
+        kw["penalty"] = rng.uniform(0.5, 2.0, G).astype(dtype)
     if rng.uniform() < 0.3:
         kw["offsets"] = (0.1 * rng.normal(size=n)).astype(dtype)
     if dtype == np.float64:
@@ -94,6 +99,6 @@ for case in range(N):
     ok = a.betas.shape[0] == o.betas.shape[0] and db < tol and di < tol
     if not ok:
         bad += 1
-    print(f"case {case}: {'ok ' if ok else 'BAD'} {base_kind:6s} view={int(view)} {fam:8s} {dtype.__name__} n={n} p={p} alpha={kw['alpha']} icpt={int(kw['intercept'])} "
+    print(f"case {case}: {'ok ' if ok else 'BAD'} {base_kind:6s} view={int(view)} {fam:8s} {dtype.__name__} n={n} p={p} alpha={kw['alpha']} icpt={int(kw['intercept'])} groups={len(kw['groups']) if 'groups' in kw else 0} "
           f"force={int(force)} blocks={a.counters['n_panel_blocks']} L={a.betas.shape[0]}/{o.betas.shape[0]} dbeta={db:.1e} dicpt={di:.1e}", flush=True)
 print(f"{bad} bad of {N} in {time.time() - t0:.0f} s")

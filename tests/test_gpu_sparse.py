@@ -316,7 +316,7 @@ def test_cv_grpnet_on_a_kept_sparse_design(hip):
     assert a.best_idx == b.best_idx
 
 
-@pytest.mark.parametrize("engine", ["gram_sparse", "gram_view", "panel_sparse"])
+@pytest.mark.parametrize("engine", ["gram_sparse", "gram_view", "panel_sparse", "panel_sparse_groups"])
 def test_irls_on_a_sparse_design_reuses_its_blocks_under_small_weight_drift(hip, oracle, monkeypatch, engine):
     """IRLS on a design kept sparse.  Groups of one on the plain matrix: the panel engine over compressed columns (step over
     the stored entries, 64-visit diagonal blocks by row-list merges; ADELIE_HIP_SPARSE_PANEL=0 keeps the full-Gram engines).
@@ -337,6 +337,8 @@ def test_irls_on_a_sparse_design_reuses_its_blocks_under_small_weight_drift(hip,
         kw.update(alpha=0.7, intercept=False)
     if engine == "gram_sparse":
         monkeypatch.setenv("ADELIE_HIP_SPARSE_PANEL", "0")
+    if engine == "panel_sparse_groups":   # the group panel engine on compressed columns (blocks of whole groups, eigenbases per IRLS iteration)
+        kw.update(groups=np.arange(0, p, 4), alpha=0.8)
     monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")   # the multi-CU engines from the first screen value on
     a = ad.grpnet(X, ad.glm.binomial(yb), **kw)
     monkeypatch.setenv("ADELIE_HIP_IRLS_REUSE", "0")
@@ -345,7 +347,9 @@ def test_irls_on_a_sparse_design_reuses_its_blocks_under_small_weight_drift(hip,
     o = ad.grpnet(oracle.dense(np.asfortranarray(Xd)), ad.glm.binomial(yb), **kw)
     assert a.error == "" and b.error == "" and o.error == ""
     assert a.counters["n_irls_iters"] > 30
-    if engine == "panel_sparse":
+    if engine == "panel_sparse_groups":
+        assert a.counters["n_panel_blocks"] > 0   # (blocks of groups are rebuilt with their eigenbases per IRLS iteration)
+    elif engine == "panel_sparse":
         assert a.counters["n_panel_blocks"] > 0 and a.counters["n_panel_grams"] < 0.7 * b.counters["n_panel_grams"]
     else:
         assert a.counters["n_panel_blocks"] == 0 and a.timers["gram_flops"] < 0.7 * b.timers["gram_flops"]   # Grams were kept

@@ -76,6 +76,8 @@ for case in range(N):
         kw["offsets"] = (0.1 * rng.normal(size=n)).astype(dtype)
     if dtype == np.float64:
         kw.update(tol=1e-12, irls_tol=1e-12)
+    else:
+        kw.update(newton_tol=1e-5)   # (the default 1e-12 is unreachable in single precision: the root find of a group would end in its error)
     force = rng.uniform() < 0.5
     if force:
         os.environ["ADELIE_HIP_CD_BLOCK_MIN_NV"] = "1"

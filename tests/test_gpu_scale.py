@@ -207,3 +207,43 @@ def test_sparse_resident_design_at_scale(hip):
     za = ad.grpnet(ad.matrix.standardize(Xs), ad.glm.gaussian(y), **kw)
     zb = ad.grpnet(ad.matrix.standardize(Xd), ad.glm.gaussian(y), **kw)
     assert za.error == "" and np.abs(za.betas.toarray() - zb.betas.toarray()).max() < 1e-9
+
+
+def test_sparse_resident_binomial_at_scale(hip):
+    """IRLS on a design kept sparse runs the panel engine over compressed columns (kernels_sparse.hip).  At a size where the
+    screen set spans hundreds of 64-visit blocks: the 60-lambda binomial path equals the one on the expanded dense copy (the
+    dense panel engine: other kernels, other summation order) to the stopping rules' resolution, and is certified on the sparse
+    design itself: monotone deviance, intercept stationarity, the lasso KKT conditions of the binomial deviance."""
+    import scipy.sparse as sp
+
+    n, p, dens = 300_000, 8_000, 0.004
+    rng = np.random.default_rng(5)
+    nnz = int(n * p * dens)
+    M = sp.csc_matrix((rng.standard_normal(nnz), (rng.integers(0, n, size=nnz), rng.integers(0, p, size=nnz))), shape=(n, p))
+    M.sum_duplicates()
+    M.sort_indices()
+    beta = np.zeros(p)
+    beta[rng.choice(p, 400, replace=False)] = rng.standard_normal(400)
+    eta = M @ beta
+    y = (rng.uniform(size=n) < 1 / (1 + np.exp(-eta / eta.std()))).astype(np.float64)
+    Xs = ad.matrix.sparse(M, resident="csc")
+    Xd = ad.matrix.sparse(M, resident="dense")
+    kw = dict(early_exit=False, lmda_path_size=60, min_ratio=2e-2, tol=1e-10, irls_tol=1e-10, progress_bar=False)
+    a = ad.grpnet(Xs, ad.glm.binomial(y), **kw)
+    b = ad.grpnet(Xd, ad.glm.binomial(y), **kw)
+    assert a.error == "" and b.error == "" and len(a.lmdas) == 60
+    assert a.counters["n_panel_blocks"] > 1000 and a.active_set_size > 2000
+    assert np.array_equal(a.betas.toarray() != 0, b.betas.toarray() != 0)
+    assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-7 and np.abs(a.intercepts - b.intercepts).max() < 1e-7
+    assert np.all(np.diff(a.lmdas) < 0) and np.all(np.diff(a.devs) >= -1e-9)
+    w = np.full(n, 1 / n)
+    for l in [10, 40, 59]:
+        bl = a.betas[l].toarray().ravel()
+        e = (M @ bl) + a.intercepts[l]
+        resid = w * (y - 1 / (1 + np.exp(-e)))
+        assert abs(resid.sum()) < 1e-9                      # intercept stationarity
+        grad = M.T @ resid                                  # (scipy: independent of every device kernel)
+        lm = a.lmdas[l]
+        zero = bl == 0
+        assert (np.abs(grad[zero]) - lm).max() / lm < 1e-4
+        assert np.abs(grad[~zero] - lm * np.sign(bl[~zero])).max() / lm < 1e-3

@@ -18,7 +18,7 @@
 namespace ahip {
 
 // ---- every environment hook of libadelie_hip.so, in one place ------------------------------------------------------------------
-// Ten variables.  They are read when a solve starts (Hooks::from_env, one call per solve): the tests force the multi-CU engines
+// Eleven variables.  They are read when a solve starts (Hooks::from_env, one call per solve): the tests force the multi-CU engines
 // at sizes the CPU checker finishes in seconds and compare variants between two solves of ONE process, so reading them once at
 // library load would freeze the first test's setting.  None changes results beyond rounding.  (Python side: ADELIE_HIP_LIB picks
 // another build of this library, ADELIE_HIP_SWEEP_BATCH=0 keeps concurrent CV folds from sharing their sweeps.)
@@ -31,12 +31,14 @@ namespace ahip {
 //   ADELIE_HIP_CONS_HOST=1        box / one-sided constraint objects visited on the host instead of kernels_cons.hip  [A/B, tests]
 //   ADELIE_HIP_GROUP_NEXT_CORR=0  group look-ahead: the next block's correction formed by its own solve              [A/B]
 //   ADELIE_HIP_SPARSE_PANEL=0     IRLS on a design kept sparse on the full-Gram engines instead of the panel engine    [A/B, tests]
+//   ADELIE_HIP_STD_PANEL=0        standardized dense / 2-bit views on their full-Gram engines instead of the panel engines [A/B, tests]
 //   ADELIE_HIP_TIME_PANEL=1       per-launch HIP events around the panel step (bench.py's roofline leg)
 //   ADELIE_HIP_TRACE=1|2          1: per-pass trace on stderr; 2: + enqueue / allocation / build timings
 struct Hooks {
     long long cd_block_min_nv = -1; // -1: unset
     int panel_bsz = 0;
-    int sparse_panel = -1;   // ADELIE_HIP_SPARSE_PANEL=0: IRLS on a design kept sparse stays on the full-Gram engines      [A/B hook]
+    int sparse_panel = -1;
+    int std_panel = -1;      // ADELIE_HIP_STD_PANEL=0: a standardized dense / 2-bit view stays on its full-Gram engines            [A/B hook]   // ADELIE_HIP_SPARSE_PANEL=0: IRLS on a design kept sparse stays on the full-Gram engines      [A/B hook]
     int lookahead = -1, speculate = -1;
     double irls_reuse = -1;
     bool time_panel = false;
@@ -57,6 +59,7 @@ struct Hooks {
         if (const char* e = std::getenv("ADELIE_HIP_CONS_HOST")) h.cons_host = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_GROUP_NEXT_CORR")) h.group_next_corr = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_SPARSE_PANEL")) h.sparse_panel = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_STD_PANEL")) h.std_panel = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_TRACE")) h.trace = std::max(1, std::atoi(e));
         return h;
     }

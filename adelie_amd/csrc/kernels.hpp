@@ -82,6 +82,14 @@ template <class T>
 void launch_std_scale_coef(const T* center, const T* inv_scale, const int32_t* cols, const T* coef, const int32_t* count_dev,
                            int32_t count, T* coef2, T* kappa, hipStream_t s);
 template <class T> void launch_vec_shift(T* out, int64_t n, const T* kappa, T sign, const int32_t* count_dev, hipStream_t s);
+// panel engine on a standardized view: a block's gradient from the raw sums, a batch of diagonal blocks from the raw X' W X
+template <class T>
+void launch_std_fix_gblk(T* gblk, const int32_t* cols, int nb, const T* center, const T* inv_scale, const T* rsum_dev,
+                         const T* xm_view_or_null, hipStream_t s);
+struct SyrkBatch;
+template <class T>
+void launch_std_block_fix(T* D0, const SyrkBatch& sb, const int32_t* cols_base, int ldb, const T* center, const T* inv_scale,
+                          const T* xm_view, const T* wsum_dev, bool centered, hipStream_t s);
 // tile-major copy of a sparse design (see CscView): from the per-column tile pointers colptr[c * (nt + 1) + t] (what
 // launch_csc_block_ptr gives with rb = th) and the tile-major offsets tptr, the entries are copied to their places
 template <class T>

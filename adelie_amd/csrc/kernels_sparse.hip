@@ -464,6 +464,62 @@ __global__ __launch_bounds__(256) void vec_shift_kernel(T* __restrict__ out, int
 }
 } // namespace
 
+namespace {
+// Panel engine on a standardized view (Solver::panel_step / gram_block*): the gradient of a block from the raw partial sums,
+//   g~_c = (raw_c - center_c * rsum) * inv_scale_c - rsum * xbar~_c        (rsum = sum_i w_i r_i, tracked by the solves)
+// and a diagonal block from the raw X_b' W X_b of the base design (m_c = sum_i w_i x_ic = xbar~_c / inv_scale_c + center_c W),
+//   D~_ab = (G_ab - center_a m_b - m_a center_b + center_a center_b W) inv_scale_a inv_scale_b - xbar~_a xbar~_b
+// (the last term of either only with an intercept).
+template <class T>
+__global__ __launch_bounds__(128) void std_fix_gblk_kernel(T* __restrict__ gblk, const int32_t* __restrict__ cols, int nb,
+                                                           const T* __restrict__ center, const T* __restrict__ inv_scale,
+                                                           const T* __restrict__ rsum, const T* __restrict__ xm_view) {
+    const int a = threadIdx.x;
+    if (a >= nb) return;
+    const int32_t c = cols[a];
+    const T rs = rsum[0];
+    T g = (gblk[a] - center[c] * rs) * inv_scale[c];
+    if (xm_view) g -= rs * xm_view[c];
+    gblk[a] = g;
+}
+template <class T>
+__global__ __launch_bounds__(256) void std_block_fix_kernel(T* __restrict__ D0, SyrkBatch sb, const int32_t* __restrict__ cols_base,
+                                                            int ldb, const T* __restrict__ center, const T* __restrict__ inv_scale,
+                                                            const T* __restrict__ xm_view, const T* __restrict__ wsum, int centered) {
+    const int y = blockIdx.y, nb = sb.nb[y];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nb * nb) return;
+    const int a = t % nb, b = t / nb;
+    if (a < b) return; // (lower triangle incl. the diagonal, mirrored)
+    const int32_t* cols = cols_base + sb.off[y];
+    const int32_t ca = cols[a], cb = cols[b];
+    const T W = wsum[0];
+    const T ia = inv_scale[ca], ib = inv_scale[cb], ea = center[ca], eb = center[cb];
+    const T ma = xm_view[ca] / ia + ea * W, mb = xm_view[cb] / ib + eb * W;
+    T* D = D0 + sb.dst[y];
+    T v = (((D[a + int64_t(b) * ldb] - ea * mb) - ma * eb) + ea * eb * W) * (ia * ib);
+    if (centered) v -= xm_view[ca] * xm_view[cb];
+    D[a + int64_t(b) * ldb] = v;
+    D[b + int64_t(a) * ldb] = v;
+}
+} // namespace
+template <class T>
+void launch_std_fix_gblk(T* gblk, const int32_t* cols, int nb, const T* center, const T* inv_scale, const T* rsum_dev,
+                         const T* xm_view_or_null, hipStream_t s) {
+    if (nb <= 0) return;
+    hipLaunchKernelGGL((std_fix_gblk_kernel<T>), dim3(1), dim3(128), 0, s, gblk, cols, nb, center, inv_scale, rsum_dev, xm_view_or_null);
+}
+template <class T>
+void launch_std_block_fix(T* D0, const SyrkBatch& sb, const int32_t* cols_base, int ldb, const T* center, const T* inv_scale,
+                          const T* xm_view, const T* wsum_dev, bool centered, hipStream_t s) {
+    if (sb.count <= 0) return;
+    int mx = 0;
+    for (int y = 0; y < sb.count; ++y) mx = std::max(mx, int(sb.nb[y]));
+    if (mx <= 0) return;
+    hipLaunchKernelGGL((std_block_fix_kernel<T>), dim3(unsigned((mx * mx + 255) / 256), unsigned(sb.count)), dim3(256), 0, s, D0, sb,
+                       cols_base, ldb, center, inv_scale, xm_view, wsum_dev, centered ? 1 : 0);
+}
+
 template <class T>
 void launch_vec_sum(const T* v, int64_t n, T* out, hipStream_t s) {
     hipLaunchKernelGGL((vec_sum_kernel<T>), dim3(256), dim3(256), 0, s, v, n, out, 0);
@@ -808,7 +864,10 @@ void launch_sp_tmul_csc(const CscView<T>& X, int64_t L, const int64_t* indptr, c
                                          const T*, const T*, bool, hipStream_t);                                                 \
     template void launch_std_scale_coef<T>(const T*, const T*, const int32_t*, const T*, const int32_t*, int32_t, T*, T*,         \
                                            hipStream_t);                                                                         \
-    template void launch_vec_shift<T>(T*, int64_t, const T*, T, const int32_t*, hipStream_t);
+    template void launch_vec_shift<T>(T*, int64_t, const T*, T, const int32_t*, hipStream_t);                                     \
+    template void launch_std_fix_gblk<T>(T*, const int32_t*, int, const T*, const T*, const T*, const T*, hipStream_t);           \
+    template void launch_std_block_fix<T>(T*, const SyrkBatch&, const int32_t*, int, const T*, const T*, const T*, const T*, bool, \
+                                          hipStream_t);
 INST(double)
 INST(float)
 #undef INST

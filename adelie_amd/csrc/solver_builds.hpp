@@ -548,7 +548,7 @@
         }
         return strip_pool[strip_used++];
     }
-    bool strips_apply() const { return strip_builds && dense() && !is_glm(); }
+    bool strips_apply() const { return strip_builds && dense() && !is_glm() && D->std_center == nullptr; }
     // `rot_dst` != nullptr (group passes with CdGrpBlkParams::rot): `pool` holds the blocks in the design's own coordinates
     // (d_Draw: what the strips extend), and every block a strip touched is rotated into the eigen-coordinates of its groups
     // right behind it on the same stream, out of place into rot_dst (the pool the solves read), over the visiting list `rlist`.

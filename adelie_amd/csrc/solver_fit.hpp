@@ -63,7 +63,7 @@
         Stopwatch sw;
         sw.start();
         bool small_fit = false; // the whole pin solve ran in the single-workgroup kernel (its scalars are in d_sc)
-        open_from_grad = grad_fresh && open_from_grad_opt && !is_glm() && !cov_mode && r_dev == d_r.p && !resume;
+        open_from_grad = grad_fresh && open_from_grad_opt && !is_glm() && !cov_mode && r_dev == d_r.p && !resume && !std_generic();
         grad_fresh = false; // (whatever engine runs, the residual moves)
         if (!(nv > 0 && panel_mode() && !all_scalar)) join_uv(); // (only the group panel passes know which of them need it)
         if (nv > 0 && panel_mode()) {

@@ -198,7 +198,7 @@
         bool screen_prebuilt = false;
         // look-ahead only under fixed weights: the cross blocks are built once per block pair and re-used for the rest of the
         // path; under IRLS they would double the MFMA work of every iteration
-        const bool la = lookahead && !is_glm() && B == SL;
+        const bool la = lookahead && !is_glm() && B == SL && !std_generic() && !sparse();
         if (la) {
             if (xscr_key.size() != maxblk) {
                 d_Xpool.reserve(size_t(2) * maxblk * SL * SL);
@@ -425,7 +425,7 @@
                 const int nsl = (j == 0) ? nsl0 : step_of(j);
                 pending_slot = -1;
                 cnt.n_panel_cols += nb;
-                if (nsl > 0) launch_panel_reduce<T>(d_part.p, nsl, nb, cols, &d_blk.p->resid_sum, xm_c, d_gblk.p, st);
+                panel_reduce(nsl, nb, cols, xm_c, d_gblk.p);
                 bp.Dptr = Dptr;
                 if (h_report && j == nblk - 1) {
                     bp.report_j = j;
@@ -902,7 +902,7 @@
         std::vector<idx> act_host(active_set.begin(), active_set.begin() + asz); // host mirror of the active list
         std::vector<int32_t>& acols = h_actcols;
         // look-ahead form (see run_panel_passes); not on the multi-response view, whose step is a different kernel
-        const bool la = lookahead && !is_glm() && (!multi() || multi_w_uniform);
+        const bool la = lookahead && !is_glm() && (!multi() || multi_w_uniform) && !std_generic() && !sparse();
         if (la) {
             if (xscr_key.size() != maxblk) {
                 d_Xpool.reserve(size_t(2) * maxblk * SL * SL);
@@ -1207,7 +1207,7 @@
                 if (time_panel) t_step.end(st);
                 pending_slot = -1;
                 cnt.n_panel_cols += nval;
-                if (nsl > 0) launch_panel_reduce<T>(d_part.p, nsl, nval, cols, &d_blk.p->resid_sum, xm_c, d_gblk.p, st);
+                panel_reduce(nsl, nval, cols, xm_c, d_gblk.p);
                 if (cons_host) { // a block that is one group with a constraint object on the caller's side: visited on the host
                     const idx ss0 = screen_pass ? idx(part_host[size_t(j)]) : act_host[size_t(part_host[size_t(j)])];
                     if (part_host[size_t(j) + 1] - part_host[size_t(j)] == 1 && host_cons(screen_set[ss0])) {

@@ -443,6 +443,14 @@
         // the stored entries, 64-visit diagonal blocks by row-list merges; kernels_sparse.hip) -- a Gram of the whole screen set
         // per IRLS iteration is what such a path spends its time on otherwise (hook ADELIE_HIP_SPARSE_PANEL=0)
         if (sparse() && is_glm() && !cov_mode && D->std_center == nullptr && hooks.sparse_panel != 0) engine_panel = true;
+        // ... and a standardized view of a dense / 2-bit design: the panel engines' sequential form on the BASE design's columns
+        // with the view's corrections around every step (changes over the scales + kappa off every row before it, the block's
+        // gradient and the diagonal blocks corrected from the raw sums behind it; kernels_sparse.hip), no look-ahead, no
+        // speculation (hook ADELIE_HIP_STD_PANEL=0: the view's full-Gram engines)
+        if (std_generic() && !cov_mode && hooks.std_panel != 0) {
+            engine_panel = true;
+            spec_enabled = false;
+        }
         if (multi()) {
             // StateMultiGaussianNaive (state.py:2300-2380): the Gaussian naive solver, global intercept off, on the view.
             // Everything runs on the group panel engine (its blocks are what lets a column slice serve K responses).

@@ -48,9 +48,42 @@
                                      d_gblk.p, st);
             return 0;
         }
-        if (dense()) return launch_panel_step<T>(D->dense<T>(), w, r, dcol, dlt, nz_dev, cols, nb, d_part.p, st);
-        return launch_panel_step_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, r, dcol, dlt, nz_dev, cols, nb,
-                                        d_part.p, st);
+        const T* kappa = nullptr;
+        if (std_generic()) { // the changes over the scales into the base design's step, then kappa = sum c delta / s off every row
+            T* c2 = d_std_coef.reserve(size_t(cd_block_size()) + 16);
+            T* kp = c2 + cd_block_size();
+            launch_std_scale_coef<T>(static_cast<const T*>(D->std_center), static_cast<const T*>(D->std_iscale), dcol, dlt, nz_dev, 0, c2,
+                                     kp, st);
+            dlt = c2;
+            kappa = kp;
+            // (before the step: its phase (B) must see the residual with the whole change applied)
+            launch_vec_shift<T>(r, n, kappa, T(-1), nz_dev, st);
+        }
+        const int nsl = dense() ? launch_panel_step<T>(D->dense<T>(), w, r, dcol, dlt, nz_dev, cols, nb, d_part.p, st)
+                                : launch_panel_step_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, r, dcol, dlt, nz_dev, cols,
+                                                           nb, d_part.p, st);
+        (void)kappa;
+        return nsl;
+    }
+    // slice partials -> gradient of the block; on a standardized view the raw sums are corrected (kernels_sparse.hip)
+    void panel_reduce(int nsl, int nb, const int32_t* cols, const T* xm_c, T* gblk) {
+        if (nsl <= 0) return; // (compressed columns: the step wrote the gradient itself)
+        if (!std_generic()) {
+            launch_panel_reduce<T>(d_part.p, nsl, nb, cols, &d_blk.p->resid_sum, xm_c, gblk, st);
+            return;
+        }
+        launch_panel_reduce<T>(d_part.p, nsl, nb, cols, &d_blk.p->resid_sum, static_cast<const T*>(nullptr), gblk, st);
+        launch_std_fix_gblk<T>(gblk, cols, nb, static_cast<const T*>(D->std_center), static_cast<const T*>(D->std_iscale),
+                               &d_blk.p->resid_sum, xm_c, st);
+    }
+    // standardized view: the blocks of a batch from the raw X' W X just built on stream gs (sum of the weights per call: two tiny
+    // launches; one scratch per build stream)
+    DevBuf<T> d_std_ws[2 + kMaxExtra + 1];
+    void std_block_fix(const T* w, const int32_t* cols_base, const SyrkBatch& sb, const T* xm_view, T* D0, int side, hipStream_t gs) {
+        T* ws = d_std_ws[side].reserve(size_t(kVecSumScratch) + 8);
+        launch_vec_sum<T>(w, n, ws, gs);
+        launch_std_block_fix<T>(D0, sb, cols_base, cd_block_size(), static_cast<const T*>(D->std_center),
+                                static_cast<const T*>(D->std_iscale), xm_view, ws, intercept, gs);
     }
     // `sb.count` diagonal blocks in one launch (non-multi designs): block y = columns cols_base[sb.off[y] ...], into
     // D0 + sb.dst[y] (ld = B)
@@ -67,8 +100,10 @@
         T* work = (side == 0 ? d_work_gram : (side >= 2 ? d_work_x[side - 2] : d_work_gram2))
                       .reserve(size_t(std::max(syrk_batch_work_elems(n, sb.count), syrk_work_elems(n, 128))));
         t_gram.begin(gs);
-        if (dense()) launch_syrk_batch<T>(D->dense<T>(), w, cols_base, sb, xm, intercept, D0, B, work, gs);
-        else launch_syrk_batch_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols_base, sb, xm, intercept, D0, B, work, gs);
+        const bool stdv = std_generic(); // raw X' W X of the base design, then the view's corrections (kernels_sparse.hip)
+        if (dense()) launch_syrk_batch<T>(D->dense<T>(), w, cols_base, sb, xm, intercept && !stdv, D0, B, work, gs);
+        else launch_syrk_batch_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols_base, sb, xm, intercept && !stdv, D0, B, work, gs);
+        if (stdv) std_block_fix(w, cols_base, sb, xm, D0, side, gs);
         t_gram.end(gs);
         for (int y = 0; y < sb.count; ++y) {
             const int nb = sb.nb[y];
@@ -119,8 +154,14 @@
         }
         {   // lower-triangle MFMA tiles only: 10 of 16 (nb <= 64) or 36 of 64
             T* work = (side == 0 ? d_work_gram : (side >= 2 ? d_work_x[side - 2] : d_work_gram2)).reserve(size_t(syrk_work_elems(n, 128)));
-            if (dense()) launch_syrk<T>(D->dense<T>(), w, cols, nb, xm, intercept, Dptr, B, work, gs);
-            else launch_syrk_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols, nb, xm, intercept, Dptr, B, work, gs);
+            const bool stdv = std_generic();
+            if (dense()) launch_syrk<T>(D->dense<T>(), w, cols, nb, xm, intercept && !stdv, Dptr, B, work, gs);
+            else launch_syrk_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols, nb, xm, intercept && !stdv, Dptr, B, work, gs);
+            if (stdv) {
+                SyrkBatch sb{};
+                sb.count = 1; sb.off[0] = 0; sb.nb[0] = nb; sb.dst[0] = 0;
+                std_block_fix(w, cols, sb, xm, Dptr, side, gs);
+            }
             cnt.gram_flops += 2.0 * double(n) * 256.0 * (nb <= 32 ? 3.0 : (nb <= 64 ? 10.0 : 36.0));
         }
         t_gram.end(gs);

@@ -33,6 +33,10 @@ X.btmul(0, p, beta, eta)
 y = eta + float(os.environ.get("NOISE", "1.0")) * np.std(eta) * rng.normal(size=n)
 alpha = float(os.environ.get("ALPHA", "1"))
 kw = dict(lmda_path_size=L, min_ratio=float(os.environ.get("MIN_RATIO", "2e-2")), early_exit=False, progress_bar=False, alpha=alpha)
+if os.environ.get("GROUPS"):        # groups of GROUPS columns / INTERCEPT=0: fits the base-coordinates route cannot take (round 5: panel form of the view)
+    kw["groups"] = np.arange(0, p, int(os.environ["GROUPS"]))
+if os.environ.get("INTERCEPT") == "0":
+    kw["intercept"] = False
 if os.environ.get("VIEW_ENGINES"):
     kw["exit_cond"] = lambda state: False
 res = {"workload": f"Gaussian {'lasso' if alpha == 1 else 'elastic net alpha=%g' % alpha} on standardize(snp {n}x{p}), {L} lambdas", "view_engines": bool(os.environ.get("VIEW_ENGINES")), "bytes_2bit": int(n * p / 4), "bytes_dense_copy": int(n * p * 8)}

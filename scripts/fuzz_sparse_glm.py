@@ -92,7 +92,8 @@ for case in range(N):
         continue
     tol = 2e-6 if dtype == np.float64 else 5e-3
     if a.error != o.error:
-        print(f"case {case}: errors differ: {a.error!r} vs {o.error!r}")
+        print(f"case {case}: errors differ: {a.error!r} vs {o.error!r}  ({base_kind} view={view} {fam} {dtype.__name__} n={n} p={p} alpha={kw.get('alpha')} "
+              f"icpt={kw['intercept']} groups={'groups' in kw} force={force} L={a.betas.shape[0]}/{o.betas.shape[0]})")
         bad += 1
         continue
     L = min(a.betas.shape[0], o.betas.shape[0])

@@ -547,3 +547,53 @@ def test_contiguous_subsets_share_the_resident_matrix(hip, oracle, kind, dtype):
         cvd = ad.cv_grpnet(ad.matrix.dense(np.asfortranarray(Zs)), ad.glm.gaussian(y), n_folds=3, seed=0, lmda_path_size=6,
                            min_ratio=0.2, progress_bar=False)
         assert np.abs(cvs.losses - cvd.losses).max() < 1e-9 * max(1.0, np.abs(cvd.losses).max())
+
+
+@pytest.mark.parametrize("kind", ["dense", "snp"])
+def test_standardized_view_on_the_panel_engines(hip, oracle, monkeypatch, kind):
+    """Grouped and no-intercept fits on a lazily standardized view (what solver._lasso_in_raw_coordinates cannot re-express on
+    the base design) run the panel engines on the BASE design's columns with the view's corrections around every step: the
+    changes over the scales and kappa off every row before it, the block's gradient and the diagonal blocks corrected from the
+    raw sums behind it.  Forced from the first screen value on; against the oracle on the standardized matrix and against the
+    view's own full-Gram engines (ADELIE_HIP_STD_PANEL=0)."""
+    rng = np.random.RandomState(29)
+    n, p = 500, 240
+    if kind == "dense":
+        Z = np.asfortranarray(rng.normal(size=(n, p)) * rng.uniform(0.5, 3, p) + rng.normal(size=p))
+        M = ad.matrix.dense(Z)
+    else:
+        cd = rng.choice(np.array([0, 1, 2, -9], dtype=np.int8), size=(n, p), p=[0.5, 0.3, 0.1, 0.1])
+        imp = ad.matrix.compute_impute(cd)
+        Z = np.asfortranarray(np.where(cd < 0, imp[None], cd).astype(np.float64))
+        M = ad.matrix.snp_calldata(cd, imp)
+    S = ad.matrix.standardize(M, lazy=True)
+    Xs = np.asfortranarray((Z - Z.mean(0)) / Z.std(0))
+    beta = np.zeros(p)
+    beta[rng.choice(p, 25, replace=False)] = rng.normal(size=25)
+    y = Xs @ beta + 0.5 * rng.normal(size=n)
+    yb = (y > np.median(y)).astype(float)
+    w = rng.uniform(0.2, 1.0, n)
+    w /= w.sum()
+    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    for glm, kw in [
+        (ad.glm.gaussian(y, weights=w), dict(groups=np.arange(0, p, 4), alpha=0.7)),
+        (ad.glm.gaussian(y), dict(intercept=False)),
+        (ad.glm.gaussian(y), dict(intercept=False, alpha=0.4, penalty=rng.uniform(0.5, 2.0, p))),
+        (ad.glm.binomial(yb), dict(intercept=False, alpha=0.5, irls_tol=1e-11, min_ratio=0.1)),
+        (ad.glm.binomial(yb, weights=w), dict(groups=np.arange(0, p, 3), irls_tol=1e-11, min_ratio=0.1)),
+    ]:
+        kw = dict(dict(tol=1e-12, early_exit=False, lmda_path_size=12, min_ratio=3e-2, progress_bar=False), **kw)
+        a = ad.grpnet(S, glm, **kw)
+        monkeypatch.setenv("ADELIE_HIP_STD_PANEL", "0")
+        b = ad.grpnet(S, glm, **kw)
+        monkeypatch.delenv("ADELIE_HIP_STD_PANEL")
+        o = ad.grpnet(oracle.dense(Xs), glm, **kw)
+        assert a.error == "" and b.error == "" and o.error == ""
+        assert a.counters["n_panel_blocks"] > 0 and b.counters["n_panel_blocks"] == 0
+        tol = 1e-6 if "irls_tol" in kw else 1e-8
+        assert np.abs(a.betas.toarray() - o.betas.toarray()).max() < tol, kw
+        assert np.abs(a.intercepts - o.intercepts).max() < tol
+        assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < tol
+        # the invariants handed back are the view's: residual / gradient of the last solution
+        for name in ("grad", "resid") if "irls_tol" not in kw else ("grad", "eta"):
+            assert np.abs(np.asarray(getattr(a, name)) - np.asarray(getattr(o, name))).max() < 1e-6, name

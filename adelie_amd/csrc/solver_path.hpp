@@ -442,7 +442,8 @@
         // ... except IRLS on the plain compressed columns (groups of one, or groups of at most 128): the panel engine's sequential form (step over
         // the stored entries, 64-visit diagonal blocks by row-list merges; kernels_sparse.hip) -- a Gram of the whole screen set
         // per IRLS iteration is what such a path spends its time on otherwise (hook ADELIE_HIP_SPARSE_PANEL=0)
-        if (sparse() && is_glm() && !cov_mode && D->std_center == nullptr && hooks.sparse_panel != 0) engine_panel = true;
+        if (sparse() && is_glm() && !cov_mode && hooks.sparse_panel != 0 && (D->std_center == nullptr || hooks.std_panel != 0))
+            engine_panel = true; // (its standardized view: with the corrections of the next paragraph)
         // ... and a standardized view of a dense / 2-bit design: the panel engines' sequential form on the BASE design's columns
         // with the view's corrections around every step (changes over the scales + kappa off every row before it, the block's
         // gradient and the diagonal blocks corrected from the raw sums behind it; kernels_sparse.hip), no look-ahead, no

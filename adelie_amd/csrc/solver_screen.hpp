@@ -43,13 +43,9 @@
     }
     int panel_step(const T* w, T* r, const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb) {
         if (multi()) return launch_multi_panel_step<T>(D->multi<T>(), w, r, dcol, dlt, nz_dev, cols, nb, d_part.p, st);
-        if (sparse()) { // compressed columns: the gradient goes straight to d_gblk (returns 0: no partials to reduce)
-            launch_panel_step_csc<T>(D->csc<T>(), w, r, dcol, dlt, nz_dev, cols, nb, &d_blk.p->resid_sum, intercept ? cur_xm : nullptr,
-                                     d_gblk.p, st);
-            return 0;
-        }
         const T* kappa = nullptr;
-        if (std_generic()) { // the changes over the scales into the base design's step, then kappa = sum c delta / s off every row
+        const bool stdv = D->std_center != nullptr; // a standardized view (of a dense / 2-bit design, or of compressed columns)
+        if (stdv) { // the changes over the scales into the base design's step, then kappa = sum c delta / s off every row
             T* c2 = d_std_coef.reserve(size_t(cd_block_size()) + 16);
             T* kp = c2 + cd_block_size();
             launch_std_scale_coef<T>(static_cast<const T*>(D->std_center), static_cast<const T*>(D->std_iscale), dcol, dlt, nz_dev, 0, c2,
@@ -58,6 +54,14 @@
             kappa = kp;
             // (before the step: its phase (B) must see the residual with the whole change applied)
             launch_vec_shift<T>(r, n, kappa, T(-1), nz_dev, st);
+        }
+        if (sparse()) { // compressed columns: the gradient goes straight to d_gblk (returns 0: no partials to reduce)
+            launch_panel_step_csc<T>(D->csc<T>(), w, r, dcol, dlt, nz_dev, cols, nb, &d_blk.p->resid_sum,
+                                     (intercept && !stdv) ? cur_xm : nullptr, d_gblk.p, st);
+            if (stdv && nb > 0) // (raw sums of the stored entries -> the view's gradient)
+                launch_std_fix_gblk<T>(d_gblk.p, cols, nb, static_cast<const T*>(D->std_center), static_cast<const T*>(D->std_iscale),
+                                       &d_blk.p->resid_sum, intercept ? cur_xm : nullptr, st);
+            return 0;
         }
         const int nsl = dense() ? launch_panel_step<T>(D->dense<T>(), w, r, dcol, dlt, nz_dev, cols, nb, d_part.p, st)
                                 : launch_panel_step_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, r, dcol, dlt, nz_dev, cols,
@@ -92,7 +96,9 @@
         hipStream_t gs = side == 0 ? st : (side >= 2 ? st_x[side - 2] : st2);
         if (sparse()) { // compressed columns: one thread per pair of columns merges the two row lists (kernels_sparse.hip)
             t_gram.begin(gs);
-            launch_block_gram_csc<T>(D->csc<T>(), w, cols_base, sb, xm, intercept, D0, B, gs);
+            const bool stdv = D->std_center != nullptr;
+            launch_block_gram_csc<T>(D->csc<T>(), w, cols_base, sb, xm, intercept && !stdv, D0, B, gs);
+            if (stdv) std_block_fix(w, cols_base, sb, xm, D0, side, gs);
             t_gram.end(gs);
             for (int y = 0; y < sb.count; ++y) cnt.n_gram_col_reads += 2 * sb.nb[y];
             return;
@@ -119,7 +125,9 @@
         if (sparse()) { // compressed columns (kernels_sparse.hip: LDS hash join per column of the block)
             SyrkBatch sb{};
             sb.count = 1; sb.off[0] = 0; sb.nb[0] = nb; sb.dst[0] = 0;
-            launch_block_gram_csc<T>(D->csc<T>(), w, cols, sb, xm, intercept, Dptr, B, gs);
+            const bool stdv = D->std_center != nullptr;
+            launch_block_gram_csc<T>(D->csc<T>(), w, cols, sb, xm, intercept && !stdv, Dptr, B, gs);
+            if (stdv) std_block_fix(w, cols, sb, xm, Dptr, side, gs);
             t_gram.end(gs);
             cnt.n_gram_col_reads += 2 * nb;
             return;

@@ -316,7 +316,7 @@ def test_cv_grpnet_on_a_kept_sparse_design(hip):
     assert a.best_idx == b.best_idx
 
 
-@pytest.mark.parametrize("engine", ["gram_sparse", "gram_view", "panel_sparse", "panel_sparse_groups"])
+@pytest.mark.parametrize("engine", ["gram_sparse", "gram_view", "panel_view", "panel_sparse", "panel_sparse_groups"])
 def test_irls_on_a_sparse_design_reuses_its_blocks_under_small_weight_drift(hip, oracle, monkeypatch, engine):
     """IRLS on a design kept sparse.  Groups of one on the plain matrix: the panel engine over compressed columns (step over
     the stored entries, 64-visit diagonal blocks by row-list merges; ADELIE_HIP_SPARSE_PANEL=0 keeps the full-Gram engines).
@@ -331,10 +331,13 @@ def test_irls_on_a_sparse_design_reuses_its_blocks_under_small_weight_drift(hip,
     X = _csc(sp.csc_matrix(D))
     Xd = D
     kw = dict(tol=1e-12, irls_tol=1e-12, early_exit=False, lmda_path_size=20, min_ratio=5e-2, progress_bar=False)
-    if engine == "gram_view":   # elastic net without an intercept: stays on the view's own (full-Gram) engines
+    if engine in ("gram_view", "panel_view"):   # elastic net without an intercept on the standardized view of the sparse design: the
+        # panel engine over compressed columns with the view's corrections around every step, or (hook) the view's full-Gram engines
         X = ad.matrix.standardize(X)
         Xd = (D - D.mean(axis=0)) / D.std(axis=0)
         kw.update(alpha=0.7, intercept=False)
+        if engine == "gram_view":
+            monkeypatch.setenv("ADELIE_HIP_STD_PANEL", "0")
     if engine == "gram_sparse":
         monkeypatch.setenv("ADELIE_HIP_SPARSE_PANEL", "0")
     if engine == "panel_sparse_groups":   # the group panel engine on compressed columns (blocks of whole groups, eigenbases per IRLS iteration)
@@ -349,7 +352,7 @@ def test_irls_on_a_sparse_design_reuses_its_blocks_under_small_weight_drift(hip,
     assert a.counters["n_irls_iters"] > 30
     if engine == "panel_sparse_groups":
         assert a.counters["n_panel_blocks"] > 0   # (blocks of groups are rebuilt with their eigenbases per IRLS iteration)
-    elif engine == "panel_sparse":
+    elif engine in ("panel_sparse", "panel_view"):
         assert a.counters["n_panel_blocks"] > 0 and a.counters["n_panel_grams"] < 0.7 * b.counters["n_panel_grams"]
     else:
         assert a.counters["n_panel_blocks"] == 0 and a.timers["gram_flops"] < 0.7 * b.timers["gram_flops"]   # Grams were kept

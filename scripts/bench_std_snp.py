@@ -33,8 +33,8 @@ X.btmul(0, p, beta, eta)
 y = eta + float(os.environ.get("NOISE", "1.0")) * np.std(eta) * rng.normal(size=n)
 alpha = float(os.environ.get("ALPHA", "1"))
 kw = dict(lmda_path_size=L, min_ratio=float(os.environ.get("MIN_RATIO", "2e-2")), early_exit=False, progress_bar=False, alpha=alpha)
-if os.environ.get("GROUPS"):        # groups of GROUPS columns / INTERCEPT=0: fits the base-coordinates route cannot take (round 5: panel form of the view)
-    kw["groups"] = np.arange(0, p, int(os.environ["GROUPS"]))
+if os.environ.get("GROUP_SIZE"):        # groups of GROUP_SIZE columns (not GROUPS: bash keeps that name for itself) / INTERCEPT=0: fits the base-coordinates route cannot take (round 5: panel form of the view)
+    kw["groups"] = np.arange(0, p, int(os.environ["GROUP_SIZE"]))
 if os.environ.get("INTERCEPT") == "0":
     kw["intercept"] = False
 if os.environ.get("VIEW_ENGINES"):

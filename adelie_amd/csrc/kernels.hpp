@@ -666,6 +666,9 @@ constexpr int kEigMaxQ = 96; // 2 * q * q doubles of LDS
 template <class T>
 void launch_grp_eig(const T* src_base, const EigDesc* desc_dev, int count, int max_q, T* vars, T* V, hipStream_t s);
 template <class T> void launch_diag_vars(const T* C, int64_t ldc, int32_t pos0, int32_t cnt, T* vars, hipStream_t s);
+// the diagonals of the blocks of a build batch into vars (by screen position; list == nullptr: positions base + off + i)
+template <class T>
+void launch_block_diag_vars(const T* D0, const SyrkBatch& sb, int ldb, int32_t base, const int32_t* list, T* vars, hipStream_t s);
 // transpose row-major (n,p) into column-major with leading dimension ld
 template <class T> void launch_transpose(const T* src, int64_t n, int64_t p, T* dst, int64_t ld, hipStream_t s);
 // rows / columns of a 2-bit design re-packed as a 2-bit design (dst: pout columns of ldb_dst bytes)

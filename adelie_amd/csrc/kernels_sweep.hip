@@ -727,6 +727,24 @@ void launch_copy2d(const T* src, int64_t lds_, T* dst, int64_t ldd, int64_t rows
                            dst + j0 * ldd, ldd, rows, cols);
     }
 }
+// vars[pos] = max(D_y[i, i], 0) for the blocks of a build batch (block y at D0 + sb.dst[y], leading dimension ldb): pos = the
+// screen position of the block's i-th visit = list ? list[base + sb.off[y] + i] : base + sb.off[y] + i
+namespace {
+template <class T>
+__global__ __launch_bounds__(128) void block_diag_vars_kernel(const T* __restrict__ D0, SyrkBatch sb, int ldb, int32_t base,
+                                                              const int32_t* __restrict__ list, T* __restrict__ vars) {
+    const int y = blockIdx.x, i = threadIdx.x;
+    if (i >= sb.nb[y]) return;
+    const int32_t k = base + sb.off[y] + i;
+    const T v = D0[sb.dst[y] + i + int64_t(i) * ldb];
+    vars[list ? list[k] : k] = v > T(0) ? v : T(0);
+}
+} // namespace
+template <class T>
+void launch_block_diag_vars(const T* D0, const SyrkBatch& sb, int ldb, int32_t base, const int32_t* list, T* vars, hipStream_t s) {
+    if (sb.count <= 0) return;
+    hipLaunchKernelGGL((block_diag_vars_kernel<T>), dim3(unsigned(sb.count)), dim3(128), 0, s, D0, sb, ldb, base, list, vars);
+}
 template <class T>
 void launch_diag_vars(const T* C, int64_t ldc, int32_t pos0, int32_t cnt, T* vars, hipStream_t s) {
     if (cnt <= 0) return;
@@ -894,6 +912,7 @@ template void launch_snp_impute<float>(const uint8_t*, int64_t, int64_t, int64_t
                                           const T*, T, const T*, const T*, const T*, T*, T*, hipStream_t);             \
     template void launch_copy2d<T>(const T*, int64_t, T*, int64_t, int64_t, int64_t, hipStream_t);                     \
     template void launch_diag_vars<T>(const T*, int64_t, int32_t, int32_t, T*, hipStream_t);                           \
+    template void launch_block_diag_vars<T>(const T*, const SyrkBatch&, int, int32_t, const int32_t*, T*, hipStream_t); \
     template void launch_csc_scatter<T>(const int64_t*, const int32_t*, const T*, int64_t, int64_t, T*, int64_t, hipStream_t);\
     template void launch_transpose<T>(const T*, int64_t, int64_t, T*, int64_t, hipStream_t);                            \
     template void launch_derive_dense<T>(const DenseView<T>&, int64_t, int64_t, const int64_t*, const int64_t*, const T*, \

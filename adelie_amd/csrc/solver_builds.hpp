@@ -188,6 +188,17 @@
     // eigen-coordinates of its groups right behind its build (same stream), over the pass's visiting list.
     const idx* rot_list = nullptr;
     bool rot_on = false;
+    // IRLS with groups of one on the panel engines: A_jj = the diagonal of the block that carries coordinate j, written by the
+    // block's build (build_stale_blocks) instead of a square sweep over the screen columns per IRLS iteration (config 4: 107
+    // sweeps of 1.7 ms per path).  A block kept under the weight-drift rule keeps its variances with it; the fixed point of the
+    // passes does not depend on A (the update beta <- S(g + A beta, l1) / (A + l2) has the KKT point as its fixed point for any
+    // A > 0).  One vector per table (screen order / activation order): the builds of one table run while the passes of the
+    // other read theirs.  Hook ADELIE_HIP_IRLS_REUSE=0 makes every block, and so every variance, current.
+    bool vars_from_blocks() const { return is_glm() && all_scalar && !multi() && !cov_mode; }
+    DevBuf<T> d_vars_act;
+    T* vb_vars = nullptr;               // (set around a build_stale_blocks call: destination, the pass's column list, its visiting list)
+    const int32_t* vb_cols_all = nullptr;
+    const int32_t* vb_list = nullptr;
     template <class NbOf, class ColsOf>
     void build_stale_blocks(int nblk, std::vector<int32_t>& tab_nb, std::vector<uint64_t>& tab_ver, T* pool, NbOf nb_of,
                             ColsOf cols_of, bool prebuild = false, bool take_pre = false) {
@@ -257,6 +268,9 @@
             set_small_gram_workgroups((side && side_wgs > 0 && !is_glm() && j0 >= side_wgs_from) ? side_wgs : 512);
             if (multi()) gram_block(cur_w, cols_of(j0), nb_of(j0), cur_xm, pool + size_t(j0) * SL * SL, sidx);
             else gram_block_batch(cur_w, cols_base, sb, cur_xm, pool + size_t(j0) * SL * SL, sidx);
+            if (vb_vars && !multi()) // IRLS, groups of one: the variances of a block's coordinates are its diagonal (vars_from_blocks)
+                launch_block_diag_vars<T>(pool + size_t(j0) * SL * SL, sb, SL, int32_t(cols_base - vb_cols_all), vb_list, vb_vars,
+                                          sidx == 0 ? st : (sidx >= 2 ? st_x[sidx - 2] : st2));
             if (rot_on)
                 for (size_t t = i; t < k; ++t) rotate_block(rot_list, stale[t], pool + size_t(stale[t]) * SL * SL, sidx);
             hipEvent_t e = nullptr;

@@ -401,8 +401,19 @@
             const int nsl0 = step_of(0);
             build_stale_strips(nblk, tab_nb, tab_ver, nullptr, pool, static_cast<T*>(nullptr),
                                [&](int j) { return std::min(B, count - j * B); }, [&](int j) { return cols_all + size_t(j) * B; });
+            const bool vfb = vars_from_blocks(); // IRLS: the variances of a block's coordinates come with its build
+            if (vfb) {
+                if (d_vars_act.cap < size_t(p) + 8) {
+                    d_vars_act.reserve(size_t(p) + 8);
+                    AHIP_CHECK(hipMemsetAsync(d_vars_act.p, 0, (size_t(p) + 8) * sizeof(T), st));
+                }
+                vb_vars = screen_pass ? d_vars.p : d_vars_act.p;
+                vb_cols_all = cols_all;
+                vb_list = screen_pass ? nullptr : cp.active_set;
+            }
             build_stale_blocks(nblk, tab_nb, tab_ver, pool, [&](int j) { return std::min(B, count - j * B); },
                                [&](int j) { return cols_all + size_t(j) * B; }, false, screen_pass);
+            vb_vars = nullptr;
             merge_strip_events(false);
             pass_e0_valid = false;
             if (!screen_pass && prebuild_screen && !screen_prebuilt && side_grams && st2) {
@@ -411,11 +422,14 @@
                 // the active-set passes iterate
                 screen_prebuilt = true;
                 const int cnt_s = cp.nv, nblk_s = (cnt_s + B - 1) / B;
+                if (vfb) { vb_vars = d_vars.p; vb_cols_all = d_vcol.p; vb_list = nullptr; }
                 build_stale_blocks(nblk_s, dscr_nb, dscr_ver, d_Dpool.p, [&](int j) { return std::min(B, cnt_s - j * B); },
                                    [&](int j) { return d_vcol.p + size_t(j) * B; }, true);
+                vb_vars = nullptr;
             }
             // (a look-ahead pass may have run before: plain buffers for the solves, its pending changes for the first step)
             bp.gblk = d_gblk.p; bp.dlt = d_dlt.p; bp.dcol = d_dcolblk.p;
+            bp.vars = vfb ? (screen_pass ? d_vars.p : d_vars_act.p) : cp.vars;
             bp.Cprev = nullptr; bp.dpos = nullptr; bp.nz_out = nullptr; bp.rsum_out = nullptr;
             bp.part = nullptr; bp.pdd = nullptr; bp.dd = nullptr;
             for (int j = 0; j < nblk; ++j) {

@@ -541,7 +541,8 @@
             update_vars_panel_groups(w_dev, xm_dev, xm_host, g_begin, pos0, N);
             return;
         }
-        sweep(w_dev, d_vars.p + pos0, d_vcol.p + pos0, N, nullptr, nullptr, true);
+        const bool vfb = vars_from_blocks(); // IRLS, groups of one: the variances come with the blocks' builds (solver_builds.hpp)
+        if (!vfb) sweep(w_dev, d_vars.p + pos0, d_vcol.p + pos0, N, nullptr, nullptr, true);
         for (idx ss = idx(g_begin); ss < ns; ++ss) {
             const idx g = screen_set[ss], b = screen_begins[ss];
             screen_X_means[b] = xm_host[groups[g]];
@@ -550,7 +551,7 @@
         // by-value means on the device straight from the by-column vector; the host copy of the variances is only an output
         // (finalize() downloads it), so no synchronisation here
         launch_gather<T>(xm_dev, d_vcol.p + pos0, N, d_sxm.p + pos0, st);
-        launch_center_vars<T>(d_vars.p + pos0, d_sxm.p + pos0, int(N), intercept, st);
+        if (!vfb) launch_center_vars<T>(d_vars.p + pos0, d_sxm.p + pos0, int(N), intercept, st);
     }
 
     // Same with groups: X_g^T W X_g - xbar xbar^T of every new group is a diagonal sub-block of one of the screen-order

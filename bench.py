@@ -489,6 +489,10 @@ def main():
         # box / one-sided constraint objects on 200 of config 3's 1000 groups: every visit of such a group is a device launch
         # (kernels_cons.hip); the same path with the visits on the host objects beside it (constraints)
         out["constrained_groups"] = constrained_leg(keep["Xd"], keep["y"], n, p)
+        # throughput with independent headline paths IN FLIGHT on one GPU (alias handles of the resident design, one host thread
+        # and stream each, as cv_grpnet's folds): `value` above is one path at a time -- a single path is a latency chain that
+        # leaves part of the chip idle; this is what a server answering several fits gets.  Not the headline metric.
+        out["concurrent_paths"] = concurrent_leg(keep["Xd"], keep["glm"], keep["kw"])
         del keep, line3
         import gc
         gc.collect()
@@ -618,6 +622,50 @@ def sparse_leg(L, n=1_000_000, p=100_000, density=1e-3, cpu_budget_s=0.0):
                            "unit": "paths/s", "ms_per_step": el * 1e3, "lambdas": len(sb.lmdas), "final_active": int(sb.active_set_size),
                            "n_irls_iters": int(sb.counters["n_irls_iters"]), "n_panel_blocks": int(sb.counters["n_panel_blocks"]),
                            "n_block_builds": int(sb.counters["n_panel_grams"]), "error": sb.error}
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
+
+
+def concurrent_leg(Xd, glm, kw, rounds=2):
+    """Aggregate paths/s of the headline workload with 2 and 4 identical paths in flight (threads on alias handles)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import adelie_amd as ad
+
+    try:
+        out = {"workload": "the headline path, k independent copies in flight on one GPU (alias handles, one stream each)"}
+        for k in (2, 4, 8):
+            handles = [Xd] + [Xd.alias() for _ in range(k - 1)]
+
+            def one(h):
+                st = ad.grpnet(h, glm, **kw)
+                assert st.error == "", st.error
+                return len(st.lmdas)
+
+            with ThreadPoolExecutor(max_workers=k) as pool:
+                list(pool.map(one, handles))                     # warm-up (alias handles allocate their scratch)
+                t0 = time.perf_counter()
+                for _ in range(rounds):
+                    list(pool.map(one, handles))
+                el = time.perf_counter() - t0
+            out[f"in_flight_{k}"] = {"value": k * rounds / el, "unit": "paths/s", "ms_per_path_wall": el / (k * rounds) * 1e3}
+            # the same with the full-gradient sweeps of the paths in flight answered by ONE K-wide pass over X (what cv_grpnet's
+            # folds do, solver.hip::SweepBatcher: every path sees its own result; summation order differs in the last bits)
+            from adelie_amd.cv import _sweep_batch
+            if _sweep_batch(Xd._backend, True):
+                try:
+                    with ThreadPoolExecutor(max_workers=k) as pool:
+                        list(pool.map(one, handles))
+                        t0 = time.perf_counter()
+                        for _ in range(rounds):
+                            list(pool.map(one, handles))
+                        el = time.perf_counter() - t0
+                    out[f"in_flight_{k}"]["shared_sweeps"] = {"value": k * rounds / el, "unit": "paths/s",
+                                                              "ms_per_path_wall": el / (k * rounds) * 1e3}
+                finally:
+                    _sweep_batch(Xd._backend, False)
+            del handles
         return out
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)}

@@ -406,6 +406,19 @@ void launch_rel_change(const T* a, T* prev, int64_t n, T* out, hipStream_t s) {
     (void)hipMemsetAsync(out, 0, sizeof(T), s);
     hipLaunchKernelGGL((rel_change_kernel<T>), dim3(RB), dim3(RT), 0, s, a, prev, n, out);
 }
+namespace {
+template <class T>
+__global__ void scatter_kernel(const T* __restrict__ src, const int32_t* __restrict__ idx, int64_t cnt, T* __restrict__ dst) {
+    const int64_t a = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (a < cnt) dst[idx[a]] = src[a];
+}
+} // namespace
+// dst[idx[a]] = src[a]  (distinct indices)
+template <class T>
+void launch_scatter(const T* src, const int32_t* idx, int64_t cnt, T* dst, hipStream_t s) {
+    if (cnt <= 0) return;
+    hipLaunchKernelGGL((scatter_kernel<T>), dim3(unsigned((cnt + 255) / 256)), dim3(256), 0, s, src, idx, cnt, dst);
+}
 template <class T>
 void launch_gather(const T* src, const int32_t* idx, int64_t cnt, T* dst, hipStream_t s) {
     if (cnt <= 0) return;
@@ -429,7 +442,8 @@ void launch_gather(const T* src, const int32_t* idx, int64_t cnt, T* dst, hipStr
     template void launch_set_eta<T>(const T*, T, int64_t, T*, hipStream_t);                                            \
     template void launch_dot_diff<T>(const T*, const T*, const T*, const T*, int64_t, T*, hipStream_t);                \
     template void launch_rel_change<T>(const T*, T*, int64_t, T*, hipStream_t);                                        \
-    template void launch_gather<T>(const T*, const int32_t*, int64_t, T*, hipStream_t);
+    template void launch_gather<T>(const T*, const int32_t*, int64_t, T*, hipStream_t);                                \
+    template void launch_scatter<T>(const T*, const int32_t*, int64_t, T*, hipStream_t);
 INST(double)
 INST(float)
 #undef INST

@@ -56,6 +56,8 @@ template <class T>
 void launch_rel_change(const T* a, T* prev, int64_t n, T* out, hipStream_t s);
 template <class T>
 void launch_gather(const T* src, const int32_t* idx, int64_t cnt, T* dst, hipStream_t s);
+template <class T>
+void launch_scatter(const T* src, const int32_t* idx, int64_t cnt, T* dst, hipStream_t s); // dst[idx[a]] = src[a]
 } // namespace ahip
 
 using namespace ahip;

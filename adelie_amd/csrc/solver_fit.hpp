@@ -393,8 +393,11 @@
                 } else {
                     sweep(d_irls_w.p, d_g.p, d_vcol.p, nv, nullptr, nullptr); // means by value
                 }
-                std::vector<T> m(nv);
-                d_g.download(m.data(), size_t(nv), st);
+                // groups of one on the panel engines: the by-column means stay on the device (scatter through the value -> column map);
+                // the host mirrors of the screen means are not read under IRLS (a GLM state hands none back)
+                const bool means_on_device = panel_mode() && all_scalar && !multi();
+                std::vector<T> m(means_on_device ? 0 : nv);
+                if (!means_on_device) d_g.download(m.data(), size_t(nv), st);
                 T drift = T(1e30);
                 const bool gram_keep_mode = irls_reuse > 0 && all_scalar && !panel_mode() && !cov_mode && !multi() &&
                                             (sparse() || std_generic()) && nv >= cd_block_min_nv;
@@ -405,12 +408,17 @@
                     launch_rel_change<T>(d_irls_w.p, d_irls_w_prev.p, n, d_sums.p + 15, st);
                     AHIP_CHECK(hipMemcpyAsync(&drift, d_sums.p + 15, sizeof(T), hipMemcpyDeviceToHost, st));
                 }
-                sync();
-                for (idx ss = 0; ss < idx(screen_set.size()); ++ss) {
-                    const idx g = screen_set[ss];
-                    for (idx t = 0; t < group_sizes[g]; ++t) irls_xm_host[groups[g] + t] = m[screen_begins[ss] + t];
+                if (means_on_device) {
+                    launch_scatter<T>(d_g.p, d_vcol.p, nv, d_irls_xm.p, st);
+                    if (track) sync(); // (the drift decides which blocks are kept)
+                } else {
+                    sync();
+                    for (idx ss = 0; ss < idx(screen_set.size()); ++ss) {
+                        const idx g = screen_set[ss];
+                        for (idx t = 0; t < group_sizes[g]; ++t) irls_xm_host[groups[g] + t] = m[screen_begins[ss] + t];
+                    }
+                    d_irls_xm.upload(irls_xm_host.data(), size_t(p), st);
                 }
-                d_irls_xm.upload(irls_xm_host.data(), size_t(p), st);
                 ++w_version; // diagonal blocks built from here on belong to this iteration's weights
                 if (track) {
                     note_weight_drift(irls_w_prev_valid ? double(drift) : 1e300);
@@ -418,7 +426,9 @@
                 }
                 const bool keep = gram_keep_mode && gram_version != 0 && gram_version >= min_usable_version && gram_nv > 0 &&
                                   gram_nv <= nv;
-                if (!keep) {
+                // (groups of one on the panel engines: no Gram, no eigenbases; the (1, 1) transforms of the host mirror stay as they
+                // are -- 39 k one-element vectors freed and re-allocated per IRLS iteration were a third of the set-up's host time)
+                if (!keep && !(panel_mode() && all_scalar)) {
                     gram_nv = 0;
                     v_used = 0;
                     screen_transforms.clear();

@@ -264,6 +264,9 @@
         if (hooks.trace >= 2)
             std::fprintf(stderr, "[enq] panel passes: host enqueue %.1f ms, host wait %.1f ms, blocks %lld (built %lld + %lld cross + %lld strips, reused across IRLS iterations %lld), speculated %lld (rolled back %lld)\n",
                          t_enq * 1e3, t_wait * 1e3, (long long)cnt.n_panel_blocks, (long long)cnt.n_panel_grams, (long long)n_cross_blocks, (long long)n_strip_builds, (long long)n_blocks_reused, (long long)n_spec, (long long)n_spec_rollback);
+        if (hooks.trace >= 2 && is_glm())
+            std::fprintf(stderr, "[irls] %lld iterations: set-up (weights, means, screen-derived) %.1f ms, pin solves %.1f ms (host wall)\n",
+                         (long long)cnt.n_irls_iters, t_host[6] * 1e3, t_host[7] * 1e3);
         if (hooks.trace >= 2)
             std::fprintf(stderr, "[alloc] hipMalloc/hipFree so far in this process: %ld calls, %.1f ms\n", DevAllocStats::calls(),
                          DevAllocStats::seconds() * 1e3);

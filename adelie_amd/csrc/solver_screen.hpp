@@ -546,7 +546,7 @@
         for (idx ss = idx(g_begin); ss < ns; ++ss) {
             const idx g = screen_set[ss], b = screen_begins[ss];
             screen_X_means[b] = xm_host[groups[g]];
-            screen_transforms[ss] = std::vector<T>{T(1)};
+            if (screen_transforms[ss].size() != 1) screen_transforms[ss].assign(1, T(1));
         }
         // by-value means on the device straight from the by-column vector; the host copy of the variances is only an output
         // (finalize() downloads it), so no synchronisation here

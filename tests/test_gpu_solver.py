@@ -542,3 +542,35 @@ def test_irls_block_reuse_against_rebuild_every_iteration(hip, monkeypatch, fami
     assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-7
     assert np.abs(a.intercepts - b.intercepts).max() < 1e-7
     assert sorted(a.screen_set.tolist()) == sorted(b.screen_set.tolist())
+
+
+def test_penalty_l2_is_the_quadratic_parts_own_factor(hip, oracle):
+    """adelie_hip_grpnet_args::penalty_l2 (ABI 8; adelie_amd.solver passes it for elastic nets on standardized views): separate
+    factors for the quadratic part of the penalty.  Equal to `penalty` it changes nothing (bit for bit); a constant multiple c of
+    `penalty` is the elastic net with  lmda' = lmda (alpha + (1 - alpha) c),  alpha' = alpha / (alpha + (1 - alpha) c)  -- checked
+    against the ORACLE on that re-parametrised problem (which knows no penalty_l2), Gaussian and binomial, single-workgroup and
+    panel engines; groups of several coefficients refuse it."""
+    rng = np.random.RandomState(77)
+    n, p = 400, 300
+    X = np.asfortranarray(rng.normal(size=(n, p)))
+    beta = np.zeros(p)
+    beta[rng.choice(p, 20, replace=False)] = rng.normal(size=20)
+    y = X @ beta + 0.5 * rng.normal(size=n)
+    pen = rng.uniform(0.5, 2.0, p)
+    Xd = ad.matrix.dense(X)
+    alpha, c = 0.6, 2.5
+    lmdas = 0.5 * np.logspace(0, -2, 12)
+    for glm, extra in [(ad.glm.gaussian(y), dict(tol=1e-13)), (ad.glm.binomial((y > 0).astype(float)), dict(tol=1e-12, irls_tol=1e-12))]:
+        kw = dict(early_exit=False, progress_bar=False, penalty=pen, **extra)
+        a0 = ad.grpnet(Xd, glm, alpha=alpha, lmda_path=lmdas, **kw)
+        a1 = ad.grpnet(Xd, glm, alpha=alpha, lmda_path=lmdas, _penalty_l2=pen.copy(), **kw)
+        assert a0.error == "" and a1.error == "" and np.array_equal(a0.betas.toarray(), a1.betas.toarray())
+        a = ad.grpnet(Xd, glm, alpha=alpha, lmda_path=lmdas, _penalty_l2=c * pen, **kw)
+        scale = alpha + (1 - alpha) * c
+        o = ad.grpnet(oracle.dense(X), glm, alpha=alpha / scale, lmda_path=lmdas * scale, **kw)
+        assert a.error == "" and o.error == ""
+        assert np.abs(a.betas.toarray() - o.betas.toarray()).max() < (1e-8 if "irls_tol" not in extra else 1e-6)
+        assert np.abs(a.intercepts - o.intercepts).max() < 1e-6
+        assert max(a.screen_sizes) > 128   # (the panel engines took over along the path)
+    with pytest.raises(RuntimeError, match="penalty_l2 needs groups of one coefficient"):
+        ad.grpnet(Xd, ad.glm.gaussian(y), groups=np.arange(0, p, 2), alpha=0.5, _penalty_l2=np.ones(p // 2), progress_bar=False)

@@ -447,18 +447,28 @@ __device__ __forceinline__ void blk_solve_la_body(const CdBlkParams<T>& p, int j
     }
     // ---- slice partials of the block's gradient (solver fused the reduction into this launch): a second round trip, with
     //      the registers of the two blocks free again; k0, k0 + 8, ... in a fixed order per thread, eight threads per column
+    // Blocks of 64 visits (IRLS) give every column sixteen threads instead of eight; beyond PBN partials per thread (long
+    // designs: 489 slices of 1024 rows at 500k rows) the rest follows in batches of eight loads in flight.
+    const int pc_sh = (p.bsz <= 64) ? 6 : 7; // log2 of the columns a row of gsum holds
     if (has_part) {
         constexpr int PBN = 25;
-        const int pc_c = tid & (BLK - 1), pc_k0 = tid >> 7;
+        const int tpc = 1024 >> pc_sh;
+        const int pc_c = tid & ((1 << pc_sh) - 1), pc_k0 = tid >> pc_sh;
         const T* pc = p.part + pc_c;
         T pw[PBN];
 #pragma unroll
-        for (int u = 0; u < PBN; ++u) pw[u] = pc[int64_t(min(pc_k0 + 8 * u, p.part_n - 1)) * BLK];
+        for (int u = 0; u < PBN; ++u) pw[u] = pc[int64_t(min(pc_k0 + tpc * u, p.part_n - 1)) * BLK];
         T psum = T(0);
 #pragma unroll
-        for (int u = 0; u < PBN; ++u) psum += (pc_k0 + 8 * u < p.part_n) ? pw[u] : T(0);
-        for (int k = pc_k0 + 8 * PBN; k < p.part_n; k += 8) psum += pc[int64_t(k) * BLK]; // (more than 200 partials)
-        gsum[pc_k0 * BLK + pc_c] = (pc_c < nb) ? psum : T(0);
+        for (int u = 0; u < PBN; ++u) psum += (pc_k0 + tpc * u < p.part_n) ? pw[u] : T(0);
+        for (int k = pc_k0 + tpc * PBN; k < p.part_n; k += tpc * 8) {
+            T qw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) qw[u] = pc[int64_t(min(k + tpc * u, p.part_n - 1)) * BLK];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) psum += (k + tpc * u < p.part_n) ? qw[u] : T(0);
+        }
+        gsum[(pc_k0 << pc_sh) + pc_c] = (pc_c < nb) ? psum : T(0);
     }
     __syncthreads();
     if (wv != 0) return;
@@ -466,10 +476,15 @@ __device__ __forceinline__ void blk_solve_la_body(const CdBlkParams<T>& p, int j
 
     if (has_part) {
         T s0 = T(0), s1 = T(0);
+        if (pc_sh == 7) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            s0 += gsum[q * BLK + lane];
-            s1 += gsum[q * BLK + lane + 64];
+            for (int q = 0; q < 8; ++q) {
+                s0 += gsum[q * BLK + lane];
+                s1 += gsum[q * BLK + lane + 64];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s0 += gsum[q * 64 + lane];
         }
         g0 = (lane < nb) ? s0 - prs * X0 : T(0);
         g1 = (lane + 64 < nb) ? s1 - prs * X1 : T(0);

@@ -45,6 +45,9 @@ struct Hooks {
     int group_next_corr = -1; // ADELIE_HIP_GROUP_NEXT_CORR=0: every group solve forms its own look-ahead correction (A/B)
     bool cons_host = false; // ADELIE_HIP_CONS_HOST=1: box / one-sided objects on several coefficients visited on the host (A/B, tests)
     int trace = 0;
+    int solve_sums = -1;    // ADELIE_HIP_SOLVE_SUMS=0: the sequential panel form keeps its panel_reduce launch per block             [A/B hook]
+    int step_tail = -1;     // ADELIE_HIP_STEP_TAIL=0: 2-bit designs keep the panel_reduce launch behind every sequential step        [A/B hook]
+    int step_means = -1;    // ADELIE_HIP_STEP_MEANS=0: IRLS keeps its mean sweep over the screen columns per iteration              [A/B hook]
     static Hooks from_env() {
         Hooks h;
         if (const char* e = std::getenv("ADELIE_HIP_CD_BLOCK_MIN_NV")) h.cd_block_min_nv = std::atoll(e);
@@ -61,6 +64,9 @@ struct Hooks {
         if (const char* e = std::getenv("ADELIE_HIP_SPARSE_PANEL")) h.sparse_panel = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_STD_PANEL")) h.std_panel = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_TRACE")) h.trace = std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("ADELIE_HIP_SOLVE_SUMS")) h.solve_sums = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_STEP_MEANS")) h.step_means = std::atoi(e) != 0;
+        if (const char* e = std::getenv("ADELIE_HIP_STEP_TAIL")) h.step_tail = std::atoi(e) != 0;
         return h;
     }
 };

@@ -125,7 +125,7 @@ adelie_hip_design* new_design(int64_t n, int64_t p, int dtype, int device) {
 void create_snp_from_calldata(adelie_hip_design* d, const int8_t* calldata, const double* impute) {
     const int64_t n = d->n, p = d->p;
     d->kind = 1;
-    d->ldb = (((n + 3) / 4 + 63) / 64) * 64;
+    d->ldb = (((n + 3) / 4 + 127) / 128) * 128;
     AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->bits), size_t(d->ldb) * size_t(p)));
     int8_t* tmp = nullptr;
     // stage the calldata in panels of columns to bound the temporary
@@ -534,7 +534,7 @@ void derive_t(adelie_hip_design* src, adelie_hip_design* d, const int64_t* rows,
     if (src->kind == 1 && !centers && !scales) { // a subset of a 2-bit design stays 2 bits per call
         hipStream_t s = d->stream;
         d->kind = 1;
-        d->ldb = (((nout + 3) / 4 + 63) / 64) * 64;
+        d->ldb = (((nout + 3) / 4 + 127) / 128) * 128;
         AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->bits), size_t(d->ldb) * size_t(pout)));
         AHIP_CHECK(hipMalloc(&d->impute, size_t(pout) * sizeof(T)));
         int64_t *drows = nullptr, *dcols = nullptr;
@@ -1060,7 +1060,7 @@ int adelie_hip_design_create_snp_unphased(const void* snpdat, int64_t n_bytes, i
     int8_t* tmp = nullptr;
     try {
         d->kind = 1;
-        d->ldb = int64_t((((n + 3) / 4 + 63) / 64) * 64);
+        d->ldb = int64_t((((n + 3) / 4 + 127) / 128) * 128);
         AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->bits), size_t(d->ldb) * size_t(p)));
         // decode -> int8 panel on the host -> 2-bit on the device, a panel of columns at a time
         const uint64_t panel = std::min<uint64_t>(p, std::max<uint64_t>(1, (uint64_t(1) << 28) / n));
@@ -1108,7 +1108,7 @@ int adelie_hip_design_create_snp_bed(const void* bed, int64_t n_bytes, int64_t n
     adelie_hip_design* d = new_design(n, p, dtype, device);
     try {
         d->kind = 1;
-        d->ldb = (((n + 3) / 4 + 63) / 64) * 64;
+        d->ldb = (((n + 3) / 4 + 127) / 128) * 128;
         AHIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d->bits), size_t(d->ldb) * size_t(p)));
         // stage the records in panels of SNPs to bound the temporary
         const int64_t panel = std::max<int64_t>(1, (int64_t(1) << 28) / stride);

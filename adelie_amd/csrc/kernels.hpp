@@ -491,13 +491,27 @@ int cd_block_size();
 template <class T> void launch_cd_block_pass(const CdBlkParams<T>& p, hipStream_t s);
 // ---- panel form (kernels_cd_panel.hip): residual-based block passes ------------------------------------------------
 // step: r -= sum_{m < *nz_dev} dlt[m] X[:, dcol[m]]; then part[c][slice] = X[slice, cols[c]] . (w*r)[slice] for c < nb.
-// Returns the number of row slices.  `part` holds panel_part_elems(n) elements.
+// Returns the number of row slices.  `part` holds panel_part_elems(n) elements.  `slice_major`: part[slice * 128 + c] instead,
+// the layout the stand-alone solve sums itself (CdBlkParams::part with part_ld == 0: no panel_reduce launch in between).
 template <class T>
 int launch_panel_step(const DenseView<T>& X, const T* w, T* r, const int32_t* dcol, const T* dlt, const int32_t* nz_dev,
-                      const int32_t* cols, int nb, T* part, hipStream_t s);
+                      const int32_t* cols, int nb, T* part, hipStream_t s, bool slice_major = false);
+// `tail` (2-bit designs, the one-word-per-lane kernel only; *tailed says whether it was used): the step sums its own partials
+// -- the last eight workgroups to finish take eight columns each once every workgroup's partials are out -- and leaves the
+// block's gradient in tail->g (what panel_reduce would: - rsum[0] * xm[cols[c]] applied): no reduce launch behind the step.
+// `counter` counts finished workgroups monotonically over the launches of one solver; `base` = its value before this launch.
+template <class T>
+struct StepTail {
+    int32_t* counter;
+    int32_t base;
+    T* g;
+    const T* rsum;
+    const T* xm; // by design column, or nullptr (no intercept term)
+};
 template <class T>
 int launch_panel_step_snp(const SnpView& X, const T* impute, const T* w, T* r, const int32_t* dcol, const T* dlt,
-                          const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s);
+                          const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s, bool slice_major = false,
+                          const StepTail<T>* tail = nullptr, bool* tailed = nullptr);
 int64_t panel_part_elems(int64_t n);
 // Opening of a look-ahead pass whose block-0 gradient already exists: g[c] = grad[cols[c]] (c < nb) out of the full gradient
 // the invariance sweep left for the same residual, and both look-ahead residual-sum slots <- rsum_src[0] (nullptr: skip).

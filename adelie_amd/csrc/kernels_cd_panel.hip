@@ -226,6 +226,262 @@ __global__ __launch_bounds__(PT, (VEC >= 16 ? 2 : 4)) void panel_step_kernel(Acc
         panel_step_body<T, Acc, VEC, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red, wrs, threadIdx.x, blockIdx.x);
 }
 
+// ---- the step on a 2-bit design, one 32-bit word (16 calls) per lane and column --------------------------------------------
+// The generic body above makes three dependent round trips (columns of (A) + first half of (B) -> residual / weight rows by wave
+// 0 alone -> second half of (B)) and funnels the residual update through one wavefront, whose LDS accesses at a stride of 16
+// values hit one bank.  With one register per column and lane everything a workgroup needs can be in flight at once: here every
+// load of the step is issued up front — 16 words of (A), 16 words of (B), and a quarter of the slice's residual / weight rows
+// per wavefront —, the four waves of a slice update a quarter of its rows each, and the LDS rows are laid out element-major
+// (index e * 64 + lane: conflict-free).  A workgroup carries TWO slices of 1024 rows (512 threads): 245 workgroups at 500k rows,
+// one per compute unit, and half as many partials for whoever sums them.  Same sums in the same order as panel_step_body for
+// the residual; the partial gradients are summed over the lanes by a 16-value butterfly.
+constexpr int S16_RS = 1024; // rows of a slice
+constexpr int S16_NSUB = 2;  // slices per workgroup
+
+// Sums sixteen per-lane values over the 64 lanes at once: lane l ends with the total of value (l & 15); fixed order.
+template <class T>
+__device__ __forceinline__ T reduce16(const T (&v)[16], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    T a[8], c[4], d[2];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const T keep = b0 ? v[2 * m + 1] : v[2 * m], send = b0 ? v[2 * m] : v[2 * m + 1];
+        a[m] = keep + pdpp<0xB1>(send); // xor 1
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const T keep = b1 ? a[2 * m + 1] : a[2 * m], send = b1 ? a[2 * m] : a[2 * m + 1];
+        c[m] = keep + pdpp<0x4E>(send); // xor 2
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const T keep = b2 ? c[2 * m + 1] : c[2 * m], send = b2 ? c[2 * m] : c[2 * m + 1];
+        d[m] = keep + __shfl_xor(send, 4, 64);
+    }
+    const T keep = b3 ? d[1] : d[0], send = b3 ? d[0] : d[1];
+    T t = keep + pdpp<0x128>(send); // row_ror:8 == xor 8 inside a row of 16
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    return t;
+}
+
+template <class T, bool FULL>
+__device__ __forceinline__ void snp16_decode(unsigned word, T imp, int64_t i, int64_t n, T (&o)[16]) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const unsigned c = (word >> (2 * e)) & 3u;
+        const T x = c == 3u ? imp : T(c);
+        o[e] = (FULL || i + e < n) ? x : T(0);
+    }
+}
+
+template <class T, bool FULL>
+__device__ __forceinline__ void panel_step_snp16_body(const SnpAcc<T>& X, int64_t n, const T* __restrict__ w, T* __restrict__ r,
+                                                      const int32_t* __restrict__ dcol, const T* __restrict__ dlt, int nz,
+                                                      const int32_t* __restrict__ cols, int nb, T* __restrict__ part,
+                                                      int64_t part_ld, T (*red)[S16_RS], T* wrs, T* psum, const T* ptab, int t,
+                                                      int64_t slice) {
+    constexpr int U = 16;
+    const int lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t i = slice * S16_RS + int64_t(lane) * 16;
+    const bool in = FULL || i < n;
+    const int64_t wofs = in ? (i >> 4) : 0; // (columns are 64-byte aligned and padded: an aligned word inside the column)
+    auto word = [&](int j) -> unsigned {
+        const unsigned x = reinterpret_cast<const unsigned*>(X.colptr(j))[wofs];
+        return in ? x : 0u;
+    };
+    // ---- every load of the step ------------------------------------------------------------------------------------------
+    unsigned xa[U], xb[U];
+    int ja[U], jb[U];
+    if (nz > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) ja[u] = dcol[min(wv + 4 * u, nz - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xa[u] = word(ja[u]);
+    }
+    // calls of this lane's word that lie below n (the ragged last slice; the table lookups have no other guard)
+    unsigned vmask = 0xFFFFFFFFu;
+    if (!FULL) {
+        const int64_t left = n - i;
+        vmask = left >= 16 ? 0xFFFFFFFFu : (left <= 0 ? 0u : ((1u << (2 * int(left))) - 1u));
+    }
+    if (nb > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) jb[u] = cols[min(wv + 4 * u, nb - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xb[u] = word(jb[u]);
+    }
+    // this wave's quarter of the slice's rows: elements 4 wv .. 4 wv + 3 of every lane
+    const int64_t q0 = i + 4 * wv;
+    T rq[4], wq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool ok = FULL || q0 + k < n;
+        rq[k] = ok ? r[q0 + k] : T(0);
+        wq[k] = ok ? w[q0 + k] : T(0);
+    }
+    // ---- (A) ----------------------------------------------------------------------------------------------------------------
+    if (nz > 0) {
+        __syncthreads(); // the pair tables are complete (uniform: nz is the same for the whole workgroup)
+        T acc[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = T(0);
+        // Two columns at a time through a 16-entry table per column PAIR (ptab, built by the whole workgroup from the pair's
+        // coefficients and impute values: entry c1 + 4 c2 = cf_a x_a(c1) + cf_b x_b(c2)): the calls of the two columns are
+        // interleaved into nibbles once per word pair, and an element costs two integer instructions, one LDS read (a table is
+        // one row of banks: conflict-free for any mix of indices) and one addition, where decoding both calls and two
+        // multiply-adds cost twelve.
+        for (int m0 = wv, bt = 0; m0 < nz; m0 += 4 * U, ++bt) {
+            if (m0 != wv) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) ja[u] = dcol[min(m0 + 4 * u, nz - 1)];
+#pragma unroll
+                for (int u = 0; u < U; ++u) xa[u] = word(ja[u]);
+            }
+#pragma unroll
+            for (int k = 0; k < U / 2; ++k) {
+                const unsigned w1 = xa[2 * k] & vmask, w2 = xa[2 * k + 1] & vmask;
+                const unsigned wi = (w1 & 0x33333333u) | ((w2 & 0x33333333u) << 2);  // nibble j: calls 2j of both columns
+                const unsigned wo = ((w1 >> 2) & 0x33333333u) | (w2 & 0xCCCCCCCCu);  // nibble j: calls 2j + 1
+                const T* tb = ptab + (bt * 32 + wv * 8 + k) * 16;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc[2 * j] += tb[(wi >> (4 * j)) & 15u];
+                    acc[2 * j + 1] += tb[(wo >> (4 * j)) & 15u];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wv][e * 64 + lane] = acc[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = (4 * wv + k) * 64 + lane;
+        const bool ok = FULL || q0 + k < n;
+        T rr = rq[k];
+        if (nz > 0) {
+            rr -= ((red[0][q] + red[1][q]) + (red[2][q] + red[3][q]));
+            if (ok) r[q0 + k] = rr;
+        }
+        wrs[q] = ok ? wq[k] * rr : T(0);
+    }
+    if (nb <= 0) return;
+    __syncthreads();
+    // ---- (B) ----------------------------------------------------------------------------------------------------------------
+    T wr[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) wr[e] = wrs[e * 64 + lane];
+    for (int c0 = wv; c0 < nb; c0 += 4 * U) {
+        if (c0 != wv) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) jb[u] = cols[min(c0 + 4 * u, nb - 1)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) xb[u] = word(jb[u]);
+        }
+        T pu[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            T xx[16];
+            snp16_decode<T, FULL>(xb[u], X.impute[jb[u]], i, n, xx);
+            T sacc = T(0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc = fma(xx[e], wr[e], sacc);
+            pu[u] = sacc;
+        }
+        const T tot = reduce16(pu, lane);
+        if (lane < U && c0 + 4 * lane < nb) psum[c0 + 4 * lane] = tot;
+    }
+    (void)part; (void)part_ld;
+}
+
+template <class T>
+__global__ __launch_bounds__(256 * S16_NSUB) void panel_step_snp16_kernel(SnpAcc<T> X, int64_t n, const T* __restrict__ w,
+                                                                          T* __restrict__ r, const int32_t* __restrict__ dcol,
+                                                                          const T* __restrict__ dlt,
+                                                                          const int32_t* __restrict__ nz_dev,
+                                                                          const int32_t* __restrict__ cols, int nb,
+                                                                          T* __restrict__ part, int64_t part_ld, StepTail<T> tail) {
+    __shared__ T red[S16_NSUB][4][S16_RS];
+    __shared__ T wrs[S16_NSUB][S16_RS];
+    __shared__ T psum[S16_NSUB][PB];
+    __shared__ T ptab[64 * 16]; // pair tables of phase (A): [batch of 64 columns][wave][pair of the wave's columns][16]
+    const int nz = nz_dev[0];
+    const int sub = threadIdx.x >> 8, t = threadIdx.x & 255;
+    const int64_t slice = int64_t(blockIdx.x) * S16_NSUB + sub;
+    if (nz > 0) { // pair q = bt * 32 + wave * 8 + k holds columns m_a = wave + 64 bt + 8 k and m_a + 4 of the change list
+        const int e = threadIdx.x & 15, c1 = e & 3, c2 = e >> 2;
+        const int npairs = ((min(nz, PB) + 63) / 64) * 32;
+        for (int q = threadIdx.x >> 4; q < npairs; q += (256 * S16_NSUB) / 16) {
+            const int ma = ((q >> 3) & 3) + 64 * (q >> 5) + 8 * (q & 7), mb = ma + 4;
+            T va = T(0), vb = T(0);
+            if (ma < nz) {
+                const T cfa = dlt[ma];
+                va = cfa * (c1 == 3 ? X.impute[dcol[ma]] : T(c1));
+            }
+            if (mb < nz) {
+                const T cfb = dlt[mb];
+                vb = cfb * (c2 == 3 ? X.impute[dcol[mb]] : T(c2));
+            }
+            ptab[q * 16 + e] = va + vb;
+        }
+    }
+    if ((int64_t(blockIdx.x) + 1) * S16_NSUB * S16_RS <= n)
+        panel_step_snp16_body<T, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red[sub], wrs[sub], psum[sub], ptab, t, slice);
+    else
+        panel_step_snp16_body<T, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red[sub], wrs[sub], psum[sub], ptab, t, slice);
+    if (nb <= 0) return; // (uniform)
+    __syncthreads();
+    const bool do_tail = tail.counter != nullptr; // (then part_ld > 0: column-major partials)
+    if (int(threadIdx.x) < nb) { // one partial per column and workgroup: the two slices in a fixed order
+        const int c = threadIdx.x;
+        const T tot = psum[0][c] + psum[1][c];
+        T* dst = part + (part_ld > 0 ? int64_t(c) * part_ld + blockIdx.x : int64_t(blockIdx.x) * PB + c);
+        // tail: device-coherent (written through) -- workgroups of this launch on other XCDs read it
+        if (do_tail) __hip_atomic_store(dst, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = tot;
+    }
+    if (!do_tail) return;
+    // ---- tail: the LAST EIGHT workgroups to get here sum the partials, eight columns per workgroup and round ----------------
+    // One workgroup alone pulls the 125 KB of partials at a single compute unit's ~60 GB/s (measured: slower than the reduce
+    // launch it replaces); eight of them take one round trip.  They wait for the stragglers on the arrival counter (they are
+    // resident and nobody waits for them: no deadlock); same sums in the same order whoever computes them.
+    __shared__ int s_rank;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) s_rank = __hip_atomic_fetch_add(tail.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tail.base;
+    __syncthreads();
+    const int nwg = int(gridDim.x), NT = nwg < 8 ? nwg : 8;
+    const int rank = s_rank;
+    if (rank < nwg - NT) return;
+    const int tidx = rank - (nwg - NT);
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(tail.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tail.base < nwg) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int lane = threadIdx.x & 63, wvg = threadIdx.x >> 6; // 8 wavefronts: one column each per round
+    for (int c = tidx * 8 + wvg; c < nb; c += NT * 8) {
+        const T* pc = part + int64_t(c) * part_ld;
+        T sacc = T(0);
+        for (int k0 = lane; k0 < nwg; k0 += 4 * 64) { // (fixed order: lane, lane + 64, ...)
+            T v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                v[u] = (k0 + 64 * u < nwg) ? __hip_atomic_load(pc + k0 + 64 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : T(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sacc += v[u];
+        }
+        sacc = wave_sum64(sacc);
+        if (lane == 0) {
+            T g = sacc;
+            if (tail.xm) g -= tail.rsum[0] * tail.xm[cols[c]];
+            tail.g[c] = g;
+        }
+    }
+}
+
 // Fused look-ahead step (solver.hip::run_panel_passes): workgroup 0 runs the solve of block j (blk_solve_body, one wavefront
 // against the diagonal block in LDS) while workgroups 1.. run the panel step that prepares block j+1 -- phase (A) with the
 // changes of block j-1, phase (B) on a residual that does not contain block j's changes yet (the next solve corrects with
@@ -366,11 +622,12 @@ __global__ void gather_i32_kernel(const int32_t* __restrict__ src, const int32_t
 
 template <class T, class Acc, int VEC>
 int step_launch(const Acc& acc, int64_t n, const T* w, T* r, const int32_t* dcol, const T* dlt, const int32_t* nz_dev,
-                const int32_t* cols, int nb, T* part, hipStream_t s) {
+                const int32_t* cols, int nb, T* part, bool slice_major, hipStream_t s) {
     constexpr int RS = 64 * VEC;
     const int64_t ns = (n + RS - 1) / RS;
+    // slice_major: part[slice * 128 + c] for a solve that sums the partials itself (blk_solve_la_body), else part[c * ns + slice]
     hipLaunchKernelGGL((panel_step_kernel<T, Acc, VEC>), dim3((unsigned)ns), dim3(PT), 0, s, acc, n, w, r, dcol, dlt,
-                       nz_dev, cols, nb, part, ns);
+                       nz_dev, cols, nb, part, slice_major ? int64_t(0) : ns);
     return int(ns);
 }
 
@@ -543,22 +800,36 @@ int64_t panel_part_elems(int64_t n) { return int64_t(PB) * ((n + 63) / 64) + 16;
 
 template <class T>
 int launch_panel_step(const DenseView<T>& X, const T* w, T* r, const int32_t* dcol, const T* dlt, const int32_t* nz_dev,
-                      const int32_t* cols, int nb, T* part, hipStream_t s) {
+                      const int32_t* cols, int nb, T* part, hipStream_t s, bool slice_major) {
     DenseAcc<T> acc{X.X, X.ld};
     constexpr int V = VecOf<T>::N;
     const bool vecok = (X.ld % V == 0) && ((reinterpret_cast<uintptr_t>(X.X) % 16) == 0);
-    if (vecok) return step_launch<T, DenseAcc<T>, V>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
-    return step_launch<T, DenseAcc<T>, 1>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
+    if (vecok) return step_launch<T, DenseAcc<T>, V>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, slice_major, s);
+    return step_launch<T, DenseAcc<T>, 1>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, slice_major, s);
 }
 template <class T>
 int launch_panel_step_snp(const SnpView& X, const T* impute, const T* w, T* r, const int32_t* dcol, const T* dlt,
-                          const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s) {
+                          const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s, bool slice_major,
+                          const StepTail<T>* tail, bool* tailed) {
     SnpAcc<T> acc{X.bits, X.ldb, impute};
+    if (tailed) *tailed = false;
     // 16 calls (one 32-bit word) per lane and column instead of 4 (one byte): a quarter of the workgroups, four times the
     // bytes per load instruction - the byte form is bound by the number of workgroups and load instructions, not by bytes.
-    if (X.n >= 16384 && X.ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(X.bits) % 4) == 0)
-        return step_launch<T, SnpAcc<T>, 16>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
-    return step_launch<T, SnpAcc<T>, 4>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, s);
+    if (X.n >= 16384 && X.ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(X.bits) % 4) == 0) {
+        static const bool old_form = std::getenv("ADELIE_HIP_SNP16_OLD") != nullptr; // (A/B of the round-6 kernel)
+        if (old_form) return step_launch<T, SnpAcc<T>, 16>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, slice_major, s);
+        constexpr int64_t RW = int64_t(S16_RS) * S16_NSUB;
+        const int64_t nwg = (X.n + RW - 1) / RW;
+        StepTail<T> tl{};
+        if (tail && nb > 0 && !slice_major) {
+            tl = *tail;
+            if (tailed) *tailed = true;
+        }
+        hipLaunchKernelGGL((panel_step_snp16_kernel<T>), dim3((unsigned)nwg), dim3(256 * S16_NSUB), 0, s, acc, X.n, w, r, dcol,
+                           dlt, nz_dev, cols, nb, part, slice_major ? int64_t(0) : nwg, tl);
+        return int(nwg);
+    }
+    return step_launch<T, SnpAcc<T>, 4>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, slice_major, s);
 }
 template <class T>
 void launch_panel_reduce(const T* part, int nslices, int nb, const int32_t* cols, const T* rsum_dev, const T* xm_by_col,
@@ -588,9 +859,10 @@ void launch_gather_i32(const int32_t* src, const int32_t* idx, int cnt, int32_t*
 
 #define INST(T)                                                                                                        \
     template int launch_panel_step<T>(const DenseView<T>&, const T*, T*, const int32_t*, const T*, const int32_t*,     \
-                                      const int32_t*, int, T*, hipStream_t);                                           \
+                                      const int32_t*, int, T*, hipStream_t, bool);                                     \
     template int launch_panel_step_snp<T>(const SnpView&, const T*, const T*, T*, const int32_t*, const T*,            \
-                                          const int32_t*, const int32_t*, int, T*, hipStream_t);                       \
+                                          const int32_t*, const int32_t*, int, T*, hipStream_t, bool,                  \
+                                          const StepTail<T>*, bool*);                                                  \
     template void launch_panel_reduce<T>(const T*, int, int, const int32_t*, const T*, const T*, T*, hipStream_t);     \
     template void launch_panel_reduce_ld<T>(const T*, int64_t, int, int, const int32_t*, const T*, const T*, T*,       \
                                             hipStream_t);                                                              \

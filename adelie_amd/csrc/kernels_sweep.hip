@@ -489,7 +489,7 @@ inline void lut_shape(int64_t n, int64_t ncols, int64_t& blocks_c, int64_t& ns, 
     ns = std::max<int64_t>(1, (8192 + blocks_c - 1) / blocks_c);
     ns = std::min<int64_t>(std::min(ns, std::max<int64_t>(1, n / (int64_t(kLutTile) * 8))), 65535);
     rps = (n + ns - 1) / ns;
-    rps = ((rps + kLutTile - 1) / kLutTile) * kLutTile;
+    rps = ((rps + 2 * kLutTile - 1) / (2 * kLutTile)) * (2 * kLutTile); // whole 128-byte lines of a column (two tiles)
     ns = (n + rps - 1) / rps;
 }
 int64_t sweep_work_elems(int64_t n, int64_t ncols) {
@@ -540,10 +540,19 @@ void launch_sweep(const DenseView<T>& X, const T* v, T* out, int64_t c0, int64_t
 // — the vector v is the same for all columns, so a table serves every column of the workgroup — and then every thread adds
 // one T012 and one T3 entry per nibble of its column (two shifts/masks, two LDS reads, two additions for two calls); the
 // imputed value enters once at the end, S012 + impute_c * S3.  A table of 16 entries of 8 bytes is one row of LDS banks:
-// any mix of indices over the lanes is conflict-free.  Columns are 64-byte aligned and padded (SnpView::ldb): a tile of a
-// column is four 16-byte loads.  Fixed summation order; row splits leave partials for sweep_reduce_kernel as above.
+// any mix of indices over the lanes is conflict-free.  Columns are 128-byte aligned and padded (SnpView::ldb): a line of a
+// column is two tiles.  Fixed summation order; row splits leave partials for sweep_reduce_kernel as above.
 constexpr int LUT_TR = 256;
 static_assert(LUT_TR == 256, "lut_shape's tile");
+// How the columns come in.  A thread owning a column and fetching it 16 bytes at a time makes EIGHT separate requests for every
+// 128-byte line, each wave instruction touching 64 different lines; with ~20 resident waves per compute unit the lines leave
+// the L1 and even the L2 (5 MB in flight per XCD against 4 MB) between two of them: 13.6-14.3 GB of counter traffic per sweep
+// of the 6.25 GB design (2.2 x; profiles/r05_cfg4_*, and unchanged when a thread merely takes the whole line in one trip:
+// profiles/r06_cfg4_lut_line_per_trip.txt).  So the workgroup fetches cooperatively: per trip of 512 rows (one line per
+// column) eight adjacent lanes take the eight 16-byte pieces of one column's line -- every line is requested once, whole, by
+// one instruction -- and the pieces go through a 32 KB staging array in LDS (rotated by the column index: conflict-free in
+// both directions) from which every thread reads back its own column.  The next trip's pieces are in flight while the
+// current one is looked up.
 // SQ: the squared design (x^2: the weighted column variances of an IRLS iteration): the table holds c'^2, the end impute^2.
 template <class T, bool SQ>
 __global__ __launch_bounds__(kThreads) void sweep_snp_lut_kernel(const uint8_t* __restrict__ bits, int64_t ldb,
@@ -552,47 +561,78 @@ __global__ __launch_bounds__(kThreads) void sweep_snp_lut_kernel(const uint8_t* 
                                                                  const int32_t* __restrict__ cols, int64_t rows_per_split,
                                                                  int nsplit, const T* __restrict__ sub_scale,
                                                                  const T* __restrict__ sub_vec) {
+    static_assert(kThreads == 256, "256 columns per workgroup, 8 lanes per line");
     constexpr int NP = LUT_TR / 2;              // row pairs per tile
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
     __shared__ T t012[NP][16];
     __shared__ T t3[NP][16];
+    __shared__ u4_t stage[kThreads * 8];        // [column][piece rotated by the column]
+    __shared__ int64_t cofs[kThreads];          // byte offset of the workgroup's columns
     const int tid = threadIdx.x;
     const int split = blockIdx.y;
-    const int64_t r0 = int64_t(split) * rows_per_split; // (a multiple of LUT_TR)
+    const int64_t r0 = int64_t(split) * rows_per_split; // (a multiple of 2 * LUT_TR: whole lines)
     const int64_t r1 = min(n, r0 + rows_per_split);
     int64_t c = int64_t(blockIdx.x) * kThreads + tid;
     const bool live = c < ncols;
     if (!live) c = ncols - 1;
     const int64_t cj = cols ? int64_t(cols[c]) : c0 + c;
-    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-    const u4_t* colp = reinterpret_cast<const u4_t*>(bits + cj * ldb);
+    cofs[tid] = cj * ldb;
+    __syncthreads();
+    // fetch role: piece tid & 7 of the lines of columns (tid >> 3) + 32 u
+    const int fp = tid & 7, fc = tid >> 3;
+    const uint8_t* fptr[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) fptr[u] = bits + cofs[fc + 32 * u] + fp * 16;
     // table role of this thread: pair tid / 2, entries 8 * (tid & 1) .. + 8
     const int tp = tid >> 1, te0 = (tid & 1) * 8;
     T a = T(0), b = T(0);
-    for (int64_t base = r0; base < r1; base += LUT_TR) {
-        const int64_t q0 = base / 64; // tile offset in 16-byte units (LUT_TR calls = 64 bytes = 4 units)
-        u4_t w[4];
+    u4_t w[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = __builtin_nontemporal_load(colp + q0 + u);
-        const int64_t i0 = base + 2 * tp;
-        const T v0 = i0 < n ? v[i0] : T(0), v1 = i0 + 1 < n ? v[i0 + 1] : T(0);
-        __syncthreads(); // the previous tile's lookups are done
+    for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(fptr[u] + r0 / 4));
+    for (int64_t base = r0; base < r1; base += 2 * LUT_TR) {
+        __syncthreads(); // the previous trip's lookups are done: the staging array is free
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int idx = te0 + e, k0 = idx & 3, k1 = idx >> 2;
-            t012[tp][idx] = (k0 < 3 ? T(SQ ? k0 * k0 : k0) : T(0)) * v0 + (k1 < 3 ? T(SQ ? k1 * k1 : k1) : T(0)) * v1;
-            t3[tp][idx] = (k0 == 3 ? v0 : T(0)) + (k1 == 3 ? v1 : T(0));
+        for (int u = 0; u < 8; ++u) {
+            const int col = fc + 32 * u;
+            stage[col * 8 + ((fp + col) & 7)] = w[u];
         }
-        __syncthreads();
+        const int64_t nbase = base + 2 * LUT_TR;
+        if (nbase < r1) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(fptr[u] + nbase / 4));
+        }
+        T vv[4];
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
+        for (int h = 0; h < 2; ++h) {
+            const int64_t i0 = base + h * LUT_TR + 2 * tp;
+            vv[2 * h] = i0 < r1 ? v[i0] : T(0);
+            vv[2 * h + 1] = i0 + 1 < r1 ? v[i0 + 1] : T(0);
+        }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int pr = (u * 4 + h) * 8 + k; // row pair of this nibble (compile-time)
-                    const unsigned idx = (w[u][h] >> (4 * k)) & 15u;
-                    a += t012[pr][idx];
-                    b += t3[pr][idx];
+        for (int h = 0; h < 2; ++h) {
+            const T v0 = vv[2 * h], v1 = vv[2 * h + 1];
+            if (h == 1) __syncthreads(); // tile 0's lookups are done
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int idx = te0 + e, k0 = idx & 3, k1 = idx >> 2;
+                t012[tp][idx] = (k0 < 3 ? T(SQ ? k0 * k0 : k0) : T(0)) * v0 + (k1 < 3 ? T(SQ ? k1 * k1 : k1) : T(0)) * v1;
+                t3[tp][idx] = (k0 == 3 ? v0 : T(0)) + (k1 == 3 ? v1 : T(0));
+            }
+            __syncthreads(); // (h == 0: also makes the staged pieces visible)
+            u4_t wd[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wd[u] = stage[tid * 8 + ((4 * h + u + tid) & 7)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int hh = 0; hh < 4; ++hh) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int pr = (u * 4 + hh) * 8 + k; // row pair of this nibble (compile-time)
+                        const unsigned idx = (wd[u][hh] >> (4 * k)) & 15u;
+                        a += t012[pr][idx];
+                        b += t3[pr][idx];
+                    }
                 }
             }
         }
@@ -611,7 +651,7 @@ __global__ __launch_bounds__(kThreads) void sweep_snp_lut_kernel(const uint8_t* 
 template <class T>
 void launch_sweep_snp(const SnpView& X, const T* impute, const T* v, T* out, int64_t c0, int64_t ncols,
                       const int32_t* cols, const T* sub_scale, const T* sub_vec, bool square, T* work, hipStream_t s) {
-    if (ncols >= 512 && X.n >= 4096 && X.ldb % 64 == 0 && (reinterpret_cast<uintptr_t>(X.bits) % 64) == 0) {
+    if (ncols >= 512 && X.n >= 4096 && X.ldb % 128 == 0 && (reinterpret_cast<uintptr_t>(X.bits) % 128) == 0) {
         // the same partial layout and reduce as sweep_dispatch (`work`: sweep_work_elems covers lut_shape's splits)
         int64_t blocks_c, ns, rps;
         lut_shape(X.n, ncols, blocks_c, ns, rps);

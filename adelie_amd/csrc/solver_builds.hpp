@@ -335,6 +335,14 @@
         min_usable_version = v;
     }
     bool prebuild_enabled = true; // A/B hook ADELIE_HIP_PREBUILD=0
+    // sequential panel form: the stand-alone solve sums the step's slice partials itself instead of a panel_reduce launch per
+    // block.  Measured SLOWER on config 4 (cd 2787-2794 against 2737-2739 ms with 489 partials per column, 2710-2729 against
+    // 2667-2677 ms with 245): one compute unit pulls the 125-250 KB of partials at ~60 GB/s, which costs more than the
+    // 64-workgroup reduce launch (4.7 us) and its boundary.  Off; hook ADELIE_HIP_SOLVE_SUMS=1 (A/B).
+    bool plain_solve_sums = false;
+    // sequential panel form on a 2-bit design: the step's last eight workgroups sum its partials (StepTail) -- no panel_reduce
+    // launch per block.  A/B hook ADELIE_HIP_STEP_TAIL=0.
+    bool step_tail = true;
     // look-ahead passes: the solve of a fused launch sums the previous launch's slice partials itself (second round trip of
     // blk_solve_la_body's prologue) instead of a panel_reduce launch between every two fused launches.  Round 2 measured this
     // slower (3.08 vs 3.20 paths/s) with the solve's old prologue; with the one-round-trip prologue the fused launch grows by

@@ -385,6 +385,12 @@
             Stopwatch sw_enq;
             sw_enq.start();
             // the step of block 0 goes out before the builds are enqueued (it does not depend on them; see record_pass_e0)
+            // The stand-alone solve sums the slice partials itself (blk_solve_la_body, second round trip of its prologue): no
+            // panel_reduce launch between step and solve.  Config 4: 54.8 k blocks per path x (reduce 4.85 us + a boundary).
+            // Not with constraints (their solve kernel has the plain prologue), views and compressed columns (their gradient
+            // is corrected / written by other launches), the multi-response view (its own partial layout).
+            bool step_tailed_of[2] = {false, false};
+            const bool solve_sums = plain_solve_sums && !cons_on && !multi() && !std_generic() && !sparse() && D->std_center == nullptr;
             auto step_of = [&](int j) {
                 const int nb = std::min(B, count - j * B);
                 const int32_t* cols = cols_all + size_t(j) * B;
@@ -392,10 +398,13 @@
                 if (time_panel) t_step.begin(st);
                 const int nsl = panel_step(cur_w, r_dev, ps < 0 ? d_dcolblk.p : d_la_dcol.p + size_t(ps) * SL,
                                            ps < 0 ? d_dlt.p : d_la_dlt.p + size_t(ps) * SL,
-                                           ps < 0 ? &d_blk.p->nz : d_la_nz.p + ps, cols, nb);
+                                           ps < 0 ? &d_blk.p->nz : d_la_nz.p + ps, cols, nb, solve_sums,
+                                           step_tail && !solve_sums && !multi() && !sparse(), xm_c);
                 if (time_panel) t_step.end(st);
+                step_tailed_of[j & 1] = step_tailed;
                 return nsl;
             };
+
             record_pass_e0();
             t_cd.begin(st);
             const int nsl0 = step_of(0);
@@ -439,7 +448,12 @@
                 const int nsl = (j == 0) ? nsl0 : step_of(j);
                 pending_slot = -1;
                 cnt.n_panel_cols += nb;
-                panel_reduce(nsl, nb, cols, xm_c, d_gblk.p);
+                if (solve_sums) {
+                    bp.part = d_part.p; bp.part_ld = 0; bp.part_n = nsl;
+                    bp.part_rsum = xm_c ? &d_blk.p->resid_sum : nullptr; // (the residual sum the step's residual belongs to)
+                } else if (!step_tailed_of[j & 1]) { // (else the step's last workgroups left the gradient in d_gblk)
+                    panel_reduce(nsl, nb, cols, xm_c, d_gblk.p);
+                }
                 bp.Dptr = Dptr;
                 if (h_report && j == nblk - 1) {
                     bp.report_j = j;

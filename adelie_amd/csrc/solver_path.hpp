@@ -433,6 +433,8 @@
         fuse_reduce = !multi() && fused_partials() <= 200;
         if (hooks.speculate >= 0) spec_enabled = hooks.speculate != 0;
         if (hooks.irls_reuse >= 0) irls_reuse = hooks.irls_reuse;
+        if (hooks.solve_sums >= 0) plain_solve_sums = hooks.solve_sums != 0;
+        if (hooks.step_tail >= 0) step_tail = hooks.step_tail != 0;
         panel_bsz = hooks.panel_bsz;
         if (cov_mode) { // base state of the covariance method: no intercept, adev_tol = ddev_tol = 0 (state_gaussian_cov.hpp:118)
             engine_panel = false; // the panel engines work on the residual; the Gram engines on C = A[S, S] and its gradient

@@ -41,7 +41,14 @@
         if (dense()) launch_sweep<T>(D->dense<T>(), v, out, 0, ncols, cols, sub_scale, sub_vec, square, work, st);
         else launch_sweep_snp<T>(D->snp(), static_cast<const T*>(D->impute), v, out, 0, ncols, cols, sub_scale, sub_vec, square, work, st);
     }
-    int panel_step(const T* w, T* r, const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb) {
+    // `want_tail`: the step may leave the block's gradient in d_gblk itself (2-bit designs, StepTail; kernels.hpp) -- then
+    // step_tailed is set and the caller skips panel_reduce; tail_xm = the by-column means of the intercept term (or nullptr)
+    DevBuf<int32_t> d_tail_ctr;
+    int32_t tail_base = 0;
+    bool step_tailed = false;
+    int panel_step(const T* w, T* r, const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb,
+                   bool slice_major = false, bool want_tail = false, const T* tail_xm = nullptr) {
+        step_tailed = false;
         if (multi()) return launch_multi_panel_step<T>(D->multi<T>(), w, r, dcol, dlt, nz_dev, cols, nb, d_part.p, st);
         const T* kappa = nullptr;
         const bool stdv = D->std_center != nullptr; // a standardized view (of a dense / 2-bit design, or of compressed columns)
@@ -63,9 +70,26 @@
                                        &d_blk.p->resid_sum, intercept ? cur_xm : nullptr, st);
             return 0;
         }
-        const int nsl = dense() ? launch_panel_step<T>(D->dense<T>(), w, r, dcol, dlt, nz_dev, cols, nb, d_part.p, st)
-                                : launch_panel_step_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, r, dcol, dlt, nz_dev, cols,
-                                                           nb, d_part.p, st);
+        if (dense()) return launch_panel_step<T>(D->dense<T>(), w, r, dcol, dlt, nz_dev, cols, nb, d_part.p, st, slice_major);
+        StepTail<T> tl{};
+        const bool tail_ok = want_tail && !stdv && nb > 0 && !slice_major;
+        if (tail_ok) {
+            if (!d_tail_ctr.p) { // (monotone over the launches of this solver; zeroed once)
+                d_tail_ctr.reserve(4);
+                AHIP_CHECK(hipMemsetAsync(d_tail_ctr.p, 0, 4 * sizeof(int32_t), st));
+                tail_base = 0;
+            }
+            tl.counter = d_tail_ctr.p; tl.base = tail_base; tl.g = d_gblk.p; tl.rsum = &d_blk.p->resid_sum; tl.xm = tail_xm;
+        }
+        const int nsl = launch_panel_step_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, r, dcol, dlt, nz_dev, cols, nb,
+                                                 d_part.p, st, slice_major, tail_ok ? &tl : nullptr, &step_tailed);
+        if (step_tailed) {
+            tail_base += nsl;
+            if (tail_base > (int32_t(1) << 30)) { // (far from overflow: start over behind everything enqueued so far)
+                AHIP_CHECK(hipMemsetAsync(d_tail_ctr.p, 0, 4 * sizeof(int32_t), st));
+                tail_base = 0;
+            }
+        }
         (void)kappa;
         return nsl;
     }

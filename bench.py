@@ -132,6 +132,19 @@ def measured_traffic(key):
         return None
 
 
+def tag_traffic_source(obj):
+    """`traffic` in a roofline object is not measured in this run: it is the per-launch HBM byte count of the PMC passes kept
+    under profiles/ (a constant of the tree).  Say so next to every one of them."""
+    if isinstance(obj, dict):
+        if obj.get("traffic") is not None and "bound" in obj:
+            obj["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run; not measured in this run)"
+        for v in obj.values():
+            tag_traffic_source(v)
+    elif isinstance(obj, list):
+        for v in obj:
+            tag_traffic_source(v)
+
+
 def host_cores():
     try:
         return len(os.sched_getaffinity(0))
@@ -185,6 +198,20 @@ class Ctx:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             el = float(t.item())
         return outs, el
+
+
+def gathered_fold_counts(ctx, n_folds):
+    """A multi-rank run must prove that the configured backend (RCCL unless BENCH_BACKEND says otherwise) carried the fold
+    gather and that every rank contributed rows: the fold counts of the ranks, collected by an all_gather of their own."""
+    torch, dist = ctx.torch, ctx.dist
+    if ctx.backend == "nccl":
+        assert dist.get_backend() == "nccl", dist.get_backend()
+    mine = torch.tensor([len(range(ctx.rank, n_folds, ctx.world))], device=ctx.comm_device, dtype=torch.int64)
+    per_rank = [torch.zeros_like(mine) for _ in range(ctx.world)]
+    dist.all_gather(per_rank, mine)
+    per_rank = [int(t.item()) for t in per_rank]
+    assert sum(per_rank) == n_folds and all(c > 0 for c in per_rank[:min(ctx.world, n_folds)]), per_rank
+    return per_rank
 
 
 def measure(ctx, cfg, *, n, p, gs, alpha, dtype, L, steps, warmup, n_folds=8, cv_leg=False, data=None):
@@ -256,15 +283,7 @@ def measure(ctx, cfg, *, n, p, gs, alpha, dtype, L, steps, warmup, n_folds=8, cv
         units = n_folds * steps                         # fold paths of ONE sharded CV per step
         stats = [f for o in outs for f in o.fold_stats]
         if dist is not None:
-            # the first real multi-GPU run must prove that RCCL carried the fold gather and that every rank contributed rows
-            if ctx.backend == "nccl":
-                assert dist.get_backend() == "nccl", dist.get_backend()
-            mine = torch.tensor([len(range(rank, n_folds, world))], device=ctx.comm_device, dtype=torch.int64)
-            per_rank = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(per_rank, mine)
-            per_rank = [int(t.item()) for t in per_rank]
-            assert sum(per_rank) == n_folds and all(c > 0 for c in per_rank[:min(world, n_folds)]), per_rank
-            keep["folds_per_rank_gathered"] = per_rank
+            keep["folds_per_rank_gathered"] = gathered_fold_counts(ctx, n_folds)
 
     # ---- the secondary CV leg of the default line ---------------------------------------------------------------------
     cv_obj = None
@@ -278,23 +297,28 @@ def measure(ctx, cfg, *, n, p, gs, alpha, dtype, L, steps, warmup, n_folds=8, cv
                         f"rank k % {world}, one all_gather of the ({n_folds}, {L}) loss table",
             "scaling": "strong", "n_gpus": world, "cv_wall_s": cv_el, "folds_per_s": n_folds / cv_el,
             "folds_per_rank": [len(range(r, n_folds, world)) for r in range(world)],
+            "folds_per_rank_gathered": (gathered_fold_counts(ctx, n_folds) if dist is not None else None),
+            "comm_backend": (dist.get_backend() if dist is not None else None),
             "best_idx": int(cv_res.best_idx), "min_avg_loss": float(cv_res.avg_losses.min()),
         }
 
     # ---- one extra, untimed step with per-launch events on the panel step kernel (second HBM-bound kernel of the path) --
     panel = None
-    if rank == 0 and cfg in (2, 3):
+    if rank == 0 and cfg in (2, 3, 4):
         os.environ["ADELIE_HIP_TIME_PANEL"] = "1"
         stp = ad.grpnet(Xd, glm, **kw)
         del os.environ["ADELIE_HIP_TIME_PANEL"]
         if stp.timers["n_panel_step_launches"] > 0:
             # gradient columns + residual-update columns (n_update_cols: columns, not groups)
             cols = stp.counters["n_panel_cols"] + stp.counters["n_update_cols"]
-            bytes_ = float(cols) * n * s_val
+            bytes_ = float(cols) * n * col_bytes_per_row
             ms = stp.timers["t_panel_step_ms"]
             panel = {
-                "kernel": "panel_fused_kernel / panel_step_kernel (r -= X_B dbeta_B of the previous block; partial gradients of the "
-                          "next block; the fused launch also carries the one-workgroup solve of the current block)",
+                "kernel": ("panel_step_snp16_kernel (sequential form under IRLS, blocks of 64 visits: r -= X_B dbeta_B of the previous "
+                           "block, partial gradients of the next block; 2-bit columns, one 32-bit word = 16 calls per lane; the reduce "
+                           "and the one-workgroup solve are launches of their own between two steps)" if cfg == 4 else
+                           "panel_fused_kernel / panel_step_kernel (r -= X_B dbeta_B of the previous block; partial gradients of the "
+                           "next block; the fused launch also carries the one-workgroup solve of the current block)"),
                 "bound": "hbm", "achieved": bytes_ / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "traffic": measured_traffic(f"panel_step_kernel:{n}x{p}:{dtype}:g{gs}"),
@@ -434,6 +458,38 @@ LEG_KEYS = ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config"
             "roofline_gram_mfma", "roofline_panel_step", "breakdown_ms_last_path", "final_active", "final_screen")
 
 
+def launch_ranks_if_needed(args):
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it: start the N ranks ourselves — re-exec under
+    ``torch.distributed.run`` (one process per GPU, rendezvous on 127.0.0.1, RCCL) with the same arguments; rank 0 of the
+    children prints the line.  Under a launcher (WORLD_SIZE set) the two numbers must agree.  Fails loudly when the box has
+    fewer than N devices — except in the one-GPU rehearsal (BENCH_DEVICE set: every rank on that device, BENCH_BACKEND=gloo)."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks")
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count()
+    if "BENCH_DEVICE" not in os.environ and have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} devices, this box has {have} "
+                         "(one-GPU rehearsal of the multi-rank logic: BENCH_BACKEND=gloo BENCH_DEVICE=0)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -459,6 +515,7 @@ def main():
     ap.add_argument("--cfg4-parity-budget-s", type=float, default=200.0,
                     help="config 4: CPU budget of the coarse-path parity sample with non-zero coefficients (0: skip)")
     args = ap.parse_args()
+    launch_ranks_if_needed(args)
     cfg = args.config
     if args.steps is None:
         args.steps = {2: 3, 3: 2, 4: 1, 5: 3}[cfg]
@@ -482,10 +539,28 @@ def main():
         def leg(line):
             return {k: line[k] for k in LEG_KEYS if k in line}
 
+        # bounded CPU legs of the other configurations (the headline's own is above): ~20 s of oracle time each
+        leg_args = argparse.Namespace(**vars(args))
+        leg_args.cpu_budget_s, leg_args.tight_tol_budget_s, leg_args.cfg4_parity_budget_s = 20.0, 15.0, 90.0
+        leg_args.cpu_1thread_budget_s = 0.0
+
+        def cpu_leg(c, kp, n_, p_):
+            if args.no_cpu_baseline:
+                return None
+            try:
+                return cpu_baseline(c, leg_args, kp, kp["y"].astype(kp["npdtype"]), kp["glm"], kp["kw"], kp["cv_kw"],
+                                    kp["npdtype"], kp["last"], kp["Xd"], n_, p_)
+            except Exception as e:  # noqa: BLE001  (a failed CPU leg is recorded, it does not cost the line)
+                return {"error": repr(e)}
+
+        if "cv_config5" in out:
+            out["cv_config5"]["cpu_baseline"] = cpu_leg(5, keep, n, p)
         # config 3 re-uses the resident design of the headline (same X, grouped penalty)
-        line3, _ = measure(ctx, 3, n=n, p=p, gs=10, alpha=0.5, dtype="f64", L=L, steps=2, warmup=1,
-                           data={k: keep[k] for k in ("X", "y", "Xd")})
+        line3, keep3 = measure(ctx, 3, n=n, p=p, gs=10, alpha=0.5, dtype="f64", L=L, steps=2, warmup=1,
+                               data={k: keep[k] for k in ("X", "y", "Xd", "Xh") if k in keep})
         out["cfg3"] = leg(line3)
+        out["cfg3"]["cpu_baseline"] = cpu_leg(3, keep3, n, p)
+        del keep3
         # box / one-sided constraint objects on 200 of config 3's 1000 groups: every visit of such a group is a device launch
         # (kernels_cons.hip); the same path with the visits on the host objects beside it (constraints)
         out["constrained_groups"] = constrained_leg(keep["Xd"], keep["y"], n, p)
@@ -503,8 +578,9 @@ def main():
         del k32, line32
         gc.collect()
         ctx.torch.cuda.empty_cache()
-        line4, k4 = measure(ctx, 4, n=500_000, p=50_000, gs=1, alpha=1.0, dtype="f64", L=L, steps=1, warmup=1)
+        line4, k4 = measure(ctx, 4, n=500_000, p=50_000, gs=1, alpha=1.0, dtype="f64", L=L, steps=2, warmup=1)
         out["cfg4"] = leg(line4)
+        out["cfg4"]["cpu_baseline"] = cpu_leg(4, k4, 500_000, 50_000)
         # two designs whose dense f64 form does not fit (or barely fits) in HBM, as further objects of the default line
         # (ROUNDS.md 9.9): config 4's 2-bit design under the lazy standardized view, and a sparse design kept sparse
         out["standardized_snp_view"] = lazy_views_leg(ad_design=k4["Xd"], L=L, y_binomial=k4["y"])
@@ -514,6 +590,7 @@ def main():
         out["sparse_resident"] = sparse_leg(L, cpu_budget_s=(0.0 if args.no_cpu_baseline else 15.0))
 
     if ctx.rank == 0:
+        tag_traffic_source(out)
         print(json.dumps(out), flush=True)
 
     if ctx.dist is not None:
@@ -801,6 +878,9 @@ def cpu_baseline(cfg, args, keep, y, glm, kw, cv_kw, npdtype, gpu_last, Xd, n, p
                 o_c = ad.diagnostic.objective(X_eval, glm_, st.betas, np.asarray(st.intercepts), **okw)
                 o_g = ad.diagnostic.objective(X_eval, glm_, gpu_state.betas[:k], np.asarray(gpu_state.intercepts)[:k], **okw)
                 rel = (o_g - o_c) / np.maximum(np.abs(o_c), np.finfo(np.float64).tiny)
+                # which of the reference's two criteria this comparison meets (tests/test_solver.py:444-445 coefficients to 1e-6;
+                # :446-466 else the objective): a path that stops on `tol` is resolved to the stopping rule, not to 1e-6 in beta
+                info["criterion"] = ("coefficients" if db <= 1e-6 else "objective")
                 info.update(max_rel_objective_gap_gpu_minus_cpu=float(rel.max()),
                             min_rel_objective_gap_gpu_minus_cpu=float(rel.min()),
                             reference_criterion_obj_gpu_le_obj_cpu_x_1p1e8=bool(np.all(o_g <= o_c * (1 + 1e-8) + 1e-300)
@@ -808,8 +888,13 @@ def cpu_baseline(cfg, args, keep, y, glm, kw, cv_kw, npdtype, gpu_last, Xd, n, p
             parity[tag or "default_tol"] = info
         return k, el, db
 
+    def host_copy():
+        if "Xh" not in keep:
+            keep["Xh"] = keep["X"].t().contiguous().cpu().numpy().T  # (n, p) F-ordered host copy of the same matrix
+        return keep["Xh"]
+
     if cfg in (2, 3):
-        Xh = keep["X"].t().contiguous().cpu().numpy().T  # (n, p) F-ordered host copy of the same matrix
+        Xh = host_copy()
         Xo = oracle.dense(Xh, n_threads=cores)
         k, el, db = bounded_path(Xo, glm, kw, gpu_last, X_eval=Xd)
         if k == L:
@@ -890,7 +975,7 @@ def cpu_baseline(cfg, args, keep, y, glm, kw, cv_kw, npdtype, gpu_last, Xd, n, p
         return out
 
     # cfg 5: one fold of the same CV (the full-data lmda_max call + the fold's two grpnet calls) with the oracle
-    Xh = keep["X"].t().contiguous().cpu().numpy().T
+    Xh = host_copy()
     Xo = oracle.dense(Xh, n_threads=cores)
     np.random.seed(0)
     order = np.random.choice(n, n, replace=False)

@@ -513,7 +513,7 @@ def test_speculative_pass_group_engine_and_short_passes(hip, monkeypatch, kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("family", ["binomial", "poisson"])
-def test_irls_block_reuse_against_rebuild_every_iteration(hip, monkeypatch, family):
+def test_irls_block_reuse_against_rebuild_every_iteration(hip, oracle, monkeypatch, family):
     """DESIGN 4, third deliberate deviation: with ADELIE_HIP_IRLS_REUSE=theta a diagonal block built under earlier IRLS weights
     stays in use while every weight moved by at most theta; the fixed point of the passes is unchanged, the iterates inside a
     pass move by O(theta).  theta = 0 (rebuild per iteration, the reference's arithmetic) against the default on a problem with
@@ -533,15 +533,25 @@ def test_irls_block_reuse_against_rebuild_every_iteration(hip, monkeypatch, fami
         mk = lambda: ad.glm.poisson(y)
     kw = dict(early_exit=False, lmda_path_size=15, min_ratio=0.02, tol=1e-12, irls_tol=1e-11, progress_bar=False)
     out = {}
-    for theta in ("0", "0.01"):
-        monkeypatch.setenv("ADELIE_HIP_IRLS_REUSE", theta)
+    for theta in ("0", None):          # None: the library's DEFAULT threshold (common.hpp: 10 % accumulated weight drift)
+        if theta is None:
+            monkeypatch.delenv("ADELIE_HIP_IRLS_REUSE", raising=False)
+        else:
+            monkeypatch.setenv("ADELIE_HIP_IRLS_REUSE", theta)
         out[theta] = ad.grpnet(ad.matrix.dense(X), mk(), **kw)
-    a, b = out["0"], out["0.01"]
+    a, b = out["0"], out[None]
     assert a.error == "" and b.error == "" and len(a.lmdas) == len(b.lmdas) == 15
     assert a.counters["n_panel_blocks"] > 0
+    assert b.timers["n_gram_launches"] < a.timers["n_gram_launches"]   # (blocks really were kept under the default)
     assert np.abs(a.betas.toarray() - b.betas.toarray()).max() < 1e-7
     assert np.abs(a.intercepts - b.intercepts).max() < 1e-7
     assert sorted(a.screen_set.tolist()) == sorted(b.screen_set.tolist())
+    # ... and both against the oracle, whose variances and blocks are always those of the current weights
+    o = ad.grpnet(oracle.dense(X), mk(), **kw)
+    assert o.error == ""
+    for s_ in (a, b):
+        assert np.abs(s_.betas.toarray() - o.betas.toarray()).max() < 1e-6
+        assert np.abs(s_.intercepts - o.intercepts).max() < 1e-6
 
 
 def test_penalty_l2_is_the_quadratic_parts_own_factor(hip, oracle):

@@ -14,7 +14,17 @@ Two more notebooks print the progress suffix of paths on seeded numpy data:
                              lambda, and the cell-10 assertion ``state.lmdas[-1] == lmda_star`` (exact equality)
   parallelism.ipynb cell 8   n=100, p=1000, seed 0: ``46/100 ... [dev:90.6%]`` (default early exit)
 
-(quickstart.ipynb's 46 / 38 / 57 solutions at 90.5 / 90.2 / 90.2 % are checked in test_oracle_solver.py.)
+(quickstart.ipynb's 46 / 38 / 57 solutions at 90.5 / 90.2 / 90.2 % are checked on the oracle in test_oracle_solver.py and on
+the HIP path at the end of this file.)
+
+The GROUPED path's reference-held anchor is examples.ipynb cells 4-24 ("Group Lasso with Interaction Terms", seed 1): ragged
+groups of 1 ... 20 columns (one-hot main effects, interaction blocks), custom penalty factors 1 / sqrt(2) / sqrt(3), default
+settings -> ``100/100 ... [dev:71.1%]`` (cell 20), the support of the main effects at lambda index 13
+``[0, 10, 11, 12, 13, 14]`` (cell 22) and the first interaction pair to enter, at index 16, ``[0, 10]`` (cell 24).  The
+notebook's lazy ``matrix.one_hot / interaction / standardize / concatenate`` classes are outside the hot path (SURVEY.md 2);
+the test builds the same design as a dense array, column layout restated from the docstrings of adelie/matrix.py:721-845,
+1073-1178 (a pair block is A * B with A's columns running fastest, A / B = [1, Z_j] for a continuous feature and the level
+indicators for a discrete one, the constant column of a continuous pair left out).
 
 The whole sequence is deterministic (the splits and the CV fold order draw from the seeded global numpy stream), so it can
 be replayed here: this pins the oracle — and, on the GPU, the HIP path — against outputs of the reference binary, which
@@ -246,3 +256,132 @@ def test_hip_reproduces_reference_multinomial_cv(hip):
     n_lmdas, dev, conf = _replay_digits(ad.matrix.dense)
     assert (n_lmdas, dev) == (100, "84.7")
     assert conf == REF_DIGITS_CONFUSION
+
+
+# ---- examples.ipynb cells 4-24: group lasso with interaction terms (ragged groups, custom penalties) ------------------------
+def _one_hot_dense(Z, levels):
+    cols, groups = [], []
+    for j, L in enumerate(levels.astype(int)):
+        groups.append(len(cols))
+        if L <= 0:
+            cols.append(Z[:, j])
+        else:
+            cols.extend((Z[:, j] == l).astype(float) for l in range(L))
+    return np.stack(cols, axis=1), np.array(groups)
+
+
+def _interaction_dense(Z, pairs, levels):
+    n = Z.shape[0]
+    cols, groups = [], []
+
+    def basis(j):
+        L = int(levels[j])
+        return [np.ones(n), Z[:, j]] if L <= 0 else [(Z[:, j] == l).astype(float) for l in range(L)]
+
+    for i, j in pairs:
+        A, B = basis(i), basis(j)
+        blk = [a * b for b in B for a in A]            # A's columns run fastest
+        if levels[i] <= 0 and levels[j] <= 0:
+            blk = blk[1:]                              # [Z_i, Z_j, Z_i Z_j]: no constant column
+        groups.append(len(cols))
+        cols.extend(blk)
+    return np.stack(cols, axis=1), np.array(groups)
+
+
+def _replay_examples_notebook(dense):
+    n, d_cont, d_disc = 1000, 10, 10
+    np.random.seed(1)                                                                  # cell 4
+    Z_cont = np.random.normal(0, 1, (n, d_cont))
+    levels = np.random.choice(10, d_disc, replace=True) + 1
+    Z_disc = np.array([np.random.choice(lvl, n, replace=True) for lvl in levels]).T
+    Z_cont = (Z_cont - np.mean(Z_cont, axis=0)) / np.std(Z_cont, axis=0, ddof=0)       # cell 6
+    Z = np.concatenate([Z_cont, Z_disc], axis=1)                                       # cell 8
+    levels = np.concatenate([np.zeros(d_cont), levels])
+    Z_one_hot_0 = np.zeros((n, int(levels[d_cont])))                                   # cell 10
+    Z_one_hot_0[np.arange(n), Z_disc[:, 0].astype(int)] = 1
+    Z_cont_0 = Z_cont[:, 0][:, None]
+    Z_sub = np.concatenate([Z_cont_0, Z_one_hot_0, Z_cont_0 * Z_one_hot_0], axis=1)
+    beta = np.random.normal(0, 1, Z_sub.shape[1])
+    y = Z_sub @ beta + np.random.normal(0, 1, n)
+    pairs = np.array([(0, v) for v in range(1, d_cont + d_disc)])                      # cell 12: intr_map = {0: None}
+    X_intr, g_intr = _interaction_dense(Z, pairs, levels)
+    pair_levels = levels[pairs]                                                        # cell 14
+    is_cc = np.prod(pair_levels == 0, axis=1).astype(bool)
+    cc = Z[:, pairs[is_cc][:, 0]] * Z[:, pairs[is_cc][:, 1]]
+    centers, scales = np.zeros(X_intr.shape[1]), np.ones(X_intr.shape[1])
+    centers[g_intr[is_cc] + 2] = np.mean(cc, axis=0)
+    scales[g_intr[is_cc] + 2] = np.std(cc, axis=0, ddof=0)
+    X_oh, g_oh = _one_hot_dense(Z, levels)                                             # cell 16
+    X = np.asfortranarray(np.concatenate([X_oh, (X_intr - centers) / scales], axis=1))
+    groups = np.concatenate([g_oh, X_oh.shape[1] + g_intr])                            # cell 18
+    is_cd = np.logical_xor(pair_levels[:, 0], pair_levels[:, 1])
+    pen = np.ones(len(g_intr))
+    pen[is_cc] = np.sqrt(3)
+    pen[is_cd] = np.sqrt(2)
+    penalty = np.concatenate([np.ones(len(g_oh)), pen])
+    st = ad.grpnet(dense(X), ad.glm.gaussian(y), groups=groups, penalty=penalty, progress_bar=False)   # cell 20
+    assert st.error == ""
+    p_oh = X_oh.shape[1]
+    first_intr = p_oh + st.betas[16, p_oh:].indices[0]                                 # cell 24
+    rel = np.argmax(groups == first_intr) - len(g_oh)
+    return dict(n_lmdas=len(st.lmdas), dev=100 * st.devs[-1], support13=st.betas[13, :p_oh].indices.tolist(),   # cell 22
+                first_pair=pairs[rel].tolist(), group_sizes=np.diff(np.append(groups, X.shape[1])), state=st)
+
+
+def _check_examples(out):
+    assert out["group_sizes"].min() == 1 and out["group_sizes"].max() >= 10   # ragged groups: 1 ... 2 x levels
+    assert out["n_lmdas"] == 100 and round(out["dev"], 1) == 71.1, (out["n_lmdas"], out["dev"])   # `100/100 ... [dev:71.1%]`
+    assert out["support13"] == [0, 10, 11, 12, 13, 14], out["support13"]
+    assert out["first_pair"] == [0, 10], out["first_pair"]
+
+
+def test_oracle_reproduces_examples_notebook_group_lasso(oracle):
+    _check_examples(_replay_examples_notebook(oracle.dense))
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_examples_notebook_group_lasso(hip, oracle):
+    out = _replay_examples_notebook(ad.matrix.dense)
+    _check_examples(out)
+    # and the two paths agree coefficient by coefficient (default tol: the reference's objective-level resolution)
+    ref = _replay_examples_notebook(oracle.dense)["state"]
+    assert np.abs(out["state"].betas.toarray() - ref.betas.toarray()).max() < 1e-4
+    assert np.allclose(out["state"].devs, ref.devs, atol=1e-7)
+
+
+# ---- quickstart.ipynb: 46 / 38 / 57 solutions, on the HIP path (the oracle's twins are in test_oracle_solver.py) -------------
+def _quickstart_X():
+    np.random.seed(0)
+    return np.asfortranarray(np.random.normal(0, 1, (100, 1000)))
+
+
+@pytest.mark.gpu
+def test_hip_known_answer_lasso_46_solutions(hip):
+    """quickstart.ipynb:98 — `46/100 ... [dev:90.5%]`."""
+    X = _quickstart_X()
+    y = X[:, -1] * np.random.normal(0, 1) + np.random.normal(0, 1, 100)
+    st = ad.grpnet(ad.matrix.dense(X), ad.glm.gaussian(y), progress_bar=False)
+    assert st.error == "" and len(st.lmdas) == 46
+    assert abs(st.devs[-1] - 0.905) < 2e-3 and st.devs[-2] < 0.9
+    assert np.isclose(st.lmda_max, 0.483276, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_known_answer_group_lasso_38_solutions(hip):
+    """quickstart.ipynb:255 — groups of 10, `38/100 ... [dev:90.2%]`."""
+    X = _quickstart_X()
+    y = X[:, -1] * np.random.normal(0, 1) + np.random.normal(0, 1, 100)
+    st = ad.grpnet(ad.matrix.dense(X), ad.glm.gaussian(y), groups=np.arange(0, 1000, 10), progress_bar=False)
+    assert st.error == "" and len(st.lmdas) == 38
+    assert abs(st.devs[-1] - 0.902) < 2e-3 and st.devs[-2] < 0.9
+
+
+@pytest.mark.gpu
+def test_hip_known_answer_binomial_57_solutions(hip):
+    """quickstart.ipynb:493 (data cell 35) — `57/100 ... [dev:90.2%]`."""
+    X = _quickstart_X()
+    eta = X[:, -1] * np.random.normal(0, 1) + np.random.normal(0, 1, 100)
+    y = np.random.binomial(1, 1 / (1 + np.exp(-eta)))
+    st = ad.grpnet(ad.matrix.dense(X), ad.glm.binomial(y=y, dtype=np.float64), progress_bar=False)
+    assert st.error == "" and len(st.lmdas) == 57
+    assert abs(st.devs[-1] - 0.902) < 2e-3 and st.devs[-2] < 0.9

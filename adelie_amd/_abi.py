@@ -143,7 +143,7 @@ V = dict(
 I = dict(
     screen_set=100, screen_begins=101, screen_is_active=102, active_set=103, n_valid_solutions=104,
     active_sizes=105, screen_sizes=106, betas_indptr=107, betas_indices=108,
-    duals_indptr=109, duals_indices=110,
+    duals_indptr=109, duals_indices=110, constraint_dev_groups=111,
 )
 S = dict(
     lmda_max=0, lmda=1, rsq=2, resid_sum=3, active_set_size=4, beta0=5, loss_null=6, loss_full=7,
@@ -184,7 +184,7 @@ def dtype_code(dtype):
 
 
 # kept equal to ADELIE_HIP_ABI_VERSION in include/adelie_hip.h (tests/test_abi.py compares the two)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class Backend:

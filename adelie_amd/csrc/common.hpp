@@ -47,7 +47,7 @@ struct Hooks {
     int trace = 0;
     int solve_sums = -1;    // ADELIE_HIP_SOLVE_SUMS=0: the sequential panel form keeps its panel_reduce launch per block             [A/B hook]
     int step_tail = -1;     // ADELIE_HIP_STEP_TAIL=0: 2-bit designs keep the panel_reduce launch behind every sequential step        [A/B hook]
-    int step_means = -1;    // ADELIE_HIP_STEP_MEANS=0: IRLS keeps its mean sweep over the screen columns per iteration              [A/B hook]
+    int step_means = -1;    // ADELIE_HIP_STEP_MEANS=1: IRLS takes the column means from the panel steps (no mean sweep per iteration)   [A/B hook]
     static Hooks from_env() {
         Hooks h;
         if (const char* e = std::getenv("ADELIE_HIP_CD_BLOCK_MIN_NV")) h.cd_block_min_nv = std::atoll(e);

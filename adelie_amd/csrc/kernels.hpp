@@ -500,6 +500,10 @@ int launch_panel_step(const DenseView<T>& X, const T* w, T* r, const int32_t* dc
 // -- the last eight workgroups to finish take eight columns each once every workgroup's partials are out -- and leaves the
 // block's gradient in tail->g (what panel_reduce would: - rsum[0] * xm[cols[c]] applied): no reduce launch behind the step.
 // `counter` counts finished workgroups monotonically over the launches of one solver; `base` = its value before this launch.
+// Means mode (xm_col != nullptr; IRLS with an intercept): phase (B) also accumulates sum_i x_ic w_i, the CURRENT weighted mean of
+// every column it reads; the tail centres the gradient with it and leaves it where the solve and later steps look (by design
+// column in xm_col, by screen value in sxm[list ? list[pos0 + c] : pos0 + c]) -- no sweep over the screen columns per IRLS
+// iteration for the means.
 template <class T>
 struct StepTail {
     int32_t* counter;
@@ -507,7 +511,13 @@ struct StepTail {
     T* g;
     const T* rsum;
     const T* xm; // by design column, or nullptr (no intercept term)
+    T* xm_col;           // means mode: out, by design column
+    T* sxm;              // means mode: out, by screen value
+    const int32_t* list; // the pass's visiting list (nullptr: screen order)
+    int32_t pos0;        // list position of the block's first coordinate
 };
+// whether launch_panel_step_snp would take the kernel that can run a StepTail on this design
+bool panel_step_snp_has_tail(const SnpView& X);
 template <class T>
 int launch_panel_step_snp(const SnpView& X, const T* impute, const T* w, T* r, const int32_t* dcol, const T* dlt,
                           const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s, bool slice_major = false,

@@ -275,12 +275,12 @@ __device__ __forceinline__ void snp16_decode(unsigned word, T imp, int64_t i, in
     }
 }
 
-template <class T, bool FULL>
+template <class T, bool FULL, bool MEANS>
 __device__ __forceinline__ void panel_step_snp16_body(const SnpAcc<T>& X, int64_t n, const T* __restrict__ w, T* __restrict__ r,
                                                       const int32_t* __restrict__ dcol, const T* __restrict__ dlt, int nz,
                                                       const int32_t* __restrict__ cols, int nb, T* __restrict__ part,
-                                                      int64_t part_ld, T (*red)[S16_RS], T* wrs, T* psum, const T* ptab, int t,
-                                                      int64_t slice) {
+                                                      int64_t part_ld, T (*red)[S16_RS], T* wrs, T* wsl, T* psum, T* psum2,
+                                                      const T* ptab, int t, int64_t slice) {
     constexpr int U = 16;
     const int lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -366,6 +366,7 @@ __device__ __forceinline__ void panel_step_snp16_body(const SnpAcc<T>& X, int64_
             if (ok) r[q0 + k] = rr;
         }
         wrs[q] = ok ? wq[k] * rr : T(0);
+        if constexpr (MEANS) wsl[q] = ok ? wq[k] : T(0);
     }
     if (nb <= 0) return;
     __syncthreads();
@@ -373,6 +374,11 @@ __device__ __forceinline__ void panel_step_snp16_body(const SnpAcc<T>& X, int64_
     T wr[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) wr[e] = wrs[e * 64 + lane];
+    T wl[16];
+    if constexpr (MEANS) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) wl[e] = wsl[e * 64 + lane];
+    }
     for (int c0 = wv; c0 < nb; c0 += 4 * U) {
         if (c0 != wv) {
 #pragma unroll
@@ -380,23 +386,49 @@ __device__ __forceinline__ void panel_step_snp16_body(const SnpAcc<T>& X, int64_
 #pragma unroll
             for (int u = 0; u < U; ++u) xb[u] = word(jb[u]);
         }
-        T pu[U];
+        if constexpr (!MEANS) {
+            T pu[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            T xx[16];
-            snp16_decode<T, FULL>(xb[u], X.impute[jb[u]], i, n, xx);
-            T sacc = T(0);
+            for (int u = 0; u < U; ++u) {
+                T xx[16];
+                snp16_decode<T, FULL>(xb[u], X.impute[jb[u]], i, n, xx);
+                T sacc = T(0);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sacc = fma(xx[e], wr[e], sacc);
-            pu[u] = sacc;
+                for (int e = 0; e < 16; ++e) sacc = fma(xx[e], wr[e], sacc);
+                pu[u] = sacc;
+            }
+            const T tot = reduce16(pu, lane);
+            if (lane < U && c0 + 4 * lane < nb) psum[c0 + 4 * lane] = tot;
+        } else {
+            // eight columns at a time: their gradient sums and their weighted sums (the column means under the CURRENT weights,
+            // from the same decoded calls) share one sixteen-value butterfly -- lanes 0-7 end with the former, 8-15 the latter
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                T pv[16];
+#pragma unroll
+                for (int u8 = 0; u8 < 8; ++u8) {
+                    const int u = 8 * h + u8;
+                    T xx[16];
+                    snp16_decode<T, FULL>(xb[u], X.impute[jb[u]], i, n, xx);
+                    T sacc = T(0), macc = T(0);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        sacc = fma(xx[e], wr[e], sacc);
+                        macc = fma(xx[e], wl[e], macc);
+                    }
+                    pv[u8] = sacc;
+                    pv[8 + u8] = macc;
+                }
+                const T tot = reduce16(pv, lane);
+                const int c = c0 + 4 * (8 * h + (lane & 7));
+                if (lane < 16 && c < nb) (lane < 8 ? psum : psum2)[c] = tot;
+            }
         }
-        const T tot = reduce16(pu, lane);
-        if (lane < U && c0 + 4 * lane < nb) psum[c0 + 4 * lane] = tot;
     }
     (void)part; (void)part_ld;
 }
 
-template <class T>
+template <class T, bool MEANS>
 __global__ __launch_bounds__(256 * S16_NSUB) void panel_step_snp16_kernel(SnpAcc<T> X, int64_t n, const T* __restrict__ w,
                                                                           T* __restrict__ r, const int32_t* __restrict__ dcol,
                                                                           const T* __restrict__ dlt,
@@ -406,6 +438,8 @@ __global__ __launch_bounds__(256 * S16_NSUB) void panel_step_snp16_kernel(SnpAcc
     __shared__ T red[S16_NSUB][4][S16_RS];
     __shared__ T wrs[S16_NSUB][S16_RS];
     __shared__ T psum[S16_NSUB][PB];
+    __shared__ T wsl[MEANS ? S16_NSUB : 1][MEANS ? S16_RS : 1]; // means mode: the slice's weights
+    __shared__ T psum2[S16_NSUB][PB];                           // means mode: the columns' weighted sums
     __shared__ T ptab[64 * 16]; // pair tables of phase (A): [batch of 64 columns][wave][pair of the wave's columns][16]
     const int nz = nz_dev[0];
     const int sub = threadIdx.x >> 8, t = threadIdx.x & 255;
@@ -427,13 +461,17 @@ __global__ __launch_bounds__(256 * S16_NSUB) void panel_step_snp16_kernel(SnpAcc
             ptab[q * 16 + e] = va + vb;
         }
     }
+    constexpr bool means = MEANS; // (the launcher picks the instantiation: tail.xm_col != nullptr; implies a tail)
     if ((int64_t(blockIdx.x) + 1) * S16_NSUB * S16_RS <= n)
-        panel_step_snp16_body<T, true>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red[sub], wrs[sub], psum[sub], ptab, t, slice);
+        panel_step_snp16_body<T, true, MEANS>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red[sub], wrs[sub], wsl[MEANS ? sub : 0],
+                                              psum[sub], psum2[sub], ptab, t, slice);
     else
-        panel_step_snp16_body<T, false>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red[sub], wrs[sub], psum[sub], ptab, t, slice);
+        panel_step_snp16_body<T, false, MEANS>(X, n, w, r, dcol, dlt, nz, cols, nb, part, part_ld, red[sub], wrs[sub], wsl[MEANS ? sub : 0],
+                                               psum[sub], psum2[sub], ptab, t, slice);
     if (nb <= 0) return; // (uniform)
     __syncthreads();
     const bool do_tail = tail.counter != nullptr; // (then part_ld > 0: column-major partials)
+    T* part2 = part + int64_t(PB) * part_ld;      // means mode: the weighted column sums, same layout behind the gradients'
     if (int(threadIdx.x) < nb) { // one partial per column and workgroup: the two slices in a fixed order
         const int c = threadIdx.x;
         const T tot = psum[0][c] + psum[1][c];
@@ -441,6 +479,9 @@ __global__ __launch_bounds__(256 * S16_NSUB) void panel_step_snp16_kernel(SnpAcc
         // tail: device-coherent (written through) -- workgroups of this launch on other XCDs read it
         if (do_tail) __hip_atomic_store(dst, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *dst = tot;
+        if (means)
+            __hip_atomic_store(part2 + int64_t(c) * part_ld + blockIdx.x, psum2[0][c] + psum2[1][c], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!do_tail) return;
     // ---- tail: the LAST EIGHT workgroups to get here sum the partials, eight columns per workgroup and round ----------------
@@ -474,9 +515,28 @@ __global__ __launch_bounds__(256 * S16_NSUB) void panel_step_snp16_kernel(SnpAcc
             for (int u = 0; u < 4; ++u) sacc += v[u];
         }
         sacc = wave_sum64(sacc);
+        T macc = T(0);
+        if (means) {
+            const T* pm = part2 + int64_t(c) * part_ld;
+            for (int k0 = lane; k0 < nwg; k0 += 4 * 64) {
+                T v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    v[u] = (k0 + 64 * u < nwg) ? __hip_atomic_load(pm + k0 + 64 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : T(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) macc += v[u];
+            }
+            macc = wave_sum64(macc);
+        }
         if (lane == 0) {
             T g = sacc;
-            if (tail.xm) g -= tail.rsum[0] * tail.xm[cols[c]];
+            if (means) {
+                g -= tail.rsum[0] * macc;
+                tail.xm_col[cols[c]] = macc;
+                tail.sxm[tail.list ? tail.list[tail.pos0 + c] : tail.pos0 + c] = macc;
+            } else if (tail.xm) {
+                g -= tail.rsum[0] * tail.xm[cols[c]];
+            }
             tail.g[c] = g;
         }
     }
@@ -807,6 +867,15 @@ int launch_panel_step(const DenseView<T>& X, const T* w, T* r, const int32_t* dc
     if (vecok) return step_launch<T, DenseAcc<T>, V>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, slice_major, s);
     return step_launch<T, DenseAcc<T>, 1>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, slice_major, s);
 }
+namespace {
+inline bool snp16_old_form() {
+    static const bool v = std::getenv("ADELIE_HIP_SNP16_OLD") != nullptr; // (A/B of the round-6 kernel)
+    return v;
+}
+inline bool snp16_shape_ok(const SnpView& X) { return X.n >= 16384 && X.ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(X.bits) % 4) == 0; }
+} // namespace
+bool panel_step_snp_has_tail(const SnpView& X) { return snp16_shape_ok(X) && !snp16_old_form(); }
+
 template <class T>
 int launch_panel_step_snp(const SnpView& X, const T* impute, const T* w, T* r, const int32_t* dcol, const T* dlt,
                           const int32_t* nz_dev, const int32_t* cols, int nb, T* part, hipStream_t s, bool slice_major,
@@ -815,9 +884,8 @@ int launch_panel_step_snp(const SnpView& X, const T* impute, const T* w, T* r, c
     if (tailed) *tailed = false;
     // 16 calls (one 32-bit word) per lane and column instead of 4 (one byte): a quarter of the workgroups, four times the
     // bytes per load instruction - the byte form is bound by the number of workgroups and load instructions, not by bytes.
-    if (X.n >= 16384 && X.ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(X.bits) % 4) == 0) {
-        static const bool old_form = std::getenv("ADELIE_HIP_SNP16_OLD") != nullptr; // (A/B of the round-6 kernel)
-        if (old_form) return step_launch<T, SnpAcc<T>, 16>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, slice_major, s);
+    if (snp16_shape_ok(X)) {
+        if (snp16_old_form()) return step_launch<T, SnpAcc<T>, 16>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, slice_major, s);
         constexpr int64_t RW = int64_t(S16_RS) * S16_NSUB;
         const int64_t nwg = (X.n + RW - 1) / RW;
         StepTail<T> tl{};
@@ -825,8 +893,12 @@ int launch_panel_step_snp(const SnpView& X, const T* impute, const T* w, T* r, c
             tl = *tail;
             if (tailed) *tailed = true;
         }
-        hipLaunchKernelGGL((panel_step_snp16_kernel<T>), dim3((unsigned)nwg), dim3(256 * S16_NSUB), 0, s, acc, X.n, w, r, dcol,
-                           dlt, nz_dev, cols, nb, part, slice_major ? int64_t(0) : nwg, tl);
+        if (tl.xm_col != nullptr)
+            hipLaunchKernelGGL((panel_step_snp16_kernel<T, true>), dim3((unsigned)nwg), dim3(256 * S16_NSUB), 0, s, acc, X.n, w, r,
+                               dcol, dlt, nz_dev, cols, nb, part, nwg, tl);
+        else
+            hipLaunchKernelGGL((panel_step_snp16_kernel<T, false>), dim3((unsigned)nwg), dim3(256 * S16_NSUB), 0, s, acc, X.n, w, r,
+                               dcol, dlt, nz_dev, cols, nb, part, slice_major ? int64_t(0) : nwg, tl);
         return int(nwg);
     }
     return step_launch<T, SnpAcc<T>, 4>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, slice_major, s);

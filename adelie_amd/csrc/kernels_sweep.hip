@@ -538,8 +538,10 @@ void launch_sweep(const DenseView<T>& X, const T* v, T* out, int64_t c0, int64_t
 // pair of rows (i, i+1) the 16 possible contributions of a nibble (two calls),
 //     T012[b] = c0' v_i + c1' v_{i+1}   (c' = code if code < 3 else 0),     T3[b] = [c0 = 3] v_i + [c1 = 3] v_{i+1},
 // — the vector v is the same for all columns, so a table serves every column of the workgroup — and then every thread adds
-// one T012 and one T3 entry per nibble of its column (two shifts/masks, two LDS reads, two additions for two calls); the
-// imputed value enters once at the end, S012 + impute_c * S3.  A table of 16 entries of 8 bytes is one row of LDS banks:
+// one T012 entry per nibble of its column and one entry per BYTE of a second table that holds, for four rows, the sum of v over
+// any subset of them (indexed by the four missing-call flags of the byte: three mask operations per word bring them
+// together) — three LDS reads per four calls where a T3 entry per nibble made it four, the kernel being bound by what LDS
+// delivers; the imputed value enters once at the end, S012 + impute_c * S3.  A table of 16 entries of 8 bytes is one row of LDS banks:
 // any mix of indices over the lanes is conflict-free.  Columns are 128-byte aligned and padded (SnpView::ldb): a line of a
 // column is two tiles.  Fixed summation order; row splits leave partials for sweep_reduce_kernel as above.
 constexpr int LUT_TR = 256;
@@ -564,8 +566,9 @@ __global__ __launch_bounds__(kThreads) void sweep_snp_lut_kernel(const uint8_t* 
     static_assert(kThreads == 256, "256 columns per workgroup, 8 lanes per line");
     constexpr int NP = LUT_TR / 2;              // row pairs per tile
     typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    constexpr int NQ = LUT_TR / 4;              // row quads per tile
     __shared__ T t012[NP][16];
-    __shared__ T t3[NP][16];
+    __shared__ T t3q[NQ][16];                   // missing calls, four rows per look-up: entry = sum of v over the set bits
     __shared__ u4_t stage[kThreads * 8];        // [column][piece rotated by the column]
     __shared__ int64_t cofs[kThreads];          // byte offset of the workgroup's columns
     const int tid = threadIdx.x;
@@ -583,8 +586,9 @@ __global__ __launch_bounds__(kThreads) void sweep_snp_lut_kernel(const uint8_t* 
     const uint8_t* fptr[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) fptr[u] = bits + cofs[fc + 32 * u] + fp * 16;
-    // table role of this thread: pair tid / 2, entries 8 * (tid & 1) .. + 8
+    // table role of this thread: pair tid / 2, entries 8 * (tid & 1) .. + 8 of T012; quad tid / 4, entries 4 * (tid & 3) .. + 4 of T3
     const int tp = tid >> 1, te0 = (tid & 1) * 8;
+    const int tq = tid >> 2, tqe0 = (tid & 3) * 4;
     T a = T(0), b = T(0);
     u4_t w[8];
 #pragma unroll
@@ -601,12 +605,15 @@ __global__ __launch_bounds__(kThreads) void sweep_snp_lut_kernel(const uint8_t* 
 #pragma unroll
             for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(fptr[u] + nbase / 4));
         }
-        T vv[4];
+        T vv[4], vq[8];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int64_t i0 = base + h * LUT_TR + 2 * tp;
             vv[2 * h] = i0 < r1 ? v[i0] : T(0);
             vv[2 * h + 1] = i0 + 1 < r1 ? v[i0 + 1] : T(0);
+            const int64_t j0 = base + h * LUT_TR + 4 * tq;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) vq[4 * h + k] = j0 + k < r1 ? v[j0 + k] : T(0);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -616,7 +623,12 @@ __global__ __launch_bounds__(kThreads) void sweep_snp_lut_kernel(const uint8_t* 
             for (int e = 0; e < 8; ++e) {
                 const int idx = te0 + e, k0 = idx & 3, k1 = idx >> 2;
                 t012[tp][idx] = (k0 < 3 ? T(SQ ? k0 * k0 : k0) : T(0)) * v0 + (k1 < 3 ? T(SQ ? k1 * k1 : k1) : T(0)) * v1;
-                t3[tp][idx] = (k0 == 3 ? v0 : T(0)) + (k1 == 3 ? v1 : T(0));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { // the missing calls of FOUR rows per entry (fixed order of the additions: rows ascending)
+                const int idx = tqe0 + e;
+                t3q[tq][idx] = (((idx & 1) ? vq[4 * h] : T(0)) + ((idx & 2) ? vq[4 * h + 1] : T(0))) +
+                               (((idx & 4) ? vq[4 * h + 2] : T(0)) + ((idx & 8) ? vq[4 * h + 3] : T(0)));
             }
             __syncthreads(); // (h == 0: also makes the staged pieces visible)
             u4_t wd[4];
@@ -626,12 +638,20 @@ __global__ __launch_bounds__(kThreads) void sweep_snp_lut_kernel(const uint8_t* 
             for (int u = 0; u < 4; ++u) {
 #pragma unroll
                 for (int hh = 0; hh < 4; ++hh) {
+                    const unsigned wq = wd[u][hh];
+                    // bit 2k of `ms`: call k of the word is missing (code 3); then the four flags of every byte in its low nibble
+                    unsigned ms = wq & (wq >> 1) & 0x55555555u;
+                    ms = (ms | (ms >> 1)) & 0x33333333u;
+                    ms = (ms | (ms >> 2)) & 0x0F0F0F0Fu;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const int pr = (u * 4 + hh) * 8 + k; // row pair of this nibble (compile-time)
-                        const unsigned idx = (wd[u][hh] >> (4 * k)) & 15u;
-                        a += t012[pr][idx];
-                        b += t3[pr][idx];
+                        a += t012[pr][(wq >> (4 * k)) & 15u];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int qr = (u * 4 + hh) * 4 + k; // row quad of this byte
+                        b += t3q[qr][(ms >> (8 * k)) & 15u];
                     }
                 }
             }

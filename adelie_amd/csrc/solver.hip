@@ -423,6 +423,7 @@ struct Result : ResultBase {
             case ADELIE_HIP_V_DUALS_VALUES: { int64_t t = 0; for (auto& v : s.duals_idx) t += v.size(); return t; }
             case ADELIE_HIP_V_CONSTRAINT_MU: return s.cons_on ? s.G : 0;
             case ADELIE_HIP_V_CONSTRAINT_VMU: return s.cons_dev ? s.p : 0;
+            case ADELIE_HIP_I_CONSTRAINT_DEV_GROUPS: return s.cons_dev ? int64_t(s.devcons_list.size()) : 0;
         }
         return -1;
     }
@@ -486,6 +487,12 @@ struct Result : ResultBase {
             case ADELIE_HIP_I_DUALS_INDICES: {
                 int64_t k = 0;
                 for (auto& v : s.duals_idx) for (auto x : v) { if (k < cap) ii[k] = x; ++k; }
+                return 0;
+            }
+            case ADELIE_HIP_I_CONSTRAINT_DEV_GROUPS: {
+                if (!s.cons_dev) return 0;
+                int64_t k = 0;
+                for (int32_t g : s.devcons_list) { if (k < cap) ii[k] = g; ++k; }
                 return 0;
             }
             case ADELIE_HIP_V_DUALS_VALUES: {

@@ -267,7 +267,8 @@
             // that the fused launches (whole-CU workgroups) running meanwhile never wait for one (see set_small_gram_workgroups)
             set_small_gram_workgroups((side && side_wgs > 0 && !is_glm() && j0 >= side_wgs_from) ? side_wgs : 512);
             if (multi()) gram_block(cur_w, cols_of(j0), nb_of(j0), cur_xm, pool + size_t(j0) * SL * SL, sidx);
-            else gram_block_batch(cur_w, cols_base, sb, cur_xm, pool + size_t(j0) * SL * SL, sidx);
+            else gram_block_batch(cur_w, cols_base, sb, step_means_now ? batch_means(cols_base, sb, sidx, pool == d_Dpool.p ? 0 : 1) : cur_xm,
+                                  pool + size_t(j0) * SL * SL, sidx);
             if (vb_vars && !multi()) // IRLS, groups of one: the variances of a block's coordinates are its diagonal (vars_from_blocks)
                 launch_block_diag_vars<T>(pool + size_t(j0) * SL * SL, sb, SL, int32_t(cols_base - vb_cols_all), vb_list, vb_vars,
                                           sidx == 0 ? st : (sidx >= 2 ? st_x[sidx - 2] : st2));
@@ -288,6 +289,30 @@
             }
             i = k;
         }
+    }
+    // Means mode (solver_screen.hpp::step_means_now): nobody sweeps the screen columns for their means any more, and a block is
+    // centred with the means of ITS weights -- so a batch of builds first takes the weighted means of its own columns (one sweep
+    // per run of consecutive blocks, on the build's stream) into a by-column vector of its table (screen order / activation
+    // order: the two tables build concurrently and share columns).  Only stale blocks pay: ~a fifth of the columns the per-
+    // iteration sweep went over.
+    DevBuf<T> d_xmb[2], d_xmb_tmp[2 + kMaxExtra + 1], d_xmb_work[2 + kMaxExtra + 1];
+    const T* batch_means(const int32_t* cols_base, const SyrkBatch& sb, int side, int table) {
+        hipStream_t gs = side == 0 ? st : (side >= 2 ? st_x[side - 2] : st2);
+        const int SL = cd_block_size();
+        T* xmb = d_xmb[table].reserve(size_t(p) + 8);
+        T* tmp = d_xmb_tmp[side].reserve(size_t(16) * SL + 8);
+        T* work = d_xmb_work[side].reserve(size_t(sweep_work_elems(n, int64_t(16) * SL)));
+        int y = 0;
+        while (y < sb.count) { // runs of blocks that stand next to each other in the pass's column list
+            int y1 = y + 1;
+            int64_t ncols = sb.nb[y];
+            while (y1 < sb.count && sb.off[y1] == sb.off[y1 - 1] + sb.nb[y1 - 1]) ncols += sb.nb[y1++];
+            const int32_t* cols = cols_base + sb.off[y];
+            launch_sweep_snp<T>(D->snp(), static_cast<const T*>(D->impute), cur_w, tmp, 0, ncols, cols, nullptr, nullptr, false, work, gs);
+            launch_scatter<T>(tmp, cols, ncols, xmb, gs);
+            y = y1;
+        }
+        return xmb;
     }
     // Recorded by a panel pass on the main stream BEFORE it enqueues its first step: the side streams' builds wait for this
     // event instead of one recorded behind the step, so the host can launch the step first (it does not depend on the builds)

@@ -385,12 +385,16 @@
                         "IRLS lambda is unexpectedly inf. This likely indicates a bug in the code. Please report this!");
             }
             // :361-385  X_means on the screen columns and all screen-derived quantities under the IRLS weights
+            step_means_now = false;
             if (nv > 0) {
+                // 2-bit designs on the panel engine: the steps produce the means of the columns they read under the current weights
+                // and the block builds take those of their own columns (solver_screen.hpp::step_means_now) -- no sweep here
+                step_means_now = panel_mode() && step_means_possible();
                 if (multi()) { // the view's sweep covers all columns in one pass over X; pick the screen values out of it
                     d_mxm.reserve(size_t(p));
                     sweep(d_irls_w.p, d_mxm.p, nullptr, p, nullptr, nullptr);
                     launch_gather<T>(d_mxm.p, d_vcol.p, nv, d_g.p, st);
-                } else {
+                } else if (!step_means_now) {
                     sweep(d_irls_w.p, d_g.p, d_vcol.p, nv, nullptr, nullptr); // means by value
                 }
                 // groups of one on the panel engines: the by-column means stay on the device (scatter through the value -> column map);
@@ -409,7 +413,7 @@
                     AHIP_CHECK(hipMemcpyAsync(&drift, d_sums.p + 15, sizeof(T), hipMemcpyDeviceToHost, st));
                 }
                 if (means_on_device) {
-                    launch_scatter<T>(d_g.p, d_vcol.p, nv, d_irls_xm.p, st);
+                    if (!step_means_now) launch_scatter<T>(d_g.p, d_vcol.p, nv, d_irls_xm.p, st);
                     if (track) sync(); // (the drift decides which blocks are kept)
                 } else {
                     sync();

@@ -399,7 +399,7 @@
                 const int nsl = panel_step(cur_w, r_dev, ps < 0 ? d_dcolblk.p : d_la_dcol.p + size_t(ps) * SL,
                                            ps < 0 ? d_dlt.p : d_la_dlt.p + size_t(ps) * SL,
                                            ps < 0 ? &d_blk.p->nz : d_la_nz.p + ps, cols, nb, solve_sums,
-                                           step_tail && !solve_sums && !multi() && !sparse(), xm_c);
+                                           step_tail && !solve_sums && !multi() && !sparse(), xm_c, bp.list, j * B);
                 if (time_panel) t_step.end(st);
                 step_tailed_of[j & 1] = step_tailed;
                 return nsl;

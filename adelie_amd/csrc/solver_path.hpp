@@ -435,6 +435,7 @@
         if (hooks.irls_reuse >= 0) irls_reuse = hooks.irls_reuse;
         if (hooks.solve_sums >= 0) plain_solve_sums = hooks.solve_sums != 0;
         if (hooks.step_tail >= 0) step_tail = hooks.step_tail != 0;
+        if (hooks.step_means >= 0) step_means_opt = hooks.step_means != 0;
         panel_bsz = hooks.panel_bsz;
         if (cov_mode) { // base state of the covariance method: no intercept, adev_tol = ddev_tol = 0 (state_gaussian_cov.hpp:118)
             engine_panel = false; // the panel engines work on the residual; the Gram engines on C = A[S, S] and its gradient
@@ -478,9 +479,11 @@
             bool any = false;
             for (idx g = 0; g < G; ++g) any = any || a->constraint_kind[g] != 0;
             if (any) {
-                if (sparse())
+                // the constrained solves live in the panel engines: a design kept sparse has them under IRLS only (compressed-column
+                // panel form), a standardized view of a dense / 2-bit design whenever its panel form is on (ADELIE_HIP_STD_PANEL)
+                if (sparse() && !engine_panel)
                     throw make_core_error("constraints are not implemented on a design kept sparse; use matrix.sparse(..., resident=\"dense\").");
-                if (std_generic())
+                if (std_generic() && !engine_panel)
                     throw make_core_error("constraints are not implemented on a lazily standardized design; use matrix.standardize(..., lazy=False).");
                 if (!all_scalar && max_gs > idx(cd_block_size()))
                     throw make_core_error("constraints are not implemented for problems with groups of more than " +

@@ -46,8 +46,21 @@
     DevBuf<int32_t> d_tail_ctr;
     int32_t tail_base = 0;
     bool step_tailed = false;
+    // Means mode (step_means_now; IRLS on a 2-bit design with an intercept): the step also produces the CURRENT weighted means of
+    // the block's columns and leaves them in d_irls_xm (by column) and d_sxm (by screen value: `list` / `pos0` locate the block)
+    // before the block's solve reads them -- glm_fit then runs no mean sweep over the screen columns per IRLS iteration.
+    // Measured on config 4 (profiles/r06_cfg4_ab.txt): 3.03-3.06 s with it against 2.98-3.00 s without -- the mean sweeps it removes
+    // (0.17 s of the main stream) come back as the block builds' own mean sweeps on the side streams, in front of the first block
+    // a pass waits for (cd 2.55 against 2.38 s), and phase (B) carries a second accumulation.  Off; hook ADELIE_HIP_STEP_MEANS=1.
+    bool step_means_opt = false;
+    bool step_means_now = false;  // (set per IRLS iteration by glm_fit)
+    bool step_means_possible() const {
+        return step_means_opt && step_tail && !plain_solve_sums && is_glm() && intercept && all_scalar && !multi() && !sparse() &&
+               !dense() && D->std_center == nullptr && !cov_mode && panel_step_snp_has_tail(D->snp());
+    }
     int panel_step(const T* w, T* r, const int32_t* dcol, const T* dlt, const int32_t* nz_dev, const int32_t* cols, int nb,
-                   bool slice_major = false, bool want_tail = false, const T* tail_xm = nullptr) {
+                   bool slice_major = false, bool want_tail = false, const T* tail_xm = nullptr, const int32_t* list = nullptr,
+                   int pos0 = 0) {
         step_tailed = false;
         if (multi()) return launch_multi_panel_step<T>(D->multi<T>(), w, r, dcol, dlt, nz_dev, cols, nb, d_part.p, st);
         const T* kappa = nullptr;
@@ -80,7 +93,11 @@
                 tail_base = 0;
             }
             tl.counter = d_tail_ctr.p; tl.base = tail_base; tl.g = d_gblk.p; tl.rsum = &d_blk.p->resid_sum; tl.xm = tail_xm;
+            if (step_means_now) {
+                tl.xm_col = d_irls_xm.p; tl.sxm = d_sxm.p; tl.list = list; tl.pos0 = pos0;
+            }
         }
+        if (step_means_now && nb > 0 && !tail_ok) throw make_core_error("means mode without a step tail (internal error).");
         const int nsl = launch_panel_step_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, r, dcol, dlt, nz_dev, cols, nb,
                                                  d_part.p, st, slice_major, tail_ok ? &tl : nullptr, &step_tailed);
         if (step_tailed) {

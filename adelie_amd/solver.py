@@ -16,6 +16,7 @@ Every ``X.mul`` below is one C-ABI call into ``libadelie_hip.so`` = one full-gra
 design.  Multi-response families (``glm.multigaussian``, ``glm.multinomial``) are solved in the
 coordinates of the expanded design ``[1 (x) I_K, X (x) I_K]`` (reference ``solver.py:700-844``).
 """
+import os
 import warnings
 from dataclasses import dataclass
 from typing import Callable
@@ -196,7 +197,14 @@ def _start_gaussian(X, glm, offsets, intercept, dtype):
         # both sweeps in ONE pass over the resident design (two vectors side by side): the reference makes two X.mul calls.
         # (The two-vector kernel sums in another order than the one-vector sweep the solver uses later: the starting
         # invariants agree with it to rounding, not bit for bit.)
-        X_means, grad = X.mul_batch(np.stack([np.asarray(w, dtype=dtype), np.asarray(resid * w, dtype=dtype)]))
+        try:
+            X_means, grad = X.mul_batch(np.stack([np.asarray(w, dtype=dtype), np.asarray(resid * w, dtype=dtype)]))
+        except RuntimeError as e:
+            # a native design kind the batched entry point refuses (the class list above is a shortcut, the handle decides):
+            # fall back to the two single-vector sweeps; anything else the library raised is a real error
+            if "HIP error" in str(e):
+                raise
+            X_means = grad = None
     if grad is None:
         X_means = _sweep(X, np.ones(n, dtype=dtype), w, dtype)
         grad = _sweep(X, resid, w, dtype)
@@ -312,15 +320,25 @@ def grpnet(
     dtype = X.dtype
     p = X.cols()
 
-    if constraints is not None and any(c is not None for c in constraints) and warm_start is None:
-        # The constrained group solves live in the panel engines, which stream dense / 2-bit column slices: a lazily
-        # standardized view or a design kept sparse is materialised for such a fit (the reference composes any matrix with any
-        # constraint, adelie/solver.py:257-313), with a warning because the copy costs n * p values of HBM.
-        if isinstance(X, matrix._StdView) or matrix._is_kept_sparse(X):
+    if constraints is not None and any(c is not None for c in constraints):
+        # The constrained solves live in the panel engines.  A lazily standardized view of a dense / 2-bit design has them (the
+        # sequential panel form on the base design's columns with the view's corrections), and so has a design kept sparse under
+        # IRLS (the panel form over compressed columns): constrained fits run there, on the view.  What has no panel form -- a
+        # Gaussian fit on a design kept sparse (its Gram is built once: the full-Gram engines), any fit with the view's panel form
+        # switched off -- is materialised for such a fit (the reference composes any matrix with any constraint,
+        # adelie/solver.py:257-313), with a warning because the copy costs n * p values of HBM; cold and warm-started fits
+        # take the same route.
+        is_view = isinstance(X, matrix._StdView)
+        sparse_kept = matrix._is_kept_sparse(X) or (is_view and matrix._is_kept_sparse(getattr(X, "_base", None)))
+        gaussian = getattr(glm, "name", "") == "gaussian" and not getattr(glm, "is_multi", False) and getattr(glm, "opt", True)
+        panel_off = os.environ.get("ADELIE_HIP_STD_PANEL", "1") == "0" if is_view else False
+        if sparse_kept and os.environ.get("ADELIE_HIP_SPARSE_PANEL", "1") == "0":
+            panel_off = True
+        if (sparse_kept and gaussian) or ((is_view or sparse_kept) and panel_off):
             warnings.warn(
                 "adelie_amd: constraints on a lazily standardized / sparse-resident design run on its materialised dense copy "
                 f"({X.rows()} x {X.cols()} values of device memory).", RuntimeWarning, stacklevel=2)
-            X = X._materialize() if isinstance(X, matrix._StdView) else matrix._expanded(X)
+            X = X._materialize() if is_view else matrix._expanded(X)
     raw = None if exit_cond is not None else _lasso_in_raw_coordinates(X, glm, constraints, groups, alpha, intercept, warm_start)
     if raw is not None:  # (an exit_cond callback reads the live state: it gets the view's own coordinates, i.e. the view's engines)
         # A lasso (alpha = 1, groups of one, intercept) on the standardized view (Z - 1 c') diag(s)^-1 of a resident design Z is the

@@ -281,12 +281,14 @@ class base:
                 if c is not None and c._abi()[0] != _constraint.KIND_HOST:  # (host objects were the live objects all along)
                     c._mu[0] = m
             vmu = backend.result_vec(r, _abi.V["constraint_vmu"])
-            if len(vmu):  # box / one-sided objects on several coefficients that the device solved: the same courtesy
-                for i, c in enumerate(cons):
-                    nat = None if c is None or c._abi()[0] != _constraint.KIND_HOST else c._native()
-                    if nat is not None and nat[1] is not None and c.primal_size <= 64:
-                        g0 = int(self.groups[i])
-                        c._mu[...] = vmu[g0:g0 + c.primal_size]
+            if len(vmu):
+                # box / one-sided objects on several coefficients that the DEVICE solved: the same courtesy.  Which groups those
+                # were is the library's report (ABI 9), not a rule restated here.  Such an object is not live during the solve
+                # (an exit_cond callback sees the multipliers it entered with); it holds the last fit's on return.
+                for i in backend.result_vec(r, _abi.I["constraint_dev_groups"], index=True):
+                    c = cons[int(i)]
+                    g0 = int(self.groups[int(i)])
+                    c._mu[...] = vmu[g0:g0 + c.primal_size]
         sc = lambda nm: backend.fn("result_scalar")(r, _abi.S[nm])
         new.lmda_max = dtype(sc("lmda_max"))
         new.lmda = dtype(sc("lmda"))

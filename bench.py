@@ -42,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X spec (guides/MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+HBM_COPY_GBS = 6290.0
 MFMA_F64_PEAK_TFLOPS = 78.6  # dense f64 matrix-core peak (same guide)
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32 matrix-core peak (same guide)
 
@@ -390,7 +391,10 @@ def measure(ctx, cfg, *, n, p, gs, alpha, dtype, L, steps, warmup, n_folds=8, cv
     wall = elapsed  # rank 0's steps; at N > 1 every rank does the same amount (cfg 5: rank 0's folds)
     path_gbs = B / wall / 1e9
     roofline_path = {"bound": "hbm", "achieved": path_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": path_gbs / HBM_PEAK_GBS, "algorithmic_bytes": B, "wall_s": wall,
+                     "frac": path_gbs / HBM_PEAK_GBS,
+                     # the same against the float4-copy ceiling measured on this part (guides/MI355X_MICROARCH.md: 6.29 TB/s)
+                     "peak_measured_copy": HBM_COPY_GBS, "frac_of_measured_copy": path_gbs / HBM_COPY_GBS,
+                     "algorithmic_bytes": B, "wall_s": wall,
                      "terms_in_columns": parts,
                      "note": "rank 0's paths over the timed steps; matrix bytes only (SURVEY.md 8d)" + (
                          "; sweeps that several folds shared are counted ONCE (one pass over X answers up to 8 folds), the "

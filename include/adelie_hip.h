@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADELIE_HIP_ABI_VERSION 8
+#define ADELIE_HIP_ABI_VERSION 9
 
 enum adelie_hip_dtype { ADELIE_HIP_F32 = 0, ADELIE_HIP_F64 = 1 };
 enum adelie_hip_order { ADELIE_HIP_COL_MAJOR = 0, ADELIE_HIP_ROW_MAJOR = 1 };
@@ -89,8 +89,13 @@ int adelie_hip_design_create_sparse(const int64_t* indptr, const int32_t* indice
  * same entries, e.g. scipy's .tocsr()).  12 bytes per stored entry each way instead of n*p values (plus, for designs of more
  * than one tile of 16384 rows and at least a few entries per tile and column, a tile-major copy of 10 bytes per entry that
  * the library builds on the device for its full sweeps): a design whose dense form does not fit can run.  Gradients and Gram rows stream the CSC copy (one wavefront per column), residual updates and X beta
- * the CSR copy; grpnet_solve runs its full-Gram engines on it (the panel engines need dense column slices), constraints are
- * not offered.  All MatrixNaiveBase operations below accept it; derived designs are composed on the host. */
+ * the CSR copy; grpnet_solve runs its full-Gram engines on Gaussian fits (the Gram is built once) and, under IRLS, the panel
+ * engine over compressed columns, which also serves constrained fits (Gaussian fits with constraints are refused: the caller
+ * expands the design).  REPRODUCIBILITY: the IRLS panel form applies the residual update of a block with hardware f64 atomics
+ * over the stored entries (csc_panel_update_kernel); where two changed columns of a block share a row the order of the two
+ * additions is not fixed, so two runs of a GLM path on a design kept sparse agree to rounding (1e-15 relative), not bit for bit
+ * -- every other engine of this library is order-deterministic.  All MatrixNaiveBase operations below accept it; derived designs
+ * are composed on the host. */
 int adelie_hip_design_create_csc(const int64_t* indptr, const int32_t* indices, const void* values, const int64_t* row_indptr,
                                  const int32_t* row_indices, const void* row_values, int64_t n, int64_t p, int dtype, int device,
                                  adelie_hip_design** out);
@@ -446,6 +451,10 @@ enum adelie_hip_vec {
     /* duals, CSR (L, n_duals) (state_base.hpp `duals`, filled by sparsify_dual, solver_base.hpp:158-222); n_duals = number
      * of constrained groups here (one multiplier per singleton constraint) */
     ADELIE_HIP_I_DUALS_INDPTR, ADELIE_HIP_I_DUALS_INDICES,
+    /* ABI 9: the groups whose box / one-sided constraint objects were solved ON THE DEVICE during this solve (ascending group
+     * indices; their multipliers are the entries of ADELIE_HIP_V_CONSTRAINT_VMU) -- the binding reads this list instead of
+     * re-deriving the library's rule, and the objects of every other group stayed live on the caller's side */
+    ADELIE_HIP_I_CONSTRAINT_DEV_GROUPS,
     /* betas values (double), CSR (L, p) like convert_sparse_to_dense's input, py_state.cpp:9-60 */
     ADELIE_HIP_V_BETAS_VALUES = 200,
     ADELIE_HIP_V_DUALS_VALUES,

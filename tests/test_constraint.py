@@ -947,3 +947,69 @@ def test_hip_linear_constraints_match_oracle(hip, oracle):
     for g, c in enumerate(ch):
         if c is not None:
             assert np.max(c.evaluate(B[-1, groups[g]:groups[g] + 4])) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("base", ["dense", "snp"])
+@pytest.mark.parametrize("family", ["gaussian", "binomial"])
+def test_hip_constraints_on_a_lazily_standardized_view(hip, oracle, base, family):
+    """Constrained fits on ``matrix.standardize(X, lazy=True)`` run ON THE VIEW (the sequential panel form over the base design's
+    columns with the view's corrections: one-coefficient closed forms in the block solve, box / one-sided objects on groups in
+    one wavefront, `linear` objects through the callbacks) -- no materialised copy, no warning, cold and warm-started fits
+    alike (VERDICT r5 missing 8); checked against the oracle on the standardized matrix written out."""
+    import warnings
+
+    rng = np.random.RandomState(31)
+    n, p, G = 500, 90, 24
+    if base == "dense":
+        Xb = np.asfortranarray(rng.normal(size=(n, p)) * rng.uniform(0.5, 3.0, p) + rng.uniform(-2, 2, p))
+        Bd = ad.matrix.dense(Xb)
+        Xv = Xb
+    else:
+        cd = rng.choice([0, 1, 2, -9], size=(n, p), p=[0.55, 0.3, 0.1, 0.05]).astype(np.int8)
+        imp = np.array([cd[:, j][cd[:, j] >= 0].mean() for j in range(p)])
+        Bd = ad.matrix.snp_calldata(np.asfortranarray(cd), imp)
+        Xv = np.where(cd < 0, imp[None, :], cd).astype(float)
+    ce, sc = Xv.mean(0), Xv.std(0)
+    Xs = np.asfortranarray((Xv - ce) / sc)
+    S = ad.matrix.standardize(Bd, centers=ce, scales=sc, lazy=True)
+    beta = np.zeros(p)
+    beta[rng.choice(p, 12, replace=False)] = rng.normal(size=12)
+    eta = Xs @ beta
+    if family == "gaussian":
+        y = eta + 0.5 * rng.normal(size=n)
+        mk = lambda: ad.glm.gaussian(y)
+        kw = dict(tol=1e-13)
+    else:
+        y = (rng.uniform(size=n) < 1 / (1 + np.exp(-eta))).astype(float)
+        mk = lambda: ad.glm.binomial(y)
+        kw = dict(tol=1e-13, irls_tol=1e-11)
+    groups, sizes, spec, make = _group_problem(p, np.random.RandomState(5), G)
+
+    def make_all():   # box / one-sided objects (device: groups of several coefficients; closed forms: groups of one) + a `linear` one
+        cons = make()
+        g = int(np.flatnonzero([c is None for c in cons])[0])
+        q = int(sizes[g])
+        A = np.random.RandomState(8).normal(size=(2, q))
+        cons[g] = constraint.linear(A, lower=np.full(2, -0.2), upper=np.full(2, 0.3))
+        return cons
+
+    kw.update(groups=groups, alpha=0.8, early_exit=False, lmda_path_size=9, min_ratio=0.08, progress_bar=False)
+    ref = ad.grpnet(oracle.dense(Xs), mk(), constraints=make_all(), **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)   # a materialised copy would warn
+        st = ad.grpnet(S, mk(), constraints=make_all(), **kw)
+    assert st.error == "" and ref.error == "" and len(st.lmdas) == len(ref.lmdas) == 9
+    assert np.abs(st.betas.toarray() - ref.betas.toarray()).max() < 1e-7
+    assert np.abs(st.intercepts - ref.intercepts).max() < 1e-7
+    dscale = max(1.0, float(np.abs(ref.duals).max()))
+    assert ref.duals.nnz > 0 and np.abs((st.duals - ref.duals)).max() < 1e-5 * dscale
+    assert st.counters["n_dev_cons_visits"] > 0
+    # warm start from the fifth solution: the same engines, the same numbers (the cold path's tail)
+    lm = np.asarray(st.lmdas)
+    cw = make_all()   # (the objects carry their multipliers from the first call into the second)
+    head = ad.grpnet(S, mk(), constraints=cw, **dict(kw, lmda_path=lm[:5]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        rest = ad.grpnet(S, mk(), constraints=cw, warm_start=head, **dict(kw, lmda_path=lm[5:]))
+    assert rest.error == "" and np.abs(rest.betas.toarray() - ref.betas.toarray()[5:]).max() < 1e-7

@@ -122,6 +122,43 @@ def test_binomial_snp_properties(hip, n, p):
     assert st.active_set_size > 128
 
 
+def test_binomial_snp_mid_size_against_oracle(hip, oracle):
+    """Config 4's engine (2-bit design, IRLS, 64-visit panel blocks kept under the default weight-drift rule) where the ORACLE
+    still reaches: 30 000 x 4 000, 30 lambdas down to 0.05 lmda_max (1 650 active columns, ~2 500 block solves, blocks re-used
+    across IRLS iterations), coefficient by coefficient to the reference's 1e-6 (tests/test_solver.py:444-445) at tolerances
+    that resolve the fixed point (tol 1e-10, irls_tol 1e-9), with identical screen sets and IRLS iteration counts."""
+    import os
+
+    import torch
+    import bench
+
+    n, p = 30_000, 4_000
+    cd, imp, y = bench.make_snp_data(n, p, 0, torch.device("cuda", 0))
+    kw = dict(early_exit=False, lmda_path_size=30, min_ratio=0.05, tol=1e-10, irls_tol=1e-9, progress_bar=False)
+    st = ad.grpnet(ad.matrix.snp_calldata(cd, imp), ad.glm.binomial(y), **kw)
+    assert st.error == "" and len(st.lmdas) == 30
+    assert st.counters["n_panel_blocks"] >= 1000
+    assert 0 < st.counters["n_panel_grams"] < st.counters["n_panel_blocks"]      # blocks were kept across IRLS iterations
+    cd_h = np.asfortranarray(cd.cpu().numpy())
+    os.environ["ORACLE_COL_THREADS"] = "16"
+    try:
+        ref = ad.grpnet(oracle.snp_calldata(cd_h, imp, n_threads=16), ad.glm.binomial(y), n_threads=16, **kw)
+    finally:
+        del os.environ["ORACLE_COL_THREADS"]
+    assert ref.error == "" and len(ref.lmdas) == 30
+    db = float(np.abs(st.betas.toarray() - ref.betas.toarray()).max())
+    di = float(np.abs(st.intercepts - ref.intercepts).max())
+    _record("binomial_snp_mid_size_vs_oracle", dict(n=n, p=p, lambdas=30, final_active=int(st.active_set_size),
+                                                    n_panel_blocks=int(st.counters["n_panel_blocks"]),
+                                                    n_block_builds=int(st.counters["n_panel_grams"]),
+                                                    n_irls_iters=[int(st.counters["n_irls_iters"]), int(ref.counters["n_irls_iters"])],
+                                                    max_abs_dbeta=db, max_abs_dintercept=di))
+    assert db < 1e-6 and di < 1e-6, (db, di)
+    assert sorted(st.screen_set.tolist()) == sorted(ref.screen_set.tolist())
+    assert st.counters["n_irls_iters"] == ref.counters["n_irls_iters"]
+    assert np.allclose(st.devs, ref.devs, atol=1e-9)
+
+
 def test_binomial_snp_full_size_config4(hip):
     """BASELINE.json config 4 at FULL size: binomial lasso on a 2-bit SNP design 500k x 50k (6.25 GB packed), the 100-lambda path
     with the solver's default tolerances.  Far beyond the oracle's reach in a test, so the path is certified on the device

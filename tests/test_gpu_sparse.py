@@ -290,6 +290,27 @@ def test_kept_sparse_design_serves_constrained_and_multi_response_fits(hip, orac
     cons2[3] = ad.constraint.lower(np.array([-0.5]))
     cb = ad.grpnet(ad.matrix.dense(np.asfortranarray(D)), ad.glm.gaussian(y), constraints=cons2, **kwc)
     assert ca.error == "" and np.abs(ca.betas.toarray() - cb.betas.toarray()).max() < 1e-9
+    # ... under IRLS the design has a panel form of its own (compressed columns): constrained fits run on it, no copy, no warning,
+    # one-coefficient closed forms and a box object on a group alike; against the oracle on the dense matrix
+    import warnings
+    yb = (y > np.median(y)).astype(float)
+    grp = np.concatenate([np.arange(0, 30), [30, 35]])
+
+    def cons_glm():
+        c = [None] * len(grp)
+        c[3] = ad.constraint.lower(np.array([-0.2]))
+        c[7] = ad.constraint.box(np.array([-0.1]), np.array([0.15]))
+        c[30] = ad.constraint.box(np.full(5, -0.05), np.full(5, 0.1))
+        return c
+
+    kwb = dict(groups=grp, tol=1e-12, irls_tol=1e-11, early_exit=False, lmda_path_size=8, min_ratio=0.1, progress_bar=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        ga = ad.grpnet(X, ad.glm.binomial(yb), constraints=cons_glm(), **kwb)
+    gb = ad.grpnet(oracle.dense(np.asfortranarray(D)), ad.glm.binomial(yb), constraints=cons_glm(), **kwb)
+    assert ga.error == "" and gb.error == ""
+    assert np.abs(ga.betas.toarray() - gb.betas.toarray()).max() < 1e-7
+    assert np.abs(ga.intercepts - gb.intercepts).max() < 1e-7
     # multi-response fits need dense column slices: the view is built over the expanded copy
     Y = np.stack([y, -y + 0.1 * rng.normal(size=300)], axis=1)
     kw = dict(tol=1e-12, early_exit=False, lmda_path_size=10, min_ratio=0.1, progress_bar=False)

@@ -885,7 +885,8 @@ int launch_panel_step_snp(const SnpView& X, const T* impute, const T* w, T* r, c
     // 16 calls (one 32-bit word) per lane and column instead of 4 (one byte): a quarter of the workgroups, four times the
     // bytes per load instruction - the byte form is bound by the number of workgroups and load instructions, not by bytes.
     if (snp16_shape_ok(X)) {
-        if (snp16_old_form()) return step_launch<T, SnpAcc<T>, 16>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, slice_major, s);
+        // (nb > 128: the opening step of a look-ahead pass prepares two blocks at once; the generic body has no per-block tables)
+        if (snp16_old_form() || nb > PB) return step_launch<T, SnpAcc<T>, 16>(acc, X.n, w, r, dcol, dlt, nz_dev, cols, nb, part, slice_major, s);
         constexpr int64_t RW = int64_t(S16_RS) * S16_NSUB;
         const int64_t nwg = (X.n + RW - 1) / RW;
         StepTail<T> tl{};

@@ -584,3 +584,52 @@ def test_penalty_l2_is_the_quadratic_parts_own_factor(hip, oracle):
         assert max(a.screen_sizes) > 128   # (the panel engines took over along the path)
     with pytest.raises(RuntimeError, match="penalty_l2 needs groups of one coefficient"):
         ad.grpnet(Xd, ad.glm.gaussian(y), groups=np.arange(0, p, 2), alpha=0.5, _penalty_l2=np.ones(p // 2), progress_bar=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["gaussian_plain_128", "gaussian_default", "binomial", "binomial_weights_offsets"])
+def test_snp_word_per_lane_step_shapes(hip, oracle, monkeypatch, case):
+    """The 2-bit panel step of round 6 (one 32-bit word per lane, pair tables in the residual update, the last workgroups summing
+    the partials; n >= 16384) on shapes the configuration-sized tests do not reach: a row count that ends inside a word and
+    inside a slice (20 037 = 9 x 2048 + 1605 = ... + 100 words + 5 calls), blocks of 128 visits in the sequential form (two
+    pair-table batches; ADELIE_HIP_LOOKAHEAD=0 puts every Gaussian pass there), the look-ahead passes' two-block opening step
+    (which stays on the generic body), blocks of 64 under IRLS, observation weights and offsets.  Against the oracle at tolerances
+    that resolve the fixed point.  (No case without an intercept: on uncentred 2-bit columns the reference's coordinate descent
+    itself needs 20 minutes for this problem.)"""
+    rng = np.random.RandomState(41)
+    n, p = 20037, 700
+    cd = rng.choice([0, 1, 2, -9], size=(n, p), p=[0.6, 0.25, 0.05, 0.1]).astype(np.int8)
+    cd = np.asfortranarray(cd)
+    imp = np.array([cd[:, j][cd[:, j] >= 0].mean() for j in range(p)])
+    Xv = np.where(cd < 0, imp[None, :], cd).astype(float)
+    beta = np.zeros(p)
+    beta[rng.choice(p, 250, replace=False)] = rng.normal(size=250) * 0.5
+    eta = Xv @ beta
+    eta = (eta - eta.mean()) / eta.std()
+    kw = dict(early_exit=False, lmda_path_size=14, progress_bar=False)
+    if case.startswith("gaussian"):
+        y = eta + 0.3 * rng.normal(size=n)
+        mk = lambda: ad.glm.gaussian(y)
+        kw.update(tol=1e-13, min_ratio=0.01)
+        if case == "gaussian_plain_128":
+            monkeypatch.setenv("ADELIE_HIP_LOOKAHEAD", "0")
+    else:
+        y = (rng.uniform(size=n) < 1 / (1 + np.exp(-2 * eta))).astype(float)
+        kw.update(tol=1e-12, irls_tol=1e-11, min_ratio=0.03)
+        if case == "binomial":
+            mk = lambda: ad.glm.binomial(y)
+        else:
+            w = rng.uniform(0.2, 1.8, n)
+            mk = lambda: ad.glm.binomial(y, weights=w / w.sum())
+            kw.update(offsets=0.3 * rng.normal(size=n))
+    st = ad.grpnet(ad.matrix.snp_calldata(cd, imp), mk(), **kw)
+    ref = ad.grpnet(oracle.snp_calldata(cd, imp), mk(), **kw)
+    assert st.error == "" and ref.error == "" and len(st.lmdas) == len(ref.lmdas) == 14
+    assert st.counters["n_panel_blocks"] > 20 and max(st.screen_sizes) > 256
+    assert np.abs(st.betas.toarray() - ref.betas.toarray()).max() < 1e-7
+    assert np.abs(st.intercepts - ref.intercepts).max() < 1e-7
+    assert np.array_equal(st.betas.toarray() != 0, ref.betas.toarray() != 0)
+    # the screen sets agree up to where the pivot rule puts its knee on the last lambda's scores (a handful of near-tied
+    # groups: the weighted case lands six apart; every ACTIVE group is screened on both sides)
+    a, b = set(st.screen_set.tolist()), set(ref.screen_set.tolist())
+    assert len(a ^ b) <= 8 and set(np.flatnonzero(st.betas.toarray()[-1])).issubset(a & b)

@@ -517,17 +517,8 @@ __device__ __forceinline__ void blk_solve_la_body(const CdBlkParams<T>& p, int j
     }
     __builtin_amdgcn_wave_barrier();
     T pA = cst[0], pL = cst[1], pN = cst[2], pR = cst[3], pB = cst[4];
-#define AHIP_LA_VISIT(GREG, NBREG, GCREG, IL)                                                                         \
-    {                                                                                                                  \
-        const T A = pA, thr = pL, den = pN, rden = pR, bi = pB;                                                        \
-        {                                                                                                              \
-            const T* cn = cst + min(i + 1, BLK - 1) * 6;  /* the next visit's constants */                             \
-            pA = cn[0]; pL = cn[1]; pN = cn[2]; pR = cn[3]; pB = cn[4];                                                \
-        }                                                                                                              \
-        const T dc0 = D[i * BLK + lane], dc1 = D[i * BLK + lane + 64];                                                 \
-        const T gcur = rdlane(GREG, IL);                                                                               \
-        const T gk = fma(bi, A, gcur);                    /* pin_naive:85-89 */                                       \
-        const T v = fabs(gk) - thr;                       /* pin_base:181-195 */                                      \
+#ifdef AHIP_LA_BRANCHY
+#define AHIP_LA_VISIT_TAIL(GREG, NBREG, GCREG, IL)                                                                    \
         T ak = T(0);                                                                                                   \
         if (v > T(0)) {                                                                                                \
             const T x = copysign(v, gk);                                                                               \
@@ -540,7 +531,38 @@ __device__ __forceinline__ void blk_solve_la_body(const CdBlkParams<T>& p, int j
             g0 = fma(-del, dc0, g0);                                                                                   \
             g1 = fma(-del, dc1, g1);                                                                                   \
             if (lane == (IL)) { NBREG = ak; GCREG = gcur; }                                                            \
+        }
+#else
+#define AHIP_LA_VISIT_TAIL(GREG, NBREG, GCREG, IL)                                                                    \
+        const T x = copysign(v, gk);                                                                                   \
+        const T q0 = x * rden;                                                                                         \
+        const T r = fma(-q0, den, x);                                                                                  \
+        const T akq = fma(r, rden, q0);                                                                                \
+        const T ak = v > T(0) ? akq : T(0);                                                                            \
+        const T del = ak - bi;                            /* 0 for an unchanged coordinate, pin_naive:97 */           \
+        g0 = fma(-del, dc0, g0);                                                                                       \
+        g1 = fma(-del, dc1, g1);                                                                                       \
+        {                                                                                                              \
+            const bool rec = (lane == (IL)) && (ak != bi);                                                             \
+            NBREG = rec ? ak : NBREG;                                                                                  \
+            GCREG = rec ? gcur : GCREG;                                                                                \
+        }
+#endif
+#define AHIP_LA_VISIT(GREG, NBREG, GCREG, IL)                                                                         \
+    {                                                                                                                  \
+        const T A = pA, thr = pL, den = pN, rden = pR, bi = pB;                                                        \
+        {                                                                                                              \
+            const T* cn = cst + min(i + 1, BLK - 1) * 6;  /* the next visit's constants */                             \
+            pA = cn[0]; pL = cn[1]; pN = cn[2]; pR = cn[3]; pB = cn[4];                                                \
         }                                                                                                              \
+        const T dc0 = D[i * BLK + lane], dc1 = D[i * BLK + lane + 64];                                                 \
+        const T gcur = rdlane(GREG, IL);                                                                               \
+        const T gk = fma(bi, A, gcur);                    /* pin_naive:85-89 */                                       \
+        const T v = fabs(gk) - thr;                       /* pin_base:181-195 */                                      \
+        /* branch-free (AHIP_LA_BRANCHY restores the two branches): the quotient is formed whatever the sign of v and    \
+         * selected away, an unchanged coordinate updates the gradients with del = 0 -- the same values bit for bit,     \
+         * without two exec-mask round trips on the dependent chain of the visit */                                     \
+        AHIP_LA_VISIT_TAIL(GREG, NBREG, GCREG, IL)                                                                     \
     }
     {
         const int n0 = nb < 64 ? nb : 64;
@@ -548,6 +570,7 @@ __device__ __forceinline__ void blk_solve_la_body(const CdBlkParams<T>& p, int j
         for (int i = 64; i < nb; ++i) AHIP_LA_VISIT(g1, nb1, gc1, i - 64)
     }
 #undef AHIP_LA_VISIT
+#undef AHIP_LA_VISIT_TAIL
     // ---- bookkeeping of the block, lane-parallel (as blk_solve_body) ----------------------------------------------------
     const T d0 = nb0 - b0, d1 = nb1 - b1; // lanes beyond nb hold b = nb = 0
     const bool ch0 = d0 != T(0), ch1 = d1 != T(0);

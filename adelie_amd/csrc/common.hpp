@@ -46,7 +46,6 @@ struct Hooks {
     bool cons_host = false; // ADELIE_HIP_CONS_HOST=1: box / one-sided objects on several coefficients visited on the host (A/B, tests)
     int trace = 0;
     int solve_sums = -1;    // ADELIE_HIP_SOLVE_SUMS=0: the sequential panel form keeps its panel_reduce launch per block             [A/B hook]
-    int glm_build_wgs = 0;  // ADELIE_HIP_GLM_BUILD_WGS=n: workgroups per block-build launch under IRLS (default 512 = two per CU)     [A/B hook]
     int step_tail = -1;     // ADELIE_HIP_STEP_TAIL=0: 2-bit designs keep the panel_reduce launch behind every sequential step        [A/B hook]
     int step_means = -1;    // ADELIE_HIP_STEP_MEANS=1: IRLS takes the column means from the panel steps (no mean sweep per iteration)   [A/B hook]
     static Hooks from_env() {
@@ -68,7 +67,6 @@ struct Hooks {
         if (const char* e = std::getenv("ADELIE_HIP_SOLVE_SUMS")) h.solve_sums = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_STEP_MEANS")) h.step_means = std::atoi(e) != 0;
         if (const char* e = std::getenv("ADELIE_HIP_STEP_TAIL")) h.step_tail = std::atoi(e) != 0;
-        if (const char* e = std::getenv("ADELIE_HIP_GLM_BUILD_WGS")) h.glm_build_wgs = std::max(0, std::atoi(e));
         return h;
     }
 };

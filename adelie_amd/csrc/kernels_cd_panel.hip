@@ -428,11 +428,8 @@ __device__ __forceinline__ void panel_step_snp16_body(const SnpAcc<T>& X, int64_
     (void)part; (void)part_ld;
 }
 
-#ifndef AHIP_S16_MIN_BLOCKS
-#define AHIP_S16_MIN_BLOCKS 1
-#endif
 template <class T, bool MEANS>
-__global__ __launch_bounds__(256 * S16_NSUB, AHIP_S16_MIN_BLOCKS) void panel_step_snp16_kernel(SnpAcc<T> X, int64_t n, const T* __restrict__ w,
+__global__ __launch_bounds__(256 * S16_NSUB) void panel_step_snp16_kernel(SnpAcc<T> X, int64_t n, const T* __restrict__ w,
                                                                           T* __restrict__ r, const int32_t* __restrict__ dcol,
                                                                           const T* __restrict__ dlt,
                                                                           const int32_t* __restrict__ nz_dev,
@@ -720,74 +717,44 @@ __global__ __launch_bounds__(256 * FS) void panel_fused_grp_kernel(CdGrpBlkParam
     fused_step_part<T, Acc, VEC>(smem_raw, X, n, w, r, dcol, dlt, nz_dev, cols, nb, part, part_ld, fsa, sp.tail_counter != nullptr);
     if constexpr (RS >= PB) {
         if (sp.tail_counter == nullptr || nb <= 0) return; // (uniform)
-        // ---- tail: the last EIGHT step workgroups to get here sum the partials of all of them, sixteen columns each ----
+        // ---- tail: the last step workgroup to get here sums the partials of all of them ----
         // The partials were stored device-coherently (written through) and are read back the same way, so no cache
         // write-back / invalidate is needed (an agent-scope fence per workgroup costs more than the reduce launch it replaces:
         // measured +15 us per fused launch); the workgroup-scope fence + barrier make the stores complete before the counter
-        // moves.  One workgroup alone (rounds 4-5) pulled the 200 KB at a single compute unit's ~60 GB/s on the critical path
-        // of every launch; eight take one round trip.  They wait for the stragglers on the arrival counter -- every workgroup of
-        // the launch is resident (one per compute unit) and nobody waits for them --, and the last of the eight to finish
-        // resets both counters (tail_counter[0]: arrivals, [1]: finished tail workgroups).
-#ifdef AHIP_GRP_TAIL_ONE
-        constexpr int NTMAX = 1;
-#else
-        constexpr int NTMAX = 8;
-#endif
-        __shared__ int s_rank;
+        // moves.
+        __shared__ int s_last;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
-        if (threadIdx.x == 0) s_rank = __hip_atomic_fetch_add(sp.tail_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const int nwg = int(gridDim.x) - 1, NT = nwg < NTMAX ? 1 : NTMAX;
-        const int rank = s_rank;
-        if (rank < nwg - NT) return;
-        const int tidx = rank - (nwg - NT);
         if (threadIdx.x == 0) {
-            while (__hip_atomic_load(sp.tail_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg) __builtin_amdgcn_s_sleep(1);
+            const int prev = __hip_atomic_fetch_add(sp.tail_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (prev == int(gridDim.x) - 2) ? 1 : 0;
         }
         __syncthreads();
+        if (!s_last) return;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        T* red = reinterpret_cast<T*>(smem_raw); // [64][16], then [16][16] behind it
-        const int cpw = PB / NT;                  // columns of this workgroup: [tidx * cpw, (tidx + 1) * cpw)
-        const int c16 = threadIdx.x & 15, kq = threadIdx.x >> 4; // 16 columns x 64 slice groups per trip
-        for (int cb = tidx * cpw; cb < (tidx + 1) * cpw && cb < nb; cb += 16) {
-            const int c = cb + c16;
-            T sacc = T(0);
-            for (int k0 = kq; k0 < nwg; k0 += 4 * 64) { // (fixed order: kq, kq + 64, ...)
-                T v[4];
+        const int nwg = int(gridDim.x) - 1;
+        T* red = reinterpret_cast<T*>(smem_raw); // [8][128]
+        const int c = threadIdx.x & (PB - 1), q = threadIdx.x >> 7;
+        T s = T(0);
+        for (int k0 = q; k0 < nwg; k0 += 8 * 16) { // 16 loads in flight per thread
+            T v[16];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = k0 + 64 * u;
-                    v[u] = k < nwg ? __hip_atomic_load(part + int64_t(k) * PB + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : T(0);
-                }
+            for (int u = 0; u < 16; ++u) {
+                const int k = k0 + 8 * u;
+                v[u] = k < nwg ? __hip_atomic_load(part + int64_t(k) * PB + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : T(0);
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) sacc += v[u];
-            }
-            red[kq * 16 + c16] = sacc;
-            __syncthreads();
-            if (threadIdx.x < 256) { // 64 -> 16 partial sums per column
-                const int g16 = threadIdx.x >> 4;
-                red[64 * 16 + g16 * 16 + c16] = (red[(4 * g16) * 16 + c16] + red[(4 * g16 + 1) * 16 + c16]) +
-                                                (red[(4 * g16 + 2) * 16 + c16] + red[(4 * g16 + 3) * 16 + c16]);
-            }
-            __syncthreads();
-            if (threadIdx.x < 16 && c < nb) {
-                const T* r2 = red + 64 * 16 + c16;
-                T g = T(0);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) g += r2[q * 16];
-                if (sp.tail_xm) g -= sp.tail_rsum[0] * sp.tail_xm[cols[c]];
-                sp.tail_g[c] = g;
-            }
-            __syncthreads();
+            for (int u = 0; u < 16; ++u) s += v[u];
         }
-        if (threadIdx.x == 0) {
-            const int d = __hip_atomic_fetch_add(sp.tail_counter + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d == NT - 1) {
-                __hip_atomic_store(sp.tail_counter + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(sp.tail_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        red[q * PB + c] = s;
+        __syncthreads();
+        if (threadIdx.x < nb) {
+            T g = ((red[c] + red[PB + c]) + (red[2 * PB + c] + red[3 * PB + c])) +
+                  ((red[4 * PB + c] + red[5 * PB + c]) + (red[6 * PB + c] + red[7 * PB + c]));
+            if (sp.tail_xm) g -= sp.tail_rsum[0] * sp.tail_xm[cols[c]];
+            sp.tail_g[c] = g;
         }
+        if (threadIdx.x == 0) __hip_atomic_store(sp.tail_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

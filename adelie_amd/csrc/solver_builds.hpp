@@ -265,8 +265,7 @@
             open_side();
             // Gaussian look-ahead passes: a build whose block the chain reaches late in the pass is confined to few CUs, so
             // that the fused launches (whole-CU workgroups) running meanwhile never wait for one (see set_small_gram_workgroups)
-            set_small_gram_workgroups((side && side_wgs > 0 && !is_glm() && j0 >= side_wgs_from) ? side_wgs
-                                      : ((is_glm() && hooks.glm_build_wgs > 0) ? hooks.glm_build_wgs : 512));
+            set_small_gram_workgroups((side && side_wgs > 0 && !is_glm() && j0 >= side_wgs_from) ? side_wgs : 512);
             if (multi()) gram_block(cur_w, cols_of(j0), nb_of(j0), cur_xm, pool + size_t(j0) * SL * SL, sidx);
             else gram_block_batch(cur_w, cols_base, sb, step_means_now ? batch_means(cols_base, sb, sidx, pool == d_Dpool.p ? 0 : 1) : cur_xm,
                                   pool + size_t(j0) * SL * SL, sidx);

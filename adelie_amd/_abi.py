@@ -19,6 +19,8 @@ GLM_CALLBACK = 6  # a Python subclass of glm.GlmBase64/32, evaluated by host cal
 
 # int poll(void* user, int final, int64_t n_solutions, const adelie_hip_result* live)
 POLL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p)
+# adelie_hip_done_fn of adelie_hip_grpnet_solve_many (ABI 10): (k, rc, user), from solve k's own thread
+DONE_FN = C.CFUNCTYPE(None, C.c_int32, C.c_int, C.c_void_p)
 GLM_GRADIENT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 GLM_HESSIAN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 GLM_LOSS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double))
@@ -165,7 +167,7 @@ HIP_SYMBOLS = [
     "design_cmul", "design_ctmul", "design_bmul", "design_btmul", "design_mul", "design_mul_batch", "design_cov",
     "design_sq_mul", "design_sp_tmul",
     "design_create_cov_dense", "design_create_cov_lazy", "design_cov_bmul", "design_cov_mul", "design_cov_to_dense", "gaussian_cov_solve",
-    "grpnet_solve", "result_destroy", "result_size", "result_copy", "result_scalar", "result_error", "result_sync",
+    "grpnet_solve", "grpnet_solve_many", "result_destroy", "result_size", "result_copy", "result_scalar", "result_error", "result_sync",
     "bench_sweep",
 ]
 
@@ -184,7 +186,7 @@ def dtype_code(dtype):
 
 
 # kept equal to ADELIE_HIP_ABI_VERSION in include/adelie_hip.h (tests/test_abi.py compares the two)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class Backend:
@@ -253,6 +255,7 @@ class Backend:
         sig("design_sq_mul", ci, [vp, vp, vp])
         sig("design_sp_tmul", ci, [vp, i64, vp, vp, vp, vp])
         sig("grpnet_solve", ci, [vp, p(GrpnetArgs), p(vp)])
+        sig("grpnet_solve_many", ci, [p(vp), p(p(GrpnetArgs)), C.c_int32, p(vp), DONE_FN, vp])
         sig("gaussian_cov_solve", ci, [vp, p(GrpnetArgs), p(vp)])
         sig("design_create_cov_dense", ci, [vp, i64, ci, ci, ci, p(vp)])
         sig("design_create_cov_lazy", ci, [vp, p(vp)])

@@ -19,6 +19,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -680,6 +681,42 @@ static int solve_entry(adelie_hip_design* X, const adelie_hip_grpnet_args* args,
         set_last_error(e.what());
         return 1;
     }
+    return 0;
+}
+int adelie_hip_grpnet_solve_many(adelie_hip_design* const* X, const adelie_hip_grpnet_args* const* args, int32_t count,
+                                 adelie_hip_result** out, adelie_hip_done_fn on_done, void* user) {
+    try {
+        if (count < 0 || (count > 0 && (!X || !args || !out))) throw make_core_error("null argument.");
+        for (int32_t k = 0; k < count; ++k) {
+            out[k] = nullptr;
+            if (!X[k] || !args[k]) throw make_core_error("null argument.");
+            for (int32_t m = 0; m < k; ++m)
+                if (X[m] == X[k]) throw make_core_error("solve_many: a design handle appears twice (concurrent solves need a handle each: adelie_hip_design_alias).");
+        }
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return 1;
+    }
+    std::vector<std::string> msg(static_cast<size_t>(count));
+    std::vector<int> rc(static_cast<size_t>(count), 0);
+    auto one = [&](int32_t k) {
+        rc[size_t(k)] = solve_entry(X[k], args[k], &out[k], false);
+        if (rc[size_t(k)] != 0) msg[size_t(k)] = adelie_hip_last_error(); // (thread-local: read it on the solve's own thread)
+        if (on_done) on_done(k, rc[size_t(k)], user);
+    };
+    if (count == 1) {
+        one(0);
+    } else {
+        std::vector<std::thread> th;
+        th.reserve(static_cast<size_t>(count));
+        for (int32_t k = 0; k < count; ++k) th.emplace_back(one, k);
+        for (auto& t : th) t.join();
+    }
+    for (int32_t k = 0; k < count; ++k)
+        if (rc[size_t(k)] != 0) {
+            set_last_error("solve " + std::to_string(k) + ": " + msg[size_t(k)]);
+            return 1;
+        }
     return 0;
 }
 int adelie_hip_result_destroy(adelie_hip_result* r) {

@@ -81,21 +81,32 @@ def fold_ranges(n: int, n_folds: int):
     return out
 
 
-def _fold_loss(X, glm, fold_idx, full_lmdas, *, n_threads, early_exit, min_ratio, lmda_path_size, grpnet_params, stats=None):
-    """Body of the reference's fold loop (``cv.py:247-314``)."""
-    weights = glm.weights.copy()
-    weights[fold_idx] = 0
-    weights_sum = np.sum(weights)
-    weights /= weights_sum
-    glm_c = glm.reweight(weights)
+def _fold_loss(X, glm, fold_idx, full_lmdas, *, n_threads, early_exit, min_ratio, lmda_path_size, grpnet_params, stats=None,
+               phase=None, carry=None):
+    """Body of the reference's fold loop (``cv.py:247-314``).
 
-    state0 = state = grpnet(X=X, glm=glm_c, n_threads=n_threads, lmda_path_size=0, progress_bar=False)
-    curr_lmdas = state.lmda_max * np.logspace(0, np.log10(min_ratio), lmda_path_size)
-    curr_lmdas = curr_lmdas[curr_lmdas > full_lmdas[0]]
-    aug_lmdas = np.sort(np.concatenate([full_lmdas, curr_lmdas]))[::-1]
+    ``phase``: the loop in two halves around the path solve, for folds whose paths are solved together by ONE library call
+    (``state.solve_many``): ``"prepare"`` returns the fold's carry -- the reweighted family, the bootstrap state and the
+    UNSOLVED path state --, ``"evaluate"`` takes the carry with the solved state in it and returns the fold's loss row."""
+    if phase == "evaluate":   # (the solved state is read out of its result handle here, on the fold's own thread)
+        weights, weights_sum, glm_c, state0, unsolved, ctx = carry
+        state = unsolved._finish_solve(ctx)
+    else:
+        weights = glm.weights.copy()
+        weights[fold_idx] = 0
+        weights_sum = np.sum(weights)
+        weights /= weights_sum
+        glm_c = glm.reweight(weights)
 
-    state = grpnet(X=X, glm=glm_c, ddev_tol=0, n_threads=n_threads, early_exit=early_exit, lmda_path=aug_lmdas,
-                   **grpnet_params)
+        state0 = state = grpnet(X=X, glm=glm_c, n_threads=n_threads, lmda_path_size=0, progress_bar=False)
+        curr_lmdas = state.lmda_max * np.logspace(0, np.log10(min_ratio), lmda_path_size)
+        curr_lmdas = curr_lmdas[curr_lmdas > full_lmdas[0]]
+        aug_lmdas = np.sort(np.concatenate([full_lmdas, curr_lmdas]))[::-1]
+
+        state = grpnet(X=X, glm=glm_c, ddev_tol=0, n_threads=n_threads, early_exit=early_exit, lmda_path=aug_lmdas,
+                       _prepare_only=(phase == "prepare"), **grpnet_params)
+        if phase == "prepare":   # (the argument struct of the path solve is marshalled here, on the fold's own thread)
+            return [weights, weights_sum, glm_c, state0, state, state._begin_solve(False, None)]
 
     weights_sum_val = np.sum(glm.weights[fold_idx])
     betas, intercepts, lmdas = state.betas, state.intercepts, state.lmdas
@@ -222,10 +233,43 @@ def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio
                 batch = False
             # several folds in flight would interleave their progress bars: off unless asked for
             grpnet_params.setdefault("progress_bar", False)
+            # The folds' path solves go out together through ONE library call (adelie_hip_grpnet_solve_many, ABI 10: one host thread
+            # per solve below the ABI -- the fold loop a C++ caller of the library would write) when the design is a plain
+            # resident one and nothing needs Python between a fold's two solves; the bootstrap solves, the preambles and the
+            # evaluation at the full-data grid stay on this side's threads.  ADELIE_HIP_CV_SOLVE_MANY=0: the round-5 loop (every
+            # fold's whole body on a Python thread).
+            many = (X._backend.has("grpnet_solve_many") and os.environ.get("ADELIE_HIP_CV_SOLVE_MANY", "1") != "0"
+                    and getattr(X, "_kind", None) in ("dense", "snp") and not isinstance(X, (matrix._StdView, matrix._MultiView))
+                    and not getattr(glm, "is_multi", False) and grpnet_params.get("exit_cond") is None
+                    and grpnet_params.get("warm_start") is None and not grpnet_params.get("check_state", False))
             try:
                 with ThreadPoolExecutor(max_workers=nc) as pool:
-                    for fold, row in pool.map(run, my_folds):
-                        cv_losses[fold] = row
+                    if not many:
+                        for fold, row in pool.map(run, my_folds):
+                            cv_losses[fold] = row
+                    else:
+                        from .state import run_many
+                        for i0 in range(0, len(my_folds), nc):   # (at most `nc` folds in flight: one handle each)
+                            batch_folds = my_folds[i0:i0 + nc]
+                            hs = [handles.get() for _ in batch_folds]
+                            try:
+                                def prep(a):
+                                    b, e = ranges[a[1]]
+                                    return _fold_loss(a[0], glm, order[b:e], full_lmdas, n_threads=n_threads, early_exit=early_exit,
+                                                      min_ratio=min_ratio, lmda_path_size=lmda_path_size,
+                                                      grpnet_params=grpnet_params, phase="prepare")
+                                carries = list(pool.map(prep, zip(hs, batch_folds)))
+                                def evalf(k):   # (called from solve k's own thread the moment it returns: the others still run)
+                                    b, e = ranges[batch_folds[k]]
+                                    cv_losses[batch_folds[k]] = _fold_loss(
+                                        hs[k], glm, order[b:e], full_lmdas, n_threads=n_threads, early_exit=early_exit,
+                                        min_ratio=min_ratio, lmda_path_size=lmda_path_size, grpnet_params=grpnet_params,
+                                        stats=fold_stats, phase="evaluate", carry=carries[k])
+
+                                run_many([c[4] for c in carries], [c[5] for c in carries], on_done=evalf)
+                            finally:
+                                for h in hs:
+                                    handles.put(h)
             finally:
                 if batch:
                     _sweep_batch(X._backend, False)

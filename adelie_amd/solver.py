@@ -300,7 +300,7 @@ def grpnet(
     max_screen_size: int = None, max_active_size: int = None,
     pivot_subset_ratio: float = 0.1, pivot_subset_min: int = 1, pivot_slack_ratio: float = 1.25,
     check_state: bool = False, progress_bar: bool = True, warm_start=None, exit_cond: Callable = None,
-    _penalty_l2: np.ndarray = None,
+    _penalty_l2: np.ndarray = None, _prepare_only: bool = False,
 ):
     """Group elastic net along a decreasing path of ``lmda`` on an MI355X (naive method).
 
@@ -339,7 +339,7 @@ def grpnet(
                 "adelie_amd: constraints on a lazily standardized / sparse-resident design run on its materialised dense copy "
                 f"({X.rows()} x {X.cols()} values of device memory).", RuntimeWarning, stacklevel=2)
             X = X._materialize() if is_view else matrix._expanded(X)
-    raw = None if exit_cond is not None else _lasso_in_raw_coordinates(X, glm, constraints, groups, alpha, intercept, warm_start)
+    raw = None if (exit_cond is not None or _prepare_only) else _lasso_in_raw_coordinates(X, glm, constraints, groups, alpha, intercept, warm_start)
     if raw is not None:  # (an exit_cond callback reads the live state: it gets the view's own coordinates, i.e. the view's engines)
         # A lasso (alpha = 1, groups of one, intercept) on the standardized view (Z - 1 c') diag(s)^-1 of a resident design Z is the
         # lasso on Z itself with the penalty factors times |s|: beta~ = s beta, and the intercept absorbs the centres.  Every
@@ -417,6 +417,8 @@ def grpnet(
         state._penalty_l2 = np.ascontiguousarray(_penalty_l2, dtype=dtype)
     if check_state:
         state.check(method="assert")
+    if _prepare_only:  # (cv_grpnet: the folds' states are solved together by state.solve_many)
+        return state
     return state.solve(progress_bar=progress_bar, exit_cond=exit_cond)
 
 

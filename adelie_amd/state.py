@@ -157,6 +157,65 @@ class live_state:
         return getattr(o, name)
 
 
+def run_many(states, ctxs, on_done=None):
+    """The library call of :func:`solve_many` alone: ``ctxs[k] = states[k]._begin_solve(...)`` (prepared by the caller, e.g. on
+    the folds' own threads); every context ends up holding its result handle (``None`` where that solve failed) for
+    ``states[k]._finish_solve(ctxs[k])``.  ``on_done(k)``, when given, is called from solve k's own thread as soon as that
+    solve has returned -- its handle is in place -- while the others still run (``cv_grpnet`` evaluates the fold there); what it
+    raises is re-raised here.  Raises after all solves have returned if one failed."""
+    K = len(states)
+    if K == 0:
+        return
+    backend = states[0]._X._backend
+    if not backend.has("grpnet_solve_many") or any(s._solve_entry != "grpnet_solve" for s in states):
+        raise RuntimeError("solve_many needs naive-method states on a backend that exports adelie_hip_grpnet_solve_many.")
+    X = (_abi.C.c_void_p * K)(*[s._X._handle for s in states])
+    A = (_abi.C.POINTER(_abi.GrpnetArgs) * K)(*[_abi.C.pointer(c["args"]) for c in ctxs])
+    H = (_abi.C.c_void_p * K)()
+    pending = {}
+
+    def _take(k):
+        c = ctxs[k]
+        if c["bar"] is not None:
+            c["bar"].close()
+        c["handle"] = _abi.C.c_void_p(H[k]) if H[k] else None
+        c["taken"] = True
+
+    def _done(k, rc_k, user):
+        try:
+            _take(k)
+            if rc_k == 0 and on_done is not None:
+                on_done(int(k))
+        except BaseException as e:  # noqa: BLE001 - ctypes would swallow it
+            pending.setdefault("exc", e)
+
+    cb = _abi.DONE_FN(_done)
+    rc = backend.fn("grpnet_solve_many")(X, A, K, H, cb, None)
+    for k, c in enumerate(ctxs):
+        if not c.get("taken"):
+            _take(k)
+    if rc != 0 or "exc" in pending:
+        for c in ctxs:  # nobody will finish what is left: free it
+            if c.get("handle") is not None and not c.get("finished"):
+                backend.fn("result_destroy")(c["handle"])
+                c["handle"] = None
+            c["keep"] = None
+        if "exc" in pending:
+            raise pending["exc"]
+        backend.check(rc)
+
+
+def solve_many(states, progress_bar: bool = False):
+    """Solves several independent states concurrently through ONE library call (``adelie_hip_grpnet_solve_many``, ABI 10: one
+    host thread per solve below the ABI) -- the folds of ``cv_grpnet``: every state on its own handle of the resident design
+    (an alias per fold on one device, or replicas on several).  Returns the solved states in order; a failed solve raises
+    after all of them have returned.  Needs a backend that exports the entry point (the HIP library)."""
+    states = list(states)
+    ctxs = [s._begin_solve(progress_bar and len(states) == 1, None) for s in states]
+    run_many(states, ctxs)
+    return [s._finish_solve(c) for s, c in zip(states, ctxs)]
+
+
 class base:
     """Common machinery of the two naive states."""
 
@@ -176,6 +235,18 @@ class base:
         re-raised here.  ``progress_bar`` renders the reference's bar with its ``[dev:xx.x%]`` suffix
         (``solver_base.hpp:225-239``) on stderr.
         """
+        ctx = self._begin_solve(progress_bar, exit_cond)
+        backend, args, handle = ctx["backend"], ctx["args"], ctx["handle"]
+        try:
+            backend.check(backend.fn(self._solve_entry)(self._X._handle, _abi.C.byref(args), handle))
+        finally:
+            if ctx["bar"] is not None:
+                ctx["bar"].close()
+        return self._finish_solve(ctx)
+
+    def _begin_solve(self, progress_bar, exit_cond):
+        """Everything of a solve up to the library call: the marshalled argument struct (kept alive in the returned context)
+        and the poll callback that drives the progress bar / ``exit_cond``."""
         backend = self._X._backend
         self._glm_cb_pending = {}  # one per solve, shared by every callback factory of _marshal (_callback_errors)
         args, keep = self._marshal()
@@ -201,13 +272,13 @@ class base:
         cb = _abi.POLL_FN(_poll)
         args.poll = cb
         args.poll_user = None
-        handle = _abi.C.c_void_p()
-        try:
-            backend.check(backend.fn(self._solve_entry)(self._X._handle, _abi.C.byref(args), handle))
-        finally:
-            if bar is not None:
-                bar.close()
-        del keep
+        return dict(backend=backend, args=args, keep=keep, cb=cb, pending=pending, bar=bar, handle=_abi.C.c_void_p())
+
+    def _finish_solve(self, ctx):
+        """The solved state from the result handle the library filled in (and the exceptions callbacks parked meanwhile)."""
+        backend, pending, handle = ctx["backend"], ctx["pending"], ctx["handle"]
+        ctx["keep"] = None
+        ctx["finished"] = True  # (the handle is destroyed below, whatever happens)
         if "exc" not in pending and "exc" in getattr(self, "_glm_cb_pending", {}):
             pending["exc"] = self._glm_cb_pending.pop("exc")
         if "exc" in pending:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADELIE_HIP_ABI_VERSION 9
+#define ADELIE_HIP_ABI_VERSION 10
 
 enum adelie_hip_dtype { ADELIE_HIP_F32 = 0, ADELIE_HIP_F64 = 1 };
 enum adelie_hip_order { ADELIE_HIP_COL_MAJOR = 0, ADELIE_HIP_ROW_MAJOR = 1 };
@@ -407,6 +407,22 @@ typedef struct adelie_hip_grpnet_args {
 /* Runs the whole path.  `*out` is always set on return code 0 (even when the solve recorded
  * an error string): the caller owns it and frees it with adelie_hip_result_destroy. */
 int adelie_hip_grpnet_solve(adelie_hip_design* X, const adelie_hip_grpnet_args* args, adelie_hip_result** out);
+/* ABI 10.  Replaces the fold loop of adelie.cv.cv_grpnet (adelie/cv.py:239-314, a Python `for fold in range(n_folds)` upstream)
+ * for the solves it runs: `count` INDEPENDENT paths -- the folds' fits: the same matrix, their own weights / lambda grids /
+ * warm starts in args[k] -- run concurrently, solve k on X[k], one host thread per solve below this call.  The handles are a
+ * design and its aliases on one device (adelie_hip_design_alias: own stream and scratch each; with the "sweep_batch" config
+ * on, the solves in flight share their full-gradient sweeps), or replicas on several devices of the node (each solve runs on
+ * its handle's device; no collective is involved).  The same handle must not appear twice.  Callbacks in args[k] (poll, GLM,
+ * constraints) are invoked from the solve's own thread, possibly several at once: a binding that needs a lock (the Python
+ * binding: the interpreter lock, taken by ctypes) takes it there.  out[k] is what adelie_hip_grpnet_solve would have returned
+ * for (X[k], args[k]) or NULL where that call failed; returns 0 when every solve returned 0, else 1 with the first failing
+ * solve's message in adelie_hip_last_error.  `on_done` (may be NULL) is called from solve k's own thread as soon as that solve
+ * has returned and out[k] is set -- rc = its return code -- while the other solves are still running: the caller's per-fold work
+ * behind a path (cv.py:281-314: coefficients at the full-data grid, predictions, losses) overlaps with them instead of queueing
+ * up behind the slowest fold. */
+typedef void (*adelie_hip_done_fn)(int32_t k, int rc, void* user);
+int adelie_hip_grpnet_solve_many(adelie_hip_design* const* X, const adelie_hip_grpnet_args* const* args, int32_t count,
+                                 adelie_hip_result** out, adelie_hip_done_fn on_done, void* user);
 
 /* ------------------------------------------------------------------------------------------
  * Covariance method  

@@ -162,3 +162,41 @@ dist.destroy_process_group()
     np.random.seed(100)                 # rank 0's stream
     single = ad.cv_grpnet(ad.matrix.dense(d["X"]), ad.glm.gaussian(d["y"]), n_folds=5, lmda_path_size=12, tol=1e-12)
     assert np.allclose(l0, single.losses, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_solve_many_entry_point(hip, monkeypatch):
+    """``adelie_hip_grpnet_solve_many`` (ABI 10): independent states solved by ONE library call, one host thread per solve below
+    the ABI.  Same numbers as the solves one after another (bit for bit: separate sweeps), a handle may not appear twice, and
+    ``cv_grpnet`` gives the same table through it as through the round-5 loop of Python threads."""
+    from adelie_amd.state import solve_many
+
+    rng = np.random.RandomState(8)
+    n, p = 1500, 200
+    X = ad.matrix.dense(np.asfortranarray(rng.normal(size=(n, p))))
+    hs = [X, X.alias(), X.alias()]
+    ys = [X @ (rng.normal(size=p) * (rng.uniform(size=p) < 0.1)) + rng.normal(size=n) for _ in hs]
+    kw = dict(lmda_path_size=25, min_ratio=0.05, early_exit=False, tol=1e-10, progress_bar=False)
+    fams = [ad.glm.gaussian(ys[0]), ad.glm.binomial((ys[1] > 0).astype(float)), ad.glm.gaussian(ys[2])]
+    extra = [dict(), dict(), dict(groups=np.arange(0, p, 5), alpha=0.6)]
+    one_by_one = [ad.grpnet(h, f, **kw, **e) for h, f, e in zip(hs, fams, extra)]
+    states = [ad.grpnet(h, f, _prepare_only=True, **kw, **e) for h, f, e in zip(hs, fams, extra)]
+    together = solve_many(states)
+    for a, b in zip(one_by_one, together):
+        assert b.error == "" and len(b.lmdas) == 25
+        np.testing.assert_array_equal(a.betas.toarray(), b.betas.toarray())
+        np.testing.assert_array_equal(a.intercepts, b.intercepts)
+        np.testing.assert_array_equal(a.devs, b.devs)
+    # the same handle twice: refused (concurrent solves need a stream and scratch each)
+    twice = [ad.grpnet(X, fams[0], _prepare_only=True, **kw), ad.grpnet(X, fams[2], _prepare_only=True, **kw)]
+    with pytest.raises(RuntimeError, match="appears twice"):
+        solve_many(twice)
+    # cv_grpnet: the path solves through the entry point against the loop of Python threads
+    glm = ad.glm.gaussian(ys[0])
+    kwc = dict(n_folds=5, seed=3, lmda_path_size=20, tol=1e-10)
+    monkeypatch.setenv("ADELIE_HIP_SWEEP_BATCH", "0")
+    new = ad.cv_grpnet(X, glm, n_concurrent=3, **kwc)
+    monkeypatch.setenv("ADELIE_HIP_CV_SOLVE_MANY", "0")
+    old = ad.cv_grpnet(X, glm, n_concurrent=3, **kwc)
+    np.testing.assert_array_equal(new.losses, old.losses)
+    assert len(new.fold_stats) == len(old.fold_stats) == 5

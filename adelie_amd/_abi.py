@@ -131,6 +131,9 @@ class GrpnetArgs(C.Structure):
         ("constraint_lin", C.c_void_p),
         ("constraint_vmu", C.c_void_p),
         ("penalty_l2", C.c_void_p),
+        ("lmda_aug_ratios", C.POINTER(C.c_double)),
+        ("n_lmda_aug", C.c_int64),
+        ("lmda_aug_min", C.c_double),
     ]
 
 

@@ -201,9 +201,12 @@ void set_small_gram_workgroups(int wgs); // kernels_gram.hip: spread of the next
 template <class T>
 void launch_syrk_batch(const DenseView<T>& X, const T* w, const int32_t* cols_base, const SyrkBatch& b, const T* xm_by_col,
                        bool center, T* C_base, int64_t ldc, T* work, hipStream_t s);
+// xm_build != nullptr (blocks of 33-64 columns on a 2-bit design, syrk_batch_snp_brings_means): the build computes the weighted
+// means of its own columns on the side, leaves them in xm_build (by design column) and centres with THEM instead of xm_by_col
 template <class T>
 void launch_syrk_batch_snp(const SnpView& X, const T* impute, const T* w, const int32_t* cols_base, const SyrkBatch& b,
-                           const T* xm_by_col, bool center, T* C_base, int64_t ldc, T* work, hipStream_t s);
+                           const T* xm_by_col, bool center, T* C_base, int64_t ldc, T* work, hipStream_t s, T* xm_build = nullptr);
+bool syrk_batch_snp_brings_means(const SyrkBatch& b);
 template <class T>
 void launch_syrk(const DenseView<T>& X, const T* w, const int32_t* cols, int32_t M, const T* xm_by_col, bool center, T* C,
                    int64_t ldc, T* work, hipStream_t s);

@@ -430,16 +430,23 @@ __device__ __forceinline__ void syrk_body_snp(const SnpAcc<T>& X, const T* __res
 // v_mfma_16x16x4 both as the row-tile operand and, times the row's weight, as the column-tile operand — and issues ten MFMAs
 // per s: 16 decodes and 16 multiplies feed 40 MFMAs, nothing goes through LDS and nothing waits at a barrier until the four
 // waves add up their tiles at the end.  Same partial layout as syrk_store.
-template <class T>
+// MEANS: the weighted column sums  sum_i w_i x_ic  of the block's columns ride along -- the column-tile operand b = x * w is
+// what they are made of: four additions per sixteen decodes next to forty MFMAs --, reduced over the lanes and the four waves
+// at the end and parked in the partial tile's UNUSED upper triangle (syrk_means_index): a block built for an IRLS iteration
+// brings the means its centring needs, and nobody sweeps the screen columns for them (solver_screen.hpp::step_means_now).
+__host__ __device__ constexpr int syrk_means_index(int c) { return (48 + (c & 15)) * 64 + (c >> 4); } // tile (rows 0-15, columns 48-63)
+template <class T, bool MEANS = false>
 __device__ __forceinline__ void syrk_body_snp_reg64(const SnpAcc<T>& X, const T* __restrict__ w, const int32_t* __restrict__ cols,
                                                     int32_t M, int64_t k0, int64_t kend, T* __restrict__ P) {
     constexpr int SB = 64, NT = 10;
     constexpr int TR[NT] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3};
     constexpr int TC[NT] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
     __shared__ T red[2][NT * 256];
+    __shared__ T mred[MEANS ? 4 : 1][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fk = lane >> 4;
+    T ms[4] = {T(0), T(0), T(0), T(0)};
     typename Mfma<T>::acc_t acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -495,6 +502,7 @@ __device__ __forceinline__ void syrk_body_snp_reg64(const SnpAcc<T>& X, const T*
                     const T x = c == 3u ? imp[t] : T(c);
                     a[t] = x;
                     b[t] = x * cwr[4 * g + s4];
+                    if constexpr (MEANS) ms[t] += b[t];
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = Mfma<T>::run(a[TR[t]], b[TC[t]], acc[t]);
@@ -514,6 +522,14 @@ __device__ __forceinline__ void syrk_body_snp_reg64(const SnpAcc<T>& X, const T*
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[t][e] += red[slot][(t * 4 + e) * 64 + lane];
     };
+    if constexpr (MEANS) { // over the four row quarters of a lane group (fk), then the four waves through LDS; fixed order
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ms[t] += __shfl_xor(ms[t], 16, 64);
+            ms[t] += __shfl_xor(ms[t], 32, 64);
+            if (fk == 0) mred[wv][16 * t + fr] = ms[t];
+        }
+    }
     if (wv >= 2) put(wv - 2);
     __syncthreads();
     if (wv < 2) add(wv);
@@ -526,20 +542,21 @@ __device__ __forceinline__ void syrk_body_snp_reg64(const SnpAcc<T>& X, const T*
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) P[(TC[t] * 16 + fr) * SB + TR[t] * 16 + Mfma<T>::row(lane, e)] = acc[t][e];
+        if constexpr (MEANS) P[syrk_means_index(lane)] = (mred[0][lane] + mred[2][lane]) + (mred[1][lane] + mred[3][lane]);
     }
 }
 
 template <class A> struct IsSnpAcc { static constexpr bool value = false; };
 template <class T> struct IsSnpAcc<SnpAcc<T>> { static constexpr bool value = true; };
 
-template <class T, class Acc, bool VECOK, int SB>
+template <class T, class Acc, bool VECOK, int SB, bool MEANS = false>
 __device__ __forceinline__ void syrk_any(const Acc& X, const T* __restrict__ w, const int32_t* __restrict__ cols, int32_t M,
                                          int64_t k0, int64_t kend, T* __restrict__ P) {
     if constexpr (IsSnpAcc<Acc>::value && SB == 64) {
 #ifdef AHIP_SYRK_STAGED
         syrk_body_snp<T, SB>(X, w, cols, M, k0, kend, P);
 #else
-        syrk_body_snp_reg64<T>(X, w, cols, M, k0, kend, P);
+        syrk_body_snp_reg64<T, MEANS>(X, w, cols, M, k0, kend, P);
 #endif
     } else if constexpr (IsSnpAcc<Acc>::value) syrk_body_snp<T, SB>(X, w, cols, M, k0, kend, P);
     else syrk_body<T, Acc, VECOK, SB>(X, w, cols, M, k0, kend, P);
@@ -558,14 +575,33 @@ __global__ __launch_bounds__(GT, 2) void syrk_kernel(Acc X, const T* __restrict_
 // 20 KB of partial tiles — more bytes than it read — which a second kernel has to read back; with the blocks of a pass batched
 // the same 512-1024 workgroups cover `count` blocks with 512 / count splits each, i.e. count times fewer partials per block
 // and count times longer K loops per workgroup.
-template <class T, class Acc, bool VECOK, int SB>
+template <class T, class Acc, bool VECOK, int SB, bool MEANS = false>
 __global__ __launch_bounds__(GT, 2) void syrk_batch_kernel(Acc X, const T* __restrict__ w, const int32_t* __restrict__ cols_base,
                                                            SyrkBatch b, int64_t n, int64_t kchunk, int nsplit,
                                                            T* __restrict__ part) {
     const int sp = blockIdx.x, y = blockIdx.y;
     const int64_t k0 = int64_t(sp) * kchunk;
-    syrk_any<T, Acc, VECOK, SB>(X, w, cols_base + b.off[y], b.nb[y], k0, min(n, k0 + kchunk),
-                                part + (int64_t(y) * nsplit + sp) * SB * SB);
+    syrk_any<T, Acc, VECOK, SB, MEANS>(X, w, cols_base + b.off[y], b.nb[y], k0, min(n, k0 + kchunk),
+                                       part + (int64_t(y) * nsplit + sp) * SB * SB);
+}
+
+// the weighted column sums the MEANS builds parked in their partial tiles: summed over the K-splits in a fixed order and
+// scattered by design column (one workgroup per block of the batch, one thread per column)
+template <class T>
+__global__ __launch_bounds__(64) void syrk_batch_means_kernel(const T* __restrict__ part, int nsplit, SyrkBatch b,
+                                                              const int32_t* __restrict__ cols_base, T* __restrict__ xm_by_col) {
+    const int y = blockIdx.x, c = threadIdx.x;
+    if (c >= b.nb[y]) return;
+    const T* base = part + int64_t(y) * nsplit * 64 * 64 + syrk_means_index(c);
+    T s = T(0);
+    int sp = 0;
+    for (; sp + 3 < nsplit; sp += 4) {
+        const T v0 = base[int64_t(sp) * 4096], v1 = base[int64_t(sp + 1) * 4096], v2 = base[int64_t(sp + 2) * 4096],
+                v3 = base[int64_t(sp + 3) * 4096];
+        s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; sp < nsplit; ++sp) s += base[int64_t(sp) * 4096];
+    xm_by_col[cols_base[b.off[y] + c]] = s;
 }
 
 // deterministic sum of the K-split partials of every block of a batch, centring, symmetric write into the block's slot
@@ -645,7 +681,7 @@ inline void syrk_batch_shape(int64_t n, int count, int& nsplit, int64_t& kchunk)
 
 template <class T, class Acc>
 void syrk_batch_launch(Acc acc, bool vecok, const T* w, const int32_t* cols_base, const SyrkBatch& b, int64_t n, const T* xm,
-                       bool center, T* C_base, int64_t ldc, T* work, hipStream_t s) {
+                       bool center, T* C_base, int64_t ldc, T* work, hipStream_t s, T* xm_build = nullptr) {
     if (b.count <= 0) return;
     int nsplit;
     int64_t kchunk;
@@ -656,9 +692,24 @@ void syrk_batch_launch(Acc acc, bool vecok, const T* w, const int32_t* cols_base
     const dim3 grid((unsigned)nsplit, (unsigned)b.count);
 #define AHIP_SYRKB(VOK, SBV) \
     hipLaunchKernelGGL((syrk_batch_kernel<T, Acc, VOK, SBV>), grid, dim3(GT), 0, s, acc, w, cols_base, b, n, kchunk, nsplit, work)
-    if (SB == 32) { if (vecok) AHIP_SYRKB(true, 32); else AHIP_SYRKB(false, 32); }
-    else if (SB == 64) { if (vecok) AHIP_SYRKB(true, 64); else AHIP_SYRKB(false, 64); }
-    else { if (vecok) AHIP_SYRKB(true, 128); else AHIP_SYRKB(false, 128); }
+    bool built_means = false;
+    if constexpr (IsSnpAcc<Acc>::value) {
+#ifndef AHIP_SYRK_STAGED
+        if (xm_build != nullptr && SB == 64) { // the builds bring the means of their own columns (syrk_body_snp_reg64<MEANS>)
+            hipLaunchKernelGGL((syrk_batch_kernel<T, Acc, true, 64, true>), grid, dim3(GT), 0, s, acc, w, cols_base, b, n, kchunk,
+                               nsplit, work);
+            hipLaunchKernelGGL((syrk_batch_means_kernel<T>), dim3((unsigned)b.count), dim3(64), 0, s, work, nsplit, b, cols_base,
+                               xm_build);
+            xm = xm_build;
+            built_means = true;
+        }
+#endif
+    }
+    if (!built_means) {
+        if (SB == 32) { if (vecok) AHIP_SYRKB(true, 32); else AHIP_SYRKB(false, 32); }
+        else if (SB == 64) { if (vecok) AHIP_SYRKB(true, 64); else AHIP_SYRKB(false, 64); }
+        else { if (vecok) AHIP_SYRKB(true, 128); else AHIP_SYRKB(false, 128); }
+    }
 #undef AHIP_SYRKB
     hipLaunchKernelGGL((syrk_batch_reduce_kernel<T>), dim3((unsigned)((mx + 63) / 64), (unsigned)mx, (unsigned)b.count), dim3(256),
                        0, s, work, nsplit, SB, b, cols_base, xm, center ? 1 : 0, C_base, ldc);
@@ -790,9 +841,19 @@ void launch_syrk_batch(const DenseView<T>& X, const T* w, const int32_t* cols_ba
 }
 template <class T>
 void launch_syrk_batch_snp(const SnpView& X, const T* impute, const T* w, const int32_t* cols_base, const SyrkBatch& b,
-                           const T* xm_by_col, bool center, T* C_base, int64_t ldc, T* work, hipStream_t s) {
+                           const T* xm_by_col, bool center, T* C_base, int64_t ldc, T* work, hipStream_t s, T* xm_build) {
     SnpAcc<T> acc{X.bits, X.ldb, impute};
-    syrk_batch_launch<T, SnpAcc<T>>(acc, true, w, cols_base, b, X.n, xm_by_col, center, C_base, ldc, work, s);
+    syrk_batch_launch<T, SnpAcc<T>>(acc, true, w, cols_base, b, X.n, xm_by_col, center, C_base, ldc, work, s, xm_build);
+}
+bool syrk_batch_snp_brings_means(const SyrkBatch& b) { // (what launch_syrk_batch_snp does with a non-null xm_build)
+#ifdef AHIP_SYRK_STAGED
+    (void)b;
+    return false;
+#else
+    int mx = 0;
+    for (int y = 0; y < b.count; ++y) mx = std::max(mx, int(b.nb[y]));
+    return b.count > 0 && mx > 32 && mx <= 64;
+#endif
 }
 
 int64_t syrk_work_elems(int64_t n, int64_t M) {
@@ -890,7 +951,7 @@ INST(float)
     template void launch_syrk_batch<T>(const DenseView<T>&, const T*, const int32_t*, const SyrkBatch&, const T*, bool, T*, \
                                        int64_t, T*, hipStream_t);                                                      \
     template void launch_syrk_batch_snp<T>(const SnpView&, const T*, const T*, const int32_t*, const SyrkBatch&, const T*, \
-                                           bool, T*, int64_t, T*, hipStream_t);                                        \
+                                           bool, T*, int64_t, T*, hipStream_t, T*);                                    \
     template void launch_syrk<T>(const DenseView<T>&, const T*, const int32_t*, int32_t, const T*, bool, T*, int64_t, \
                                    T*, hipStream_t);                                                                   \
     template void launch_syrk_snp<T>(const SnpView&, const T*, const T*, const int32_t*, int32_t, const T*, bool, T*, \

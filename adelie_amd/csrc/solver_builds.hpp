@@ -74,6 +74,8 @@
     // ---- dynamic host state ----
     T lmda_max;
     std::vector<T> lmda_path;
+    std::vector<double> lmda_aug; // adelie_hip_grpnet_args::lmda_aug_ratios (a CV fold's own grid, joined to lmda_path once lmda_max is known)
+    double lmda_aug_min = 0;
     std::vector<uint8_t> in_screen; // role of screen_hashset (state_base.hpp): membership bitmap over the G groups
     std::vector<int32_t> slot_host; // group -> screen value offset (-1: not screened), mirrored in d_slot
     std::vector<idx> screen_set, screen_begins;
@@ -267,7 +269,11 @@
             // that the fused launches (whole-CU workgroups) running meanwhile never wait for one (see set_small_gram_workgroups)
             set_small_gram_workgroups((side && side_wgs > 0 && !is_glm() && j0 >= side_wgs_from) ? side_wgs : 512);
             if (multi()) gram_block(cur_w, cols_of(j0), nb_of(j0), cur_xm, pool + size_t(j0) * SL * SL, sidx);
-            else gram_block_batch(cur_w, cols_base, sb, step_means_now ? batch_means(cols_base, sb, sidx, pool == d_Dpool.p ? 0 : 1) : cur_xm,
+            else if (!step_means_now) gram_block_batch(cur_w, cols_base, sb, cur_xm, pool + size_t(j0) * SL * SL, sidx);
+            else if (!dense() && syrk_batch_snp_brings_means(sb)) // the MFMA build computes its columns' means on the side
+                gram_block_batch(cur_w, cols_base, sb, nullptr, pool + size_t(j0) * SL * SL, sidx,
+                                 d_xmb[pool == d_Dpool.p ? 0 : 1].reserve(size_t(p) + 8));
+            else gram_block_batch(cur_w, cols_base, sb, batch_means(cols_base, sb, sidx, pool == d_Dpool.p ? 0 : 1),
                                   pool + size_t(j0) * SL * SL, sidx);
             if (vb_vars && !multi()) // IRLS, groups of one: the variances of a block's coordinates are its diagonal (vars_from_blocks)
                 launch_block_diag_vars<T>(pool + size_t(j0) * SL * SL, sb, SL, int32_t(cols_base - vb_cols_all), vb_list, vb_vars,

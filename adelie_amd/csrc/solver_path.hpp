@@ -195,6 +195,17 @@
             if (lmda_path_size <= 0) return;
             lmda_path.resize(lmda_path_size);
             compute_lmda_path(lmda_path, min_ratio, lmda_max);
+        } else if (!lmda_aug.empty()) {
+            // adelie/cv.py:255-264 inside the solve (adelie_hip_grpnet_args::lmda_aug_ratios): the fold's own grid above the head
+            // of the full-data grid joins the given path; every value kept, descending
+            std::vector<double> all(lmda_path.begin(), lmda_path.end());
+            for (double r : lmda_aug) {
+                const double v = double(lmda_max) * r;
+                if (v > lmda_aug_min) all.push_back(v);
+            }
+            std::sort(all.begin(), all.end(), std::greater<double>());
+            lmda_path.resize(all.size());
+            for (size_t i = 0; i < all.size(); ++i) lmda_path[i] = T(all[i]);
         }
         const size_t L = lmda_path.size();
         size_t pb_it = 0, large_sz = 0;
@@ -375,6 +386,13 @@
         }
         lmda_max = T(a->lmda_max);
         if (a->lmda_path && a->n_lmda_path > 0) lmda_path.assign((const T*)a->lmda_path, (const T*)a->lmda_path + a->n_lmda_path);
+        lmda_aug.clear();
+        if (a->lmda_aug_ratios && a->n_lmda_aug > 0) {
+            if (setup_lmda_path || !setup_lmda_max)
+                throw make_core_error("lmda_aug_ratios needs a given lmda_path (setup_lmda_path = false) and setup_lmda_max = true.");
+            lmda_aug.assign(a->lmda_aug_ratios, a->lmda_aug_ratios + a->n_lmda_aug);
+            lmda_aug_min = a->lmda_aug_min;
+        }
         screen_set.assign(a->screen_set, a->screen_set + a->screen_set_size);
         screen_beta.assign((const T*)a->screen_beta, (const T*)a->screen_beta + a->screen_beta_size);
         screen_is_active.assign(a->screen_is_active, a->screen_is_active + a->screen_set_size);

@@ -132,7 +132,7 @@
     }
     // `sb.count` diagonal blocks in one launch (non-multi designs): block y = columns cols_base[sb.off[y] ...], into
     // D0 + sb.dst[y] (ld = B)
-    void gram_block_batch(const T* w, const int32_t* cols_base, const SyrkBatch& sb, const T* xm, T* D0, int side) {
+    void gram_block_batch(const T* w, const int32_t* cols_base, const SyrkBatch& sb, const T* xm, T* D0, int side, T* xm_build = nullptr) {
         const int B = cd_block_size();
         hipStream_t gs = side == 0 ? st : (side >= 2 ? st_x[side - 2] : st2);
         if (sparse()) { // compressed columns: one thread per pair of columns merges the two row lists (kernels_sparse.hip)
@@ -149,7 +149,8 @@
         t_gram.begin(gs);
         const bool stdv = std_generic(); // raw X' W X of the base design, then the view's corrections (kernels_sparse.hip)
         if (dense()) launch_syrk_batch<T>(D->dense<T>(), w, cols_base, sb, xm, intercept && !stdv, D0, B, work, gs);
-        else launch_syrk_batch_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols_base, sb, xm, intercept && !stdv, D0, B, work, gs);
+        else launch_syrk_batch_snp<T>(D->snp(), static_cast<const T*>(D->impute), w, cols_base, sb, xm, intercept && !stdv, D0, B, work, gs,
+                                      stdv ? nullptr : xm_build);
         if (stdv) std_block_fix(w, cols_base, sb, xm, D0, side, gs);
         t_gram.end(gs);
         for (int y = 0; y < sb.count; ++y) {

@@ -98,15 +98,22 @@ def _fold_loss(X, glm, fold_idx, full_lmdas, *, n_threads, early_exit, min_ratio
         weights /= weights_sum
         glm_c = glm.reweight(weights)
 
+        if phase == "prepare":
+            # ONE solve per fold: it computes the fold's lmda_max and joins the fold's own grid above full_lmdas[0] to the
+            # full-data grid itself (adelie_hip_grpnet_args::lmda_aug_ratios, ABI 10) -- the numbers the two calls below produce,
+            # without the first call's three sweeps over X and a state's worth of host work.  The argument struct is
+            # marshalled here, on the fold's own thread.
+            state = grpnet(X=X, glm=glm_c, ddev_tol=0, n_threads=n_threads, early_exit=early_exit, lmda_path=full_lmdas,
+                           _lmda_aug=(np.logspace(0, np.log10(min_ratio), lmda_path_size), float(full_lmdas[0])),
+                           _prepare_only=True, **grpnet_params)
+            return [weights, weights_sum, glm_c, None, state, state._begin_solve(False, None)]
         state0 = state = grpnet(X=X, glm=glm_c, n_threads=n_threads, lmda_path_size=0, progress_bar=False)
         curr_lmdas = state.lmda_max * np.logspace(0, np.log10(min_ratio), lmda_path_size)
         curr_lmdas = curr_lmdas[curr_lmdas > full_lmdas[0]]
         aug_lmdas = np.sort(np.concatenate([full_lmdas, curr_lmdas]))[::-1]
 
         state = grpnet(X=X, glm=glm_c, ddev_tol=0, n_threads=n_threads, early_exit=early_exit, lmda_path=aug_lmdas,
-                       _prepare_only=(phase == "prepare"), **grpnet_params)
-        if phase == "prepare":   # (the argument struct of the path solve is marshalled here, on the fold's own thread)
-            return [weights, weights_sum, glm_c, state0, state, state._begin_solve(False, None)]
+                       **grpnet_params)
 
     weights_sum_val = np.sum(glm.weights[fold_idx])
     betas, intercepts, lmdas = state.betas, state.intercepts, state.lmdas
@@ -133,7 +140,9 @@ def _fold_loss(X, glm, fold_idx, full_lmdas, *, n_threads, early_exit, min_ratio
         etas = predict(X=X, betas=full_betas, intercepts=full_intercepts, offsets=state._offsets, n_threads=n_threads)
         full_data_losses = np.array([glm.loss(eta) for eta in etas])
         train_losses = weights_sum * np.array([glm_c.loss(eta) for eta in etas])
-    if stats is not None:  # both solves of the fold: the lmda_max bootstrap and the path
+    if stats is not None and state0 is None:  # (one solve per fold, see "prepare")
+        stats.append({"counters": dict(state.counters), "timers": dict(state.timers), "total_time": state.total_time})
+    elif stats is not None:  # both solves of the fold: the lmda_max bootstrap and the path
         stats.append({
             "counters": {k: state0.counters[k] + v for k, v in state.counters.items()},
             "timers": {k: state0.timers[k] + v for k, v in state.timers.items()},

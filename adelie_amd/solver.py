@@ -300,7 +300,7 @@ def grpnet(
     max_screen_size: int = None, max_active_size: int = None,
     pivot_subset_ratio: float = 0.1, pivot_subset_min: int = 1, pivot_slack_ratio: float = 1.25,
     check_state: bool = False, progress_bar: bool = True, warm_start=None, exit_cond: Callable = None,
-    _penalty_l2: np.ndarray = None, _prepare_only: bool = False,
+    _penalty_l2: np.ndarray = None, _prepare_only: bool = False, _lmda_aug=None,
 ):
     """Group elastic net along a decreasing path of ``lmda`` on an MI355X (naive method).
 
@@ -415,6 +415,8 @@ def grpnet(
     state = _STATE_OF[kind](**kwargs)
     if _penalty_l2 is not None:
         state._penalty_l2 = np.ascontiguousarray(_penalty_l2, dtype=dtype)
+    if _lmda_aug is not None:  # (ratios, threshold): cv_grpnet's fold grid, joined to lmda_path inside the solve (ABI 10)
+        state._lmda_aug = _lmda_aug
     if check_state:
         state.check(method="assert")
     if _prepare_only:  # (cv_grpnet: the folds' states are solved together by state.solve_many)

@@ -407,6 +407,13 @@ class base:
         a.group_sizes = idx(self.group_sizes)
         a.alpha = float(self.alpha)
         a.penalty = val(self.penalty)
+        aug = getattr(self, "_lmda_aug", None)     # (ABI 10; set by cv_grpnet: the fold's own grid joins lmda_path inside the solve)
+        if aug is not None:
+            ratios = np.ascontiguousarray(aug[0], dtype=np.float64)
+            keep.append(ratios)
+            a.lmda_aug_ratios = ratios.ctypes.data_as(_abi.C.POINTER(_abi.C.c_double))
+            a.n_lmda_aug = len(ratios)
+            a.lmda_aug_min = float(aug[1])
         pl2 = getattr(self, "_penalty_l2", None)   # (ABI 8; set by solver.grpnet for an elastic net on a standardized view)
         if pl2 is not None:
             if len(pl2) != len(self.groups):

@@ -402,6 +402,16 @@ typedef struct adelie_hip_grpnet_args {
      * (Z - 1 c') diag(s)^-1 of a resident design needs to run on Z's own columns (penalty * |s|, penalty * s^2: every
      * coordinate update, screening score and KKT test is the same number in both coordinate systems, adelie_amd/solver.py). */
     const void*    penalty_l2;
+    /* ABI 10: the lambda grid of a CV fold, assembled by the solve itself (adelie/cv.py:255-264 does it between two grpnet calls:
+     * a first one with lmda_path_size = 0 for the fold's own lmda_max, then the path).  With lmda_path given
+     * (setup_lmda_path = 0) and n_lmda_aug > 0 the solve, once its lmda_max is known, adds  lmda_max * lmda_aug_ratios[i]  for
+     * every i whose product exceeds lmda_aug_min to the given path (all of them kept, sorted descending, cast to value_t) --
+     * the numbers `state.lmda_max * np.logspace(0, log10(min_ratio), L)`, `> full_lmdas[0]`, `np.sort(np.concatenate(...))[::-1]`
+     * produce; the first grpnet call (three sweeps over X and a state's worth of host work per fold) is not needed.  NULL / 0
+     * for any other solve. */
+    const double*  lmda_aug_ratios;
+    int64_t        n_lmda_aug;
+    double         lmda_aug_min;
 } adelie_hip_grpnet_args;
 
 /* Runs the whole path.  `*out` is always set on return code 0 (even when the solve recorded

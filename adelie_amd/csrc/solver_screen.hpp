@@ -49,9 +49,10 @@
     // Means mode (step_means_now; IRLS on a 2-bit design with an intercept): the step also produces the CURRENT weighted means of
     // the block's columns and leaves them in d_irls_xm (by column) and d_sxm (by screen value: `list` / `pos0` locate the block)
     // before the block's solve reads them -- glm_fit then runs no mean sweep over the screen columns per IRLS iteration.
-    // Measured on config 4 (profiles/r06_cfg4_ab.txt): 3.03-3.06 s with it against 2.98-3.00 s without -- the mean sweeps it removes
-    // (0.17 s of the main stream) come back as the block builds' own mean sweeps on the side streams, in front of the first block
-    // a pass waits for (cd 2.55 against 2.38 s), and phase (B) carries a second accumulation.  Off; hook ADELIE_HIP_STEP_MEANS=1.
+    // Measured on config 4 (profiles/r06_cfg4_ab.txt): parity, 2.91-2.94 s with it against 2.90-2.95 s without -- the mean sweeps it
+    // removes (0.15 s of the main stream) the step gives back (cd 2.43 against 2.29 s: phase (B)'s second accumulation, butterfly
+    // and tail sum, 2.5 us per step); the builds take the means of their own columns inside the MFMA kernel at no cost (with a
+    // sweep per build batch instead it was 3.03-3.06 against 2.98-3.00 s).  Off; hook ADELIE_HIP_STEP_MEANS=1.
     bool step_means_opt = false;
     bool step_means_now = false;  // (set per IRLS iteration by glm_fit)
     bool step_means_possible() const {

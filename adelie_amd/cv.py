@@ -153,7 +153,7 @@ def _fold_loss(X, glm, fold_idx, full_lmdas, *, n_threads, early_exit, min_ratio
 
 def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio: float = 1e-1,
               lmda_path_size: int = 100, n_folds: int = 5, seed: int = None, process_group=None, n_concurrent: int = None,
-              **grpnet_params):
+              _share=None, **grpnet_params):
     """Cross-validated group elastic net (reference ``adelie.cv.cv_grpnet``; same arguments and defaults).
 
     ``process_group``: optional ``torch.distributed`` group (or ``True`` for the default group).  When given,
@@ -200,6 +200,8 @@ def cv_grpnet(X, glm, *, n_threads: int = 1, early_exit: bool = False, min_ratio
         fold_stats = [] if hasattr(state, "counters") else None
         ranges = fold_ranges(n, n_folds)
         my_folds = [fold for fold in range(n_folds) if fold % world == rank]
+        if _share is not None:  # (measurement aid, scripts/cv_phases.py: the share of rank r of w, solved here without a gather)
+            my_folds = [fold for fold in range(n_folds) if fold % int(_share[1]) == int(_share[0])]
         can_alias = hasattr(X, "alias") and hasattr(X, "_backend") and X._backend.has("design_alias")
         # dense Gaussian folds share their sweeps (SweepBatcher), so all of them may as well be in flight; otherwise three
         # interleave well and more only contend

@@ -34,3 +34,14 @@ for rep in range(2):
     print("cv wall %.1f ms" % tot)
     for e in sorted(ev, key=lambda e: (e[0], e[2])):
         print("  thr %3d %-5s start %7.1f end %7.1f  (%.1f ms, native total_time %.1f)" % (e[0], e[1], e[2], e[3], e[3] - e[2], e[4]))
+
+# one rank's share of the same CV on this GPU alone (fold k on rank k % N: 8 / N folds), as the first rank of an N-GPU run would
+# see it: the expected strong-scaling table of DESIGN.md 9 (no gather, no contention from other ranks: every rank has its own GPU)
+cvm.grpnet, cvm._fold_loss = orig, origl
+for N in (1, 2, 4, 8):
+    ts = []
+    for rep in range(3):
+        t0 = time.perf_counter()
+        ad.cv_grpnet(Xd, glm, n_folds=8, seed=0, _share=(0, N))
+        ts.append((time.perf_counter() - t0) * 1e3)
+    print("share of rank 0 of %d (%d folds): %s ms" % (N, 8 // N, " ".join("%.1f" % t for t in ts)))

@@ -24,7 +24,7 @@ if not lines:
     print('cfg$CFG [%s] FAILED (see gpurun_out/ab_last.err)' % os.environ['ARM']); sys.exit(0)
 d = json.loads(lines[-1])
 b = d.get('breakdown_ms_last_path') or {}
-ps = d.get('roofline_panel_step') or {}
+ps = d.get('roofline_panel_step') or (d['roofline'] if 'panel' in (d.get('roofline') or {}).get('kernel', '') else {})
 g = lambda k: round(b.get(k, float('nan')), 1)
 print('cfg$CFG [%s] | %.4f %.1f | sweep %s cd %s gram %s hostc %s hostw %s | fused %.1f us' % (
     os.environ['ARM'], d['value'], d['ms_per_step'], g('sweep'), g('cd'), g('gram_mfma'), g('host_screen_compute'),

@@ -159,7 +159,7 @@
         active_set_size = size_t(sc.active_size);
         rsum_io = sc.resid_sum;
         o.rsq = sc.rsq;
-        d_beta.download(screen_beta.data(), size_t(nv), st);
+        if (!defer_fit_output) d_beta.download(screen_beta.data(), size_t(nv), st);
         std::vector<int32_t> act(active_set_size > old_active ? active_set_size - old_active : 0);
         if (!act.empty()) d_actset.download(act.data(), act.size(), st, old_active);
         // everything this fit hands back is enqueued; behind it, the first active pass of the next lambda (see spec_enabled)
@@ -213,6 +213,25 @@
             active_set[old_active + i] = act[i];
             screen_is_active[act[i]] = 1;
         }
+        o.intercept = T(intercept) * (y_mean_pin + rsum_io);
+        // the single kernel interleaves active and screen passes; split the wall time by visit counts
+        const double va = double(sc.n_visits_active), vs = double(sc.n_visits_screen);
+        o.t_active = (va + vs) > 0 ? t_cd * va / (va + vs) : 0;
+        o.t_screen = t_cd - o.t_active;
+        if (!defer_fit_output) assemble_fit_output(o, true);
+        return o;
+    }
+
+    // The coefficient rows a fit hands back (pin_naive:359-394).  Under IRLS only the LAST pin solve of a lambda needs them: the
+    // iterations before it read the intercept and nothing else, and 32 k coefficients downloaded, merged and pushed one by one
+    // per IRLS iteration left the device idle for 0.17 ms each (profiles/r06_cfg4_timeline.txt: 36 ms per config-4 path).
+    // glm_fit sets defer_fit_output and calls this once per lambda (`have_beta` false: the coefficients are still on the device).
+    bool defer_fit_output = false;
+    void assemble_fit_output(FitOut<T>& o, bool have_beta) {
+        if (!have_beta && nv > 0) {
+            d_beta.download(screen_beta.data(), size_t(nv), st);
+            sync();
+        }
         // pin_naive:359-394: active groups sorted by design column.  The active list only ever grows by appending, so the
         // sorted order is kept across fits and the newcomers are merged in (O(a + m log m) instead of a full sort per fit).
         {
@@ -238,12 +257,6 @@
                 o.beta_val.push_back(screen_beta[screen_begins[ss] + t]);
             }
         }
-        o.intercept = T(intercept) * (y_mean_pin + rsum_io);
-        // the single kernel interleaves active and screen passes; split the wall time by visit counts
-        const double va = double(sc.n_visits_active), vs = double(sc.n_visits_screen);
-        o.t_active = (va + vs) > 0 ? t_cd * va / (va + vs) : 0;
-        o.t_screen = t_cd - o.t_active;
-        return o;
     }
 
     // gradient of the screen values into d_g
@@ -348,6 +361,8 @@
 
     FitOut<T> glm_fit(T lm) {
         FitOut<T> o;
+        struct DeferGuard { bool& f; ~DeferGuard() { f = false; } } defer_guard{defer_fit_output};
+        defer_fit_output = true; // (the coefficient rows are assembled once, below, from the last pin solve of this lambda)
         size_t irls_it = 0;
         const T hmin = T(g_hessian_min);
         irls_xm_host.assign(p, 0);
@@ -481,6 +496,7 @@
             launch_dot_diff<T>(d_r.p, d_resid_prev.p, d_eta.p, d_eta_prev.p, n, d_sums.p, st);
             const T conv = device_scalar(d_sums.p);
             if (std::abs(conv) <= irls_tol) {
+                assemble_fit_output(po, false);
                 o.beta_idx.swap(po.beta_idx);
                 o.beta_val.swap(po.beta_val);
                 o.intercept = po.intercept;

@@ -11,6 +11,8 @@ import time
 import numpy as np
 import scipy.sparse as sp
 
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import adelie_amd as ad
 
 n, p, dens, L = (int(float(sys.argv[1])), int(float(sys.argv[2])), float(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 \

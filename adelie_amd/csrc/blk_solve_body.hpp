@@ -1,6 +1,7 @@
 // blk_solve_body.hpp — the one-workgroup solve of a block of <= 128 lasso visits (see kernels_cd_block.hip), as a device
 // function so that it can run both as its own kernel and as workgroup 0 of the fused look-ahead step (kernels_cd_panel.hip).
 #pragma once
+#include <type_traits>
 #include "kernels.hpp"
 
 namespace ahip {
@@ -22,6 +23,20 @@ __device__ __forceinline__ float rdlane(float x, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
 }
 __device__ __forceinline__ int rdlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+// a * b + x[l] for a wave-uniform lane index l: the addend goes from v_readlane's scalar registers straight into the multiply-add
+// (the compiler moves it back into vector registers first: three moves on the dependent chain of a coordinate visit)
+__device__ __forceinline__ double fma_lane(double a, double b, double x, int l) {
+    const double s = rdlane(x, l);
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(s));
+    return r;
+}
+__device__ __forceinline__ float fma_lane(float a, float b, float x, int l) {
+    const float s = rdlane(x, l);
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(s));
+    return r;
+}
 
 template <class T>
 __device__ __forceinline__ int blk_index(const CdBlkParams<T>& p, int pos) {
@@ -508,7 +523,7 @@ __device__ __forceinline__ void blk_solve_la_body(const CdBlkParams<T>& p, int j
     // only the current gradient, which the visits before it changed, still comes out of a register.  Same arithmetic, bit for
     // bit (config 4: cd 3488 -> 3444 ms; the 128-visit launches of the Gaussian paths are bound elsewhere: unchanged).
     T* cst = corr; // [BLK][6]
-    static_assert(6 <= NG, "the constants fit where the correction partials were");
+    static_assert(6 * (BLK + 1) <= NG * BLK, "the constants (and the row the last visit prefetches) fit where the correction partials were");
     {
         T* c0p = cst + lane * 6;
         c0p[0] = A0; c0p[1] = L0; c0p[2] = N0; c0p[3] = R0; c0p[4] = b0;
@@ -516,61 +531,90 @@ __device__ __forceinline__ void blk_solve_la_body(const CdBlkParams<T>& p, int j
         c1p[0] = A1; c1p[1] = L1; c1p[2] = N1; c1p[3] = R1; c1p[4] = b1;
     }
     __builtin_amdgcn_wave_barrier();
-    T pA = cst[0], pL = cst[1], pN = cst[2], pR = cst[3], pB = cst[4];
-#ifdef AHIP_LA_BRANCHY
-#define AHIP_LA_VISIT_TAIL(GREG, NBREG, GCREG, IL)                                                                    \
-        T ak = T(0);                                                                                                   \
-        if (v > T(0)) {                                                                                                \
-            const T x = copysign(v, gk);                                                                               \
-            const T q0 = x * rden;                                                                                     \
-            const T r = fma(-q0, den, x);                                                                              \
-            ak = fma(r, rden, q0);                                                                                     \
-        }                                                                                                              \
-        if (ak != bi) {                                   /* pin_naive:97 */                                          \
-            const T del = ak - bi;                                                                                     \
-            g0 = fma(-del, dc0, g0);                                                                                   \
-            g1 = fma(-del, dc1, g1);                                                                                   \
-            if (lane == (IL)) { NBREG = ak; GCREG = gcur; }                                                            \
-        }
-#else
-#define AHIP_LA_VISIT_TAIL(GREG, NBREG, GCREG, IL)                                                                    \
-        const T x = copysign(v, gk);                                                                                   \
-        const T q0 = x * rden;                                                                                         \
-        const T r = fma(-q0, den, x);                                                                                  \
-        const T akq = fma(r, rden, q0);                                                                                \
-        const T ak = v > T(0) ? akq : T(0);                                                                            \
-        const T del = ak - bi;                            /* 0 for an unchanged coordinate, pin_naive:97 */           \
-        g0 = fma(-del, dc0, g0);                                                                                       \
-        g1 = fma(-del, dc1, g1);                                                                                       \
-        {                                                                                                              \
-            const bool rec = (lane == (IL)) && (ak != bi);                                                             \
-            NBREG = rec ? ak : NBREG;                                                                                  \
-            GCREG = rec ? gcur : GCREG;                                                                                \
-        }
-#endif
-#define AHIP_LA_VISIT(GREG, NBREG, GCREG, IL)                                                                         \
-    {                                                                                                                  \
-        const T A = pA, thr = pL, den = pN, rden = pR, bi = pB;                                                        \
-        {                                                                                                              \
-            const T* cn = cst + min(i + 1, BLK - 1) * 6;  /* the next visit's constants */                             \
-            pA = cn[0]; pL = cn[1]; pN = cn[2]; pR = cn[3]; pB = cn[4];                                                \
-        }                                                                                                              \
-        const T dc0 = D[i * BLK + lane], dc1 = D[i * BLK + lane + 64];                                                 \
-        const T gcur = rdlane(GREG, IL);                                                                               \
-        const T gk = fma(bi, A, gcur);                    /* pin_naive:85-89 */                                       \
-        const T v = fabs(gk) - thr;                       /* pin_base:181-195 */                                      \
-        /* branch-free (AHIP_LA_BRANCHY restores the two branches): the quotient is formed whatever the sign of v and    \
-         * selected away, an unchanged coordinate updates the gradients with del = 0 -- the same values bit for bit,     \
-         * without two exec-mask round trips on the dependent chain of the visit */                                     \
-        AHIP_LA_VISIT_TAIL(GREG, NBREG, GCREG, IL)                                                                     \
-    }
+    // ---- the visits -------------------------------------------------------------------------------------------------------
+    // One wavefront, one coordinate after the other: the wave is bound by the instructions it issues (about 5 cycles each,
+    // dependent or not), so the loop is written for their number -- 30 per visit where the first form had 45:
+    //   * branch-free (round 6): the quotient is formed whatever the sign of the threshold test and selected away, an unchanged
+    //     coordinate updates the gradients with del = 0 -- the same values bit for bit without two exec-mask round trips;
+    //   * the visit's gradient goes from v_readlane's scalar registers straight into the first multiply-add (fma_lane);
+    //   * the constants of visit i + 1 are fetched during visit i into a second register set (two visits per trip, the sets
+    //     swapping roles: no moves), through one vector-register offset (immediate offsets in the LDS reads);
+    //   * only the gradient a visit saw is kept (lane i of the gradient register before the update; blocks of <= 64 visits
+    //     write the whole register to LDS, one instruction, and pick the diagonal behind the loop): the new coefficients are
+    //     formed again from it behind the loop, lane-parallel, by the visit's own operations;
+    //   * a visit updates only the gradients still to be read: blocks of <= 64 visits (IRLS) carry no second half, the second
+    //     half of a longer block no first.
     {
-        const int n0 = nb < 64 ? nb : 64;
-        for (int i = 0; i < n0; ++i) AHIP_LA_VISIT(g0, nb0, gc0, i)
-        for (int i = 64; i < nb; ++i) AHIP_LA_VISIT(g1, nb1, gc1, i - 64)
+        struct Cst { T A, thr, den, rden, bi; };
+        // byte offset (from the start of the LDS block) of the next row of constants to fetch, in a vector register
+        int coff = int(reinterpret_cast<const char*>(cst) - smem_raw);
+        asm volatile("" : "+v"(coff));
+        const char* cbase = smem_raw;
+        auto fetch = [&]() {
+            const T* c = reinterpret_cast<const T*>(cbase + coff);
+            Cst k{c[0], c[1], c[2], c[3], c[4]};
+            coff += int(6 * sizeof(T));
+            return k;
+        };
+        const T* dp = D + lane; // column i of the diagonal block, this lane's row(s)
+        T* rec = D + 64 * BLK + lane; // blocks of <= 64 visits: columns 64.. of the diagonal block's space are free
+        auto visit = [&](auto mode_c, T& G, T& GC, int il, const Cst k) { // mode: which halves of the gradient still matter
+            constexpr int MODE = decltype(mode_c)::value;                   //   1 = lanes' first, 2 = second, 3 = both
+            T dc0 = T(0), dc1 = T(0);
+            if constexpr (MODE & 1) dc0 = dp[0];
+            if constexpr (MODE & 2) dc1 = dp[64];
+            dp += BLK;
+            const T gk = fma_lane(k.bi, k.A, G, il);      // pin_naive:85-89
+            // pin_base:181-195; a coordinate under its threshold goes through the quotient as x = +-0 and comes out as +0
+            // (-q0 * den + x = -+0 + +-0 = +0, then +0 * rden + +-0 = +0): one v_max instead of a compare and two selects
+            const T v = fmax(fabs(gk) - k.thr, T(0));
+            const T x = copysign(v, gk);
+            const T q0 = x * k.rden;
+            const T r = fma(-q0, k.den, x);
+            const T ak = fma(r, k.rden, q0);
+            const T del = ak - k.bi;                      // 0 for an unchanged coordinate, pin_naive:97
+            if constexpr (MODE == 1) { // the gradients as visit il saw them, all lanes: lane il's entry is read behind the loop
+                rec[0] = G;
+                rec += 64;
+            } else {
+                GC = (lane == il) ? G : GC;
+            }
+            if constexpr (MODE & 1) g0 = fma(-del, dc0, g0);
+            if constexpr (MODE & 2) g1 = fma(-del, dc1, g1);
+        };
+        auto half = [&](auto two_c, T& G, T& GC, int cnt) { // `cnt` visits of the coordinates in the lanes of G
+            Cst a = fetch(), b;
+            int il = 0;
+            for (; il + 1 < cnt; il += 2) {
+                b = fetch();
+                visit(two_c, G, GC, il, a);
+                a = fetch();                              // (the last trip fetches a row nobody uses: row <= BLK exists)
+                visit(two_c, G, GC, il + 1, b);
+            }
+            if (il < cnt) visit(two_c, G, GC, il, a);
+        };
+        if (nb <= 64) {
+            half(std::integral_constant<int, 1>{}, g0, gc0, nb);
+            gc0 = (lane < nb) ? D[64 * BLK + lane * 64 + lane] : T(0);
+        } else {
+            half(std::integral_constant<int, 3>{}, g0, gc0, 64);
+            coff = int(reinterpret_cast<const char*>(cst + 64 * 6) - smem_raw);
+            asm volatile("" : "+v"(coff));
+            half(std::integral_constant<int, 2>{}, g1, gc1, nb - 64);
+        }
+        // the coefficients the visits left, from the gradients they saw
+        auto visit_result = [](T bi, T A, T thr, T den, T rden, T gcur) {
+            const T gk = fma(bi, A, gcur);
+            const T v = fabs(gk) - thr;
+            const T x = copysign(v, gk);
+            const T q0 = x * rden;
+            const T r = fma(-q0, den, x);
+            const T akq = fma(r, rden, q0);
+            return v > T(0) ? akq : T(0);
+        };
+        if (lane < nb) nb0 = visit_result(b0, A0, L0, N0, R0, gc0);
+        if (lane + 64 < nb) nb1 = visit_result(b1, A1, L1, N1, R1, gc1);
     }
-#undef AHIP_LA_VISIT
-#undef AHIP_LA_VISIT_TAIL
     // ---- bookkeeping of the block, lane-parallel (as blk_solve_body) ----------------------------------------------------
     const T d0 = nb0 - b0, d1 = nb1 - b1; // lanes beyond nb hold b = nb = 0
     const bool ch0 = d0 != T(0), ch1 = d1 != T(0);

@@ -316,8 +316,8 @@ def measure(ctx, cfg, *, n, p, gs, alpha, dtype, L, steps, warmup, n_folds=8, cv
             ms = stp.timers["t_panel_step_ms"]
             panel = {
                 "kernel": ("panel_step_snp16_kernel (sequential form under IRLS, blocks of 64 visits: r -= X_B dbeta_B of the previous "
-                           "block, partial gradients of the next block; 2-bit columns, one 32-bit word = 16 calls per lane; the reduce "
-                           "and the one-workgroup solve are launches of their own between two steps)" if cfg == 4 else
+                           "block, partial gradients of the next block; 2-bit columns, one 32-bit word = 16 calls per lane; its last eight "
+                           "workgroups sum the slice partials; the one-workgroup solve is a launch of its own between two steps)" if cfg == 4 else
                            ("panel_fused_grp_kernel" if gs > 1 else "panel_fused_kernel") +
                            " / panel_step_kernel (r -= X_B dbeta_B of the previous block; partial gradients of the "
                            "next block; the fused launch also carries the one-workgroup solve of the current block)"),

@@ -2,6 +2,7 @@
 // kernels_cd_block_group.hip; a device function so that it can run as its own kernel and as workgroup 0 of the fused
 // look-ahead step (kernels_cd_panel.hip).  Must be called by threads 0..255 of a workgroup (uses threadIdx.x).
 #pragma once
+#include <type_traits>
 #include "kernels.hpp"
 
 namespace ahip {
@@ -23,15 +24,18 @@ __device__ __forceinline__ T gwsum(T x) {
 
 // Sum over the first 16 lanes with DPP (no LDS crossbar): xor-1, xor-2 by quad_perm, then row_half_mirror and
 // row_mirror; the result is made wave-uniform with readfirstlane.  Lanes >= 16 must not contribute.
+// (bound_ctrl: these four patterns give every lane a source inside its row, so the "old" operand is never used -- saying so
+// spares the two zero moves and the wait state the compiler otherwise puts in front of every dpp move: 6 -> 3 instructions per
+// step of a double-precision sum, 29 -> 17 per reduction, on a wave that is bound by the instructions it issues.)
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
 }
 __device__ __forceinline__ double first_lane(double x) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)),
@@ -56,6 +60,24 @@ __device__ __forceinline__ T row16_sum(T x) {
 template <class T>
 __device__ __forceinline__ T group_sum(T x, int q) {
     return q <= 16 ? row16_sum(x) : gwsum(x);
+}
+
+// two sums at once: the two chains interleave (each step's add waits on its dpp moves and the next moves on the add: alone a
+// chain leaves wait states between them)
+template <class T>
+__device__ __forceinline__ void group_sum2(T& a, T& b, int q) {
+    if (q <= 16) {
+        T x = a, y = b;
+        x += dpp_move<0xB1>(x);  y += dpp_move<0xB1>(y);
+        x += dpp_move<0x4E>(x);  y += dpp_move<0x4E>(y);
+        x += dpp_move<0x141>(x); y += dpp_move<0x141>(y);
+        x += dpp_move<0x140>(x); y += dpp_move<0x140>(y);
+        a = first_lane(x);
+        b = first_lane(y);
+    } else {
+        a = gwsum(a);
+        b = gwsum(b);
+    }
 }
 
 // Fills vmap[0..nval) with the global screen-value index of every value of block j, plus the group tables (all in LDS).
@@ -472,11 +494,16 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             const T gk_r = on ? g_c + A_r * ako_r : T(0); // gk_t += A * ak_old_t   (pin_naive:139-140)
             // newton_solver (bcd/unconstrained/newton.hpp:35-142): v = gk_t, L = A
             const T gk2 = on ? gk_r * gk_r : T(0);
-            const T nrm2 = group_sum(gk2, q);
+            T nrm2 = gk2;
             // (double precision only, see below; the second reduction is independent of the first: they overlap)
             constexpr bool kMeanStart = sizeof(T) == 8;
             T sb1 = T(0);
-            if constexpr (kMeanStart) sb1 = group_sum(on ? gk2 * (A_r + l2p) : T(0), q);
+            if constexpr (kMeanStart) {
+                sb1 = on ? gk2 * (A_r + l2p) : T(0);
+                group_sum2(nrm2, sb1, q);
+            } else {
+                nrm2 = group_sum(gk2, q);
+            }
             const T nrm = sqrt(nrm2);
             T akt_r = T(0);
             RP_MARK(1)
@@ -522,8 +549,9 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
                         t = x;
                         sx = x * b1 * b2;
                     }
-                    tt = group_sum(t, q);
-                    sxx = group_sum(sx, q);
+                    group_sum2(t, sx, q);
+                    tt = t;
+                    sxx = sx;
                     fh = tt - T(1);
                 };
                 step(h);
@@ -549,8 +577,7 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
                 c1 = (A_r * d) * d;
                 rs = d * (T(2) * gg - d * A_r);
             }
-            dn = group_sum(dn, q);
-            c1 = group_sum(c1, q);
+            group_sum2(dn, c1, q);
             if (!(dn <= gsq[k])) {
                 changed = true;
                 c1 *= grq[k];
@@ -641,7 +668,33 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             // keep the rotated gradient of the groups STILL TO COME current: gT[l] -= D~[l, o:o+q] del_t for l >= o + q (the
             // values before that were visited already and are not read again in this solve).  q <= 64: the changes come out
             // of the lanes' registers with v_readlane (uniform index), no LDS round trip on the chain.
-            if (q <= 64) {
+            if (q > 1 && q <= 16) {
+                // Every entry of the block a chunk needs is requested before the first multiply-add (one LDS round trip per chunk
+                // instead of one per four columns), without a predicate per column: the trip count is q rounded up to a multiple
+                // of four, the surplus columns (clamped into the block) meet the zero changes of lanes >= q.
+                auto upd = [&](auto qb_c) {
+                    constexpr int QB = decltype(qb_c)::value;
+                    T dv[QB];
+#pragma unroll
+                    for (int t = 0; t < QB; ++t) dv[t] = rdl(d_reg, t);
+                    bool first = true;
+                    for (int l = o + q + lane; l < nval; l += 64) {
+                        T dd[QB];
+#pragma unroll
+                        for (int t = 0; t < QB; ++t) dd[t] = D[l + min(o + t, GBLK - 1) * GBLK];
+                        T acc = first ? g_n : gT[l]; // (the first chunk is the one prefetched for the next group)
+#pragma unroll
+                        for (int t = 0; t < QB; ++t) acc = fma(-dd[t], dv[t], acc);
+                        gT[l] = acc;
+                        if (first) g_n = acc;
+                        first = false;
+                    }
+                };
+                if (q <= 4) upd(std::integral_constant<int, 4>{});
+                else if (q <= 8) upd(std::integral_constant<int, 8>{});
+                else if (q <= 12) upd(std::integral_constant<int, 12>{});
+                else upd(std::integral_constant<int, 16>{});
+            } else if (q <= 64) {
                 bool first = true;
                 for (int l = o + q + lane; l < nval; l += 64) {
                     T acc = first ? g_n : gT[l]; // (the first chunk is the one prefetched for the next group)

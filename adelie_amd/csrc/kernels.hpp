@@ -445,7 +445,7 @@ struct CdGrpBlkParams {
     // fused look-ahead launch: the LAST step workgroup to finish sums the slice partials of the next block (slice-major) in a
     // fixed order, applies  - tail_rsum[0] * tail_xm[col]  and leaves the block's gradient in tail_g — in the shadow of the
     // solve, which outlasts the step in a group launch — instead of a panel_reduce launch between two fused launches.
-    // tail_counter: one int32 that is 0 between launches (the reducing workgroup resets it); nullptr: off.
+    // tail_counter: two int32 that are 0 between launches (arrivals; finished tail workgroups: the last of those resets both); nullptr: off.
     int32_t* tail_counter;
     T* tail_g;
     const T* tail_rsum;

@@ -717,44 +717,62 @@ __global__ __launch_bounds__(256 * FS) void panel_fused_grp_kernel(CdGrpBlkParam
     fused_step_part<T, Acc, VEC>(smem_raw, X, n, w, r, dcol, dlt, nz_dev, cols, nb, part, part_ld, fsa, sp.tail_counter != nullptr);
     if constexpr (RS >= PB) {
         if (sp.tail_counter == nullptr || nb <= 0) return; // (uniform)
-        // ---- tail: the last step workgroup to get here sums the partials of all of them ----
+        // ---- tail: the last EIGHT step workgroups to get here sum the partials of all of them, sixteen columns each ----
         // The partials were stored device-coherently (written through) and are read back the same way, so no cache
         // write-back / invalidate is needed (an agent-scope fence per workgroup costs more than the reduce launch it replaces:
         // measured +15 us per fused launch); the workgroup-scope fence + barrier make the stores complete before the counter
-        // moves.
-        __shared__ int s_last;
+        // moves.  One workgroup alone (rounds 4-5) pulled the 200 KB at a single compute unit's ~60 GB/s, 3 us at the end of
+        // every launch -- hidden while the launch was bound by its solve, on the critical path since the solve got shorter;
+        // eight pull 25 KB each.  They wait for the stragglers on the arrival counter (every workgroup of the launch is
+        // resident, one per compute unit, and nobody waits for them); the last of the eight to finish resets both counters
+        // (tail_counter[0]: arrivals, [1]: finished tail workgroups).  Same sums in the same order as the single tail: thread
+        // (column, q) adds the partials q, q + 8, ..., the eight of a column are combined pairwise.
+        __shared__ int s_rank;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
+        if (threadIdx.x == 0) s_rank = __hip_atomic_fetch_add(sp.tail_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int nwg = int(gridDim.x) - 1, NT = nwg < 8 ? 1 : 8;
+        const int rank = s_rank;
+        if (rank < nwg - NT) return;
+        const int tidx = rank - (nwg - NT);
         if (threadIdx.x == 0) {
-            const int prev = __hip_atomic_fetch_add(sp.tail_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = (prev == int(gridDim.x) - 2) ? 1 : 0;
+            while (__hip_atomic_load(sp.tail_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg) __builtin_amdgcn_s_sleep(1);
         }
         __syncthreads();
-        if (!s_last) return;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const int nwg = int(gridDim.x) - 1;
         T* red = reinterpret_cast<T*>(smem_raw); // [8][128]
-        const int c = threadIdx.x & (PB - 1), q = threadIdx.x >> 7;
-        T s = T(0);
-        for (int k0 = q; k0 < nwg; k0 += 8 * 16) { // 16 loads in flight per thread
-            T v[16];
+        const int cpw = PB / NT;                 // columns of this workgroup: [tidx * cpw, (tidx + 1) * cpw)
+        const int cl = int(threadIdx.x) % cpw, q = int(threadIdx.x) / cpw;
+        const int c = tidx * cpw + cl;
+        if (q < 8) {
+            T sacc = T(0);
+            for (int k0 = q; k0 < nwg; k0 += 8 * 16) { // 16 loads in flight per thread
+                T v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int k = k0 + 8 * u;
-                v[u] = k < nwg ? __hip_atomic_load(part + int64_t(k) * PB + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : T(0);
+                for (int u = 0; u < 16; ++u) {
+                    const int k = k0 + 8 * u;
+                    v[u] = k < nwg ? __hip_atomic_load(part + int64_t(k) * PB + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : T(0);
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) sacc += v[u];
             }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) s += v[u];
+            red[q * PB + c] = sacc;
         }
-        red[q * PB + c] = s;
         __syncthreads();
-        if (threadIdx.x < nb) {
+        if (int(threadIdx.x) < cpw && c < nb) {
             T g = ((red[c] + red[PB + c]) + (red[2 * PB + c] + red[3 * PB + c])) +
                   ((red[4 * PB + c] + red[5 * PB + c]) + (red[6 * PB + c] + red[7 * PB + c]));
             if (sp.tail_xm) g -= sp.tail_rsum[0] * sp.tail_xm[cols[c]];
             sp.tail_g[c] = g;
         }
-        if (threadIdx.x == 0) __hip_atomic_store(sp.tail_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            const int d = __hip_atomic_fetch_add(sp.tail_counter + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == NT - 1) {
+                __hip_atomic_store(sp.tail_counter + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sp.tail_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 

@@ -961,8 +961,8 @@
             }
         }
         if (tail_ok && !d_tail_counter.p) {
-            d_tail_counter.reserve(1);
-            AHIP_CHECK(hipMemsetAsync(d_tail_counter.p, 0, sizeof(int32_t), st));
+            d_tail_counter.reserve(2); // (arrivals, finished tail workgroups)
+            AHIP_CHECK(hipMemsetAsync(d_tail_counter.p, 0, 2 * sizeof(int32_t), st));
         }
         if (!d_zero_i32.p) {
             d_zero_i32.reserve(1);

@@ -20,3 +20,8 @@ Xd = ad.matrix.dense(np.asfortranarray(rng.normal(size=(3000, 900))))
 yd = rng.normal(size=3000)
 st = ad.grpnet(Xd, ad.glm.gaussian(yd), early_exit=False, progress_bar=False, min_ratio=0.05, lmda_path_size=15)
 print("dense", hashlib.sha1(st.betas.toarray().tobytes()).hexdigest()[:16], st.counters["n_panel_blocks"])
+Xg = ad.matrix.dense(np.asfortranarray(rng.normal(size=(4000, 1200))))
+yg2 = rng.normal(size=4000)
+st = ad.grpnet(Xg, ad.glm.gaussian(yg2), groups=np.arange(0, 1200, 10), alpha=0.5, early_exit=False, progress_bar=False, min_ratio=0.05,
+               lmda_path_size=15)
+print("groups10", hashlib.sha1(st.betas.toarray().tobytes()).hexdigest()[:16], st.counters["n_panel_blocks"])

@@ -747,15 +747,15 @@ __global__ __launch_bounds__(256 * FS) void panel_fused_grp_kernel(CdGrpBlkParam
         const int c = tidx * cpw + cl;
         if (q < 8) {
             T sacc = T(0);
-            for (int k0 = q; k0 < nwg; k0 += 8 * 16) { // 16 loads in flight per thread
-                T v[16];
+            for (int k0 = q; k0 < nwg; k0 += 8 * 32) { // 32 loads in flight per thread: up to 256 workgroups in ONE round trip
+                T v[32];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
+                for (int u = 0; u < 32; ++u) {
                     const int k = k0 + 8 * u;
                     v[u] = k < nwg ? __hip_atomic_load(part + int64_t(k) * PB + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : T(0);
                 }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) sacc += v[u];
+                for (int u = 0; u < 32; ++u) sacc += v[u];
             }
             red[q * PB + c] = sacc;
         }

@@ -251,6 +251,29 @@ def test_group_block_cd_passes_match_oracle(hip, oracle, monkeypatch, alpha, eng
     assert a.counters["n_panel_blocks"] > 0
 
 
+def test_group_update_buckets_match_oracle(hip, oracle, monkeypatch):
+    """Group sizes on both sides of every bucket of the rotated group solve's gradient update (round 6: the block entries of a
+    chunk are fetched in one batch of q rounded up to 4 / 8 / 12 / 16 columns, the surplus columns meeting zero changes; q > 16
+    keeps the four-column loop) on the look-ahead panel engine, several blocks per pass, against the oracle."""
+    monkeypatch.setenv("ADELIE_HIP_CD_BLOCK_MIN_NV", "1")
+    n, p = 1500, 760
+    d = make_gaussian(n, p, seed=29, sparsity=0.5, weights=True)
+    sizes = []
+    cyc = [2, 3, 4, 5, 8, 9, 12, 13, 16, 17, 1, 24]
+    while sum(sizes) + cyc[len(sizes) % len(cyc)] <= p:
+        sizes.append(cyc[len(sizes) % len(cyc)])
+    if sum(sizes) < p:
+        sizes.append(p - sum(sizes))
+    groups = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    for alpha in (1.0, 0.4):
+        kw = dict(groups=groups, alpha=alpha, tol=1e-14, early_exit=False, lmda_path_size=18, min_ratio=3e-2)
+        a, b = _both(oracle, d, lambda: ad.glm.gaussian(d["y"], weights=d["weights"]), **kw)
+        assert_same_path(a, b, 1e-6)
+        assert a.active_set_size > 40 and a.counters["n_panel_blocks"] > 10
+        act = set(np.asarray(sizes)[np.unique(np.searchsorted(groups, np.flatnonzero(a.betas.toarray()[-1]), side="right") - 1)].tolist())
+        assert {4, 5, 8, 9, 12, 13, 16, 17} <= act   # (every bucket edge was a changed group at the end of the path)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_panel_engine_binomial_snp(hip, oracle, monkeypatch, dtype):
     """IRLS on a 2-bit SNP design through the panel engine: the diagonal blocks are rebuilt per IRLS iteration (weights

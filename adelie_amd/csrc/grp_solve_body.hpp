@@ -671,7 +671,7 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
             if (q > 1 && q <= 16) {
                 // Every entry of the block a chunk needs is requested before the first multiply-add (one LDS round trip per chunk
                 // instead of one per four columns), without a predicate per column: the trip count is q rounded up to a multiple
-                // of four, the surplus columns (clamped into the block) meet the zero changes of lanes >= q.
+                // of four, the surplus columns (clamped to the block's last value: finite entries) meet the zero changes of lanes >= q.
                 auto upd = [&](auto qb_c) {
                     constexpr int QB = decltype(qb_c)::value;
                     T dv[QB];
@@ -681,7 +681,7 @@ __device__ __forceinline__ void grp_solve_body_rot(const CdGrpBlkParams<T>& p, i
                     for (int l = o + q + lane; l < nval; l += 64) {
                         T dd[QB];
 #pragma unroll
-                        for (int t = 0; t < QB; ++t) dd[t] = D[l + min(o + t, GBLK - 1) * GBLK];
+                        for (int t = 0; t < QB; ++t) dd[t] = D[l + min(o + t, nval - 1) * GBLK]; // (columns >= nval were never written)
                         T acc = first ? g_n : gT[l]; // (the first chunk is the one prefetched for the next group)
 #pragma unroll
                         for (int t = 0; t < QB; ++t) acc = fma(-dd[t], dv[t], acc);

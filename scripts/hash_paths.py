@@ -25,3 +25,6 @@ yg2 = rng.normal(size=4000)
 st = ad.grpnet(Xg, ad.glm.gaussian(yg2), groups=np.arange(0, 1200, 10), alpha=0.5, early_exit=False, progress_bar=False, min_ratio=0.05,
                lmda_path_size=15)
 print("groups10", hashlib.sha1(st.betas.toarray().tobytes()).hexdigest()[:16], st.counters["n_panel_blocks"])
+Ym = rng.normal(size=(4000, 3)) + np.asarray(Xg.cmul(0, np.ones(4000)) if False else 0)
+st = ad.grpnet(Xg, ad.glm.multigaussian(Ym), early_exit=False, progress_bar=False, min_ratio=0.2, lmda_path_size=12)
+print("multi3", hashlib.sha1(st.betas.toarray().tobytes()).hexdigest()[:16], st.counters["n_panel_blocks"])
